@@ -1,0 +1,289 @@
+// extern "C" surface of libzethprover.so -- see include/zeth_prover.h for the contract.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "ctx.hpp"
+#include "poseidon_default_table.inc"
+
+extern "C" {
+
+const char *zp_version(void) { return "zethprover-mi355x 0.1 (gfx950)"; }
+
+int32_t zp_create(zp_ctx **out, int32_t device) {
+    if (!out) return ZP_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZP_ERR_HIP;
+    if (device < 0 || device >= ndev) return ZP_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return ZP_ERR_HIP;
+    zp_ctx *ctx = new (std::nothrow) zp_ctx();
+    if (!ctx) return ZP_ERR_NOMEM;
+    ctx->device = device;
+    memcpy(ctx->h_rc, ZP_POSEIDON_DEFAULT_RC, sizeof(ctx->h_rc));
+    memcpy(ctx->h_mds, ZP_POSEIDON_DEFAULT_MDS, sizeof(ctx->h_mds));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    *out = ctx;
+    return ZP_OK;
+}
+
+void zp_destroy(zp_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->plans) {
+        if (kv.second.d_twl) (void)hipFree(kv.second.d_twl);
+        if (kv.second.d_twh) (void)hipFree(kv.second.d_twh);
+        if (kv.second.d_tws) (void)hipFree(kv.second.d_tws);
+    }
+    for (auto &c : ctx->cosets) {
+        if (c.d_lo) (void)hipFree(c.d_lo);
+        if (c.d_hi) (void)hipFree(c.d_hi);
+    }
+    for (int i = 0; i < 4; i++)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->d_rc) (void)hipFree(ctx->d_rc);
+    if (ctx->d_mds) (void)hipFree(ctx->d_mds);
+    delete ctx;
+}
+
+const char *zp_last_error(zp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int32_t zp_set_stream(zp_ctx *ctx, void *hip_stream) {
+    if (!ctx) return ZP_ERR_ARG;
+    ctx->stream = (hipStream_t)hip_stream;
+    return ZP_OK;
+}
+
+int32_t zp_sync(zp_ctx *ctx) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZP_OK;
+}
+
+static void drop_plans(zp_ctx *ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->plans) {
+        if (kv.second.d_twl) (void)hipFree(kv.second.d_twl);
+        if (kv.second.d_twh) (void)hipFree(kv.second.d_twh);
+        if (kv.second.d_tws) (void)hipFree(kv.second.d_tws);
+    }
+    ctx->plans.clear();
+}
+
+int32_t zp_set_constants(zp_ctx *ctx, int32_t kind, const uint64_t *blob, size_t n) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, blob != nullptr, "null blob");
+    switch (kind) {
+        case ZP_CONST_ROOT32: {
+            ZP_ARG(ctx, n == 1, "ROOT32 takes one element");
+            u64 r = blob[0];
+            ZP_ARG(ctx, r < GL_P, "root not canonical");
+            // must have exact order 2^32:  r^(2^31) == -1
+            u64 t = r;
+            for (int i = 0; i < 31; i++) t = gl_mul(t, t);
+            ZP_ARG(ctx, t == GL_P - 1, "root32 is not a primitive 2^32-th root of unity");
+            if (r != ctx->root32) {
+                ctx->root32 = r;
+                drop_plans(ctx);
+            }
+            return ZP_OK;
+        }
+        case ZP_CONST_POSEIDON_RC:
+            ZP_ARG(ctx, n == 360, "POSEIDON_RC takes 360 elements");
+            for (size_t i = 0; i < n; i++) ZP_ARG(ctx, blob[i] < GL_P, "constant not canonical");
+            memcpy(ctx->h_rc, blob, sizeof(ctx->h_rc));
+            ctx->poseidon_dirty = true;
+            return ZP_OK;
+        case ZP_CONST_POSEIDON_MDS:
+            ZP_ARG(ctx, n == 144, "POSEIDON_MDS takes 144 elements");
+            for (size_t i = 0; i < n; i++) ZP_ARG(ctx, blob[i] < (1ULL << 28), "MDS entries must be < 2^28");
+            memcpy(ctx->h_mds, blob, sizeof(ctx->h_mds));
+            ctx->poseidon_dirty = true;
+            return ZP_OK;
+        case ZP_CONST_COSET_SHIFT:
+            ZP_ARG(ctx, n == 1 && blob[0] != 0 && blob[0] < GL_P, "bad coset shift");
+            ctx->coset_shift = blob[0];
+            return ZP_OK;
+        default:
+            ctx->err = "unknown constant kind";
+            return ZP_ERR_ARG;
+    }
+}
+
+int32_t zp_get_constants(zp_ctx *ctx, int32_t kind, uint64_t *blob, size_t n) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, blob != nullptr, "null blob");
+    switch (kind) {
+        case ZP_CONST_ROOT32: ZP_ARG(ctx, n == 1, "size"); blob[0] = ctx->root32; return ZP_OK;
+        case ZP_CONST_POSEIDON_RC: ZP_ARG(ctx, n == 360, "size"); memcpy(blob, ctx->h_rc, sizeof(ctx->h_rc)); return ZP_OK;
+        case ZP_CONST_POSEIDON_MDS: ZP_ARG(ctx, n == 144, "size"); memcpy(blob, ctx->h_mds, sizeof(ctx->h_mds)); return ZP_OK;
+        case ZP_CONST_COSET_SHIFT: ZP_ARG(ctx, n == 1, "size"); blob[0] = ctx->coset_shift; return ZP_OK;
+        default: ctx->err = "unknown constant kind"; return ZP_ERR_ARG;
+    }
+}
+
+// ---- memory
+int32_t zp_dev_alloc(zp_ctx *ctx, size_t bytes, void **d_ptr) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, d_ptr != nullptr, "null out pointer");
+    *d_ptr = nullptr;
+    if (bytes == 0) return ZP_OK;
+    ZP_HIP(ctx, hipSetDevice(ctx->device));
+    ZP_HIP(ctx, hipMalloc(d_ptr, bytes));
+    return ZP_OK;
+}
+int32_t zp_dev_free(zp_ctx *ctx, void *d_ptr) {
+    if (!ctx) return ZP_ERR_ARG;
+    if (!d_ptr) return ZP_OK;
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZP_HIP(ctx, hipFree(d_ptr));
+    return ZP_OK;
+}
+int32_t zp_h2d(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!ctx) return ZP_ERR_ARG;
+    if (bytes == 0) return ZP_OK;
+    ZP_ARG(ctx, d_dst && h_src, "null pointer");
+    ZP_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZP_OK;
+}
+int32_t zp_d2h(zp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    if (!ctx) return ZP_ERR_ARG;
+    if (bytes == 0) return ZP_OK;
+    ZP_ARG(ctx, h_dst && d_src, "null pointer");
+    ZP_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZP_OK;
+}
+int32_t zp_d2d(zp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+    if (!ctx) return ZP_ERR_ARG;
+    if (bytes == 0) return ZP_OK;
+    ZP_ARG(ctx, d_dst && d_src, "null pointer");
+    ZP_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return ZP_OK;
+}
+
+// ---- N1
+int32_t zp_ntt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t W) {
+    if (!ctx) return ZP_ERR_ARG;
+    NttRunOpts o;
+    return zpi_ntt_run(ctx, (const u64 *)d_in, (u64 *)d_out, logn, W, false, o);
+}
+int32_t zp_intt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t W) {
+    if (!ctx) return ZP_ERR_ARG;
+    NttRunOpts o;
+    return zpi_ntt_run(ctx, (const u64 *)d_in, (u64 *)d_out, logn, W, true, o);
+}
+
+// ---- N2
+int32_t zp_lde(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t *d_coef, int32_t logn,
+               int32_t logb, int32_t W, uint64_t shift) {
+    if (!ctx) return ZP_ERR_ARG;
+    return zpi_lde(ctx, (const u64 *)d_in, (u64 *)d_out, (u64 *)d_coef, logn, logb, W, shift);
+}
+
+// ---- host conveniences
+int32_t zp_ntt_host(zp_ctx *ctx, uint64_t *h_cols, int32_t logn, int32_t W, int32_t inverse) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, h_cols != nullptr || W == 0, "null host pointer");
+    ZP_ARG(ctx, logn >= 0 && logn <= 32 && W >= 0, "logn/W out of range");
+    if (W == 0) return ZP_OK;
+    const size_t bytes = ((size_t)W << logn) * sizeof(u64);
+    void *d = nullptr;
+    ZP_TRY(zp_dev_alloc(ctx, bytes, &d));
+    int32_t rc = zp_h2d(ctx, d, h_cols, bytes);
+    if (rc == ZP_OK) {
+        NttRunOpts o;
+        rc = zpi_ntt_run(ctx, (u64 *)d, (u64 *)d, logn, W, inverse != 0, o);
+    }
+    if (rc == ZP_OK) rc = zp_d2h(ctx, h_cols, d, bytes);
+    (void)zp_dev_free(ctx, d);
+    return rc;
+}
+
+int32_t zp_lde_host(zp_ctx *ctx, const uint64_t *h_in, uint64_t *h_out, int32_t logn, int32_t logb,
+                    int32_t W, uint64_t shift) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, (h_in && h_out) || W == 0, "null host pointer");
+    ZP_ARG(ctx, logn >= 0 && logb >= 0 && logn + logb <= 32 && W >= 0, "logn/logb/W out of range");
+    if (W == 0) return ZP_OK;
+    const size_t bin = ((size_t)W << logn) * sizeof(u64), bout = bin << logb;
+    void *di = nullptr, *dout = nullptr;
+    ZP_TRY(zp_dev_alloc(ctx, bin, &di));
+    int32_t rc = zp_dev_alloc(ctx, bout, &dout);
+    if (rc == ZP_OK) rc = zp_h2d(ctx, di, h_in, bin);
+    if (rc == ZP_OK) rc = zp_lde(ctx, (const uint64_t *)di, (uint64_t *)dout, nullptr, logn, logb, W, shift);
+    if (rc == ZP_OK) rc = zp_d2h(ctx, h_out, dout, bout);
+    (void)zp_dev_free(ctx, di);
+    (void)zp_dev_free(ctx, dout);
+    return rc;
+}
+
+int32_t zp_set_profiling(zp_ctx *ctx, int32_t on) {
+    if (!ctx) return ZP_ERR_ARG;
+    ctx->profiling = on != 0;
+    return ZP_OK;
+}
+
+int32_t zp_get_pass_timings(zp_ctx *ctx, float *ms, int32_t *radix_log, int32_t cap, int32_t *count) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, count != nullptr && cap >= 0 && (cap == 0 || (ms && radix_log)), "bad arguments");
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int n = 0;
+    for (auto &ev : ctx->pass_events) {
+        if (n < cap) {
+            float t = 0.f;
+            ZP_HIP(ctx, hipEventElapsedTime(&t, ev.a, ev.b));
+            ms[n] = t;
+            radix_log[n] = ev.radix_log;
+            n++;
+        }
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    ctx->pass_events.clear();
+    *count = n;
+    return ZP_OK;
+}
+
+int32_t zp_ntt_plan_json(zp_ctx *ctx, int32_t logn, char *buf, size_t buflen) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, buf && buflen > 0, "null buffer");
+    NttPlan *pl;
+    ZP_TRY(zpi_get_plan(ctx, logn, false, &pl));
+    std::string s = "{\"logn\": " + std::to_string(logn) + ", \"passes\": [";
+    for (int i = 0; i < pl->npass; i++) {
+        const NttPass &p = pl->pass[i];
+        if (i) s += ", ";
+        s += "{\"radix_log\": " + std::to_string(p.L) + ", \"rounds\": [" + std::to_string(p.A1) + ", " +
+             std::to_string(p.A2) + ", " + std::to_string(p.A3) + "], \"tile\": " + std::to_string(1 << p.logT) + "}";
+    }
+    s += "], \"small_kernel\": ";
+    s += (logn <= 12) ? "true" : "false";
+    s += "}";
+    ZP_ARG(ctx, s.size() + 1 <= buflen, "buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return ZP_OK;
+}
+
+int32_t zp_device_info_json(zp_ctx *ctx, char *buf, size_t buflen) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, buf && buflen > 0, "null buffer");
+    hipDeviceProp_t prop;
+    ZP_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    size_t fr = 0, tot = 0;
+    ZP_HIP(ctx, hipMemGetInfo(&fr, &tot));
+    char tmp[512];
+    snprintf(tmp, sizeof(tmp),
+             "{\"name\": \"%s\", \"arch\": \"%s\", \"cus\": %d, \"clock_khz\": %d, \"total_mem\": %zu, \"free_mem\": %zu}",
+             prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate, tot, fr);
+    ZP_ARG(ctx, strlen(tmp) + 1 <= buflen, "buffer too small");
+    memcpy(buf, tmp, strlen(tmp) + 1);
+    return ZP_OK;
+}
+
+}  // extern "C"

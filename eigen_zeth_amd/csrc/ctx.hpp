@@ -1,0 +1,100 @@
+// Internal context shared by the translation units of libzethprover.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/zeth_prover.h"
+#include "gl.hpp"
+
+#define ZP_ROOT32_DEFAULT 1753635133440165772ULL /* 7^((p-1)/2^32), SURVEY.md 8a-N1 */
+#define ZP_SHIFT_DEFAULT 49ULL
+
+struct NttPass {
+    int L, A1, A2, A3, logT;
+    int logPprev;  // log2 of the product of the radices of the previous passes
+};
+
+struct NttPlan {
+    int logn = 0;
+    bool inverse = false;
+    int npass = 0;
+    NttPass pass[6];
+    int lb = 0;               // twiddle split: w^e = twl[e & (2^lb-1)] * twh[e >> lb]
+    u64 *d_twl = nullptr;     // 2^lb entries
+    u64 *d_twh = nullptr;     // 2^(logn-lb) entries
+    u64 *d_tws = nullptr;     // w_4096^e (direction matched), 4096 entries
+    u64 w16[8];               // w_16^i (direction matched)
+    u64 ninv = 1;
+};
+
+struct CosetTable {  // shift^i * pre, i < 2^logn, two-level
+    int logn = 0, lb = 0;
+    u64 shift = 0, pre = 0;
+    u64 *d_lo = nullptr, *d_hi = nullptr;
+};
+
+struct zp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    u64 root32 = ZP_ROOT32_DEFAULT;
+    u64 coset_shift = ZP_SHIFT_DEFAULT;
+    // Poseidon tables (device copies)
+    u64 h_rc[360];
+    u64 h_mds[144];
+    u64 *d_rc = nullptr;
+    u32 *d_mds = nullptr;
+    bool poseidon_dirty = true;
+    // plans
+    std::map<int, NttPlan> plans;  // key = logn*2 + inverse
+    std::vector<CosetTable> cosets;
+    // scratch (two ping-pong buffers, grown on demand)
+    u64 *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_elems[4] = {0, 0, 0, 0};
+    // misc small device buffer for parameters
+    int num_cu = 256;
+    // per-launch event profiling (zp_set_profiling)
+    bool profiling = false;
+    struct PassEv { hipEvent_t a, b; int radix_log; };
+    std::vector<PassEv> pass_events;
+};
+
+#define ZP_HIP(ctx, call)                                                                    \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return e_ == hipErrorOutOfMemory ? ZP_ERR_NOMEM : ZP_ERR_HIP;                    \
+        }                                                                                    \
+    } while (0)
+
+#define ZP_ARG(ctx, cond, msg)                                                               \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            (ctx)->err = std::string("bad argument: ") + (msg);                              \
+            return ZP_ERR_ARG;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define ZP_TRY(expr)                                                                         \
+    do {                                                                                     \
+        int32_t rc_ = (expr);                                                                \
+        if (rc_ != ZP_OK) return rc_;                                                        \
+    } while (0)
+
+// internal helpers implemented across the .hip files
+int32_t zpi_scratch(zp_ctx *ctx, int which, size_t elems, u64 **out);
+int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out);
+int32_t zpi_get_coset(zp_ctx *ctx, int logn, u64 shift, u64 pre, CosetTable **out);
+int32_t zpi_poseidon_sync_tables(zp_ctx *ctx);
+// run the transform on W columns; in/out column strides are 2^logn (or in_valid for zero-padded input)
+struct NttRunOpts {
+    const CosetTable *post_scale = nullptr;  // multiply output i by table(i) (last pass)
+    int in_valid_log = -1;                   // >=0: input columns have 2^in_valid_log elements, rest is zero
+};
+int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn, int logb, int W, u64 shift);
+int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, bool inverse,
+                    const NttRunOpts &opts);

@@ -1,0 +1,559 @@
+// Goldilocks NTT / iNTT / LDE for gfx950.
+//
+// No reference counterpart exists in /root/reference (the prover arithmetic is external to
+// eigen-zeth); reference call site served: src/prover/provider.rs:358-377
+// (GenChunkProof).  Algorithm: Stockham auto-sort, decimation in frequency, m = ceil(logN/9)
+// out-of-place passes of radix R = 2^L (L = 6..9).  Pass i views the column as [R][N/R], a
+// workgroup owns a tile of T = 32 consecutive u in [0, N/R):
+//     a_r = in[r*(N/R) + u]                               (R segments of T*8 = 256 contiguous bytes)
+//     b_k = (sum_r a_r w_R^(rk)) * w_N^(Pprev*k*s)          u = s*Pprev + c,  Pprev = R_1*...*R_(i-1)
+//     out[s*Pprev*R + k*Pprev + c] = b_k                    (segments of >= 256 contiguous bytes)
+// so natural order goes in and natural order comes out with every global access coalesced in
+// 256-byte runs and no separate transpose / bit-reversal pass.  Inside a tile the R-point DFT is
+// 2-3 rounds of register radix-2^A (A <= 4, 16 elements per thread) exchanged through LDS with an
+// XOR swizzle so that both the row accesses and the transposing copy-out of pass 1 are
+// bank-conflict free (MI355X_MICROARCH.md, LDS: ds_read_b64 = 2x32 lanes over 64 banks).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "ctx.hpp"
+
+namespace {
+
+struct PassArgs {
+    const u64 *in;
+    u64 *out;
+    u64 in_cs, out_cs;  // column strides in elements
+    u64 in_valid;       // elements per input column that are real; the rest reads as zero
+    const u64 *twl, *twh;
+    const u64 *tws;
+    const u64 *csl, *csh;  // coset post-scale tables (last pass of the inverse transform in LDE)
+    u64 w16[8];
+    u64 scale;
+    int logn, logPprev, lb, cslb;
+    int flags;  // 1: inter-pass twiddle  2: multiply by `scale`  4: coset post-scale
+};
+
+__device__ __forceinline__ constexpr int brev(int x, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+__device__ __forceinline__ constexpr int slot_of(int o, int j, int pos, int A) {
+    return ((o >> pos) << (pos + A)) | (j << pos) | (o & ((1 << pos) - 1));
+}
+
+// radix-2^A decimation-in-frequency on v[0..2^A): output X[brev(p)] lands in v[p]
+template <int A>
+__device__ __forceinline__ void dif(u64 *v, const u64 *w16) {
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int half = 1 << (A - 1 - s);
+#pragma unroll
+        for (int b = 0; b < (1 << A); b += 2 * half) {
+#pragma unroll
+            for (int i = 0; i < half; i++) {
+                u64 x = v[b + i], y = v[b + i + half];
+                v[b + i] = gl_add(x, y);
+                u64 d = gl_sub(x, y);
+                const int e = i * (8 / half);
+                v[b + i + half] = (e == 0) ? d : gl_mul(d, w16[e]);
+            }
+        }
+    }
+}
+
+template <int A1, int A2, int A3, int LOGT>
+struct Geo {
+    static constexpr int L = A1 + A2 + A3;
+    static constexpr int R = 1 << L;
+    static constexpr int T = 1 << LOGT;
+    static constexpr int LT = LOGT;
+    static constexpr int NT = (R * T) / 16;
+    static constexpr int J = 1 + (A2 > 0 ? 1 : 0) + (A3 > 0 ? 1 : 0);
+    static constexpr int POS1 = L - A1;
+    static constexpr int POS2 = L - A1 - A2;
+    static constexpr int AJ = (J == 1) ? A1 : (J == 2 ? A2 : A3);
+    // output index k held by slot sigma once all rounds are done
+    __device__ static __forceinline__ int kof(int sigma) {
+        int k = (sigma >> POS1) & ((1 << A1) - 1);
+        if (A2 > 0) k |= ((sigma >> POS2) & ((1 << A2) - 1)) << A1;
+        if (A3 > 0) k |= (sigma & ((1 << A3) - 1)) << (A1 + A2);
+        return k;
+    }
+    __device__ static __forceinline__ int sigma_of_k(int k) {
+        int s = (k & ((1 << A1) - 1)) << POS1;
+        if (A2 > 0) s |= ((k >> A1) & ((1 << A2) - 1)) << POS2;
+        if (A3 > 0) s |= (k >> (A1 + A2)) & ((1 << A3) - 1);
+        return s;
+    }
+    __device__ static __forceinline__ int lpos(int sigma, int t) {
+        return (sigma << LOGT) + (t ^ (kof(sigma) & (T - 1)));
+    }
+};
+
+__device__ __forceinline__ u64 tw_lookup(const u64 *lo, const u64 *hi, int lb, u64 e) {
+    u64 a = lo[e & ((1ULL << lb) - 1)];
+    u64 b = hi[e >> lb];
+    return gl_mul(a, b);
+}
+
+// one LDS-exchanged round: registers -> (twiddle) -> LDS -> barrier -> registers of the next round
+template <typename G, int A, int POS, int ANEXT, int POSNEXT>
+__device__ __forceinline__ void exchange(u64 *v, u64 *lds, const PassArgs &a, int tid) {
+    constexpr int GR = 16 >> A;
+#pragma unroll
+    for (int g = 0; g < GR; g++) {
+        const int gamma = g * G::NT + tid;
+        const int t = gamma & (G::T - 1), o = gamma >> G::LT;
+        const int rho = o & ((1 << POS) - 1);
+#pragma unroll
+        for (int p = 0; p < (1 << A); p++) {
+            const int kj = brev(p, A);
+            u64 x = v[g * (1 << A) + p];
+            // w_(2^(POS+A))^(kj*rho) = w_4096^(kj*rho*2^(12-POS-A))
+            if (kj != 0) x = gl_mul(x, a.tws[(kj * rho) << (12 - POS - A)]);
+            lds[G::lpos(slot_of(o, kj, POS, A), t)] = x;
+        }
+    }
+    __syncthreads();
+    constexpr int GN = 16 >> ANEXT;
+#pragma unroll
+    for (int g = 0; g < GN; g++) {
+        const int gamma = g * G::NT + tid;
+        const int t = gamma & (G::T - 1), o = gamma >> G::LT;
+#pragma unroll
+        for (int j = 0; j < (1 << ANEXT); j++)
+            v[g * (1 << ANEXT) + j] = lds[G::lpos(slot_of(o, j, POSNEXT, ANEXT), t)];
+    }
+}
+
+template <int A1, int A2, int A3, int LOGT, bool TRANSPOSE>
+__global__ void __launch_bounds__((1 << (A1 + A2 + A3 + LOGT)) / 16)
+ntt_pass_kernel(PassArgs a) {
+    using G = Geo<A1, A2, A3, LOGT>;
+    constexpr int L = G::L, T = G::T, NT = G::NT, AJ = G::AJ;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+    const u64 col = blockIdx.y;
+    const u64 u0 = (u64)blockIdx.x << LOGT;
+    const int logNR = a.logn - L;
+    const u64 *src = a.in + col * a.in_cs;
+    u64 *dst = a.out + col * a.out_cs;
+    u64 v[16];
+
+    // ---- round 1: global -> registers
+    {
+        constexpr int GR = 16 >> A1;
+#pragma unroll
+        for (int g = 0; g < GR; g++) {
+            const int gamma = g * NT + tid;
+            const int t = gamma & (T - 1), o = gamma >> LOGT;
+#pragma unroll
+            for (int j = 0; j < (1 << A1); j++) {
+                const u64 idx = ((u64)slot_of(o, j, G::POS1, A1) << logNR) + u0 + t;
+                v[g * (1 << A1) + j] = idx < a.in_valid ? src[idx] : 0ULL;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GR; g++) dif<A1>(v + g * (1 << A1), a.w16);
+    }
+    if constexpr (G::J >= 2) {
+        exchange<G, A1, G::POS1, A2, G::POS2>(v, lds, a, tid);
+#pragma unroll
+        for (int g = 0; g < (16 >> A2); g++) dif<A2>(v + g * (1 << A2), a.w16);
+    }
+    if constexpr (G::J >= 3) {
+        exchange<G, A2, G::POS2, A3, 0>(v, lds, a, tid);
+#pragma unroll
+        for (int g = 0; g < (16 >> A3); g++) dif<A3>(v + g * (1 << A3), a.w16);
+    }
+
+    // ---- output: the last round's field sits at bit 0 of the slot
+    constexpr int GR = 16 >> AJ;
+    const int logP = a.logPprev;
+#pragma unroll
+    for (int g = 0; g < GR; g++) {
+        const int gamma = g * NT + tid;
+        const int t = gamma & (T - 1), o = gamma >> LOGT;
+        const int klow = G::kof(o << AJ);
+        const u64 u = u0 + t;
+        const u64 s = TRANSPOSE ? u : (u0 >> logP);
+        const u64 e0 = TRANSPOSE ? u : (s << logP);
+        u64 w = 1, wstep = 1;
+        if (a.flags & 1) {
+            w = tw_lookup(a.twl, a.twh, a.lb, e0 * (u64)klow);
+            wstep = tw_lookup(a.twl, a.twh, a.lb, e0 << (L - AJ));
+        }
+        if (a.flags & 2) w = gl_mul(w, a.scale);
+        // natural output index of (k, u):  s*Pprev*R + k*Pprev + c
+        const u64 obase = TRANSPOSE ? 0 : ((s << (logP + L)) + (u & ((1ULL << logP) - 1)));
+        u64 cw = 1, cstep = 1;
+        if (a.flags & 4) {  // only used on a last pass (s == 0): i = k*Pprev + c
+            cw = tw_lookup(a.csl, a.csh, a.cslb, obase + ((u64)klow << logP));
+            cstep = tw_lookup(a.csl, a.csh, a.cslb, 1ULL << (logP + L - AJ));
+            w = gl_mul(w, cw);
+            wstep = cstep;
+        }
+#pragma unroll
+        for (int kj = 0; kj < (1 << AJ); kj++) {
+            const int p = brev(kj, AJ);
+            u64 x = v[g * (1 << AJ) + p];
+            if (a.flags & 7) {
+                x = gl_mul(x, w);
+                if (a.flags & 5) w = gl_mul(w, wstep);
+            }
+            const int k = klow + (kj << (L - AJ));
+            if constexpr (TRANSPOSE) {
+                lds[G::lpos(slot_of(o, kj, 0, AJ), t)] = x;
+            } else {
+                dst[obase + ((u64)k << logP)] = x;
+            }
+        }
+    }
+    if constexpr (TRANSPOSE) {
+        __syncthreads();
+        // tile output is the contiguous block out[u0*R, (u0+T)*R): out[(u0+t)*R + k]
+        u64 *blk = dst + (u0 << L);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int idx = i * NT + tid;
+            const int t2 = idx >> L, k = idx & ((1 << L) - 1);
+            blk[idx] = lds[(G::sigma_of_k(k) << LOGT) + (t2 ^ (k & (T - 1)))];
+        }
+    }
+}
+
+// ---- small transforms (N <= 4096): one workgroup per column, radix-2 DIF stages in LDS
+struct SmallArgs {
+    const u64 *in;
+    u64 *out;
+    u64 in_cs, out_cs, in_valid;
+    const u64 *tws;
+    const u64 *csl, *csh;
+    u64 scale;
+    int logn, cslb, flags;
+};
+
+__global__ void __launch_bounds__(256) ntt_small_kernel(SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+    const int n = 1 << a.logn;
+    const u64 *src = a.in + (u64)blockIdx.x * a.in_cs;
+    u64 *dst = a.out + (u64)blockIdx.x * a.out_cs;
+    for (int i = tid; i < n; i += 256) lds[i] = (u64)i < a.in_valid ? src[i] : 0ULL;
+    __syncthreads();
+    for (int s = 0; s < a.logn; s++) {
+        const int lh = a.logn - 1 - s;  // log2(half)
+        const int half = 1 << lh;
+        for (int b = tid; b < (n >> 1); b += 256) {
+            const int i = b & (half - 1);
+            const int i0 = ((b >> lh) << (lh + 1)) + i, i1 = i0 + half;
+            u64 x = lds[i0], y = lds[i1];
+            lds[i0] = gl_add(x, y);
+            u64 d = gl_sub(x, y);
+            lds[i1] = i ? gl_mul(d, a.tws[(u64)i << (12 - (lh + 1))]) : d;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) {
+        const int k = brev(i, a.logn);
+        u64 x = lds[i];
+        if (a.flags & 2) x = gl_mul(x, a.scale);
+        if (a.flags & 4) x = gl_mul(x, tw_lookup(a.csl, a.csh, a.cslb, (u64)k));
+        dst[k] = x;
+    }
+}
+
+// out[i] = in[i] * shift^i  (coefficients -> coset-scaled coefficients), 2 elements per thread
+__global__ void __launch_bounds__(256) coset_scale_kernel(const u64 *in, u64 *out, u64 n, const u64 *lo,
+                                                         const u64 *hi, int lb) {
+    const u64 col = blockIdx.y;
+    const u64 i = ((u64)blockIdx.x * 256 + threadIdx.x);
+    if (i < n) out[col * n + i] = gl_mul(in[col * n + i], tw_lookup(lo, hi, lb, i));
+}
+
+template <int A1, int A2, int A3, int LOGT>
+int32_t launch_pass(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
+    using G = Geo<A1, A2, A3, LOGT>;
+    const u64 tiles = (1ULL << (a.logn - G::L)) >> LOGT;
+    dim3 grid((unsigned)tiles, (unsigned)W), block(G::NT);
+    const size_t shmem = (size_t)G::R * G::T * sizeof(u64);
+    if (transpose) {
+        auto k = ntt_pass_kernel<A1, A2, A3, LOGT, true>;
+        if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a);
+    } else {
+        auto k = ntt_pass_kernel<A1, A2, A3, LOGT, false>;
+        if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a);
+    }
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}
+
+int32_t dispatch_pass(zp_ctx *ctx, const NttPass &p, const PassArgs &a, bool transpose, int W) {
+    switch (p.L) {
+        case 5: return launch_pass<3, 2, 0, 5>(ctx, a, transpose, W);
+        case 6: return launch_pass<3, 3, 0, 5>(ctx, a, transpose, W);
+        case 7: return launch_pass<4, 3, 0, 5>(ctx, a, transpose, W);
+        case 8: return launch_pass<4, 4, 0, 5>(ctx, a, transpose, W);
+        case 9: return launch_pass<3, 3, 3, 5>(ctx, a, transpose, W);
+        default: ctx->err = "unsupported pass radix"; return ZP_ERR_UNSUPPORTED;
+    }
+}
+
+void split_digit(NttPass &p) {
+    switch (p.L) {
+        case 5: p.A1 = 3; p.A2 = 2; p.A3 = 0; break;
+        case 6: p.A1 = 3; p.A2 = 3; p.A3 = 0; break;
+        case 7: p.A1 = 4; p.A2 = 3; p.A3 = 0; break;
+        case 8: p.A1 = 4; p.A2 = 4; p.A3 = 0; break;
+        default: p.A1 = 3; p.A2 = 3; p.A3 = 3; break;
+    }
+    p.logT = 5;
+}
+
+}  // namespace
+
+int32_t zpi_scratch(zp_ctx *ctx, int which, size_t elems, u64 **out) {
+    if (ctx->scratch_elems[which] < elems) {
+        if (ctx->scratch[which]) {
+            ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ZP_HIP(ctx, hipFree(ctx->scratch[which]));
+            ctx->scratch[which] = nullptr;
+            ctx->scratch_elems[which] = 0;
+        }
+        ZP_HIP(ctx, hipMalloc((void **)&ctx->scratch[which], elems * sizeof(u64)));
+        ctx->scratch_elems[which] = elems;
+    }
+    *out = ctx->scratch[which];
+    return ZP_OK;
+}
+
+static int32_t upload(zp_ctx *ctx, const std::vector<u64> &h, u64 **d) {
+    ZP_HIP(ctx, hipMalloc((void **)d, h.size() * sizeof(u64)));
+    ZP_HIP(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(u64), hipMemcpyHostToDevice));
+    return ZP_OK;
+}
+
+int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
+    const int key = logn * 2 + (inverse ? 1 : 0);
+    auto it = ctx->plans.find(key);
+    if (it != ctx->plans.end()) {
+        *out = &it->second;
+        return ZP_OK;
+    }
+    NttPlan pl;
+    pl.logn = logn;
+    pl.inverse = inverse;
+    u64 w = gl_root(ctx->root32, logn);
+    u64 w4096 = gl_root(ctx->root32, 12);
+    u64 w16 = gl_root(ctx->root32, 4);
+    if (inverse) {
+        w = gl_inv(w);
+        w4096 = gl_inv(w4096);
+        w16 = gl_inv(w16);
+    }
+    pl.ninv = gl_inv((1ULL << logn) % GL_P);
+    pl.w16[0] = 1;
+    for (int i = 1; i < 8; i++) pl.w16[i] = gl_mul(pl.w16[i - 1], w16);
+    std::vector<u64> tws(4096);
+    tws[0] = 1;
+    for (int i = 1; i < 4096; i++) tws[i] = gl_mul(tws[i - 1], w4096);
+    ZP_TRY(upload(ctx, tws, &pl.d_tws));
+    if (logn > 12) {
+        const int m = (logn + 8) / 9;
+        int rem = logn;
+        int logP = 0;
+        pl.npass = m;
+        for (int i = 0; i < m; i++) {
+            NttPass &p = pl.pass[i];
+            p.L = (rem + (m - i) - 1) / (m - i);  // balanced, larger digits first
+            rem -= p.L;
+            split_digit(p);
+            p.logPprev = logP;
+            logP += p.L;
+        }
+    }
+    {   // two-level table of w^e, e < N (also used by the FRI fold for w_n^-i)
+        pl.lb = (logn + 1) / 2;
+        std::vector<u64> lo(1ULL << pl.lb), hi(1ULL << (logn - pl.lb));
+        lo[0] = 1;
+        for (size_t i = 1; i < lo.size(); i++) lo[i] = gl_mul(lo[i - 1], w);
+        u64 wl = gl_mul(lo.back(), w);  // w^(2^lb)
+        hi[0] = 1;
+        for (size_t i = 1; i < hi.size(); i++) hi[i] = gl_mul(hi[i - 1], wl);
+        ZP_TRY(upload(ctx, lo, &pl.d_twl));
+        ZP_TRY(upload(ctx, hi, &pl.d_twh));
+    }
+    auto ins = ctx->plans.emplace(key, pl);
+    *out = &ins.first->second;
+    return ZP_OK;
+}
+
+int32_t zpi_get_coset(zp_ctx *ctx, int logn, u64 shift, u64 pre, CosetTable **out) {
+    for (auto &c : ctx->cosets)
+        if (c.logn == logn && c.shift == shift && c.pre == pre) {
+            *out = &c;
+            return ZP_OK;
+        }
+    CosetTable c;
+    c.logn = logn;
+    c.shift = shift;
+    c.pre = pre;
+    c.lb = (logn + 1) / 2;
+    std::vector<u64> lo(1ULL << c.lb), hi(1ULL << (logn - c.lb));
+    lo[0] = pre;
+    u64 sp = 1;
+    for (size_t i = 1; i < lo.size(); i++) {
+        sp = gl_mul(sp, shift);
+        lo[i] = gl_mul(pre, sp);
+    }
+    u64 sl = gl_mul(sp, shift);  // shift^(2^lb)
+    hi[0] = 1;
+    for (size_t i = 1; i < hi.size(); i++) hi[i] = gl_mul(hi[i - 1], sl);
+    ZP_TRY(upload(ctx, lo, &c.d_lo));
+    ZP_TRY(upload(ctx, hi, &c.d_hi));
+    ctx->cosets.push_back(c);
+    *out = &ctx->cosets.back();
+    return ZP_OK;
+}
+
+int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, bool inverse,
+                    const NttRunOpts &opts) {
+    ZP_ARG(ctx, logn >= 0 && logn <= 32, "logn must be in [0,32]");
+    ZP_ARG(ctx, W >= 0, "W must be >= 0");
+    ZP_ARG(ctx, d_in && d_out, "null device pointer");
+    if (W == 0) return ZP_OK;
+    NttPlan *pl;
+    ZP_TRY(zpi_get_plan(ctx, logn, inverse, &pl));
+    const u64 N = 1ULL << logn;
+    const u64 in_valid = opts.in_valid_log >= 0 ? (1ULL << opts.in_valid_log) : N;
+    ZP_ARG(ctx, in_valid <= N, "in_valid_log > logn");
+    ZP_ARG(ctx, !(in_valid != N && (const u64 *)d_out == d_in), "zero-padded input cannot be in place");
+
+    if (logn <= 12) {
+        SmallArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = d_in;
+        a.out = d_out;
+        a.in_cs = in_valid;
+        a.out_cs = N;
+        a.in_valid = in_valid;
+        a.tws = pl->d_tws;
+        a.scale = pl->ninv;
+        a.logn = logn;
+        a.flags = inverse ? 2 : 0;
+        if (opts.post_scale) {
+            a.flags |= 4;
+            a.csl = opts.post_scale->d_lo;
+            a.csh = opts.post_scale->d_hi;
+            a.cslb = opts.post_scale->lb;
+        }
+        // in place is safe: a block owns its column and loads all of it into LDS before storing
+        hipLaunchKernelGGL(ntt_small_kernel, dim3((unsigned)W), dim3(256), (size_t)N * sizeof(u64), ctx->stream, a);
+        ZP_HIP(ctx, hipGetLastError());
+        return ZP_OK;
+    }
+
+    // chunk the columns so that each ping-pong scratch buffer stays <= 2 GiB
+    const u64 cap_elems = 1ULL << 28;
+    int wc = (int)(cap_elems >> logn);
+    if (wc < 1) wc = 1;
+    if (wc > W) wc = W;
+    const int m = pl->npass;
+    u64 *s0 = nullptr, *s1 = nullptr;
+    if (m >= 2) ZP_TRY(zpi_scratch(ctx, 0, (size_t)wc << logn, &s0));
+    if (m >= 3) ZP_TRY(zpi_scratch(ctx, 1, (size_t)wc << logn, &s1));
+
+    for (int c0 = 0; c0 < W; c0 += wc) {
+        const int w = (W - c0 < wc) ? (W - c0) : wc;
+        const u64 *cur = d_in + (u64)c0 * in_valid;
+        u64 cur_cs = in_valid;
+        for (int i = 0; i < m; i++) {
+            const bool last = (i == m - 1);
+            u64 *nxt = last ? d_out + ((u64)c0 << logn) : ((i & 1) ? s1 : s0);
+            PassArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in = cur;
+            a.out = nxt;
+            a.in_cs = cur_cs;
+            a.out_cs = N;
+            a.in_valid = (i == 0) ? in_valid : N;
+            a.twl = pl->d_twl;
+            a.twh = pl->d_twh;
+            a.lb = pl->lb;
+            a.tws = pl->d_tws;
+            memcpy(a.w16, pl->w16, sizeof(a.w16));
+            a.scale = pl->ninv;
+            a.logn = logn;
+            a.logPprev = pl->pass[i].logPprev;
+            a.flags = last ? 0 : 1;
+            if (last && inverse) a.flags |= 2;
+            if (last && opts.post_scale) {
+                a.flags |= 4;
+                a.csl = opts.post_scale->d_lo;
+                a.csh = opts.post_scale->d_hi;
+                a.cslb = opts.post_scale->lb;
+            }
+            zp_ctx::PassEv ev;
+            if (ctx->profiling) {
+                ZP_HIP(ctx, hipEventCreate(&ev.a));
+                ZP_HIP(ctx, hipEventCreate(&ev.b));
+                ev.radix_log = (i == 0) ? -pl->pass[i].L : pl->pass[i].L;
+                ZP_HIP(ctx, hipEventRecord(ev.a, ctx->stream));
+            }
+            ZP_TRY(dispatch_pass(ctx, pl->pass[i], a, i == 0, w));
+            if (ctx->profiling) {
+                ZP_HIP(ctx, hipEventRecord(ev.b, ctx->stream));
+                ctx->pass_events.push_back(ev);
+            }
+            cur = nxt;
+            cur_cs = N;
+        }
+    }
+    return ZP_OK;
+}
+
+int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn, int logb, int W, u64 shift) {
+    ZP_ARG(ctx, logn >= 0 && logb >= 0 && logn + logb <= 32, "logn/logb out of range");
+    ZP_ARG(ctx, W >= 0, "W must be >= 0");
+    ZP_ARG(ctx, d_in && d_out, "null device pointer");
+    ZP_ARG(ctx, d_out != d_in, "zp_lde cannot run in place");
+    if (W == 0) return ZP_OK;
+    if (shift == 0) shift = ctx->coset_shift;
+    ZP_ARG(ctx, shift < GL_P, "shift not canonical");
+    const u64 N = 1ULL << logn;
+    CosetTable *ct;
+    ZP_TRY(zpi_get_coset(ctx, logn, shift, 1, &ct));
+    // columns go in chunks so that the scaled-coefficient buffer stays <= 2 GiB
+    int wc = (int)((1ULL << 28) >> logn);
+    if (wc < 1) wc = 1;
+    if (wc > W) wc = W;
+    u64 *scaled = nullptr;
+    ZP_TRY(zpi_scratch(ctx, 2, (size_t)wc << logn, &scaled));
+    for (int c0 = 0; c0 < W; c0 += wc) {
+        const int w = (W - c0 < wc) ? (W - c0) : wc;
+        const u64 *in = d_in + (u64)c0 * N;
+        u64 *out = d_out + ((u64)c0 << (logn + logb));
+        NttRunOpts inv;
+        if (d_coef) {
+            u64 *coef = d_coef + (u64)c0 * N;
+            ZP_TRY(zpi_ntt_run(ctx, in, coef, logn, w, true, inv));
+            dim3 grid((unsigned)((N + 255) / 256), (unsigned)w);
+            hipLaunchKernelGGL(coset_scale_kernel, grid, dim3(256), 0, ctx->stream, coef, scaled, N, ct->d_lo,
+                               ct->d_hi, ct->lb);
+            ZP_HIP(ctx, hipGetLastError());
+        } else {
+            inv.post_scale = ct;  // the inverse transform's last pass multiplies c_i by shift^i
+            ZP_TRY(zpi_ntt_run(ctx, in, scaled, logn, w, true, inv));
+        }
+        NttRunOpts fwd;
+        fwd.in_valid_log = logn;  // zero padding is implicit: rows >= N read as 0
+        ZP_TRY(zpi_ntt_run(ctx, scaled, out, logn + logb, w, false, fwd));
+    }
+    return ZP_OK;
+}

@@ -1,0 +1,244 @@
+// Poseidon-12 over Goldilocks, linear-hash leaves and binary Merkle trees.
+//
+// No reference counterpart in /root/reference (hashing happens inside the external prover service
+// that src/prover/provider.rs:358-377 calls).  Textbook schedule ARK -> S-box(x^7) -> MDS, 4 full +
+// 22 partial + 4 full rounds, tables injected through zp_set_constants.
+//
+// Mapping: one lane = one permutation, the 12-element state lives in 24 VGPRs; round constants and
+// the MDS matrix are wave-uniform and are fetched with scalar loads.  The leaf kernel walks the
+// column-major matrix with lane = row, so every column read is a coalesced 512-byte run per wave.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "ctx.hpp"
+
+namespace {
+
+__device__ __forceinline__ u64 sbox7(u64 x) {
+    u64 x2 = gl_mul(x, x), x4 = gl_mul(x2, x2), x3 = gl_mul(x2, x);
+    return gl_mul(x3, x4);
+}
+
+// out[i] = sum_j m[i][j] * s[j],  m entries < 2^28 so both 64-bit partial sums cannot overflow
+__device__ __forceinline__ void mds_mul(u64 *s, const u32 *__restrict__ mds) {
+    u64 o[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        u64 alo = 0, ahi = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const u32 m = mds[i * 12 + j];
+            alo += (u64)m * (u32)s[j];
+            ahi += (u64)m * (u32)(s[j] >> 32);
+        }
+        // value = alo + ahi * 2^32
+        const u64 mid = (alo >> 32) + ahi;
+        o[i] = gl_reduce_limbs((u32)alo, (u32)mid, (u32)(mid >> 32), 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = o[i];
+}
+
+__device__ __forceinline__ void poseidon_perm(u64 *s, const u64 *__restrict__ rc, const u32 *__restrict__ mds) {
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox7(gl_add(s[i], rc[r * 12 + i]));
+        mds_mul(s, mds);
+    }
+#pragma unroll 1
+    for (int r = 4; r < 26; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], rc[r * 12 + i]);
+        s[0] = sbox7(s[0]);
+        mds_mul(s, mds);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 30; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox7(gl_add(s[i], rc[r * 12 + i]));
+        mds_mul(s, mds);
+    }
+}
+
+__global__ void __launch_bounds__(256) poseidon_perm_kernel(u64 *states, size_t count, const u64 *rc, const u32 *mds) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    u64 s[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) s[j] = states[i * 12 + j];
+    poseidon_perm(s, rc, mds);
+#pragma unroll
+    for (int j = 0; j < 12; j++) states[i * 12 + j] = s[j];
+}
+
+// leaf i = linear hash of (cols[0][i], cols[1][i], ... cols[W-1][i]);  lane = row
+__global__ void __launch_bounds__(256) merkle_leaves_kernel(const u64 *__restrict__ cols, size_t M, int W,
+                                                           u64 *__restrict__ tree, const u64 *rc, const u32 *mds) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    u64 s[12];
+    if (W <= 4) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) tree[i * 4 + j] = j < W ? cols[(size_t)j * M + i] : 0ULL;
+        return;
+    }
+#pragma unroll
+    for (int j = 8; j < 12; j++) s[j] = 0;
+    for (int off = 0; off < W; off += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = (off + j < W) ? cols[(size_t)(off + j) * M + i] : 0ULL;
+        poseidon_perm(s, rc, mds);
+#pragma unroll
+        for (int j = 0; j < 4; j++) s[8 + j] = s[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) tree[i * 4 + j] = s[8 + j];
+}
+
+// leaves given as M contiguous rows of `len` elements
+__global__ void __launch_bounds__(256) merkle_leaves_rows_kernel(const u64 *__restrict__ rows, size_t M, size_t len,
+                                                                u64 *__restrict__ tree, const u64 *rc, const u32 *mds) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const u64 *row = rows + i * len;
+    u64 s[12];
+    if (len <= 4) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) tree[i * 4 + j] = (size_t)j < len ? row[j] : 0ULL;
+        return;
+    }
+#pragma unroll
+    for (int j = 8; j < 12; j++) s[j] = 0;
+    for (size_t off = 0; off < len; off += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = (off + j < len) ? row[off + j] : 0ULL;
+        poseidon_perm(s, rc, mds);
+#pragma unroll
+        for (int j = 0; j < 4; j++) s[8 + j] = s[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) tree[i * 4 + j] = s[8 + j];
+}
+
+// one tree level: node i = P(child[2i] || child[2i+1] || 0^4)[0..4]
+__global__ void __launch_bounds__(256) merkle_level_kernel(const u64 *__restrict__ prev, u64 *__restrict__ next,
+                                                          size_t half, const u64 *rc, const u32 *mds) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= half) return;
+    u64 s[12];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = prev[i * 8 + j];
+#pragma unroll
+    for (int j = 8; j < 12; j++) s[j] = 0;
+    poseidon_perm(s, rc, mds);
+#pragma unroll
+    for (int j = 0; j < 4; j++) next[i * 4 + j] = s[j];
+}
+
+int32_t tree_levels(zp_ctx *ctx, u64 *tree, size_t M) {
+    u64 *prev = tree;
+    size_t cnt = M;
+    while (cnt > 1) {
+        u64 *next = prev + cnt * 4;
+        const size_t half = cnt >> 1;
+        hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream,
+                           prev, next, half, ctx->d_rc, ctx->d_mds);
+        ZP_HIP(ctx, hipGetLastError());
+        prev = next;
+        cnt = half;
+    }
+    return ZP_OK;
+}
+
+}  // namespace
+
+int32_t zpi_poseidon_sync_tables(zp_ctx *ctx) {
+    if (!ctx->poseidon_dirty) return ZP_OK;
+    for (int i = 0; i < 144; i++) ZP_ARG(ctx, ctx->h_mds[i] < (1ULL << 28), "MDS entries must be < 2^28");
+    if (!ctx->d_rc) ZP_HIP(ctx, hipMalloc((void **)&ctx->d_rc, 360 * sizeof(u64)));
+    if (!ctx->d_mds) ZP_HIP(ctx, hipMalloc((void **)&ctx->d_mds, 144 * sizeof(u32)));
+    u32 m32[144];
+    for (int i = 0; i < 144; i++) m32[i] = (u32)ctx->h_mds[i];
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZP_HIP(ctx, hipMemcpy(ctx->d_rc, ctx->h_rc, 360 * sizeof(u64), hipMemcpyHostToDevice));
+    ZP_HIP(ctx, hipMemcpy(ctx->d_mds, m32, sizeof(m32), hipMemcpyHostToDevice));
+    ctx->poseidon_dirty = false;
+    return ZP_OK;
+}
+
+extern "C" {
+
+int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count) {
+    if (!ctx) return ZP_ERR_ARG;
+    if (count == 0) return ZP_OK;
+    ZP_ARG(ctx, d_states != nullptr, "null device pointer");
+    ZP_TRY(zpi_poseidon_sync_tables(ctx));
+    hipLaunchKernelGGL(poseidon_perm_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (u64 *)d_states, count, ctx->d_rc, ctx->d_mds);
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}
+
+int32_t zp_merkle_commit(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, uint64_t *d_tree) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, M >= 1 && (M & (M - 1)) == 0, "M must be a power of two");
+    ZP_ARG(ctx, W >= 1, "W must be >= 1");
+    ZP_ARG(ctx, d_cols && d_tree, "null device pointer");
+    ZP_TRY(zpi_poseidon_sync_tables(ctx));
+    hipLaunchKernelGGL(merkle_leaves_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const u64 *)d_cols, M, (int)W, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
+    ZP_HIP(ctx, hipGetLastError());
+    return tree_levels(ctx, (u64 *)d_tree, M);
+}
+
+int32_t zp_merkle_commit_rows(zp_ctx *ctx, const uint64_t *d_rows, size_t M, size_t len, uint64_t *d_tree) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, M >= 1 && (M & (M - 1)) == 0, "M must be a power of two");
+    ZP_ARG(ctx, len >= 1, "len must be >= 1");
+    ZP_ARG(ctx, d_rows && d_tree, "null device pointer");
+    ZP_TRY(zpi_poseidon_sync_tables(ctx));
+    hipLaunchKernelGGL(merkle_leaves_rows_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const u64 *)d_rows, M, len, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
+    ZP_HIP(ctx, hipGetLastError());
+    return tree_levels(ctx, (u64 *)d_tree, M);
+}
+
+int32_t zp_merkle_open(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx, uint64_t *h_path) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, M >= 1 && (M & (M - 1)) == 0, "M must be a power of two");
+    ZP_ARG(ctx, idx < M, "leaf index out of range");
+    ZP_ARG(ctx, d_tree && h_path, "null pointer");
+    const u64 *lvl = (const u64 *)d_tree;
+    size_t cnt = M;
+    int d = 0;
+    while (cnt > 1) {
+        ZP_HIP(ctx, hipMemcpyAsync(h_path + 4 * d, lvl + (idx ^ 1) * 4, 4 * sizeof(u64), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        lvl += cnt * 4;
+        cnt >>= 1;
+        idx >>= 1;
+        d++;
+    }
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZP_OK;
+}
+
+int32_t zp_merkle_commit_host(zp_ctx *ctx, const uint64_t *h_cols, size_t M, int32_t W, uint64_t *h_tree) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, M >= 1 && (M & (M - 1)) == 0, "M must be a power of two");
+    ZP_ARG(ctx, W >= 1 && h_cols && h_tree, "bad arguments");
+    const size_t bin = (size_t)W * M * sizeof(u64), bt = (2 * M - 1) * 4 * sizeof(u64);
+    void *dc = nullptr, *dt = nullptr;
+    ZP_TRY(zp_dev_alloc(ctx, bin, &dc));
+    int32_t rc = zp_dev_alloc(ctx, bt, &dt);
+    if (rc == ZP_OK) rc = zp_h2d(ctx, dc, h_cols, bin);
+    if (rc == ZP_OK) rc = zp_merkle_commit(ctx, (const uint64_t *)dc, M, W, (uint64_t *)dt);
+    if (rc == ZP_OK) rc = zp_d2h(ctx, h_tree, dt, bt);
+    (void)zp_dev_free(ctx, dc);
+    (void)zp_dev_free(ctx, dt);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+"""ctypes binding of libzethprover.so (include/zeth_prover.h) -- the host side of the C-ABI.
+
+This is the Python stand-in for the Rust host BASELINE.json's north_star names (no Rust toolchain in
+the image; INTEGRATION.md shows the equivalent `extern "C"` block).  It mirrors the boundary
+one-to-one: every method is one zp_* call.  There is NO CPU fallback: if the HIP library is missing
+or no GPU is present, construction raises.
+
+Reference call sites this path serves: src/prover/provider.rs:358-390 (GenChunkProof) of eigen-zeth.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libzethprover.so")
+
+P = 0xFFFFFFFF00000001
+ROOT32_DEFAULT = 1753635133440165772
+ROOT32_ALT = 7277203076849721926
+SHIFT_DEFAULT = 49
+
+ZP_CONST_ROOT32 = 1
+ZP_CONST_POSEIDON_RC = 2
+ZP_CONST_POSEIDON_MDS = 3
+ZP_CONST_COSET_SHIFT = 4
+
+_u64p = C.POINTER(C.c_uint64)
+_vp = C.c_void_p
+
+# every symbol include/zeth_prover.h declares: (restype, argtypes)
+SIGNATURES = {
+    "zp_create": (C.c_int32, [C.POINTER(_vp), C.c_int32]),
+    "zp_destroy": (None, [_vp]),
+    "zp_last_error": (C.c_char_p, [_vp]),
+    "zp_version": (C.c_char_p, []),
+    "zp_set_stream": (C.c_int32, [_vp, _vp]),
+    "zp_sync": (C.c_int32, [_vp]),
+    "zp_set_constants": (C.c_int32, [_vp, C.c_int32, _u64p, C.c_size_t]),
+    "zp_get_constants": (C.c_int32, [_vp, C.c_int32, _u64p, C.c_size_t]),
+    "zp_dev_alloc": (C.c_int32, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "zp_dev_free": (C.c_int32, [_vp, _vp]),
+    "zp_h2d": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
+    "zp_d2h": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
+    "zp_d2d": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
+    "zp_ntt": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32]),
+    "zp_intt": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32]),
+    "zp_lde": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
+    "zp_poseidon_perm": (C.c_int32, [_vp, _vp, C.c_size_t]),
+    "zp_merkle_commit": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp]),
+    "zp_merkle_commit_rows": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _vp]),
+    "zp_merkle_open": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _u64p]),
+    "zp_fri_fold": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, _u64p, C.c_uint64]),
+    "zp_ntt_host": (C.c_int32, [_vp, _u64p, C.c_int32, C.c_int32, C.c_int32]),
+    "zp_lde_host": (C.c_int32, [_vp, _u64p, _u64p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
+    "zp_merkle_commit_host": (C.c_int32, [_vp, _u64p, C.c_size_t, C.c_int32, _u64p]),
+    "zp_set_profiling": (C.c_int32, [_vp, C.c_int32]),
+    "zp_get_pass_timings": (C.c_int32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32,
+                                        C.POINTER(C.c_int32)]),
+    "zp_ntt_plan_json": (C.c_int32, [_vp, C.c_int32, C.c_char_p, C.c_size_t]),
+    "zp_device_info_json": (C.c_int32, [_vp, C.c_char_p, C.c_size_t]),
+}
+
+
+class ZpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libzethprover error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library and bind every declared symbol.  Raises if the .so is missing --
+    the product path never degrades to a CPU implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libzethprover.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C eigen_zeth_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(x):
+    """device pointer of a DeviceBuffer / torch tensor / raw int"""
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+class DeviceBuffer:
+    """u64 device array owned through zp_dev_alloc / zp_dev_free"""
+
+    def __init__(self, prover, n_elems):
+        self.prover = prover
+        self.n = int(n_elems)
+        p = _vp()
+        prover._chk(prover.lib.zp_dev_alloc(prover.ctx, self.n * 8, C.byref(p)))
+        self.ptr = p.value or 0
+
+    def offset(self, elems):
+        return self.ptr + 8 * int(elems)
+
+    def free(self):
+        if self.ptr and self.prover.ctx:
+            self.prover.lib.zp_dev_free(self.prover.ctx, self.ptr)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Prover:
+    """One zp_ctx = one GPU + one stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        ctx = _vp()
+        rc = self.lib.zp_create(C.byref(ctx), device)
+        if rc != 0:
+            raise ZpError(rc, "zp_create failed (no HIP device %d?) -- the prover requires an MI355X" % device)
+        self.ctx = ctx
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if self.ctx:
+            self.lib.zp_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise ZpError(rc, (self.lib.zp_last_error(self.ctx) or b"").decode())
+
+    # ---- plumbing
+    def set_stream(self, stream):
+        self._chk(self.lib.zp_set_stream(self.ctx, int(stream) if stream else None))
+
+    def sync(self):
+        self._chk(self.lib.zp_sync(self.ctx))
+
+    def set_constants(self, kind, values):
+        a = np.ascontiguousarray(np.asarray(values, dtype=np.uint64).ravel())
+        self._chk(self.lib.zp_set_constants(self.ctx, kind, a.ctypes.data_as(_u64p), a.size))
+
+    def get_constants(self, kind, n):
+        a = np.zeros(n, dtype=np.uint64)
+        self._chk(self.lib.zp_get_constants(self.ctx, kind, a.ctypes.data_as(_u64p), n))
+        return a
+
+    def alloc(self, n_elems):
+        return DeviceBuffer(self, n_elems)
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.uint64))
+        buf = DeviceBuffer(self, a.size)
+        self._chk(self.lib.zp_h2d(self.ctx, buf.ptr, a.ctypes.data, a.nbytes))
+        return buf
+
+    def download(self, buf, shape, offset_elems=0):
+        out = np.empty(shape, dtype=np.uint64)
+        self._chk(self.lib.zp_d2h(self.ctx, out.ctypes.data, _ptr(buf) + 8 * offset_elems, out.nbytes))
+        return out
+
+    def h2d(self, dst, arr):
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.uint64))
+        self._chk(self.lib.zp_h2d(self.ctx, _ptr(dst), a.ctypes.data, a.nbytes))
+
+    # ---- hot path (device pointers)
+    def ntt(self, d_in, d_out, logn, W):
+        self._chk(self.lib.zp_ntt(self.ctx, _ptr(d_in), _ptr(d_out), logn, W))
+
+    def intt(self, d_in, d_out, logn, W):
+        self._chk(self.lib.zp_intt(self.ctx, _ptr(d_in), _ptr(d_out), logn, W))
+
+    def lde(self, d_in, d_out, logn, logb, W, shift=0, d_coef=None):
+        self._chk(self.lib.zp_lde(self.ctx, _ptr(d_in), _ptr(d_out), _ptr(d_coef), logn, logb, W, shift))
+
+    def poseidon_perm(self, d_states, count):
+        self._chk(self.lib.zp_poseidon_perm(self.ctx, _ptr(d_states), count))
+
+    def merkle_commit(self, d_cols, M, W, d_tree):
+        self._chk(self.lib.zp_merkle_commit(self.ctx, _ptr(d_cols), M, W, _ptr(d_tree)))
+
+    def merkle_commit_rows(self, d_rows, M, length, d_tree):
+        self._chk(self.lib.zp_merkle_commit_rows(self.ctx, _ptr(d_rows), M, length, _ptr(d_tree)))
+
+    def merkle_open(self, d_tree, M, idx):
+        depth = int(M).bit_length() - 1
+        path = np.zeros((max(depth, 1), 4), dtype=np.uint64)
+        self._chk(self.lib.zp_merkle_open(self.ctx, _ptr(d_tree), M, idx, path.ctypes.data_as(_u64p)))
+        return path[:depth]
+
+    def fri_fold(self, d_in, d_out, logn, logf, beta, shift):
+        b = (C.c_uint64 * 3)(*[int(x) for x in beta])
+        self._chk(self.lib.zp_fri_fold(self.ctx, _ptr(d_in), _ptr(d_out), logn, logf, b, shift))
+
+    # ---- host-buffer forms
+    def ntt_host(self, cols, inverse=False):
+        a = np.ascontiguousarray(np.asarray(cols, dtype=np.uint64)).copy()
+        W, N = a.shape
+        self._chk(self.lib.zp_ntt_host(self.ctx, a.ctypes.data_as(_u64p), N.bit_length() - 1, W, int(inverse)))
+        return a
+
+    def lde_host(self, cols, logb, shift=0):
+        a = np.ascontiguousarray(np.asarray(cols, dtype=np.uint64))
+        W, N = a.shape
+        out = np.empty((W, N << logb), dtype=np.uint64)
+        self._chk(self.lib.zp_lde_host(self.ctx, a.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p),
+                                       N.bit_length() - 1, logb, W, shift))
+        return out
+
+    def merkle_commit_host(self, cols):
+        a = np.ascontiguousarray(np.asarray(cols, dtype=np.uint64))
+        W, M = a.shape
+        tree = np.empty((2 * M - 1, 4), dtype=np.uint64)
+        self._chk(self.lib.zp_merkle_commit_host(self.ctx, a.ctypes.data_as(_u64p), M, W,
+                                                 tree.ctypes.data_as(_u64p)))
+        return tree
+
+    # ---- measurement
+    def set_profiling(self, on):
+        self._chk(self.lib.zp_set_profiling(self.ctx, int(bool(on))))
+
+    def pass_timings(self, cap=4096):
+        ms = (C.c_float * cap)()
+        rl = (C.c_int32 * cap)()
+        n = C.c_int32(0)
+        self._chk(self.lib.zp_get_pass_timings(self.ctx, ms, rl, cap, C.byref(n)))
+        return [(rl[i], ms[i]) for i in range(n.value)]
+
+    # ---- introspection
+    def ntt_plan(self, logn):
+        buf = C.create_string_buffer(4096)
+        self._chk(self.lib.zp_ntt_plan_json(self.ctx, logn, buf, 4096))
+        return json.loads(buf.value.decode())
+
+    def device_info(self):
+        buf = C.create_string_buffer(4096)
+        self._chk(self.lib.zp_device_info_json(self.ctx, buf, 4096))
+        return json.loads(buf.value.decode())

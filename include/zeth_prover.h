@@ -1,0 +1,120 @@
+/*
+ * zeth_prover.h -- C ABI of libzethprover.so, the MI355X-native arithmetic back end of the
+ * prover.v1.ProverService batch prover that eigen-zeth calls.
+ *
+ * What this replaces in the reference: nothing *inside* /root/reference -- eigen-zeth holds only
+ * the gRPC client (src/prover/provider.rs:603-705 connects, :292-310/:358-377/:422-433/:472-483
+ * send the four requests of proto/prover/v1/prover.proto:13-36).  The arithmetic that answers
+ * GenChunkProof (prover.proto:56-66,93-111) lives in the external prover service (SURVEY.md par.0.2,
+ * row 16 of par.2).  A Rust host (as BASELINE.json's north_star asks) would bind exactly these
+ * entry points with `extern "C"` -- see INTEGRATION.md for the stub; in this repo the host side is
+ * Python/ctypes (eigen_zeth_amd/native.py) because no Rust toolchain exists in the image.
+ *
+ * Conventions
+ *  - every function returns int32_t: 0 = ZP_OK, <0 = error; zp_last_error(ctx) gives the text.
+ *  - no exceptions / C++ types cross the boundary; pointers + sizes only.
+ *  - field elements are canonical uint64_t (< p = 2^64 - 2^32 + 1).
+ *  - matrices are COLUMN-MAJOR  u64[W][N]  (column c at base + c*N), N a power of two.
+ *  - F_{p^3} vectors are plane-major u64[3][n]  (x^3 - x - 1).
+ *  - pointers named d_* are DEVICE pointers (hipMalloc / torch.cuda storage); h_* are host.
+ *  - a ctx is bound to one HIP device and one stream (zp_set_stream; default = the null stream);
+ *    it is single-threaded; separate ctxs may run concurrently (one per GPU / per stream).
+ *  - all compute entry points are asynchronous on the ctx stream; zp_sync() waits.
+ */
+#ifndef ZETH_PROVER_H
+#define ZETH_PROVER_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zp_ctx zp_ctx;
+
+enum {
+    ZP_OK = 0,
+    ZP_ERR_ARG = -1,     /* bad argument (size not a power of two, null pointer, ...) */
+    ZP_ERR_HIP = -2,     /* HIP runtime error (text in zp_last_error) */
+    ZP_ERR_NOMEM = -3,   /* device allocation failed */
+    ZP_ERR_UNSUPPORTED = -4
+};
+
+/* kinds for zp_set_constants */
+enum {
+    ZP_CONST_ROOT32 = 1,        /* blob[1]: primitive 2^32-th root of unity (default 7^((p-1)/2^32)) */
+    ZP_CONST_POSEIDON_RC = 2,   /* blob[360]: round constants, rc[r*12+i] */
+    ZP_CONST_POSEIDON_MDS = 3,  /* blob[144]: row-major 12x12, out[r] = sum_j m[r*12+j]*in[j] (entries < 2^28) */
+    ZP_CONST_COSET_SHIFT = 4    /* blob[1]: default LDE coset shift (49) */
+};
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int32_t zp_create(zp_ctx **out, int32_t device);
+void zp_destroy(zp_ctx *ctx);
+const char *zp_last_error(zp_ctx *ctx);
+const char *zp_version(void);
+int32_t zp_set_stream(zp_ctx *ctx, void *hip_stream);
+int32_t zp_sync(zp_ctx *ctx);
+int32_t zp_set_constants(zp_ctx *ctx, int32_t kind, const uint64_t *blob, size_t n);
+int32_t zp_get_constants(zp_ctx *ctx, int32_t kind, uint64_t *blob, size_t n);
+
+/* ---- device memory (for hosts without their own allocator) ---------------------------------- */
+int32_t zp_dev_alloc(zp_ctx *ctx, size_t bytes, void **d_ptr);
+int32_t zp_dev_free(zp_ctx *ctx, void *d_ptr);
+int32_t zp_h2d(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int32_t zp_d2h(zp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int32_t zp_d2d(zp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+
+/* ---- N1: Goldilocks NTT / iNTT  (natural order in, natural order out) ------------------------
+ * d_in, d_out: u64[W][2^logn].  d_in == d_out is allowed.  d_in is preserved when d_in != d_out. */
+int32_t zp_ntt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t W);
+int32_t zp_intt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t W);
+
+/* ---- N2: low-degree extension ----------------------------------------------------------------
+ * d_in u64[W][2^logn] evaluations on <w_N>; d_out u64[W][2^(logn+logb)] evaluations on
+ * shift*<w_bN>, natural order.  If d_coef != NULL it receives the interpolant's coefficients
+ * u64[W][2^logn] (ascending).  shift == 0 selects the ctx default (ZP_CONST_COSET_SHIFT).       */
+int32_t zp_lde(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t *d_coef, int32_t logn,
+               int32_t logb, int32_t W, uint64_t shift);
+
+/* ---- N3: Poseidon-12 and Merkle commitment -------------------------------------------------- */
+/* d_states: u64[count][12], permuted in place */
+int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count);
+/* leaf i = linear hash (sponge, rate 8, capacity 4; rows of <= 4 elements are identity-padded) of
+ * row i across the W columns of d_cols u64[W][M]; d_tree receives (2M-1)*4 u64: M leaves, then
+ * M/2 nodes ... the root is the last 4 elements.                                               */
+int32_t zp_merkle_commit(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, uint64_t *d_tree);
+/* same, leaves are M contiguous rows of `len` elements (row-major), e.g. FRI layer cosets */
+int32_t zp_merkle_commit_rows(zp_ctx *ctx, const uint64_t *d_rows, size_t M, size_t len, uint64_t *d_tree);
+/* authentication path (host tree or device tree): depth*4 u64, bottom-up siblings */
+int32_t zp_merkle_open(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx, uint64_t *h_path);
+
+/* ---- N5: FRI fold ------------------------------------------------------------------------------
+ * d_in u64[3][2^logn] = f on shift*<w_n> (natural order);  d_out u64[3][2^(logn-logf)] =
+ * sum_j beta^j g_j on shift^(2^logf)*<w_(n>>logf)>,  f(x) = sum_j x^j g_j(x^(2^logf)), logf in 1..4 */
+int32_t zp_fri_fold(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t logf,
+                    const uint64_t beta[3], uint64_t shift);
+
+/* ---- host-buffer conveniences (H2D + compute + D2H + sync), the form a non-GPU-aware host uses */
+int32_t zp_ntt_host(zp_ctx *ctx, uint64_t *h_cols, int32_t logn, int32_t W, int32_t inverse);
+int32_t zp_lde_host(zp_ctx *ctx, const uint64_t *h_in, uint64_t *h_out, int32_t logn, int32_t logb,
+                    int32_t W, uint64_t shift);
+int32_t zp_merkle_commit_host(zp_ctx *ctx, const uint64_t *h_cols, size_t M, int32_t W, uint64_t *h_tree);
+
+/* ---- measurement ---------------------------------------------------------------------------
+ * With profiling on, every NTT pass launch of the next transforms is bracketed by HIP events on the
+ * ctx stream.  zp_get_pass_timings synchronises, then returns for the launches recorded since the
+ * last call: duration in ms and log2(radix) (negative for the transposing first pass).           */
+int32_t zp_set_profiling(zp_ctx *ctx, int32_t on);
+int32_t zp_get_pass_timings(zp_ctx *ctx, float *ms, int32_t *radix_log, int32_t cap, int32_t *count);
+
+/* ---- introspection ------------------------------------------------------------------------- */
+/* JSON description of the pass plan used for a 2^logn transform (for DESIGN/bench reporting) */
+int32_t zp_ntt_plan_json(zp_ctx *ctx, int32_t logn, char *buf, size_t buflen);
+/* name of the dominant kernel symbol of zp_ntt for this size (for matching rocprof output) */
+int32_t zp_device_info_json(zp_ctx *ctx, char *buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

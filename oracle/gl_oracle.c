@@ -1,0 +1,413 @@
+/*
+ * oracle/gl_oracle.c -- CPU restatement of the batch-prover hot path (TEST INFRASTRUCTURE).
+ *
+ * This file is the CHECKER, never the product: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product path (eigen_zeth_amd/) never links
+ * or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference (/root/reference, 0xEigenLabs/eigen-zeth) contains only the
+ * gRPC *client* of the prover (src/prover/provider.rs:1-706, proto/prover/v1/prover.proto:1-195);
+ * the arithmetic of the path lives in an external, un-pinned prover service.
+ * There is no reference file, golden vector or known-answer test for any function below, so this
+ * restatement follows the public algorithm definitions and is pinned by
+ *   - mathematical identities (naive O(n^2) DFT with Python big-ints, direct polynomial
+ *     evaluation, round trips) -- tests/test_oracle.py, tests/golden/
+ *   - one external anchor: the Poseidon Grain-LFSR generator reproduces the published BN254 t=3
+ *     first round constant, see tests/test_poseidon_constants.py.
+ * Every unpinned choice (root of unity, coset shift, Poseidon tables, F_{p^3} modulus) is a
+ * parameter here, exactly as in the product.
+ *
+ * Call sites in the reference that this path serves: src/prover/provider.rs:358-390
+ * (GenChunkProof -> chunk STARK proofs), :422-451 (aggregation), :472-503 (final proof).
+ *
+ * Plain C11 + OpenMP.  Layout everywhere: column-major u64[W][N], canonical values < p.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+#define GL_P 0xFFFFFFFF00000001ULL
+#define GL_EPS 0xFFFFFFFFULL /* 2^64 mod p */
+
+/* ------------------------------------------------------------------ field */
+static inline u64 gl_add(u64 a, u64 b) {
+    u64 s = a + b;
+    if (s < a) s += GL_EPS; /* wrapped: +2^64 == +EPS (mod p), cannot wrap twice for a,b<p */
+    if (s >= GL_P) s -= GL_P;
+    return s;
+}
+static inline u64 gl_sub(u64 a, u64 b) {
+    u64 d = a - b;
+    if (a < b) d -= GL_EPS; /* borrowed 2^64 == EPS too much */
+    return d;
+}
+static inline u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
+static inline u64 gl_red128(u128 x) {
+    u64 lo = (u64)x, hi = (u64)(x >> 64);
+    u64 hh = hi >> 32, hl = hi & GL_EPS;
+    /* x = lo + hl*2^64 + hh*2^96 == lo + hl*EPS - hh  (2^96 == -1) */
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= GL_EPS;
+    u64 t1 = hl * GL_EPS;
+    u64 r = t0 + t1;
+    if (r < t1) r += GL_EPS;
+    if (r >= GL_P) r -= GL_P;
+    return r;
+}
+static inline u64 gl_mul(u64 a, u64 b) { return gl_red128((u128)a * b); }
+static u64 gl_pow(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = gl_mul(r, b);
+        b = gl_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+static inline u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }
+
+u64 orc_add(u64 a, u64 b) { return gl_add(a, b); }
+u64 orc_sub(u64 a, u64 b) { return gl_sub(a, b); }
+u64 orc_mul(u64 a, u64 b) { return gl_mul(a, b); }
+u64 orc_pow(u64 a, u64 e) { return gl_pow(a, e); }
+u64 orc_inv(u64 a) { return gl_inv(a); }
+
+/* root of the 2^logn subgroup derived from the configured 2^32-th root */
+u64 orc_root(u64 root32, int logn) {
+    u64 w = root32;
+    for (int i = logn; i < 32; i++) w = gl_mul(w, w);
+    return w;
+}
+
+/* ------------------------------------------------------------------ NTT (N1) */
+static inline uint32_t bitrev32(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+/* in-place, natural in -> natural out:  X[k] = sum_n x[n] w^(nk) */
+static void ntt_one(u64 *a, int logn, u64 w, const u64 *tw /* w^j, j<n/2 */) {
+    size_t n = (size_t)1 << logn;
+    (void)w;
+    for (size_t i = 0; i < n; i++) {
+        size_t j = bitrev32((uint32_t)i, logn);
+        if (i < j) { u64 t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    for (int s = 1; s <= logn; s++) {
+        size_t m = (size_t)1 << s, half = m >> 1, step = n >> s;
+        for (size_t k = 0; k < n; k += m)
+            for (size_t j = 0; j < half; j++) {
+                u64 t = gl_mul(tw[j * step], a[k + j + half]);
+                u64 u = a[k + j];
+                a[k + j] = gl_add(u, t);
+                a[k + j + half] = gl_sub(u, t);
+            }
+    }
+}
+
+static u64 *make_tw(int logn, u64 w) {
+    size_t half = logn ? ((size_t)1 << (logn - 1)) : 1;
+    u64 *tw = (u64 *)malloc(half * sizeof(u64));
+    u64 c = 1;
+    for (size_t i = 0; i < half; i++) { tw[i] = c; c = gl_mul(c, w); }
+    return tw;
+}
+
+/* cols: u64[W][N] column-major, in place */
+void orc_ntt(u64 *cols, int logn, int W, u64 root32) {
+    u64 w = orc_root(root32, logn);
+    u64 *tw = make_tw(logn, w);
+    size_t n = (size_t)1 << logn;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int c = 0; c < W; c++) ntt_one(cols + (size_t)c * n, logn, w, tw);
+    free(tw);
+}
+
+void orc_intt(u64 *cols, int logn, int W, u64 root32) {
+    u64 w = gl_inv(orc_root(root32, logn));
+    u64 *tw = make_tw(logn, w);
+    size_t n = (size_t)1 << logn;
+    u64 ninv = gl_inv((u64)n % GL_P);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int c = 0; c < W; c++) {
+        u64 *a = cols + (size_t)c * n;
+        ntt_one(a, logn, w, tw);
+        for (size_t i = 0; i < n; i++) a[i] = gl_mul(a[i], ninv);
+    }
+    free(tw);
+}
+
+/* ------------------------------------------------------------------ LDE (N2)
+ * in u64[W][N] evaluations on <w_N>;  out u64[W][bN] evaluations on shift*<w_bN>, natural order:
+ *   c = iNTT_N(in);  c_i *= shift^i;  zero-pad to bN;  out = NTT_bN(c)                         */
+void orc_lde(const u64 *in, u64 *out, int logn, int logb, int W, u64 shift, u64 root32) {
+    size_t n = (size_t)1 << logn, m = (size_t)1 << (logn + logb);
+    u64 wi = gl_inv(orc_root(root32, logn));
+    u64 wm = orc_root(root32, logn + logb);
+    u64 *twi = make_tw(logn, wi), *twm = make_tw(logn + logb, wm);
+    u64 ninv = gl_inv((u64)n % GL_P);
+    u64 *sp = (u64 *)malloc(n * sizeof(u64));
+    u64 c = ninv;
+    for (size_t i = 0; i < n; i++) { sp[i] = c; c = gl_mul(c, shift); }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int col = 0; col < W; col++) {
+        u64 *o = out + (size_t)col * m;
+        memcpy(o, in + (size_t)col * n, n * sizeof(u64));
+        ntt_one(o, logn, wi, twi);
+        for (size_t i = 0; i < n; i++) o[i] = gl_mul(o[i], sp[i]);
+        memset(o + n, 0, (m - n) * sizeof(u64));
+        ntt_one(o, logn + logb, wm, twm);
+    }
+    free(sp); free(twi); free(twm);
+}
+
+/* ------------------------------------------------------------------ Poseidon-12 (N3)
+ * width 12 (rate 8 / capacity 4), S-box x^7, RF=8 (4+4) full and RP=22 partial rounds,
+ * unoptimised textbook schedule: ARK -> S-box -> MDS per round.
+ * rc: 30*12 round constants;  mds: 12x12 row-major, out[r] = sum_j mds[r][j]*in[j].        */
+#define PW 12
+#define PRF 8
+#define PRP 22
+static inline u64 sbox7(u64 x) {
+    u64 x2 = gl_mul(x, x), x4 = gl_mul(x2, x2), x3 = gl_mul(x2, x);
+    return gl_mul(x3, x4);
+}
+static void poseidon_perm(u64 st[PW], const u64 *rc, const u64 *mds) {
+    for (int r = 0; r < PRF + PRP; r++) {
+        for (int i = 0; i < PW; i++) st[i] = gl_add(st[i], rc[r * PW + i]);
+        if (r < PRF / 2 || r >= PRF / 2 + PRP) {
+            for (int i = 0; i < PW; i++) st[i] = sbox7(st[i]);
+        } else {
+            st[0] = sbox7(st[0]);
+        }
+        u64 nx[PW];
+        for (int i = 0; i < PW; i++) {
+            u64 acc = 0;
+            for (int j = 0; j < PW; j++) acc = gl_add(acc, gl_mul(mds[i * PW + j], st[j]));
+            nx[i] = acc;
+        }
+        memcpy(st, nx, sizeof(nx));
+    }
+}
+void orc_poseidon_perm(u64 *states, size_t count, const u64 *rc, const u64 *mds) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < count; i++) poseidon_perm(states + i * PW, rc, mds);
+}
+
+/* linear hash of a row of `len` elements -> 4 elements.
+ *  len <= 4 : identity, zero-padded (no permutation)
+ *  else     : sponge, state = [rate 0..7 | capacity 8..11], capacity starts 0, each block of
+ *             up to 8 elements OVERWRITES the rate (missing tail elements = 0), permute,
+ *             the 4 outputs state[0..3] become the next block's capacity.                    */
+static void linear_hash(const u64 *row, size_t len, u64 out[4], const u64 *rc, const u64 *mds) {
+    if (len <= 4) {
+        for (size_t i = 0; i < 4; i++) out[i] = i < len ? row[i] : 0;
+        return;
+    }
+    u64 st[PW];
+    u64 cap[4] = {0, 0, 0, 0};
+    for (size_t off = 0; off < len; off += 8) {
+        for (int i = 0; i < 8; i++) st[i] = (off + i < len) ? row[off + i] : 0;
+        for (int i = 0; i < 4; i++) st[8 + i] = cap[i];
+        poseidon_perm(st, rc, mds);
+        for (int i = 0; i < 4; i++) cap[i] = st[i];
+    }
+    for (int i = 0; i < 4; i++) out[i] = cap[i];
+}
+static void hash_pair(const u64 *l, const u64 *r, u64 out[4], const u64 *rc, const u64 *mds) {
+    u64 st[PW];
+    for (int i = 0; i < 4; i++) { st[i] = l[i]; st[4 + i] = r[i]; st[8 + i] = 0; }
+    poseidon_perm(st, rc, mds);
+    for (int i = 0; i < 4; i++) out[i] = st[i];
+}
+
+/* Merkle commitment over M rows of a column-major matrix u64[W][M] (leaf i = linear hash of
+ * row i across the W columns).  tree: (2M-1)*4 u64, level 0 (M leaves) first, then M/2 ... 1;
+ * the root is the last 4 elements.  M must be a power of two.                                */
+void orc_merkle_commit(const u64 *cols, size_t M, int W, u64 *tree, const u64 *rc, const u64 *mds) {
+#pragma omp parallel
+    {
+        u64 *row = (u64 *)malloc((size_t)(W > 0 ? W : 1) * sizeof(u64));
+#pragma omp for schedule(static)
+        for (size_t i = 0; i < M; i++) {
+            for (int c = 0; c < W; c++) row[c] = cols[(size_t)c * M + i];
+            linear_hash(row, (size_t)W, tree + i * 4, rc, mds);
+        }
+        free(row);
+    }
+    u64 *prev = tree;
+    size_t cnt = M;
+    while (cnt > 1) {
+        u64 *next = prev + cnt * 4;
+        size_t half = cnt >> 1;
+#pragma omp parallel for schedule(static) if (half > 64)
+        for (size_t i = 0; i < half; i++)
+            hash_pair(prev + (2 * i) * 4, prev + (2 * i + 1) * 4, next + i * 4, rc, mds);
+        prev = next;
+        cnt = half;
+    }
+}
+
+/* leaves already given as rows of `len` contiguous elements (row-major [M][len]) */
+void orc_merkle_commit_rows(const u64 *rows, size_t M, size_t len, u64 *tree, const u64 *rc,
+                            const u64 *mds) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < M; i++) linear_hash(rows + i * len, len, tree + i * 4, rc, mds);
+    u64 *prev = tree;
+    size_t cnt = M;
+    while (cnt > 1) {
+        u64 *next = prev + cnt * 4;
+        size_t half = cnt >> 1;
+#pragma omp parallel for schedule(static) if (half > 64)
+        for (size_t i = 0; i < half; i++)
+            hash_pair(prev + (2 * i) * 4, prev + (2 * i + 1) * 4, next + i * 4, rc, mds);
+        prev = next;
+        cnt = half;
+    }
+}
+
+void orc_linear_hash(const u64 *row, size_t len, u64 *out4, const u64 *rc, const u64 *mds) {
+    linear_hash(row, len, out4, rc, mds);
+}
+
+/* authentication path of leaf idx: log2(M) siblings of 4 elements, bottom-up */
+void orc_merkle_path(const u64 *tree, size_t M, size_t idx, u64 *path) {
+    const u64 *lvl = tree;
+    size_t cnt = M;
+    int d = 0;
+    while (cnt > 1) {
+        memcpy(path + 4 * d, lvl + (idx ^ 1) * 4, 4 * sizeof(u64));
+        lvl += cnt * 4;
+        cnt >>= 1;
+        idx >>= 1;
+        d++;
+    }
+}
+
+int orc_merkle_verify(const u64 *leaf4, size_t M, size_t idx, const u64 *path, const u64 *root,
+                      const u64 *rc, const u64 *mds) {
+    u64 cur[4];
+    memcpy(cur, leaf4, sizeof(cur));
+    int d = 0;
+    for (size_t cnt = M; cnt > 1; cnt >>= 1, idx >>= 1, d++) {
+        u64 nx[4];
+        if (idx & 1) hash_pair(path + 4 * d, cur, nx, rc, mds);
+        else hash_pair(cur, path + 4 * d, nx, rc, mds);
+        memcpy(cur, nx, sizeof(cur));
+    }
+    return memcmp(cur, root, sizeof(cur)) == 0;
+}
+
+/* ------------------------------------------------------------------ F_{p^3} = F_p[x]/(x^3 - x - 1) */
+typedef struct { u64 c[3]; } e3;
+static inline e3 e3_add(e3 a, e3 b) { e3 r = {{gl_add(a.c[0], b.c[0]), gl_add(a.c[1], b.c[1]), gl_add(a.c[2], b.c[2])}}; return r; }
+static inline e3 e3_sub(e3 a, e3 b) { e3 r = {{gl_sub(a.c[0], b.c[0]), gl_sub(a.c[1], b.c[1]), gl_sub(a.c[2], b.c[2])}}; return r; }
+static inline e3 e3_mul(e3 a, e3 b) {
+    /* schoolbook, then x^3 = x + 1, x^4 = x^2 + x */
+    u64 d0 = gl_mul(a.c[0], b.c[0]);
+    u64 d1 = gl_add(gl_mul(a.c[0], b.c[1]), gl_mul(a.c[1], b.c[0]));
+    u64 d2 = gl_add(gl_add(gl_mul(a.c[0], b.c[2]), gl_mul(a.c[1], b.c[1])), gl_mul(a.c[2], b.c[0]));
+    u64 d3 = gl_add(gl_mul(a.c[1], b.c[2]), gl_mul(a.c[2], b.c[1]));
+    u64 d4 = gl_mul(a.c[2], b.c[2]);
+    e3 r = {{gl_add(d0, d3), gl_add(gl_add(d1, d3), d4), gl_add(d2, d4)}};
+    return r;
+}
+static inline e3 e3_scale(e3 a, u64 s) { e3 r = {{gl_mul(a.c[0], s), gl_mul(a.c[1], s), gl_mul(a.c[2], s)}}; return r; }
+void orc_e3_mul(const u64 *a, const u64 *b, u64 *out) {
+    e3 x = {{a[0], a[1], a[2]}}, y = {{b[0], b[1], b[2]}};
+    e3 r = e3_mul(x, y);
+    out[0] = r.c[0]; out[1] = r.c[1]; out[2] = r.c[2];
+}
+static e3 e3_pow(e3 b, const u64 e[3]) { /* exponent up to 192 bits, little-endian limbs */
+    e3 r = {{1, 0, 0}};
+    for (int l = 2; l >= 0; l--)
+        for (int i = 63; i >= 0; i--) {
+            r = e3_mul(r, r);
+            if ((e[l] >> i) & 1) r = e3_mul(r, b);
+        }
+    return r;
+}
+/* inverse via a^(p^3-2); exponent p^3-2 is passed by the caller (python big-int -> 3 limbs) */
+void orc_e3_pow(const u64 *a, const u64 *e3limbs, u64 *out) {
+    e3 x = {{a[0], a[1], a[2]}};
+    e3 r = e3_pow(x, e3limbs);
+    out[0] = r.c[0]; out[1] = r.c[1]; out[2] = r.c[2];
+}
+
+/* ------------------------------------------------------------------ FRI fold (N5)
+ * layer_in : evaluations of a polynomial f (values in F_{p^3}, stored as 3 planes u64[3][n],
+ *            plane-major) on the coset  shift*<w_n>, natural order.
+ * fold by 2^logf:  f(x) = sum_{j<2^logf} x^j g_j(x^(2^logf));  out(y) = sum_j beta^j g_j(y)
+ *            evaluated on (shift^(2^logf))*<w_{n/2^logf}>, natural order, planes u64[3][n>>logf].
+ * Computation per output index i (m = n>>logf): the 2^logf values f(shift*w_n^(i + m*k)),
+ * k<2^logf, are the evaluations of the degree<2^logf polynomial  h_i(z)=sum_j g_j(y_i) z^j  on
+ * the coset (shift*w_n^i)*<w_{2^logf}>;  interpolate (iNTT + coset unscale) then Horner at beta. */
+void orc_fri_fold(const u64 *in, u64 *out, int logn, int logf, const u64 *beta3, u64 shift,
+                  u64 root32) {
+    size_t n = (size_t)1 << logn, f = (size_t)1 << logf, m = n >> logf;
+    u64 wn = orc_root(root32, logn);
+    u64 wf_inv = gl_inv(orc_root(root32, logf));
+    u64 finv = gl_inv((u64)f);
+    e3 beta = {{beta3[0], beta3[1], beta3[2]}};
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < m; i++) {
+        e3 v[64], cof[64];
+        for (size_t k = 0; k < f; k++)
+            for (int c = 0; c < 3; c++) v[k].c[c] = in[(size_t)c * n + i + m * k];
+        /* naive inverse DFT of size f (f <= 64): cof_j = 1/f * sum_k v_k wf^(-jk) */
+        for (size_t j = 0; j < f; j++) {
+            e3 acc = {{0, 0, 0}};
+            for (size_t k = 0; k < f; k++) acc = e3_add(acc, e3_scale(v[k], gl_pow(wf_inv, (j * k) % f)));
+            cof[j] = e3_scale(acc, finv);
+        }
+        /* unscale the coset: h_i coefficient j = cof_j / (shift*w_n^i)^j */
+        u64 xi_inv = gl_inv(gl_mul(shift, gl_pow(wn, i)));
+        u64 sc = 1;
+        e3 acc = {{0, 0, 0}}, bp = {{1, 0, 0}};
+        for (size_t j = 0; j < f; j++) {
+            acc = e3_add(acc, e3_mul(e3_scale(cof[j], sc), bp));
+            sc = gl_mul(sc, xi_inv);
+            bp = e3_mul(bp, beta);
+        }
+        for (int c = 0; c < 3; c++) out[(size_t)c * m + i] = acc.c[c];
+    }
+}
+
+/* ------------------------------------------------------------------ polynomial helpers used by tests */
+/* evaluate polynomial with base-field coefficients (ascending) at base point x */
+u64 orc_poly_eval(const u64 *coef, size_t n, u64 x) {
+    u64 acc = 0;
+    for (size_t i = n; i-- > 0;) acc = gl_add(gl_mul(acc, x), coef[i]);
+    return acc;
+}
+/* evaluate polynomial with base-field coefficients at an F_{p^3} point */
+void orc_poly_eval_e3(const u64 *coef, size_t n, const u64 *x3, u64 *out3) {
+    e3 x = {{x3[0], x3[1], x3[2]}}, acc = {{0, 0, 0}};
+    for (size_t i = n; i-- > 0;) {
+        acc = e3_mul(acc, x);
+        acc.c[0] = gl_add(acc.c[0], coef[i]);
+    }
+    out3[0] = acc.c[0]; out3[1] = acc.c[1]; out3[2] = acc.c[2];
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -1,0 +1,152 @@
+"""oracle/naive.py -- pure-Python big-int definitions (TEST INFRASTRUCTURE, never product).
+
+These are the *definitions* the C restatement (gl_oracle.c) and the HIP kernels are checked
+against on small sizes: O(n^2) DFT, direct polynomial evaluation, textbook Poseidon.  They use
+only Python ints, so no shared code (and no shared bug) with either implementation.
+
+PARITY UNPINNED at the arithmetic level: the reference (eigen-zeth) holds no arithmetic for this
+path; reference call sites are src/prover/provider.rs:358-503.
+"""
+P = 0xFFFFFFFF00000001
+ROOT32_DEFAULT = 1753635133440165772   # 7^((p-1)/2^32)   (candidate 1)
+ROOT32_ALT = 7277203076849721926       # SURVEY.md 8a-N1, candidate 2
+SHIFT_DEFAULT = 49
+
+
+def root(logn, root32=ROOT32_DEFAULT):
+    return pow(root32, 1 << (32 - logn), P)
+
+
+def dft(x, w):
+    """X[k] = sum_n x[n] w^(nk)   -- O(n^2)"""
+    n = len(x)
+    pw = [pow(w, i, P) for i in range(n)]
+    return [sum(x[j] * pw[(j * k) % n] for j in range(n)) % P for k in range(n)]
+
+
+def ntt(x, root32=ROOT32_DEFAULT):
+    n = len(x)
+    logn = n.bit_length() - 1
+    return dft(x, root(logn, root32))
+
+
+def intt(x, root32=ROOT32_DEFAULT):
+    n = len(x)
+    logn = n.bit_length() - 1
+    winv = pow(root(logn, root32), P - 2, P)
+    ninv = pow(n, P - 2, P)
+    return [(v * ninv) % P for v in dft(x, winv)]
+
+
+def poly_eval(coef, x):
+    acc = 0
+    for c in reversed(coef):
+        acc = (acc * x + c) % P
+    return acc
+
+
+def lde(x, logb, shift=SHIFT_DEFAULT, root32=ROOT32_DEFAULT):
+    """evaluate the interpolant of x (on <w_n>) on the coset shift*<w_{bn}>, natural order"""
+    n = len(x)
+    coef = intt(x, root32)
+    m = n << logb
+    wm = root(m.bit_length() - 1, root32)
+    return [poly_eval(coef, shift * pow(wm, i, P) % P) for i in range(m)]
+
+
+# ---------------------------------------------------------------- Poseidon (textbook)
+def poseidon_perm(state, rc, mds):
+    """width 12, x^7, 4 full + 22 partial + 4 full;  ARK -> S-box -> MDS each round.
+    rc: flat list of 360;  mds: flat row-major 144, out[r] = sum_j mds[r*12+j]*in[j]"""
+    st = list(state)
+    for r in range(30):
+        st = [(st[i] + rc[r * 12 + i]) % P for i in range(12)]
+        if r < 4 or r >= 26:
+            st = [pow(v, 7, P) for v in st]
+        else:
+            st[0] = pow(st[0], 7, P)
+        st = [sum(mds[i * 12 + j] * st[j] for j in range(12)) % P for i in range(12)]
+    return st
+
+
+def linear_hash(row, rc, mds):
+    if len(row) <= 4:
+        return list(row) + [0] * (4 - len(row))
+    cap = [0, 0, 0, 0]
+    for off in range(0, len(row), 8):
+        blk = list(row[off:off + 8])
+        blk += [0] * (8 - len(blk))
+        st = poseidon_perm(blk + cap, rc, mds)
+        cap = st[:4]
+    return cap
+
+
+def hash_pair(l, r, rc, mds):
+    return poseidon_perm(list(l) + list(r) + [0, 0, 0, 0], rc, mds)[:4]
+
+
+def merkle_root(rows, rc, mds):
+    lvl = [linear_hash(r, rc, mds) for r in rows]
+    while len(lvl) > 1:
+        lvl = [hash_pair(lvl[2 * i], lvl[2 * i + 1], rc, mds) for i in range(len(lvl) // 2)]
+    return lvl[0]
+
+
+# ---------------------------------------------------------------- F_{p^3} = F_p[x]/(x^3 - x - 1)
+def e3_mul(a, b):
+    d = [0] * 5
+    for i in range(3):
+        for j in range(3):
+            d[i + j] += a[i] * b[j]
+    # x^3 = x + 1 ; x^4 = x^2 + x
+    return [(d[0] + d[3]) % P, (d[1] + d[3] + d[4]) % P, (d[2] + d[4]) % P]
+
+
+def e3_add(a, b):
+    return [(a[i] + b[i]) % P for i in range(3)]
+
+
+def e3_pow(a, e):
+    r = [1, 0, 0]
+    while e:
+        if e & 1:
+            r = e3_mul(r, a)
+        a = e3_mul(a, a)
+        e >>= 1
+    return r
+
+
+def e3_inv(a):
+    return e3_pow(a, P ** 3 - 2)
+
+
+def poly_eval_e3(coef3, x):
+    """coef3: list of F_{p^3} coefficients (ascending); x base-field or ext point (as 3-list)"""
+    acc = [0, 0, 0]
+    for c in reversed(coef3):
+        acc = e3_add(e3_mul(acc, x), c)
+    return acc
+
+
+def fri_fold(vals3, logf, beta, shift=SHIFT_DEFAULT, root32=ROOT32_DEFAULT):
+    """vals3: list of n ext values = f on shift*<w_n> natural order.  Returns n>>logf ext values of
+    sum_j beta^j g_j(y) on shift^(2^logf)*<w_{n>>logf}>, where f(x)=sum_j x^j g_j(x^(2^logf)).
+    Definition-level: interpolate f (ext coefficients), split, re-evaluate."""
+    n = len(vals3)
+    logn = n.bit_length() - 1
+    f = 1 << logf
+    m = n >> logf
+    # interpolate: coefficients of f(shift*X) via inverse DFT per component, then unscale
+    planes = [intt([v[c] for v in vals3], root32) for c in range(3)]
+    sinv = pow(shift, P - 2, P)
+    coef = [[planes[c][i] * pow(sinv, i, P) % P for c in range(3)] for i in range(n)]
+    # g_j coefficients: coef[j + f*t]
+    bp = [1, 0, 0]
+    folded = [[0, 0, 0] for _ in range(m)]
+    for j in range(f):
+        for t in range(m):
+            folded[t] = e3_add(folded[t], e3_mul(coef[j + f * t], bp))
+        bp = e3_mul(bp, beta)
+    wm = root(logn - logf, root32) if logn - logf > 0 else 1
+    s2 = pow(shift, f, P)
+    return [poly_eval_e3(folded, [s2 * pow(wm, i, P) % P, 0, 0]) for i in range(m)]

@@ -1,0 +1,202 @@
+"""oracle/oracle.py -- ctypes binding of the CPU restatement (TEST INFRASTRUCTURE ONLY).
+
+Importers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.  The product
+package (eigen_zeth_amd) must never import this module.  PARITY UNPINNED -- see gl_oracle.c.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+
+P = 0xFFFFFFFF00000001
+ROOT32_DEFAULT = 1753635133440165772
+ROOT32_ALT = 7277203076849721926
+SHIFT_DEFAULT = 49
+
+_u64p = C.POINTER(C.c_uint64)
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
+            os.path.join(_HERE, "gl_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        u64, i32, sz = C.c_uint64, C.c_int, C.c_size_t
+        for name in ("orc_add", "orc_sub", "orc_mul", "orc_pow"):
+            getattr(L, name).restype = u64
+            getattr(L, name).argtypes = [u64, u64]
+        L.orc_inv.restype = u64
+        L.orc_inv.argtypes = [u64]
+        L.orc_root.restype = u64
+        L.orc_root.argtypes = [u64, i32]
+        L.orc_ntt.argtypes = [_u64p, i32, i32, u64]
+        L.orc_intt.argtypes = [_u64p, i32, i32, u64]
+        L.orc_lde.argtypes = [_u64p, _u64p, i32, i32, i32, u64, u64]
+        L.orc_poseidon_perm.argtypes = [_u64p, sz, _u64p, _u64p]
+        L.orc_merkle_commit.argtypes = [_u64p, sz, i32, _u64p, _u64p, _u64p]
+        L.orc_merkle_commit_rows.argtypes = [_u64p, sz, sz, _u64p, _u64p, _u64p]
+        L.orc_linear_hash.argtypes = [_u64p, sz, _u64p, _u64p, _u64p]
+        L.orc_merkle_path.argtypes = [_u64p, sz, sz, _u64p]
+        L.orc_merkle_verify.restype = i32
+        L.orc_merkle_verify.argtypes = [_u64p, sz, sz, _u64p, _u64p, _u64p, _u64p]
+        L.orc_e3_mul.argtypes = [_u64p, _u64p, _u64p]
+        L.orc_e3_pow.argtypes = [_u64p, _u64p, _u64p]
+        L.orc_fri_fold.argtypes = [_u64p, _u64p, i32, i32, _u64p, u64, u64]
+        L.orc_poly_eval.restype = u64
+        L.orc_poly_eval.argtypes = [_u64p, sz, u64]
+        L.orc_poly_eval_e3.argtypes = [_u64p, sz, _u64p, _u64p]
+        L.orc_num_threads.restype = i32
+        L.orc_set_threads.argtypes = [i32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_u64p)
+
+
+def _arr(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+
+
+def ntt(cols, root32=ROOT32_DEFAULT):
+    """cols: uint64 [W][N] -> new array, natural in / natural out"""
+    a = _arr(cols).copy()
+    W, N = a.shape
+    lib().orc_ntt(_p(a), N.bit_length() - 1, W, root32)
+    return a
+
+
+def intt(cols, root32=ROOT32_DEFAULT):
+    a = _arr(cols).copy()
+    W, N = a.shape
+    lib().orc_intt(_p(a), N.bit_length() - 1, W, root32)
+    return a
+
+
+def lde(cols, logb, shift=SHIFT_DEFAULT, root32=ROOT32_DEFAULT):
+    a = _arr(cols)
+    W, N = a.shape
+    out = np.empty((W, N << logb), dtype=np.uint64)
+    lib().orc_lde(_p(a), _p(out), N.bit_length() - 1, logb, W, shift, root32)
+    return out
+
+
+def poseidon_perm(states, rc, mds):
+    """states: uint64 [B][12] -> permuted copy"""
+    s = _arr(states).copy()
+    rc = _arr(rc)
+    mds = _arr(mds)
+    lib().orc_poseidon_perm(_p(s), s.shape[0], _p(rc), _p(mds))
+    return s
+
+
+def merkle_commit(cols, rc, mds):
+    """cols: uint64 [W][M] -> tree uint64 [(2M-1)][4] (leaves first, root last)"""
+    a = _arr(cols)
+    W, M = a.shape
+    tree = np.empty((2 * M - 1, 4), dtype=np.uint64)
+    lib().orc_merkle_commit(_p(a), M, W, _p(tree), _p(_arr(rc)), _p(_arr(mds)))
+    return tree
+
+
+def merkle_commit_rows(rows, rc, mds):
+    a = _arr(rows)
+    M, ln = a.shape
+    tree = np.empty((2 * M - 1, 4), dtype=np.uint64)
+    lib().orc_merkle_commit_rows(_p(a), M, ln, _p(tree), _p(_arr(rc)), _p(_arr(mds)))
+    return tree
+
+
+def linear_hash(row, rc, mds):
+    r = _arr(row)
+    out = np.empty(4, dtype=np.uint64)
+    lib().orc_linear_hash(_p(r), r.shape[0], _p(out), _p(_arr(rc)), _p(_arr(mds)))
+    return out
+
+
+def merkle_path(tree, idx):
+    t = _arr(tree)
+    M = (t.shape[0] + 1) // 2
+    depth = M.bit_length() - 1
+    path = np.empty((max(depth, 1), 4), dtype=np.uint64)
+    lib().orc_merkle_path(_p(t), M, idx, _p(path))
+    return path[:depth]
+
+
+def merkle_verify(leaf4, M, idx, path, root, rc, mds):
+    pth = _arr(path) if len(path) else np.zeros((1, 4), dtype=np.uint64)
+    return bool(lib().orc_merkle_verify(_p(_arr(leaf4)), M, idx, _p(pth), _p(_arr(root)),
+                                        _p(_arr(rc)), _p(_arr(mds))))
+
+
+def e3_mul(a, b):
+    out = np.empty(3, dtype=np.uint64)
+    lib().orc_e3_mul(_p(_arr(a)), _p(_arr(b)), _p(out))
+    return out
+
+
+def e3_inv(a):
+    e = P ** 3 - 2
+    limbs = np.array([(e >> (64 * i)) & (2 ** 64 - 1) for i in range(3)], dtype=np.uint64)
+    out = np.empty(3, dtype=np.uint64)
+    lib().orc_e3_pow(_p(_arr(a)), _p(limbs), _p(out))
+    return out
+
+
+def fri_fold(planes, logf, beta, shift=SHIFT_DEFAULT, root32=ROOT32_DEFAULT):
+    """planes: uint64 [3][n] -> uint64 [3][n >> logf]"""
+    a = _arr(planes)
+    n = a.shape[1]
+    out = np.empty((3, n >> logf), dtype=np.uint64)
+    lib().orc_fri_fold(_p(a), _p(out), n.bit_length() - 1, logf, _p(_arr(beta)), shift, root32)
+    return out
+
+
+def poly_eval(coef, x):
+    c = _arr(coef)
+    return int(lib().orc_poly_eval(_p(c), c.shape[0], x))
+
+
+def poly_eval_e3(coef, x3):
+    c = _arr(coef)
+    out = np.empty(3, dtype=np.uint64)
+    lib().orc_poly_eval_e3(_p(c), c.shape[0], _p(_arr(x3)), _p(out))
+    return out
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def random_field(shape, seed):
+    """uniform in [0,p) by rejection, PCG64(seed)  (SURVEY.md 8d synthetic inputs)"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    a = rng.integers(0, 2 ** 64, size=shape, dtype=np.uint64, endpoint=False)
+    bad = a >= np.uint64(P)
+    while bad.any():
+        a[bad] = rng.integers(0, 2 ** 64, size=int(bad.sum()), dtype=np.uint64, endpoint=False)
+        bad = a >= np.uint64(P)
+    return a

@@ -1,0 +1,117 @@
+"""CPU tests: the C restatement (oracle/) against the definition-level golden vectors.
+
+Parity with the external reference prover is UNPINNED: the reference holds no
+arithmetic, no golden vector and no test for this path, so the oracle is pinned by identities and
+definition-level vectors only."""
+import numpy as np
+
+from oracle import oracle as O
+
+P = O.P
+
+
+def u(a):
+    return np.array(a, dtype=np.uint64)
+
+
+def test_field_edge_cases():
+    L = O.lib()
+    vals = [0, 1, 2, P - 1, P - 2, 2 ** 32, 2 ** 32 - 1, 2 ** 32 + 1, P - 2 ** 32, 2 ** 63, 2 ** 63 + 1]
+    for a in vals:
+        for b in vals:
+            assert L.orc_mul(a, b) == a * b % P
+            assert L.orc_add(a, b) == (a + b) % P
+            assert L.orc_sub(a, b) == (a - b) % P
+    for a in vals[1:]:
+        assert L.orc_mul(a, L.orc_inv(a)) == 1
+    assert L.orc_pow(7, P - 1) == 1
+
+
+def test_roots():
+    for r32 in (O.ROOT32_DEFAULT, O.ROOT32_ALT):
+        assert pow(r32, 2 ** 31, P) == P - 1
+        for logn in (0, 1, 5, 20, 32):
+            w = O.lib().orc_root(r32, logn)
+            assert pow(w, 1 << logn, P) == 1
+            if logn:
+                assert pow(w, 1 << (logn - 1), P) == P - 1
+    assert pow(7, (P - 1) >> 32, P) == O.ROOT32_DEFAULT
+    assert pow(O.SHIFT_DEFAULT, 2 ** 32, P) != 1  # 49 is outside the 2-adic subgroup
+
+
+def test_ntt_golden(golden):
+    for case in golden["ntt"]:
+        x = u([case["x"]])
+        got = O.ntt(x, case["root32"])
+        assert got[0].tolist() == case["X"], (case["logn"], case["root32"])
+        assert (O.intt(got, case["root32"]) == x).all()
+
+
+def test_lde_golden(golden):
+    for case in golden["lde"]:
+        got = O.lde(u([case["x"]]), case["logb"], case["shift"])
+        assert got[0].tolist() == case["y"], (case["logn"], case["logb"])
+
+
+def test_lde_restricts_to_input():
+    # every b-th point of the coset LDE with shift=1 is the original evaluation
+    x = O.random_field((3, 64), 11)
+    y = O.lde(x, 2, shift=1)
+    assert (y[:, ::4] == x).all()
+
+
+def test_poseidon_golden(golden, tables):
+    rc, mds = tables
+    for case in golden["poseidon_perm"]:
+        assert O.poseidon_perm(u([case["in"]]), rc, mds)[0].tolist() == case["out"]
+    for case in golden["linear_hash"]:
+        assert O.linear_hash(u(case["row"]), rc, mds).tolist() == case["hash"]
+
+
+def test_merkle_golden(golden, tables):
+    rc, mds = tables
+    for case in golden["merkle"]:
+        rows = u(case["rows"])
+        tree = O.merkle_commit(np.ascontiguousarray(rows.T), rc, mds)
+        assert tree[-1].tolist() == case["root"]
+        tree2 = O.merkle_commit_rows(rows, rc, mds)
+        assert (tree2 == tree).all()
+        M = case["M"]
+        for idx in range(M):
+            path = O.merkle_path(tree, idx)
+            assert O.merkle_verify(tree[idx], M, idx, path, tree[-1], rc, mds)
+            if M > 1:
+                assert not O.merkle_verify(tree[idx ^ 1] if M > 1 else tree[idx], M, idx, path, tree[-1], rc, mds) \
+                    or (tree[idx ^ 1] == tree[idx]).all()
+
+
+def test_fri_fold_golden(golden):
+    for case in golden["fri_fold"]:
+        planes = np.ascontiguousarray(u(case["vals"]).T)
+        got = O.fri_fold(planes, case["logf"], case["beta"], case["shift"])
+        assert np.ascontiguousarray(got.T).tolist() == case["out"], (case["logn"], case["logf"])
+
+
+def test_fri_fold_composes():
+    # folding by 4 with beta equals folding by 2 with beta then by 2 with beta^2
+    pl = O.random_field((3, 64), 5)
+    beta = [3, 1, 4]
+    b2 = O.e3_mul(beta, beta)
+    one = O.fri_fold(pl, 2, beta, 49)
+    two = O.fri_fold(O.fri_fold(pl, 1, beta, 49), 1, b2, pow(49, 2, P))
+    assert (one == two).all()
+
+
+def test_e3_golden(golden):
+    for case in golden["e3"]:
+        assert O.e3_mul(case["a"], case["b"]).tolist() == case["ab"]
+        assert O.e3_inv(case["a"]).tolist() == case["ainv"]
+
+
+def test_ntt_linearity_and_large_roundtrip():
+    a = O.random_field((2, 1 << 16), 21)
+    fa = O.ntt(a)
+    assert (O.intt(fa) == a).all()
+    s = ((a[0].astype(object) + a[1].astype(object)) % P).astype(np.uint64)
+    fs = O.ntt(s[None, :])
+    assert (fs[0].astype(object) == (fa[0].astype(object) + fa[1].astype(object)) % P).all()
