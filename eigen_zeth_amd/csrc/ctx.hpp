@@ -28,6 +28,7 @@ struct NttPlan {
     u64 *d_tws = nullptr;     // w_4096^e (direction matched), 4096 entries
     u64 w16[8];               // w_16^i (direction matched)
     u64 ninv = 1;
+    int j0inv = 0;            // w_16 = (2^12)^j0 ; j0inv = j0^-1 mod 16 (0: not on the power-of-two path)
 };
 
 struct CosetTable {  // shift^i * pre, i < 2^logn, two-level
@@ -56,6 +57,8 @@ struct zp_ctx {
     size_t scratch_elems[4] = {0, 0, 0, 0};
     // misc small device buffer for parameters
     int num_cu = 256;
+    // experiment knobs (zp_set_tuning): not part of the stable surface
+    int tune_diag = 0, tune_logt = 5, tune_v2 = 2, tune_tpw = 4;
     // per-launch event profiling (zp_set_profiling)
     bool profiling = false;
     struct PassEv { hipEvent_t a, b; int radix_log; };

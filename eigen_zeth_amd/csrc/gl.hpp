@@ -22,36 +22,72 @@ GL_HD u64 gl_canon(u64 s) {  // s in [0,2^64) -> s mod p   (s >= p  <=>  s + EPS
     u64 t = s + GL_EPS;
     return t < s ? t : s;
 }
-GL_HD u64 gl_add(u64 a, u64 b) {  // canonical in, canonical out
-    u64 s = a + b;
-    if (s < a) s += GL_EPS;
-    return gl_canon(s);
+GL_HD u64 gl_add(u64 a, u64 b) {  // canonical in, canonical out (6 VALU on gfx950)
+    u64 s = a + b, u = s + GL_EPS;    // u = s - p (mod 2^64)
+    return ((s < a) | (u < s)) ? u : s;
 }
 GL_HD u64 gl_sub(u64 a, u64 b) {
-    u64 d = a - b;
-    if (a < b) d -= GL_EPS;
-    return d;
+    u64 d = a - b, w = d + GL_P;
+    return (a < b) ? w : d;
 }
 GL_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 
-// x = c0 + c1*2^32 + c2*2^64 + c3*2^96  ==  (c0 + c1*2^32) + c2*EPS - c3
-GL_HD u64 gl_reduce_limbs(u32 c0, u32 c1, u32 c2, u32 c3) {
-    u64 lo = ((u64)c1 << 32) | c0;
-    u64 t0 = lo - c3;
-    if (lo < (u64)c3) t0 -= GL_EPS;
-    u64 t1 = ((u64)c2 << 32) - c2;  // c2 * EPS
-    u64 r = t0 + t1;
-    if (r < t1) r += GL_EPS;
-    return gl_canon(r);
+// lo + hl*2^64 + hh*2^96  ==  lo + hl*EPS - hh   (any lo, hl, hh) -> canonical.
+// One v_mad_u64_u32 forms lo + hl*EPS; the carry (+2^64) and the borrow of "- hh" (-2^64) are
+// folded with a single 3-way correction (k = carry - borrow in {-1,0,1}).
+GL_HD u64 gl_reduce96(u64 lo, u32 hl, u32 hh) {
+    u64 r = (u64)hl * 0xFFFFFFFFu + lo;
+    bool c2 = r < lo;
+    u64 r2 = r - hh;
+    bool bb = r < (u64)hh;
+    u64 u = r2 + GL_EPS;
+    bool c3 = u < r2;
+    u64 w = r2 + GL_P;
+    bool cw = bb & !c2;
+    bool cu = (c2 & !bb) | ((bb == c2) & c3);
+    u64 t = cu ? u : r2;
+    return cw ? w : t;
 }
+// x = c0 + c1*2^32 + c2*2^64 + c3*2^96
+GL_HD u64 gl_reduce_limbs(u32 c0, u32 c1, u32 c2, u32 c3) { return gl_reduce96(((u64)c1 << 32) | c0, c2, c3); }
 
-GL_HD u64 gl_mul(u64 a, u64 b) {
+GL_HD u64 gl_mul(u64 a, u64 b) {  // any u64 inputs, canonical output
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0;
     u64 p01 = (u64)a0 * b1 + (p00 >> 32);
     u64 p10 = (u64)a1 * b0 + (u32)p01;
     u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
-    return gl_reduce_limbs((u32)p00, (u32)p10, (u32)p11, (u32)(p11 >> 32));
+    return gl_reduce96(((u64)(u32)p10 << 32) | (u32)p00, (u32)p11, (u32)(p11 >> 32));
+}
+
+// x * 2^S mod p for a compile-time 0 < S < 96 (2 is a 192-th root of unity: 2^96 == -1, so every
+// 64-th root of unity is a power of 8 and radix-16 butterflies need shifts only).  x canonical.
+template <int S>
+GL_HD u64 gl_mul_pow2(u64 x) {
+    static_assert(S > 0 && S < 96, "shift out of range");
+    constexpr int q = S / 32, r = S % 32;
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+    u32 y0, y1, y2;
+    if (r == 0) {
+        y0 = x0; y1 = x1; y2 = 0;
+    } else {
+        y0 = x0 << r;
+        y1 = (u32)(x >> (32 - r));
+        y2 = x1 >> (32 - r);
+    }
+    if (q == 0) {  // (y1:y0) + y2*EPS
+        const u64 lo = ((u64)y1 << 32) | y0;
+        const u64 t = (u64)y2 * 0xFFFFFFFFu + lo;
+        const u64 u = t + GL_EPS;
+        return ((t < lo) | (u < t)) ? u : t;
+    } else if (q == 1) {  // (y0:0) + y1*EPS - y2
+        return gl_reduce96((u64)y0 << 32, y1, y2);
+    } else {  // y0*EPS - (y2:y1)      [2^128 == -2^32]
+        const u64 t = (u64)y0 * 0xFFFFFFFFu;
+        const u64 m = ((u64)y2 << 32) | y1;
+        const u64 d = t - m, w = d + GL_P;
+        return (t < m) ? w : d;
+    }
 }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 

@@ -33,6 +33,7 @@ struct PassArgs {
     u64 w16[8];
     u64 scale;
     int logn, logPprev, lb, cslb;
+    int j0inv;  // w_16(user) = (2^12)^j0, j0inv = j0^-1 mod 16; 0 = root not a power of two path (generic twiddles)
     int flags;  // 1: inter-pass twiddle  2: multiply by `scale`  4: coset post-scale
 };
 
@@ -101,7 +102,7 @@ __device__ __forceinline__ u64 tw_lookup(const u64 *lo, const u64 *hi, int lb, u
 }
 
 // one LDS-exchanged round: registers -> (twiddle) -> LDS -> barrier -> registers of the next round
-template <typename G, int A, int POS, int ANEXT, int POSNEXT>
+template <typename G, int A, int POS, int ANEXT, int POSNEXT, int DIAG>
 __device__ __forceinline__ void exchange(u64 *v, u64 *lds, const PassArgs &a, int tid) {
     constexpr int GR = 16 >> A;
 #pragma unroll
@@ -114,7 +115,7 @@ __device__ __forceinline__ void exchange(u64 *v, u64 *lds, const PassArgs &a, in
             const int kj = brev(p, A);
             u64 x = v[g * (1 << A) + p];
             // w_(2^(POS+A))^(kj*rho) = w_4096^(kj*rho*2^(12-POS-A))
-            if (kj != 0) x = gl_mul(x, a.tws[(kj * rho) << (12 - POS - A)]);
+            if (kj != 0 && DIAG != 1) x = gl_mul(x, a.tws[(kj * rho) << (12 - POS - A)]);
             lds[G::lpos(slot_of(o, kj, POS, A), t)] = x;
         }
     }
@@ -130,7 +131,7 @@ __device__ __forceinline__ void exchange(u64 *v, u64 *lds, const PassArgs &a, in
     }
 }
 
-template <int A1, int A2, int A3, int LOGT, bool TRANSPOSE>
+template <int A1, int A2, int A3, int LOGT, bool TRANSPOSE, int DIAG>
 __global__ void __launch_bounds__((1 << (A1 + A2 + A3 + LOGT)) / 16)
 ntt_pass_kernel(PassArgs a) {
     using G = Geo<A1, A2, A3, LOGT>;
@@ -154,21 +155,25 @@ ntt_pass_kernel(PassArgs a) {
 #pragma unroll
             for (int j = 0; j < (1 << A1); j++) {
                 const u64 idx = ((u64)slot_of(o, j, G::POS1, A1) << logNR) + u0 + t;
-                v[g * (1 << A1) + j] = idx < a.in_valid ? src[idx] : 0ULL;
+                if constexpr (DIAG == 2) v[g * (1 << A1) + j] = idx * 0x9E3779B97F4A7C15ULL >> 1;
+                else v[g * (1 << A1) + j] = idx < a.in_valid ? src[idx] : 0ULL;
             }
         }
+        if constexpr (DIAG != 1)
 #pragma unroll
-        for (int g = 0; g < GR; g++) dif<A1>(v + g * (1 << A1), a.w16);
+            for (int g = 0; g < GR; g++) dif<A1>(v + g * (1 << A1), a.w16);
     }
     if constexpr (G::J >= 2) {
-        exchange<G, A1, G::POS1, A2, G::POS2>(v, lds, a, tid);
+        exchange<G, A1, G::POS1, A2, G::POS2, DIAG>(v, lds, a, tid);
+        if constexpr (DIAG != 1)
 #pragma unroll
-        for (int g = 0; g < (16 >> A2); g++) dif<A2>(v + g * (1 << A2), a.w16);
+            for (int g = 0; g < (16 >> A2); g++) dif<A2>(v + g * (1 << A2), a.w16);
     }
     if constexpr (G::J >= 3) {
-        exchange<G, A2, G::POS2, A3, 0>(v, lds, a, tid);
+        exchange<G, A2, G::POS2, A3, 0, DIAG>(v, lds, a, tid);
+        if constexpr (DIAG != 1)
 #pragma unroll
-        for (int g = 0; g < (16 >> A3); g++) dif<A3>(v + g * (1 << A3), a.w16);
+            for (int g = 0; g < (16 >> A3); g++) dif<A3>(v + g * (1 << A3), a.w16);
     }
 
     // ---- output: the last round's field sits at bit 0 of the slot
@@ -183,7 +188,7 @@ ntt_pass_kernel(PassArgs a) {
         const u64 s = TRANSPOSE ? u : (u0 >> logP);
         const u64 e0 = TRANSPOSE ? u : (s << logP);
         u64 w = 1, wstep = 1;
-        if (a.flags & 1) {
+        if ((a.flags & 1) && DIAG != 1) {
             w = tw_lookup(a.twl, a.twh, a.lb, e0 * (u64)klow);
             wstep = tw_lookup(a.twl, a.twh, a.lb, e0 << (L - AJ));
         }
@@ -201,7 +206,7 @@ ntt_pass_kernel(PassArgs a) {
         for (int kj = 0; kj < (1 << AJ); kj++) {
             const int p = brev(kj, AJ);
             u64 x = v[g * (1 << AJ) + p];
-            if (a.flags & 7) {
+            if ((a.flags & 7) && DIAG != 1) {
                 x = gl_mul(x, w);
                 if (a.flags & 5) w = gl_mul(w, wstep);
             }
@@ -209,7 +214,7 @@ ntt_pass_kernel(PassArgs a) {
             if constexpr (TRANSPOSE) {
                 lds[G::lpos(slot_of(o, kj, 0, AJ), t)] = x;
             } else {
-                dst[obase + ((u64)k << logP)] = x;
+                if (DIAG != 2 || (a.flags & 256)) dst[obase + ((u64)k << logP)] = x;
             }
         }
     }
@@ -221,7 +226,252 @@ ntt_pass_kernel(PassArgs a) {
         for (int i = 0; i < 16; i++) {
             const int idx = i * NT + tid;
             const int t2 = idx >> L, k = idx & ((1 << L) - 1);
-            blk[idx] = lds[(G::sigma_of_k(k) << LOGT) + (t2 ^ (k & (T - 1)))];
+            if (DIAG != 2 || (a.flags & 256)) blk[idx] = lds[(G::sigma_of_k(k) << LOGT) + (t2 ^ (k & (T - 1)))];
+        }
+    }
+}
+
+
+// radix-2^A DIF with the canonical root c = 2^12 (order 16): every twiddle is a shift.
+// v[p] receives DFT_c[brev(p)];  the caller maps that to the user's root, w_16 = c^j0:
+// DFT_user[k'] = DFT_c[j0*k' mod 2^A]  =>  register p holds user index  k' = j0inv*brev(p) mod 2^A.
+template <int E>
+__device__ __forceinline__ u64 mul_c16(u64 d) {
+    if constexpr (E == 0) return d;
+    else return gl_mul_pow2<12 * E>(d);
+}
+template <int A, int S = 0, int B = 0, int I = 0>
+__device__ __forceinline__ void dif_shift(u64 *v) {
+    if constexpr (S < A) {
+        constexpr int half = 1 << (A - 1 - S);
+        if constexpr (B < (1 << A)) {
+            if constexpr (I < half) {
+                u64 x = v[B + I], y = v[B + I + half];
+                v[B + I] = gl_add(x, y);
+                v[B + I + half] = mul_c16<I * (8 / half)>(gl_sub(x, y));
+                dif_shift<A, S, B, I + 1>(v);
+            } else {
+                dif_shift<A, S, B + 2 * half, 0>(v);
+            }
+        } else {
+            dif_shift<A, S + 1, 0, 0>(v);
+        }
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain vmcnt, so
+// the next tile's global loads (and the previous tile's stores) stay in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <typename G, int A, int POS, int ANEXT, int POSNEXT>
+__device__ __forceinline__ void exchange2(u64 *v, u64 *lds, const u64 *twr, int j0inv, int tid) {
+    constexpr int GR = 16 >> A;
+#pragma unroll
+    for (int g = 0; g < GR; g++) {
+        const int gamma = g * G::NT + tid;
+        const int t = gamma & (G::T - 1), o = gamma >> G::LT;
+        const int rho = o & ((1 << POS) - 1);
+#pragma unroll
+        for (int p = 0; p < (1 << A); p++) {
+            const int kj = (j0inv * brev(p, A)) & ((1 << A) - 1);  // wave-uniform
+            u64 x = v[g * (1 << A) + p];
+            if (p != 0) x = gl_mul(x, twr[kj * rho]);  // w_(2^(POS+A))^(kj*rho), LDS copy
+            lds[G::lpos(slot_of(o, kj, POS, A), t)] = x;
+        }
+    }
+    lds_barrier();
+    constexpr int GN = 16 >> ANEXT;
+#pragma unroll
+    for (int g = 0; g < GN; g++) {
+        const int gamma = g * G::NT + tid;
+        const int t = gamma & (G::T - 1), o = gamma >> G::LT;
+#pragma unroll
+        for (int j = 0; j < (1 << ANEXT); j++)
+            v[g * (1 << ANEXT) + j] = lds[G::lpos(slot_of(o, j, POSNEXT, ANEXT), t)];
+    }
+}
+
+// Pass kernel, second generation.
+//  * A workgroup walks `tiles_per_wg` consecutive tiles of one column.  ALL vector global loads of
+//    tile i+1 (16 data elements per lane + the few twiddle-table entries it needs) are issued at the
+//    top of iteration i and consumed in iteration i+1; the body of an iteration touches only
+//    registers and LDS, and barriers order LDS only.  vmcnt is an in-order counter, so this is what
+//    keeps HBM loads (and the previous tile's stores) in flight under the integer work.
+//  * butterflies use the canonical 16-th root 2^12 (shifts only); the user's root enters through
+//    j0inv as a renaming of outputs.
+//  * TRANSPOSE=false (passes 2..m, Pprev >= T): the tile shares s; the inter-pass twiddle w^(e0*k)
+//    (times 1/N and the k-part of a coset power on a last pass) is a per-tile table of R entries in
+//    LDS -> one multiplication per element.
+//  * TRANSPOSE=true (pass 1, Pprev = 1): s = u varies with the lane; w^(u*k) is a per-lane geometric
+//    chain walked in the order the shift butterflies deliver outputs: k_j = jr*i mod 2^A, so
+//    h^(k_j) = (h^jr)^i * (h^-(2^A))^floor(jr*i/2^A).
+// MODE (non-transposing passes): 0 = plain last pass, 1 = multiply by the per-tile table,
+// 2 = table and the per-lane part of a coset power (last pass of the inverse transform in an LDE)
+template <int A1, int A2, int A3, int LOGT, bool TRANSPOSE, bool PADDED, int MODE>
+__global__ void __launch_bounds__((1 << (A1 + A2 + A3 + LOGT)) / 16)
+ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
+    using G = Geo<A1, A2, A3, LOGT>;
+    constexpr int L = G::L, R = G::R, T = G::T, NT = G::NT, AJ = G::AJ;
+    constexpr int GRJ = 16 >> AJ;
+    constexpr int R2 = 1 << (A2 + A3);
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    u64 *tab = lds + R * T;   // R entries: per-tile inter-pass twiddles
+    u64 *twr1 = tab + R;      // R entries:  w_R^e      (inter-round twiddles, first exchange)
+    u64 *twr2 = twr1 + R;     // R2 entries: w_(R2)^e   (second exchange, 3-round passes)
+    const u64 col = blockIdx.y;
+    const int logNR = a.logn - L;
+    const int logP = a.logPprev;
+    const u64 N = 1ULL << a.logn;
+    const u64 *src = a.in + col * a.in_cs;
+    u64 *dst = a.out + col * a.out_cs;
+    u64 v[16], vn[16];
+    // twiddle-table entries fetched one tile ahead (raw lo/hi halves)
+    constexpr int NTW = TRANSPOSE ? (GRJ + 2) : (MODE == 2 ? 2 : 1);
+    u64 twl_c[NTW], twh_c[NTW], twl_n[NTW], twh_n[NTW];
+
+    auto fetch_tile = [&](u64 *r, u64 *tl, u64 *th, u64 u0, int tid) {
+        constexpr int GR = 16 >> A1;
+#pragma unroll
+        for (int g = 0; g < GR; g++) {
+            const int gamma = g * NT + tid;
+            const int t = gamma & (T - 1), o = gamma >> LOGT;
+#pragma unroll
+            for (int j = 0; j < (1 << A1); j++) {
+                const u64 idx = ((u64)slot_of(o, j, G::POS1, A1) << logNR) + u0 + t;
+                if constexpr (PADDED) r[g * (1 << A1) + j] = idx < a.in_valid ? src[idx] : 0ULL;
+                else r[g * (1 << A1) + j] = src[idx];
+            }
+        }
+        const u64 lm = (1ULL << a.lb) - 1;
+        if constexpr (TRANSPOSE) {
+            const int t = tid & (T - 1);
+            const u64 u = u0 + t;
+            const int jr = a.j0inv & ((1 << AJ) - 1);
+            u64 e[NTW];
+#pragma unroll
+            for (int g = 0; g < GRJ; g++) e[g] = u * (u64)G::kof(((g * NT + tid) >> LOGT) << AJ);   // w^(u*klow_g)
+            e[GRJ] = ((u << (L - AJ)) * (u64)jr) & (N - 1);                                       // h^jr
+            e[GRJ + 1] = (N - ((u << L) & (N - 1))) & (N - 1);                                    // h^-(2^AJ) = w^-(u*R)
+#pragma unroll
+            for (int i = 0; i < NTW; i++) { tl[i] = a.twl[e[i] & lm]; th[i] = a.twh[e[i] >> a.lb]; }
+        } else {
+            if constexpr (MODE >= 1) {
+                const u64 e0 = (u0 >> logP) << logP;
+                const u64 e = (a.flags & 1) ? e0 * (u64)(tid & (R - 1)) : 0;  // entry k = tid (tid < R used)
+                tl[0] = a.twl[e & lm];
+                th[0] = a.twh[e >> a.lb];
+            }
+            if constexpr (MODE == 2) {
+                const u64 c = (u0 + (tid & (T - 1))) & ((1ULL << logP) - 1);
+                tl[1] = a.csl[c & ((1ULL << a.cslb) - 1)];
+                th[1] = a.csh[c >> a.cslb];
+            }
+        }
+    };
+
+    const u64 tile0 = (u64)blockIdx.x * tiles_per_wg;
+    fetch_tile(v, twl_c, twh_c, tile0 << LOGT, threadIdx.x);
+    // once per workgroup: inter-round twiddles into LDS, tile-independent factors into registers
+    u64 kfac = 1;
+    {
+        const int tid0 = threadIdx.x;
+        if (tid0 < R) twr1[tid0] = a.tws[tid0 << (12 - L)];
+        if constexpr (G::J >= 3) {
+            if (tid0 < R2) twr2[tid0] = a.tws[tid0 << (12 - (A2 + A3))];
+        }
+        if constexpr (!TRANSPOSE && MODE >= 1) {
+            if (a.flags & 2) kfac = a.scale;
+            if constexpr (MODE == 2) {
+                const u64 ek = (u64)(tid0 & (R - 1)) << logP;
+                kfac = gl_mul(kfac, gl_mul(a.csl[ek & ((1ULL << a.cslb) - 1)], a.csh[ek >> a.cslb]));
+            }
+        }
+    }
+    lds_barrier();  // twr1/twr2 are read by other lanes before the first exchange barrier
+    // drain the prologue loads here so that the loop is entered with nothing pending: the waitcnt
+    // insertion then needs no vmcnt wait inside the body (one there would also drain the prefetch)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+#pragma clang loop unroll(disable)
+    for (int it = 0; it < tiles_per_wg; it++) {
+        const u64 u0 = (tile0 + it) << LOGT;
+        const bool more = it + 1 < tiles_per_wg;
+        // opaque copy of the lane id: keeps the compiler from hoisting every per-lane address of the
+        // loop body out of the loop (that costs > 100 VGPRs and spills)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (more) fetch_tile(vn, twl_n, twh_n, u0 + T, tid);
+
+        const u64 s = TRANSPOSE ? 0 : (u0 >> logP);
+        if constexpr (!TRANSPOSE && MODE >= 1) {
+            if (tid < R) tab[tid] = gl_mul(gl_mul(twl_c[0], twh_c[0]), kfac);
+        }
+#pragma unroll
+        for (int g = 0; g < (16 >> A1); g++) dif_shift<A1>(v + g * (1 << A1));
+        exchange2<G, A1, G::POS1, A2, G::POS2>(v, lds, twr1, a.j0inv, tid);
+#pragma unroll
+        for (int g = 0; g < (16 >> A2); g++) dif_shift<A2>(v + g * (1 << A2));
+        if constexpr (G::J >= 3) {
+            exchange2<G, A2, G::POS2, A3, 0>(v, lds, twr2, a.j0inv, tid);
+#pragma unroll
+            for (int g = 0; g < (16 >> A3); g++) dif_shift<A3>(v + g * (1 << A3));
+        }
+#pragma unroll
+        for (int g = 0; g < GRJ; g++) {
+            const int gamma = g * NT + tid;
+            const int t = gamma & (T - 1), o = gamma >> LOGT;
+            const int klow = G::kof(o << AJ);
+            if constexpr (TRANSPOSE) {
+                const int jr = a.j0inv & ((1 << AJ) - 1);  // odd, < 2^AJ: floor(jr*i/2^AJ) steps by 0 or 1
+                u64 w = gl_mul(twl_c[g], twh_c[g]);
+                const u64 hj = gl_mul(twl_c[GRJ], twh_c[GRJ]);
+                const u64 hjd = gl_mul(hj, gl_mul(twl_c[GRJ + 1], twh_c[GRJ + 1]));
+#pragma unroll
+                for (int i = 0; i < (1 << AJ); i++) {
+                    const int p = brev(i, AJ);
+                    const int kj = (jr * i) & ((1 << AJ) - 1);
+                    u64 x = gl_mul(v[g * (1 << AJ) + p], w);
+                    if (i + 1 < (1 << AJ)) {
+                        const bool wrap = ((jr * (i + 1)) >> AJ) != ((jr * i) >> AJ);  // wave-uniform
+                        w = gl_mul(w, wrap ? hjd : hj);
+                    }
+                    lds[G::lpos(slot_of(o, kj, 0, AJ), t)] = x;
+                }
+            } else {
+                const u64 c = (u0 + t) & ((1ULL << logP) - 1);
+                const u64 obase = (s << (logP + L)) + c;
+                u64 cw = 1;
+                if constexpr (MODE == 2) cw = gl_mul(twl_c[1], twh_c[1]);  // shift^c, c < Pprev
+#pragma unroll
+                for (int p = 0; p < (1 << AJ); p++) {
+                    const int kj = (a.j0inv * brev(p, AJ)) & ((1 << AJ) - 1);
+                    const int k = klow + (kj << (L - AJ));
+                    u64 x = v[g * (1 << AJ) + p];
+                    if constexpr (MODE >= 1) x = gl_mul(x, tab[k]);
+                    if constexpr (MODE == 2) x = gl_mul(x, cw);
+                    dst[obase + ((u64)k << logP)] = x;
+                }
+            }
+        }
+        if constexpr (TRANSPOSE) {
+            lds_barrier();
+            u64 *blk = dst + (u0 << L);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int idx = i * NT + tid;
+                const int t2 = idx >> L, k = idx & ((1 << L) - 1);
+                blk[idx] = lds[(G::sigma_of_k(k) << LOGT) + (t2 ^ (k & (T - 1)))];
+            }
+        }
+        if (more) {
+            lds_barrier();  // LDS (tile + table) is reused by the next tile
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = vn[i];
+#pragma unroll
+            for (int i = 0; i < NTW; i++) { twl_c[i] = twl_n[i]; twh_c[i] = twh_n[i]; }
         }
     }
 }
@@ -275,18 +525,18 @@ __global__ void __launch_bounds__(256) coset_scale_kernel(const u64 *in, u64 *ou
     if (i < n) out[col * n + i] = gl_mul(in[col * n + i], tw_lookup(lo, hi, lb, i));
 }
 
-template <int A1, int A2, int A3, int LOGT>
+template <int A1, int A2, int A3, int LOGT, int DIAG>
 int32_t launch_pass(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
     using G = Geo<A1, A2, A3, LOGT>;
     const u64 tiles = (1ULL << (a.logn - G::L)) >> LOGT;
     dim3 grid((unsigned)tiles, (unsigned)W), block(G::NT);
     const size_t shmem = (size_t)G::R * G::T * sizeof(u64);
     if (transpose) {
-        auto k = ntt_pass_kernel<A1, A2, A3, LOGT, true>;
+        auto k = ntt_pass_kernel<A1, A2, A3, LOGT, true, DIAG>;
         if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a);
     } else {
-        auto k = ntt_pass_kernel<A1, A2, A3, LOGT, false>;
+        auto k = ntt_pass_kernel<A1, A2, A3, LOGT, false, DIAG>;
         if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a);
     }
@@ -294,13 +544,52 @@ int32_t launch_pass(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
     return ZP_OK;
 }
 
+template <int A1, int A2, int A3, int LOGT>
+int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
+    using G = Geo<A1, A2, A3, LOGT>;
+    const u64 tiles = (1ULL << (a.logn - G::L)) >> LOGT;
+    // tiles per workgroup: a power of two that divides the tile count and (passes >= 2) keeps a
+    // workgroup inside one s-block only by construction of the table per tile (no constraint)
+    int tpw = ctx->tune_tpw;
+    while (tpw > 1 && (tiles % tpw != 0 || tiles / tpw * (u64)W < (u64)ctx->num_cu * 4)) tpw >>= 1;
+    dim3 grid((unsigned)(tiles / tpw), (unsigned)W), block(G::NT);
+    const size_t shmem = ((size_t)G::R * G::T + 2 * G::R + (1 << (A2 + A3))) * sizeof(u64);
+    if (transpose) {
+        const bool padded = a.in_valid != (1ULL << a.logn);
+        auto k = padded ? ntt_pass2_kernel<A1, A2, A3, LOGT, true, true, 1> : ntt_pass2_kernel<A1, A2, A3, LOGT, true, false, 1>;
+        if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a, tpw);
+    } else {
+        auto k = (a.flags & 4) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 2>
+                 : (a.flags & 3) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 1>
+                                 : ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 0>;
+        if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a, tpw);
+    }
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}
+
 int32_t dispatch_pass(zp_ctx *ctx, const NttPass &p, const PassArgs &a, bool transpose, int W) {
+    if (a.j0inv != 0 && ctx->tune_diag == 0 && ctx->tune_v2 != 0 && (!transpose || ctx->tune_v2 >= 2)) {
+        switch (p.L) {
+            case 5: return launch_pass2<3, 2, 0, 5>(ctx, a, transpose, W);
+            case 6: return launch_pass2<3, 3, 0, 5>(ctx, a, transpose, W);
+            case 7: return launch_pass2<4, 3, 0, 5>(ctx, a, transpose, W);
+            case 8: return launch_pass2<4, 4, 0, 5>(ctx, a, transpose, W);
+            case 9: return launch_pass2<3, 3, 3, 5>(ctx, a, transpose, W);
+            default: break;
+        }
+    }
+    if (p.L == 8 && ctx->tune_diag == 1) return launch_pass<4, 4, 0, 5, 1>(ctx, a, transpose, W);
+    if (p.L == 8 && ctx->tune_diag == 2) return launch_pass<4, 4, 0, 5, 2>(ctx, a, transpose, W);
+    if (p.L == 8 && ctx->tune_logt == 4) return launch_pass<4, 4, 0, 4, 0>(ctx, a, transpose, W);
     switch (p.L) {
-        case 5: return launch_pass<3, 2, 0, 5>(ctx, a, transpose, W);
-        case 6: return launch_pass<3, 3, 0, 5>(ctx, a, transpose, W);
-        case 7: return launch_pass<4, 3, 0, 5>(ctx, a, transpose, W);
-        case 8: return launch_pass<4, 4, 0, 5>(ctx, a, transpose, W);
-        case 9: return launch_pass<3, 3, 3, 5>(ctx, a, transpose, W);
+        case 5: return launch_pass<3, 2, 0, 5, 0>(ctx, a, transpose, W);
+        case 6: return launch_pass<3, 3, 0, 5, 0>(ctx, a, transpose, W);
+        case 7: return launch_pass<4, 3, 0, 5, 0>(ctx, a, transpose, W);
+        case 8: return launch_pass<4, 4, 0, 5, 0>(ctx, a, transpose, W);
+        case 9: return launch_pass<3, 3, 3, 5, 0>(ctx, a, transpose, W);
         default: ctx->err = "unsupported pass radix"; return ZP_ERR_UNSUPPORTED;
     }
 }
@@ -358,6 +647,11 @@ int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
         w16 = gl_inv(w16);
     }
     pl.ninv = gl_inv((1ULL << logn) % GL_P);
+    pl.j0inv = 0;
+    for (int j = 1; j < 16; j += 2)
+        if (gl_pow(1ULL << 12, (u64)j) == w16)
+            for (int ji = 1; ji < 16; ji += 2)
+                if (((j * ji) & 15) == 1) pl.j0inv = ji;
     pl.w16[0] = 1;
     for (int i = 1; i < 8; i++) pl.w16[i] = gl_mul(pl.w16[i - 1], w16);
     std::vector<u64> tws(4096);
@@ -491,6 +785,7 @@ int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, b
             a.scale = pl->ninv;
             a.logn = logn;
             a.logPprev = pl->pass[i].logPprev;
+            a.j0inv = pl->j0inv;
             a.flags = last ? 0 : 1;
             if (last && inverse) a.flags |= 2;
             if (last && opts.post_scale) {

@@ -57,6 +57,7 @@ SIGNATURES = {
     "zp_ntt_host": (C.c_int32, [_vp, _u64p, C.c_int32, C.c_int32, C.c_int32]),
     "zp_lde_host": (C.c_int32, [_vp, _u64p, _u64p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_merkle_commit_host": (C.c_int32, [_vp, _u64p, C.c_size_t, C.c_int32, _u64p]),
+    "zp_set_tuning": (C.c_int32, [_vp, C.c_char_p, C.c_int32]),
     "zp_set_profiling": (C.c_int32, [_vp, C.c_int32]),
     "zp_get_pass_timings": (C.c_int32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32,
                                         C.POINTER(C.c_int32)]),
@@ -243,6 +244,9 @@ class Prover:
         return tree
 
     # ---- measurement
+    def set_tuning(self, key, value):
+        self._chk(self.lib.zp_set_tuning(self.ctx, key.encode(), int(value)))
+
     def set_profiling(self, on):
         self._chk(self.lib.zp_set_profiling(self.ctx, int(bool(on))))
 

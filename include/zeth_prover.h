@@ -108,6 +108,9 @@ int32_t zp_merkle_commit_host(zp_ctx *ctx, const uint64_t *h_cols, size_t M, int
 int32_t zp_set_profiling(zp_ctx *ctx, int32_t on);
 int32_t zp_get_pass_timings(zp_ctx *ctx, float *ms, int32_t *radix_log, int32_t cap, int32_t *count);
 
+/* experiment knobs for kernel tuning sweeps (key: "ntt_diag" 0|1|2, "ntt_logt" 4|5); not for production hosts */
+int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value);
+
 /* ---- introspection ------------------------------------------------------------------------- */
 /* JSON description of the pass plan used for a 2^logn transform (for DESIGN/bench reporting) */
 int32_t zp_ntt_plan_json(zp_ctx *ctx, int32_t logn, char *buf, size_t buflen);
