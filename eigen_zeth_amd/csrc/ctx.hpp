@@ -49,6 +49,7 @@ struct zp_ctx {
     u64 *d_rc = nullptr;
     u32 *d_mds = nullptr;
     bool poseidon_dirty = true;
+    bool mds_is_default = false;  // compile-time literal fast path for the documented default matrix
     // plans
     std::map<int, NttPlan> plans;  // key = logn*2 + inverse
     std::vector<CosetTable> cosets;

@@ -91,6 +91,28 @@ GL_HD u64 gl_mul_pow2(u64 x) {
 }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 
+// ---- "weak" forms: any u64 in, any u64 out, value preserved mod p (no final canonicalisation).
+// Safe wherever the consumer is another multiplication or a limb-wise accumulation.
+GL_HD u64 gl_reduce96_weak(u64 lo, u32 hl, u32 hh) {
+    u64 r = (u64)hl * 0xFFFFFFFFu + lo;
+    r += (r < lo) ? GL_EPS : 0;     // +2^64 == +EPS; cannot wrap again (r < 2^64 - 2^33 after a wrap)
+    const u64 d = r - hh;
+    return d - ((r < (u64)hh) ? GL_EPS : 0);  // -2^64 == -EPS; d >= 2^64 - 2^32 after a borrow
+}
+GL_HD u64 gl_mul_weak(u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0;
+    u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+    u64 p10 = (u64)a1 * b0 + (u32)p01;
+    u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    return gl_reduce96_weak(((u64)(u32)p10 << 32) | (u32)p00, (u32)p11, (u32)(p11 >> 32));
+}
+// weak + canonical -> weak
+GL_HD u64 gl_add_weak(u64 a_any, u64 b_canon) {
+    u64 s = a_any + b_canon;
+    return s + ((s < a_any) ? GL_EPS : 0);
+}
+
 GL_HD u64 gl_pow(u64 b, u64 e) {
     u64 r = 1;
     while (e) {

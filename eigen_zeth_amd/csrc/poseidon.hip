@@ -15,67 +15,99 @@
 
 namespace {
 
+// x^7 with weak (non-canonical) intermediates: the consumers are multiplications / limb sums
 __device__ __forceinline__ u64 sbox7(u64 x) {
-    u64 x2 = gl_mul(x, x), x4 = gl_mul(x2, x2), x3 = gl_mul(x2, x);
-    return gl_mul(x3, x4);
+    u64 x2 = gl_mul_weak(x, x), x4 = gl_mul_weak(x2, x2), x3 = gl_mul_weak(x2, x);
+    return gl_mul_weak(x3, x4);
 }
 
-// out[i] = sum_j m[i][j] * s[j],  m entries < 2^28 so both 64-bit partial sums cannot overflow
-__device__ __forceinline__ void mds_mul(u64 *s, const u32 *__restrict__ mds) {
+// default MDS (eigen_zeth_amd/poseidon_constants.py): circulant [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0,..]
+// coefficient of in[j] in out[i] is circ[(j-i) mod 12] (+8 at i=j=0).  As compile-time literals the
+// entries are inline constants of v_mad_u64_u32: no SGPRs, no scalar loads.
+__host__ __device__ __forceinline__ constexpr u32 def_mds(int i, int j) {
+    constexpr u32 circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    return circ[(j - i + 12) % 12] + ((i == 0 && j == 0) ? 8u : 0u);
+}
+
+// s <- M*s + c   (c = the NEXT round's constants, or none): out[i] = sum_j m[i][j]*s[j] + c[i].
+// m entries < 2^28 and s any u64: the two 64-bit partial sums over 32-bit halves cannot overflow
+// (12 * 2^28 * 2^32 + 2^32 < 2^64).  Result weak.
+// DEFMDS=false: injected matrix, staged once per workgroup in LDS (keeping 144 entries in SGPRs
+// spills them to VGPR lanes; LDS reads of a wave-uniform address are broadcasts).
+template <bool ADDC, bool DEFMDS>
+__device__ __forceinline__ void mds_ark(u64 *s, const u32 *__restrict__ mds, const u64 *__restrict__ c) {
     u64 o[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        u64 alo = 0, ahi = 0;
+        u64 alo = ADDC ? (u64)(u32)c[i] : 0ULL, ahi = ADDC ? (c[i] >> 32) : 0ULL;
+        const u32 *mrow = mds + i * 12;  // DEFMDS=false: mds points at the workgroup's LDS copy
 #pragma unroll
         for (int j = 0; j < 12; j++) {
-            const u32 m = mds[i * 12 + j];
+            const u32 m = DEFMDS ? def_mds(i, j) : mrow[j];
             alo += (u64)m * (u32)s[j];
             ahi += (u64)m * (u32)(s[j] >> 32);
         }
-        // value = alo + ahi * 2^32
-        const u64 mid = (alo >> 32) + ahi;
-        o[i] = gl_reduce_limbs((u32)alo, (u32)mid, (u32)(mid >> 32), 0u);
+        const u64 mid = (alo >> 32) + ahi;  // value = (u32)alo + mid * 2^32
+        o[i] = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = o[i];
 }
 
+// textbook schedule ARK -> S-box -> MDS, with each round's ARK folded into the previous round's
+// MDS accumulators; state is weak between rounds and canonicalised once at the end.
+template <bool DEFMDS>
 __device__ __forceinline__ void poseidon_perm(u64 *s, const u64 *__restrict__ rc, const u32 *__restrict__ mds) {
-#pragma unroll 1
-    for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox7(gl_add(s[i], rc[r * 12 + i]));
-        mds_mul(s, mds);
+    for (int i = 0; i < 12; i++) s[i] = gl_add_weak(s[i], rc[i]);
+#pragma unroll 1
+    for (int r = 0; r < 29; r++) {
+        if (r < 4 || r >= 26) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) s[i] = sbox7(s[i]);
+        } else {
+            s[0] = sbox7(s[0]);
+        }
+        mds_ark<true, DEFMDS>(s, mds, rc + (r + 1) * 12);
     }
-#pragma unroll 1
-    for (int r = 4; r < 26; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], rc[r * 12 + i]);
-        s[0] = sbox7(s[0]);
-        mds_mul(s, mds);
-    }
-#pragma unroll 1
-    for (int r = 26; r < 30; r++) {
+    for (int i = 0; i < 12; i++) s[i] = sbox7(s[i]);
+    mds_ark<false, DEFMDS>(s, mds, rc);
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox7(gl_add(s[i], rc[r * 12 + i]));
-        mds_mul(s, mds);
+    for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+}
+
+template <bool DEFMDS>
+__device__ __forceinline__ const u32 *stage_mds(const u32 *mds, u32 *smds) {
+    if constexpr (DEFMDS) {
+        return mds;
+    } else {
+        if (threadIdx.x < 144) smds[threadIdx.x] = mds[threadIdx.x];
+        __syncthreads();
+        return smds;
     }
 }
 
+template <bool DEFMDS>
 __global__ void __launch_bounds__(256) poseidon_perm_kernel(u64 *states, size_t count, const u64 *rc, const u32 *mds) {
+    __shared__ u32 smds[DEFMDS ? 1 : 144];
+    mds = stage_mds<DEFMDS>(mds, smds);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
     u64 s[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) s[j] = states[i * 12 + j];
-    poseidon_perm(s, rc, mds);
+    poseidon_perm<DEFMDS>(s, rc, mds);
 #pragma unroll
     for (int j = 0; j < 12; j++) states[i * 12 + j] = s[j];
 }
 
 // leaf i = linear hash of (cols[0][i], cols[1][i], ... cols[W-1][i]);  lane = row
+template <bool DEFMDS>
 __global__ void __launch_bounds__(256) merkle_leaves_kernel(const u64 *__restrict__ cols, size_t M, int W,
                                                            u64 *__restrict__ tree, const u64 *rc, const u32 *mds) {
+    __shared__ u32 smds[DEFMDS ? 1 : 144];
+    mds = stage_mds<DEFMDS>(mds, smds);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     u64 s[12];
@@ -89,7 +121,7 @@ __global__ void __launch_bounds__(256) merkle_leaves_kernel(const u64 *__restric
     for (int off = 0; off < W; off += 8) {
 #pragma unroll
         for (int j = 0; j < 8; j++) s[j] = (off + j < W) ? cols[(size_t)(off + j) * M + i] : 0ULL;
-        poseidon_perm(s, rc, mds);
+        poseidon_perm<DEFMDS>(s, rc, mds);
 #pragma unroll
         for (int j = 0; j < 4; j++) s[8 + j] = s[j];
     }
@@ -98,8 +130,11 @@ __global__ void __launch_bounds__(256) merkle_leaves_kernel(const u64 *__restric
 }
 
 // leaves given as M contiguous rows of `len` elements
+template <bool DEFMDS>
 __global__ void __launch_bounds__(256) merkle_leaves_rows_kernel(const u64 *__restrict__ rows, size_t M, size_t len,
                                                                 u64 *__restrict__ tree, const u64 *rc, const u32 *mds) {
+    __shared__ u32 smds[DEFMDS ? 1 : 144];
+    mds = stage_mds<DEFMDS>(mds, smds);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     const u64 *row = rows + i * len;
@@ -114,7 +149,7 @@ __global__ void __launch_bounds__(256) merkle_leaves_rows_kernel(const u64 *__re
     for (size_t off = 0; off < len; off += 8) {
 #pragma unroll
         for (int j = 0; j < 8; j++) s[j] = (off + j < len) ? row[off + j] : 0ULL;
-        poseidon_perm(s, rc, mds);
+        poseidon_perm<DEFMDS>(s, rc, mds);
 #pragma unroll
         for (int j = 0; j < 4; j++) s[8 + j] = s[j];
     }
@@ -123,8 +158,11 @@ __global__ void __launch_bounds__(256) merkle_leaves_rows_kernel(const u64 *__re
 }
 
 // one tree level: node i = P(child[2i] || child[2i+1] || 0^4)[0..4]
+template <bool DEFMDS>
 __global__ void __launch_bounds__(256) merkle_level_kernel(const u64 *__restrict__ prev, u64 *__restrict__ next,
                                                           size_t half, const u64 *rc, const u32 *mds) {
+    __shared__ u32 smds[DEFMDS ? 1 : 144];
+    mds = stage_mds<DEFMDS>(mds, smds);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= half) return;
     u64 s[12];
@@ -132,7 +170,7 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const u64 *__restrict
     for (int j = 0; j < 8; j++) s[j] = prev[i * 8 + j];
 #pragma unroll
     for (int j = 8; j < 12; j++) s[j] = 0;
-    poseidon_perm(s, rc, mds);
+    poseidon_perm<DEFMDS>(s, rc, mds);
 #pragma unroll
     for (int j = 0; j < 4; j++) next[i * 4 + j] = s[j];
 }
@@ -143,8 +181,12 @@ int32_t tree_levels(zp_ctx *ctx, u64 *tree, size_t M) {
     while (cnt > 1) {
         u64 *next = prev + cnt * 4;
         const size_t half = cnt >> 1;
-        hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream,
-                           prev, next, half, ctx->d_rc, ctx->d_mds);
+        if (ctx->mds_is_default)
+            hipLaunchKernelGGL(merkle_level_kernel<true>, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream,
+                               prev, next, half, ctx->d_rc, ctx->d_mds);
+        else
+            hipLaunchKernelGGL(merkle_level_kernel<false>, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream,
+                               prev, next, half, ctx->d_rc, ctx->d_mds);
         ZP_HIP(ctx, hipGetLastError());
         prev = next;
         cnt = half;
@@ -164,6 +206,10 @@ int32_t zpi_poseidon_sync_tables(zp_ctx *ctx) {
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZP_HIP(ctx, hipMemcpy(ctx->d_rc, ctx->h_rc, 360 * sizeof(u64), hipMemcpyHostToDevice));
     ZP_HIP(ctx, hipMemcpy(ctx->d_mds, m32, sizeof(m32), hipMemcpyHostToDevice));
+    ctx->mds_is_default = true;
+    for (int i = 0; i < 12; i++)
+        for (int j = 0; j < 12; j++)
+            if (ctx->h_mds[i * 12 + j] != def_mds(i, j)) ctx->mds_is_default = false;
     ctx->poseidon_dirty = false;
     return ZP_OK;
 }
@@ -175,8 +221,12 @@ int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count) {
     if (count == 0) return ZP_OK;
     ZP_ARG(ctx, d_states != nullptr, "null device pointer");
     ZP_TRY(zpi_poseidon_sync_tables(ctx));
-    hipLaunchKernelGGL(poseidon_perm_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (u64 *)d_states, count, ctx->d_rc, ctx->d_mds);
+    if (ctx->mds_is_default)
+        hipLaunchKernelGGL(poseidon_perm_kernel<true>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (u64 *)d_states, count, ctx->d_rc, ctx->d_mds);
+    else
+        hipLaunchKernelGGL(poseidon_perm_kernel<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (u64 *)d_states, count, ctx->d_rc, ctx->d_mds);
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
 }
@@ -187,8 +237,12 @@ int32_t zp_merkle_commit(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t 
     ZP_ARG(ctx, W >= 1, "W must be >= 1");
     ZP_ARG(ctx, d_cols && d_tree, "null device pointer");
     ZP_TRY(zpi_poseidon_sync_tables(ctx));
-    hipLaunchKernelGGL(merkle_leaves_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const u64 *)d_cols, M, (int)W, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
+    if (ctx->mds_is_default)
+        hipLaunchKernelGGL(merkle_leaves_kernel<true>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const u64 *)d_cols, M, (int)W, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
+    else
+        hipLaunchKernelGGL(merkle_leaves_kernel<false>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const u64 *)d_cols, M, (int)W, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
     ZP_HIP(ctx, hipGetLastError());
     return tree_levels(ctx, (u64 *)d_tree, M);
 }
@@ -199,8 +253,12 @@ int32_t zp_merkle_commit_rows(zp_ctx *ctx, const uint64_t *d_rows, size_t M, siz
     ZP_ARG(ctx, len >= 1, "len must be >= 1");
     ZP_ARG(ctx, d_rows && d_tree, "null device pointer");
     ZP_TRY(zpi_poseidon_sync_tables(ctx));
-    hipLaunchKernelGGL(merkle_leaves_rows_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const u64 *)d_rows, M, len, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
+    if (ctx->mds_is_default)
+        hipLaunchKernelGGL(merkle_leaves_rows_kernel<true>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const u64 *)d_rows, M, len, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
+    else
+        hipLaunchKernelGGL(merkle_leaves_rows_kernel<false>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const u64 *)d_rows, M, len, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
     ZP_HIP(ctx, hipGetLastError());
     return tree_levels(ctx, (u64 *)d_tree, M);
 }

@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libzethprover.so")
+LIB_PATH = os.environ.get("ZP_LIB_PATH") or os.path.join(_HERE, "csrc", "libzethprover.so")  # override: A/B builds
 
 P = 0xFFFFFFFF00000001
 ROOT32_DEFAULT = 1753635133440165772
