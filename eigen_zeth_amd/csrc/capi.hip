@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "ctx.hpp"
 #include "poseidon_default_table.inc"
@@ -184,6 +185,60 @@ int32_t zp_lde(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t *d_c
                int32_t logb, int32_t W, uint64_t shift) {
     if (!ctx) return ZP_ERR_ARG;
     return zpi_lde(ctx, (const u64 *)d_in, (u64 *)d_out, (u64 *)d_coef, logn, logb, W, shift);
+}
+
+// ---- AIR plug-in support
+int32_t zp_domain_tables(zp_ctx *ctx, int32_t logm, const uint64_t **d_lo, const uint64_t **d_hi, int32_t *lb) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, logm >= 0 && logm <= 32 && d_lo && d_hi && lb, "bad arguments");
+    NttPlan *pl;
+    ZP_TRY(zpi_get_plan(ctx, logm, false, &pl));
+    *d_lo = (const uint64_t *)pl->d_twl;
+    *d_hi = (const uint64_t *)pl->d_twh;
+    *lb = pl->lb;
+    return ZP_OK;
+}
+
+int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uint64_t *h_trace, uint64_t *h_pub) {
+    if (logn < 1 || logn > 30 || !h_trace || !h_pub) return ZP_ERR_ARG;
+    const size_t N = (size_t)1 << logn;
+    // splitmix64 -> canonical field elements
+    auto next = [&seed]() {
+        u64 z = (seed += 0x9E3779B97F4A7C15ULL);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        return z >= GL_P ? z - GL_P : z;
+    };
+    if (kind == 0) {
+        if (W != 2) return ZP_ERR_ARG;
+        u64 a = next(), b = next();
+        h_pub[0] = a;
+        h_pub[1] = b;
+        for (size_t i = 0; i < N; i++) {
+            h_trace[i] = a;
+            h_trace[N + i] = b;
+            const u64 t = gl_add(a, b);
+            a = b;
+            b = t;
+        }
+        h_pub[2] = h_trace[N + N - 1];
+        return ZP_OK;
+    }
+    if (kind == 1) {
+        if (W < 3) return ZP_ERR_ARG;
+        std::vector<u64> cur(W), nx(W);
+        for (int i = 0; i < W; i++) cur[i] = next();
+        for (int i = 0; i < (W < 4 ? W : 4); i++) h_pub[i] = cur[i];
+        for (size_t r = 0; r < N; r++) {
+            for (int i = 0; i < W; i++) h_trace[(size_t)i * N + r] = cur[i];
+            for (int i = 0; i < W; i++)
+                nx[i] = gl_add(gl_add(gl_mul(cur[i], cur[(i + 1) % W]), cur[(i + 2) % W]), (u64)i);
+            cur.swap(nx);
+        }
+        return ZP_OK;
+    }
+    return ZP_ERR_ARG;
 }
 
 // ---- host conveniences

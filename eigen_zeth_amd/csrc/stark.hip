@@ -1,0 +1,241 @@
+// STARK stages around the committed columns (SURVEY.md 8a N4/N5 support): out-of-domain
+// evaluation, DEEP quotient, row gathers and batched Merkle openings.  No reference counterpart in
+// /root/reference (the prover behind src/prover/provider.rs:358-377 is external); definitions follow
+// the public DEEP-FRI construction, checked against oracle/ and an independent verifier in tests/.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "ctx.hpp"
+
+namespace {
+
+// ---- p_c(z) for W polynomials with base-field coefficients at an F_{p^3} point --------------------
+// lane t of a block owns 16 consecutive coefficients: sum_j c[16t+j] z^j (z^j wave-uniform), times
+// z^(16t) from a 256-entry table, block-reduced in LDS; one partial per (4096-coefficient chunk, col).
+struct EvalArgs {
+    const u64 *coef;
+    u64 n;
+    const u64 *zlow;   // z^j, j < 16          [16][3]
+    const u64 *zmid;   // z^(16 t), t < 256     [256][3]
+    u64 *partial;      // [chunks][W][3]
+    int W;
+};
+
+__global__ void __launch_bounds__(256) poly_eval_ext_kernel(EvalArgs a) {
+    __shared__ u64 red[3][256];
+    const int t = threadIdx.x;
+    const u64 chunk = blockIdx.x, col = blockIdx.y;
+    const u64 base = chunk * 4096 + (u64)t * 16;
+    const u64 *c = a.coef + col * a.n;
+    u64 acc0 = 0, acc1 = 0, acc2 = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const u64 v = (base + j < a.n) ? c[base + j] : 0ULL;
+        acc0 = gl_add(acc0, gl_mul(v, a.zlow[j * 3 + 0]));
+        acc1 = gl_add(acc1, gl_mul(v, a.zlow[j * 3 + 1]));
+        acc2 = gl_add(acc2, gl_mul(v, a.zlow[j * 3 + 2]));
+    }
+    e3 r = e3_mul(e3_make(acc0, acc1, acc2), e3_make(a.zmid[t * 3], a.zmid[t * 3 + 1], a.zmid[t * 3 + 2]));
+    red[0][t] = r.c[0]; red[1][t] = r.c[1]; red[2][t] = r.c[2];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) red[k][t] = gl_add(red[k][t], red[k][t + s]);
+        }
+        __syncthreads();
+    }
+    if (t < 3) a.partial[(chunk * a.W + col) * 3 + t] = red[t][0];
+}
+
+// ---- DEEP quotient ---------------------------------------------------------------------------------
+// F(x) = sum_{k<Wa+Wb} g^k (p_k(x) - e_k)/(x - z) + sum_{k<nnext} g^(Wa+Wb+k) (p_k(x) - e'_k)/(x - zw)
+// on x = shift * w_M^r.  lane = row; column reads are coalesced; g^k and the constant terms are uniform.
+struct DeepArgs {
+    const u64 *cols_a, *cols_b;
+    u64 *out;
+    const u64 *gpow;     // [(Wa+Wb+nnext)][3]
+    const u64 *twl, *twh;  // w_M^e
+    u64 ca[3], cb[3];    // sum g^k e_k ,  sum g^(W+k) e'_k
+    u64 z[3], zw[3];
+    u64 shift;
+    int logm, Wa, Wb, nnext, lb;
+};
+
+__global__ void __launch_bounds__(256) deep_quotient_kernel(DeepArgs a) {
+    const u64 M = 1ULL << a.logm;
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= M) return;
+    e3 A = e3_make(0, 0, 0), B = e3_make(0, 0, 0);
+    const int W = a.Wa + a.Wb;
+    for (int k = 0; k < W; k++) {
+        const u64 v = k < a.Wa ? a.cols_a[(u64)k * M + r] : a.cols_b[(u64)(k - a.Wa) * M + r];
+        const u64 *g = a.gpow + k * 3;
+        A.c[0] = gl_add(A.c[0], gl_mul(v, g[0]));
+        A.c[1] = gl_add(A.c[1], gl_mul(v, g[1]));
+        A.c[2] = gl_add(A.c[2], gl_mul(v, g[2]));
+        if (k < a.nnext) {
+            const u64 *h = a.gpow + (W + k) * 3;
+            B.c[0] = gl_add(B.c[0], gl_mul(v, h[0]));
+            B.c[1] = gl_add(B.c[1], gl_mul(v, h[1]));
+            B.c[2] = gl_add(B.c[2], gl_mul(v, h[2]));
+        }
+    }
+    A = e3_sub(A, e3_make(a.ca[0], a.ca[1], a.ca[2]));
+    B = e3_sub(B, e3_make(a.cb[0], a.cb[1], a.cb[2]));
+    const u64 x = gl_mul(a.shift, gl_mul(a.twl[r & ((1ULL << a.lb) - 1)], a.twh[r >> a.lb]));
+    const e3 d1 = e3_inv(e3_make(gl_sub(x, a.z[0]), gl_neg(a.z[1]), gl_neg(a.z[2])));
+    e3 F = e3_mul(A, d1);
+    if (a.nnext > 0) {
+        const e3 d2 = e3_inv(e3_make(gl_sub(x, a.zw[0]), gl_neg(a.zw[1]), gl_neg(a.zw[2])));
+        F = e3_add(F, e3_mul(B, d2));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) a.out[(u64)c * M + r] = F.c[c];
+}
+
+__global__ void __launch_bounds__(256) gather_rows_kernel(const u64 *cols, u64 M, int W, const u64 *idx, int nq, u64 *out) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (u64)nq * W) return;
+    const u64 q = i / W, c = i % W;
+    out[i] = cols[c * M + idx[q]];
+}
+
+__global__ void __launch_bounds__(256) merkle_paths_kernel(const u64 *tree, u64 M, int depth, const u64 *idx, int nq, u64 *out) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (u64)nq * depth * 4) return;
+    const int e = (int)(i & 3);
+    const u64 qd = i >> 2;
+    const int d = (int)(qd % depth);
+    const u64 q = qd / depth;
+    u64 off = 0, cnt = M;
+    for (int l = 0; l < d; l++) { off += cnt; cnt >>= 1; }
+    const u64 node = (idx[q] >> d) ^ 1;
+    out[i] = tree[(off + node) * 4 + e];
+}
+
+}  // namespace
+
+static e3 to_e3(const void *pv) { const u64 *p = (const u64 *)pv; return e3_make(p[0], p[1], p[2]); }
+
+extern "C" {
+
+int32_t zp_poly_eval_ext(zp_ctx *ctx, const uint64_t *d_coef, int32_t logn, int32_t W, const uint64_t z[3],
+                         uint64_t *h_out) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, logn >= 0 && logn <= 32 && W >= 0, "logn/W out of range");
+    ZP_ARG(ctx, (d_coef && z && h_out) || W == 0, "null pointer");
+    if (W == 0) return ZP_OK;
+    ZP_ARG(ctx, z[0] < GL_P && z[1] < GL_P && z[2] < GL_P, "point not canonical");
+    const u64 n = 1ULL << logn;
+    const u64 chunks = (n + 4095) / 4096;
+    std::vector<u64> tab((16 + 256) * 3);
+    e3 zz = to_e3(z), cur = e3_make(1, 0, 0);
+    for (int j = 0; j < 16; j++) { memcpy(&tab[j * 3], cur.c, 24); cur = e3_mul(cur, zz); }
+    e3 z16 = cur;  // z^16
+    cur = e3_make(1, 0, 0);
+    for (int t = 0; t < 256; t++) { memcpy(&tab[(16 + t) * 3], cur.c, 24); cur = e3_mul(cur, z16); }
+    e3 z4096 = cur;
+    u64 *d_tab = nullptr, *d_part = nullptr;
+    ZP_TRY(zpi_scratch(ctx, 3, tab.size() + chunks * W * 3, &d_tab));
+    d_part = d_tab + tab.size();
+    ZP_HIP(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    EvalArgs a;
+    a.coef = (const u64 *)d_coef; a.n = n; a.zlow = d_tab; a.zmid = d_tab + 48; a.partial = d_part; a.W = W;
+    hipLaunchKernelGGL(poly_eval_ext_kernel, dim3((unsigned)chunks, (unsigned)W), dim3(256), 0, ctx->stream, a);
+    ZP_HIP(ctx, hipGetLastError());
+    std::vector<u64> part(chunks * W * 3);
+    ZP_HIP(ctx, hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // combine the per-chunk partials on the host: sum_ch partial[ch] * (z^4096)^ch   (tiny: chunks*W terms)
+    for (int c = 0; c < W; c++) {
+        e3 acc = e3_make(0, 0, 0);
+        for (u64 ch = chunks; ch-- > 0;) {
+            acc = e3_mul(acc, z4096);
+            acc = e3_add(acc, to_e3(&part[(ch * W + c) * 3]));
+        }
+        memcpy(h_out + c * 3, acc.c, 24);
+    }
+    return ZP_OK;
+}
+
+int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, const uint64_t *d_cols_b, int32_t Wb,
+                         int32_t logm, int32_t n_next, const uint64_t z[3], const uint64_t zw[3],
+                         const uint64_t gamma[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t shift,
+                         uint64_t *d_out) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, logm >= 0 && logm <= 32, "logm out of range");
+    ZP_ARG(ctx, Wa >= 1 && Wb >= 0 && n_next >= 0 && n_next <= Wa, "bad widths");
+    ZP_ARG(ctx, d_cols_a && (d_cols_b || Wb == 0) && z && zw && gamma && h_ev_z && (h_ev_zw || n_next == 0) && d_out,
+           "null pointer");
+    if (shift == 0) shift = ctx->coset_shift;
+    const int W = Wa + Wb;
+    NttPlan *pl;
+    ZP_TRY(zpi_get_plan(ctx, logm, false, &pl));
+    std::vector<u64> gp((size_t)(W + n_next) * 3);
+    e3 g = to_e3(gamma), cur = e3_make(1, 0, 0), ca = e3_make(0, 0, 0), cb = e3_make(0, 0, 0);
+    for (int k = 0; k < W + n_next; k++) {
+        memcpy(&gp[(size_t)k * 3], cur.c, 24);
+        if (k < W) ca = e3_add(ca, e3_mul(cur, to_e3(h_ev_z + (size_t)k * 3)));
+        else cb = e3_add(cb, e3_mul(cur, to_e3(h_ev_zw + (size_t)(k - W) * 3)));
+        cur = e3_mul(cur, g);
+    }
+    u64 *d_gp = nullptr;
+    ZP_TRY(zpi_scratch(ctx, 3, gp.size(), &d_gp));
+    ZP_HIP(ctx, hipMemcpyAsync(d_gp, gp.data(), gp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // gp is a stack vector
+    DeepArgs a;
+    a.cols_a = (const u64 *)d_cols_a; a.cols_b = (const u64 *)d_cols_b; a.out = (u64 *)d_out; a.gpow = d_gp;
+    a.twl = pl->d_twl; a.twh = pl->d_twh; a.lb = pl->lb;
+    memcpy(a.ca, ca.c, 24); memcpy(a.cb, cb.c, 24); memcpy(a.z, z, 24); memcpy(a.zw, zw, 24);
+    a.shift = shift; a.logm = logm; a.Wa = Wa; a.Wb = Wb; a.nnext = n_next;
+    const u64 M = 1ULL << logm;
+    hipLaunchKernelGGL(deep_quotient_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}
+
+int32_t zp_gather_rows(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, const uint64_t *h_idx, int32_t nq,
+                       uint64_t *h_out) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, W >= 1 && nq >= 0 && M >= 1, "bad sizes");
+    if (nq == 0) return ZP_OK;
+    ZP_ARG(ctx, d_cols && h_idx && h_out, "null pointer");
+    for (int i = 0; i < nq; i++) ZP_ARG(ctx, h_idx[i] < M, "row index out of range");
+    u64 *d = nullptr;
+    ZP_TRY(zpi_scratch(ctx, 3, (size_t)nq * (W + 1), &d));
+    ZP_HIP(ctx, hipMemcpyAsync(d, h_idx, (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
+    const u64 total = (u64)nq * W;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const u64 *)d_cols, (u64)M, (int)W, d, (int)nq, d + nq);
+    ZP_HIP(ctx, hipGetLastError());
+    ZP_HIP(ctx, hipMemcpyAsync(h_out, d + nq, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZP_OK;
+}
+
+int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, const uint64_t *h_idx, int32_t nq,
+                             uint64_t *h_paths) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, M >= 1 && (M & (M - 1)) == 0, "M must be a power of two");
+    ZP_ARG(ctx, nq >= 0, "bad query count");
+    int depth = 0;
+    while (((size_t)1 << depth) < M) depth++;
+    if (nq == 0 || depth == 0) return ZP_OK;
+    ZP_ARG(ctx, d_tree && h_idx && h_paths, "null pointer");
+    for (int i = 0; i < nq; i++) ZP_ARG(ctx, h_idx[i] < M, "leaf index out of range");
+    u64 *d = nullptr;
+    const u64 total = (u64)nq * depth * 4;
+    ZP_TRY(zpi_scratch(ctx, 3, (size_t)nq + total, &d));
+    ZP_HIP(ctx, hipMemcpyAsync(d, h_idx, (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(merkle_paths_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const u64 *)d_tree, (u64)M, depth, d, (int)nq, d + nq);
+    ZP_HIP(ctx, hipGetLastError());
+    ZP_HIP(ctx, hipMemcpyAsync(h_paths, d + nq, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZP_OK;
+}
+
+}  // extern "C"

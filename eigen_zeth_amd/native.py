@@ -54,6 +54,13 @@ SIGNATURES = {
     "zp_merkle_commit_rows": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _vp]),
     "zp_merkle_open": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _u64p]),
     "zp_fri_fold": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, _u64p, C.c_uint64]),
+    "zp_poly_eval_ext": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _u64p, _u64p]),
+    "zp_deep_quotient": (C.c_int32, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, _u64p, _u64p, _u64p,
+                                     _u64p, _u64p, C.c_uint64, _vp]),
+    "zp_gather_rows": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _u64p, C.c_int32, _u64p]),
+    "zp_merkle_open_batch": (C.c_int32, [_vp, _vp, C.c_size_t, _u64p, C.c_int32, _u64p]),
+    "zp_domain_tables": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int32)]),
+    "zp_synth_trace": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p]),
     "zp_ntt_host": (C.c_int32, [_vp, _u64p, C.c_int32, C.c_int32, C.c_int32]),
     "zp_lde_host": (C.c_int32, [_vp, _u64p, _u64p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_merkle_commit_host": (C.c_int32, [_vp, _u64p, C.c_size_t, C.c_int32, _u64p]),
@@ -64,6 +71,17 @@ SIGNATURES = {
     "zp_ntt_plan_json": (C.c_int32, [_vp, C.c_int32, C.c_char_p, C.c_size_t]),
     "zp_device_info_json": (C.c_int32, [_vp, C.c_char_p, C.c_size_t]),
 }
+
+
+def synth_trace(kind, logn, W, seed):
+    """synthetic witness (host code inside the library, no GPU needed): (trace [W][N], publics)"""
+    lib = load_library()
+    tr = np.empty((W, 1 << logn), dtype=np.uint64)
+    pub = np.zeros(4, dtype=np.uint64)
+    rc = lib.zp_synth_trace(kind, logn, W, seed, tr.ctypes.data_as(_u64p), pub.ctypes.data_as(_u64p))
+    if rc != 0:
+        raise ValueError("zp_synth_trace: bad arguments")
+    return tr, pub[:3 if kind == 0 else min(4, W)].copy()
 
 
 class ZpError(RuntimeError):
@@ -219,6 +237,41 @@ class Prover:
     def fri_fold(self, d_in, d_out, logn, logf, beta, shift):
         b = (C.c_uint64 * 3)(*[int(x) for x in beta])
         self._chk(self.lib.zp_fri_fold(self.ctx, _ptr(d_in), _ptr(d_out), logn, logf, b, shift))
+
+    # ---- STARK stages
+    def poly_eval_ext(self, d_coef, logn, W, z):
+        zz = (C.c_uint64 * 3)(*[int(v) for v in z])
+        out = np.zeros((W, 3), dtype=np.uint64)
+        self._chk(self.lib.zp_poly_eval_ext(self.ctx, _ptr(d_coef), logn, W, zz, out.ctypes.data_as(_u64p)))
+        return out
+
+    def deep_quotient(self, d_cols_a, Wa, d_cols_b, Wb, logm, n_next, z, zw, gamma, ev_z, ev_zw, shift, d_out):
+        a3 = lambda v: (C.c_uint64 * 3)(*[int(x) for x in v])
+        ez = np.ascontiguousarray(np.asarray(ev_z, dtype=np.uint64))
+        ezw = np.ascontiguousarray(np.asarray(ev_zw, dtype=np.uint64)) if n_next else np.zeros((1, 3), dtype=np.uint64)
+        self._chk(self.lib.zp_deep_quotient(self.ctx, _ptr(d_cols_a), Wa, _ptr(d_cols_b), Wb, logm, n_next, a3(z),
+                                            a3(zw), a3(gamma), ez.ctypes.data_as(_u64p), ezw.ctypes.data_as(_u64p),
+                                            shift, _ptr(d_out)))
+
+    def gather_rows(self, d_cols, M, W, idx):
+        ii = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64))
+        out = np.zeros((len(ii), W), dtype=np.uint64)
+        self._chk(self.lib.zp_gather_rows(self.ctx, _ptr(d_cols), M, W, ii.ctypes.data_as(_u64p), len(ii),
+                                          out.ctypes.data_as(_u64p)))
+        return out
+
+    def merkle_open_batch(self, d_tree, M, idx):
+        ii = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64))
+        depth = int(M).bit_length() - 1
+        out = np.zeros((len(ii), max(depth, 1), 4), dtype=np.uint64)
+        self._chk(self.lib.zp_merkle_open_batch(self.ctx, _ptr(d_tree), M, ii.ctypes.data_as(_u64p), len(ii),
+                                                out.ctypes.data_as(_u64p)))
+        return out[:, :depth]
+
+    def domain_tables(self, logm):
+        lo, hi, lb = _vp(), _vp(), C.c_int32(0)
+        self._chk(self.lib.zp_domain_tables(self.ctx, logm, C.byref(lo), C.byref(hi), C.byref(lb)))
+        return lo.value, hi.value, lb.value
 
     # ---- host-buffer forms
     def ntt_host(self, cols, inverse=False):

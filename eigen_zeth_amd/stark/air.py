@@ -1,0 +1,209 @@
+"""AIR definitions and the constraint code generator.
+
+An AIR is a list of polynomial constraints over the trace columns at the current and the next
+row, fixed selector columns, public inputs and the evaluation point x.  Constraints are expression
+trees; `emit_quotient_source` turns them into one row-parallel kernel (HIP for the product, plain C
+for the CPU checker) that evaluates every constraint at an LDE row, combines them with powers of the
+F_{p^3} challenge alpha and multiplies by 1/Z_H(x) (periodic with the blow-up).  The reference has
+no counterpart (the prover is external to eigen-zeth); the request this serves is
+GenChunkProof (src/prover/provider.rs:358-377).
+
+Conventions: transition constraints hold on rows 0..N-2 and are multiplied by (x - w^(N-1));
+boundary constraints use the Lagrange selectors L_first / L_last (fixed columns 0 and 1).
+Maximum constraint degree 2 in the trace polynomials (+1 for the transition factor), so the
+quotient has degree < N and the blow-up can be 2.
+"""
+from __future__ import annotations
+
+import hashlib
+
+P = 0xFFFFFFFF00000001
+
+
+class Expr:
+    def __add__(self, o): return Op("add", self, wrap(o))
+    def __radd__(self, o): return Op("add", wrap(o), self)
+    def __sub__(self, o): return Op("sub", self, wrap(o))
+    def __rsub__(self, o): return Op("sub", wrap(o), self)
+    def __mul__(self, o): return Op("mul", self, wrap(o))
+    def __rmul__(self, o): return Op("mul", wrap(o), self)
+
+
+class Col(Expr):
+    def __init__(self, i, nxt=False): self.i, self.nxt = i, nxt
+    def key(self): return ("col", self.i, self.nxt)
+
+
+class Fixed(Expr):
+    def __init__(self, i): self.i = i
+    def key(self): return ("fixed", self.i)
+
+
+class Pub(Expr):
+    def __init__(self, i): self.i = i
+    def key(self): return ("pub", self.i)
+
+
+class Const(Expr):
+    def __init__(self, v): self.v = v % P
+    def key(self): return ("const", self.v)
+
+
+class XMinusLast(Expr):
+    """x - w^(N-1): vanishes on the last trace row only"""
+    def key(self): return ("xml",)
+
+
+class Op(Expr):
+    def __init__(self, op, a, b): self.op, self.a, self.b = op, a, b
+    def key(self): return (self.op, self.a.key(), self.b.key())
+
+
+def wrap(v):
+    return v if isinstance(v, Expr) else Const(int(v))
+
+
+L_FIRST, L_LAST = Fixed(0), Fixed(1)
+
+
+class Air:
+    """name, width, number of public inputs, constraint list (transition constraints already carry
+    their XMinusLast factor)."""
+
+    def __init__(self, name, width, n_pub, constraints, trace_kind):
+        self.name, self.width, self.n_pub = name, width, n_pub
+        self.constraints = constraints
+        self.trace_kind = trace_kind  # id understood by zp_synth_trace
+        self.n_fixed = 2
+
+    def digest(self):
+        h = hashlib.sha256(repr([c.key() for c in self.constraints]).encode()).hexdigest()
+        return h[:16]
+
+    @property
+    def symbol(self):
+        return "zpair_%s_quotient" % self.name
+
+
+def transition(e):
+    return e * XMinusLast()
+
+
+def fibonacci_air():
+    """a' = b, b' = a + b; a[0] = pub0, b[0] = pub1, b[N-1] = pub2"""
+    a, b, an, bn = Col(0), Col(1), Col(0, True), Col(1, True)
+    cs = [transition(an - b), transition(bn - (a + b)),
+          L_FIRST * (a - Pub(0)), L_FIRST * (b - Pub(1)), L_LAST * (b - Pub(2))]
+    return Air("fib", 2, 3, cs, trace_kind=0)
+
+
+def wide_air(width):
+    """width columns, degree-2 mixing:  c_i' = c_i * c_(i+1) + c_(i+2) + i   (indices mod width);
+    c_i[0] = pub_i for i < 4.  Stands in for the width of a zkEVM chunk trace."""
+    cs = []
+    for i in range(width):
+        c, c1, c2 = Col(i), Col((i + 1) % width), Col((i + 2) % width)
+        cs.append(transition(Col(i, True) - (c * c1 + c2 + Const(i))))
+    for i in range(min(4, width)):
+        cs.append(L_FIRST * (Col(i) - Pub(i)))
+    return Air("wide%d" % width, width, min(4, width), cs, trace_kind=1)
+
+
+BUILTIN_AIRS = {"fib": fibonacci_air, "wide8": lambda: wide_air(8), "wide32": lambda: wide_air(32),
+                "wide64": lambda: wide_air(64)}
+
+
+def get_air(name):
+    return BUILTIN_AIRS[name]()
+
+
+# ---------------------------------------------------------------------------------- code generation
+class _Emitter:
+    """common-subexpression-eliminating emitter of straight-line code over u64 field elements"""
+
+    def __init__(self):
+        self.lines, self.memo, self.n = [], {}, 0
+        self.cols, self.fixed = set(), set()
+
+    def tmp(self, expr_c):
+        name = "t%d" % self.n
+        self.n += 1
+        self.lines.append("    const u64 %s = %s;" % (name, expr_c))
+        return name
+
+    def emit(self, e):
+        k = e.key()
+        if k in self.memo:
+            return self.memo[k]
+        if isinstance(e, Col):
+            self.cols.add((e.i, e.nxt))
+            r = "c%d%s" % (e.i, "n" if e.nxt else "")
+        elif isinstance(e, Fixed):
+            self.fixed.add(e.i)
+            r = "f%d" % e.i
+        elif isinstance(e, Pub):
+            r = "pub[%d]" % e.i
+        elif isinstance(e, Const):
+            r = "%dULL" % e.v
+        elif isinstance(e, XMinusLast):
+            r = "xml"
+        else:
+            a, b = self.emit(e.a), self.emit(e.b)
+            r = self.tmp("gl_%s(%s, %s)" % (e.op, a, b))
+        self.memo[k] = r
+        return r
+
+
+def emit_quotient_source(air, target):
+    """target: 'hip' (device kernel + host launcher exported as air.symbol) or 'c' (OpenMP loop)"""
+    em = _Emitter()
+    outs = [em.emit(c) for c in air.constraints]
+    body = []
+    for (i, nxt) in sorted(em.cols):
+        body.append("    const u64 c%d%s = cols[(u64)%d * M + %s];" % (i, "n" if nxt else "", i, "rn" if nxt else "r"))
+    for i in sorted(em.fixed):
+        body.append("    const u64 f%d = fixedc[(u64)%d * M + r];" % (i, i))
+    body += em.lines
+    body.append("    u64 a0 = 0, a1 = 0, a2 = 0;")
+    for k, o in enumerate(outs):
+        body.append("    a0 = gl_add(a0, gl_mul(%s, apow[%d])); a1 = gl_add(a1, gl_mul(%s, apow[%d])); "
+                    "a2 = gl_add(a2, gl_mul(%s, apow[%d]));" % (o, 3 * k, o, 3 * k + 1, o, 3 * k + 2))
+    body.append("    const u64 zi = zhinv[r & (b - 1)];")
+    body.append("    out[r] = gl_mul(a0, zi); out[M + r] = gl_mul(a1, zi); out[2 * M + r] = gl_mul(a2, zi);")
+    body = "\n".join(body)
+    hdr = ("// generated by eigen_zeth_amd/stark/air.py for AIR '%s' (digest %s) -- do not edit\n"
+           "// row-parallel constraint evaluation + quotient: lane = LDE row, column reads coalesced.\n"
+           % (air.name, air.digest()))
+    args = ("const u64 *__restrict__ cols, const u64 *__restrict__ fixedc, u64 M, u64 b, const u64 *__restrict__ pub, "
+            "const u64 *__restrict__ apow, const u64 *__restrict__ zhinv, const u64 *__restrict__ xs_lo, "
+            "const u64 *__restrict__ xs_hi, int lb, u64 shift, u64 wlast, u64 *__restrict__ out")
+    xcode = ("    const u64 rn = (r + b) & (M - 1);\n"
+             "    const u64 x = gl_mul(shift, gl_mul(xs_lo[r & ((1ULL << lb) - 1)], xs_hi[r >> lb]));\n"
+             "    const u64 xml = gl_sub(x, wlast);\n")
+    if target == "hip":
+        return (hdr + '#include <hip/hip_runtime.h>\n#include "gl.hpp"\n'
+                "__global__ void __launch_bounds__(256) %s_kernel(%s) {\n"
+                "    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (r >= M) return;\n%s%s\n}\n"
+                'extern "C" int %s(void *stream, %s) {\n'
+                "    hipLaunchKernelGGL(%s_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,\n"
+                "                       cols, fixedc, M, b, pub, apow, zhinv, xs_lo, xs_hi, lb, shift, wlast, out);\n"
+                "    return (int)hipGetLastError();\n}\n"
+                % (air.symbol, args, xcode, body, air.symbol, args, air.symbol))
+    return (hdr + '#include "gl_field.h"\n'
+            "void %s(%s) {\n#pragma omp parallel for schedule(static)\n"
+            "    for (u64 r = 0; r < M; r++) {\n%s%s\n    }\n}\n"
+            % (air.symbol, args.replace("__restrict__", "restrict"), xcode, body))
+
+
+# ---------------------------------------------------------------------------------- evaluation over F_{p^3}
+def eval_constraints_ext(air, col_at, col_next_at, fixed_at, pubs, xml, mul, add, sub, embed):
+    """used by verifiers: evaluate every constraint with arbitrary field callbacks"""
+    def ev(e):
+        if isinstance(e, Col): return (col_next_at if e.nxt else col_at)[e.i]
+        if isinstance(e, Fixed): return fixed_at[e.i]
+        if isinstance(e, Pub): return embed(pubs[e.i])
+        if isinstance(e, Const): return embed(e.v)
+        if isinstance(e, XMinusLast): return xml
+        a, b = ev(e.a), ev(e.b)
+        return {"add": add, "sub": sub, "mul": mul}[e.op](a, b)
+    return [ev(c) for c in air.constraints]

@@ -1,0 +1,124 @@
+"""GPU backend of the STARK prover: every method is one or two C-ABI calls on device-resident data.
+No CPU fallback: construction fails without libzethprover.so and an MI355X."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import native
+from . import build_airs
+
+_u64p = C.POINTER(C.c_uint64)
+
+
+class Commit:
+    def __init__(self, root, tree, ext=None, coef=None):
+        self.root, self.tree, self.ext, self.coef = root, tree, ext, coef
+
+
+class HipBackend:
+    def __init__(self, device=0, prover=None):
+        self.p = prover or native.Prover(device)
+        self.root32 = int(self.p.get_constants(native.ZP_CONST_ROOT32, 1)[0])
+        self.shift = int(self.p.get_constants(native.ZP_CONST_COSET_SHIFT, 1)[0])
+        self._fixed = {}
+        self._airlibs = {}
+        self._perm_buf = self.p.alloc(12)
+
+    def sync(self):
+        self.p.sync()
+
+    # ---- transcript permutation (one tiny launch)
+    def poseidon_perm(self, state):
+        self.p.h2d(self._perm_buf, np.array(state, dtype=np.uint64))
+        self.p.poseidon_perm(self._perm_buf, 1)
+        return [int(v) for v in self.p.download(self._perm_buf, (12,))]
+
+    # ---- commitments
+    def _root(self, tree, M):
+        return [int(v) for v in self.p.download(tree, (4,), offset_elems=(2 * M - 2) * 4)]
+
+    def commit_trace(self, trace, logn, logb):
+        W = trace.shape[0]
+        M = 1 << (logn + logb)
+        d_tr = self.p.upload(trace)
+        ext, coef, tree = self.p.alloc(W * M), self.p.alloc(W << logn), self.p.alloc((2 * M - 1) * 4)
+        self.p.lde(d_tr, ext, logn, logb, W, self.shift, d_coef=coef)
+        self.p.merkle_commit(ext, M, W, tree)
+        d_tr.free()
+        return Commit(self._root(tree, M), tree, ext, coef)
+
+    def commit_cols(self, d_cols, M, W):
+        tree = self.p.alloc((2 * M - 1) * 4)
+        self.p.merkle_commit(d_cols, M, W, tree)
+        return Commit(self._root(tree, M), tree)
+
+    def fixed_ext(self, logn, logb):
+        key = (logn, logb)
+        if key not in self._fixed:
+            N = 1 << logn
+            ind = np.zeros((2, N), dtype=np.uint64)
+            ind[0, 0] = 1
+            ind[1, N - 1] = 1
+            d_in = self.p.upload(ind)
+            d_out = self.p.alloc(2 << (logn + logb))
+            self.p.lde(d_in, d_out, logn, logb, 2, self.shift)
+            d_in.free()
+            self._fixed[key] = d_out
+        return self._fixed[key]
+
+    # ---- N4: generated constraint kernel
+    def _airlib(self, air):
+        if air.name not in self._airlibs:
+            lib = C.CDLL(build_airs.build_air(air))
+            fn = getattr(lib, air.symbol)
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_int, C.c_uint64,
+                                                                                                 C.c_uint64, C.c_void_p]
+            self._airlibs[air.name] = fn
+        return self._airlibs[air.name]
+
+    def quotient(self, air, c1, fixed, pubs, apow, zhinv, logn, logb, wlast):
+        M = 1 << (logn + logb)
+        fn = self._airlib(air)
+        d_pub = self.p.upload(np.array(list(pubs) + [0], dtype=np.uint64))
+        d_ap = self.p.upload(np.array(apow, dtype=np.uint64).reshape(-1))
+        d_zh = self.p.upload(np.array(zhinv, dtype=np.uint64))
+        lo, hi, lb = self.p.domain_tables(logn + logb)
+        out = self.p.alloc(3 * M)
+        rc = fn(None, c1.ext.ptr, fixed.ptr, M, 1 << logb, d_pub.ptr, d_ap.ptr, d_zh.ptr, lo, hi, lb, self.shift,
+                wlast, out.ptr)
+        if rc != 0:
+            raise native.ZpError(-2, "constraint kernel launch failed (hip error %d)" % rc)
+        self.p.sync()
+        for b in (d_pub, d_ap, d_zh):
+            b.free()
+        return out
+
+    def coset_coefficients(self, d_planes, logm, W):
+        out = self.p.alloc(W << logm)
+        self.p.intt(d_planes, out, logm, W)
+        return out
+
+    def eval_ext(self, d_coef, logn, W, point):
+        return self.p.poly_eval_ext(d_coef, logn, W, point)
+
+    def deep(self, d_a, Wa, d_b, Wb, logm, n_next, z, zw, gamma, ev_z, ev_zw):
+        out = self.p.alloc(3 << logm)
+        self.p.deep_quotient(d_a, Wa, d_b, Wb, logm, n_next, z, zw, gamma, ev_z, ev_zw, self.shift, out)
+        return out
+
+    def fri_fold(self, d_in, logn, logf, beta, shift):
+        out = self.p.alloc(3 << (logn - logf))
+        self.p.fri_fold(d_in, out, logn, logf, beta, shift)
+        return out
+
+    def download(self, d, shape):
+        return self.p.download(d, shape)
+
+    def gather_rows(self, d_cols, M, W, idx):
+        return self.p.gather_rows(d_cols, M, W, idx)
+
+    def open_paths(self, tree, M, idx):
+        return self.p.merkle_open_batch(tree, M, idx)

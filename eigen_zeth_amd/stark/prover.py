@@ -1,0 +1,171 @@
+"""Chunk STARK prover: trace -> LDE -> commit -> constraint quotient -> commit -> out-of-domain
+evaluations -> DEEP quotient -> FRI -> query openings.  Backend-agnostic orchestration; every
+O(trace) step is one backend call (GPU backend: backend_hip.py, one C-ABI call each).
+
+Serves GenChunkProof (proto/prover/v1/prover.proto:56-66; client src/prover/provider.rs:358-390).
+The protocol follows the public DEEP-FRI STARK construction; it is NOT
+claimed bit-compatible with the external eigen-zkvm prover (parity unpinned)."""
+from __future__ import annotations
+
+import json
+import time
+
+from . import field as F
+from .transcript import Transcript
+
+P = F.P
+
+
+class StarkParams:
+    def __init__(self, logn, logb=1, fri_logf=3, fri_final_log=6, n_queries=24):
+        self.logn, self.logb = logn, logb
+        self.fri_logf, self.fri_final_log, self.n_queries = fri_logf, fri_final_log, n_queries
+
+    def to_dict(self):
+        return dict(logn=self.logn, logb=self.logb, fri_logf=self.fri_logf, fri_final_log=self.fri_final_log,
+                    n_queries=self.n_queries)
+
+    @staticmethod
+    def from_dict(d):
+        return StarkParams(d["logn"], d["logb"], d["fri_logf"], d["fri_final_log"], d["n_queries"])
+
+    def fri_schedule(self):
+        """list of (log size of the layer that is committed and folded, log fold factor)"""
+        logm = self.logn + self.logb
+        sched = []
+        cur = logm
+        while cur > self.fri_final_log + self.logb:
+            f = min(self.fri_logf, cur - (self.fri_final_log + self.logb))
+            sched.append((cur, f))
+            cur -= f
+        return sched, cur
+
+
+def _ints(a):
+    return [int(v) for v in a]
+
+
+def prove(air, trace, pubs, params, be, timings=None):
+    """trace: uint64 [W][N] host array (the witness), pubs: public inputs; be: backend."""
+    t_all = time.perf_counter()
+    tm = {} if timings is None else timings
+
+    def tick(name, t0):
+        be.sync()
+        tm[name] = tm.get(name, 0.0) + (time.perf_counter() - t0)
+
+    logn, logb = params.logn, params.logb
+    logm = logn + logb
+    N, M, W = 1 << logn, 1 << logm, air.width
+    assert trace.shape == (W, N)
+    shift, root32 = be.shift, be.root32
+    wN = F.root(logn, root32)
+    tr = Transcript(be.poseidon_perm)
+    tr.absorb([logn, logb, W] + _ints(pubs))
+
+    # 1. commit the trace
+    t0 = time.perf_counter()
+    c1 = be.commit_trace(trace, logn, logb)
+    tick("lde+merkle(trace)", t0)
+    tr.absorb(c1.root)
+    alpha = tr.challenge_e3()
+
+    # 2. constraint quotient on the coset, committed as 3 base columns
+    t0 = time.perf_counter()
+    fixed = be.fixed_ext(logn, logb)
+    K = len(air.constraints)
+    apow, cur = [], [1, 0, 0]
+    for _ in range(K):
+        apow.append(cur)
+        cur = F.e3_mul(cur, alpha)
+    sN = pow(shift, N, P)
+    wb = F.root(logb, root32)
+    zhinv = [F.inv((sN * pow(wb, j, P) - 1) % P) for j in range(1 << logb)]
+    d_q = be.quotient(air, c1, fixed, pubs, apow, zhinv, logn, logb, F.inv(wN))
+    tick("quotient", t0)
+    t0 = time.perf_counter()
+    cq = be.commit_cols(d_q, M, 3)
+    d_qcoef = be.coset_coefficients(d_q, logm, 3)   # coefficients of q_c(shift * X)
+    tick("merkle+intt(quotient)", t0)
+    tr.absorb(cq.root)
+    zeta = tr.challenge_e3()
+
+    # 3. out-of-domain evaluations
+    t0 = time.perf_counter()
+    zeta_w = F.e3_scale(zeta, wN)
+    ev_z = be.eval_ext(c1.coef, logn, W, zeta)
+    ev_zw = be.eval_ext(c1.coef, logn, W, zeta_w)
+    ev_q = be.eval_ext(d_qcoef, logm, 3, F.e3_scale(zeta, F.inv(shift)))
+    tick("ood-evals", t0)
+    ev_all = [_ints(r) for r in ev_z] + [_ints(r) for r in ev_q]
+    ev_next = [_ints(r) for r in ev_zw]
+    for r in ev_all + ev_next:
+        tr.absorb(r)
+    gamma = tr.challenge_e3()
+
+    # 4. DEEP quotient
+    t0 = time.perf_counter()
+    d_f = be.deep(c1.ext, W, d_q, 3, logm, W, zeta, zeta_w, gamma, ev_all, ev_next)
+    tick("deep", t0)
+
+    # 5. FRI
+    t0 = time.perf_counter()
+    sched, final_log = params.fri_schedule()
+    layers = []
+    cur_shift = shift
+    d_layer = d_f
+    for (lg, f) in sched:
+        com = be.commit_cols(d_layer, 1 << (lg - f), 3 << f)   # leaf = the 2^f * 3 values folded together
+        tr.absorb(com.root)
+        beta = tr.challenge_e3()
+        d_next = be.fri_fold(d_layer, lg, f, beta, cur_shift)
+        layers.append((lg, f, com, d_layer))
+        d_layer = d_next
+        cur_shift = pow(cur_shift, 1 << f, P)
+    final = be.download(d_layer, (3, 1 << final_log))
+    tick("fri", t0)
+    final_l = [_ints(final[c]) for c in range(3)]
+    for c in range(3):
+        tr.absorb(final_l[c])
+
+    # 6. queries
+    t0 = time.perf_counter()
+    qidx = tr.indices(params.n_queries, logm)
+    q_trace_vals = be.gather_rows(c1.ext, M, W, qidx)
+    q_trace_paths = be.open_paths(c1.tree, M, qidx)
+    q_q_vals = be.gather_rows(d_q, M, 3, qidx)
+    q_q_paths = be.open_paths(cq.tree, M, qidx)
+    fri_open = []
+    pos = list(qidx)
+    for (lg, f, com, d_l) in layers:
+        m = 1 << (lg - f)
+        rows = [p & (m - 1) for p in pos]
+        vals = be.gather_rows(d_l, m, 3 << f, rows)
+        paths = be.open_paths(com.tree, m, rows)
+        fri_open.append((rows, vals, paths))
+        pos = rows
+    tick("queries", t0)
+
+    queries = []
+    for i, j in enumerate(qidx):
+        queries.append({
+            "index": int(j),
+            "trace": {"values": _ints(q_trace_vals[i]), "path": [_ints(x) for x in q_trace_paths[i]]},
+            "quotient": {"values": _ints(q_q_vals[i]), "path": [_ints(x) for x in q_q_paths[i]]},
+            "fri": [{"values": _ints(fo[1][i]), "path": [_ints(x) for x in fo[2][i]]} for fo in fri_open],
+        })
+    proof = {
+        "air": air.name, "air_digest": air.digest(), "params": params.to_dict(),
+        "root32": int(root32), "shift": int(shift),
+        "publics": _ints(pubs),
+        "roots": {"trace": _ints(c1.root), "quotient": _ints(cq.root)},
+        "evals": {"z": ev_all, "zw": ev_next},
+        "fri": {"roots": [_ints(l[2].root) for l in layers], "final": final_l},
+        "queries": queries,
+    }
+    tm["total"] = time.perf_counter() - t_all
+    return proof
+
+
+def proof_to_json(proof):
+    return json.dumps(proof, separators=(",", ":"))

@@ -95,6 +95,41 @@ int32_t zp_merkle_open(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx
 int32_t zp_fri_fold(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t logf,
                     const uint64_t beta[3], uint64_t shift);
 
+/* ---- STARK stages around the committed columns (N4/N5 support) -------------------------------
+ * zp_poly_eval_ext: p_c(z) for W polynomials with base-field coefficients u64[W][2^logn]
+ *   (ascending) at the F_{p^3} point z; h_out[W][3].
+ * zp_deep_quotient: on x = shift*w_M^r, r < 2^logm,
+ *   F(x) = sum_{k<Wa+Wb} g^k (p_k(x)-e_k)/(x-z) + sum_{k<n_next} g^(Wa+Wb+k) (p_k(x)-e'_k)/(x-zw)
+ *   p_k = columns of d_cols_a (k<Wa) then d_cols_b; e = h_ev_z[Wa+Wb][3], e' = h_ev_zw[n_next][3];
+ *   d_out u64[3][2^logm].
+ * zp_gather_rows: h_out[nq][W] = row h_idx[q] of the column-major matrix (query openings).
+ * zp_merkle_open_batch: h_paths[nq][log2 M][4], bottom-up siblings for every queried leaf.        */
+int32_t zp_poly_eval_ext(zp_ctx *ctx, const uint64_t *d_coef, int32_t logn, int32_t W, const uint64_t z[3],
+                         uint64_t *h_out);
+int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, const uint64_t *d_cols_b, int32_t Wb,
+                         int32_t logm, int32_t n_next, const uint64_t z[3], const uint64_t zw[3],
+                         const uint64_t gamma[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t shift,
+                         uint64_t *d_out);
+int32_t zp_gather_rows(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, const uint64_t *h_idx, int32_t nq,
+                       uint64_t *h_out);
+int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, const uint64_t *h_idx, int32_t nq,
+                             uint64_t *h_paths);
+
+/* ---- AIR plug-in ABI (N4: row-parallel constraint evaluation + quotient) ---------------------------
+ * Constraint kernels are generated per AIR (eigen_zeth_amd/stark/air.py -> generated/<air>.hip) and
+ * built into libzpair_<air>.so, each exporting
+ *   int zpair_<air>_quotient(void *hip_stream, const u64 *d_cols, const u64 *d_fixed, u64 M, u64 blowup,
+ *        const u64 *d_pub, const u64 *d_alpha_pows, const u64 *d_zhinv, const u64 *d_xs_lo,
+ *        const u64 *d_xs_hi, int lb, u64 shift, u64 w_last, u64 *d_out);
+ *   d_cols [W][M] LDE of the trace, d_fixed [2][M] LDE of L_first/L_last, d_alpha_pows [K][3],
+ *   d_zhinv [blowup] = 1/Z_H on the coset (periodic), d_out [3][M] = quotient planes.
+ * zp_domain_tables hands such kernels the ctx-owned two-level table of w_M^e (x = shift*lo[e&mask]*hi[e>>lb]). */
+int32_t zp_domain_tables(zp_ctx *ctx, int32_t logm, const uint64_t **d_lo, const uint64_t **d_hi, int32_t *lb);
+/* synthetic witness generation (stands in for the zkVM executor, which is not obtainable offline):
+ * kind 0 = Fibonacci (W=2), kind 1 = wide degree-2 mix (any W >= 3).  h_trace u64[W][2^logn],
+ * h_pub receives the public inputs (3 for kind 0, min(4,W) for kind 1).  Host code.                 */
+int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uint64_t *h_trace, uint64_t *h_pub);
+
 /* ---- host-buffer conveniences (H2D + compute + D2H + sync), the form a non-GPU-aware host uses */
 int32_t zp_ntt_host(zp_ctx *ctx, uint64_t *h_cols, int32_t logn, int32_t W, int32_t inverse);
 int32_t zp_lde_host(zp_ctx *ctx, const uint64_t *h_in, uint64_t *h_out, int32_t logn, int32_t logb,

@@ -356,6 +356,9 @@ void orc_fri_fold(const u64 *in, u64 *out, int logn, int logf, const u64 *beta3,
     u64 wf_inv = gl_inv(orc_root(root32, logf));
     u64 finv = gl_inv((u64)f);
     e3 beta = {{beta3[0], beta3[1], beta3[2]}};
+    u64 wfp[64];
+    wfp[0] = 1;
+    for (size_t k = 1; k < f; k++) wfp[k] = gl_mul(wfp[k - 1], wf_inv);
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < m; i++) {
         e3 v[64], cof[64];
@@ -364,7 +367,7 @@ void orc_fri_fold(const u64 *in, u64 *out, int logn, int logf, const u64 *beta3,
         /* naive inverse DFT of size f (f <= 64): cof_j = 1/f * sum_k v_k wf^(-jk) */
         for (size_t j = 0; j < f; j++) {
             e3 acc = {{0, 0, 0}};
-            for (size_t k = 0; k < f; k++) acc = e3_add(acc, e3_scale(v[k], gl_pow(wf_inv, (j * k) % f)));
+            for (size_t k = 0; k < f; k++) acc = e3_add(acc, e3_scale(v[k], wfp[(j * k) % f]));
             cof[j] = e3_scale(acc, finv);
         }
         /* unscale the coset: h_i coefficient j = cof_j / (shift*w_n^i)^j */
@@ -378,6 +381,50 @@ void orc_fri_fold(const u64 *in, u64 *out, int logn, int logf, const u64 *beta3,
         }
         for (int c = 0; c < 3; c++) out[(size_t)c * m + i] = acc.c[c];
     }
+}
+
+/* ------------------------------------------------------------------ DEEP quotient (definition level)
+ * F(x) = sum_{k<Wa+Wb} g^k (p_k(x)-e_k)/(x-z) + sum_{k<n_next} g^(Wa+Wb+k) (p_k(x)-e'_k)/(x-zw),
+ * x = shift*w_M^r.  Every term is divided separately (inverse by a^(p^3-2)).                     */
+static e3 e3_inv_pow(e3 a) {
+    /* p^3 - 2, little-endian 64-bit limbs */
+    static const u64 E[3] = {0xfffffffcffffffffULL, 0xfffffff900000005ULL, 0xfffffffd00000005ULL};
+    return e3_pow(a, E);
+}
+void orc_e3_inv(const u64 *a, u64 *out) {
+    e3 x = {{a[0], a[1], a[2]}};
+    e3 r = e3_inv_pow(x);
+    out[0] = r.c[0]; out[1] = r.c[1]; out[2] = r.c[2];
+}
+void orc_deep_quotient(const u64 *cols_a, int Wa, const u64 *cols_b, int Wb, int logm, int n_next,
+                       const u64 *z, const u64 *zw, const u64 *gamma, const u64 *ev_z, const u64 *ev_zw,
+                       u64 shift, u64 root32, u64 *out) {
+    size_t M = (size_t)1 << logm;
+    int W = Wa + Wb;
+    u64 wm = orc_root(root32, logm);
+    e3 g = {{gamma[0], gamma[1], gamma[2]}};
+    e3 *gp = (e3 *)malloc((size_t)(W + n_next) * sizeof(e3));
+    e3 cur = {{1, 0, 0}};
+    for (int k = 0; k < W + n_next; k++) { gp[k] = cur; cur = e3_mul(cur, g); }
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < M; r++) {
+        u64 x = gl_mul(shift, gl_pow(wm, r));
+        e3 d1 = {{gl_sub(x, z[0]), gl_neg(z[1]), gl_neg(z[2])}};
+        e3 d2 = {{gl_sub(x, zw[0]), gl_neg(zw[1]), gl_neg(zw[2])}};
+        e3 i1 = e3_inv_pow(d1), i2 = e3_inv_pow(d2);
+        e3 acc = {{0, 0, 0}};
+        for (int k = 0; k < W; k++) {
+            u64 v = k < Wa ? cols_a[(size_t)k * M + r] : cols_b[(size_t)(k - Wa) * M + r];
+            e3 num = {{gl_sub(v, ev_z[k * 3]), gl_neg(ev_z[k * 3 + 1]), gl_neg(ev_z[k * 3 + 2])}};
+            acc = e3_add(acc, e3_mul(gp[k], e3_mul(num, i1)));
+            if (k < n_next) {
+                e3 n2 = {{gl_sub(v, ev_zw[k * 3]), gl_neg(ev_zw[k * 3 + 1]), gl_neg(ev_zw[k * 3 + 2])}};
+                acc = e3_add(acc, e3_mul(gp[W + k], e3_mul(n2, i2)));
+            }
+        }
+        for (int c = 0; c < 3; c++) out[(size_t)c * M + r] = acc.c[c];
+    }
+    free(gp);
 }
 
 /* ------------------------------------------------------------------ polynomial helpers used by tests */
@@ -395,6 +442,65 @@ void orc_poly_eval_e3(const u64 *coef, size_t n, const u64 *x3, u64 *out3) {
         acc.c[0] = gl_add(acc.c[0], coef[i]);
     }
     out3[0] = acc.c[0]; out3[1] = acc.c[1]; out3[2] = acc.c[2];
+}
+
+/* W polynomials (base coefficients u64[W][n]) at an F_{p^3} point: out[W][3] (Horner) */
+void orc_poly_eval_e3_cols(const u64 *coef, size_t n, int W, const u64 *x3, u64 *out) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int c = 0; c < W; c++) orc_poly_eval_e3(coef + (size_t)c * n, n, x3, out + 3 * c);
+}
+
+/* same DEEP quotient with the adjugate inverse (fast path for the CPU baseline; the pow-based
+ * orc_deep_quotient above stays the definition it is tested against) */
+static e3 e3_inv_adj(e3 a) {
+    u64 a0 = a.c[0], a1 = a.c[1], a2 = a.c[2];
+    u64 s02 = gl_add(a0, a2), s12 = gl_add(a1, a2);
+    u64 c00 = gl_sub(gl_mul(s02, s02), gl_mul(s12, a1));
+    u64 c01 = gl_sub(gl_mul(s12, a2), gl_mul(a1, s02));
+    u64 c02 = gl_sub(gl_mul(a1, a1), gl_mul(s02, a2));
+    u64 det = gl_add(gl_add(gl_mul(a0, c00), gl_mul(a2, c01)), gl_mul(a1, c02));
+    u64 di = gl_inv(det);
+    e3 r = {{gl_mul(c00, di), gl_mul(c01, di), gl_mul(c02, di)}};
+    return r;
+}
+void orc_deep_quotient_fast(const u64 *cols_a, int Wa, const u64 *cols_b, int Wb, int logm, int n_next,
+                            const u64 *z, const u64 *zw, const u64 *gamma, const u64 *ev_z, const u64 *ev_zw,
+                            u64 shift, u64 root32, u64 *out) {
+    size_t M = (size_t)1 << logm;
+    int W = Wa + Wb;
+    u64 wm = orc_root(root32, logm);
+    e3 g = {{gamma[0], gamma[1], gamma[2]}};
+    e3 *gp = (e3 *)malloc((size_t)(W + n_next) * sizeof(e3));
+    e3 cur = {{1, 0, 0}}, ca = {{0, 0, 0}}, cb = {{0, 0, 0}};
+    for (int k = 0; k < W + n_next; k++) {
+        gp[k] = cur;
+        if (k < W) { e3 e = {{ev_z[3 * k], ev_z[3 * k + 1], ev_z[3 * k + 2]}}; ca = e3_add(ca, e3_mul(cur, e)); }
+        else { int j = k - W; e3 e = {{ev_zw[3 * j], ev_zw[3 * j + 1], ev_zw[3 * j + 2]}}; cb = e3_add(cb, e3_mul(cur, e)); }
+        cur = e3_mul(cur, g);
+    }
+#pragma omp parallel
+    {
+#pragma omp for schedule(static)
+        for (size_t r = 0; r < M; r++) {
+            u64 x = gl_mul(shift, gl_pow(wm, r));
+            e3 A = {{0, 0, 0}}, B = {{0, 0, 0}};
+            for (int k = 0; k < W; k++) {
+                u64 v = k < Wa ? cols_a[(size_t)k * M + r] : cols_b[(size_t)(k - Wa) * M + r];
+                A = e3_add(A, e3_scale(gp[k], v));
+                if (k < n_next) B = e3_add(B, e3_scale(gp[W + k], v));
+            }
+            A = e3_sub(A, ca);
+            B = e3_sub(B, cb);
+            e3 d1 = {{gl_sub(x, z[0]), gl_neg(z[1]), gl_neg(z[2])}};
+            e3 Fv = e3_mul(A, e3_inv_adj(d1));
+            if (n_next > 0) {
+                e3 d2 = {{gl_sub(x, zw[0]), gl_neg(zw[1]), gl_neg(zw[2])}};
+                Fv = e3_add(Fv, e3_mul(B, e3_inv_adj(d2)));
+            }
+            for (int c = 0; c < 3; c++) out[(size_t)c * M + r] = Fv.c[c];
+        }
+    }
+    free(gp);
 }
 
 int orc_num_threads(void) {

@@ -58,6 +58,10 @@ def lib():
         L.orc_merkle_verify.argtypes = [_u64p, sz, sz, _u64p, _u64p, _u64p, _u64p]
         L.orc_e3_mul.argtypes = [_u64p, _u64p, _u64p]
         L.orc_e3_pow.argtypes = [_u64p, _u64p, _u64p]
+        L.orc_e3_inv.argtypes = [_u64p, _u64p]
+        L.orc_deep_quotient.argtypes = [_u64p, i32, _u64p, i32, i32, i32, _u64p, _u64p, _u64p, _u64p, _u64p, u64, u64, _u64p]
+        L.orc_poly_eval_e3_cols.argtypes = [_u64p, sz, i32, _u64p, _u64p]
+        L.orc_deep_quotient_fast.argtypes = L.orc_deep_quotient.argtypes
         L.orc_fri_fold.argtypes = [_u64p, _u64p, i32, i32, _u64p, u64, u64]
         L.orc_poly_eval.restype = u64
         L.orc_poly_eval.argtypes = [_u64p, sz, u64]
@@ -162,6 +166,18 @@ def e3_inv(a):
     return out
 
 
+def deep_quotient(cols_a, cols_b, n_next, z, zw, gamma, ev_z, ev_zw, shift=SHIFT_DEFAULT, root32=ROOT32_DEFAULT, fast=False):
+    a = _arr(cols_a)
+    Wa, M = a.shape
+    b = _arr(cols_b) if cols_b is not None and len(cols_b) else np.zeros((1, M), dtype=np.uint64)
+    Wb = 0 if cols_b is None or len(cols_b) == 0 else b.shape[0]
+    out = np.empty((3, M), dtype=np.uint64)
+    ezw = _arr(ev_zw) if n_next else np.zeros((1, 3), dtype=np.uint64)
+    (lib().orc_deep_quotient_fast if fast else lib().orc_deep_quotient)(_p(a), Wa, _p(b), Wb, M.bit_length() - 1, n_next, _p(_arr(z)), _p(_arr(zw)),
+                            _p(_arr(gamma)), _p(_arr(ev_z)), _p(ezw), shift, root32, _p(out))
+    return out
+
+
 def fri_fold(planes, logf, beta, shift=SHIFT_DEFAULT, root32=ROOT32_DEFAULT):
     """planes: uint64 [3][n] -> uint64 [3][n >> logf]"""
     a = _arr(planes)
@@ -180,6 +196,14 @@ def poly_eval_e3(coef, x3):
     c = _arr(coef)
     out = np.empty(3, dtype=np.uint64)
     lib().orc_poly_eval_e3(_p(c), c.shape[0], _p(_arr(x3)), _p(out))
+    return out
+
+
+def poly_eval_e3_cols(coef, x3):
+    c = _arr(coef)
+    W, n = c.shape
+    out = np.empty((W, 3), dtype=np.uint64)
+    lib().orc_poly_eval_e3_cols(_p(c), n, W, _p(_arr(x3)), _p(out))
     return out
 
 

@@ -1,0 +1,117 @@
+"""oracle/stark_cpu.py -- CPU backend of the STARK prover built from the oracle primitives
+(TEST INFRASTRUCTURE: used by tests/ for bit-exact proof comparison and by bench.py's cpu_baseline
+leg).  It plugs into the same orchestration (eigen_zeth_amd/stark/prover.py) as the GPU backend,
+so a proof produced here and one produced on the MI355X from the same witness must be identical.
+PARITY UNPINNED with respect to the external reference prover (see gl_oracle.c)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import oracle as O
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_u64p = C.POINTER(C.c_uint64)
+
+
+class Commit:
+    def __init__(self, root, tree, ext=None, coef=None):
+        self.root, self.tree, self.ext, self.coef = root, tree, ext, coef
+
+
+def _air_cpu_lib(air):
+    from eigen_zeth_amd.stark.air import emit_quotient_source
+    bdir = os.path.join(_HERE, "_build")
+    os.makedirs(bdir, exist_ok=True)
+    src = os.path.join(bdir, "air_%s_%s.c" % (air.name, air.digest()))
+    out = src[:-2] + ".so"
+    if not os.path.exists(out):
+        with open(src, "w") as f:
+            f.write(emit_quotient_source(air, "c"))
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-I", _HERE, "-o", out, src])
+    fn = getattr(C.CDLL(out), air.symbol)
+    fn.restype = None
+    fn.argtypes = [_u64p, _u64p, C.c_uint64, C.c_uint64, _u64p, _u64p, _u64p, _u64p, _u64p, C.c_int, C.c_uint64,
+                   C.c_uint64, _u64p]
+    return fn
+
+
+class CpuBackend:
+    def __init__(self, rc, mds, root32=O.ROOT32_DEFAULT, shift=O.SHIFT_DEFAULT):
+        self.rc, self.mds = np.asarray(rc, dtype=np.uint64), np.asarray(mds, dtype=np.uint64)
+        self.root32, self.shift = root32, shift
+        self._fixed = {}
+
+    def sync(self):
+        pass
+
+    def poseidon_perm(self, state):
+        return [int(v) for v in O.poseidon_perm(np.array([state], dtype=np.uint64), self.rc, self.mds)[0]]
+
+    def commit_trace(self, trace, logn, logb):
+        ext = O.lde(trace, logb, self.shift, self.root32)
+        coef = O.intt(trace, self.root32)
+        tree = O.merkle_commit(ext, self.rc, self.mds)
+        return Commit([int(v) for v in tree[-1]], tree, ext, coef)
+
+    def commit_cols(self, cols, M, W):
+        mat = np.ascontiguousarray(np.asarray(cols).reshape(W, M))
+        tree = O.merkle_commit(mat, self.rc, self.mds)
+        return Commit([int(v) for v in tree[-1]], tree)
+
+    def fixed_ext(self, logn, logb):
+        key = (logn, logb)
+        if key not in self._fixed:
+            N = 1 << logn
+            ind = np.zeros((2, N), dtype=np.uint64)
+            ind[0, 0] = 1
+            ind[1, N - 1] = 1
+            self._fixed[key] = O.lde(ind, logb, self.shift, self.root32)
+        return self._fixed[key]
+
+    def quotient(self, air, c1, fixed, pubs, apow, zhinv, logn, logb, wlast):
+        logm = logn + logb
+        M = 1 << logm
+        fn = _air_cpu_lib(air)
+        lb = (logm + 1) // 2
+        w = O.lib().orc_root(self.root32, logm)
+        lo = np.array([pow(w, i, O.P) for i in range(1 << lb)], dtype=np.uint64)
+        wl = pow(w, 1 << lb, O.P)
+        hi = np.array([pow(wl, i, O.P) for i in range(1 << (logm - lb))], dtype=np.uint64)
+        out = np.empty((3, M), dtype=np.uint64)
+        pub = np.array(list(pubs) + [0], dtype=np.uint64)
+        ap = np.ascontiguousarray(np.array(apow, dtype=np.uint64).reshape(-1))
+        zh = np.array(zhinv, dtype=np.uint64)
+        fn(O._p(c1.ext), O._p(fixed), M, 1 << logb, O._p(pub), O._p(ap), O._p(zh), O._p(lo), O._p(hi), lb, self.shift,
+           wlast, O._p(out))
+        return out
+
+    def coset_coefficients(self, planes, logm, W):
+        return O.intt(np.asarray(planes).reshape(W, 1 << logm), self.root32)
+
+    def eval_ext(self, coef, logn, W, point):
+        return O.poly_eval_e3_cols(np.asarray(coef).reshape(W, 1 << logn), point)
+
+    def deep(self, a, Wa, b, Wb, logm, n_next, z, zw, gamma, ev_z, ev_zw):
+        return O.deep_quotient(np.asarray(a).reshape(Wa, 1 << logm), np.asarray(b).reshape(Wb, 1 << logm), n_next, z, zw,
+                               gamma, ev_z, ev_zw, self.shift, self.root32, fast=True)
+
+    def fri_fold(self, planes, logn, logf, beta, shift):
+        return O.fri_fold(np.asarray(planes).reshape(3, 1 << logn), logf, beta, shift, self.root32)
+
+    def download(self, d, shape):
+        return np.asarray(d).reshape(shape)
+
+    def gather_rows(self, cols, M, W, idx):
+        mat = np.asarray(cols).reshape(W, M)
+        return np.ascontiguousarray(mat[:, np.asarray(idx, dtype=np.int64)].T)
+
+    def open_paths(self, tree, M, idx):
+        depth = int(M).bit_length() - 1
+        out = np.zeros((len(idx), depth, 4), dtype=np.uint64)
+        for i, j in enumerate(idx):
+            out[i] = O.merkle_path(tree, int(j))
+        return out

@@ -1,0 +1,78 @@
+"""CPU tests of the STARK stage logic (no GPU): the orchestration + the independent verifier on the
+oracle backend, AIR code generation, transcript."""
+import copy
+
+import pytest
+
+from eigen_zeth_amd import native
+from eigen_zeth_amd.stark import air as AIR
+from eigen_zeth_amd.stark import prover as PR
+from eigen_zeth_amd.stark.transcript import Transcript
+from oracle import stark_verify as V
+from oracle.stark_cpu import CpuBackend
+
+
+@pytest.fixture(scope="module")
+def be(tables):
+    return CpuBackend(*tables)
+
+
+def test_synthetic_traces_satisfy_their_airs():
+    P = V.P
+    tr, pub = native.synth_trace(0, 6, 2, 1)
+    for i in range(63):
+        assert int(tr[0, i + 1]) == int(tr[1, i]) and int(tr[1, i + 1]) == (int(tr[0, i]) + int(tr[1, i])) % P
+    assert pub.tolist() == [int(tr[0, 0]), int(tr[1, 0]), int(tr[1, 63])]
+    tr, pub = native.synth_trace(1, 5, 6, 2)
+    for r in range(31):
+        for i in range(6):
+            assert int(tr[i, r + 1]) == (int(tr[i, r]) * int(tr[(i + 1) % 6, r]) + int(tr[(i + 2) % 6, r]) + i) % P
+    with pytest.raises(ValueError):
+        native.synth_trace(0, 6, 3, 1)
+
+
+def test_codegen_is_deterministic_and_shares_subexpressions():
+    a = AIR.wide_air(8)
+    src = AIR.emit_quotient_source(a, "hip")
+    assert src == AIR.emit_quotient_source(AIR.wide_air(8), "hip")
+    assert a.symbol in src and "__global__" in src
+    assert "omp parallel for" in AIR.emit_quotient_source(a, "c")
+    assert src.count("cols[(u64)0 * M + r]") == 1  # each column value is loaded once
+
+
+def test_transcript_is_deterministic_and_order_sensitive(be):
+    t1, t2, t3 = Transcript(be.poseidon_perm), Transcript(be.poseidon_perm), Transcript(be.poseidon_perm)
+    t1.absorb([1, 2, 3]); t2.absorb([1, 2, 3]); t3.absorb([3, 2, 1])
+    a, b, c = t1.squeeze(5), t2.squeeze(5), t3.squeeze(5)
+    assert a == b and a != c
+    assert t1.squeeze(9) == t2.squeeze(9)
+
+
+@pytest.mark.parametrize("name,logn", [("fib", 5), ("wide8", 7)])
+def test_cpu_proof_verifies_and_tampering_is_rejected(be, tables, name, logn):
+    rc, mds = tables
+    air = AIR.get_air(name)
+    tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 77)
+    proof = PR.prove(air, tr, pub, PR.StarkParams(logn, 1, 3, 3, 6), be)
+    assert V.verify(proof, air, rc, mds)
+    for mutate in (lambda p: p["evals"]["zw"][0].__setitem__(1, 5),
+                   lambda p: p["roots"]["trace"].__setitem__(0, 1),
+                   lambda p: p["publics"].__setitem__(0, 7),
+                   lambda p: p["queries"][0]["quotient"]["values"].__setitem__(2, 9),
+                   lambda p: p["queries"][2]["fri"][0]["path"][0].__setitem__(0, 3)):
+        bad = copy.deepcopy(proof)
+        mutate(bad)
+        with pytest.raises(V.Reject):
+            V.verify(bad, air, rc, mds)
+    with pytest.raises(V.Reject):
+        V.verify(proof, AIR.get_air("wide32"), rc, mds)
+
+
+def test_wrong_witness_cannot_be_proven(be, tables):
+    rc, mds = tables
+    air = AIR.get_air("fib")
+    tr, pub = native.synth_trace(0, 6, 2, 5)
+    tr[0, 9] ^= 1
+    proof = PR.prove(air, tr, pub, PR.StarkParams(6, 1, 3, 3, 6), be)
+    with pytest.raises(V.Reject):
+        V.verify(proof, air, rc, mds)
