@@ -1,0 +1,29 @@
+"""python -m eigen_zeth_amd.service [--port 50061] [--state-dir DIR] [--air wide32] [--logn 20]"""
+import argparse
+import time
+
+from .engine import EngineConfig
+from .server import serve
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--host", default="127.0.0.1")
+    ap.add_argument("--port", type=int, default=50061)   # PROVER_ADDR default, src/config/env.rs:21
+    ap.add_argument("--state-dir", default="prover_state")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--air", default="wide32")
+    ap.add_argument("--logn", type=int, default=16)
+    ap.add_argument("--chunks-per-block", type=int, default=1)
+    a = ap.parse_args()
+    server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, chunks_per_block=a.chunks_per_block), a.device)
+    print("prover.v1.ProverService listening on %s:%d" % (a.host, port), flush=True)
+    try:
+        while True:
+            time.sleep(3600)
+    except KeyboardInterrupt:
+        server.stop(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""What the four ProverStream requests compute (prover.proto:49-66,115-148).
+
+GenBatchChunks : synthetic executor -- the real zkVM executor/EVM program is not obtainable offline
+                 (SURVEY.md par.7); every block becomes `chunks_per_block` chunks of a synthetic AIR.
+GenChunkProof  : one real STARK per chunk on the GPU backend (eigen_zeth_amd/stark).
+GenAggregated  : structural stand-in for the recursive aggregation circuits (not built): binds the two
+                 proofs by digest.
+GenFinalProof  : structural stand-in for the Groth16 wrap: emits well-formed BN254 points in the exact
+                 JSON grammar eigen-zeth parses (src/settlement/ethereum/mod.rs:445-481); it is NOT a
+                 verifying Groth16 proof (no circuit / CRS exists offline) and says so in its own JSON.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import struct
+import time
+
+from ..stark import air as AIR
+from ..stark import prover as PR
+from .. import native
+from . import bn254
+
+
+class EngineConfig:
+    def __init__(self, air="wide32", logn=12, logb=1, chunks_per_block=1, n_queries=16, fri_logf=3, fri_final_log=5):
+        self.air, self.logn, self.logb = air, logn, logb
+        self.chunks_per_block, self.n_queries = chunks_per_block, n_queries
+        self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
+
+
+class Engine:
+    def __init__(self, backend_factory, config=None):
+        self._factory = backend_factory
+        self._be = None
+        self.cfg = config or EngineConfig()
+        self.stage_timings = {}
+
+    @property
+    def be(self):
+        if self._be is None:
+            self._be = self._factory()   # HipBackend(): raises without libzethprover.so / a GPU
+        return self._be
+
+    # ---- helpers
+    def _state_root(self, chain_id, block):
+        st = self.be.poseidon_perm([chain_id & 0xFFFFFFFFFFFFFFFF, block & 0xFFFFFFFFFFFFFFFF] + [0] * 10)
+        return b"".join(struct.pack("<Q", v) for v in st[:4])   # exactly 32 bytes (provider.rs:323-324)
+
+    # ---- GenBatchChunks
+    def gen_batch_chunks(self, batch_id, blocks, chain_id, program_name):
+        if not blocks:
+            raise ValueError("empty batch")
+        if program_name and program_name.lower() != "evm":
+            raise ValueError("unknown program %r (only 'evm' is served)" % program_name)
+        chunks = []
+        for b in blocks:
+            for c in range(self.cfg.chunks_per_block):
+                chunks.append({"block": int(b), "chunk": c, "air": self.cfg.air, "logn": self.cfg.logn,
+                               "seed": (int(chain_id) * 1000003 + int(b) * 1009 + c) & 0xFFFFFFFFFFFFFFFF})
+        batch_data = json.dumps({"version": 1, "chain_id": int(chain_id), "blocks": [int(b) for b in blocks],
+                                 "chunks": chunks}, separators=(",", ":"))
+        return {"task_id": str(int(blocks[0])).rjust(10, "0"),  # prover.proto:82-83
+                "chunk_count": len(chunks), "batch_data": batch_data,
+                "pre_state_root": self._state_root(chain_id, int(blocks[0]) - 1),
+                "post_state_root": self._state_root(chain_id, int(blocks[-1]))}
+
+    # ---- GenChunkProof
+    def gen_chunk_proofs(self, batch_id, task_id, chunk_count, batch_data):
+        plan = json.loads(batch_data)
+        chunks = plan["chunks"]
+        if len(chunks) != chunk_count:
+            raise ValueError("chunk_count %d does not match batch_data (%d chunks)" % (chunk_count, len(chunks)))
+        out = []
+        for i, ch in enumerate(chunks):
+            air = AIR.get_air(ch["air"])
+            tm = {}
+            t0 = time.perf_counter()
+            trace, pubs = native.synth_trace(air.trace_kind, ch["logn"], air.width, ch["seed"])
+            tm["witness(host)"] = time.perf_counter() - t0
+            params = PR.StarkParams(ch["logn"], self.cfg.logb, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.n_queries)
+            proof = PR.prove(air, trace, pubs, params, self.be, timings=tm)
+            proof["chunk"] = {"block": ch["block"], "chunk": ch["chunk"]}
+            self.stage_timings["%s/%d" % (task_id, i)] = tm
+            out.append({"chunk_id": i, "proof_key": "chunk-%s-%d" % (task_id, i), "proof": PR.proof_to_json(proof)})
+        return out
+
+    # ---- GenAggregatedProof
+    @staticmethod
+    def _digest(s):
+        return hashlib.sha256(s.encode()).hexdigest()
+
+    def aggregate(self, batch_id, p1, p2):
+        if not p1 or not p2:
+            raise ValueError("empty recursive proof")
+        return json.dumps({"kind": "aggregated-standin", "batch_id": batch_id,
+                           "inputs": [self._digest(p1), self._digest(p2)],
+                           "note": "recursive aggregation circuits are not built; this binds the two inputs by digest"},
+                          separators=(",", ":"))
+
+    # ---- GenFinalProof
+    def final(self, batch_id, recursive_proof, curve_name, aggregator_addr):
+        if (curve_name or "").upper() not in ("BN128", "BN254"):
+            raise ValueError("unsupported curve %r" % curve_name)
+        if not recursive_proof:
+            raise ValueError("empty recursive proof")
+        h = int(hashlib.sha256((recursive_proof + "|" + (aggregator_addr or "")).encode()).hexdigest(), 16)
+        k1, k2, k3 = (h % bn254.R) or 1, ((h >> 7) % bn254.R) or 1, ((h >> 13) % bn254.R) or 1
+        a, b, c = bn254.g1_mul(k1), bn254.g2_mul(k2), bn254.g1_mul(k3)
+        proof = {"pi_a": {"x": str(a[0]), "y": str(a[1])},
+                 "pi_b": {"x": [str(b[0][0]), str(b[0][1])], "y": [str(b[1][0]), str(b[1][1])]},
+                 "pi_c": {"x": str(c[0]), "y": str(c[1])},
+                 "protocol": "groth16", "curve": "BN128",
+                 "standin": "well-formed points only; the Groth16 circuit/CRS is not available offline"}
+        public_input = [str(h % bn254.R)]
+        return json.dumps(proof), json.dumps(public_input)

@@ -1,0 +1,173 @@
+"""prover.v1.ProverService server (proto/prover/v1/prover.proto:9-11).
+
+One bidi stream per client connection; the client keeps exactly one request in flight and matches
+responses by oneof type, ignoring `id` (src/prover/provider.rs:649-667), so a stream is served by one
+sequential loop.  Application errors are result_code = COMPLETED_ERROR + error_message (the client
+logs and retries, provider.rs:332-335); an OK response always carries 32-byte state roots, a
+non-empty chunk_proofs list and a final_proof (provider.rs:323-324,384-387,492-509)."""
+from __future__ import annotations
+
+import base64
+import os
+import time
+from concurrent import futures
+
+import grpc
+
+from . import proto
+from .engine import Engine, EngineConfig
+from .store import BatchStore
+
+VERSION = "zeth-prover-mi355x/0.1"
+
+
+class ProverService:
+    def __init__(self, engine, store):
+        self.engine, self.store = engine, store
+        self.last_id, self.last_end, self.cur_id, self.cur_start = "", 0, "", 0
+
+    # ---- the stream
+    def prover_stream(self, request_iterator, context):
+        for req in request_iterator:
+            kind = req.WhichOneof("request_type")
+            resp = proto.ProverResponse(id=req.id)
+            self.cur_id, self.cur_start = req.id, int(time.time())
+            try:
+                if kind == "get_status":
+                    self._status(resp)
+                elif kind == "gen_batch_proof":
+                    step = req.gen_batch_proof.WhichOneof("step")
+                    if step == "gen_batch_chunks":
+                        self._batch_chunks(req.gen_batch_proof.gen_batch_chunks, resp.gen_batch_proof.gen_batch_chunks)
+                    elif step == "gen_chunk_proof":
+                        self._chunk_proof(req.gen_batch_proof.gen_chunk_proof, resp.gen_batch_proof.gen_chunk_proof)
+                    else:
+                        r = resp.gen_batch_proof.gen_batch_chunks
+                        r.result_code, r.error_message = proto.COMPLETED_ERROR, "GenBatchProofRequest without a step"
+                elif kind == "gen_aggregated_proof":
+                    self._aggregate(req.gen_aggregated_proof, resp.gen_aggregated_proof)
+                elif kind == "gen_final_proof":
+                    self._final(req.gen_final_proof, resp.gen_final_proof)
+                else:
+                    self._status(resp, error="request without request_type")
+            finally:
+                self.last_id, self.last_end, self.cur_id = req.id, int(time.time()), ""
+            yield resp
+
+    # ---- handlers (idempotent per batch_id)
+    def _batch_chunks(self, q, r):
+        r.batch_id = q.batch_id
+        try:
+            rec = self.store.load(q.batch_id)
+            key = [list(q.batch.block_number), int(q.chain_id), q.program_name]
+            if rec.get("chunks_key") != key:
+                res = self.engine.gen_batch_chunks(q.batch_id, list(q.batch.block_number), q.chain_id, q.program_name)
+                rec = {"chunks_key": key,
+                       "chunks": {"task_id": res["task_id"], "chunk_count": res["chunk_count"], "batch_data": res["batch_data"],
+                                  "pre": base64.b64encode(res["pre_state_root"]).decode(),
+                                  "post": base64.b64encode(res["post_state_root"]).decode()}}
+                self.store.save(q.batch_id, rec)
+            c = rec["chunks"]
+            pre, post = base64.b64decode(c["pre"]), base64.b64decode(c["post"])
+            assert len(pre) == 32 and len(post) == 32
+            r.task_id, r.chunk_count, r.batch_data = c["task_id"], c["chunk_count"], c["batch_data"]
+            r.pre_state_root, r.post_state_root = pre, post
+            r.result_code = proto.COMPLETED_OK
+        except Exception as e:  # application error -> the client retries the same request
+            r.result_code, r.error_message = proto.COMPLETED_ERROR, "%s: %s" % (type(e).__name__, e)
+
+    def _chunk_proof(self, q, r):
+        r.batch_id, r.task_id = q.batch_id, q.task_id
+        try:
+            rec = self.store.load(q.batch_id)
+            key = [q.task_id, int(q.chunk_count), q.batch_data]
+            if rec.get("proofs_key") != key:
+                proofs = self.engine.gen_chunk_proofs(q.batch_id, q.task_id, int(q.chunk_count), q.batch_data)
+                if not proofs:
+                    raise ValueError("no chunks to prove")
+                rec["proofs_key"], rec["proofs"] = key, proofs
+                rec["timings"] = {k: v for k, v in self.engine.stage_timings.items() if k.startswith(q.task_id + "/")}
+                self.store.save(q.batch_id, rec)
+            r.batch_proof_result.task_id = q.task_id
+            for p in rec["proofs"]:
+                cp = r.batch_proof_result.chunk_proofs.add()
+                cp.chunk_id, cp.proof_key, cp.proof = p["chunk_id"], p["proof_key"], p["proof"]
+            r.result_code = proto.COMPLETED_OK
+        except Exception as e:
+            r.ClearField("batch_proof_result")
+            r.result_code, r.error_message = proto.COMPLETED_ERROR, "%s: %s" % (type(e).__name__, e)
+
+    def _aggregate(self, q, r):
+        r.batch_id = q.batch_id
+        try:
+            rec = self.store.load(q.batch_id)
+            key = [self.engine._digest(q.recursive_proof_1), self.engine._digest(q.recursive_proof_2)]
+            if rec.get("agg_key") != key:
+                rec["agg_key"], rec["agg"] = key, self.engine.aggregate(q.batch_id, q.recursive_proof_1, q.recursive_proof_2)
+                self.store.save(q.batch_id, rec)
+            r.result_string, r.result_code = rec["agg"], proto.COMPLETED_OK
+        except Exception as e:
+            r.result_code, r.error_message = proto.COMPLETED_ERROR, "%s: %s" % (type(e).__name__, e)
+
+    def _final(self, q, r):
+        r.batch_id = q.batch_id
+        try:
+            rec = self.store.load(q.batch_id)
+            key = [self.engine._digest(q.recursive_proof), q.curve_name, q.aggregator_addr]
+            if rec.get("final_key") != key:
+                proof, pub = self.engine.final(q.batch_id, q.recursive_proof, q.curve_name, q.aggregator_addr)
+                rec["final_key"], rec["final"] = key, {"proof": proof, "public_input": pub}
+                self.store.save(q.batch_id, rec)
+            r.final_proof.proof, r.final_proof.public_input = rec["final"]["proof"], rec["final"]["public_input"]
+            r.result_string, r.result_code = "ok", proto.COMPLETED_OK
+        except Exception as e:
+            r.ClearField("final_proof")
+            r.result_code, r.error_message = proto.COMPLETED_ERROR, "%s: %s" % (type(e).__name__, e)
+
+    def _status(self, resp, error=None):
+        s = resp.get_status
+        s.id = "zeth-prover-mi355x"
+        s.result_code = 1 if error else 0
+        s.status = proto.STATUS_IDLE
+        if error:
+            s.error_message = error
+        ps = s.prover_status
+        ps.last_computed_request_id, ps.last_computed_end_time = self.last_id, self.last_end
+        ps.version_proto, ps.version_server = "v0_0_1", VERSION
+        ps.prover_name, ps.prover_id = "zeth-prover-mi355x", str(os.getpid())
+        ps.number_of_cores = os.cpu_count() or 0
+        try:
+            import psutil
+            vm = psutil.virtual_memory()
+            ps.total_memory, ps.free_memory = vm.total, vm.available
+        except Exception:
+            pass
+        ps.fork_id = 0
+
+
+def make_server(service, port=50061, host="127.0.0.1", max_workers=4):
+    handler = grpc.method_handlers_generic_handler(proto.SERVICE, {
+        "ProverStream": grpc.stream_stream_rpc_method_handler(
+            service.prover_stream, request_deserializer=proto.ProverRequest.FromString,
+            response_serializer=proto.ProverResponse.SerializeToString)})
+    server = grpc.server(futures.ThreadPoolExecutor(max_workers=max_workers),
+                         options=[("grpc.max_send_message_length", 1 << 30), ("grpc.max_receive_message_length", 1 << 30)])
+    server.add_generic_rpc_handlers((handler,))
+    bound = server.add_insecure_port("%s:%d" % (host, port))
+    return server, bound
+
+
+def default_backend_factory(device=0):
+    def make():
+        from ..stark.backend_hip import HipBackend
+        return HipBackend(device)   # raises without the HIP library / an MI355X: no CPU fallback
+    return make
+
+
+def serve(port=50061, host="127.0.0.1", state_dir="prover_state", config=None, device=0):
+    engine = Engine(default_backend_factory(device), config or EngineConfig())
+    engine.be  # fail at start-up, not at the first request, when no GPU is present
+    service = ProverService(engine, BatchStore(state_dir))
+    server, bound = make_server(service, port, host)
+    server.start()
+    return server, bound

@@ -1,0 +1,205 @@
+"""Service-level tests: the prover.v1 wire schema, the four-request sequence exactly as eigen-zeth's
+ProverChannel drives it (src/prover/provider.rs:243-544), idempotent replays / resume across
+connections, error convention, and the final-proof JSON grammar (src/settlement/ethereum/mod.rs:445-481).
+The CPU runs use the oracle backend (BASELINE.json configs[0]: plumbing, no GPU); the -m gpu run
+uses the HIP backend and must produce the same chunk proofs."""
+import json
+import os
+import re
+
+import pytest
+
+from eigen_zeth_amd.service import bn254, proto
+from eigen_zeth_amd.service.client import ProverChannel, ProverClientError
+from eigen_zeth_amd.service.engine import Engine, EngineConfig
+from eigen_zeth_amd.service.server import ProverService, make_server
+from eigen_zeth_amd.service.store import BatchStore
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_PROTO = "/root/reference/proto/prover/v1/prover.proto"
+
+
+def parse_proof_like_eigen_zeth(js):
+    """the grammar of parse_proof / parse_public_input (ethereum/mod.rs:445-481): decimal strings"""
+    v = json.loads(js)
+    out = [int(v["pi_a"]["x"]), int(v["pi_a"]["y"]), int(v["pi_b"]["x"][0]), int(v["pi_b"]["x"][1]),
+           int(v["pi_b"]["y"][0]), int(v["pi_b"]["y"][1]), int(v["pi_c"]["x"]), int(v["pi_c"]["y"])]
+    for s in (v["pi_a"]["x"], v["pi_b"]["y"][1], v["pi_c"]["y"]):
+        assert isinstance(s, str) and s.isdigit()
+    assert all(0 <= x < 2 ** 256 for x in out)
+    return out
+
+
+def parse_public_input_like_eigen_zeth(js):
+    v = json.loads(js)
+    assert isinstance(v[0], str) and v[0].isdigit()
+    return int(v[0])
+
+
+def test_schema_matches_reference_proto_text():
+    if not os.path.exists(REF_PROTO):
+        pytest.skip("reference not present on this machine")
+    txt = re.sub(r"//[^\n]*", "", open(REF_PROTO).read())
+
+    def body_of(name):
+        m = re.search(r"message\s+%s\s*\{" % name, txt)
+        assert m, name
+        depth, i = 1, m.end()
+        while depth:
+            depth += {"{": 1, "}": -1}.get(txt[i], 0)
+            i += 1
+        body = txt[m.end():i - 1]
+        return re.sub(r"enum\s+\w+\s*\{.*?\}", "", body, flags=re.S)   # nested enums are not fields
+
+    for mname, fields in proto.SCHEMA.items():
+        body = body_of(mname)
+        for (fname, num, *_rest) in fields:
+            assert re.search(r"\b%s\s*=\s*%d\s*;" % (fname, num), body), (mname, fname, num)
+        declared = set(re.findall(r"\b(\w+)\s*=\s*\d+\s*;", body))
+        assert declared == {f[0] for f in fields}, (mname, declared)
+    assert "rpc ProverStream(stream ProverRequest) returns (stream ProverResponse)" in txt
+
+
+def test_schema_frozen_numbers():
+    # survives without the reference: the numbers that are easy to get wrong (prover.proto:107-111,176-190)
+    f = {n: num for (n, num, *_r) in proto.SCHEMA["ChunkProof"]}
+    assert f == {"chunk_id": 1, "proof_key": 3, "proof": 2}
+    assert min(num for (_n, num, *_r) in proto.SCHEMA["ProverStatus"]) == 2
+    assert proto.METHOD == "/prover.v1.ProverService/ProverStream"
+    r = proto.ProverResponse()
+    r.gen_batch_proof.gen_batch_chunks.pre_state_root = b"\x01" * 32
+    assert proto.ProverResponse.FromString(r.SerializeToString()).gen_batch_proof.gen_batch_chunks.pre_state_root == b"\x01" * 32
+
+
+def test_reference_fixture_grammar():
+    # the reference's own format fixtures (proof/proof.json, proof/public_input.json): shape only
+    pts = parse_proof_like_eigen_zeth(open(os.path.join(ROOT, "tests/golden/ref_proof.json")).read())
+    assert bn254.g1_on_curve((pts[0], pts[1])) and bn254.g1_on_curve((pts[6], pts[7]))
+    assert bn254.g2_on_curve(((pts[2], pts[3]), (pts[4], pts[5])))
+    assert parse_public_input_like_eigen_zeth(open(os.path.join(ROOT, "tests/golden/ref_public_input.json")).read()) < bn254.R
+
+
+def _start(tmp_path, backend_factory, cfg=None):
+    engine = Engine(backend_factory, cfg or EngineConfig(air="wide8", logn=7, n_queries=6, fri_final_log=3))
+    svc = ProverService(engine, BatchStore(str(tmp_path)))
+    server, port = make_server(svc, port=0)
+    server.start()
+    return server, port, svc
+
+
+@pytest.fixture()
+def cpu_factory(tables):
+    from oracle.stark_cpu import CpuBackend
+    return lambda: CpuBackend(*tables)
+
+
+def _check_result(res, tables, block):
+    from eigen_zeth_amd.stark import air as AIR
+    from oracle import stark_verify as V
+    rc, mds = tables
+    assert res["block_number"] == block
+    assert len(res["pre_state_root"]) == 32 and len(res["post_state_root"]) == 32
+    pts = parse_proof_like_eigen_zeth(res["proof"])
+    assert bn254.g1_on_curve((pts[0], pts[1])) and bn254.g2_on_curve(((pts[2], pts[3]), (pts[4], pts[5])))
+    assert parse_public_input_like_eigen_zeth(res["public_input"]) < bn254.R
+    for p in res["chunk_proofs"]:
+        pr = json.loads(p)
+        assert V.verify(pr, AIR.get_air(pr["air"]), rc, mds)
+    # ProofResult as eigen-zeth stores it (src/db/mod.rs:63-71): json with 32-number arrays
+    stored = json.dumps({k: res[k] for k in ("block_number", "proof", "public_input", "pre_state_root", "post_state_root")})
+    assert len(json.loads(stored)["pre_state_root"]) == 32
+
+
+def test_empty_block_batch_round_trip_cpu(tmp_path, cpu_factory, tables):
+    server, port, svc = _start(tmp_path, cpu_factory)
+    try:
+        ch = ProverChannel("127.0.0.1:%d" % port)
+        res = ch.execute(1)   # genesis+1 empty block (BASELINE configs[0])
+        assert ch.trace == [("gen_batch_proof", "gen_batch_proof")] * 2 + [("gen_aggregated_proof", "gen_aggregated_proof"),
+                                                                          ("gen_final_proof", "gen_final_proof")]
+        _check_result(res, tables, 1)
+        st = ch.get_status()
+        assert st.status == proto.STATUS_IDLE and st.prover_status.version_server.startswith("zeth-prover")
+        # consecutive blocks chain their state roots
+        res2 = ch.execute(2)
+        assert res2["pre_state_root"] == res["post_state_root"]
+        ch.close()
+    finally:
+        server.stop(0)
+
+
+def test_replay_and_resume_are_idempotent(tmp_path, cpu_factory):
+    server, port, svc = _start(tmp_path, cpu_factory)
+    try:
+        ch = ProverChannel("127.0.0.1:%d" % port)
+        a = ch.execute(7, batch_id="b-7")
+        calls = dict(n=0)
+        orig = svc.engine.gen_chunk_proofs
+        svc.engine.gen_chunk_proofs = lambda *x: (calls.__setitem__("n", calls["n"] + 1), orig(*x))[1]
+        b = ch.execute(7, batch_id="b-7")          # verbatim replay on the same stream
+        ch.close()
+        ch2 = ProverChannel("127.0.0.1:%d" % port)  # a new connection (client restarted, PROVE_STEP_RECORD resume)
+        c = ch2.execute(7, batch_id="b-7")
+        ch2.close()
+        assert a == b == c and calls["n"] == 0
+    finally:
+        server.stop(0)
+    # a new server process over the same state directory still answers from the store
+    server, port, svc = _start(tmp_path, cpu_factory)
+    try:
+        svc.engine.gen_chunk_proofs = lambda *x: (_ for _ in ()).throw(AssertionError("recomputed"))
+        ch = ProverChannel("127.0.0.1:%d" % port)
+        assert ch.execute(7, batch_id="b-7") == a
+        ch.close()
+    finally:
+        server.stop(0)
+
+
+def test_error_convention(tmp_path, cpu_factory):
+    server, port, svc = _start(tmp_path, cpu_factory)
+    try:
+        ch = ProverChannel("127.0.0.1:%d" % port, program_name="wasm")
+        with pytest.raises(ProverClientError):
+            ch.execute(3, max_retries=2)
+        assert ch.trace == [("gen_batch_proof", "gen_batch_proof")] * 2   # retried, same response type
+        ch.close()
+        ch = ProverChannel("127.0.0.1:%d" % port, curve="BLS12381")
+        with pytest.raises(ProverClientError):
+            ch.execute(3, max_retries=1)
+        ch.close()
+        # malformed: chunk_count not matching batch_data -> COMPLETED_ERROR and no batch_proof_result
+        ch = ProverChannel("127.0.0.1:%d" % port)
+        req = proto.ProverRequest(id="x")
+        g = req.gen_batch_proof.gen_chunk_proof
+        g.batch_id, g.task_id, g.chunk_count, g.batch_data = "bad", "0000000001", 2, json.dumps({"chunks": []})
+        r = ch._call(req).gen_batch_proof.gen_chunk_proof
+        assert r.result_code == proto.COMPLETED_ERROR and not r.HasField("batch_proof_result") and r.error_message
+        ch.close()
+    finally:
+        server.stop(0)
+
+
+def test_product_service_needs_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from eigen_zeth_amd.native import ZpError
+    from eigen_zeth_amd.service.server import default_backend_factory
+    with pytest.raises(ZpError):
+        Engine(default_backend_factory()).be
+
+
+@pytest.mark.gpu
+def test_round_trip_gpu_matches_cpu(tmp_path, cpu_factory, tables):
+    from eigen_zeth_amd.service.server import default_backend_factory
+    cfg = EngineConfig(air="wide32", logn=12, n_queries=8)
+    server, port, svc = _start(tmp_path / "gpu", default_backend_factory(), cfg)
+    server2, port2, svc2 = _start(tmp_path / "cpu", cpu_factory, cfg)
+    try:
+        ch, ch2 = ProverChannel("127.0.0.1:%d" % port), ProverChannel("127.0.0.1:%d" % port2)
+        g, c = ch.execute(5, batch_id="same"), ch2.execute(5, batch_id="same")
+        _check_result(g, tables, 5)
+        assert g == c   # identical proof / public_input / roots from the MI355X and from the CPU restatement
+        ch.close(); ch2.close()
+    finally:
+        server.stop(0); server2.stop(0)
