@@ -46,7 +46,7 @@ def cpu_baseline(logn, budget_cols):
     import numpy as np
     from oracle import oracle as O
     cores = O.num_threads()
-    cols = max(cores, min(budget_cols, 2 * cores))
+    cols = max(1, min(cores, 128))
     x = O.random_field((cols, 1 << logn), 0xE16E2E70 + 2)
     t0 = time.perf_counter()
     y = O.ntt(x)
@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=24)
     ap.add_argument("--cols", type=int, default=64, help="columns per GPU")
+    ap.add_argument("--stark-logn", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
     args = ap.parse_args()
@@ -120,6 +121,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
 
+    pipe = None
+    if not args.no_pipeline:
+        del x
+        torch.cuda.empty_cache()
+        try:   # every rank takes part (all-to-all); reported by rank 0, outside the K timed steps
+            pipe = pipeline_probe(torch, dist, prover, dev, logn, min(cols, 32), world)
+        except Exception as e:
+            pipe = {"error": repr(e)}
+
     if rank == 0:
         plan = prover.ntt_plan(logn)
         npass = max(1, len(plan["passes"]))
@@ -163,7 +173,7 @@ def main():
             "device_ms_per_step": dev_ms / args.steps,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ntt_pass_kernel radix 2^%d (%s)" % (abs(dom), "transposing first pass" if dom < 0 else "strided pass"),
+                "kernel": "ntt_pass2_kernel radix 2^%d (%s)" % (abs(dom), "transposing first pass" if dom < 0 else "non-transposing pass, passes 2..m"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if launches else None,
                 "traffic": traffic,
@@ -174,13 +184,19 @@ def main():
                 "per_pass_avg_ms": {str(k): sum(v) / len(v) for k, v in sorted(by_kind.items())},
             },
         }
-        if not args.no_pipeline:
+        if pipe is not None:
+            out["pipeline"] = pipe
+        if world == 1 and not args.no_pipeline:
             try:
-                out["pipeline"] = pipeline_probe(torch, prover, dev, logn, min(cols, 32))
-            except Exception as e:  # reported, not fatal for the headline
-                out["pipeline"] = {"error": repr(e)}
+                out["batch_proof"] = batch_proof_probe(args.stark_logn)
+            except Exception as e:
+                out["batch_proof"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(logn, 32)
+            try:
+                out["cpu_baseline"]["stark"] = cpu_stark_baseline(min(args.stark_logn, 16))
+            except Exception as e:
+                out["cpu_baseline"]["stark"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
@@ -189,26 +205,99 @@ def main():
         dist.destroy_process_group()
 
 
-def pipeline_probe(torch, prover, dev, logn, cols):
-    """LDE (blow-up 2) + Poseidon Merkle commit of a column shard, timed once after one warm-up"""
+def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
+    """commit stage of one trace shard: LDE (blow-up 2) of this rank's columns, then -- for N > 1 -- the
+    column->row all-to-all over xGMI (eigen_zeth_amd/multigpu.py), then Poseidon leaf hashing + Merkle
+    subtree of the local rows and the all-gather of sub-roots.  Timed once after one warm-up."""
+    import numpy as np
+    from eigen_zeth_amd import multigpu
     N = 1 << logn
+    M = 2 * N
     x = random_field_tensor(torch, (cols, N), dev, 99)
-    y = torch.empty((cols, 2 * N), dtype=torch.int64, device=dev)
-    tree = torch.empty(((4 * N - 1) * 4,), dtype=torch.int64, device=dev)
+    y = torch.empty((cols, M), dtype=torch.int64, device=dev)
+    Wtot, Mloc = cols * world, M // world
+    tree = torch.empty(((2 * Mloc - 1) * 4,), dtype=torch.int64, device=dev)
+    st = torch.zeros((12,), dtype=torch.int64, device=dev)
+
+    def commit_rows(mat):
+        prover.merkle_commit(mat, Mloc, Wtot, tree)
+        return [int(v) & 0xFFFFFFFFFFFFFFFF for v in tree[-4:].tolist()]
+
+    def hash_pair(l, r):
+        vals = [v - (1 << 64) if v >= (1 << 63) else v for v in (list(l) + list(r) + [0] * 4)]
+        st.copy_(torch.tensor(vals, dtype=torch.int64))
+        prover.poseidon_perm(st, 1)
+        return [int(v) & 0xFFFFFFFFFFFFFFFF for v in st[:4].tolist()]
+
     res = {}
     for it in range(2):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
         prover.lde(x, y, logn, 1, cols)
         e[1].record()
-        prover.merkle_commit(y, 2 * N, cols, tree)
+        if world > 1:
+            rows, sent = multigpu.exchange_columns_to_rows(y)
+        else:
+            rows, sent = y, 0
         e[2].record()
+        sub = commit_rows(rows)
+        e[3].record()
         torch.cuda.synchronize()
-        res = {"cols": cols, "blowup": 2, "lde_ms": e[0].elapsed_time(e[1]), "merkle_ms": e[1].elapsed_time(e[2])}
-    perms = ((cols + 7) // 8) * 2 * N + (2 * N - 1)
+        if world > 1:
+            t = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in sub], dtype=torch.int64, device=dev)
+            allr = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allr, t)
+            root = multigpu.tree_top([[int(v) & 0xFFFFFFFFFFFFFFFF for v in r.tolist()] for r in allr], hash_pair)
+        else:
+            root = sub
+        res = {"cols_per_gpu": cols, "blowup": 2, "lde_ms": e[0].elapsed_time(e[1]),
+               "all_to_all_ms": e[1].elapsed_time(e[2]) if world > 1 else 0.0,
+               "merkle_ms": e[2].elapsed_time(e[3]), "root": [hex(v) for v in root]}
+        if world > 1:
+            res["all_to_all_GBs_sent_per_gpu"] = sent / (res["all_to_all_ms"] * 1e-3) / 1e9
+    perms = ((Wtot + 7) // 8) * Mloc + (Mloc - 1)
     res["lde_GBs_algorithmic"] = 8.0 * N * 3 * cols / (res["lde_ms"] * 1e-3) / 1e9
-    res["poseidon_perms_per_s"] = perms / (res["merkle_ms"] * 1e-3)
+    res["poseidon_perms_per_s_per_gpu"] = perms / (res["merkle_ms"] * 1e-3)
     return res
+
+
+def batch_proof_probe(logn, air_name="wide64"):
+    """BASELINE configs[2]-shaped: one chunk, full STARK (trace -> LDE -> constraints -> FRI) on one GPU"""
+    from eigen_zeth_amd import native
+    from eigen_zeth_amd.stark import air as AIR, prover as PR
+    from eigen_zeth_amd.stark.backend_hip import HipBackend
+    air = AIR.get_air(air_name)
+    t0 = time.perf_counter()
+    tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 42)
+    tw = time.perf_counter() - t0
+    be = HipBackend(0)
+    params = PR.StarkParams(logn, logb=1, fri_logf=3, fri_final_log=5, n_queries=32)
+    PR.prove(air, tr, pub, params, be)
+    tm = {}
+    t0 = time.perf_counter()
+    proof = PR.prove(air, tr, pub, params, be, timings=tm)
+    wall = time.perf_counter() - t0
+    return {"workload": "single chunk full STARK, AIR %s (%d columns), 2^%d rows, blow-up 2, 32 queries" % (air_name, air.width, logn),
+            "wall_s": wall, "stages_ms": {k: round(v * 1e3, 2) for k, v in tm.items()},
+            "witness_host_s": tw, "proof_bytes": len(PR.proof_to_json(proof))}
+
+
+def cpu_stark_baseline(logn, air_name="wide64"):
+    import numpy as np
+    from eigen_zeth_amd import native
+    from eigen_zeth_amd.poseidon_constants import default_round_constants, default_mds
+    from eigen_zeth_amd.stark import air as AIR, prover as PR
+    from oracle.stark_cpu import CpuBackend
+    from oracle import oracle as O
+    air = AIR.get_air(air_name)
+    tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 42)
+    be = CpuBackend(default_round_constants(), default_mds())
+    tm = {}
+    t0 = time.perf_counter()
+    PR.prove(air, tr, pub, PR.StarkParams(logn, 1, 3, 5, 32), be, timings=tm)
+    return {"wall_s": time.perf_counter() - t0, "cores": O.num_threads(), "kind": "port",
+            "sample": "same STARK at 2^%d rows on the CPU restatement (oracle/stark_cpu.py)" % logn,
+            "stages_ms": {k: round(v * 1e3, 1) for k, v in tm.items()}}
 
 
 if __name__ == "__main__":

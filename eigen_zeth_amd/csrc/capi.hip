@@ -326,7 +326,7 @@ int32_t zp_ntt_plan_json(zp_ctx *ctx, int32_t logn, char *buf, size_t buflen) {
         const NttPass &p = pl->pass[i];
         if (i) s += ", ";
         s += "{\"radix_log\": " + std::to_string(p.L) + ", \"rounds\": [" + std::to_string(p.A1) + ", " +
-             std::to_string(p.A2) + ", " + std::to_string(p.A3) + "], \"tile\": " + std::to_string(1 << p.logT) + "}";
+             std::to_string(p.A2) + ", " + std::to_string(p.A3) + "], \"tile\": " + std::to_string(p.L == 8 ? (1 << ctx->tune_logt) : (1 << p.logT)) + "}";
     }
     s += "], \"small_kernel\": ";
     s += (logn <= 12) ? "true" : "false";

@@ -38,14 +38,13 @@ typedef unsigned __int128 u128;
 /* ------------------------------------------------------------------ field */
 static inline u64 gl_add(u64 a, u64 b) {
     u64 s = a + b;
-    if (s < a) s += GL_EPS; /* wrapped: +2^64 == +EPS (mod p), cannot wrap twice for a,b<p */
-    if (s >= GL_P) s -= GL_P;
-    return s;
+    s += (0 - (u64)(s < a)) & GL_EPS; /* wrapped: +2^64 == +EPS (mod p), cannot wrap twice for a,b<p */
+    u64 t = s - GL_P;
+    return s >= GL_P ? t : s;         /* branch-free (cmov): operands are random, branches mispredict */
 }
 static inline u64 gl_sub(u64 a, u64 b) {
     u64 d = a - b;
-    if (a < b) d -= GL_EPS; /* borrowed 2^64 == EPS too much */
-    return d;
+    return d - ((0 - (u64)(a < b)) & GL_EPS); /* borrowed 2^64 == EPS too much */
 }
 static inline u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 static inline u64 gl_red128(u128 x) {
@@ -53,12 +52,12 @@ static inline u64 gl_red128(u128 x) {
     u64 hh = hi >> 32, hl = hi & GL_EPS;
     /* x = lo + hl*2^64 + hh*2^96 == lo + hl*EPS - hh  (2^96 == -1) */
     u64 t0 = lo - hh;
-    if (lo < hh) t0 -= GL_EPS;
+    t0 -= (0 - (u64)(lo < hh)) & GL_EPS;
     u64 t1 = hl * GL_EPS;
     u64 r = t0 + t1;
-    if (r < t1) r += GL_EPS;
-    if (r >= GL_P) r -= GL_P;
-    return r;
+    r += (0 - (u64)(r < t1)) & GL_EPS;
+    u64 t = r - GL_P;
+    return r >= GL_P ? t : r;
 }
 static inline u64 gl_mul(u64 a, u64 b) { return gl_red128((u128)a * b); }
 static u64 gl_pow(u64 b, u64 e) {
@@ -92,8 +91,9 @@ static inline uint32_t bitrev32(uint32_t x, int bits) {
     return r;
 }
 
-/* in-place, natural in -> natural out:  X[k] = sum_n x[n] w^(nk) */
-static void ntt_one(u64 *a, int logn, u64 w, const u64 *tw /* w^j, j<n/2 */) {
+/* in-place, natural in -> natural out:  X[k] = sum_n x[n] w^(nk)
+ * tw: per-stage compact twiddles, tw[half + j] = w_(2*half)^j for j < half (half = 1,2,4,..,n/2) */
+static void ntt_one(u64 *a, int logn, u64 w, const u64 *tw) {
     size_t n = (size_t)1 << logn;
     (void)w;
     for (size_t i = 0; i < n; i++) {
@@ -101,10 +101,11 @@ static void ntt_one(u64 *a, int logn, u64 w, const u64 *tw /* w^j, j<n/2 */) {
         if (i < j) { u64 t = a[i]; a[i] = a[j]; a[j] = t; }
     }
     for (int s = 1; s <= logn; s++) {
-        size_t m = (size_t)1 << s, half = m >> 1, step = n >> s;
+        size_t m = (size_t)1 << s, half = m >> 1;
+        const u64 *ts = tw + half;
         for (size_t k = 0; k < n; k += m)
             for (size_t j = 0; j < half; j++) {
-                u64 t = gl_mul(tw[j * step], a[k + j + half]);
+                u64 t = gl_mul(ts[j], a[k + j + half]);
                 u64 u = a[k + j];
                 a[k + j] = gl_add(u, t);
                 a[k + j + half] = gl_sub(u, t);
@@ -113,10 +114,18 @@ static void ntt_one(u64 *a, int logn, u64 w, const u64 *tw /* w^j, j<n/2 */) {
 }
 
 static u64 *make_tw(int logn, u64 w) {
-    size_t half = logn ? ((size_t)1 << (logn - 1)) : 1;
-    u64 *tw = (u64 *)malloc(half * sizeof(u64));
-    u64 c = 1;
-    for (size_t i = 0; i < half; i++) { tw[i] = c; c = gl_mul(c, w); }
+    size_t n = (size_t)1 << logn;
+    u64 *tw = (u64 *)malloc((n > 1 ? n : 2) * sizeof(u64));
+    tw[0] = 0;
+    tw[1] = 1;
+    /* top stage directly, lower stages by striding the stage above: w_(m/2)^j = w_m^(2j) */
+    if (logn >= 1) {
+        size_t half = n >> 1;
+        u64 c = 1;
+        for (size_t j = 0; j < half; j++) { tw[half + j] = c; c = gl_mul(c, w); }
+        for (size_t h = half >> 1; h >= 1; h >>= 1)
+            for (size_t j = 0; j < h; j++) tw[h + j] = tw[2 * h + 2 * j];
+    }
     return tw;
 }
 

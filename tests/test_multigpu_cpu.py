@@ -1,0 +1,73 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU commit: column shards + one all-to-all + local
+subtrees + all-gather must give exactly the single-process Merkle root."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, W, logm, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from eigen_zeth_amd import multigpu
+    from eigen_zeth_amd.poseidon_constants import default_round_constants, default_mds
+    from oracle import oracle as O
+    rc = np.array(default_round_constants(), dtype=np.uint64)
+    mds = np.array(default_mds(), dtype=np.uint64)
+    M = 1 << logm
+    full = O.random_field((W, M), 4242)                      # every rank derives the same matrix ...
+    Wl = W // world
+    local = torch.from_numpy(full[rank * Wl:(rank + 1) * Wl].view(np.int64).copy())   # ... and keeps its columns
+
+    def commit_rows(mat):
+        a = np.ascontiguousarray(mat.numpy().view(np.uint64))
+        assert a.shape == (W, M // world)
+        assert (a == full[:, rank * (M // world):(rank + 1) * (M // world)]).all()   # all columns, my rows
+        return [int(v) for v in O.merkle_commit(a, rc, mds)[-1]]
+
+    def hash_pair(l, r):
+        st = np.array([list(l) + list(r) + [0, 0, 0, 0]], dtype=np.uint64)
+        return [int(v) for v in O.poseidon_perm(st, rc, mds)[0][:4]]
+
+    root, stats = multigpu.distributed_commit(local, commit_rows, hash_pair)
+    if rank == 0:
+        ref = [int(v) for v in O.merkle_commit(full, rc, mds)[-1]]
+        out_q.put((root, ref, stats["sent_bytes"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,logm", [(2, 6, 8), (2, 16, 10)])
+def test_distributed_commit_equals_single_root(world, W, logm):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, logm, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    root, ref, sent = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert root == ref
+    assert sent == (W // world) * (1 << logm) * 8 * (world - 1) // world
+
+
+def test_pack_layout():
+    from eigen_zeth_amd import multigpu
+    x = torch.arange(2 * 8, dtype=torch.int64).view(2, 8)
+    p = multigpu.pack_for_exchange(x, 4)
+    assert p.shape == (4, 2, 2) and p[1].tolist() == [[2, 3], [10, 11]]
