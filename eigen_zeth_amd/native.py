@@ -61,6 +61,7 @@ SIGNATURES = {
     "zp_merkle_open_batch": (C.c_int32, [_vp, _vp, C.c_size_t, _u64p, C.c_int32, _u64p]),
     "zp_domain_tables": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int32)]),
     "zp_synth_trace": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p]),
+    "zp_msm_bn254": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
     "zp_ntt_host": (C.c_int32, [_vp, _u64p, C.c_int32, C.c_int32, C.c_int32]),
     "zp_lde_host": (C.c_int32, [_vp, _u64p, _u64p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_merkle_commit_host": (C.c_int32, [_vp, _u64p, C.c_size_t, C.c_int32, _u64p]),
@@ -272,6 +273,34 @@ class Prover:
         lo, hi, lb = _vp(), _vp(), C.c_int32(0)
         self._chk(self.lib.zp_domain_tables(self.ctx, logm, C.byref(lo), C.byref(hi), C.byref(lb)))
         return lo.value, hi.value, lb.value
+
+    # ---- N6
+    def msm_bn254(self, points_xy, scalars):
+        """points_xy: list of (x, y) ints ((0,0) = infinity); scalars: ints.  Returns (x, y) or None."""
+        n = len(points_xy)
+        pts = np.zeros((max(n, 1), 16), dtype=np.uint32)
+        scs = np.zeros((max(n, 1), 8), dtype=np.uint32)
+        for i, ((x, y), s) in enumerate(zip(points_xy, scalars)):
+            for k in range(8):
+                pts[i, k] = (x >> (32 * k)) & 0xFFFFFFFF
+                pts[i, 8 + k] = (y >> (32 * k)) & 0xFFFFFFFF
+                scs[i, k] = (s >> (32 * k)) & 0xFFFFFFFF
+        return self.msm_bn254_arrays(pts[:n], scs[:n])
+
+    def msm_bn254_arrays(self, pts, scs):
+        pts = np.ascontiguousarray(pts, dtype=np.uint32)
+        scs = np.ascontiguousarray(scs, dtype=np.uint32)
+        n = pts.shape[0]
+        d_p = DeviceBuffer(self, max(1, pts.size // 2 + 1))
+        d_s = DeviceBuffer(self, max(1, scs.size // 2 + 1))
+        if n:
+            self._chk(self.lib.zp_h2d(self.ctx, d_p.ptr, pts.ctypes.data, pts.nbytes))
+            self._chk(self.lib.zp_h2d(self.ctx, d_s.ptr, scs.ctypes.data, scs.nbytes))
+        out = (C.c_uint32 * 16)()
+        self._chk(self.lib.zp_msm_bn254(self.ctx, d_p.ptr, d_s.ptr, n, out))
+        x = sum(int(out[k]) << (32 * k) for k in range(8))
+        y = sum(int(out[8 + k]) << (32 * k) for k in range(8))
+        return None if (x == 0 and y == 0) else (x, y)
 
     # ---- host-buffer forms
     def ntt_host(self, cols, inverse=False):

@@ -130,6 +130,12 @@ int32_t zp_domain_tables(zp_ctx *ctx, int32_t logm, const uint64_t **d_lo, const
  * h_pub receives the public inputs (3 for kind 0, min(4,W) for kind 1).  Host code.                 */
 int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uint64_t *h_trace, uint64_t *h_pub);
 
+/* ---- N6: BN254 (alt_bn128) G1 multi-scalar multiplication ---------------------------------------
+ * d_points u32[n][16]: affine x (8 little-endian 32-bit limbs) then y, standard (non-Montgomery)
+ * integers < q; (0,0) encodes the point at infinity.  d_scalars u32[n][8] little-endian, any 256-bit
+ * value (used mod the group order implicitly).  h_out u32[16] = affine sum, all zero = infinity.   */
+int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n, uint32_t *h_out);
+
 /* ---- host-buffer conveniences (H2D + compute + D2H + sync), the form a non-GPU-aware host uses */
 int32_t zp_ntt_host(zp_ctx *ctx, uint64_t *h_cols, int32_t logn, int32_t W, int32_t inverse);
 int32_t zp_lde_host(zp_ctx *ctx, const uint64_t *h_in, uint64_t *h_out, int32_t logn, int32_t logb,
