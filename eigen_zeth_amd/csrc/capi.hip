@@ -285,6 +285,7 @@ int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value) {
     else if (!strcmp(key, "ntt_logt")) ctx->tune_logt = value;
     else if (!strcmp(key, "ntt_v2")) ctx->tune_v2 = value;
     else if (!strcmp(key, "ntt_tpw")) ctx->tune_tpw = value;
+    else if (!strcmp(key, "ntt_logt9")) ctx->tune_logt9 = value;
     else { ctx->err = "unknown tuning key"; return ZP_ERR_ARG; }
     return ZP_OK;
 }

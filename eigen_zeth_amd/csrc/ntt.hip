@@ -577,7 +577,7 @@ int32_t dispatch_pass(zp_ctx *ctx, const NttPass &p, const PassArgs &a, bool tra
             case 6: return launch_pass2<3, 3, 0, 5>(ctx, a, transpose, W);
             case 7: return launch_pass2<4, 3, 0, 5>(ctx, a, transpose, W);
             case 8: return ctx->tune_logt == 4 ? launch_pass2<4, 4, 0, 4>(ctx, a, transpose, W) : launch_pass2<4, 4, 0, 5>(ctx, a, transpose, W);
-            case 9: return launch_pass2<3, 3, 3, 5>(ctx, a, transpose, W);
+            case 9: return ctx->tune_logt9 == 4 ? launch_pass2<3, 3, 3, 4>(ctx, a, transpose, W) : launch_pass2<3, 3, 3, 5>(ctx, a, transpose, W);
             default: break;
         }
     }
