@@ -246,3 +246,44 @@ def test_fri_fold_composition_large(prover):
     prover.fri_fold(d_in, d_b, logn, 1, beta, 49)
     prover.fri_fold(d_b, d_c, logn - 1, 1, b2, pow(49, 2, P))
     assert (prover.download(d_a, (3, 1 << (logn - 2))) == prover.download(d_c, (3, 1 << (logn - 2)))).all()
+
+
+@pytest.mark.parametrize("logn", [25, 26])
+def test_ntt_max_bench_sizes_roundtrip_and_shift_theorem(prover, logn):
+    """sizes that use the radix-512 three-round pass ((9,8,8) and (9,9,8)); checked through size-independent
+    properties: iNTT(NTT(x)) = x, X[0] = sum(x), and the NTT of a delta at position 1 is the root's powers."""
+    n = 1 << logn
+    x = O.random_field((1, n), 1234 + logn)
+    d = prover.upload(x)
+    prover.ntt(d, d, logn, 1)
+    fx = prover.download(d, (1, n))[0]
+    assert int(fx[0]) == int(np.sum(x[0].astype(object)) % P)
+    prover.intt(d, d, logn, 1)
+    assert (prover.download(d, (1, n)) == x).all()
+    delta = np.zeros((1, n), dtype=np.uint64)
+    delta[0, 1] = 1
+    d2 = prover.upload(delta)
+    prover.ntt(d2, d2, logn, 1)
+    got = prover.download(d2, (1, n))[0]
+    w = O.lib().orc_root(O.ROOT32_DEFAULT, logn)
+    idx = [0, 1, 2, 3, n // 2, n - 1, 12345, (1 << 20) + 7]
+    for k in idx:
+        assert int(got[k]) == pow(w, k, P)
+
+
+def test_lde_blowup4_restriction_large(prover):
+    logn, W = 22, 2
+    x = O.random_field((W, 1 << logn), 77)
+    d_in, d_out = prover.upload(x), prover.alloc(W << (logn + 2))
+    prover.lde(d_in, d_out, logn, 2, W, shift=1)
+    y = prover.download(d_out, (W, 1 << (logn + 2)))
+    assert (y[:, ::4] == x).all()
+
+
+def test_merkle_ragged_widths_and_single_row(prover, tables):
+    rc, mds = tables
+    for (M, W) in [(1, 1), (1, 4), (1, 5), (2, 7), (4, 9), (16, 15), (16, 16), (16, 17)]:
+        cols = O.random_field((W, M), 900 + W)
+        d_tree = prover.alloc((2 * M - 1) * 4)
+        prover.merkle_commit(prover.upload(cols), M, W, d_tree)
+        assert (prover.download(d_tree, (2 * M - 1, 4)) == O.merkle_commit(cols, rc, mds)).all(), (M, W)
