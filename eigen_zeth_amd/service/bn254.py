@@ -47,15 +47,59 @@ def _pt_add(o, p, q):
     return (x, o.sub(o.mul(lam, o.sub(p[0], x)), p[1]))
 
 
+def _jac_dbl(o, p):
+    X, Y, Z = p
+    A = o.mul(X, X); B = o.mul(Y, Y); C = o.mul(B, B)
+    t = o.add(X, B)
+    D = o.sub(o.sub(o.mul(t, t), A), C); D = o.add(D, D)
+    E = o.add(o.add(A, A), A)
+    X3 = o.sub(o.mul(E, E), o.add(D, D))
+    C8 = o.add(C, C); C8 = o.add(C8, C8); C8 = o.add(C8, C8)
+    Y3 = o.sub(o.mul(E, o.sub(D, X3)), C8)
+    Z3 = o.mul(Y, Z); Z3 = o.add(Z3, Z3)
+    return (X3, Y3, Z3)
+
+
+def _jac_madd(o, p, q):   # Jacobian p + affine q (p not infinity, q not infinity)
+    X1, Y1, Z1 = p
+    Z1Z1 = o.mul(Z1, Z1)
+    U2 = o.mul(q[0], Z1Z1)
+    S2 = o.mul(o.mul(q[1], Z1), Z1Z1)
+    if U2 == X1:
+        if S2 == Y1:
+            return _jac_dbl(o, p)
+        return None
+    H = o.sub(U2, X1)
+    HH = o.mul(H, H)
+    I = o.add(HH, HH); I = o.add(I, I)
+    J = o.mul(H, I)
+    rr = o.sub(S2, Y1); rr = o.add(rr, rr)
+    V = o.mul(X1, I)
+    X3 = o.sub(o.sub(o.mul(rr, rr), J), o.add(V, V))
+    YJ = o.mul(Y1, J)
+    Y3 = o.sub(o.mul(rr, o.sub(V, X3)), o.add(YJ, YJ))
+    ZH = o.add(Z1, H)
+    Z3 = o.sub(o.sub(o.mul(ZH, ZH), Z1Z1), HH)
+    return (X3, Y3, Z3)
+
+
 def _pt_mul(o, p, k):
+    """k * p, Jacobian double-and-add (one inversion at the end)"""
     k %= R
+    if p is None or k == 0:
+        return None
     acc = None
-    while k:
-        if k & 1:
-            acc = _pt_add(o, acc, p)
-        p = _pt_add(o, p, p)
-        k >>= 1
-    return acc
+    one = o.small(1)
+    for i in range(k.bit_length() - 1, -1, -1):
+        if acc is not None:
+            acc = _jac_dbl(o, acc)
+        if (k >> i) & 1:
+            acc = (p[0], p[1], one) if acc is None else _jac_madd(o, acc, p)
+    if acc is None or acc[2] == o.zero:
+        return None
+    zi = o.inv(acc[2])
+    zi2 = o.mul(zi, zi)
+    return (o.mul(acc[0], zi2), o.mul(acc[1], o.mul(zi2, zi)))
 
 
 def g1_mul(k): return _pt_mul(_Ops1, G1, k)

@@ -122,3 +122,7 @@ class HipBackend:
 
     def open_paths(self, tree, M, idx):
         return self.p.merkle_open_batch(tree, M, idx)
+
+    # ---- N6 (Groth16 wrap)
+    def msm_g1(self, points, scalars):
+        return self.p.msm_bn254([p if p is not None else (0, 0) for p in points], [int(s) for s in scalars])

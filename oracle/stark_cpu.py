@@ -115,3 +115,7 @@ class CpuBackend:
         for i, j in enumerate(idx):
             out[i] = O.merkle_path(tree, int(j))
         return out
+
+    def msm_g1(self, points, scalars):
+        from . import naive_bn254 as B1
+        return B1.msm([p if p is not None else (0, 0) for p in points], scalars)

@@ -80,7 +80,9 @@ def test_reference_fixture_grammar():
 
 
 def _start(tmp_path, backend_factory, cfg=None):
-    engine = Engine(backend_factory, cfg or EngineConfig(air="wide8", logn=7, n_queries=6, fri_final_log=3))
+    cfg = cfg or EngineConfig(air="wide8", logn=7, n_queries=6, fri_final_log=3)
+    cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
+    engine = Engine(backend_factory, cfg)
     svc = ProverService(engine, BatchStore(str(tmp_path)))
     server, port = make_server(svc, port=0)
     server.start()
@@ -93,7 +95,7 @@ def cpu_factory(tables):
     return lambda: CpuBackend(*tables)
 
 
-def _check_result(res, tables, block):
+def _check_result(res, tables, block, svc=None):
     from eigen_zeth_amd.stark import air as AIR
     from oracle import stark_verify as V
     rc, mds = tables
@@ -101,10 +103,21 @@ def _check_result(res, tables, block):
     assert len(res["pre_state_root"]) == 32 and len(res["post_state_root"]) == 32
     pts = parse_proof_like_eigen_zeth(res["proof"])
     assert bn254.g1_on_curve((pts[0], pts[1])) and bn254.g2_on_curve(((pts[2], pts[3]), (pts[4], pts[5])))
-    assert parse_public_input_like_eigen_zeth(res["public_input"]) < bn254.R
+    pub = parse_public_input_like_eigen_zeth(res["public_input"])
+    assert pub < bn254.R
     for p in res["chunk_proofs"]:
         pr = json.loads(p)
         assert V.verify(pr, AIR.get_air(pr["air"]), rc, mds)
+    if svc is not None:   # the final proof is a Groth16 proof that verifies under the service's VK (pairing check)
+        from oracle import groth16_verify as GV
+        vk = json.loads(svc.engine.verifying_key_json())
+        g1 = lambda d: (int(d["x"]), int(d["y"]))
+        g2 = lambda d: ((int(d["x"][0]), int(d["x"][1])), (int(d["y"][0]), int(d["y"][1])))
+        vkp = {"alpha1": g1(vk["alpha1"]), "beta2": g2(vk["beta2"]), "gamma2": g2(vk["gamma2"]), "delta2": g2(vk["delta2"]),
+               "ic": [g1(p) for p in vk["ic"]]}
+        proof = {"pi_a": (pts[0], pts[1]), "pi_b": ((pts[2], pts[3]), (pts[4], pts[5])), "pi_c": (pts[6], pts[7])}
+        assert GV.verify(vkp, proof, [pub])
+        assert not GV.verify(vkp, proof, [(pub + 1) % bn254.R])
     # ProofResult as eigen-zeth stores it (src/db/mod.rs:63-71): json with 32-number arrays
     stored = json.dumps({k: res[k] for k in ("block_number", "proof", "public_input", "pre_state_root", "post_state_root")})
     assert len(json.loads(stored)["pre_state_root"]) == 32
@@ -117,7 +130,7 @@ def test_empty_block_batch_round_trip_cpu(tmp_path, cpu_factory, tables):
         res = ch.execute(1)   # genesis+1 empty block (BASELINE configs[0])
         assert ch.trace == [("gen_batch_proof", "gen_batch_proof")] * 2 + [("gen_aggregated_proof", "gen_aggregated_proof"),
                                                                           ("gen_final_proof", "gen_final_proof")]
-        _check_result(res, tables, 1)
+        _check_result(res, tables, 1, svc)
         st = ch.get_status()
         assert st.status == proto.STATUS_IDLE and st.prover_status.version_server.startswith("zeth-prover")
         # consecutive blocks chain their state roots
@@ -198,7 +211,7 @@ def test_round_trip_gpu_matches_cpu(tmp_path, cpu_factory, tables):
     try:
         ch, ch2 = ProverChannel("127.0.0.1:%d" % port), ProverChannel("127.0.0.1:%d" % port2)
         g, c = ch.execute(5, batch_id="same"), ch2.execute(5, batch_id="same")
-        _check_result(g, tables, 5)
+        _check_result(g, tables, 5, svc)
         assert g == c   # identical proof / public_input / roots from the MI355X and from the CPU restatement
         ch.close(); ch2.close()
     finally:
