@@ -15,8 +15,9 @@ def main():
     ap.add_argument("--air", default="wide32")
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--chunks-per-block", type=int, default=1)
+    ap.add_argument("--l2-addr", default=None, help="L2 JSON-RPC (ZETH_L2_ADDR) to fetch block inputs from")
     a = ap.parse_args()
-    server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, chunks_per_block=a.chunks_per_block), a.device)
+    server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, chunks_per_block=a.chunks_per_block, l2_addr=a.l2_addr), a.device)
     print("prover.v1.ProverService listening on %s:%d" % (a.host, port), flush=True)
     try:
         while True:

@@ -27,11 +27,12 @@ from . import groth16
 
 class EngineConfig:
     def __init__(self, air="wide32", logn=12, logb=1, chunks_per_block=1, n_queries=16, fri_logf=3, fri_final_log=5,
-                 groth16_logm=6, crs_dir=None):
+                 groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64):
         self.air, self.logn, self.logb = air, logn, logb
         self.chunks_per_block, self.n_queries = chunks_per_block, n_queries
         self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
         self.groth16_logm, self.crs_dir = groth16_logm, crs_dir
+        self.l2_addr, self.txs_per_chunk = l2_addr, txs_per_chunk   # optional block-input fetcher
 
 
 class Engine:
@@ -59,17 +60,27 @@ class Engine:
             raise ValueError("empty batch")
         if program_name and program_name.lower() != "evm":
             raise ValueError("unknown program %r (only 'evm' is served)" % program_name)
-        chunks = []
+        chunks, fetched = [], []
+        l2 = None
+        if self.cfg.l2_addr:
+            from .l2client import L2Client
+            l2 = L2Client(self.cfg.l2_addr)
         for b in blocks:
-            for c in range(self.cfg.chunks_per_block):
+            nchunks = self.cfg.chunks_per_block
+            if l2 is not None:   # real block: chunk count follows the transaction count, roots come from the node
+                info = l2.block(int(b))
+                fetched.append(info)
+                nchunks = max(1, -(-info["n_tx"] // self.cfg.txs_per_chunk))
+            for c in range(nchunks):
                 chunks.append({"block": int(b), "chunk": c, "air": self.cfg.air, "logn": self.cfg.logn,
                                "seed": (int(chain_id) * 1000003 + int(b) * 1009 + c) & 0xFFFFFFFFFFFFFFFF})
         batch_data = json.dumps({"version": 1, "chain_id": int(chain_id), "blocks": [int(b) for b in blocks],
-                                 "chunks": chunks}, separators=(",", ":"))
+                                 "block_hashes": [f["hash"] for f in fetched], "chunks": chunks}, separators=(",", ":"))
         return {"task_id": str(int(blocks[0])).rjust(10, "0"),  # prover.proto:82-83
                 "chunk_count": len(chunks), "batch_data": batch_data,
-                "pre_state_root": self._state_root(chain_id, int(blocks[0]) - 1),
-                "post_state_root": self._state_root(chain_id, int(blocks[-1]))}
+                "pre_state_root": (fetched[0]["parent_state_root"] if fetched and fetched[0]["parent_state_root"] else
+                                   self._state_root(chain_id, int(blocks[0]) - 1)),
+                "post_state_root": fetched[-1]["state_root"] if fetched else self._state_root(chain_id, int(blocks[-1]))}
 
     # ---- GenChunkProof
     def gen_chunk_proofs(self, batch_id, task_id, chunk_count, batch_data):

@@ -216,3 +216,38 @@ def test_round_trip_gpu_matches_cpu(tmp_path, cpu_factory, tables):
         ch.close(); ch2.close()
     finally:
         server.stop(0); server2.stop(0)
+
+
+def test_block_input_fetcher_with_stub_node(tmp_path, cpu_factory):
+    """with an L2 JSON-RPC endpoint configured, state roots and chunk counts come from the block"""
+    import http.server
+    import threading
+
+    blocks = {n: {"number": hex(n), "hash": "0x" + "%064x" % (n + 7), "stateRoot": "0x" + "%064x" % (1000 + n),
+                  "transactions": ["0x" + "%064x" % i for i in range(3 if n == 5 else 0)]} for n in range(0, 8)}
+
+    class H(http.server.BaseHTTPRequestHandler):
+        def do_POST(self):
+            q = json.loads(self.rfile.read(int(self.headers["Content-Length"])))
+            assert q["method"] == "eth_getBlockByNumber"
+            body = json.dumps({"jsonrpc": "2.0", "id": q["id"], "result": blocks.get(int(q["params"][0], 16))}).encode()
+            self.send_response(200); self.send_header("Content-Type", "application/json"); self.end_headers(); self.wfile.write(body)
+
+        def log_message(self, *a):
+            pass
+
+    httpd = http.server.HTTPServer(("127.0.0.1", 0), H)
+    threading.Thread(target=httpd.serve_forever, daemon=True).start()
+    cfg = EngineConfig(air="fib", logn=5, n_queries=4, fri_final_log=3, l2_addr="http://127.0.0.1:%d" % httpd.server_port, txs_per_chunk=2)
+    server, port, svc = _start(tmp_path, cpu_factory, cfg)
+    try:
+        ch = ProverChannel("127.0.0.1:%d" % port)
+        res = ch.execute(5)
+        assert bytes(res["pre_state_root"]) == bytes.fromhex("%064x" % 1004) and bytes(res["post_state_root"]) == bytes.fromhex("%064x" % 1005)
+        assert len(res["chunk_proofs"]) == 2           # 3 transactions, 2 per chunk
+        assert len(ch.execute(6)["chunk_proofs"]) == 1  # empty block still gets one chunk (SURVEY 3.4)
+        with pytest.raises(ProverClientError):
+            ch.execute(99, max_retries=1)               # unknown block -> COMPLETED_ERROR
+        ch.close()
+    finally:
+        server.stop(0); httpd.shutdown()
