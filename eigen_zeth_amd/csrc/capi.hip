@@ -238,6 +238,16 @@ int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uin
         }
         return ZP_OK;
     }
+    if (kind == 2) {  // permutation AIR: a random, b[i] = a[(5*i + 3) mod N], c = a^2
+        if (W != 3) return ZP_ERR_ARG;
+        for (size_t i = 0; i < N; i++) h_trace[i] = next();
+        for (size_t i = 0; i < N; i++) {
+            h_trace[N + i] = h_trace[(5 * i + 3) & (N - 1)];
+            h_trace[2 * N + i] = gl_mul(h_trace[i], h_trace[i]);
+        }
+        h_pub[0] = h_trace[0];
+        return ZP_OK;
+    }
     return ZP_ERR_ARG;
 }
 

@@ -239,3 +239,122 @@ int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, cons
 }
 
 }  // extern "C"
+
+// ---- grand product (stage-2 witness of a permutation argument) ---------------------------------------
+// Z[0] = 1,  Z[i+1] = Z[i] * (a[i] + g) / (b[i] + g)   in F_{p^3};  out planes u64[3][N].
+// Three launches: (1) per-lane ratios r_i and the exclusive product of each lane's 16 ratios, block scan
+// in LDS, one total per block;  (2) exclusive scan of the block totals (one workgroup);  (3) offsets.
+namespace {
+
+struct GpArgs {
+    const u64 *a, *b;
+    u64 *out;       // [3][N]
+    e3 *totals;     // [nblocks]
+    u64 g[3];
+    u64 n;
+};
+#define GP_PER 16
+#define GP_BLK 256
+
+__device__ __forceinline__ e3 gp_ratio(const GpArgs &A, u64 i) {
+    const e3 num = e3_make(gl_add(A.a[i], A.g[0]), A.g[1], A.g[2]);
+    const e3 den = e3_make(gl_add(A.b[i], A.g[0]), A.g[1], A.g[2]);
+    return e3_mul(num, e3_inv(den));
+}
+
+__global__ void __launch_bounds__(GP_BLK) gp_local_kernel(GpArgs A) {
+    __shared__ e3 sh[GP_BLK];
+    const int t = threadIdx.x;
+    const u64 base = ((u64)blockIdx.x * GP_BLK + t) * GP_PER;
+    e3 acc = e3_make(1, 0, 0);
+    // exclusive products inside the lane's run, stored unscaled; scaled by the lane/block prefix later
+    for (int k = 0; k < GP_PER; k++) {
+        const u64 i = base + k;
+        if (i < A.n) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) A.out[(u64)c * A.n + i] = acc.c[c];
+            acc = e3_mul(acc, gp_ratio(A, i));
+        }
+    }
+    sh[t] = acc;
+    __syncthreads();
+    // inclusive Hillis-Steele scan of the lane totals
+    for (int d = 1; d < GP_BLK; d <<= 1) {
+        e3 v = sh[t];
+        if (t >= d) v = e3_mul(sh[t - d], v);
+        __syncthreads();
+        sh[t] = v;
+        __syncthreads();
+    }
+    const e3 lane_prefix = t ? sh[t - 1] : e3_make(1, 0, 0);
+    if (t == GP_BLK - 1) A.totals[blockIdx.x] = sh[t];
+    for (int k = 0; k < GP_PER; k++) {
+        const u64 i = base + k;
+        if (i < A.n) {
+            e3 v = e3_mul(lane_prefix, e3_make(A.out[i], A.out[A.n + i], A.out[2 * A.n + i]));
+#pragma unroll
+            for (int c = 0; c < 3; c++) A.out[(u64)c * A.n + i] = v.c[c];
+        }
+    }
+}
+
+// exclusive scan of the block totals, in place, one workgroup (sequential over chunks of GP_BLK)
+__global__ void __launch_bounds__(GP_BLK) gp_scan_totals_kernel(e3 *totals, u64 nblocks) {
+    __shared__ e3 sh[GP_BLK];
+    __shared__ e3 carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = e3_make(1, 0, 0);
+    __syncthreads();
+    for (u64 base = 0; base < nblocks; base += GP_BLK) {
+        const u64 i = base + t;
+        sh[t] = i < nblocks ? totals[i] : e3_make(1, 0, 0);
+        __syncthreads();
+        for (int d = 1; d < GP_BLK; d <<= 1) {
+            e3 v = sh[t];
+            if (t >= d) v = e3_mul(sh[t - d], v);
+            __syncthreads();
+            sh[t] = v;
+            __syncthreads();
+        }
+        const e3 excl = e3_mul(carry, t ? sh[t - 1] : e3_make(1, 0, 0));
+        const e3 last = e3_mul(carry, sh[GP_BLK - 1]);
+        __syncthreads();
+        if (i < nblocks) totals[i] = excl;
+        if (t == 0) carry = last;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(GP_BLK) gp_apply_kernel(GpArgs A) {
+    const e3 off = A.totals[blockIdx.x];
+    const u64 base = ((u64)blockIdx.x * GP_BLK + threadIdx.x) * GP_PER;
+    for (int k = 0; k < GP_PER; k++) {
+        const u64 i = base + k;
+        if (i < A.n) {
+            e3 v = e3_mul(off, e3_make(A.out[i], A.out[A.n + i], A.out[2 * A.n + i]));
+#pragma unroll
+            for (int c = 0; c < 3; c++) A.out[(u64)c * A.n + i] = v.c[c];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t zp_grand_product(zp_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t n, const uint64_t gamma[3],
+                                    uint64_t *d_out) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, n >= 1, "n must be >= 1");
+    ZP_ARG(ctx, d_a && d_b && gamma && d_out, "null pointer");
+    ZP_ARG(ctx, gamma[0] < GL_P && gamma[1] < GL_P && gamma[2] < GL_P, "challenge not canonical");
+    const u64 nblocks = (n + (u64)GP_BLK * GP_PER - 1) / ((u64)GP_BLK * GP_PER);
+    u64 *scr = nullptr;
+    ZP_TRY(zpi_scratch(ctx, 3, nblocks * 3 + 8, &scr));
+    GpArgs A;
+    A.a = (const u64 *)d_a; A.b = (const u64 *)d_b; A.out = (u64 *)d_out; A.totals = (e3 *)scr; A.n = n;
+    for (int i = 0; i < 3; i++) A.g[i] = gamma[i];
+    hipLaunchKernelGGL(gp_local_kernel, dim3((unsigned)nblocks), dim3(GP_BLK), 0, ctx->stream, A);
+    hipLaunchKernelGGL(gp_scan_totals_kernel, dim3(1), dim3(GP_BLK), 0, ctx->stream, (e3 *)scr, nblocks);
+    hipLaunchKernelGGL(gp_apply_kernel, dim3((unsigned)nblocks), dim3(GP_BLK), 0, ctx->stream, A);
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}

@@ -49,6 +49,12 @@ class Const(Expr):
     def key(self): return ("const", self.v)
 
 
+class Chal(Expr):
+    """component i of the stage-2 Fiat-Shamir challenge (known only after the first commitment)"""
+    def __init__(self, i): self.i = i
+    def key(self): return ("chal", self.i)
+
+
 class XMinusLast(Expr):
     """x - w^(N-1): vanishes on the last trace row only"""
     def key(self): return ("xml",)
@@ -70,11 +76,16 @@ class Air:
     """name, width, number of public inputs, constraint list (transition constraints already carry
     their XMinusLast factor)."""
 
-    def __init__(self, name, width, n_pub, constraints, trace_kind):
+    def __init__(self, name, width, n_pub, constraints, trace_kind, stage2=None):
         self.name, self.width, self.n_pub = name, width, n_pub
         self.constraints = constraints
         self.trace_kind = trace_kind  # id understood by zp_synth_trace
         self.n_fixed = 2
+        # stage 2 (committed after a challenge): {"kind": "perm", "a": col, "b": col} -> a grand-product column
+        # Z in F_{p^3}, stored as 3 base columns with indices width .. width+2
+        self.stage2 = stage2
+        self.width2 = 3 if stage2 else 0
+        self.n_chal = 3 if stage2 else 0
 
     def digest(self):
         h = hashlib.sha256(repr([c.key() for c in self.constraints]).encode()).hexdigest()
@@ -109,7 +120,31 @@ def wide_air(width):
     return Air("wide%d" % width, width, min(4, width), cs, trace_kind=1)
 
 
-BUILTIN_AIRS = {"fib": fibonacci_air, "wide8": lambda: wide_air(8), "wide32": lambda: wide_air(32),
+def e3x_mul(a, b):
+    """product of two F_{p^3} values given as triples of expressions (t^3 = t + 1)"""
+    d0 = a[0] * b[0]
+    d1 = a[0] * b[1] + a[1] * b[0]
+    d2 = a[0] * b[2] + a[1] * b[1] + a[2] * b[0]
+    d3 = a[1] * b[2] + a[2] * b[1]
+    d4 = a[2] * b[2]
+    return [d0 + d3, d1 + d3 + d4, d2 + d4]
+
+
+def permutation_air():
+    """columns a, b, c with  c = a^2  and  b a permutation of a, proven by the grand product
+    Z' (b + g) = Z (a + g) (cyclic: the product over all rows is 1), Z[0] = 1.  g = stage-2 challenge."""
+    a, b, c = Col(0), Col(1), Col(2)
+    Z = [Col(3), Col(4), Col(5)]
+    Zn = [Col(3, True), Col(4, True), Col(5, True)]
+    g = [Chal(0), Chal(1), Chal(2)]
+    lhs = e3x_mul(Zn, [b + g[0], g[1], g[2]])
+    rhs = e3x_mul(Z, [a + g[0], g[1], g[2]])
+    cs = [c - a * a] + [lhs[i] - rhs[i] for i in range(3)]
+    cs += [L_FIRST * (Z[0] - 1), L_FIRST * Z[1], L_FIRST * Z[2], L_FIRST * (a - Pub(0))]
+    return Air("perm", 3, 1, cs, trace_kind=2, stage2={"kind": "perm", "a": 0, "b": 1})
+
+
+BUILTIN_AIRS = {"perm": permutation_air, "fib": fibonacci_air, "wide8": lambda: wide_air(8), "wide32": lambda: wide_air(32),
                 "wide64": lambda: wide_air(64)}
 
 
@@ -121,7 +156,8 @@ def get_air(name):
 class _Emitter:
     """common-subexpression-eliminating emitter of straight-line code over u64 field elements"""
 
-    def __init__(self):
+    def __init__(self, n_pub=0):
+        self.n_pub = n_pub
         self.lines, self.memo, self.n = [], {}, 0
         self.cols, self.fixed = set(), set()
 
@@ -145,6 +181,8 @@ class _Emitter:
             r = "pub[%d]" % e.i
         elif isinstance(e, Const):
             r = "%dULL" % e.v
+        elif isinstance(e, Chal):
+            r = "pub[%d]" % (self.n_pub + e.i)   # challenges follow the publics in the same array
         elif isinstance(e, XMinusLast):
             r = "xml"
         else:
@@ -156,7 +194,7 @@ class _Emitter:
 
 def emit_quotient_source(air, target):
     """target: 'hip' (device kernel + host launcher exported as air.symbol) or 'c' (OpenMP loop)"""
-    em = _Emitter()
+    em = _Emitter(air.n_pub)
     outs = [em.emit(c) for c in air.constraints]
     body = []
     for (i, nxt) in sorted(em.cols):
@@ -196,13 +234,14 @@ def emit_quotient_source(air, target):
 
 
 # ---------------------------------------------------------------------------------- evaluation over F_{p^3}
-def eval_constraints_ext(air, col_at, col_next_at, fixed_at, pubs, xml, mul, add, sub, embed):
+def eval_constraints_ext(air, col_at, col_next_at, fixed_at, pubs, xml, mul, add, sub, embed, chal=()):
     """used by verifiers: evaluate every constraint with arbitrary field callbacks"""
     def ev(e):
         if isinstance(e, Col): return (col_next_at if e.nxt else col_at)[e.i]
         if isinstance(e, Fixed): return fixed_at[e.i]
         if isinstance(e, Pub): return embed(pubs[e.i])
         if isinstance(e, Const): return embed(e.v)
+        if isinstance(e, Chal): return embed(chal[e.i])
         if isinstance(e, XMinusLast): return xml
         a, b = ev(e.a), ev(e.b)
         return {"add": add, "sub": sub, "mul": mul}[e.op](a, b)

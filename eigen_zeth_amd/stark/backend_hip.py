@@ -39,15 +39,38 @@ class HipBackend:
     def _root(self, tree, M):
         return [int(v) for v in self.p.download(tree, (4,), offset_elems=(2 * M - 2) * 4)]
 
-    def commit_trace(self, trace, logn, logb):
+    def commit_trace(self, trace, logn, logb, extra_cols=0):
+        """ext / coef are allocated with room for `extra_cols` stage-2 columns behind the trace columns"""
         W = trace.shape[0]
         M = 1 << (logn + logb)
         d_tr = self.p.upload(trace)
-        ext, coef, tree = self.p.alloc(W * M), self.p.alloc(W << logn), self.p.alloc((2 * M - 1) * 4)
+        ext, coef = self.p.alloc((W + extra_cols) * M), self.p.alloc((W + extra_cols) << logn)
+        tree = self.p.alloc((2 * M - 1) * 4)
         self.p.lde(d_tr, ext, logn, logb, W, self.shift, d_coef=coef)
         self.p.merkle_commit(ext, M, W, tree)
-        d_tr.free()
-        return Commit(self._root(tree, M), tree, ext, coef)
+        c = Commit(self._root(tree, M), tree, ext, coef)
+        if extra_cols:
+            c.trace, c.W = d_tr, W   # stage 2 reads witness columns
+        else:
+            d_tr.free()
+        return c
+
+    def column_view(self, d_mat, col, rows):
+        return d_mat.offset(col * rows)
+
+    def commit_stage2(self, air, c1, chal, logn, logb):
+        """grand-product column Z (3 base columns) -> LDE into columns W.. of c1.ext / c1.coef -> its own tree"""
+        N, M, W = 1 << logn, 1 << (logn + logb), c1.W
+        st = air.stage2
+        d_z = self.p.alloc(3 * N)
+        self.p.grand_product(c1.trace.offset(st["a"] * N), c1.trace.offset(st["b"] * N), N, chal, d_z)
+        self.p.lde(d_z, c1.ext.offset(W * M), logn, logb, 3, self.shift, d_coef=c1.coef.offset(W * N))
+        tree = self.p.alloc((2 * M - 1) * 4)
+        self.p.merkle_commit(c1.ext.offset(W * M), M, 3, tree)
+        self.p.sync()
+        d_z.free()
+        c1.trace.free()
+        return Commit(self._root(tree, M), tree)
 
     def commit_cols(self, d_cols, M, W):
         tree = self.p.alloc((2 * M - 1) * 4)

@@ -65,9 +65,19 @@ def prove(air, trace, pubs, params, be, timings=None):
 
     # 1. commit the trace
     t0 = time.perf_counter()
-    c1 = be.commit_trace(trace, logn, logb)
+    W2 = air.width2
+    Wt = W + W2                      # committed base columns: trace, then the stage-2 columns
+    c1 = be.commit_trace(trace, logn, logb, W2)
     tick("lde+merkle(trace)", t0)
     tr.absorb(c1.root)
+    chal, c2 = [], None
+    if air.stage2:
+        # stage 2: a challenge that depends on the first commitment, then the grand-product column
+        t0 = time.perf_counter()
+        chal = tr.challenge_e3()
+        c2 = be.commit_stage2(air, c1, chal, logn, logb)
+        tick("grand-product+lde+merkle(stage2)", t0)
+        tr.absorb(c2.root)
     alpha = tr.challenge_e3()
 
     # 2. constraint quotient on the coset, committed as 3 base columns
@@ -81,7 +91,7 @@ def prove(air, trace, pubs, params, be, timings=None):
     sN = pow(shift, N, P)
     wb = F.root(logb, root32)
     zhinv = [F.inv((sN * pow(wb, j, P) - 1) % P) for j in range(1 << logb)]
-    d_q = be.quotient(air, c1, fixed, pubs, apow, zhinv, logn, logb, F.inv(wN))
+    d_q = be.quotient(air, c1, fixed, list(_ints(pubs)) + list(chal), apow, zhinv, logn, logb, F.inv(wN))
     tick("quotient", t0)
     t0 = time.perf_counter()
     cq = be.commit_cols(d_q, M, 3)
@@ -93,8 +103,8 @@ def prove(air, trace, pubs, params, be, timings=None):
     # 3. out-of-domain evaluations
     t0 = time.perf_counter()
     zeta_w = F.e3_scale(zeta, wN)
-    ev_z = be.eval_ext(c1.coef, logn, W, zeta)
-    ev_zw = be.eval_ext(c1.coef, logn, W, zeta_w)
+    ev_z = be.eval_ext(c1.coef, logn, Wt, zeta)
+    ev_zw = be.eval_ext(c1.coef, logn, Wt, zeta_w)
     ev_q = be.eval_ext(d_qcoef, logm, 3, F.e3_scale(zeta, F.inv(shift)))
     tick("ood-evals", t0)
     ev_all = [_ints(r) for r in ev_z] + [_ints(r) for r in ev_q]
@@ -105,7 +115,7 @@ def prove(air, trace, pubs, params, be, timings=None):
 
     # 4. DEEP quotient
     t0 = time.perf_counter()
-    d_f = be.deep(c1.ext, W, d_q, 3, logm, W, zeta, zeta_w, gamma, ev_all, ev_next)
+    d_f = be.deep(c1.ext, Wt, d_q, 3, logm, Wt, zeta, zeta_w, gamma, ev_all, ev_next)
     tick("deep", t0)
 
     # 5. FRI
@@ -133,6 +143,9 @@ def prove(air, trace, pubs, params, be, timings=None):
     qidx = tr.indices(params.n_queries, logm)
     q_trace_vals = be.gather_rows(c1.ext, M, W, qidx)
     q_trace_paths = be.open_paths(c1.tree, M, qidx)
+    if c2 is not None:
+        q_s2_vals = be.gather_rows(be.column_view(c1.ext, W, M), M, W2, qidx)
+        q_s2_paths = be.open_paths(c2.tree, M, qidx)
     q_q_vals = be.gather_rows(d_q, M, 3, qidx)
     q_q_paths = be.open_paths(cq.tree, M, qidx)
     fri_open = []
@@ -152,13 +165,14 @@ def prove(air, trace, pubs, params, be, timings=None):
             "index": int(j),
             "trace": {"values": _ints(q_trace_vals[i]), "path": [_ints(x) for x in q_trace_paths[i]]},
             "quotient": {"values": _ints(q_q_vals[i]), "path": [_ints(x) for x in q_q_paths[i]]},
+            **({"stage2": {"values": _ints(q_s2_vals[i]), "path": [_ints(x) for x in q_s2_paths[i]]}} if c2 is not None else {}),
             "fri": [{"values": _ints(fo[1][i]), "path": [_ints(x) for x in fo[2][i]]} for fo in fri_open],
         })
     proof = {
         "air": air.name, "air_digest": air.digest(), "params": params.to_dict(),
         "root32": int(root32), "shift": int(shift),
         "publics": _ints(pubs),
-        "roots": {"trace": _ints(c1.root), "quotient": _ints(cq.root)},
+        "roots": {"trace": _ints(c1.root), "quotient": _ints(cq.root), **({"stage2": _ints(c2.root)} if c2 is not None else {})},
         "evals": {"z": ev_all, "zw": ev_next},
         "fri": {"roots": [_ints(l[2].root) for l in layers], "final": final_l},
         "queries": queries,

@@ -110,6 +110,11 @@ int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, cons
                          int32_t logm, int32_t n_next, const uint64_t z[3], const uint64_t zw[3],
                          const uint64_t gamma[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t shift,
                          uint64_t *d_out);
+/* grand product column of a permutation argument (stage-2 witness): Z[0]=1, Z[i+1]=Z[i]*(a[i]+g)/(b[i]+g)
+ * in F_{p^3}; d_a, d_b u64[n]; d_out u64[3][n] plane-major.  Division by zero (b[i]+g = 0) is the
+ * caller's concern (g is a Fiat-Shamir challenge).                                                   */
+int32_t zp_grand_product(zp_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t n, const uint64_t gamma[3],
+                         uint64_t *d_out);
 int32_t zp_gather_rows(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, const uint64_t *h_idx, int32_t nq,
                        uint64_t *h_out);
 int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, const uint64_t *h_idx, int32_t nq,
@@ -126,8 +131,8 @@ int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, cons
  * zp_domain_tables hands such kernels the ctx-owned two-level table of w_M^e (x = shift*lo[e&mask]*hi[e>>lb]). */
 int32_t zp_domain_tables(zp_ctx *ctx, int32_t logm, const uint64_t **d_lo, const uint64_t **d_hi, int32_t *lb);
 /* synthetic witness generation (stands in for the zkVM executor, which is not obtainable offline):
- * kind 0 = Fibonacci (W=2), kind 1 = wide degree-2 mix (any W >= 3).  h_trace u64[W][2^logn],
- * h_pub receives the public inputs (3 for kind 0, min(4,W) for kind 1).  Host code.                 */
+ * kind 0 = Fibonacci (W=2), kind 1 = wide degree-2 mix (any W >= 3), kind 2 = permutation AIR (W=3:
+ * a, b = a permuted, c = a^2).  h_trace u64[W][2^logn]; h_pub receives the public inputs (3 / min(4,W) / 1).                 */
 int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uint64_t *h_trace, uint64_t *h_pub);
 
 /* ---- N6: BN254 (alt_bn128) G1 multi-scalar multiplication ---------------------------------------

@@ -512,6 +512,16 @@ void orc_deep_quotient_fast(const u64 *cols_a, int Wa, const u64 *cols_b, int Wb
     free(gp);
 }
 
+/* grand product column (sequential definition): Z[0]=1, Z[i+1] = Z[i]*(a[i]+g)/(b[i]+g) in F_{p^3} */
+void orc_grand_product(const u64 *a, const u64 *b, size_t n, const u64 *g, u64 *out) {
+    e3 z = {{1, 0, 0}};
+    for (size_t i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) out[(size_t)c * n + i] = z.c[c];
+        e3 num = {{gl_add(a[i], g[0]), g[1], g[2]}}, den = {{gl_add(b[i], g[0]), g[1], g[2]}};
+        z = e3_mul(z, e3_mul(num, e3_inv_pow(den)));
+    }
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -62,6 +62,7 @@ def lib():
         L.orc_deep_quotient.argtypes = [_u64p, i32, _u64p, i32, i32, i32, _u64p, _u64p, _u64p, _u64p, _u64p, u64, u64, _u64p]
         L.orc_poly_eval_e3_cols.argtypes = [_u64p, sz, i32, _u64p, _u64p]
         L.orc_deep_quotient_fast.argtypes = L.orc_deep_quotient.argtypes
+        L.orc_grand_product.argtypes = [_u64p, _u64p, sz, _u64p, _u64p]
         L.orc_fri_fold.argtypes = [_u64p, _u64p, i32, i32, _u64p, u64, u64]
         L.orc_poly_eval.restype = u64
         L.orc_poly_eval.argtypes = [_u64p, sz, u64]
@@ -175,6 +176,13 @@ def deep_quotient(cols_a, cols_b, n_next, z, zw, gamma, ev_z, ev_zw, shift=SHIFT
     ezw = _arr(ev_zw) if n_next else np.zeros((1, 3), dtype=np.uint64)
     (lib().orc_deep_quotient_fast if fast else lib().orc_deep_quotient)(_p(a), Wa, _p(b), Wb, M.bit_length() - 1, n_next, _p(_arr(z)), _p(_arr(zw)),
                             _p(_arr(gamma)), _p(_arr(ev_z)), _p(ezw), shift, root32, _p(out))
+    return out
+
+
+def grand_product(a, b, gamma):
+    a, b = _arr(a), _arr(b)
+    out = np.empty((3, a.shape[0]), dtype=np.uint64)
+    lib().orc_grand_product(_p(a), _p(b), a.shape[0], _p(_arr(gamma)), _p(out))
     return out
 
 

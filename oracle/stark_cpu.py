@@ -51,11 +51,27 @@ class CpuBackend:
     def poseidon_perm(self, state):
         return [int(v) for v in O.poseidon_perm(np.array([state], dtype=np.uint64), self.rc, self.mds)[0]]
 
-    def commit_trace(self, trace, logn, logb):
-        ext = O.lde(trace, logb, self.shift, self.root32)
-        coef = O.intt(trace, self.root32)
-        tree = O.merkle_commit(ext, self.rc, self.mds)
-        return Commit([int(v) for v in tree[-1]], tree, ext, coef)
+    def commit_trace(self, trace, logn, logb, extra_cols=0):
+        W = trace.shape[0]
+        e1 = O.lde(trace, logb, self.shift, self.root32)
+        tree = O.merkle_commit(e1, self.rc, self.mds)
+        ext = np.zeros((W + extra_cols, e1.shape[1]), dtype=np.uint64)
+        coef = np.zeros((W + extra_cols, trace.shape[1]), dtype=np.uint64)
+        ext[:W], coef[:W] = e1, O.intt(trace, self.root32)
+        c = Commit([int(v) for v in tree[-1]], tree, ext, coef)
+        c.trace, c.W = trace, W
+        return c
+
+    def column_view(self, mat, col, rows):
+        return np.asarray(mat).reshape(-1, rows)[col:]
+
+    def commit_stage2(self, air, c1, chal, logn, logb):
+        st, W = air.stage2, c1.W
+        z = O.grand_product(c1.trace[st["a"]], c1.trace[st["b"]], chal)
+        c1.ext[W:] = O.lde(z, logb, self.shift, self.root32)
+        c1.coef[W:] = O.intt(z, self.root32)
+        tree = O.merkle_commit(np.ascontiguousarray(c1.ext[W:]), self.rc, self.mds)
+        return Commit([int(v) for v in tree[-1]], tree)
 
     def commit_cols(self, cols, M, W):
         mat = np.ascontiguousarray(np.asarray(cols).reshape(W, M))
@@ -85,7 +101,7 @@ class CpuBackend:
         pub = np.array(list(pubs) + [0], dtype=np.uint64)
         ap = np.ascontiguousarray(np.array(apow, dtype=np.uint64).reshape(-1))
         zh = np.array(zhinv, dtype=np.uint64)
-        fn(O._p(c1.ext), O._p(fixed), M, 1 << logb, O._p(pub), O._p(ap), O._p(zh), O._p(lo), O._p(hi), lb, self.shift,
+        fn(O._p(np.ascontiguousarray(c1.ext)), O._p(fixed), M, 1 << logb, O._p(pub), O._p(ap), O._p(zh), O._p(lo), O._p(hi), lb, self.shift,
            wlast, O._p(out))
         return out
 
@@ -93,10 +109,10 @@ class CpuBackend:
         return O.intt(np.asarray(planes).reshape(W, 1 << logm), self.root32)
 
     def eval_ext(self, coef, logn, W, point):
-        return O.poly_eval_e3_cols(np.asarray(coef).reshape(W, 1 << logn), point)
+        return O.poly_eval_e3_cols(np.ascontiguousarray(np.asarray(coef).reshape(-1, 1 << logn)[:W]), point)
 
     def deep(self, a, Wa, b, Wb, logm, n_next, z, zw, gamma, ev_z, ev_zw):
-        return O.deep_quotient(np.asarray(a).reshape(Wa, 1 << logm), np.asarray(b).reshape(Wb, 1 << logm), n_next, z, zw,
+        return O.deep_quotient(np.ascontiguousarray(np.asarray(a).reshape(-1, 1 << logm)[:Wa]), np.asarray(b).reshape(Wb, 1 << logm), n_next, z, zw,
                                gamma, ev_z, ev_zw, self.shift, self.root32, fast=True)
 
     def fri_fold(self, planes, logn, logf, beta, shift):
@@ -106,7 +122,7 @@ class CpuBackend:
         return np.asarray(d).reshape(shape)
 
     def gather_rows(self, cols, M, W, idx):
-        mat = np.asarray(cols).reshape(W, M)
+        mat = np.asarray(cols).reshape(-1, M)[:W]
         return np.ascontiguousarray(mat[:, np.asarray(idx, dtype=np.int64)].T)
 
     def open_paths(self, tree, M, idx):

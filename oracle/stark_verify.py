@@ -70,11 +70,19 @@ def verify(proof, air, rc, mds):
     tr = Transcript(perm)
     tr.absorb([logn, logb, W] + pubs)
     tr.absorb(proof["roots"]["trace"])
+    W2 = air.width2
+    Wt = W + W2
+    chal = []
+    if air.stage2:
+        if "stage2" not in proof["roots"]:
+            raise Reject("missing stage-2 commitment")
+        chal = tr.challenge_e3()
+        tr.absorb(proof["roots"]["stage2"])
     alpha = tr.challenge_e3()
     tr.absorb(proof["roots"]["quotient"])
     zeta = tr.challenge_e3()
     ev_all, ev_next = proof["evals"]["z"], proof["evals"]["zw"]
-    if len(ev_all) != W + 3 or len(ev_next) != W:
+    if len(ev_all) != Wt + 3 or len(ev_next) != Wt:
         raise Reject("wrong number of evaluations")
     for r in ev_all + ev_next:
         tr.absorb(r)
@@ -88,15 +96,15 @@ def verify(proof, air, rc, mds):
     l_first = NV.e3_mul([v * ninv % P for v in zh], NV.e3_inv(_e3_sub(zeta, [1, 0, 0])))
     l_last = NV.e3_mul([v * ninv % P * wlast % P for v in zh], NV.e3_inv(_e3_sub(zeta, [wlast, 0, 0])))
     xml = _e3_sub(zeta, [wlast, 0, 0])
-    cs = eval_constraints_ext(air, ev_all[:W], ev_next, [l_first, l_last], pubs, xml, NV.e3_mul, NV.e3_add, _e3_sub,
-                              lambda v: [v % P, 0, 0])
+    cs = eval_constraints_ext(air, ev_all[:Wt], ev_next, [l_first, l_last], pubs, xml, NV.e3_mul, NV.e3_add, _e3_sub,
+                              lambda v: [v % P, 0, 0], chal)
     lhs, ap = [0, 0, 0], [1, 0, 0]
     for c in cs:
         lhs = NV.e3_add(lhs, NV.e3_mul(ap, c))
         ap = NV.e3_mul(ap, alpha)
-    q = ev_all[W]
-    q = NV.e3_add(q, _mul_theta(ev_all[W + 1]))
-    q = NV.e3_add(q, _mul_theta(_mul_theta(ev_all[W + 2])))
+    q = ev_all[Wt]
+    q = NV.e3_add(q, _mul_theta(ev_all[Wt + 1]))
+    q = NV.e3_add(q, _mul_theta(_mul_theta(ev_all[Wt + 2])))
     if lhs != NV.e3_mul(q, zh):
         raise Reject("constraint identity fails at the out-of-domain point")
 
@@ -129,9 +137,9 @@ def verify(proof, air, rc, mds):
             raise Reject("final FRI layer is not low degree")
 
     zeta_w = [v * wN % P for v in zeta]
-    Wall = W + 3
+    Wall = Wt + 3
     gp, cur = [], [1, 0, 0]
-    for _ in range(Wall + W):
+    for _ in range(Wall + Wt):
         gp.append(cur)
         cur = NV.e3_mul(cur, gamma)
 
@@ -146,12 +154,21 @@ def verify(proof, air, rc, mds):
         if not O.merkle_verify(O.linear_hash(np.array(qv, dtype=np.uint64), rc, mds), M, j, np.array(qq["quotient"]["path"], dtype=np.uint64),
                                np.array(proof["roots"]["quotient"], dtype=np.uint64), rc, mds):
             raise Reject("quotient opening does not verify")
+        s2v = []
+        if air.stage2:
+            s2 = qq.get("stage2")
+            if s2 is None or len(s2["values"]) != W2:
+                raise Reject("missing stage-2 opening")
+            s2v = s2["values"]
+            if not O.merkle_verify(O.linear_hash(np.array(s2v, dtype=np.uint64), rc, mds), M, j, np.array(s2["path"], dtype=np.uint64),
+                                   np.array(proof["roots"]["stage2"], dtype=np.uint64), rc, mds):
+                raise Reject("stage-2 opening does not verify")
         x = shift * pow(wM, j, P) % P
-        vals = tv + qv
+        vals = tv + s2v + qv
         A, B = [0, 0, 0], [0, 0, 0]
         for k in range(Wall):
             A = NV.e3_add(A, NV.e3_mul(gp[k], _e3_sub([vals[k], 0, 0], ev_all[k])))
-        for k in range(W):
+        for k in range(Wt):
             B = NV.e3_add(B, NV.e3_mul(gp[Wall + k], _e3_sub([vals[k], 0, 0], ev_next[k])))
         Fx = NV.e3_add(NV.e3_mul(A, NV.e3_inv(_e3_sub([x, 0, 0], zeta))),
                        NV.e3_mul(B, NV.e3_inv(_e3_sub([x, 0, 0], zeta_w))))

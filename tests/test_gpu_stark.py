@@ -72,6 +72,25 @@ def test_gather_and_batch_open(prover, tables):
         prover.gather_rows(d, M, W, [M])
 
 
+@pytest.mark.parametrize("n", [1, 2, 17, 4096, 4097, (1 << 16) + 5, 1 << 20])
+def test_grand_product_matches_oracle(prover, n):
+    a = O.random_field((n,), 80)
+    b = a[np.random.default_rng(81).permutation(n)]
+    g = O.random_field((3,), 82).tolist()
+    d_out = prover.alloc(3 * n)
+    prover.grand_product(prover.upload(a), prover.upload(b), n, g, d_out)
+    got = prover.download(d_out, (3, n))
+    if n <= (1 << 16) + 5:
+        assert (got == O.grand_product(a, b, g)).all()
+    else:   # size-independent properties: Z[0] = 1 and the recurrence at sampled rows
+        assert got[:, 0].tolist() == [1, 0, 0]
+        for i in [0, 1, 4095, 4096, n // 2, n - 2]:
+            zi = [int(got[c, i]) for c in range(3)]
+            zn = [int(got[c, i + 1]) for c in range(3)]
+            lhs = NV.e3_mul(zn, [(int(b[i]) + g[0]) % P, g[1], g[2]])
+            assert lhs == NV.e3_mul(zi, [(int(a[i]) + g[0]) % P, g[1], g[2]])
+
+
 @pytest.mark.parametrize("name,logn", [("fib", 5), ("wide8", 8), ("wide32", 10)])
 def test_constraint_kernel_matches_cpu_codegen(hip_backend, cpu_backend, name, logn):
     air = AIR.get_air(name)
@@ -86,7 +105,7 @@ def test_constraint_kernel_matches_cpu_codegen(hip_backend, cpu_backend, name, l
     assert (hip_backend.download(d_q, q_cpu.shape) == q_cpu).all()
 
 
-@pytest.mark.parametrize("name,logn,queries", [("fib", 6, 5), ("fib", 12, 8), ("wide8", 10, 8), ("wide32", 13, 12), ("wide64", 14, 8)])
+@pytest.mark.parametrize("name,logn,queries", [("fib", 6, 5), ("fib", 12, 8), ("perm", 7, 6), ("perm", 13, 8), ("wide8", 10, 8), ("wide32", 13, 12), ("wide64", 14, 8)])
 def test_gpu_proof_is_bit_identical_to_cpu_and_verifies(hip_backend, cpu_backend, tables, name, logn, queries):
     rc, mds = tables
     air = AIR.get_air(name)

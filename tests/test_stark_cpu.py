@@ -48,7 +48,7 @@ def test_transcript_is_deterministic_and_order_sensitive(be):
     assert t1.squeeze(9) == t2.squeeze(9)
 
 
-@pytest.mark.parametrize("name,logn", [("fib", 5), ("wide8", 7)])
+@pytest.mark.parametrize("name,logn", [("fib", 5), ("wide8", 7), ("perm", 6)])
 def test_cpu_proof_verifies_and_tampering_is_rejected(be, tables, name, logn):
     rc, mds = tables
     air = AIR.get_air(name)
@@ -76,3 +76,24 @@ def test_wrong_witness_cannot_be_proven(be, tables):
     proof = PR.prove(air, tr, pub, PR.StarkParams(6, 1, 3, 3, 6), be)
     with pytest.raises(V.Reject):
         V.verify(proof, air, rc, mds)
+
+
+def test_permutation_argument_rejects_non_permutation(be, tables):
+    rc, mds = tables
+    air = AIR.get_air("perm")
+    tr, pub = native.synth_trace(2, 6, 3, 11)
+    assert sorted(tr[0].tolist()) == sorted(tr[1].tolist())
+    tr[1, 5] = (int(tr[1, 5]) + 1) % V.P
+    proof = PR.prove(air, tr, pub, PR.StarkParams(6, 1, 3, 3, 6), be)
+    with pytest.raises(V.Reject):
+        V.verify(proof, air, rc, mds)
+    good, pub = native.synth_trace(2, 6, 3, 11)
+    proof = PR.prove(air, good, pub, PR.StarkParams(6, 1, 3, 3, 6), be)
+    bad = copy.deepcopy(proof)
+    bad["queries"][0]["stage2"]["values"][0] ^= 1
+    with pytest.raises(V.Reject):
+        V.verify(bad, air, rc, mds)
+    bad = copy.deepcopy(proof)
+    del bad["roots"]["stage2"]
+    with pytest.raises(V.Reject):
+        V.verify(bad, air, rc, mds)
