@@ -122,7 +122,25 @@ GL_HD u64 gl_pow(u64 b, u64 e) {
     }
     return r;
 }
-GL_HD u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }
+// a^(p-2), p-2 = 0xFFFFFFFE_FFFFFFFF = (2*(2^31-1))*2^32 + (2^32-1): addition chain on x^(2^k-1),
+// 75 squarings + 10 multiplications (plain square-and-multiply needs 63 + 63)
+GL_HD u64 gl_sqr_n(u64 x, int n) {
+    for (int i = 0; i < n; i++) x = gl_mul(x, x);
+    return x;
+}
+GL_HD u64 gl_inv(u64 a) {
+    const u64 t2 = gl_mul(gl_sqr_n(a, 1), a);        // a^(2^2-1)
+    const u64 t3 = gl_mul(gl_sqr_n(t2, 1), a);       // 2^3-1
+    const u64 t4 = gl_mul(gl_sqr_n(t2, 2), t2);      // 2^4-1
+    const u64 t7 = gl_mul(gl_sqr_n(t4, 3), t3);      // 2^7-1
+    const u64 t8 = gl_mul(gl_sqr_n(t4, 4), t4);      // 2^8-1
+    const u64 t15 = gl_mul(gl_sqr_n(t8, 7), t7);     // 2^15-1
+    const u64 t16 = gl_mul(gl_sqr_n(t8, 8), t8);     // 2^16-1
+    const u64 t31 = gl_mul(gl_sqr_n(t16, 15), t15);  // 2^31-1
+    const u64 t32 = gl_mul(gl_sqr_n(t31, 1), a);     // 2^32-1
+    const u64 hi = gl_sqr_n(t31, 1);                 // a^(2^32-2)
+    return gl_mul(gl_sqr_n(hi, 32), t32);
+}
 
 // primitive 2^logn-th root derived from the configured 2^32-th root
 GL_HD u64 gl_root(u64 root32, int logn) {

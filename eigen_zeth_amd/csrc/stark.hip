@@ -86,11 +86,15 @@ __global__ void __launch_bounds__(256) deep_quotient_kernel(DeepArgs a) {
     A = e3_sub(A, e3_make(a.ca[0], a.ca[1], a.ca[2]));
     B = e3_sub(B, e3_make(a.cb[0], a.cb[1], a.cb[2]));
     const u64 x = gl_mul(a.shift, gl_mul(a.twl[r & ((1ULL << a.lb) - 1)], a.twh[r >> a.lb]));
-    const e3 d1 = e3_inv(e3_make(gl_sub(x, a.z[0]), gl_neg(a.z[1]), gl_neg(a.z[2])));
-    e3 F = e3_mul(A, d1);
+    const e3 d1 = e3_make(gl_sub(x, a.z[0]), gl_neg(a.z[1]), gl_neg(a.z[2]));
+    e3 F;
     if (a.nnext > 0) {
-        const e3 d2 = e3_inv(e3_make(gl_sub(x, a.zw[0]), gl_neg(a.zw[1]), gl_neg(a.zw[2])));
-        F = e3_add(F, e3_mul(B, d2));
+        // one inversion for both denominators: 1/d1 = d2/(d1 d2), 1/d2 = d1/(d1 d2)
+        const e3 d2 = e3_make(gl_sub(x, a.zw[0]), gl_neg(a.zw[1]), gl_neg(a.zw[2]));
+        const e3 pi = e3_inv(e3_mul(d1, d2));
+        F = e3_add(e3_mul(A, e3_mul(pi, d2)), e3_mul(B, e3_mul(pi, d1)));
+    } else {
+        F = e3_mul(A, e3_inv(d1));
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) a.out[(u64)c * M + r] = F.c[c];
