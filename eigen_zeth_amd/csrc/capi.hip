@@ -291,9 +291,7 @@ int32_t zp_lde_host(zp_ctx *ctx, const uint64_t *h_in, uint64_t *h_out, int32_t 
 int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value) {
     if (!ctx) return ZP_ERR_ARG;
     ZP_ARG(ctx, key != nullptr, "null key");
-    if (!strcmp(key, "ntt_diag")) ctx->tune_diag = value;
-    else if (!strcmp(key, "ntt_logt")) ctx->tune_logt = value;
-    else if (!strcmp(key, "ntt_v2")) ctx->tune_v2 = value;
+    if (!strcmp(key, "ntt_logt")) ctx->tune_logt = value;
     else if (!strcmp(key, "ntt_tpw")) ctx->tune_tpw = value;
     else if (!strcmp(key, "ntt_logt9")) ctx->tune_logt9 = value;
     else { ctx->err = "unknown tuning key"; return ZP_ERR_ARG; }

@@ -59,7 +59,7 @@ struct zp_ctx {
     // misc small device buffer for parameters
     int num_cu = 256;
     // experiment knobs (zp_set_tuning): not part of the stable surface
-    int tune_diag = 0, tune_logt = 4, tune_v2 = 2, tune_tpw = 4, tune_logt9 = 5;
+    int tune_logt = 4, tune_tpw = 4, tune_logt9 = 5;
     // per-launch event profiling (zp_set_profiling)
     bool profiling = false;
     struct PassEv { hipEvent_t a, b; int radix_log; };

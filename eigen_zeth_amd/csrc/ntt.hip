@@ -10,8 +10,8 @@
 //     out[s*Pprev*R + k*Pprev + c] = b_k                    (segments of >= 256 contiguous bytes)
 // so natural order goes in and natural order comes out with every global access coalesced in
 // 256-byte runs and no separate transpose / bit-reversal pass.  Inside a tile the R-point DFT is
-// 2-3 rounds of register radix-2^A (A <= 4, 16 elements per thread) exchanged through LDS with an
-// XOR swizzle so that both the row accesses and the transposing copy-out of pass 1 are
+// 2-3 rounds of register radix-2^A (A <= 4, 16 elements per thread, shift-only butterflies) exchanged
+// through LDS with an XOR swizzle so that both the row accesses and the transposing copy-out of pass 1 are
 // bank-conflict free (MI355X_MICROARCH.md, LDS: ds_read_b64 = 2x32 lanes over 64 banks).
 #include <hip/hip_runtime.h>
 
@@ -30,7 +30,6 @@ struct PassArgs {
     const u64 *twl, *twh;
     const u64 *tws;
     const u64 *csl, *csh;  // coset post-scale tables (last pass of the inverse transform in LDE)
-    u64 w16[8];
     u64 scale;
     int logn, logPprev, lb, cslb;
     int j0inv;  // w_16(user) = (2^12)^j0, j0inv = j0^-1 mod 16; 0 = root not a power of two path (generic twiddles)
@@ -44,26 +43,6 @@ __device__ __forceinline__ constexpr int brev(int x, int bits) {
 }
 __device__ __forceinline__ constexpr int slot_of(int o, int j, int pos, int A) {
     return ((o >> pos) << (pos + A)) | (j << pos) | (o & ((1 << pos) - 1));
-}
-
-// radix-2^A decimation-in-frequency on v[0..2^A): output X[brev(p)] lands in v[p]
-template <int A>
-__device__ __forceinline__ void dif(u64 *v, const u64 *w16) {
-#pragma unroll
-    for (int s = 0; s < A; s++) {
-        const int half = 1 << (A - 1 - s);
-#pragma unroll
-        for (int b = 0; b < (1 << A); b += 2 * half) {
-#pragma unroll
-            for (int i = 0; i < half; i++) {
-                u64 x = v[b + i], y = v[b + i + half];
-                v[b + i] = gl_add(x, y);
-                u64 d = gl_sub(x, y);
-                const int e = i * (8 / half);
-                v[b + i + half] = (e == 0) ? d : gl_mul(d, w16[e]);
-            }
-        }
-    }
 }
 
 template <int A1, int A2, int A3, int LOGT>
@@ -99,136 +78,6 @@ __device__ __forceinline__ u64 tw_lookup(const u64 *lo, const u64 *hi, int lb, u
     u64 a = lo[e & ((1ULL << lb) - 1)];
     u64 b = hi[e >> lb];
     return gl_mul(a, b);
-}
-
-// one LDS-exchanged round: registers -> (twiddle) -> LDS -> barrier -> registers of the next round
-template <typename G, int A, int POS, int ANEXT, int POSNEXT, int DIAG>
-__device__ __forceinline__ void exchange(u64 *v, u64 *lds, const PassArgs &a, int tid) {
-    constexpr int GR = 16 >> A;
-#pragma unroll
-    for (int g = 0; g < GR; g++) {
-        const int gamma = g * G::NT + tid;
-        const int t = gamma & (G::T - 1), o = gamma >> G::LT;
-        const int rho = o & ((1 << POS) - 1);
-#pragma unroll
-        for (int p = 0; p < (1 << A); p++) {
-            const int kj = brev(p, A);
-            u64 x = v[g * (1 << A) + p];
-            // w_(2^(POS+A))^(kj*rho) = w_4096^(kj*rho*2^(12-POS-A))
-            if (kj != 0 && DIAG != 1) x = gl_mul(x, a.tws[(kj * rho) << (12 - POS - A)]);
-            lds[G::lpos(slot_of(o, kj, POS, A), t)] = x;
-        }
-    }
-    __syncthreads();
-    constexpr int GN = 16 >> ANEXT;
-#pragma unroll
-    for (int g = 0; g < GN; g++) {
-        const int gamma = g * G::NT + tid;
-        const int t = gamma & (G::T - 1), o = gamma >> G::LT;
-#pragma unroll
-        for (int j = 0; j < (1 << ANEXT); j++)
-            v[g * (1 << ANEXT) + j] = lds[G::lpos(slot_of(o, j, POSNEXT, ANEXT), t)];
-    }
-}
-
-template <int A1, int A2, int A3, int LOGT, bool TRANSPOSE, int DIAG>
-__global__ void __launch_bounds__((1 << (A1 + A2 + A3 + LOGT)) / 16)
-ntt_pass_kernel(PassArgs a) {
-    using G = Geo<A1, A2, A3, LOGT>;
-    constexpr int L = G::L, T = G::T, NT = G::NT, AJ = G::AJ;
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const int tid = threadIdx.x;
-    const u64 col = blockIdx.y;
-    const u64 u0 = (u64)blockIdx.x << LOGT;
-    const int logNR = a.logn - L;
-    const u64 *src = a.in + col * a.in_cs;
-    u64 *dst = a.out + col * a.out_cs;
-    u64 v[16];
-
-    // ---- round 1: global -> registers
-    {
-        constexpr int GR = 16 >> A1;
-#pragma unroll
-        for (int g = 0; g < GR; g++) {
-            const int gamma = g * NT + tid;
-            const int t = gamma & (T - 1), o = gamma >> LOGT;
-#pragma unroll
-            for (int j = 0; j < (1 << A1); j++) {
-                const u64 idx = ((u64)slot_of(o, j, G::POS1, A1) << logNR) + u0 + t;
-                if constexpr (DIAG == 2) v[g * (1 << A1) + j] = idx * 0x9E3779B97F4A7C15ULL >> 1;
-                else v[g * (1 << A1) + j] = idx < a.in_valid ? src[idx] : 0ULL;
-            }
-        }
-        if constexpr (DIAG != 1)
-#pragma unroll
-            for (int g = 0; g < GR; g++) dif<A1>(v + g * (1 << A1), a.w16);
-    }
-    if constexpr (G::J >= 2) {
-        exchange<G, A1, G::POS1, A2, G::POS2, DIAG>(v, lds, a, tid);
-        if constexpr (DIAG != 1)
-#pragma unroll
-            for (int g = 0; g < (16 >> A2); g++) dif<A2>(v + g * (1 << A2), a.w16);
-    }
-    if constexpr (G::J >= 3) {
-        exchange<G, A2, G::POS2, A3, 0, DIAG>(v, lds, a, tid);
-        if constexpr (DIAG != 1)
-#pragma unroll
-            for (int g = 0; g < (16 >> A3); g++) dif<A3>(v + g * (1 << A3), a.w16);
-    }
-
-    // ---- output: the last round's field sits at bit 0 of the slot
-    constexpr int GR = 16 >> AJ;
-    const int logP = a.logPprev;
-#pragma unroll
-    for (int g = 0; g < GR; g++) {
-        const int gamma = g * NT + tid;
-        const int t = gamma & (T - 1), o = gamma >> LOGT;
-        const int klow = G::kof(o << AJ);
-        const u64 u = u0 + t;
-        const u64 s = TRANSPOSE ? u : (u0 >> logP);
-        const u64 e0 = TRANSPOSE ? u : (s << logP);
-        u64 w = 1, wstep = 1;
-        if ((a.flags & 1) && DIAG != 1) {
-            w = tw_lookup(a.twl, a.twh, a.lb, e0 * (u64)klow);
-            wstep = tw_lookup(a.twl, a.twh, a.lb, e0 << (L - AJ));
-        }
-        if (a.flags & 2) w = gl_mul(w, a.scale);
-        // natural output index of (k, u):  s*Pprev*R + k*Pprev + c
-        const u64 obase = TRANSPOSE ? 0 : ((s << (logP + L)) + (u & ((1ULL << logP) - 1)));
-        u64 cw = 1, cstep = 1;
-        if (a.flags & 4) {  // only used on a last pass (s == 0): i = k*Pprev + c
-            cw = tw_lookup(a.csl, a.csh, a.cslb, obase + ((u64)klow << logP));
-            cstep = tw_lookup(a.csl, a.csh, a.cslb, 1ULL << (logP + L - AJ));
-            w = gl_mul(w, cw);
-            wstep = cstep;
-        }
-#pragma unroll
-        for (int kj = 0; kj < (1 << AJ); kj++) {
-            const int p = brev(kj, AJ);
-            u64 x = v[g * (1 << AJ) + p];
-            if ((a.flags & 7) && DIAG != 1) {
-                x = gl_mul(x, w);
-                if (a.flags & 5) w = gl_mul(w, wstep);
-            }
-            const int k = klow + (kj << (L - AJ));
-            if constexpr (TRANSPOSE) {
-                lds[G::lpos(slot_of(o, kj, 0, AJ), t)] = x;
-            } else {
-                if (DIAG != 2 || (a.flags & 256)) dst[obase + ((u64)k << logP)] = x;
-            }
-        }
-    }
-    if constexpr (TRANSPOSE) {
-        __syncthreads();
-        // tile output is the contiguous block out[u0*R, (u0+T)*R): out[(u0+t)*R + k]
-        u64 *blk = dst + (u0 << L);
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int idx = i * NT + tid;
-            const int t2 = idx >> L, k = idx & ((1 << L) - 1);
-            if (DIAG != 2 || (a.flags & 256)) blk[idx] = lds[(G::sigma_of_k(k) << LOGT) + (t2 ^ (k & (T - 1)))];
-        }
-    }
 }
 
 
@@ -525,25 +374,6 @@ __global__ void __launch_bounds__(256) coset_scale_kernel(const u64 *in, u64 *ou
     if (i < n) out[col * n + i] = gl_mul(in[col * n + i], tw_lookup(lo, hi, lb, i));
 }
 
-template <int A1, int A2, int A3, int LOGT, int DIAG>
-int32_t launch_pass(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
-    using G = Geo<A1, A2, A3, LOGT>;
-    const u64 tiles = (1ULL << (a.logn - G::L)) >> LOGT;
-    dim3 grid((unsigned)tiles, (unsigned)W), block(G::NT);
-    const size_t shmem = (size_t)G::R * G::T * sizeof(u64);
-    if (transpose) {
-        auto k = ntt_pass_kernel<A1, A2, A3, LOGT, true, DIAG>;
-        if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a);
-    } else {
-        auto k = ntt_pass_kernel<A1, A2, A3, LOGT, false, DIAG>;
-        if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a);
-    }
-    ZP_HIP(ctx, hipGetLastError());
-    return ZP_OK;
-}
-
 template <int A1, int A2, int A3, int LOGT>
 int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
     using G = Geo<A1, A2, A3, LOGT>;
@@ -571,25 +401,12 @@ int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
 }
 
 int32_t dispatch_pass(zp_ctx *ctx, const NttPass &p, const PassArgs &a, bool transpose, int W) {
-    if (a.j0inv != 0 && ctx->tune_diag == 0 && ctx->tune_v2 != 0 && (!transpose || ctx->tune_v2 >= 2)) {
-        switch (p.L) {
-            case 5: return launch_pass2<3, 2, 0, 5>(ctx, a, transpose, W);
-            case 6: return launch_pass2<3, 3, 0, 5>(ctx, a, transpose, W);
-            case 7: return launch_pass2<4, 3, 0, 5>(ctx, a, transpose, W);
-            case 8: return ctx->tune_logt == 4 ? launch_pass2<4, 4, 0, 4>(ctx, a, transpose, W) : launch_pass2<4, 4, 0, 5>(ctx, a, transpose, W);
-            case 9: return ctx->tune_logt9 == 4 ? launch_pass2<3, 3, 3, 4>(ctx, a, transpose, W) : launch_pass2<3, 3, 3, 5>(ctx, a, transpose, W);
-            default: break;
-        }
-    }
-    if (p.L == 8 && ctx->tune_diag == 1) return launch_pass<4, 4, 0, 5, 1>(ctx, a, transpose, W);
-    if (p.L == 8 && ctx->tune_diag == 2) return launch_pass<4, 4, 0, 5, 2>(ctx, a, transpose, W);
-    if (p.L == 8 && ctx->tune_logt == 4) return launch_pass<4, 4, 0, 4, 0>(ctx, a, transpose, W);
     switch (p.L) {
-        case 5: return launch_pass<3, 2, 0, 5, 0>(ctx, a, transpose, W);
-        case 6: return launch_pass<3, 3, 0, 5, 0>(ctx, a, transpose, W);
-        case 7: return launch_pass<4, 3, 0, 5, 0>(ctx, a, transpose, W);
-        case 8: return launch_pass<4, 4, 0, 5, 0>(ctx, a, transpose, W);
-        case 9: return launch_pass<3, 3, 3, 5, 0>(ctx, a, transpose, W);
+        case 5: return launch_pass2<3, 2, 0, 5>(ctx, a, transpose, W);
+        case 6: return launch_pass2<3, 3, 0, 5>(ctx, a, transpose, W);
+        case 7: return launch_pass2<4, 3, 0, 5>(ctx, a, transpose, W);
+        case 8: return ctx->tune_logt == 4 ? launch_pass2<4, 4, 0, 4>(ctx, a, transpose, W) : launch_pass2<4, 4, 0, 5>(ctx, a, transpose, W);
+        case 9: return ctx->tune_logt9 == 4 ? launch_pass2<3, 3, 3, 4>(ctx, a, transpose, W) : launch_pass2<3, 3, 3, 5>(ctx, a, transpose, W);
         default: ctx->err = "unsupported pass radix"; return ZP_ERR_UNSUPPORTED;
     }
 }
@@ -781,7 +598,6 @@ int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, b
             a.twh = pl->d_twh;
             a.lb = pl->lb;
             a.tws = pl->d_tws;
-            memcpy(a.w16, pl->w16, sizeof(a.w16));
             a.scale = pl->ninv;
             a.logn = logn;
             a.logPprev = pl->pass[i].logPprev;

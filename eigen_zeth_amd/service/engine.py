@@ -27,12 +27,14 @@ from . import groth16
 
 class EngineConfig:
     def __init__(self, air="wide32", logn=12, logb=1, chunks_per_block=1, n_queries=16, fri_logf=3, fri_final_log=5,
-                 groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64):
+                 groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
+                 witness_threads=8):
         self.air, self.logn, self.logb = air, logn, logb
         self.chunks_per_block, self.n_queries = chunks_per_block, n_queries
         self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
         self.groth16_logm, self.crs_dir = groth16_logm, crs_dir
         self.l2_addr, self.txs_per_chunk = l2_addr, txs_per_chunk   # optional block-input fetcher
+        self.witness_threads = witness_threads
 
 
 class Engine:
@@ -88,18 +90,33 @@ class Engine:
         chunks = plan["chunks"]
         if len(chunks) != chunk_count:
             raise ValueError("chunk_count %d does not match batch_data (%d chunks)" % (chunk_count, len(chunks)))
-        out = []
-        for i, ch in enumerate(chunks):
+        # witness generation is host code (stand-in for the zkVM executor); run it ahead of the GPU on a small
+        # thread pool (ctypes releases the GIL) so that chunk i+1.. are generated while chunk i is being proven
+        from concurrent.futures import ThreadPoolExecutor
+
+        def witness(ch):
             air = AIR.get_air(ch["air"])
-            tm = {}
             t0 = time.perf_counter()
             trace, pubs = native.synth_trace(air.trace_kind, ch["logn"], air.width, ch["seed"])
-            tm["witness(host)"] = time.perf_counter() - t0
-            params = PR.StarkParams(ch["logn"], self.cfg.logb, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.n_queries)
-            proof = PR.prove(air, trace, pubs, params, self.be, timings=tm)
-            proof["chunk"] = {"block": ch["block"], "chunk": ch["chunk"]}
-            self.stage_timings["%s/%d" % (task_id, i)] = tm
-            out.append({"chunk_id": i, "proof_key": "chunk-%s-%d" % (task_id, i), "proof": PR.proof_to_json(proof)})
+            return air, trace, pubs, time.perf_counter() - t0
+
+        out = []
+        with ThreadPoolExecutor(max_workers=max(1, min(self.cfg.witness_threads, len(chunks)))) as pool:
+            pending = [pool.submit(witness, ch) for ch in chunks[:self.cfg.witness_threads * 2]]
+            nxt = len(pending)
+            for i, ch in enumerate(chunks):
+                air, trace, pubs, tw = pending[i].result()
+                pending[i] = None   # drop the reference: traces are large
+                if nxt < len(chunks):
+                    pending.append(pool.submit(witness, chunks[nxt]))
+                    nxt += 1
+                tm = {"witness(host)": tw}
+                params = PR.StarkParams(ch["logn"], self.cfg.logb, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.n_queries)
+                proof = PR.prove(air, trace, pubs, params, self.be, timings=tm)
+                del trace
+                proof["chunk"] = {"block": ch["block"], "chunk": ch["chunk"]}
+                self.stage_timings["%s/%d" % (task_id, i)] = tm
+                out.append({"chunk_id": i, "proof_key": "chunk-%s-%d" % (task_id, i), "proof": PR.proof_to_json(proof)})
         return out
 
     # ---- GenAggregatedProof

@@ -154,7 +154,7 @@ int32_t zp_merkle_commit_host(zp_ctx *ctx, const uint64_t *h_cols, size_t M, int
 int32_t zp_set_profiling(zp_ctx *ctx, int32_t on);
 int32_t zp_get_pass_timings(zp_ctx *ctx, float *ms, int32_t *radix_log, int32_t cap, int32_t *count);
 
-/* experiment knobs for kernel tuning sweeps (key: "ntt_diag" 0|1|2, "ntt_logt" 4|5); not for production hosts */
+/* experiment knobs for kernel tuning sweeps (keys: "ntt_logt" 4|5 tile of the radix-256 pass, "ntt_logt9" 4|5, "ntt_tpw" tiles per workgroup); not for production hosts */
 int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value);
 
 /* ---- introspection ------------------------------------------------------------------------- */

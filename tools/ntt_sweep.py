@@ -33,18 +33,10 @@ def run(label, reps=5, **tune):
     gbs = 16.0 * N * cols / dt / 1e9
     print("%-34s %8.3f ms/transform  %7.1f Gelem/s  alg %6.0f GB/s  per-pass ms %s" % (label, dt * 1e3, cols * N / dt / 1e9, gbs, per), flush=True)
     for k in tune:
-        p.set_tuning(k, {"ntt_logt": 4, "ntt_v2": 2, "ntt_tpw": 4}.get(k, 0))
+        p.set_tuning(k, {"ntt_logt": 4, "ntt_tpw": 4}.get(k, 0))
 
-run("v2 tpw=4 (default)")
-run("v1 kernels", ntt_v2=0)
-run("no-math (memory+LDS only, v1)", ntt_diag=1)
-run("no-global (compute+LDS only, v1)", ntt_diag=2)
-run("v2 passes>=2 only, tpw=1", ntt_v2=1, ntt_tpw=1)
-run("v2 tpw=1", ntt_tpw=1)
-run("v2 tpw=2", ntt_tpw=2)
-run("v2 tpw=8", ntt_tpw=8)
-run("v2 tpw=16", ntt_tpw=16)
-run("v2 T=16 tpw=1", ntt_logt=4, ntt_tpw=1)
-run("v2 T=16 tpw=2", ntt_logt=4, ntt_tpw=2)
-run("v2 T=16 tpw=4", ntt_logt=4, ntt_tpw=4)
-run("v2 T=16 tpw=8", ntt_logt=4, ntt_tpw=8)
+run("default (T=16, tpw=4)")
+run("T=32 tpw=4", ntt_logt=5)
+run("T=16 tpw=1", ntt_tpw=1)
+run("T=16 tpw=2", ntt_tpw=2)
+run("T=16 tpw=8", ntt_tpw=8)
