@@ -173,7 +173,7 @@ def main():
             "device_ms_per_step": dev_ms / args.steps,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ntt_pass2_kernel radix 2^%d (%s)" % (abs(dom), "transposing first pass" if dom < 0 else "non-transposing pass, passes 2..m"),
+                "kernel": "ntt_pass2_kernel<%s> radix 2^%d (%s)" % ("4,4,0,4,false,false,{1,0}" if dom == 8 else "...", abs(dom), "transposing first pass" if dom < 0 else "non-transposing passes 2..m: MODE 1 = twiddle table, MODE 0 = plain last pass"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if launches else None,
                 "traffic": traffic,
