@@ -64,49 +64,53 @@ FQ_HD bool fq_eq(const fq &a, const fq &b) {
     for (int i = 0; i < 8; i++) o |= a.l[i] ^ b.l[i];
     return o == 0;
 }
-FQ_HD bool fq_geq_q(const u32 *t) {
+// r = t - q if (extra || t >= q) else t   -- branch-free (a divergent early-exit compare in every field
+// operation serialises the wave)
+FQ_HD fq fq_cond_sub(const u32 *t, u32 extra) {
     const u32 *q = fq_q();
-    for (int i = 7; i >= 0; i--) {
-        if (t[i] > q[i]) return true;
-        if (t[i] < q[i]) return false;
+    u32 d[8];
+    u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 x = (u64)t[i] - q[i] - br;
+        d[i] = (u32)x;
+        br = (x >> 32) & 1;
     }
-    return true;
+    const u32 use_d = 0u - (u32)((extra != 0) | (br == 0));   // all ones: take t - q
+    fq r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = (d[i] & use_d) | (t[i] & ~use_d);
+    return r;
 }
 FQ_HD fq fq_add(const fq &a, const fq &b) {
-    const u32 *q = fq_q();
-    fq r;
+    u32 t[8];
     u64 c = 0;
+#pragma unroll
     for (int i = 0; i < 8; i++) {
         c += (u64)a.l[i] + b.l[i];
-        r.l[i] = (u32)c;
+        t[i] = (u32)c;
         c >>= 32;
     }
-    if (c || fq_geq_q(r.l)) {
-        u64 br = 0;
-        for (int i = 0; i < 8; i++) {
-            u64 d = (u64)r.l[i] - q[i] - br;
-            r.l[i] = (u32)d;
-            br = (d >> 32) & 1;
-        }
-    }
-    return r;
+    return fq_cond_sub(t, (u32)c);
 }
 FQ_HD fq fq_sub(const fq &a, const fq &b) {
     const u32 *q = fq_q();
-    fq r;
+    u32 t[8];
     u64 br = 0;
+#pragma unroll
     for (int i = 0; i < 8; i++) {
-        u64 d = (u64)a.l[i] - b.l[i] - br;
-        r.l[i] = (u32)d;
+        const u64 d = (u64)a.l[i] - b.l[i] - br;
+        t[i] = (u32)d;
         br = (d >> 32) & 1;
     }
-    if (br) {
-        u64 c = 0;
-        for (int i = 0; i < 8; i++) {
-            c += (u64)r.l[i] + q[i];
-            r.l[i] = (u32)c;
-            c >>= 32;
-        }
+    const u32 m = 0u - (u32)br;   // borrowed: add q back
+    fq r;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (u64)t[i] + (q[i] & m);
+        r.l[i] = (u32)c;
+        c >>= 32;
     }
     return r;
 }
@@ -141,18 +145,7 @@ FQ_HD fq fq_mul(const fq &a, const fq &b) {
         t[7] = (u32)s;
         t[8] = t[9] + (u32)(s >> 32);
     }
-    fq r;
-    if (t[8] || fq_geq_q(t)) {
-        u64 br = 0;
-        for (int i = 0; i < 8; i++) {
-            u64 d = (u64)t[i] - q[i] - br;
-            r.l[i] = (u32)d;
-            br = (d >> 32) & 1;
-        }
-    } else {
-        for (int i = 0; i < 8; i++) r.l[i] = t[i];
-    }
-    return r;
+    return fq_cond_sub(t, t[8]);
 }
 FQ_HD fq fq_sqr(const fq &a) { return fq_mul(a, a); }
 FQ_HD fq fq_to_mont(const fq &a) { return fq_mul(a, fq_r2()); }
@@ -305,20 +298,52 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const u32 *scalars, u6
         }
     }
 }
-// ---- 2. bucket sums: lane = (window, bucket)
-__global__ void __launch_bounds__(256) msm_bucket_kernel(const u32 *points, u64 n, int c, int nwin, const u32 *starts,
+// ---- 2a. one-time conversion of the affine inputs to Montgomery form (16-byte vector accesses)
+__global__ void __launch_bounds__(256) msm_to_mont_kernel(const uint4 *points, u64 n, uint4 *mont) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint4 q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = points[i * 4 + k];
+    fq x, y;
+    x.l[0] = q[0].x; x.l[1] = q[0].y; x.l[2] = q[0].z; x.l[3] = q[0].w; x.l[4] = q[1].x; x.l[5] = q[1].y; x.l[6] = q[1].z; x.l[7] = q[1].w;
+    y.l[0] = q[2].x; y.l[1] = q[2].y; y.l[2] = q[2].z; y.l[3] = q[2].w; y.l[4] = q[3].x; y.l[5] = q[3].y; y.l[6] = q[3].z; y.l[7] = q[3].w;
+    x = fq_to_mont(x);   // (0,0) stays (0,0): still the infinity marker
+    y = fq_to_mont(y);
+    mont[i * 4 + 0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+    mont[i * 4 + 1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    mont[i * 4 + 2] = make_uint4(y.l[0], y.l[1], y.l[2], y.l[3]);
+    mont[i * 4 + 3] = make_uint4(y.l[4], y.l[5], y.l[6], y.l[7]);
+}
+// ---- 2b. bucket sums: lane = (window, bucket); the next point is fetched while the current one is added
+__global__ void __launch_bounds__(256) msm_bucket_kernel(const uint4 *mont, u64 n, int c, int nwin, const u32 *starts,
                                                         const u32 *counts, const u32 *sorted, jac *buckets) {
     const u64 id = (u64)blockIdx.x * 256 + threadIdx.x;
     if (id >= ((u64)nwin << c)) return;
     const u64 w = id >> c;
     const u32 st = starts[id], cnt = counts[id];
+    const u32 *idx = sorted + w * n + st;
     jac acc = jac_inf();
+    uint4 nx[4];
+    if (cnt) {
+        const u64 p0 = idx[0];
+#pragma unroll
+        for (int k = 0; k < 4; k++) nx[k] = mont[p0 * 4 + k];
+    }
     for (u32 k = 0; k < cnt; k++) {
-        const u32 pi = sorted[w * n + st + k];
+        uint4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = nx[j];
+        if (k + 1 < cnt) {
+            const u64 pn = idx[k + 1];
+#pragma unroll
+            for (int j = 0; j < 4; j++) nx[j] = mont[pn * 4 + j];
+        }
         fq x, y;
-        for (int j = 0; j < 8; j++) { x.l[j] = points[(u64)pi * 16 + j]; y.l[j] = points[(u64)pi * 16 + 8 + j]; }
+        x.l[0] = q[0].x; x.l[1] = q[0].y; x.l[2] = q[0].z; x.l[3] = q[0].w; x.l[4] = q[1].x; x.l[5] = q[1].y; x.l[6] = q[1].z; x.l[7] = q[1].w;
+        y.l[0] = q[2].x; y.l[1] = q[2].y; y.l[2] = q[2].z; y.l[3] = q[2].w; y.l[4] = q[3].x; y.l[5] = q[3].y; y.l[6] = q[3].z; y.l[7] = q[3].w;
         if (fq_is_zero(x) && fq_is_zero(y)) continue;  // (0,0) encodes the point at infinity
-        acc = jac_madd(acc, fq_to_mont(x), fq_to_mont(y));
+        acc = jac_madd(acc, x, y);
     }
     buckets[id] = acc;
 }
@@ -384,22 +409,25 @@ extern "C" int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uin
     const u64 nb = (u64)nwin << c;
     u32 *d_counts = nullptr, *d_starts = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
     jac *d_buckets = nullptr, *d_segs = nullptr, *d_wins = nullptr;
+    uint4 *d_mont = nullptr;
     const u64 nseg = (1ULL << c) / MSM_SEG;
     ZP_HIP(ctx, hipSetDevice(ctx->device));
     ZP_HIP(ctx, hipMalloc((void **)&d_counts, nb * 4 * 3));
     d_starts = d_counts + nb;
     d_cursor = d_starts + nb;
     ZP_HIP(ctx, hipMalloc((void **)&d_sorted, (u64)nwin * n * 4));
+    ZP_HIP(ctx, hipMalloc((void **)&d_mont, (u64)n * 64));
     ZP_HIP(ctx, hipMalloc((void **)&d_buckets, (nb + nwin * nseg + nwin) * sizeof(jac)));
     d_segs = d_buckets + nb;
     d_wins = d_segs + nwin * nseg;
     ZP_HIP(ctx, hipMemsetAsync(d_counts, 0, nb * 4, ctx->stream));
     const unsigned gb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(msm_to_mont_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const uint4 *)d_points, (u64)n, d_mont);
     hipLaunchKernelGGL(msm_hist_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const u32 *)d_scalars, (u64)n, c, nwin, d_counts);
     hipLaunchKernelGGL(msm_scan_kernel, dim3(nwin), dim3(1024), 0, ctx->stream, d_counts, d_starts, d_cursor, c);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const u32 *)d_scalars, (u64)n, c, nwin, d_cursor, d_sorted);
     hipLaunchKernelGGL(msm_bucket_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const u32 *)d_points, (u64)n, c, nwin, d_starts, d_counts, d_sorted, d_buckets);
+                       (const uint4 *)d_mont, (u64)n, c, nwin, d_starts, d_counts, d_sorted, d_buckets);
     hipLaunchKernelGGL(msm_segment_kernel, dim3((unsigned)((nwin * nseg + 63) / 64)), dim3(64), 0, ctx->stream, d_buckets, c, nwin, d_segs);
     hipLaunchKernelGGL(msm_window_kernel, dim3(nwin), dim3(256), 0, ctx->stream, d_segs, (int)nseg, d_wins);
     hipError_t le = hipGetLastError();
@@ -408,6 +436,7 @@ extern "C" int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uin
     hipError_t se = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_counts);
     (void)hipFree(d_sorted);
+    (void)hipFree(d_mont);
     (void)hipFree(d_buckets);
     ZP_HIP(ctx, le);
     ZP_HIP(ctx, ce);
