@@ -139,3 +139,19 @@ def test_blowup_four(hip_backend, cpu_backend, tables):
     gpu = PR.prove(air, tr, pub, params, hip_backend)
     assert PR.proof_to_json(gpu) == PR.proof_to_json(PR.prove(air, tr, pub, params, cpu_backend))
     assert V.verify(gpu, air, rc, mds)
+
+
+@pytest.mark.parametrize("name,logn", [("wide64", 22), ("wide8", 24), ("perm", 22)])
+def test_full_size_proofs_pass_the_independent_verifier(hip_backend, tables, name, logn):
+    """BASELINE configs[2]/[3] sizes: the CPU prover is too slow to compare against, but the verifier's
+    cost does not depend on the trace length -- a 2^22..2^24-row proof from the MI355X must verify."""
+    rc, mds = tables
+    air = AIR.get_air(name)
+    tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 31337)
+    proof = PR.prove(air, tr, pub, PR.StarkParams(logn, logb=1, fri_logf=3, fri_final_log=5, n_queries=16), hip_backend)
+    del tr
+    assert V.verify(proof, air, rc, mds)
+    bad = copy.deepcopy(proof)
+    bad["evals"]["zw"][1][2] ^= 1
+    with pytest.raises(V.Reject):
+        V.verify(bad, air, rc, mds)
