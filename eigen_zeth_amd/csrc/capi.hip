@@ -171,11 +171,13 @@ int32_t zp_d2d(zp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
 // ---- N1
 int32_t zp_ntt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t W) {
     if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "ntt");
     NttRunOpts o;
     return zpi_ntt_run(ctx, (const u64 *)d_in, (u64 *)d_out, logn, W, false, o);
 }
 int32_t zp_intt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t W) {
     if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "intt");
     NttRunOpts o;
     return zpi_ntt_run(ctx, (const u64 *)d_in, (u64 *)d_out, logn, W, true, o);
 }
@@ -184,6 +186,7 @@ int32_t zp_intt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn
 int32_t zp_lde(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t *d_coef, int32_t logn,
                int32_t logb, int32_t W, uint64_t shift) {
     if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "lde");
     return zpi_lde(ctx, (const u64 *)d_in, (u64 *)d_out, (u64 *)d_coef, logn, logb, W, shift);
 }
 
@@ -322,6 +325,30 @@ int32_t zp_get_pass_timings(zp_ctx *ctx, float *ms, int32_t *radix_log, int32_t 
     }
     ctx->pass_events.clear();
     *count = n;
+    return ZP_OK;
+}
+
+int32_t zp_stage_timings(zp_ctx *ctx, char *buf, size_t buflen) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, buf && buflen > 2, "null buffer");
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::string s = "[";
+    bool first = true;
+    for (auto &ev : ctx->stage_events) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ev.a, ev.b) == hipSuccess) {
+            char tmp[128];
+            snprintf(tmp, sizeof(tmp), "%s{\"stage\": \"%s\", \"ms\": %.4f}", first ? "" : ", ", ev.name, t);
+            s += tmp;
+            first = false;
+        }
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    ctx->stage_events.clear();
+    s += "]";
+    ZP_ARG(ctx, s.size() + 1 <= buflen, "buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
     return ZP_OK;
 }
 

@@ -64,6 +64,25 @@ struct zp_ctx {
     bool profiling = false;
     struct PassEv { hipEvent_t a, b; int radix_log; };
     std::vector<PassEv> pass_events;
+    struct StageEv { hipEvent_t a, b; const char *name; };
+    std::vector<StageEv> stage_events;
+};
+
+// brackets one C-ABI compute call with HIP events on the ctx stream when profiling is on (zp_stage_timings)
+struct ZpStage {
+    zp_ctx *ctx;
+    zp_ctx::StageEv ev;
+    bool on;
+    ZpStage(zp_ctx *c, const char *name) : ctx(c), on(c && c->profiling) {
+        if (on) {
+            ev.name = name;
+            on = hipEventCreate(&ev.a) == hipSuccess && hipEventCreate(&ev.b) == hipSuccess &&
+                 hipEventRecord(ev.a, ctx->stream) == hipSuccess;
+        }
+    }
+    ~ZpStage() {
+        if (on && hipEventRecord(ev.b, ctx->stream) == hipSuccess) ctx->stage_events.push_back(ev);
+    }
 };
 
 #define ZP_HIP(ctx, call)                                                                    \

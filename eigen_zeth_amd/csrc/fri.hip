@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(FoldArgs a) {
 extern "C" int32_t zp_fri_fold(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t logf,
                                const uint64_t beta[3], uint64_t shift) {
     if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "fri_fold");
     ZP_ARG(ctx, logf >= 1 && logf <= 4, "logf must be in 1..4");
     ZP_ARG(ctx, logn >= logf && logn <= 32, "logn out of range");
     ZP_ARG(ctx, d_in && d_out && beta, "null pointer");

@@ -397,6 +397,7 @@ fq fq_inv_host(const fq &a) {  // a^(q-2) in Montgomery form (host, once per MSM
 extern "C" int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n,
                                 uint32_t *h_out) {
     if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "msm_bn254");
     ZP_ARG(ctx, h_out != nullptr, "null output");
     ZP_ARG(ctx, n < (1ULL << 31), "too many points");
     memset(h_out, 0, 16 * sizeof(uint32_t));

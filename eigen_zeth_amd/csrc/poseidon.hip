@@ -218,6 +218,7 @@ extern "C" {
 
 int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count) {
     if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "poseidon_perm");
     if (count == 0) return ZP_OK;
     ZP_ARG(ctx, d_states != nullptr, "null device pointer");
     ZP_TRY(zpi_poseidon_sync_tables(ctx));
@@ -233,6 +234,7 @@ int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count) {
 
 int32_t zp_merkle_commit(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, uint64_t *d_tree) {
     if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "merkle_commit");
     ZP_ARG(ctx, M >= 1 && (M & (M - 1)) == 0, "M must be a power of two");
     ZP_ARG(ctx, W >= 1, "W must be >= 1");
     ZP_ARG(ctx, d_cols && d_tree, "null device pointer");
@@ -249,6 +251,7 @@ int32_t zp_merkle_commit(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t 
 
 int32_t zp_merkle_commit_rows(zp_ctx *ctx, const uint64_t *d_rows, size_t M, size_t len, uint64_t *d_tree) {
     if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "merkle_commit_rows");
     ZP_ARG(ctx, M >= 1 && (M & (M - 1)) == 0, "M must be a power of two");
     ZP_ARG(ctx, len >= 1, "len must be >= 1");
     ZP_ARG(ctx, d_rows && d_tree, "null device pointer");

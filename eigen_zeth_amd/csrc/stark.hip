@@ -129,6 +129,7 @@ extern "C" {
 int32_t zp_poly_eval_ext(zp_ctx *ctx, const uint64_t *d_coef, int32_t logn, int32_t W, const uint64_t z[3],
                          uint64_t *h_out) {
     if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "poly_eval_ext");
     ZP_ARG(ctx, logn >= 0 && logn <= 32 && W >= 0, "logn/W out of range");
     ZP_ARG(ctx, (d_coef && z && h_out) || W == 0, "null pointer");
     if (W == 0) return ZP_OK;
@@ -170,6 +171,7 @@ int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, cons
                          const uint64_t gamma[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t shift,
                          uint64_t *d_out) {
     if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "deep_quotient");
     ZP_ARG(ctx, logm >= 0 && logm <= 32, "logm out of range");
     ZP_ARG(ctx, Wa >= 1 && Wb >= 0 && n_next >= 0 && n_next <= Wa, "bad widths");
     ZP_ARG(ctx, d_cols_a && (d_cols_b || Wb == 0) && z && zw && gamma && h_ev_z && (h_ev_zw || n_next == 0) && d_out,
@@ -347,6 +349,7 @@ __global__ void __launch_bounds__(GP_BLK) gp_apply_kernel(GpArgs A) {
 extern "C" int32_t zp_grand_product(zp_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t n, const uint64_t gamma[3],
                                     uint64_t *d_out) {
     if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "grand_product");
     ZP_ARG(ctx, n >= 1, "n must be >= 1");
     ZP_ARG(ctx, d_a && d_b && gamma && d_out, "null pointer");
     ZP_ARG(ctx, gamma[0] < GL_P && gamma[1] < GL_P && gamma[2] < GL_P, "challenge not canonical");

@@ -70,6 +70,7 @@ SIGNATURES = {
     "zp_set_profiling": (C.c_int32, [_vp, C.c_int32]),
     "zp_get_pass_timings": (C.c_int32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32,
                                         C.POINTER(C.c_int32)]),
+    "zp_stage_timings": (C.c_int32, [_vp, C.c_char_p, C.c_size_t]),
     "zp_ntt_plan_json": (C.c_int32, [_vp, C.c_int32, C.c_char_p, C.c_size_t]),
     "zp_device_info_json": (C.c_int32, [_vp, C.c_char_p, C.c_size_t]),
 }
@@ -343,6 +344,11 @@ class Prover:
         n = C.c_int32(0)
         self._chk(self.lib.zp_get_pass_timings(self.ctx, ms, rl, cap, C.byref(n)))
         return [(rl[i], ms[i]) for i in range(n.value)]
+
+    def stage_timings(self):
+        buf = C.create_string_buffer(1 << 20)
+        self._chk(self.lib.zp_stage_timings(self.ctx, buf, 1 << 20))
+        return json.loads(buf.value.decode())
 
     # ---- introspection
     def ntt_plan(self, logn):

@@ -153,6 +153,9 @@ int32_t zp_merkle_commit_host(zp_ctx *ctx, const uint64_t *h_cols, size_t M, int
  * last call: duration in ms and log2(radix) (negative for the transposing first pass).           */
 int32_t zp_set_profiling(zp_ctx *ctx, int32_t on);
 int32_t zp_get_pass_timings(zp_ctx *ctx, float *ms, int32_t *radix_log, int32_t cap, int32_t *count);
+/* JSON array [{"stage": name, "ms": t}, ...] of the compute entry points called since the last call
+ * (device time between HIP events on the ctx stream; profiling must be on).                          */
+int32_t zp_stage_timings(zp_ctx *ctx, char *buf, size_t buflen);
 
 /* experiment knobs for kernel tuning sweeps (keys: "ntt_logt" 4|5 tile of the radix-256 pass, "ntt_logt9" 4|5, "ntt_tpw" tiles per workgroup); not for production hosts */
 int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value);

@@ -287,3 +287,38 @@ def test_merkle_ragged_widths_and_single_row(prover, tables):
         d_tree = prover.alloc((2 * M - 1) * 4)
         prover.merkle_commit(prover.upload(cols), M, W, d_tree)
         assert (prover.download(d_tree, (2 * M - 1, 4)) == O.merkle_commit(cols, rc, mds)).all(), (M, W)
+
+
+def test_stage_timings_report(prover):
+    x = O.random_field((2, 1 << 14), 5)
+    d = prover.upload(x)
+    o = prover.alloc(2 << 15)
+    t = prover.alloc((2 * (1 << 15) - 1) * 4)
+    prover.set_profiling(True)
+    prover.lde(d, o, 14, 1, 2)
+    prover.merkle_commit(o, 1 << 15, 2, t)
+    rep = prover.stage_timings()
+    prover.set_profiling(False)
+    prover.pass_timings()
+    names = [r["stage"] for r in rep]
+    assert names == ["lde", "merkle_commit"] and all(r["ms"] > 0 for r in rep)
+    assert prover.stage_timings() == []
+
+
+def test_ntt_column_chunking(prover):
+    """more columns than one scratch chunk holds (2^28 elements): 70 columns of 2^22 go in two chunks"""
+    logn, W = 22, 70
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 2 ** 63, size=(W, 1 << logn), dtype=np.uint64)
+    d = prover.upload(x)
+    prover.ntt(d, d, logn, W)
+    fx = prover.download(d, x.shape)
+    for c in (0, 63, 64, 69):
+        assert (fx[c] == O.ntt(x[c:c + 1])[0]).all(), c
+    prover.intt(d, d, logn, W)
+    assert (prover.download(d, x.shape) == x).all()
+    # LDE of the same shape crosses the chunk boundary too
+    d_out = prover.alloc(W << (logn + 1))
+    prover.lde(d, d_out, logn, 1, W, shift=1)
+    y = prover.download(d_out, (W, 1 << (logn + 1)))
+    assert (y[:, ::2] == x).all()
