@@ -134,6 +134,7 @@ class DeviceBuffer:
         p = _vp()
         prover._chk(prover.lib.zp_dev_alloc(prover.ctx, self.n * 8, C.byref(p)))
         self.ptr = p.value or 0
+        self.shape = (self.n,)
 
     def offset(self, elems):
         return self.ptr + 8 * int(elems)

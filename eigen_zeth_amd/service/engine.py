@@ -98,11 +98,14 @@ class Engine:
             air = AIR.get_air(ch["air"])
             t0 = time.perf_counter()
             trace, pubs = native.synth_trace(air.trace_kind, ch["logn"], air.width, ch["seed"])
-            return air, trace, pubs, time.perf_counter() - t0
+            tw = time.perf_counter() - t0
+            if hasattr(self.be, "prefetch_trace"):   # copy to the GPU from this worker thread, on its own stream
+                trace = self.be.prefetch_trace(trace)
+            return air, trace, pubs, tw
 
         out = []
         with ThreadPoolExecutor(max_workers=max(1, min(self.cfg.witness_threads, len(chunks)))) as pool:
-            pending = [pool.submit(witness, ch) for ch in chunks[:self.cfg.witness_threads * 2]]
+            pending = [pool.submit(witness, ch) for ch in chunks[:self.cfg.witness_threads + 2]]
             nxt = len(pending)
             for i, ch in enumerate(chunks):
                 air, trace, pubs, tw = pending[i].result()

@@ -5,7 +5,8 @@ multi-scalar multiplications on the GPU (zp_msm_bn254) -- whose proofs verify un
 (oracle/groth16_verify.py in tests).  What is NOT available offline: the circuit that verifies the
 recursive STARK (circom/R1CS of eigen-zkvm) and its ceremony CRS.  The circuit proven instead is a
 fixed arithmetic chain binding the public input to a secret derived from the aggregated proof:
-    x_0 = s,  x_(i+1) = x_i^2 + (i+1)  (i < steps),  pub = x_steps + s
+    x_0 = s,  x_(i+1) = x_i * s + (i+1)  (i < steps),  pub = x_steps + s
+(the right-hand factor of every product is the single wire s, so the G2 side of B is one scalar multiplication)
 and the CRS comes from a LOCAL setup with a published seed (toxic waste known -- test setup, not a
 ceremony).  The JSON emitted follows the grammar eigen-zeth parses (src/settlement/ethereum/mod.rs:445-481).
 """
@@ -56,16 +57,17 @@ class Circuit:
         prev = 2
         for i in range(self.steps):
             nxt = 3 + i
-            A.append({prev: 1}); B.append({prev: 1}); C.append({nxt: 1, 0: (-(i + 1)) % R})
+            A.append({prev: 1}); B.append({2: 1}); C.append({nxt: 1, 0: (-(i + 1)) % R})
             prev = nxt
         A.append({prev: 1, 2: 1}); B.append({0: 1}); C.append({1: 1})
         self.A, self.B, self.C = A, B, C
 
     def witness(self, s):
-        w = [1, 0, s % R]
-        x = s % R
+        s %= R
+        w = [1, 0, s]
+        x = s
         for i in range(self.steps):
-            x = (x * x + (i + 1)) % R
+            x = (x * s + (i + 1)) % R
             w.append(x)
         w[1] = (x + s) % R
         return w
@@ -170,7 +172,7 @@ def vk_to_json(vk):
 def load_or_setup(circ, cache_dir):
     """the CRS is deterministic (seeded); cache it next to the batch store"""
     import pickle
-    path = os.path.join(cache_dir, "groth16_crs_logm%d.pkl" % circ.logm)
+    path = os.path.join(cache_dir, "groth16_crs_v2_logm%d.pkl" % circ.logm)
     if os.path.exists(path):
         with open(path, "rb") as f:
             return pickle.load(f)

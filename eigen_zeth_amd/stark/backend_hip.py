@@ -25,6 +25,8 @@ class HipBackend:
         self._fixed = {}
         self._airlibs = {}
         self._perm_buf = self.p.alloc(12)
+        self.p_device = device
+        self._up = None
 
     def sync(self):
         self.p.sync()
@@ -39,11 +41,20 @@ class HipBackend:
     def _root(self, tree, M):
         return [int(v) for v in self.p.download(tree, (4,), offset_elems=(2 * M - 2) * 4)]
 
+    def prefetch_trace(self, trace):
+        """H2D of a witness on a second ctx/stream (safe to call from a worker thread): lets the engine copy
+        chunk i+1 while chunk i is being proven.  Returns a handle commit_trace accepts in place of the array."""
+        if self._up is None:
+            self._up = native.Prover(self.p_device)
+        buf = self._up.upload(trace)
+        buf.shape = trace.shape
+        return buf
+
     def commit_trace(self, trace, logn, logb, extra_cols=0):
         """ext / coef are allocated with room for `extra_cols` stage-2 columns behind the trace columns"""
         W = trace.shape[0]
         M = 1 << (logn + logb)
-        d_tr = self.p.upload(trace)
+        d_tr = trace if isinstance(trace, native.DeviceBuffer) else self.p.upload(trace)
         ext, coef = self.p.alloc((W + extra_cols) * M), self.p.alloc((W + extra_cols) << logn)
         tree = self.p.alloc((2 * M - 1) * 4)
         self.p.lde(d_tr, ext, logn, logb, W, self.shift, d_coef=coef)

@@ -57,7 +57,7 @@ def prove(air, trace, pubs, params, be, timings=None):
     logn, logb = params.logn, params.logb
     logm = logn + logb
     N, M, W = 1 << logn, 1 << logm, air.width
-    assert trace.shape == (W, N)
+    assert tuple(trace.shape) == (W, N)
     shift, root32 = be.shift, be.root32
     wN = F.root(logn, root32)
     tr = Transcript(be.poseidon_perm)
