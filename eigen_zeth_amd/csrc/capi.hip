@@ -46,6 +46,7 @@ void zp_destroy(zp_ctx *ctx) {
     }
     for (int i = 0; i < 4; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->d_rc) (void)hipFree(ctx->d_rc);
     if (ctx->d_mds) (void)hipFree(ctx->d_mds);
     delete ctx;
@@ -148,6 +149,7 @@ int32_t zp_h2d(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     if (!ctx) return ZP_ERR_ARG;
     if (bytes == 0) return ZP_OK;
     ZP_ARG(ctx, d_dst && h_src, "null pointer");
+    if (bytes <= ZP_SMALL_COPY) return zpi_h2d_small(ctx, d_dst, h_src, bytes);
     ZP_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZP_OK;
@@ -156,6 +158,7 @@ int32_t zp_d2h(zp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (!ctx) return ZP_ERR_ARG;
     if (bytes == 0) return ZP_OK;
     ZP_ARG(ctx, h_dst && d_src, "null pointer");
+    if (bytes <= ZP_SMALL_COPY) return zpi_d2h_small(ctx, h_dst, d_src, bytes);
     ZP_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZP_OK;

@@ -56,7 +56,9 @@ struct zp_ctx {
     // scratch (two ping-pong buffers, grown on demand)
     u64 *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_elems[4] = {0, 0, 0, 0};
-    // misc small device buffer for parameters
+    // pinned host staging for small transfers (pageable async copies lock/unlock host pages on every call)
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
     int num_cu = 256;
     // experiment knobs (zp_set_tuning): not part of the stable surface
     int tune_logt = 4, tune_tpw = 4, tune_logt9 = 5;
@@ -110,6 +112,11 @@ struct ZpStage {
 
 // internal helpers implemented across the .hip files
 int32_t zpi_scratch(zp_ctx *ctx, int which, size_t elems, u64 **out);
+int32_t zpi_pinned(zp_ctx *ctx, size_t bytes, void **out);
+// small copies through the pinned staging buffer (synchronous on the ctx stream)
+int32_t zpi_d2h_small(zp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int32_t zpi_h2d_small(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+#define ZP_SMALL_COPY (4u << 20)
 int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out);
 int32_t zpi_get_coset(zp_ctx *ctx, int logn, u64 shift, u64 pre, CosetTable **out);
 int32_t zpi_poseidon_sync_tables(zp_ctx *ctx);

@@ -439,6 +439,41 @@ int32_t zpi_scratch(zp_ctx *ctx, int which, size_t elems, u64 **out) {
     return ZP_OK;
 }
 
+int32_t zpi_pinned(zp_ctx *ctx, size_t bytes, void **out) {
+    if (ctx->pinned_bytes < bytes) {
+        if (ctx->pinned) {
+            ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ZP_HIP(ctx, hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_bytes = 0;
+        }
+        size_t cap = bytes < (8u << 20) ? (8u << 20) : bytes;
+        ZP_HIP(ctx, hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+        ctx->pinned_bytes = cap;
+    }
+    *out = ctx->pinned;
+    return ZP_OK;
+}
+
+int32_t zpi_d2h_small(zp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    void *st;
+    ZP_TRY(zpi_pinned(ctx, bytes, &st));
+    ZP_HIP(ctx, hipMemcpyAsync(st, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(h_dst, st, bytes);
+    return ZP_OK;
+}
+
+int32_t zpi_h2d_small(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    void *st;
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still feed an earlier copy
+    ZP_TRY(zpi_pinned(ctx, bytes, &st));
+    memcpy(st, h_src, bytes);
+    ZP_HIP(ctx, hipMemcpyAsync(d_dst, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZP_OK;
+}
+
 static int32_t upload(zp_ctx *ctx, const std::vector<u64> &h, u64 **d) {
     ZP_HIP(ctx, hipMalloc((void **)d, h.size() * sizeof(u64)));
     ZP_HIP(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(u64), hipMemcpyHostToDevice));

@@ -146,14 +146,18 @@ int32_t zp_poly_eval_ext(zp_ctx *ctx, const uint64_t *d_coef, int32_t logn, int3
     u64 *d_tab = nullptr, *d_part = nullptr;
     ZP_TRY(zpi_scratch(ctx, 3, tab.size() + chunks * W * 3, &d_tab));
     d_part = d_tab + tab.size();
-    ZP_HIP(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    ZP_TRY(zpi_h2d_small(ctx, d_tab, tab.data(), tab.size() * 8));
     EvalArgs a;
     a.coef = (const u64 *)d_coef; a.n = n; a.zlow = d_tab; a.zmid = d_tab + 48; a.partial = d_part; a.W = W;
     hipLaunchKernelGGL(poly_eval_ext_kernel, dim3((unsigned)chunks, (unsigned)W), dim3(256), 0, ctx->stream, a);
     ZP_HIP(ctx, hipGetLastError());
     std::vector<u64> part(chunks * W * 3);
-    ZP_HIP(ctx, hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (part.size() * 8 <= ZP_SMALL_COPY) {
+        ZP_TRY(zpi_d2h_small(ctx, part.data(), d_part, part.size() * 8));
+    } else {
+        ZP_HIP(ctx, hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     // combine the per-chunk partials on the host: sum_ch partial[ch] * (z^4096)^ch   (tiny: chunks*W terms)
     for (int c = 0; c < W; c++) {
         e3 acc = e3_make(0, 0, 0);
@@ -190,8 +194,7 @@ int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, cons
     }
     u64 *d_gp = nullptr;
     ZP_TRY(zpi_scratch(ctx, 3, gp.size(), &d_gp));
-    ZP_HIP(ctx, hipMemcpyAsync(d_gp, gp.data(), gp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // gp is a stack vector
+    ZP_TRY(zpi_h2d_small(ctx, d_gp, gp.data(), gp.size() * 8));
     DeepArgs a;
     a.cols_a = (const u64 *)d_cols_a; a.cols_b = (const u64 *)d_cols_b; a.out = (u64 *)d_out; a.gpow = d_gp;
     a.twl = pl->d_twl; a.twh = pl->d_twh; a.lb = pl->lb;
@@ -212,11 +215,12 @@ int32_t zp_gather_rows(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W,
     for (int i = 0; i < nq; i++) ZP_ARG(ctx, h_idx[i] < M, "row index out of range");
     u64 *d = nullptr;
     ZP_TRY(zpi_scratch(ctx, 3, (size_t)nq * (W + 1), &d));
-    ZP_HIP(ctx, hipMemcpyAsync(d, h_idx, (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
+    ZP_TRY(zpi_h2d_small(ctx, d, h_idx, (size_t)nq * 8));
     const u64 total = (u64)nq * W;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const u64 *)d_cols, (u64)M, (int)W, d, (int)nq, d + nq);
     ZP_HIP(ctx, hipGetLastError());
+    if (total * 8 <= ZP_SMALL_COPY) return zpi_d2h_small(ctx, h_out, d + nq, total * 8);
     ZP_HIP(ctx, hipMemcpyAsync(h_out, d + nq, total * 8, hipMemcpyDeviceToHost, ctx->stream));
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZP_OK;
@@ -235,10 +239,11 @@ int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, cons
     u64 *d = nullptr;
     const u64 total = (u64)nq * depth * 4;
     ZP_TRY(zpi_scratch(ctx, 3, (size_t)nq + total, &d));
-    ZP_HIP(ctx, hipMemcpyAsync(d, h_idx, (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
+    ZP_TRY(zpi_h2d_small(ctx, d, h_idx, (size_t)nq * 8));
     hipLaunchKernelGGL(merkle_paths_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const u64 *)d_tree, (u64)M, depth, d, (int)nq, d + nq);
     ZP_HIP(ctx, hipGetLastError());
+    if (total * 8 <= ZP_SMALL_COPY) return zpi_d2h_small(ctx, h_paths, d + nq, total * 8);
     ZP_HIP(ctx, hipMemcpyAsync(h_paths, d + nq, total * 8, hipMemcpyDeviceToHost, ctx->stream));
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZP_OK;

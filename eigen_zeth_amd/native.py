@@ -131,17 +131,24 @@ class DeviceBuffer:
     def __init__(self, prover, n_elems):
         self.prover = prover
         self.n = int(n_elems)
+        self.shape = (self.n,)
+        pool = prover._pool.get(self.n) if prover.pooling else None
+        if pool:
+            self.ptr = pool.pop()     # reuse: hipMalloc/hipFree and the first touch of fresh memory are slow
+            return
         p = _vp()
         prover._chk(prover.lib.zp_dev_alloc(prover.ctx, self.n * 8, C.byref(p)))
         self.ptr = p.value or 0
-        self.shape = (self.n,)
 
     def offset(self, elems):
         return self.ptr + 8 * int(elems)
 
     def free(self):
         if self.ptr and self.prover.ctx:
-            self.prover.lib.zp_dev_free(self.prover.ctx, self.ptr)
+            if self.prover.pooling and self.n >= 1024:
+                self.prover._pool.setdefault(self.n, []).append(self.ptr)
+            else:
+                self.prover.lib.zp_dev_free(self.prover.ctx, self.ptr)
         self.ptr = 0
 
     def __del__(self):
@@ -161,11 +168,21 @@ class Prover:
         if rc != 0:
             raise ZpError(rc, "zp_create failed (no HIP device %d?) -- the prover requires an MI355X" % device)
         self.ctx = ctx
+        self.pooling = False      # device-buffer reuse by exact size (set True for repeated same-shape work)
+        self._pool = {}
         if stream is not None:
             self.set_stream(stream)
 
+    def trim(self):
+        """release every pooled device buffer"""
+        for ptrs in self._pool.values():
+            for ptr in ptrs:
+                self.lib.zp_dev_free(self.ctx, ptr)
+        self._pool = {}
+
     def close(self):
         if self.ctx:
+            self.trim()
             self.lib.zp_destroy(self.ctx)
             self.ctx = None
 

@@ -20,6 +20,7 @@ class Commit:
 class HipBackend:
     def __init__(self, device=0, prover=None):
         self.p = prover or native.Prover(device)
+        self.p.pooling = True   # chunk after chunk has the same shapes: reuse device buffers
         self.root32 = int(self.p.get_constants(native.ZP_CONST_ROOT32, 1)[0])
         self.shift = int(self.p.get_constants(native.ZP_CONST_COSET_SHIFT, 1)[0])
         self._fixed = {}
@@ -46,6 +47,7 @@ class HipBackend:
         chunk i+1 while chunk i is being proven.  Returns a handle commit_trace accepts in place of the array."""
         if self._up is None:
             self._up = native.Prover(self.p_device)
+            self._up.pooling = True
         buf = self._up.upload(trace)
         buf.shape = trace.shape
         return buf
