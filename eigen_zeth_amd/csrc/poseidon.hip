@@ -102,6 +102,37 @@ __global__ void __launch_bounds__(256) poseidon_perm_kernel(u64 *states, size_t 
     for (int j = 0; j < 12; j++) states[i * 12 + j] = s[j];
 }
 
+// Latency form for a handful of permutations (Fiat-Shamir transcript: one state at a time).  One lane per
+// state WORD instead of one lane per state: 12 lanes share a permutation through LDS, so a round is one
+// S-box + one 12-term row sum per lane (~150 dependent instructions) instead of ~1600 on a single lane.
+__global__ void __launch_bounds__(64) poseidon_perm_small_kernel(u64 *states, int count, const u64 *rc, const u32 *mds) {
+    __shared__ u64 sh[5][12];
+    const int lane = threadIdx.x, q = lane / 12, e = lane % 12;
+    const int perm = blockIdx.x * 5 + q;
+    const bool on = q < 5 && perm < count;
+    u64 s = on ? states[(size_t)perm * 12 + e] : 0ULL;
+    for (int r = 0; r < 30; r++) {
+        s = gl_add_weak(s, rc[r * 12 + e]);
+        if (r < 4 || r >= 26 || e == 0) s = sbox7(s);
+        if (on) sh[q][e] = s;
+        __syncthreads();
+        u64 alo = 0, ahi = 0;
+        if (on) {
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const u64 v = sh[q][j];
+                const u32 m = mds[e * 12 + j];
+                alo += (u64)m * (u32)v;
+                ahi += (u64)m * (u32)(v >> 32);
+            }
+        }
+        __syncthreads();
+        const u64 mid = (alo >> 32) + ahi;
+        s = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
+    }
+    if (on) states[(size_t)perm * 12 + e] = gl_canon(s);
+}
+
 // leaf i = linear hash of (cols[0][i], cols[1][i], ... cols[W-1][i]);  lane = row
 template <bool DEFMDS>
 __global__ void __launch_bounds__(256) merkle_leaves_kernel(const u64 *__restrict__ cols, size_t M, int W,
@@ -175,12 +206,52 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const u64 *__restrict
     for (int j = 0; j < 4; j++) next[i * 4 + j] = s[j];
 }
 
+// top of the tree in ONE launch: every level with <= 64 nodes, 12 lanes per node (a per-level launch of the
+// lane-per-node kernel costs a full single-lane permutation latency, ~0.1-0.3 ms, for each of the last ~7 levels)
+__global__ void __launch_bounds__(768) merkle_top_kernel(u64 *prev, size_t cnt, const u64 *rc, const u32 *mds) {
+    __shared__ u64 sh[64][12];
+    const int node = threadIdx.x / 12, e = threadIdx.x % 12;
+    while (cnt > 1) {
+        const size_t half = cnt >> 1;
+        u64 *next = prev + cnt * 4;
+        const bool on = (size_t)node < half;
+        u64 s = (on && e < 8) ? prev[(size_t)node * 8 + e] : 0ULL;
+        for (int r = 0; r < 30; r++) {
+            s = gl_add_weak(s, rc[r * 12 + e]);
+            if (r < 4 || r >= 26 || e == 0) s = sbox7(s);
+            sh[node][e] = s;
+            __syncthreads();
+            u64 alo = 0, ahi = 0;
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const u64 v = sh[node][j];
+                const u32 m = mds[e * 12 + j];
+                alo += (u64)m * (u32)v;
+                ahi += (u64)m * (u32)(v >> 32);
+            }
+            __syncthreads();
+            const u64 mid = (alo >> 32) + ahi;
+            s = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
+        }
+        if (on && e < 4) next[(size_t)node * 4 + e] = gl_canon(s);
+        __threadfence_block();
+        __syncthreads();
+        prev = next;
+        cnt = half;
+    }
+}
+
 int32_t tree_levels(zp_ctx *ctx, u64 *tree, size_t M) {
     u64 *prev = tree;
     size_t cnt = M;
     while (cnt > 1) {
         u64 *next = prev + cnt * 4;
         const size_t half = cnt >> 1;
+        if (half <= 64) {
+            hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(768), 0, ctx->stream, prev, cnt, ctx->d_rc, ctx->d_mds);
+            ZP_HIP(ctx, hipGetLastError());
+            break;
+        }
         if (ctx->mds_is_default)
             hipLaunchKernelGGL(merkle_level_kernel<true>, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream,
                                prev, next, half, ctx->d_rc, ctx->d_mds);
@@ -222,6 +293,12 @@ int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count) {
     if (count == 0) return ZP_OK;
     ZP_ARG(ctx, d_states != nullptr, "null device pointer");
     ZP_TRY(zpi_poseidon_sync_tables(ctx));
+    if (count <= 64) {   // latency-bound regime: spread each state over 12 lanes
+        hipLaunchKernelGGL(poseidon_perm_small_kernel, dim3((unsigned)((count + 4) / 5)), dim3(64), 0, ctx->stream,
+                           (u64 *)d_states, (int)count, ctx->d_rc, ctx->d_mds);
+        ZP_HIP(ctx, hipGetLastError());
+        return ZP_OK;
+    }
     if (ctx->mds_is_default)
         hipLaunchKernelGGL(poseidon_perm_kernel<true>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream,
                            (u64 *)d_states, count, ctx->d_rc, ctx->d_mds);

@@ -164,6 +164,17 @@ def test_poseidon_batch_matches_oracle(prover, tables):
     prover.poseidon_perm(d, 0)
 
 
+@pytest.mark.parametrize("count", [1, 2, 5, 6, 11, 64, 65])
+def test_poseidon_small_batches(prover, tables, count):
+    """the latency kernel (<= 64 states, 12 lanes per state) and the throughput kernel agree with the oracle"""
+    rc, mds = tables
+    st = O.random_field((count, 12), 700 + count)
+    st[0, :3] = u([0, P - 1, 1])
+    d = prover.upload(st)
+    prover.poseidon_perm(d, count)
+    assert (prover.download(d, st.shape) == O.poseidon_perm(st, rc, mds)).all()
+
+
 def test_poseidon_custom_tables(prover, tables):
     from eigen_zeth_amd import native
     rc, mds = tables
