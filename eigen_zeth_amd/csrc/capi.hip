@@ -254,6 +254,47 @@ int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uin
         h_pub[0] = h_trace[0];
         return ZP_OK;
     }
+    if (kind == 3) {  // chunk AIR: wide mix | Fibonacci | range values, their permutation, table, multiplicities | products
+        if (W < 12) return ZP_ERR_ARG;
+        const int Ww = W - 8;
+        std::vector<u64> cur(Ww), nx(Ww);
+        for (int i = 0; i < Ww; i++) cur[i] = next();
+        for (int i = 0; i < 4; i++) h_pub[i] = cur[i];
+        for (size_t r = 0; r < N; r++) {
+            for (int i = 0; i < Ww; i++) h_trace[(size_t)i * N + r] = cur[i];
+            for (int i = 0; i < Ww; i++)
+                nx[i] = gl_add(gl_add(gl_mul(cur[i], cur[(i + 1) % Ww]), cur[(i + 2) % Ww]), (u64)i);
+            cur.swap(nx);
+        }
+        u64 *fa = (u64 *)h_trace + (size_t)Ww * N, *fb = fa + N, *rv = fb + N, *qv = rv + N, *tv = qv + N, *mv = tv + N,
+            *cv = mv + N, *dv = cv + N;
+        u64 a = next(), b = next();
+        h_pub[4] = a;
+        h_pub[5] = b;
+        for (size_t i = 0; i < N; i++) {
+            fa[i] = a;
+            fb[i] = b;
+            const u64 t = gl_add(a, b);
+            a = b;
+            b = t;
+        }
+        h_pub[6] = fb[N - 1];
+        const int k = logn < 16 ? logn : 16;
+        const int rep = logn - k;
+        h_pub[7] = ((u64)1 << k) - 1;
+        for (size_t i = 0; i < N; i++) {
+            rv[i] = next() & (((u64)1 << k) - 1);
+            tv[i] = (u64)(i >> rep);
+            mv[i] = 0;
+        }
+        for (size_t i = 0; i < N; i++) {
+            mv[(size_t)rv[i] << rep] += 1;
+            qv[i] = rv[(5 * i + 3) & (N - 1)];
+            cv[i] = gl_mul(rv[i], rv[i]);
+            dv[i] = gl_add(gl_mul(fa[i], rv[i]), fb[i]);
+        }
+        return ZP_OK;
+    }
     return ZP_ERR_ARG;
 }
 

@@ -349,7 +349,115 @@ __global__ void __launch_bounds__(GP_BLK) gp_apply_kernel(GpArgs A) {
     }
 }
 
+// ---- LogUp lookup columns (stage-2 witness of a range-check / lookup argument)
+// h1 = 1/(a+g), h2 = m/(t+g), S[0] = 0, S[i+1] = S[i] + h1[i] - h2[i]   (all in F_{p^3}; planes h1 0..2, h2 3..5, S 6..8)
+struct LuArgs {
+    const u64 *a, *t, *m;
+    u64 *out;
+    e3 *totals;
+    u64 n;
+    u64 g[3];
+};
+
+__global__ void __launch_bounds__(GP_BLK) lu_local_kernel(LuArgs A) {
+    __shared__ e3 sh[GP_BLK];
+    const int t = threadIdx.x;
+    const u64 base = ((u64)blockIdx.x * GP_BLK + t) * GP_PER;
+    e3 acc = e3_make(0, 0, 0);
+    for (int k = 0; k < GP_PER; k++) {
+        const u64 i = base + k;
+        if (i < A.n) {
+            const e3 h1 = e3_inv(e3_make(gl_add(A.a[i], A.g[0]), A.g[1], A.g[2]));
+            const e3 h2 = e3_scale(e3_inv(e3_make(gl_add(A.t[i], A.g[0]), A.g[1], A.g[2])), A.m[i]);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                A.out[(u64)c * A.n + i] = h1.c[c];
+                A.out[(u64)(3 + c) * A.n + i] = h2.c[c];
+                A.out[(u64)(6 + c) * A.n + i] = acc.c[c];
+            }
+            acc = e3_add(acc, e3_sub(h1, h2));
+        }
+    }
+    sh[t] = acc;
+    __syncthreads();
+    for (int d = 1; d < GP_BLK; d <<= 1) {
+        e3 v = sh[t];
+        if (t >= d) v = e3_add(sh[t - d], v);
+        __syncthreads();
+        sh[t] = v;
+        __syncthreads();
+    }
+    const e3 lane_prefix = t ? sh[t - 1] : e3_make(0, 0, 0);
+    if (t == GP_BLK - 1) A.totals[blockIdx.x] = sh[t];
+    for (int k = 0; k < GP_PER; k++) {
+        const u64 i = base + k;
+        if (i < A.n) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) A.out[(u64)(6 + c) * A.n + i] = gl_add(A.out[(u64)(6 + c) * A.n + i], lane_prefix.c[c]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(GP_BLK) lu_scan_totals_kernel(e3 *totals, u64 nblocks) {
+    __shared__ e3 sh[GP_BLK];
+    __shared__ e3 carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = e3_make(0, 0, 0);
+    __syncthreads();
+    for (u64 base = 0; base < nblocks; base += GP_BLK) {
+        const u64 i = base + t;
+        sh[t] = i < nblocks ? totals[i] : e3_make(0, 0, 0);
+        __syncthreads();
+        for (int d = 1; d < GP_BLK; d <<= 1) {
+            e3 v = sh[t];
+            if (t >= d) v = e3_add(sh[t - d], v);
+            __syncthreads();
+            sh[t] = v;
+            __syncthreads();
+        }
+        const e3 excl = e3_add(carry, t ? sh[t - 1] : e3_make(0, 0, 0));
+        const e3 last = e3_add(carry, sh[GP_BLK - 1]);
+        __syncthreads();
+        if (i < nblocks) totals[i] = excl;
+        if (t == 0) carry = last;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(GP_BLK) lu_apply_kernel(LuArgs A) {
+    const e3 off = A.totals[blockIdx.x];
+    const u64 base = ((u64)blockIdx.x * GP_BLK + threadIdx.x) * GP_PER;
+    for (int k = 0; k < GP_PER; k++) {
+        const u64 i = base + k;
+        if (i < A.n) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) A.out[(u64)(6 + c) * A.n + i] = gl_add(A.out[(u64)(6 + c) * A.n + i], off.c[c]);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int32_t zp_logup_columns(zp_ctx *ctx, const uint64_t *d_a, const uint64_t *d_t, const uint64_t *d_m, size_t n,
+                                    const uint64_t gamma[3], uint64_t *d_out) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "logup_columns");
+    ZP_ARG(ctx, n >= 1, "n must be >= 1");
+    ZP_ARG(ctx, d_a && d_t && d_m && gamma && d_out, "null pointer");
+    ZP_ARG(ctx, gamma[0] < GL_P && gamma[1] < GL_P && gamma[2] < GL_P, "challenge not canonical");
+    const u64 nblocks = (n + (u64)GP_BLK * GP_PER - 1) / ((u64)GP_BLK * GP_PER);
+    u64 *scr = nullptr;
+    ZP_TRY(zpi_scratch(ctx, 3, nblocks * 3 + 8, &scr));
+    LuArgs A;
+    A.a = (const u64 *)d_a; A.t = (const u64 *)d_t; A.m = (const u64 *)d_m; A.out = (u64 *)d_out; A.totals = (e3 *)scr; A.n = n;
+    for (int i = 0; i < 3; i++) A.g[i] = gamma[i];
+    hipLaunchKernelGGL(lu_local_kernel, dim3((unsigned)nblocks), dim3(GP_BLK), 0, ctx->stream, A);
+    hipLaunchKernelGGL(lu_scan_totals_kernel, dim3(1), dim3(GP_BLK), 0, ctx->stream, (e3 *)scr, nblocks);
+    hipLaunchKernelGGL(lu_apply_kernel, dim3((unsigned)nblocks), dim3(GP_BLK), 0, ctx->stream, A);
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}
+
 
 extern "C" int32_t zp_grand_product(zp_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t n, const uint64_t gamma[3],
                                     uint64_t *d_out) {

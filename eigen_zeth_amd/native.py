@@ -58,6 +58,7 @@ SIGNATURES = {
     "zp_deep_quotient": (C.c_int32, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, _u64p, _u64p, _u64p,
                                      _u64p, _u64p, C.c_uint64, _vp]),
     "zp_grand_product": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _u64p, _vp]),
+    "zp_logup_columns": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _u64p, _vp]),
     "zp_gather_rows": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _u64p, C.c_int32, _u64p]),
     "zp_merkle_open_batch": (C.c_int32, [_vp, _vp, C.c_size_t, _u64p, C.c_int32, _u64p]),
     "zp_domain_tables": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int32)]),
@@ -80,11 +81,11 @@ def synth_trace(kind, logn, W, seed):
     """synthetic witness (host code inside the library, no GPU needed): (trace [W][N], publics)"""
     lib = load_library()
     tr = np.empty((W, 1 << logn), dtype=np.uint64)
-    pub = np.zeros(4, dtype=np.uint64)
+    pub = np.zeros(8, dtype=np.uint64)
     rc = lib.zp_synth_trace(kind, logn, W, seed, tr.ctypes.data_as(_u64p), pub.ctypes.data_as(_u64p))
     if rc != 0:
         raise ValueError("zp_synth_trace: bad arguments")
-    return tr, pub[:{0: 3, 2: 1}.get(kind, min(4, W))].copy()
+    return tr, pub[:{0: 3, 2: 1, 3: 8}.get(kind, min(4, W))].copy()
 
 
 class ZpError(RuntimeError):
@@ -277,6 +278,10 @@ class Prover:
     def grand_product(self, d_a, d_b, n, gamma, d_out):
         g = (C.c_uint64 * 3)(*[int(x) for x in gamma])
         self._chk(self.lib.zp_grand_product(self.ctx, _ptr(d_a), _ptr(d_b), n, g, _ptr(d_out)))
+
+    def logup_columns(self, d_a, d_t, d_m, n, gamma, d_out):
+        g = (C.c_uint64 * 3)(*[int(x) for x in gamma])
+        self._chk(self.lib.zp_logup_columns(self.ctx, _ptr(d_a), _ptr(d_t), _ptr(d_m), n, g, _ptr(d_out)))
 
     def gather_rows(self, d_cols, M, W, idx):
         ii = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64))

@@ -81,10 +81,12 @@ class Air:
         self.constraints = constraints
         self.trace_kind = trace_kind  # id understood by zp_synth_trace
         self.n_fixed = 2
-        # stage 2 (committed after a challenge): {"kind": "perm", "a": col, "b": col} -> a grand-product column
-        # Z in F_{p^3}, stored as 3 base columns with indices width .. width+2
-        self.stage2 = stage2
-        self.width2 = 3 if stage2 else 0
+        # stage 2 (committed after one F_{p^3} challenge g shared by all arguments): a list of
+        #   {"kind": "perm", "a": col, "b": col}             -> grand-product column Z            (3 base columns)
+        #   {"kind": "lookup", "a": col, "t": col, "m": col} -> LogUp columns h1, h2, running sum S (9 base columns)
+        # laid out one after the other from column index `width`
+        self.stage2 = list(stage2) if stage2 else []
+        self.width2 = sum(STAGE2_WIDTH[s["kind"]] for s in self.stage2)
         self.n_chal = 3 if stage2 else 0
 
     def digest(self):
@@ -94,6 +96,9 @@ class Air:
     @property
     def symbol(self):
         return "zpair_%s_quotient" % self.name
+
+
+STAGE2_WIDTH = {"perm": 3, "lookup": 9}
 
 
 def transition(e):
@@ -141,11 +146,47 @@ def permutation_air():
     rhs = e3x_mul(Z, [a + g[0], g[1], g[2]])
     cs = [c - a * a] + [lhs[i] - rhs[i] for i in range(3)]
     cs += [L_FIRST * (Z[0] - 1), L_FIRST * Z[1], L_FIRST * Z[2], L_FIRST * (a - Pub(0))]
-    return Air("perm", 3, 1, cs, trace_kind=2, stage2={"kind": "perm", "a": 0, "b": 1})
+    return Air("perm", 3, 1, cs, trace_kind=2, stage2=[{"kind": "perm", "a": 0, "b": 1}])
+
+
+def chunk_air(width):
+    """The synthetic chunk AIR of SURVEY.md 8d (C3): wide mixing columns + Fibonacci + permutation + range check.
+    columns 0..Ww-1 (Ww = width-8): the wide_air mix;  then  fa, fb (Fibonacci),  r (values < 2^k),  q (a permutation
+    of r, grand product),  t (range table: starts at 0, steps by 0 or 1, ends at pub7 = 2^k-1),  m (multiplicities of
+    the LogUp lookup r in t),  c = r^2,  d = fa*r + fb.   Stage 2 (challenge g): Z | h1, h2, S  (12 base columns)."""
+    assert width >= 12
+    Ww = width - 8
+    cs = []
+    for i in range(Ww):
+        c, c1, c2 = Col(i), Col((i + 1) % Ww), Col((i + 2) % Ww)
+        cs.append(transition(Col(i, True) - (c * c1 + c2 + Const(i))))
+    for i in range(4):
+        cs.append(L_FIRST * (Col(i) - Pub(i)))
+    fa, fb, r, q, t, m, c, d = [Col(Ww + i) for i in range(8)]
+    fan, fbn, tn = Col(Ww, True), Col(Ww + 1, True), Col(Ww + 4, True)
+    cs += [transition(fan - fb), transition(fbn - (fa + fb)),
+           L_FIRST * (fa - Pub(4)), L_FIRST * (fb - Pub(5)), L_LAST * (fb - Pub(6))]
+    cs += [c - r * r, d - (fa * r + fb)]
+    step = tn - t
+    cs += [L_FIRST * t, L_LAST * (t - Pub(7)), transition(step * (step - 1))]
+    g = [Chal(0), Chal(1), Chal(2)]
+    s2 = lambda j, nxt=False: [Col(width + 3 * j + i, nxt) for i in range(3)]
+    Z, Zn, H1, H2, S, Sn = s2(0), s2(0, True), s2(1), s2(2), s2(3), s2(3, True)
+    lhs = e3x_mul(Zn, [q + g[0], g[1], g[2]])
+    rhs = e3x_mul(Z, [r + g[0], g[1], g[2]])
+    cs += [lhs[i] - rhs[i] for i in range(3)]
+    cs += [L_FIRST * (Z[0] - 1), L_FIRST * Z[1], L_FIRST * Z[2]]
+    p1 = e3x_mul(H1, [r + g[0], g[1], g[2]])
+    p2 = e3x_mul(H2, [t + g[0], g[1], g[2]])
+    cs += [p1[0] - 1, p1[1], p1[2], p2[0] - m, p2[1], p2[2]]
+    cs += [Sn[i] - S[i] - H1[i] + H2[i] for i in range(3)]      # cyclic: the sum over all rows is zero
+    cs += [L_FIRST * S[i] for i in range(3)]
+    return Air("chunk%d" % width, width, 8, cs, trace_kind=3,
+               stage2=[{"kind": "perm", "a": Ww + 2, "b": Ww + 3}, {"kind": "lookup", "a": Ww + 2, "t": Ww + 4, "m": Ww + 5}])
 
 
 BUILTIN_AIRS = {"perm": permutation_air, "fib": fibonacci_air, "wide8": lambda: wide_air(8), "wide32": lambda: wide_air(32),
-                "wide64": lambda: wide_air(64)}
+                "wide64": lambda: wide_air(64), "chunk16": lambda: chunk_air(16), "chunk64": lambda: chunk_air(64)}
 
 
 def get_air(name):

@@ -7,6 +7,7 @@ import ctypes as C
 import numpy as np
 
 from .. import native
+from . import air as air_mod
 from . import build_airs
 
 _u64p = C.POINTER(C.c_uint64)
@@ -72,16 +73,22 @@ class HipBackend:
         return d_mat.offset(col * rows)
 
     def commit_stage2(self, air, c1, chal, logn, logb):
-        """grand-product column Z (3 base columns) -> LDE into columns W.. of c1.ext / c1.coef -> its own tree"""
-        N, M, W = 1 << logn, 1 << (logn + logb), c1.W
-        st = air.stage2
-        d_z = self.p.alloc(3 * N)
-        self.p.grand_product(c1.trace.offset(st["a"] * N), c1.trace.offset(st["b"] * N), N, chal, d_z)
-        self.p.lde(d_z, c1.ext.offset(W * M), logn, logb, 3, self.shift, d_coef=c1.coef.offset(W * N))
+        """stage-2 witness columns (grand products Z, LogUp h1/h2/S) -> LDE into columns W.. of c1.ext / c1.coef -> their tree"""
+        N, M, W, W2 = 1 << logn, 1 << (logn + logb), c1.W, air.width2
+        d_s2 = self.p.alloc(W2 * N)
+        at = 0
+        for st in air.stage2:
+            col = lambda k: c1.trace.offset(st[k] * N)
+            if st["kind"] == "perm":
+                self.p.grand_product(col("a"), col("b"), N, chal, d_s2.offset(at * N))
+            else:
+                self.p.logup_columns(col("a"), col("t"), col("m"), N, chal, d_s2.offset(at * N))
+            at += air_mod.STAGE2_WIDTH[st["kind"]]
+        self.p.lde(d_s2, c1.ext.offset(W * M), logn, logb, W2, self.shift, d_coef=c1.coef.offset(W * N))
         tree = self.p.alloc((2 * M - 1) * 4)
-        self.p.merkle_commit(c1.ext.offset(W * M), M, 3, tree)
+        self.p.merkle_commit(c1.ext.offset(W * M), M, W2, tree)
         self.p.sync()
-        d_z.free()
+        d_s2.free()
         c1.trace.free()
         return Commit(self._root(tree, M), tree)
 

@@ -115,6 +115,12 @@ int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, cons
  * caller's concern (g is a Fiat-Shamir challenge).                                                   */
 int32_t zp_grand_product(zp_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t n, const uint64_t gamma[3],
                          uint64_t *d_out);
+/* LogUp lookup columns (stage-2 witness of a lookup / range-check argument): values d_a u64[n] are looked up in the
+ * table column d_t u64[n] with multiplicities d_m u64[n] (m[i] = how often t[i] is hit, counted once per table
+ * value).  d_out u64[9][n] plane-major: h1 = 1/(a+g) (planes 0..2), h2 = m/(t+g) (3..5) and the running sum
+ * S[0]=0, S[i+1]=S[i]+h1[i]-h2[i] (6..8), all in F_{p^3}.  The lookup holds iff S wraps to 0.           */
+int32_t zp_logup_columns(zp_ctx *ctx, const uint64_t *d_a, const uint64_t *d_t, const uint64_t *d_m, size_t n,
+                         const uint64_t gamma[3], uint64_t *d_out);
 int32_t zp_gather_rows(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, const uint64_t *h_idx, int32_t nq,
                        uint64_t *h_out);
 int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, const uint64_t *h_idx, int32_t nq,
@@ -132,7 +138,9 @@ int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, cons
 int32_t zp_domain_tables(zp_ctx *ctx, int32_t logm, const uint64_t **d_lo, const uint64_t **d_hi, int32_t *lb);
 /* synthetic witness generation (stands in for the zkVM executor, which is not obtainable offline):
  * kind 0 = Fibonacci (W=2), kind 1 = wide degree-2 mix (any W >= 3), kind 2 = permutation AIR (W=3:
- * a, b = a permuted, c = a^2).  h_trace u64[W][2^logn]; h_pub receives the public inputs (3 / min(4,W) / 1).                 */
+ * a, b = a permuted, c = a^2), kind 3 = chunk AIR (W >= 12: W-8 wide-mix columns, then Fibonacci a,b, range values r,
+ * r permuted, range table t, multiplicities m, r^2, a*r+b).  h_trace u64[W][2^logn]; h_pub (room for 8) receives the
+ * public inputs (3 / min(4,W) / 1 / 8).                 */
 int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uint64_t *h_trace, uint64_t *h_pub);
 
 /* ---- N6: BN254 (alt_bn128) G1 multi-scalar multiplication ---------------------------------------

@@ -522,6 +522,23 @@ void orc_grand_product(const u64 *a, const u64 *b, size_t n, const u64 *g, u64 *
     }
 }
 
+/* LogUp lookup columns (sequential definition): h1 = 1/(a+g), h2 = m/(t+g), S[0] = 0, S[i+1] = S[i] + h1[i] - h2[i];
+ * out u64[9][n]: planes h1 0..2, h2 3..5, S 6..8.  Inversion by Fermat (e3_inv_pow), independent of the GPU's adjugate form. */
+void orc_logup_columns(const u64 *a, const u64 *t, const u64 *m, size_t n, const u64 *g, u64 *out) {
+    e3 s = {{0, 0, 0}};
+    for (size_t i = 0; i < n; i++) {
+        e3 da = {{gl_add(a[i], g[0]), g[1], g[2]}}, dt = {{gl_add(t[i], g[0]), g[1], g[2]}};
+        e3 h1 = e3_inv_pow(da), h2 = e3_inv_pow(dt);
+        for (int c = 0; c < 3; c++) h2.c[c] = gl_mul(h2.c[c], m[i]);
+        for (int c = 0; c < 3; c++) {
+            out[(size_t)c * n + i] = h1.c[c];
+            out[(size_t)(3 + c) * n + i] = h2.c[c];
+            out[(size_t)(6 + c) * n + i] = s.c[c];
+            s.c[c] = gl_add(s.c[c], gl_sub(h1.c[c], h2.c[c]));
+        }
+    }
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

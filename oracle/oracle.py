@@ -63,6 +63,7 @@ def lib():
         L.orc_poly_eval_e3_cols.argtypes = [_u64p, sz, i32, _u64p, _u64p]
         L.orc_deep_quotient_fast.argtypes = L.orc_deep_quotient.argtypes
         L.orc_grand_product.argtypes = [_u64p, _u64p, sz, _u64p, _u64p]
+        L.orc_logup_columns.argtypes = [_u64p, _u64p, _u64p, sz, _u64p, _u64p]
         L.orc_fri_fold.argtypes = [_u64p, _u64p, i32, i32, _u64p, u64, u64]
         L.orc_poly_eval.restype = u64
         L.orc_poly_eval.argtypes = [_u64p, sz, u64]
@@ -183,6 +184,13 @@ def grand_product(a, b, gamma):
     a, b = _arr(a), _arr(b)
     out = np.empty((3, a.shape[0]), dtype=np.uint64)
     lib().orc_grand_product(_p(a), _p(b), a.shape[0], _p(_arr(gamma)), _p(out))
+    return out
+
+
+def logup_columns(a, t, m, gamma):
+    a, t, m = _arr(a), _arr(t), _arr(m)
+    out = np.empty((9, a.shape[0]), dtype=np.uint64)
+    lib().orc_logup_columns(_p(a), _p(t), _p(m), a.shape[0], _p(_arr(gamma)), _p(out))
     return out
 
 

@@ -66,8 +66,14 @@ class CpuBackend:
         return np.asarray(mat).reshape(-1, rows)[col:]
 
     def commit_stage2(self, air, c1, chal, logn, logb):
-        st, W = air.stage2, c1.W
-        z = O.grand_product(c1.trace[st["a"]], c1.trace[st["b"]], chal)
+        W = c1.W
+        parts = []
+        for st in air.stage2:
+            if st["kind"] == "perm":
+                parts.append(O.grand_product(c1.trace[st["a"]], c1.trace[st["b"]], chal))
+            else:
+                parts.append(O.logup_columns(c1.trace[st["a"]], c1.trace[st["t"]], c1.trace[st["m"]], chal))
+        z = np.ascontiguousarray(np.concatenate(parts, axis=0))
         c1.ext[W:] = O.lde(z, logb, self.shift, self.root32)
         c1.coef[W:] = O.intt(z, self.root32)
         tree = O.merkle_commit(np.ascontiguousarray(c1.ext[W:]), self.rc, self.mds)

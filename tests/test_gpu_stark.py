@@ -91,6 +91,30 @@ def test_grand_product_matches_oracle(prover, n):
             assert lhs == NV.e3_mul(zi, [(int(a[i]) + g[0]) % P, g[1], g[2]])
 
 
+@pytest.mark.parametrize("n", [1, 2, 17, 4096, 4097, (1 << 16) + 5, 1 << 20])
+def test_logup_columns_match_oracle(prover, n):
+    rng = np.random.default_rng(90)
+    k = max(1, min(12, n.bit_length() - 1))
+    a = rng.integers(0, 1 << k, size=n, dtype=np.uint64)
+    t_ = (np.arange(n, dtype=np.uint64) % np.uint64(1 << k))
+    m = rng.integers(0, 5, size=n, dtype=np.uint64)     # the kernel does not care whether the lookup holds
+    g = O.random_field((3,), 91).tolist()
+    d_out = prover.alloc(9 * n)
+    prover.logup_columns(prover.upload(a), prover.upload(t_), prover.upload(m), n, g, d_out)
+    got = prover.download(d_out, (9, n))
+    if n <= (1 << 16) + 5:
+        assert (got == O.logup_columns(a, t_, m, g)).all()
+    else:   # definitions at sampled rows: h1 (a+g) = 1, h2 (t+g) = m, S' = S + h1 - h2, S[0] = 0
+        assert got[6:9, 0].tolist() == [0, 0, 0]
+        for i in [0, 1, 4095, 4096, n // 2, n - 2]:
+            h1 = [int(got[c, i]) for c in range(3)]
+            h2 = [int(got[3 + c, i]) for c in range(3)]
+            assert NV.e3_mul(h1, [(int(a[i]) + g[0]) % P, g[1], g[2]]) == [1, 0, 0]
+            assert NV.e3_mul(h2, [(int(t_[i]) + g[0]) % P, g[1], g[2]]) == [int(m[i]), 0, 0]
+            for c in range(3):
+                assert int(got[6 + c, i + 1]) == (int(got[6 + c, i]) + h1[c] - h2[c]) % P
+
+
 @pytest.mark.parametrize("name,logn", [("fib", 5), ("wide8", 8), ("wide32", 10)])
 def test_constraint_kernel_matches_cpu_codegen(hip_backend, cpu_backend, name, logn):
     air = AIR.get_air(name)
@@ -105,7 +129,7 @@ def test_constraint_kernel_matches_cpu_codegen(hip_backend, cpu_backend, name, l
     assert (hip_backend.download(d_q, q_cpu.shape) == q_cpu).all()
 
 
-@pytest.mark.parametrize("name,logn,queries", [("fib", 6, 5), ("fib", 12, 8), ("perm", 7, 6), ("perm", 13, 8), ("wide8", 10, 8), ("wide32", 13, 12), ("wide64", 14, 8)])
+@pytest.mark.parametrize("name,logn,queries", [("fib", 6, 5), ("fib", 12, 8), ("perm", 7, 6), ("perm", 13, 8), ("wide8", 10, 8), ("wide32", 13, 12), ("wide64", 14, 8), ("chunk16", 8, 6), ("chunk64", 13, 8)])
 def test_gpu_proof_is_bit_identical_to_cpu_and_verifies(hip_backend, cpu_backend, tables, name, logn, queries):
     rc, mds = tables
     air = AIR.get_air(name)
@@ -141,7 +165,7 @@ def test_blowup_four(hip_backend, cpu_backend, tables):
     assert V.verify(gpu, air, rc, mds)
 
 
-@pytest.mark.parametrize("name,logn", [("wide64", 22), ("wide8", 24), ("perm", 22)])
+@pytest.mark.parametrize("name,logn", [("wide64", 22), ("wide8", 24), ("perm", 22), ("chunk64", 22)])
 def test_full_size_proofs_pass_the_independent_verifier(hip_backend, tables, name, logn):
     """BASELINE configs[2]/[3] sizes: the CPU prover is too slow to compare against, but the verifier's
     cost does not depend on the trace length -- a 2^22..2^24-row proof from the MI355X must verify."""
