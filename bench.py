@@ -121,6 +121,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
 
+    # achievable HBM ceiling on this device (report against both the vendor peak and a measured copy):
+    # device-to-device copy of the same 2^logn x cols matrix, read + write bytes counted
+    copy_gbs = None
+    if rank == 0:
+        y = torch.empty_like(x)
+        for _ in range(2):
+            y.copy_(x)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            y.copy_(x)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * x.numel() * 8 * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del y
+
     pipe = None
     if not args.no_pipeline:
         del x
@@ -177,6 +193,8 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if launches else None,
                 "traffic": traffic,
+                "hbm_copy_ceiling_GBs": copy_gbs,
+                "frac_of_copy_ceiling": (achieved / copy_gbs) if (launches and copy_gbs) else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_ms, "launches_timed": launches,
                 "whole_transform_GBs": 16.0 * N * cols * args.steps / (dev_ms * 1e-3) / 1e9,
@@ -261,7 +279,7 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
     return res
 
 
-def batch_proof_probe(logn, air_name="wide64"):
+def batch_proof_probe(logn, air_name="chunk64"):
     """BASELINE configs[2]-shaped: one chunk, full STARK (trace -> LDE -> constraints -> FRI) on one GPU"""
     from eigen_zeth_amd import native
     from eigen_zeth_amd.stark import air as AIR, prover as PR
@@ -282,7 +300,7 @@ def batch_proof_probe(logn, air_name="wide64"):
             "witness_host_s": tw, "proof_bytes": len(PR.proof_to_json(proof))}
 
 
-def cpu_stark_baseline(logn, air_name="wide64"):
+def cpu_stark_baseline(logn, air_name="chunk64"):
     import numpy as np
     from eigen_zeth_amd import native
     from eigen_zeth_amd.poseidon_constants import default_round_constants, default_mds

@@ -1,4 +1,4 @@
-"""python -m eigen_zeth_amd.service [--port 50061] [--state-dir DIR] [--air wide32] [--logn 20]"""
+"""python -m eigen_zeth_amd.service [--port 50061] [--state-dir DIR] [--air chunk64] [--logn 20]"""
 import argparse
 import time
 
@@ -12,12 +12,14 @@ def main():
     ap.add_argument("--port", type=int, default=50061)   # PROVER_ADDR default, src/config/env.rs:21
     ap.add_argument("--state-dir", default="prover_state")
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--air", default="wide32")
+    ap.add_argument("--air", default="chunk64")
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--chunks-per-block", type=int, default=1)
     ap.add_argument("--l2-addr", default=None, help="L2 JSON-RPC (ZETH_L2_ADDR) to fetch block inputs from")
+    ap.add_argument("--metrics-port", type=int, default=None, help="serve Prometheus text metrics on /metrics")
     a = ap.parse_args()
-    server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, chunks_per_block=a.chunks_per_block, l2_addr=a.l2_addr), a.device)
+    server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, chunks_per_block=a.chunks_per_block, l2_addr=a.l2_addr), a.device,
+                         metrics_port=a.metrics_port)
     print("prover.v1.ProverService listening on %s:%d" % (a.host, port), flush=True)
     try:
         while True:

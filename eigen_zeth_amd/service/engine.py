@@ -26,7 +26,7 @@ from . import groth16
 
 
 class EngineConfig:
-    def __init__(self, air="wide32", logn=12, logb=1, chunks_per_block=1, n_queries=16, fri_logf=3, fri_final_log=5,
+    def __init__(self, air="chunk64", logn=12, logb=1, chunks_per_block=1, n_queries=16, fri_logf=3, fri_final_log=5,
                  groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
                  witness_threads=8):
         self.air, self.logn, self.logb = air, logn, logb
@@ -43,6 +43,7 @@ class Engine:
         self._be = None
         self.cfg = config or EngineConfig()
         self.stage_timings = {}
+        self.metrics = None   # service/metrics.py Metrics, attached by serve()
         self._g16 = None
 
     @property
@@ -119,6 +120,8 @@ class Engine:
                 del trace
                 proof["chunk"] = {"block": ch["block"], "chunk": ch["chunk"]}
                 self.stage_timings["%s/%d" % (task_id, i)] = tm
+                if self.metrics is not None:
+                    self.metrics.record_proof(tm, ch["logn"], self.cfg.logb, air.width)
                 out.append({"chunk_id": i, "proof_key": "chunk-%s-%d" % (task_id, i), "proof": PR.proof_to_json(proof)})
         return out
 
@@ -158,5 +161,7 @@ class Engine:
         t0 = time.perf_counter()
         proof, pub = groth16.prove(circ, pk, w, self.be.msm_g1, rnd)
         self.stage_timings["final/" + batch_id] = {"groth16": time.perf_counter() - t0}
+        if self.metrics is not None:
+            self.metrics.record_stage("groth16", self.stage_timings["final/" + batch_id]["groth16"])
         js = groth16.proof_to_json(proof, {"circuit": "arithmetic-chain(logm=%d), local CRS -- stand-in for the recursive-verifier circuit" % circ.logm})
         return js, json.dumps([str(pub[0])])

@@ -22,8 +22,11 @@ VERSION = "zeth-prover-mi355x/0.1"
 
 
 class ProverService:
-    def __init__(self, engine, store):
+    def __init__(self, engine, store, metrics=None):
         self.engine, self.store = engine, store
+        self.metrics = metrics
+        if metrics is not None:
+            engine.metrics = metrics
         self.last_id, self.last_end, self.cur_id, self.cur_start = "", 0, "", 0
 
     # ---- the stream
@@ -52,6 +55,8 @@ class ProverService:
                     self._status(resp, error="request without request_type")
             finally:
                 self.last_id, self.last_end, self.cur_id = req.id, int(time.time()), ""
+            if self.metrics is not None:
+                self.metrics.count_request(*_outcome(resp))
             yield resp
 
     # ---- handlers (idempotent per batch_id)
@@ -145,6 +150,17 @@ class ProverService:
         ps.fork_id = 0
 
 
+def _outcome(resp):
+    """(request kind, ok?) of a response, for the request counters"""
+    kind = resp.WhichOneof("response_type")
+    if kind == "gen_batch_proof":
+        step = resp.gen_batch_proof.WhichOneof("step")
+        return step or kind, getattr(resp.gen_batch_proof, step).result_code == proto.COMPLETED_OK if step else False
+    if kind in ("gen_aggregated_proof", "gen_final_proof"):
+        return kind, getattr(resp, kind).result_code == proto.COMPLETED_OK
+    return kind or "unknown", True
+
+
 def make_server(service, port=50061, host="127.0.0.1", max_workers=4):
     handler = grpc.method_handlers_generic_handler(proto.SERVICE, {
         "ProverStream": grpc.stream_stream_rpc_method_handler(
@@ -164,10 +180,15 @@ def default_backend_factory(device=0):
     return make
 
 
-def serve(port=50061, host="127.0.0.1", state_dir="prover_state", config=None, device=0):
+def serve(port=50061, host="127.0.0.1", state_dir="prover_state", config=None, device=0, metrics_port=None):
     engine = Engine(default_backend_factory(device), config or EngineConfig())
     engine.be  # fail at start-up, not at the first request, when no GPU is present
-    service = ProverService(engine, BatchStore(state_dir))
+    metrics = None
+    if metrics_port is not None:
+        from .metrics import Metrics
+        metrics = Metrics()
+        metrics.serve(metrics_port, host)
+    service = ProverService(engine, BatchStore(state_dir), metrics)
     server, bound = make_server(service, port, host)
     server.start()
     return server, bound

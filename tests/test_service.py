@@ -205,7 +205,7 @@ def test_product_service_needs_gpu():
 @pytest.mark.gpu
 def test_round_trip_gpu_matches_cpu(tmp_path, cpu_factory, tables):
     from eigen_zeth_amd.service.server import default_backend_factory
-    cfg = EngineConfig(air="wide32", logn=12, n_queries=8)
+    cfg = EngineConfig(air="chunk64", logn=12, n_queries=8)
     server, port, svc = _start(tmp_path / "gpu", default_backend_factory(), cfg)
     server2, port2, svc2 = _start(tmp_path / "cpu", cpu_factory, cfg)
     try:
@@ -249,5 +249,33 @@ def test_block_input_fetcher_with_stub_node(tmp_path, cpu_factory):
         with pytest.raises(ProverClientError):
             ch.execute(99, max_retries=1)               # unknown block -> COMPLETED_ERROR
         ch.close()
+    finally:
+        server.stop(0); httpd.shutdown()
+
+
+def test_metrics_endpoint_counts_requests_and_stage_time(tmp_path, cpu_factory):
+    """Prometheus text on /metrics with request counters, per-stage seconds and the HBM rate gauge"""
+    import urllib.request
+    from eigen_zeth_amd.service.metrics import Metrics
+    cfg = EngineConfig(air="chunk16", logn=6, n_queries=4, fri_final_log=3)
+    cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
+    m = Metrics()
+    httpd = m.serve(0)
+    svc = ProverService(Engine(cpu_factory, cfg), BatchStore(str(tmp_path)), m)
+    server, port = make_server(svc, port=0)
+    server.start()
+    try:
+        ch = ProverChannel("127.0.0.1:%d" % port)
+        ch.execute(3)
+        ch.close()
+        txt = urllib.request.urlopen("http://127.0.0.1:%d/metrics" % httpd.server_address[1]).read().decode()
+        assert 'zeth_prover_requests_total{type="gen_chunk_proof",outcome="ok"} 1' in txt
+        assert 'zeth_prover_requests_total{type="gen_final_proof",outcome="ok"} 1' in txt
+        assert "zeth_prover_chunk_proofs_total 1" in txt
+        assert 'zeth_prover_stage_seconds_count{stage="grand-product+lde+merkle(stage2)"} 1' in txt
+        assert 'zeth_prover_stage_seconds_count{stage="groth16"} 1' in txt
+        assert 'zeth_prover_stage_hbm_gbps{stage="lde+merkle(trace)"}' in txt
+        with pytest.raises(Exception):
+            urllib.request.urlopen("http://127.0.0.1:%d/other" % httpd.server_address[1])
     finally:
         server.stop(0); httpd.shutdown()

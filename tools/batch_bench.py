@@ -1,12 +1,12 @@
 """Batch-proof wall-clock on one GPU (BASELINE configs[4] shape at N=1): K blocks -> K chunk STARKs ->
-aggregate -> Groth16 wrap, through the engine (no gRPC).  usage: python tools/batch_bench.py [K=16] [logn=20] [air=wide64]"""
+aggregate -> Groth16 wrap, through the engine (no gRPC).  usage: python tools/batch_bench.py [K=16] [logn=20] [air=chunk64]"""
 import json, os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eigen_zeth_amd.service.engine import Engine, EngineConfig
 from eigen_zeth_amd.service.server import default_backend_factory
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-air = sys.argv[3] if len(sys.argv) > 3 else "wide64"
+air = sys.argv[3] if len(sys.argv) > 3 else "chunk64"
 cfg = EngineConfig(air=air, logn=logn, n_queries=32, groth16_logm=8, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs"), witness_threads=16)
 eng = Engine(default_backend_factory(0), cfg)
 eng.be
