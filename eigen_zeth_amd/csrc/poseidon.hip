@@ -206,16 +206,20 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const u64 *__restrict
     for (int j = 0; j < 4; j++) next[i * 4 + j] = s[j];
 }
 
-// top of the tree in ONE launch: every level with <= 64 nodes, 12 lanes per node (a per-level launch of the
-// lane-per-node kernel costs a full single-lane permutation latency, ~0.1-0.3 ms, for each of the last ~7 levels)
-__global__ void __launch_bounds__(768) merkle_top_kernel(u64 *prev, size_t cnt, const u64 *rc, const u32 *mds) {
+// upper part of the tree, up to 7 levels per launch, 12 lanes per node: workgroup b reduces nodes
+// [128b, 128b+128) of the level at `prev` (cnt nodes, a power of two) through nlev levels.  The lane-per-node kernel
+// below ~2^15 nodes is latency-bound (one permutation takes a single lane ~0.1 ms); spreading a state over 12 lanes
+// brings a level to ~30 us, and fusing the levels of a 128-node subtree removes the launches in between.
+__global__ void __launch_bounds__(768) merkle_subtree_kernel(u64 *prev, size_t cnt, int nlev, const u64 *rc, const u32 *mds) {
     __shared__ u64 sh[64][12];
     const int node = threadIdx.x / 12, e = threadIdx.x % 12;
-    while (cnt > 1) {
-        const size_t half = cnt >> 1;
+    size_t first = (size_t)blockIdx.x * 128;          // first node of this workgroup in the current level
+    size_t width = cnt < 128 ? cnt : 128;             // nodes of the current level this workgroup owns
+    for (int l = 0; l < nlev; l++) {
+        const size_t half = width >> 1;
         u64 *next = prev + cnt * 4;
         const bool on = (size_t)node < half;
-        u64 s = (on && e < 8) ? prev[(size_t)node * 8 + e] : 0ULL;
+        u64 s = (on && e < 8) ? prev[(first + 2 * (size_t)node) * 4 + e] : 0ULL;
         for (int r = 0; r < 30; r++) {
             s = gl_add_weak(s, rc[r * 12 + e]);
             if (r < 4 || r >= 26 || e == 0) s = sbox7(s);
@@ -233,11 +237,13 @@ __global__ void __launch_bounds__(768) merkle_top_kernel(u64 *prev, size_t cnt, 
             const u64 mid = (alo >> 32) + ahi;
             s = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
         }
-        if (on && e < 4) next[(size_t)node * 4 + e] = gl_canon(s);
+        if (on && e < 4) next[((first >> 1) + (size_t)node) * 4 + e] = gl_canon(s);
         __threadfence_block();
         __syncthreads();
         prev = next;
-        cnt = half;
+        cnt >>= 1;
+        first >>= 1;
+        width = half;
     }
 }
 
@@ -247,10 +253,18 @@ int32_t tree_levels(zp_ctx *ctx, u64 *tree, size_t M) {
     while (cnt > 1) {
         u64 *next = prev + cnt * 4;
         const size_t half = cnt >> 1;
-        if (half <= 64) {
-            hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(768), 0, ctx->stream, prev, cnt, ctx->d_rc, ctx->d_mds);
+        if (cnt <= ((size_t)1 << 15)) {
+            int lg = 0;
+            while (((size_t)1 << lg) < cnt) lg++;
+            const int nlev = lg < 7 ? lg : 7;
+            hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(cnt < 128 ? 1 : cnt / 128)), dim3(768), 0, ctx->stream,
+                               prev, cnt, nlev, ctx->d_rc, ctx->d_mds);
             ZP_HIP(ctx, hipGetLastError());
-            break;
+            for (int l = 0; l < nlev; l++) {
+                prev += cnt * 4;
+                cnt >>= 1;
+            }
+            continue;
         }
         if (ctx->mds_is_default)
             hipLaunchKernelGGL(merkle_level_kernel<true>, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream,
