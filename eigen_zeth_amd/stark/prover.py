@@ -42,6 +42,8 @@ class StarkParams:
 
 
 def _ints(a):
+    if hasattr(a, "tolist"):      # numpy array (any rank): converted by a C loop into (nested) lists of Python ints
+        return a.tolist()
     return [int(v) for v in a]
 
 
