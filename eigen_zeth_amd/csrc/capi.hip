@@ -27,6 +27,13 @@ int32_t zp_create(zp_ctx **out, int32_t device) {
     memcpy(ctx->h_mds, ZP_POSEIDON_DEFAULT_MDS, sizeof(ctx->h_mds));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    // a ctx owns a non-blocking stream: two ctxs (e.g. prover + witness upload) overlap instead of serialising on
+    // the legacy default stream
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return ZP_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
     *out = ctx;
     return ZP_OK;
 }
@@ -49,6 +56,7 @@ void zp_destroy(zp_ctx *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->d_rc) (void)hipFree(ctx->d_rc);
     if (ctx->d_mds) (void)hipFree(ctx->d_mds);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -57,6 +65,13 @@ const char *zp_last_error(zp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null c
 int32_t zp_set_stream(zp_ctx *ctx, void *hip_stream) {
     if (!ctx) return ZP_ERR_ARG;
     ctx->stream = (hipStream_t)hip_stream;
+    return ZP_OK;
+}
+
+int32_t zp_get_stream(zp_ctx *ctx, void **hip_stream) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, hip_stream != nullptr, "null pointer");
+    *hip_stream = (void *)ctx->stream;
     return ZP_OK;
 }
 
@@ -143,6 +158,23 @@ int32_t zp_dev_free(zp_ctx *ctx, void *d_ptr) {
     if (!d_ptr) return ZP_OK;
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZP_HIP(ctx, hipFree(d_ptr));
+    return ZP_OK;
+}
+int32_t zp_host_alloc(zp_ctx *ctx, size_t bytes, void **h_ptr) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, h_ptr != nullptr && bytes > 0, "null pointer / zero size");
+    (void)hipSetDevice(ctx->device);
+    if (hipHostMalloc(h_ptr, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->err = "zp_host_alloc: hipHostMalloc failed";
+        return ZP_ERR_NOMEM;
+    }
+    return ZP_OK;
+}
+int32_t zp_host_free(zp_ctx *ctx, void *h_ptr) {
+    if (!ctx) return ZP_ERR_ARG;
+    if (!h_ptr) return ZP_OK;
+    ZP_HIP(ctx, hipHostFree(h_ptr));
     return ZP_OK;
 }
 int32_t zp_h2d(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {

@@ -39,7 +39,8 @@ struct CosetTable {  // shift^i * pre, i < 2^logn, two-level
 
 struct zp_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // where every launch of this ctx goes
+    hipStream_t own_stream = nullptr;  // created by zp_create (non-blocking); replaced, not destroyed, by zp_set_stream
     std::string err;
     u64 root32 = ZP_ROOT32_DEFAULT;
     u64 coset_shift = ZP_SHIFT_DEFAULT;

@@ -448,17 +448,39 @@ int32_t zpi_pinned(zp_ctx *ctx, size_t bytes, void **out) {
             ctx->pinned_bytes = 0;
         }
         size_t cap = bytes < (8u << 20) ? (8u << 20) : bytes;
-        ZP_HIP(ctx, hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+        ZP_HIP(ctx, hipHostMalloc(&ctx->pinned, cap, hipHostMallocMapped | hipHostMallocPortable));
         ctx->pinned_bytes = cap;
     }
     *out = ctx->pinned;
     return ZP_OK;
 }
 
+// Small host<->device copies are KERNELS through the pinned (device-visible) staging buffer, not DMA copies: a
+// hipMemcpyAsync of a few hundred bytes queues behind whatever the copy engines are doing -- with a second ctx
+// streaming 512 MB witnesses in, the transcript's tiny copies waited for all of them (0.47 s in the first chunk
+// of a 16-chunk batch).  A copy kernel is ordered on the ctx stream with the compute it feeds and never meets
+// the DMA queues.
+__global__ void __launch_bounds__(256) small_copy_kernel(const u32 *__restrict__ src, u32 *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+static inline bool word_copyable(const void *a, size_t bytes) { return (((uintptr_t)a | bytes) & 3u) == 0; }
+
+static inline void launch_small_copy(zp_ctx *ctx, const void *src, void *dst, size_t bytes) {
+    const size_t n = bytes / 4;
+    const unsigned blocks = (unsigned)(n < 256 * 256 ? (n + 255) / 256 : 256);
+    hipLaunchKernelGGL(small_copy_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, ctx->stream, (const u32 *)src, (u32 *)dst, n);
+}
+
 int32_t zpi_d2h_small(zp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     void *st;
     ZP_TRY(zpi_pinned(ctx, bytes, &st));
-    ZP_HIP(ctx, hipMemcpyAsync(st, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (word_copyable(d_src, bytes)) {
+        launch_small_copy(ctx, d_src, st, bytes);
+        ZP_HIP(ctx, hipGetLastError());
+    } else {
+        ZP_HIP(ctx, hipMemcpyAsync(st, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(h_dst, st, bytes);
     return ZP_OK;
@@ -469,7 +491,12 @@ int32_t zpi_h2d_small(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still feed an earlier copy
     ZP_TRY(zpi_pinned(ctx, bytes, &st));
     memcpy(st, h_src, bytes);
-    ZP_HIP(ctx, hipMemcpyAsync(d_dst, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (word_copyable(d_dst, bytes)) {
+        launch_small_copy(ctx, st, d_dst, bytes);
+        ZP_HIP(ctx, hipGetLastError());
+    } else {
+        ZP_HIP(ctx, hipMemcpyAsync(d_dst, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZP_OK;
 }

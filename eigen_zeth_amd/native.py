@@ -10,6 +10,7 @@ Reference call sites this path serves: src/prover/provider.rs:358-390 (GenChunkP
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import json
 import os
 
@@ -38,11 +39,14 @@ SIGNATURES = {
     "zp_last_error": (C.c_char_p, [_vp]),
     "zp_version": (C.c_char_p, []),
     "zp_set_stream": (C.c_int32, [_vp, _vp]),
+    "zp_get_stream": (C.c_int32, [_vp, C.POINTER(C.c_void_p)]),
     "zp_sync": (C.c_int32, [_vp]),
     "zp_set_constants": (C.c_int32, [_vp, C.c_int32, _u64p, C.c_size_t]),
     "zp_get_constants": (C.c_int32, [_vp, C.c_int32, _u64p, C.c_size_t]),
     "zp_dev_alloc": (C.c_int32, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "zp_dev_free": (C.c_int32, [_vp, _vp]),
+    "zp_host_alloc": (C.c_int32, [_vp, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "zp_host_free": (C.c_int32, [_vp, _vp]),
     "zp_h2d": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
     "zp_d2h": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
     "zp_d2d": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
@@ -77,10 +81,12 @@ SIGNATURES = {
 }
 
 
-def synth_trace(kind, logn, W, seed):
-    """synthetic witness (host code inside the library, no GPU needed): (trace [W][N], publics)"""
+def synth_trace(kind, logn, W, seed, out=None):
+    """synthetic witness (host code inside the library, no GPU needed): (trace [W][N], publics);
+    `out`: optional uint64 [W][N] array to fill (e.g. page-locked memory from Prover.host_array)"""
     lib = load_library()
-    tr = np.empty((W, 1 << logn), dtype=np.uint64)
+    tr = np.empty((W, 1 << logn), dtype=np.uint64) if out is None else out
+    assert tr.shape == (W, 1 << logn) and tr.dtype == np.uint64 and tr.flags["C_CONTIGUOUS"]
     pub = np.zeros(8, dtype=np.uint64)
     rc = lib.zp_synth_trace(kind, logn, W, seed, tr.ctypes.data_as(_u64p), pub.ctypes.data_as(_u64p))
     if rc != 0:
@@ -133,10 +139,12 @@ class DeviceBuffer:
         self.prover = prover
         self.n = int(n_elems)
         self.shape = (self.n,)
-        pool = prover._pool.get(self.n) if prover.pooling else None
-        if pool:
-            self.ptr = pool.pop()     # reuse: hipMalloc/hipFree and the first touch of fresh memory are slow
-            return
+        if prover.pooling:
+            with prover._lock:
+                pool = prover._pool.get(self.n)
+                if pool:
+                    self.ptr = pool.pop()     # reuse: hipMalloc/hipFree and the first touch of fresh memory are slow
+                    return
         p = _vp()
         prover._chk(prover.lib.zp_dev_alloc(prover.ctx, self.n * 8, C.byref(p)))
         self.ptr = p.value or 0
@@ -147,7 +155,8 @@ class DeviceBuffer:
     def free(self):
         if self.ptr and self.prover.ctx:
             if self.prover.pooling and self.n >= 1024:
-                self.prover._pool.setdefault(self.n, []).append(self.ptr)
+                with self.prover._lock:
+                    self.prover._pool.setdefault(self.n, []).append(self.ptr)
             else:
                 self.prover.lib.zp_dev_free(self.prover.ctx, self.ptr)
         self.ptr = 0
@@ -171,11 +180,17 @@ class Prover:
         self.ctx = ctx
         self.pooling = False      # device-buffer reuse by exact size (set True for repeated same-shape work)
         self._pool = {}
+        self._hpool = {}          # page-locked host buffers by byte size
+        self._lock = threading.Lock()
         if stream is not None:
             self.set_stream(stream)
 
     def trim(self):
         """release every pooled device buffer"""
+        for ptrs in self._hpool.values():
+            for ptr in ptrs:
+                self.lib.zp_host_free(self.ctx, ptr)
+        self._hpool = {}
         for ptrs in self._pool.values():
             for ptr in ptrs:
                 self.lib.zp_dev_free(self.ctx, ptr)
@@ -198,6 +213,12 @@ class Prover:
             raise ZpError(rc, (self.lib.zp_last_error(self.ctx) or b"").decode())
 
     # ---- plumbing
+    def stream_handle(self):
+        """the hipStream_t every launch of this ctx goes to (None = the legacy default stream)"""
+        out = C.c_void_p()
+        self._chk(self.lib.zp_get_stream(self.ctx, C.byref(out)))
+        return out.value
+
     def set_stream(self, stream):
         self._chk(self.lib.zp_set_stream(self.ctx, int(stream) if stream else None))
 
@@ -215,6 +236,27 @@ class Prover:
 
     def alloc(self, n_elems):
         return DeviceBuffer(self, n_elems)
+
+    def host_array(self, shape):
+        """uint64 numpy array in page-locked host memory (zp_host_alloc), pooled by size; hand it back with
+        release_host_array when the copy that read it has completed"""
+        nbytes = int(np.prod(shape)) * 8
+        with self._lock:
+            pool = self._hpool.get(nbytes)
+            ptr = pool.pop() if pool else None
+        if ptr is None:
+            p = C.c_void_p()
+            self._chk(self.lib.zp_host_alloc(self.ctx, nbytes, C.byref(p)))
+            ptr = p.value
+        arr = np.ctypeslib.as_array((C.c_uint64 * (nbytes // 8)).from_address(ptr)).reshape(shape)
+        self._host_ptrs = getattr(self, "_host_ptrs", {})
+        self._host_ptrs[arr.ctypes.data] = (ptr, nbytes)
+        return arr
+
+    def release_host_array(self, arr):
+        ptr, nbytes = self._host_ptrs.pop(arr.ctypes.data)
+        with self._lock:
+            self._hpool.setdefault(nbytes, []).append(ptr)
 
     def upload(self, arr):
         a = np.ascontiguousarray(np.asarray(arr, dtype=np.uint64))

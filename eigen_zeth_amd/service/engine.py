@@ -98,7 +98,10 @@ class Engine:
         def witness(ch):
             air = AIR.get_air(ch["air"])
             t0 = time.perf_counter()
-            trace, pubs = native.synth_trace(air.trace_kind, ch["logn"], air.width, ch["seed"])
+            out = None
+            if hasattr(self.be, "witness_buffer"):   # generate straight into page-locked memory: the copy is then plain DMA
+                out = self.be.witness_buffer(air.width, 1 << ch["logn"])
+            trace, pubs = native.synth_trace(air.trace_kind, ch["logn"], air.width, ch["seed"], out=out)
             tw = time.perf_counter() - t0
             if hasattr(self.be, "prefetch_trace"):   # copy to the GPU from this worker thread, on its own stream
                 trace = self.be.prefetch_trace(trace)

@@ -3,6 +3,7 @@ No CPU fallback: construction fails without libzethprover.so and an MI355X."""
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -29,6 +30,7 @@ class HipBackend:
         self._perm_buf = self.p.alloc(12)
         self.p_device = device
         self._up = None
+        self._up_lock, self._copy_lock = threading.Lock(), threading.Lock()
 
     def sync(self):
         self.p.sync()
@@ -43,14 +45,27 @@ class HipBackend:
     def _root(self, tree, M):
         return [int(v) for v in self.p.download(tree, (4,), offset_elems=(2 * M - 2) * 4)]
 
+    def _uploader(self):
+        with self._up_lock:
+            if self._up is None:
+                self._up = native.Prover(self.p_device)
+                self._up.pooling = True
+        return self._up
+
+    def witness_buffer(self, W, N):
+        """page-locked host array for a witness generator to fill (pooled); pass it to prefetch_trace"""
+        return self._uploader().host_array((W, N))
+
     def prefetch_trace(self, trace):
         """H2D of a witness on a second ctx/stream (safe to call from a worker thread): lets the engine copy
-        chunk i+1 while chunk i is being proven.  Returns a handle commit_trace accepts in place of the array."""
-        if self._up is None:
-            self._up = native.Prover(self.p_device)
-            self._up.pooling = True
-        buf = self._up.upload(trace)
+        chunk i+1 while chunk i is being proven.  One copy in flight at a time (PCIe is the limit anyway).
+        Returns a handle commit_trace accepts in place of the array; a witness_buffer is recycled."""
+        up = self._uploader()
+        with self._copy_lock:
+            buf = up.upload(trace)
         buf.shape = trace.shape
+        if trace.ctypes.data in getattr(up, "_host_ptrs", {}):
+            up.release_host_array(trace)
         return buf
 
     def commit_trace(self, trace, logn, logb, extra_cols=0):
@@ -130,7 +145,7 @@ class HipBackend:
         d_zh = self.p.upload(np.array(zhinv, dtype=np.uint64))
         lo, hi, lb = self.p.domain_tables(logn + logb)
         out = self.p.alloc(3 * M)
-        rc = fn(None, c1.ext.ptr, fixed.ptr, M, 1 << logb, d_pub.ptr, d_ap.ptr, d_zh.ptr, lo, hi, lb, self.shift,
+        rc = fn(self.p.stream_handle(), c1.ext.ptr, fixed.ptr, M, 1 << logb, d_pub.ptr, d_ap.ptr, d_zh.ptr, lo, hi, lb, self.shift,
                 wlast, out.ptr)
         if rc != 0:
             raise native.ZpError(-2, "constraint kernel launch failed (hip error %d)" % rc)

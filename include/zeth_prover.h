@@ -17,8 +17,11 @@
  *  - matrices are COLUMN-MAJOR  u64[W][N]  (column c at base + c*N), N a power of two.
  *  - F_{p^3} vectors are plane-major u64[3][n]  (x^3 - x - 1).
  *  - pointers named d_* are DEVICE pointers (hipMalloc / torch.cuda storage); h_* are host.
- *  - a ctx is bound to one HIP device and one stream (zp_set_stream; default = the null stream);
- *    it is single-threaded; separate ctxs may run concurrently (one per GPU / per stream).
+ *  - a ctx is bound to one HIP device and one stream: zp_create makes a non-blocking stream of its own, so
+ *    separate ctxs overlap (one per GPU, or prover + witness upload on one GPU); zp_set_stream replaces it with
+ *    the caller's stream (NULL = the legacy default stream), zp_get_stream hands it to code that launches beside
+ *    the library (the AIR plug-in kernels).  A ctx is single-threaded; buffers written through one ctx may be
+ *    read through another after zp_sync / a synchronous copy on the writer.
  *  - all compute entry points are asynchronous on the ctx stream; zp_sync() waits.
  */
 #ifndef ZETH_PROVER_H
@@ -54,6 +57,7 @@ void zp_destroy(zp_ctx *ctx);
 const char *zp_last_error(zp_ctx *ctx);
 const char *zp_version(void);
 int32_t zp_set_stream(zp_ctx *ctx, void *hip_stream);
+int32_t zp_get_stream(zp_ctx *ctx, void **hip_stream);
 int32_t zp_sync(zp_ctx *ctx);
 int32_t zp_set_constants(zp_ctx *ctx, int32_t kind, const uint64_t *blob, size_t n);
 int32_t zp_get_constants(zp_ctx *ctx, int32_t kind, uint64_t *blob, size_t n);
@@ -61,6 +65,10 @@ int32_t zp_get_constants(zp_ctx *ctx, int32_t kind, uint64_t *blob, size_t n);
 /* ---- device memory (for hosts without their own allocator) ---------------------------------- */
 int32_t zp_dev_alloc(zp_ctx *ctx, size_t bytes, void **d_ptr);
 int32_t zp_dev_free(zp_ctx *ctx, void *d_ptr);
+/* page-locked, device-visible host memory for witnesses: zp_h2d / zp_d2h from it are plain DMA at PCIe rate; a copy
+ * from pageable memory is staged by the runtime under a lock that stalls every other thread's HIP calls meanwhile */
+int32_t zp_host_alloc(zp_ctx *ctx, size_t bytes, void **h_ptr);
+int32_t zp_host_free(zp_ctx *ctx, void *h_ptr);
 int32_t zp_h2d(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int32_t zp_d2h(zp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int32_t zp_d2d(zp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);

@@ -333,3 +333,46 @@ def test_ntt_column_chunking(prover):
     prover.lde(d, d_out, logn, 1, W, shift=1)
     y = prover.download(d_out, (W, 1 << (logn + 1)))
     assert (y[:, ::2] == x).all()
+
+
+def test_ctx_owns_a_stream_and_two_ctxs_share_buffers(prover):
+    """zp_create gives every ctx its own non-blocking stream; a buffer uploaded through one ctx is readable
+    through another (the engine's witness-upload ctx beside the proving ctx)"""
+    from eigen_zeth_amd import native
+    other = native.Prover(0)
+    try:
+        s1, s2 = prover.stream_handle(), other.stream_handle()
+        assert s1 and s2 and s1 != s2
+        x = O.random_field((3, 1 << 12), 4242)
+        d = other.upload(x)                       # synchronous on the uploading ctx
+        out = prover.alloc(3 << 12)
+        prover.ntt(d, out, 12, 3)
+        assert (prover.download(out, x.shape) == O.ntt(x)).all()
+        other.set_stream(None)                    # legacy default stream
+        assert other.stream_handle() is None
+        other.ntt(d, out, 12, 3)
+        assert (other.download(out, x.shape) == O.ntt(x)).all()
+    finally:
+        other.close()
+
+
+def test_page_locked_host_arrays_round_trip_and_are_pooled(prover):
+    a = prover.host_array((3, 1 << 17))           # > the small-copy threshold: plain DMA from pinned memory
+    a[:] = O.random_field(a.shape, 777)
+    keep = a.copy()
+    d = prover.upload(a)
+    assert (prover.download(d, a.shape) == keep).all()
+    addr = a.ctypes.data
+    prover.release_host_array(a)
+    b = prover.host_array((3, 1 << 17))
+    assert b.ctypes.data == addr                  # reused, not re-pinned
+    prover.release_host_array(b)
+    tr, pub = native_mod().synth_trace(1, 10, 6, 3, out=prover.host_array((6, 1 << 10)))
+    ref, pub2 = native_mod().synth_trace(1, 10, 6, 3)
+    assert (tr == ref).all() and (pub == pub2).all()
+    prover.release_host_array(tr)
+
+
+def native_mod():
+    from eigen_zeth_amd import native
+    return native

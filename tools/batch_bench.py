@@ -25,6 +25,9 @@ for rep in range(2):
         if "/" in k and not k.startswith("final"):
             for kk, vv in v.items():
                 stages[kk] = stages.get(kk, 0.0) + vv
+    if rep == 1 and os.environ.get("ZP_BATCH_VERBOSE"):
+        for k, v in eng.stage_timings.items():
+            print(k, {kk: round(vv * 1e3, 1) for kk, vv in v.items()}, file=sys.stderr)
     print(json.dumps({"rep": rep, "chunks": K, "logn": logn, "air": air, "batch_wall_s": t3 - t0, "chunks_s": t1 - t0,
                       "chunk_proofs_s": t2 - t1, "aggregate_final_s": t3 - t2, "crs_setup_s(one-time)": t_crs,
                       "sum_stage_s": {k: round(v, 3) for k, v in stages.items()},
