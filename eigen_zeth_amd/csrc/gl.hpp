@@ -113,6 +113,41 @@ GL_HD u64 gl_add_weak(u64 a_any, u64 b_canon) {
     return s + ((s < a_any) ? GL_EPS : 0);
 }
 
+// ---- unreduced dot-product accumulator: sum of up to 2^31 full products a*b in 160 bits, one reduction at the end
+// (a multiply-accumulate is 4 v_mad_u64_u32 + carry adds instead of a multiply with reduction plus a modular add)
+struct gl_acc {
+    u64 lo, hi;
+    u32 top;
+};
+GL_HD gl_acc gl_acc_zero() {
+    gl_acc s;
+    s.lo = 0;
+    s.hi = 0;
+    s.top = 0;
+    return s;
+}
+GL_HD void gl_acc_mac(gl_acc &s, u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p00 = (u64)a0 * b0;
+    const u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+    const u64 p10 = (u64)a1 * b0 + (u32)p01;
+    const u64 phi = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    const u64 plo = ((u64)(u32)p10 << 32) | (u32)p00;
+    s.lo += plo;
+    const u64 c = s.lo < plo ? 1u : 0u;
+    const u64 h1 = s.hi + phi;
+    u32 c2 = h1 < phi ? 1u : 0u;
+    const u64 h2 = h1 + c;
+    c2 += h2 < c ? 1u : 0u;
+    s.hi = h2;
+    s.top += c2;
+}
+// lo + hi*2^64 + top*2^128 with 2^128 == -2^32  -> canonical
+GL_HD u64 gl_acc_reduce(const gl_acc &s) {
+    const u64 r = gl_reduce96(s.lo, (u32)s.hi, (u32)(s.hi >> 32));
+    return gl_sub(r, (u64)s.top << 32);
+}
+
 GL_HD u64 gl_pow(u64 b, u64 e) {
     u64 r = 1;
     while (e) {

@@ -12,13 +12,16 @@
 namespace {
 
 // ---- p_c(z) for W polynomials with base-field coefficients at an F_{p^3} point --------------------
-// lane t of a block owns 16 consecutive coefficients: sum_j c[16t+j] z^j (z^j wave-uniform), times
-// z^(16t) from a 256-entry table, block-reduced in LDS; one partial per (4096-coefficient chunk, col).
+// a block owns EV_CH = 256*EV_J consecutive coefficients; lane t reads c[256 j + t] (coalesced rows of 2 KiB),
+// accumulates sum_j c[256 j + t] z^(256 j) unreduced (z^(256 j) wave-uniform), multiplies by z^t from a
+// 256-entry table and the block reduces in LDS; one partial per (chunk, column).
+#define EV_J 32
+#define EV_CH (256 * EV_J)
 struct EvalArgs {
     const u64 *coef;
     u64 n;
-    const u64 *zlow;   // z^j, j < 16          [16][3]
-    const u64 *zmid;   // z^(16 t), t < 256     [256][3]
+    const u64 *zlow;   // z^(256 j), j < EV_J   [EV_J][3]
+    const u64 *zmid;   // z^t, t < 256          [256][3]
     u64 *partial;      // [chunks][W][3]
     int W;
 };
@@ -27,17 +30,18 @@ __global__ void __launch_bounds__(256) poly_eval_ext_kernel(EvalArgs a) {
     __shared__ u64 red[3][256];
     const int t = threadIdx.x;
     const u64 chunk = blockIdx.x, col = blockIdx.y;
-    const u64 base = chunk * 4096 + (u64)t * 16;
+    const u64 base = chunk * EV_CH + (u64)t;
     const u64 *c = a.coef + col * a.n;
-    u64 acc0 = 0, acc1 = 0, acc2 = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const u64 v = (base + j < a.n) ? c[base + j] : 0ULL;
-        acc0 = gl_add(acc0, gl_mul(v, a.zlow[j * 3 + 0]));
-        acc1 = gl_add(acc1, gl_mul(v, a.zlow[j * 3 + 1]));
-        acc2 = gl_add(acc2, gl_mul(v, a.zlow[j * 3 + 2]));
+    gl_acc s0 = gl_acc_zero(), s1 = gl_acc_zero(), s2 = gl_acc_zero();   // unreduced: one reduction per EV_J terms
+#pragma unroll 8
+    for (int j = 0; j < EV_J; j++) {
+        const u64 i = base + (u64)j * 256;
+        const u64 v = (i < a.n) ? c[i] : 0ULL;
+        gl_acc_mac(s0, v, a.zlow[j * 3 + 0]);
+        gl_acc_mac(s1, v, a.zlow[j * 3 + 1]);
+        gl_acc_mac(s2, v, a.zlow[j * 3 + 2]);
     }
-    e3 r = e3_mul(e3_make(acc0, acc1, acc2), e3_make(a.zmid[t * 3], a.zmid[t * 3 + 1], a.zmid[t * 3 + 2]));
+    e3 r = e3_mul(e3_make(gl_acc_reduce(s0), gl_acc_reduce(s1), gl_acc_reduce(s2)), e3_make(a.zmid[t * 3], a.zmid[t * 3 + 1], a.zmid[t * 3 + 2]));
     red[0][t] = r.c[0]; red[1][t] = r.c[1]; red[2][t] = r.c[2];
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -68,21 +72,22 @@ __global__ void __launch_bounds__(256) deep_quotient_kernel(DeepArgs a) {
     const u64 M = 1ULL << a.logm;
     const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
     if (r >= M) return;
-    e3 A = e3_make(0, 0, 0), B = e3_make(0, 0, 0);
+    // A = sum g^k p_k(x) as three unreduced 160-bit dot products; the second sum runs over the same columns with
+    // the powers shifted by W, so it is g^W times the prefix of A over the first nnext columns.
+    gl_acc s0 = gl_acc_zero(), s1 = gl_acc_zero(), s2 = gl_acc_zero();
+    e3 A, B = e3_make(0, 0, 0);
     const int W = a.Wa + a.Wb;
     for (int k = 0; k < W; k++) {
+        if (k == a.nnext && k > 0) B = e3_make(gl_acc_reduce(s0), gl_acc_reduce(s1), gl_acc_reduce(s2));
         const u64 v = k < a.Wa ? a.cols_a[(u64)k * M + r] : a.cols_b[(u64)(k - a.Wa) * M + r];
         const u64 *g = a.gpow + k * 3;
-        A.c[0] = gl_add(A.c[0], gl_mul(v, g[0]));
-        A.c[1] = gl_add(A.c[1], gl_mul(v, g[1]));
-        A.c[2] = gl_add(A.c[2], gl_mul(v, g[2]));
-        if (k < a.nnext) {
-            const u64 *h = a.gpow + (W + k) * 3;
-            B.c[0] = gl_add(B.c[0], gl_mul(v, h[0]));
-            B.c[1] = gl_add(B.c[1], gl_mul(v, h[1]));
-            B.c[2] = gl_add(B.c[2], gl_mul(v, h[2]));
-        }
+        gl_acc_mac(s0, v, g[0]);
+        gl_acc_mac(s1, v, g[1]);
+        gl_acc_mac(s2, v, g[2]);
     }
+    A = e3_make(gl_acc_reduce(s0), gl_acc_reduce(s1), gl_acc_reduce(s2));
+    if (a.nnext >= W) B = A;
+    if (a.nnext > 0) B = e3_mul(B, e3_make(a.gpow[W * 3], a.gpow[W * 3 + 1], a.gpow[W * 3 + 2]));
     A = e3_sub(A, e3_make(a.ca[0], a.ca[1], a.ca[2]));
     B = e3_sub(B, e3_make(a.cb[0], a.cb[1], a.cb[2]));
     const u64 x = gl_mul(a.shift, gl_mul(a.twl[r & ((1ULL << a.lb) - 1)], a.twh[r >> a.lb]));
@@ -135,20 +140,20 @@ int32_t zp_poly_eval_ext(zp_ctx *ctx, const uint64_t *d_coef, int32_t logn, int3
     if (W == 0) return ZP_OK;
     ZP_ARG(ctx, z[0] < GL_P && z[1] < GL_P && z[2] < GL_P, "point not canonical");
     const u64 n = 1ULL << logn;
-    const u64 chunks = (n + 4095) / 4096;
-    std::vector<u64> tab((16 + 256) * 3);
+    const u64 chunks = (n + EV_CH - 1) / EV_CH;
+    std::vector<u64> tab((EV_J + 256) * 3);
     e3 zz = to_e3(z), cur = e3_make(1, 0, 0);
-    for (int j = 0; j < 16; j++) { memcpy(&tab[j * 3], cur.c, 24); cur = e3_mul(cur, zz); }
-    e3 z16 = cur;  // z^16
+    for (int t = 0; t < 256; t++) { memcpy(&tab[(EV_J + t) * 3], cur.c, 24); cur = e3_mul(cur, zz); }
+    e3 z256 = cur;  // z^256
     cur = e3_make(1, 0, 0);
-    for (int t = 0; t < 256; t++) { memcpy(&tab[(16 + t) * 3], cur.c, 24); cur = e3_mul(cur, z16); }
-    e3 z4096 = cur;
+    for (int j = 0; j < EV_J; j++) { memcpy(&tab[j * 3], cur.c, 24); cur = e3_mul(cur, z256); }
+    e3 zch = cur;   // z^EV_CH
     u64 *d_tab = nullptr, *d_part = nullptr;
     ZP_TRY(zpi_scratch(ctx, 3, tab.size() + chunks * W * 3, &d_tab));
     d_part = d_tab + tab.size();
     ZP_TRY(zpi_h2d_small(ctx, d_tab, tab.data(), tab.size() * 8));
     EvalArgs a;
-    a.coef = (const u64 *)d_coef; a.n = n; a.zlow = d_tab; a.zmid = d_tab + 48; a.partial = d_part; a.W = W;
+    a.coef = (const u64 *)d_coef; a.n = n; a.zlow = d_tab; a.zmid = d_tab + EV_J * 3; a.partial = d_part; a.W = W;
     hipLaunchKernelGGL(poly_eval_ext_kernel, dim3((unsigned)chunks, (unsigned)W), dim3(256), 0, ctx->stream, a);
     ZP_HIP(ctx, hipGetLastError());
     std::vector<u64> part(chunks * W * 3);
@@ -158,11 +163,11 @@ int32_t zp_poly_eval_ext(zp_ctx *ctx, const uint64_t *d_coef, int32_t logn, int3
         ZP_HIP(ctx, hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    // combine the per-chunk partials on the host: sum_ch partial[ch] * (z^4096)^ch   (tiny: chunks*W terms)
+    // combine the per-chunk partials on the host: sum_ch partial[ch] * (z^EV_CH)^ch   (tiny: chunks*W terms)
     for (int c = 0; c < W; c++) {
         e3 acc = e3_make(0, 0, 0);
         for (u64 ch = chunks; ch-- > 0;) {
-            acc = e3_mul(acc, z4096);
+            acc = e3_mul(acc, zch);
             acc = e3_add(acc, to_e3(&part[(ch * W + c) * 3]));
         }
         memcpy(h_out + c * 3, acc.c, 24);

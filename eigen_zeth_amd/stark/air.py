@@ -243,10 +243,18 @@ def emit_quotient_source(air, target):
     for i in sorted(em.fixed):
         body.append("    const u64 f%d = fixedc[(u64)%d * M + r];" % (i, i))
     body += em.lines
-    body.append("    u64 a0 = 0, a1 = 0, a2 = 0;")
-    for k, o in enumerate(outs):
-        body.append("    a0 = gl_add(a0, gl_mul(%s, apow[%d])); a1 = gl_add(a1, gl_mul(%s, apow[%d])); "
-                    "a2 = gl_add(a2, gl_mul(%s, apow[%d]));" % (o, 3 * k, o, 3 * k + 1, o, 3 * k + 2))
+    if target == "hip":
+        # random linear combination with alpha^k as three unreduced 160-bit dot products (gl_acc), reduced once
+        body.append("    gl_acc s0 = gl_acc_zero(), s1 = gl_acc_zero(), s2 = gl_acc_zero();")
+        for k, o in enumerate(outs):
+            body.append("    gl_acc_mac(s0, %s, apow[%d]); gl_acc_mac(s1, %s, apow[%d]); gl_acc_mac(s2, %s, apow[%d]);"
+                        % (o, 3 * k, o, 3 * k + 1, o, 3 * k + 2))
+        body.append("    const u64 a0 = gl_acc_reduce(s0), a1 = gl_acc_reduce(s1), a2 = gl_acc_reduce(s2);")
+    else:
+        body.append("    u64 a0 = 0, a1 = 0, a2 = 0;")
+        for k, o in enumerate(outs):
+            body.append("    a0 = gl_add(a0, gl_mul(%s, apow[%d])); a1 = gl_add(a1, gl_mul(%s, apow[%d])); "
+                        "a2 = gl_add(a2, gl_mul(%s, apow[%d]));" % (o, 3 * k, o, 3 * k + 1, o, 3 * k + 2))
     body.append("    const u64 zi = zhinv[r & (b - 1)];")
     body.append("    out[r] = gl_mul(a0, zi); out[M + r] = gl_mul(a1, zi); out[2 * M + r] = gl_mul(a2, zi);")
     body = "\n".join(body)
