@@ -218,6 +218,17 @@ int32_t zp_intt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn
 }
 
 // ---- N2
+int32_t zp_twiddle_rows(zp_ctx *ctx, uint64_t *d_rows, int32_t logn_row, int32_t W, uint64_t row0, int32_t logn_total,
+                        int32_t inverse) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "twiddle_rows");
+    ZP_ARG(ctx, logn_row >= 0 && logn_total >= logn_row && logn_total <= 32 && W >= 0, "sizes out of range");
+    ZP_ARG(ctx, d_rows != nullptr || W == 0, "null pointer");
+    ZP_ARG(ctx, row0 + (uint64_t)W <= (1ULL << (logn_total - logn_row)), "rows beyond N / 2^logn_row");
+    if (W == 0) return ZP_OK;
+    return zpi_twiddle_rows(ctx, (u64 *)d_rows, logn_row, W, row0, logn_total, inverse != 0);
+}
+
 int32_t zp_lde(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t *d_coef, int32_t logn,
                int32_t logb, int32_t W, uint64_t shift) {
     if (!ctx) return ZP_ERR_ARG;

@@ -126,6 +126,7 @@ struct NttRunOpts {
     const CosetTable *post_scale = nullptr;  // multiply output i by table(i) (last pass)
     int in_valid_log = -1;                   // >=0: input columns have 2^in_valid_log elements, rest is zero
 };
+int32_t zpi_twiddle_rows(zp_ctx *ctx, u64 *d_rows, int logn_row, int W, u64 row0, int logn_total, bool inverse);
 int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn, int logb, int W, u64 shift);
 int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, bool inverse,
                     const NttRunOpts &opts);

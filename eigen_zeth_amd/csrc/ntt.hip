@@ -374,6 +374,17 @@ __global__ void __launch_bounds__(256) coset_scale_kernel(const u64 *in, u64 *ou
     if (i < n) out[col * n + i] = gl_mul(in[col * n + i], tw_lookup(lo, hi, lb, i));
 }
 
+// four-step NTT of one column split over GPUs: between the two local transforms every element of the
+// N2/G x N1 block is multiplied by w_N^(i2 * k1):  rows[r][k] *= w_N^((row0 + r) * k)
+__global__ void __launch_bounds__(256) twiddle_rows_kernel(u64 *rows, int logn_row, u64 total, u64 row0, u64 nmask,
+                                                           const u64 *lo, const u64 *hi, int lb) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const u64 r = i >> logn_row, k = i & ((1ULL << logn_row) - 1);
+    const u64 e = ((row0 + r) * k) & nmask;
+    rows[i] = gl_mul(rows[i], tw_lookup(lo, hi, lb, e));
+}
+
 template <int A1, int A2, int A3, int LOGT>
 int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
     using G = Geo<A1, A2, A3, LOGT>;
@@ -728,5 +739,16 @@ int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn,
         fwd.in_valid_log = logn;  // zero padding is implicit: rows >= N read as 0
         ZP_TRY(zpi_ntt_run(ctx, scaled, out, logn + logb, w, false, fwd));
     }
+    return ZP_OK;
+}
+
+int32_t zpi_twiddle_rows(zp_ctx *ctx, u64 *d_rows, int logn_row, int W, u64 row0, int logn_total, bool inverse) {
+    NttPlan *pl;
+    ZP_TRY(zpi_get_plan(ctx, logn_total, inverse, &pl));
+    const u64 total = (u64)W << logn_row;
+    const u64 nmask = logn_total >= 64 ? ~0ULL : ((1ULL << logn_total) - 1);
+    hipLaunchKernelGGL(twiddle_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_rows, logn_row,
+                       total, row0, nmask, pl->d_twl, pl->d_twh, pl->lb);
+    ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
 }

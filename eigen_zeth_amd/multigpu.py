@@ -54,3 +54,63 @@ def distributed_commit(local_ext, commit_rows_fn, hash_pair, group=None):
     dist.all_gather(allr, t, group=group)
     subroots = [[int(v) & 0xFFFFFFFFFFFFFFFF for v in r.tolist()] for r in allr]
     return tree_top(subroots, hash_pair), {"sent_bytes": sent, "rows_shape": tuple(rows.shape)}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# One column split over GPUs ("single huge column"): four-step NTT.  N = N1*N2, input index
+# i = i1*N2 + i2, output index k = k1 + N1*k2:
+#     X[k1 + N1 k2] = sum_i2 w_N2^(i2 k2) * w_N^(i2 k1) * ( sum_i1 x[i1 N2 + i2] w_N1^(i1 k1) )
+# Rank g holds the contiguous block i in [g N/G, (g+1) N/G) = rows i1 of the N1 x N2 matrix.  Steps: transpose
+# (all-to-all) -> N1-point transforms on the local N2/G rows -> twiddle w_N^(i2 k1) -> transpose (all-to-all) ->
+# N2-point transforms on the local N1/G rows -> (optionally) a third transpose back to natural order.
+# Every transpose is one all_to_all_single with the same message shape as the column->row exchange above.
+
+def distributed_transpose(local, group=None):
+    """local [R/G][C] (this rank's rows of an R x C matrix) -> [C/G][R] (this rank's rows of the transpose)"""
+    G = dist.get_world_size(group) if dist.is_initialized() else 1
+    Rl, C = local.shape
+    if G == 1:
+        return local.t().contiguous()
+    send = local.view(Rl, G, C // G).permute(1, 0, 2).contiguous()        # block h = my rows, rank h's columns
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)                         # recv[h] = rank h's rows, my columns
+    return recv.permute(2, 0, 1).reshape(C // G, G * Rl).contiguous()       # [my column][global row h*Rl + r]
+
+
+def four_step_ntt(local, logn, ntt_rows, twiddle_rows, group=None, inverse=False, natural_output=True):
+    """local: int64/uint64 tensor of N/G elements, this rank's contiguous block of the column (N = 2^logn).
+    ntt_rows(mat [W][n], inverse) -> transformed rows (natural order in/out, as zp_ntt / zp_intt);
+    twiddle_rows(mat [W][n], row0, logn_total, inverse) -> mat[r][k] * w_N^((row0+r) k)   (zp_twiddle_rows).
+    Returns this rank's contiguous block of the transform if natural_output, else the N1/G rows k1 of
+    Y[k1][k2] = X[k1 + N1 k2]."""
+    G = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    l1 = logn // 2
+    l2 = logn - l1
+    N1, N2 = 1 << l1, 1 << l2
+    assert N1 % G == 0 and N2 % G == 0 and local.numel() == (N1 // G) * N2
+    a = distributed_transpose(local.view(N1 // G, N2), group)                # [N2/G][N1]: row i2, entries over i1
+    b = ntt_rows(a, inverse)                                                 # over i1 -> k1
+    b = twiddle_rows(b, rank * (N2 // G), logn, inverse)                     # * w_N^(i2 k1)
+    c = distributed_transpose(b, group)                                      # [N1/G][N2]: row k1, entries over i2
+    d = ntt_rows(c, inverse)                                                 # over i2 -> k2 : Y[k1][k2]
+    if not natural_output:
+        return d
+    return distributed_transpose(d, group).reshape(-1)                       # [N2/G][N1]: k = k1 + N1 k2, my k2 rows
+
+
+def hip_row_ops(prover):
+    """(ntt_rows, twiddle_rows) for four_step_ntt on torch CUDA tensors through the C-ABI (zp_ntt / zp_intt /
+    zp_twiddle_rows).  The prover's ctx must run on torch's current stream (Prover(dev, stream=...))."""
+    def ntt_rows(mat, inverse):
+        W, n = mat.shape
+        out = torch.empty_like(mat)
+        (prover.intt if inverse else prover.ntt)(mat, out, n.bit_length() - 1, W)
+        return out
+
+    def twiddle_rows(mat, row0, logn_total, inverse):
+        W, n = mat.shape
+        prover.twiddle_rows(mat, n.bit_length() - 1, W, row0, logn_total, inverse)
+        return mat
+
+    return ntt_rows, twiddle_rows

@@ -52,6 +52,7 @@ SIGNATURES = {
     "zp_d2d": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
     "zp_ntt": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32]),
     "zp_intt": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32]),
+    "zp_twiddle_rows": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32]),
     "zp_lde": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_poseidon_perm": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "zp_merkle_commit": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp]),
@@ -279,6 +280,9 @@ class Prover:
 
     def intt(self, d_in, d_out, logn, W):
         self._chk(self.lib.zp_intt(self.ctx, _ptr(d_in), _ptr(d_out), logn, W))
+
+    def twiddle_rows(self, d_rows, logn_row, W, row0, logn_total, inverse=False):
+        self._chk(self.lib.zp_twiddle_rows(self.ctx, _ptr(d_rows), logn_row, W, row0, logn_total, 1 if inverse else 0))
 
     def lde(self, d_in, d_out, logn, logb, W, shift=0, d_coef=None):
         self._chk(self.lib.zp_lde(self.ctx, _ptr(d_in), _ptr(d_out), _ptr(d_coef), logn, logb, W, shift))

@@ -78,6 +78,14 @@ int32_t zp_d2d(zp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 int32_t zp_ntt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t W);
 int32_t zp_intt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t W);
 
+/* four-step NTT of ONE column of 2^logn_total elements that is split over GPUs ("single huge
+ * column"): between the two local transforms the N2/G x N1 block a GPU holds is multiplied by w_N^(i2*k1):
+ *   d_rows[r][k] *= w_N^((row0 + r) * k),  r < W rows of 2^logn_row elements, N = 2^logn_total
+ * (inverse != 0: the inverse root).  The transforms themselves are zp_ntt / zp_intt on the rows; the exchange
+ * is the host's (eigen_zeth_amd/multigpu.py: one all-to-all per transpose).                               */
+int32_t zp_twiddle_rows(zp_ctx *ctx, uint64_t *d_rows, int32_t logn_row, int32_t W, uint64_t row0, int32_t logn_total,
+                        int32_t inverse);
+
 /* ---- N2: low-degree extension ----------------------------------------------------------------
  * d_in u64[W][2^logn] evaluations on <w_N>; d_out u64[W][2^(logn+logb)] evaluations on
  * shift*<w_bN>, natural order.  If d_coef != NULL it receives the interpolant's coefficients

@@ -3,6 +3,7 @@ restatement (oracle/) on the same seeded inputs, vs the committed golden vectors
 BASELINE.json sizes -- through size-independent properties (round trip, linearity, restriction).
 Bar: bit-exact (integer arithmetic).  Parity with the external reference prover is unpinned
 (SURVEY.md 8c)."""
+import os
 import numpy as np
 import pytest
 
@@ -376,3 +377,32 @@ def test_page_locked_host_arrays_round_trip_and_are_pooled(prover):
 def native_mod():
     from eigen_zeth_amd import native
     return native
+
+
+def test_twiddle_rows_matches_definition(prover):
+    from eigen_zeth_amd.stark import field as F
+    logn_row, W, row0, logn_total = 5, 4, 9, 9
+    x = O.random_field((W, 1 << logn_row), 31337)
+    for inverse in (False, True):
+        d = prover.upload(x)
+        prover.twiddle_rows(d, logn_row, W, row0, logn_total, inverse)
+        got = prover.download(d, x.shape)
+        w = F.root(logn_total, O.ROOT32_DEFAULT)
+        if inverse:
+            w = F.inv(w)
+        for r in range(W):
+            for k in range(1 << logn_row):
+                assert int(got[r, k]) == int(x[r, k]) * pow(w, (row0 + r) * k, O.P) % O.P
+    import pytest as _pt
+    from eigen_zeth_amd.native import ZpError
+    with _pt.raises(ZpError):
+        prover.twiddle_rows(prover.upload(x), logn_row, W, 14, logn_total)   # rows beyond N / 2^logn_row
+
+
+def test_four_step_ntt_on_one_gpu_matches_plain_transform():
+    """the multi-GPU path of one split column with G = 1, in a child process (torch first)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "four_step_check.py"), "12", "17", "22"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout + r.stderr

@@ -71,3 +71,53 @@ def test_pack_layout():
     x = torch.arange(2 * 8, dtype=torch.int64).view(2, 8)
     p = multigpu.pack_for_exchange(x, 4)
     assert p.shape == (4, 2, 2) and p[1].tolist() == [[2, 3], [10, 11]]
+
+
+def _fs_worker(rank, world, port, logn, inverse, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from eigen_zeth_amd import multigpu
+    from oracle import oracle as O
+    N = 1 << logn
+    full = O.random_field((1, N), 777 + logn)
+    local = torch.from_numpy(full[0, rank * (N // world):(rank + 1) * (N // world)].view(np.int64).copy())
+
+    def ntt_rows(mat, inv):
+        a = np.ascontiguousarray(mat.numpy().view(np.uint64))
+        return torch.from_numpy((O.intt(a) if inv else O.ntt(a)).view(np.int64))
+
+    def twiddle_rows(mat, row0, logn_total, inv):
+        a = np.ascontiguousarray(mat.numpy().view(np.uint64))
+        w = O.lib().orc_root(O.ROOT32_DEFAULT, logn_total)
+        if inv:
+            w = pow(w, O.P - 2, O.P)
+        out = np.empty_like(a)
+        for r in range(a.shape[0]):
+            for k in range(a.shape[1]):
+                out[r, k] = int(a[r, k]) * pow(w, (row0 + r) * k, O.P) % O.P
+        return torch.from_numpy(out.view(np.int64))
+
+    got = multigpu.four_step_ntt(local, logn, ntt_rows, twiddle_rows, inverse=inverse)
+    ref = (O.intt(full) if inverse else O.ntt(full))[0, rank * (N // world):(rank + 1) * (N // world)]
+    ok = bool((got.numpy().view(np.uint64) == ref).all())
+    t = torch.tensor([1 if ok else 0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out_q.put(int(t.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,logn,inverse", [(2, 8, False), (2, 9, False), (2, 8, True)])
+def test_four_step_ntt_of_one_split_column_equals_the_plain_transform(world, logn, inverse):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fs_worker, args=(r, world, port, logn, inverse, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) == 1
