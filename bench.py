@@ -273,6 +273,22 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
                "merkle_ms": e[2].elapsed_time(e[3]), "root": [hex(v) for v in root]}
         if world > 1:
             res["all_to_all_GBs_sent_per_gpu"] = sent / (res["all_to_all_ms"] * 1e-3) / 1e9
+    # one column of 2^28 elements split over the ranks (SURVEY 8e alternative): four-step NTT, three transposes
+    try:
+        flog = 28
+        ops = multigpu.hip_row_ops(prover)
+        blk = random_field_tensor(torch, ((1 << flog) // world,), dev, 7 + (dist.get_rank() if world > 1 else 0))
+        for it in range(2):
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record()
+            multigpu.four_step_ntt(blk, flog, *ops)
+            f1.record()
+            torch.cuda.synchronize()
+        res["four_step_single_column"] = {"logn": flog, "ms": f0.elapsed_time(f1),
+                                          "elems_per_s": (1 << flog) / (f0.elapsed_time(f1) * 1e-3)}
+        del blk
+    except Exception as ex:
+        res["four_step_single_column"] = {"error": repr(ex)}
     perms = ((Wtot + 7) // 8) * Mloc + (Mloc - 1)
     res["lde_GBs_algorithmic"] = 8.0 * N * 3 * cols / (res["lde_ms"] * 1e-3) / 1e9
     res["poseidon_perms_per_s_per_gpu"] = perms / (res["merkle_ms"] * 1e-3)
