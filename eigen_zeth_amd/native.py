@@ -182,6 +182,7 @@ class Prover:
         self.pooling = False      # device-buffer reuse by exact size (set True for repeated same-shape work)
         self._pool = {}
         self._hpool = {}          # page-locked host buffers by byte size
+        self._host_ptrs = {}      # numpy data address -> (pointer, bytes) of the arrays handed out by host_array
         self._lock = threading.Lock()
         if stream is not None:
             self.set_stream(stream)
@@ -250,7 +251,6 @@ class Prover:
             self._chk(self.lib.zp_host_alloc(self.ctx, nbytes, C.byref(p)))
             ptr = p.value
         arr = np.ctypeslib.as_array((C.c_uint64 * (nbytes // 8)).from_address(ptr)).reshape(shape)
-        self._host_ptrs = getattr(self, "_host_ptrs", {})
         self._host_ptrs[arr.ctypes.data] = (ptr, nbytes)
         return arr
 

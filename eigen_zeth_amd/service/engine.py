@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import hashlib
 import json
+import queue
+import threading
 import os
 import struct
 import time
@@ -28,13 +30,14 @@ from . import groth16
 class EngineConfig:
     def __init__(self, air="chunk64", logn=12, logb=1, chunks_per_block=1, n_queries=16, fri_logf=3, fri_final_log=5,
                  groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
-                 witness_threads=8):
+                 witness_threads=8, prover_streams=3):
         self.air, self.logn, self.logb = air, logn, logb
         self.chunks_per_block, self.n_queries = chunks_per_block, n_queries
         self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
         self.groth16_logm, self.crs_dir = groth16_logm, crs_dir
         self.l2_addr, self.txs_per_chunk = l2_addr, txs_per_chunk   # optional block-input fetcher
         self.witness_threads = witness_threads
+        self.prover_streams = prover_streams   # chunk proofs in flight on one GPU (each on its own ctx / stream)
 
 
 class Engine:
@@ -45,12 +48,20 @@ class Engine:
         self.stage_timings = {}
         self.metrics = None   # service/metrics.py Metrics, attached by serve()
         self._g16 = None
+        self._extra_be, self._be_lock = [], threading.Lock()
 
     @property
     def be(self):
         if self._be is None:
             self._be = self._factory()   # HipBackend(): raises without libzethprover.so / a GPU
         return self._be
+
+    def _backends(self, n):
+        """the first n proving backends (one ctx / stream each); backend 0 is self.be"""
+        with self._be_lock:
+            while len(self._extra_be) < n - 1:
+                self._extra_be.append(self._factory())
+            return [self.be] + self._extra_be[:n - 1]
 
     # ---- helpers
     def _state_root(self, chain_id, block):
@@ -107,26 +118,45 @@ class Engine:
                 trace = self.be.prefetch_trace(trace)
             return air, trace, pubs, tw
 
-        out = []
-        with ThreadPoolExecutor(max_workers=max(1, min(self.cfg.witness_threads, len(chunks)))) as pool:
-            pending = [pool.submit(witness, ch) for ch in chunks[:self.cfg.witness_threads + 2]]
-            nxt = len(pending)
-            for i, ch in enumerate(chunks):
-                air, trace, pubs, tw = pending[i].result()
-                pending[i] = None   # drop the reference: traces are large
-                if nxt < len(chunks):
-                    pending.append(pool.submit(witness, chunks[nxt]))
-                    nxt += 1
+        # proving runs on `prover_streams` backends (ctxs with their own streams) in as many threads: the latency-bound
+        # tail of one proof (FRI layers, queries, transcript) overlaps the Poseidon-bound head of the next
+        n_streams = max(1, min(self.cfg.prover_streams, len(chunks)))
+        backends = self._backends(n_streams)
+        free_be = queue.SimpleQueue()
+        for b in backends:
+            free_be.put(b)
+        ahead = threading.Semaphore(self.cfg.witness_threads + 2)   # witnesses generated but not yet proven (memory bound)
+
+        def witness_bounded(ch):
+            ahead.acquire()
+            try:
+                return witness(ch)
+            except BaseException:
+                ahead.release()
+                raise
+
+        def prove_chunk(i, ch, wfut):
+            air, trace, pubs, tw = wfut.result()
+            be = free_be.get()
+            try:
                 tm = {"witness(host)": tw}
                 params = PR.StarkParams(ch["logn"], self.cfg.logb, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.n_queries)
-                proof = PR.prove(air, trace, pubs, params, self.be, timings=tm)
-                del trace
-                proof["chunk"] = {"block": ch["block"], "chunk": ch["chunk"]}
-                self.stage_timings["%s/%d" % (task_id, i)] = tm
-                if self.metrics is not None:
-                    self.metrics.record_proof(tm, ch["logn"], self.cfg.logb, air.width)
-                out.append({"chunk_id": i, "proof_key": "chunk-%s-%d" % (task_id, i), "proof": PR.proof_to_json(proof)})
-        return out
+                proof = PR.prove(air, trace, pubs, params, be, timings=tm)
+            finally:
+                free_be.put(be)
+                ahead.release()
+            del trace
+            proof["chunk"] = {"block": ch["block"], "chunk": ch["chunk"]}
+            self.stage_timings["%s/%d" % (task_id, i)] = tm
+            if self.metrics is not None:
+                self.metrics.record_proof(tm, ch["logn"], self.cfg.logb, air.width)
+            return {"chunk_id": i, "proof_key": "chunk-%s-%d" % (task_id, i), "proof": PR.proof_to_json(proof)}
+
+        with ThreadPoolExecutor(max_workers=max(1, min(self.cfg.witness_threads, len(chunks)))) as wpool, \
+                ThreadPoolExecutor(max_workers=n_streams) as ppool:
+            wfuts = [wpool.submit(witness_bounded, ch) for ch in chunks]
+            pfuts = [ppool.submit(prove_chunk, i, ch, wfuts[i]) for i, ch in enumerate(chunks)]
+            return [f.result() for f in pfuts]
 
     # ---- GenAggregatedProof
     @staticmethod
