@@ -8,8 +8,8 @@
 //   3. reduction  : running sums over segments of 64 buckets, segment weights by double-and-add,
 //                   tree sum per window in LDS
 //   4. the <= 32 window results are combined on the host (254 doublings).
-// Field: F_q in Montgomery form, 8 x 32-bit limbs, CIOS with v_mad_u64_u32.  This first version is
-// VALU only; the MFMA limb-product formulation north_star mentions is not built.
+// Field: F_q in Montgomery form, 9 x 29-bit limbs, product scanning with v_mad_u64_u32 (see below).  VALU only;
+// the MFMA limb-product formulation north_star mentions is not built.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -19,133 +19,151 @@
 
 namespace {
 
+// ---- F_q in Montgomery form with R = 2^261: NINE 29-BIT LIMBS.
+// v_mad_u64_u32 has a carry-out but no carry-in, so a 32-bit-limb multiplier spends two thirds of its instructions
+// moving carries around (the first version compiled to ~790 instructions per product, 47 % of them v_mov).  With
+// 29-bit limbs a 64-bit column accumulator takes all 18 products of a column (18 * 2^58 < 2^63) without any carry
+// handling: one v_mad_u64_u32 per product, one shift per column -- 162 mads + ~110 other instructions.
+// Values are always fully reduced (< q) and normalised (limbs < 2^29) between operations, so equality and the
+// infinity tests are plain limb comparisons.
+#define FQ_B 29
+#define FQ_MASK 0x1FFFFFFFu
+#define FQ_INV29 0x04866389u   // -q^-1 mod 2^29
 struct fq {
-    u32 l[8];
+    u32 l[9];
 };
 #define FQ_HD __host__ __device__ __forceinline__
 
-__device__ __constant__ const u32 FQ_Q_D[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
-                                               0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+#define FQ_Q0 0x187cfd47u
+#define FQ_Q1 0x010460b6u
+#define FQ_Q2 0x1c72a34fu
+#define FQ_Q3 0x02d522d0u
+#define FQ_Q4 0x1585d978u
+#define FQ_Q5 0x02db40c0u
+#define FQ_Q6 0x00a6e141u
+#define FQ_Q7 0x0e5c2634u
+#define FQ_Q8 0x0030644eu
+// q as 8 x 32-bit words (exponent bits of the host inversion)
 static const u32 FQ_Q_H[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
                               0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-#define FQ_INV32 0xe4866389u
 
-FQ_HD const u32 *fq_q() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return FQ_Q_D;
-#else
-    return FQ_Q_H;
-#endif
+FQ_HD u32 fq_q(int i) {
+    switch (i) {
+        case 0: return FQ_Q0;
+        case 1: return FQ_Q1;
+        case 2: return FQ_Q2;
+        case 3: return FQ_Q3;
+        case 4: return FQ_Q4;
+        case 5: return FQ_Q5;
+        case 6: return FQ_Q6;
+        case 7: return FQ_Q7;
+        default: return FQ_Q8;
+    }
 }
 FQ_HD fq fq_zero() {
     fq r;
-    for (int i = 0; i < 8; i++) r.l[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = 0;
     return r;
 }
 FQ_HD fq fq_one() {  // R mod q
-    const u32 v[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    const u32 v[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
     fq r;
-    for (int i = 0; i < 8; i++) r.l[i] = v[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = v[i];
     return r;
 }
 FQ_HD fq fq_r2() {  // R^2 mod q
-    const u32 v[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    const u32 v[9] = {0x059bac10u, 0x0d1503a3u, 0x018016b8u, 0x10ab0ca8u, 0x02632639u, 0x02c0169fu, 0x169bfd53u, 0x11869d4cu, 0x002a11a6u};
     fq r;
-    for (int i = 0; i < 8; i++) r.l[i] = v[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = v[i];
     return r;
 }
 FQ_HD bool fq_is_zero(const fq &a) {
     u32 o = 0;
-    for (int i = 0; i < 8; i++) o |= a.l[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.l[i];
     return o == 0;
 }
 FQ_HD bool fq_eq(const fq &a, const fq &b) {
     u32 o = 0;
-    for (int i = 0; i < 8; i++) o |= a.l[i] ^ b.l[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.l[i] ^ b.l[i];
     return o == 0;
 }
-// r = t - q if (extra || t >= q) else t   -- branch-free (a divergent early-exit compare in every field
-// operation serialises the wave)
-FQ_HD fq fq_cond_sub(const u32 *t, u32 extra) {
-    const u32 *q = fq_q();
-    u32 d[8];
-    u64 br = 0;
+// t: limbs possibly unnormalised (each < 2^31), value < 2q  ->  normalised value mod q.  Branch-free: both
+// the carry-propagated t and t - q are formed, the sign of the last borrow selects.
+FQ_HD fq fq_norm_sub(const u32 *t) {
+    u32 n[9], d[9];
+    int cn = 0, cd = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const u64 x = (u64)t[i] - q[i] - br;
-        d[i] = (u32)x;
-        br = (x >> 32) & 1;
+    for (int i = 0; i < 9; i++) {
+        const int vn = (int)t[i] + cn;
+        n[i] = (u32)vn & FQ_MASK;
+        cn = vn >> FQ_B;
+        const int vd = (int)t[i] - (int)fq_q(i) + cd;
+        d[i] = (u32)vd & FQ_MASK;
+        cd = vd >> FQ_B;   // arithmetic shift: -1 on borrow
     }
-    const u32 use_d = 0u - (u32)((extra != 0) | (br == 0));   // all ones: take t - q
+    const u32 use_d = cd < 0 ? 0u : 0xFFFFFFFFu;   // no final borrow: t >= q
     fq r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = (d[i] & use_d) | (t[i] & ~use_d);
+    for (int i = 0; i < 9; i++) r.l[i] = (d[i] & use_d) | (n[i] & ~use_d);
     return r;
 }
 FQ_HD fq fq_add(const fq &a, const fq &b) {
-    u32 t[8];
-    u64 c = 0;
+    u32 t[9];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (u64)a.l[i] + b.l[i];
-        t[i] = (u32)c;
-        c >>= 32;
-    }
-    return fq_cond_sub(t, (u32)c);
+    for (int i = 0; i < 9; i++) t[i] = a.l[i] + b.l[i];
+    return fq_norm_sub(t);
 }
 FQ_HD fq fq_sub(const fq &a, const fq &b) {
-    const u32 *q = fq_q();
-    u32 t[8];
-    u64 br = 0;
+    // a - b, plus q when negative: both chains, select by the final borrow of a - b
+    u32 d[9], e[9];
+    int cd = 0, ce = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const u64 d = (u64)a.l[i] - b.l[i] - br;
-        t[i] = (u32)d;
-        br = (d >> 32) & 1;
+    for (int i = 0; i < 9; i++) {
+        const int vd = (int)a.l[i] - (int)b.l[i] + cd;
+        d[i] = (u32)vd & FQ_MASK;
+        cd = vd >> FQ_B;
+        const int ve = (int)a.l[i] - (int)b.l[i] + (int)fq_q(i) + ce;
+        e[i] = (u32)ve & FQ_MASK;
+        ce = ve >> FQ_B;
     }
-    const u32 m = 0u - (u32)br;   // borrowed: add q back
+    const u32 use_e = cd < 0 ? 0xFFFFFFFFu : 0u;
     fq r;
-    u64 c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (u64)t[i] + (q[i] & m);
-        r.l[i] = (u32)c;
-        c >>= 32;
-    }
+    for (int i = 0; i < 9; i++) r.l[i] = (e[i] & use_e) | (d[i] & ~use_e);
     return r;
 }
 FQ_HD fq fq_dbl(const fq &a) { return fq_add(a, a); }
-// Montgomery product a*b/R mod q (CIOS, 32-bit limbs)
+// Montgomery product a*b/R mod q, R = 2^261: product scanning, one 64-bit accumulator per column
 FQ_HD fq fq_mul(const fq &a, const fq &b) {
-    const u32 *q = fq_q();
-    u32 t[10];
-    for (int i = 0; i < 10; i++) t[i] = 0;
+    u32 m[9], t[9];
+    u64 acc = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 carry = 0;
+    for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            u64 p = (u64)a.l[j] * b.l[i] + t[j] + carry;
-            t[j] = (u32)p;
-            carry = p >> 32;
-        }
-        u64 s = (u64)t[8] + carry;
-        t[8] = (u32)s;
-        t[9] = (u32)(s >> 32);
-        const u32 m = t[0] * FQ_INV32;
-        u64 p = (u64)m * q[0] + t[0];
-        carry = p >> 32;
+        for (int i = 0; i <= k; i++) acc += (u64)a.l[i] * b.l[k - i];
 #pragma unroll
-        for (int j = 1; j < 8; j++) {
-            p = (u64)m * q[j] + t[j] + carry;
-            t[j - 1] = (u32)p;
-            carry = p >> 32;
-        }
-        s = (u64)t[8] + carry;
-        t[7] = (u32)s;
-        t[8] = t[9] + (u32)(s >> 32);
+        for (int i = 0; i < k; i++) acc += (u64)m[i] * fq_q(k - i);
+        m[k] = ((u32)acc * FQ_INV29) & FQ_MASK;
+        acc += (u64)m[k] * FQ_Q0;
+        acc >>= FQ_B;
     }
-    return fq_cond_sub(t, t[8]);
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) {
+            acc += (u64)a.l[i] * b.l[k - i];
+            acc += (u64)m[i] * fq_q(k - i);
+        }
+        t[k - 9] = (u32)acc & FQ_MASK;
+        acc >>= FQ_B;
+    }
+    t[8] = (u32)acc;
+    return fq_norm_sub(t);   // (ab + mq)/R < q (q/R + 1) < 2q
 }
 FQ_HD fq fq_sqr(const fq &a) { return fq_mul(a, a); }
 FQ_HD fq fq_to_mont(const fq &a) { return fq_mul(a, fq_r2()); }
@@ -153,6 +171,31 @@ FQ_HD fq fq_from_mont(const fq &a) {
     fq one = fq_zero();
     one.l[0] = 1;
     return fq_mul(a, one);
+}
+// 8 x 32-bit words (little endian, value < 2^256... here always < q) <-> 9 x 29-bit limbs
+FQ_HD fq fq_from_words(const u32 *w) {
+    fq r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = FQ_B * i, k = bit >> 5, off = bit & 31;
+        u64 v = w[k];
+        if (k + 1 < 8) v |= (u64)w[k + 1] << 32;
+        r.l[i] = (u32)(v >> off) & FQ_MASK;
+    }
+    return r;
+}
+FQ_HD void fq_to_words(const fq &a, u32 *w) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        // word k holds bits [32k, 32k+32): limbs i with 29i < 32k+32 and 29i+29 > 32k
+        u64 v = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int lo = FQ_B * i - 32 * k;   // position of limb i relative to word k
+            if (lo > -FQ_B && lo < 32) v |= lo >= 0 ? ((u64)a.l[i] << lo) : ((u64)a.l[i] >> (-lo));
+        }
+        w[k] = (u32)v;
+    }
 }
 
 struct jac {
@@ -305,15 +348,16 @@ __global__ void __launch_bounds__(256) msm_to_mont_kernel(const uint4 *points, u
     uint4 q[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) q[k] = points[i * 4 + k];
-    fq x, y;
-    x.l[0] = q[0].x; x.l[1] = q[0].y; x.l[2] = q[0].z; x.l[3] = q[0].w; x.l[4] = q[1].x; x.l[5] = q[1].y; x.l[6] = q[1].z; x.l[7] = q[1].w;
-    y.l[0] = q[2].x; y.l[1] = q[2].y; y.l[2] = q[2].z; y.l[3] = q[2].w; y.l[4] = q[3].x; y.l[5] = q[3].y; y.l[6] = q[3].z; y.l[7] = q[3].w;
-    x = fq_to_mont(x);   // (0,0) stays (0,0): still the infinity marker
-    y = fq_to_mont(y);
-    mont[i * 4 + 0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
-    mont[i * 4 + 1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
-    mont[i * 4 + 2] = make_uint4(y.l[0], y.l[1], y.l[2], y.l[3]);
-    mont[i * 4 + 3] = make_uint4(y.l[4], y.l[5], y.l[6], y.l[7]);
+    const u32 wx[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
+    const u32 wy[8] = {q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
+    // (0,0) stays (0,0): still the infinity marker.  Stored packed (8 words per coordinate, Montgomery form, < q).
+    u32 ox[8], oy[8];
+    fq_to_words(fq_to_mont(fq_from_words(wx)), ox);
+    fq_to_words(fq_to_mont(fq_from_words(wy)), oy);
+    mont[i * 4 + 0] = make_uint4(ox[0], ox[1], ox[2], ox[3]);
+    mont[i * 4 + 1] = make_uint4(ox[4], ox[5], ox[6], ox[7]);
+    mont[i * 4 + 2] = make_uint4(oy[0], oy[1], oy[2], oy[3]);
+    mont[i * 4 + 3] = make_uint4(oy[4], oy[5], oy[6], oy[7]);
 }
 // ---- 2b. bucket sums: lane = (window, bucket); the next point is fetched while the current one is added
 __global__ void __launch_bounds__(256) msm_bucket_kernel(const uint4 *mont, u64 n, int c, int nwin, const u32 *starts,
@@ -339,9 +383,9 @@ __global__ void __launch_bounds__(256) msm_bucket_kernel(const uint4 *mont, u64 
 #pragma unroll
             for (int j = 0; j < 4; j++) nx[j] = mont[pn * 4 + j];
         }
-        fq x, y;
-        x.l[0] = q[0].x; x.l[1] = q[0].y; x.l[2] = q[0].z; x.l[3] = q[0].w; x.l[4] = q[1].x; x.l[5] = q[1].y; x.l[6] = q[1].z; x.l[7] = q[1].w;
-        y.l[0] = q[2].x; y.l[1] = q[2].y; y.l[2] = q[2].z; y.l[3] = q[2].w; y.l[4] = q[3].x; y.l[5] = q[3].y; y.l[6] = q[3].z; y.l[7] = q[3].w;
+        const u32 wx[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
+        const u32 wy[8] = {q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
+        const fq x = fq_from_words(wx), y = fq_from_words(wy);
         if (fq_is_zero(x) && fq_is_zero(y)) continue;  // (0,0) encodes the point at infinity
         acc = jac_madd(acc, x, y);
     }
@@ -405,6 +449,7 @@ extern "C" int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uin
     ZP_ARG(ctx, d_points && d_scalars, "null device pointer");
     int c = 4;
     while (c < 16 && (1ULL << (c + 2)) <= n) c++;   // ~4 points per bucket up to c = 16
+    while (c < 20 && (1ULL << (c + 7)) <= n) c++;   // wider windows only while buckets keep >= 64 points (2^26 -> c = 19..20)
     if (c < 6) c = 6;                                // segments of 64 buckets need c >= 6
     const int nwin = (254 + c - 1) / c;
     const u64 nb = (u64)nwin << c;
@@ -453,7 +498,7 @@ extern "C" int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uin
     fq zi2 = fq_sqr(zi);
     fq x = fq_from_mont(fq_mul(acc.X, zi2));
     fq y = fq_from_mont(fq_mul(acc.Y, fq_mul(zi2, zi)));
-    memcpy(h_out, x.l, 32);
-    memcpy(h_out + 8, y.l, 32);
+    fq_to_words(x, h_out);
+    fq_to_words(y, h_out + 8);
     return ZP_OK;
 }
