@@ -359,7 +359,17 @@ __global__ void __launch_bounds__(256) msm_to_mont_kernel(const uint4 *points, u
     mont[i * 4 + 2] = make_uint4(oy[0], oy[1], oy[2], oy[3]);
     mont[i * 4 + 3] = make_uint4(oy[4], oy[5], oy[6], oy[7]);
 }
-// ---- 2b. bucket sums: lane = (window, bucket); the next point is fetched while the current one is added
+// ---- 2b. bucket sums: lane = (window, bucket).  Software pipeline, two points per trip: while point k is added,
+// point k+1 and the index of point k+2 are in flight.  All loads are unconditional (indices clamped to the bucket's
+// last point) so that no loop-carried register needs a copy under an exec mask -- with a conditional prefetch the
+// compiler parked a v_mov (and therefore an s_waitcnt) right behind every load and nothing was overlapped.
+__device__ __forceinline__ jac madd_packed(const jac &acc, const uint4 *q) {
+    const u32 wx[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
+    const u32 wy[8] = {q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
+    const fq x = fq_from_words(wx), y = fq_from_words(wy);
+    if (fq_is_zero(x) && fq_is_zero(y)) return acc;  // (0,0) encodes the point at infinity
+    return jac_madd(acc, x, y);
+}
 __global__ void __launch_bounds__(256) msm_bucket_kernel(const uint4 *mont, u64 n, int c, int nwin, const u32 *starts,
                                                         const u32 *counts, const u32 *sorted, jac *buckets) {
     const u64 id = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -368,26 +378,25 @@ __global__ void __launch_bounds__(256) msm_bucket_kernel(const uint4 *mont, u64 
     const u32 st = starts[id], cnt = counts[id];
     const u32 *idx = sorted + w * n + st;
     jac acc = jac_inf();
-    uint4 nx[4];
     if (cnt) {
-        const u64 p0 = idx[0];
+        const u32 last = cnt - 1;
+        uint4 A[4], B[4];
+        u64 pa = idx[0];
 #pragma unroll
-        for (int k = 0; k < 4; k++) nx[k] = mont[p0 * 4 + k];
-    }
-    for (u32 k = 0; k < cnt; k++) {
-        uint4 q[4];
+        for (int j = 0; j < 4; j++) A[j] = mont[pa * 4 + j];
+        u32 ia = idx[last < 1 ? last : 1];
+        for (u32 k = 0; k < cnt; k += 2) {
+            const u64 pb = ia;
 #pragma unroll
-        for (int j = 0; j < 4; j++) q[j] = nx[j];
-        if (k + 1 < cnt) {
-            const u64 pn = idx[k + 1];
+            for (int j = 0; j < 4; j++) B[j] = mont[pb * 4 + j];
+            const u32 ib = idx[k + 2 < last ? k + 2 : last];
+            acc = madd_packed(acc, A);
+            pa = ib;
 #pragma unroll
-            for (int j = 0; j < 4; j++) nx[j] = mont[pn * 4 + j];
+            for (int j = 0; j < 4; j++) A[j] = mont[pa * 4 + j];
+            ia = idx[k + 3 < last ? k + 3 : last];
+            if (k + 1 < cnt) acc = madd_packed(acc, B);
         }
-        const u32 wx[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
-        const u32 wy[8] = {q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
-        const fq x = fq_from_words(wx), y = fq_from_words(wy);
-        if (fq_is_zero(x) && fq_is_zero(y)) continue;  // (0,0) encodes the point at infinity
-        acc = jac_madd(acc, x, y);
     }
     buckets[id] = acc;
 }
@@ -438,20 +447,13 @@ fq fq_inv_host(const fq &a) {  // a^(q-2) in Montgomery form (host, once per MSM
 
 }  // namespace
 
-extern "C" int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n,
-                                uint32_t *h_out) {
-    if (!ctx) return ZP_ERR_ARG;
-    ZpStage stage_(ctx, "msm_bn254");
-    ZP_ARG(ctx, h_out != nullptr, "null output");
-    ZP_ARG(ctx, n < (1ULL << 31), "too many points");
-    memset(h_out, 0, 16 * sizeof(uint32_t));
-    if (n == 0) return ZP_OK;
-    ZP_ARG(ctx, d_points && d_scalars, "null device pointer");
+// one Pippenger run over n points (n <= 2^24 from zp_msm_bn254): result as a Jacobian point in *out
+static int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n, jac *out) {
     int c = 4;
     while (c < 16 && (1ULL << (c + 2)) <= n) c++;   // ~4 points per bucket up to c = 16
-    while (c < 20 && (1ULL << (c + 7)) <= n) c++;   // wider windows only while buckets keep >= 64 points (2^26 -> c = 19..20)
+    while (c < 20 && (1ULL << (c + 7)) <= n) c++;   // wider windows only while buckets keep >= 64 points
     if (c < 6) c = 6;                                // segments of 64 buckets need c >= 6
-    const int nwin = (254 + c - 1) / c;
+    const int nwin = (256 + c - 1) / c;              // any 256-bit scalar (the BN254 group order has 254 bits)
     const u64 nb = (u64)nwin << c;
     u32 *d_counts = nullptr, *d_starts = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
     jac *d_buckets = nullptr, *d_segs = nullptr, *d_wins = nullptr;
@@ -487,11 +489,36 @@ extern "C" int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uin
     ZP_HIP(ctx, le);
     ZP_HIP(ctx, ce);
     ZP_HIP(ctx, se);
-    // 4. host: result = sum_w 2^(c*w) * W_w  (Horner from the top window)
+    // host: sum_w 2^(c*w) * W_w  (Horner from the top window)
     jac acc = jac_inf();
     for (int w = nwin - 1; w >= 0; w--) {
         for (int k = 0; k < c; k++) acc = jac_dbl(acc);
         acc = jac_add(acc, wins[w]);
+    }
+    *out = acc;
+    return ZP_OK;
+}
+
+// Points are processed in runs of 2^24 (1 GiB of points): the bucket kernel reads points at random, and beyond that
+// footprint its rate halves (2^26 in one run: 3.7 G additions/s against 8.1 G/s at 2^24); the partial sums are
+// added on the host.
+#define MSM_CHUNK_LOG 24
+extern "C" int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n,
+                                uint32_t *h_out) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "msm_bn254");
+    ZP_ARG(ctx, h_out != nullptr, "null output");
+    ZP_ARG(ctx, n < (1ULL << 31), "too many points");
+    memset(h_out, 0, 16 * sizeof(uint32_t));
+    if (n == 0) return ZP_OK;
+    ZP_ARG(ctx, d_points && d_scalars, "null device pointer");
+    jac acc = jac_inf();
+    const size_t chunk = (size_t)1 << (ctx->tune_msm_chunk_log > 0 ? ctx->tune_msm_chunk_log : MSM_CHUNK_LOG);
+    for (size_t off = 0; off < n; off += chunk) {
+        const size_t len = n - off < chunk ? n - off : chunk;
+        jac part;
+        ZP_TRY(msm_chunk(ctx, d_points + off * 16, d_scalars + off * 8, len, &part));
+        acc = jac_add(acc, part);
     }
     if (fq_is_zero(acc.Z)) return ZP_OK;  // infinity: all-zero output
     fq zi = fq_inv_host(acc.Z);

@@ -181,7 +181,8 @@ int32_t zp_get_pass_timings(zp_ctx *ctx, float *ms, int32_t *radix_log, int32_t 
  * (device time between HIP events on the ctx stream; profiling must be on).                          */
 int32_t zp_stage_timings(zp_ctx *ctx, char *buf, size_t buflen);
 
-/* experiment knobs for kernel tuning sweeps (keys: "ntt_logt" 4|5 tile of the radix-256 pass, "ntt_logt9" 4|5, "ntt_tpw" tiles per workgroup); not for production hosts */
+/* experiment knobs for kernel tuning sweeps (keys: "ntt_logt" 4|5 tile of the radix-256 pass, "ntt_logt9" 4|5, "ntt_tpw" tiles per workgroup,
+ * "msm_chunk_log" log2 of the points per Pippenger run, default 24); not for production hosts */
 int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value);
 
 /* ---- introspection ------------------------------------------------------------------------- */

@@ -32,6 +32,19 @@ def test_msm_matches_oracle(prover, table, n):
     assert prover.msm_bn254(pts, scs) == B.msm(pts, scs)
 
 
+def test_msm_in_several_runs_matches_oracle(prover, table):
+    """n above the run size: partial sums of the runs are added on the host (forced here with 2^6-point runs)"""
+    rnd = random.Random(4711)
+    n = 300
+    pts = [table[rnd.randrange(len(table))] for _ in range(n)]
+    scs = [rnd.randrange(0, 1 << 256) for _ in range(n)]
+    prover.set_tuning("msm_chunk_log", 6)
+    try:
+        assert prover.msm_bn254(pts, scs) == B.msm(pts, scs)
+    finally:
+        prover.set_tuning("msm_chunk_log", 0)
+
+
 def test_msm_infinity_inputs_and_cancellation(prover, table):
     p = table[0]
     neg = (p[0], B.Q - p[1])
