@@ -311,9 +311,40 @@ def batch_proof_probe(logn, air_name="chunk64"):
     t0 = time.perf_counter()
     proof = PR.prove(air, tr, pub, params, be, timings=tm)
     wall = time.perf_counter() - t0
-    return {"workload": "single chunk full STARK, AIR %s (%d columns), 2^%d rows, blow-up 2, 32 queries" % (air_name, air.width, logn),
-            "wall_s": wall, "stages_ms": {k: round(v * 1e3, 2) for k, v in tm.items()},
-            "witness_host_s": tw, "proof_bytes": len(PR.proof_to_json(proof))}
+    out = {"workload": "single chunk full STARK, AIR %s (%d columns), 2^%d rows, blow-up 2, 32 queries" % (air_name, air.width, logn),
+           "wall_s": wall, "stages_ms": {k: round(v * 1e3, 2) for k, v in tm.items()},
+           "witness_host_s": tw, "proof_bytes": len(PR.proof_to_json(proof))}
+    del be, tr
+    try:   # BASELINE metric (i): batch-proof wall-clock, GenBatchChunks -> GenFinalProof, through the engine
+        out["batch"] = engine_batch_probe(16, logn, air_name)
+    except Exception as e:
+        out["batch"] = {"error": repr(e)}
+    return out
+
+
+def engine_batch_probe(K, logn, air_name):
+    """K blocks -> K chunk STARKs -> aggregate -> Groth16 wrap on one GPU through service/engine.py (no gRPC);
+    second of two runs (the first builds the local CRS and warms the buffer pools)"""
+    import tempfile
+    from eigen_zeth_amd.service.engine import Engine, EngineConfig
+    from eigen_zeth_amd.service.server import default_backend_factory
+    cfg = EngineConfig(air=air_name, logn=logn, n_queries=32, groth16_logm=8,
+                       crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_bench"), witness_threads=16)
+    eng = Engine(default_backend_factory(0), cfg)
+    eng.groth16_keys()
+    res = {}
+    for rep in range(2):
+        t0 = time.perf_counter()
+        ch = eng.gen_batch_chunks("bench", list(range(1, K + 1)), 12345, "evm")
+        proofs = eng.gen_chunk_proofs("bench", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+        t1 = time.perf_counter()
+        agg = eng.aggregate("bench", proofs[0]["proof"], proofs[-1]["proof"])
+        eng.final("bench", agg, "BN128", "479881985774944702531460751064278034642760119942")
+        t2 = time.perf_counter()
+        res = {"chunks": K, "wall_s": t2 - t0, "chunk_proofs_s": t1 - t0, "aggregate_final_s": t2 - t1,
+               "prover_streams": cfg.prover_streams,
+               "note": "synthetic witnesses are generated on the host inside the timed region (0.33 s each, 16 threads)"}
+    return res
 
 
 def cpu_stark_baseline(logn, air_name="chunk64"):

@@ -77,6 +77,7 @@ int32_t zp_get_stream(zp_ctx *ctx, void **hip_stream) {
 
 int32_t zp_sync(zp_ctx *ctx) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZP_OK;
 }
@@ -93,6 +94,7 @@ static void drop_plans(zp_ctx *ctx) {
 
 int32_t zp_set_constants(zp_ctx *ctx, int32_t kind, const uint64_t *blob, size_t n) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, blob != nullptr, "null blob");
     switch (kind) {
         case ZP_CONST_ROOT32: {
@@ -146,6 +148,7 @@ int32_t zp_get_constants(zp_ctx *ctx, int32_t kind, uint64_t *blob, size_t n) {
 // ---- memory
 int32_t zp_dev_alloc(zp_ctx *ctx, size_t bytes, void **d_ptr) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, d_ptr != nullptr, "null out pointer");
     *d_ptr = nullptr;
     if (bytes == 0) return ZP_OK;
@@ -155,6 +158,7 @@ int32_t zp_dev_alloc(zp_ctx *ctx, size_t bytes, void **d_ptr) {
 }
 int32_t zp_dev_free(zp_ctx *ctx, void *d_ptr) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     if (!d_ptr) return ZP_OK;
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZP_HIP(ctx, hipFree(d_ptr));
@@ -162,6 +166,7 @@ int32_t zp_dev_free(zp_ctx *ctx, void *d_ptr) {
 }
 int32_t zp_host_alloc(zp_ctx *ctx, size_t bytes, void **h_ptr) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, h_ptr != nullptr && bytes > 0, "null pointer / zero size");
     (void)hipSetDevice(ctx->device);
     if (hipHostMalloc(h_ptr, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
@@ -173,12 +178,14 @@ int32_t zp_host_alloc(zp_ctx *ctx, size_t bytes, void **h_ptr) {
 }
 int32_t zp_host_free(zp_ctx *ctx, void *h_ptr) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     if (!h_ptr) return ZP_OK;
     ZP_HIP(ctx, hipHostFree(h_ptr));
     return ZP_OK;
 }
 int32_t zp_h2d(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     if (bytes == 0) return ZP_OK;
     ZP_ARG(ctx, d_dst && h_src, "null pointer");
     if (bytes <= ZP_SMALL_COPY) return zpi_h2d_small(ctx, d_dst, h_src, bytes);
@@ -188,6 +195,7 @@ int32_t zp_h2d(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
 }
 int32_t zp_d2h(zp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     if (bytes == 0) return ZP_OK;
     ZP_ARG(ctx, h_dst && d_src, "null pointer");
     if (bytes <= ZP_SMALL_COPY) return zpi_d2h_small(ctx, h_dst, d_src, bytes);
@@ -197,6 +205,7 @@ int32_t zp_d2h(zp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
 }
 int32_t zp_d2d(zp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     if (bytes == 0) return ZP_OK;
     ZP_ARG(ctx, d_dst && d_src, "null pointer");
     ZP_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -239,6 +248,7 @@ int32_t zp_lde(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t *d_c
 // ---- AIR plug-in support
 int32_t zp_domain_tables(zp_ctx *ctx, int32_t logm, const uint64_t **d_lo, const uint64_t **d_hi, int32_t *lb) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, logm >= 0 && logm <= 32 && d_lo && d_hi && lb, "bad arguments");
     NttPlan *pl;
     ZP_TRY(zpi_get_plan(ctx, logm, false, &pl));
@@ -344,6 +354,7 @@ int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uin
 // ---- host conveniences
 int32_t zp_ntt_host(zp_ctx *ctx, uint64_t *h_cols, int32_t logn, int32_t W, int32_t inverse) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, h_cols != nullptr || W == 0, "null host pointer");
     ZP_ARG(ctx, logn >= 0 && logn <= 32 && W >= 0, "logn/W out of range");
     if (W == 0) return ZP_OK;
@@ -363,6 +374,7 @@ int32_t zp_ntt_host(zp_ctx *ctx, uint64_t *h_cols, int32_t logn, int32_t W, int3
 int32_t zp_lde_host(zp_ctx *ctx, const uint64_t *h_in, uint64_t *h_out, int32_t logn, int32_t logb,
                     int32_t W, uint64_t shift) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, (h_in && h_out) || W == 0, "null host pointer");
     ZP_ARG(ctx, logn >= 0 && logb >= 0 && logn + logb <= 32 && W >= 0, "logn/logb/W out of range");
     if (W == 0) return ZP_OK;
@@ -397,6 +409,7 @@ int32_t zp_set_profiling(zp_ctx *ctx, int32_t on) {
 
 int32_t zp_get_pass_timings(zp_ctx *ctx, float *ms, int32_t *radix_log, int32_t cap, int32_t *count) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, count != nullptr && cap >= 0 && (cap == 0 || (ms && radix_log)), "bad arguments");
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int n = 0;
@@ -418,6 +431,7 @@ int32_t zp_get_pass_timings(zp_ctx *ctx, float *ms, int32_t *radix_log, int32_t 
 
 int32_t zp_stage_timings(zp_ctx *ctx, char *buf, size_t buflen) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, buf && buflen > 2, "null buffer");
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::string s = "[";

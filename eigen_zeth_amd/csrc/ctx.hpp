@@ -78,6 +78,7 @@ struct ZpStage {
     zp_ctx::StageEv ev;
     bool on;
     ZpStage(zp_ctx *c, const char *name) : ctx(c), on(c && c->profiling) {
+        if (c) (void)hipSetDevice(c->device);   // a host thread may alternate between ctxs of different GPUs
         if (on) {
             ev.name = name;
             on = hipEventCreate(&ev.a) == hipSuccess && hipEventCreate(&ev.b) == hipSuccess &&
@@ -88,6 +89,9 @@ struct ZpStage {
         if (on && hipEventRecord(ev.b, ctx->stream) == hipSuccess) ctx->stage_events.push_back(ev);
     }
 };
+
+// first statement of every entry point that touches the device without a ZpStage
+#define ZP_BIND(ctx) do { if (ctx) (void)hipSetDevice((ctx)->device); } while (0)
 
 #define ZP_HIP(ctx, call)                                                                    \
     do {                                                                                     \

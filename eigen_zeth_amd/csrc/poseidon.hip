@@ -359,6 +359,7 @@ int32_t zp_merkle_commit_rows(zp_ctx *ctx, const uint64_t *d_rows, size_t M, siz
 
 int32_t zp_merkle_open(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx, uint64_t *h_path) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, M >= 1 && (M & (M - 1)) == 0, "M must be a power of two");
     ZP_ARG(ctx, idx < M, "leaf index out of range");
     ZP_ARG(ctx, d_tree && h_path, "null pointer");
@@ -379,6 +380,7 @@ int32_t zp_merkle_open(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx
 
 int32_t zp_merkle_commit_host(zp_ctx *ctx, const uint64_t *h_cols, size_t M, int32_t W, uint64_t *h_tree) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, M >= 1 && (M & (M - 1)) == 0, "M must be a power of two");
     ZP_ARG(ctx, W >= 1 && h_cols && h_tree, "bad arguments");
     const size_t bin = (size_t)W * M * sizeof(u64), bt = (2 * M - 1) * 4 * sizeof(u64);

@@ -180,6 +180,7 @@ int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, cons
                          const uint64_t gamma[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t shift,
                          uint64_t *d_out) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZpStage stage_(ctx, "deep_quotient");
     ZP_ARG(ctx, logm >= 0 && logm <= 32, "logm out of range");
     ZP_ARG(ctx, Wa >= 1 && Wb >= 0 && n_next >= 0 && n_next <= Wa, "bad widths");
@@ -214,6 +215,7 @@ int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, cons
 int32_t zp_gather_rows(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, const uint64_t *h_idx, int32_t nq,
                        uint64_t *h_out) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, W >= 1 && nq >= 0 && M >= 1, "bad sizes");
     if (nq == 0) return ZP_OK;
     ZP_ARG(ctx, d_cols && h_idx && h_out, "null pointer");
@@ -234,6 +236,7 @@ int32_t zp_gather_rows(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W,
 int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, const uint64_t *h_idx, int32_t nq,
                              uint64_t *h_paths) {
     if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
     ZP_ARG(ctx, M >= 1 && (M & (M - 1)) == 0, "M must be a power of two");
     ZP_ARG(ctx, nq >= 0, "bad query count");
     int depth = 0;

@@ -16,10 +16,12 @@ def main():
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--chunks-per-block", type=int, default=1)
     ap.add_argument("--l2-addr", default=None, help="L2 JSON-RPC (ZETH_L2_ADDR) to fetch block inputs from")
+    ap.add_argument("--devices", default=None, help="comma-separated GPU ids to spread chunk proofs over (default: --device)")
     ap.add_argument("--metrics-port", type=int, default=None, help="serve Prometheus text metrics on /metrics")
     a = ap.parse_args()
     server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, chunks_per_block=a.chunks_per_block, l2_addr=a.l2_addr), a.device,
-                         metrics_port=a.metrics_port)
+                         metrics_port=a.metrics_port,
+                         devices=[int(x) for x in a.devices.split(',')] if a.devices else None)
     print("prover.v1.ProverService listening on %s:%d" % (a.host, port), flush=True)
     try:
         while True:

@@ -42,7 +42,8 @@ class EngineConfig:
 
 class Engine:
     def __init__(self, backend_factory, config=None):
-        self._factory = backend_factory
+        self._factories = list(backend_factory) if isinstance(backend_factory, (list, tuple)) else [backend_factory]
+        self._factory = self._factories[0]
         self._be = None
         self.cfg = config or EngineConfig()
         self.stage_timings = {}
@@ -57,10 +58,13 @@ class Engine:
         return self._be
 
     def _backends(self, n):
-        """the first n proving backends (one ctx / stream each); backend 0 is self.be"""
+        """the first n proving backends (one ctx / stream each); backend 0 is self.be.  With several factories
+        (one per GPU: Engine(backend_factory=[f0, f1, ...])) backends are dealt round-robin over the GPUs, so
+        independent chunk proofs of a batch spread over the devices with no exchange between them."""
         with self._be_lock:
             while len(self._extra_be) < n - 1:
-                self._extra_be.append(self._factory())
+                k = len(self._extra_be) + 1
+                self._extra_be.append(self._factories[k % len(self._factories)]())
             return [self.be] + self._extra_be[:n - 1]
 
     # ---- helpers
@@ -120,7 +124,7 @@ class Engine:
 
         # proving runs on `prover_streams` backends (ctxs with their own streams) in as many threads: the latency-bound
         # tail of one proof (FRI layers, queries, transcript) overlaps the Poseidon-bound head of the next
-        n_streams = max(1, min(self.cfg.prover_streams, len(chunks)))
+        n_streams = max(1, min(self.cfg.prover_streams * len(self._factories), len(chunks)))
         backends = self._backends(n_streams)
         free_be = queue.SimpleQueue()
         for b in backends:
