@@ -198,83 +198,146 @@ FQ_HD void fq_to_words(const fq &a, u32 *w) {
     }
 }
 
-struct jac {
-    fq X, Y, Z;  // Z == 0: point at infinity
+// ---- F_q2 = F_q[u]/(u^2 + 1)  (G2 coordinates)
+struct fq2 {
+    fq c0, c1;
 };
-FQ_HD jac jac_inf() {
-    jac p;
-    p.X = fq_one();
-    p.Y = fq_one();
-    p.Z = fq_zero();
+FQ_HD fq2 fq2_make(const fq &a, const fq &b) {
+    fq2 r;
+    r.c0 = a;
+    r.c1 = b;
+    return r;
+}
+
+// ---- one set of names over both fields, so that the curve code and the kernels are written once
+template <class F> struct FT;
+template <> struct FT<fq> {
+    static constexpr int WORDS = 8;   // 32-bit words of one packed element
+    static FQ_HD fq zero() { return fq_zero(); }
+    static FQ_HD fq one() { return fq_one(); }
+    static FQ_HD fq from_words(const u32 *w) { return fq_from_words(w); }
+    static FQ_HD void to_words(const fq &a, u32 *w) { fq_to_words(a, w); }
+};
+template <> struct FT<fq2> {
+    static constexpr int WORDS = 16;
+    static FQ_HD fq2 zero() { return fq2_make(fq_zero(), fq_zero()); }
+    static FQ_HD fq2 one() { return fq2_make(fq_one(), fq_zero()); }
+    static FQ_HD fq2 from_words(const u32 *w) { return fq2_make(fq_from_words(w), fq_from_words(w + 8)); }
+    static FQ_HD void to_words(const fq2 &a, u32 *w) {
+        fq_to_words(a.c0, w);
+        fq_to_words(a.c1, w + 8);
+    }
+};
+FQ_HD bool f_is_zero(const fq &a) { return fq_is_zero(a); }
+FQ_HD bool f_eq(const fq &a, const fq &b) { return fq_eq(a, b); }
+FQ_HD fq f_add(const fq &a, const fq &b) { return fq_add(a, b); }
+FQ_HD fq f_sub(const fq &a, const fq &b) { return fq_sub(a, b); }
+FQ_HD fq f_dbl(const fq &a) { return fq_dbl(a); }
+FQ_HD fq f_mul(const fq &a, const fq &b) { return fq_mul(a, b); }
+FQ_HD fq f_sqr(const fq &a) { return fq_sqr(a); }
+FQ_HD fq f_to_mont(const fq &a) { return fq_to_mont(a); }
+FQ_HD fq f_from_mont(const fq &a) { return fq_from_mont(a); }
+FQ_HD bool f_is_zero(const fq2 &a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
+FQ_HD bool f_eq(const fq2 &a, const fq2 &b) { return fq_eq(a.c0, b.c0) && fq_eq(a.c1, b.c1); }
+FQ_HD fq2 f_add(const fq2 &a, const fq2 &b) { return fq2_make(fq_add(a.c0, b.c0), fq_add(a.c1, b.c1)); }
+FQ_HD fq2 f_sub(const fq2 &a, const fq2 &b) { return fq2_make(fq_sub(a.c0, b.c0), fq_sub(a.c1, b.c1)); }
+FQ_HD fq2 f_dbl(const fq2 &a) { return fq2_make(fq_dbl(a.c0), fq_dbl(a.c1)); }
+FQ_HD fq2 f_mul(const fq2 &a, const fq2 &b) {   // Karatsuba: 3 products
+    const fq t0 = fq_mul(a.c0, b.c0), t1 = fq_mul(a.c1, b.c1);
+    const fq t2 = fq_mul(fq_add(a.c0, a.c1), fq_add(b.c0, b.c1));
+    return fq2_make(fq_sub(t0, t1), fq_sub(fq_sub(t2, t0), t1));
+}
+FQ_HD fq2 f_sqr(const fq2 &a) {   // (a0+a1)(a0-a1) + 2 a0 a1 u
+    const fq m = fq_mul(a.c0, a.c1);
+    return fq2_make(fq_mul(fq_add(a.c0, a.c1), fq_sub(a.c0, a.c1)), fq_dbl(m));
+}
+FQ_HD fq2 f_to_mont(const fq2 &a) { return fq2_make(fq_to_mont(a.c0), fq_to_mont(a.c1)); }
+FQ_HD fq2 f_from_mont(const fq2 &a) { return fq2_make(fq_from_mont(a.c0), fq_from_mont(a.c1)); }
+
+// ---- short Weierstrass curve y^2 = x^3 + b (a = 0) in Jacobian coordinates over F (G1: F_q, G2: F_q2)
+template <class F>
+struct jacT {
+    F X, Y, Z;  // Z == 0: point at infinity
+};
+template <class F>
+FQ_HD jacT<F> jac_inf() {
+    jacT<F> p;
+    p.X = FT<F>::one();
+    p.Y = FT<F>::one();
+    p.Z = FT<F>::zero();
     return p;
 }
 // dbl-2009-l (a = 0)
-FQ_HD jac jac_dbl(const jac &p) {
-    if (fq_is_zero(p.Z)) return p;
-    fq A = fq_sqr(p.X), B = fq_sqr(p.Y), C = fq_sqr(B);
-    fq t = fq_add(p.X, B);
-    fq D = fq_dbl(fq_sub(fq_sub(fq_sqr(t), A), C));
-    fq E = fq_add(fq_dbl(A), A);
-    fq F = fq_sqr(E);
-    jac r;
-    r.X = fq_sub(F, fq_dbl(D));
-    fq C8 = fq_dbl(fq_dbl(fq_dbl(C)));
-    r.Y = fq_sub(fq_mul(E, fq_sub(D, r.X)), C8);
-    r.Z = fq_dbl(fq_mul(p.Y, p.Z));
+template <class F>
+FQ_HD jacT<F> jac_dbl(const jacT<F> &p) {
+    if (f_is_zero(p.Z)) return p;
+    F A = f_sqr(p.X), B = f_sqr(p.Y), C = f_sqr(B);
+    F t = f_add(p.X, B);
+    F D = f_dbl(f_sub(f_sub(f_sqr(t), A), C));
+    F E = f_add(f_dbl(A), A);
+    F G = f_sqr(E);
+    jacT<F> r;
+    r.X = f_sub(G, f_dbl(D));
+    F C8 = f_dbl(f_dbl(f_dbl(C)));
+    r.Y = f_sub(f_mul(E, f_sub(D, r.X)), C8);
+    r.Z = f_dbl(f_mul(p.Y, p.Z));
     return r;
 }
 // madd-2007-bl: Jacobian + affine (qx, qy) (affine point must not be infinity)
-FQ_HD jac jac_madd(const jac &p, const fq &qx, const fq &qy) {
-    if (fq_is_zero(p.Z)) {
-        jac r;
+template <class F>
+FQ_HD jacT<F> jac_madd(const jacT<F> &p, const F &qx, const F &qy) {
+    if (f_is_zero(p.Z)) {
+        jacT<F> r;
         r.X = qx;
         r.Y = qy;
-        r.Z = fq_one();
+        r.Z = FT<F>::one();
         return r;
     }
-    fq Z1Z1 = fq_sqr(p.Z);
-    fq U2 = fq_mul(qx, Z1Z1);
-    fq S2 = fq_mul(fq_mul(qy, p.Z), Z1Z1);
-    if (fq_eq(U2, p.X)) {
-        if (fq_eq(S2, p.Y)) return jac_dbl(p);
-        return jac_inf();
+    F Z1Z1 = f_sqr(p.Z);
+    F U2 = f_mul(qx, Z1Z1);
+    F S2 = f_mul(f_mul(qy, p.Z), Z1Z1);
+    if (f_eq(U2, p.X)) {
+        if (f_eq(S2, p.Y)) return jac_dbl(p);
+        return jac_inf<F>();
     }
-    fq H = fq_sub(U2, p.X);
-    fq HH = fq_sqr(H);
-    fq I = fq_dbl(fq_dbl(HH));
-    fq J = fq_mul(H, I);
-    fq rr = fq_dbl(fq_sub(S2, p.Y));
-    fq V = fq_mul(p.X, I);
-    jac r;
-    r.X = fq_sub(fq_sub(fq_sqr(rr), J), fq_dbl(V));
-    r.Y = fq_sub(fq_mul(rr, fq_sub(V, r.X)), fq_dbl(fq_mul(p.Y, J)));
-    r.Z = fq_sub(fq_sub(fq_sqr(fq_add(p.Z, H)), Z1Z1), HH);
+    F H = f_sub(U2, p.X);
+    F HH = f_sqr(H);
+    F I = f_dbl(f_dbl(HH));
+    F J = f_mul(H, I);
+    F rr = f_dbl(f_sub(S2, p.Y));
+    F V = f_mul(p.X, I);
+    jacT<F> r;
+    r.X = f_sub(f_sub(f_sqr(rr), J), f_dbl(V));
+    r.Y = f_sub(f_mul(rr, f_sub(V, r.X)), f_dbl(f_mul(p.Y, J)));
+    r.Z = f_sub(f_sub(f_sqr(f_add(p.Z, H)), Z1Z1), HH);
     return r;
 }
 // add-2007-bl: Jacobian + Jacobian
-FQ_HD jac jac_add(const jac &p, const jac &q) {
-    if (fq_is_zero(p.Z)) return q;
-    if (fq_is_zero(q.Z)) return p;
-    fq Z1Z1 = fq_sqr(p.Z), Z2Z2 = fq_sqr(q.Z);
-    fq U1 = fq_mul(p.X, Z2Z2), U2 = fq_mul(q.X, Z1Z1);
-    fq S1 = fq_mul(fq_mul(p.Y, q.Z), Z2Z2), S2 = fq_mul(fq_mul(q.Y, p.Z), Z1Z1);
-    if (fq_eq(U1, U2)) {
-        if (fq_eq(S1, S2)) return jac_dbl(p);
-        return jac_inf();
+template <class F>
+FQ_HD jacT<F> jac_add(const jacT<F> &p, const jacT<F> &q) {
+    if (f_is_zero(p.Z)) return q;
+    if (f_is_zero(q.Z)) return p;
+    F Z1Z1 = f_sqr(p.Z), Z2Z2 = f_sqr(q.Z);
+    F U1 = f_mul(p.X, Z2Z2), U2 = f_mul(q.X, Z1Z1);
+    F S1 = f_mul(f_mul(p.Y, q.Z), Z2Z2), S2 = f_mul(f_mul(q.Y, p.Z), Z1Z1);
+    if (f_eq(U1, U2)) {
+        if (f_eq(S1, S2)) return jac_dbl(p);
+        return jac_inf<F>();
     }
-    fq H = fq_sub(U2, U1);
-    fq I = fq_sqr(fq_dbl(H));
-    fq J = fq_mul(H, I);
-    fq rr = fq_dbl(fq_sub(S2, S1));
-    fq V = fq_mul(U1, I);
-    jac r;
-    r.X = fq_sub(fq_sub(fq_sqr(rr), J), fq_dbl(V));
-    r.Y = fq_sub(fq_mul(rr, fq_sub(V, r.X)), fq_dbl(fq_mul(S1, J)));
-    r.Z = fq_mul(fq_sub(fq_sub(fq_sqr(fq_add(p.Z, q.Z)), Z1Z1), Z2Z2), H);
+    F H = f_sub(U2, U1);
+    F I = f_sqr(f_dbl(H));
+    F J = f_mul(H, I);
+    F rr = f_dbl(f_sub(S2, S1));
+    F V = f_mul(U1, I);
+    jacT<F> r;
+    r.X = f_sub(f_sub(f_sqr(rr), J), f_dbl(V));
+    r.Y = f_sub(f_mul(rr, f_sub(V, r.X)), f_dbl(f_mul(S1, J)));
+    r.Z = f_mul(f_sub(f_sub(f_sqr(f_add(p.Z, q.Z)), Z1Z1), Z2Z2), H);
     return r;
 }
-FQ_HD jac jac_mul_small(const jac &p, u32 k) {  // k * p by double-and-add (k < 2^32)
-    jac acc = jac_inf();
+template <class F>
+FQ_HD jacT<F> jac_mul_small(const jacT<F> &p, u32 k) {  // k * p by double-and-add (k < 2^32)
+    jacT<F> acc = jac_inf<F>();
     for (int i = 31; i >= 0; i--) {
         acc = jac_dbl(acc);
         if ((k >> i) & 1) acc = jac_add(acc, p);
@@ -341,75 +404,93 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const u32 *scalars, u6
         }
     }
 }
-// ---- 2a. one-time conversion of the affine inputs to Montgomery form (16-byte vector accesses)
+
+// a packed affine point = 2 * FT<F>::WORDS words = NV uint4 (G1: 4, G2: 8); (0, 0) encodes the point at infinity
+template <class F>
+__device__ __forceinline__ void unpack_point(const uint4 *q, F &x, F &y) {
+    constexpr int NV = FT<F>::WORDS / 2;
+    u32 w[FT<F>::WORDS * 2];
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        w[4 * k] = q[k].x;
+        w[4 * k + 1] = q[k].y;
+        w[4 * k + 2] = q[k].z;
+        w[4 * k + 3] = q[k].w;
+    }
+    x = FT<F>::from_words(w);
+    y = FT<F>::from_words(w + FT<F>::WORDS);
+}
+// ---- 2a. one-time conversion of the affine inputs to Montgomery form (16-byte vector accesses); stored packed
+template <class F>
 __global__ void __launch_bounds__(256) msm_to_mont_kernel(const uint4 *points, u64 n, uint4 *mont) {
+    constexpr int NV = FT<F>::WORDS / 2;
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    uint4 q[4];
+    uint4 q[NV];
 #pragma unroll
-    for (int k = 0; k < 4; k++) q[k] = points[i * 4 + k];
-    const u32 wx[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
-    const u32 wy[8] = {q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
-    // (0,0) stays (0,0): still the infinity marker.  Stored packed (8 words per coordinate, Montgomery form, < q).
-    u32 ox[8], oy[8];
-    fq_to_words(fq_to_mont(fq_from_words(wx)), ox);
-    fq_to_words(fq_to_mont(fq_from_words(wy)), oy);
-    mont[i * 4 + 0] = make_uint4(ox[0], ox[1], ox[2], ox[3]);
-    mont[i * 4 + 1] = make_uint4(ox[4], ox[5], ox[6], ox[7]);
-    mont[i * 4 + 2] = make_uint4(oy[0], oy[1], oy[2], oy[3]);
-    mont[i * 4 + 3] = make_uint4(oy[4], oy[5], oy[6], oy[7]);
+    for (int k = 0; k < NV; k++) q[k] = points[i * NV + k];
+    F x, y;
+    unpack_point<F>(q, x, y);
+    u32 w[FT<F>::WORDS * 2];
+    FT<F>::to_words(f_to_mont(x), w);   // (0,0) stays (0,0): still the infinity marker
+    FT<F>::to_words(f_to_mont(y), w + FT<F>::WORDS);
+#pragma unroll
+    for (int k = 0; k < NV; k++) mont[i * NV + k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
 }
 // ---- 2b. bucket sums: lane = (window, bucket).  Software pipeline, two points per trip: while point k is added,
 // point k+1 and the index of point k+2 are in flight.  All loads are unconditional (indices clamped to the bucket's
 // last point) so that no loop-carried register needs a copy under an exec mask -- with a conditional prefetch the
 // compiler parked a v_mov (and therefore an s_waitcnt) right behind every load and nothing was overlapped.
-__device__ __forceinline__ jac madd_packed(const jac &acc, const uint4 *q) {
-    const u32 wx[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
-    const u32 wy[8] = {q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
-    const fq x = fq_from_words(wx), y = fq_from_words(wy);
-    if (fq_is_zero(x) && fq_is_zero(y)) return acc;  // (0,0) encodes the point at infinity
+template <class F>
+__device__ __forceinline__ jacT<F> madd_packed(const jacT<F> &acc, const uint4 *q) {
+    F x, y;
+    unpack_point<F>(q, x, y);
+    if (f_is_zero(x) && f_is_zero(y)) return acc;
     return jac_madd(acc, x, y);
 }
+template <class F>
 __global__ void __launch_bounds__(256) msm_bucket_kernel(const uint4 *mont, u64 n, int c, int nwin, const u32 *starts,
-                                                        const u32 *counts, const u32 *sorted, jac *buckets) {
+                                                        const u32 *counts, const u32 *sorted, jacT<F> *buckets) {
+    constexpr int NV = FT<F>::WORDS / 2;
     const u64 id = (u64)blockIdx.x * 256 + threadIdx.x;
     if (id >= ((u64)nwin << c)) return;
     const u64 w = id >> c;
     const u32 st = starts[id], cnt = counts[id];
     const u32 *idx = sorted + w * n + st;
-    jac acc = jac_inf();
+    jacT<F> acc = jac_inf<F>();
     if (cnt) {
         const u32 last = cnt - 1;
-        uint4 A[4], B[4];
+        uint4 A[NV], B[NV];
         u64 pa = idx[0];
 #pragma unroll
-        for (int j = 0; j < 4; j++) A[j] = mont[pa * 4 + j];
+        for (int j = 0; j < NV; j++) A[j] = mont[pa * NV + j];
         u32 ia = idx[last < 1 ? last : 1];
         for (u32 k = 0; k < cnt; k += 2) {
             const u64 pb = ia;
 #pragma unroll
-            for (int j = 0; j < 4; j++) B[j] = mont[pb * 4 + j];
+            for (int j = 0; j < NV; j++) B[j] = mont[pb * NV + j];
             const u32 ib = idx[k + 2 < last ? k + 2 : last];
-            acc = madd_packed(acc, A);
+            acc = madd_packed<F>(acc, A);
             pa = ib;
 #pragma unroll
-            for (int j = 0; j < 4; j++) A[j] = mont[pa * 4 + j];
+            for (int j = 0; j < NV; j++) A[j] = mont[pa * NV + j];
             ia = idx[k + 3 < last ? k + 3 : last];
-            if (k + 1 < cnt) acc = madd_packed(acc, B);
+            if (k + 1 < cnt) acc = madd_packed<F>(acc, B);
         }
     }
     buckets[id] = acc;
 }
 // ---- 3a. per segment of SEG buckets: sum_{b in seg} b * B_b
 #define MSM_SEG 64
-__global__ void __launch_bounds__(64) msm_segment_kernel(const jac *buckets, int c, int nwin, jac *segs) {
+template <class F>
+__global__ void __launch_bounds__(64) msm_segment_kernel(const jacT<F> *buckets, int c, int nwin, jacT<F> *segs) {
     const u64 id = (u64)blockIdx.x * 64 + threadIdx.x;
     const u64 segs_per_win = (1ULL << c) / MSM_SEG;
     if (id >= (u64)nwin * segs_per_win) return;
     const u64 w = id / segs_per_win, sidx = id % segs_per_win;
     const u64 s = sidx * MSM_SEG;
-    const jac *B = buckets + (w << c) + s;
-    jac run = jac_inf(), acc = jac_inf();
+    const jacT<F> *B = buckets + (w << c) + s;
+    jacT<F> run = jac_inf<F>(), acc = jac_inf<F>();
     for (int k = MSM_SEG - 1; k >= 1; k--) {
         run = jac_add(run, B[k]);
         acc = jac_add(acc, run);
@@ -419,14 +500,15 @@ __global__ void __launch_bounds__(64) msm_segment_kernel(const jac *buckets, int
     segs[id] = acc;
 }
 // ---- 3b. tree sum of the segment results of one window (one block per window)
-__global__ void __launch_bounds__(256) msm_window_kernel(const jac *segs, int nseg, jac *wins) {
-    __shared__ jac sh[256];
-    const jac *S = segs + (u64)blockIdx.x * nseg;
-    jac acc = jac_inf();
-    for (int k = threadIdx.x; k < nseg; k += 256) acc = jac_add(acc, S[k]);
+template <class F>
+__global__ void __launch_bounds__(128) msm_window_kernel(const jacT<F> *segs, int nseg, jacT<F> *wins) {
+    __shared__ jacT<F> sh[128];
+    const jacT<F> *S = segs + (u64)blockIdx.x * nseg;
+    jacT<F> acc = jac_inf<F>();
+    for (int k = threadIdx.x; k < nseg; k += 128) acc = jac_add(acc, S[k]);
     sh[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = 64; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) sh[threadIdx.x] = jac_add(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
@@ -444,11 +526,17 @@ fq fq_inv_host(const fq &a) {  // a^(q-2) in Montgomery form (host, once per MSM
     }
     return r;
 }
+fq f_inv_host(const fq &a) { return fq_inv_host(a); }
+fq2 f_inv_host(const fq2 &a) {  // (a0 - a1 u) / (a0^2 + a1^2)
+    const fq d = fq_inv_host(fq_add(fq_sqr(a.c0), fq_sqr(a.c1)));
+    return fq2_make(fq_mul(a.c0, d), fq_sub(fq_zero(), fq_mul(a.c1, d)));
+}
 
-}  // namespace
-
-// one Pippenger run over n points (n <= 2^24 from zp_msm_bn254): result as a Jacobian point in *out
-static int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n, jac *out) {
+// one Pippenger run over n points (n <= 2^24 from the entry points): result as a Jacobian point in *out
+template <class F>
+int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n, jacT<F> *out) {
+    constexpr int NV = FT<F>::WORDS / 2;
+    using J = jacT<F>;
     int c = 4;
     while (c < 16 && (1ULL << (c + 2)) <= n) c++;   // ~4 points per bucket up to c = 16
     while (c < 20 && (1ULL << (c + 7)) <= n) c++;   // wider windows only while buckets keep >= 64 points
@@ -456,7 +544,7 @@ static int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *
     const int nwin = (256 + c - 1) / c;              // any 256-bit scalar (the BN254 group order has 254 bits)
     const u64 nb = (u64)nwin << c;
     u32 *d_counts = nullptr, *d_starts = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
-    jac *d_buckets = nullptr, *d_segs = nullptr, *d_wins = nullptr;
+    J *d_buckets = nullptr, *d_segs = nullptr, *d_wins = nullptr;
     uint4 *d_mont = nullptr;
     const u64 nseg = (1ULL << c) / MSM_SEG;
     ZP_HIP(ctx, hipSetDevice(ctx->device));
@@ -464,23 +552,23 @@ static int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *
     d_starts = d_counts + nb;
     d_cursor = d_starts + nb;
     ZP_HIP(ctx, hipMalloc((void **)&d_sorted, (u64)nwin * n * 4));
-    ZP_HIP(ctx, hipMalloc((void **)&d_mont, (u64)n * 64));
-    ZP_HIP(ctx, hipMalloc((void **)&d_buckets, (nb + nwin * nseg + nwin) * sizeof(jac)));
+    ZP_HIP(ctx, hipMalloc((void **)&d_mont, (u64)n * NV * 16));
+    ZP_HIP(ctx, hipMalloc((void **)&d_buckets, (nb + nwin * nseg + nwin) * sizeof(J)));
     d_segs = d_buckets + nb;
     d_wins = d_segs + nwin * nseg;
     ZP_HIP(ctx, hipMemsetAsync(d_counts, 0, nb * 4, ctx->stream));
     const unsigned gb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(msm_to_mont_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const uint4 *)d_points, (u64)n, d_mont);
+    hipLaunchKernelGGL(msm_to_mont_kernel<F>, dim3(gb), dim3(256), 0, ctx->stream, (const uint4 *)d_points, (u64)n, d_mont);
     hipLaunchKernelGGL(msm_hist_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const u32 *)d_scalars, (u64)n, c, nwin, d_counts);
     hipLaunchKernelGGL(msm_scan_kernel, dim3(nwin), dim3(1024), 0, ctx->stream, d_counts, d_starts, d_cursor, c);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const u32 *)d_scalars, (u64)n, c, nwin, d_cursor, d_sorted);
-    hipLaunchKernelGGL(msm_bucket_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(msm_bucket_kernel<F>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const uint4 *)d_mont, (u64)n, c, nwin, d_starts, d_counts, d_sorted, d_buckets);
-    hipLaunchKernelGGL(msm_segment_kernel, dim3((unsigned)((nwin * nseg + 63) / 64)), dim3(64), 0, ctx->stream, d_buckets, c, nwin, d_segs);
-    hipLaunchKernelGGL(msm_window_kernel, dim3(nwin), dim3(256), 0, ctx->stream, d_segs, (int)nseg, d_wins);
+    hipLaunchKernelGGL(msm_segment_kernel<F>, dim3((unsigned)((nwin * nseg + 63) / 64)), dim3(64), 0, ctx->stream, d_buckets, c, nwin, d_segs);
+    hipLaunchKernelGGL(msm_window_kernel<F>, dim3(nwin), dim3(128), 0, ctx->stream, d_segs, (int)nseg, d_wins);
     hipError_t le = hipGetLastError();
-    std::vector<jac> wins(nwin);
-    hipError_t ce = hipMemcpyAsync(wins.data(), d_wins, nwin * sizeof(jac), hipMemcpyDeviceToHost, ctx->stream);
+    std::vector<J> wins(nwin);
+    hipError_t ce = hipMemcpyAsync(wins.data(), d_wins, nwin * sizeof(J), hipMemcpyDeviceToHost, ctx->stream);
     hipError_t se = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_counts);
     (void)hipFree(d_sorted);
@@ -490,7 +578,7 @@ static int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *
     ZP_HIP(ctx, ce);
     ZP_HIP(ctx, se);
     // host: sum_w 2^(c*w) * W_w  (Horner from the top window)
-    jac acc = jac_inf();
+    J acc = jac_inf<F>();
     for (int w = nwin - 1; w >= 0; w--) {
         for (int k = 0; k < c; k++) acc = jac_dbl(acc);
         acc = jac_add(acc, wins[w]);
@@ -499,33 +587,48 @@ static int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *
     return ZP_OK;
 }
 
-// Points are processed in runs of 2^24 (1 GiB of points): the bucket kernel reads points at random, and beyond that
-// footprint its rate halves (2^26 in one run: 3.7 G additions/s against 8.1 G/s at 2^24); the partial sums are
+// Points are processed in runs of 2^24 (G1: 1 GiB of points): the bucket kernel reads points at random, and beyond
+// that footprint its rate halves (2^26 in one run: 3.7 G additions/s against 8.1 G/s at 2^24); the partial sums are
 // added on the host.
 #define MSM_CHUNK_LOG 24
+template <class F>
+int32_t msm_run(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n, uint32_t *h_out) {
+    constexpr int PW = FT<F>::WORDS * 2;   // words per affine point
+    ZP_ARG(ctx, h_out != nullptr, "null output");
+    ZP_ARG(ctx, n < (1ULL << 31), "too many points");
+    memset(h_out, 0, PW * sizeof(uint32_t));
+    if (n == 0) return ZP_OK;
+    ZP_ARG(ctx, d_points && d_scalars, "null device pointer");
+    jacT<F> acc = jac_inf<F>();
+    const size_t chunk = (size_t)1 << (ctx->tune_msm_chunk_log > 0 ? ctx->tune_msm_chunk_log : MSM_CHUNK_LOG);
+    for (size_t off = 0; off < n; off += chunk) {
+        const size_t len = n - off < chunk ? n - off : chunk;
+        jacT<F> part;
+        ZP_TRY(msm_chunk<F>(ctx, d_points + off * PW, d_scalars + off * 8, len, &part));
+        acc = jac_add(acc, part);
+    }
+    if (f_is_zero(acc.Z)) return ZP_OK;  // infinity: all-zero output
+    F zi = f_inv_host(acc.Z);
+    F zi2 = f_sqr(zi);
+    F x = f_from_mont(f_mul(acc.X, zi2));
+    F y = f_from_mont(f_mul(acc.Y, f_mul(zi2, zi)));
+    FT<F>::to_words(x, h_out);
+    FT<F>::to_words(y, h_out + FT<F>::WORDS);
+    return ZP_OK;
+}
+
+}  // namespace
+
 extern "C" int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n,
                                 uint32_t *h_out) {
     if (!ctx) return ZP_ERR_ARG;
     ZpStage stage_(ctx, "msm_bn254");
-    ZP_ARG(ctx, h_out != nullptr, "null output");
-    ZP_ARG(ctx, n < (1ULL << 31), "too many points");
-    memset(h_out, 0, 16 * sizeof(uint32_t));
-    if (n == 0) return ZP_OK;
-    ZP_ARG(ctx, d_points && d_scalars, "null device pointer");
-    jac acc = jac_inf();
-    const size_t chunk = (size_t)1 << (ctx->tune_msm_chunk_log > 0 ? ctx->tune_msm_chunk_log : MSM_CHUNK_LOG);
-    for (size_t off = 0; off < n; off += chunk) {
-        const size_t len = n - off < chunk ? n - off : chunk;
-        jac part;
-        ZP_TRY(msm_chunk(ctx, d_points + off * 16, d_scalars + off * 8, len, &part));
-        acc = jac_add(acc, part);
-    }
-    if (fq_is_zero(acc.Z)) return ZP_OK;  // infinity: all-zero output
-    fq zi = fq_inv_host(acc.Z);
-    fq zi2 = fq_sqr(zi);
-    fq x = fq_from_mont(fq_mul(acc.X, zi2));
-    fq y = fq_from_mont(fq_mul(acc.Y, fq_mul(zi2, zi)));
-    fq_to_words(x, h_out);
-    fq_to_words(y, h_out + 8);
-    return ZP_OK;
+    return msm_run<fq>(ctx, d_points, d_scalars, n, h_out);
+}
+
+extern "C" int32_t zp_msm_bn254_g2(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n,
+                                   uint32_t *h_out) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "msm_bn254_g2");
+    return msm_run<fq2>(ctx, d_points, d_scalars, n, h_out);
 }

@@ -69,6 +69,7 @@ SIGNATURES = {
     "zp_domain_tables": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int32)]),
     "zp_synth_trace": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p]),
     "zp_msm_bn254": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "zp_msm_bn254_g2": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
     "zp_ntt_host": (C.c_int32, [_vp, _u64p, C.c_int32, C.c_int32, C.c_int32]),
     "zp_lde_host": (C.c_int32, [_vp, _u64p, _u64p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_merkle_commit_host": (C.c_int32, [_vp, _u64p, C.c_size_t, C.c_int32, _u64p]),
@@ -376,6 +377,29 @@ class Prover:
         x = sum(int(out[k]) << (32 * k) for k in range(8))
         y = sum(int(out[8 + k]) << (32 * k) for k in range(8))
         return None if (x == 0 and y == 0) else (x, y)
+
+    def msm_bn254_g2(self, points, scalars):
+        """points: list of ((x0, x1), (y0, y1)) ints over F_q2 (None or zeros = infinity); scalars: ints.
+        Returns ((x0, x1), (y0, y1)) or None."""
+        n_ = len(points)
+        pts = np.zeros((max(n_, 1), 32), dtype=np.uint32)
+        scs = np.zeros((max(n_, 1), 8), dtype=np.uint32)
+        for i, (p, s) in enumerate(zip(points, scalars)):
+            if p is not None:
+                for c, v in enumerate((p[0][0], p[0][1], p[1][0], p[1][1])):
+                    for k in range(8):
+                        pts[i, 8 * c + k] = (v >> (32 * k)) & 0xFFFFFFFF
+            for k in range(8):
+                scs[i, k] = (s >> (32 * k)) & 0xFFFFFFFF
+        d_p = DeviceBuffer(self, max(1, pts.size // 2 + 1))
+        d_s = DeviceBuffer(self, max(1, scs.size // 2 + 1))
+        if n_:
+            self._chk(self.lib.zp_h2d(self.ctx, d_p.ptr, pts.ctypes.data, pts[:n_].nbytes))
+            self._chk(self.lib.zp_h2d(self.ctx, d_s.ptr, scs.ctypes.data, scs[:n_].nbytes))
+        out = (C.c_uint32 * 32)()
+        self._chk(self.lib.zp_msm_bn254_g2(self.ctx, d_p.ptr, d_s.ptr, n_, out))
+        v = [sum(int(out[8 * c + k]) << (32 * k) for k in range(8)) for c in range(4)]
+        return None if not any(v) else ((v[0], v[1]), (v[2], v[3]))
 
     # ---- host-buffer forms
     def ntt_host(self, cols, inverse=False):

@@ -196,7 +196,7 @@ class Engine:
         w = circ.witness(h % bn254.R)
         rnd = ((h >> 11) % bn254.R or 1, (h >> 23) % bn254.R or 1)   # blinding derived from the input: replays are identical
         t0 = time.perf_counter()
-        proof, pub = groth16.prove(circ, pk, w, self.be.msm_g1, rnd)
+        proof, pub = groth16.prove(circ, pk, w, self.be.msm_g1, rnd, getattr(self.be, "msm_g2", None))
         self.stage_timings["final/" + batch_id] = {"groth16": time.perf_counter() - t0}
         if self.metrics is not None:
             self.metrics.record_stage("groth16", self.stage_timings["final/" + batch_id]["groth16"])

@@ -119,8 +119,9 @@ def _g2_add(a, b):
     return bn254._pt_add(bn254._Ops2, a, b)
 
 
-def prove(circ, pk, w, msm_g1, rand):
-    """msm_g1(points[(x,y)], scalars[int]) -> (x, y) | None   (GPU: Prover.msm_bn254);  rand = (r, s)"""
+def prove(circ, pk, w, msm_g1, rand, msm_g2=None):
+    """msm_g1(points[(x,y)], scalars[int]) -> (x, y) | None   (GPU: Prover.msm_bn254);  rand = (r, s);
+    msm_g2(points[((x0,x1),(y0,y1)) | None], scalars) -> point | None  (GPU: Prover.msm_bn254_g2) for the G2 side of B"""
     assert circ.check(w)
     m, om = circ.m, _root(circ.logm)
     dot = lambda row: sum(c * w[j] for j, c in row.items()) % R
@@ -141,9 +142,12 @@ def prove(circ, pk, w, msm_g1, rand):
     A1 = _g1_add(_g1_add(pk["alpha1"], msm_g1(pk["u1"], w)), bn254._pt_mul(bn254._Ops1, pk["delta1"], r))
     B1 = _g1_add(_g1_add(pk["beta1"], msm_g1(pk["v1"], w)), bn254._pt_mul(bn254._Ops1, pk["delta1"], s))
     B2 = pk["beta2"]
-    for j, pt in enumerate(pk["v2"]):            # G2 side on the host (few non-zero wires per row)
-        if pt is not None and w[j]:
-            B2 = _g2_add(B2, bn254._pt_mul(bn254._Ops2, pt, w[j]))
+    if msm_g2 is not None:                       # sum_j w_j [v_j(tau)]_2 as one G2 multi-scalar multiplication
+        B2 = _g2_add(B2, msm_g2(pk["v2"], w))
+    else:
+        for j, pt in enumerate(pk["v2"]):
+            if pt is not None and w[j]:
+                B2 = _g2_add(B2, bn254._pt_mul(bn254._Ops2, pt, w[j]))
     B2 = _g2_add(B2, bn254._pt_mul(bn254._Ops2, pk["delta2"], s))
     priv = list(range(1 + circ.npub, circ.nwires))
     Cp = msm_g1([pk["l1"][j] for j in priv] + pk["h1"], [w[j] for j in priv] + hco[:m - 1])

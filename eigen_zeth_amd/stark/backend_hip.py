@@ -184,3 +184,6 @@ class HipBackend:
     # ---- N6 (Groth16 wrap)
     def msm_g1(self, points, scalars):
         return self.p.msm_bn254([p if p is not None else (0, 0) for p in points], [int(s) for s in scalars])
+
+    def msm_g2(self, points, scalars):
+        return self.p.msm_bn254_g2(points, [int(s) for s in scalars])

@@ -164,6 +164,11 @@ int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uin
  * integers < q; (0,0) encodes the point at infinity.  d_scalars u32[n][8] little-endian, any 256-bit
  * value (used mod the group order implicitly).  h_out u32[16] = affine sum, all zero = infinity.   */
 int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n, uint32_t *h_out);
+/* the same over G2 (the B element of a Groth16 proof): affine points over F_q2 = F_q[u]/(u^2+1) on the twist
+ * y^2 = x^3 + 3/(9+u); d_points u32[n][32] = x.c0, x.c1, y.c0, y.c1 (8 little-endian words each, standard form,
+ * all-zero = infinity), d_scalars u32[n][8]; h_out u32[32] in the same layout (all-zero = infinity).          */
+int32_t zp_msm_bn254_g2(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n,
+                        uint32_t *h_out);
 
 /* ---- host-buffer conveniences (H2D + compute + D2H + sync), the form a non-GPU-aware host uses */
 int32_t zp_ntt_host(zp_ctx *ctx, uint64_t *h_cols, int32_t logn, int32_t W, int32_t inverse);

@@ -80,3 +80,30 @@ def test_msm_large_table_property(prover, table):
     for i, j in enumerate(idx):
         per[j] = (per[j] + ints[i]) % B.R
     assert prover.msm_bn254_arrays(pts, scs) == B.msm(table, per)
+
+
+@pytest.fixture(scope="module")
+def table_g2():
+    rnd = random.Random(77)
+    pts = [B.mul_g2(B.G2, rnd.randrange(1, B.R)) for _ in range(16)]
+    assert B.on_curve_g2(B.G2) and all(B.on_curve_g2(p) for p in pts)
+    return pts
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 5, 64, 300])
+def test_msm_g2_matches_oracle(prover, table_g2, n):
+    rnd = random.Random(900 + n)
+    pts = [table_g2[rnd.randrange(len(table_g2))] for _ in range(n)]
+    scs = [rnd.randrange(0, 1 << 256) for _ in range(n)]
+    for i, v in enumerate([0, 1, B.R - 1, B.R][:n]):
+        scs[i] = v
+    if n > 4:
+        pts[4] = None                                     # infinity among the inputs
+    assert prover.msm_bn254_g2(pts, scs) == B.msm_g2(pts, scs)
+
+
+def test_msm_g2_cancellation_and_doubling(prover, table_g2):
+    p = table_g2[0]
+    neg = (p[0], ((-p[1][0]) % B.Q, (-p[1][1]) % B.Q))
+    assert prover.msm_bn254_g2([p, neg], [5, 5]) is None
+    assert prover.msm_bn254_g2([p] * 7, [1] * 7) == B.mul_g2(p, 7)      # same point in one bucket: the doubling branch
