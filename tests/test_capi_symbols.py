@@ -54,3 +54,14 @@ def test_no_gpu_means_loud_failure():
     from eigen_zeth_amd import native
     with pytest.raises(native.ZpError):
         native.Prover(0)
+
+
+def test_integration_doc_lists_every_entry_point():
+    """INTEGRATION.md's Rust extern block binds exactly the functions include/zeth_prover.h declares"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "zeth_prover.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    declared = set(re.findall(r"^(?:int32_t|void|const char \*)\s*\*?(zp_[a-z0-9_]+)\(", hdr, re.M))
+    bound = set(re.findall(r"pub fn (zp_[a-z0-9_]+)", doc))
+    assert declared == bound, (declared - bound, bound - declared)
