@@ -353,24 +353,50 @@ __device__ __forceinline__ u32 digit_of(const u32 *sc, int w, int c) {
     return (u32)(v >> off) & ((1u << c) - 1);
 }
 
-// ---- 1. counting sort of point indices by window digit
-__global__ void __launch_bounds__(256) msm_hist_kernel(const u32 *scalars, u64 n, int c, int nwin, u32 *counts) {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    u32 sc[8];
-    for (int k = 0; k < 8; k++) sc[k] = scalars[i * 8 + k];
-    for (int w = 0; w < nwin; w++) {
-        const u32 d = digit_of(sc, w, c);
-        if (d) atomicAdd(&counts[((u64)w << c) + d], 1u);
+// ---- 1. sort of the point indices by window digit, two levels so that every global write lands next to its
+// neighbours.  (The first version was one atomic counting sort: 4-byte writes to random addresses, 16x write
+// amplification and a returning global atomic per (point, window) -- as slow as the bucket sums themselves.)
+//   coarse digit = top `hi` bits of the window digit, fine digit = low `lo` bits (lo <= 10)
+//   1a. msm_coarse_hist : LDS histogram per 4096-point tile -> counts[window][coarse]
+//   1b. msm_scan        : exclusive scan per window -> coarse starts
+//   1c. msm_coarse_part : per tile, LDS ranks + one global reservation per (window, coarse bin) -> (index, fine
+//                         digit) pairs grouped by coarse bin (order inside a bin is arbitrary)
+//   1d. msm_fine_sort   : one workgroup per (window, coarse bin): counting sort by fine digit with LDS counters,
+//                         inside that bin's contiguous (L2-sized) region; also emits starts/counts per bucket
+#define MSM_TILE 4096
+#define MSM_LO_MAX 10
+struct SortGeo {
+    int c, hi, lo, nwin, wgroup;   // wgroup: windows handled per pass of the tile kernels (LDS budget)
+};
+__global__ void __launch_bounds__(256) msm_coarse_hist_kernel(const u32 *scalars, u64 n, SortGeo g, int w0, u32 *ccounts) {
+    extern __shared__ u32 lh[];   // [wgroup][2^hi]
+    const int nbin = 1 << g.hi, nw = min(g.wgroup, g.nwin - w0);
+    for (int i = threadIdx.x; i < nw * nbin; i += 256) lh[i] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * MSM_TILE;
+    for (int k = 0; k < MSM_TILE / 256; k++) {
+        const u64 i = base + (u64)k * 256 + threadIdx.x;
+        if (i < n) {
+            u32 sc[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) sc[j] = scalars[i * 8 + j];
+            for (int w = 0; w < nw; w++) {
+                const u32 d = digit_of(sc, w0 + w, g.c);
+                if (d) atomicAdd(&lh[w * nbin + (d >> g.lo)], 1u);
+            }
+        }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nw * nbin; i += 256)
+        if (lh[i]) atomicAdd(&ccounts[(u64)(w0 + i / nbin) * nbin + (i % nbin)], lh[i]);
 }
-// exclusive scan of the 2^c counters of one window (one block per window)
-__global__ void __launch_bounds__(1024) msm_scan_kernel(const u32 *counts, u32 *starts, u32 *cursor, int c) {
+// exclusive scan of the 2^bits counters of one window (one block per window)
+__global__ void __launch_bounds__(1024) msm_scan_kernel(const u32 *counts, u32 *starts, u32 *cursor, int bits) {
     __shared__ u32 part[1024];
-    const u64 base = (u64)blockIdx.x << c;
-    const u32 nb = 1u << c;
+    const u64 base = (u64)blockIdx.x << bits;
+    const u32 nb = 1u << bits;
     const u32 per = (nb + 1023) / 1024;
-    const u32 lo = threadIdx.x * per, hi = min(lo + per, nb);
+    const u32 lo = min(threadIdx.x * per, nb), hi = min(lo + per, nb);
     u32 s = 0;
     for (u32 b = lo; b < hi; b++) s += counts[base + b];
     part[threadIdx.x] = s;
@@ -391,17 +417,87 @@ __global__ void __launch_bounds__(1024) msm_scan_kernel(const u32 *counts, u32 *
         run += counts[base + b];
     }
 }
-__global__ void __launch_bounds__(256) msm_scatter_kernel(const u32 *scalars, u64 n, int c, int nwin, u32 *cursor, u32 *sorted) {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    u32 sc[8];
-    for (int k = 0; k < 8; k++) sc[k] = scalars[i * 8 + k];
-    for (int w = 0; w < nwin; w++) {
-        const u32 d = digit_of(sc, w, c);
-        if (d) {
-            const u32 pos = atomicAdd(&cursor[((u64)w << c) + d], 1u);
-            sorted[(u64)w * n + pos] = (u32)i;
+__global__ void __launch_bounds__(256) msm_coarse_part_kernel(const u32 *scalars, u64 n, SortGeo g, int w0, u32 *ccursor,
+                                                             u32 *pidx, u32 *pfine) {
+    extern __shared__ u32 lh[];   // [wgroup][2^hi] counters, then [wgroup][2^hi] global bases
+    const int nbin = 1 << g.hi, nw = min(g.wgroup, g.nwin - w0);
+    u32 *lbase = lh + g.wgroup * nbin;
+    for (int i = threadIdx.x; i < nw * nbin; i += 256) lh[i] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * MSM_TILE;
+    for (int k = 0; k < MSM_TILE / 256; k++) {   // phase A: how many of this tile go to each (window, coarse bin)
+        const u64 i = base + (u64)k * 256 + threadIdx.x;
+        if (i < n) {
+            u32 sc[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) sc[j] = scalars[i * 8 + j];
+            for (int w = 0; w < nw; w++) {
+                const u32 d = digit_of(sc, w0 + w, g.c);
+                if (d) atomicAdd(&lh[w * nbin + (d >> g.lo)], 1u);
+            }
         }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nw * nbin; i += 256) {   // one global reservation per (window, coarse bin) of the tile
+        const u32 cnt = lh[i];
+        lbase[i] = cnt ? atomicAdd(&ccursor[(u64)(w0 + i / nbin) * nbin + (i % nbin)], cnt) : 0u;
+        lh[i] = 0;
+    }
+    __syncthreads();
+    const u32 fmask = (1u << g.lo) - 1;
+    for (int k = 0; k < MSM_TILE / 256; k++) {   // phase B: rank inside the tile's share of the bin, write the pair
+        const u64 i = base + (u64)k * 256 + threadIdx.x;
+        if (i < n) {
+            u32 sc[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) sc[j] = scalars[i * 8 + j];
+            for (int w = 0; w < nw; w++) {
+                const u32 d = digit_of(sc, w0 + w, g.c);
+                if (d) {
+                    const int b = w * nbin + (d >> g.lo);
+                    const u32 pos = lbase[b] + atomicAdd(&lh[b], 1u);
+                    pidx[(u64)(w0 + w) * n + pos] = (u32)i;
+                    pfine[(u64)(w0 + w) * n + pos] = d & fmask;
+                }
+            }
+        }
+    }
+}
+// one workgroup per (window, coarse bin): its elements sit in [cstart, cstart + ccount) of the window's region
+__global__ void __launch_bounds__(1024) msm_fine_sort_kernel(const u32 *pidx, const u32 *pfine, u64 n, SortGeo g,
+                                                            const u32 *cstarts, const u32 *ccounts, u32 *sorted,
+                                                            u32 *starts, u32 *counts) {
+    __shared__ u32 cnt[1 << MSM_LO_MAX], cur[1 << MSM_LO_MAX], part[1024];
+    const int nbin = 1 << g.hi, nf = 1 << g.lo;
+    const u64 w = blockIdx.x / nbin, bin = blockIdx.x % nbin;
+    const u32 cs = cstarts[w * nbin + bin], cc = ccounts[w * nbin + bin];
+    const u32 *pi = pidx + w * n + cs, *pf = pfine + w * n + cs;
+    for (int i = threadIdx.x; i < nf; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < cc; i += 1024) atomicAdd(&cnt[pf[i]], 1u);
+    __syncthreads();
+    // exclusive scan of the nf (<= 1024) fine counters: one counter per thread
+    const u32 mine = (int)threadIdx.x < nf ? cnt[threadIdx.x] : 0u;
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const u32 v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < nf) {
+        const u32 excl = part[threadIdx.x] - mine;
+        cur[threadIdx.x] = excl;
+        const u64 bucket = (w << g.c) + ((u64)bin << g.lo) + threadIdx.x;
+        starts[bucket] = cs + excl;
+        counts[bucket] = mine;
+    }
+    __syncthreads();
+    u32 *out = sorted + w * n + cs;
+    for (u32 i = threadIdx.x; i < cc; i += 1024) {
+        const u32 pos = atomicAdd(&cur[pf[i]], 1u);
+        out[pos] = pi[i];
     }
 }
 
@@ -543,25 +639,41 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     if (c < 6) c = 6;                                // segments of 64 buckets need c >= 6
     const int nwin = (256 + c - 1) / c;              // any 256-bit scalar (the BN254 group order has 254 bits)
     const u64 nb = (u64)nwin << c;
-    u32 *d_counts = nullptr, *d_starts = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
+    u32 *d_counts = nullptr, *d_starts = nullptr, *d_sorted = nullptr;
     J *d_buckets = nullptr, *d_segs = nullptr, *d_wins = nullptr;
     uint4 *d_mont = nullptr;
     const u64 nseg = (1ULL << c) / MSM_SEG;
+    SortGeo g;
+    g.c = c;
+    g.lo = c < MSM_LO_MAX ? c : MSM_LO_MAX;
+    g.hi = c - g.lo;
+    g.nwin = nwin;
+    g.wgroup = nwin;
+    while ((size_t)g.wgroup * ((size_t)2 << g.hi) * sizeof(u32) > 48 * 1024 && g.wgroup > 1) g.wgroup = (g.wgroup + 1) / 2;
+    const u64 ncoarse = (u64)nwin << g.hi;
     ZP_HIP(ctx, hipSetDevice(ctx->device));
-    ZP_HIP(ctx, hipMalloc((void **)&d_counts, nb * 4 * 3));
+    // per-bucket counts/starts | coarse counts/starts/cursor | sorted indices + the coarse-partitioned (index, fine) pairs
+    ZP_HIP(ctx, hipMalloc((void **)&d_counts, (nb * 2 + ncoarse * 3) * 4));
     d_starts = d_counts + nb;
-    d_cursor = d_starts + nb;
-    ZP_HIP(ctx, hipMalloc((void **)&d_sorted, (u64)nwin * n * 4));
+    u32 *d_ccounts = d_starts + nb, *d_cstarts = d_ccounts + ncoarse, *d_ccursor = d_cstarts + ncoarse;
+    ZP_HIP(ctx, hipMalloc((void **)&d_sorted, (u64)nwin * n * 4 * 3));
+    u32 *d_pidx = d_sorted + (u64)nwin * n, *d_pfine = d_pidx + (u64)nwin * n;
     ZP_HIP(ctx, hipMalloc((void **)&d_mont, (u64)n * NV * 16));
     ZP_HIP(ctx, hipMalloc((void **)&d_buckets, (nb + nwin * nseg + nwin) * sizeof(J)));
     d_segs = d_buckets + nb;
     d_wins = d_segs + nwin * nseg;
-    ZP_HIP(ctx, hipMemsetAsync(d_counts, 0, nb * 4, ctx->stream));
-    const unsigned gb = (unsigned)((n + 255) / 256);
+    ZP_HIP(ctx, hipMemsetAsync(d_ccounts, 0, ncoarse * 4, ctx->stream));
+    const unsigned gb = (unsigned)((n + 255) / 256), gt = (unsigned)((n + MSM_TILE - 1) / MSM_TILE);
     hipLaunchKernelGGL(msm_to_mont_kernel<F>, dim3(gb), dim3(256), 0, ctx->stream, (const uint4 *)d_points, (u64)n, d_mont);
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const u32 *)d_scalars, (u64)n, c, nwin, d_counts);
-    hipLaunchKernelGGL(msm_scan_kernel, dim3(nwin), dim3(1024), 0, ctx->stream, d_counts, d_starts, d_cursor, c);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const u32 *)d_scalars, (u64)n, c, nwin, d_cursor, d_sorted);
+    const size_t lds1 = (size_t)g.wgroup * ((size_t)1 << g.hi) * sizeof(u32);
+    for (int w0 = 0; w0 < nwin; w0 += g.wgroup)
+        hipLaunchKernelGGL(msm_coarse_hist_kernel, dim3(gt), dim3(256), lds1, ctx->stream, (const u32 *)d_scalars, (u64)n, g, w0, d_ccounts);
+    hipLaunchKernelGGL(msm_scan_kernel, dim3(nwin), dim3(1024), 0, ctx->stream, d_ccounts, d_cstarts, d_ccursor, g.hi);
+    for (int w0 = 0; w0 < nwin; w0 += g.wgroup)
+        hipLaunchKernelGGL(msm_coarse_part_kernel, dim3(gt), dim3(256), 2 * lds1, ctx->stream, (const u32 *)d_scalars, (u64)n, g, w0,
+                           d_ccursor, d_pidx, d_pfine);
+    hipLaunchKernelGGL(msm_fine_sort_kernel, dim3((unsigned)ncoarse), dim3(1024), 0, ctx->stream, d_pidx, d_pfine, (u64)n, g,
+                       d_cstarts, d_ccounts, d_sorted, d_starts, d_counts);
     hipLaunchKernelGGL(msm_bucket_kernel<F>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const uint4 *)d_mont, (u64)n, c, nwin, d_starts, d_counts, d_sorted, d_buckets);
     hipLaunchKernelGGL(msm_segment_kernel<F>, dim3((unsigned)((nwin * nseg + 63) / 64)), dim3(64), 0, ctx->stream, d_buckets, c, nwin, d_segs);
