@@ -356,7 +356,9 @@ __device__ __forceinline__ u32 digit_of(const u32 *sc, int w, int c) {
 // ---- 1. sort of the point indices by window digit, two levels so that every global write lands next to its
 // neighbours.  (The first version was one atomic counting sort: 4-byte writes to random addresses, 16x write
 // amplification and a returning global atomic per (point, window) -- as slow as the bucket sums themselves.)
-//   coarse digit = top `hi` bits of the window digit, fine digit = low `lo` bits (lo <= 10)
+//   coarse digit = LOW `hi` bits of the window digit, fine digit = the `lo` bits above them (lo <= 10): skewed scalars
+//   (many equal or tiny values, the short top window) then land in coarse bins that hold a single digit each, which
+//   the fine stage handles with one LDS atomic per wave instead of 64 colliding ones
 //   1a. msm_coarse_hist : LDS histogram per 4096-point tile -> counts[window][coarse]
 //   1b. msm_scan        : exclusive scan per window -> coarse starts
 //   1c. msm_coarse_part : per tile, LDS ranks + one global reservation per (window, coarse bin) -> (index, fine
@@ -382,7 +384,7 @@ __global__ void __launch_bounds__(256) msm_coarse_hist_kernel(const u32 *scalars
             for (int j = 0; j < 8; j++) sc[j] = scalars[i * 8 + j];
             for (int w = 0; w < nw; w++) {
                 const u32 d = digit_of(sc, w0 + w, g.c);
-                if (d) atomicAdd(&lh[w * nbin + (d >> g.lo)], 1u);
+                if (d) atomicAdd(&lh[w * nbin + (d & (nbin - 1))], 1u);
             }
         }
     }
@@ -433,7 +435,7 @@ __global__ void __launch_bounds__(256) msm_coarse_part_kernel(const u32 *scalars
             for (int j = 0; j < 8; j++) sc[j] = scalars[i * 8 + j];
             for (int w = 0; w < nw; w++) {
                 const u32 d = digit_of(sc, w0 + w, g.c);
-                if (d) atomicAdd(&lh[w * nbin + (d >> g.lo)], 1u);
+                if (d) atomicAdd(&lh[w * nbin + (d & (nbin - 1))], 1u);
             }
         }
     }
@@ -444,7 +446,6 @@ __global__ void __launch_bounds__(256) msm_coarse_part_kernel(const u32 *scalars
         lh[i] = 0;
     }
     __syncthreads();
-    const u32 fmask = (1u << g.lo) - 1;
     for (int k = 0; k < MSM_TILE / 256; k++) {   // phase B: rank inside the tile's share of the bin, write the pair
         const u64 i = base + (u64)k * 256 + threadIdx.x;
         if (i < n) {
@@ -454,30 +455,68 @@ __global__ void __launch_bounds__(256) msm_coarse_part_kernel(const u32 *scalars
             for (int w = 0; w < nw; w++) {
                 const u32 d = digit_of(sc, w0 + w, g.c);
                 if (d) {
-                    const int b = w * nbin + (d >> g.lo);
+                    const int b = w * nbin + (d & (nbin - 1));
                     const u32 pos = lbase[b] + atomicAdd(&lh[b], 1u);
                     pidx[(u64)(w0 + w) * n + pos] = (u32)i;
-                    pfine[(u64)(w0 + w) * n + pos] = d & fmask;
+                    pfine[(u64)(w0 + w) * n + pos] = d >> g.hi;
                 }
             }
         }
     }
 }
-// one workgroup per (window, coarse bin): its elements sit in [cstart, cstart + ccount) of the window's region
-__global__ void __launch_bounds__(1024) msm_fine_sort_kernel(const u32 *pidx, const u32 *pfine, u64 n, SortGeo g,
-                                                            const u32 *cstarts, const u32 *ccounts, u32 *sorted,
-                                                            u32 *starts, u32 *counts) {
-    __shared__ u32 cnt[1 << MSM_LO_MAX], cur[1 << MSM_LO_MAX], part[1024];
+// ---- 1d. fine stage, slice-parallel: a coarse bin is cut into slices of MSM_FSLICE elements, one workgroup each, so
+// that a bin holding millions of elements (skewed scalars) is sorted by many workgroups.
+//   msm_slices      : slice list (coarse bin, slice number) per (window, coarse bin)
+//   msm_fine_hist   : LDS histogram of a slice by fine digit -> counts[bucket] (global atomics, one per digit present)
+//   msm_fine_scan   : per coarse bin: exclusive scan of its <= 1024 bucket counts -> starts[bucket], cursor[bucket]
+//   msm_fine_scatter: per slice: reserve cursor[bucket] once per digit present, rank in LDS, write the indices
+// A wave whose 64 elements carry one and the same digit (the skewed case) issues one LDS atomic, not 64 colliding ones.
+#define MSM_FSLICE 8192
+__global__ void __launch_bounds__(256) msm_slices_kernel(const u32 *ccounts, u32 ncoarse, u32 *slice_count, uint2 *slices) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ncoarse) return;
+    const u32 cc = ccounts[i];
+    const u32 nsl = (cc + MSM_FSLICE - 1) / MSM_FSLICE;
+    if (!nsl) return;
+    const u32 base = atomicAdd(slice_count, nsl);
+    for (u32 s = 0; s < nsl; s++) slices[base + s] = make_uint2(i, s);
+}
+// LDS histogram of one slice by fine digit (cnt must be zero on entry, nf entries)
+__device__ __forceinline__ void slice_hist(const u32 *pf, u32 lo, u32 hi, u32 *cnt) {
+    const int lane = threadIdx.x & 63;
+    for (u32 i = lo + threadIdx.x; i < hi; i += 256) {
+        const u32 f = pf[i];
+        const u64 act = __ballot(1);
+        if (__ballot(f == (u32)__builtin_amdgcn_readfirstlane((int)f)) == act) {   // one digit in the whole wave
+            if (lane == __ffsll((long long)act) - 1) atomicAdd(&cnt[f], (u32)__popcll(act));
+        } else {
+            atomicAdd(&cnt[f], 1u);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) msm_fine_hist_kernel(const u32 *pfine, u64 n, SortGeo g, const uint2 *slices,
+                                                           const u32 *cstarts, const u32 *ccounts, u32 *counts) {
+    __shared__ u32 cnt[1 << MSM_LO_MAX];
+    const int nbin = 1 << g.hi, nf = 1 << g.lo;
+    const uint2 sl = slices[blockIdx.x];
+    const u64 w = sl.x / nbin, bin = sl.x % nbin;
+    const u32 cs = cstarts[sl.x], cc = ccounts[sl.x];
+    const u32 lo = sl.y * MSM_FSLICE, hi = min(lo + (u32)MSM_FSLICE, cc);
+    for (int i = threadIdx.x; i < nf; i += 256) cnt[i] = 0;
+    __syncthreads();
+    slice_hist(pfine + w * n + cs, lo, hi, cnt);
+    __syncthreads();
+    for (int f = threadIdx.x; f < nf; f += 256)
+        if (cnt[f]) atomicAdd(&counts[(w << g.c) + ((u64)f << g.hi) + bin], cnt[f]);
+}
+__global__ void __launch_bounds__(1024) msm_fine_scan_kernel(SortGeo g, const u32 *cstarts, const u32 *counts, u32 *starts,
+                                                            u32 *cursor) {
+    __shared__ u32 part[1024];
     const int nbin = 1 << g.hi, nf = 1 << g.lo;
     const u64 w = blockIdx.x / nbin, bin = blockIdx.x % nbin;
-    const u32 cs = cstarts[w * nbin + bin], cc = ccounts[w * nbin + bin];
-    const u32 *pi = pidx + w * n + cs, *pf = pfine + w * n + cs;
-    for (int i = threadIdx.x; i < nf; i += 1024) cnt[i] = 0;
-    __syncthreads();
-    for (u32 i = threadIdx.x; i < cc; i += 1024) atomicAdd(&cnt[pf[i]], 1u);
-    __syncthreads();
-    // exclusive scan of the nf (<= 1024) fine counters: one counter per thread
-    const u32 mine = (int)threadIdx.x < nf ? cnt[threadIdx.x] : 0u;
+    const u32 cs = cstarts[blockIdx.x];
+    const u64 bucket = (w << g.c) + ((u64)threadIdx.x << g.hi) + bin;
+    const u32 mine = (int)threadIdx.x < nf ? counts[bucket] : 0u;
     part[threadIdx.x] = mine;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
@@ -487,17 +526,46 @@ __global__ void __launch_bounds__(1024) msm_fine_sort_kernel(const u32 *pidx, co
         __syncthreads();
     }
     if ((int)threadIdx.x < nf) {
-        const u32 excl = part[threadIdx.x] - mine;
-        cur[threadIdx.x] = excl;
-        const u64 bucket = (w << g.c) + ((u64)bin << g.lo) + threadIdx.x;
-        starts[bucket] = cs + excl;
-        counts[bucket] = mine;
+        const u32 at = cs + part[threadIdx.x] - mine;
+        starts[bucket] = at;
+        cursor[bucket] = at;
+    }
+}
+__global__ void __launch_bounds__(256) msm_fine_scatter_kernel(const u32 *pidx, const u32 *pfine, u64 n, SortGeo g,
+                                                              const uint2 *slices, const u32 *cstarts, const u32 *ccounts,
+                                                              u32 *cursor, u32 *sorted) {
+    __shared__ u32 cnt[1 << MSM_LO_MAX], lbase[1 << MSM_LO_MAX];
+    const int nbin = 1 << g.hi, nf = 1 << g.lo;
+    const uint2 sl = slices[blockIdx.x];
+    const u64 w = sl.x / nbin, bin = sl.x % nbin;
+    const u32 cs = cstarts[sl.x], cc = ccounts[sl.x];
+    const u32 lo = sl.y * MSM_FSLICE, hi = min(lo + (u32)MSM_FSLICE, cc);
+    const u32 *pi = pidx + w * n + cs, *pf = pfine + w * n + cs;
+    for (int i = threadIdx.x; i < nf; i += 256) cnt[i] = 0;
+    __syncthreads();
+    slice_hist(pf, lo, hi, cnt);
+    __syncthreads();
+    for (int f = threadIdx.x; f < nf; f += 256) {   // one global reservation per digit present in the slice
+        const u32 k = cnt[f];
+        lbase[f] = k ? atomicAdd(&cursor[(w << g.c) + ((u64)f << g.hi) + bin], k) : 0u;
+        cnt[f] = 0;
     }
     __syncthreads();
-    u32 *out = sorted + w * n + cs;
-    for (u32 i = threadIdx.x; i < cc; i += 1024) {
-        const u32 pos = atomicAdd(&cur[pf[i]], 1u);
-        out[pos] = pi[i];
+    u32 *out = sorted + w * n;
+    const int lane = threadIdx.x & 63;
+    for (u32 i = lo + threadIdx.x; i < hi; i += 256) {
+        const u32 f = pf[i];
+        const u64 act = __ballot(1);
+        u32 rank;
+        if (__ballot(f == (u32)__builtin_amdgcn_readfirstlane((int)f)) == act) {
+            u32 base = 0;
+            if (lane == __ffsll((long long)act) - 1) base = atomicAdd(&cnt[f], (u32)__popcll(act));
+            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+            rank = base + (u32)__popcll(act & ((1ULL << lane) - 1));
+        } else {
+            rank = atomicAdd(&cnt[f], 1u);
+        }
+        out[lbase[f] + rank] = pi[i];
     }
 }
 
@@ -544,14 +612,32 @@ __device__ __forceinline__ jacT<F> madd_packed(const jacT<F> &acc, const uint4 *
     if (f_is_zero(x) && f_is_zero(y)) return acc;
     return jac_madd(acc, x, y);
 }
+// Buckets with more than MSM_HEAVY points are not summed by one lane: real scalars are not uniform (the top window of
+// a 254-bit scalar has 2-12 significant bits, witnesses are full of small values), and one lane walking a million points
+// would take seconds.  Such a bucket is cut into chunks of MSM_HCHUNK points, each summed by a whole workgroup
+// (msm_heavy_kernel), and the chunk sums are added per bucket (msm_heavy_combine_kernel).
+#define MSM_HEAVY 256
+#define MSM_HCHUNK 16384
+struct HeavyLists {
+    u32 *counters;   // [0] = chunks appended, [1] = heavy buckets appended
+    uint2 *chunks;   // (bucket id, chunk number)
+    uint4 *heavy;    // (bucket id, first chunk slot, number of chunks, 0)
+};
 template <class F>
 __global__ void __launch_bounds__(256) msm_bucket_kernel(const uint4 *mont, u64 n, int c, int nwin, const u32 *starts,
-                                                        const u32 *counts, const u32 *sorted, jacT<F> *buckets) {
+                                                        const u32 *counts, const u32 *sorted, jacT<F> *buckets, HeavyLists hl) {
     constexpr int NV = FT<F>::WORDS / 2;
     const u64 id = (u64)blockIdx.x * 256 + threadIdx.x;
     if (id >= ((u64)nwin << c)) return;
     const u64 w = id >> c;
     const u32 st = starts[id], cnt = counts[id];
+    if (cnt > MSM_HEAVY) {
+        const u32 nch = (cnt + MSM_HCHUNK - 1) / MSM_HCHUNK;
+        const u32 slot = atomicAdd(&hl.counters[0], nch);
+        for (u32 k = 0; k < nch; k++) hl.chunks[slot + k] = make_uint2((u32)id, k);
+        hl.heavy[atomicAdd(&hl.counters[1], 1u)] = make_uint4((u32)id, slot, nch, 0u);
+        return;
+    }
     const u32 *idx = sorted + w * n + st;
     jacT<F> acc = jac_inf<F>();
     if (cnt) {
@@ -575,6 +661,48 @@ __global__ void __launch_bounds__(256) msm_bucket_kernel(const uint4 *mont, u64 
         }
     }
     buckets[id] = acc;
+}
+// one workgroup per chunk of a heavy bucket: lane t sums points t, t+256, ... of the chunk, LDS tree over the lanes
+template <class F>
+__global__ void __launch_bounds__(256) msm_heavy_kernel(const uint4 *mont, u64 n, int c, const u32 *starts, const u32 *counts,
+                                                       const u32 *sorted, HeavyLists hl, jacT<F> *partial) {
+    constexpr int NV = FT<F>::WORDS / 2;
+    __shared__ jacT<F> sh[256];
+    const uint2 ch = hl.chunks[blockIdx.x];
+    const u64 id = ch.x, w = id >> c;
+    const u32 cnt = counts[id];
+    const u32 lo = ch.y * MSM_HCHUNK, hi = min(lo + (u32)MSM_HCHUNK, cnt);
+    const u32 *idx = sorted + w * n + starts[id];
+    jacT<F> acc = jac_inf<F>();
+    for (u32 k = lo + threadIdx.x; k < hi; k += 256) {
+        const u64 pi = idx[k];
+        uint4 q[NV];
+#pragma unroll
+        for (int j = 0; j < NV; j++) q[j] = mont[pi * NV + j];
+        acc = madd_packed<F>(acc, q);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = jac_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+// one wave per heavy bucket: lane t adds chunk sums t, t+64, ..., LDS tree over the lanes
+template <class F>
+__global__ void __launch_bounds__(64) msm_heavy_combine_kernel(HeavyLists hl, u32 nheavy, const jacT<F> *partial, jacT<F> *buckets) {
+    __shared__ jacT<F> sh[64];
+    const uint4 h = hl.heavy[blockIdx.x];
+    jacT<F> acc = jac_inf<F>();
+    for (u32 k = threadIdx.x; k < h.z; k += 64) acc = jac_add(acc, partial[h.y + k]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = jac_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) buckets[h.x] = sh[0];
 }
 // ---- 3a. per segment of SEG buckets: sum_{b in seg} b * B_b
 #define MSM_SEG 64
@@ -636,7 +764,9 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     int c = 4;
     while (c < 16 && (1ULL << (c + 2)) <= n) c++;   // ~4 points per bucket up to c = 16
     while (c < 20 && (1ULL << (c + 7)) <= n) c++;   // wider windows only while buckets keep >= 64 points
+    if (ctx->tune_msm_c > 0) c = ctx->tune_msm_c;    // experiment knob
     if (c < 6) c = 6;                                // segments of 64 buckets need c >= 6
+    if (c > 22) c = 22;
     const int nwin = (256 + c - 1) / c;              // any 256-bit scalar (the BN254 group order has 254 bits)
     const u64 nb = (u64)nwin << c;
     u32 *d_counts = nullptr, *d_starts = nullptr, *d_sorted = nullptr;
@@ -653,16 +783,20 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     const u64 ncoarse = (u64)nwin << g.hi;
     ZP_HIP(ctx, hipSetDevice(ctx->device));
     // per-bucket counts/starts | coarse counts/starts/cursor | sorted indices + the coarse-partitioned (index, fine) pairs
-    ZP_HIP(ctx, hipMalloc((void **)&d_counts, (nb * 2 + ncoarse * 3) * 4));
+    const u64 max_slices = (u64)nwin * n / MSM_FSLICE + ncoarse + 1;
+    ZP_HIP(ctx, hipMalloc((void **)&d_counts, (nb * 3 + ncoarse * 3 + 8 + max_slices * 2) * 4));
     d_starts = d_counts + nb;
-    u32 *d_ccounts = d_starts + nb, *d_cstarts = d_ccounts + ncoarse, *d_ccursor = d_cstarts + ncoarse;
+    u32 *d_fcursor = d_starts + nb;
+    u32 *d_ccounts = d_fcursor + nb, *d_cstarts = d_ccounts + ncoarse, *d_ccursor = d_cstarts + ncoarse;
+    u32 *d_slice_count = d_ccursor + ncoarse;
+    uint2 *d_slices = (uint2 *)(((uintptr_t)(d_slice_count + 4) + 7) & ~(uintptr_t)7);
     ZP_HIP(ctx, hipMalloc((void **)&d_sorted, (u64)nwin * n * 4 * 3));
     u32 *d_pidx = d_sorted + (u64)nwin * n, *d_pfine = d_pidx + (u64)nwin * n;
     ZP_HIP(ctx, hipMalloc((void **)&d_mont, (u64)n * NV * 16));
     ZP_HIP(ctx, hipMalloc((void **)&d_buckets, (nb + nwin * nseg + nwin) * sizeof(J)));
     d_segs = d_buckets + nb;
     d_wins = d_segs + nwin * nseg;
-    ZP_HIP(ctx, hipMemsetAsync(d_ccounts, 0, ncoarse * 4, ctx->stream));
+    ZP_HIP(ctx, hipMemsetAsync(d_ccounts, 0, (ncoarse * 3 + 4) * 4, ctx->stream));   // coarse counters + slice count
     const unsigned gb = (unsigned)((n + 255) / 256), gt = (unsigned)((n + MSM_TILE - 1) / MSM_TILE);
     hipLaunchKernelGGL(msm_to_mont_kernel<F>, dim3(gb), dim3(256), 0, ctx->stream, (const uint4 *)d_points, (u64)n, d_mont);
     const size_t lds1 = (size_t)g.wgroup * ((size_t)1 << g.hi) * sizeof(u32);
@@ -672,10 +806,46 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     for (int w0 = 0; w0 < nwin; w0 += g.wgroup)
         hipLaunchKernelGGL(msm_coarse_part_kernel, dim3(gt), dim3(256), 2 * lds1, ctx->stream, (const u32 *)d_scalars, (u64)n, g, w0,
                            d_ccursor, d_pidx, d_pfine);
-    hipLaunchKernelGGL(msm_fine_sort_kernel, dim3((unsigned)ncoarse), dim3(1024), 0, ctx->stream, d_pidx, d_pfine, (u64)n, g,
-                       d_cstarts, d_ccounts, d_sorted, d_starts, d_counts);
+    // fine stage: slice list on the device, its length read back (one of the two host round trips of a run)
+    hipLaunchKernelGGL(msm_slices_kernel, dim3((unsigned)((ncoarse + 255) / 256)), dim3(256), 0, ctx->stream, d_ccounts, (u32)ncoarse,
+                       d_slice_count, d_slices);
+    u32 nslices = 0;
+    hipError_t he = hipMemcpyAsync(&nslices, d_slice_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(d_counts, 0, nb * 4, ctx->stream);
+    if (he == hipSuccess && nslices)
+        hipLaunchKernelGGL(msm_fine_hist_kernel, dim3(nslices), dim3(256), 0, ctx->stream, d_pfine, (u64)n, g, d_slices, d_cstarts,
+                           d_ccounts, d_counts);
+    if (he == hipSuccess)
+        hipLaunchKernelGGL(msm_fine_scan_kernel, dim3((unsigned)ncoarse), dim3(1024), 0, ctx->stream, g, d_cstarts, d_counts, d_starts,
+                           d_fcursor);
+    if (he == hipSuccess && nslices)
+        hipLaunchKernelGGL(msm_fine_scatter_kernel, dim3(nslices), dim3(256), 0, ctx->stream, d_pidx, d_pfine, (u64)n, g, d_slices,
+                           d_cstarts, d_ccounts, d_fcursor, d_sorted);
+    // heavy-bucket lists: at most nwin*n/MSM_HEAVY heavy buckets and nwin*n/MSM_HCHUNK + that many chunks
+    const u64 max_heavy = (u64)nwin * n / MSM_HEAVY + 1, max_chunks = (u64)nwin * n / MSM_HCHUNK + max_heavy + 1;
+    HeavyLists hl;
+    u32 *d_hl = nullptr;
+    ZP_HIP(ctx, hipMalloc((void **)&d_hl, 16 + max_chunks * sizeof(uint2) + max_heavy * sizeof(uint4)));
+    hl.counters = d_hl;
+    hl.heavy = (uint4 *)(d_hl + 4);
+    hl.chunks = (uint2 *)(hl.heavy + max_heavy);
+    ZP_HIP(ctx, hipMemsetAsync(d_hl, 0, 16, ctx->stream));
     hipLaunchKernelGGL(msm_bucket_kernel<F>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const uint4 *)d_mont, (u64)n, c, nwin, d_starts, d_counts, d_sorted, d_buckets);
+                       (const uint4 *)d_mont, (u64)n, c, nwin, d_starts, d_counts, d_sorted, d_buckets, hl);
+    u32 hcnt[2] = {0, 0};
+    if (he == hipSuccess) he = hipMemcpyAsync(hcnt, d_hl, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+    J *d_partial = nullptr;
+    if (he == hipSuccess && hcnt[0]) {
+        he = hipMalloc((void **)&d_partial, (u64)hcnt[0] * sizeof(J));
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(msm_heavy_kernel<F>, dim3(hcnt[0]), dim3(256), 0, ctx->stream, (const uint4 *)d_mont, (u64)n, c, d_starts,
+                               d_counts, d_sorted, hl, d_partial);
+            hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hcnt[1]), dim3(64), 0, ctx->stream, hl, hcnt[1], d_partial,
+                               d_buckets);
+        }
+    }
     hipLaunchKernelGGL(msm_segment_kernel<F>, dim3((unsigned)((nwin * nseg + 63) / 64)), dim3(64), 0, ctx->stream, d_buckets, c, nwin, d_segs);
     hipLaunchKernelGGL(msm_window_kernel<F>, dim3(nwin), dim3(128), 0, ctx->stream, d_segs, (int)nseg, d_wins);
     hipError_t le = hipGetLastError();
@@ -686,6 +856,9 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     (void)hipFree(d_sorted);
     (void)hipFree(d_mont);
     (void)hipFree(d_buckets);
+    (void)hipFree(d_hl);
+    if (d_partial) (void)hipFree(d_partial);
+    ZP_HIP(ctx, he);
     ZP_HIP(ctx, le);
     ZP_HIP(ctx, ce);
     ZP_HIP(ctx, se);

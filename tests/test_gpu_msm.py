@@ -45,6 +45,31 @@ def test_msm_in_several_runs_matches_oracle(prover, table):
         prover.set_tuning("msm_chunk_log", 0)
 
 
+@pytest.mark.parametrize("kind", ["ones", "tiny", "two_values", "top_heavy"])
+def test_msm_skewed_scalars_take_the_heavy_bucket_path(prover, table, kind):
+    """non-uniform scalars put thousands of points into one bucket: such buckets are summed by whole workgroups"""
+    rnd = random.Random(31 + len(kind))
+    n = 3000
+    pts = [table[rnd.randrange(len(table))] for _ in range(n)]
+    if kind == "ones":
+        scs = [1] * n
+    elif kind == "tiny":
+        scs = [rnd.randrange(0, 4) for _ in range(n)]
+    elif kind == "two_values":
+        scs = [rnd.choice([B.R - 1, 12345678901234567890]) for _ in range(n)]
+    else:   # random low bits, identical top bits: every window above the first is one heavy bucket
+        scs = [(0x2F << 248) | (0xABCDEF << 100) | rnd.randrange(0, 1 << 20) for _ in range(n)]
+    assert prover.msm_bn254(pts, scs) == B.msm(pts, scs)
+
+
+def test_msm_g2_heavy_bucket_path(prover, table_g2):
+    rnd = random.Random(5)
+    n = 700
+    pts = [table_g2[rnd.randrange(len(table_g2))] for _ in range(n)]
+    scs = [rnd.randrange(1, 3) for _ in range(n)]
+    assert prover.msm_bn254_g2(pts, scs) == B.msm_g2(pts, scs)
+
+
 def test_msm_infinity_inputs_and_cancellation(prover, table):
     p = table[0]
     neg = (p[0], B.Q - p[1])

@@ -5,6 +5,7 @@ import numpy as np
 from eigen_zeth_amd.native import Prover, DeviceBuffer
 from eigen_zeth_amd.service import bn254
 p = Prover(0)
+if os.environ.get('ZP_MSM_C'): p.set_tuning('msm_c', int(os.environ['ZP_MSM_C']))
 rnd = random.Random(1)
 table = [bn254.g1_mul(rnd.randrange(1, bn254.R)) for _ in range(64)]
 tab = np.array([[(c >> (32 * k)) & 0xFFFFFFFF for c in pt for k in range(8)] for pt in table], dtype=np.uint32)
@@ -12,7 +13,7 @@ for logn in [int(a) for a in sys.argv[1:]] or [16, 20, 22]:
     n = 1 << logn
     g = np.random.default_rng(logn)
     pts = tab[g.integers(0, 64, size=n)]
-    scs = g.integers(0, 1 << 32, size=(n, 8), dtype=np.uint64).astype(np.uint32); scs[:, 7] &= 0x0FFFFFFF
+    scs = g.integers(0, 1 << 32, size=(n, 8), dtype=np.uint64).astype(np.uint32); scs[:, 7] &= 0x1FFFFFFF   # uniform 253-bit scalars (< r): the top window is a few heavy buckets
     d_p, d_s = DeviceBuffer(p, pts.size // 2), DeviceBuffer(p, scs.size // 2)
     p._chk(p.lib.zp_h2d(p.ctx, d_p.ptr, pts.ctypes.data, pts.nbytes)); p._chk(p.lib.zp_h2d(p.ctx, d_s.ptr, scs.ctypes.data, scs.nbytes))
     out = (C.c_uint32 * 16)()
@@ -31,7 +32,7 @@ for logn in [int(a) for a in os.environ.get("ZP_MSM_G2", "").split()]:
     t2 = np.array([[(c >> (32 * k)) & 0xFFFFFFFF for c in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]) for k in range(8)] for pt in tab2], dtype=np.uint32)
     g = np.random.default_rng(logn)
     pts = t2[g.integers(0, 16, size=n)]
-    scs = g.integers(0, 1 << 32, size=(n, 8), dtype=np.uint64).astype(np.uint32); scs[:, 7] &= 0x0FFFFFFF
+    scs = g.integers(0, 1 << 32, size=(n, 8), dtype=np.uint64).astype(np.uint32); scs[:, 7] &= 0x1FFFFFFF
     d_p, d_s = DeviceBuffer(p, pts.size // 2), DeviceBuffer(p, scs.size // 2)
     p._chk(p.lib.zp_h2d(p.ctx, d_p.ptr, pts.ctypes.data, pts.nbytes)); p._chk(p.lib.zp_h2d(p.ctx, d_s.ptr, scs.ctypes.data, scs.nbytes))
     out = (C.c_uint32 * 32)()
