@@ -146,6 +146,21 @@ def main():
         except Exception as e:
             pipe = {"error": repr(e)}
 
+    batch_multi = None
+    if world > 1 and not args.no_pipeline:
+        # BASELINE metric (i) on N GPUs: independent chunk proofs shard over the ranks with no exchange; every rank
+        # proves its own 16-chunk batch (weak scaling) and the slowest rank's wall-clock is reported
+        try:
+            r = engine_batch_probe(16, args.stark_logn, "chunk64", device=local, tag="_r%d" % rank)
+            tb = torch.tensor([r["wall_s"]], dtype=torch.float64, device=dev)
+            err = None
+        except Exception as e:
+            tb = torch.tensor([-1.0], dtype=torch.float64, device=dev)
+            err = repr(e)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        batch_multi = {"chunks_total": 16 * world, "chunks_per_gpu": 16, "wall_s_max_over_ranks": float(tb.item()),
+                       "rank0_error": err}
+
     if rank == 0:
         plan = prover.ntt_plan(logn)
         npass = max(1, len(plan["passes"]))
@@ -204,6 +219,8 @@ def main():
         }
         if pipe is not None:
             out["pipeline"] = pipe
+        if batch_multi is not None:
+            out["batch_proof"] = {"batch": batch_multi}
         if world == 1 and not args.no_pipeline:
             try:
                 out["batch_proof"] = batch_proof_probe(args.stark_logn)
@@ -322,15 +339,15 @@ def batch_proof_probe(logn, air_name="chunk64"):
     return out
 
 
-def engine_batch_probe(K, logn, air_name):
+def engine_batch_probe(K, logn, air_name, device=0, tag=""):
     """K blocks -> K chunk STARKs -> aggregate -> Groth16 wrap on one GPU through service/engine.py (no gRPC);
     second of two runs (the first builds the local CRS and warms the buffer pools)"""
     import tempfile
     from eigen_zeth_amd.service.engine import Engine, EngineConfig
     from eigen_zeth_amd.service.server import default_backend_factory
     cfg = EngineConfig(air=air_name, logn=logn, n_queries=32, groth16_logm=8,
-                       crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_bench"), witness_threads=16)
-    eng = Engine(default_backend_factory(0), cfg)
+                       crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_bench" + tag), witness_threads=16)
+    eng = Engine(default_backend_factory(device), cfg)
     eng.groth16_keys()
     res = {}
     for rep in range(2):
