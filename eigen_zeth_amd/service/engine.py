@@ -30,7 +30,7 @@ from . import groth16
 class EngineConfig:
     def __init__(self, air="chunk64", logn=12, logb=1, chunks_per_block=1, n_queries=16, fri_logf=3, fri_final_log=5,
                  groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
-                 witness_threads=8, prover_streams=3):
+                 witness_threads=8, prover_streams=4):
         self.air, self.logn, self.logb = air, logn, logb
         self.chunks_per_block, self.n_queries = chunks_per_block, n_queries
         self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
