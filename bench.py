@@ -92,6 +92,8 @@ def main():
     logn, cols = args.logn, args.cols
     N = 1 << logn
     prover = Prover(local, stream=torch.cuda.current_stream().cuda_stream)
+    if os.environ.get("ZP_NTT_CHUNK_LOG"):
+        prover.set_tuning("ntt_chunk_log", int(os.environ["ZP_NTT_CHUNK_LOG"]))
     x = random_field_tensor(torch, (cols, N), dev, 0xE16E2E70 + 4 + rank)
 
     def barrier():
@@ -172,7 +174,7 @@ def main():
         dom = max(by_kind, key=lambda k: sum(by_kind[k])) if by_kind else 0
         launches = len(by_kind.get(dom, []))
         avg_ms = sum(by_kind[dom]) / launches if launches else float("nan")
-        chunk_cols = min(cols, max(1, (1 << 28) >> logn))
+        chunk_cols = min(cols, max(1, (1 << int(os.environ.get("ZP_NTT_CHUNK_LOG", "28"))) >> logn))
         # algorithmic bytes of one launch: SURVEY 8d gives 16*N bytes per column transform (ideal single
         # pass); a launch does one of the `npass` passes over chunk_cols columns -> 16*N*chunk/npass
         alg_bytes = 16.0 * N * chunk_cols / npass

@@ -644,7 +644,7 @@ int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, b
     }
 
     // chunk the columns so that each ping-pong scratch buffer stays <= 2 GiB
-    const u64 cap_elems = 1ULL << 28;
+    const u64 cap_elems = 1ULL << (ctx->tune_ntt_chunk_log > 0 ? ctx->tune_ntt_chunk_log : 28);
     int wc = (int)(cap_elems >> logn);
     if (wc < 1) wc = 1;
     if (wc > W) wc = W;
@@ -714,7 +714,7 @@ int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn,
     CosetTable *ct;
     ZP_TRY(zpi_get_coset(ctx, logn, shift, 1, &ct));
     // columns go in chunks so that the scaled-coefficient buffer stays <= 2 GiB
-    int wc = (int)((1ULL << 28) >> logn);
+    int wc = (int)((1ULL << (ctx->tune_ntt_chunk_log > 0 ? ctx->tune_ntt_chunk_log : 28)) >> logn);
     if (wc < 1) wc = 1;
     if (wc > W) wc = W;
     u64 *scaled = nullptr;
