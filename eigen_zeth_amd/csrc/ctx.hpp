@@ -63,6 +63,7 @@ struct zp_ctx {
     int num_cu = 256;
     // experiment knobs (zp_set_tuning): not part of the stable surface
     int tune_logt = 4, tune_tpw = 4, tune_logt9 = 5;
+    int tune_merkle_coop_log = 0; // 0 = 15: tree levels with <= 2^15 nodes go to the 12-lanes-per-node subtree kernel
     int tune_ntt_chunk_log = 0;   // 0 = 28: columns per launch such that a ping-pong scratch buffer is <= 2 GiB
     int tune_msm_c = 0;           // 0 = window width chosen from n
     int tune_msm_chunk_log = 0;   // 0 = default (2^24 points per Pippenger run)

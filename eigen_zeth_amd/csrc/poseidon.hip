@@ -253,7 +253,7 @@ int32_t tree_levels(zp_ctx *ctx, u64 *tree, size_t M) {
     while (cnt > 1) {
         u64 *next = prev + cnt * 4;
         const size_t half = cnt >> 1;
-        if (cnt <= ((size_t)1 << 15)) {
+        if (cnt <= ((size_t)1 << (ctx->tune_merkle_coop_log > 0 ? ctx->tune_merkle_coop_log : 15))) {
             int lg = 0;
             while (((size_t)1 << lg) < cnt) lg++;
             const int nlev = lg < 7 ? lg : 7;
