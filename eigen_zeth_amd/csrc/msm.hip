@@ -338,7 +338,9 @@ FQ_HD jacT<F> jac_add(const jacT<F> &p, const jacT<F> &q) {
 template <class F>
 FQ_HD jacT<F> jac_mul_small(const jacT<F> &p, u32 k) {  // k * p by double-and-add (k < 2^32)
     jacT<F> acc = jac_inf<F>();
-    for (int i = 31; i >= 0; i--) {
+    int top = 31;
+    while (top > 0 && !((k >> top) & 1)) top--;   // skip the leading zero bits (doublings of the point at infinity)
+    for (int i = top; i >= 0; i--) {
         acc = jac_dbl(acc);
         if ((k >> i) & 1) acc = jac_add(acc, p);
     }
