@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--stark-logn", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
+    ap.add_argument("--stage-roofline", action="store_true",
+                    help="cpu_baseline leg also times every hot-path stage on GPU and CPU restatement (tools/stage_roofline.py)")
     args = ap.parse_args()
 
     import torch
@@ -234,6 +236,15 @@ def main():
                 out["cpu_baseline"]["stark"] = cpu_stark_baseline(min(args.stark_logn, 16))
             except Exception as e:
                 out["cpu_baseline"]["stark"] = {"error": repr(e)}
+            if args.stage_roofline:
+                try:
+                    import types
+                    from oracle import oracle as O, naive_bn254 as B1
+                    from oracle.stark_cpu import CpuBackend
+                    from tools import stage_roofline
+                    out["cpu_baseline"]["stages"] = stage_roofline.run(22, 32, cpu=types.SimpleNamespace(O=O, CpuBackend=CpuBackend, B1=B1))
+                except Exception as e:
+                    out["cpu_baseline"]["stages"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -54,6 +54,7 @@ void zp_destroy(zp_ctx *ctx) {
     for (int i = 0; i < 4; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->msm_arena) (void)hipFree(ctx->msm_arena);
     if (ctx->d_rc) (void)hipFree(ctx->d_rc);
     if (ctx->d_mds) (void)hipFree(ctx->d_mds);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -62,6 +62,8 @@ struct zp_ctx {
     size_t pinned_bytes = 0;
     int num_cu = 256;
     // experiment knobs (zp_set_tuning): not part of the stable surface
+    void *msm_arena = nullptr;    // scratch of zp_msm_bn254*: grows to the largest run, freed by zp_destroy
+    size_t msm_arena_bytes = 0;
     int tune_logt = 4, tune_tpw = 4, tune_logt9 = 5;
     int tune_merkle_coop_log = 0; // 0 = 15: tree levels with <= 2^15 nodes go to the 12-lanes-per-node subtree kernel
     int tune_ntt_chunk_log = 0;   // 0 = 28: columns per launch such that a ping-pong scratch buffer is <= 2 GiB

@@ -758,6 +758,23 @@ fq2 f_inv_host(const fq2 &a) {  // (a0 - a1 u) / (a0^2 + a1^2)
     return fq2_make(fq_mul(a.c0, d), fq_sub(fq_zero(), fq_mul(a.c1, d)));
 }
 
+// All scratch of a run comes from ONE ctx-owned arena that only grows: hipMalloc/hipFree of gigabytes per call cost
+// up to 45 ms (more than the 2^22-point run itself) once the process holds other large allocations.
+static int32_t msm_arena(zp_ctx *ctx, size_t bytes, char **out) {
+    if (ctx->msm_arena_bytes < bytes) {
+        if (ctx->msm_arena) {
+            ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ZP_HIP(ctx, hipFree(ctx->msm_arena));
+            ctx->msm_arena = nullptr;
+            ctx->msm_arena_bytes = 0;
+        }
+        ZP_HIP(ctx, hipMalloc(&ctx->msm_arena, bytes));
+        ctx->msm_arena_bytes = bytes;
+    }
+    *out = (char *)ctx->msm_arena;
+    return ZP_OK;
+}
+
 // one Pippenger run over n points (n <= 2^24 from the entry points): result as a Jacobian point in *out
 template <class F>
 int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n, jacT<F> *out) {
@@ -784,18 +801,28 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     while ((size_t)g.wgroup * ((size_t)2 << g.hi) * sizeof(u32) > 48 * 1024 && g.wgroup > 1) g.wgroup = (g.wgroup + 1) / 2;
     const u64 ncoarse = (u64)nwin << g.hi;
     ZP_HIP(ctx, hipSetDevice(ctx->device));
-    // per-bucket counts/starts | coarse counts/starts/cursor | sorted indices + the coarse-partitioned (index, fine) pairs
+    // arena layout (256-byte aligned pieces): per-bucket counts/starts/cursor | coarse counts/starts/cursor | slice list |
+    // sorted indices + coarse-partitioned (index, fine) pairs | Montgomery points | buckets/segments/windows | heavy lists | chunk sums
     const u64 max_slices = (u64)nwin * n / MSM_FSLICE + ncoarse + 1;
-    ZP_HIP(ctx, hipMalloc((void **)&d_counts, (nb * 3 + ncoarse * 3 + 8 + max_slices * 2) * 4));
+    const u64 max_heavy = (u64)nwin * n / MSM_HEAVY + 1, max_chunks = (u64)nwin * n / MSM_HCHUNK + max_heavy + 1;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t sz_counts = al((nb * 3 + ncoarse * 3 + 8 + max_slices * 2) * 4), sz_sorted = al((u64)nwin * n * 4 * 3),
+                 sz_mont = al((u64)n * NV * 16), sz_buckets = al((nb + nwin * nseg + nwin) * sizeof(J)),
+                 sz_hl = al(16 + max_chunks * sizeof(uint2) + max_heavy * sizeof(uint4)), sz_partial = al(max_chunks * sizeof(J));
+    char *arena = nullptr;
+    ZP_TRY(msm_arena(ctx, sz_counts + sz_sorted + sz_mont + sz_buckets + sz_hl + sz_partial, &arena));
+    d_counts = (u32 *)arena;
+    d_sorted = (u32 *)(arena + sz_counts);
+    d_mont = (uint4 *)(arena + sz_counts + sz_sorted);
+    d_buckets = (J *)(arena + sz_counts + sz_sorted + sz_mont);
+    u32 *d_hl = (u32 *)(arena + sz_counts + sz_sorted + sz_mont + sz_buckets);
+    J *d_partial = (J *)(arena + sz_counts + sz_sorted + sz_mont + sz_buckets + sz_hl);
     d_starts = d_counts + nb;
     u32 *d_fcursor = d_starts + nb;
     u32 *d_ccounts = d_fcursor + nb, *d_cstarts = d_ccounts + ncoarse, *d_ccursor = d_cstarts + ncoarse;
     u32 *d_slice_count = d_ccursor + ncoarse;
     uint2 *d_slices = (uint2 *)(((uintptr_t)(d_slice_count + 4) + 7) & ~(uintptr_t)7);
-    ZP_HIP(ctx, hipMalloc((void **)&d_sorted, (u64)nwin * n * 4 * 3));
     u32 *d_pidx = d_sorted + (u64)nwin * n, *d_pfine = d_pidx + (u64)nwin * n;
-    ZP_HIP(ctx, hipMalloc((void **)&d_mont, (u64)n * NV * 16));
-    ZP_HIP(ctx, hipMalloc((void **)&d_buckets, (nb + nwin * nseg + nwin) * sizeof(J)));
     d_segs = d_buckets + nb;
     d_wins = d_segs + nwin * nseg;
     ZP_HIP(ctx, hipMemsetAsync(d_ccounts, 0, (ncoarse * 3 + 4) * 4, ctx->stream));   // coarse counters + slice count
@@ -824,11 +851,7 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     if (he == hipSuccess && nslices)
         hipLaunchKernelGGL(msm_fine_scatter_kernel, dim3(nslices), dim3(256), 0, ctx->stream, d_pidx, d_pfine, (u64)n, g, d_slices,
                            d_cstarts, d_ccounts, d_fcursor, d_sorted);
-    // heavy-bucket lists: at most nwin*n/MSM_HEAVY heavy buckets and nwin*n/MSM_HCHUNK + that many chunks
-    const u64 max_heavy = (u64)nwin * n / MSM_HEAVY + 1, max_chunks = (u64)nwin * n / MSM_HCHUNK + max_heavy + 1;
     HeavyLists hl;
-    u32 *d_hl = nullptr;
-    ZP_HIP(ctx, hipMalloc((void **)&d_hl, 16 + max_chunks * sizeof(uint2) + max_heavy * sizeof(uint4)));
     hl.counters = d_hl;
     hl.heavy = (uint4 *)(d_hl + 4);
     hl.chunks = (uint2 *)(hl.heavy + max_heavy);
@@ -838,10 +861,8 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     u32 hcnt[2] = {0, 0};
     if (he == hipSuccess) he = hipMemcpyAsync(hcnt, d_hl, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
-    J *d_partial = nullptr;
     if (he == hipSuccess && hcnt[0]) {
-        he = hipMalloc((void **)&d_partial, (u64)hcnt[0] * sizeof(J));
-        if (he == hipSuccess) {
+        {
             hipLaunchKernelGGL(msm_heavy_kernel<F>, dim3(hcnt[0]), dim3(256), 0, ctx->stream, (const uint4 *)d_mont, (u64)n, c, d_starts,
                                d_counts, d_sorted, hl, d_partial);
             hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hcnt[1]), dim3(64), 0, ctx->stream, hl, hcnt[1], d_partial,
@@ -854,12 +875,6 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     std::vector<J> wins(nwin);
     hipError_t ce = hipMemcpyAsync(wins.data(), d_wins, nwin * sizeof(J), hipMemcpyDeviceToHost, ctx->stream);
     hipError_t se = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_counts);
-    (void)hipFree(d_sorted);
-    (void)hipFree(d_mont);
-    (void)hipFree(d_buckets);
-    (void)hipFree(d_hl);
-    if (d_partial) (void)hipFree(d_partial);
     ZP_HIP(ctx, he);
     ZP_HIP(ctx, le);
     ZP_HIP(ctx, ce);

@@ -26,9 +26,8 @@ for logn in [int(a) for a in sys.argv[1:]] or [16, 20, 22]:
     d_p.free(); d_s.free()
 # G2 (the B element of Groth16): ZP_MSM_G2="18 20" python tools/msm_bench.py 0
 for logn in [int(a) for a in os.environ.get("ZP_MSM_G2", "").split()]:
-    from oracle import naive_bn254 as NB   # only to draw valid G2 points for the measurement
     n = 1 << logn
-    tab2 = [NB.mul_g2(NB.G2, rnd.randrange(1, NB.R)) for _ in range(16)]
+    tab2 = [bn254.g2_mul(rnd.randrange(1, bn254.R)) for _ in range(16)]
     t2 = np.array([[(c >> (32 * k)) & 0xFFFFFFFF for c in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]) for k in range(8)] for pt in tab2], dtype=np.uint32)
     g = np.random.default_rng(logn)
     pts = t2[g.integers(0, 16, size=n)]
