@@ -162,7 +162,9 @@ int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uin
 /* ---- N6: BN254 (alt_bn128) G1 multi-scalar multiplication ---------------------------------------
  * d_points u32[n][16]: affine x (8 little-endian 32-bit limbs) then y, standard (non-Montgomery)
  * integers < q; (0,0) encodes the point at infinity.  d_scalars u32[n][8] little-endian, any 256-bit
- * value (used mod the group order implicitly).  h_out u32[16] = affine sum, all zero = infinity.   */
+ * value (used mod the group order implicitly).  h_out u32[16] = affine sum, all zero = infinity.
+ * Pippenger; inputs above 2^24 points run as 2^24-point passes; scratch (about 300 B per point of a pass) comes from
+ * an arena the ctx keeps until zp_destroy.  Skewed scalars (many equal/small values) are handled in parallel.   */
 int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n, uint32_t *h_out);
 /* the same over G2 (the B element of a Groth16 proof): affine points over F_q2 = F_q[u]/(u^2+1) on the twist
  * y^2 = x^3 + 3/(9+u); d_points u32[n][32] = x.c0, x.c1, y.c0, y.c1 (8 little-endian words each, standard form,
@@ -187,7 +189,8 @@ int32_t zp_get_pass_timings(zp_ctx *ctx, float *ms, int32_t *radix_log, int32_t 
 int32_t zp_stage_timings(zp_ctx *ctx, char *buf, size_t buflen);
 
 /* experiment knobs for kernel tuning sweeps (keys: "ntt_logt" 4|5 tile of the radix-256 pass, "ntt_logt9" 4|5, "ntt_tpw" tiles per workgroup,
- * "msm_chunk_log" log2 of the points per Pippenger run, default 24); not for production hosts */
+ * "ntt_chunk_log" log2 of the elements per NTT launch (28), "merkle_coop_log" largest tree level given to the 12-lanes-per-node
+ * kernel (15), "msm_chunk_log" log2 of the points per Pippenger run (24), "msm_c" window width; 0 = default); not for production hosts */
 int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value);
 
 /* ---- introspection ------------------------------------------------------------------------- */
