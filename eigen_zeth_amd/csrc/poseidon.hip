@@ -160,6 +160,55 @@ __global__ void __launch_bounds__(256) merkle_leaves_kernel(const u64 *__restric
     for (int j = 0; j < 4; j++) tree[i * 4 + j] = s[8 + j];
 }
 
+// Small trees (FRI layers below 2^14 leaves): 12 lanes per leaf, like merkle_subtree_kernel -- a leaf of 24 values is
+// three dependent permutations, 0.33 ms on a single lane while the chip idles, ~50 us with the state spread over lanes.
+// One permutation of the 64 states a workgroup holds, lane = (state, element); sh is the exchange buffer.
+__device__ __forceinline__ u64 coop_perm(u64 s, int node, int e, u64 (*sh)[12], const u64 *rc, const u32 *mds) {
+    for (int r = 0; r < 30; r++) {
+        s = gl_add_weak(s, rc[r * 12 + e]);
+        if (r < 4 || r >= 26 || e == 0) s = sbox7(s);
+        sh[node][e] = s;
+        __syncthreads();
+        u64 alo = 0, ahi = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const u64 v = sh[node][j];
+            const u32 m = mds[e * 12 + j];
+            alo += (u64)m * (u32)v;
+            ahi += (u64)m * (u32)(v >> 32);
+        }
+        __syncthreads();
+        const u64 mid = (alo >> 32) + ahi;
+        s = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
+    }
+    return gl_canon(s);
+}
+// stride_e / stride_i: element (row i, position k) sits at src[k * stride_e + i * stride_i]  (columns: M, 1; rows: 1, len)
+__global__ void __launch_bounds__(768) merkle_leaves_coop_kernel(const u64 *__restrict__ src, size_t M, size_t len, size_t stride_e,
+                                                                size_t stride_i, u64 *__restrict__ tree, const u64 *rc,
+                                                                const u32 *mds) {
+    __shared__ u64 sh[64][12];
+    const int node = threadIdx.x / 12, e = threadIdx.x % 12;
+    const size_t i = (size_t)blockIdx.x * 64 + node;
+    const bool on = i < M;                       // every lane runs the barriers; idle leaves compute on zeros
+    if (len <= 4) {
+        if (on && e < 4) tree[i * 4 + e] = (size_t)e < len ? src[(size_t)e * stride_e + i * stride_i] : 0ULL;
+        return;
+    }
+    u64 s = 0;
+    for (size_t off = 0; off < len; off += 8) {
+        if (e < 8) s = (on && off + e < len) ? src[(off + e) * stride_e + i * stride_i] : 0ULL;
+        s = coop_perm(s, node, e, sh, rc, mds);
+        // capacity of the next block = the first four outputs
+        sh[node][e] = s;
+        __syncthreads();
+        const u64 cap = sh[node][e & 3];
+        __syncthreads();
+        if (e >= 8) s = cap;
+        else if (off + 8 >= len && e < 4 && on) tree[i * 4 + e] = s;
+    }
+}
+
 // leaves given as M contiguous rows of `len` elements
 template <bool DEFMDS>
 __global__ void __launch_bounds__(256) merkle_leaves_rows_kernel(const u64 *__restrict__ rows, size_t M, size_t len,
@@ -330,7 +379,10 @@ int32_t zp_merkle_commit(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t 
     ZP_ARG(ctx, W >= 1, "W must be >= 1");
     ZP_ARG(ctx, d_cols && d_tree, "null device pointer");
     ZP_TRY(zpi_poseidon_sync_tables(ctx));
-    if (ctx->mds_is_default)
+    if (M <= ((size_t)1 << 14) && W > 4)
+        hipLaunchKernelGGL(merkle_leaves_coop_kernel, dim3((unsigned)((M + 63) / 64)), dim3(768), 0, ctx->stream, (const u64 *)d_cols, M,
+                           (size_t)W, M, (size_t)1, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
+    else if (ctx->mds_is_default)
         hipLaunchKernelGGL(merkle_leaves_kernel<true>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const u64 *)d_cols, M, (int)W, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
     else
@@ -347,7 +399,10 @@ int32_t zp_merkle_commit_rows(zp_ctx *ctx, const uint64_t *d_rows, size_t M, siz
     ZP_ARG(ctx, len >= 1, "len must be >= 1");
     ZP_ARG(ctx, d_rows && d_tree, "null device pointer");
     ZP_TRY(zpi_poseidon_sync_tables(ctx));
-    if (ctx->mds_is_default)
+    if (M <= ((size_t)1 << 14) && len > 4)
+        hipLaunchKernelGGL(merkle_leaves_coop_kernel, dim3((unsigned)((M + 63) / 64)), dim3(768), 0, ctx->stream, (const u64 *)d_rows, M,
+                           len, (size_t)1, len, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
+    else if (ctx->mds_is_default)
         hipLaunchKernelGGL(merkle_leaves_rows_kernel<true>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const u64 *)d_rows, M, len, (u64 *)d_tree, ctx->d_rc, ctx->d_mds);
     else
