@@ -279,3 +279,19 @@ def test_metrics_endpoint_counts_requests_and_stage_time(tmp_path, cpu_factory):
             urllib.request.urlopen("http://127.0.0.1:%d/other" % httpd.server_address[1])
     finally:
         server.stop(0); httpd.shutdown()
+
+
+def test_chunk_proofs_identical_across_streams_and_devices(tmp_path, cpu_factory):
+    """the engine proves chunks on several backends in parallel (streams of one GPU, or one factory per GPU):
+    the batch result must not depend on how many there are"""
+    def run(factories, streams):
+        cfg = EngineConfig(air="chunk16", logn=6, n_queries=4, fri_final_log=3, chunks_per_block=1, prover_streams=streams,
+                           witness_threads=3)
+        cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
+        eng = Engine(factories, cfg)
+        ch = eng.gen_batch_chunks("b", [3, 4, 5, 6, 7], 12345, "evm")
+        return eng.gen_chunk_proofs("b", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+    one = run(cpu_factory, 1)
+    assert [p["chunk_id"] for p in one] == [0, 1, 2, 3, 4]
+    assert run(cpu_factory, 3) == one
+    assert run([cpu_factory, cpu_factory], 2) == one
