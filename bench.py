@@ -111,12 +111,16 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    step_ev[0].record()
+    for k in range(args.steps):
         prover.ntt(x, x, logn, cols)
+        step_ev[k + 1].record()
     ev1.record()
     barrier()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    per_step = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))   # median + min
     passes = prover.pass_timings()
     prover.set_profiling(False)
 
@@ -206,6 +210,8 @@ def main():
                        "logn": logn, "cols_per_gpu": cols, "sharding": "columns, no data-path collective",
                        "plan": plan},
             "device_ms_per_step": dev_ms / args.steps,
+            "device_ms_per_step_median": per_step[len(per_step) // 2],
+            "device_ms_per_step_min": per_step[0],
             "roofline": {
                 "bound": "hbm",
                 "kernel": "ntt_pass2_kernel<%s> radix 2^%d (%s)" % ("4,4,0,4,false,false,{1,0}" if dom == 8 else "...", abs(dom), "transposing first pass" if dom < 0 else "non-transposing passes 2..m: MODE 1 = twiddle table, MODE 0 = plain last pass"),
