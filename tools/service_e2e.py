@@ -1,0 +1,25 @@
+"""end-to-end over gRPC on the GPU: serve() + the ProverChannel mirror of eigen-zeth's client, N blocks, metrics scrape
+usage: python tools/service_e2e.py [blocks=2] [logn=20] [chunks_per_block=4]"""
+import json, os, sys, tempfile, time, urllib.request
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eigen_zeth_amd.service.engine import EngineConfig
+from eigen_zeth_amd.service.server import serve
+from eigen_zeth_amd.service.client import ProverChannel
+from eigen_zeth_amd.service.metrics import Metrics
+
+blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+cpb = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+tmp = tempfile.mkdtemp()
+cfg = EngineConfig(air="chunk64", logn=logn, chunks_per_block=cpb, n_queries=32, groth16_logm=8, crs_dir=os.path.join(tmp, "crs"), witness_threads=8)
+server, port = serve(0, "127.0.0.1", os.path.join(tmp, "state"), cfg, 0, metrics_port=0)
+ch = ProverChannel("127.0.0.1:%d" % port)
+for b in range(1, blocks + 1):
+    t0 = time.perf_counter()
+    res = ch.execute(b)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"block": b, "wall_s": round(dt, 3), "proof_bytes": len(res["proof"]), "public_input": res["public_input"][:40],
+                      "post_state_root": bytes(res["post_state_root"]).hex()[:16], "chunks": len(res["chunk_proofs"])}), flush=True)
+ch.close()
+server.stop(0)
+print("OK")
