@@ -379,7 +379,7 @@ def engine_batch_probe(K, logn, air_name, device=0, tag=""):
         t2 = time.perf_counter()
         res = {"chunks": K, "wall_s": t2 - t0, "chunk_proofs_s": t1 - t0, "aggregate_final_s": t2 - t1,
                "prover_streams": cfg.prover_streams,
-               "note": "synthetic witnesses are generated on the host inside the timed region (0.33 s each, 16 threads)"}
+               "note": "synthetic witnesses are generated on the host inside the timed region (0.23 s each, 16 threads)"}
     return res
 
 

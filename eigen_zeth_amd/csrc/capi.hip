@@ -259,6 +259,12 @@ int32_t zp_domain_tables(zp_ctx *ctx, int32_t logm, const uint64_t **d_lo, const
     return ZP_OK;
 }
 
+// host-only product mod p through the 128-bit multiply of the host CPU (the shared gl_mul is written for 32-bit GPU limbs)
+static inline u64 host_mulmod(u64 a, u64 b) {
+    const unsigned __int128 t = (unsigned __int128)a * b;
+    return gl_reduce96((u64)t, (u32)(t >> 64), (u32)(t >> 96));
+}
+
 int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uint64_t *h_trace, uint64_t *h_pub) {
     if (logn < 1 || logn > 30 || !h_trace || !h_pub) return ZP_ERR_ARG;
     const size_t N = (size_t)1 << logn;
@@ -314,11 +320,23 @@ int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uin
         std::vector<u64> cur(Ww), nx(Ww);
         for (int i = 0; i < Ww; i++) cur[i] = next();
         for (int i = 0; i < 4; i++) h_pub[i] = cur[i];
-        for (size_t r = 0; r < N; r++) {
-            for (int i = 0; i < Ww; i++) h_trace[(size_t)i * N + r] = cur[i];
-            for (int i = 0; i < Ww; i++)
-                nx[i] = gl_add(gl_add(gl_mul(cur[i], cur[(i + 1) % Ww]), cur[(i + 2) % Ww]), (u64)i);
-            cur.swap(nx);
+        // rows are produced 64 at a time into a small row-major block and written out column by column, so that the
+        // column-major trace receives 512-byte runs instead of one 8-byte store per (row, column)
+        {
+            const size_t RB = N < 64 ? N : 64;
+            std::vector<u64> blk((size_t)Ww * RB), ext(Ww + 2);
+            for (size_t r0 = 0; r0 < N; r0 += RB) {
+                for (size_t rr = 0; rr < RB; rr++) {
+                    for (int i = 0; i < Ww; i++) {
+                        blk[(size_t)i * RB + rr] = cur[i];
+                        ext[i] = cur[i];
+                    }
+                    ext[Ww] = cur[0];            // wrap-around neighbours without a modulo in the inner loop
+                    ext[Ww + 1] = cur[1 % Ww];
+                    for (int i = 0; i < Ww; i++) cur[i] = gl_add(gl_add(host_mulmod(ext[i], ext[i + 1]), ext[i + 2]), (u64)i);
+                }
+                for (int i = 0; i < Ww; i++) memcpy(h_trace + (size_t)i * N + r0, &blk[(size_t)i * RB], RB * sizeof(u64));
+            }
         }
         u64 *fa = (u64 *)h_trace + (size_t)Ww * N, *fb = fa + N, *rv = fb + N, *qv = rv + N, *tv = qv + N, *mv = tv + N,
             *cv = mv + N, *dv = cv + N;
