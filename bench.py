@@ -20,6 +20,10 @@ import os
 import sys
 import time
 
+# idle OpenMP workers of the CPU checker must sleep, not spin: spinning threads delay the host side of the GPU timings
+# taken after the cpu_baseline leg (a DEEP launch measured 29 ms instead of 1.7 ms)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
