@@ -58,7 +58,7 @@ def cpu_baseline(logn, budget_cols):
     del y
     # subtract nothing: copy + transform is what the CPU path does per call
     return {"value": cols * (1 << logn) / dt, "unit": "field-elems/s", "cores": cores, "kind": "port",
-            "sample": "%d columns x 2^%d rows, oracle/gl_oracle.c radix-2 NTT, OpenMP over columns, %.2f s"
+            "sample": "%d columns x 2^%d rows, oracle/gl_oracle.c cache-blocked radix-2 NTT, OpenMP over columns, %.2f s"
                       % (cols, logn, dt),
             "note": "CPU restatement, not the eigen-zkvm prover (parity unpinned, SURVEY.md 8c)"}
 

@@ -129,28 +129,77 @@ static u64 *make_tw(int logn, u64 w) {
     return tw;
 }
 
-/* cols: u64[W][N] column-major, in place */
-void orc_ntt(u64 *cols, int logn, int W, u64 root32) {
-    u64 w = orc_root(root32, logn);
-    u64 *tw = make_tw(logn, w);
-    size_t n = (size_t)1 << logn;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int c = 0; c < W; c++) ntt_one(cols + (size_t)c * n, logn, w, tw);
-    free(tw);
+/* Cache-blocked form of the same transform for large N (what a tuned CPU prover does; the plain radix-2 loop above
+ * walks the whole 128 MiB column 24 times): N = N1*N2, index i = i1*N2 + i2, output k = k1 + N1*k2,
+ *   X[k1 + N1 k2] = sum_i2 w_N2^(i2 k2) w_N^(i2 k1) sum_i1 x[i1 N2 + i2] w_N1^(i1 k1).
+ * Eight strided sub-vectors are gathered at a time so that every 64-byte line read is used whole; the sub-transforms
+ * run on contiguous cache-resident buffers with ntt_one.  Exact arithmetic: bit-identical to ntt_one
+ * (tests/test_oracle.py).  tmp: N elements, buf: 8*max(N1,N2) elements. */
+static void ntt_one_blocked(u64 *a, int logn, u64 w, const u64 *tw1, const u64 *tw2, u64 *tmp, u64 *buf) {
+    const int l1 = logn / 2, l2 = logn - l1;
+    const size_t N1 = (size_t)1 << l1, N2 = (size_t)1 << l2;
+    u64 wi2 = 1; /* w^i2 */
+    for (size_t i2 = 0; i2 < N2; i2 += 8) {
+        for (size_t i1 = 0; i1 < N1; i1++)
+            for (int b = 0; b < 8; b++) buf[(size_t)b * N1 + i1] = a[i1 * N2 + i2 + b];
+        for (int b = 0; b < 8; b++) {
+            u64 *v = buf + (size_t)b * N1;
+            ntt_one(v, l1, 0, tw1);
+            u64 c = 1;
+            for (size_t k1 = 0; k1 < N1; k1++) {
+                tmp[(i2 + b) * N1 + k1] = gl_mul(v[k1], c);
+                c = gl_mul(c, wi2);
+            }
+            wi2 = gl_mul(wi2, w);
+        }
+    }
+    for (size_t k1 = 0; k1 < N1; k1 += 8) {
+        for (size_t i2 = 0; i2 < N2; i2++)
+            for (int b = 0; b < 8; b++) buf[(size_t)b * N2 + i2] = tmp[i2 * N1 + k1 + b];
+        for (int b = 0; b < 8; b++) ntt_one(buf + (size_t)b * N2, l2, 0, tw2);
+        for (size_t k2 = 0; k2 < N2; k2++)
+            for (int b = 0; b < 8; b++) a[k1 + b + N1 * k2] = buf[(size_t)b * N2 + k2];
+    }
 }
 
+#define ORC_BLOCKED_MIN_LOG 16
+static int orc_force_simple = 0;
+void orc_set_simple_ntt(int on) { orc_force_simple = on; }   /* tests: compare the two forms */
+
+/* all W columns with root w (the caller passes the inverse root for the inverse transform) */
+static void ntt_cols(u64 *cols, int logn, int W, u64 w) {
+    const size_t n = (size_t)1 << logn;
+    if (logn < ORC_BLOCKED_MIN_LOG || orc_force_simple) {
+        u64 *tw = make_tw(logn, w);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int c = 0; c < W; c++) ntt_one(cols + (size_t)c * n, logn, w, tw);
+        free(tw);
+        return;
+    }
+    const int l1 = logn / 2, l2 = logn - l1;
+    u64 *tw1 = make_tw(l1, gl_pow(w, (u64)1 << l2)), *tw2 = make_tw(l2, gl_pow(w, (u64)1 << l1));
+#pragma omp parallel
+    {
+        u64 *tmp = (u64 *)malloc(n * sizeof(u64));
+        u64 *buf = (u64 *)malloc(((size_t)8 << l2) * sizeof(u64));
+#pragma omp for schedule(dynamic, 1)
+        for (int c = 0; c < W; c++) ntt_one_blocked(cols + (size_t)c * n, logn, w, tw1, tw2, tmp, buf);
+        free(tmp);
+        free(buf);
+    }
+    free(tw1);
+    free(tw2);
+}
+
+/* cols: u64[W][N] column-major, in place */
+void orc_ntt(u64 *cols, int logn, int W, u64 root32) { ntt_cols(cols, logn, W, orc_root(root32, logn)); }
+
 void orc_intt(u64 *cols, int logn, int W, u64 root32) {
-    u64 w = gl_inv(orc_root(root32, logn));
-    u64 *tw = make_tw(logn, w);
+    ntt_cols(cols, logn, W, gl_inv(orc_root(root32, logn)));
     size_t n = (size_t)1 << logn;
     u64 ninv = gl_inv((u64)n % GL_P);
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int c = 0; c < W; c++) {
-        u64 *a = cols + (size_t)c * n;
-        ntt_one(a, logn, w, tw);
-        for (size_t i = 0; i < n; i++) a[i] = gl_mul(a[i], ninv);
-    }
-    free(tw);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < (size_t)W * n; i++) cols[i] = gl_mul(cols[i], ninv);
 }
 
 /* ------------------------------------------------------------------ LDE (N2)

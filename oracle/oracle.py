@@ -68,6 +68,7 @@ def lib():
         L.orc_poly_eval.restype = u64
         L.orc_poly_eval.argtypes = [_u64p, sz, u64]
         L.orc_poly_eval_e3.argtypes = [_u64p, sz, _u64p, _u64p]
+        L.orc_set_simple_ntt.argtypes = [i32]
         L.orc_num_threads.restype = i32
         L.orc_set_threads.argtypes = [i32]
         _lib = L
@@ -221,6 +222,11 @@ def poly_eval_e3_cols(coef, x3):
     out = np.empty((W, 3), dtype=np.uint64)
     lib().orc_poly_eval_e3_cols(_p(c), n, W, _p(_arr(x3)), _p(out))
     return out
+
+
+def set_simple_ntt(on):
+    """force the plain radix-2 loop for every size (the default switches to the cache-blocked form at 2^16)"""
+    lib().orc_set_simple_ntt(int(bool(on)))
 
 
 def num_threads():

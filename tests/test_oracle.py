@@ -115,3 +115,16 @@ def test_ntt_linearity_and_large_roundtrip():
     s = ((a[0].astype(object) + a[1].astype(object)) % P).astype(np.uint64)
     fs = O.ntt(s[None, :])
     assert (fs[0].astype(object) == (fa[0].astype(object) + fa[1].astype(object)) % P).all()
+
+
+def test_blocked_ntt_is_bit_identical_to_the_plain_loop():
+    """the cache-blocked (four-step) CPU transform used from 2^16 up equals the plain radix-2 definition"""
+    for logn in (16, 17):
+        x = O.random_field((2, 1 << logn), 4000 + logn)
+        blocked, iblocked = O.ntt(x), O.intt(x)
+        O.set_simple_ntt(True)
+        try:
+            assert (O.ntt(x) == blocked).all() and (O.intt(x) == iblocked).all()
+        finally:
+            O.set_simple_ntt(False)
+        assert (O.intt(blocked) == x).all()
