@@ -18,6 +18,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 # idle OpenMP workers of the CPU checker must sleep, not spin: spinning threads delay the host side of the GPU timings
@@ -28,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PROBE_LIMIT_S = 300   # watchdog for the multi-rank probes of an N > 1 run
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 
 
@@ -149,30 +151,6 @@ def main():
         copy_gbs = 2.0 * x.numel() * 8 * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del y
 
-    pipe = None
-    if not args.no_pipeline:
-        del x
-        torch.cuda.empty_cache()
-        try:   # every rank takes part (all-to-all); reported by rank 0, outside the K timed steps
-            pipe = pipeline_probe(torch, dist, prover, dev, logn, min(cols, 32), world)
-        except Exception as e:
-            pipe = {"error": repr(e)}
-
-    batch_multi = None
-    if world > 1 and not args.no_pipeline:
-        # BASELINE metric (i) on N GPUs: independent chunk proofs shard over the ranks with no exchange; every rank
-        # proves its own 16-chunk batch (weak scaling) and the slowest rank's wall-clock is reported
-        try:
-            r = engine_batch_probe(16, args.stark_logn, "chunk64", device=local, tag="_r%d" % rank)
-            tb = torch.tensor([r["wall_s"]], dtype=torch.float64, device=dev)
-            err = None
-        except Exception as e:
-            tb = torch.tensor([-1.0], dtype=torch.float64, device=dev)
-            err = repr(e)
-        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
-        batch_multi = {"chunks_total": 16 * world, "chunks_per_gpu": 16, "wall_s_max_over_ranks": float(tb.item()),
-                       "rank0_error": err}
-
     if rank == 0:
         plan = prover.ntt_plan(logn)
         npass = max(1, len(plan["passes"]))
@@ -231,6 +209,54 @@ def main():
                 "per_pass_avg_ms": {str(k): sum(v) / len(v) for k, v in sorted(by_kind.items())},
             },
         }
+
+    # ---- optional probes.  At N > 1 they contain collectives that cannot be rehearsed on the one-GPU development box:
+    # a watchdog prints the line with the headline numbers and ends every rank if they do not return in time.
+    out_lock = threading.Lock()
+    printed = [False]
+    watchdog = None
+    wd_test = os.environ.get("ZP_BENCH_WATCHDOG_TEST")   # rehearsal hook: arm the watchdog on one GPU and stall the probes
+    if (world > 1 and not args.no_pipeline) or wd_test:
+        def bail():
+            with out_lock:
+                if rank == 0 and not printed[0]:
+                    out["pipeline"] = {"error": "multi-rank probes did not finish within %d s; line printed by the watchdog" % PROBE_LIMIT_S}
+                    print(json.dumps(out), flush=True)
+                    printed[0] = True
+            os._exit(0)
+        watchdog = threading.Timer(2 if wd_test else PROBE_LIMIT_S, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        if wd_test:
+            time.sleep(6)
+
+    pipe = None
+    if not args.no_pipeline:
+        del x
+        torch.cuda.empty_cache()
+        try:   # every rank takes part (all-to-all); reported by rank 0, outside the K timed steps
+            pipe = pipeline_probe(torch, dist, prover, dev, logn, min(cols, 32), world)
+        except Exception as e:
+            pipe = {"error": repr(e)}
+
+    batch_multi = None
+    if world > 1 and not args.no_pipeline:
+        # BASELINE metric (i) on N GPUs: independent chunk proofs shard over the ranks with no exchange; every rank
+        # proves its own 16-chunk batch (weak scaling) and the slowest rank's wall-clock is reported
+        try:
+            r = engine_batch_probe(16, args.stark_logn, "chunk64", device=local, tag="_r%d" % rank)
+            tb = torch.tensor([r["wall_s"]], dtype=torch.float64, device=dev)
+            err = None
+        except Exception as e:
+            tb = torch.tensor([-1.0], dtype=torch.float64, device=dev)
+            err = repr(e)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        batch_multi = {"chunks_total": 16 * world, "chunks_per_gpu": 16, "wall_s_max_over_ranks": float(tb.item()),
+                       "rank0_error": err}
+
+    if watchdog is not None:
+        watchdog.cancel()
+    if rank == 0:
         if pipe is not None:
             out["pipeline"] = pipe
         if batch_multi is not None:
@@ -257,7 +283,10 @@ def main():
                     out["cpu_baseline"]["stages"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        with out_lock:
+            if not printed[0]:
+                print(json.dumps(out), flush=True)
+                printed[0] = True
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
