@@ -86,6 +86,26 @@ def test_bad_arguments_are_errors(prover):
         prover.set_constants(1, [5])  # not a 2^32-th root
     with pytest.raises(ZpError):
         prover.merkle_commit(d, 3, 1, d)  # M not a power of two
+    with pytest.raises(ZpError):
+        prover.logup_columns(d, d, d, 0, [1, 2, 3], d)          # empty lookup
+    with pytest.raises(ZpError):
+        prover.logup_columns(d, d, d, 4, [O.P, 0, 0], d)        # challenge not canonical
+    with pytest.raises(ZpError):
+        prover.grand_product(d, None, 4, [1, 2, 3], d)          # null column
+    with pytest.raises(ZpError):
+        prover.fri_fold(d, d, 3, 1, [1, 2, 3], 49)              # in place fold
+    with pytest.raises(ZpError):
+        prover.set_tuning("no_such_knob", 1)
+    with pytest.raises(ZpError):
+        prover.set_constants(3, [1 << 28] * 144)                # MDS entries must be < 2^28
+    import ctypes as C
+    out = (C.c_uint32 * 16)()
+    assert prover.lib.zp_msm_bn254(prover.ctx, None, None, 5, out) != 0      # null device pointers with n > 0
+    assert prover.lib.zp_msm_bn254(prover.ctx, None, None, 0, out) == 0      # the empty sum is the point at infinity
+    assert list(out) == [0] * 16
+    p = C.c_void_p()
+    assert prover.lib.zp_host_alloc(prover.ctx, 0, C.byref(p)) != 0          # zero-size pinned allocation
+    assert b"zero size" in prover.lib.zp_last_error(prover.ctx) or prover.lib.zp_last_error(prover.ctx)
 
 
 def test_golden_lde_through_cabi(prover, golden):
