@@ -358,6 +358,29 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
         del blk
     except Exception as ex:
         res["four_step_single_column"] = {"error": repr(ex)}
+    # BN254 MSM over the ranks: 2^22 points per GPU, partial sums all-gathered and added
+    try:
+        from eigen_zeth_amd.service import bn254
+        import random as _random
+        rnd = _random.Random(11)
+        table = [bn254.g1_mul(rnd.randrange(1, bn254.R)) for _ in range(16)]
+        tab = np.array([[(c >> (32 * k)) & 0xFFFFFFFF for c in pt for k in range(8)] for pt in table], dtype=np.uint32)
+        rk = dist.get_rank() if world > 1 else 0
+        g = np.random.default_rng(100 + rk)
+        nloc = 1 << 22
+        pts = tab[g.integers(0, 16, size=nloc)]
+        scs = g.integers(0, 1 << 32, size=(nloc, 8), dtype=np.uint64).astype(np.uint32)
+        scs[:, 7] &= 0x1FFFFFFF
+        add = lambda p, q: bn254._pt_add(bn254._Ops1, p, q)
+        multigpu.distributed_msm(lambda: prover.msm_bn254_arrays(pts, scs), add)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        total = multigpu.distributed_msm(lambda: prover.msm_bn254_arrays(pts, scs), add)
+        dt = time.perf_counter() - t0
+        res["msm_bn254"] = {"points_per_gpu": nloc, "wall_ms_incl_upload": dt * 1e3, "points_per_s_all_gpus": world * nloc / dt,
+                            "on_curve": bool(total is None or bn254.g1_on_curve(total))}
+    except Exception as ex:
+        res["msm_bn254"] = {"error": repr(ex)}
     perms = ((Wtot + 7) // 8) * Mloc + (Mloc - 1)
     res["lde_GBs_algorithmic"] = 8.0 * N * 3 * cols / (res["lde_ms"] * 1e-3) / 1e9
     res["poseidon_perms_per_s_per_gpu"] = perms / (res["merkle_ms"] * 1e-3)

@@ -114,3 +114,34 @@ def hip_row_ops(prover):
         return mat
 
     return ntt_rows, twiddle_rows
+
+
+# ---------------------------------------------------------------------------------------------------------
+# MSM over several GPUs: independent point ranges per rank, one affine partial sum each, combined on
+# every rank -- "replicas + trivial reduce", no data-path collective beyond the all-gather of G x 64 bytes.
+
+def distributed_msm(local_msm, add_points, group=None):
+    """local_msm() -> this rank's partial sum as (x, y) ints or None (infinity), e.g. Prover.msm_bn254 over the rank's
+    range of points and scalars; add_points(p, q) -> p + q on the curve (None = infinity).  Returns the total."""
+    part = local_msm()
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return part
+    G = dist.get_world_size(group)
+    words = [0] * 17                      # flag + x, y as 8 x 32-bit words each (int64 tensor elements)
+    if part is not None:
+        words[0] = 1
+        for k in range(8):
+            words[1 + k] = (part[0] >> (32 * k)) & 0xFFFFFFFF
+            words[9 + k] = (part[1] >> (32 * k)) & 0xFFFFFFFF
+    t = torch.tensor(words, dtype=torch.int64)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    allr = [torch.empty_like(t) for _ in range(G)]
+    dist.all_gather(allr, t, group=group)
+    total = None
+    for r in allr:
+        w = r.tolist()
+        if w[0]:
+            p = (sum(w[1 + k] << (32 * k) for k in range(8)), sum(w[9 + k] << (32 * k) for k in range(8)))
+            total = add_points(total, p)
+    return total

@@ -121,3 +121,41 @@ def test_four_step_ntt_of_one_split_column_equals_the_plain_transform(world, log
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=10) == 1
+
+
+def _msm_worker(rank, world, port, n, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import random
+    from eigen_zeth_amd import multigpu
+    from oracle import naive_bn254 as B
+    rnd = random.Random(5)
+    pts = [B.mul(B.G, rnd.randrange(1, B.R)) for _ in range(n)]
+    scs = [rnd.randrange(B.R) for _ in range(n)]
+    if n >= 4:   # rank 1's range sums to infinity: the flag word must carry that
+        half = n // 2
+        pts[half:] = [pts[half], (pts[half][0], (-pts[half][1]) % B.Q)] + [None] * (n - half - 2)
+        scs[half:] = [7, 7] + [0] * (n - half - 2)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    got = multigpu.distributed_msm(lambda: B.msm([p for p in pts[lo:hi]], scs[lo:hi]), B.add)
+    ref = B.msm(pts, scs)
+    t = torch.tensor([1 if got == ref else 0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out_q.put(int(t.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_msm_equals_single_msm():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_msm_worker, args=(r, 2, port, 12, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) == 1
