@@ -20,6 +20,10 @@
 
 #include "ctx.hpp"
 
+// the data of a pass is touched exactly once: non-temporal loads/stores (measured +1 % on the 2^24 bench, same results)
+#define ZP_LDG(p) __builtin_nontemporal_load(p)
+#define ZP_STG(p, v) __builtin_nontemporal_store(v, p)
+
 namespace {
 
 struct PassArgs {
@@ -191,8 +195,8 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
 #pragma unroll
             for (int j = 0; j < (1 << A1); j++) {
                 const u64 idx = ((u64)slot_of(o, j, G::POS1, A1) << logNR) + u0 + t;
-                if constexpr (PADDED) r[g * (1 << A1) + j] = idx < a.in_valid ? src[idx] : 0ULL;
-                else r[g * (1 << A1) + j] = src[idx];
+                if constexpr (PADDED) r[g * (1 << A1) + j] = idx < a.in_valid ? ZP_LDG(&src[idx]) : 0ULL;
+                else r[g * (1 << A1) + j] = ZP_LDG(&src[idx]);
             }
         }
         const u64 lm = (1ULL << a.lb) - 1;
@@ -301,7 +305,7 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
                     u64 x = v[g * (1 << AJ) + p];
                     if constexpr (MODE >= 1) x = gl_mul(x, tab[k]);
                     if constexpr (MODE == 2) x = gl_mul(x, cw);
-                    dst[obase + ((u64)k << logP)] = x;
+                    ZP_STG(&dst[obase + ((u64)k << logP)], x);
                 }
             }
         }
@@ -312,7 +316,7 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
             for (int i = 0; i < 16; i++) {
                 const int idx = i * NT + tid;
                 const int t2 = idx >> L, k = idx & ((1 << L) - 1);
-                blk[idx] = lds[(G::sigma_of_k(k) << LOGT) + (t2 ^ (k & (T - 1)))];
+                ZP_STG(&blk[idx], lds[(G::sigma_of_k(k) << LOGT) + (t2 ^ (k & (T - 1)))]);
             }
         }
         if (more) {
