@@ -1,0 +1,56 @@
+"""External anchor of the constant generator.
+
+The reference holds no hash constants; the one value in this repo's hash stack that is pinned to something
+published outside the repo is the Poseidon reference Grain-LFSR stream: with the parameters of the widely published
+BN254 t = 3 instance (field 1, s-box 0, n = 254, t = 3, R_F = 8, R_P = 57) its first outputs are the first round
+constants of that instance.  The same generator, run with (1, 0, 64, 12, 8, 22), yields this repo's default
+Goldilocks table, which the C-ABI library compiles in (csrc/poseidon_default_table.inc)."""
+import os
+import re
+
+from eigen_zeth_amd import poseidon_constants as PC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# first four round constants of the published BN254 x^5 t=3 instance (8 full + 57 partial rounds)
+BN254_T3_FIRST = [
+    0x0EE9A592BA9A9518D05986D656F40C2114C4993C11BB29938D21D47304CD8E6E,
+    0x00F1445235F2148C5986587169FC1BCD887B08D4D00868DF5696FFF40956E864,
+    0x08DFF3487E8AC99E1F29A058D0FA80B930C728730B7AB36CE879F3890ECF73F5,
+    0x2F27BE690FDAEE46C3CE28F7532B13C856C35342C84BDA6E20966310FADC01D0,
+]
+
+
+def test_grain_lfsr_reproduces_published_bn254_t3_constants():
+    got = PC.grain_round_constants(1, 0, 254, 3, 8, 57, PC.BN254_R, count=4)
+    assert got == BN254_T3_FIRST
+
+
+def test_grain_stream_is_prefix_stable_and_in_range():
+    a = PC.grain_round_constants(1, 0, 254, 3, 8, 57, PC.BN254_R, count=10)
+    b = PC.grain_round_constants(1, 0, 254, 3, 8, 57, PC.BN254_R)
+    assert len(b) == (8 + 57) * 3 and b[:10] == a
+    assert all(0 <= v < PC.BN254_R for v in b)
+
+
+def test_default_goldilocks_table():
+    rc = PC.default_round_constants()
+    assert len(rc) == 360 and all(0 <= v < PC.GL_P for v in rc)
+    # the (1,0,64,12,8,22) stream starts with these two values
+    assert rc[0] == 0x13DCF33ABA214F46 and rc[1] == 0x30B3B654A1DA6D83
+    mds = PC.default_mds()
+    # effective first row = circulant first row + diagonal term: [17+8, 15, 41, ...]
+    assert mds[:12] == [25, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+    for r in range(12):
+        for j in range(12):
+            assert mds[r * 12 + j] == PC.MDS_CIRC[(j - r) % 12] + (8 if r == j == 0 else 0)
+
+
+def test_compiled_in_table_is_the_generated_one():
+    path = os.path.join(ROOT, "eigen_zeth_amd", "csrc", "poseidon_default_table.inc")
+    text = open(path).read()
+    rc_txt, mds_txt = text.split("ZP_POSEIDON_DEFAULT_MDS")
+    rc = [int(h, 16) for h in re.findall(r"0x([0-9a-f]{16})ULL", rc_txt)]
+    assert rc == PC.default_round_constants()
+    mds = [int(v) for v in re.findall(r"\b(\d+)\b", mds_txt.split("{", 1)[1])]
+    assert mds == PC.default_mds()
