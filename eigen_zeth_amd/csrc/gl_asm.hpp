@@ -1,0 +1,52 @@
+// Hand-scheduled Goldilocks butterflies for gfx950 (device only).
+//
+// hipcc lowers gl_add / gl_sub (gl.hpp) to 64-bit adds + v_cmp_*_u64 + two selects: 6 VALU each, and it pads every
+// VALU-writes-SGPR -> VALU-reads-SGPR pair (carry, compare mask) with s_nop because it keeps each chain contiguous.
+// Here the same canonical results come from carry chains:
+//     x - y : v_sub_co, v_subb_co            borrow br  => subtract EPS = 2^32 - 1 (i.e. add p mod 2^64):
+//             lo += br (carry c2), hi -= br & ~c2                                   4 VALU + 1 SALU
+//     x + y : v_add_co, v_addc_co  (carry c1);  u = s + EPS (carry c2  <=>  s >= p);
+//             take u when c1 | c2                                                    6 VALU + 1 SALU
+// and two butterflies are issued as four round-robin streams, so every SGPR written by a VALU instruction is read at
+// least three instructions later (gfx950 needs two wait states there; inside an asm statement nobody pads them).
+// Inputs and outputs are canonical (< p), bit-identical to gl_add / gl_sub.
+#pragma once
+#include "gl.hpp"
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ void gl_bfly2(u64 &xa, u64 &ya, u64 &xb, u64 &yb) {
+    u32 xa0 = (u32)xa, xa1 = (u32)(xa >> 32), ya0 = (u32)ya, ya1 = (u32)(ya >> 32);
+    u32 xb0 = (u32)xb, xb1 = (u32)(xb >> 32), yb0 = (u32)yb, yb1 = (u32)(yb >> 32);
+    u32 ta0, ta1, ua0, ua1, tb0, tb1, ub0, ub1;
+    u64 ca, fa, ea, ga, cb, fb, eb, gb;
+    asm("v_sub_co_u32 %8, %16, %0, %2\n\t"          //  1 S1a  t0 = x0 - y0            -> c
+        "v_add_co_u32 %0, %18, %0, %2\n\t"          //  2 A1a  x0 = x0 + y0            -> e
+        "v_sub_co_u32 %12, %20, %4, %6\n\t"         //  3 S1b
+        "v_add_co_u32 %4, %22, %4, %6\n\t"          //  4 A1b
+        "v_subb_co_u32 %9, %16, %1, %3, %16\n\t"    //  5 S2a  t1 = x1 - y1 - c        -> c = borrow
+        "v_addc_co_u32 %1, %18, %1, %3, %18\n\t"    //  6 A2a  x1 = x1 + y1 + e        -> e = carry c1
+        "v_subb_co_u32 %13, %20, %5, %7, %20\n\t"   //  7 S2b
+        "v_addc_co_u32 %5, %22, %5, %7, %22\n\t"    //  8 A2b
+        "v_addc_co_u32 %2, %17, %8, 0, %16\n\t"     //  9 S3a  y0 = t0 + borrow        -> f
+        "v_add_co_u32 %10, %19, %0, -1\n\t"         // 10 A3a  u0 = x0 + 0xFFFFFFFF    -> g
+        "v_addc_co_u32 %6, %21, %12, 0, %20\n\t"    // 11 S3b
+        "v_add_co_u32 %14, %23, %4, -1\n\t"         // 12 A3b
+        "s_andn2_b64 %16, %16, %17\n\t"             // 13 S4a  c = borrow & ~f
+        "v_addc_co_u32 %11, %19, %1, 0, %19\n\t"    // 14 A4a  u1 = x1 + g             -> g = carry c2
+        "s_andn2_b64 %20, %20, %21\n\t"             // 15 S4b
+        "v_addc_co_u32 %15, %23, %5, 0, %23\n\t"    // 16 A4b
+        "v_subbrev_co_u32 %3, %17, 0, %9, %16\n\t"  // 17 S5a  y1 = t1 - c
+        "s_or_b64 %18, %18, %19\n\t"                // 18 A5a  e = c1 | c2
+        "v_subbrev_co_u32 %7, %21, 0, %13, %20\n\t" // 19 S5b
+        "s_or_b64 %22, %22, %23\n\t"                // 20 A5b
+        "v_cndmask_b32 %0, %0, %10, %18\n\t"        // 21 A6a
+        "v_cndmask_b32 %1, %1, %11, %18\n\t"        // 22 A7a
+        "v_cndmask_b32 %4, %4, %14, %22\n\t"        // 23 A6b
+        "v_cndmask_b32 %5, %5, %15, %22"            // 24 A7b
+        : "+v"(xa0), "+v"(xa1), "+v"(ya0), "+v"(ya1), "+v"(xb0), "+v"(xb1), "+v"(yb0), "+v"(yb1),   // 0..7
+          "=&v"(ta0), "=&v"(ta1), "=&v"(ua0), "=&v"(ua1), "=&v"(tb0), "=&v"(tb1), "=&v"(ub0), "=&v"(ub1),  // 8..15
+          "=&s"(ca), "=&s"(fa), "=&s"(ea), "=&s"(ga), "=&s"(cb), "=&s"(fb), "=&s"(eb), "=&s"(gb));        // 16..23
+    xa = ((u64)xa1 << 32) | xa0; ya = ((u64)ya1 << 32) | ya0;
+    xb = ((u64)xb1 << 32) | xb0; yb = ((u64)yb1 << 32) | yb0;
+}
+#endif

@@ -133,6 +133,24 @@ __global__ void __launch_bounds__(64) poseidon_perm_small_kernel(u64 *states, in
     if (on) states[(size_t)perm * 12 + e] = gl_canon(s);
 }
 
+// proof-of-work grinding (before the query phase of a STARK): lane = candidate nonce base + gid; a hit is a nonce with
+// Poseidon(seed[0..3] || nonce || 0^7)[0] >> (64 - bits) == 0; the smallest hit of the batch wins (atomicMin).
+template <bool DEFMDS>
+__global__ void __launch_bounds__(256) pow_grind_kernel(const u64 *__restrict__ seed4, int bits, u64 base, u64 *best,
+                                                       const u64 *rc, const u32 *mds) {
+    __shared__ u32 smds[DEFMDS ? 1 : 144];
+    mds = stage_mds<DEFMDS>(mds, smds);
+    const u64 nonce = base + (u64)blockIdx.x * 256 + threadIdx.x;
+    u64 s[12];
+#pragma unroll
+    for (int j = 0; j < 4; j++) s[j] = seed4[j];
+    s[4] = nonce;
+#pragma unroll
+    for (int j = 5; j < 12; j++) s[j] = 0;
+    poseidon_perm<DEFMDS>(s, rc, mds);
+    if ((s[0] >> (64 - bits)) == 0) atomicMin((unsigned long long *)best, (unsigned long long)nonce);
+}
+
 // leaf i = linear hash of (cols[0][i], cols[1][i], ... cols[W-1][i]);  lane = row
 template <bool DEFMDS>
 __global__ void __launch_bounds__(256) merkle_leaves_kernel(const u64 *__restrict__ cols, size_t M, int W,
@@ -370,6 +388,34 @@ int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count) {
                            (u64 *)d_states, count, ctx->d_rc, ctx->d_mds);
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
+}
+
+int32_t zp_pow_grind(zp_ctx *ctx, const uint64_t *h_seed4, int32_t bits, uint64_t *h_nonce) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "pow_grind");
+    ZP_ARG(ctx, h_seed4 && h_nonce, "null pointer");
+    ZP_ARG(ctx, bits >= 0 && bits <= 40, "bits must be in [0,40]");
+    for (int i = 0; i < 4; i++) ZP_ARG(ctx, h_seed4[i] < GL_P, "seed not canonical");
+    if (bits == 0) { *h_nonce = 0; return ZP_OK; }
+    ZP_TRY(zpi_poseidon_sync_tables(ctx));
+    u64 *d;   // [0..3] seed, [4] best nonce of the batch
+    ZP_TRY(zpi_scratch(ctx, 3, 8, &d));
+    u64 h[5] = {h_seed4[0], h_seed4[1], h_seed4[2], h_seed4[3], ~0ULL};
+    ZP_TRY(zpi_h2d_small(ctx, d, h, sizeof(h)));
+    const u64 batch = 1ULL << (bits >= 16 ? 20 : bits + 4);   // expected hits per batch: 16 (fewer for bits >= 16)
+    for (u64 base = 0;; base += batch) {
+        ZP_ARG(ctx, base < (1ULL << 50), "no proof-of-work nonce below 2^50");
+        if (ctx->mds_is_default)
+            hipLaunchKernelGGL(pow_grind_kernel<true>, dim3((unsigned)(batch / 256)), dim3(256), 0, ctx->stream, d, (int)bits, base, d + 4,
+                               ctx->d_rc, ctx->d_mds);
+        else
+            hipLaunchKernelGGL(pow_grind_kernel<false>, dim3((unsigned)(batch / 256)), dim3(256), 0, ctx->stream, d, (int)bits, base, d + 4,
+                               ctx->d_rc, ctx->d_mds);
+        ZP_HIP(ctx, hipGetLastError());
+        u64 best;
+        ZP_TRY(zpi_d2h_small(ctx, &best, d + 4, sizeof(best)));
+        if (best != ~0ULL) { *h_nonce = best; return ZP_OK; }
+    }
 }
 
 int32_t zp_merkle_commit(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, uint64_t *d_tree) {

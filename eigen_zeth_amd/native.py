@@ -55,6 +55,7 @@ SIGNATURES = {
     "zp_twiddle_rows": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32]),
     "zp_lde": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_poseidon_perm": (C.c_int32, [_vp, _vp, C.c_size_t]),
+    "zp_pow_grind": (C.c_int32, [_vp, _vp, C.c_int32, _vp]),
     "zp_merkle_commit": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp]),
     "zp_merkle_commit_rows": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _vp]),
     "zp_merkle_open": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _u64p]),
@@ -290,6 +291,12 @@ class Prover:
 
     def poseidon_perm(self, d_states, count):
         self._chk(self.lib.zp_poseidon_perm(self.ctx, _ptr(d_states), count))
+
+    def pow_grind(self, seed4, bits):
+        sd = (C.c_uint64 * 4)(*[int(v) for v in seed4])
+        out = C.c_uint64(0)
+        self._chk(self.lib.zp_pow_grind(self.ctx, sd, int(bits), C.byref(out)))
+        return int(out.value)
 
     def merkle_commit(self, d_cols, M, W, d_tree):
         self._chk(self.lib.zp_merkle_commit(self.ctx, _ptr(d_cols), M, W, _ptr(d_tree)))

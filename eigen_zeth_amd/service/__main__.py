@@ -15,14 +15,18 @@ def main():
     ap.add_argument("--air", default="chunk64")
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--chunks-per-block", type=int, default=1)
+    ap.add_argument("--logb", type=int, default=1, help="log2 of the LDE blow-up (1 bit of soundness per query and unit)")
+    ap.add_argument("--n-queries", type=int, default=80, help="FRI queries per chunk proof")
+    ap.add_argument("--pow-bits", type=int, default=20, help="proof-of-work grinding bits before the query phase")
     ap.add_argument("--l2-addr", default=None, help="L2 JSON-RPC (ZETH_L2_ADDR) to fetch block inputs from")
     ap.add_argument("--devices", default=None, help="comma-separated GPU ids to spread chunk proofs over (default: --device)")
     ap.add_argument("--metrics-port", type=int, default=None, help="serve Prometheus text metrics on /metrics")
     a = ap.parse_args()
-    server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, chunks_per_block=a.chunks_per_block, l2_addr=a.l2_addr), a.device,
+    server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, logb=a.logb, chunks_per_block=a.chunks_per_block, l2_addr=a.l2_addr, n_queries=a.n_queries, pow_bits=a.pow_bits), a.device,
                          metrics_port=a.metrics_port,
                          devices=[int(x) for x in a.devices.split(',')] if a.devices else None)
-    print("prover.v1.ProverService listening on %s:%d" % (a.host, port), flush=True)
+    print("prover.v1.ProverService listening on %s:%d  (chunk STARKs: %d queries x blow-up %d + %d grinding bits = %d bits conjectured)"
+          % (a.host, port, a.n_queries, 1 << a.logb, a.pow_bits, a.n_queries * a.logb + a.pow_bits), flush=True)
     try:
         while True:
             time.sleep(3600)

@@ -28,11 +28,14 @@ from . import groth16
 
 
 class EngineConfig:
-    def __init__(self, air="chunk64", logn=12, logb=1, chunks_per_block=1, n_queries=16, fri_logf=3, fri_final_log=5,
+    """Default chunk-STARK security: 80 queries x blow-up 2 (1 bit each) + 20 bits of proof-of-work grinding = 100 bits
+    conjectured (stark/prover.py StarkParams.security_bits); every value is bound into the proof's transcript."""
+
+    def __init__(self, air="chunk64", logn=12, logb=1, chunks_per_block=1, n_queries=80, fri_logf=3, fri_final_log=5,
                  groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
-                 witness_threads=8, prover_streams=4):
+                 witness_threads=8, prover_streams=4, pow_bits=20):
         self.air, self.logn, self.logb = air, logn, logb
-        self.chunks_per_block, self.n_queries = chunks_per_block, n_queries
+        self.chunks_per_block, self.n_queries, self.pow_bits = chunks_per_block, n_queries, pow_bits
         self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
         self.groth16_logm, self.crs_dir = groth16_logm, crs_dir
         self.l2_addr, self.txs_per_chunk = l2_addr, txs_per_chunk   # optional block-input fetcher
@@ -50,12 +53,22 @@ class Engine:
         self.metrics = None   # service/metrics.py Metrics, attached by serve()
         self._g16 = None
         self._extra_be, self._be_lock = [], threading.Lock()
+        # One request at a time per engine: every backend (zp_ctx: scratch buffers, pinned staging, buffer pools,
+        # last-error slot) is single-threaded by contract, and backend 0 also serves state roots, witness uploads
+        # and the Groth16 MSMs.  A reconnecting client may replay a request while the old handler still runs
+        # (src/prover/provider.rs:671-700): the replay waits here, it never drives the same ctx concurrently.
+        self._serial = threading.RLock()
+        self._free_be = None    # engine-owned pool of idle proving backends, shared by all calls
 
     @property
     def be(self):
         if self._be is None:
             self._be = self._factory()   # HipBackend(): raises without libzethprover.so / a GPU
         return self._be
+
+    def stark_params(self, logn=None):
+        return PR.StarkParams(self.cfg.logn if logn is None else logn, self.cfg.logb, self.cfg.fri_logf, self.cfg.fri_final_log,
+                              self.cfg.n_queries, self.cfg.pow_bits)
 
     def _backends(self, n):
         """the first n proving backends (one ctx / stream each); backend 0 is self.be.  With several factories
@@ -74,6 +87,10 @@ class Engine:
 
     # ---- GenBatchChunks
     def gen_batch_chunks(self, batch_id, blocks, chain_id, program_name):
+        with self._serial:
+            return self._gen_batch_chunks(batch_id, blocks, chain_id, program_name)
+
+    def _gen_batch_chunks(self, batch_id, blocks, chain_id, program_name):
         if not blocks:
             raise ValueError("empty batch")
         if program_name and program_name.lower() != "evm":
@@ -102,6 +119,10 @@ class Engine:
 
     # ---- GenChunkProof
     def gen_chunk_proofs(self, batch_id, task_id, chunk_count, batch_data):
+        with self._serial:
+            return self._gen_chunk_proofs(batch_id, task_id, chunk_count, batch_data)
+
+    def _gen_chunk_proofs(self, batch_id, task_id, chunk_count, batch_data):
         plan = json.loads(batch_data)
         chunks = plan["chunks"]
         if len(chunks) != chunk_count:
@@ -125,10 +146,12 @@ class Engine:
         # proving runs on `prover_streams` backends (ctxs with their own streams) in as many threads: the latency-bound
         # tail of one proof (FRI layers, queries, transcript) overlaps the Poseidon-bound head of the next
         n_streams = max(1, min(self.cfg.prover_streams * len(self._factories), len(chunks)))
-        backends = self._backends(n_streams)
-        free_be = queue.SimpleQueue()
-        for b in backends:
-            free_be.put(b)
+        if self._free_be is None or self._free_be[0] < n_streams:   # (size, queue): grown under the engine lock, all idle here
+            free_be = queue.SimpleQueue()
+            for b in self._backends(n_streams):
+                free_be.put(b)
+            self._free_be = (n_streams, free_be)
+        free_be = self._free_be[1]
         ahead = threading.Semaphore(self.cfg.witness_threads + 2)   # witnesses generated but not yet proven (memory bound)
 
         def witness_bounded(ch):
@@ -144,7 +167,7 @@ class Engine:
             be = free_be.get()
             try:
                 tm = {"witness(host)": tw}
-                params = PR.StarkParams(ch["logn"], self.cfg.logb, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.n_queries)
+                params = self.stark_params(ch["logn"])
                 proof = PR.prove(air, trace, pubs, params, be, timings=tm)
             finally:
                 free_be.put(be)
@@ -187,6 +210,10 @@ class Engine:
         return groth16.vk_to_json(self.groth16_keys()[2])
 
     def final(self, batch_id, recursive_proof, curve_name, aggregator_addr):
+        with self._serial:
+            return self._final(batch_id, recursive_proof, curve_name, aggregator_addr)
+
+    def _final(self, batch_id, recursive_proof, curve_name, aggregator_addr):
         if (curve_name or "").upper() not in ("BN128", "BN254"):
             raise ValueError("unsupported curve %r" % curve_name)
         if not recursive_proof:

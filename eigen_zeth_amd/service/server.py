@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import base64
 import os
+import threading
 import time
 from concurrent import futures
 
@@ -28,17 +29,26 @@ class ProverService:
         if metrics is not None:
             engine.metrics = metrics
         self.last_id, self.last_end, self.cur_id, self.cur_start = "", 0, "", 0
+        # gRPC serves every stream on its own worker thread.  `_work` makes load -> compute -> save of a request atomic,
+        # so a replay that arrives on a new stream while the old handler is still proving waits and then finds the
+        # stored result (in-flight dedup per batch: nothing is computed twice, no ctx is driven from two threads);
+        # `_stat` guards the few status fields GetStatus reads while a proof is running.
+        self._work, self._stat = threading.Lock(), threading.Lock()
 
     # ---- the stream
     def prover_stream(self, request_iterator, context):
         for req in request_iterator:
             kind = req.WhichOneof("request_type")
             resp = proto.ProverResponse(id=req.id)
-            self.cur_id, self.cur_start = req.id, int(time.time())
+            if kind == "get_status":      # never waits for a running proof
+                self._status(resp)
+                yield resp
+                continue
+            with self._stat:
+                self.cur_id, self.cur_start = req.id, int(time.time())
+            self._work.acquire()
             try:
-                if kind == "get_status":
-                    self._status(resp)
-                elif kind == "gen_batch_proof":
+                if kind == "gen_batch_proof":
                     step = req.gen_batch_proof.WhichOneof("step")
                     if step == "gen_batch_chunks":
                         self._batch_chunks(req.gen_batch_proof.gen_batch_chunks, resp.gen_batch_proof.gen_batch_chunks)
@@ -54,7 +64,9 @@ class ProverService:
                 else:
                     self._status(resp, error="request without request_type")
             finally:
-                self.last_id, self.last_end, self.cur_id = req.id, int(time.time()), ""
+                self._work.release()
+                with self._stat:
+                    self.last_id, self.last_end, self.cur_id = req.id, int(time.time()), ""
             if self.metrics is not None:
                 self.metrics.count_request(*_outcome(resp))
             yield resp
@@ -133,11 +145,13 @@ class ProverService:
         s = resp.get_status
         s.id = "zeth-prover-mi355x"
         s.result_code = 1 if error else 0
-        s.status = proto.STATUS_IDLE
+        with self._stat:
+            busy, last_id, last_end = bool(self.cur_id), self.last_id, self.last_end
+        s.status = getattr(proto, "STATUS_COMPUTING", proto.STATUS_IDLE) if busy else proto.STATUS_IDLE
         if error:
             s.error_message = error
         ps = s.prover_status
-        ps.last_computed_request_id, ps.last_computed_end_time = self.last_id, self.last_end
+        ps.last_computed_request_id, ps.last_computed_end_time = last_id, last_end
         ps.version_proto, ps.version_server = "v0_0_1", VERSION
         ps.prover_name, ps.prover_id = "zeth-prover-mi355x", str(os.getpid())
         ps.number_of_cores = os.cpu_count() or 0

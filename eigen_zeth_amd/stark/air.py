@@ -2,8 +2,7 @@
 
 An AIR is a list of polynomial constraints over the trace columns at the current and the next
 row, fixed selector columns, public inputs and the evaluation point x.  Constraints are expression
-trees; `emit_quotient_source` turns them into one row-parallel kernel (HIP for the product, plain C
-for the CPU checker) that evaluates every constraint at an LDE row, combines them with powers of the
+trees; `emit_quotient_source` turns them into one row-parallel kernel (HIP for gfx950) that evaluates every constraint at an LDE row, combines them with powers of the
 F_{p^3} challenge alpha and multiplies by 1/Z_H(x) (periodic with the blow-up).  The reference has
 no counterpart (the prover is external to eigen-zeth); the request this serves is
 GenChunkProof (src/prover/provider.rs:358-377).
@@ -88,10 +87,22 @@ class Air:
         self.stage2 = list(stage2) if stage2 else []
         self.width2 = sum(STAGE2_WIDTH[s["kind"]] for s in self.stage2)
         self.n_chal = 3 if stage2 else 0
+        self._program = None
+
+    def program(self):
+        """the constraint program blob (u64 words, layout in include/zeth_prover.h "constraint program"): the AIR as
+        DATA -- what zp_eval_quotient interprets on the GPU and what the checker in oracle/ decodes on its own."""
+        if self._program is None:
+            self._program = compile_program(self)
+        return self._program
 
     def digest(self):
-        h = hashlib.sha256(repr([c.key() for c in self.constraints]).encode()).hexdigest()
-        return h[:16]
+        return hashlib.sha256(self.program().tobytes()).hexdigest()[:16]
+
+    def digest_words(self):
+        """the digest as four u64 words (absorbed into the Fiat-Shamir transcript)"""
+        h = hashlib.sha256(self.program().tobytes()).digest()
+        return [int.from_bytes(h[8 * i:8 * i + 8], "little") % P for i in range(4)]
 
     @property
     def symbol(self):
@@ -193,6 +204,111 @@ def get_air(name):
     return BUILTIN_AIRS[name]()
 
 
+# ---------------------------------------------------------------------------------- constraint program (AIR as data)
+PROGRAM_MAGIC = int.from_bytes(b"ZPAIR1\0\0", "little")
+OP_ADD, OP_SUB, OP_MUL, OP_OUT = 1, 2, 3, 4
+K_SLOT, K_COL, K_COLN, K_FIXED, K_PUB, K_CONST, K_XML = 0, 1, 2, 3, 4, 5, 6
+S2_PERM, S2_LOOKUP = 1, 2
+PROGRAM_HEADER_WORDS = 12
+
+
+def degree(e):
+    """(a, b): the polynomial e has degree <= a*(N-1) + b when every column is a polynomial of degree N-1"""
+    if isinstance(e, (Col, Fixed)):
+        return (1, 0)
+    if isinstance(e, XMinusLast):
+        return (0, 1)
+    if isinstance(e, (Pub, Const, Chal)):
+        return (0, 0)
+    da, db = degree(e.a), degree(e.b)
+    if e.op == "mul":
+        return (da[0] + db[0], da[1] + db[1])
+    return max(da, db)
+
+
+def quotient_chunks(air):
+    """number of degree-<N pieces the quotient splits into: deg(C/Z_H) = (a-1)N - a + b"""
+    q = 1
+    for c in air.constraints:
+        a, b = degree(c)
+        q = max(q, a - 1 if b < a else a)
+    return q
+
+
+def compile_program(air):
+    """Expr trees -> common-subexpression-eliminated three-address code over a small slot file -> u64 blob.
+    Constraint k is announced by an OUT instruction right after the value it names exists, so an interpreter can
+    fold it into its alpha-accumulators at once and no constraint value has to stay live."""
+    import numpy as np
+    consts, cmap = [], {}
+    instrs, memo = [], {}          # instrs: [op, a_ref, b_ref]; the value of instruction k is SSA name k
+
+    def ref(e):
+        k = e.key()
+        if k in memo:
+            return memo[k]
+        if isinstance(e, Col):
+            r = (K_COLN if e.nxt else K_COL, e.i)
+        elif isinstance(e, Fixed):
+            r = (K_FIXED, e.i)
+        elif isinstance(e, Pub):
+            r = (K_PUB, e.i)
+        elif isinstance(e, Chal):
+            r = (K_PUB, air.n_pub + e.i)          # challenges follow the publics
+        elif isinstance(e, Const):
+            if e.v not in cmap:
+                cmap[e.v] = len(consts)
+                consts.append(e.v)
+            r = (K_CONST, cmap[e.v])
+        elif isinstance(e, XMinusLast):
+            r = (K_XML, 0)
+        else:
+            a, b = ref(e.a), ref(e.b)
+            instrs.append([{"add": OP_ADD, "sub": OP_SUB, "mul": OP_MUL}[e.op], a, b])
+            r = ("ssa", len(instrs) - 1)
+        memo[k] = r
+        return r
+
+    for c in air.constraints:
+        r = ref(c)
+        instrs.append([OP_OUT, r, (K_CONST, 0)])
+    # slot allocation: SSA value k lives from instruction k to its last use
+    last = {}
+    for k, (_, a, b) in enumerate(instrs):
+        for r in (a, b):
+            if r[0] == "ssa":
+                last[r[1]] = k
+    expiring = {}
+    for v, k in last.items():
+        expiring.setdefault(k, []).append(v)
+    free, slot_of, n_slots, words = [], {}, 0, []
+    for k, (op, a, b) in enumerate(instrs):
+        (ka, ia), (kb, ib) = [((K_SLOT, slot_of[r[1]]) if r[0] == "ssa" else r) for r in (a, b)]
+        for v in expiring.get(k, []):     # operands that die here free their slot first: dst may reuse a source slot
+            free.append(slot_of[v])
+        d = 0
+        if op != OP_OUT:
+            assert k in last, "dead value after CSE"
+            if free:
+                d = free.pop()
+            else:
+                d = n_slots
+                n_slots += 1
+            slot_of[k] = d
+        assert max(ia, ib, d) < (1 << 16) and max(ka, kb) < 16
+        words.append(op | (d << 8) | (ka << 24) | (ia << 28) | (kb << 44) | (ib << 48))
+    s2 = []
+    for st in air.stage2:
+        if st["kind"] == "perm":
+            s2 += [S2_PERM, st["a"], st["b"], 0]
+        else:
+            s2 += [S2_LOOKUP, st["a"], st["t"], st["m"]]
+    hdr = [PROGRAM_MAGIC, air.width, air.width2, air.n_fixed, air.n_pub, air.n_chal, len(consts), len(words),
+           len(air.constraints), max(n_slots, 1), len(air.stage2), quotient_chunks(air)]
+    assert len(hdr) == PROGRAM_HEADER_WORDS
+    return np.array(hdr + consts + words + s2, dtype=np.uint64)
+
+
 # ---------------------------------------------------------------------------------- code generation
 class _Emitter:
     """common-subexpression-eliminating emitter of straight-line code over u64 field elements"""
@@ -233,8 +349,10 @@ class _Emitter:
         return r
 
 
-def emit_quotient_source(air, target):
-    """target: 'hip' (device kernel + host launcher exported as air.symbol) or 'c' (OpenMP loop)"""
+def emit_quotient_source(air, target="hip"):
+    """device kernel + host launcher exported as air.symbol (gfx950 only; the checker in oracle/ interprets the
+    constraint program blob instead and shares no code with this emitter)"""
+    assert target == "hip"
     em = _Emitter(air.n_pub)
     outs = [em.emit(c) for c in air.constraints]
     body = []
@@ -243,18 +361,12 @@ def emit_quotient_source(air, target):
     for i in sorted(em.fixed):
         body.append("    const u64 f%d = fixedc[(u64)%d * M + r];" % (i, i))
     body += em.lines
-    if target == "hip":
-        # random linear combination with alpha^k as three unreduced 160-bit dot products (gl_acc), reduced once
-        body.append("    gl_acc s0 = gl_acc_zero(), s1 = gl_acc_zero(), s2 = gl_acc_zero();")
-        for k, o in enumerate(outs):
-            body.append("    gl_acc_mac(s0, %s, apow[%d]); gl_acc_mac(s1, %s, apow[%d]); gl_acc_mac(s2, %s, apow[%d]);"
-                        % (o, 3 * k, o, 3 * k + 1, o, 3 * k + 2))
-        body.append("    const u64 a0 = gl_acc_reduce(s0), a1 = gl_acc_reduce(s1), a2 = gl_acc_reduce(s2);")
-    else:
-        body.append("    u64 a0 = 0, a1 = 0, a2 = 0;")
-        for k, o in enumerate(outs):
-            body.append("    a0 = gl_add(a0, gl_mul(%s, apow[%d])); a1 = gl_add(a1, gl_mul(%s, apow[%d])); "
-                        "a2 = gl_add(a2, gl_mul(%s, apow[%d]));" % (o, 3 * k, o, 3 * k + 1, o, 3 * k + 2))
+    # random linear combination with alpha^k as three unreduced 160-bit dot products (gl_acc), reduced once
+    body.append("    gl_acc s0 = gl_acc_zero(), s1 = gl_acc_zero(), s2 = gl_acc_zero();")
+    for k, o in enumerate(outs):
+        body.append("    gl_acc_mac(s0, %s, apow[%d]); gl_acc_mac(s1, %s, apow[%d]); gl_acc_mac(s2, %s, apow[%d]);"
+                    % (o, 3 * k, o, 3 * k + 1, o, 3 * k + 2))
+    body.append("    const u64 a0 = gl_acc_reduce(s0), a1 = gl_acc_reduce(s1), a2 = gl_acc_reduce(s2);")
     body.append("    const u64 zi = zhinv[r & (b - 1)];")
     body.append("    out[r] = gl_mul(a0, zi); out[M + r] = gl_mul(a1, zi); out[2 * M + r] = gl_mul(a2, zi);")
     body = "\n".join(body)
@@ -267,31 +379,11 @@ def emit_quotient_source(air, target):
     xcode = ("    const u64 rn = (r + b) & (M - 1);\n"
              "    const u64 x = gl_mul(shift, gl_mul(xs_lo[r & ((1ULL << lb) - 1)], xs_hi[r >> lb]));\n"
              "    const u64 xml = gl_sub(x, wlast);\n")
-    if target == "hip":
-        return (hdr + '#include <hip/hip_runtime.h>\n#include "gl.hpp"\n'
-                "__global__ void __launch_bounds__(256) %s_kernel(%s) {\n"
-                "    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (r >= M) return;\n%s%s\n}\n"
-                'extern "C" int %s(void *stream, %s) {\n'
-                "    hipLaunchKernelGGL(%s_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,\n"
-                "                       cols, fixedc, M, b, pub, apow, zhinv, xs_lo, xs_hi, lb, shift, wlast, out);\n"
-                "    return (int)hipGetLastError();\n}\n"
-                % (air.symbol, args, xcode, body, air.symbol, args, air.symbol))
-    return (hdr + '#include "gl_field.h"\n'
-            "void %s(%s) {\n#pragma omp parallel for schedule(static)\n"
-            "    for (u64 r = 0; r < M; r++) {\n%s%s\n    }\n}\n"
-            % (air.symbol, args.replace("__restrict__", "restrict"), xcode, body))
-
-
-# ---------------------------------------------------------------------------------- evaluation over F_{p^3}
-def eval_constraints_ext(air, col_at, col_next_at, fixed_at, pubs, xml, mul, add, sub, embed, chal=()):
-    """used by verifiers: evaluate every constraint with arbitrary field callbacks"""
-    def ev(e):
-        if isinstance(e, Col): return (col_next_at if e.nxt else col_at)[e.i]
-        if isinstance(e, Fixed): return fixed_at[e.i]
-        if isinstance(e, Pub): return embed(pubs[e.i])
-        if isinstance(e, Const): return embed(e.v)
-        if isinstance(e, Chal): return embed(chal[e.i])
-        if isinstance(e, XMinusLast): return xml
-        a, b = ev(e.a), ev(e.b)
-        return {"add": add, "sub": sub, "mul": mul}[e.op](a, b)
-    return [ev(c) for c in air.constraints]
+    return (hdr + '#include <hip/hip_runtime.h>\n#include "gl.hpp"\n'
+            "__global__ void __launch_bounds__(256) %s_kernel(%s) {\n"
+            "    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (r >= M) return;\n%s%s\n}\n"
+            'extern "C" int %s(void *stream, %s) {\n'
+            "    hipLaunchKernelGGL(%s_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,\n"
+            "                       cols, fixedc, M, b, pub, apow, zhinv, xs_lo, xs_hi, lb, shift, wlast, out);\n"
+            "    return (int)hipGetLastError();\n}\n"
+            % (air.symbol, args, xcode, body, air.symbol, args, air.symbol))

@@ -41,6 +41,9 @@ class HipBackend:
         self.p.poseidon_perm(self._perm_buf, 1)
         return [int(v) for v in self.p.download(self._perm_buf, (12,))]
 
+    def pow_grind(self, seed4, bits):
+        return self.p.pow_grind(seed4, bits)
+
     # ---- commitments
     def _root(self, tree, M):
         return [int(v) for v in self.p.download(tree, (4,), offset_elems=(2 * M - 2) * 4)]

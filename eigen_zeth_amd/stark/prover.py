@@ -17,17 +17,24 @@ P = F.P
 
 
 class StarkParams:
-    def __init__(self, logn, logb=1, fri_logf=3, fri_final_log=6, n_queries=24):
+    """Security (conjectured, ethSTARK-style): n_queries * logb + pow_bits bits -- each query of a rate-2^-logb code
+    rejects a far word with probability 1 - 2^-logb, and the prover must grind pow_bits of Poseidon work before it
+    learns the query positions.  The service default (engine.EngineConfig) is 80 queries, blow-up 2, 20 bits = 100."""
+
+    def __init__(self, logn, logb=1, fri_logf=3, fri_final_log=6, n_queries=24, pow_bits=0):
         self.logn, self.logb = logn, logb
-        self.fri_logf, self.fri_final_log, self.n_queries = fri_logf, fri_final_log, n_queries
+        self.fri_logf, self.fri_final_log, self.n_queries, self.pow_bits = fri_logf, fri_final_log, n_queries, pow_bits
 
     def to_dict(self):
         return dict(logn=self.logn, logb=self.logb, fri_logf=self.fri_logf, fri_final_log=self.fri_final_log,
-                    n_queries=self.n_queries)
+                    n_queries=self.n_queries, pow_bits=self.pow_bits)
 
     @staticmethod
     def from_dict(d):
-        return StarkParams(d["logn"], d["logb"], d["fri_logf"], d["fri_final_log"], d["n_queries"])
+        return StarkParams(d["logn"], d["logb"], d["fri_logf"], d["fri_final_log"], d["n_queries"], d.get("pow_bits", 0))
+
+    def security_bits(self):
+        return self.n_queries * self.logb + self.pow_bits
 
     def fri_schedule(self):
         """list of (log size of the layer that is committed and folded, log fold factor)"""
@@ -62,12 +69,15 @@ def prove(air, trace, pubs, params, be, timings=None):
     assert tuple(trace.shape) == (W, N)
     shift, root32 = be.shift, be.root32
     wN = F.root(logn, root32)
+    W2 = air.width2
+    assert len(pubs) == air.n_pub
+    # every parameter the verifier relies on is bound into the transcript (a proof cannot choose its own security level)
     tr = Transcript(be.poseidon_perm)
-    tr.absorb([logn, logb, W] + _ints(pubs))
+    tr.absorb([logn, logb, W, W2, params.fri_logf, params.fri_final_log, params.n_queries, params.pow_bits,
+               int(root32), int(shift)] + air.digest_words() + [len(pubs)] + _ints(pubs))
 
     # 1. commit the trace
     t0 = time.perf_counter()
-    W2 = air.width2
     Wt = W + W2                      # committed base columns: trace, then the stage-2 columns
     c1 = be.commit_trace(trace, logn, logb, W2)
     tick("lde+merkle(trace)", t0)
@@ -140,8 +150,12 @@ def prove(air, trace, pubs, params, be, timings=None):
     for c in range(3):
         tr.absorb(final_l[c])
 
-    # 6. queries
+    # 6. proof of work, then queries
     t0 = time.perf_counter()
+    pow_nonce = None
+    if params.pow_bits:
+        pow_nonce = int(be.pow_grind(tr.squeeze(4), params.pow_bits))
+        tr.absorb([pow_nonce])
     qidx = tr.indices(params.n_queries, logm)
     q_trace_vals = be.gather_rows(c1.ext, M, W, qidx)
     q_trace_paths = be.open_paths(c1.tree, M, qidx)
@@ -178,6 +192,7 @@ def prove(air, trace, pubs, params, be, timings=None):
         "evals": {"z": ev_all, "zw": ev_next},
         "fri": {"roots": [_ints(l[2].root) for l in layers], "final": final_l},
         "queries": queries,
+        **({"pow_nonce": pow_nonce} if pow_nonce is not None else {}),
     }
     tm["total"] = time.perf_counter() - t_all
     return proof

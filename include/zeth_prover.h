@@ -96,6 +96,9 @@ int32_t zp_lde(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t *d_c
 /* ---- N3: Poseidon-12 and Merkle commitment -------------------------------------------------- */
 /* d_states: u64[count][12], permuted in place */
 int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count);
+/* proof-of-work grinding in front of a STARK's query phase: *h_nonce = the smallest n with
+ * Poseidon(h_seed4[0..3] || n || 0^7)[0] >> (64 - bits) == 0   (bits in 0..40; 0 returns 0).     */
+int32_t zp_pow_grind(zp_ctx *ctx, const uint64_t *h_seed4, int32_t bits, uint64_t *h_nonce);
 /* leaf i = linear hash (sponge, rate 8, capacity 4; rows of <= 4 elements are identity-padded) of
  * row i across the W columns of d_cols u64[W][M]; d_tree receives (2M-1)*4 u64: M leaves, then
  * M/2 nodes ... the root is the last 4 elements.                                               */

@@ -588,6 +588,88 @@ void orc_logup_columns(const u64 *a, const u64 *t, const u64 *m, size_t n, const
     }
 }
 
+/* ---------------------------------------------------------------- constraint program interpreter (N4)
+ * The AIR arrives as data: the "constraint program" blob of include/zeth_prover.h (header of 12 words, constants,
+ * three-address instructions over a small slot file, OUT marks constraint k, stage-2 table).  This interpreter is
+ * written against that layout only -- it shares nothing with the product's code generator or GPU interpreter.
+ * Per LDE row r: x = shift * wM^r, xml = x - wlast, rn = (r + b) mod M;  out[c][r] = (sum_k alpha^k C_k) * zhinv[r mod b].
+ * returns 0, or -1 for a malformed program. */
+int orc_quotient_program(const u64 *prog, size_t prog_len, const u64 *cols, const u64 *fixedc, size_t M, size_t b,
+                         const u64 *pub, const u64 *apow, const u64 *zhinv, u64 shift, u64 wM, u64 wlast, u64 *out) {
+    if (prog_len < 12) return -1;
+    static const unsigned char magic[8] = {'Z', 'P', 'A', 'I', 'R', '1', 0, 0};
+    if (memcmp(prog, magic, 8) != 0) return -1;
+    const size_t n_const = prog[6], n_instr = prog[7], n_slots = prog[9], n_s2 = prog[10];
+    if (prog_len != 12 + n_const + n_instr + 4 * n_s2 || n_slots == 0 || n_slots > 4096) return -1;
+    const u64 *consts = prog + 12, *ins = consts + n_const;
+    int bad = 0;
+#pragma omp parallel
+    {
+        u64 *slots = (u64 *)malloc(n_slots * sizeof(u64));
+#pragma omp for schedule(static)
+        for (size_t r = 0; r < M; r++) {
+            const size_t rn = (r + b) & (M - 1);
+            const u64 x = gl_mul(shift, gl_pow(wM, (u64)r));
+            const u64 xml = gl_sub(x, wlast);
+            u64 acc[3] = {0, 0, 0};
+            size_t k_out = 0;
+            for (size_t i = 0; i < n_instr; i++) {
+                const u64 w = ins[i];
+                const unsigned op = (unsigned)(w & 0xFF), dst = (unsigned)((w >> 8) & 0xFFFF);
+                u64 v[2];
+                for (int o = 0; o < 2; o++) {
+                    const unsigned kind = (unsigned)((w >> (24 + 20 * o)) & 0xF), idx = (unsigned)((w >> (28 + 20 * o)) & 0xFFFF);
+                    switch (kind) {
+                        case 0: v[o] = slots[idx]; break;
+                        case 1: v[o] = cols[(size_t)idx * M + r]; break;
+                        case 2: v[o] = cols[(size_t)idx * M + rn]; break;
+                        case 3: v[o] = fixedc[(size_t)idx * M + r]; break;
+                        case 4: v[o] = pub[idx]; break;
+                        case 5: v[o] = n_const ? consts[idx] : 0; break;
+                        case 6: v[o] = xml; break;
+                        default: v[o] = 0; bad = 1;
+                    }
+                    if (op == 4) break;   /* OUT has one operand */
+                }
+                if (op == 1) slots[dst] = gl_add(v[0], v[1]);
+                else if (op == 2) slots[dst] = gl_sub(v[0], v[1]);
+                else if (op == 3) slots[dst] = gl_mul(v[0], v[1]);
+                else if (op == 4) {
+                    for (int c = 0; c < 3; c++) acc[c] = gl_add(acc[c], gl_mul(v[0], apow[3 * k_out + c]));
+                    k_out++;
+                } else bad = 1;
+            }
+            const u64 zi = zhinv[r & (b - 1)];
+            for (int c = 0; c < 3; c++) out[(size_t)c * M + r] = gl_mul(acc[c], zi);
+        }
+        free(slots);
+    }
+    return bad ? -1 : 0;
+}
+
+/* proof-of-work grinding before the query phase: the smallest nonce n with
+ * Poseidon(seed[0..3] || n || 0^7)[0] >> (64 - bits) == 0.  Blocks of 4096 nonces are searched in parallel, in order. */
+void orc_poseidon_perm(u64 *states, size_t count, const u64 *rc, const u64 *mds);
+u64 orc_pow_grind(const u64 *seed4, int bits, const u64 *rc, const u64 *mds) {
+    if (bits <= 0) return 0;
+    enum { BLK = 4096 };
+    u64 *st = (u64 *)malloc((size_t)BLK * 12 * sizeof(u64));
+    for (u64 base = 0;; base += BLK) {
+        for (size_t i = 0; i < BLK; i++) {
+            u64 *s = st + 12 * i;
+            memcpy(s, seed4, 4 * sizeof(u64));
+            s[4] = base + i;
+            memset(s + 5, 0, 7 * sizeof(u64));
+        }
+        orc_poseidon_perm(st, BLK, rc, mds);
+        for (size_t i = 0; i < BLK; i++)
+            if ((st[12 * i] >> (64 - bits)) == 0) {
+                free(st);
+                return base + i;
+            }
+    }
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -64,6 +64,10 @@ def lib():
         L.orc_deep_quotient_fast.argtypes = L.orc_deep_quotient.argtypes
         L.orc_grand_product.argtypes = [_u64p, _u64p, sz, _u64p, _u64p]
         L.orc_logup_columns.argtypes = [_u64p, _u64p, _u64p, sz, _u64p, _u64p]
+        L.orc_quotient_program.restype = i32
+        L.orc_quotient_program.argtypes = [_u64p, sz, _u64p, _u64p, sz, sz, _u64p, _u64p, _u64p, u64, u64, u64, _u64p]
+        L.orc_pow_grind.restype = u64
+        L.orc_pow_grind.argtypes = [_u64p, i32, _u64p, _u64p]
         L.orc_fri_fold.argtypes = [_u64p, _u64p, i32, i32, _u64p, u64, u64]
         L.orc_poly_eval.restype = u64
         L.orc_poly_eval.argtypes = [_u64p, sz, u64]
@@ -222,6 +226,12 @@ def poly_eval_e3_cols(coef, x3):
     out = np.empty((W, 3), dtype=np.uint64)
     lib().orc_poly_eval_e3_cols(_p(c), n, W, _p(_arr(x3)), _p(out))
     return out
+
+
+def pow_grind(seed4, bits, rc, mds):
+    """smallest nonce with Poseidon(seed || nonce || 0^7)[0] >> (64 - bits) == 0"""
+    sd = _arr([int(v) for v in seed4])
+    return int(lib().orc_pow_grind(_p(sd), int(bits), _p(_arr(rc)), _p(_arr(mds))))
 
 
 def set_simple_ntt(on):

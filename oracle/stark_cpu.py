@@ -2,41 +2,19 @@
 (TEST INFRASTRUCTURE: used by tests/ for bit-exact proof comparison and by bench.py's cpu_baseline
 leg).  It plugs into the same orchestration (eigen_zeth_amd/stark/prover.py) as the GPU backend,
 so a proof produced here and one produced on the MI355X from the same witness must be identical.
+Nothing is imported from the product package: the AIR reaches quotient() as its constraint program blob (data) and is
+run by the checker's own interpreter (gl_oracle.c: orc_quotient_program).
 PARITY UNPINNED with respect to the external reference prover (see gl_oracle.c)."""
 from __future__ import annotations
-
-import ctypes as C
-import os
-import subprocess
 
 import numpy as np
 
 from . import oracle as O
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
-_u64p = C.POINTER(C.c_uint64)
-
 
 class Commit:
     def __init__(self, root, tree, ext=None, coef=None):
         self.root, self.tree, self.ext, self.coef = root, tree, ext, coef
-
-
-def _air_cpu_lib(air):
-    from eigen_zeth_amd.stark.air import emit_quotient_source
-    bdir = os.path.join(_HERE, "_build")
-    os.makedirs(bdir, exist_ok=True)
-    src = os.path.join(bdir, "air_%s_%s.c" % (air.name, air.digest()))
-    out = src[:-2] + ".so"
-    if not os.path.exists(out):
-        with open(src, "w") as f:
-            f.write(emit_quotient_source(air, "c"))
-        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-I", _HERE, "-o", out, src])
-    fn = getattr(C.CDLL(out), air.symbol)
-    fn.restype = None
-    fn.argtypes = [_u64p, _u64p, C.c_uint64, C.c_uint64, _u64p, _u64p, _u64p, _u64p, _u64p, C.c_int, C.c_uint64,
-                   C.c_uint64, _u64p]
-    return fn
 
 
 class CpuBackend:
@@ -97,19 +75,20 @@ class CpuBackend:
     def quotient(self, air, c1, fixed, pubs, apow, zhinv, logn, logb, wlast):
         logm = logn + logb
         M = 1 << logm
-        fn = _air_cpu_lib(air)
-        lb = (logm + 1) // 2
-        w = O.lib().orc_root(self.root32, logm)
-        lo = np.array([pow(w, i, O.P) for i in range(1 << lb)], dtype=np.uint64)
-        wl = pow(w, 1 << lb, O.P)
-        hi = np.array([pow(wl, i, O.P) for i in range(1 << (logm - lb))], dtype=np.uint64)
+        prog = np.ascontiguousarray(np.asarray(air.program(), dtype=np.uint64))   # the statement, as data
         out = np.empty((3, M), dtype=np.uint64)
         pub = np.array(list(pubs) + [0], dtype=np.uint64)
         ap = np.ascontiguousarray(np.array(apow, dtype=np.uint64).reshape(-1))
         zh = np.array(zhinv, dtype=np.uint64)
-        fn(O._p(np.ascontiguousarray(c1.ext)), O._p(fixed), M, 1 << logb, O._p(pub), O._p(ap), O._p(zh), O._p(lo), O._p(hi), lb, self.shift,
-           wlast, O._p(out))
+        rc = O.lib().orc_quotient_program(O._p(prog), prog.size, O._p(np.ascontiguousarray(c1.ext)), O._p(fixed), M, 1 << logb,
+                                          O._p(pub), O._p(ap), O._p(zh), self.shift, O.lib().orc_root(self.root32, logm), wlast,
+                                          O._p(out))
+        if rc != 0:
+            raise ValueError("malformed constraint program")
         return out
+
+    def pow_grind(self, seed4, bits):
+        return O.pow_grind(seed4, bits, self.rc, self.mds)
 
     def coset_coefficients(self, planes, logm, W):
         return O.intt(np.asarray(planes).reshape(W, 1 << logm), self.root32)

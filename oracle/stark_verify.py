@@ -1,22 +1,73 @@
 """oracle/stark_verify.py -- independent verifier of the chunk STARK proofs (TEST INFRASTRUCTURE).
 
-Written against the protocol description only (pure Python ints + oracle Poseidon), sharing no
-code with the prover orchestration except the AIR's constraint expressions (the statement) and the
-transcript rule.  A proof that verifies here is the end-to-end correctness check of the GPU path:
-commitments open, the constraint identity holds out of domain, the DEEP quotient matches the opened
-rows and every FRI fold is consistent down to a low-degree final layer."""
+Written against the protocol description only (pure Python ints + oracle Poseidon).  It imports NOTHING from the
+product package: the statement arrives as data (the constraint program blob, decoded by oracle/air_program.py), and
+the Fiat-Shamir sponge, the parameter set and the FRI schedule are restated here.  A proof that verifies here is the
+end-to-end correctness check of the GPU path: commitments open, the constraint identity holds out of domain, the DEEP
+quotient matches the opened rows and every FRI fold is consistent down to a low-degree final layer.
+
+The security parameters are the CALLER's (`expect`), never the proof's: a proof that claims other parameters (fewer
+queries, another blow-up, another root of unity) is rejected, and every parameter is bound into the transcript.
+PARITY UNPINNED with respect to the external reference prover (see gl_oracle.c)."""
 from __future__ import annotations
 
 import numpy as np
 
 from . import naive as NV
 from . import oracle as O
+from .air_program import Program
 
 P = NV.P
+PARAM_KEYS = ("logn", "logb", "fri_logf", "fri_final_log", "n_queries", "pow_bits")
 
 
 class Reject(Exception):
     pass
+
+
+class Sponge:
+    """Poseidon-12 sponge, rate 8 / capacity 4.  absorb() queues elements; the next squeeze first absorbs everything
+    queued in blocks of 8 that overwrite the rate (zero padded; one permutation even when nothing is queued), then
+    hands out the 8 rate elements in order, permuting again when they are used up."""
+
+    def __init__(self, perm):
+        self.perm, self.state, self.queue, self.avail = perm, [0] * 12, [], []
+
+    def absorb(self, vals):
+        self.queue.extend(int(v) % P for v in vals)
+        self.avail = []
+
+    def squeeze(self, n):
+        out = []
+        while len(out) < n:
+            if self.queue or not self.avail:
+                if not self.queue:
+                    self.state = self.perm(self.state)
+                while self.queue:
+                    blk = self.queue[:8]
+                    del self.queue[:8]
+                    self.state = self.perm(blk + [0] * (8 - len(blk)) + self.state[8:])
+                self.avail = list(self.state[:8])
+            out.append(self.avail.pop(0))
+        return out
+
+
+def fri_schedule(logn, logb, fri_logf, fri_final_log):
+    """[(log size of the committed layer, log fold factor)], log size of the final layer sent in clear"""
+    cur, stop, sched = logn + logb, fri_final_log + logb, []
+    while cur > stop:
+        f = min(fri_logf, cur - stop)
+        sched.append((cur, f))
+        cur -= f
+    return sched, cur
+
+
+def pow_ok(perm, seed4, nonce, bits):
+    """grinding check: Poseidon(seed || nonce || 0^7)[0] has `bits` leading zero bits"""
+    if bits == 0:
+        return True
+    out = perm([int(v) for v in seed4] + [int(nonce)] + [0] * 7)
+    return 0 <= int(nonce) < P and (out[0] >> (64 - bits)) == 0
 
 
 def _mul_theta(a):  # theta * (a0 + a1 t + a2 t^2), t^3 = t + 1
@@ -47,46 +98,68 @@ def _fold(values3, logf, beta, x_base, root32):
     return acc
 
 
-def verify(proof, air, rc, mds):
-    from eigen_zeth_amd.stark.air import eval_constraints_ext
-    from eigen_zeth_amd.stark.prover import StarkParams
-    from eigen_zeth_amd.stark.transcript import Transcript
+def expectation(params, root32=NV.ROOT32_DEFAULT, shift=NV.SHIFT_DEFAULT):
+    """the verifier's parameter set from a plain dict of protocol parameters (+ the evaluation-domain constants)"""
+    e = {k: int(params[k]) for k in PARAM_KEYS if k in params}
+    e.setdefault("pow_bits", 0)
+    e["root32"], e["shift"] = int(root32), int(shift)
+    return e
 
+
+def verify(proof, program, rc, mds, expect):
+    """program: the constraint program blob (u64 words) of the statement;  expect: the verifier's own parameters
+    {logn, logb, fri_logf, fri_final_log, n_queries, pow_bits, root32, shift}."""
     rc = np.asarray(rc, dtype=np.uint64)
     mds = np.asarray(mds, dtype=np.uint64)
-    params = StarkParams.from_dict(proof["params"])
-    if proof["air"] != air.name or proof["air_digest"] != air.digest():
+    air = program if isinstance(program, Program) else Program(program)
+    missing = [k for k in PARAM_KEYS + ("root32", "shift") if k not in expect]
+    if missing:
+        raise ValueError("verifier parameters missing: %s" % missing)
+    for k in PARAM_KEYS:
+        if proof["params"].get(k) != expect[k]:
+            raise Reject("proof claims %s = %r, the verifier requires %r" % (k, proof["params"].get(k), expect[k]))
+    if proof["root32"] != expect["root32"] or proof["shift"] != expect["shift"]:
+        raise Reject("proof is over another evaluation domain")
+    if expect["n_queries"] < 1 or expect["logb"] < 1:
+        raise Reject("parameters give no soundness")
+    if proof["air_digest"] != air.digest():
         raise Reject("proof is for a different AIR")
-    root32, shift = proof["root32"], proof["shift"]
-    logn, logb = params.logn, params.logb
+    root32, shift = expect["root32"], expect["shift"]
+    logn, logb, n_queries, pow_bits = expect["logn"], expect["logb"], expect["n_queries"], expect["pow_bits"]
+    if air.q_chunks > (1 << logb):
+        raise Reject("blow-up too small for the constraint degree")
     logm = logn + logb
     N, M, W = 1 << logn, 1 << logm, air.width
     pubs = proof["publics"]
+    if len(pubs) != air.n_pub:
+        raise Reject("wrong number of public inputs")
     wN, wM = NV.root(logn, root32), NV.root(logm, root32)
 
     def perm(st):
         return [int(v) for v in O.poseidon_perm(np.array([st], dtype=np.uint64), rc, mds)[0]]
 
-    tr = Transcript(perm)
-    tr.absorb([logn, logb, W] + pubs)
-    tr.absorb(proof["roots"]["trace"])
     W2 = air.width2
     Wt = W + W2
+    tr = Sponge(perm)
+    tr.absorb([logn, logb, W, W2, expect["fri_logf"], expect["fri_final_log"], n_queries, pow_bits, root32, shift]
+              + air.digest_words() + [len(pubs)] + pubs)
+    tr.absorb(proof["roots"]["trace"])
     chal = []
     if air.stage2:
         if "stage2" not in proof["roots"]:
             raise Reject("missing stage-2 commitment")
-        chal = tr.challenge_e3()
+        chal = tr.squeeze(3)
         tr.absorb(proof["roots"]["stage2"])
-    alpha = tr.challenge_e3()
+    alpha = tr.squeeze(3)
     tr.absorb(proof["roots"]["quotient"])
-    zeta = tr.challenge_e3()
+    zeta = tr.squeeze(3)
     ev_all, ev_next = proof["evals"]["z"], proof["evals"]["zw"]
-    if len(ev_all) != Wt + 3 or len(ev_next) != Wt:
+    Q = air.q_chunks                 # the quotient is committed as Q pieces of degree < N, 3 base columns each
+    if len(ev_all) != Wt + 3 * Q or len(ev_next) != Wt:
         raise Reject("wrong number of evaluations")
     for r in ev_all + ev_next:
         tr.absorb(r)
-    gamma = tr.challenge_e3()
+    gamma = tr.squeeze(3)
 
     # ---- constraint identity at zeta
     zN = NV.e3_pow(zeta, N)
@@ -96,33 +169,42 @@ def verify(proof, air, rc, mds):
     l_first = NV.e3_mul([v * ninv % P for v in zh], NV.e3_inv(_e3_sub(zeta, [1, 0, 0])))
     l_last = NV.e3_mul([v * ninv % P * wlast % P for v in zh], NV.e3_inv(_e3_sub(zeta, [wlast, 0, 0])))
     xml = _e3_sub(zeta, [wlast, 0, 0])
-    cs = eval_constraints_ext(air, ev_all[:Wt], ev_next, [l_first, l_last], pubs, xml, NV.e3_mul, NV.e3_add, _e3_sub,
-                              lambda v: [v % P, 0, 0], chal)
+    cs = air.evaluate_ext(ev_all[:Wt], ev_next, [l_first, l_last], list(pubs) + list(chal), xml)
     lhs, ap = [0, 0, 0], [1, 0, 0]
     for c in cs:
         lhs = NV.e3_add(lhs, NV.e3_mul(ap, c))
         ap = NV.e3_mul(ap, alpha)
-    q = ev_all[Wt]
-    q = NV.e3_add(q, _mul_theta(ev_all[Wt + 1]))
-    q = NV.e3_add(q, _mul_theta(_mul_theta(ev_all[Wt + 2])))
+    q, zpow = [0, 0, 0], [1, 0, 0]
+    for j in range(Q):               # q(zeta) = sum_j zeta^(jN) (q_j0 + theta q_j1 + theta^2 q_j2)(zeta)
+        qj = ev_all[Wt + 3 * j]
+        qj = NV.e3_add(qj, _mul_theta(ev_all[Wt + 3 * j + 1]))
+        qj = NV.e3_add(qj, _mul_theta(_mul_theta(ev_all[Wt + 3 * j + 2])))
+        q = NV.e3_add(q, NV.e3_mul(zpow, qj))
+        zpow = NV.e3_mul(zpow, zN)
     if lhs != NV.e3_mul(q, zh):
         raise Reject("constraint identity fails at the out-of-domain point")
 
     # ---- FRI transcript
-    sched, final_log = params.fri_schedule()
+    sched, final_log = fri_schedule(logn, logb, expect["fri_logf"], expect["fri_final_log"])
     if len(proof["fri"]["roots"]) != len(sched):
         raise Reject("wrong number of FRI layers")
     betas = []
     for root in proof["fri"]["roots"]:
         tr.absorb(root)
-        betas.append(tr.challenge_e3())
+        betas.append(tr.squeeze(3))
     final = proof["fri"]["final"]
     if len(final) != 3 or any(len(pl) != (1 << final_log) for pl in final):
         raise Reject("bad final layer size")
     for c in range(3):
         tr.absorb(final[c])
-    qidx = tr.indices(params.n_queries, logm)
-    if [qq["index"] for qq in proof["queries"]] != qidx:
+    if pow_bits:
+        seed = tr.squeeze(4)
+        nonce = proof.get("pow_nonce")
+        if nonce is None or not pow_ok(perm, seed, nonce, pow_bits):
+            raise Reject("proof-of-work nonce missing or wrong")
+        tr.absorb([nonce])
+    qidx = [v & (M - 1) for v in tr.squeeze(n_queries)]
+    if len(proof["queries"]) != n_queries or [qq["index"] for qq in proof["queries"]] != qidx:
         raise Reject("query indices do not follow the transcript")
 
     # ---- final layer is low degree: degree < 2^(final_log - logb) on its coset
@@ -137,7 +219,7 @@ def verify(proof, air, rc, mds):
             raise Reject("final FRI layer is not low degree")
 
     zeta_w = [v * wN % P for v in zeta]
-    Wall = Wt + 3
+    Wall = Wt + 3 * Q
     gp, cur = [], [1, 0, 0]
     for _ in range(Wall + Wt):
         gp.append(cur)
@@ -146,7 +228,7 @@ def verify(proof, air, rc, mds):
     for qq in proof["queries"]:
         j = qq["index"]
         tv, qv = qq["trace"]["values"], qq["quotient"]["values"]
-        if len(tv) != W or len(qv) != 3:
+        if len(tv) != W or len(qv) != 3 * Q:
             raise Reject("bad opening width")
         if not O.merkle_verify(O.linear_hash(np.array(tv, dtype=np.uint64), rc, mds), M, j, np.array(qq["trace"]["path"], dtype=np.uint64),
                                np.array(proof["roots"]["trace"], dtype=np.uint64), rc, mds):

@@ -116,7 +116,9 @@ def test_logup_columns_match_oracle(prover, n):
 
 
 @pytest.mark.parametrize("name,logn", [("fib", 5), ("wide8", 8), ("wide32", 10)])
-def test_constraint_kernel_matches_cpu_codegen(hip_backend, cpu_backend, name, logn):
+def test_constraint_kernel_matches_the_checkers_interpreter(hip_backend, cpu_backend, name, logn):
+    """generated gfx950 kernel (product code generator) vs the checker's own interpreter of the constraint program blob
+    (oracle/gl_oracle.c: orc_quotient_program) -- two lowerings that share no code"""
     air = AIR.get_air(name)
     tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 99)
     from eigen_zeth_amd.stark import field as F
@@ -138,11 +140,11 @@ def test_gpu_proof_is_bit_identical_to_cpu_and_verifies(hip_backend, cpu_backend
     gpu = PR.prove(air, tr, pub, params, hip_backend)
     cpu = PR.prove(air, tr, pub, params, cpu_backend)
     assert PR.proof_to_json(gpu) == PR.proof_to_json(cpu)
-    assert V.verify(gpu, air, rc, mds)
+    assert V.verify(gpu, air.program(), rc, mds, V.expectation(params.to_dict()))
     bad = copy.deepcopy(gpu)
     bad["queries"][1]["fri"][0]["values"][0] ^= 1
     with pytest.raises(V.Reject):
-        V.verify(bad, air, rc, mds)
+        V.verify(bad, air.program(), rc, mds, V.expectation(params.to_dict()))
 
 
 def test_gpu_rejects_bad_witness_downstream(hip_backend, tables):
@@ -150,9 +152,10 @@ def test_gpu_rejects_bad_witness_downstream(hip_backend, tables):
     air = AIR.get_air("wide8")
     tr, pub = native.synth_trace(1, 9, 8, 3)
     tr[3, 100] = (int(tr[3, 100]) + 1) % P
-    proof = PR.prove(air, tr, pub, PR.StarkParams(9, 1, 3, 4, 6), hip_backend)
+    params = PR.StarkParams(9, 1, 3, 4, 6)
+    proof = PR.prove(air, tr, pub, params, hip_backend)
     with pytest.raises(V.Reject):
-        V.verify(proof, air, rc, mds)
+        V.verify(proof, air.program(), rc, mds, V.expectation(params.to_dict()))
 
 
 def test_blowup_four(hip_backend, cpu_backend, tables):
@@ -162,7 +165,7 @@ def test_blowup_four(hip_backend, cpu_backend, tables):
     params = PR.StarkParams(9, logb=2, fri_logf=2, fri_final_log=3, n_queries=6)
     gpu = PR.prove(air, tr, pub, params, hip_backend)
     assert PR.proof_to_json(gpu) == PR.proof_to_json(PR.prove(air, tr, pub, params, cpu_backend))
-    assert V.verify(gpu, air, rc, mds)
+    assert V.verify(gpu, air.program(), rc, mds, V.expectation(params.to_dict()))
 
 
 @pytest.mark.parametrize("name,logn", [("wide64", 22), ("wide8", 24), ("perm", 22), ("chunk64", 22)])
@@ -172,10 +175,11 @@ def test_full_size_proofs_pass_the_independent_verifier(hip_backend, tables, nam
     rc, mds = tables
     air = AIR.get_air(name)
     tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 31337)
-    proof = PR.prove(air, tr, pub, PR.StarkParams(logn, logb=1, fri_logf=3, fri_final_log=5, n_queries=16), hip_backend)
+    params = PR.StarkParams(logn, logb=1, fri_logf=3, fri_final_log=5, n_queries=16)
+    proof = PR.prove(air, tr, pub, params, hip_backend)
     del tr
-    assert V.verify(proof, air, rc, mds)
+    assert V.verify(proof, air.program(), rc, mds, V.expectation(params.to_dict()))
     bad = copy.deepcopy(proof)
     bad["evals"]["zw"][1][2] ^= 1
     with pytest.raises(V.Reject):
-        V.verify(bad, air, rc, mds)
+        V.verify(bad, air.program(), rc, mds, V.expectation(params.to_dict()))

@@ -80,7 +80,7 @@ def test_reference_fixture_grammar():
 
 
 def _start(tmp_path, backend_factory, cfg=None):
-    cfg = cfg or EngineConfig(air="wide8", logn=7, n_queries=6, fri_final_log=3)
+    cfg = cfg or EngineConfig(air="wide8", logn=7, n_queries=6, fri_final_log=3, pow_bits=6)
     cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
     engine = Engine(backend_factory, cfg)
     svc = ProverService(engine, BatchStore(str(tmp_path)))
@@ -107,7 +107,8 @@ def _check_result(res, tables, block, svc=None):
     assert pub < bn254.R
     for p in res["chunk_proofs"]:
         pr = json.loads(p)
-        assert V.verify(pr, AIR.get_air(pr["air"]), rc, mds)
+        assert V.verify(pr, AIR.get_air(pr["air"]).program(), rc, mds, V.expectation(svc.engine.stark_params(pr["params"]["logn"]).to_dict())
+                        if svc is not None else V.expectation(pr["params"]))
     if svc is not None:   # the final proof is a Groth16 proof that verifies under the service's VK (pairing check)
         from oracle import groth16_verify as GV
         vk = json.loads(svc.engine.verifying_key_json())
@@ -205,7 +206,7 @@ def test_product_service_needs_gpu():
 @pytest.mark.gpu
 def test_round_trip_gpu_matches_cpu(tmp_path, cpu_factory, tables):
     from eigen_zeth_amd.service.server import default_backend_factory
-    cfg = EngineConfig(air="chunk64", logn=12, n_queries=8)
+    cfg = EngineConfig(air="chunk64", logn=12, n_queries=8, pow_bits=12)
     server, port, svc = _start(tmp_path / "gpu", default_backend_factory(), cfg)
     server2, port2, svc2 = _start(tmp_path / "cpu", cpu_factory, cfg)
     try:
@@ -238,7 +239,7 @@ def test_block_input_fetcher_with_stub_node(tmp_path, cpu_factory):
 
     httpd = http.server.HTTPServer(("127.0.0.1", 0), H)
     threading.Thread(target=httpd.serve_forever, daemon=True).start()
-    cfg = EngineConfig(air="fib", logn=5, n_queries=4, fri_final_log=3, l2_addr="http://127.0.0.1:%d" % httpd.server_port, txs_per_chunk=2)
+    cfg = EngineConfig(air="fib", logn=5, n_queries=4, fri_final_log=3, pow_bits=4, l2_addr="http://127.0.0.1:%d" % httpd.server_port, txs_per_chunk=2)
     server, port, svc = _start(tmp_path, cpu_factory, cfg)
     try:
         ch = ProverChannel("127.0.0.1:%d" % port)
@@ -257,7 +258,7 @@ def test_metrics_endpoint_counts_requests_and_stage_time(tmp_path, cpu_factory):
     """Prometheus text on /metrics with request counters, per-stage seconds and the HBM rate gauge"""
     import urllib.request
     from eigen_zeth_amd.service.metrics import Metrics
-    cfg = EngineConfig(air="chunk16", logn=6, n_queries=4, fri_final_log=3)
+    cfg = EngineConfig(air="chunk16", logn=6, n_queries=4, fri_final_log=3, pow_bits=4)
     cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
     m = Metrics()
     httpd = m.serve(0)
@@ -285,7 +286,7 @@ def test_chunk_proofs_identical_across_streams_and_devices(tmp_path, cpu_factory
     """the engine proves chunks on several backends in parallel (streams of one GPU, or one factory per GPU):
     the batch result must not depend on how many there are"""
     def run(factories, streams):
-        cfg = EngineConfig(air="chunk16", logn=6, n_queries=4, fri_final_log=3, chunks_per_block=1, prover_streams=streams,
+        cfg = EngineConfig(air="chunk16", logn=6, n_queries=4, fri_final_log=3, pow_bits=4, chunks_per_block=1, prover_streams=streams,
                            witness_threads=3)
         cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
         eng = Engine(factories, cfg)
@@ -295,3 +296,66 @@ def test_chunk_proofs_identical_across_streams_and_devices(tmp_path, cpu_factory
     assert [p["chunk_id"] for p in one] == [0, 1, 2, 3, 4]
     assert run(cpu_factory, 3) == one
     assert run([cpu_factory, cpu_factory], 2) == one
+
+
+def test_two_concurrent_streams_replaying_one_request(tmp_path, cpu_factory):
+    """A reconnecting client replays GenChunkProof on a new stream while the old handler is still proving
+    (src/prover/provider.rs:671-700).  The service must answer both with the same proofs, compute them once, and never
+    drive one backend from two threads."""
+    import threading
+    from eigen_zeth_amd.service import proto
+    cfg = EngineConfig(air="chunk16", logn=7, n_queries=4, fri_final_log=3, pow_bits=4, chunks_per_block=3, prover_streams=2)
+    server, port, svc = _start(tmp_path, cpu_factory, cfg)
+    calls, inside, overlap = [], [0], [0]
+    real = svc.engine._gen_chunk_proofs
+
+    def counted(*a):
+        inside[0] += 1
+        overlap[0] = max(overlap[0], inside[0])
+        try:
+            calls.append(a[1])
+            return real(*a)
+        finally:
+            inside[0] -= 1
+    svc.engine._gen_chunk_proofs = counted
+    try:
+        ch = ProverChannel("127.0.0.1:%d" % port)
+        q = proto.ProverRequest(id="1")
+        g = q.gen_batch_proof.gen_batch_chunks
+        g.batch_id, g.chain_id, g.program_name = "dup", 12345, "evm"
+        g.batch.block_number.append(9)
+        r = ch._call(q).gen_batch_proof.gen_batch_chunks
+        assert r.result_code == proto.COMPLETED_OK and r.chunk_count == 3
+        out = [None, None]
+
+        def go(i):
+            c = ProverChannel("127.0.0.1:%d" % port)
+            q = proto.ProverRequest(id="r%d" % i)       # the replay carries a new request id, same batch_id
+            g = q.gen_batch_proof.gen_chunk_proof
+            g.batch_id, g.task_id, g.chunk_count, g.chain_id, g.program_name, g.batch_data = "dup", r.task_id, r.chunk_count, 12345, "evm", r.batch_data
+            out[i] = c._call(q).gen_batch_proof.gen_chunk_proof
+            c.close()
+        ts = [threading.Thread(target=go, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        ch.close()
+        a, b = out
+        assert a.result_code == proto.COMPLETED_OK and b.result_code == proto.COMPLETED_OK
+        pa = [(p.chunk_id, p.proof) for p in a.batch_proof_result.chunk_proofs]
+        assert pa == [(p.chunk_id, p.proof) for p in b.batch_proof_result.chunk_proofs] and len(pa) == 3
+        assert len(calls) == 1 and overlap[0] == 1      # computed once; the replay waited and read the stored result
+        # the engine itself serialises direct callers too
+        e2 = [None, None]
+
+        def direct(i):
+            e2[i] = svc.engine.gen_chunk_proofs("x%d" % i, r.task_id, r.chunk_count, r.batch_data)
+        ts = [threading.Thread(target=direct, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert e2[0] == e2[1] and overlap[0] == 1
+    finally:
+        server.stop(0)

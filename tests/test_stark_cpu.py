@@ -36,7 +36,8 @@ def test_codegen_is_deterministic_and_shares_subexpressions():
     src = AIR.emit_quotient_source(a, "hip")
     assert src == AIR.emit_quotient_source(AIR.wide_air(8), "hip")
     assert a.symbol in src and "__global__" in src
-    assert "omp parallel for" in AIR.emit_quotient_source(a, "c")
+    with pytest.raises(AssertionError):
+        AIR.emit_quotient_source(a, "c")      # the product emits device code only; the checker interprets the blob
     assert src.count("cols[(u64)0 * M + r]") == 1  # each column value is loaded once
 
 
@@ -53,8 +54,9 @@ def test_cpu_proof_verifies_and_tampering_is_rejected(be, tables, name, logn):
     rc, mds = tables
     air = AIR.get_air(name)
     tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 77)
-    proof = PR.prove(air, tr, pub, PR.StarkParams(logn, 1, 3, 3, 6), be)
-    assert V.verify(proof, air, rc, mds)
+    params = PR.StarkParams(logn, 1, 3, 3, 6)
+    proof = PR.prove(air, tr, pub, params, be)
+    assert V.verify(proof, air.program(), rc, mds, V.expectation(params.to_dict()))
     for mutate in (lambda p: p["evals"]["zw"][0].__setitem__(1, 5),
                    lambda p: p["roots"]["trace"].__setitem__(0, 1),
                    lambda p: p["publics"].__setitem__(0, 7),
@@ -63,9 +65,9 @@ def test_cpu_proof_verifies_and_tampering_is_rejected(be, tables, name, logn):
         bad = copy.deepcopy(proof)
         mutate(bad)
         with pytest.raises(V.Reject):
-            V.verify(bad, air, rc, mds)
+            V.verify(bad, air.program(), rc, mds, V.expectation(params.to_dict()))
     with pytest.raises(V.Reject):
-        V.verify(proof, AIR.get_air("wide32"), rc, mds)
+        V.verify(proof, AIR.get_air("wide32").program(), rc, mds, V.expectation(params.to_dict()))
 
 
 def test_wrong_witness_cannot_be_proven(be, tables):
@@ -73,9 +75,10 @@ def test_wrong_witness_cannot_be_proven(be, tables):
     air = AIR.get_air("fib")
     tr, pub = native.synth_trace(0, 6, 2, 5)
     tr[0, 9] ^= 1
-    proof = PR.prove(air, tr, pub, PR.StarkParams(6, 1, 3, 3, 6), be)
+    params = PR.StarkParams(6, 1, 3, 3, 6)
+    proof = PR.prove(air, tr, pub, params, be)
     with pytest.raises(V.Reject):
-        V.verify(proof, air, rc, mds)
+        V.verify(proof, air.program(), rc, mds, V.expectation(params.to_dict()))
 
 
 def test_permutation_argument_rejects_non_permutation(be, tables):
@@ -84,19 +87,21 @@ def test_permutation_argument_rejects_non_permutation(be, tables):
     tr, pub = native.synth_trace(2, 6, 3, 11)
     assert sorted(tr[0].tolist()) == sorted(tr[1].tolist())
     tr[1, 5] = (int(tr[1, 5]) + 1) % V.P
-    proof = PR.prove(air, tr, pub, PR.StarkParams(6, 1, 3, 3, 6), be)
+    params = PR.StarkParams(6, 1, 3, 3, 6)
+    proof = PR.prove(air, tr, pub, params, be)
     with pytest.raises(V.Reject):
-        V.verify(proof, air, rc, mds)
+        V.verify(proof, air.program(), rc, mds, V.expectation(params.to_dict()))
     good, pub = native.synth_trace(2, 6, 3, 11)
-    proof = PR.prove(air, good, pub, PR.StarkParams(6, 1, 3, 3, 6), be)
+    params = PR.StarkParams(6, 1, 3, 3, 6)
+    proof = PR.prove(air, good, pub, params, be)
     bad = copy.deepcopy(proof)
     bad["queries"][0]["stage2"]["values"][0] ^= 1
     with pytest.raises(V.Reject):
-        V.verify(bad, air, rc, mds)
+        V.verify(bad, air.program(), rc, mds, V.expectation(params.to_dict()))
     bad = copy.deepcopy(proof)
     del bad["roots"]["stage2"]
     with pytest.raises(V.Reject):
-        V.verify(bad, air, rc, mds)
+        V.verify(bad, air.program(), rc, mds, V.expectation(params.to_dict()))
 
 
 def test_chunk_trace_satisfies_every_constraint_on_the_trace_domain(tables):
@@ -106,7 +111,10 @@ def test_chunk_trace_satisfies_every_constraint_on_the_trace_domain(tables):
     import numpy as np
     P = V.P
     logn, N = 5, 32
+    from oracle.air_program import Program
     air = AIR.get_air("chunk16")
+    prog = Program(air.program())
+    assert prog.digest() == air.digest() and prog.n_constraints == len(air.constraints)
     tr, pub = native.synth_trace(3, logn, 16, 9)
     Ww = 8
     assert int(pub[7]) == N - 1 and sorted(tr[Ww + 2].tolist()) == sorted(tr[Ww + 3].tolist())
@@ -121,9 +129,7 @@ def test_chunk_trace_satisfies_every_constraint_on_the_trace_domain(tables):
         cur = [int(v) for v in full[:, i]]
         nxt = [int(v) for v in full[:, (i + 1) % N]]
         fixed = [1 if i == 0 else 0, 1 if i == N - 1 else 0]
-        vals = AIR.eval_constraints_ext(air, cur, nxt, fixed, [int(v) for v in pub], (pow(w, i, P) - wlast) % P,
-                                        lambda a, b: a * b % P, lambda a, b: (a + b) % P, lambda a, b: (a - b) % P,
-                                        lambda v: v % P, g)
+        vals = prog.evaluate_base(cur, nxt, fixed, [int(v) for v in pub] + g, (pow(w, i, P) - wlast) % P)
         assert all(v == 0 for v in vals), (i, [k for k, v in enumerate(vals) if v])
 
 
@@ -139,9 +145,79 @@ def test_lookup_argument_rejects_out_of_range_value(be, tables):
     bad[Ww + 3, :] = bad[Ww + 2, [(5 * i + 3) % 64 for i in range(64)]]
     bad[Ww + 6, j] = (int(bad[Ww + 2, j]) ** 2) % V.P
     bad[Ww + 7, j] = (int(bad[Ww, j]) * int(bad[Ww + 2, j]) + int(bad[Ww + 1, j])) % V.P
-    proof = PR.prove(air, bad, pub, PR.StarkParams(6, 1, 3, 3, 6), be)
+    params = PR.StarkParams(6, 1, 3, 3, 6)
+    proof = PR.prove(air, bad, pub, params, be)
     with pytest.raises(V.Reject):
-        V.verify(proof, air, rc, mds)
-    proof = PR.prove(air, tr, pub, PR.StarkParams(6, 1, 3, 3, 6), be)
-    assert V.verify(proof, air, rc, mds)
+        V.verify(proof, air.program(), rc, mds, V.expectation(params.to_dict()))
+    params = PR.StarkParams(6, 1, 3, 3, 6)
+    proof = PR.prove(air, tr, pub, params, be)
+    assert V.verify(proof, air.program(), rc, mds, V.expectation(params.to_dict()))
     assert len(proof["queries"][0]["stage2"]["values"]) == 12
+
+
+def test_verifier_uses_its_own_parameters_not_the_proofs(be, tables):
+    """a proof that claims weaker parameters (fewer or zero queries) must not verify: the verifier's parameter set is
+    the caller's, and every parameter is bound into the transcript"""
+    rc, mds = tables
+    air = AIR.get_air("fib")
+    tr, pub = native.synth_trace(0, 6, 2, 5)
+    params = PR.StarkParams(6, 1, 3, 3, 6)
+    proof = PR.prove(air, tr, pub, params, be)
+    exp = V.expectation(params.to_dict())
+    assert V.verify(proof, air.program(), rc, mds, exp)
+    # forged: zero queries claimed, query list emptied, evaluations then unconstrained
+    bad = copy.deepcopy(proof)
+    bad["params"]["n_queries"] = 0
+    bad["queries"] = []
+    with pytest.raises(V.Reject):
+        V.verify(bad, air.program(), rc, mds, exp)
+    with pytest.raises(V.Reject):      # ... also when the verifier is (wrongly) configured with zero queries
+        V.verify(bad, air.program(), rc, mds, dict(exp, n_queries=0))
+    # a proof made with other parameters does not verify under the caller's
+    weak = PR.prove(air, tr, pub, PR.StarkParams(6, 1, 3, 3, 2), be)
+    with pytest.raises(V.Reject):
+        V.verify(weak, air.program(), rc, mds, exp)
+    relabel = copy.deepcopy(weak)
+    relabel["params"]["n_queries"] = 6     # same proof relabelled: transcript binding breaks it
+    with pytest.raises(V.Reject):
+        V.verify(relabel, air.program(), rc, mds, exp)
+    for key, val in (("root32", 7277203076849721926), ("shift", 7)):
+        with pytest.raises(V.Reject):
+            V.verify(proof, air.program(), rc, mds, dict(exp, **{key: val}))
+    with pytest.raises(ValueError):
+        V.verify(proof, air.program(), rc, mds, {"logn": 6})
+
+
+def test_proof_of_work_is_checked(be, tables):
+    rc, mds = tables
+    air = AIR.get_air("fib")
+    tr, pub = native.synth_trace(0, 6, 2, 5)
+    params = PR.StarkParams(6, 1, 3, 3, 6, pow_bits=10)
+    assert params.security_bits() == 16
+    proof = PR.prove(air, tr, pub, params, be)
+    exp = V.expectation(params.to_dict())
+    assert "pow_nonce" in proof and V.verify(proof, air.program(), rc, mds, exp)
+    bad = copy.deepcopy(proof)
+    bad["pow_nonce"] += 1
+    with pytest.raises(V.Reject):
+        V.verify(bad, air.program(), rc, mds, exp)
+    del bad["pow_nonce"]
+    with pytest.raises(V.Reject):
+        V.verify(bad, air.program(), rc, mds, exp)
+
+
+def test_constraint_program_blob_is_checked_and_statement_bound(tables):
+    import numpy as np
+    from oracle.air_program import Program, BadProgram
+    blob = AIR.get_air("chunk16").program()
+    pr = Program(blob)
+    assert (pr.width, pr.width2, pr.n_pub, pr.n_chal, pr.q_chunks) == (16, 12, 8, 3, 1) and pr.n_slots <= 16
+    for mutate in (lambda b: b.__setitem__(0, 1), lambda b: b.__setitem__(7, int(b[7]) + 1),
+                   lambda b: b.__setitem__(12 + int(b[6]), 9)):      # magic, length, opcode
+        bad = blob.copy()
+        mutate(bad)
+        with pytest.raises(BadProgram):
+            Program(bad)
+    other = blob.copy()
+    other[12] = (int(other[12]) + 1) % V.P            # one constant changed: another statement, another digest
+    assert Program(other).digest() != pr.digest()

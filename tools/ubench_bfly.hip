@@ -1,0 +1,81 @@
+// Throughput + equality check of Goldilocks butterfly formulations on gfx950 (measurement tool, not product).
+//   variant 0: compiler-scheduled gl_add / gl_sub (csrc/gl.hpp)
+//   variant 1: hand-scheduled carry-chain butterflies (csrc/gl_asm.hpp): 10 VALU + 2 SALU per butterfly
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/ubench_bfly tools/ubench_bfly.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../eigen_zeth_amd/csrc/gl.hpp"
+#include "../eigen_zeth_amd/csrc/gl_asm.hpp"
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+constexpr int ITERS = 64;
+
+template <int VAR>
+__global__ void __launch_bounds__(256) k(const u64 *in, u64 *out) {
+    u64 v[16];
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = in[g * 16 + i];
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            const int half = 8 >> l;
+            if (VAR == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    if (!(i & half)) { u64 x = v[i], y = v[i + half]; v[i] = gl_add(x, y); v[i + half] = gl_sub(x, y); }
+            } else {
+                int idx[8], n = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) if (!(i & half)) idx[n++] = i;
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) gl_bfly2(v[idx[q]], v[idx[q] + half], v[idx[q + 1]], v[idx[q + 1] + half]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[g * 16 + i] = v[i];
+}
+
+int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    printf("start\n");
+    const int blocks = 256 * 8;
+    const size_t n = (size_t)blocks * 256 * 16;
+    std::vector<u64> h(n);
+    u64 s = 88172645463325252ULL;
+    for (size_t i = 0; i < n; i++) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        u64 v = s;
+        if (i % 97 == 0) v = GL_P - 1 - (i % 5);         // stress values next to p
+        if (i % 101 == 0) v = (i % 3);                   // and next to 0
+        if (i % 103 == 0) v = 0xFFFFFFFF00000000ULL - (i % 2);
+        h[i] = v >= GL_P ? v - GL_P : v;
+    }
+    u64 *d_in, *d0, *d1;
+    CHK(hipMalloc(&d_in, n * 8)); CHK(hipMalloc(&d0, n * 8)); CHK(hipMalloc(&d1, n * 8));
+    CHK(hipMemcpy(d_in, h.data(), n * 8, hipMemcpyHostToDevice));
+    printf("uploaded\n");
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    float ms[2];
+    for (int var = 0; var < 2; var++) {
+        u64 *o = var ? d1 : d0;
+        for (int rep = 0; rep < 2; rep++) {
+            CHK(hipEventRecord(e0));
+            if (var == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, d_in, o);
+            else hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, d_in, o);
+            CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
+            CHK(hipEventElapsedTime(&ms[var], e0, e1));
+        }
+        const double bf = (double)blocks * 256 * ITERS * 32;
+        printf("variant %d: %.3f ms  %.1f G butterflies/s  (%.2f T add|sub /s)\n", var, ms[var], bf / ms[var] / 1e6, 2 * bf / ms[var] / 1e9);
+    }
+    std::vector<u64> r0(n), r1(n);
+    CHK(hipMemcpy(r0.data(), d0, n * 8, hipMemcpyDeviceToHost)); CHK(hipMemcpy(r1.data(), d1, n * 8, hipMemcpyDeviceToHost));
+    size_t bad = 0, noncanon = 0;
+    for (size_t i = 0; i < n; i++) { if (r0[i] != r1[i]) bad++; if (r1[i] >= GL_P) noncanon++; }
+    printf("mismatches vs compiler butterflies: %zu of %zu; non-canonical outputs: %zu\n", bad, n, noncanon);
+    return bad || noncanon ? 1 : 0;
+}
