@@ -45,7 +45,9 @@ __device__ __forceinline__ void gl_bfly2(u64 &xa, u64 &ya, u64 &xb, u64 &yb) {
         "v_cndmask_b32 %5, %5, %15, %22"            // 24 A7b
         : "+v"(xa0), "+v"(xa1), "+v"(ya0), "+v"(ya1), "+v"(xb0), "+v"(xb1), "+v"(yb0), "+v"(yb1),   // 0..7
           "=&v"(ta0), "=&v"(ta1), "=&v"(ua0), "=&v"(ua1), "=&v"(tb0), "=&v"(tb1), "=&v"(ub0), "=&v"(ub1),  // 8..15
-          "=&s"(ca), "=&s"(fa), "=&s"(ea), "=&s"(ga), "=&s"(cb), "=&s"(fb), "=&s"(eb), "=&s"(gb));        // 16..23
+          "=&s"(ca), "=&s"(fa), "=&s"(ea), "=&s"(ga), "=&s"(cb), "=&s"(fb), "=&s"(eb), "=&s"(gb)         // 16..23
+        :
+        : "scc");   // s_andn2 / s_or write SCC: without the clobber a loop branch scheduled across the block reads garbage
     xa = ((u64)xa1 << 32) | xa0; ya = ((u64)ya1 << 32) | ya0;
     xb = ((u64)xb1 << 32) | xb0; yb = ((u64)yb1 << 32) | yb0;
 }

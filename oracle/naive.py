@@ -150,3 +150,64 @@ def fri_fold(vals3, logf, beta, shift=SHIFT_DEFAULT, root32=ROOT32_DEFAULT):
     wm = root(logn - logf, root32) if logn - logf > 0 else 1
     s2 = pow(shift, f, P)
     return [poly_eval_e3(folded, [s2 * pow(wm, i, P) % P, 0, 0]) for i in range(m)]
+
+
+# ---------------------------------------------------------------- stage-2 arguments, OOD evaluation, DEEP quotient
+def _shift3(v, g):
+    """v + g for a base value v and an F_{p^3} challenge g"""
+    return [(v + g[0]) % P, g[1] % P, g[2] % P]
+
+
+def grand_product(a, b, g):
+    """Z[0] = 1, Z[i+1] = Z[i] * (a[i] + g) / (b[i] + g) in F_{p^3}; returns the three planes [Z.c0, Z.c1, Z.c2]"""
+    z, out = [1, 0, 0], []
+    for ai, bi in zip(a, b):
+        out.append(z)
+        z = e3_mul(z, e3_mul(_shift3(ai, g), e3_inv(_shift3(bi, g))))
+    return [[v[c] for v in out] for c in range(3)]
+
+
+def logup_columns(a, t, m, g):
+    """LogUp lookup of the values a in the table t with multiplicities m: h1 = 1/(a+g), h2 = m/(t+g),
+    S[0] = 0, S[i+1] = S[i] + h1[i] - h2[i]; returns nine planes h1.c0..c2, h2.c0..c2, S.c0..c2"""
+    s, rows = [0, 0, 0], []
+    for ai, ti, mi in zip(a, t, m):
+        h1 = e3_inv(_shift3(ai, g))
+        h2 = [v * mi % P for v in e3_inv(_shift3(ti, g))]
+        rows.append(h1 + h2 + s)
+        s = [(s[c] + h1[c] - h2[c]) % P for c in range(3)]
+    return [[r[k] for r in rows] for k in range(9)]
+
+
+def ood_eval(coef, z):
+    """sum_i coef[i] z^i for base-field coefficients and an F_{p^3} point (Horner)"""
+    acc = [0, 0, 0]
+    for c in reversed(coef):
+        acc = e3_mul(acc, z)
+        acc[0] = (acc[0] + c) % P
+    return acc
+
+
+def deep_quotient(cols, n_next, z, zw, gamma, ev_z, ev_zw, shift=SHIFT_DEFAULT, root32=ROOT32_DEFAULT):
+    """cols: W columns of M values on shift*<w_M>.  F(x) = sum_{k<W} gamma^k (p_k(x) - ev_z[k]) / (x - z)
+                                                        + sum_{k<n_next} gamma^(W+k) (p_k(x) - ev_zw[k]) / (x - zw)"""
+    W, M = len(cols), len(cols[0])
+    wm = root(M.bit_length() - 1, root32)
+    gp, cur = [], [1, 0, 0]
+    for _ in range(W + n_next):
+        gp.append(cur)
+        cur = e3_mul(cur, gamma)
+    out = []
+    for r in range(M):
+        x = shift * pow(wm, r, P) % P
+        i1 = e3_inv([(x - z[0]) % P, -z[1] % P, -z[2] % P])
+        i2 = e3_inv([(x - zw[0]) % P, -zw[1] % P, -zw[2] % P])
+        acc = [0, 0, 0]
+        for k in range(W):
+            num = [(cols[k][r] - ev_z[k][0]) % P, -ev_z[k][1] % P, -ev_z[k][2] % P]
+            acc = e3_add(acc, e3_mul(gp[k], e3_mul(num, i1)))
+        for k in range(n_next):
+            num = [(cols[k][r] - ev_zw[k][0]) % P, -ev_zw[k][1] % P, -ev_zw[k][2] % P]
+            acc = e3_add(acc, e3_mul(gp[W + k], e3_mul(num, i2)))
+        out.append(acc)
+    return [[v[c] for v in out] for c in range(3)]

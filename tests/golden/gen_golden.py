@@ -76,6 +76,65 @@ def main():
         a, b = rv(3), rv(3)
         e3.append({"a": a, "b": b, "ab": NV.e3_mul(a, b), "ainv": NV.e3_inv(a)})
     out["e3"] = e3
+    # stage 2: grand product and LogUp columns (sequential definitions with Fermat inverses)
+    gpv = []
+    for n in (1, 2, 8, 33):
+        a, b, g = rv(n), rv(n), rv(3)
+        gpv.append({"a": a, "b": b, "g": g, "z": NV.grand_product(a, b, g)})
+    a = rv(16)
+    perm = a[5:] + a[:5]
+    g = rv(3)
+    gpv.append({"a": a, "b": perm, "g": g, "z": NV.grand_product(a, perm, g), "cyclic": True})   # a permutation: the product closes to 1
+    out["grand_product"] = gpv
+    lu = []
+    for n, k in ((8, 3), (32, 4)):
+        t = [min(i, (1 << k) - 1) for i in range(n)]
+        a = [rnd.randrange(1 << k) for _ in range(n)]
+        m = [0] * n
+        for v in a:
+            m[t.index(v)] += 1
+        g = rv(3)
+        lu.append({"a": a, "t": t, "m": m, "g": g, "cols": NV.logup_columns(a, t, m, g)})
+    a, t, m, g = rv(5), rv(5), rv(5), rv(3)
+    lu.append({"a": a, "t": t, "m": m, "g": g, "cols": NV.logup_columns(a, t, m, g)})
+    out["logup"] = lu
+    # out-of-domain evaluation and the DEEP quotient
+    ood = []
+    for n in (1, 2, 7, 64, 300):
+        c, z = rv(n), rv(3)
+        ood.append({"coef": c, "z": z, "value": NV.ood_eval(c, z)})
+    out["ood_eval"] = ood
+    dq = []
+    for logm, W, n_next in ((3, 2, 2), (4, 5, 3), (5, 3, 0), (2, 1, 1)):
+        cols = [rv(1 << logm) for _ in range(W)]
+        z, zw, gamma = rv(3), rv(3), rv(3)
+        ev_z, ev_zw = [rv(3) for _ in range(W)], [rv(3) for _ in range(n_next)]
+        dq.append({"logm": logm, "cols": cols, "n_next": n_next, "z": z, "zw": zw, "gamma": gamma, "ev_z": ev_z, "ev_zw": ev_zw,
+                   "shift": 49, "out": NV.deep_quotient(cols, n_next, z, zw, gamma, ev_z, ev_zw)})
+    out["deep_quotient"] = dq
+    # N6: BN254 MSM by double-and-add (decimal strings: 254-bit values)
+    from oracle import naive_bn254 as B
+    msm = []
+    for n in (1, 2, 5, 9):
+        pts = [B.mul(B.G, rnd.randrange(1, B.R)) for _ in range(n)]
+        sc = [rnd.randrange(B.R) for _ in range(n)]
+        if n >= 5:
+            sc[1], sc[2] = 0, B.R - 1
+            pts[3] = None                       # point at infinity, encoded (0, 0)
+        res = B.msm(pts, sc)
+        msm.append({"points": [[str(p[0]), str(p[1])] if p else ["0", "0"] for p in pts], "scalars": [str(v) for v in sc],
+                    "sum": [str(res[0]), str(res[1])] if res else ["0", "0"]})
+    p0 = B.mul(B.G, 77)
+    msm.append({"points": [[str(p0[0]), str(p0[1])], [str(p0[0]), str((B.Q - p0[1]) % B.Q)]], "scalars": ["5", "5"], "sum": ["0", "0"]})
+    out["msm_g1"] = msm
+    msm2 = []
+    for n in (1, 3):
+        pts = [B.mul_g2(B.G2, rnd.randrange(1, B.R)) for _ in range(n)]
+        sc = [rnd.randrange(B.R) for _ in range(n)]
+        res = B.msm_g2(pts, sc)
+        msm2.append({"points": [[[str(c) for c in p[0]], [str(c) for c in p[1]]] for p in pts], "scalars": [str(v) for v in sc],
+                     "sum": [[str(c) for c in res[0]], [str(c) for c in res[1]]]})
+    out["msm_g2"] = msm2
     with open(os.path.join(HERE, "vectors.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
     print("wrote vectors.json", os.path.getsize(os.path.join(HERE, "vectors.json")))

@@ -132,3 +132,16 @@ def test_msm_g2_cancellation_and_doubling(prover, table_g2):
     neg = (p[0], ((-p[1][0]) % B.Q, (-p[1][1]) % B.Q))
     assert prover.msm_bn254_g2([p, neg], [5, 5]) is None
     assert prover.msm_bn254_g2([p] * 7, [1] * 7) == B.mul_g2(p, 7)      # same point in one bucket: the doubling branch
+
+
+def test_golden_msm_vectors_through_cabi(prover, golden):
+    """double-and-add vectors (oracle/naive_bn254.py -> tests/golden/vectors.json): infinity, zero and r-1 scalars, P + (-P)"""
+    for case in golden["msm_g1"]:
+        pts = [(int(x), int(y)) for x, y in case["points"]]
+        got = prover.msm_bn254(pts, [int(v) for v in case["scalars"]])
+        want = (int(case["sum"][0]), int(case["sum"][1]))
+        assert (got or (0, 0)) == want
+    for case in golden["msm_g2"]:
+        pts = [((int(p[0][0]), int(p[0][1])), (int(p[1][0]), int(p[1][1]))) for p in case["points"]]
+        got = prover.msm_bn254_g2(pts, [int(v) for v in case["scalars"]])
+        assert got == ((int(case["sum"][0][0]), int(case["sum"][0][1])), (int(case["sum"][1][0]), int(case["sum"][1][1])))

@@ -426,3 +426,38 @@ def test_four_step_ntt_on_one_gpu_matches_plain_transform():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "four_step_check.py"), "12", "17", "22"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout + r.stderr
+
+
+# ---- definition-level vectors (oracle/naive.py -> tests/golden/vectors.json) for stage 2, OOD, DEEP -- through the C-ABI
+@pytest.mark.gpu
+def test_golden_grand_product_and_logup_through_cabi(prover, golden):
+    for case in golden["grand_product"]:
+        n = len(case["a"])
+        d_a, d_b = prover.upload(u(case["a"])), prover.upload(u(case["b"]))
+        d_o = prover.alloc(3 * n)
+        prover.grand_product(d_a, d_b, n, case["g"], d_o)
+        assert prover.download(d_o, (3, n)).tolist() == case["z"]
+    for case in golden["logup"]:
+        n = len(case["a"])
+        d = [prover.upload(u(case[k])) for k in ("a", "t", "m")]
+        d_o = prover.alloc(9 * n)
+        prover.logup_columns(d[0], d[1], d[2], n, case["g"], d_o)
+        assert prover.download(d_o, (9, n)).tolist() == case["cols"]
+
+
+@pytest.mark.gpu
+def test_golden_ood_and_deep_through_cabi(prover, golden):
+    for case in golden["ood_eval"]:
+        n = len(case["coef"])
+        if n & (n - 1):
+            continue                      # zp_poly_eval_ext takes 2^logn coefficients
+        d = prover.upload(u(case["coef"]))
+        assert prover.poly_eval_ext(d, n.bit_length() - 1, 1, case["z"]).tolist() == [case["value"]]
+    for case in golden["deep_quotient"]:
+        cols = u(case["cols"])
+        W, M = cols.shape
+        d_a = prover.upload(cols)
+        d_o = prover.alloc(3 * M)
+        prover.deep_quotient(d_a, W, d_a, 0, case["logm"], case["n_next"], case["z"], case["zw"], case["gamma"], case["ev_z"],
+                             case["ev_zw"], case["shift"], d_o)
+        assert prover.download(d_o, (3, M)).tolist() == case["out"], case["logm"]

@@ -128,3 +128,39 @@ def test_blocked_ntt_is_bit_identical_to_the_plain_loop():
         finally:
             O.set_simple_ntt(False)
         assert (O.intt(blocked) == x).all()
+
+
+# ---- definition-level vectors for the stage-2 arguments, OOD evaluation and the DEEP quotient (oracle/naive.py)
+def test_grand_product_golden(golden):
+    for case in golden["grand_product"]:
+        got = O.grand_product(case["a"], case["b"], case["g"])
+        assert got.tolist() == case["z"]
+        if case.get("cyclic"):      # b is a permutation of a: the running product closes to one
+            last = [int(got[c][-1]) for c in range(3)]
+            from oracle import naive as NV
+            step = NV.e3_mul(NV._shift3(case["a"][-1], case["g"]), NV.e3_inv(NV._shift3(case["b"][-1], case["g"])))
+            assert NV.e3_mul(last, step) == [1, 0, 0]
+
+
+def test_logup_golden(golden):
+    for case in golden["logup"]:
+        assert O.logup_columns(case["a"], case["t"], case["m"], case["g"]).tolist() == case["cols"]
+
+
+def test_ood_eval_golden(golden):
+    for case in golden["ood_eval"]:
+        assert O.poly_eval_e3(case["coef"], case["z"]).tolist() == case["value"]
+        assert O.poly_eval_e3_cols([case["coef"]], case["z"]).tolist() == [case["value"]]
+
+
+def test_deep_quotient_golden(golden):
+    for case in golden["deep_quotient"]:
+        for fast in (False, True):      # the definition and the batch-inverted form used by the CPU backend
+            got = O.deep_quotient(case["cols"], None, case["n_next"], case["z"], case["zw"], case["gamma"], case["ev_z"],
+                                  case["ev_zw"], case["shift"], fast=fast)
+            assert got.tolist() == case["out"], (case["logm"], fast)
+        if len(case["cols"]) > 1:       # the same columns split between the two matrices the C-ABI takes
+            got = O.deep_quotient(case["cols"][:1], case["cols"][1:], min(case["n_next"], 1), case["z"], case["zw"], case["gamma"],
+                                  case["ev_z"], case["ev_zw"][:1], case["shift"])
+            if case["n_next"] <= 1:
+                assert got.tolist() == case["out"]
