@@ -51,4 +51,69 @@ __device__ __forceinline__ void gl_bfly2(u64 &xa, u64 &ya, u64 &xb, u64 &yb) {
     xa = ((u64)xa1 << 32) | xa0; ya = ((u64)ya1 << 32) | ya0;
     xb = ((u64)xb1 << 32) | xb0; yb = ((u64)yb1 << 32) | yb0;
 }
+
+// Two independent products a*b, c*d (any u64 inputs, canonical outputs), bit-identical to gl_mul.
+// hipcc's gl_mul is 5 v_mad_u64_u32 + ~10 v_mov (zero-extending 32-bit halves into aligned 64-bit addend pairs) +
+// 64-bit adds, five compares and four selects: ~100 issue cycles.  Here (70 cycles): three plain products and one
+// accumulating one, the four limbs L0..L3 assembled with one carry chain, then  x = (L1:L0) - L3 + L2*EPS  as a
+// borrow-corrected subtraction, ONE more mad whose carry-out and the carry of "+EPS" pick the canonical value.
+// The mad results live in fixed scratch pairs v[116:127] so that their halves can be named (an inline-asm operand
+// cannot name half of a 64-bit register pair); two products are interleaved and s_nop 0 pads the places where a carry
+// would otherwise be read one instruction after it was written.
+__device__ __forceinline__ void gl_mul2(u64 &a, u64 b, u64 &c, u64 d) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u32 c0 = (u32)c, c1 = (u32)(c >> 32), d0 = (u32)d, d1 = (u32)(d >> 32);
+    u32 ra0, ra1, rb0, rb1;
+    u64 sd, cra, crb, ea, eb, fa, fb;
+    asm("v_mad_u64_u32 v[116:117], %4, %11, %13, 0\n\t"          // PA = a0*b0
+        "v_mad_u64_u32 v[122:123], %4, %15, %17, 0\n\t"          // PB
+        "v_mad_u64_u32 v[118:119], %4, %11, %14, 0\n\t"          // RA = a0*b1
+        "v_mad_u64_u32 v[124:125], %4, %15, %18, 0\n\t"
+        "v_mad_u64_u32 v[120:121], %4, %12, %14, 0\n\t"          // HA = a1*b1
+        "v_mad_u64_u32 v[126:127], %4, %16, %18, 0\n\t"
+        "v_mad_u64_u32 v[118:119], %5, %12, %13, v[118:119]\n\t" // RA += a1*b0            -> cr
+        "v_mad_u64_u32 v[124:125], %6, %16, %17, v[124:125]\n\t"
+        "v_add_co_u32 v117, %7, v117, v118\n\t"                  // L1 = p1 + r0            -> c1
+        "v_add_co_u32 v123, %8, v123, v124\n\t"
+        "v_addc_co_u32 v121, %5, v121, 0, %5\n\t"                // L3 = h1 + cr
+        "v_addc_co_u32 v127, %6, v127, 0, %6\n\t"
+        "v_addc_co_u32 v120, %7, v120, v119, %7\n\t"             // L2 = h0 + r1 + c1       -> c2
+        "v_addc_co_u32 v126, %8, v126, v125, %8\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 v121, %7, v121, 0, %7\n\t"                // L3 += c2
+        "v_addc_co_u32 v127, %8, v127, 0, %8\n\t"
+        "v_sub_co_u32 v116, %7, v116, v121\n\t"                  // t0 = L0 - L3            -> borrow
+        "v_sub_co_u32 v122, %8, v122, v127\n\t"
+        "s_nop 0\n\t"
+        "v_subbrev_co_u32 v117, %7, 0, v117, %7\n\t"             // t1 = L1 - borrow        -> borrow
+        "v_subbrev_co_u32 v123, %8, 0, v123, %8\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 v116, %9, v116, 0, %7\n\t"                // borrowed 2^64 == EPS too much: t0 += 1 -> f
+        "v_addc_co_u32 v122, %10, v122, 0, %8\n\t"
+        "s_nop 0\n\t"
+        "s_andn2_b64 %7, %7, %9\n\t"
+        "s_andn2_b64 %8, %8, %10\n\t"
+        "v_subbrev_co_u32 v117, %9, 0, v117, %7\n\t"             //                          t1 -= borrow & ~f
+        "v_subbrev_co_u32 v123, %10, 0, v123, %8\n\t"
+        "v_mad_u64_u32 v[116:117], %7, v120, -1, v[116:117]\n\t" // T = L2*EPS + t            -> g
+        "v_mad_u64_u32 v[122:123], %8, v126, -1, v[122:123]\n\t"
+        "v_add_co_u32 v118, %9, v116, -1\n\t"                    // u = T + EPS               -> h
+        "v_add_co_u32 v124, %10, v122, -1\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 v119, %9, v117, 0, %9\n\t"
+        "v_addc_co_u32 v125, %10, v123, 0, %10\n\t"
+        "s_nop 1\n\t"
+        "s_or_b64 %7, %7, %9\n\t"                                // g | h: take u
+        "s_or_b64 %8, %8, %10\n\t"
+        "v_cndmask_b32 %0, v116, v118, %7\n\t"
+        "v_cndmask_b32 %1, v117, v119, %7\n\t"
+        "v_cndmask_b32 %2, v122, v124, %8\n\t"
+        "v_cndmask_b32 %3, v123, v125, %8"
+        : "=v"(ra0), "=v"(ra1), "=v"(rb0), "=v"(rb1),                                                  // 0..3
+          "=&s"(sd), "=&s"(cra), "=&s"(crb), "=&s"(ea), "=&s"(eb), "=&s"(fa), "=&s"(fb)                // 4..10
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(c0), "v"(c1), "v"(d0), "v"(d1)                       // 11..18
+        : "scc", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    a = ((u64)ra1 << 32) | ra0;
+    c = ((u64)rb1 << 32) | rb0;
+}
 #endif

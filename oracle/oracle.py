@@ -23,8 +23,8 @@ _u64p = C.POINTER(C.c_uint64)
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
-            os.path.join(_HERE, "gl_oracle.c")):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(
+            os.path.getmtime(os.path.join(_HERE, f)) for f in ("gl_oracle.c", "bn254_gen.c")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -66,6 +66,9 @@ def lib():
         L.orc_logup_columns.argtypes = [_u64p, _u64p, _u64p, sz, _u64p, _u64p]
         L.orc_quotient_program.restype = i32
         L.orc_quotient_program.argtypes = [_u64p, sz, _u64p, _u64p, sz, sz, _u64p, _u64p, _u64p, u64, u64, u64, _u64p]
+        L.orc_bn254_consecutive_points.restype = i32
+        L.orc_bn254_consecutive_points.argtypes = [C.c_void_p, sz, u64]
+        L.orc_bn254_weighted_scalar_sum.argtypes = [C.c_void_p, sz, u64, C.c_void_p]
         L.orc_pow_grind.restype = u64
         L.orc_pow_grind.argtypes = [_u64p, i32, _u64p, _u64p]
         L.orc_fri_fold.argtypes = [_u64p, _u64p, i32, i32, _u64p, u64, u64]
@@ -232,6 +235,22 @@ def pow_grind(seed4, bits, rc, mds):
     """smallest nonce with Poseidon(seed || nonce || 0^7)[0] >> (64 - bits) == 0"""
     sd = _arr([int(v) for v in seed4])
     return int(lib().orc_pow_grind(_p(sd), int(bits), _p(_arr(rc)), _p(_arr(mds))))
+
+
+def bn254_consecutive_points(n, start=1025):
+    """uint32 [n][16]: point i = (start + i) * G of BN254 G1 in the zp_msm_bn254 layout (x then y, little-endian limbs)"""
+    out = np.empty((n, 16), dtype=np.uint32)
+    if lib().orc_bn254_consecutive_points(out.ctypes.data, n, start) != 0:
+        raise ValueError("start must exceed 1024")
+    return out
+
+
+def bn254_weighted_scalar_sum(scalars, start=1025):
+    """sum_i scalar_i * (start + i) as a Python int; scalars uint32 [n][8] little-endian limbs"""
+    s = np.ascontiguousarray(scalars, dtype=np.uint32)
+    out = np.zeros(10, dtype=np.uint32)
+    lib().orc_bn254_weighted_scalar_sum(s.ctypes.data, s.shape[0], start, out.ctypes.data)
+    return sum(int(out[k]) << (32 * k) for k in range(10))
 
 
 def set_simple_ntt(on):

@@ -1,0 +1,38 @@
+"""BASELINE configs[3] in its stated form -- shards over several GPUs of one node with RCCL collectives over xGMI.
+Runs whenever at least two GPUs are visible (the driver's 8-GPU node); skipped on a one-GPU box, where the same code
+is covered by the world_size-2 gloo tests (tests/test_multigpu_cpu.py) and by G = 1 through the HIP kernels."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_commit_four_step_ntt_and_msm_over_rccl():
+    import torch
+    n = torch.cuda.device_count()        # does not initialise the GPU in this process
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL over xGMI); one visible")
+    ranks = 4 if n >= 4 else 2           # at most 6 processes may hold the GPUs at once on the test box
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "multigpu_check.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["ok"] and res["world"] == ranks
+    assert res["commit_root_matches_single_gpu"] and res["four_step_matches_plain_ntt"] and res["msm_matches_single_gpu"]

@@ -39,6 +39,24 @@ __global__ void __launch_bounds__(256) k(const u64 *in, u64 *out) {
     for (int i = 0; i < 16; i++) out[g * 16 + i] = v[i];
 }
 
+template <int VAR>
+__global__ void __launch_bounds__(256) km(const u64 *in, u64 *out) {
+    u64 v[16];
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = in[g * 16 + i];
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const u64 b0 = v[(i + 5) & 15] ^ (u64)it, b1 = v[(i + 9) & 15] + 12345u;   // any u64 (also >= p)
+            if (VAR == 0) { v[i] = gl_mul(v[i], b0); v[i + 1] = gl_mul(v[i + 1], b1); }
+            else gl_mul2(v[i], b0, v[i + 1], b1);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[g * 16 + i] = v[i];
+}
+
 int main() {
     setvbuf(stdout, nullptr, _IONBF, 0);
     printf("start\n");
@@ -71,6 +89,33 @@ int main() {
         }
         const double bf = (double)blocks * 256 * ITERS * 32;
         printf("variant %d: %.3f ms  %.1f G butterflies/s  (%.2f T add|sub /s)\n", var, ms[var], bf / ms[var] / 1e6, 2 * bf / ms[var] / 1e9);
+    }
+    for (int var = 0; var < 2; var++) {
+        u64 *o = var ? d1 : d0;
+        for (int rep = 0; rep < 2; rep++) {
+            CHK(hipEventRecord(e0));
+            if (var == 0) hipLaunchKernelGGL(km<0>, dim3(blocks), dim3(256), 0, 0, d_in, o);
+            else hipLaunchKernelGGL(km<1>, dim3(blocks), dim3(256), 0, 0, d_in, o);
+            CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
+            CHK(hipEventElapsedTime(&ms[var], e0, e1));
+        }
+        const double mu = (double)blocks * 256 * ITERS * 16;
+        printf("mul variant %d: %.3f ms  %.2f T modmul/s\n", var, ms[var], mu / ms[var] / 1e9);
+    }
+    {
+        std::vector<u64> m0(n), m1(n);
+        CHK(hipMemcpy(m0.data(), d0, n * 8, hipMemcpyDeviceToHost)); CHK(hipMemcpy(m1.data(), d1, n * 8, hipMemcpyDeviceToHost));
+        size_t badm = 0, nc = 0;
+        for (size_t i = 0; i < n; i++) { if (m0[i] != m1[i]) badm++; if (m1[i] >= GL_P) nc++; }
+        printf("gl_mul2 mismatches vs gl_mul: %zu of %zu; non-canonical: %zu\n", badm, n, nc);
+        if (badm || nc) return 1;
+    }
+    // butterflies again (their outputs are what the check below compares)
+    for (int var = 0; var < 2; var++) {
+        u64 *o = var ? d1 : d0;
+        if (var == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, d_in, o);
+        else hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, d_in, o);
+        CHK(hipDeviceSynchronize());
     }
     std::vector<u64> r0(n), r1(n);
     CHK(hipMemcpy(r0.data(), d0, n * 8, hipMemcpyDeviceToHost)); CHK(hipMemcpy(r1.data(), d1, n * 8, hipMemcpyDeviceToHost));
