@@ -17,37 +17,38 @@
 __device__ __forceinline__ void gl_bfly2(u64 &xa, u64 &ya, u64 &xb, u64 &yb) {
     u32 xa0 = (u32)xa, xa1 = (u32)(xa >> 32), ya0 = (u32)ya, ya1 = (u32)(ya >> 32);
     u32 xb0 = (u32)xb, xb1 = (u32)(xb >> 32), yb0 = (u32)yb, yb1 = (u32)(yb >> 32);
-    u32 ta0, ta1, ua0, ua1, tb0, tb1, ub0, ub1;
     u64 ca, fa, ea, ga, cb, fb, eb, gb;
-    asm("v_sub_co_u32 %8, %16, %0, %2\n\t"          //  1 S1a  t0 = x0 - y0            -> c
-        "v_add_co_u32 %0, %18, %0, %2\n\t"          //  2 A1a  x0 = x0 + y0            -> e
-        "v_sub_co_u32 %12, %20, %4, %6\n\t"         //  3 S1b
-        "v_add_co_u32 %4, %22, %4, %6\n\t"          //  4 A1b
-        "v_subb_co_u32 %9, %16, %1, %3, %16\n\t"    //  5 S2a  t1 = x1 - y1 - c        -> c = borrow
-        "v_addc_co_u32 %1, %18, %1, %3, %18\n\t"    //  6 A2a  x1 = x1 + y1 + e        -> e = carry c1
-        "v_subb_co_u32 %13, %20, %5, %7, %20\n\t"   //  7 S2b
-        "v_addc_co_u32 %5, %22, %5, %7, %22\n\t"    //  8 A2b
-        "v_addc_co_u32 %2, %17, %8, 0, %16\n\t"     //  9 S3a  y0 = t0 + borrow        -> f
-        "v_add_co_u32 %10, %19, %0, -1\n\t"         // 10 A3a  u0 = x0 + 0xFFFFFFFF    -> g
-        "v_addc_co_u32 %6, %21, %12, 0, %20\n\t"    // 11 S3b
-        "v_add_co_u32 %14, %23, %4, -1\n\t"         // 12 A3b
-        "s_andn2_b64 %16, %16, %17\n\t"             // 13 S4a  c = borrow & ~f
-        "v_addc_co_u32 %11, %19, %1, 0, %19\n\t"    // 14 A4a  u1 = x1 + g             -> g = carry c2
-        "s_andn2_b64 %20, %20, %21\n\t"             // 15 S4b
-        "v_addc_co_u32 %15, %23, %5, 0, %23\n\t"    // 16 A4b
-        "v_subbrev_co_u32 %3, %17, 0, %9, %16\n\t"  // 17 S5a  y1 = t1 - c
-        "s_or_b64 %18, %18, %19\n\t"                // 18 A5a  e = c1 | c2
-        "v_subbrev_co_u32 %7, %21, 0, %13, %20\n\t" // 19 S5b
-        "s_or_b64 %22, %22, %23\n\t"                // 20 A5b
-        "v_cndmask_b32 %0, %0, %10, %18\n\t"        // 21 A6a
-        "v_cndmask_b32 %1, %1, %11, %18\n\t"        // 22 A7a
-        "v_cndmask_b32 %4, %4, %14, %22\n\t"        // 23 A6b
-        "v_cndmask_b32 %5, %5, %15, %22"            // 24 A7b
+    // temporaries: the fixed scratch registers gl_mul2 also uses (t = v116,v117 / v120,v121; u = v118,v119 / v122,v123),
+    // so that the asm blocks of a kernel share one scratch window instead of each asking the allocator for its own
+    asm("v_sub_co_u32 v116, %8, %0, %2\n\t"          //  1 S1a  t0 = x0 - y0            -> c
+        "v_add_co_u32 %0, %10, %0, %2\n\t"           //  2 A1a  x0 = x0 + y0            -> e
+        "v_sub_co_u32 v120, %12, %4, %6\n\t"         //  3 S1b
+        "v_add_co_u32 %4, %14, %4, %6\n\t"           //  4 A1b
+        "v_subb_co_u32 v117, %8, %1, %3, %8\n\t"     //  5 S2a  t1 = x1 - y1 - c        -> c = borrow
+        "v_addc_co_u32 %1, %10, %1, %3, %10\n\t"     //  6 A2a  x1 = x1 + y1 + e        -> e = carry c1
+        "v_subb_co_u32 v121, %12, %5, %7, %12\n\t"   //  7 S2b
+        "v_addc_co_u32 %5, %14, %5, %7, %14\n\t"     //  8 A2b
+        "v_addc_co_u32 %2, %9, v116, 0, %8\n\t"      //  9 S3a  y0 = t0 + borrow        -> f
+        "v_add_co_u32 v118, %11, %0, -1\n\t"         // 10 A3a  u0 = x0 + 0xFFFFFFFF    -> g
+        "v_addc_co_u32 %6, %13, v120, 0, %12\n\t"    // 11 S3b
+        "v_add_co_u32 v122, %15, %4, -1\n\t"         // 12 A3b
+        "s_andn2_b64 %8, %8, %9\n\t"                 // 13 S4a  c = borrow & ~f
+        "v_addc_co_u32 v119, %11, %1, 0, %11\n\t"    // 14 A4a  u1 = x1 + g             -> g = carry c2
+        "s_andn2_b64 %12, %12, %13\n\t"              // 15 S4b
+        "v_addc_co_u32 v123, %15, %5, 0, %15\n\t"    // 16 A4b
+        "v_subbrev_co_u32 %3, %9, 0, v117, %8\n\t"   // 17 S5a  y1 = t1 - c
+        "s_or_b64 %10, %10, %11\n\t"                 // 18 A5a  e = c1 | c2
+        "v_subbrev_co_u32 %7, %13, 0, v121, %12\n\t" // 19 S5b
+        "s_or_b64 %14, %14, %15\n\t"                 // 20 A5b
+        "v_cndmask_b32 %0, %0, v118, %10\n\t"        // 21 A6a
+        "v_cndmask_b32 %1, %1, v119, %10\n\t"        // 22 A7a
+        "v_cndmask_b32 %4, %4, v122, %14\n\t"        // 23 A6b
+        "v_cndmask_b32 %5, %5, v123, %14"            // 24 A7b
         : "+v"(xa0), "+v"(xa1), "+v"(ya0), "+v"(ya1), "+v"(xb0), "+v"(xb1), "+v"(yb0), "+v"(yb1),   // 0..7
-          "=&v"(ta0), "=&v"(ta1), "=&v"(ua0), "=&v"(ua1), "=&v"(tb0), "=&v"(tb1), "=&v"(ub0), "=&v"(ub1),  // 8..15
-          "=&s"(ca), "=&s"(fa), "=&s"(ea), "=&s"(ga), "=&s"(cb), "=&s"(fb), "=&s"(eb), "=&s"(gb)         // 16..23
+          "=&s"(ca), "=&s"(fa), "=&s"(ea), "=&s"(ga), "=&s"(cb), "=&s"(fb), "=&s"(eb), "=&s"(gb)     // 8..15
         :
-        : "scc");   // s_andn2 / s_or write SCC: without the clobber a loop branch scheduled across the block reads garbage
+        : "scc", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123");
+    // (s_andn2 / s_or write SCC: without the clobber a loop branch scheduled across the block reads garbage)
     xa = ((u64)xa1 << 32) | xa0; ya = ((u64)ya1 << 32) | ya0;
     xb = ((u64)xb1 << 32) | xb0; yb = ((u64)yb1 << 32) | yb0;
 }
@@ -115,5 +116,42 @@ __device__ __forceinline__ void gl_mul2(u64 &a, u64 b, u64 &c, u64 d) {
         : "scc", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
     a = ((u64)ra1 << 32) | ra0;
     c = ((u64)rb1 << 32) | rb0;
+}
+
+// one product (odd counts): the same instruction sequence with s_nop 1 where the second product would have stood
+__device__ __forceinline__ u64 gl_mul1(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u32 r0, r1;
+    u64 sd, cr, e, f;
+    asm("v_mad_u64_u32 v[116:117], %2, %6, %8, 0\n\t"
+        "v_mad_u64_u32 v[118:119], %2, %6, %9, 0\n\t"
+        "v_mad_u64_u32 v[120:121], %2, %7, %9, 0\n\t"
+        "v_mad_u64_u32 v[118:119], %3, %7, %8, v[118:119]\n\t"
+        "v_add_co_u32 v117, %4, v117, v118\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 v121, %3, v121, 0, %3\n\t"
+        "v_addc_co_u32 v120, %4, v120, v119, %4\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 v121, %4, v121, 0, %4\n\t"
+        "v_sub_co_u32 v116, %4, v116, v121\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 v117, %4, 0, v117, %4\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 v116, %5, v116, 0, %4\n\t"
+        "s_nop 1\n\t"
+        "s_andn2_b64 %4, %4, %5\n\t"
+        "v_subbrev_co_u32 v117, %5, 0, v117, %4\n\t"
+        "v_mad_u64_u32 v[116:117], %4, v120, -1, v[116:117]\n\t"
+        "v_add_co_u32 v118, %5, v116, -1\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 v119, %5, v117, 0, %5\n\t"
+        "s_nop 1\n\t"
+        "s_or_b64 %4, %4, %5\n\t"
+        "v_cndmask_b32 %0, v116, v118, %4\n\t"
+        "v_cndmask_b32 %1, v117, v119, %4"
+        : "=v"(r0), "=v"(r1), "=&s"(sd), "=&s"(cr), "=&s"(e), "=&s"(f)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+        : "scc", "v116", "v117", "v118", "v119", "v120", "v121");
+    return ((u64)r1 << 32) | r0;
 }
 #endif

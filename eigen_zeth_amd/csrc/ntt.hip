@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "ctx.hpp"
+#include "gl_asm.hpp"
 
 // the data of a pass is touched exactly once: non-temporal loads/stores (measured +1 % on the 2^24 bench, same results)
 #define ZP_LDG(p) __builtin_nontemporal_load(p)
@@ -88,26 +89,31 @@ __device__ __forceinline__ u64 tw_lookup(const u64 *lo, const u64 *hi, int lb, u
 // radix-2^A DIF with the canonical root c = 2^12 (order 16): every twiddle is a shift.
 // v[p] receives DFT_c[brev(p)];  the caller maps that to the user's root, w_16 = c^j0:
 // DFT_user[k'] = DFT_c[j0*k' mod 2^A]  =>  register p holds user index  k' = j0inv*brev(p) mod 2^A.
-template <int E>
-__device__ __forceinline__ u64 mul_c16(u64 d) {
-    if constexpr (E == 0) return d;
-    else return gl_mul_pow2<12 * E>(d);
+__device__ __forceinline__ u64 mul_c16(int e, u64 d) {   // e is a constant after unrolling: the switch folds away
+    switch (e) {
+        case 0: return d;
+        case 1: return gl_mul_pow2<12>(d);
+        case 2: return gl_mul_pow2<24>(d);
+        case 3: return gl_mul_pow2<36>(d);
+        case 4: return gl_mul_pow2<48>(d);
+        case 5: return gl_mul_pow2<60>(d);
+        case 6: return gl_mul_pow2<72>(d);
+        default: return gl_mul_pow2<84>(d);
+    }
 }
-template <int A, int S = 0, int B = 0, int I = 0>
+// butterflies two at a time through the hand-scheduled carry chains of gl_asm.hpp (x+y, x-y canonical)
+template <int A>
 __device__ __forceinline__ void dif_shift(u64 *v) {
-    if constexpr (S < A) {
-        constexpr int half = 1 << (A - 1 - S);
-        if constexpr (B < (1 << A)) {
-            if constexpr (I < half) {
-                u64 x = v[B + I], y = v[B + I + half];
-                v[B + I] = gl_add(x, y);
-                v[B + I + half] = mul_c16<I * (8 / half)>(gl_sub(x, y));
-                dif_shift<A, S, B, I + 1>(v);
-            } else {
-                dif_shift<A, S, B + 2 * half, 0>(v);
-            }
-        } else {
-            dif_shift<A, S + 1, 0, 0>(v);
+    static_assert(A >= 2 && A <= 4, "radix 4, 8 or 16");
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int half = 1 << (A - 1 - s);
+#pragma unroll
+        for (int t = 0; t < (1 << (A - 1)); t += 2) {
+            const int i0 = (t / half) * 2 * half + (t % half), i1 = ((t + 1) / half) * 2 * half + ((t + 1) % half);
+            gl_bfly2(v[i0], v[i0 + half], v[i1], v[i1 + half]);
+            v[i0 + half] = mul_c16((t % half) * (8 / half), v[i0 + half]);
+            v[i1 + half] = mul_c16(((t + 1) % half) * (8 / half), v[i1 + half]);
         }
     }
 }
@@ -128,12 +134,20 @@ __device__ __forceinline__ void exchange2(u64 *v, u64 *lds, const u64 *twr, int 
         const int gamma = g * G::NT + tid;
         const int t = gamma & (G::T - 1), o = gamma >> G::LT;
         const int rho = o & ((1 << POS) - 1);
+        // w_(2^(POS+A))^(kj*rho) from the LDS copy; p = 0 needs none, the rest go two products at a time
+        {
+            const int kj1 = (j0inv * brev(1, A)) & ((1 << A) - 1);
+            v[g * (1 << A) + 1] = gl_mul1(v[g * (1 << A) + 1], twr[kj1 * rho]);
+        }
+#pragma unroll
+        for (int p = 2; p < (1 << A); p += 2) {
+            const int kja = (j0inv * brev(p, A)) & ((1 << A) - 1), kjb = (j0inv * brev(p + 1, A)) & ((1 << A) - 1);
+            gl_mul2(v[g * (1 << A) + p], twr[kja * rho], v[g * (1 << A) + p + 1], twr[kjb * rho]);
+        }
 #pragma unroll
         for (int p = 0; p < (1 << A); p++) {
             const int kj = (j0inv * brev(p, A)) & ((1 << A) - 1);  // wave-uniform
-            u64 x = v[g * (1 << A) + p];
-            if (p != 0) x = gl_mul(x, twr[kj * rho]);  // w_(2^(POS+A))^(kj*rho), LDS copy
-            lds[G::lpos(slot_of(o, kj, POS, A), t)] = x;
+            lds[G::lpos(slot_of(o, kj, POS, A), t)] = v[g * (1 << A) + p];
         }
     }
     lds_barrier();
@@ -165,7 +179,7 @@ __device__ __forceinline__ void exchange2(u64 *v, u64 *lds, const u64 *twr, int 
 // MODE (non-transposing passes): 0 = plain last pass, 1 = multiply by the per-tile table,
 // 2 = table and the per-lane part of a coset power (last pass of the inverse transform in an LDE)
 template <int A1, int A2, int A3, int LOGT, bool TRANSPOSE, bool PADDED, int MODE>
-__global__ void __launch_bounds__((1 << (A1 + A2 + A3 + LOGT)) / 16)
+__global__ void __launch_bounds__((1 << (A1 + A2 + A3 + LOGT)) / 16, 4)   // 4 waves per SIMD: 128 VGPRs, of which v116..v127 are the scratch window of gl_asm.hpp
 ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     using G = Geo<A1, A2, A3, LOGT>;
     constexpr int L = G::L, R = G::R, T = G::T, NT = G::NT, AJ = G::AJ;
@@ -286,10 +300,14 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
                 for (int i = 0; i < (1 << AJ); i++) {
                     const int p = brev(i, AJ);
                     const int kj = (jr * i) & ((1 << AJ) - 1);
-                    u64 x = gl_mul(v[g * (1 << AJ) + p], w);
+                    u64 x = v[g * (1 << AJ) + p];
                     if (i + 1 < (1 << AJ)) {
                         const bool wrap = ((jr * (i + 1)) >> AJ) != ((jr * i) >> AJ);  // wave-uniform
-                        w = gl_mul(w, wrap ? hjd : hj);
+                        u64 wn = w;
+                        gl_mul2(x, w, wn, wrap ? hjd : hj);
+                        w = wn;
+                    } else {
+                        x = gl_mul1(x, w);
                     }
                     lds[G::lpos(slot_of(o, kj, 0, AJ), t)] = x;
                 }
@@ -299,13 +317,14 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
                 u64 cw = 1;
                 if constexpr (MODE == 2) cw = gl_mul(twl_c[1], twh_c[1]);  // shift^c, c < Pprev
 #pragma unroll
-                for (int p = 0; p < (1 << AJ); p++) {
-                    const int kj = (a.j0inv * brev(p, AJ)) & ((1 << AJ) - 1);
-                    const int k = klow + (kj << (L - AJ));
-                    u64 x = v[g * (1 << AJ) + p];
-                    if constexpr (MODE >= 1) x = gl_mul(x, tab[k]);
-                    if constexpr (MODE == 2) x = gl_mul(x, cw);
-                    ZP_STG(&dst[obase + ((u64)k << logP)], x);
+                for (int p = 0; p < (1 << AJ); p += 2) {
+                    const int kja = (a.j0inv * brev(p, AJ)) & ((1 << AJ) - 1), kjb = (a.j0inv * brev(p + 1, AJ)) & ((1 << AJ) - 1);
+                    const int ka = klow + (kja << (L - AJ)), kb = klow + (kjb << (L - AJ));
+                    u64 xa = v[g * (1 << AJ) + p], xb = v[g * (1 << AJ) + p + 1];
+                    if constexpr (MODE >= 1) gl_mul2(xa, tab[ka], xb, tab[kb]);
+                    if constexpr (MODE == 2) gl_mul2(xa, cw, xb, cw);
+                    ZP_STG(&dst[obase + ((u64)ka << logP)], xa);
+                    ZP_STG(&dst[obase + ((u64)kb << logP)], xb);
                 }
             }
         }
@@ -422,6 +441,7 @@ int32_t dispatch_pass(zp_ctx *ctx, const NttPass &p, const PassArgs &a, bool tra
         case 7: return launch_pass2<4, 3, 0, 5>(ctx, a, transpose, W);
         case 8: return ctx->tune_logt == 4 ? launch_pass2<4, 4, 0, 4>(ctx, a, transpose, W) : launch_pass2<4, 4, 0, 5>(ctx, a, transpose, W);
         case 9: return ctx->tune_logt9 == 4 ? launch_pass2<3, 3, 3, 4>(ctx, a, transpose, W) : launch_pass2<3, 3, 3, 5>(ctx, a, transpose, W);
+        case 10: return launch_pass2<4, 3, 3, 4>(ctx, a, transpose, W);   // 1024 threads, 128 KiB tile: two-pass plans up to 2^20
         default: ctx->err = "unsupported pass radix"; return ZP_ERR_UNSUPPORTED;
     }
 }
@@ -432,6 +452,7 @@ void split_digit(NttPass &p) {
         case 6: p.A1 = 3; p.A2 = 3; p.A3 = 0; break;
         case 7: p.A1 = 4; p.A2 = 3; p.A3 = 0; break;
         case 8: p.A1 = 4; p.A2 = 4; p.A3 = 0; break;
+        case 10: p.A1 = 4; p.A2 = 3; p.A3 = 3; break;
         default: p.A1 = 3; p.A2 = 3; p.A3 = 3; break;
     }
     p.logT = 5;
@@ -523,7 +544,8 @@ static int32_t upload(zp_ctx *ctx, const std::vector<u64> &h, u64 **d) {
 }
 
 int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
-    const int key = logn * 2 + (inverse ? 1 : 0);
+    const int maxl = (ctx->tune_ntt_maxl >= 6 && ctx->tune_ntt_maxl <= 10) ? ctx->tune_ntt_maxl : 9;
+    const int key = (logn * 2 + (inverse ? 1 : 0)) * 16 + maxl;
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) {
         *out = &it->second;
@@ -553,7 +575,7 @@ int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
     for (int i = 1; i < 4096; i++) tws[i] = gl_mul(tws[i - 1], w4096);
     ZP_TRY(upload(ctx, tws, &pl.d_tws));
     if (logn > 12) {
-        const int m = (logn + 8) / 9;
+        const int m = (logn + maxl - 1) / maxl;
         int rem = logn;
         int logP = 0;
         pl.npass = m;
@@ -647,8 +669,9 @@ int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, b
         return ZP_OK;
     }
 
-    // chunk the columns so that each ping-pong scratch buffer stays <= 2 GiB
-    const u64 cap_elems = 1ULL << (ctx->tune_ntt_chunk_log > 0 ? ctx->tune_ntt_chunk_log : 28);
+    // chunk the columns so that each ping-pong scratch buffer stays <= 1 GiB (measured: 2^27-element chunks run 10 % faster
+    // than 2^28 at 2^24 rows, 2^26 is best at 2^22 rows -- tools/ntt_chunk_sweep.py, profiles/r2_chunk_sweep.txt)
+    const u64 cap_elems = 1ULL << (ctx->tune_ntt_chunk_log > 0 ? ctx->tune_ntt_chunk_log : 27);
     int wc = (int)(cap_elems >> logn);
     if (wc < 1) wc = 1;
     if (wc > W) wc = W;
@@ -718,7 +741,7 @@ int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn,
     CosetTable *ct;
     ZP_TRY(zpi_get_coset(ctx, logn, shift, 1, &ct));
     // columns go in chunks so that the scaled-coefficient buffer stays <= 2 GiB
-    int wc = (int)((1ULL << (ctx->tune_ntt_chunk_log > 0 ? ctx->tune_ntt_chunk_log : 28)) >> logn);
+    int wc = (int)((1ULL << (ctx->tune_ntt_chunk_log > 0 ? ctx->tune_ntt_chunk_log : 27)) >> logn);
     if (wc < 1) wc = 1;
     if (wc > W) wc = W;
     u64 *scaled = nullptr;

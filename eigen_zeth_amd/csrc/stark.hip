@@ -486,3 +486,148 @@ extern "C" int32_t zp_grand_product(zp_ctx *ctx, const uint64_t *d_a, const uint
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
 }
+
+// ---- N4 through the C-ABI: interpreter of a constraint program (include/zeth_prover.h "constraint program") ----------
+// A host that cannot generate and compile a kernel per AIR (the Rust host of src/prover/provider.rs:358-377 has no hipcc at
+// run time) hands the AIR over as data.  lane = LDE row; the instruction stream is wave-uniform, so decoding is scalar
+// work (s_load + SALU) and every operand kind is a uniform branch; the slot file lives in LDS as [slot][lane] (no bank
+// conflicts: consecutive lanes, consecutive 8-byte words).  Constraint k is folded into three unreduced 160-bit
+// accumulators (alpha^k planes) at its OUT instruction; one reduction and the 1/Z_H multiplication at the end.
+namespace {
+
+constexpr int QP_MAX_SLOTS = 24;   // 24 * 256 lanes * 8 B = 48 KiB of LDS per workgroup
+
+struct QProgArgs {
+    const u64 *prog;      // device copy of the blob
+    const u64 *cols, *fixedc;
+    const u64 *pub, *apow, *zhinv;
+    const u64 *xs_lo, *xs_hi;
+    u64 *out;
+    u64 M, b, shift, wlast;
+    int lb, n_const, n_instr, n_slots;
+};
+
+__global__ void __launch_bounds__(256) quotient_program_kernel(QProgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u64 slots[];   // [n_slots][256]
+    const int tid = threadIdx.x;
+    const u64 r = (u64)blockIdx.x * 256 + tid;
+    const bool live = r < a.M;
+    const u64 rr = live ? r : 0;
+    const u64 rn = (rr + a.b) & (a.M - 1);
+    const u64 x = gl_mul(a.shift, gl_mul(a.xs_lo[rr & ((1ULL << a.lb) - 1)], a.xs_hi[rr >> a.lb]));
+    const u64 xml = gl_sub(x, a.wlast);
+    const u64 *consts = a.prog + 12, *ins = consts + a.n_const;
+    gl_acc s0 = gl_acc_zero(), s1 = gl_acc_zero(), s2 = gl_acc_zero();
+    int k_out = 0;
+    for (int i = 0; i < a.n_instr; i++) {
+        const u64 w = ins[i];                                   // uniform address: scalar load
+        const u32 wl = __builtin_amdgcn_readfirstlane((u32)w), wh = __builtin_amdgcn_readfirstlane((u32)(w >> 32));
+        const u64 wu = ((u64)wh << 32) | wl;
+        const int op = (int)(wu & 0xFF), dst = (int)((wu >> 8) & 0xFFFF);
+        u64 v[2];
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            const int kind = (int)((wu >> (24 + 20 * o)) & 0xF), idx = (int)((wu >> (28 + 20 * o)) & 0xFFFF);
+            u64 val;
+            switch (kind) {
+                case 0: val = slots[idx * 256 + tid]; break;
+                case 1: val = a.cols[(u64)idx * a.M + rr]; break;
+                case 2: val = a.cols[(u64)idx * a.M + rn]; break;
+                case 3: val = a.fixedc[(u64)idx * a.M + rr]; break;
+                case 4: val = a.pub[idx]; break;
+                case 5: val = consts[idx]; break;
+                default: val = xml; break;
+            }
+            v[o] = val;
+            if (op == 4) break;
+        }
+        if (op == 1) slots[dst * 256 + tid] = gl_add(v[0], v[1]);
+        else if (op == 2) slots[dst * 256 + tid] = gl_sub(v[0], v[1]);
+        else if (op == 3) slots[dst * 256 + tid] = gl_mul(v[0], v[1]);
+        else {
+            gl_acc_mac(s0, v[0], a.apow[3 * k_out]);
+            gl_acc_mac(s1, v[0], a.apow[3 * k_out + 1]);
+            gl_acc_mac(s2, v[0], a.apow[3 * k_out + 2]);
+            k_out++;
+        }
+    }
+    if (!live) return;
+    const u64 zi = a.zhinv[r & (a.b - 1)];
+    a.out[r] = gl_mul(gl_acc_reduce(s0), zi);
+    a.out[a.M + r] = gl_mul(gl_acc_reduce(s1), zi);
+    a.out[2 * a.M + r] = gl_mul(gl_acc_reduce(s2), zi);
+}
+
+}  // namespace
+
+extern "C" int32_t zp_eval_quotient(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *d_cols,
+                                    const uint64_t *d_fixed, int32_t logm, int32_t logb, const uint64_t *h_pub, int32_t n_pub,
+                                    const uint64_t *h_alpha_pows, const uint64_t *h_zhinv, uint64_t shift, uint64_t w_last,
+                                    uint64_t *d_out) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "eval_quotient");
+    ZP_ARG(ctx, h_program && d_cols && d_fixed && h_alpha_pows && h_zhinv && d_out, "null pointer");
+    ZP_ARG(ctx, logm >= 0 && logm <= 32 && logb >= 0 && logb <= logm, "logm/logb out of range");
+    ZP_ARG(ctx, program_words >= 12, "constraint program shorter than its header");
+    static const unsigned char magic[8] = {'Z', 'P', 'A', 'I', 'R', '1', 0, 0};
+    ZP_ARG(ctx, memcmp(h_program, magic, 8) == 0, "not a ZPAIR1 constraint program");
+    const u64 width = h_program[1], width2 = h_program[2], n_fixed = h_program[3], np = h_program[4], nchal = h_program[5];
+    const u64 n_const = h_program[6], n_instr = h_program[7], n_cons = h_program[8], n_slots = h_program[9], n_s2 = h_program[10];
+    ZP_ARG(ctx, n_const < (1u << 16) && n_instr < (1u << 24) && n_s2 < (1u << 16) &&
+                    program_words == 12 + n_const + n_instr + 4 * n_s2, "constraint program length does not match its header");
+    ZP_ARG(ctx, n_slots >= 1 && n_slots <= (u64)QP_MAX_SLOTS, "constraint program needs more slots than the interpreter has (24)");
+    ZP_ARG(ctx, (u64)n_pub == np + nchal && (np + nchal == 0 || h_pub), "n_pub must equal publics + challenges of the program");
+    ZP_ARG(ctx, n_fixed <= 2, "at most the two boundary selectors are supported as fixed columns");
+    ZP_ARG(ctx, shift < GL_P && w_last < GL_P, "shift / w_last not canonical");
+    const uint64_t *consts = h_program + 12, *ins = consts + n_const;
+    u64 outs = 0;
+    for (u64 i = 0; i < n_const; i++) ZP_ARG(ctx, consts[i] < GL_P, "constant not canonical");
+    for (u64 i = 0; i < n_instr; i++) {
+        const u64 w = ins[i];
+        const unsigned op = (unsigned)(w & 0xFF), dst = (unsigned)((w >> 8) & 0xFFFF);
+        ZP_ARG(ctx, op >= 1 && op <= 4, "unknown opcode in constraint program");
+        for (int o = 0; o < (op == 4 ? 1 : 2); o++) {
+            const unsigned kind = (unsigned)((w >> (24 + 20 * o)) & 0xF), idx = (unsigned)((w >> (28 + 20 * o)) & 0xFFFF);
+            const u64 lim = kind == 0 ? n_slots : (kind == 1 || kind == 2) ? width + width2 : kind == 3 ? n_fixed
+                            : kind == 4 ? np + nchal : kind == 5 ? n_const : kind == 6 ? 1 : 0;
+            ZP_ARG(ctx, idx < lim, "operand out of range in constraint program");
+        }
+        if (op != 4) ZP_ARG(ctx, dst < n_slots, "destination slot out of range in constraint program");
+        outs += op == 4;
+    }
+    ZP_ARG(ctx, outs == n_cons, "OUT count does not match the header");
+    for (int i = 0; i < n_pub; i++) ZP_ARG(ctx, h_pub[i] < GL_P, "public input not canonical");
+    const u64 M = 1ULL << logm, b = 1ULL << logb;
+    NttPlan *pl;
+    ZP_TRY(zpi_get_plan(ctx, logm, false, &pl));
+    // one upload: program | pub | apow | zhinv
+    const size_t np_all = (size_t)n_pub + 1, total = program_words + np_all + 3 * (size_t)n_cons + (size_t)b;
+    std::vector<u64> h(total);
+    memcpy(h.data(), h_program, program_words * 8);
+    for (int i = 0; i < n_pub; i++) h[program_words + i] = h_pub[i];
+    h[program_words + n_pub] = 0;
+    memcpy(h.data() + program_words + np_all, h_alpha_pows, 3 * (size_t)n_cons * 8);
+    memcpy(h.data() + program_words + np_all + 3 * (size_t)n_cons, h_zhinv, (size_t)b * 8);
+    u64 *d;
+    ZP_TRY(zpi_scratch(ctx, 3, total, &d));
+    if (total * 8 <= ZP_SMALL_COPY) ZP_TRY(zpi_h2d_small(ctx, d, h.data(), total * 8));
+    else {
+        ZP_HIP(ctx, hipMemcpyAsync(d, h.data(), total * 8, hipMemcpyHostToDevice, ctx->stream));
+        ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    QProgArgs a;
+    a.prog = d;
+    a.cols = (const u64 *)d_cols;
+    a.fixedc = (const u64 *)d_fixed;
+    a.pub = d + program_words;
+    a.apow = a.pub + np_all;
+    a.zhinv = a.apow + 3 * (size_t)n_cons;
+    a.xs_lo = pl->d_twl;
+    a.xs_hi = pl->d_twh;
+    a.out = (u64 *)d_out;
+    a.M = M; a.b = b; a.shift = shift; a.wlast = w_last;
+    a.lb = pl->lb; a.n_const = (int)n_const; a.n_instr = (int)n_instr; a.n_slots = (int)n_slots;
+    hipLaunchKernelGGL(quotient_program_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)n_slots * 256 * 8, ctx->stream, a);
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}

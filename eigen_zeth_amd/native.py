@@ -56,6 +56,8 @@ SIGNATURES = {
     "zp_lde": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_poseidon_perm": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "zp_pow_grind": (C.c_int32, [_vp, _vp, C.c_int32, _vp]),
+    "zp_eval_quotient": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_uint64,
+                                     C.c_uint64, _vp]),
     "zp_merkle_commit": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp]),
     "zp_merkle_commit_rows": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _vp]),
     "zp_merkle_open": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _u64p]),
@@ -291,6 +293,15 @@ class Prover:
 
     def poseidon_perm(self, d_states, count):
         self._chk(self.lib.zp_poseidon_perm(self.ctx, _ptr(d_states), count))
+
+    def eval_quotient(self, program, d_cols, d_fixed, logm, logb, pubs, apow, zhinv, shift, w_last, d_out):
+        """constraint program blob (numpy u64) interpreted on the GPU: quotient planes u64[3][2^logm] into d_out"""
+        prog = np.ascontiguousarray(np.asarray(program, dtype=np.uint64))
+        pb = np.ascontiguousarray(np.asarray(list(pubs) + [0], dtype=np.uint64))
+        ap = np.ascontiguousarray(np.asarray(apow, dtype=np.uint64).reshape(-1))
+        zh = np.ascontiguousarray(np.asarray(zhinv, dtype=np.uint64))
+        self._chk(self.lib.zp_eval_quotient(self.ctx, prog.ctypes.data, prog.size, _ptr(d_cols), _ptr(d_fixed), logm, logb, pb.ctypes.data,
+                                            len(pubs), ap.ctypes.data, zh.ctypes.data, shift, w_last, _ptr(d_out)))
 
     def pow_grind(self, seed4, bits):
         sd = (C.c_uint64 * 4)(*[int(v) for v in seed4])

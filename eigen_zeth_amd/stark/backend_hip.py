@@ -20,7 +20,11 @@ class Commit:
 
 
 class HipBackend:
-    def __init__(self, device=0, prover=None):
+    def __init__(self, device=0, prover=None, quotient="kernel"):
+        """quotient: "kernel" = the generated per-AIR constraint kernel (AIR plug-in ABI, needs hipcc at build time);
+        "program" = zp_eval_quotient interpreting the AIR's constraint program blob (what a host without a compiler uses)"""
+        assert quotient in ("kernel", "program")
+        self.quotient_mode = quotient
         self.p = prover or native.Prover(device)
         self.p.pooling = True   # chunk after chunk has the same shapes: reuse device buffers
         self.root32 = int(self.p.get_constants(native.ZP_CONST_ROOT32, 1)[0])
@@ -142,6 +146,10 @@ class HipBackend:
 
     def quotient(self, air, c1, fixed, pubs, apow, zhinv, logn, logb, wlast):
         M = 1 << (logn + logb)
+        if self.quotient_mode == "program":
+            out = self.p.alloc(3 * M)
+            self.p.eval_quotient(air.program(), c1.ext, fixed, logn + logb, logb, [int(v) for v in pubs], apow, zhinv, self.shift, wlast, out)
+            return out
         fn = self._airlib(air)
         d_pub = self.p.upload(np.array(list(pubs) + [0], dtype=np.uint64))
         d_ap = self.p.upload(np.array(apow, dtype=np.uint64).reshape(-1))

@@ -155,6 +155,25 @@ int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, cons
  *   d_zhinv [blowup] = 1/Z_H on the coset (periodic), d_out [3][M] = quotient planes.
  * zp_domain_tables hands such kernels the ctx-owned two-level table of w_M^e (x = shift*lo[e&mask]*hi[e>>lb]). */
 int32_t zp_domain_tables(zp_ctx *ctx, int32_t logm, const uint64_t **d_lo, const uint64_t **d_hi, int32_t *lb);
+/* ---- N4 as data: the constraint program ----------------------------------------------------------------
+ * An AIR handed over as a u64 blob instead of a generated kernel (a host without hipcc at run time can still
+ * prove any AIR; slower than the plug-in kernel, same results).  Layout, all words u64 little-endian:
+ *   [0] magic "ZPAIR1\0\0"   [1] trace width W   [2] stage-2 width W2   [3] fixed columns (2: L_first, L_last)
+ *   [4] publics   [5] challenges (0 or 3; they follow the publics in the operand space)   [6] n_const   [7] n_instr
+ *   [8] n_constraints   [9] n_slots   [10] n_stage2   [11] quotient chunks Q (pieces of degree < N)
+ *   consts[n_const] | instr[n_instr] | stage2[n_stage2][4] = {kind 1 perm: a, b, 0 | kind 2 lookup: a, t, m}
+ *   instr: bits 0-7 opcode (1 add, 2 sub, 3 mul: slot[dst] = a op b;  4 OUT: constraint k = a, k counts the OUTs),
+ *          8-23 dst slot, 24-27 kind(a), 28-43 index(a), 44-47 kind(b), 48-63 index(b)
+ *   operand kinds: 0 slot, 1 column at row r, 2 column at the next trace row (r + blow-up), 3 fixed column,
+ *                  4 public/challenge, 5 constant, 6 the factor x - w_N^(N-1) of a transition constraint
+ * zp_eval_quotient evaluates the program on every row of the LDE domain (M = 2^logm rows, x = shift*w_M^r), combines
+ * constraint k with alpha^k in F_{p^3} (h_alpha_pows [K][3]), multiplies by h_zhinv[r mod 2^logb] and writes the three
+ * planes d_out u64[3][M].  d_cols u64[W+W2][M], d_fixed u64[2][M]; h_pub = publics then challenges (n_pub values).
+ * A malformed program (bad magic, lengths, operand or slot out of range, more than 24 slots) is ZP_ERR_ARG.        */
+int32_t zp_eval_quotient(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *d_cols,
+                         const uint64_t *d_fixed, int32_t logm, int32_t logb, const uint64_t *h_pub, int32_t n_pub,
+                         const uint64_t *h_alpha_pows, const uint64_t *h_zhinv, uint64_t shift, uint64_t w_last,
+                         uint64_t *d_out);
 /* synthetic witness generation (stands in for the zkVM executor, which is not obtainable offline):
  * kind 0 = Fibonacci (W=2), kind 1 = wide degree-2 mix (any W >= 3), kind 2 = permutation AIR (W=3:
  * a, b = a permuted, c = a^2), kind 3 = chunk AIR (W >= 12: W-8 wide-mix columns, then Fibonacci a,b, range values r,

@@ -183,3 +183,38 @@ def test_full_size_proofs_pass_the_independent_verifier(hip_backend, tables, nam
     bad["evals"]["zw"][1][2] ^= 1
     with pytest.raises(V.Reject):
         V.verify(bad, air.program(), rc, mds, V.expectation(params.to_dict()))
+
+
+@pytest.mark.parametrize("name,logn", [("fib", 6), ("perm", 8), ("wide32", 11), ("chunk16", 9), ("chunk64", 12)])
+def test_constraint_program_interpreter_gives_the_same_proof(prover, hip_backend, cpu_backend, tables, name, logn):
+    """zp_eval_quotient (the AIR as a data blob, interpreted on the GPU) == the generated kernel == the checker's CPU interpreter:
+    whole proofs are byte-identical whichever evaluates the constraints"""
+    from eigen_zeth_amd.stark.backend_hip import HipBackend
+    rc, mds = tables
+    air = AIR.get_air(name)
+    tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 555 + logn)
+    params = PR.StarkParams(logn, logb=1, fri_logf=3, fri_final_log=4, n_queries=5, pow_bits=6)
+    be_prog = HipBackend(prover=prover, quotient="program")
+    a = PR.proof_to_json(PR.prove(air, tr, pub, params, be_prog))
+    assert a == PR.proof_to_json(PR.prove(air, tr, pub, params, hip_backend))
+    assert a == PR.proof_to_json(PR.prove(air, tr, pub, params, cpu_backend))
+    import json
+    assert V.verify(json.loads(a), air.program(), rc, mds, V.expectation(params.to_dict()))
+
+
+def test_eval_quotient_rejects_malformed_programs(prover):
+    air = AIR.get_air("fib")
+    good = air.program()
+    M = 1 << 6
+    d_cols, d_fixed, d_out = prover.alloc(2 * M), prover.alloc(2 * M), prover.alloc(3 * M)
+    apow = [[1, 0, 0]] * len(air.constraints)
+    args = lambda blob, pubs=(1, 2, 3): (blob, d_cols, d_fixed, 6, 1, list(pubs), apow, [1, 1], 49, 5, d_out)
+    prover.eval_quotient(*args(good))
+    for mutate in (lambda b: b.__setitem__(0, 7), lambda b: b.__setitem__(7, int(b[7]) + 1), lambda b: b.__setitem__(9, 99),
+                   lambda b: b.__setitem__(12 + int(b[6]), 9), lambda b: b.__setitem__(12 + int(b[6]), int(b[12 + int(b[6])]) | (0xFFFF << 28))):
+        bad = good.copy()
+        mutate(bad)
+        with pytest.raises(native.ZpError):
+            prover.eval_quotient(*args(bad))
+    with pytest.raises(native.ZpError):
+        prover.eval_quotient(*args(good, pubs=(1, 2)))
