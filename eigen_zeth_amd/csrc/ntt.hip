@@ -74,8 +74,19 @@ struct Geo {
         if (A3 > 0) s |= (k >> (A1 + A2)) & ((1 << A3) - 1);
         return s;
     }
+    // LDS position of (slot sigma, column t).  t is XORed with the low bits of the output index (conflict-free row accesses
+    // and transposing copy-out at T >= 16).  With T < 16 one slot is only T*8 < 128 bytes, so the 32 lanes of a half-wave
+    // span 32/T slots and those must fall into different 32/T-ths of a 256-byte bank row: the low bits of sigma (inside
+    // the last-round field) are XORed with the low bits of the middle field (last-round reads and writes: consecutive lanes
+    // = consecutive middle-field values) and, one bit up, with the top-field bits the t-swizzle does not use (transposing
+    // copy-out: consecutive lanes = consecutive top-field values, then the middle field steps by one).
     __device__ static __forceinline__ int lpos(int sigma, int t) {
-        return (sigma << LOGT) + (t ^ (kof(sigma) & (T - 1)));
+        int s2 = sigma;
+        if constexpr (LOGT < 4 && A3 > 0) {
+            constexpr int GB = 5 - LOGT;
+            s2 ^= ((sigma >> POS2) & ((1 << GB) - 1)) ^ (((sigma >> (POS1 + LOGT)) & ((1 << (A1 - LOGT)) - 1)) << 1);
+        }
+        return (s2 << LOGT) + (t ^ (kof(sigma) & (T - 1)));
     }
 };
 
@@ -126,7 +137,9 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <typename G, int A, int POS, int ANEXT, int POSNEXT>
+// twr: LDS copy of w_(2^(POS+A))^e (TWSH = 0) or, for the radix-2^11 / 2^12 passes whose LDS is all tile, the global
+// table of w_4096^e (TWSH = 12 - (POS + A)); 32 KiB, read by every workgroup, L2 / L1 resident
+template <typename G, int A, int POS, int ANEXT, int POSNEXT, int TWSH>
 __device__ __forceinline__ void exchange2(u64 *v, u64 *lds, const u64 *twr, int j0inv, int tid) {
     constexpr int GR = 16 >> A;
 #pragma unroll
@@ -137,12 +150,12 @@ __device__ __forceinline__ void exchange2(u64 *v, u64 *lds, const u64 *twr, int 
         // w_(2^(POS+A))^(kj*rho) from the LDS copy; p = 0 needs none, the rest go two products at a time
         {
             const int kj1 = (j0inv * brev(1, A)) & ((1 << A) - 1);
-            v[g * (1 << A) + 1] = gl_mul1(v[g * (1 << A) + 1], twr[kj1 * rho]);
+            v[g * (1 << A) + 1] = gl_mul1(v[g * (1 << A) + 1], twr[(kj1 * rho) << TWSH]);
         }
 #pragma unroll
         for (int p = 2; p < (1 << A); p += 2) {
             const int kja = (j0inv * brev(p, A)) & ((1 << A) - 1), kjb = (j0inv * brev(p + 1, A)) & ((1 << A) - 1);
-            gl_mul2(v[g * (1 << A) + p], twr[kja * rho], v[g * (1 << A) + p + 1], twr[kjb * rho]);
+            gl_mul2(v[g * (1 << A) + p], twr[(kja * rho) << TWSH], v[g * (1 << A) + p + 1], twr[(kjb * rho) << TWSH]);
         }
 #pragma unroll
         for (int p = 0; p < (1 << A); p++) {
@@ -185,10 +198,13 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     constexpr int L = G::L, R = G::R, T = G::T, NT = G::NT, AJ = G::AJ;
     constexpr int GRJ = 16 >> AJ;
     constexpr int R2 = 1 << (A2 + A3);
+    constexpr bool HAS_TAB = !TRANSPOSE && MODE >= 1;
+    constexpr bool TWR_LDS = L <= 10;          // radix 2^11 / 2^12: the 128 KiB tile leaves no room, twiddles come from L2
+    constexpr int TPL = (R + NT - 1) / NT;     // per-tile table entries a lane prepares
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    u64 *tab = lds + R * T;   // R entries: per-tile inter-pass twiddles
-    u64 *twr1 = tab + R;      // R entries:  w_R^e      (inter-round twiddles, first exchange)
-    u64 *twr2 = twr1 + R;     // R2 entries: w_(R2)^e   (second exchange, 3-round passes)
+    u64 *tab = lds + R * T;                    // R entries: per-tile inter-pass twiddles (HAS_TAB)
+    u64 *twr1 = tab + (HAS_TAB ? R : 0);       // R entries:  w_R^e      (inter-round twiddles, first exchange)
+    u64 *twr2 = twr1 + R;                      // R2 entries: w_(R2)^e   (second exchange, 3-round passes)
     const u64 col = blockIdx.y;
     const int logNR = a.logn - L;
     const int logP = a.logPprev;
@@ -197,7 +213,7 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     u64 *dst = a.out + col * a.out_cs;
     u64 v[16], vn[16];
     // twiddle-table entries fetched one tile ahead (raw lo/hi halves)
-    constexpr int NTW = TRANSPOSE ? (GRJ + 2) : (MODE == 2 ? 2 : 1);
+    constexpr int NTW = TRANSPOSE ? (GRJ + 2) : (MODE == 2 ? TPL + 1 : TPL);
     u64 twl_c[NTW], twh_c[NTW], twl_n[NTW], twh_n[NTW];
 
     auto fetch_tile = [&](u64 *r, u64 *tl, u64 *th, u64 u0, int tid) {
@@ -209,8 +225,9 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
 #pragma unroll
             for (int j = 0; j < (1 << A1); j++) {
                 const u64 idx = ((u64)slot_of(o, j, G::POS1, A1) << logNR) + u0 + t;
-                if constexpr (PADDED) r[g * (1 << A1) + j] = idx < a.in_valid ? ZP_LDG(&src[idx]) : 0ULL;
-                else r[g * (1 << A1) + j] = ZP_LDG(&src[idx]);
+                // short runs (T < 16) want the L2 to merge neighbouring tiles' pieces of a line: plain, cacheable loads
+                if constexpr (PADDED) r[g * (1 << A1) + j] = idx < a.in_valid ? (LOGT < 4 ? src[idx] : ZP_LDG(&src[idx])) : 0ULL;
+                else r[g * (1 << A1) + j] = LOGT < 4 ? src[idx] : ZP_LDG(&src[idx]);
             }
         }
         const u64 lm = (1ULL << a.lb) - 1;
@@ -228,33 +245,49 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
         } else {
             if constexpr (MODE >= 1) {
                 const u64 e0 = (u0 >> logP) << logP;
-                const u64 e = (a.flags & 1) ? e0 * (u64)(tid & (R - 1)) : 0;  // entry k = tid (tid < R used)
-                tl[0] = a.twl[e & lm];
-                th[0] = a.twh[e >> a.lb];
+#pragma unroll
+                for (int j = 0; j < TPL; j++) {
+                    const u64 e = (a.flags & 1) ? e0 * (u64)((tid + j * NT) & (R - 1)) : 0;  // entry k = tid + j*NT (k < R used)
+                    tl[j] = a.twl[e & lm];
+                    th[j] = a.twh[e >> a.lb];
+                }
             }
             if constexpr (MODE == 2) {
                 const u64 c = (u0 + (tid & (T - 1))) & ((1ULL << logP) - 1);
-                tl[1] = a.csl[c & ((1ULL << a.cslb) - 1)];
-                th[1] = a.csh[c >> a.cslb];
+                tl[TPL] = a.csl[c & ((1ULL << a.cslb) - 1)];
+                th[TPL] = a.csh[c >> a.cslb];
             }
         }
     };
 
-    const u64 tile0 = (u64)blockIdx.x * tiles_per_wg;
+    // Runs shorter than a 128-byte line (T < 16) are shared between neighbouring tiles: hand neighbours to workgroups
+    // of the same XCD (blockIdx % 8 -- a speed hint only, MI355X_MICROARCH.md "Workgroup dispatch") so that the other
+    // parts of a line are L2 hits; measured on the bare access pattern: 2.7 -> 4.8 TB/s (profiles/r2_ubench_mem.txt)
+    u64 wg = blockIdx.x;
+    if constexpr (LOGT < 4) {
+        if ((gridDim.x & 7u) == 0) wg = (u64)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    }
+    const u64 tile0 = wg * tiles_per_wg;
     fetch_tile(v, twl_c, twh_c, tile0 << LOGT, threadIdx.x);
     // once per workgroup: inter-round twiddles into LDS, tile-independent factors into registers
-    u64 kfac = 1;
+    u64 kfac[TPL];
     {
         const int tid0 = threadIdx.x;
-        if (tid0 < R) twr1[tid0] = a.tws[tid0 << (12 - L)];
-        if constexpr (G::J >= 3) {
-            if (tid0 < R2) twr2[tid0] = a.tws[tid0 << (12 - (A2 + A3))];
+        if constexpr (TWR_LDS) {
+            if (tid0 < R) twr1[tid0] = a.tws[tid0 << (12 - L)];
+            if constexpr (G::J >= 3) {
+                if (tid0 < R2) twr2[tid0] = a.tws[tid0 << (12 - (A2 + A3))];
+            }
         }
-        if constexpr (!TRANSPOSE && MODE >= 1) {
-            if (a.flags & 2) kfac = a.scale;
-            if constexpr (MODE == 2) {
-                const u64 ek = (u64)(tid0 & (R - 1)) << logP;
-                kfac = gl_mul(kfac, gl_mul(a.csl[ek & ((1ULL << a.cslb) - 1)], a.csh[ek >> a.cslb]));
+#pragma unroll
+        for (int j = 0; j < TPL; j++) {
+            kfac[j] = 1;
+            if constexpr (HAS_TAB) {
+                if (a.flags & 2) kfac[j] = a.scale;
+                if constexpr (MODE == 2) {
+                    const u64 ek = (u64)((tid0 + j * NT) & (R - 1)) << logP;
+                    kfac[j] = gl_mul(kfac[j], gl_mul(a.csl[ek & ((1ULL << a.cslb) - 1)], a.csh[ek >> a.cslb]));
+                }
             }
         }
     }
@@ -273,16 +306,18 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
         if (more) fetch_tile(vn, twl_n, twh_n, u0 + T, tid);
 
         const u64 s = TRANSPOSE ? 0 : (u0 >> logP);
-        if constexpr (!TRANSPOSE && MODE >= 1) {
-            if (tid < R) tab[tid] = gl_mul(gl_mul(twl_c[0], twh_c[0]), kfac);
+        if constexpr (HAS_TAB) {
+#pragma unroll
+            for (int j = 0; j < TPL; j++)
+                if (tid + j * NT < R) tab[tid + j * NT] = gl_mul(gl_mul(twl_c[j], twh_c[j]), kfac[j]);
         }
 #pragma unroll
         for (int g = 0; g < (16 >> A1); g++) dif_shift<A1>(v + g * (1 << A1));
-        exchange2<G, A1, G::POS1, A2, G::POS2>(v, lds, twr1, a.j0inv, tid);
+        exchange2<G, A1, G::POS1, A2, G::POS2, TWR_LDS ? 0 : 12 - L>(v, lds, TWR_LDS ? twr1 : a.tws, a.j0inv, tid);
 #pragma unroll
         for (int g = 0; g < (16 >> A2); g++) dif_shift<A2>(v + g * (1 << A2));
         if constexpr (G::J >= 3) {
-            exchange2<G, A2, G::POS2, A3, 0>(v, lds, twr2, a.j0inv, tid);
+            exchange2<G, A2, G::POS2, A3, 0, TWR_LDS ? 0 : 12 - (A2 + A3)>(v, lds, TWR_LDS ? twr2 : a.tws, a.j0inv, tid);
 #pragma unroll
             for (int g = 0; g < (16 >> A3); g++) dif_shift<A3>(v + g * (1 << A3));
         }
@@ -315,7 +350,7 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
                 const u64 c = (u0 + t) & ((1ULL << logP) - 1);
                 const u64 obase = (s << (logP + L)) + c;
                 u64 cw = 1;
-                if constexpr (MODE == 2) cw = gl_mul(twl_c[1], twh_c[1]);  // shift^c, c < Pprev
+                if constexpr (MODE == 2) cw = gl_mul(twl_c[TPL], twh_c[TPL]);  // shift^c, c < Pprev
 #pragma unroll
                 for (int p = 0; p < (1 << AJ); p += 2) {
                     const int kja = (a.j0inv * brev(p, AJ)) & ((1 << AJ) - 1), kjb = (a.j0inv * brev(p + 1, AJ)) & ((1 << AJ) - 1);
@@ -323,8 +358,13 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
                     u64 xa = v[g * (1 << AJ) + p], xb = v[g * (1 << AJ) + p + 1];
                     if constexpr (MODE >= 1) gl_mul2(xa, tab[ka], xb, tab[kb]);
                     if constexpr (MODE == 2) gl_mul2(xa, cw, xb, cw);
-                    ZP_STG(&dst[obase + ((u64)ka << logP)], xa);
-                    ZP_STG(&dst[obase + ((u64)kb << logP)], xb);
+                    if constexpr (LOGT < 4) {
+                        dst[obase + ((u64)ka << logP)] = xa;
+                        dst[obase + ((u64)kb << logP)] = xb;
+                    } else {
+                        ZP_STG(&dst[obase + ((u64)ka << logP)], xa);
+                        ZP_STG(&dst[obase + ((u64)kb << logP)], xb);
+                    }
                 }
             }
         }
@@ -335,7 +375,7 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
             for (int i = 0; i < 16; i++) {
                 const int idx = i * NT + tid;
                 const int t2 = idx >> L, k = idx & ((1 << L) - 1);
-                ZP_STG(&blk[idx], lds[(G::sigma_of_k(k) << LOGT) + (t2 ^ (k & (T - 1)))]);
+                ZP_STG(&blk[idx], lds[G::lpos(G::sigma_of_k(k), t2)]);
             }
         }
         if (more) {
@@ -417,7 +457,9 @@ int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
     int tpw = ctx->tune_tpw;
     while (tpw > 1 && (tiles % tpw != 0 || tiles / tpw * (u64)W < (u64)ctx->num_cu * 4)) tpw >>= 1;
     dim3 grid((unsigned)(tiles / tpw), (unsigned)W), block(G::NT);
-    const size_t shmem = ((size_t)G::R * G::T + 2 * G::R + (1 << (A2 + A3))) * sizeof(u64);
+    // tile + (per-tile table: non-transposing passes with a multiplication) + (LDS copies of the inter-round twiddles, L <= 10)
+    const bool has_tab = !transpose && (a.flags & 7) != 0;
+    const size_t shmem = ((size_t)G::R * G::T + (has_tab ? G::R : 0) + (G::L <= 10 ? G::R + (1 << (A2 + A3)) : 0)) * sizeof(u64);
     if (transpose) {
         const bool padded = a.in_valid != (1ULL << a.logn);
         auto k = padded ? ntt_pass2_kernel<A1, A2, A3, LOGT, true, true, 1> : ntt_pass2_kernel<A1, A2, A3, LOGT, true, false, 1>;
@@ -441,7 +483,10 @@ int32_t dispatch_pass(zp_ctx *ctx, const NttPass &p, const PassArgs &a, bool tra
         case 7: return launch_pass2<4, 3, 0, 5>(ctx, a, transpose, W);
         case 8: return ctx->tune_logt == 4 ? launch_pass2<4, 4, 0, 4>(ctx, a, transpose, W) : launch_pass2<4, 4, 0, 5>(ctx, a, transpose, W);
         case 9: return ctx->tune_logt9 == 4 ? launch_pass2<3, 3, 3, 4>(ctx, a, transpose, W) : launch_pass2<3, 3, 3, 5>(ctx, a, transpose, W);
-        case 10: return launch_pass2<4, 3, 3, 4>(ctx, a, transpose, W);   // 1024 threads, 128 KiB tile: two-pass plans up to 2^20
+        // 1024-thread workgroups, 128 KiB tiles: two-pass plans up to 2^20 / 2^22 / 2^24 (runs of 128 / 64 / 32 bytes)
+        case 10: return launch_pass2<4, 3, 3, 4>(ctx, a, transpose, W);
+        case 11: return launch_pass2<4, 4, 3, 3>(ctx, a, transpose, W);
+        case 12: return launch_pass2<4, 4, 4, 2>(ctx, a, transpose, W);
         default: ctx->err = "unsupported pass radix"; return ZP_ERR_UNSUPPORTED;
     }
 }
@@ -453,6 +498,8 @@ void split_digit(NttPass &p) {
         case 7: p.A1 = 4; p.A2 = 3; p.A3 = 0; break;
         case 8: p.A1 = 4; p.A2 = 4; p.A3 = 0; break;
         case 10: p.A1 = 4; p.A2 = 3; p.A3 = 3; break;
+        case 11: p.A1 = 4; p.A2 = 4; p.A3 = 3; break;
+        case 12: p.A1 = 4; p.A2 = 4; p.A3 = 4; break;
         default: p.A1 = 3; p.A2 = 3; p.A3 = 3; break;
     }
     p.logT = 5;
@@ -544,7 +591,7 @@ static int32_t upload(zp_ctx *ctx, const std::vector<u64> &h, u64 **d) {
 }
 
 int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
-    const int maxl = (ctx->tune_ntt_maxl >= 6 && ctx->tune_ntt_maxl <= 10) ? ctx->tune_ntt_maxl : 9;
+    const int maxl = (ctx->tune_ntt_maxl >= 6 && ctx->tune_ntt_maxl <= 12) ? ctx->tune_ntt_maxl : 9;
     const int key = (logn * 2 + (inverse ? 1 : 0)) * 16 + maxl;
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) {
