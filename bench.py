@@ -47,21 +47,62 @@ def random_field_tensor(torch, shape, device, seed):
     return x
 
 
+def host_cpu_info():
+    """CPU model, physical cores (distinct (physical id, core id) pairs) and logical CPUs of this host, from /proc/cpuinfo"""
+    model, pairs, logical, phys, core = "", set(), 0, None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if phys is not None or core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+                continue
+            k, v = [x.strip() for x in line.split(":", 1)]
+            if k == "processor":
+                logical += 1
+            elif k == "model name" and not model:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+        if phys is not None or core is not None:
+            pairs.add((phys, core))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 0
+    return {"cpu_model": model, "physical_cores": len(pairs) or None, "logical_cpus": logical or None, "cpus_usable_by_this_process": usable}
+
+
 def cpu_baseline(logn, budget_cols):
-    """oracle NTT (OpenMP over columns) on a bounded sample of the same workload"""
+    """oracle NTT (OpenMP over columns) on a bounded sample of the same workload: one thread per physical core this
+    process may use, plus the single-thread rate"""
     import numpy as np
     from oracle import oracle as O
-    cores = O.num_threads()
-    cols = max(1, min(cores, 128))
+    host = host_cpu_info()
+    avail = O.num_threads()
+    threads = max(1, min(avail, host["physical_cores"] or avail, host["cpus_usable_by_this_process"] or avail))
+    O.set_threads(threads)
+    cols = max(1, min(threads, 128))
     x = O.random_field((cols, 1 << logn), 0xE16E2E70 + 2)
     t0 = time.perf_counter()
     y = O.ntt(x)
     dt = time.perf_counter() - t0
     del y
+    O.set_threads(1)
+    t0 = time.perf_counter()
+    y = O.ntt(x[:1])
+    dt1 = time.perf_counter() - t0
+    del y
+    O.set_threads(avail)
     # subtract nothing: copy + transform is what the CPU path does per call
-    return {"value": cols * (1 << logn) / dt, "unit": "field-elems/s", "cores": cores, "kind": "port",
-            "sample": "%d columns x 2^%d rows, oracle/gl_oracle.c cache-blocked radix-2 NTT, OpenMP over columns, %.2f s"
-                      % (cols, logn, dt),
+    return {"value": cols * (1 << logn) / dt, "unit": "field-elems/s", "cores": threads, "kind": "port",
+            "sample": "%d columns x 2^%d rows, oracle/gl_oracle.c cache-blocked radix-2 NTT, OpenMP over columns, %d threads, %.2f s"
+                      % (cols, logn, threads, dt),
+            "single_thread_value": (1 << logn) / dt1, "host": host,
             "note": "CPU restatement, not the eigen-zkvm prover (parity unpinned, SURVEY.md 8c)"}
 
 
@@ -140,15 +181,8 @@ def main():
     copy_gbs = None
     if rank == 0:
         y = torch.empty_like(x)
-        for _ in range(2):
-            y.copy_(x)
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0.record()
-        for _ in range(5):
-            y.copy_(x)
-        c1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 2.0 * x.numel() * 8 * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        ms = prover.hbm_copy_probe(x, y, x.numel() * 8, reps=5)     # libzethprover's own 16 B/lane non-temporal copy kernel
+        copy_gbs = 2.0 * x.numel() * 8 / (ms * 1e-3) / 1e9
         del y
 
     if rank == 0:
@@ -162,7 +196,7 @@ def main():
         dom = max(by_kind, key=lambda k: sum(by_kind[k])) if by_kind else 0
         launches = len(by_kind.get(dom, []))
         avg_ms = sum(by_kind[dom]) / launches if launches else float("nan")
-        chunk_cols = min(cols, max(1, (1 << int(os.environ.get("ZP_NTT_CHUNK_LOG", "28"))) >> logn))
+        chunk_cols = min(cols, max(1, (1 << int(os.environ.get("ZP_NTT_CHUNK_LOG", "27"))) >> logn))
         # algorithmic bytes of one launch: SURVEY 8d gives 16*N bytes per column transform (ideal single
         # pass); a launch does one of the `npass` passes over chunk_cols columns -> 16*N*chunk/npass
         alg_bytes = 16.0 * N * chunk_cols / npass
@@ -197,6 +231,7 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": "ntt_pass2_kernel<%s> radix 2^%d (%s)" % ("4,4,0,4,false,false,{1,0}" if dom == 8 else "...", abs(dom), "transposing first pass" if dom < 0 else "non-transposing passes 2..m: MODE 1 = twiddle table, MODE 0 = plain last pass"),
+                "launch_columns": chunk_cols,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if launches else None,
                 "traffic": traffic,
@@ -223,7 +258,7 @@ def main():
                     out["pipeline"] = {"error": "multi-rank probes did not finish within %d s; line printed by the watchdog" % PROBE_LIMIT_S}
                     print(json.dumps(out), flush=True)
                     printed[0] = True
-            os._exit(0)
+            os._exit(3)      # a stalled collective is a failure: the line above carries the headline, the exit code says so
         watchdog = threading.Timer(2 if wd_test else PROBE_LIMIT_S, bail)
         watchdog.daemon = True
         watchdog.start()
@@ -257,34 +292,36 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
     if rank == 0:
+        extra = {}      # gathered outside the lock; merged into `out` and printed under it (the watchdog reads `out`)
         if pipe is not None:
-            out["pipeline"] = pipe
+            extra["pipeline"] = pipe
         if batch_multi is not None:
-            out["batch_proof"] = {"batch": batch_multi}
+            extra["batch_proof"] = {"batch": batch_multi}
         if world == 1 and not args.no_pipeline:
             try:
-                out["batch_proof"] = batch_proof_probe(args.stark_logn)
+                extra["batch_proof"] = batch_proof_probe(args.stark_logn)
             except Exception as e:
-                out["batch_proof"] = {"error": repr(e)}
+                extra["batch_proof"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(logn, 32)
+            extra["cpu_baseline"] = cpu_baseline(logn, 32)
             try:
-                out["cpu_baseline"]["stark"] = cpu_stark_baseline(min(args.stark_logn, 16))
+                extra["cpu_baseline"]["stark"] = cpu_stark_baseline(min(args.stark_logn, 17))
             except Exception as e:
-                out["cpu_baseline"]["stark"] = {"error": repr(e)}
+                extra["cpu_baseline"]["stark"] = {"error": repr(e)}
             if args.stage_roofline:
                 try:
                     import types
                     from oracle import oracle as O, naive_bn254 as B1
                     from oracle.stark_cpu import CpuBackend
                     from tools import stage_roofline
-                    out["cpu_baseline"]["stages"] = stage_roofline.run(22, 32, cpu=types.SimpleNamespace(O=O, CpuBackend=CpuBackend, B1=B1))
+                    extra["cpu_baseline"]["stages"] = stage_roofline.run(22, 32, cpu=types.SimpleNamespace(O=O, CpuBackend=CpuBackend, B1=B1))
                 except Exception as e:
-                    out["cpu_baseline"]["stages"] = {"error": repr(e)}
+                    extra["cpu_baseline"]["stages"] = {"error": repr(e)}
         else:
-            out["cpu_baseline"] = None
+            extra["cpu_baseline"] = None
         with out_lock:
             if not printed[0]:
+                out.update(extra)
                 print(json.dumps(out), flush=True)
                 printed[0] = True
     if world > 1:
@@ -361,14 +398,11 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
     # BN254 MSM over the ranks: 2^22 points per GPU, partial sums all-gathered and added
     try:
         from eigen_zeth_amd.service import bn254
-        import random as _random
-        rnd = _random.Random(11)
-        table = [bn254.g1_mul(rnd.randrange(1, bn254.R)) for _ in range(16)]
-        tab = np.array([[(c >> (32 * k)) & 0xFFFFFFFF for c in pt for k in range(8)] for pt in table], dtype=np.uint32)
+        from eigen_zeth_amd import native as _native
         rk = dist.get_rank() if world > 1 else 0
         g = np.random.default_rng(100 + rk)
         nloc = 1 << 22
-        pts = tab[g.integers(0, 16, size=nloc)]
+        pts = _native.synth_g1_points(nloc, start=1025 + rk * nloc)     # all ranks' points distinct: (1025 + i) G
         scs = g.integers(0, 1 << 32, size=(nloc, 8), dtype=np.uint64).astype(np.uint32)
         scs[:, 7] &= 0x1FFFFFFF
         add = lambda p, q: bn254._pt_add(bn254._Ops1, p, q)
@@ -377,7 +411,8 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
         t0 = time.perf_counter()
         total = multigpu.distributed_msm(lambda: prover.msm_bn254_arrays(pts, scs), add)
         dt = time.perf_counter() - t0
-        res["msm_bn254"] = {"points_per_gpu": nloc, "wall_ms_incl_upload": dt * 1e3, "points_per_s_all_gpus": world * nloc / dt,
+        res["msm_bn254"] = {"points_per_gpu": nloc, "points": "distinct: (1025 + i) G (zp_synth_g1_points), uniform 253-bit scalars",
+                            "wall_ms_incl_upload": dt * 1e3, "points_per_s_all_gpus": world * nloc / dt,
                             "on_curve": bool(total is None or bn254.g1_on_curve(total))}
     except Exception as ex:
         res["msm_bn254"] = {"error": repr(ex)}
@@ -397,13 +432,14 @@ def batch_proof_probe(logn, air_name="chunk64"):
     tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 42)
     tw = time.perf_counter() - t0
     be = HipBackend(0)
-    params = PR.StarkParams(logn, logb=1, fri_logf=3, fri_final_log=5, n_queries=32)
+    params = PR.StarkParams(logn, logb=1, fri_logf=3, fri_final_log=5, n_queries=80, pow_bits=20)   # the service default: 100 bits
     PR.prove(air, tr, pub, params, be)
     tm = {}
     t0 = time.perf_counter()
     proof = PR.prove(air, tr, pub, params, be, timings=tm)
     wall = time.perf_counter() - t0
-    out = {"workload": "single chunk full STARK, AIR %s (%d columns), 2^%d rows, blow-up 2, 32 queries" % (air_name, air.width, logn),
+    out = {"workload": "single chunk full STARK, AIR %s (%d columns), 2^%d rows, blow-up 2, 80 queries + 20 grinding bits (%d bits conjectured)"
+                       % (air_name, air.width, logn, params.security_bits()),
            "wall_s": wall, "stages_ms": {k: round(v * 1e3, 2) for k, v in tm.items()},
            "witness_host_s": tw, "proof_bytes": len(PR.proof_to_json(proof))}
     del be, tr
@@ -415,27 +451,39 @@ def batch_proof_probe(logn, air_name="chunk64"):
 
 
 def engine_batch_probe(K, logn, air_name, device=0, tag=""):
-    """K blocks -> K chunk STARKs -> aggregate -> Groth16 wrap on one GPU through service/engine.py (no gRPC);
-    second of two runs (the first builds the local CRS and warms the buffer pools)"""
+    """K blocks -> K chunk STARKs -> aggregate -> Groth16 wrap on one GPU through service/engine.py (no gRPC), at the
+    service's default security (80 queries, blow-up 2, 20 grinding bits).  Reported twice: with the synthetic witness
+    generator (host code standing in for the zkVM executor) inside the timed region, and with the witnesses generated
+    beforehand (what the prover itself costs).  Each is the second of two runs (the first builds the local CRS and
+    warms the buffer pools)."""
     import tempfile
     from eigen_zeth_amd.service.engine import Engine, EngineConfig
     from eigen_zeth_amd.service.server import default_backend_factory
-    cfg = EngineConfig(air=air_name, logn=logn, n_queries=32, groth16_logm=8,
-                       crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_bench" + tag), witness_threads=16)
+    cfg = EngineConfig(air=air_name, logn=logn, groth16_logm=8,
+                       crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_bench_%d%s" % (os.getuid(), tag)), witness_threads=16)
     eng = Engine(default_backend_factory(device), cfg)
     eng.groth16_keys()
     res = {}
-    for rep in range(2):
-        t0 = time.perf_counter()
-        ch = eng.gen_batch_chunks("bench", list(range(1, K + 1)), 12345, "evm")
-        proofs = eng.gen_chunk_proofs("bench", ch["task_id"], ch["chunk_count"], ch["batch_data"])
-        t1 = time.perf_counter()
-        agg = eng.aggregate("bench", proofs[0]["proof"], proofs[-1]["proof"])
-        eng.final("bench", agg, "BN128", "479881985774944702531460751064278034642760119942")
-        t2 = time.perf_counter()
-        res = {"chunks": K, "wall_s": t2 - t0, "chunk_proofs_s": t1 - t0, "aggregate_final_s": t2 - t1,
-               "prover_streams": cfg.prover_streams,
-               "note": "synthetic witnesses are generated on the host inside the timed region (0.23 s each, 16 threads)"}
+    for pre in (False, True):
+        eng.pregenerate_witnesses = pre
+        for rep in range(2):
+            ch = eng.gen_batch_chunks("bench", list(range(1, K + 1)), 12345, "evm")
+            tw0 = time.perf_counter()
+            if pre:
+                eng.prepare_witnesses(ch["batch_data"])
+            t0 = time.perf_counter()
+            proofs = eng.gen_chunk_proofs("bench", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+            t1 = time.perf_counter()
+            agg = eng.aggregate("bench", proofs[0]["proof"], proofs[-1]["proof"])
+            eng.final("bench", agg, "BN128", "479881985774944702531460751064278034642760119942")
+            t2 = time.perf_counter()
+            r = {"wall_s": t2 - t0, "chunk_proofs_s": t1 - t0, "aggregate_final_s": t2 - t1}
+            if pre:
+                r["witness_generation_s_outside"] = t0 - tw0
+        res["witnesses_pregenerated" if pre else "with_witness_generator"] = r
+    res.update({"chunks": K, "prover_streams": cfg.prover_streams, "wall_s": res["witnesses_pregenerated"]["wall_s"],
+                "stark_security_bits": eng.stark_params(logn).security_bits(),
+                "note": "wall_s = prover only (witnesses pre-generated); the synthetic generator is host code (about 0.2 s per 2^20 x 64 chunk)"})
     return res
 
 
@@ -452,8 +500,11 @@ def cpu_stark_baseline(logn, air_name="chunk64"):
     tm = {}
     t0 = time.perf_counter()
     PR.prove(air, tr, pub, PR.StarkParams(logn, 1, 3, 5, 32), be, timings=tm)
-    return {"wall_s": time.perf_counter() - t0, "cores": O.num_threads(), "kind": "port",
-            "sample": "same STARK at 2^%d rows on the CPU restatement (oracle/stark_cpu.py)" % logn,
+    wall = time.perf_counter() - t0
+    return {"wall_s": wall, "cores": O.num_threads(), "kind": "port",
+            "sample": "same STARK (same AIR, 32 queries) at 2^%d rows on the CPU restatement (oracle/stark_cpu.py); the GPU line is at 2^20" % logn,
+            "extrapolated_2^20_wall_s": wall * (1 << (20 - logn)) if logn < 20 else wall,
+            "extrapolation": "linear in the row count (every stage is O(N) or O(N log N)): a lower bound for the CPU at 2^20",
             "stages_ms": {k: round(v * 1e3, 1) for k, v in tm.items()}}
 
 

@@ -934,3 +934,102 @@ extern "C" int32_t zp_msm_bn254_g2(zp_ctx *ctx, const uint32_t *d_points, const 
     ZpStage stage_(ctx, "msm_bn254_g2");
     return msm_run<fq2>(ctx, d_points, d_scalars, n, h_out);
 }
+
+// ---- synthetic MSM inputs: n DISTINCT points P_i = (start + i) * G of BN254 G1 (host code, this file's own field
+// arithmetic).  Like zp_synth_trace it stands in for data the offline build cannot obtain (a real proving key); distinct
+// points make an MSM benchmark read 64 B per point from HBM instead of hitting a small table in cache, and the known
+// discrete logs give a checkable answer: sum_i s_i P_i = (sum_i s_i (start + i) mod r) * G.
+// Affine chord additions P_base + j*G against a table of 1024 multiples, one batched inversion per block.
+namespace {
+struct affp { fq x, y; };
+affp aff_add_host(const affp &p, const affp &q) {   // p != -q
+    fq num, den;
+    if (fq_eq(p.x, q.x)) {
+        const fq t = fq_sqr(p.x);
+        num = fq_add(fq_add(t, t), t);
+        den = fq_add(p.y, p.y);
+    } else {
+        num = fq_sub(q.y, p.y);
+        den = fq_sub(q.x, p.x);
+    }
+    const fq lam = fq_mul(num, fq_inv_host(den));
+    affp r;
+    r.x = fq_sub(fq_sub(fq_sqr(lam), p.x), q.x);
+    r.y = fq_sub(fq_mul(lam, fq_sub(p.x, r.x)), p.y);
+    return r;
+}
+affp aff_mul_g_host(const affp &g, u64 k) {   // k >= 1
+    affp acc = g, base = g;
+    bool started = false;
+    for (int i = 0; i < 64 && (k >> i); i++) {
+        if ((k >> i) & 1) {
+            acc = started ? aff_add_host(acc, base) : base;
+            started = true;
+        }
+        base = aff_add_host(base, base);
+    }
+    return acc;
+}
+void aff_store(uint32_t *out, const affp &p) {
+    fq_to_words(fq_from_mont(p.x), out);
+    fq_to_words(fq_from_mont(p.y), out + 8);
+}
+}  // namespace
+
+#include <thread>
+extern "C" int32_t zp_synth_g1_points(uint64_t start, size_t n, uint32_t *h_points, int32_t threads) {
+    constexpr int BLK = 1024;
+    if (!h_points || start <= (uint64_t)BLK || start + n < start) return ZP_ERR_ARG;
+    if (n == 0) return ZP_OK;
+    affp g;
+    {
+        fq one = fq_zero(), two = fq_zero();
+        one.l[0] = 1;
+        two.l[0] = 2;
+        g.x = fq_to_mont(one);
+        g.y = fq_to_mont(two);
+    }
+    std::vector<affp> tab(BLK + 1);   // tab[j] = j*G
+    tab[1] = g;
+    for (int j = 2; j <= BLK; j++) tab[j] = aff_add_host(tab[j - 1], g);
+    const size_t nblk = (n + BLK - 1) / BLK;
+    int T = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (T < 1) T = 1;
+    if ((size_t)T > nblk) T = (int)nblk;
+    auto work = [&](size_t b0, size_t b1) {
+        std::vector<fq> den(BLK), pre(BLK);
+        affp base = aff_mul_g_host(g, start + b0 * BLK);
+        for (size_t b = b0; b < b1; b++) {
+            const size_t cnt = (b + 1) * BLK <= n ? BLK : n - b * BLK;
+            uint32_t *o = h_points + b * BLK * 16;
+            aff_store(o, base);
+            fq acc = fq_one();
+            for (int j = 1; j <= BLK; j++) {
+                den[j - 1] = fq_sub(tab[j].x, base.x);
+                pre[j - 1] = acc;
+                acc = fq_mul(acc, den[j - 1]);
+            }
+            fq inv = fq_inv_host(acc);
+            affp next = base;
+            for (int j = BLK; j >= 1; j--) {
+                const fq dinv = fq_mul(inv, pre[j - 1]);
+                inv = fq_mul(inv, den[j - 1]);
+                if ((size_t)j >= cnt && j != BLK) continue;
+                const fq lam = fq_mul(fq_sub(tab[j].y, base.y), dinv);
+                affp r;
+                r.x = fq_sub(fq_sub(fq_sqr(lam), base.x), tab[j].x);
+                r.y = fq_sub(fq_mul(lam, fq_sub(base.x, r.x)), base.y);
+                if (j == BLK) next = r;
+                if ((size_t)j < cnt) aff_store(o + (size_t)j * 16, r);
+            }
+            base = next;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; t++) {
+        const size_t b0 = nblk * t / T, b1 = nblk * (t + 1) / T;
+        if (b0 < b1) pool.emplace_back(work, b0, b1);
+    }
+    for (auto &th : pool) th.join();
+    return ZP_OK;
+}

@@ -191,7 +191,7 @@ __device__ __forceinline__ void exchange2(u64 *v, u64 *lds, const u64 *twr, int 
 //    h^(k_j) = (h^jr)^i * (h^-(2^A))^floor(jr*i/2^A).
 // MODE (non-transposing passes): 0 = plain last pass, 1 = multiply by the per-tile table,
 // 2 = table and the per-lane part of a coset power (last pass of the inverse transform in an LDE)
-template <int A1, int A2, int A3, int LOGT, bool TRANSPOSE, bool PADDED, int MODE>
+template <int A1, int A2, int A3, int LOGT, bool TRANSPOSE, bool PADDED, int MODE, bool BIG = false>
 __global__ void __launch_bounds__((1 << (A1 + A2 + A3 + LOGT)) / 16, 4)   // 4 waves per SIMD: 128 VGPRs, of which v116..v127 are the scratch window of gl_asm.hpp
 ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     using G = Geo<A1, A2, A3, LOGT>;
@@ -216,18 +216,32 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     constexpr int NTW = TRANSPOSE ? (GRJ + 2) : (MODE == 2 ? TPL + 1 : TPL);
     u64 twl_c[NTW], twh_c[NTW], twl_n[NTW], twh_n[NTW];
 
+    // Addressing: row j of a lane's 16 loads is  (uniform: column base + (j << POS1) rows + u0)  +  (lane: slot0 rows + t).
+    // With the lane part as a 32-bit BYTE offset the loads take the scalar-base form (global_load v, voff, s[base]) and the
+    // 64-bit address arithmetic -- three VALU instructions per load when written naively -- is scalar work.  The byte
+    // offset fits 32 bits up to 2^28 rows; larger transforms are the BIG instantiation with 64-bit lane offsets.
+    constexpr bool small_n = !BIG;
     auto fetch_tile = [&](u64 *r, u64 *tl, u64 *th, u64 u0, int tid) {
         constexpr int GR = 16 >> A1;
+        const u64 valid_rows = a.in_valid >> logNR;     // PADDED: rows >= valid_rows read as zero (in_valid is a multiple of N/R)
 #pragma unroll
         for (int g = 0; g < GR; g++) {
             const int gamma = g * NT + tid;
             const int t = gamma & (T - 1), o = gamma >> LOGT;
+            const u32 slot0 = (u32)slot_of(o, 0, G::POS1, A1);
+            const u32 lane_bytes = (((u32)slot0 << logNR) + (u32)t) << 3;
+            const u64 lane_el = ((u64)slot0 << logNR) + (u64)t;
 #pragma unroll
             for (int j = 0; j < (1 << A1); j++) {
-                const u64 idx = ((u64)slot_of(o, j, G::POS1, A1) << logNR) + u0 + t;
+                const u64 *rowp = src + (((u64)j << G::POS1) << logNR) + u0;      // wave-uniform
+                const u64 *ptr;
+                if constexpr (small_n) ptr = (const u64 *)((const char *)rowp + lane_bytes);
+                else ptr = rowp + lane_el;
                 // short runs (T < 16) want the L2 to merge neighbouring tiles' pieces of a line: plain, cacheable loads
-                if constexpr (PADDED) r[g * (1 << A1) + j] = idx < a.in_valid ? (LOGT < 4 ? src[idx] : ZP_LDG(&src[idx])) : 0ULL;
-                else r[g * (1 << A1) + j] = LOGT < 4 ? src[idx] : ZP_LDG(&src[idx]);
+                u64 val;
+                if constexpr (PADDED) val = (u64)(slot0 + ((u32)j << G::POS1)) < valid_rows ? (LOGT < 4 ? *ptr : ZP_LDG(ptr)) : 0ULL;
+                else val = LOGT < 4 ? *ptr : ZP_LDG(ptr);
+                r[g * (1 << A1) + j] = val;
             }
         }
         const u64 lm = (1ULL << a.lb) - 1;
@@ -347,8 +361,10 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
                     lds[G::lpos(slot_of(o, kj, 0, AJ), t)] = x;
                 }
             } else {
-                const u64 c = (u0 + t) & ((1ULL << logP) - 1);
-                const u64 obase = (s << (logP + L)) + c;
+                // store address = (uniform: s-block + the tile's first column + k-step)  +  (lane: klow rows + t), as for the loads
+                u64 *const sbase = dst + (s << (logP + L)) + (u0 & ((1ULL << logP) - 1));
+                const u32 lane_sb = (((u32)klow << logP) + (u32)t) << 3;
+                const u64 lane_se = ((u64)klow << logP) + (u64)t;
                 u64 cw = 1;
                 if constexpr (MODE == 2) cw = gl_mul(twl_c[TPL], twh_c[TPL]);  // shift^c, c < Pprev
 #pragma unroll
@@ -358,12 +374,16 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
                     u64 xa = v[g * (1 << AJ) + p], xb = v[g * (1 << AJ) + p + 1];
                     if constexpr (MODE >= 1) gl_mul2(xa, tab[ka], xb, tab[kb]);
                     if constexpr (MODE == 2) gl_mul2(xa, cw, xb, cw);
+                    u64 *const ua = sbase + ((u64)(kja << (L - AJ)) << logP), *const ub = sbase + ((u64)(kjb << (L - AJ)) << logP);   // uniform
+                    u64 *pa, *pb;
+                    if constexpr (small_n) { pa = (u64 *)((char *)ua + lane_sb); pb = (u64 *)((char *)ub + lane_sb); }
+                    else { pa = ua + lane_se; pb = ub + lane_se; }
                     if constexpr (LOGT < 4) {
-                        dst[obase + ((u64)ka << logP)] = xa;
-                        dst[obase + ((u64)kb << logP)] = xb;
+                        *pa = xa;
+                        *pb = xb;
                     } else {
-                        ZP_STG(&dst[obase + ((u64)ka << logP)], xa);
-                        ZP_STG(&dst[obase + ((u64)kb << logP)], xb);
+                        ZP_STG(pa, xa);
+                        ZP_STG(pb, xb);
                     }
                 }
             }
@@ -448,7 +468,7 @@ __global__ void __launch_bounds__(256) twiddle_rows_kernel(u64 *rows, int logn_r
     rows[i] = gl_mul(rows[i], tw_lookup(lo, hi, lb, e));
 }
 
-template <int A1, int A2, int A3, int LOGT>
+template <int A1, int A2, int A3, int LOGT, bool BIG = false>
 int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
     using G = Geo<A1, A2, A3, LOGT>;
     const u64 tiles = (1ULL << (a.logn - G::L)) >> LOGT;
@@ -462,13 +482,13 @@ int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
     const size_t shmem = ((size_t)G::R * G::T + (has_tab ? G::R : 0) + (G::L <= 10 ? G::R + (1 << (A2 + A3)) : 0)) * sizeof(u64);
     if (transpose) {
         const bool padded = a.in_valid != (1ULL << a.logn);
-        auto k = padded ? ntt_pass2_kernel<A1, A2, A3, LOGT, true, true, 1> : ntt_pass2_kernel<A1, A2, A3, LOGT, true, false, 1>;
+        auto k = padded ? ntt_pass2_kernel<A1, A2, A3, LOGT, true, true, 1, BIG> : ntt_pass2_kernel<A1, A2, A3, LOGT, true, false, 1, BIG>;
         if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a, tpw);
     } else {
-        auto k = (a.flags & 4) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 2>
-                 : (a.flags & 3) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 1>
-                                 : ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 0>;
+        auto k = (a.flags & 4) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 2, BIG>
+                 : (a.flags & 3) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 1, BIG>
+                                 : ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 0, BIG>;
         if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a, tpw);
     }
@@ -477,6 +497,13 @@ int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
 }
 
 int32_t dispatch_pass(zp_ctx *ctx, const NttPass &p, const PassArgs &a, bool transpose, int W) {
+    if (a.logn > 28) {   // 64-bit lane offsets: only the shapes the default plan uses above 2^28 rows (digits 7 and 8)
+        switch (p.L) {
+            case 7: return launch_pass2<4, 3, 0, 5, true>(ctx, a, transpose, W);
+            case 8: return launch_pass2<4, 4, 0, 4, true>(ctx, a, transpose, W);
+            default: ctx->err = "pass radix not built for transforms above 2^28 rows"; return ZP_ERR_UNSUPPORTED;
+        }
+    }
     switch (p.L) {
         case 5: return launch_pass2<3, 2, 0, 5>(ctx, a, transpose, W);
         case 6: return launch_pass2<3, 3, 0, 5>(ctx, a, transpose, W);
@@ -792,26 +819,21 @@ int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn,
     if (wc < 1) wc = 1;
     if (wc > W) wc = W;
     u64 *scaled = nullptr;
-    ZP_TRY(zpi_scratch(ctx, 2, (size_t)wc << logn, &scaled));
+    if (!d_coef) ZP_TRY(zpi_scratch(ctx, 2, (size_t)wc << logn, &scaled));
     for (int c0 = 0; c0 < W; c0 += wc) {
         const int w = (W - c0 < wc) ? (W - c0) : wc;
         const u64 *in = d_in + (u64)c0 * N;
         u64 *out = d_out + ((u64)c0 << (logn + logb));
         NttRunOpts inv;
-        if (d_coef) {
-            u64 *coef = d_coef + (u64)c0 * N;
-            ZP_TRY(zpi_ntt_run(ctx, in, coef, logn, w, true, inv));
-            dim3 grid((unsigned)((N + 255) / 256), (unsigned)w);
-            hipLaunchKernelGGL(coset_scale_kernel, grid, dim3(256), 0, ctx->stream, coef, scaled, N, ct->d_lo,
-                               ct->d_hi, ct->lb);
-            ZP_HIP(ctx, hipGetLastError());
-        } else {
-            inv.post_scale = ct;  // the inverse transform's last pass multiplies c_i by shift^i
-            ZP_TRY(zpi_ntt_run(ctx, in, scaled, logn, w, true, inv));
-        }
+        inv.post_scale = ct;  // the inverse transform's last pass multiplies c_i by shift^i
+        // d_coef (optional) IS the scaled-coefficient buffer: the interpolant composed with the coset shift, c_i * shift^i.
+        // Nothing downstream needs the plain c_i: p(z) = sum_i (c_i shift^i) (z / shift)^i  (stark/prover.py evaluates there),
+        // so the separate copy + scaling pass of round 1 (32*N bytes per column) is gone.
+        u64 *sc = d_coef ? d_coef + (u64)c0 * N : scaled;
+        ZP_TRY(zpi_ntt_run(ctx, in, sc, logn, w, true, inv));
         NttRunOpts fwd;
         fwd.in_valid_log = logn;  // zero padding is implicit: rows >= N read as 0
-        ZP_TRY(zpi_ntt_run(ctx, scaled, out, logn + logb, w, false, fwd));
+        ZP_TRY(zpi_ntt_run(ctx, sc, out, logn + logb, w, false, fwd));
     }
     return ZP_OK;
 }
@@ -824,5 +846,43 @@ int32_t zpi_twiddle_rows(zp_ctx *ctx, u64 *d_rows, int logn_row, int W, u64 row0
     hipLaunchKernelGGL(twiddle_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_rows, logn_row,
                        total, row0, nmask, pl->d_twl, pl->d_twh, pl->lb);
     ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}
+
+// ---- measurement: what this device sustains on a plain copy, with this library's own kernel (16 bytes per lane,
+// non-temporal, 2048 workgroups each keeping four loads in flight) -- the ceiling bench.py prints next to the vendor peak
+typedef __attribute__((ext_vector_type(4))) unsigned int zp_u32x4;
+__global__ void __launch_bounds__(256) hbm_copy_kernel(const zp_u32x4 *__restrict__ in, zp_u32x4 *__restrict__ out, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const zp_u32x4 a = __builtin_nontemporal_load(in + i), b = __builtin_nontemporal_load(in + i + stride);
+        const zp_u32x4 c = __builtin_nontemporal_load(in + i + 2 * stride), d = __builtin_nontemporal_load(in + i + 3 * stride);
+        __builtin_nontemporal_store(a, out + i);
+        __builtin_nontemporal_store(b, out + i + stride);
+        __builtin_nontemporal_store(c, out + i + 2 * stride);
+        __builtin_nontemporal_store(d, out + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
+
+extern "C" int32_t zp_hbm_copy_probe(zp_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int32_t reps, float *ms_per_copy) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
+    ZP_ARG(ctx, d_src && d_dst && ms_per_copy && reps >= 1 && (bytes & 15) == 0 && bytes >= 16, "bad arguments");
+    hipEvent_t e0, e1;
+    ZP_HIP(ctx, hipEventCreate(&e0));
+    ZP_HIP(ctx, hipEventCreate(&e1));
+    hipLaunchKernelGGL(hbm_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const zp_u32x4 *)d_src, (zp_u32x4 *)d_dst, bytes / 16);
+    ZP_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; r++)
+        hipLaunchKernelGGL(hbm_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const zp_u32x4 *)d_src, (zp_u32x4 *)d_dst, bytes / 16);
+    ZP_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    ZP_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    ZP_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_copy = ms / reps;
     return ZP_OK;
 }

@@ -56,6 +56,8 @@ SIGNATURES = {
     "zp_lde": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_poseidon_perm": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "zp_pow_grind": (C.c_int32, [_vp, _vp, C.c_int32, _vp]),
+    "zp_synth_g1_points": (C.c_int32, [C.c_uint64, C.c_size_t, _vp, C.c_int32]),
+    "zp_hbm_copy_probe": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_int32, C.POINTER(C.c_float)]),
     "zp_eval_quotient": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_uint64,
                                      C.c_uint64, _vp]),
     "zp_merkle_commit": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp]),
@@ -84,6 +86,15 @@ SIGNATURES = {
     "zp_ntt_plan_json": (C.c_int32, [_vp, C.c_int32, C.c_char_p, C.c_size_t]),
     "zp_device_info_json": (C.c_int32, [_vp, C.c_char_p, C.c_size_t]),
 }
+
+
+def synth_g1_points(n, start=1025, threads=0):
+    """uint32 [n][16]: n distinct BN254 G1 points (start + i) * G in the zp_msm_bn254 layout (host generator of the library)"""
+    out = np.empty((n, 16), dtype=np.uint32)
+    rc = load_library().zp_synth_g1_points(start, n, out.ctypes.data, threads)
+    if rc != 0:
+        raise ValueError("zp_synth_g1_points: bad arguments (start must exceed 1024)")
+    return out
 
 
 def synth_trace(kind, logn, W, seed, out=None):
@@ -302,6 +313,12 @@ class Prover:
         zh = np.ascontiguousarray(np.asarray(zhinv, dtype=np.uint64))
         self._chk(self.lib.zp_eval_quotient(self.ctx, prog.ctypes.data, prog.size, _ptr(d_cols), _ptr(d_fixed), logm, logb, pb.ctypes.data,
                                             len(pubs), ap.ctypes.data, zh.ctypes.data, shift, w_last, _ptr(d_out)))
+
+    def hbm_copy_probe(self, d_src, d_dst, nbytes, reps=5):
+        """average ms of one device copy of nbytes with the library's own 16 B/lane kernel"""
+        ms = C.c_float(0)
+        self._chk(self.lib.zp_hbm_copy_probe(self.ctx, _ptr(d_src), _ptr(d_dst), nbytes, reps, C.byref(ms)))
+        return float(ms.value)
 
     def pow_grind(self, seed4, bits):
         sd = (C.c_uint64 * 4)(*[int(v) for v in seed4])

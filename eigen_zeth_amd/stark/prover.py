@@ -115,9 +115,11 @@ def prove(air, trace, pubs, params, be, timings=None):
     # 3. out-of-domain evaluations
     t0 = time.perf_counter()
     zeta_w = F.e3_scale(zeta, wN)
-    ev_z = be.eval_ext(c1.coef, logn, Wt, zeta)
-    ev_zw = be.eval_ext(c1.coef, logn, Wt, zeta_w)
-    ev_q = be.eval_ext(d_qcoef, logm, 3, F.e3_scale(zeta, F.inv(shift)))
+    # every coefficient buffer holds c_i * shift^i (what the LDE has in hand): p(z) = sum_i (c_i shift^i) (z / shift)^i
+    sinv = F.inv(shift)
+    ev_z = be.eval_ext(c1.coef, logn, Wt, F.e3_scale(zeta, sinv))
+    ev_zw = be.eval_ext(c1.coef, logn, Wt, F.e3_scale(zeta_w, sinv))
+    ev_q = be.eval_ext(d_qcoef, logm, 3, F.e3_scale(zeta, sinv))
     tick("ood-evals", t0)
     ev_all = [_ints(r) for r in ev_z] + [_ints(r) for r in ev_q]
     ev_next = [_ints(r) for r in ev_zw]

@@ -88,8 +88,10 @@ int32_t zp_twiddle_rows(zp_ctx *ctx, uint64_t *d_rows, int32_t logn_row, int32_t
 
 /* ---- N2: low-degree extension ----------------------------------------------------------------
  * d_in u64[W][2^logn] evaluations on <w_N>; d_out u64[W][2^(logn+logb)] evaluations on
- * shift*<w_bN>, natural order.  If d_coef != NULL it receives the interpolant's coefficients
- * u64[W][2^logn] (ascending).  shift == 0 selects the ctx default (ZP_CONST_COSET_SHIFT).       */
+ * shift*<w_bN>, natural order.  If d_coef != NULL it receives u64[W][2^logn], the coefficients of the
+ * interpolant composed with the coset shift: d_coef[c][i] = c_i * shift^i (ascending), i.e. p_c(z) = sum_i d_coef[c][i]
+ * (z/shift)^i -- zp_poly_eval_ext at z/shift gives p_c(z); the transform already has this vector in hand, the plain c_i
+ * would cost one more pass over the data.  shift == 0 selects the ctx default (ZP_CONST_COSET_SHIFT).              */
 int32_t zp_lde(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t *d_coef, int32_t logn,
                int32_t logb, int32_t W, uint64_t shift);
 
@@ -181,6 +183,11 @@ int32_t zp_eval_quotient(zp_ctx *ctx, const uint64_t *h_program, size_t program_
  * public inputs (3 / min(4,W) / 1 / 8).                 */
 int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uint64_t *h_trace, uint64_t *h_pub);
 
+/* synthetic MSM input (stands in for a proving key, which the offline build cannot obtain): n DISTINCT points
+ * P_i = (start + i) * G of BN254 G1 in the zp_msm_bn254 layout, generated on the host with `threads` threads (0 = all);
+ * start must exceed 1024.  Known discrete logs: sum_i s_i P_i = (sum_i s_i (start + i) mod r) * G.            */
+int32_t zp_synth_g1_points(uint64_t start, size_t n, uint32_t *h_points, int32_t threads);
+
 /* ---- N6: BN254 (alt_bn128) G1 multi-scalar multiplication ---------------------------------------
  * d_points u32[n][16]: affine x (8 little-endian 32-bit limbs) then y, standard (non-Montgomery)
  * integers < q; (0,0) encodes the point at infinity.  d_scalars u32[n][8] little-endian, any 256-bit
@@ -210,8 +217,11 @@ int32_t zp_get_pass_timings(zp_ctx *ctx, float *ms, int32_t *radix_log, int32_t 
  * (device time between HIP events on the ctx stream; profiling must be on).                          */
 int32_t zp_stage_timings(zp_ctx *ctx, char *buf, size_t buflen);
 
+/* device-to-device copy of `bytes` (multiple of 16) with the library's own 16-byte-per-lane non-temporal kernel, `reps`
+ * times after one warm-up; *ms_per_copy = average duration (HIP events).  The HBM ceiling bench.py reports.      */
+int32_t zp_hbm_copy_probe(zp_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int32_t reps, float *ms_per_copy);
 /* experiment knobs for kernel tuning sweeps (keys: "ntt_logt" 4|5 tile of the radix-256 pass, "ntt_logt9" 4|5, "ntt_tpw" tiles per workgroup,
- * "ntt_chunk_log" log2 of the elements per NTT launch (28), "merkle_coop_log" largest tree level given to the 12-lanes-per-node
+ * "ntt_chunk_log" log2 of the elements per NTT launch (27), "ntt_maxl" largest log2 radix of a pass (9; 10..12 select the 1024-thread two-pass plans), "merkle_coop_log" largest tree level given to the 12-lanes-per-node
  * kernel (15), "msm_chunk_log" log2 of the points per Pippenger run (24), "msm_c" window width; 0 = default); not for production hosts */
 int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value);
 

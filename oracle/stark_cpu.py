@@ -35,10 +35,21 @@ class CpuBackend:
         tree = O.merkle_commit(e1, self.rc, self.mds)
         ext = np.zeros((W + extra_cols, e1.shape[1]), dtype=np.uint64)
         coef = np.zeros((W + extra_cols, trace.shape[1]), dtype=np.uint64)
-        ext[:W], coef[:W] = e1, O.intt(trace, self.root32)
+        ext[:W], coef[:W] = e1, self._scaled_coef(trace)
         c = Commit([int(v) for v in tree[-1]], tree, ext, coef)
         c.trace, c.W = trace, W
         return c
+
+    def _scaled_coef(self, cols):
+        """coefficients of p(shift * X): c_i * shift^i -- the vector the orchestration evaluates at z / shift"""
+        c = O.intt(cols, self.root32)
+        n = c.shape[1]
+        pw = np.empty(n, dtype=object)
+        acc = 1
+        for i in range(n):
+            pw[i] = acc
+            acc = acc * self.shift % O.P
+        return ((c.astype(object) * pw[None, :]) % O.P).astype(np.uint64)
 
     def column_view(self, mat, col, rows):
         return np.asarray(mat).reshape(-1, rows)[col:]
@@ -53,7 +64,7 @@ class CpuBackend:
                 parts.append(O.logup_columns(c1.trace[st["a"]], c1.trace[st["t"]], c1.trace[st["m"]], chal))
         z = np.ascontiguousarray(np.concatenate(parts, axis=0))
         c1.ext[W:] = O.lde(z, logb, self.shift, self.root32)
-        c1.coef[W:] = O.intt(z, self.root32)
+        c1.coef[W:] = self._scaled_coef(z)
         tree = O.merkle_commit(np.ascontiguousarray(c1.ext[W:]), self.rc, self.mds)
         return Commit([int(v) for v in tree[-1]], tree)
 

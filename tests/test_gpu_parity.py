@@ -124,10 +124,11 @@ def test_lde_matches_oracle(prover, logn, logb, W):
     d_coef = prover.alloc(W << logn)
     prover.lde(d_in, d_out, logn, logb, W)
     assert (prover.download(d_out, ref.shape) == ref).all()
-    # with coefficients requested: same extension, coefficients = iNTT
+    # with coefficients requested: same extension, d_coef = coefficients of p(shift * X) = iNTT(x)_i * shift^i
     prover.lde(d_in, d_out, logn, logb, W, d_coef=d_coef)
     assert (prover.download(d_out, ref.shape) == ref).all()
-    assert (prover.download(d_coef, x.shape) == O.intt(x)).all()
+    pw = np.array([pow(49, i, P) for i in range(1 << logn)], dtype=object)
+    assert (prover.download(d_coef, x.shape).astype(object) == (O.intt(x).astype(object) * pw[None, :]) % P).all()
     assert (prover.download(d_in, x.shape) == x).all()
 
 
