@@ -337,6 +337,7 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
     from eigen_zeth_amd import multigpu
     N = 1 << logn
     M = 2 * N
+    multigpu.use_device_layout(prover)     # pack / transpose through zp_pack_blocks / zp_transpose on the ctx stream
     x = random_field_tensor(torch, (cols, N), dev, 99)
     y = torch.empty((cols, M), dtype=torch.int64, device=dev)
     Wtot, Mloc = cols * world, M // world

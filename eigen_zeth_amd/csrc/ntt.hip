@@ -886,3 +886,62 @@ extern "C" int32_t zp_hbm_copy_probe(zp_ctx *ctx, const void *d_src, void *d_dst
     *ms_per_copy = ms / reps;
     return ZP_OK;
 }
+
+// ---- layout kernels of the multi-GPU paths: the send-buffer packing of the column->row all-to-all and the
+// local transposes of the four-step NTT.  (Round 1 did these with generic tensor copies: 21 G elements/s for a four-step
+// transform on one GPU against 75 G for the plain one.)
+// out[h][w][j] = in[w][h*Mg + j]:  [Wl][G*Mg] -> [G][Wl][Mg]; runs of Mg contiguous elements, 16 bytes per lane
+__global__ void __launch_bounds__(256) pack_blocks_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 Wl, u64 G, u64 Mg) {
+    const u64 total2 = Wl * G * Mg / 2;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total2; i += (u64)gridDim.x * 256) {
+        const u64 e = 2 * i, j = e % Mg, w = (e / Mg) % Wl, h = e / (Mg * Wl);
+        const u64 *src = in + w * (G * Mg) + h * Mg + j;
+        u64 *dst = out + e;
+        dst[0] = ZP_LDG(src);
+        dst[1] = ZP_LDG(src + 1);
+    }
+}
+// out[c][r] = in[r][c], 64 x 64 tiles through LDS (row length 65: the column reads of the write phase hit 64 banks)
+__global__ void __launch_bounds__(256) transpose_u64_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 R, u64 C) {
+    __shared__ u64 tile[64][65];
+    const u64 tiles_c = (C + 63) / 64;
+    const u64 r0 = (blockIdx.x / tiles_c) * 64, c0 = (blockIdx.x % tiles_c) * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const u64 r = r0 + i * 4 + w, c = c0 + lane;
+        if (r < R && c < C) tile[i * 4 + w][lane] = ZP_LDG(&in[r * C + c]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const u64 c = c0 + i * 4 + w, r = r0 + lane;
+        if (r < R && c < C) ZP_STG(&out[c * R + r], tile[lane][i * 4 + w]);
+    }
+}
+
+extern "C" int32_t zp_pack_blocks(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t rows, size_t row_len, int32_t parts) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "pack_blocks");
+    ZP_ARG(ctx, d_in && d_out && d_in != d_out && parts >= 1 && row_len % (size_t)parts == 0, "bad arguments");
+    const size_t Mg = row_len / parts;
+    ZP_ARG(ctx, Mg % 2 == 0 || rows * row_len == 0, "part length must be even");
+    if (rows * row_len == 0) return ZP_OK;
+    const size_t total2 = rows * row_len / 2;
+    const unsigned blocks = (unsigned)(total2 / 256 + 1 < 8192 ? total2 / 256 + 1 : 8192);
+    hipLaunchKernelGGL(pack_blocks_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const u64 *)d_in, (u64 *)d_out, (u64)rows, (u64)parts, (u64)Mg);
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}
+
+extern "C" int32_t zp_transpose(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t rows, size_t cols) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "transpose");
+    ZP_ARG(ctx, d_in && d_out && d_in != d_out, "bad arguments");
+    if (rows * cols == 0) return ZP_OK;
+    const size_t tiles = ((rows + 63) / 64) * ((cols + 63) / 64);
+    ZP_ARG(ctx, tiles < (1ULL << 31), "matrix too large for one launch");
+    hipLaunchKernelGGL(transpose_u64_kernel, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (const u64 *)d_in, (u64 *)d_out, (u64)rows, (u64)cols);
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}

@@ -17,10 +17,39 @@ import torch
 import torch.distributed as dist
 
 
+_LAYOUT = {"prover": None}
+
+
+def use_device_layout(prover):
+    """route the packing / transposing copies of CUDA tensors through the library's HIP kernels (zp_pack_blocks,
+    zp_transpose) on `prover`'s stream instead of generic tensor copies; None switches back (CPU tensors always use torch)"""
+    _LAYOUT["prover"] = prover
+
+
+def _hip(t):
+    return _LAYOUT["prover"] if (t.is_cuda and _LAYOUT["prover"] is not None) else None
+
+
 def pack_for_exchange(local_cols, G):
     """[Wl][M] -> [G][Wl][M/G] contiguous (block h = the rows that go to rank h)"""
     Wl, M = local_cols.shape
+    p = _hip(local_cols)
+    if p is not None and (M // G) % 2 == 0:
+        out = torch.empty((G, Wl, M // G), dtype=local_cols.dtype, device=local_cols.device)
+        p.pack_blocks(local_cols.contiguous(), out, Wl, M, G)
+        return out
     return local_cols.view(Wl, G, M // G).permute(1, 0, 2).contiguous()
+
+
+def transpose2d(mat):
+    """[R][C] -> [C][R] contiguous"""
+    p = _hip(mat)
+    if p is not None:
+        R, C = mat.shape
+        out = torch.empty((C, R), dtype=mat.dtype, device=mat.device)
+        p.transpose(mat.contiguous(), out, R, C)
+        return out
+    return mat.t().contiguous()
 
 
 def exchange_columns_to_rows(local_cols, group=None):
@@ -70,11 +99,11 @@ def distributed_transpose(local, group=None):
     G = dist.get_world_size(group) if dist.is_initialized() else 1
     Rl, C = local.shape
     if G == 1:
-        return local.t().contiguous()
-    send = local.view(Rl, G, C // G).permute(1, 0, 2).contiguous()        # block h = my rows, rank h's columns
+        return transpose2d(local)
+    send = pack_for_exchange(local, G)                                      # block h = my rows, rank h's columns
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)                         # recv[h] = rank h's rows, my columns
-    return recv.permute(2, 0, 1).reshape(C // G, G * Rl).contiguous()       # [my column][global row h*Rl + r]
+    return transpose2d(recv.view(G * Rl, C // G))                           # [my column][global row h*Rl + r]
 
 
 def four_step_ntt(local, logn, ntt_rows, twiddle_rows, group=None, inverse=False, natural_output=True):
@@ -101,7 +130,10 @@ def four_step_ntt(local, logn, ntt_rows, twiddle_rows, group=None, inverse=False
 
 def hip_row_ops(prover):
     """(ntt_rows, twiddle_rows) for four_step_ntt on torch CUDA tensors through the C-ABI (zp_ntt / zp_intt /
-    zp_twiddle_rows).  The prover's ctx must run on torch's current stream (Prover(dev, stream=...))."""
+    zp_twiddle_rows).  The prover's ctx must run on torch's current stream (Prover(dev, stream=...)).  Also routes the
+    packing / transposing copies of CUDA tensors through the library's layout kernels (use_device_layout)."""
+    use_device_layout(prover)
+
     def ntt_rows(mat, inverse):
         W, n = mat.shape
         out = torch.empty_like(mat)

@@ -56,6 +56,8 @@ SIGNATURES = {
     "zp_lde": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_poseidon_perm": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "zp_pow_grind": (C.c_int32, [_vp, _vp, C.c_int32, _vp]),
+    "zp_pack_blocks": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int32]),
+    "zp_transpose": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t]),
     "zp_synth_g1_points": (C.c_int32, [C.c_uint64, C.c_size_t, _vp, C.c_int32]),
     "zp_hbm_copy_probe": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_int32, C.POINTER(C.c_float)]),
     "zp_eval_quotient": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_uint64,
@@ -313,6 +315,12 @@ class Prover:
         zh = np.ascontiguousarray(np.asarray(zhinv, dtype=np.uint64))
         self._chk(self.lib.zp_eval_quotient(self.ctx, prog.ctypes.data, prog.size, _ptr(d_cols), _ptr(d_fixed), logm, logb, pb.ctypes.data,
                                             len(pubs), ap.ctypes.data, zh.ctypes.data, shift, w_last, _ptr(d_out)))
+
+    def pack_blocks(self, d_in, d_out, rows, row_len, parts):
+        self._chk(self.lib.zp_pack_blocks(self.ctx, _ptr(d_in), _ptr(d_out), rows, row_len, parts))
+
+    def transpose(self, d_in, d_out, rows, cols):
+        self._chk(self.lib.zp_transpose(self.ctx, _ptr(d_in), _ptr(d_out), rows, cols))
 
     def hbm_copy_probe(self, d_src, d_dst, nbytes, reps=5):
         """average ms of one device copy of nbytes with the library's own 16 B/lane kernel"""

@@ -86,6 +86,13 @@ int32_t zp_intt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn
 int32_t zp_twiddle_rows(zp_ctx *ctx, uint64_t *d_rows, int32_t logn_row, int32_t W, uint64_t row0, int32_t logn_total,
                         int32_t inverse);
 
+/* layout kernels of the multi-GPU paths (device buffers, out of place):
+ * zp_pack_blocks: u64[rows][row_len] -> u64[parts][rows][row_len/parts] (block h = columns [h*len/parts, (h+1)*len/parts) of
+ *   every row): the send buffer of the column-shard -> row-shard all-to-all, message h contiguous;
+ * zp_transpose:   u64[rows][cols] -> u64[cols][rows]: the local part of a distributed transpose (four-step NTT).        */
+int32_t zp_pack_blocks(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t rows, size_t row_len, int32_t parts);
+int32_t zp_transpose(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t rows, size_t cols);
+
 /* ---- N2: low-degree extension ----------------------------------------------------------------
  * d_in u64[W][2^logn] evaluations on <w_N>; d_out u64[W][2^(logn+logb)] evaluations on
  * shift*<w_bN>, natural order.  If d_coef != NULL it receives u64[W][2^logn], the coefficients of the

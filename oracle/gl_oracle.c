@@ -670,6 +670,18 @@ u64 orc_pow_grind(const u64 *seed4, int bits, const u64 *rc, const u64 *mds) {
     }
 }
 
+/* coefficients of p(shift * X): cols[c][i] *= shift^i  (what the LDE has between its two transforms) */
+void orc_coset_scale(u64 *cols, size_t n, int W, u64 shift) {
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < W; c++) {
+        u64 s = 1;
+        for (size_t i = 0; i < n; i++) {
+            cols[(size_t)c * n + i] = gl_mul(cols[(size_t)c * n + i], s);
+            s = gl_mul(s, shift);
+        }
+    }
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

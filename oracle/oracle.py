@@ -69,6 +69,7 @@ def lib():
         L.orc_bn254_consecutive_points.restype = i32
         L.orc_bn254_consecutive_points.argtypes = [C.c_void_p, sz, u64]
         L.orc_bn254_weighted_scalar_sum.argtypes = [C.c_void_p, sz, u64, C.c_void_p]
+        L.orc_coset_scale.argtypes = [_u64p, sz, i32, u64]
         L.orc_pow_grind.restype = u64
         L.orc_pow_grind.argtypes = [_u64p, i32, _u64p, _u64p]
         L.orc_fri_fold.argtypes = [_u64p, _u64p, i32, i32, _u64p, u64, u64]
@@ -229,6 +230,13 @@ def poly_eval_e3_cols(coef, x3):
     out = np.empty((W, 3), dtype=np.uint64)
     lib().orc_poly_eval_e3_cols(_p(c), n, W, _p(_arr(x3)), _p(out))
     return out
+
+
+def coset_scaled_coefficients(cols, shift=SHIFT_DEFAULT, root32=ROOT32_DEFAULT):
+    """coefficients of the interpolant composed with the coset shift: iNTT(cols)[i] * shift^i"""
+    a = intt(cols, root32)
+    lib().orc_coset_scale(_p(a), a.shape[1], a.shape[0], shift)
+    return a
 
 
 def pow_grind(seed4, bits, rc, mds):

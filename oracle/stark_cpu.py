@@ -42,14 +42,7 @@ class CpuBackend:
 
     def _scaled_coef(self, cols):
         """coefficients of p(shift * X): c_i * shift^i -- the vector the orchestration evaluates at z / shift"""
-        c = O.intt(cols, self.root32)
-        n = c.shape[1]
-        pw = np.empty(n, dtype=object)
-        acc = 1
-        for i in range(n):
-            pw[i] = acc
-            acc = acc * self.shift % O.P
-        return ((c.astype(object) * pw[None, :]) % O.P).astype(np.uint64)
+        return O.coset_scaled_coefficients(cols, self.shift, self.root32)
 
     def column_view(self, mat, col, rows):
         return np.asarray(mat).reshape(-1, rows)[col:]

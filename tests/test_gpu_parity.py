@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+from eigen_zeth_amd import native
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -462,3 +463,43 @@ def test_golden_ood_and_deep_through_cabi(prover, golden):
         prover.deep_quotient(d_a, W, d_a, 0, case["logm"], case["n_next"], case["z"], case["zw"], case["gamma"], case["ev_z"],
                              case["ev_zw"], case["shift"], d_o)
         assert prover.download(d_o, (3, M)).tolist() == case["out"], case["logm"]
+
+
+@pytest.mark.parametrize("R,C", [(1, 1), (64, 64), (3, 130), (257, 65), (1024, 4096), (4096, 512)])
+def test_transpose_kernel(prover, R, C):
+    x = O.random_field((R, C), 7000 + R)
+    d_in, d_out = prover.upload(x), prover.alloc(R * C)
+    prover.transpose(d_in, d_out, R, C)
+    assert (prover.download(d_out, (C, R)) == x.T).all()
+
+
+@pytest.mark.parametrize("rows,row_len,parts", [(1, 8, 1), (3, 24, 4), (8, 1 << 12, 8), (5, 96, 2)])
+def test_pack_blocks_kernel(prover, rows, row_len, parts):
+    x = O.random_field((rows, row_len), 7100 + rows)
+    d_in, d_out = prover.upload(x), prover.alloc(rows * row_len)
+    prover.pack_blocks(d_in, d_out, rows, row_len, parts)
+    want = x.reshape(rows, parts, row_len // parts).transpose(1, 0, 2)
+    assert (prover.download(d_out, want.shape) == want).all()
+    with pytest.raises(native.ZpError):
+        prover.pack_blocks(d_in, d_out, rows, row_len, 5 if row_len % 5 else 7)
+
+
+def test_four_step_ntt_through_layout_kernels_one_gpu(prover):
+    """G = 1: three zp_transpose + two batched zp_ntt + zp_twiddle_rows == zp_ntt of the whole column"""
+    import torch
+    from eigen_zeth_amd import multigpu
+    from eigen_zeth_amd.native import Prover
+    logn = 20
+    p2 = Prover(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        x = torch.from_numpy(O.random_field((1 << logn,), 7200).view(np.int64)).cuda()
+        got = multigpu.four_step_ntt(x, logn, *multigpu.hip_row_ops(p2))
+        ref = torch.empty_like(x)
+        p2.ntt(x, ref, logn, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+        back = multigpu.four_step_ntt(got, logn, *multigpu.hip_row_ops(p2), inverse=True)
+        assert torch.equal(back, x)
+    finally:
+        multigpu.use_device_layout(None)
+        p2.close()

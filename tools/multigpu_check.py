@@ -28,6 +28,7 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl", device_id=dev)
     prover = Prover(local, stream=torch.cuda.current_stream().cuda_stream)
+    multigpu.use_device_layout(prover)
     logn, cols = int(os.environ.get("ZP_CHECK_LOGN", "16")), 4
     N, M = 1 << logn, 2 << logn
     res, ok = {"world": world, "logn": logn}, True
