@@ -64,14 +64,14 @@ struct DeepArgs {
     const u64 *twl, *twh;  // w_M^e
     u64 ca[3], cb[3];    // sum g^k e_k ,  sum g^(W+k) e'_k
     u64 z[3], zw[3];
-    u64 shift;
+    u64 shift;               // shift * w_M^row0 for a row window
+    u64 nrows, sa, sb, so;   // rows of this launch; column strides of cols_a, cols_b, out
     int logm, Wa, Wb, nnext, lb;
 };
 
 __global__ void __launch_bounds__(256) deep_quotient_kernel(DeepArgs a) {
-    const u64 M = 1ULL << a.logm;
     const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (r >= M) return;
+    if (r >= a.nrows) return;
     // A = sum g^k p_k(x) as three unreduced 160-bit dot products; the second sum runs over the same columns with
     // the powers shifted by W, so it is g^W times the prefix of A over the first nnext columns.
     gl_acc s0 = gl_acc_zero(), s1 = gl_acc_zero(), s2 = gl_acc_zero();
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) deep_quotient_kernel(DeepArgs a) {
     const int W = a.Wa + a.Wb;
     for (int k = 0; k < W; k++) {
         if (k == a.nnext && k > 0) B = e3_make(gl_acc_reduce(s0), gl_acc_reduce(s1), gl_acc_reduce(s2));
-        const u64 v = k < a.Wa ? a.cols_a[(u64)k * M + r] : a.cols_b[(u64)(k - a.Wa) * M + r];
+        const u64 v = k < a.Wa ? a.cols_a[(u64)k * a.sa + r] : a.cols_b[(u64)(k - a.Wa) * a.sb + r];
         const u64 *g = a.gpow + k * 3;
         gl_acc_mac(s0, v, g[0]);
         gl_acc_mac(s1, v, g[1]);
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) deep_quotient_kernel(DeepArgs a) {
         F = e3_mul(A, e3_inv(d1));
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++) a.out[(u64)c * M + r] = F.c[c];
+    for (int c = 0; c < 3; c++) a.out[(u64)c * a.so + r] = F.c[c];
 }
 
 __global__ void __launch_bounds__(256) gather_rows_kernel(const u64 *cols, u64 M, int W, const u64 *idx, int nq, u64 *out) {
@@ -175,10 +175,10 @@ int32_t zp_poly_eval_ext(zp_ctx *ctx, const uint64_t *d_coef, int32_t logn, int3
     return ZP_OK;
 }
 
-int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, const uint64_t *d_cols_b, int32_t Wb,
-                         int32_t logm, int32_t n_next, const uint64_t z[3], const uint64_t zw[3],
-                         const uint64_t gamma[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t shift,
-                         uint64_t *d_out) {
+int32_t zp_deep_quotient_rows(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, size_t stride_a, const uint64_t *d_cols_b, int32_t Wb,
+                              size_t stride_b, int32_t logm, size_t row0, size_t nrows, int32_t n_next, const uint64_t z[3],
+                              const uint64_t zw[3], const uint64_t gamma[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw,
+                              uint64_t shift, uint64_t *d_out, size_t stride_out) {
     if (!ctx) return ZP_ERR_ARG;
     ZP_BIND(ctx);
     ZpStage stage_(ctx, "deep_quotient");
@@ -186,6 +186,9 @@ int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, cons
     ZP_ARG(ctx, Wa >= 1 && Wb >= 0 && n_next >= 0 && n_next <= Wa, "bad widths");
     ZP_ARG(ctx, d_cols_a && (d_cols_b || Wb == 0) && z && zw && gamma && h_ev_z && (h_ev_zw || n_next == 0) && d_out,
            "null pointer");
+    const u64 M = 1ULL << logm;
+    ZP_ARG(ctx, row0 + nrows <= M && stride_a >= nrows && (Wb == 0 || stride_b >= nrows) && stride_out >= nrows, "row window / strides out of range");
+    if (nrows == 0) return ZP_OK;
     if (shift == 0) shift = ctx->coset_shift;
     const int W = Wa + Wb;
     NttPlan *pl;
@@ -205,11 +208,23 @@ int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, cons
     a.cols_a = (const u64 *)d_cols_a; a.cols_b = (const u64 *)d_cols_b; a.out = (u64 *)d_out; a.gpow = d_gp;
     a.twl = pl->d_twl; a.twh = pl->d_twh; a.lb = pl->lb;
     memcpy(a.ca, ca.c, 24); memcpy(a.cb, cb.c, 24); memcpy(a.z, z, 24); memcpy(a.zw, zw, 24);
-    a.shift = shift; a.logm = logm; a.Wa = Wa; a.Wb = Wb; a.nnext = n_next;
-    const u64 M = 1ULL << logm;
-    hipLaunchKernelGGL(deep_quotient_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    // x of local row j is shift * w_M^(row0 + j) = (shift * w_M^row0) * w_M^j: the window only changes the constant factor
+    a.shift = gl_mul(shift, gl_pow(gl_root(ctx->root32, logm), (u64)row0));
+    a.logm = logm; a.Wa = Wa; a.Wb = Wb; a.nnext = n_next;
+    a.nrows = nrows; a.sa = stride_a; a.sb = stride_b; a.so = stride_out;
+    hipLaunchKernelGGL(deep_quotient_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, ctx->stream, a);
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
+}
+
+int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, const uint64_t *d_cols_b, int32_t Wb,
+                         int32_t logm, int32_t n_next, const uint64_t z[3], const uint64_t zw[3],
+                         const uint64_t gamma[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t shift,
+                         uint64_t *d_out) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, logm >= 0 && logm <= 32, "logm out of range");
+    const size_t M = (size_t)1 << logm;
+    return zp_deep_quotient_rows(ctx, d_cols_a, Wa, M, d_cols_b, Wb, M, logm, 0, M, n_next, z, zw, gamma, h_ev_z, h_ev_zw, shift, d_out, M);
 }
 
 int32_t zp_gather_rows(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, const uint64_t *h_idx, int32_t nq,
@@ -504,6 +519,8 @@ struct QProgArgs {
     const u64 *xs_lo, *xs_hi;
     u64 *out;
     u64 M, b, shift, wlast;
+    u64 nrows, sc, sf, so;   // rows of this launch (a window of the M-row domain), column strides of cols / fixed / out
+    int wrap;                // 1: the window is the whole domain, the next row wraps mod M; 0: rows r + b are in the buffer (halo)
     int lb, n_const, n_instr, n_slots;
 };
 
@@ -511,9 +528,9 @@ __global__ void __launch_bounds__(256) quotient_program_kernel(QProgArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 slots[];   // [n_slots][256]
     const int tid = threadIdx.x;
     const u64 r = (u64)blockIdx.x * 256 + tid;
-    const bool live = r < a.M;
+    const bool live = r < a.nrows;
     const u64 rr = live ? r : 0;
-    const u64 rn = (rr + a.b) & (a.M - 1);
+    const u64 rn = a.wrap ? ((rr + a.b) & (a.M - 1)) : rr + a.b;
     const u64 x = gl_mul(a.shift, gl_mul(a.xs_lo[rr & ((1ULL << a.lb) - 1)], a.xs_hi[rr >> a.lb]));
     const u64 xml = gl_sub(x, a.wlast);
     const u64 *consts = a.prog + 12, *ins = consts + a.n_const;
@@ -531,9 +548,9 @@ __global__ void __launch_bounds__(256) quotient_program_kernel(QProgArgs a) {
             u64 val;
             switch (kind) {
                 case 0: val = slots[idx * 256 + tid]; break;
-                case 1: val = a.cols[(u64)idx * a.M + rr]; break;
-                case 2: val = a.cols[(u64)idx * a.M + rn]; break;
-                case 3: val = a.fixedc[(u64)idx * a.M + rr]; break;
+                case 1: val = a.cols[(u64)idx * a.sc + rr]; break;
+                case 2: val = a.cols[(u64)idx * a.sc + rn]; break;
+                case 3: val = a.fixedc[(u64)idx * a.sf + rr]; break;
                 case 4: val = a.pub[idx]; break;
                 case 5: val = consts[idx]; break;
                 default: val = xml; break;
@@ -554,16 +571,34 @@ __global__ void __launch_bounds__(256) quotient_program_kernel(QProgArgs a) {
     if (!live) return;
     const u64 zi = a.zhinv[r & (a.b - 1)];
     a.out[r] = gl_mul(gl_acc_reduce(s0), zi);
-    a.out[a.M + r] = gl_mul(gl_acc_reduce(s1), zi);
-    a.out[2 * a.M + r] = gl_mul(gl_acc_reduce(s2), zi);
+    a.out[a.so + r] = gl_mul(gl_acc_reduce(s1), zi);
+    a.out[2 * a.so + r] = gl_mul(gl_acc_reduce(s2), zi);
 }
 
 }  // namespace
+
+extern "C" int32_t zp_eval_quotient_rows(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *d_cols,
+                                         size_t stride_cols, const uint64_t *d_fixed, size_t stride_fixed, int32_t logm, int32_t logb,
+                                         size_t row0, size_t nrows, const uint64_t *h_pub, int32_t n_pub,
+                                         const uint64_t *h_alpha_pows, const uint64_t *h_zhinv, uint64_t shift, uint64_t w_last,
+                                         uint64_t *d_out, size_t stride_out);
 
 extern "C" int32_t zp_eval_quotient(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *d_cols,
                                     const uint64_t *d_fixed, int32_t logm, int32_t logb, const uint64_t *h_pub, int32_t n_pub,
                                     const uint64_t *h_alpha_pows, const uint64_t *h_zhinv, uint64_t shift, uint64_t w_last,
                                     uint64_t *d_out) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, logm >= 0 && logm <= 32, "logm/logb out of range");
+    const size_t M = (size_t)1 << logm;
+    return zp_eval_quotient_rows(ctx, h_program, program_words, d_cols, M, d_fixed, M, logm, logb, 0, M, h_pub, n_pub, h_alpha_pows,
+                                 h_zhinv, shift, w_last, d_out, M);
+}
+
+extern "C" int32_t zp_eval_quotient_rows(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *d_cols,
+                                         size_t stride_cols, const uint64_t *d_fixed, size_t stride_fixed, int32_t logm, int32_t logb,
+                                         size_t row0, size_t nrows, const uint64_t *h_pub, int32_t n_pub,
+                                         const uint64_t *h_alpha_pows, const uint64_t *h_zhinv, uint64_t shift, uint64_t w_last,
+                                         uint64_t *d_out, size_t stride_out) {
     if (!ctx) return ZP_ERR_ARG;
     ZpStage stage_(ctx, "eval_quotient");
     ZP_ARG(ctx, h_program && d_cols && d_fixed && h_alpha_pows && h_zhinv && d_out, "null pointer");
@@ -598,6 +633,11 @@ extern "C" int32_t zp_eval_quotient(zp_ctx *ctx, const uint64_t *h_program, size
     ZP_ARG(ctx, outs == n_cons, "OUT count does not match the header");
     for (int i = 0; i < n_pub; i++) ZP_ARG(ctx, h_pub[i] < GL_P, "public input not canonical");
     const u64 M = 1ULL << logm, b = 1ULL << logb;
+    const bool whole = row0 == 0 && nrows == M;
+    ZP_ARG(ctx, row0 + nrows <= M && row0 % b == 0 && nrows % b == 0, "row window must be aligned to the blow-up and inside the domain");
+    ZP_ARG(ctx, stride_cols >= nrows + (whole ? 0 : b) && stride_fixed >= nrows && stride_out >= nrows,
+           "strides too small (a partial window needs its blow-up halo rows behind the columns)");
+    if (nrows == 0) return ZP_OK;
     NttPlan *pl;
     ZP_TRY(zpi_get_plan(ctx, logm, false, &pl));
     // one upload: program | pub | apow | zhinv
@@ -625,9 +665,11 @@ extern "C" int32_t zp_eval_quotient(zp_ctx *ctx, const uint64_t *h_program, size
     a.xs_lo = pl->d_twl;
     a.xs_hi = pl->d_twh;
     a.out = (u64 *)d_out;
-    a.M = M; a.b = b; a.shift = shift; a.wlast = w_last;
+    a.M = M; a.b = b; a.wlast = w_last;
+    a.shift = gl_mul(shift, gl_pow(gl_root(ctx->root32, logm), (u64)row0));   // x of local row j = (shift * w_M^row0) * w_M^j
+    a.nrows = nrows; a.sc = stride_cols; a.sf = stride_fixed; a.so = stride_out; a.wrap = whole ? 1 : 0;
     a.lb = pl->lb; a.n_const = (int)n_const; a.n_instr = (int)n_instr; a.n_slots = (int)n_slots;
-    hipLaunchKernelGGL(quotient_program_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)n_slots * 256 * 8, ctx->stream, a);
+    hipLaunchKernelGGL(quotient_program_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), (size_t)n_slots * 256 * 8, ctx->stream, a);
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
 }

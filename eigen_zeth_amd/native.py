@@ -56,6 +56,10 @@ SIGNATURES = {
     "zp_lde": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_poseidon_perm": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "zp_pow_grind": (C.c_int32, [_vp, _vp, C.c_int32, _vp]),
+    "zp_deep_quotient_rows": (C.c_int32, [_vp, _vp, C.c_int32, C.c_size_t, _vp, C.c_int32, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, C.c_int32,
+                                          _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, C.c_size_t]),
+    "zp_eval_quotient_rows": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_size_t, C.c_size_t,
+                                          _vp, C.c_int32, _vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_size_t]),
     "zp_pack_blocks": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int32]),
     "zp_transpose": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t]),
     "zp_synth_g1_points": (C.c_int32, [C.c_uint64, C.c_size_t, _vp, C.c_int32]),
@@ -364,6 +368,25 @@ class Prover:
         self._chk(self.lib.zp_deep_quotient(self.ctx, _ptr(d_cols_a), Wa, _ptr(d_cols_b), Wb, logm, n_next, a3(z),
                                             a3(zw), a3(gamma), ez.ctypes.data_as(_u64p), ezw.ctypes.data_as(_u64p),
                                             shift, _ptr(d_out)))
+
+    def deep_quotient_rows(self, d_cols_a, Wa, stride_a, d_cols_b, Wb, stride_b, logm, row0, nrows, n_next, z, zw, gamma, ev_z, ev_zw, shift,
+                           d_out, stride_out):
+        a3 = lambda v: (C.c_uint64 * 3)(*[int(x) for x in v])
+        ez = np.ascontiguousarray(np.asarray(ev_z, dtype=np.uint64))
+        ezw = np.ascontiguousarray(np.asarray(ev_zw, dtype=np.uint64)) if n_next else np.zeros((1, 3), dtype=np.uint64)
+        self._chk(self.lib.zp_deep_quotient_rows(self.ctx, _ptr(d_cols_a), Wa, stride_a, _ptr(d_cols_b), Wb, stride_b, logm, row0, nrows,
+                                                 n_next, a3(z), a3(zw), a3(gamma), ez.ctypes.data, ezw.ctypes.data, shift, _ptr(d_out),
+                                                 stride_out))
+
+    def eval_quotient_rows(self, program, d_cols, stride_cols, d_fixed, stride_fixed, logm, logb, row0, nrows, pubs, apow, zhinv, shift,
+                           w_last, d_out, stride_out):
+        prog = np.ascontiguousarray(np.asarray(program, dtype=np.uint64))
+        pb = np.ascontiguousarray(np.asarray(list(pubs) + [0], dtype=np.uint64))
+        ap = np.ascontiguousarray(np.asarray(apow, dtype=np.uint64).reshape(-1))
+        zh = np.ascontiguousarray(np.asarray(zhinv, dtype=np.uint64))
+        self._chk(self.lib.zp_eval_quotient_rows(self.ctx, prog.ctypes.data, prog.size, _ptr(d_cols), stride_cols, _ptr(d_fixed), stride_fixed,
+                                                 logm, logb, row0, nrows, pb.ctypes.data, len(pubs), ap.ctypes.data, zh.ctypes.data, shift,
+                                                 w_last, _ptr(d_out), stride_out))
 
     def grand_product(self, d_a, d_b, n, gamma, d_out):
         g = (C.c_uint64 * 3)(*[int(x) for x in gamma])

@@ -138,6 +138,12 @@ int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, cons
                          int32_t logm, int32_t n_next, const uint64_t z[3], const uint64_t zw[3],
                          const uint64_t gamma[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t shift,
                          uint64_t *d_out);
+/* the same for a window of the domain (one row shard of a proof spread over GPUs): local row j is row row0 + j of the
+ * 2^logm-row domain; columns are given with explicit strides (elements), nrows rows each.                          */
+int32_t zp_deep_quotient_rows(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, size_t stride_a, const uint64_t *d_cols_b,
+                              int32_t Wb, size_t stride_b, int32_t logm, size_t row0, size_t nrows, int32_t n_next,
+                              const uint64_t z[3], const uint64_t zw[3], const uint64_t gamma[3], const uint64_t *h_ev_z,
+                              const uint64_t *h_ev_zw, uint64_t shift, uint64_t *d_out, size_t stride_out);
 /* grand product column of a permutation argument (stage-2 witness): Z[0]=1, Z[i+1]=Z[i]*(a[i]+g)/(b[i]+g)
  * in F_{p^3}; d_a, d_b u64[n]; d_out u64[3][n] plane-major.  Division by zero (b[i]+g = 0) is the
  * caller's concern (g is a Fiat-Shamir challenge).                                                   */
@@ -183,6 +189,13 @@ int32_t zp_eval_quotient(zp_ctx *ctx, const uint64_t *h_program, size_t program_
                          const uint64_t *d_fixed, int32_t logm, int32_t logb, const uint64_t *h_pub, int32_t n_pub,
                          const uint64_t *h_alpha_pows, const uint64_t *h_zhinv, uint64_t shift, uint64_t w_last,
                          uint64_t *d_out);
+/* the same for a window [row0, row0 + nrows) of the domain (a row shard): columns with explicit strides; unless the
+ * window is the whole domain the caller appends the 2^logb halo rows (rows row0+nrows .. of the domain, wrapping to 0)
+ * behind each column (stride_cols >= nrows + 2^logb); row0 and nrows are multiples of 2^logb.                      */
+int32_t zp_eval_quotient_rows(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *d_cols,
+                              size_t stride_cols, const uint64_t *d_fixed, size_t stride_fixed, int32_t logm, int32_t logb,
+                              size_t row0, size_t nrows, const uint64_t *h_pub, int32_t n_pub, const uint64_t *h_alpha_pows,
+                              const uint64_t *h_zhinv, uint64_t shift, uint64_t w_last, uint64_t *d_out, size_t stride_out);
 /* synthetic witness generation (stands in for the zkVM executor, which is not obtainable offline):
  * kind 0 = Fibonacci (W=2), kind 1 = wide degree-2 mix (any W >= 3), kind 2 = permutation AIR (W=3:
  * a, b = a permuted, c = a^2), kind 3 = chunk AIR (W >= 12: W-8 wide-mix columns, then Fibonacci a,b, range values r,

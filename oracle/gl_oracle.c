@@ -594,8 +594,19 @@ void orc_logup_columns(const u64 *a, const u64 *t, const u64 *m, size_t n, const
  * written against that layout only -- it shares nothing with the product's code generator or GPU interpreter.
  * Per LDE row r: x = shift * wM^r, xml = x - wlast, rn = (r + b) mod M;  out[c][r] = (sum_k alpha^k C_k) * zhinv[r mod b].
  * returns 0, or -1 for a malformed program. */
+int orc_quotient_program_rows(const u64 *prog, size_t prog_len, const u64 *cols, size_t sc, const u64 *fixedc, size_t sf, size_t M,
+                              size_t b, size_t row0, size_t nrows, const u64 *pub, const u64 *apow, const u64 *zhinv, u64 shift, u64 wM,
+                              u64 wlast, u64 *out, size_t so);
 int orc_quotient_program(const u64 *prog, size_t prog_len, const u64 *cols, const u64 *fixedc, size_t M, size_t b,
                          const u64 *pub, const u64 *apow, const u64 *zhinv, u64 shift, u64 wM, u64 wlast, u64 *out) {
+    return orc_quotient_program_rows(prog, prog_len, cols, M, fixedc, M, M, b, 0, M, pub, apow, zhinv, shift, wM, wlast, out, M);
+}
+/* row window [row0, row0 + nrows) of the M-row domain (one row shard): local row j = domain row row0 + j, columns with
+ * strides sc / sf / so; unless the window is the whole domain the b halo rows follow each column (next row = j + b) */
+int orc_quotient_program_rows(const u64 *prog, size_t prog_len, const u64 *cols, size_t sc, const u64 *fixedc, size_t sf, size_t M,
+                              size_t b, size_t row0, size_t nrows, const u64 *pub, const u64 *apow, const u64 *zhinv, u64 shift, u64 wM,
+                              u64 wlast, u64 *out, size_t so) {
+    const int whole = row0 == 0 && nrows == M;
     if (prog_len < 12) return -1;
     static const unsigned char magic[8] = {'Z', 'P', 'A', 'I', 'R', '1', 0, 0};
     if (memcmp(prog, magic, 8) != 0) return -1;
@@ -607,9 +618,9 @@ int orc_quotient_program(const u64 *prog, size_t prog_len, const u64 *cols, cons
     {
         u64 *slots = (u64 *)malloc(n_slots * sizeof(u64));
 #pragma omp for schedule(static)
-        for (size_t r = 0; r < M; r++) {
-            const size_t rn = (r + b) & (M - 1);
-            const u64 x = gl_mul(shift, gl_pow(wM, (u64)r));
+        for (size_t r = 0; r < nrows; r++) {
+            const size_t rn = whole ? ((r + b) & (M - 1)) : r + b;
+            const u64 x = gl_mul(shift, gl_pow(wM, (u64)(row0 + r)));
             const u64 xml = gl_sub(x, wlast);
             u64 acc[3] = {0, 0, 0};
             size_t k_out = 0;
@@ -621,9 +632,9 @@ int orc_quotient_program(const u64 *prog, size_t prog_len, const u64 *cols, cons
                     const unsigned kind = (unsigned)((w >> (24 + 20 * o)) & 0xF), idx = (unsigned)((w >> (28 + 20 * o)) & 0xFFFF);
                     switch (kind) {
                         case 0: v[o] = slots[idx]; break;
-                        case 1: v[o] = cols[(size_t)idx * M + r]; break;
-                        case 2: v[o] = cols[(size_t)idx * M + rn]; break;
-                        case 3: v[o] = fixedc[(size_t)idx * M + r]; break;
+                        case 1: v[o] = cols[(size_t)idx * sc + r]; break;
+                        case 2: v[o] = cols[(size_t)idx * sc + rn]; break;
+                        case 3: v[o] = fixedc[(size_t)idx * sf + r]; break;
                         case 4: v[o] = pub[idx]; break;
                         case 5: v[o] = n_const ? consts[idx] : 0; break;
                         case 6: v[o] = xml; break;
@@ -640,7 +651,7 @@ int orc_quotient_program(const u64 *prog, size_t prog_len, const u64 *cols, cons
                 } else bad = 1;
             }
             const u64 zi = zhinv[r & (b - 1)];
-            for (int c = 0; c < 3; c++) out[(size_t)c * M + r] = gl_mul(acc[c], zi);
+            for (int c = 0; c < 3; c++) out[(size_t)c * so + r] = gl_mul(acc[c], zi);
         }
         free(slots);
     }
@@ -680,6 +691,37 @@ void orc_coset_scale(u64 *cols, size_t n, int W, u64 shift) {
             s = gl_mul(s, shift);
         }
     }
+}
+
+/* DEEP quotient on a row window [row0, row0 + nrows) of the 2^logm-row domain (one row shard), strides in elements */
+void orc_deep_quotient_rows(const u64 *cols_a, int Wa, size_t sa, const u64 *cols_b, int Wb, size_t sb, int logm, size_t row0,
+                            size_t nrows, int n_next, const u64 *z, const u64 *zw, const u64 *gamma, const u64 *ev_z,
+                            const u64 *ev_zw, u64 shift, u64 root32, u64 *out, size_t so) {
+    int W = Wa + Wb;
+    u64 wm = orc_root(root32, logm);
+    e3 g = {{gamma[0], gamma[1], gamma[2]}};
+    e3 *gp = (e3 *)malloc((size_t)(W + n_next) * sizeof(e3));
+    e3 cur = {{1, 0, 0}};
+    for (int k = 0; k < W + n_next; k++) { gp[k] = cur; cur = e3_mul(cur, g); }
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < nrows; r++) {
+        u64 x = gl_mul(shift, gl_pow(wm, (u64)(row0 + r)));
+        e3 d1 = {{gl_sub(x, z[0]), gl_neg(z[1]), gl_neg(z[2])}};
+        e3 d2 = {{gl_sub(x, zw[0]), gl_neg(zw[1]), gl_neg(zw[2])}};
+        e3 i1 = e3_inv_pow(d1), i2 = e3_inv_pow(d2);
+        e3 acc = {{0, 0, 0}};
+        for (int k = 0; k < W; k++) {
+            u64 v = k < Wa ? cols_a[(size_t)k * sa + r] : cols_b[(size_t)(k - Wa) * sb + r];
+            e3 num = {{gl_sub(v, ev_z[k * 3]), gl_neg(ev_z[k * 3 + 1]), gl_neg(ev_z[k * 3 + 2])}};
+            acc = e3_add(acc, e3_mul(gp[k], e3_mul(num, i1)));
+            if (k < n_next) {
+                e3 n2 = {{gl_sub(v, ev_zw[k * 3]), gl_neg(ev_zw[k * 3 + 1]), gl_neg(ev_zw[k * 3 + 2])}};
+                acc = e3_add(acc, e3_mul(gp[W + k], e3_mul(n2, i2)));
+            }
+        }
+        for (int c = 0; c < 3; c++) out[(size_t)c * so + r] = acc.c[c];
+    }
+    free(gp);
 }
 
 int orc_num_threads(void) {

@@ -70,6 +70,9 @@ def lib():
         L.orc_bn254_consecutive_points.argtypes = [C.c_void_p, sz, u64]
         L.orc_bn254_weighted_scalar_sum.argtypes = [C.c_void_p, sz, u64, C.c_void_p]
         L.orc_coset_scale.argtypes = [_u64p, sz, i32, u64]
+        L.orc_quotient_program_rows.restype = i32
+        L.orc_quotient_program_rows.argtypes = [_u64p, sz, _u64p, sz, _u64p, sz, sz, sz, sz, sz, _u64p, _u64p, _u64p, u64, u64, u64, _u64p, sz]
+        L.orc_deep_quotient_rows.argtypes = [_u64p, i32, sz, _u64p, i32, sz, i32, sz, sz, i32, _u64p, _u64p, _u64p, _u64p, _u64p, u64, u64, _u64p, sz]
         L.orc_pow_grind.restype = u64
         L.orc_pow_grind.argtypes = [_u64p, i32, _u64p, _u64p]
         L.orc_fri_fold.argtypes = [_u64p, _u64p, i32, i32, _u64p, u64, u64]

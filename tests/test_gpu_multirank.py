@@ -36,3 +36,4 @@ def test_sharded_commit_four_step_ntt_and_msm_over_rccl():
     res = json.loads(line)
     assert res["ok"] and res["world"] == ranks
     assert res["commit_root_matches_single_gpu"] and res["four_step_matches_plain_ntt"] and res["msm_matches_single_gpu"]
+    assert res["sharded_proof_matches_single_gpu"]

@@ -218,3 +218,63 @@ def test_eval_quotient_rejects_malformed_programs(prover):
             prover.eval_quotient(*args(bad))
     with pytest.raises(native.ZpError):
         prover.eval_quotient(*args(good, pubs=(1, 2)))
+
+
+def test_row_window_entry_points_match_the_whole_domain(prover):
+    """zp_deep_quotient_rows / zp_eval_quotient_rows on a window (with its blow-up halo) == the same rows of the full call"""
+    logm, logb, Wt = 10, 1, 8
+    M, b = 1 << logm, 2
+    air = AIR.get_air("wide8")
+    cols = O.random_field((Wt, M), 901)
+    q = O.random_field((3, M), 902)
+    fixed = O.random_field((2, M), 903)
+    z, zw, gamma = [O.random_field((3,), 904 + i).tolist() for i in range(3)]
+    ev_z = O.random_field((Wt + 3, 3), 910)
+    ev_zw = O.random_field((Wt, 3), 911)
+    d_cols, d_q, d_fixed = prover.upload(cols), prover.upload(q), prover.upload(fixed)
+    d_full = prover.alloc(3 * M)
+    prover.deep_quotient(d_cols, Wt, d_q, 3, logm, Wt, z, zw, gamma, ev_z, ev_zw, 49, d_full)
+    full = prover.download(d_full, (3, M))
+    apow = [O.random_field((3,), 920 + k).tolist() for k in range(len(air.constraints))]
+    pubs = [5, 6, 7, 8]
+    d_qf = prover.alloc(3 * M)
+    prover.eval_quotient(air.program(), d_cols, d_fixed, logm, logb, pubs, apow, [3, 9], 49, 12345, d_qf)
+    qfull = prover.download(d_qf, (3, M))
+    for row0, nrows in ((0, M // 4), (M // 4, M // 2), (3 * M // 4, M // 4)):
+        d_a = prover.upload(cols[:, row0:row0 + nrows])
+        d_b = prover.upload(q[:, row0:row0 + nrows])
+        d_o = prover.alloc(3 * nrows)
+        prover.deep_quotient_rows(d_a, Wt, nrows, d_b, 3, nrows, logm, row0, nrows, Wt, z, zw, gamma, ev_z, ev_zw, 49, d_o, nrows)
+        assert (prover.download(d_o, (3, nrows)) == full[:, row0:row0 + nrows]).all()
+        halo = np.concatenate([cols[:, row0:row0 + nrows], cols[:, [(row0 + nrows + k) % M for k in range(b)]]], axis=1)
+        d_h = prover.upload(halo)
+        d_f = prover.upload(fixed[:, row0:row0 + nrows])
+        prover.eval_quotient_rows(air.program(), d_h, nrows + b, d_f, nrows, logm, logb, row0, nrows, pubs, apow, [3, 9], 49, 12345, d_o, nrows)
+        assert (prover.download(d_o, (3, nrows)) == qfull[:, row0:row0 + nrows]).all()
+    with pytest.raises(native.ZpError):      # a partial window without room for its halo
+        prover.eval_quotient_rows(air.program(), d_cols, M // 2, d_fixed, M // 2, logm, logb, 0, M // 2, pubs, apow, [3, 9], 49, 12345, d_qf, M // 2)
+
+
+def test_sharded_backend_on_one_gpu_gives_the_same_proof(hip_backend, tables):
+    """the multi-GPU orchestration (stark/sharded.py) with its HIP ops, world size 1: same proof as the plain backend"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from eigen_zeth_amd.native import Prover
+    from eigen_zeth_amd.stark.sharded import HipShardOps, ShardedBackend
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    p2 = Prover(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        for name, logn in (("chunk16", 9), ("wide32", 10)):
+            air = AIR.get_air(name)
+            tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 77)
+            params = PR.StarkParams(logn, 1, 3, 4, 6, pow_bits=5)
+            a = PR.proof_to_json(PR.prove(air, tr, pub, params, ShardedBackend(HipShardOps(p2, torch.device("cuda", 0)))))
+            assert a == PR.proof_to_json(PR.prove(air, tr, pub, params, hip_backend))
+    finally:
+        dist.destroy_process_group()
+        p2.close()

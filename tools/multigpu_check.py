@@ -4,6 +4,7 @@ Every rank owns one GPU.  Checked against ONE GPU (rank 0 recomputes on the gath
   1. column shards -> LDE -> all-to-all -> row-sharded Poseidon Merkle -> all-gathered sub-roots == single-GPU root
   2. four-step NTT of one column split over the ranks == zp_ntt of the whole column
   3. MSM by point ranges + all-gather of the partial sums == single MSM
+  4. one chunk STARK sharded over the ranks (stark/sharded.py) == the single-GPU proof, byte for byte
 Rank 0 prints one JSON line; exit code 1 on any mismatch."""
 import json
 import os
@@ -101,6 +102,22 @@ def main():
         single = prover.msm_bn254_arrays(np.concatenate([tab[i] for i in idx]), np.concatenate(scs))
         res["msm_matches_single_gpu"] = total == single
         ok &= total == single
+    # ---- 4. one proof spread over the ranks (row-sharded quotient / DEEP, gather before FRI) == the single-GPU proof
+    from eigen_zeth_amd import native as _native
+    from eigen_zeth_amd.stark import air as AIR, prover as PR
+    from eigen_zeth_amd.stark.backend_hip import HipBackend
+    from eigen_zeth_amd.stark.sharded import HipShardOps, ShardedBackend
+    air = AIR.get_air("chunk64")
+    slog = int(os.environ.get("ZP_CHECK_STARK_LOGN", "14"))
+    tr, pub = _native.synth_trace(air.trace_kind, slog, air.width, 31)
+    params = PR.StarkParams(slog, 1, 3, 4, 8, pow_bits=8)
+    t0 = time.perf_counter()
+    sharded = PR.proof_to_json(PR.prove(air, tr, pub, params, ShardedBackend(HipShardOps(prover, dev))))
+    res["sharded_proof_ms"] = (time.perf_counter() - t0) * 1e3
+    if rank == 0:
+        single = PR.proof_to_json(PR.prove(air, tr, pub, params, HipBackend(prover=prover)))
+        res["sharded_proof_matches_single_gpu"] = sharded == single
+        ok &= sharded == single
     flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
     dist.broadcast(flag, 0)
     if rank == 0:
