@@ -60,6 +60,11 @@ SIGNATURES = {
                                           _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, C.c_size_t]),
     "zp_eval_quotient_rows": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_size_t, C.c_size_t,
                                           _vp, C.c_int32, _vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_size_t]),
+    "zp_set_poseidon_bn254": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
+    "zp_poseidon_bn254_perm": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32]),
+    "zp_merkle16_nodes": (C.c_size_t, [C.c_size_t]),
+    "zp_merkle16_commit_bn254": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp]),
+    "zp_merkle16_open_bn254": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _vp]),
     "zp_pack_blocks": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int32]),
     "zp_transpose": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t]),
     "zp_synth_g1_points": (C.c_int32, [C.c_uint64, C.c_size_t, _vp, C.c_int32]),
@@ -319,6 +324,51 @@ class Prover:
         zh = np.ascontiguousarray(np.asarray(zhinv, dtype=np.uint64))
         self._chk(self.lib.zp_eval_quotient(self.ctx, prog.ctypes.data, prog.size, _ptr(d_cols), _ptr(d_fixed), logm, logb, pb.ctypes.data,
                                             len(pubs), ap.ctypes.data, zh.ctypes.data, shift, w_last, _ptr(d_out)))
+
+    # ---- BN128-hash mode (Poseidon over the BN254 scalar field); field elements = 4 little-endian u64 words
+    @staticmethod
+    def _fr_words(vals):
+        a = np.zeros((len(vals), 4), dtype=np.uint64)
+        for i, v in enumerate(vals):
+            for k in range(4):
+                a[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+        return a
+
+    @staticmethod
+    def _fr_ints(a):
+        a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+        return [sum(int(a[i, k]) << (64 * k) for k in range(4)) for i in range(a.shape[0])]
+
+    def install_poseidon_bn254(self, t):
+        """derive (poseidon_constants.bn254_poseidon_params) and install the tables of width t (3 or 17)"""
+        from .poseidon_constants import bn254_poseidon_params
+        rc, mds, rp = bn254_poseidon_params(t)
+        rcw = self._fr_words(rc)
+        mw = self._fr_words([v for row in mds for v in row])
+        self._chk(self.lib.zp_set_poseidon_bn254(self.ctx, t, rp, rcw.ctypes.data, mw.ctypes.data))
+
+    def poseidon_bn254_perm(self, states):
+        """states: list of lists of t ints < r -> permuted (host convenience around zp_poseidon_bn254_perm)"""
+        t = len(states[0])
+        buf = self.upload(self._fr_words([v for st in states for v in st]).reshape(-1))
+        self._chk(self.lib.zp_poseidon_bn254_perm(self.ctx, buf.ptr, len(states), t))
+        out = self._fr_ints(self.download(buf, (len(states) * t * 4,)))
+        return [out[i * t:(i + 1) * t] for i in range(len(states))]
+
+    def merkle16_nodes(self, M):
+        return int(self.lib.zp_merkle16_nodes(M))
+
+    def merkle16_commit_bn254(self, d_cols, M, W, d_tree):
+        self._chk(self.lib.zp_merkle16_commit_bn254(self.ctx, _ptr(d_cols), M, W, _ptr(d_tree)))
+
+    def merkle16_open_bn254(self, d_tree, M, idx):
+        levels, n = 0, M
+        while n > 1:
+            n = (n + 15) // 16
+            levels += 1
+        out = np.zeros((max(levels, 1), 16, 4), dtype=np.uint64)
+        self._chk(self.lib.zp_merkle16_open_bn254(self.ctx, _ptr(d_tree), M, idx, out.ctypes.data))
+        return [self._fr_ints(out[l]) for l in range(levels)]
 
     def pack_blocks(self, d_in, d_out, rows, row_len, parts):
         self._chk(self.lib.zp_pack_blocks(self.ctx, _ptr(d_in), _ptr(d_out), rows, row_len, parts))

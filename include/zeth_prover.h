@@ -117,6 +117,23 @@ int32_t zp_merkle_commit_rows(zp_ctx *ctx, const uint64_t *d_rows, size_t M, siz
 /* authentication path (host tree or device tree): depth*4 u64, bottom-up siblings */
 int32_t zp_merkle_open(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx, uint64_t *h_path);
 
+/* ---- BN128-hash mode (the last recursive STARK before the Groth16 wrap): Poseidon over the BN254 scalar field F_r,
+ * x^5, 8 full + rp partial rounds, widths t = 3 and t = 17; 16-ary Merkle tree over Goldilocks columns packed three to a
+ * field element.  Field elements cross the ABI as 4 little-endian u64 words, standard form, < r.
+ * zp_set_poseidon_bn254 installs the tables of one width (h_rc: (8 + rp) * t elements round-major, h_mds: t * t row-major);
+ * eigen_zeth_amd/poseidon_constants.py:bn254_poseidon_params derives them (Grain LFSR; the t = 3 set reproduces the
+ * published vector poseidon([1, 2]) = 0x115cc0f5e7d690413df64c6b9662e9cf2a3617f2743245519e19607a4417189a).
+ * zp_poseidon_bn254_perm: d_states u64[count][t][4] permuted in place.
+ * zp_merkle16_commit_bn254: leaf i = sponge (16 elements per permutation, capacity = previous digest, first capacity 0)
+ *   over row i of d_cols u64[W][M] packed as a + b 2^64 + c 2^128; node = digest of [0, 16 children] (missing = 0);
+ *   d_tree u64[zp_merkle16_nodes(M)][4]: leaves, then each level, root last.
+ * zp_merkle16_open_bn254: h_path u64[levels][16][4] = per level the 16 digests of the group on the path (bottom-up).   */
+int32_t zp_set_poseidon_bn254(zp_ctx *ctx, int32_t t, int32_t rp, const uint64_t *h_rc, const uint64_t *h_mds);
+int32_t zp_poseidon_bn254_perm(zp_ctx *ctx, uint64_t *d_states, size_t count, int32_t t);
+size_t zp_merkle16_nodes(size_t M);
+int32_t zp_merkle16_commit_bn254(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, uint64_t *d_tree);
+int32_t zp_merkle16_open_bn254(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx, uint64_t *h_path);
+
 /* ---- N5: FRI fold ------------------------------------------------------------------------------
  * d_in u64[3][2^logn] = f on shift*<w_n> (natural order);  d_out u64[3][2^(logn-logf)] =
  * sum_j beta^j g_j on shift^(2^logf)*<w_(n>>logf)>,  f(x) = sum_j x^j g_j(x^(2^logf)), logf in 1..4 */

@@ -211,3 +211,52 @@ def deep_quotient(cols, n_next, z, zw, gamma, ev_z, ev_zw, shift=SHIFT_DEFAULT, 
             acc = e3_add(acc, e3_mul(gp[W + k], e3_mul(num, i2)))
         out.append(acc)
     return [[v[c] for v in out] for c in range(3)]
+
+
+# ---------------------------------------------------------------- BN128-hash mode: Poseidon over the BN254 scalar field
+BN254_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def poseidon_bn254_perm(state, rc, mds, rp):
+    """textbook schedule: ARK -> x^5 (all elements in the 4 + 4 full rounds, element 0 in the rp partial rounds) -> MDS"""
+    t = len(state)
+    st = [v % BN254_R for v in state]
+    for r in range(8 + rp):
+        st = [(st[i] + rc[r * t + i]) % BN254_R for i in range(t)]
+        if r < 4 or r >= 4 + rp:
+            st = [pow(v, 5, BN254_R) for v in st]
+        else:
+            st[0] = pow(st[0], 5, BN254_R)
+        st = [sum(mds[i][j] * st[j] for j in range(t)) % BN254_R for i in range(t)]
+    return st
+
+
+def poseidon_bn254_hash(inputs, rc, mds, rp):
+    """the published convention: state = [0, inputs...], digest = state[0] after one permutation (len(inputs) = t - 1)"""
+    return poseidon_bn254_perm([0] + list(inputs), rc, mds, rp)[0]
+
+
+def pack3(vals):
+    """three Goldilocks values per BN254 element: a + b 2^64 + c 2^128 (missing values = 0)"""
+    vals = list(vals) + [0] * (-len(vals) % 3)
+    return [vals[i] + (vals[i + 1] << 64) + (vals[i + 2] << 128) for i in range(0, len(vals), 3)]
+
+
+def merkle16_leaf(row, rc, mds, rp):
+    """sponge over the packed row, 16 elements per permutation, the digest being the capacity of the next block"""
+    e = pack3(row)
+    cap = 0
+    for off in range(0, max(len(e), 1), 16):
+        blk = e[off:off + 16]
+        cap = poseidon_bn254_perm([cap] + blk + [0] * (16 - len(blk)), rc, mds, rp)[0]
+    return cap
+
+
+def merkle16_tree(rows, rc, mds, rp):
+    """all levels, leaves first; a node hashes its (up to) 16 children, missing ones as 0"""
+    levels = [[merkle16_leaf(r, rc, mds, rp) for r in rows]]
+    while len(levels[-1]) > 1:
+        prev = levels[-1]
+        levels.append([poseidon_bn254_perm([0] + prev[i:i + 16] + [0] * (16 - len(prev[i:i + 16])), rc, mds, rp)[0]
+                       for i in range(0, len(prev), 16)])
+    return levels

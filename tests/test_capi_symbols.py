@@ -62,6 +62,6 @@ def test_integration_doc_lists_every_entry_point():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "zeth_prover.h")).read()
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
-    declared = set(re.findall(r"^(?:int32_t|void|const char \*)\s*\*?(zp_[a-z0-9_]+)\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:int32_t|size_t|void|const char \*)\s*\*?(zp_[a-z0-9_]+)\(", hdr, re.M))
     bound = set(re.findall(r"pub fn (zp_[a-z0-9_]+)", doc))
     assert declared == bound, (declared - bound, bound - declared)

@@ -1,0 +1,68 @@
+"""GPU tests of the BN128-hash mode (Poseidon over the BN254 scalar field, 16-ary Merkle tree) against the definition-level
+Python in oracle/naive.py, anchored on the published t = 3 vector."""
+import random
+
+import numpy as np
+import pytest
+
+from eigen_zeth_amd import poseidon_constants as PC
+from oracle import naive as NV
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+R = NV.BN254_R
+
+
+@pytest.fixture(scope="module")
+def p254(prover):
+    prover.install_poseidon_bn254(3)
+    prover.install_poseidon_bn254(17)
+    return prover
+
+
+def test_published_vector_on_the_gpu(p254):
+    out = p254.poseidon_bn254_perm([[0, 1, 2]])
+    assert out[0][0] == 0x115CC0F5E7D690413DF64C6B9662E9CF2A3617F2743245519E19607A4417189A
+
+
+@pytest.mark.parametrize("t,count", [(3, 1), (3, 50), (17, 1), (17, 7)])
+def test_permutation_matches_the_definition(p254, t, count):
+    rc, mds, rp = PC.bn254_poseidon_params(t)
+    rnd = random.Random(t * 100 + count)
+    states = [[rnd.randrange(R) for _ in range(t)] for _ in range(count)]
+    states[0][:3] = [0, R - 1, 1]
+    got = p254.poseidon_bn254_perm(states)
+    for st, g in zip(states, got):
+        assert g == NV.poseidon_bn254_perm(st, rc, mds, rp)
+
+
+@pytest.mark.parametrize("M,W", [(1, 5), (16, 3), (20, 50), (64, 49), (300, 7)])
+def test_merkle16_tree_and_openings(p254, M, W):
+    rc, mds, rp = PC.bn254_poseidon_params(17)
+    cols = O.random_field((W, M), 5000 + M)
+    d_cols = p254.upload(cols)
+    nodes = p254.merkle16_nodes(M)
+    d_tree = p254.alloc(nodes * 4)
+    p254.merkle16_commit_bn254(d_cols, M, W, d_tree)
+    tree = p254._fr_ints(p254.download(d_tree, (nodes * 4,)))
+    levels = NV.merkle16_tree([[int(v) for v in cols[:, i]] for i in range(M)], rc, mds, rp)
+    assert tree == [v for lvl in levels for v in lvl]
+    for idx in {0, M - 1, M // 2}:
+        path = p254.merkle16_open_bn254(d_tree, M, idx)
+        pos, digest = idx, levels[0][idx]
+        for l, grp in enumerate(path):       # re-hash upwards from the opened groups
+            assert grp[pos % 16] == digest
+            digest = NV.poseidon_bn254_perm([0] + grp, rc, mds, rp)[0]
+            pos //= 16
+        assert digest == levels[-1][0]
+
+
+def test_tables_must_be_installed_and_reduced(prover):
+    from eigen_zeth_amd import native
+    rc, mds, rp = PC.bn254_poseidon_params(3)
+    bad = prover._fr_words([R] + rc[1:])
+    mw = prover._fr_words([v for row in mds for v in row])
+    with pytest.raises(native.ZpError):
+        prover._chk(prover.lib.zp_set_poseidon_bn254(prover.ctx, 3, rp, bad.ctypes.data, mw.ctypes.data))
+    with pytest.raises(native.ZpError):
+        prover._chk(prover.lib.zp_set_poseidon_bn254(prover.ctx, 5, rp, mw.ctypes.data, mw.ctypes.data))

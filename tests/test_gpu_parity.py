@@ -482,24 +482,3 @@ def test_pack_blocks_kernel(prover, rows, row_len, parts):
     assert (prover.download(d_out, want.shape) == want).all()
     with pytest.raises(native.ZpError):
         prover.pack_blocks(d_in, d_out, rows, row_len, 5 if row_len % 5 else 7)
-
-
-def test_four_step_ntt_through_layout_kernels_one_gpu(prover):
-    """G = 1: three zp_transpose + two batched zp_ntt + zp_twiddle_rows == zp_ntt of the whole column"""
-    import torch
-    from eigen_zeth_amd import multigpu
-    from eigen_zeth_amd.native import Prover
-    logn = 20
-    p2 = Prover(0, stream=torch.cuda.current_stream().cuda_stream)
-    try:
-        x = torch.from_numpy(O.random_field((1 << logn,), 7200).view(np.int64)).cuda()
-        got = multigpu.four_step_ntt(x, logn, *multigpu.hip_row_ops(p2))
-        ref = torch.empty_like(x)
-        p2.ntt(x, ref, logn, 1)
-        torch.cuda.synchronize()
-        assert torch.equal(got, ref)
-        back = multigpu.four_step_ntt(got, logn, *multigpu.hip_row_ops(p2), inverse=True)
-        assert torch.equal(back, x)
-    finally:
-        multigpu.use_device_layout(None)
-        p2.close()

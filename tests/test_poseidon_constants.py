@@ -54,3 +54,19 @@ def test_compiled_in_table_is_the_generated_one():
     assert rc == PC.default_round_constants()
     mds = [int(v) for v in re.findall(r"\b(\d+)\b", mds_txt.split("{", 1)[1])]
     assert mds == PC.default_mds()
+
+
+def test_bn254_t3_instance_reproduces_the_published_hash_vector():
+    """the whole chain -- Grain round constants, the Cauchy MDS drawn from the continued stream, the permutation -- against
+    the published value poseidon([1, 2]) of the BN254 x^5 t = 3 instance (the only externally pinned hash in the repo)"""
+    from oracle import naive as NV
+    rc, mds, rp = PC.bn254_poseidon_params(3)
+    assert rp == 57 and rc[:4] == BN254_T3_FIRST and len(rc) == 65 * 3
+    assert mds[0][0] == 0x109B7F411BA0E4C9B2B70CAF5C36A7B194BE7C11AD24378BFEDB68592BA8118B
+    assert NV.poseidon_bn254_hash([1, 2], rc, mds, rp) == 0x115CC0F5E7D690413DF64C6B9662E9CF2A3617F2743245519E19607A4417189A
+
+
+def test_bn254_t17_parameters_are_well_formed():
+    rc, mds, rp = PC.bn254_poseidon_params(17)
+    assert rp == 68 and len(rc) == 76 * 17 and len(mds) == 17 and all(len(r) == 17 for r in mds)
+    assert all(0 < v < PC.BN254_R for row in mds for v in row) and len({v for row in mds for v in row}) == 289
