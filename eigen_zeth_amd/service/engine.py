@@ -237,7 +237,9 @@ class Engine:
         h = int(hashlib.sha256((recursive_proof + "|" + (aggregator_addr or "")).encode()).hexdigest(), 16)
         circ, pk, vk = self.groth16_keys()
         w = circ.witness(h % bn254.R)
-        rnd = ((h >> 11) % bn254.R or 1, (h >> 23) % bn254.R or 1)   # blinding derived from the input: replays are identical
+        # fresh blinding per proof (zero knowledge); replays of a request are answered from the batch store (server.py),
+        # which keeps the finished proof, so the client still sees one proof per batch
+        rnd = (int.from_bytes(os.urandom(32), "big") % bn254.R or 1, int.from_bytes(os.urandom(32), "big") % bn254.R or 1)
         t0 = time.perf_counter()
         proof, pub = groth16.prove(circ, pk, w, self.be.msm_g1, rnd, getattr(self.be, "msm_g2", None))
         self.stage_timings["final/" + batch_id] = {"groth16": time.perf_counter() - t0}

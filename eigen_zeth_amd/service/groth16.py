@@ -173,16 +173,47 @@ def vk_to_json(vk):
                        "delta2": f2(vk["delta2"]), "ic": [f1(p) for p in vk["ic"]]})
 
 
+def _enc(o):
+    """CRS as plain JSON: ints as decimal strings, points as lists, None (infinity) as null -- nothing executable"""
+    if isinstance(o, dict):
+        return {k: _enc(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_enc(v) for v in o]
+    if isinstance(o, int):
+        return str(o)
+    return o
+
+
+def _dec(o):
+    if isinstance(o, dict):
+        return {k: _dec(v) for k, v in o.items()}
+    if isinstance(o, list):
+        vals = [_dec(v) for v in o]
+        # points are tuples in the prover: (x, y) over F_q, ((x0, x1), (y0, y1)) over F_q2
+        if len(vals) == 2 and all(isinstance(v, (int, tuple)) for v in vals):
+            return tuple(vals)
+        return vals
+    if isinstance(o, str):
+        return int(o)
+    return o
+
+
 def load_or_setup(circ, cache_dir):
-    """the CRS is deterministic (seeded); cache it next to the batch store"""
-    import pickle
-    path = os.path.join(cache_dir, "groth16_crs_v2_logm%d.pkl" % circ.logm)
+    """The CRS of the stand-in circuit is deterministic (SEEDED: a test-only key, its toxic waste is public) and cached
+    as JSON in a directory only this user can write (0700); the file is written through a unique temporary name."""
+    import tempfile
+    os.makedirs(cache_dir, mode=0o700, exist_ok=True)
+    st = os.stat(cache_dir)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise PermissionError("CRS cache directory %s must be owned by this user and not writable by others" % cache_dir)
+    path = os.path.join(cache_dir, "groth16_crs_v3_logm%d.json" % circ.logm)
     if os.path.exists(path):
-        with open(path, "rb") as f:
-            return pickle.load(f)
+        with open(path) as f:
+            d = _dec(json.load(f))
+        return d["pk"], d["vk"]
     pk, vk = setup(circ)
-    os.makedirs(cache_dir, exist_ok=True)
-    with open(path + ".tmp", "wb") as f:
-        pickle.dump((pk, vk), f)
-    os.replace(path + ".tmp", path)
+    fd, tmp = tempfile.mkstemp(prefix=".crs-", dir=cache_dir)
+    with os.fdopen(fd, "w") as f:
+        json.dump({"pk": _enc(pk), "vk": _enc(vk)}, f)
+    os.replace(tmp, path)
     return pk, vk
