@@ -213,6 +213,15 @@ int32_t zp_d2d(zp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
     return ZP_OK;
 }
 
+int32_t zp_dev_zero(zp_ctx *ctx, void *d_dst, size_t bytes) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
+    if (bytes == 0) return ZP_OK;
+    ZP_ARG(ctx, d_dst != nullptr, "null pointer");
+    ZP_HIP(ctx, hipMemsetAsync(d_dst, 0, bytes, ctx->stream));
+    return ZP_OK;
+}
+
 // ---- N1
 int32_t zp_ntt(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t W) {
     if (!ctx) return ZP_ERR_ARG;

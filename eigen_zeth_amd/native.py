@@ -50,6 +50,7 @@ SIGNATURES = {
     "zp_h2d": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
     "zp_d2h": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
     "zp_d2d": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
+    "zp_dev_zero": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "zp_ntt": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32]),
     "zp_intt": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32]),
     "zp_twiddle_rows": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32]),
@@ -295,6 +296,13 @@ class Prover:
         out = np.empty(shape, dtype=np.uint64)
         self._chk(self.lib.zp_d2h(self.ctx, out.ctypes.data, _ptr(buf) + 8 * offset_elems, out.nbytes))
         return out
+
+    def d2d(self, dst, src, nbytes):
+        self._chk(self.lib.zp_d2d(self.ctx, _ptr(dst), _ptr(src), nbytes))
+
+    def memset(self, dst, value, nbytes):
+        assert value == 0
+        self._chk(self.lib.zp_dev_zero(self.ctx, _ptr(dst), nbytes))
 
     def h2d(self, dst, arr):
         a = np.ascontiguousarray(np.asarray(arr, dtype=np.uint64))

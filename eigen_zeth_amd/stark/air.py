@@ -196,7 +196,29 @@ def chunk_air(width):
                stage2=[{"kind": "perm", "a": Ww + 2, "b": Ww + 3}, {"kind": "lookup", "a": Ww + 2, "t": Ww + 4, "m": Ww + 5}])
 
 
-BUILTIN_AIRS = {"perm": permutation_air, "fib": fibonacci_air, "wide8": lambda: wide_air(8), "wide32": lambda: wide_air(32),
+def cubic_air():
+    """degree-3 transition constraints (quotient committed in two pieces at blow-up 2):
+    a' = a^3 + b,  b' = a b + 7;  a[0] = pub0, b[0] = pub1, a[N-1] = pub2"""
+    a, b, an, bn = Col(0), Col(1), Col(0, True), Col(1, True)
+    cs = [transition(an - (a * a * a + b)), transition(bn - (a * b + Const(7))),
+          L_FIRST * (a - Pub(0)), L_FIRST * (b - Pub(1)), L_LAST * (a - Pub(2))]
+    return Air("cubic", 2, 3, cs, trace_kind=None)
+
+
+def cubic_witness(logn, seed):
+    """(trace u64[2][N], publics) of cubic_air: host-side stand-in like zp_synth_trace"""
+    import numpy as np
+    N = 1 << logn
+    tr = np.zeros((2, N), dtype=np.uint64)
+    a, b = (seed * 0x9E3779B97F4A7C15 + 1) % P, (seed * 0xC2B2AE3D27D4EB4F + 5) % P
+    a0, b0 = a, b
+    for i in range(N):
+        tr[0, i], tr[1, i] = a, b
+        a, b = (a * a * a + b) % P, (a * b + 7) % P
+    return tr, np.array([a0, b0, int(tr[0, N - 1])], dtype=np.uint64)
+
+
+BUILTIN_AIRS = {"cubic": cubic_air, "perm": permutation_air, "fib": fibonacci_air, "wide8": lambda: wide_air(8), "wide32": lambda: wide_air(32),
                 "wide64": lambda: wide_air(64), "chunk16": lambda: chunk_air(16), "chunk64": lambda: chunk_air(64)}
 
 

@@ -170,6 +170,24 @@ class HipBackend:
         self.p.intt(d_planes, out, logm, W)
         return out
 
+    def split_quotient(self, d_coef, logn, logb, Q):
+        """d_coef u64[3][M] (coefficients of q(shift X)) -> (LDEs of the Q pieces u64[3Q][M], their coefficients u64[3Q][N]),
+        piece-major.  Piece j of plane c = coefficients [jN, (j+1)N): zero-padded to M and transformed."""
+        N, M = 1 << logn, 1 << (logn + logb)
+        coef = self.p.alloc(3 * Q * N)
+        pad = self.p.alloc(3 * Q * M)
+        self.p.memset(pad, 0, 3 * Q * M * 8)
+        for j in range(Q):
+            for c in range(3):
+                src = d_coef.offset(c * M + j * N)
+                self.p.d2d(coef.offset((3 * j + c) * N), src, N * 8)
+                self.p.d2d(pad.offset((3 * j + c) * M), src, N * 8)
+        ext = self.p.alloc(3 * Q * M)
+        self.p.ntt(pad, ext, logn + logb, 3 * Q)
+        self.p.sync()
+        pad.free()
+        return ext, coef
+
     def eval_ext(self, d_coef, logn, W, point):
         return self.p.poly_eval_ext(d_coef, logn, W, point)
 

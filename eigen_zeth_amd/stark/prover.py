@@ -10,6 +10,7 @@ from __future__ import annotations
 import json
 import time
 
+from . import air as air_mod
 from . import field as F
 from .transcript import Transcript
 
@@ -106,8 +107,18 @@ def prove(air, trace, pubs, params, be, timings=None):
     d_q = be.quotient(air, c1, fixed, list(_ints(pubs)) + list(chal), apow, zhinv, logn, logb, F.inv(wN))
     tick("quotient", t0)
     t0 = time.perf_counter()
-    cq = be.commit_cols(d_q, M, 3)
-    d_qcoef = be.coset_coefficients(d_q, logm, 3)   # coefficients of q_c(shift * X)
+    Q = air_mod.quotient_chunks(air)                 # pieces of degree < N the quotient is committed in
+    assert Q <= (1 << logb), "the blow-up must cover the quotient degree: constraints of degree d need blow-up >= d - 1"
+    d_qcoef = be.coset_coefficients(d_q, logm, 3)   # coefficients of q_c(shift * X), c'_i = c_i shift^i, i < M
+    if Q == 1:
+        cq = be.commit_cols(d_q, M, 3)
+        q_logn, Wq = logm, 3
+    else:
+        # q(x) = sum_j (x / shift)^(jN) qt_j(x), qt_j(shift X) = sum_{i<N} c'_(jN+i) X^i: the pieces are slices of the
+        # coefficient vector already in hand; their LDEs (3Q base columns, piece-major) are what gets committed and opened
+        d_q, d_qcoef = be.split_quotient(d_qcoef, logn, logb, Q)
+        cq = be.commit_cols(d_q, M, 3 * Q)
+        q_logn, Wq = logn, 3 * Q
     tick("merkle+intt(quotient)", t0)
     tr.absorb(cq.root)
     zeta = tr.challenge_e3()
@@ -119,7 +130,7 @@ def prove(air, trace, pubs, params, be, timings=None):
     sinv = F.inv(shift)
     ev_z = be.eval_ext(c1.coef, logn, Wt, F.e3_scale(zeta, sinv))
     ev_zw = be.eval_ext(c1.coef, logn, Wt, F.e3_scale(zeta_w, sinv))
-    ev_q = be.eval_ext(d_qcoef, logm, 3, F.e3_scale(zeta, sinv))
+    ev_q = be.eval_ext(d_qcoef, q_logn, Wq, F.e3_scale(zeta, sinv))
     tick("ood-evals", t0)
     ev_all = [_ints(r) for r in ev_z] + [_ints(r) for r in ev_q]
     ev_next = [_ints(r) for r in ev_zw]
@@ -129,7 +140,7 @@ def prove(air, trace, pubs, params, be, timings=None):
 
     # 4. DEEP quotient
     t0 = time.perf_counter()
-    d_f = be.deep(c1.ext, Wt, d_q, 3, logm, Wt, zeta, zeta_w, gamma, ev_all, ev_next)
+    d_f = be.deep(c1.ext, Wt, d_q, Wq, logm, Wt, zeta, zeta_w, gamma, ev_all, ev_next)
     tick("deep", t0)
 
     # 5. FRI
@@ -164,7 +175,7 @@ def prove(air, trace, pubs, params, be, timings=None):
     if c2 is not None:
         q_s2_vals = be.gather_rows(be.column_view(c1.ext, W, M), M, W2, qidx)
         q_s2_paths = be.open_paths(c2.tree, M, qidx)
-    q_q_vals = be.gather_rows(d_q, M, 3, qidx)
+    q_q_vals = be.gather_rows(d_q, M, Wq, qidx)
     q_q_paths = be.open_paths(cq.tree, M, qidx)
     fri_open = []
     pos = list(qidx)

@@ -195,6 +195,15 @@ class ShardedBackend:
             return self.ops.intt(full, logm)
         return self.ops.intt(planes, logm)
 
+    def split_quotient(self, coef, logn, logb, Q):
+        """the quotient's coefficients are replicated after coset_coefficients: every rank forms the Q pieces (3Q short
+        columns) and keeps its rows of their LDEs"""
+        ext, pieces = self.ops.split_quotient(coef, logn, logb, Q)
+        M = 1 << (logn + logb)
+        nloc = M // self.G
+        r0 = self.rank * nloc
+        return ShardMat(ext[:, r0:r0 + nloc].contiguous(), M, r0, nloc, 0, 3 * Q), pieces
+
     def eval_ext(self, coef, logn, W, point):
         if not isinstance(coef, ShardCoef):
             return self.ops.eval_ext(coef, logn, W, point)
@@ -345,6 +354,16 @@ class HipShardOps:
         out = torch.empty_like(cols)
         self.p.intt(cols, out, logn, cols.shape[0])
         return out
+
+    def split_quotient(self, coef, logn, logb, Q):
+        N, M = 1 << logn, 1 << (logn + logb)
+        c = coef.reshape(3, M)
+        pieces = torch.stack([c[p, j * N:(j + 1) * N] for j in range(Q) for p in range(3)]).contiguous()
+        pad = torch.zeros((3 * Q, M), dtype=torch.int64, device=self.device)
+        pad[:, :N] = pieces
+        ext = torch.empty_like(pad)
+        self.p.ntt(pad, ext, logn + logb, 3 * Q)
+        return ext, pieces
 
     def eval_ext(self, coef, logn, W, point):
         return self.p.poly_eval_ext(coef, logn, W, point)

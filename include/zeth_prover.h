@@ -72,6 +72,7 @@ int32_t zp_host_free(zp_ctx *ctx, void *h_ptr);
 int32_t zp_h2d(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int32_t zp_d2h(zp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int32_t zp_d2d(zp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+int32_t zp_dev_zero(zp_ctx *ctx, void *d_dst, size_t bytes);   /* zero-fill on the ctx stream */
 
 /* ---- N1: Goldilocks NTT / iNTT  (natural order in, natural order out) ------------------------
  * d_in, d_out: u64[W][2^logn].  d_in == d_out is allowed.  d_in is preserved when d_in != d_out. */

@@ -97,6 +97,14 @@ class CpuBackend:
     def coset_coefficients(self, planes, logm, W):
         return O.intt(np.asarray(planes).reshape(W, 1 << logm), self.root32)
 
+    def split_quotient(self, coef, logn, logb, Q):
+        N, M = 1 << logn, 1 << (logn + logb)
+        c = np.asarray(coef).reshape(3, M)
+        pieces = np.ascontiguousarray(np.stack([c[p, j * N:(j + 1) * N] for j in range(Q) for p in range(3)]))
+        pad = np.zeros((3 * Q, M), dtype=np.uint64)
+        pad[:, :N] = pieces
+        return O.ntt(pad, self.root32), pieces
+
     def eval_ext(self, coef, logn, W, point):
         return O.poly_eval_e3_cols(np.ascontiguousarray(np.asarray(coef).reshape(-1, 1 << logn)[:W]), point)
 

@@ -175,12 +175,13 @@ def verify(proof, program, rc, mds, expect):
         lhs = NV.e3_add(lhs, NV.e3_mul(ap, c))
         ap = NV.e3_mul(ap, alpha)
     q, zpow = [0, 0, 0], [1, 0, 0]
-    for j in range(Q):               # q(zeta) = sum_j zeta^(jN) (q_j0 + theta q_j1 + theta^2 q_j2)(zeta)
+    zsN = NV.e3_pow([v * pow(shift, P - 2, P) % P for v in zeta], N)     # (zeta / shift)^N
+    for j in range(Q):               # q(zeta) = sum_j (zeta/shift)^(jN) (q_j0 + theta q_j1 + theta^2 q_j2)(zeta)
         qj = ev_all[Wt + 3 * j]
         qj = NV.e3_add(qj, _mul_theta(ev_all[Wt + 3 * j + 1]))
         qj = NV.e3_add(qj, _mul_theta(_mul_theta(ev_all[Wt + 3 * j + 2])))
         q = NV.e3_add(q, NV.e3_mul(zpow, qj))
-        zpow = NV.e3_mul(zpow, zN)
+        zpow = NV.e3_mul(zpow, zsN)
     if lhs != NV.e3_mul(q, zh):
         raise Reject("constraint identity fails at the out-of-domain point")
 

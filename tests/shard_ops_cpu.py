@@ -97,6 +97,14 @@ class CpuShardOps:
     def intt(self, cols, logn):
         return _t(O.intt(_np(cols).reshape(-1, 1 << logn), self.root32))
 
+    def split_quotient(self, coef, logn, logb, Q):
+        N, M = 1 << logn, 1 << (logn + logb)
+        c = _np(coef).reshape(3, M)
+        pieces = np.ascontiguousarray(np.stack([c[p, j * N:(j + 1) * N] for j in range(Q) for p in range(3)]))
+        pad = np.zeros((3 * Q, M), dtype=np.uint64)
+        pad[:, :N] = pieces
+        return _t(O.ntt(pad, self.root32)), _t(pieces)
+
     def eval_ext(self, coef, logn, W, point):
         return O.poly_eval_e3_cols(_np(coef).reshape(-1, 1 << logn)[:W], point)
 

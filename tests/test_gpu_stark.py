@@ -268,3 +268,15 @@ def test_torch_side_paths_in_a_fresh_process():
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert res["ok"] and res["four_step_matches_plain_ntt"] and res["four_step_inverse_round_trip"]
     assert res["sharded_backend_world1_matches_plain_backend"]
+
+
+@pytest.mark.parametrize("mode", ["kernel", "program"])
+def test_degree_three_air_quotient_in_two_pieces(prover, cpu_backend, tables, mode):
+    from eigen_zeth_amd.stark.backend_hip import HipBackend
+    rc, mds = tables
+    air = AIR.get_air("cubic")
+    tr, pub = AIR.cubic_witness(11, 9)
+    params = PR.StarkParams(11, logb=1, fri_logf=3, fri_final_log=4, n_queries=6, pow_bits=6)
+    gpu = PR.prove(air, tr, pub, params, HipBackend(prover=prover, quotient=mode))
+    assert PR.proof_to_json(gpu) == PR.proof_to_json(PR.prove(air, tr, pub, params, cpu_backend))
+    assert V.verify(gpu, air.program(), rc, mds, V.expectation(params.to_dict()))

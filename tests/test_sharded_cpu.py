@@ -33,7 +33,7 @@ def _worker(rank, world, port, name, logn, logb, out_q):
     from shard_ops_cpu import CpuShardOps
     rc, mds = default_round_constants(), default_mds()
     air = AIR.get_air(name)
-    tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 4040)
+    tr, pub = AIR.cubic_witness(logn, 4040) if name == "cubic" else native.synth_trace(air.trace_kind, logn, air.width, 4040)
     params = PR.StarkParams(logn, logb, 2, 3, 5, pow_bits=4)
     proof = PR.prove(air, tr, pub, params, ShardedBackend(CpuShardOps(rc, mds)))
     if rank == 0:
@@ -42,7 +42,7 @@ def _worker(rank, world, port, name, logn, logb, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,logn,logb", [("wide8", 7, 1), ("chunk16", 7, 1), ("fib", 6, 2)])
+@pytest.mark.parametrize("name,logn,logb", [("wide8", 7, 1), ("chunk16", 7, 1), ("fib", 6, 2), ("cubic", 6, 1)])
 def test_two_rank_sharded_proof_equals_the_single_rank_proof(tables, name, logn, logb):
     import json
     from eigen_zeth_amd import native
@@ -61,7 +61,7 @@ def test_two_rank_sharded_proof_equals_the_single_rank_proof(tables, name, logn,
         assert p.exitcode == 0
     rc, mds = tables
     air = AIR.get_air(name)
-    tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 4040)
+    tr, pub = AIR.cubic_witness(logn, 4040) if name == "cubic" else native.synth_trace(air.trace_kind, logn, air.width, 4040)
     params = PR.StarkParams(logn, logb, 2, 3, 5, pow_bits=4)
     single = PR.proof_to_json(PR.prove(air, tr, pub, params, CpuBackend(rc, mds)))
     assert sharded == single

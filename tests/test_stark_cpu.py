@@ -221,3 +221,27 @@ def test_constraint_program_blob_is_checked_and_statement_bound(tables):
     other = blob.copy()
     other[12] = (int(other[12]) + 1) % V.P            # one constant changed: another statement, another digest
     assert Program(other).digest() != pr.digest()
+
+
+def test_degree_three_constraints_split_the_quotient(be, tables):
+    """constraints of degree 3 (+1 for the transition factor): the quotient has degree < 2N and is committed as two pieces of
+    degree < N (6 base columns); q(z) = q0(z) + (z/shift)^N q1(z) is what the verifier checks"""
+    rc, mds = tables
+    air = AIR.get_air("cubic")
+    assert AIR.quotient_chunks(air) == 2 and AIR.quotient_chunks(AIR.get_air("chunk16")) == 1
+    tr, pub = AIR.cubic_witness(6, 3)
+    params = PR.StarkParams(6, 1, 2, 3, 6, pow_bits=4)
+    proof = PR.prove(air, tr, pub, params, be)
+    exp = V.expectation(params.to_dict())
+    assert len(proof["evals"]["z"]) == 2 + 6 and len(proof["queries"][0]["quotient"]["values"]) == 6
+    assert V.verify(proof, air.program(), rc, mds, exp)
+    for mutate in (lambda p: p["evals"]["z"][5].__setitem__(0, 1), lambda p: p["queries"][1]["quotient"]["values"].__setitem__(4, 2)):
+        bad = copy.deepcopy(proof)
+        mutate(bad)
+        with pytest.raises(V.Reject):
+            V.verify(bad, air.program(), rc, mds, exp)
+    tr[1, 9] ^= 1
+    with pytest.raises(V.Reject):
+        V.verify(PR.prove(air, tr, pub, params, be), air.program(), rc, mds, exp)
+    with pytest.raises(AssertionError):          # blow-up 1 cannot hold a degree-2N quotient
+        PR.prove(air, tr, pub, PR.StarkParams(6, 0, 2, 3, 6), be)
