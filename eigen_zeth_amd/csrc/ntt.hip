@@ -101,15 +101,15 @@ __device__ __forceinline__ u64 tw_lookup(const u64 *lo, const u64 *hi, int lb, u
 // v[p] receives DFT_c[brev(p)];  the caller maps that to the user's root, w_16 = c^j0:
 // DFT_user[k'] = DFT_c[j0*k' mod 2^A]  =>  register p holds user index  k' = j0inv*brev(p) mod 2^A.
 __device__ __forceinline__ u64 mul_c16(int e, u64 d) {   // e is a constant after unrolling: the switch folds away
-    switch (e) {
+    switch (e) {                                          // x * 2^(12 e): hand-written forms of gl_asm.hpp
         case 0: return d;
-        case 1: return gl_mul_pow2<12>(d);
-        case 2: return gl_mul_pow2<24>(d);
-        case 3: return gl_mul_pow2<36>(d);
-        case 4: return gl_mul_pow2<48>(d);
-        case 5: return gl_mul_pow2<60>(d);
-        case 6: return gl_mul_pow2<72>(d);
-        default: return gl_mul_pow2<84>(d);
+        case 1: return gl_shl12<1>(d);
+        case 2: return gl_shl12<2>(d);
+        case 3: return gl_shl12<3>(d);
+        case 4: return gl_shl12<4>(d);
+        case 5: return gl_shl12<5>(d);
+        case 6: return gl_shl12<6>(d);
+        default: return gl_shl12<7>(d);
     }
 }
 // butterflies two at a time through the hand-scheduled carry chains of gl_asm.hpp (x+y, x-y canonical)

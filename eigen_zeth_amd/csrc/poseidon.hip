@@ -12,13 +12,28 @@
 #include <cstring>
 
 #include "ctx.hpp"
+// the Poseidon kernels fit 64 VGPRs (8 waves per SIMD) with the literal-table MDS: low scratch window
+#define GL_ASM_SCRATCH_BASE 52
+#include "gl_asm.hpp"
 
 namespace {
 
-// x^7 with weak (non-canonical) intermediates: the consumers are multiplications / limb sums
+// x^7 (any u64 in): the hand-scheduled 17-instruction products of gl_asm.hpp -- hipcc's gl_mul_weak is ~28 instructions,
+// a third of them moves that build zero-extended 64-bit addends
 __device__ __forceinline__ u64 sbox7(u64 x) {
-    u64 x2 = gl_mul_weak(x, x), x4 = gl_mul_weak(x2, x2), x3 = gl_mul_weak(x2, x);
-    return gl_mul_weak(x3, x4);
+    const u64 x2 = gl_mul1(x, x);
+    u64 x4 = x2, x3 = x2;
+    gl_mul2(x4, x2, x3, x);
+    return gl_mul1(x3, x4);
+}
+// two S-boxes at once: every product has an independent partner, no padding nops
+__device__ __forceinline__ void sbox7x2(u64 &a, u64 &b) {
+    u64 a2 = a, b2 = b;
+    gl_mul2(a2, a, b2, b);
+    u64 a4 = a2, b4 = b2;
+    gl_mul2(a4, a2, b4, b2);
+    gl_mul2(a, a2, b, b2);        // a^3, b^3
+    gl_mul2(a, a4, b, b4);        // a^7, b^7
 }
 
 // default MDS (eigen_zeth_amd/poseidon_constants.py): circulant [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0,..]
@@ -34,8 +49,14 @@ __host__ __device__ __forceinline__ constexpr u32 def_mds(int i, int j) {
 // (12 * 2^28 * 2^32 + 2^32 < 2^64).  Result weak.
 // DEFMDS=false: injected matrix, staged once per workgroup in LDS (keeping 144 entries in SGPRs
 // spills them to VGPR lanes; LDS reads of a wave-uniform address are broadcasts).
+#include "poseidon_mds_asm.inc"   // mds_ark_default_asm: the default matrix as mad chains, 24 + 4 instructions per row
+
 template <bool ADDC, bool DEFMDS>
 __device__ __forceinline__ void mds_ark(u64 *s, const u32 *__restrict__ mds, const u64 *__restrict__ c) {
+    if constexpr (DEFMDS) {
+        mds_ark_default_asm<ADDC>(s, c);
+        return;
+    }
     u64 o[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
@@ -64,14 +85,14 @@ __device__ __forceinline__ void poseidon_perm(u64 *s, const u64 *__restrict__ rc
     for (int r = 0; r < 29; r++) {
         if (r < 4 || r >= 26) {
 #pragma unroll
-            for (int i = 0; i < 12; i++) s[i] = sbox7(s[i]);
+            for (int i = 0; i < 12; i += 2) sbox7x2(s[i], s[i + 1]);
         } else {
             s[0] = sbox7(s[0]);
         }
         mds_ark<true, DEFMDS>(s, mds, rc + (r + 1) * 12);
     }
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = sbox7(s[i]);
+    for (int i = 0; i < 12; i += 2) sbox7x2(s[i], s[i + 1]);
     mds_ark<false, DEFMDS>(s, mds, rc);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);

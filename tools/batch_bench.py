@@ -7,13 +7,17 @@ from eigen_zeth_amd.service.server import default_backend_factory
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 air = sys.argv[3] if len(sys.argv) > 3 else "chunk64"
-cfg = EngineConfig(air=air, logn=logn, n_queries=32, groth16_logm=8, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs"), witness_threads=16, prover_streams=int(os.environ.get('ZP_STREAMS', '4')))
+cfg = EngineConfig(air=air, logn=logn, groth16_logm=8, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs"), witness_threads=16, prover_streams=int(os.environ.get('ZP_STREAMS', '4')))
 eng = Engine(default_backend_factory(0), cfg)
+eng.pregenerate_witnesses = bool(os.environ.get("ZP_PREGEN"))
 eng.be
 t0 = time.perf_counter(); eng.groth16_keys(); t_crs = time.perf_counter() - t0
 for rep in range(2):
     t0 = time.perf_counter()
     ch = eng.gen_batch_chunks("b", list(range(1, K + 1)), 12345, "evm")
+    if eng.pregenerate_witnesses:
+        eng.prepare_witnesses(ch["batch_data"])
+        t0 = time.perf_counter()
     t1 = time.perf_counter()
     proofs = eng.gen_chunk_proofs("b", ch["task_id"], ch["chunk_count"], ch["batch_data"])
     t2 = time.perf_counter()

@@ -12,7 +12,7 @@ air = AIR.get_air(name)
 t0 = time.perf_counter(); tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 42); tw = time.perf_counter() - t0
 be = HipBackend(0)
 if os.environ.get('ZP_COOP_LOG'): be.p.set_tuning('merkle_coop_log', int(os.environ['ZP_COOP_LOG']))
-params = PR.StarkParams(logn, logb=1, fri_logf=3, fri_final_log=5, n_queries=32)
+params = PR.StarkParams(logn, logb=1, fri_logf=3, fri_final_log=5, n_queries=80, pow_bits=20)   # the service default (100 bits)
 for r in range(reps):
     tm = {}
     proof = PR.prove(air, tr, pub, params, be, timings=tm)

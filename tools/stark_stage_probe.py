@@ -9,7 +9,7 @@ logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 air = AIR.get_air(name)
 tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 42)
 be = HipBackend(0)
-params = PR.StarkParams(logn, logb=1, fri_logf=3, fri_final_log=5, n_queries=32)
+params = PR.StarkParams(logn, logb=1, fri_logf=3, fri_final_log=5, n_queries=80, pow_bits=20)   # the service default (100 bits)
 PR.prove(air, tr, pub, params, be)
 be.p.set_profiling(True)
 tm = {}

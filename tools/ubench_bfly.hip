@@ -57,6 +57,29 @@ __global__ void __launch_bounds__(256) km(const u64 *in, u64 *out) {
     for (int i = 0; i < 16; i++) out[g * 16 + i] = v[i];
 }
 
+template <int VAR>
+__global__ void __launch_bounds__(256) ks(const u64 *in, u64 *out) {
+    u64 v[16];
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = in[g * 16 + i];
+    for (int it = 0; it < ITERS; it++) {
+        if (VAR == 0) {
+            v[1] = gl_mul_pow2<12>(v[1]); v[2] = gl_mul_pow2<24>(v[2]); v[3] = gl_mul_pow2<36>(v[3]); v[4] = gl_mul_pow2<48>(v[4]);
+            v[5] = gl_mul_pow2<60>(v[5]); v[6] = gl_mul_pow2<72>(v[6]); v[7] = gl_mul_pow2<84>(v[7]); v[8] = gl_mul_pow2<48>(v[8]);
+            v[9] = gl_mul_pow2<12>(v[9]); v[10] = gl_mul_pow2<24>(v[10]); v[11] = gl_mul_pow2<36>(v[11]); v[12] = gl_mul_pow2<48>(v[12]);
+            v[13] = gl_mul_pow2<60>(v[13]); v[14] = gl_mul_pow2<72>(v[14]); v[15] = gl_mul_pow2<84>(v[15]); v[0] = gl_mul_pow2<48>(v[0]);
+        } else {
+            v[1] = gl_shl12<1>(v[1]); v[2] = gl_shl12<2>(v[2]); v[3] = gl_shl12<3>(v[3]); v[4] = gl_shl12<4>(v[4]);
+            v[5] = gl_shl12<5>(v[5]); v[6] = gl_shl12<6>(v[6]); v[7] = gl_shl12<7>(v[7]); v[8] = gl_shl12<4>(v[8]);
+            v[9] = gl_shl12<1>(v[9]); v[10] = gl_shl12<2>(v[10]); v[11] = gl_shl12<3>(v[11]); v[12] = gl_shl12<4>(v[12]);
+            v[13] = gl_shl12<5>(v[13]); v[14] = gl_shl12<6>(v[14]); v[15] = gl_shl12<7>(v[15]); v[0] = gl_shl12<4>(v[0]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[g * 16 + i] = v[i];
+}
+
 int main() {
     setvbuf(stdout, nullptr, _IONBF, 0);
     printf("start\n");
@@ -109,6 +132,26 @@ int main() {
         for (size_t i = 0; i < n; i++) { if (m0[i] != m1[i]) badm++; if (m1[i] >= GL_P) nc++; }
         printf("gl_mul2 mismatches vs gl_mul: %zu of %zu; non-canonical: %zu\n", badm, n, nc);
         if (badm || nc) return 1;
+    }
+    for (int var = 0; var < 2; var++) {
+        u64 *o = var ? d1 : d0;
+        for (int rep = 0; rep < 2; rep++) {
+            CHK(hipEventRecord(e0));
+            if (var == 0) hipLaunchKernelGGL(ks<0>, dim3(blocks), dim3(256), 0, 0, d_in, o);
+            else hipLaunchKernelGGL(ks<1>, dim3(blocks), dim3(256), 0, 0, d_in, o);
+            CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
+            CHK(hipEventElapsedTime(&ms[var], e0, e1));
+        }
+        const double mu = (double)blocks * 256 * ITERS * 16;
+        printf("shift variant %d: %.3f ms  %.2f T shift-multiplies/s\n", var, ms[var], mu / ms[var] / 1e9);
+    }
+    {
+        std::vector<u64> m0(n), m1(n);
+        CHK(hipMemcpy(m0.data(), d0, n * 8, hipMemcpyDeviceToHost)); CHK(hipMemcpy(m1.data(), d1, n * 8, hipMemcpyDeviceToHost));
+        size_t bads = 0, nc = 0;
+        for (size_t i = 0; i < n; i++) { if (m0[i] != m1[i]) bads++; if (m1[i] >= GL_P) nc++; }
+        printf("gl_shl12 mismatches vs gl_mul_pow2: %zu of %zu; non-canonical: %zu\n", bads, n, nc);
+        if (bads || nc) return 1;
     }
     // butterflies again (their outputs are what the check below compares)
     for (int var = 0; var < 2; var++) {
