@@ -66,6 +66,8 @@ SIGNATURES = {
     "zp_merkle16_nodes": (C.c_size_t, [C.c_size_t]),
     "zp_merkle16_commit_bn254": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp]),
     "zp_merkle16_open_bn254": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _vp]),
+    "zp_ntt_bn254": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
+    "zp_qap_quotient_bn254": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "zp_pack_blocks": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int32]),
     "zp_transpose": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t]),
     "zp_synth_g1_points": (C.c_int32, [C.c_uint64, C.c_size_t, _vp, C.c_int32]),
@@ -377,6 +379,22 @@ class Prover:
         out = np.zeros((max(levels, 1), 16, 4), dtype=np.uint64)
         self._chk(self.lib.zp_merkle16_open_bn254(self.ctx, _ptr(d_tree), M, idx, out.ctypes.data))
         return [self._fr_ints(out[l]) for l in range(levels)]
+
+    def ntt_bn254(self, d_data, logn, inverse=False, coset=None):
+        """in-place NTT over the BN254 scalar field on d_data u64[2^logn][4]; coset: int g or None"""
+        cw = self._fr_words([coset]) if coset is not None else None
+        self._chk(self.lib.zp_ntt_bn254(self.ctx, _ptr(d_data), logn, 1 if inverse else 0, cw.ctypes.data if cw is not None else None))
+
+    def qap_quotient_bn254(self, a_ev, b_ev, c_ev, logm, coset):
+        """lists of ints (evaluations of A, B, C on <w>) -> coefficients of H = (A B - C) / (x^m - 1), list of ints"""
+        m = 1 << logm
+        bufs = [self.upload(self._fr_words(v).reshape(-1)) for v in (a_ev, b_ev, c_ev)]
+        cw = self._fr_words([coset])
+        self._chk(self.lib.zp_qap_quotient_bn254(self.ctx, _ptr(bufs[0]), _ptr(bufs[1]), _ptr(bufs[2]), logm, cw.ctypes.data))
+        out = self._fr_ints(self.download(bufs[0], (m, 4)))
+        for b in bufs:
+            b.free()
+        return out
 
     def pack_blocks(self, d_in, d_out, rows, row_len, parts):
         self._chk(self.lib.zp_pack_blocks(self.ctx, _ptr(d_in), _ptr(d_out), rows, row_len, parts))

@@ -241,7 +241,7 @@ class Engine:
         # which keeps the finished proof, so the client still sees one proof per batch
         rnd = (int.from_bytes(os.urandom(32), "big") % bn254.R or 1, int.from_bytes(os.urandom(32), "big") % bn254.R or 1)
         t0 = time.perf_counter()
-        proof, pub = groth16.prove(circ, pk, w, self.be.msm_g1, rnd, getattr(self.be, "msm_g2", None))
+        proof, pub = groth16.prove(circ, pk, w, self.be.msm_g1, rnd, getattr(self.be, "msm_g2", None), self.be.qap_quotient)
         self.stage_timings["final/" + batch_id] = {"groth16": time.perf_counter() - t0}
         if self.metrics is not None:
             self.metrics.record_stage("groth16", self.stage_timings["final/" + batch_id]["groth16"])

@@ -26,25 +26,6 @@ def _root(logm):
     return pow(TWO_ADIC_ROOT, 1 << (28 - logm), R)
 
 
-def _ntt(a, w):
-    n = len(a)
-    if n == 1:
-        return a
-    ev, od = _ntt(a[0::2], w * w % R), _ntt(a[1::2], w * w % R)
-    out, t = [0] * n, 1
-    for i in range(n // 2):
-        x = t * od[i] % R
-        out[i], out[i + n // 2] = (ev[i] + x) % R, (ev[i] - x) % R
-        t = t * w % R
-    return out
-
-
-def _intt(a, w):
-    n = len(a)
-    ninv = pow(n, R - 2, R)
-    return [v * ninv % R for v in _ntt(a, pow(w, R - 2, R))]
-
-
 class Circuit:
     """R1CS of the arithmetic chain.  wires: [1, pub, s, x_1 .. x_steps]"""
 
@@ -119,25 +100,23 @@ def _g2_add(a, b):
     return bn254._pt_add(bn254._Ops2, a, b)
 
 
-def prove(circ, pk, w, msm_g1, rand, msm_g2=None):
+QAP_COSET = 7   # H is computed on the coset 7 <w> (any g with g^m != 1 gives the same coefficients)
+
+
+def prove(circ, pk, w, msm_g1, rand, msm_g2, qap_quotient):
     """msm_g1(points[(x,y)], scalars[int]) -> (x, y) | None   (GPU: Prover.msm_bn254);  rand = (r, s);
-    msm_g2(points[((x0,x1),(y0,y1)) | None], scalars) -> point | None  (GPU: Prover.msm_bn254_g2) for the G2 side of B"""
+    msm_g2(points[((x0,x1),(y0,y1)) | None], scalars) -> point | None  (GPU: Prover.msm_bn254_g2) for the G2 side of B;
+    qap_quotient(a_ev, b_ev, c_ev, logm, coset) -> coefficients of H = (A B - C) / (x^m - 1)  (GPU: zp_qap_quotient_bn254).
+    msm_g2 may be None (a backend without a G2 kernel: the CPU checker); the other two are required -- no host fallback."""
     assert circ.check(w)
-    m, om = circ.m, _root(circ.logm)
+    m = circ.m
     dot = lambda row: sum(c * w[j] for j, c in row.items()) % R
     a_ev = [dot(r) for r in circ.A] + [0] * (m - len(circ.A))
     b_ev = [dot(r) for r in circ.B] + [0] * (m - len(circ.B))
     c_ev = [dot(r) for r in circ.C] + [0] * (m - len(circ.C))
-    # h = (a*b - c) / (x^m - 1): evaluate on the coset g*<w>, divide by the constant g^m - 1 there
-    g = 7
-    ac, bc, cc = _intt(a_ev, om), _intt(b_ev, om), _intt(c_ev, om)
-    sh = lambda co: _ntt([co[i] * pow(g, i, R) % R for i in range(m)], om)
-    A, B, Cc = sh(ac), sh(bc), sh(cc)
-    zinv = pow((pow(g, m, R) - 1) % R, R - 2, R)
-    hc = _intt([(A[i] * B[i] - Cc[i]) % R * zinv % R for i in range(m)], om)
-    ginv = pow(g, R - 2, R)
-    hco = [hc[i] * pow(ginv, i, R) % R for i in range(m)]
-    assert hco[m - 1] == 0
+    g = QAP_COSET
+    hco = qap_quotient(a_ev, b_ev, c_ev, circ.logm, g)
+    assert len(hco) == m and hco[m - 1] == 0
     r, s = rand
     A1 = _g1_add(_g1_add(pk["alpha1"], msm_g1(pk["u1"], w)), bn254._pt_mul(bn254._Ops1, pk["delta1"], r))
     B1 = _g1_add(_g1_add(pk["beta1"], msm_g1(pk["v1"], w)), bn254._pt_mul(bn254._Ops1, pk["delta1"], s))

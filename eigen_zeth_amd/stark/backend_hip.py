@@ -216,3 +216,7 @@ class HipBackend:
 
     def msm_g2(self, points, scalars):
         return self.p.msm_bn254_g2(points, [int(s) for s in scalars])
+
+    def qap_quotient(self, a_ev, b_ev, c_ev, logm, coset):
+        """coefficients of H = (A B - C) / (x^m - 1): seven F_r transforms + one pointwise kernel (zp_qap_quotient_bn254)"""
+        return self.p.qap_quotient_bn254(a_ev, b_ev, c_ev, logm, coset)

@@ -135,6 +135,19 @@ size_t zp_merkle16_nodes(size_t M);
 int32_t zp_merkle16_commit_bn254(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, uint64_t *d_tree);
 int32_t zp_merkle16_open_bn254(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx, uint64_t *h_path);
 
+/* ---- Groth16 wrap, QAP step: NTT over the BN254 scalar field F_r (serves GenFinalProof, prover.proto:130-148 /
+ * provider.rs:472-503; the G1/G2 multi-scalar multiplications are zp_msm_bn254* below).
+ * Elements: 4 little-endian u64 words, standard form, < r.  Root of unity: 5^((r-1)/2^logn) (5 generates F_r^*, the
+ * convention of the snarkjs/circom family), logn <= 28.
+ * zp_ntt_bn254, in place, natural order in and out:
+ *   inverse = 0: y_k = sum_i x_i (g w^k)^i          (h_coset = g as 4 words, or NULL for g = 1)
+ *   inverse = 1: x_i = g^-i / N * sum_k y_k w^(-ik)  (the inverse of the above)
+ * zp_qap_quotient_bn254: d_a, d_b, d_c hold the evaluations of A(x), B(x), C(x) on <w> (2^logm points each);
+ *   on return d_a holds the 2^logm coefficients of H = (A B - C) / (x^m - 1) (the top one is 0 for a satisfied
+ *   system); d_b, d_c are overwritten (evaluations on the coset g <w>).  g must not be an m-th root of unity.      */
+int32_t zp_ntt_bn254(zp_ctx *ctx, uint64_t *d_data, int32_t logn, int32_t inverse, const uint64_t *h_coset);
+int32_t zp_qap_quotient_bn254(zp_ctx *ctx, uint64_t *d_a, uint64_t *d_b, uint64_t *d_c, int32_t logm, const uint64_t *h_coset);
+
 /* ---- N5: FRI fold ------------------------------------------------------------------------------
  * d_in u64[3][2^logn] = f on shift*<w_n> (natural order);  d_out u64[3][2^(logn-logf)] =
  * sum_j beta^j g_j on shift^(2^logf)*<w_(n>>logf)>,  f(x) = sum_j x^j g_j(x^(2^logf)), logf in 1..4 */

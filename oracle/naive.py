@@ -260,3 +260,80 @@ def merkle16_tree(rows, rc, mds, rp):
         levels.append([poseidon_bn254_perm([0] + prev[i:i + 16] + [0] * (16 - len(prev[i:i + 16])), rc, mds, rp)[0]
                        for i in range(0, len(prev), 16)])
     return levels
+
+
+# ---- F_r transforms of the Groth16 QAP step (definition level: O(n^2) sums, schoolbook products) ----
+FR = BN254_R
+def fr_root(logn):
+    """5^((r-1)/2^logn): 5 generates F_r^* (r - 1 = 2^28 * odd); the convention of the snarkjs / circom family"""
+    assert 0 <= logn <= 28
+    return pow(5, (FR - 1) >> logn, FR)
+
+
+def fr_ntt(x, inverse=False, coset=1):
+    """forward: y_k = sum_i x_i (g w^k)^i ;  inverse: x_i = g^-i / n * sum_k y_k w^(-i k)"""
+    n = len(x)
+    logn = n.bit_length() - 1
+    assert 1 << logn == n
+    w = fr_root(logn)
+    if not inverse:
+        return [poly_eval_mod(x, coset * pow(w, k, FR) % FR, FR) for k in range(n)]
+    winv, ninv, ginv = pow(w, FR - 2, FR), pow(n, FR - 2, FR), pow(coset, FR - 2, FR)
+    return [sum(x[k] * pow(winv, i * k, FR) for k in range(n)) % FR * ninv % FR * pow(ginv, i, FR) % FR for i in range(n)]
+
+
+def poly_eval_mod(coef, z, mod):
+    acc = 0
+    for c in reversed(coef):
+        acc = (acc * z + c) % mod
+    return acc
+
+
+def qap_quotient(a_ev, b_ev, c_ev):
+    """evaluations of A, B, C on <w> -> coefficients of H with A B - C = H (x^m - 1), by interpolation, a schoolbook
+    product and the division identity  P_(j+m) = H_j,  P_j = -H_j  (j < m)"""
+    m = len(a_ev)
+    A, B, Cc = fr_ntt(a_ev, inverse=True), fr_ntt(b_ev, inverse=True), fr_ntt(c_ev, inverse=True)
+    prod = [0] * (2 * m)
+    for i, ai in enumerate(A):
+        if ai:
+            for j, bj in enumerate(B):
+                prod[i + j] = (prod[i + j] + ai * bj) % FR
+    for i, ci in enumerate(Cc):
+        prod[i] = (prod[i] - ci) % FR
+    H = prod[m:]
+    assert all((prod[j] + H[j]) % FR == 0 for j in range(m)), "A B - C is not divisible by x^m - 1"
+    return H
+
+
+def fr_ntt_fast(x, inverse=False, coset=1):
+    """the same map as fr_ntt by recursive even/odd splitting (for sizes the O(n^2) sums cannot reach); pinned to fr_ntt
+    on small sizes by tests/test_oracle.py"""
+    n = len(x)
+    logn = n.bit_length() - 1
+    assert 1 << logn == n
+    w = fr_root(logn)
+
+    def rec(a, ww):
+        if len(a) == 1:
+            return a
+        ev, od = rec(a[0::2], ww * ww % FR), rec(a[1::2], ww * ww % FR)
+        h, t, out = len(a) // 2, 1, [0] * len(a)
+        for i in range(h):
+            v = t * od[i] % FR
+            out[i], out[i + h] = (ev[i] + v) % FR, (ev[i] - v) % FR
+            t = t * ww % FR
+        return out
+
+    if not inverse:
+        gi, xs = 1, []
+        for v in x:
+            xs.append(v * gi % FR)
+            gi = gi * coset % FR
+        return rec(xs, w)
+    y = rec(list(x), pow(w, FR - 2, FR))
+    ninv, ginv, gi, out = pow(n, FR - 2, FR), pow(coset, FR - 2, FR), 1, []
+    for v in y:
+        out.append(v * ninv % FR * gi % FR)
+        gi = gi * ginv % FR
+    return out

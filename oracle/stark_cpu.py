@@ -132,3 +132,7 @@ class CpuBackend:
     def msm_g1(self, points, scalars):
         from . import naive_bn254 as B1
         return B1.msm([p if p is not None else (0, 0) for p in points], scalars)
+
+    def qap_quotient(self, a_ev, b_ev, c_ev, logm, coset):
+        from . import naive
+        return naive.qap_quotient(a_ev, b_ev, c_ev)       # definition level; independent of the coset the GPU path evaluates on

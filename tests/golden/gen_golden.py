@@ -135,6 +135,23 @@ def main():
         msm2.append({"points": [[[str(c) for c in p[0]], [str(c) for c in p[1]]] for p in pts], "scalars": [str(v) for v in sc],
                      "sum": [[str(c) for c in res[0]], [str(c) for c in res[1]]]})
     out["msm_g2"] = msm2
+    # F_r transforms of the Groth16 QAP step (oracle/naive.py: O(n^2) definition, schoolbook product and division identity)
+    frv = []
+    for n, g in ((1, 1), (2, 1), (8, 1), (8, 7), (32, 5)):
+        x = [rnd.randrange(NV.FR) for _ in range(n)]
+        if n >= 8:
+            x[0], x[1], x[2] = 0, NV.FR - 1, 1
+        frv.append({"coset": str(g), "in": [str(v) for v in x], "forward": [str(v) for v in NV.fr_ntt(x, coset=g)],
+                    "inverse": [str(v) for v in NV.fr_ntt(x, inverse=True, coset=g)]})
+    out["fr_ntt"] = frv
+    qv = []
+    for m in (4, 16):
+        a_ev = [rnd.randrange(NV.FR) for _ in range(m)]
+        b_ev = [rnd.randrange(NV.FR) for _ in range(m)]
+        c_ev = [a_ev[i] * b_ev[i] % NV.FR for i in range(m)]
+        qv.append({"a": [str(v) for v in a_ev], "b": [str(v) for v in b_ev], "c": [str(v) for v in c_ev],
+                   "h": [str(v) for v in NV.qap_quotient(a_ev, b_ev, c_ev)]})
+    out["qap_quotient"] = qv
     with open(os.path.join(HERE, "vectors.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
     print("wrote vectors.json", os.path.getsize(os.path.join(HERE, "vectors.json")))

@@ -8,6 +8,9 @@ from eigen_zeth_amd.service import groth16 as G
 from oracle import bn254_pairing as BP
 from oracle import groth16_verify as GV
 from oracle import naive_bn254 as B1
+from oracle import naive as NV
+
+QAP = lambda a, b, c, logm, g: NV.qap_quotient(a, b, c) if logm <= 5 else None   # definition-level H (the checker)
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +38,7 @@ def test_groth16_verifies_and_rejects(keys):
     c, pk, vk = keys
     w = c.witness(987654321)
     assert c.check(w)
-    proof, pub = G.prove(c, pk, w, B1.msm, (5, 9))
+    proof, pub = G.prove(c, pk, w, B1.msm, (5, 9), None, QAP)
     assert GV.verify(vk, proof, pub)
     assert not GV.verify(vk, proof, [(pub[0] + 1) % G.R])
     bad = dict(proof)
@@ -44,7 +47,7 @@ def test_groth16_verifies_and_rejects(keys):
     wbad = list(w)
     wbad[5] = (wbad[5] + 1) % G.R
     with pytest.raises(AssertionError):
-        G.prove(c, pk, wbad, B1.msm, (5, 9))   # an unsatisfying witness is refused
+        G.prove(c, pk, wbad, B1.msm, (5, 9), None, QAP)   # an unsatisfying witness is refused
     # the JSON form is the grammar eigen-zeth parses
     import json
     js = json.loads(G.proof_to_json(proof))
@@ -56,7 +59,7 @@ def test_groth16_with_gpu_msm_equals_cpu(prover, keys):
     c, pk, vk = keys
     w = c.witness(55555)
     gpu_msm = lambda pts, sc: prover.msm_bn254([p if p is not None else (0, 0) for p in pts], [int(s) for s in sc])
-    pg, pubg = G.prove(c, pk, w, gpu_msm, (7, 8))
-    pc, pubc = G.prove(c, pk, w, B1.msm, (7, 8))
+    pg, pubg = G.prove(c, pk, w, gpu_msm, (7, 8), None, lambda a, b, cc, logm, g: prover.qap_quotient_bn254(a, b, cc, logm, g))
+    pc, pubc = G.prove(c, pk, w, B1.msm, (7, 8), None, QAP)
     assert pg == pc and pubg == pubc
     assert GV.verify(vk, pg, pubg)

@@ -164,3 +164,29 @@ def test_deep_quotient_golden(golden):
                                   case["ev_z"], case["ev_zw"][:1], case["shift"])
             if case["n_next"] <= 1:
                 assert got.tolist() == case["out"]
+
+
+# ---- F_r transforms of the Groth16 QAP step
+def test_fr_ntt_golden_and_fast_form(golden):
+    from oracle import naive as NV
+    for case in golden["fr_ntt"]:
+        x, g = [int(v) for v in case["in"]], int(case["coset"])
+        fwd, inv = [int(v) for v in case["forward"]], [int(v) for v in case["inverse"]]
+        assert NV.fr_ntt(x, coset=g) == fwd and NV.fr_ntt_fast(x, coset=g) == fwd
+        assert NV.fr_ntt(x, inverse=True, coset=g) == inv and NV.fr_ntt_fast(x, inverse=True, coset=g) == inv
+        assert NV.fr_ntt_fast(fwd, inverse=True, coset=g) == x
+    # the root convention: 5 generates F_r^*, w has exact order 2^28
+    w = NV.fr_root(28)
+    assert pow(w, 1 << 27, NV.FR) == NV.FR - 1 and NV.fr_root(3) == pow(w, 1 << 25, NV.FR)
+
+
+def test_qap_quotient_golden(golden):
+    from oracle import naive as NV
+    for case in golden["qap_quotient"]:
+        a, b, c, h = ([int(v) for v in case[k]] for k in "abch")
+        assert NV.qap_quotient(a, b, c) == h and h[-1] == 0
+        # the identity it encodes, at a point outside the domain: A(z) B(z) - C(z) = H(z) (z^m - 1)
+        m, z = len(a), 0x1234567
+        A, B, C = (NV.fr_ntt(v, inverse=True) for v in (a, b, c))
+        ev = lambda co: NV.poly_eval_mod(co, z, NV.FR)
+        assert (ev(A) * ev(B) - ev(C)) % NV.FR == ev(h) * (pow(z, m, NV.FR) - 1) % NV.FR

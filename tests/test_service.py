@@ -213,7 +213,11 @@ def test_round_trip_gpu_matches_cpu(tmp_path, cpu_factory, tables):
         ch, ch2 = ProverChannel("127.0.0.1:%d" % port), ProverChannel("127.0.0.1:%d" % port2)
         g, c = ch.execute(5, batch_id="same"), ch2.execute(5, batch_id="same")
         _check_result(g, tables, 5, svc)
-        assert g == c   # identical proof / public_input / roots from the MI355X and from the CPU restatement
+        _check_result(c, tables, 5, svc2)
+        # identical chunk STARKs / public_input / roots from the MI355X and from the CPU restatement; the final Groth16
+        # proofs carry fresh blinding (r, s) per proof, so they differ as group elements and both verify (above)
+        assert {k: v for k, v in g.items() if k != "proof"} == {k: v for k, v in c.items() if k != "proof"}
+        assert g["proof"] != c["proof"]
         ch.close(); ch2.close()
     finally:
         server.stop(0); server2.stop(0)

@@ -97,6 +97,24 @@ __global__ void __launch_bounds__(256) k_mad_u64_u32(u32 *out, u32 seed) {
     u64 x = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
     out[blockIdx.x * 256 + threadIdx.x] = (u32)x ^ (u32)(x >> 32);
 }
+#define F_MAD24(i, s) "v_mad_u32_u24 %" #i ", %" #i ", %8, %9"
+K32(k_mad_u32_u24, F_MAD24(0, ), F_MAD24(1, ), F_MAD24(2, ), F_MAD24(3, ), F_MAD24(4, ), F_MAD24(5, ), F_MAD24(6, ), F_MAD24(7, ))
+#define F_MUL24(i, s) "v_mul_u32_u24 %" #i ", %" #i ", %8"
+K32(k_mul_u32_u24, F_MUL24(0, ), F_MUL24(1, ), F_MUL24(2, ), F_MUL24(3, ), F_MUL24(4, ), F_MUL24(5, ), F_MUL24(6, ), F_MUL24(7, ))
+#define F_DOT4(i, s) "v_dot4_u32_u8 %" #i ", %8, %9, %" #i
+K32(k_dot4_u32_u8, F_DOT4(0, ), F_DOT4(1, ), F_DOT4(2, ), F_DOT4(3, ), F_DOT4(4, ), F_DOT4(5, ), F_DOT4(6, ), F_DOT4(7, ))
+#define F_PERM(i, s) "v_perm_b32 %" #i ", %" #i ", %8, %9"
+K32(k_perm_b32, F_PERM(0, ), F_PERM(1, ), F_PERM(2, ), F_PERM(3, ), F_PERM(4, ), F_PERM(5, ), F_PERM(6, ), F_PERM(7, ))
+#define F_PKADD(i, s) "v_pk_add_u16 %" #i ", %" #i ", %8"
+K32(k_pk_add_u16, F_PKADD(0, ), F_PKADD(1, ), F_PKADD(2, ), F_PKADD(3, ), F_PKADD(4, ), F_PKADD(5, ), F_PKADD(6, ), F_PKADD(7, ))
+#define F_PKMAD(i, s) "v_pk_mad_u16 %" #i ", %" #i ", %8, %9"
+K32(k_pk_mad_u16, F_PKMAD(0, ), F_PKMAD(1, ), F_PKMAD(2, ), F_PKMAD(3, ), F_PKMAD(4, ), F_PKMAD(5, ), F_PKMAD(6, ), F_PKMAD(7, ))
+#define F_BFE(i, s) "v_bfe_u32 %" #i ", %" #i ", 3, 29"
+K32(k_bfe_u32, F_BFE(0, ), F_BFE(1, ), F_BFE(2, ), F_BFE(3, ), F_BFE(4, ), F_BFE(5, ), F_BFE(6, ), F_BFE(7, ))
+#define F_FMA64(i, s) "v_fma_f64 %" #i ", %" #i ", 1.0, 0"
+K64(k_fma_f64, F_FMA64(0, ), F_FMA64(1, ), F_FMA64(2, ), F_FMA64(3, ), F_FMA64(4, ), F_FMA64(5, ), F_FMA64(6, ), F_FMA64(7, ))
+#define F_PKFMA32(i, s) "v_pk_fma_f32 %" #i ", %" #i ", 1.0, 0"
+K64(k_pk_fma_f32, F_PKFMA32(0, ), F_PKFMA32(1, ), F_PKFMA32(2, ), F_PKFMA32(3, ), F_PKFMA32(4, ), F_PKFMA32(5, ), F_PKFMA32(6, ), F_PKFMA32(7, ))
 // clock probe: cycles per 100 MHz tick
 __global__ void k_clock(u64 *out) {
     u64 t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -138,5 +156,6 @@ int main() {
     RUN(k_alignbit); RUN(k_add3); RUN(k_bitop3); RUN(k_mul_lo); RUN(k_mul_hi); RUN(k_cmp_u32_sgpr); RUN(k_min_u32);
     RUN(k_mov_b32); RUN(k_lshl_add_u32); RUN(k_ashr);
     RUN(k_lshl_add_u64); RUN(k_cmp_u64_sgpr); RUN(k_cmp_u64_vcc); RUN(k_lshlrev_b64); RUN(k_mov_b64); RUN(k_mad_u64_u32);
+    RUN(k_mad_u32_u24); RUN(k_mul_u32_u24); RUN(k_dot4_u32_u8); RUN(k_perm_b32); RUN(k_pk_add_u16); RUN(k_pk_mad_u16); RUN(k_bfe_u32); RUN(k_fma_f64); RUN(k_pk_fma_f32);
     return 0;
 }
