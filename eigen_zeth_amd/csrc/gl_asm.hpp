@@ -204,6 +204,98 @@ __device__ __forceinline__ u64 gl_mul1(u64 a, u64 b) {
     return ((u64)r1 << 32) | r0;
 }
 
+// Weak forms (Poseidon: consumers take any u64): the same sequence without the final canonical choice -- the carry of the
+// last mad is folded back as +EPS (T <= 2^64 - 2^33 after a wrap, so T + EPS cannot wrap again).  15 VALU instead of 17.
+// The result is congruent to a*b mod p and < 2^64, NOT necessarily < p.
+__device__ __forceinline__ void gl_mul2w(u64 &a, u64 b, u64 &c, u64 d) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u32 c0 = (u32)c, c1 = (u32)(c >> 32), d0 = (u32)d, d1 = (u32)(d >> 32);
+    u32 ra0, ra1, rb0, rb1;
+    u64 sd, cra, crb, ea, eb, fa, fb;
+    asm("v_mad_u64_u32 " GL_P0 ", %4, %11, %13, 0\n\t"          // PA = a0*b0
+        "v_mad_u64_u32 " GL_P6 ", %4, %15, %17, 0\n\t"          // PB
+        "v_mad_u64_u32 " GL_P2 ", %4, %11, %14, 0\n\t"          // RA = a0*b1
+        "v_mad_u64_u32 " GL_P8 ", %4, %15, %18, 0\n\t"
+        "v_mad_u64_u32 " GL_P4 ", %4, %12, %14, 0\n\t"          // HA = a1*b1
+        "v_mad_u64_u32 " GL_P10 ", %4, %16, %18, 0\n\t"
+        "v_mad_u64_u32 " GL_P2 ", %5, %12, %13, " GL_P2 "\n\t" // RA += a1*b0            -> cr
+        "v_mad_u64_u32 " GL_P8 ", %6, %16, %17, " GL_P8 "\n\t"
+        "v_add_co_u32 " GL_V1 ", %7, " GL_V1 ", " GL_V2 "\n\t"                  // L1 = p1 + r0            -> c1
+        "v_add_co_u32 " GL_V7 ", %8, " GL_V7 ", " GL_V8 "\n\t"
+        "v_addc_co_u32 " GL_V5 ", %5, " GL_V5 ", 0, %5\n\t"                // L3 = h1 + cr
+        "v_addc_co_u32 " GL_V11 ", %6, " GL_V11 ", 0, %6\n\t"
+        "v_addc_co_u32 " GL_V4 ", %7, " GL_V4 ", " GL_V3 ", %7\n\t"             // L2 = h0 + r1 + c1       -> c2
+        "v_addc_co_u32 " GL_V10 ", %8, " GL_V10 ", " GL_V9 ", %8\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 " GL_V5 ", %7, " GL_V5 ", 0, %7\n\t"                // L3 += c2
+        "v_addc_co_u32 " GL_V11 ", %8, " GL_V11 ", 0, %8\n\t"
+        "v_sub_co_u32 " GL_V0 ", %7, " GL_V0 ", " GL_V5 "\n\t"                  // t0 = L0 - L3            -> borrow
+        "v_sub_co_u32 " GL_V6 ", %8, " GL_V6 ", " GL_V11 "\n\t"
+        "s_nop 0\n\t"
+        "v_subbrev_co_u32 " GL_V1 ", %7, 0, " GL_V1 ", %7\n\t"             // t1 = L1 - borrow        -> borrow
+        "v_subbrev_co_u32 " GL_V7 ", %8, 0, " GL_V7 ", %8\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 " GL_V0 ", %9, " GL_V0 ", 0, %7\n\t"                // borrowed 2^64 == EPS too much: t0 += 1 -> f
+        "v_addc_co_u32 " GL_V6 ", %10, " GL_V6 ", 0, %8\n\t"
+        "s_nop 0\n\t"
+        "s_andn2_b64 %7, %7, %9\n\t"
+        "s_andn2_b64 %8, %8, %10\n\t"
+        "v_subbrev_co_u32 " GL_V1 ", %9, 0, " GL_V1 ", %7\n\t"             //                          t1 -= borrow & ~f
+        "v_subbrev_co_u32 " GL_V7 ", %10, 0, " GL_V7 ", %8\n\t"
+        "v_mad_u64_u32 " GL_P0 ", %7, " GL_V4 ", -1, " GL_P0 "\n\t" // T = L2*EPS + t            -> g
+        "v_mad_u64_u32 " GL_P6 ", %8, " GL_V10 ", -1, " GL_P6 "\n\t"
+        "s_nop 0\n\t"
+        "v_subbrev_co_u32 %0, %9, 0, " GL_V0 ", %7\n\t"                 // 2^64 == EPS dropped by the mad: lo = T_lo - g -> h
+        "v_subbrev_co_u32 %2, %10, 0, " GL_V6 ", %8\n\t"
+        "s_nop 0\n\t"
+        "s_andn2_b64 %7, %7, %9\n\t"
+        "s_andn2_b64 %8, %8, %10\n\t"
+        "v_addc_co_u32 %1, %9, " GL_V1 ", 0, %7\n\t"                    // hi = T_hi + (g & ~h)   (T + EPS cannot wrap again)
+        "v_addc_co_u32 %3, %10, " GL_V7 ", 0, %8"
+        : "=v"(ra0), "=v"(ra1), "=v"(rb0), "=v"(rb1),                                                  // 0..3
+          "=&s"(sd), "=&s"(cra), "=&s"(crb), "=&s"(ea), "=&s"(eb), "=&s"(fa), "=&s"(fb)                // 4..10
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(c0), "v"(c1), "v"(d0), "v"(d1)                       // 11..18
+        : "scc", "" GL_V0 "", "" GL_V1 "", "" GL_V2 "", "" GL_V3 "", "" GL_V4 "", "" GL_V5 "", "" GL_V6 "", "" GL_V7 "", "" GL_V8 "", "" GL_V9 "", "" GL_V10 "", "" GL_V11 "");
+    a = ((u64)ra1 << 32) | ra0;
+    c = ((u64)rb1 << 32) | rb0;
+}
+
+
+__device__ __forceinline__ u64 gl_mul1w(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u32 r0, r1;
+    u64 sd, cr, e, f;
+    asm("v_mad_u64_u32 " GL_P0 ", %2, %6, %8, 0\n\t"
+        "v_mad_u64_u32 " GL_P2 ", %2, %6, %9, 0\n\t"
+        "v_mad_u64_u32 " GL_P4 ", %2, %7, %9, 0\n\t"
+        "v_mad_u64_u32 " GL_P2 ", %3, %7, %8, " GL_P2 "\n\t"
+        "v_add_co_u32 " GL_V1 ", %4, " GL_V1 ", " GL_V2 "\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 " GL_V5 ", %3, " GL_V5 ", 0, %3\n\t"
+        "v_addc_co_u32 " GL_V4 ", %4, " GL_V4 ", " GL_V3 ", %4\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 " GL_V5 ", %4, " GL_V5 ", 0, %4\n\t"
+        "v_sub_co_u32 " GL_V0 ", %4, " GL_V0 ", " GL_V5 "\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 " GL_V1 ", %4, 0, " GL_V1 ", %4\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 " GL_V0 ", %5, " GL_V0 ", 0, %4\n\t"
+        "s_nop 1\n\t"
+        "s_andn2_b64 %4, %4, %5\n\t"
+        "v_subbrev_co_u32 " GL_V1 ", %5, 0, " GL_V1 ", %4\n\t"
+        "v_mad_u64_u32 " GL_P0 ", %4, " GL_V4 ", -1, " GL_P0 "\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %0, %5, 0, " GL_V0 ", %4\n\t"
+        "s_nop 1\n\t"
+        "s_andn2_b64 %4, %4, %5\n\t"
+        "v_addc_co_u32 %1, %5, " GL_V1 ", 0, %4"
+        : "=v"(r0), "=v"(r1), "=&s"(sd), "=&s"(cr), "=&s"(e), "=&s"(f)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+        : "scc", "" GL_V0 "", "" GL_V1 "", "" GL_V2 "", "" GL_V3 "", "" GL_V4 "", "" GL_V5 "");
+    return ((u64)r1 << 32) | r0;
+}
+
+
 // x * 2^(12 e) mod p for the radix-16 butterflies (e = 1..7; canonical in, canonical out, bit-identical to gl_mul_pow2<12 e>).
 // y = x << r as three words (r = 12 e mod 32), placed at word offset q = 12 e div 32, folded with 2^64 == EPS, 2^96 == -1,
 // 2^128 == -2^32 by the same borrow / carry corrections as gl_mul1 (8 VALU for q = 0 and q = 2, 12 for q = 1; hipcc's

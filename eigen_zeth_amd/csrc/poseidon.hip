@@ -18,22 +18,22 @@
 
 namespace {
 
-// x^7 (any u64 in): the hand-scheduled 17-instruction products of gl_asm.hpp -- hipcc's gl_mul_weak is ~28 instructions,
+// x^7 (any u64 in, weak out): the hand-scheduled 15-instruction weak products of gl_asm.hpp -- hipcc's gl_mul_weak is ~28 instructions,
 // a third of them moves that build zero-extended 64-bit addends
 __device__ __forceinline__ u64 sbox7(u64 x) {
-    const u64 x2 = gl_mul1(x, x);
+    const u64 x2 = gl_mul1w(x, x);
     u64 x4 = x2, x3 = x2;
-    gl_mul2(x4, x2, x3, x);
-    return gl_mul1(x3, x4);
+    gl_mul2w(x4, x2, x3, x);
+    return gl_mul1w(x3, x4);
 }
 // two S-boxes at once: every product has an independent partner, no padding nops
 __device__ __forceinline__ void sbox7x2(u64 &a, u64 &b) {
     u64 a2 = a, b2 = b;
-    gl_mul2(a2, a, b2, b);
+    gl_mul2w(a2, a, b2, b);
     u64 a4 = a2, b4 = b2;
-    gl_mul2(a4, a2, b4, b2);
-    gl_mul2(a, a2, b, b2);        // a^3, b^3
-    gl_mul2(a, a4, b, b4);        // a^7, b^7
+    gl_mul2w(a4, a2, b4, b2);
+    gl_mul2w(a, a2, b, b2);        // a^3, b^3
+    gl_mul2w(a, a4, b, b4);        // a^7, b^7
 }
 
 // default MDS (eigen_zeth_amd/poseidon_constants.py): circulant [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0,..]

@@ -57,6 +57,29 @@ __global__ void __launch_bounds__(256) km(const u64 *in, u64 *out) {
     for (int i = 0; i < 16; i++) out[g * 16 + i] = v[i];
 }
 
+// weak products (gl_mul2w / gl_mul1w): one step per pair, operands also non-canonical (>= p, up to 2^64 - 1);
+// canon(weak) must equal gl_mul
+__global__ void __launch_bounds__(256) kw(const u64 *in, unsigned long long *bad) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u64 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = in[g * 16 + i];
+    unsigned long long nb = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        u64 a0 = v[i], a1 = v[i + 1];
+        if ((g + i) % 7 == 0) { a0 = ~a0; a1 += GL_P - 1; }                 // weak inputs
+        if ((g + i) % 11 == 0) { a0 = 0xFFFFFFFFFFFFFFFFULL; }
+        const u64 b0 = v[(i + 5) & 15] ^ 0x8000000000000000ULL, b1 = v[(i + 9) & 15];
+        const u64 r0 = gl_mul(a0, b0), r1 = gl_mul(a1, b1);
+        u64 w0 = a0, w1 = a1;
+        gl_mul2w(w0, b0, w1, b1);
+        const u64 w2 = gl_mul1w(a1, b0), r2 = gl_mul(a1, b0);
+        nb += (gl_canon(w0) != r0) + (gl_canon(w1) != r1) + (gl_canon(w2) != r2);
+    }
+    if (nb) atomicAdd(bad, nb);
+}
+
 template <int VAR>
 __global__ void __launch_bounds__(256) ks(const u64 *in, u64 *out) {
     u64 v[16];
@@ -132,6 +155,14 @@ int main() {
         for (size_t i = 0; i < n; i++) { if (m0[i] != m1[i]) badm++; if (m1[i] >= GL_P) nc++; }
         printf("gl_mul2 mismatches vs gl_mul: %zu of %zu; non-canonical: %zu\n", badm, n, nc);
         if (badm || nc) return 1;
+    }
+    {
+        unsigned long long *d_bad, h_bad = 0;
+        CHK(hipMalloc(&d_bad, 8)); CHK(hipMemset(d_bad, 0, 8));
+        hipLaunchKernelGGL(kw, dim3(blocks), dim3(256), 0, 0, d_in, d_bad);
+        CHK(hipMemcpy(&h_bad, d_bad, 8, hipMemcpyDeviceToHost));
+        printf("weak products gl_mul2w / gl_mul1w: canon(weak) != gl_mul in %llu of %zu\n", h_bad, (size_t)blocks * 256 * 24);
+        if (h_bad) return 1;
     }
     for (int var = 0; var < 2; var++) {
         u64 *o = var ? d1 : d0;
