@@ -619,7 +619,8 @@ static int32_t upload(zp_ctx *ctx, const std::vector<u64> &h, u64 **d) {
 
 int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
     const int maxl = (ctx->tune_ntt_maxl >= 6 && ctx->tune_ntt_maxl <= 12) ? ctx->tune_ntt_maxl : 9;
-    const int key = (logn * 2 + (inverse ? 1 : 0)) * 16 + maxl;
+    const int order = ctx->tune_ntt_order;          // 0: larger digits first, 1: larger digits last
+    const int key = ((logn * 2 + (inverse ? 1 : 0)) * 16 + maxl) * 2 + (order ? 1 : 0);
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) {
         *out = &it->second;
@@ -653,10 +654,14 @@ int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
         int rem = logn;
         int logP = 0;
         pl.npass = m;
+        int digits[6];
+        for (int i = 0; i < m; i++) {
+            digits[i] = (rem + (m - i) - 1) / (m - i);  // balanced, larger digits first
+            rem -= digits[i];
+        }
         for (int i = 0; i < m; i++) {
             NttPass &p = pl.pass[i];
-            p.L = (rem + (m - i) - 1) / (m - i);  // balanced, larger digits first
-            rem -= p.L;
+            p.L = order ? digits[m - 1 - i] : digits[i];
             split_digit(p);
             p.logPprev = logP;
             logP += p.L;

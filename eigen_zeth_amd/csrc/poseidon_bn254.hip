@@ -6,9 +6,13 @@
 // value poseidon([1, 2]) = 0x115cc0f5...189a (tests/test_poseidon_constants.py, tests/test_gpu_bn254_hash.py).
 //
 // Mapping: T lanes per permutation (lane e owns state element e in nine 29-bit Montgomery limbs), floor(64/T)
-// permutations per 64-lane workgroup; a round is  ARK -> S-box (lane-local) -> state to LDS -> each lane one row of the
-// dense t x t matrix.  Textbook schedule (no sparse partial-round matrices yet): 22 k field products per t = 17
-// permutation, VALU-bound by construction.
+// permutations per 64-lane workgroup; a full round is  ARK -> S-box (lane-local) -> state to LDS -> each lane one row of the
+// dense t x t matrix (T + 3 products deep).
+// t = 17, partial rounds: the equivalent SPARSE form (computed by zp_set_poseidon_bn254 from the textbook tables, bit-identical
+// results): M = S_i D_i with D_i = diag(1, M^_i) commuting with the one-element S-box and absorbed by the previous round's
+// matrix, so a partial round is  s_0 += a_j; s_0 <- s_0^5;  s_0' = m00 s_0 + sum_k v^_k s_k;  s_k' = w_k s_0 + s_k :
+// five products deep (x^2 together with the v^_k s_k of the other lanes, x^4, x^5, the column products, one Montgomery
+// reduction of the limb-wise row sum) instead of 20.  Per permutation 8 x 20 + 68 x 5 product steps instead of 76 x 20.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -21,9 +25,15 @@ namespace {
 
 struct P254Table {    // device tables of one instance, Montgomery form, 9 x u32 per element
     int t = 0, rp = 0;
-    u32 *d_rc = nullptr;    // [(8 + rp) * t][9]
+    u32 *d_rc = nullptr;    // [(8 + rp) * t][9]   textbook round constants
     u32 *d_mds = nullptr;   // [t * t][9]   row-major: out[i] = sum_j mds[i][j] * in[j]
+    // sparse form of the partial rounds (t = 17 only; nullptr otherwise)
+    u32 *d_pre = nullptr;   // [t * t][9]   D_(rp-1) M: the matrix of the last full round before the partial rounds
+    u32 *d_a = nullptr;     // [rp][9]      the one constant of partial round j (element 0)
+    u32 *d_sp = nullptr;    // [rp][2t-1][9]  per partial round: m00, v^_1 .. v^_(t-1), w_1 .. w_(t-1)
+    u32 *d_rcb = nullptr;   // [t][9]       constants of the first full round after the partial rounds (+ the carried rest)
 };
+struct P254Dev { const u32 *rc, *mds, *pre, *a, *sp, *rcb; int rp; };
 P254Table g_tables[2];      // [0]: t = 3, [1]: t = 17  (per process; the tables are public constants)
 
 __device__ __forceinline__ fr fr_load(const u32 *p) {
@@ -37,36 +47,109 @@ __device__ __forceinline__ fr sbox5(const fr &x) {
     return fr_mul(x4, x);
 }
 
+// one full round: ARK (constants c) -> x^5 -> dense matrix m
+template <int T>
+__device__ __forceinline__ fr full_round(fr s, int q, int e, bool on, u32 (*sh)[T][9], const u32 *c, const u32 *m) {
+    if (on) {
+        s = sbox5(fr_add(s, fr_load(c + (size_t)e * 9)));
+#pragma unroll
+        for (int i = 0; i < 9; i++) sh[q][e][i] = s.l[i];
+    }
+    __syncthreads();
+    if (on) {
+        fr acc = fr_zero();
+        for (int j = 0; j < T; j++) {
+            fr v;
+#pragma unroll
+            for (int i = 0; i < 9; i++) v.l[i] = sh[q][j][i];
+            acc = fr_add(acc, fr_mul(fr_load(m + ((size_t)e * T + j) * 9), v));
+        }
+        s = acc;
+    }
+    __syncthreads();
+    return s;
+}
+
 // one permutation of the PPW states a 64-lane workgroup holds; lane = (slot q, element e); sh[q][j] = element j of slot q
 template <int T>
-__device__ __forceinline__ fr perm_coop(fr s, int q, int e, bool on, u32 (*sh)[T][9], int rp, const u32 *rc, const u32 *mds) {
-    const int rounds = 8 + rp;
-    for (int r = 0; r < rounds; r++) {
-        if (on) {
-            s = fr_add(s, fr_load(rc + ((size_t)r * T + e) * 9));
-            if (r < 4 || r >= 4 + rp || e == 0) s = sbox5(s);
+__device__ __forceinline__ fr perm_coop(fr s, int q, int e, bool on, u32 (*sh)[T][9], const P254Dev &d) {
+    const int rp = d.rp;
+    if (d.sp == nullptr) {                      // textbook schedule (t = 3)
+        for (int r = 0; r < 8 + rp; r++) {
+            if (on) {
+                s = fr_add(s, fr_load(d.rc + ((size_t)r * T + e) * 9));
+                if (r < 4 || r >= 4 + rp || e == 0) s = sbox5(s);
 #pragma unroll
-            for (int i = 0; i < 9; i++) sh[q][e][i] = s.l[i];
+                for (int i = 0; i < 9; i++) sh[q][e][i] = s.l[i];
+            }
+            __syncthreads();
+            if (on) {
+                fr acc = fr_zero();
+                for (int j = 0; j < T; j++) {
+                    fr v;
+#pragma unroll
+                    for (int i = 0; i < 9; i++) v.l[i] = sh[q][j][i];
+                    acc = fr_add(acc, fr_mul(fr_load(d.mds + ((size_t)e * T + j) * 9), v));
+                }
+                s = acc;
+            }
+            __syncthreads();
+        }
+        return s;
+    }
+    for (int r = 0; r < 4; r++) s = full_round<T>(s, q, e, on, sh, d.rc + (size_t)r * T * 9, r == 3 ? d.pre : d.mds);
+    for (int j = 0; j < rp; j++) {
+        const u32 *sp = d.sp + (size_t)j * (2 * T - 1) * 9;
+        if (on) {
+            // step A (all lanes, one product): lane 0 squares s_0 + a_j, lane k forms v^_k s_k
+            const fr x = e == 0 ? fr_add(s, fr_load(d.a + (size_t)j * 9)) : s;
+            const fr y = e == 0 ? x : fr_load(sp + (size_t)e * 9);
+            fr p = fr_mul(x, y);
+            if (e == 0) {                       // steps B, C: x^4, x^5
+                p = fr_mul(p, p);
+                p = fr_mul(p, x);
+            }
+#pragma unroll
+            for (int i = 0; i < 9; i++) sh[q][e][i] = p.l[i];
         }
         __syncthreads();
         if (on) {
-            fr acc = fr_zero();
-            for (int j = 0; j < T; j++) {
-                fr v;
+            fr s0;
 #pragma unroll
-                for (int i = 0; i < 9; i++) v.l[i] = sh[q][j][i];
-                acc = fr_add(acc, fr_mul(fr_load(mds + ((size_t)e * T + j) * 9), v));
+            for (int i = 0; i < 9; i++) s0.l[i] = sh[q][0][i];
+            // step D (all lanes): lane 0: m00 s_0', lane k: w_k s_0'
+            const fr c = fr_mul(fr_load(sp + (size_t)(e == 0 ? 0 : T - 1 + e) * 9), s0);
+            if (e != 0) {
+                s = fr_add(c, s);
+            } else {                            // row sum: limb-wise over the T - 1 products, one Montgomery reduction
+                u64 acc[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) acc[i] = c.l[i];
+                for (int k = 1; k < T; k++) {
+#pragma unroll
+                    for (int i = 0; i < 9; i++) acc[i] += sh[q][k][i];
+                }
+                fr x;
+                u64 carry = 0;
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    const u64 v = acc[i] + carry;
+                    x.l[i] = i < 8 ? ((u32)v & FR_MASK) : (u32)v;       // value < T r < 2^261
+                    carry = v >> FR_B;
+                }
+                s = fr_mul(x, fr_one());        // x R / R = x mod r (same representation)
             }
-            s = acc;
         }
         __syncthreads();
     }
+    s = full_round<T>(s, q, e, on, sh, d.rcb, d.mds);
+    for (int r = 5 + rp; r < 8 + rp; r++) s = full_round<T>(s, q, e, on, sh, d.rc + (size_t)r * T * 9, d.mds);
     return s;
 }
 
 // states: u64[count][T][4] standard form, permuted in place
 template <int T>
-__global__ void __launch_bounds__(64) poseidon254_perm_kernel(u64 *states, size_t count, int rp, const u32 *rc, const u32 *mds) {
+__global__ void __launch_bounds__(64) poseidon254_perm_kernel(u64 *states, size_t count, P254Dev d) {
     constexpr int PPW = 64 / T;
     __shared__ u32 sh[PPW][T][9];
     const int q = threadIdx.x / T, e = threadIdx.x % T;
@@ -79,7 +162,7 @@ __global__ void __launch_bounds__(64) poseidon254_perm_kernel(u64 *states, size_
         for (int k = 0; k < 4; k++) w[k] = states[(idx * T + e) * 4 + k];
         s = fr_to_mont(fr_from_u64(w));
     }
-    s = perm_coop<T>(s, q, e, on, sh, rp, rc, mds);
+    s = perm_coop<T>(s, q, e, on, sh, d);
     if (on) {
         u64 w[4];
         fr_to_u64(fr_from_mont(s), w);
@@ -91,8 +174,7 @@ __global__ void __launch_bounds__(64) poseidon254_perm_kernel(u64 *states, size_
 // 16-ary Merkle tree, t = 17: state = [capacity, 16 inputs]; digest = state[0] after the permutation.
 // leaves: row i of the Goldilocks matrix cols[W][M], three values per field element (a + b 2^64 + c 2^128), sponge over
 // blocks of 16 elements with the digest as the next capacity.  nodes: 16 child digests (missing children = 0).
-__global__ void __launch_bounds__(64) merkle16_leaves_kernel(const u64 *__restrict__ cols, size_t M, int W, u64 *__restrict__ tree, int rp,
-                                                            const u32 *rc, const u32 *mds) {
+__global__ void __launch_bounds__(64) merkle16_leaves_kernel(const u64 *__restrict__ cols, size_t M, int W, u64 *__restrict__ tree, P254Dev d) {
     constexpr int T = 17, PPW = 3;
     __shared__ u32 sh[PPW][T][9];
     const int q = threadIdx.x / T, e = threadIdx.x % T;
@@ -111,7 +193,7 @@ __global__ void __launch_bounds__(64) merkle16_leaves_kernel(const u64 *__restri
             }
             s = fr_to_mont(fr_from_u64(w));
         }
-        s = perm_coop<T>(s, q, e, on, sh, rp, rc, mds);
+        s = perm_coop<T>(s, q, e, on, sh, d);
         // the digest (element 0) is the capacity of the next block: lane e = 0 already holds it
     }
     if (on && e == 0) {
@@ -122,8 +204,7 @@ __global__ void __launch_bounds__(64) merkle16_leaves_kernel(const u64 *__restri
     }
 }
 
-__global__ void __launch_bounds__(64) merkle16_level_kernel(const u64 *__restrict__ prev, size_t nprev, u64 *__restrict__ next, size_t nnext, int rp,
-                                                           const u32 *rc, const u32 *mds) {
+__global__ void __launch_bounds__(64) merkle16_level_kernel(const u64 *__restrict__ prev, size_t nprev, u64 *__restrict__ next, size_t nnext, P254Dev d) {
     constexpr int T = 17, PPW = 3;
     __shared__ u32 sh[PPW][T][9];
     const int q = threadIdx.x / T, e = threadIdx.x % T;
@@ -139,7 +220,7 @@ __global__ void __launch_bounds__(64) merkle16_level_kernel(const u64 *__restric
         }
         s = fr_to_mont(fr_from_u64(w));
     }
-    s = perm_coop<T>(s, q, e, on, sh, rp, rc, mds);
+    s = perm_coop<T>(s, q, e, on, sh, d);
     if (on && e == 0) {
         u64 w[4];
         fr_to_u64(fr_from_mont(s), w);
@@ -153,6 +234,117 @@ int32_t table_for(zp_ctx *ctx, int t, P254Table **out) {
     ZP_ARG(ctx, tb != nullptr, "Poseidon-BN254 width must be 3 or 17");
     ZP_ARG(ctx, tb->d_rc != nullptr, "Poseidon-BN254 tables not installed (zp_set_poseidon_bn254)");
     *out = tb;
+    return ZP_OK;
+}
+P254Dev dev_of(const P254Table *tb) { return P254Dev{tb->d_rc, tb->d_mds, tb->d_pre, tb->d_a, tb->d_sp, tb->d_rcb, tb->rp}; }
+
+// ---- host: the sparse form of the partial rounds (column-vector convention, values in Montgomery form) ----
+// round j (0 <= j < rp) of the textbook is  x <- M sigma(x + c_j),  sigma = x^5 on element 0.  Backwards from the last round,
+// M_0 = M:  M_i = S_i D_i,  D_i = diag(1, M^_i)  (M^_i = M_i without row/column 0),  S_i = M_i D_i^-1 = [[m00, v M^_i^-1], [w, I]].
+// D_i commutes with sigma and moves into the previous round: M_(i+1) = D_i M, c_j <- D_i c_j  (j = rp - 1 - i); what is left
+// after round 0 is the matrix D_(rp-1) M of the full round before.  Forwards, the constants of elements 1.. pass sigma
+// unchanged and are carried through S (carry_0' = v^ . rest, carry_k' = rest_k) into the next round's constants; the last
+// carry lands in the constants of the first full round after the partial rounds.
+typedef std::vector<fr> FrVec;
+fr h_inv_fr(fr a) {
+    const u64 e[4] = {0x43e1f593f0000001ULL - 2, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    fr r = fr_one();
+    for (int k = 3; k >= 0; k--)
+        for (int b = 63; b >= 0; b--) {
+            r = fr_mul(r, r);
+            if ((e[k] >> b) & 1) r = fr_mul(r, a);
+        }
+    return r;
+}
+bool fr_is_zero(const fr &a) {
+    u32 o = 0;
+    for (int i = 0; i < 9; i++) o |= a.l[i];
+    return o == 0;
+}
+// inverse of an n x n matrix (row-major) by Gauss-Jordan; false if singular
+bool mat_inv(const FrVec &a_in, int n, FrVec &out) {
+    FrVec a = a_in;
+    out.assign((size_t)n * n, fr_zero());
+    for (int i = 0; i < n; i++) out[(size_t)i * n + i] = fr_one();
+    for (int c = 0; c < n; c++) {
+        int piv = -1;
+        for (int r = c; r < n; r++)
+            if (!fr_is_zero(a[(size_t)r * n + c])) { piv = r; break; }
+        if (piv < 0) return false;
+        if (piv != c)
+            for (int k = 0; k < n; k++) { std::swap(a[(size_t)piv * n + k], a[(size_t)c * n + k]); std::swap(out[(size_t)piv * n + k], out[(size_t)c * n + k]); }
+        const fr pi = h_inv_fr(a[(size_t)c * n + c]);
+        for (int k = 0; k < n; k++) { a[(size_t)c * n + k] = fr_mul(a[(size_t)c * n + k], pi); out[(size_t)c * n + k] = fr_mul(out[(size_t)c * n + k], pi); }
+        for (int r = 0; r < n; r++) {
+            if (r == c || fr_is_zero(a[(size_t)r * n + c])) continue;
+            const fr f = a[(size_t)r * n + c];
+            for (int k = 0; k < n; k++) {
+                a[(size_t)r * n + k] = fr_sub(a[(size_t)r * n + k], fr_mul(f, a[(size_t)c * n + k]));
+                out[(size_t)r * n + k] = fr_sub(out[(size_t)r * n + k], fr_mul(f, out[(size_t)c * n + k]));
+            }
+        }
+    }
+    return true;
+}
+// rc: (8 + rp) t constants round-major, M: t x t.  Outputs: pre (t x t), a (rp), sp (rp x (2t-1)), rcb (t).
+bool sparse_form(const FrVec &rc, const FrVec &M, int t, int rp, FrVec &pre, FrVec &a, FrVec &sp, FrVec &rcb) {
+    const int n = t - 1;
+    FrVec Mi = M, cD((size_t)rp * t);
+    sp.assign((size_t)rp * (2 * t - 1), fr_zero());
+    for (int i = 0; i < rp; i++) {
+        const int j = rp - 1 - i;
+        FrVec Mh((size_t)n * n), Mhinv;
+        for (int r = 0; r < n; r++)
+            for (int c = 0; c < n; c++) Mh[(size_t)r * n + c] = Mi[(size_t)(r + 1) * t + (c + 1)];
+        if (!mat_inv(Mh, n, Mhinv)) return false;
+        fr *S = &sp[(size_t)j * (2 * t - 1)];
+        S[0] = Mi[0];                                                    // m00
+        for (int k = 0; k < n; k++) {                                    // v^ = v M^^-1
+            fr acc = fr_zero();
+            for (int l = 0; l < n; l++) acc = fr_add(acc, fr_mul(Mi[(size_t)(l + 1)], Mhinv[(size_t)l * n + k]));
+            S[1 + k] = acc;
+            S[t + k] = Mi[(size_t)(k + 1) * t];                          // w_k
+        }
+        // c_j <- D_i c_j
+        const fr *c = &rc[(size_t)(4 + j) * t];
+        cD[(size_t)j * t] = c[0];
+        for (int r = 0; r < n; r++) {
+            fr acc = fr_zero();
+            for (int l = 0; l < n; l++) acc = fr_add(acc, fr_mul(Mh[(size_t)r * n + l], c[l + 1]));
+            cD[(size_t)j * t + r + 1] = acc;
+        }
+        // M_(i+1) = D_i M: row 0 of M, rows 1.. = M^ M[1:, :]
+        FrVec nx((size_t)t * t);
+        for (int c2 = 0; c2 < t; c2++) nx[c2] = M[c2];
+        for (int r = 0; r < n; r++)
+            for (int c2 = 0; c2 < t; c2++) {
+                fr acc = fr_zero();
+                for (int l = 0; l < n; l++) acc = fr_add(acc, fr_mul(Mh[(size_t)r * n + l], M[(size_t)(l + 1) * t + c2]));
+                nx[(size_t)(r + 1) * t + c2] = acc;
+            }
+        Mi = nx;
+    }
+    pre = Mi;
+    a.assign(rp, fr_zero());
+    FrVec carry(t, fr_zero());
+    for (int j = 0; j < rp; j++) {
+        const fr *S = &sp[(size_t)j * (2 * t - 1)];
+        FrVec tv(t);
+        for (int k = 0; k < t; k++) tv[k] = fr_add(cD[(size_t)j * t + k], carry[k]);
+        a[j] = tv[0];
+        fr acc = fr_zero();
+        for (int k = 1; k < t; k++) { acc = fr_add(acc, fr_mul(S[k], tv[k])); carry[k] = tv[k]; }
+        carry[0] = acc;
+    }
+    rcb.resize(t);
+    for (int k = 0; k < t; k++) rcb[k] = fr_add(rc[(size_t)(4 + rp) * t + k], carry[k]);
+    return true;
+}
+int32_t upload_fr(zp_ctx *ctx, const FrVec &v, u32 **d) {
+    std::vector<u32> flat(v.size() * 9);
+    for (size_t i = 0; i < v.size(); i++) memcpy(&flat[i * 9], v[i].l, 36);
+    ZP_HIP(ctx, hipMalloc((void **)d, flat.size() * 4));
+    ZP_HIP(ctx, hipMemcpy(*d, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
     return ZP_OK;
 }
 
@@ -175,7 +367,18 @@ int32_t zp_set_poseidon_bn254(zp_ctx *ctx, int32_t t, int32_t rp, const uint64_t
     }
     P254Table *tb = t == 3 ? &g_tables[0] : &g_tables[1];
     ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (tb->d_rc) { (void)hipFree(tb->d_rc); (void)hipFree(tb->d_mds); tb->d_rc = tb->d_mds = nullptr; }
+    for (u32 **pp : {&tb->d_rc, &tb->d_mds, &tb->d_pre, &tb->d_a, &tb->d_sp, &tb->d_rcb})
+        if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+    if (t == 17) {                                  // sparse form of the partial rounds
+        FrVec frc(nrc), fm(nm), pre, a, sp, rcb;
+        for (size_t i = 0; i < nrc; i++) memcpy(frc[i].l, &rc[i * 9], 36);
+        for (size_t i = 0; i < nm; i++) memcpy(fm[i].l, &md[i * 9], 36);
+        ZP_ARG(ctx, sparse_form(frc, fm, t, rp, pre, a, sp, rcb), "matrix has a singular minor: no sparse form (not an MDS matrix)");
+        ZP_TRY(upload_fr(ctx, pre, &tb->d_pre));
+        ZP_TRY(upload_fr(ctx, a, &tb->d_a));
+        ZP_TRY(upload_fr(ctx, sp, &tb->d_sp));
+        ZP_TRY(upload_fr(ctx, rcb, &tb->d_rcb));
+    }
     ZP_HIP(ctx, hipMalloc((void **)&tb->d_rc, rc.size() * 4));
     ZP_HIP(ctx, hipMalloc((void **)&tb->d_mds, md.size() * 4));
     ZP_HIP(ctx, hipMemcpy(tb->d_rc, rc.data(), rc.size() * 4, hipMemcpyHostToDevice));
@@ -194,10 +397,10 @@ int32_t zp_poseidon_bn254_perm(zp_ctx *ctx, uint64_t *d_states, size_t count, in
     ZP_ARG(ctx, d_states != nullptr, "null device pointer");
     if (t == 3)
         hipLaunchKernelGGL(poseidon254_perm_kernel<3>, dim3((unsigned)((count + 20) / 21)), dim3(64), 0, ctx->stream, (u64 *)d_states, count,
-                           tb->rp, tb->d_rc, tb->d_mds);
+                           dev_of(tb));
     else
         hipLaunchKernelGGL(poseidon254_perm_kernel<17>, dim3((unsigned)((count + 2) / 3)), dim3(64), 0, ctx->stream, (u64 *)d_states, count,
-                           tb->rp, tb->d_rc, tb->d_mds);
+                           dev_of(tb));
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
 }
@@ -216,13 +419,13 @@ int32_t zp_merkle16_commit_bn254(zp_ctx *ctx, const uint64_t *d_cols, size_t M, 
     ZP_TRY(table_for(ctx, 17, &tb));
     ZP_ARG(ctx, d_cols && d_tree && M >= 1 && W >= 1, "bad arguments");
     hipLaunchKernelGGL(merkle16_leaves_kernel, dim3((unsigned)((M + 2) / 3)), dim3(64), 0, ctx->stream, (const u64 *)d_cols, M, (int)W,
-                       (u64 *)d_tree, tb->rp, tb->d_rc, tb->d_mds);
+                       (u64 *)d_tree, dev_of(tb));
     ZP_HIP(ctx, hipGetLastError());
     size_t n = M, off = 0;
     while (n > 1) {
         const size_t nn = (n + 15) / 16;
         hipLaunchKernelGGL(merkle16_level_kernel, dim3((unsigned)((nn + 2) / 3)), dim3(64), 0, ctx->stream, (const u64 *)d_tree + off * 4, n,
-                           (u64 *)d_tree + (off + n) * 4, nn, tb->rp, tb->d_rc, tb->d_mds);
+                           (u64 *)d_tree + (off + n) * 4, nn, dev_of(tb));
         ZP_HIP(ctx, hipGetLastError());
         off += n;
         n = nn;
