@@ -65,7 +65,7 @@ struct zp_ctx {
     void *msm_arena = nullptr;    // scratch of zp_msm_bn254*: grows to the largest run, freed by zp_destroy
     size_t msm_arena_bytes = 0;
     int tune_logt = 4, tune_tpw = 2, tune_logt9 = 5;   // tiles per workgroup: 2 measured best with the gl_asm.hpp arithmetic (profiles/r2_ntt_sweep.txt)
-    int tune_ntt_order = 0;       // 0: larger radices first, 1: larger radices last (plan digit order)
+    int tune_ntt_order = 0;       // plan digit order: 0 auto (a radix-512 digit goes last), 1 larger radices first, 2 larger radices last
     int tune_ntt_maxl = 0;        // 0 = 9: largest log2 radix of one NTT pass (10: 1024-thread workgroups, two-pass plans up to 2^20)
     int tune_merkle_coop_log = 0; // 0 = 15: tree levels with <= 2^15 nodes go to the 12-lanes-per-node subtree kernel
     int tune_ntt_chunk_log = 0;   // 0 = 28: columns per launch such that a ping-pong scratch buffer is <= 2 GiB

@@ -619,8 +619,8 @@ static int32_t upload(zp_ctx *ctx, const std::vector<u64> &h, u64 **d) {
 
 int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
     const int maxl = (ctx->tune_ntt_maxl >= 6 && ctx->tune_ntt_maxl <= 12) ? ctx->tune_ntt_maxl : 9;
-    const int order = ctx->tune_ntt_order;          // 0: larger digits first, 1: larger digits last
-    const int key = ((logn * 2 + (inverse ? 1 : 0)) * 16 + maxl) * 2 + (order ? 1 : 0);
+    const int order = ctx->tune_ntt_order;          // 0: auto, 1: larger digits first, 2: larger digits last
+    const int key = ((logn * 2 + (inverse ? 1 : 0)) * 16 + maxl) * 4 + (order & 3);
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) {
         *out = &it->second;
@@ -661,7 +661,11 @@ int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
         }
         for (int i = 0; i < m; i++) {
             NttPass &p = pl.pass[i];
-            p.L = order ? digits[m - 1 - i] : digits[i];
+            // the transposing first pass pays a per-lane twiddle chain on top of its rounds: a three-round radix-512 digit is
+            // cheaper as the (plain) last pass; with digits <= 8 the larger-first order measured 1-4 % faster
+            // (profiles/r2_order_sweep.txt)
+            const bool last = order == 2 || (order == 0 && digits[0] == 9 && digits[m - 1] < 9);
+            p.L = last ? digits[m - 1 - i] : digits[i];
             split_digit(p);
             p.logPprev = logP;
             logP += p.L;

@@ -13,7 +13,7 @@ for logn, cols in ((21, 64), (22, 64), (23, 32), (25, 16)):
     x = rng.integers(0, 2**63, size=(cols, 1 << logn), dtype=np.uint64)
     d = p.upload(x); o = p.alloc(cols << logn)
     ref = None
-    for order in (0, 1):
+    for order in (1, 2):
         p.set_tuning("ntt_order", order)
         ms = t(lambda: p.ntt(d, o, logn, cols))
         y = p.download(o, (cols, 1 << logn))[:, ::4097].copy()
@@ -24,7 +24,7 @@ for logn, cols in ((20, 64), (24, 32)):
     x = rng.integers(0, 2**63, size=(cols, 1 << logn), dtype=np.uint64)
     d = p.upload(x); o = p.alloc(cols << (logn + 1))
     ref = None
-    for order in (0, 1):
+    for order in (1, 2):
         p.set_tuning("ntt_order", order)
         ms = t(lambda: p.lde(d, o, logn, 1, cols))
         y = p.download(o, (cols, 2 << logn))[:, ::4097].copy()
