@@ -197,15 +197,20 @@ GL_HD e3 e3_add(e3 a, e3 b) { return e3_make(gl_add(a.c[0], b.c[0]), gl_add(a.c[
 GL_HD e3 e3_sub(e3 a, e3 b) { return e3_make(gl_sub(a.c[0], b.c[0]), gl_sub(a.c[1], b.c[1]), gl_sub(a.c[2], b.c[2])); }
 GL_HD e3 e3_scale(e3 a, u64 s) { return e3_make(gl_mul(a.c[0], s), gl_mul(a.c[1], s), gl_mul(a.c[2], s)); }
 // inverse through the adjugate of the multiplication matrix of a (basis 1, t, t^2; t^3 = t + 1)
-GL_HD e3 e3_inv(e3 a) {
+// a^-1 = adj / det: the two halves separately, so that callers can share one base-field inversion between several elements
+GL_HD e3 e3_adj(e3 a, u64 *det) {
     const u64 a0 = a.c[0], a1 = a.c[1], a2 = a.c[2];
     const u64 s02 = gl_add(a0, a2), s12 = gl_add(a1, a2);
     const u64 c00 = gl_sub(gl_mul(s02, s02), gl_mul(s12, a1));
     const u64 c01 = gl_sub(gl_mul(s12, a2), gl_mul(a1, s02));
     const u64 c02 = gl_sub(gl_mul(a1, a1), gl_mul(s02, a2));
-    const u64 det = gl_add(gl_add(gl_mul(a0, c00), gl_mul(a2, c01)), gl_mul(a1, c02));
-    const u64 di = gl_inv(det);
-    return e3_make(gl_mul(c00, di), gl_mul(c01, di), gl_mul(c02, di));
+    *det = gl_add(gl_add(gl_mul(a0, c00), gl_mul(a2, c01)), gl_mul(a1, c02));
+    return e3_make(c00, c01, c02);
+}
+GL_HD e3 e3_inv(e3 a) {
+    u64 det;
+    const e3 adj = e3_adj(a, &det);
+    return e3_scale(adj, gl_inv(det));
 }
 GL_HD e3 e3_mul(e3 a, e3 b) {
     u64 d0 = gl_mul(a.c[0], b.c[0]);

@@ -69,40 +69,61 @@ struct DeepArgs {
     int logm, Wa, Wb, nnext, lb;
 };
 
-__global__ void __launch_bounds__(256) deep_quotient_kernel(DeepArgs a) {
-    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (r >= a.nrows) return;
-    // A = sum g^k p_k(x) as three unreduced 160-bit dot products; the second sum runs over the same columns with
-    // the powers shifted by W, so it is g^W times the prefix of A over the first nnext columns.
+// numerators and denominators of one row: A = sum g^k p_k(x) - c_a, B = (prefix over the first nnext columns) g^W - c_b,
+// d1 = x - z, d2 = x - zw
+struct DeepRow { e3 A, B, d1, d2; };
+__device__ __forceinline__ DeepRow deep_row(const DeepArgs &a, u64 r) {
+    // three unreduced 160-bit dot products; the second sum runs over the same columns with the powers shifted by W, so it is
+    // g^W times the prefix of A over the first nnext columns
     gl_acc s0 = gl_acc_zero(), s1 = gl_acc_zero(), s2 = gl_acc_zero();
-    e3 A, B = e3_make(0, 0, 0);
+    DeepRow o;
+    o.B = e3_make(0, 0, 0);
     const int W = a.Wa + a.Wb;
     for (int k = 0; k < W; k++) {
-        if (k == a.nnext && k > 0) B = e3_make(gl_acc_reduce(s0), gl_acc_reduce(s1), gl_acc_reduce(s2));
+        if (k == a.nnext && k > 0) o.B = e3_make(gl_acc_reduce(s0), gl_acc_reduce(s1), gl_acc_reduce(s2));
         const u64 v = k < a.Wa ? a.cols_a[(u64)k * a.sa + r] : a.cols_b[(u64)(k - a.Wa) * a.sb + r];
         const u64 *g = a.gpow + k * 3;
         gl_acc_mac(s0, v, g[0]);
         gl_acc_mac(s1, v, g[1]);
         gl_acc_mac(s2, v, g[2]);
     }
-    A = e3_make(gl_acc_reduce(s0), gl_acc_reduce(s1), gl_acc_reduce(s2));
-    if (a.nnext >= W) B = A;
-    if (a.nnext > 0) B = e3_mul(B, e3_make(a.gpow[W * 3], a.gpow[W * 3 + 1], a.gpow[W * 3 + 2]));
-    A = e3_sub(A, e3_make(a.ca[0], a.ca[1], a.ca[2]));
-    B = e3_sub(B, e3_make(a.cb[0], a.cb[1], a.cb[2]));
+    o.A = e3_make(gl_acc_reduce(s0), gl_acc_reduce(s1), gl_acc_reduce(s2));
+    if (a.nnext >= W) o.B = o.A;
+    if (a.nnext > 0) o.B = e3_mul(o.B, e3_make(a.gpow[W * 3], a.gpow[W * 3 + 1], a.gpow[W * 3 + 2]));
+    o.A = e3_sub(o.A, e3_make(a.ca[0], a.ca[1], a.ca[2]));
+    o.B = e3_sub(o.B, e3_make(a.cb[0], a.cb[1], a.cb[2]));
     const u64 x = gl_mul(a.shift, gl_mul(a.twl[r & ((1ULL << a.lb) - 1)], a.twh[r >> a.lb]));
-    const e3 d1 = e3_make(gl_sub(x, a.z[0]), gl_neg(a.z[1]), gl_neg(a.z[2]));
-    e3 F;
+    o.d1 = e3_make(gl_sub(x, a.z[0]), gl_neg(a.z[1]), gl_neg(a.z[2]));
+    o.d2 = e3_make(gl_sub(x, a.zw[0]), gl_neg(a.zw[1]), gl_neg(a.zw[2]));
+    return o;
+}
+// Two rows per lane and ONE base-field inversion (Fermat, ~85 products) for their four denominators:
+// 1/d1 = d2 adj(d1 d2) / det, 1/d2 = d1 adj(d1 d2) / det per row, and 1/det_0, 1/det_1 from 1/(det_0 det_1).
+__global__ void __launch_bounds__(256) deep_quotient_kernel(DeepArgs a) {
+    const u64 r0 = ((u64)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (r0 >= a.nrows) return;
+    const bool two = r0 + 1 < a.nrows;
+    const DeepRow q0 = deep_row(a, r0), q1 = two ? deep_row(a, r0 + 1) : q0;
+    u64 det0, det1;
+    const e3 adj0 = e3_adj(a.nnext > 0 ? e3_mul(q0.d1, q0.d2) : q0.d1, &det0);
+    const e3 adj1 = e3_adj(a.nnext > 0 ? e3_mul(q1.d1, q1.d2) : q1.d1, &det1);
+    // a vanishing denominator (z on the domain: excluded by the protocol) keeps the convention 1/0 = 0 for ITS row only
+    const u64 m0 = det0 ? det0 : 1, m1 = det1 ? det1 : 1;
+    const u64 inv01 = gl_inv(gl_mul(m0, m1));
+    const e3 pi0 = e3_scale(adj0, det0 ? gl_mul(inv01, m1) : 0), pi1 = e3_scale(adj1, det1 ? gl_mul(inv01, m0) : 0);
+    e3 F0, F1;
     if (a.nnext > 0) {
-        // one inversion for both denominators: 1/d1 = d2/(d1 d2), 1/d2 = d1/(d1 d2)
-        const e3 d2 = e3_make(gl_sub(x, a.zw[0]), gl_neg(a.zw[1]), gl_neg(a.zw[2]));
-        const e3 pi = e3_inv(e3_mul(d1, d2));
-        F = e3_add(e3_mul(A, e3_mul(pi, d2)), e3_mul(B, e3_mul(pi, d1)));
+        F0 = e3_add(e3_mul(q0.A, e3_mul(pi0, q0.d2)), e3_mul(q0.B, e3_mul(pi0, q0.d1)));
+        F1 = e3_add(e3_mul(q1.A, e3_mul(pi1, q1.d2)), e3_mul(q1.B, e3_mul(pi1, q1.d1)));
     } else {
-        F = e3_mul(A, e3_inv(d1));
+        F0 = e3_mul(q0.A, pi0);
+        F1 = e3_mul(q1.A, pi1);
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++) a.out[(u64)c * a.so + r] = F.c[c];
+    for (int c = 0; c < 3; c++) {
+        a.out[(u64)c * a.so + r0] = F0.c[c];
+        if (two) a.out[(u64)c * a.so + r0 + 1] = F1.c[c];
+    }
 }
 
 __global__ void __launch_bounds__(256) gather_rows_kernel(const u64 *cols, u64 M, int W, const u64 *idx, int nq, u64 *out) {
@@ -212,7 +233,7 @@ int32_t zp_deep_quotient_rows(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa,
     a.shift = gl_mul(shift, gl_pow(gl_root(ctx->root32, logm), (u64)row0));
     a.logm = logm; a.Wa = Wa; a.Wb = Wb; a.nnext = n_next;
     a.nrows = nrows; a.sa = stride_a; a.sb = stride_b; a.so = stride_out;
-    hipLaunchKernelGGL(deep_quotient_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(deep_quotient_kernel, dim3((unsigned)((nrows + 511) / 512)), dim3(256), 0, ctx->stream, a);
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
 }
