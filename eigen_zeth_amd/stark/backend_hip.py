@@ -20,11 +20,13 @@ class Commit:
 
 
 class HipBackend:
-    def __init__(self, device=0, prover=None, quotient="kernel"):
+    def __init__(self, device=0, prover=None, quotient="kernel", hash_mode="gl"):
         """quotient: "kernel" = the generated per-AIR constraint kernel (AIR plug-in ABI, needs hipcc at build time);
-        "program" = zp_eval_quotient interpreting the AIR's constraint program blob (what a host without a compiler uses)"""
-        assert quotient in ("kernel", "program")
+        "program" = zp_eval_quotient interpreting the AIR's constraint program blob (what a host without a compiler uses).
+        hash_mode: "gl" = Poseidon-Goldilocks binary trees; "bn128" = Poseidon-BN254 16-ary trees + transcript (final STARK)"""
+        assert quotient in ("kernel", "program") and hash_mode in ("gl", "bn128")
         self.quotient_mode = quotient
+        self.hash_mode = hash_mode
         self.p = prover or native.Prover(device)
         self.p.pooling = True   # chunk after chunk has the same shapes: reuse device buffers
         self.root32 = int(self.p.get_constants(native.ZP_CONST_ROOT32, 1)[0])
@@ -35,6 +37,21 @@ class HipBackend:
         self.p_device = device
         self._up = None
         self._up_lock, self._copy_lock = threading.Lock(), threading.Lock()
+        if hash_mode == "bn128":
+            self.p.install_poseidon_bn254(17)
+
+    # ---- Merkle trees of the configured hash mode
+    def _tree_alloc(self, M):
+        return self.p.alloc(self.p.merkle16_nodes(M) * 4 if self.hash_mode == "bn128" else (2 * M - 1) * 4)
+
+    def _commit(self, d_cols, M, W, tree):
+        if self.hash_mode == "bn128":
+            self.p.merkle16_commit_bn254(d_cols, M, W, tree)
+        else:
+            self.p.merkle_commit(d_cols, M, W, tree)
+
+    def poseidon_bn254_perm17(self, state):
+        return self.p.poseidon_bn254_perm([state])[0]
 
     def sync(self):
         self.p.sync()
@@ -50,6 +67,8 @@ class HipBackend:
 
     # ---- commitments
     def _root(self, tree, M):
+        if self.hash_mode == "bn128":   # one field element: the last node of the 16-ary tree
+            return self.p._fr_ints(self.p.download(tree, (4,), offset_elems=(self.p.merkle16_nodes(M) - 1) * 4))
         return [int(v) for v in self.p.download(tree, (4,), offset_elems=(2 * M - 2) * 4)]
 
     def _uploader(self):
@@ -81,9 +100,9 @@ class HipBackend:
         M = 1 << (logn + logb)
         d_tr = trace if isinstance(trace, native.DeviceBuffer) else self.p.upload(trace)
         ext, coef = self.p.alloc((W + extra_cols) * M), self.p.alloc((W + extra_cols) << logn)
-        tree = self.p.alloc((2 * M - 1) * 4)
+        tree = self._tree_alloc(M)
         self.p.lde(d_tr, ext, logn, logb, W, self.shift, d_coef=coef)
-        self.p.merkle_commit(ext, M, W, tree)
+        self._commit(ext, M, W, tree)
         c = Commit(self._root(tree, M), tree, ext, coef)
         if extra_cols:
             c.trace, c.W = d_tr, W   # stage 2 reads witness columns
@@ -107,16 +126,16 @@ class HipBackend:
                 self.p.logup_columns(col("a"), col("t"), col("m"), N, chal, d_s2.offset(at * N))
             at += air_mod.STAGE2_WIDTH[st["kind"]]
         self.p.lde(d_s2, c1.ext.offset(W * M), logn, logb, W2, self.shift, d_coef=c1.coef.offset(W * N))
-        tree = self.p.alloc((2 * M - 1) * 4)
-        self.p.merkle_commit(c1.ext.offset(W * M), M, W2, tree)
+        tree = self._tree_alloc(M)
+        self._commit(c1.ext.offset(W * M), M, W2, tree)
         self.p.sync()
         d_s2.free()
         c1.trace.free()
         return Commit(self._root(tree, M), tree)
 
     def commit_cols(self, d_cols, M, W):
-        tree = self.p.alloc((2 * M - 1) * 4)
-        self.p.merkle_commit(d_cols, M, W, tree)
+        tree = self._tree_alloc(M)
+        self._commit(d_cols, M, W, tree)
         return Commit(self._root(tree, M), tree)
 
     def fixed_ext(self, logn, logb):
@@ -208,6 +227,8 @@ class HipBackend:
         return self.p.gather_rows(d_cols, M, W, idx)
 
     def open_paths(self, tree, M, idx):
+        if self.hash_mode == "bn128":   # per query: per level the 16 digests of the group on the path
+            return [self.p.merkle16_open_bn254(tree, M, int(i)) for i in idx]
         return self.p.merkle_open_batch(tree, M, idx)
 
     # ---- N6 (Groth16 wrap)

@@ -12,7 +12,7 @@ import time
 
 from . import air as air_mod
 from . import field as F
-from .transcript import Transcript
+from .transcript import Transcript, TranscriptBN128
 
 P = F.P
 
@@ -22,17 +22,26 @@ class StarkParams:
     rejects a far word with probability 1 - 2^-logb, and the prover must grind pow_bits of Poseidon work before it
     learns the query positions.  The service default (engine.EngineConfig) is 80 queries, blow-up 2, 20 bits = 100."""
 
-    def __init__(self, logn, logb=1, fri_logf=3, fri_final_log=6, n_queries=24, pow_bits=0):
+    def __init__(self, logn, logb=1, fri_logf=3, fri_final_log=6, n_queries=24, pow_bits=0, hash="gl"):
+        """hash: "gl" = Poseidon over Goldilocks, binary Merkle trees (chunk / recursion STARKs);  "bn128" = Poseidon over the
+        BN254 scalar field, 16-ary trees, transcript over the same field (the last STARK before the Groth16 wrap)."""
+        assert hash in ("gl", "bn128")
+        assert hash == "gl" or pow_bits == 0, "the grinding hash is Goldilocks-Poseidon: BN128 mode takes its bits from queries"
         self.logn, self.logb = logn, logb
         self.fri_logf, self.fri_final_log, self.n_queries, self.pow_bits = fri_logf, fri_final_log, n_queries, pow_bits
+        self.hash = hash
 
     def to_dict(self):
-        return dict(logn=self.logn, logb=self.logb, fri_logf=self.fri_logf, fri_final_log=self.fri_final_log,
-                    n_queries=self.n_queries, pow_bits=self.pow_bits)
+        d = dict(logn=self.logn, logb=self.logb, fri_logf=self.fri_logf, fri_final_log=self.fri_final_log,
+                 n_queries=self.n_queries, pow_bits=self.pow_bits)
+        if self.hash != "gl":
+            d["hash"] = self.hash
+        return d
 
     @staticmethod
     def from_dict(d):
-        return StarkParams(d["logn"], d["logb"], d["fri_logf"], d["fri_final_log"], d["n_queries"], d.get("pow_bits", 0))
+        return StarkParams(d["logn"], d["logb"], d["fri_logf"], d["fri_final_log"], d["n_queries"], d.get("pow_bits", 0),
+                           d.get("hash", "gl"))
 
     def security_bits(self):
         return self.n_queries * self.logb + self.pow_bits
@@ -73,16 +82,19 @@ def prove(air, trace, pubs, params, be, timings=None):
     W2 = air.width2
     assert len(pubs) == air.n_pub
     # every parameter the verifier relies on is bound into the transcript (a proof cannot choose its own security level)
-    tr = Transcript(be.poseidon_perm)
+    bn = params.hash == "bn128"
+    assert getattr(be, "hash_mode", "gl") == params.hash, "backend and parameters disagree on the hash mode"
+    tr = TranscriptBN128(be.poseidon_bn254_perm17) if bn else Transcript(be.poseidon_perm)
     tr.absorb([logn, logb, W, W2, params.fri_logf, params.fri_final_log, params.n_queries, params.pow_bits,
                int(root32), int(shift)] + air.digest_words() + [len(pubs)] + _ints(pubs))
+    root_out = (lambda r: [str(int(r[0]))]) if bn else _ints      # a BN128 root is one 254-bit field element
 
     # 1. commit the trace
     t0 = time.perf_counter()
     Wt = W + W2                      # committed base columns: trace, then the stage-2 columns
     c1 = be.commit_trace(trace, logn, logb, W2)
     tick("lde+merkle(trace)", t0)
-    tr.absorb(c1.root)
+    tr.absorb_root(c1.root)
     chal, c2 = [], None
     if air.stage2:
         # stage 2: a challenge that depends on the first commitment, then the grand-product column
@@ -90,7 +102,7 @@ def prove(air, trace, pubs, params, be, timings=None):
         chal = tr.challenge_e3()
         c2 = be.commit_stage2(air, c1, chal, logn, logb)
         tick("grand-product+lde+merkle(stage2)", t0)
-        tr.absorb(c2.root)
+        tr.absorb_root(c2.root)
     alpha = tr.challenge_e3()
 
     # 2. constraint quotient on the coset, committed as 3 base columns
@@ -120,7 +132,7 @@ def prove(air, trace, pubs, params, be, timings=None):
         cq = be.commit_cols(d_q, M, 3 * Q)
         q_logn, Wq = logn, 3 * Q
     tick("merkle+intt(quotient)", t0)
-    tr.absorb(cq.root)
+    tr.absorb_root(cq.root)
     zeta = tr.challenge_e3()
 
     # 3. out-of-domain evaluations
@@ -151,7 +163,7 @@ def prove(air, trace, pubs, params, be, timings=None):
     d_layer = d_f
     for (lg, f) in sched:
         com = be.commit_cols(d_layer, 1 << (lg - f), 3 << f)   # leaf = the 2^f * 3 values folded together
-        tr.absorb(com.root)
+        tr.absorb_root(com.root)
         beta = tr.challenge_e3()
         d_next = be.fri_fold(d_layer, lg, f, beta, cur_shift)
         layers.append((lg, f, com, d_layer))
@@ -188,22 +200,26 @@ def prove(air, trace, pubs, params, be, timings=None):
         pos = rows
     tick("queries", t0)
 
+    if bn:    # a BN128 path: per level the 16 digests of the group (decimal strings: 254-bit values)
+        _path = lambda pth: [[str(int(v)) for v in lvl] for lvl in pth]
+    else:
+        _path = lambda pth: [_ints(x) for x in pth]
     queries = []
     for i, j in enumerate(qidx):
         queries.append({
             "index": int(j),
-            "trace": {"values": _ints(q_trace_vals[i]), "path": [_ints(x) for x in q_trace_paths[i]]},
-            "quotient": {"values": _ints(q_q_vals[i]), "path": [_ints(x) for x in q_q_paths[i]]},
-            **({"stage2": {"values": _ints(q_s2_vals[i]), "path": [_ints(x) for x in q_s2_paths[i]]}} if c2 is not None else {}),
-            "fri": [{"values": _ints(fo[1][i]), "path": [_ints(x) for x in fo[2][i]]} for fo in fri_open],
+            "trace": {"values": _ints(q_trace_vals[i]), "path": _path(q_trace_paths[i])},
+            "quotient": {"values": _ints(q_q_vals[i]), "path": _path(q_q_paths[i])},
+            **({"stage2": {"values": _ints(q_s2_vals[i]), "path": _path(q_s2_paths[i])}} if c2 is not None else {}),
+            "fri": [{"values": _ints(fo[1][i]), "path": _path(fo[2][i])} for fo in fri_open],
         })
     proof = {
         "air": air.name, "air_digest": air.digest(), "params": params.to_dict(),
         "root32": int(root32), "shift": int(shift),
         "publics": _ints(pubs),
-        "roots": {"trace": _ints(c1.root), "quotient": _ints(cq.root), **({"stage2": _ints(c2.root)} if c2 is not None else {})},
+        "roots": {"trace": root_out(c1.root), "quotient": root_out(cq.root), **({"stage2": root_out(c2.root)} if c2 is not None else {})},
         "evals": {"z": ev_all, "zw": ev_next},
-        "fri": {"roots": [_ints(l[2].root) for l in layers], "final": final_l},
+        "fri": {"roots": [root_out(l[2].root) for l in layers], "final": final_l},
         "queries": queries,
         **({"pow_nonce": pow_nonce} if pow_nonce is not None else {}),
     }

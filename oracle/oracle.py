@@ -24,7 +24,7 @@ _u64p = C.POINTER(C.c_uint64)
 
 def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(
-            os.path.getmtime(os.path.join(_HERE, f)) for f in ("gl_oracle.c", "bn254_gen.c")):
+            os.path.getmtime(os.path.join(_HERE, f)) for f in ("gl_oracle.c", "bn254_gen.c", "bn254_hash.c")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -82,6 +82,16 @@ def lib():
         L.orc_set_simple_ntt.argtypes = [i32]
         L.orc_num_threads.restype = i32
         L.orc_set_threads.argtypes = [i32]
+        L.orc_p254_set.restype = i32
+        L.orc_p254_set.argtypes = [i32, i32, _u64p, _u64p]
+        L.orc_p254_perm.restype = i32
+        L.orc_p254_perm.argtypes = [_u64p, sz, i32]
+        L.orc_merkle16_nodes.restype = sz
+        L.orc_merkle16_nodes.argtypes = [sz]
+        L.orc_merkle16_tree.restype = i32
+        L.orc_merkle16_tree.argtypes = [_u64p, sz, i32, _u64p]
+        L.orc_merkle16_leaf.restype = i32
+        L.orc_merkle16_leaf.argtypes = [_u64p, sz, _u64p]
         _lib = L
     return _lib
 
@@ -286,3 +296,57 @@ def random_field(shape, seed):
         a[bad] = rng.integers(0, 2 ** 64, size=int(bad.sum()), dtype=np.uint64, endpoint=False)
         bad = a >= np.uint64(P)
     return a
+
+
+# ---- BN128-hash mode (oracle/bn254_hash.c): field elements are Python ints < r here, 4-word arrays at the C boundary
+def _fr_words(vals):
+    a = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        v = int(v)
+        for k in range(4):
+            a[i, k] = (v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return a
+
+
+def _fr_ints(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+    return [sum(int(a[i, k]) << (64 * k) for k in range(4)) for i in range(a.shape[0])]
+
+
+def p254_set(t, rp, rc, mds):
+    """install the tables of width t (3 or 17): rc = (8 + rp) * t ints round-major, mds = t x t (nested lists or flat)"""
+    flat = [v for row in mds for v in row] if isinstance(mds[0], (list, tuple)) else list(mds)
+    rcw, mw = _fr_words(rc), _fr_words(flat)
+    if lib().orc_p254_set(t, rp, _p(rcw), _p(mw)) != 0:
+        raise ValueError("bad Poseidon-BN254 tables")
+
+
+def p254_perm(states, t):
+    """list of states (t ints each) -> permuted states"""
+    a = _fr_words([v for st in states for v in st])
+    if lib().orc_p254_perm(_p(a), len(states), t) != 0:
+        raise ValueError("Poseidon-BN254 tables of width %d not installed" % t)
+    out = _fr_ints(a)
+    return [out[i * t:(i + 1) * t] for i in range(len(states))]
+
+
+def merkle16_nodes(M):
+    return int(lib().orc_merkle16_nodes(M))
+
+
+def merkle16_tree(cols):
+    """cols uint64 [W][M] -> uint64 [nodes][4]: leaves, then each level, root last"""
+    a = _arr(cols)
+    W, M = a.shape
+    tree = np.empty((merkle16_nodes(M), 4), dtype=np.uint64)
+    if lib().orc_merkle16_tree(_p(a), M, W, _p(tree)) != 0:
+        raise ValueError("Poseidon-BN254 tables (t = 17) not installed")
+    return tree
+
+
+def merkle16_leaf(row):
+    a = _arr(row).reshape(-1)
+    out = np.empty(4, dtype=np.uint64)
+    if lib().orc_merkle16_leaf(_p(a), a.size, _p(out)) != 0:
+        raise ValueError("Poseidon-BN254 tables (t = 17) not installed")
+    return _fr_ints(out)[0]

@@ -18,10 +18,27 @@ class Commit:
 
 
 class CpuBackend:
-    def __init__(self, rc, mds, root32=O.ROOT32_DEFAULT, shift=O.SHIFT_DEFAULT):
+    def __init__(self, rc, mds, root32=O.ROOT32_DEFAULT, shift=O.SHIFT_DEFAULT, hash_mode="gl", bn_tables=None):
+        """hash_mode "bn128": 16-ary Poseidon-BN254 trees and transcript permutation (oracle/bn254_hash.c); bn_tables =
+        (rc, mds, rp) of the t = 17 instance -- configuration, handed in by the caller like the Goldilocks tables"""
         self.rc, self.mds = np.asarray(rc, dtype=np.uint64), np.asarray(mds, dtype=np.uint64)
         self.root32, self.shift = root32, shift
         self._fixed = {}
+        self.hash_mode = hash_mode
+        if hash_mode == "bn128":
+            O.p254_set(17, bn_tables[2], bn_tables[0], bn_tables[1])
+
+    # ---- Merkle trees of the configured hash mode: (root, tree)
+    def _tree(self, mat):
+        mat = np.ascontiguousarray(mat)
+        if self.hash_mode == "bn128":
+            tree = O.merkle16_tree(mat)
+            return [O._fr_ints(tree[-1])[0]], tree
+        tree = O.merkle_commit(mat, self.rc, self.mds)
+        return [int(v) for v in tree[-1]], tree
+
+    def poseidon_bn254_perm17(self, state):
+        return O.p254_perm([state], 17)[0]
 
     def sync(self):
         pass
@@ -32,11 +49,11 @@ class CpuBackend:
     def commit_trace(self, trace, logn, logb, extra_cols=0):
         W = trace.shape[0]
         e1 = O.lde(trace, logb, self.shift, self.root32)
-        tree = O.merkle_commit(e1, self.rc, self.mds)
+        root, tree = self._tree(e1)
         ext = np.zeros((W + extra_cols, e1.shape[1]), dtype=np.uint64)
         coef = np.zeros((W + extra_cols, trace.shape[1]), dtype=np.uint64)
         ext[:W], coef[:W] = e1, self._scaled_coef(trace)
-        c = Commit([int(v) for v in tree[-1]], tree, ext, coef)
+        c = Commit(root, tree, ext, coef)
         c.trace, c.W = trace, W
         return c
 
@@ -58,13 +75,13 @@ class CpuBackend:
         z = np.ascontiguousarray(np.concatenate(parts, axis=0))
         c1.ext[W:] = O.lde(z, logb, self.shift, self.root32)
         c1.coef[W:] = self._scaled_coef(z)
-        tree = O.merkle_commit(np.ascontiguousarray(c1.ext[W:]), self.rc, self.mds)
-        return Commit([int(v) for v in tree[-1]], tree)
+        root, tree = self._tree(c1.ext[W:])
+        return Commit(root, tree)
 
     def commit_cols(self, cols, M, W):
         mat = np.ascontiguousarray(np.asarray(cols).reshape(W, M))
-        tree = O.merkle_commit(mat, self.rc, self.mds)
-        return Commit([int(v) for v in tree[-1]], tree)
+        root, tree = self._tree(mat)
+        return Commit(root, tree)
 
     def fixed_ext(self, logn, logb):
         key = (logn, logb)
@@ -123,6 +140,16 @@ class CpuBackend:
         return np.ascontiguousarray(mat[:, np.asarray(idx, dtype=np.int64)].T)
 
     def open_paths(self, tree, M, idx):
+        if self.hash_mode == "bn128":       # per level the 16 digests of the group on the path (missing children = 0)
+            out = []
+            for j in idx:
+                n, off, pos, lv = M, 0, int(j), []
+                while n > 1:
+                    g0 = (pos // 16) * 16
+                    lv.append([O._fr_ints(tree[off + g0 + c])[0] if g0 + c < n else 0 for c in range(16)])
+                    off, n, pos = off + n, (n + 15) // 16, pos // 16
+                out.append(lv)
+            return out
         depth = int(M).bit_length() - 1
         out = np.zeros((len(idx), depth, 4), dtype=np.uint64)
         for i, j in enumerate(idx):

@@ -52,6 +52,63 @@ class Sponge:
         return out
 
 
+R_BN254 = NV.BN254_R
+
+
+class SpongeBN128:
+    """BN128-hash mode: Poseidon-BN254 sponge of width 17 (element 0 = capacity, 1..16 = rate).  absorb() packs Goldilocks
+    values three to a field element (a + b 2^64 + c 2^128, each call padded separately), absorb_root() queues a root (one
+    field element); squeeze() absorbs the queue in blocks of 16 overwriting the rate (one permutation even when empty) and
+    hands out the three low 64-bit words of each rate element, reduced mod p."""
+
+    def __init__(self, perm17):
+        self.perm, self.state, self.queue, self.avail = perm17, [0] * 17, [], []
+
+    def absorb(self, vals):
+        v = [int(x) % P for x in vals]
+        v += [0] * (-len(v) % 3)
+        self.queue.extend(v[i] | (v[i + 1] << 64) | (v[i + 2] << 128) for i in range(0, len(v), 3))
+        self.avail = []
+
+    def absorb_root(self, root):
+        if len(root) != 1 or not 0 <= int(root[0]) < R_BN254:
+            raise Reject("malformed BN128 root")
+        self.queue.append(int(root[0]))
+        self.avail = []
+
+    def squeeze(self, n):
+        out = []
+        while len(out) < n:
+            if self.queue or not self.avail:
+                if not self.queue:
+                    self.state = self.perm(self.state)
+                while self.queue:
+                    blk = self.queue[:16]
+                    del self.queue[:16]
+                    self.state = self.perm([self.state[0]] + blk + [0] * (16 - len(blk)))
+                self.avail = [((e >> s) & 0xFFFFFFFFFFFFFFFF) % P for e in self.state[1:] for s in (0, 64, 128)]
+            out.append(self.avail.pop(0))
+        return out
+
+
+def merkle16_verify(leaf_digest, M, index, path, root):
+    """path: per level the 16 digests of the group; the digest computed so far must sit at its position in the group"""
+    n, pos, cur = M, int(index), int(leaf_digest)
+    levels = 0
+    while n > 1:
+        if levels >= len(path) or len(path[levels]) != 16:
+            return False
+        grp = [int(v) for v in path[levels]]
+        if any(not 0 <= v < R_BN254 for v in grp) or grp[pos % 16] != cur:
+            return False
+        g0 = (pos // 16) * 16
+        if any(grp[c] != 0 for c in range(16) if g0 + c >= n):      # children beyond the level are zero
+            return False
+        cur = O.p254_perm([[0] + grp], 17)[0][0]
+        n, pos, levels = (n + 15) // 16, pos // 16, levels + 1
+    return levels == len(path) and cur == int(root)
+
+
 def fri_schedule(logn, logb, fri_logf, fri_final_log):
     """[(log size of the committed layer, log fold factor)], log size of the final layer sent in clear"""
     cur, stop, sched = logn + logb, fri_final_log + logb, []
@@ -102,13 +159,16 @@ def expectation(params, root32=NV.ROOT32_DEFAULT, shift=NV.SHIFT_DEFAULT):
     """the verifier's parameter set from a plain dict of protocol parameters (+ the evaluation-domain constants)"""
     e = {k: int(params[k]) for k in PARAM_KEYS if k in params}
     e.setdefault("pow_bits", 0)
+    if params.get("hash", "gl") != "gl":
+        e["hash"] = params["hash"]
     e["root32"], e["shift"] = int(root32), int(shift)
     return e
 
 
-def verify(proof, program, rc, mds, expect):
+def verify(proof, program, rc, mds, expect, bn_tables=None):
     """program: the constraint program blob (u64 words) of the statement;  expect: the verifier's own parameters
-    {logn, logb, fri_logf, fri_final_log, n_queries, pow_bits, root32, shift}."""
+    {logn, logb, fri_logf, fri_final_log, n_queries, pow_bits, root32, shift [, hash]}.  hash = "bn128": the proof must be in
+    BN128-hash mode (16-ary Poseidon-BN254 trees + transcript); bn_tables = (rc, mds, rp) of the t = 17 instance."""
     rc = np.asarray(rc, dtype=np.uint64)
     mds = np.asarray(mds, dtype=np.uint64)
     air = program if isinstance(program, Program) else Program(program)
@@ -118,6 +178,13 @@ def verify(proof, program, rc, mds, expect):
     for k in PARAM_KEYS:
         if proof["params"].get(k) != expect[k]:
             raise Reject("proof claims %s = %r, the verifier requires %r" % (k, proof["params"].get(k), expect[k]))
+    bn = expect.get("hash", "gl") == "bn128"
+    if proof["params"].get("hash", "gl") != expect.get("hash", "gl"):
+        raise Reject("proof is in another hash mode")
+    if bn:
+        if expect["pow_bits"] != 0:
+            raise Reject("BN128 mode has no grinding")
+        O.p254_set(17, bn_tables[2], bn_tables[0], bn_tables[1])
     if proof["root32"] != expect["root32"] or proof["shift"] != expect["shift"]:
         raise Reject("proof is over another evaluation domain")
     if expect["n_queries"] < 1 or expect["logb"] < 1:
@@ -140,18 +207,31 @@ def verify(proof, program, rc, mds, expect):
 
     W2 = air.width2
     Wt = W + W2
-    tr = Sponge(perm)
+    if bn:
+        tr = SpongeBN128(lambda st: O.p254_perm([st], 17)[0])
+        absorb_root = lambda r: tr.absorb_root([int(v) for v in r])
+        as_root = lambda r: int(r[0])
+
+        def opening_ok(values, m, idx, path, root):
+            return merkle16_verify(O.merkle16_leaf(np.array(values, dtype=np.uint64)), m, idx, path, as_root(root))
+    else:
+        tr = Sponge(perm)
+        absorb_root = tr.absorb
+
+        def opening_ok(values, m, idx, path, root):
+            return bool(O.merkle_verify(O.linear_hash(np.array(values, dtype=np.uint64), rc, mds), m, idx, np.array(path, dtype=np.uint64),
+                                        np.array(root, dtype=np.uint64), rc, mds))
     tr.absorb([logn, logb, W, W2, expect["fri_logf"], expect["fri_final_log"], n_queries, pow_bits, root32, shift]
               + air.digest_words() + [len(pubs)] + pubs)
-    tr.absorb(proof["roots"]["trace"])
+    absorb_root(proof["roots"]["trace"])
     chal = []
     if air.stage2:
         if "stage2" not in proof["roots"]:
             raise Reject("missing stage-2 commitment")
         chal = tr.squeeze(3)
-        tr.absorb(proof["roots"]["stage2"])
+        absorb_root(proof["roots"]["stage2"])
     alpha = tr.squeeze(3)
-    tr.absorb(proof["roots"]["quotient"])
+    absorb_root(proof["roots"]["quotient"])
     zeta = tr.squeeze(3)
     ev_all, ev_next = proof["evals"]["z"], proof["evals"]["zw"]
     Q = air.q_chunks                 # the quotient is committed as Q pieces of degree < N, 3 base columns each
@@ -191,7 +271,7 @@ def verify(proof, program, rc, mds, expect):
         raise Reject("wrong number of FRI layers")
     betas = []
     for root in proof["fri"]["roots"]:
-        tr.absorb(root)
+        absorb_root(root)
         betas.append(tr.squeeze(3))
     final = proof["fri"]["final"]
     if len(final) != 3 or any(len(pl) != (1 << final_log) for pl in final):
@@ -231,11 +311,9 @@ def verify(proof, program, rc, mds, expect):
         tv, qv = qq["trace"]["values"], qq["quotient"]["values"]
         if len(tv) != W or len(qv) != 3 * Q:
             raise Reject("bad opening width")
-        if not O.merkle_verify(O.linear_hash(np.array(tv, dtype=np.uint64), rc, mds), M, j, np.array(qq["trace"]["path"], dtype=np.uint64),
-                               np.array(proof["roots"]["trace"], dtype=np.uint64), rc, mds):
+        if not opening_ok(tv, M, j, qq["trace"]["path"], proof["roots"]["trace"]):
             raise Reject("trace opening does not verify")
-        if not O.merkle_verify(O.linear_hash(np.array(qv, dtype=np.uint64), rc, mds), M, j, np.array(qq["quotient"]["path"], dtype=np.uint64),
-                               np.array(proof["roots"]["quotient"], dtype=np.uint64), rc, mds):
+        if not opening_ok(qv, M, j, qq["quotient"]["path"], proof["roots"]["quotient"]):
             raise Reject("quotient opening does not verify")
         s2v = []
         if air.stage2:
@@ -243,8 +321,7 @@ def verify(proof, program, rc, mds, expect):
             if s2 is None or len(s2["values"]) != W2:
                 raise Reject("missing stage-2 opening")
             s2v = s2["values"]
-            if not O.merkle_verify(O.linear_hash(np.array(s2v, dtype=np.uint64), rc, mds), M, j, np.array(s2["path"], dtype=np.uint64),
-                                   np.array(proof["roots"]["stage2"], dtype=np.uint64), rc, mds):
+            if not opening_ok(s2v, M, j, s2["path"], proof["roots"]["stage2"]):
                 raise Reject("stage-2 opening does not verify")
         x = shift * pow(wM, j, P) % P
         vals = tv + s2v + qv
@@ -266,8 +343,7 @@ def verify(proof, program, rc, mds, expect):
             lv = fo["values"]
             if len(lv) != (3 << f):
                 raise Reject("bad FRI leaf width")
-            if not O.merkle_verify(O.linear_hash(np.array(lv, dtype=np.uint64), rc, mds), m, row, np.array(fo["path"], dtype=np.uint64),
-                                   np.array(proof["fri"]["roots"][li], dtype=np.uint64), rc, mds):
+            if not opening_ok(lv, m, row, fo["path"], proof["fri"]["roots"][li]):
                 raise Reject("FRI opening does not verify (layer %d)" % li)
             pts = [[lv[c * (1 << f) + k] for c in range(3)] for k in range(1 << f)]
             if pts[k0] != expect:
