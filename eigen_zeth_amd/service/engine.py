@@ -33,7 +33,8 @@ class EngineConfig:
 
     def __init__(self, air="chunk64", logn=12, logb=1, chunks_per_block=1, n_queries=80, fri_logf=3, fri_final_log=5,
                  groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
-                 witness_threads=8, prover_streams=4, pow_bits=20):
+                 witness_threads=8, prover_streams=4, pow_bits=20,
+                 final_air="chunk16", final_logn=10, final_logb=2, final_queries=50):
         self.air, self.logn, self.logb = air, logn, logb
         self.chunks_per_block, self.n_queries, self.pow_bits = chunks_per_block, n_queries, pow_bits
         self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
@@ -41,6 +42,8 @@ class EngineConfig:
         self.l2_addr, self.txs_per_chunk = l2_addr, txs_per_chunk   # optional block-input fetcher
         self.witness_threads = witness_threads
         self.prover_streams = prover_streams   # chunk proofs in flight on one GPU (each on its own ctx / stream)
+        # the final STARK (BN128-hash mode, no grinding: 50 queries x blow-up 4 = 100 bits conjectured)
+        self.final_air, self.final_logn, self.final_logb, self.final_queries = final_air, final_logn, final_logb, final_queries
 
 
 class Engine:
@@ -48,6 +51,8 @@ class Engine:
         self._factories = list(backend_factory) if isinstance(backend_factory, (list, tuple)) else [backend_factory]
         self._factory = self._factories[0]
         self._be = None
+        self._be_bn = None        # backend of the final STARK (BN128-hash mode), created at the first GenFinalProof
+        self.final_starks = {}    # batch_id -> final STARK JSON of the most recent batches (inspection / tests)
         self.cfg = config or EngineConfig()
         self.stage_timings = {}
         self.metrics = None   # service/metrics.py Metrics, attached by serve()
@@ -67,6 +72,16 @@ class Engine:
         if self._be is None:
             self._be = self._factory()   # HipBackend(): raises without libzethprover.so / a GPU
         return self._be
+
+    @property
+    def be_bn128(self):
+        if self._be_bn is None:
+            self._be_bn = self._factory(hash_mode="bn128")
+        return self._be_bn
+
+    def final_stark_params(self):
+        return PR.StarkParams(self.cfg.final_logn, self.cfg.final_logb, self.cfg.fri_logf, min(self.cfg.fri_final_log, self.cfg.final_logn - 1),
+                              self.cfg.final_queries, 0, hash="bn128")
 
     def stark_params(self, logn=None):
         return PR.StarkParams(self.cfg.logn if logn is None else logn, self.cfg.logb, self.cfg.fri_logf, self.cfg.fri_final_log,
@@ -234,7 +249,22 @@ class Engine:
             raise ValueError("unsupported curve %r" % curve_name)
         if not recursive_proof:
             raise ValueError("empty recursive proof")
-        h = int(hashlib.sha256((recursive_proof + "|" + (aggregator_addr or "")).encode()).hexdigest(), 16)
+        # 1. the final STARK: BN128-hash mode (16-ary Poseidon-BN254 trees, transcript over the BN254 scalar field), the form a
+        #    Groth16 circuit over that field can verify.  The statement is a stand-in AIR whose witness is seeded by the
+        #    aggregated proof (the recursive-verifier AIR is not built); the wrap below binds its digest.
+        t0 = time.perf_counter()
+        fair = AIR.get_air(self.cfg.final_air)
+        seed = int(hashlib.sha256(recursive_proof.encode()).hexdigest()[:8], 16)
+        ftrace, fpubs = native.synth_trace(fair.trace_kind, self.cfg.final_logn, fair.width, seed)
+        fproof = PR.prove(fair, ftrace, fpubs, self.final_stark_params(), self.be_bn128)
+        final_stark = PR.proof_to_json(fproof)
+        t_fs = time.perf_counter() - t0
+        self.final_starks[batch_id] = final_stark
+        while len(self.final_starks) > 4:
+            self.final_starks.pop(next(iter(self.final_starks)))
+        fs_digest = hashlib.sha256(final_stark.encode()).hexdigest()
+        # 2. the Groth16 wrap
+        h = int(hashlib.sha256((fs_digest + "|" + recursive_proof + "|" + (aggregator_addr or "")).encode()).hexdigest(), 16)
         circ, pk, vk = self.groth16_keys()
         w = circ.witness(h % bn254.R)
         # fresh blinding per proof (zero knowledge); replays of a request are answered from the batch store (server.py),
@@ -242,8 +272,9 @@ class Engine:
         rnd = (int.from_bytes(os.urandom(32), "big") % bn254.R or 1, int.from_bytes(os.urandom(32), "big") % bn254.R or 1)
         t0 = time.perf_counter()
         proof, pub = groth16.prove(circ, pk, w, self.be.msm_g1, rnd, getattr(self.be, "msm_g2", None), self.be.qap_quotient)
-        self.stage_timings["final/" + batch_id] = {"groth16": time.perf_counter() - t0}
+        self.stage_timings["final/" + batch_id] = {"final_stark(bn128)": t_fs, "groth16": time.perf_counter() - t0}
         if self.metrics is not None:
             self.metrics.record_stage("groth16", self.stage_timings["final/" + batch_id]["groth16"])
-        js = groth16.proof_to_json(proof, {"circuit": "arithmetic-chain(logm=%d), local CRS -- stand-in for the recursive-verifier circuit" % circ.logm})
+        js = groth16.proof_to_json(proof, {"circuit": "arithmetic-chain(logm=%d), local CRS -- stand-in for the recursive-verifier circuit" % circ.logm,
+                                            "final_stark_sha256": fs_digest})
         return js, json.dumps([str(pub[0])])

@@ -188,9 +188,10 @@ def make_server(service, port=50061, host="127.0.0.1", max_workers=4):
 
 
 def default_backend_factory(device=0):
-    def make():
+    def make(hash_mode="gl"):
+        """hash_mode "bn128": the backend of the final STARK (16-ary Poseidon-BN254 trees, transcript over F_r)"""
         from ..stark.backend_hip import HipBackend
-        return HipBackend(device)   # raises without the HIP library / an MI355X: no CPU fallback
+        return HipBackend(device, hash_mode=hash_mode)   # raises without the HIP library / an MI355X: no CPU fallback
     return make
 
 

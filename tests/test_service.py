@@ -81,6 +81,7 @@ def test_reference_fixture_grammar():
 
 def _start(tmp_path, backend_factory, cfg=None):
     cfg = cfg or EngineConfig(air="wide8", logn=7, n_queries=6, fri_final_log=3, pow_bits=6)
+    cfg.final_logn, cfg.final_logb, cfg.final_queries = 6, 1, 5      # a small final STARK: the checker verifies it in Python
     cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
     engine = Engine(backend_factory, cfg)
     svc = ProverService(engine, BatchStore(str(tmp_path)))
@@ -91,8 +92,10 @@ def _start(tmp_path, backend_factory, cfg=None):
 
 @pytest.fixture()
 def cpu_factory(tables):
+    from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
     from oracle.stark_cpu import CpuBackend
-    return lambda: CpuBackend(*tables)
+    return lambda hash_mode="gl": CpuBackend(*tables, hash_mode=hash_mode,
+                                             bn_tables=bn254_poseidon_params(17) if hash_mode == "bn128" else None)
 
 
 def _check_result(res, tables, block, svc=None):
@@ -119,6 +122,15 @@ def _check_result(res, tables, block, svc=None):
         proof = {"pi_a": (pts[0], pts[1]), "pi_b": ((pts[2], pts[3]), (pts[4], pts[5])), "pi_c": (pts[6], pts[7])}
         assert GV.verify(vkp, proof, [pub])
         assert not GV.verify(vkp, proof, [(pub + 1) % bn254.R])
+        # ... and it names (by digest) a final STARK in BN128-hash mode that the independent verifier accepts
+        import hashlib
+        from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
+        fs = [v for v in svc.engine.final_starks.values() if hashlib.sha256(v.encode()).hexdigest() == json.loads(res["proof"])["final_stark_sha256"]]
+        assert len(fs) == 1
+        fsp = json.loads(fs[0])
+        assert fsp["params"]["hash"] == "bn128" and len(fsp["roots"]["trace"]) == 1
+        assert V.verify(fsp, AIR.get_air(fsp["air"]).program(), rc, mds, V.expectation(svc.engine.final_stark_params().to_dict()),
+                        bn254_poseidon_params(17))
     # ProofResult as eigen-zeth stores it (src/db/mod.rs:63-71): json with 32-number arrays
     stored = json.dumps({k: res[k] for k in ("block_number", "proof", "public_input", "pre_state_root", "post_state_root")})
     assert len(json.loads(stored)["pre_state_root"]) == 32
@@ -218,6 +230,8 @@ def test_round_trip_gpu_matches_cpu(tmp_path, cpu_factory, tables):
         # proofs carry fresh blinding (r, s) per proof, so they differ as group elements and both verify (above)
         assert {k: v for k, v in g.items() if k != "proof"} == {k: v for k, v in c.items() if k != "proof"}
         assert g["proof"] != c["proof"]
+        # the final STARKs (BN128-hash mode) behind the two wraps are the same bytes
+        assert json.loads(g["proof"])["final_stark_sha256"] == json.loads(c["proof"])["final_stark_sha256"]
         ch.close(); ch2.close()
     finally:
         server.stop(0); server2.stop(0)
