@@ -229,6 +229,22 @@ __global__ void __launch_bounds__(64) merkle16_level_kernel(const u64 *__restric
     }
 }
 
+// openings of nq leaves in one launch: out u64[nq][levels][16][4], per level the 16 digests of the group on the path (children
+// beyond the level read as zero)
+__global__ void __launch_bounds__(256) merkle16_paths_kernel(const u64 *__restrict__ tree, u64 M, int levels, const u64 *__restrict__ idx, int nq,
+                                                            u64 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (u64)nq * levels * 64) return;
+    const int word = (int)(i & 3), child = (int)((i >> 2) & 15);
+    const u64 ql = i >> 6;
+    const int lvl = (int)(ql % levels);
+    const u64 q = ql / levels;
+    u64 n = M, off = 0, pos = idx[q];
+    for (int l = 0; l < lvl; l++) { off += n; n = (n + 15) / 16; pos /= 16; }
+    const u64 c = (pos / 16) * 16 + child;
+    out[i] = c < n ? tree[(off + c) * 4 + word] : 0ULL;
+}
+
 int32_t table_for(zp_ctx *ctx, int t, P254Table **out) {
     P254Table *tb = t == 3 ? &g_tables[0] : t == 17 ? &g_tables[1] : nullptr;
     ZP_ARG(ctx, tb != nullptr, "Poseidon-BN254 width must be 3 or 17");
@@ -453,6 +469,29 @@ int32_t zp_merkle16_open_bn254(zp_ctx *ctx, const uint64_t *d_tree, size_t M, si
         pos /= 16;
         lvl++;
     }
+    return ZP_OK;
+}
+
+// the same for nq leaves at once (one gather kernel, one copy): h_paths u64[nq][levels][16][4]
+int32_t zp_merkle16_open_batch_bn254(zp_ctx *ctx, const uint64_t *d_tree, size_t M, const uint64_t *h_idx, int32_t nq, uint64_t *h_paths) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
+    ZP_ARG(ctx, M >= 1 && nq >= 0, "bad sizes");
+    int levels = 0;
+    for (size_t n = M; n > 1; n = (n + 15) / 16) levels++;
+    if (nq == 0 || levels == 0) return ZP_OK;
+    ZP_ARG(ctx, d_tree && h_idx && h_paths, "null pointer");
+    for (int i = 0; i < nq; i++) ZP_ARG(ctx, h_idx[i] < M, "leaf index out of range");
+    const u64 total = (u64)nq * levels * 64;
+    u64 *d = nullptr;
+    ZP_TRY(zpi_scratch(ctx, 3, (size_t)nq + total, &d));
+    ZP_TRY(zpi_h2d_small(ctx, d, h_idx, (size_t)nq * 8));
+    hipLaunchKernelGGL(merkle16_paths_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const u64 *)d_tree, (u64)M, levels, d,
+                       (int)nq, d + nq);
+    ZP_HIP(ctx, hipGetLastError());
+    if (total * 8 <= ZP_SMALL_COPY) return zpi_d2h_small(ctx, h_paths, d + nq, total * 8);
+    ZP_HIP(ctx, hipMemcpyAsync(h_paths, d + nq, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZP_OK;
 }
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "zp_merkle16_nodes": (C.c_size_t, [C.c_size_t]),
     "zp_merkle16_commit_bn254": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp]),
     "zp_merkle16_open_bn254": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _vp]),
+    "zp_merkle16_open_batch_bn254": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, C.c_int32, _vp]),
     "zp_ntt_bn254": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
     "zp_qap_quotient_bn254": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "zp_pack_blocks": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int32]),
@@ -379,6 +380,17 @@ class Prover:
         out = np.zeros((max(levels, 1), 16, 4), dtype=np.uint64)
         self._chk(self.lib.zp_merkle16_open_bn254(self.ctx, _ptr(d_tree), M, idx, out.ctypes.data))
         return [self._fr_ints(out[l]) for l in range(levels)]
+
+    def merkle16_open_batch_bn254(self, d_tree, M, idx):
+        """-> per query: per level the 16 digests (ints) of the group on the path"""
+        levels, n = 0, M
+        while n > 1:
+            n = (n + 15) // 16
+            levels += 1
+        ii = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64))
+        out = np.zeros((len(ii), max(levels, 1), 16, 4), dtype=np.uint64)
+        self._chk(self.lib.zp_merkle16_open_batch_bn254(self.ctx, _ptr(d_tree), M, ii.ctypes.data, len(ii), out.ctypes.data))
+        return [[self._fr_ints(out[q, l]) for l in range(levels)] for q in range(len(ii))]
 
     def ntt_bn254(self, d_data, logn, inverse=False, coset=None):
         """in-place NTT over the BN254 scalar field on d_data u64[2^logn][4]; coset: int g or None"""

@@ -228,7 +228,7 @@ class HipBackend:
 
     def open_paths(self, tree, M, idx):
         if self.hash_mode == "bn128":   # per query: per level the 16 digests of the group on the path
-            return [self.p.merkle16_open_bn254(tree, M, int(i)) for i in idx]
+            return self.p.merkle16_open_batch_bn254(tree, M, idx)
         return self.p.merkle_open_batch(tree, M, idx)
 
     # ---- N6 (Groth16 wrap)

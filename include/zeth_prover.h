@@ -134,6 +134,8 @@ int32_t zp_poseidon_bn254_perm(zp_ctx *ctx, uint64_t *d_states, size_t count, in
 size_t zp_merkle16_nodes(size_t M);
 int32_t zp_merkle16_commit_bn254(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, uint64_t *d_tree);
 int32_t zp_merkle16_open_bn254(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx, uint64_t *h_path);
+/* nq openings in one launch: h_paths u64[nq][levels][16][4] (levels = ceil(log16 M)) */
+int32_t zp_merkle16_open_batch_bn254(zp_ctx *ctx, const uint64_t *d_tree, size_t M, const uint64_t *h_idx, int32_t nq, uint64_t *h_paths);
 
 /* ---- Groth16 wrap, QAP step: NTT over the BN254 scalar field F_r (serves GenFinalProof, prover.proto:130-148 /
  * provider.rs:472-503; the G1/G2 multi-scalar multiplications are zp_msm_bn254* below).

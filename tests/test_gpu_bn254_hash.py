@@ -66,3 +66,17 @@ def test_tables_must_be_installed_and_reduced(prover):
         prover._chk(prover.lib.zp_set_poseidon_bn254(prover.ctx, 3, rp, bad.ctypes.data, mw.ctypes.data))
     with pytest.raises(native.ZpError):
         prover._chk(prover.lib.zp_set_poseidon_bn254(prover.ctx, 5, rp, mw.ctypes.data, mw.ctypes.data))
+
+
+def test_merkle16_batch_openings_equal_single_openings(prover):
+    import numpy as np
+    prover.install_poseidon_bn254(17)
+    rng = np.random.default_rng(3)
+    for M, W in ((1, 4), (16, 3), (17, 5), (300, 7), (4096, 9)):
+        cols = rng.integers(0, 1 << 63, size=(W, M), dtype=np.uint64)
+        d = prover.upload(cols)
+        tree = prover.alloc(prover.merkle16_nodes(M) * 4)
+        prover.merkle16_commit_bn254(d, M, W, tree)
+        idx = sorted(set([0, M - 1, M // 2] + [int(v) for v in rng.integers(0, M, size=5)]))
+        batch = prover.merkle16_open_batch_bn254(tree, M, idx)
+        assert batch == [prover.merkle16_open_bn254(tree, M, i) for i in idx]
