@@ -154,6 +154,44 @@ __global__ void __launch_bounds__(64) poseidon_perm_small_kernel(u64 *states, in
     if (on) states[(size_t)perm * 12 + e] = gl_canon(s);
 }
 
+// The Fiat-Shamir sponge as ONE launch: buf = [12 state words][nblocks x 8 block words][(1 + extra) x 8 rate words out].
+// For every block: the rate (state[0..8)) is overwritten with the block, then one permutation (no block: one permutation);
+// then `extra` further permutations, the rate after each of the 1 + extra steps is written out.  Same 12-lanes-per-state form
+// as above: a transcript of k permutations costs one host round trip instead of k.
+__global__ void __launch_bounds__(64) poseidon_sponge_kernel(u64 *buf, int nblocks, int extra, const u64 *rc, const u32 *mds) {
+    __shared__ u64 sh[12];
+    const int e = threadIdx.x;
+    const bool on = e < 12;
+    u64 s = on ? buf[e] : 0ULL;
+    u64 *rates = buf + 12 + (size_t)nblocks * 8;
+    const int absorb = nblocks > 0 ? nblocks : 1;
+    for (int b = 0; b < absorb + extra; b++) {
+        if (b < nblocks && e < 8) s = buf[12 + (size_t)b * 8 + e];
+        for (int r = 0; r < 30; r++) {
+            s = gl_add_weak(s, rc[r * 12 + (on ? e : 0)]);
+            if (r < 4 || r >= 26 || e == 0) s = sbox7(s);
+            if (on) sh[e] = s;
+            __syncthreads();
+            u64 alo = 0, ahi = 0;
+            if (on) {
+#pragma unroll
+                for (int j = 0; j < 12; j++) {
+                    const u64 v = sh[j];
+                    const u32 m = mds[e * 12 + j];
+                    alo += (u64)m * (u32)v;
+                    ahi += (u64)m * (u32)(v >> 32);
+                }
+            }
+            __syncthreads();
+            const u64 mid = (alo >> 32) + ahi;
+            s = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
+        }
+        s = gl_canon(s);
+        if (b >= absorb - 1 && e < 8) rates[(size_t)(b - (absorb - 1)) * 8 + e] = s;
+    }
+    if (on) buf[e] = s;
+}
+
 // proof-of-work grinding (before the query phase of a STARK): lane = candidate nonce base + gid; a hit is a nonce with
 // Poseidon(seed[0..3] || nonce || 0^7)[0] >> (64 - bits) == 0; the smallest hit of the batch wins (atomicMin).
 template <bool DEFMDS>
@@ -408,6 +446,32 @@ int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count) {
         hipLaunchKernelGGL(poseidon_perm_kernel<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream,
                            (u64 *)d_states, count, ctx->d_rc, ctx->d_mds);
     ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}
+
+int32_t zp_poseidon_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "poseidon_sponge");
+    ZP_ARG(ctx, h_state && h_rates && (h_blocks || nblocks == 0), "null pointer");
+    ZP_ARG(ctx, nblocks <= 65536 && extra <= 65536, "too many blocks");
+    for (int i = 0; i < 12; i++) ZP_ARG(ctx, h_state[i] < GL_P, "state not canonical");
+    for (size_t i = 0; i < nblocks * 8; i++) ZP_ARG(ctx, h_blocks[i] < GL_P, "block not canonical");
+    ZP_TRY(zpi_poseidon_sync_tables(ctx));
+    const size_t nin = 12 + nblocks * 8, nout = (1 + extra) * 8;
+    u64 *d = nullptr;
+    ZP_TRY(zpi_scratch(ctx, 3, nin + nout, &d));
+    std::vector<u64> in(nin);
+    memcpy(in.data(), h_state, 96);
+    if (nblocks) memcpy(in.data() + 12, h_blocks, nblocks * 64);
+    ZP_TRY(zpi_h2d_small(ctx, d, in.data(), nin * 8));
+    hipLaunchKernelGGL(poseidon_sponge_kernel, dim3(1), dim3(64), 0, ctx->stream, d, (int)nblocks, (int)extra, ctx->d_rc, ctx->d_mds);
+    ZP_HIP(ctx, hipGetLastError());
+    std::vector<u64> out(12 + nout);
+    // state and rates are not adjacent (the blocks sit between them): two small copies
+    ZP_TRY(zpi_d2h_small(ctx, out.data(), d, 96));
+    ZP_TRY(zpi_d2h_small(ctx, out.data() + 12, d + nin, nout * 8));
+    memcpy(h_state, out.data(), 96);
+    memcpy(h_rates, out.data() + 12, nout * 8);
     return ZP_OK;
 }
 

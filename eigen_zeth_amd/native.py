@@ -57,6 +57,7 @@ SIGNATURES = {
     "zp_lde": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_poseidon_perm": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "zp_pow_grind": (C.c_int32, [_vp, _vp, C.c_int32, _vp]),
+    "zp_poseidon_sponge": (C.c_int32, [_vp, _u64p, _u64p, C.c_size_t, C.c_size_t, _u64p]),
     "zp_deep_quotient_rows": (C.c_int32, [_vp, _vp, C.c_int32, C.c_size_t, _vp, C.c_int32, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, C.c_int32,
                                           _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, C.c_size_t]),
     "zp_eval_quotient_rows": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_size_t, C.c_size_t,
@@ -419,6 +420,15 @@ class Prover:
         ms = C.c_float(0)
         self._chk(self.lib.zp_hbm_copy_probe(self.ctx, _ptr(d_src), _ptr(d_dst), nbytes, reps, C.byref(ms)))
         return float(ms.value)
+
+    def poseidon_sponge(self, state, blocks, extra=0):
+        """state: 12 ints, blocks: list of 8-int blocks -> (new state, [rate after absorbing, rate after each extra permutation])"""
+        st = np.array(state, dtype=np.uint64)
+        bl = np.ascontiguousarray(np.array(blocks, dtype=np.uint64).reshape(-1)) if blocks else np.zeros(1, dtype=np.uint64)
+        rates = np.zeros((1 + extra) * 8, dtype=np.uint64)
+        self._chk(self.lib.zp_poseidon_sponge(self.ctx, st.ctypes.data_as(_u64p), bl.ctypes.data_as(_u64p), len(blocks), extra,
+                                              rates.ctypes.data_as(_u64p)))
+        return st.tolist(), rates.reshape(-1, 8).tolist()
 
     def pow_grind(self, seed4, bits):
         sd = (C.c_uint64 * 4)(*[int(v) for v in seed4])

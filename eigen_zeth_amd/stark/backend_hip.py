@@ -62,6 +62,9 @@ class HipBackend:
         self.p.poseidon_perm(self._perm_buf, 1)
         return [int(v) for v in self.p.download(self._perm_buf, (12,))]
 
+    def poseidon_sponge(self, state, blocks, extra):
+        return self.p.poseidon_sponge(state, blocks, extra)
+
     def pow_grind(self, seed4, bits):
         return self.p.pow_grind(seed4, bits)
 

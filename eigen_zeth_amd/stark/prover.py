@@ -84,7 +84,7 @@ def prove(air, trace, pubs, params, be, timings=None):
     # every parameter the verifier relies on is bound into the transcript (a proof cannot choose its own security level)
     bn = params.hash == "bn128"
     assert getattr(be, "hash_mode", "gl") == params.hash, "backend and parameters disagree on the hash mode"
-    tr = TranscriptBN128(be.poseidon_bn254_perm17) if bn else Transcript(be.poseidon_perm)
+    tr = TranscriptBN128(be.poseidon_bn254_perm17) if bn else Transcript(be.poseidon_perm, getattr(be, "poseidon_sponge", None))
     tr.absorb([logn, logb, W, W2, params.fri_logf, params.fri_final_log, params.n_queries, params.pow_bits,
                int(root32), int(shift)] + air.digest_words() + [len(pubs)] + _ints(pubs))
     root_out = (lambda r: [str(int(r[0]))]) if bn else _ints      # a BN128 root is one 254-bit field element

@@ -6,8 +6,11 @@ P = 0xFFFFFFFF00000001
 
 
 class Transcript:
-    def __init__(self, perm):
-        self.perm = perm          # callable: list[12] -> list[12]
+    def __init__(self, perm, sponge=None):
+        """perm: list[12] -> list[12].  sponge (optional, GPU: zp_poseidon_sponge): (state, blocks, extra) -> (state, rates) runs a
+        whole absorb / squeeze step in one call; the result is the same as permutation by permutation"""
+        self.perm = perm
+        self.sponge = sponge
         self.state = [0] * 12
         self.pending = []
         self.out = []
@@ -20,7 +23,14 @@ class Transcript:
         """a Merkle root of the Goldilocks-hash mode: four field elements"""
         self.absorb(root)
 
-    def _flush(self):
+    def _flush(self, want=8):
+        """absorb what is queued (one permutation if nothing is), then make at least `want` output elements available"""
+        if self.sponge is not None:
+            blocks = [self.pending[i:i + 8] + [0] * (8 - len(self.pending[i:i + 8])) for i in range(0, len(self.pending), 8)]
+            self.pending = []
+            self.state, rates = self.sponge(self.state, blocks, max(0, (want + 7) // 8 - 1))
+            self.out = [v for r in rates for v in r]
+            return
         if not self.pending:
             self.state = self.perm(self.state)
         while self.pending:
@@ -33,7 +43,7 @@ class Transcript:
         res = []
         while len(res) < n:
             if self.pending or not self.out:
-                self._flush()
+                self._flush(n - len(res))
             res.append(self.out.pop(0))
         return res
 

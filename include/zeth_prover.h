@@ -108,6 +108,11 @@ int32_t zp_lde(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t *d_c
 int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count);
 /* proof-of-work grinding in front of a STARK's query phase: *h_nonce = the smallest n with
  * Poseidon(h_seed4[0..3] || n || 0^7)[0] >> (64 - bits) == 0   (bits in 0..40; 0 returns 0).     */
+/* The Fiat-Shamir sponge (rate 8, capacity 4) in one launch: for each of the nblocks blocks of 8 the rate h_state[0..8) is
+ * overwritten with the block and the state permuted (nblocks = 0: one permutation); then `extra` more permutations.
+ * h_state (12 words) is updated; h_rates receives (1 + extra) * 8 words: the rate after the absorption and after each
+ * extra permutation.  One host round trip per transcript step instead of one per permutation.                          */
+int32_t zp_poseidon_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates);
 int32_t zp_pow_grind(zp_ctx *ctx, const uint64_t *h_seed4, int32_t bits, uint64_t *h_nonce);
 /* leaf i = linear hash (sponge, rate 8, capacity 4; rows of <= 4 elements are identity-padded) of
  * row i across the W columns of d_cols u64[W][M]; d_tree receives (2M-1)*4 u64: M leaves, then

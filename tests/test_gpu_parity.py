@@ -482,3 +482,26 @@ def test_pack_blocks_kernel(prover, rows, row_len, parts):
     assert (prover.download(d_out, want.shape) == want).all()
     with pytest.raises(native.ZpError):
         prover.pack_blocks(d_in, d_out, rows, row_len, 5 if row_len % 5 else 7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nblocks,extra", [(0, 0), (0, 3), (1, 0), (2, 1), (7, 0), (60, 9)])
+def test_sponge_in_one_launch_equals_permutation_by_permutation(prover, tables, nblocks, extra):
+    """zp_poseidon_sponge (the Fiat-Shamir transcript step) against the oracle's permutation applied block by block"""
+    rc, mds = tables
+    state = [int(v) for v in O.random_field((12,), 5 + nblocks)]
+    blocks = [[int(v) for v in O.random_field((8,), 100 + i)] for i in range(nblocks)]
+    if nblocks:
+        blocks[0][0], blocks[-1][7] = 0, O.P - 1
+    perm = lambda st: [int(v) for v in O.poseidon_perm(np.array([st], dtype=np.uint64), rc, mds)[0]]
+    st, rates = list(state), []
+    if not blocks:
+        st = perm(st)
+    for b in blocks:
+        st = perm(b + st[8:])
+    rates.append(st[:8])
+    for _ in range(extra):
+        st = perm(st)
+        rates.append(st[:8])
+    got_state, got_rates = prover.poseidon_sponge(state, blocks, extra)
+    assert got_state == st and got_rates == rates
