@@ -33,7 +33,7 @@ class EngineConfig:
 
     def __init__(self, air="chunk64", logn=12, logb=1, chunks_per_block=1, n_queries=80, fri_logf=3, fri_final_log=5,
                  groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
-                 witness_threads=8, prover_streams=4, pow_bits=20,
+                 witness_threads=8, prover_streams=8, pow_bits=20,
                  final_air="chunk16", final_logn=10, final_logb=2, final_queries=50):
         self.air, self.logn, self.logb = air, logn, logb
         self.chunks_per_block, self.n_queries, self.pow_bits = chunks_per_block, n_queries, pow_bits
@@ -41,7 +41,7 @@ class EngineConfig:
         self.groth16_logm, self.crs_dir = groth16_logm, crs_dir
         self.l2_addr, self.txs_per_chunk = l2_addr, txs_per_chunk   # optional block-input fetcher
         self.witness_threads = witness_threads
-        self.prover_streams = prover_streams   # chunk proofs in flight on one GPU (each on its own ctx / stream)
+        self.prover_streams = prover_streams   # chunk proofs in flight on one GPU (each on its own ctx / stream); 8 measured best (profiles/r2_streams_sweep.txt)
         # the final STARK (BN128-hash mode, no grinding: 50 queries x blow-up 4 = 100 bits conjectured)
         self.final_air, self.final_logn, self.final_logb, self.final_queries = final_air, final_logn, final_logb, final_queries
 
