@@ -190,3 +190,17 @@ def test_qap_quotient_golden(golden):
         A, B, C = (NV.fr_ntt(v, inverse=True) for v in (a, b, c))
         ev = lambda co: NV.poly_eval_mod(co, z, NV.FR)
         assert (ev(A) * ev(B) - ev(C)) % NV.FR == ev(h) * (pow(z, m, NV.FR) - 1) % NV.FR
+
+
+def test_merkle16_c_restatement_matches_the_definition():
+    """oracle/bn254_hash.c against oracle/naive.py: 16-ary tree incl. a ragged last group and a multi-block leaf sponge"""
+    from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
+    from oracle import naive as NV
+    rc, mds, rp = bn254_poseidon_params(17)
+    O.p254_set(17, rp, rc, mds)
+    for W, M in ((1, 1), (3, 16), (50, 40), (100, 17)):
+        cols = O.random_field((W, M), 7 * W + M)
+        tree = O.merkle16_tree(cols)
+        lv = NV.merkle16_tree([[int(cols[c, i]) for c in range(W)] for i in range(M)], rc, mds, rp)
+        assert O._fr_ints(tree) == [v for level in lv for v in level]
+        assert O.merkle16_leaf(np.ascontiguousarray(cols[:, M - 1])) == lv[0][M - 1]

@@ -64,6 +64,18 @@ def test_bn254_t3_instance_reproduces_the_published_hash_vector():
     assert rp == 57 and rc[:4] == BN254_T3_FIRST and len(rc) == 65 * 3
     assert mds[0][0] == 0x109B7F411BA0E4C9B2B70CAF5C36A7B194BE7C11AD24378BFEDB68592BA8118B
     assert NV.poseidon_bn254_hash([1, 2], rc, mds, rp) == 0x115CC0F5E7D690413DF64C6B9662E9CF2A3617F2743245519E19607A4417189A
+    # the checker's C restatement (4 x 64-bit Montgomery words) hits the same published value, and agrees with the
+    # big-int definition on random states of both widths
+    import random
+    from oracle import oracle as O
+    O.p254_set(3, rp, rc, mds)
+    assert O.p254_perm([[0, 1, 2]], 3)[0][0] == 0x115CC0F5E7D690413DF64C6B9662E9CF2A3617F2743245519E19607A4417189A
+    rnd = random.Random(17)
+    for t in (3, 17):
+        rc_t, mds_t, rp_t = PC.bn254_poseidon_params(t)
+        O.p254_set(t, rp_t, rc_t, mds_t)
+        sts = [[rnd.randrange(PC.BN254_R) for _ in range(t)] for _ in range(2)] + [[0] * t, [PC.BN254_R - 1] * t]
+        assert O.p254_perm(sts, t) == [NV.poseidon_bn254_perm(st, rc_t, mds_t, rp_t) for st in sts]
 
 
 def test_bn254_t17_parameters_are_well_formed():
