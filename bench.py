@@ -74,7 +74,35 @@ def host_cpu_info():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 0
-    return {"cpu_model": model, "physical_cores": len(pairs) or None, "logical_cpus": logical or None, "cpus_usable_by_this_process": usable}
+    return {"cpu_model": model, "physical_cores": len(pairs) or None, "logical_cpus": logical or None, "cpus_usable_by_this_process": usable,
+            "cgroup_cpu_quota": cgroup_cpu_quota()}
+
+
+def cgroup_cpu_quota():
+    """CPUs' worth of CFS quota of this process's cgroup (None = unlimited / unknown): a container may SEE every CPU of
+    the host and still be throttled to a few of them, which is what bounds an OpenMP baseline"""
+    paths = ["/sys/fs/cgroup/cpu.max"]
+    try:
+        for line in open("/proc/self/cgroup"):
+            rel = line.strip().split(":", 2)[-1]
+            paths.insert(0, "/sys/fs/cgroup" + rel.rstrip("/") + "/cpu.max")
+    except OSError:
+        pass
+    for pth in paths:
+        try:
+            q, per = open(pth).read().split()[:2]
+            if q != "max":
+                return float(q) / float(per)
+        except (OSError, ValueError):
+            continue
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(logn, budget_cols):
@@ -85,24 +113,30 @@ def cpu_baseline(logn, budget_cols):
     host = host_cpu_info()
     avail = O.num_threads()
     threads = max(1, min(avail, host["physical_cores"] or avail, host["cpus_usable_by_this_process"] or avail))
+    if host["cgroup_cpu_quota"]:          # more threads than the quota only adds throttling
+        threads = max(1, min(threads, int(host["cgroup_cpu_quota"] + 0.999)))
+    x1 = O.random_field((1, 1 << logn), 0xE16E2E70 + 1)
+    O.set_threads(1)
+    t0 = time.perf_counter()
+    y = O.ntt(x1)
+    dt1 = time.perf_counter() - t0
+    del y, x1
+    # a bounded sample of about 10 s: whole rounds of one column per thread, at most 128 columns (16 GiB at 2^24)
+    rounds = max(1, int(10.0 / max(dt1, 1e-3)))
+    cols = max(1, min(threads * rounds, max(threads, 128) if threads <= 128 else threads))
+    cols -= cols % threads if cols >= threads else 0
     O.set_threads(threads)
-    cols = max(1, min(threads, 128))
     x = O.random_field((cols, 1 << logn), 0xE16E2E70 + 2)
     t0 = time.perf_counter()
     y = O.ntt(x)
     dt = time.perf_counter() - t0
-    del y
-    O.set_threads(1)
-    t0 = time.perf_counter()
-    y = O.ntt(x[:1])
-    dt1 = time.perf_counter() - t0
     del y
     O.set_threads(avail)
     # subtract nothing: copy + transform is what the CPU path does per call
     return {"value": cols * (1 << logn) / dt, "unit": "field-elems/s", "cores": threads, "kind": "port",
             "sample": "%d columns x 2^%d rows, oracle/gl_oracle.c cache-blocked radix-2 NTT, OpenMP over columns, %d threads, %.2f s"
                       % (cols, logn, threads, dt),
-            "single_thread_value": (1 << logn) / dt1, "host": host,
+            "single_thread_value": (1 << logn) / dt1, "effective_parallelism": round((cols * (1 << logn) / dt) / ((1 << logn) / dt1), 1), "host": host,
             "note": "CPU restatement, not the eigen-zkvm prover (parity unpinned, SURVEY.md 8c)"}
 
 
