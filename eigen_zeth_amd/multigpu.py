@@ -20,6 +20,50 @@ import torch.distributed as dist
 _LAYOUT = {"prover": None}
 
 
+# ---- collectives.  On GPUs the backend is "nccl" (= RCCL over xGMI) and tensors go in as they are.  The same code also runs
+# with the gloo backend: on CPU tensors (the world-2 CPU tests) and -- for rehearsing several ranks on ONE GPU, which RCCL
+# refuses -- on device tensors staged through the host (data path only: HIP kernels, layouts and indexing are the real ones).
+def _staged(t, group):
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_to_all_single(recv, send, group=None):
+    if _staged(send, group):
+        r = torch.empty(send.shape, dtype=send.dtype)
+        dist.all_to_all_single(r, send.cpu(), group=group)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv, send, group=group)
+
+
+def all_gather(outs, t, group=None):
+    if _staged(t, group):
+        tmp = [torch.empty(t.shape, dtype=t.dtype) for _ in outs]
+        dist.all_gather(tmp, t.cpu(), group=group)
+        for o, v in zip(outs, tmp):
+            o.copy_(v)
+    else:
+        dist.all_gather(outs, t, group=group)
+
+
+def all_reduce(t, group=None):
+    if _staged(t, group):
+        c = t.cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, group=group)
+
+
+def broadcast(t, src, group=None):
+    if _staged(t, group):
+        c = t.cpu()
+        dist.broadcast(c, src, group=group)
+        t.copy_(c)
+    else:
+        dist.broadcast(t, src, group=group)
+
+
 def use_device_layout(prover):
     """route the packing / transposing copies of CUDA tensors through the library's HIP kernels (zp_pack_blocks,
     zp_transpose) on `prover`'s stream instead of generic tensor copies; None switches back (CPU tensors always use torch)"""
@@ -58,7 +102,7 @@ def exchange_columns_to_rows(local_cols, group=None):
     Wl, M = local_cols.shape
     send = pack_for_exchange(local_cols, G)
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
+    all_to_all_single(recv, send, group=group)
     sent_bytes = send.numel() * 8 * (G - 1) // G
     return recv.view(G * Wl, M // G), sent_bytes
 
@@ -80,7 +124,7 @@ def distributed_commit(local_ext, commit_rows_fn, hash_pair, group=None):
     t = torch.tensor([int(v) - (1 << 64) if int(v) >= (1 << 63) else int(v) for v in sub], dtype=torch.int64,
                      device=local_ext.device)
     allr = [torch.empty_like(t) for _ in range(G)]
-    dist.all_gather(allr, t, group=group)
+    all_gather(allr, t, group=group)
     subroots = [[int(v) & 0xFFFFFFFFFFFFFFFF for v in r.tolist()] for r in allr]
     return tree_top(subroots, hash_pair), {"sent_bytes": sent, "rows_shape": tuple(rows.shape)}
 
@@ -102,7 +146,7 @@ def distributed_transpose(local, group=None):
         return transpose2d(local)
     send = pack_for_exchange(local, G)                                      # block h = my rows, rank h's columns
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)                         # recv[h] = rank h's rows, my columns
+    all_to_all_single(recv, send, group=group)                         # recv[h] = rank h's rows, my columns
     return transpose2d(recv.view(G * Rl, C // G))                           # [my column][global row h*Rl + r]
 
 
@@ -169,7 +213,7 @@ def distributed_msm(local_msm, add_points, group=None):
     if dist.get_backend(group) == "nccl":
         t = t.cuda()
     allr = [torch.empty_like(t) for _ in range(G)]
-    dist.all_gather(allr, t, group=group)
+    all_gather(allr, t, group=group)
     total = None
     for r in allr:
         w = r.tolist()

@@ -25,6 +25,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .. import multigpu as MG
 from . import air as air_mod
 from . import field as F
 
@@ -78,7 +79,7 @@ class ShardedBackend:
     # ---- collectives
     def _all_gather(self, t):
         out = [torch.empty_like(t) for _ in range(self.G)]
-        dist.all_gather(out, t.contiguous(), group=self.group)
+        MG.all_gather(out, t.contiguous(), group=self.group)
         return out
 
     def _cols_to_rows(self, local_cols):
@@ -144,7 +145,7 @@ class ShardedBackend:
             return self.ops.from_host(c1.witness[idx:idx + 1])[0]
         owner, j = divmod(idx, c1.wl)
         t = c1.local_witness[j] if owner == self.rank else self.ops.empty((N,))
-        dist.broadcast(t, owner, group=self.group)
+        MG.broadcast(t, owner, group=self.group)
         return t
 
     def commit_stage2(self, air, c1, chal, logn, logb):
@@ -234,7 +235,7 @@ class ShardedBackend:
         for i, j in enumerate(idx):
             if cols.row0 <= j < cols.row0 + cols.nloc:
                 mine[i] = cols.t[cols.col0:cols.col0 + W, j - cols.row0]
-        dist.all_reduce(mine, group=self.group)      # every row has exactly one owner; the others contribute zeros
+        MG.all_reduce(mine, group=self.group)      # every row has exactly one owner; the others contribute zeros
         return self.ops.to_host(mine).reshape(len(idx), W)
 
     def open_paths(self, tree, M, idx):
@@ -247,7 +248,7 @@ class ShardedBackend:
         if own and dl > 0:
             paths = self.ops.open_paths(tree.local, tree.nloc, [idx[i] - self.rank * tree.nloc for i in own])
             mine[own] = self.ops.from_host(np.asarray(paths, dtype=np.uint64).reshape(len(own), dl, 4))
-        dist.all_reduce(mine, group=self.group)
+        MG.all_reduce(mine, group=self.group)
         low = self.ops.to_host(mine).reshape(len(idx), max(dl, 1), 4)
         _, levels = self._top(tree.subroots)
         out = np.zeros((len(idx), depth, 4), dtype=np.uint64)

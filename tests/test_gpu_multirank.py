@@ -37,3 +37,18 @@ def test_sharded_commit_four_step_ntt_and_msm_over_rccl():
     assert res["ok"] and res["world"] == ranks
     assert res["commit_root_matches_single_gpu"] and res["four_step_matches_plain_ntt"] and res["msm_matches_single_gpu"]
     assert res["sharded_proof_matches_single_gpu"]
+
+
+def test_two_ranks_on_one_gpu_with_host_staged_collectives():
+    """rehearsal on the one-GPU box: two processes, both computing on GPU 0 through the HIP kernels (pack / transpose / LDE /
+    row-sharded Merkle / four-step NTT / MSM ranges / one sharded proof), collectives over gloo staged through the host --
+    everything but the RCCL transport itself"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ZP_CHECK_BACKEND="gloo", ZP_CHECK_LOGN="14", ZP_CHECK_STARK_LOGN="12")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "multigpu_check.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"] and res["world"] == 2 and res["backend"] == "gloo"
+    assert res["commit_root_matches_single_gpu"] and res["four_step_matches_plain_ntt"] and res["msm_matches_single_gpu"]
+    assert res["sharded_proof_matches_single_gpu"]

@@ -24,15 +24,22 @@ def main():
     from eigen_zeth_amd.service import bn254
 
     world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    # ZP_CHECK_BACKEND=gloo: rehearsal of several ranks on fewer GPUs than ranks (RCCL refuses two ranks on one device):
+    # every rank computes on GPU local % device_count, the collectives are staged through the host (multigpu.py)
+    backend = os.environ.get("ZP_CHECK_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
     prover = Prover(local, stream=torch.cuda.current_stream().cuda_stream)
     multigpu.use_device_layout(prover)
     logn, cols = int(os.environ.get("ZP_CHECK_LOGN", "16")), 4
     N, M = 1 << logn, 2 << logn
-    res, ok = {"world": world, "logn": logn}, True
+    res, ok = {"world": world, "logn": logn, "backend": backend}, True
     u64 = lambda t: [int(v) & 0xFFFFFFFFFFFFFFFF for v in t.tolist()]
 
     def hash_pair_on(p, st):
@@ -59,7 +66,7 @@ def main():
     torch.cuda.synchronize()
     res["commit_ms"] = (time.perf_counter() - t0) * 1e3
     allx = [torch.empty_like(x) for _ in range(world)]
-    dist.all_gather(allx, x)
+    multigpu.all_gather(allx, x)
     if rank == 0:
         full = torch.cat(allx, dim=0)                                     # [Wtot][N] in rank order = column order
         yf = torch.empty((Wtot, M), dtype=torch.int64, device=dev)
@@ -76,8 +83,8 @@ def main():
     out = multigpu.four_step_ntt(blk, flog, *multigpu.hip_row_ops(prover))
     parts_in = [torch.empty_like(blk) for _ in range(world)]
     parts_out = [torch.empty_like(out) for _ in range(world)]
-    dist.all_gather(parts_in, blk)
-    dist.all_gather(parts_out, out)
+    multigpu.all_gather(parts_in, blk)
+    multigpu.all_gather(parts_out, out)
     if rank == 0:
         col = torch.cat(parts_in).view(1, -1)
         ref = torch.empty_like(col)
@@ -119,7 +126,7 @@ def main():
         res["sharded_proof_matches_single_gpu"] = sharded == single
         ok &= sharded == single
     flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
-    dist.broadcast(flag, 0)
+    multigpu.broadcast(flag, 0)
     if rank == 0:
         res["ok"] = bool(ok)
         print(json.dumps(res), flush=True)
