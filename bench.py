@@ -164,11 +164,21 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # ZP_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path with fewer GPUs than ranks (RCCL refuses two ranks on one
+    # device): ranks compute on GPU local % device_count, collectives are staged through the host (eigen_zeth_amd/multigpu.py).
+    # The driver's runs use the default, "nccl" (= RCCL).
+    backend = os.environ.get("ZP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    from eigen_zeth_amd import multigpu as MG
 
     from eigen_zeth_amd.native import Prover
 
@@ -207,7 +217,7 @@ def main():
 
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        MG.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
 
     # achievable HBM ceiling on this device (report against both the vendor peak and a measured copy):
@@ -319,7 +329,7 @@ def main():
         except Exception as e:
             tb = torch.tensor([-1.0], dtype=torch.float64, device=dev)
             err = repr(e)
-        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        MG.all_reduce(tb, op=dist.ReduceOp.MAX)
         batch_multi = {"chunks_total": 16 * world, "chunks_per_gpu": 16, "wall_s_max_over_ranks": float(tb.item()),
                        "rank0_error": err}
 
@@ -405,7 +415,7 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
         if world > 1:
             t = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in sub], dtype=torch.int64, device=dev)
             allr = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(allr, t)
+            multigpu.all_gather(allr, t)
             root = multigpu.tree_top([[int(v) & 0xFFFFFFFFFFFFFFFF for v in r.tolist()] for r in allr], hash_pair)
         else:
             root = sub

@@ -46,13 +46,14 @@ def all_gather(outs, t, group=None):
         dist.all_gather(outs, t, group=group)
 
 
-def all_reduce(t, group=None):
+def all_reduce(t, group=None, op=None):
+    op = dist.ReduceOp.SUM if op is None else op
     if _staged(t, group):
         c = t.cpu()
-        dist.all_reduce(c, group=group)
+        dist.all_reduce(c, op=op, group=group)
         t.copy_(c)
     else:
-        dist.all_reduce(t, group=group)
+        dist.all_reduce(t, op=op, group=group)
 
 
 def broadcast(t, src, group=None):

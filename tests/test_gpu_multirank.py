@@ -52,3 +52,20 @@ def test_two_ranks_on_one_gpu_with_host_staged_collectives():
     assert res["ok"] and res["world"] == 2 and res["backend"] == "gloo"
     assert res["commit_root_matches_single_gpu"] and res["four_step_matches_plain_ntt"] and res["msm_matches_single_gpu"]
     assert res["sharded_proof_matches_single_gpu"]
+
+
+def test_bench_n2_code_path_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), rehearsed on the one-GPU
+    box with ZP_BENCH_BACKEND=gloo: the multi-rank pipeline probes (all-to-all commit, four-step NTT, MSM ranges, per-rank
+    batch) must run to completion and the line must carry them"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ZP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--logn", "20", "--cols", "16", "--stark-logn", "14"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    pipe = line["pipeline"]
+    assert "error" not in pipe and pipe["all_to_all_ms"] > 0 and pipe["four_step_single_column"]["ms"] > 0
+    assert pipe["msm_bn254"]["on_curve"]
