@@ -131,7 +131,7 @@ def cpu_baseline(logn, budget_cols):
     y = O.ntt(x)
     dt = time.perf_counter() - t0
     del y
-    O.set_threads(avail)
+    O.set_threads(threads)    # later CPU legs (cpu_stark_baseline) keep the thread count the quota allows
     # subtract nothing: copy + transform is what the CPU path does per call
     return {"value": cols * (1 << logn) / dt, "unit": "field-elems/s", "cores": threads, "kind": "port",
             "sample": "%d columns x 2^%d rows, oracle/gl_oracle.c cache-blocked radix-2 NTT, OpenMP over columns, %d threads, %.2f s"
@@ -499,7 +499,7 @@ def engine_batch_probe(K, logn, air_name, device=0, tag=""):
     """K blocks -> K chunk STARKs -> aggregate -> Groth16 wrap on one GPU through service/engine.py (no gRPC), at the
     service's default security (80 queries, blow-up 2, 20 grinding bits).  Reported twice: with the synthetic witness
     generator (host code standing in for the zkVM executor) inside the timed region, and with the witnesses generated
-    beforehand (what the prover itself costs).  Each is the second of two runs (the first builds the local CRS and
+    beforehand (what the prover itself costs).  Each is the last of two / three runs (the first builds the local CRS and
     warms the buffer pools)."""
     import tempfile
     from eigen_zeth_amd.service.engine import Engine, EngineConfig
@@ -511,7 +511,7 @@ def engine_batch_probe(K, logn, air_name, device=0, tag=""):
     res = {}
     for pre in (False, True):
         eng.pregenerate_witnesses = pre
-        for rep in range(2):
+        for rep in range(3 if pre else 2):     # steady state: the first runs build the CRS and fill the buffer pools of every stream
             ch = eng.gen_batch_chunks("bench", list(range(1, K + 1)), 12345, "evm")
             tw0 = time.perf_counter()
             if pre:
