@@ -82,3 +82,19 @@ def test_bn254_t17_parameters_are_well_formed():
     rc, mds, rp = PC.bn254_poseidon_params(17)
     assert rp == 68 and len(rc) == 76 * 17 and len(mds) == 17 and all(len(r) == 17 for r in mds)
     assert all(0 < v < PC.BN254_R for row in mds for v in row) and len({v for row in mds for v in row}) == 289
+
+
+def test_generated_mds_rows_are_the_committed_ones(tmp_path):
+    """csrc/poseidon_mds_asm.inc is generated (tools/gen_mds_asm.py) from the same circulant the tables use"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "eigen_zeth_amd", "csrc", "poseidon_mds_asm.inc")
+    before = open(inc).read()
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_mds_asm.py")], stdout=subprocess.DEVNULL)
+    assert open(inc).read() == before
+    src = open(os.path.join(root, "tools", "gen_mds_asm.py")).read()
+    circ = [int(v) for v in re.search(r"CIRC = \[([^\]]*)\]", src).group(1).split(",")]
+    m = PC.default_mds()
+    assert [m[j] for j in range(12)] == [circ[j] + (8 if j == 0 else 0) for j in range(12)]
+    assert all(m[i * 12 + j] == circ[(j - i) % 12] + (8 if i == j == 0 else 0) for i in range(12) for j in range(12))
