@@ -347,12 +347,27 @@ FQ_HD jacT<F> jac_mul_small(const jacT<F> &p, u32 k) {  // k * p by double-and-a
     return acc;
 }
 
-__device__ __forceinline__ u32 digit_of(const u32 *sc, int w, int c) {
-    const int bit = w * c;
+// Signed window digits.  With K = sum_w 2^(cd w + cd - 1) the unsigned digits u_w of s + K give  s = sum_w (u_w - 2^(cd-1)) 2^(cd w):
+// digits d_w in [-2^(cd-1), 2^(cd-1)), so a window has 2^(cd-1) buckets |d| = 1 .. 2^(cd-1) (bucket index |d| - 1) and a negative
+// digit adds -P.  One more bit of window for the same bucket memory: 14 windows of 19 bits instead of 15 of 18.
+// sc9 = s + K as nine 32-bit words (carry-propagated once per scalar); returns |d| (0: skip) and the sign.
+__device__ __forceinline__ void add_bias9(const u32 *sc, const u32 *K, u32 *s9) {
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        c += (u64)(j < 8 ? sc[j] : 0u) + K[j];
+        s9[j] = (u32)c;
+        c >>= 32;
+    }
+}
+__device__ __forceinline__ u32 digit_key(const u32 *s9, int w, int cd, u32 &neg) {
+    const int bit = w * cd;
     const int limb = bit >> 5, off = bit & 31;
-    u64 v = sc[limb];
-    if (limb + 1 < 8) v |= (u64)sc[limb + 1] << 32;
-    return (u32)(v >> off) & ((1u << c) - 1);
+    u64 v = s9[limb];
+    if (limb + 1 < 9) v |= (u64)s9[limb + 1] << 32;
+    const int d = (int)((u32)(v >> off) & ((1u << cd) - 1)) - (1 << (cd - 1));
+    neg = d < 0 ? 1u : 0u;
+    return (u32)(d < 0 ? -d : d);
 }
 
 // ---- 1. sort of the point indices by window digit, two levels so that every global write lands next to its
@@ -370,7 +385,9 @@ __device__ __forceinline__ u32 digit_of(const u32 *sc, int w, int c) {
 #define MSM_TILE 4096
 #define MSM_LO_MAX 10
 struct SortGeo {
-    int c, hi, lo, nwin, wgroup;   // wgroup: windows handled per pass of the tile kernels (LDS budget)
+    int c, hi, lo, nwin, wgroup;   // c = hi + lo: bucket-index bits of a window; wgroup: windows per pass of the tile kernels (LDS budget)
+    int cd;                        // digit width = c + 1 (signed digits)
+    u32 K[9];                      // the recoding bias  sum_w 2^(cd w + cd - 1)
 };
 __global__ void __launch_bounds__(256) msm_coarse_hist_kernel(const u32 *scalars, u64 n, SortGeo g, int w0, u32 *ccounts) {
     extern __shared__ u32 lh[];   // [wgroup][2^hi]
@@ -384,9 +401,11 @@ __global__ void __launch_bounds__(256) msm_coarse_hist_kernel(const u32 *scalars
             u32 sc[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) sc[j] = scalars[i * 8 + j];
+            u32 s9[9], neg;
+            add_bias9(sc, g.K, s9);
             for (int w = 0; w < nw; w++) {
-                const u32 d = digit_of(sc, w0 + w, g.c);
-                if (d) atomicAdd(&lh[w * nbin + (d & (nbin - 1))], 1u);
+                const u32 d = digit_key(s9, w0 + w, g.cd, neg);
+                if (d) atomicAdd(&lh[w * nbin + ((d - 1) & (nbin - 1))], 1u);
             }
         }
     }
@@ -435,9 +454,11 @@ __global__ void __launch_bounds__(256) msm_coarse_part_kernel(const u32 *scalars
             u32 sc[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) sc[j] = scalars[i * 8 + j];
+            u32 s9[9], neg;
+            add_bias9(sc, g.K, s9);
             for (int w = 0; w < nw; w++) {
-                const u32 d = digit_of(sc, w0 + w, g.c);
-                if (d) atomicAdd(&lh[w * nbin + (d & (nbin - 1))], 1u);
+                const u32 d = digit_key(s9, w0 + w, g.cd, neg);
+                if (d) atomicAdd(&lh[w * nbin + ((d - 1) & (nbin - 1))], 1u);
             }
         }
     }
@@ -454,13 +475,15 @@ __global__ void __launch_bounds__(256) msm_coarse_part_kernel(const u32 *scalars
             u32 sc[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) sc[j] = scalars[i * 8 + j];
+            u32 s9[9], neg;
+            add_bias9(sc, g.K, s9);
             for (int w = 0; w < nw; w++) {
-                const u32 d = digit_of(sc, w0 + w, g.c);
+                const u32 d = digit_key(s9, w0 + w, g.cd, neg);
                 if (d) {
-                    const int b = w * nbin + (d & (nbin - 1));
+                    const int b = w * nbin + ((d - 1) & (nbin - 1));
                     const u32 pos = lbase[b] + atomicAdd(&lh[b], 1u);
-                    pidx[(u64)(w0 + w) * n + pos] = (u32)i;
-                    pfine[(u64)(w0 + w) * n + pos] = d >> g.hi;
+                    pidx[(u64)(w0 + w) * n + pos] = (u32)i | (neg << 31);   // the sign of the digit travels with the index
+                    pfine[(u64)(w0 + w) * n + pos] = (d - 1) >> g.hi;
                 }
             }
         }
@@ -608,10 +631,11 @@ __global__ void __launch_bounds__(256) msm_to_mont_kernel(const uint4 *points, u
 // last point) so that no loop-carried register needs a copy under an exec mask -- with a conditional prefetch the
 // compiler parked a v_mov (and therefore an s_waitcnt) right behind every load and nothing was overlapped.
 template <class F>
-__device__ __forceinline__ jacT<F> madd_packed(const jacT<F> &acc, const uint4 *q) {
+__device__ __forceinline__ jacT<F> madd_packed(const jacT<F> &acc, const uint4 *q, u32 neg) {
     F x, y;
     unpack_point<F>(q, x, y);
     if (f_is_zero(x) && f_is_zero(y)) return acc;
+    if (neg) y = f_sub(FT<F>::zero(), y);      // negative digit: add -P = (x, -y)
     return jac_madd(acc, x, y);
 }
 // Buckets with more than MSM_HEAVY points are not summed by one lane: real scalars are not uniform (the top window of
@@ -645,21 +669,24 @@ __global__ void __launch_bounds__(256) msm_bucket_kernel(const uint4 *mont, u64 
     if (cnt) {
         const u32 last = cnt - 1;
         uint4 A[NV], B[NV];
-        u64 pa = idx[0];
+        u32 va = idx[0];                     // bit 31: sign of the digit, bits 0..30: point index
+        u64 pa = va & 0x7FFFFFFFu;
 #pragma unroll
         for (int j = 0; j < NV; j++) A[j] = mont[pa * NV + j];
         u32 ia = idx[last < 1 ? last : 1];
         for (u32 k = 0; k < cnt; k += 2) {
-            const u64 pb = ia;
+            const u32 vb = ia;
+            const u64 pb = vb & 0x7FFFFFFFu;
 #pragma unroll
             for (int j = 0; j < NV; j++) B[j] = mont[pb * NV + j];
             const u32 ib = idx[k + 2 < last ? k + 2 : last];
-            acc = madd_packed<F>(acc, A);
-            pa = ib;
+            acc = madd_packed<F>(acc, A, va >> 31);
+            va = ib;
+            pa = va & 0x7FFFFFFFu;
 #pragma unroll
             for (int j = 0; j < NV; j++) A[j] = mont[pa * NV + j];
             ia = idx[k + 3 < last ? k + 3 : last];
-            if (k + 1 < cnt) acc = madd_packed<F>(acc, B);
+            if (k + 1 < cnt) acc = madd_packed<F>(acc, B, vb >> 31);
         }
     }
     buckets[id] = acc;
@@ -677,11 +704,12 @@ __global__ void __launch_bounds__(256) msm_heavy_kernel(const uint4 *mont, u64 n
     const u32 *idx = sorted + w * n + starts[id];
     jacT<F> acc = jac_inf<F>();
     for (u32 k = lo + threadIdx.x; k < hi; k += 256) {
-        const u64 pi = idx[k];
+        const u32 vi = idx[k];
+        const u64 pi = vi & 0x7FFFFFFFu;
         uint4 q[NV];
 #pragma unroll
         for (int j = 0; j < NV; j++) q[j] = mont[pi * NV + j];
-        acc = madd_packed<F>(acc, q);
+        acc = madd_packed<F>(acc, q, vi >> 31);
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
@@ -706,7 +734,7 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(HeavyLists hl, u3
     }
     if (threadIdx.x == 0) buckets[h.x] = sh[0];
 }
-// ---- 3a. per segment of SEG buckets: sum_{b in seg} b * B_b
+// ---- 3a. per segment of SEG buckets: sum_{b in seg} (b + 1) * B_b   (bucket index b holds the points of digit magnitude b + 1)
 #define MSM_SEG 64
 template <class F>
 __global__ void __launch_bounds__(64) msm_segment_kernel(const jacT<F> *buckets, int c, int nwin, jacT<F> *segs) {
@@ -722,7 +750,7 @@ __global__ void __launch_bounds__(64) msm_segment_kernel(const jacT<F> *buckets,
         acc = jac_add(acc, run);
     }
     run = jac_add(run, B[0]);                       // total of the segment
-    if (s) acc = jac_add(acc, jac_mul_small(run, (u32)s));  // + s * total
+    acc = jac_add(acc, jac_mul_small(run, (u32)s + 1));     // + (s + 1) * total
     segs[id] = acc;
 }
 // ---- 3b. tree sum of the segment results of one window (one block per window)
@@ -786,7 +814,10 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     if (ctx->tune_msm_c > 0) c = ctx->tune_msm_c;    // experiment knob
     if (c < 6) c = 6;                                // segments of 64 buckets need c >= 6
     if (c > 22) c = 22;
-    const int nwin = (256 + c - 1) / c;              // any 256-bit scalar (the BN254 group order has 254 bits)
+    // c = bucket-index bits of a window; digits are signed and one bit wider (cd = c + 1).  s + K must stay below 2^(cd nwin)
+    // for any 256-bit scalar (the BN254 group order has 254 bits): cd * nwin >= 258
+    const int cd = c + 1;
+    const int nwin = (258 + cd - 1) / cd;
     const u64 nb = (u64)nwin << c;
     u32 *d_counts = nullptr, *d_starts = nullptr, *d_sorted = nullptr;
     J *d_buckets = nullptr, *d_segs = nullptr, *d_wins = nullptr;
@@ -797,6 +828,12 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     g.lo = c < MSM_LO_MAX ? c : MSM_LO_MAX;
     g.hi = c - g.lo;
     g.nwin = nwin;
+    g.cd = cd;
+    for (int j = 0; j < 9; j++) g.K[j] = 0;
+    for (int w = 0; w < nwin; w++) {
+        const int bit = cd * w + cd - 1;            // < 288
+        g.K[bit >> 5] |= 1u << (bit & 31);
+    }
     g.wgroup = nwin;
     while ((size_t)g.wgroup * ((size_t)2 << g.hi) * sizeof(u32) > 48 * 1024 && g.wgroup > 1) g.wgroup = (g.wgroup + 1) / 2;
     const u64 ncoarse = (u64)nwin << g.hi;
@@ -879,10 +916,10 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     ZP_HIP(ctx, le);
     ZP_HIP(ctx, ce);
     ZP_HIP(ctx, se);
-    // host: sum_w 2^(c*w) * W_w  (Horner from the top window)
+    // host: sum_w 2^(cd*w) * W_w  (Horner from the top window)
     J acc = jac_inf<F>();
     for (int w = nwin - 1; w >= 0; w--) {
-        for (int k = 0; k < c; k++) acc = jac_dbl(acc);
+        for (int k = 0; k < cd; k++) acc = jac_dbl(acc);
         acc = jac_add(acc, wins[w]);
     }
     *out = acc;
