@@ -810,7 +810,7 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     using J = jacT<F>;
     int c = 4;
     while (c < 16 && (1ULL << (c + 2)) <= n) c++;   // ~4 points per bucket up to c = 16
-    while (c < 20 && (1ULL << (c + 7)) <= n) c++;   // wider windows only while buckets keep >= 64 points
+    while (c < 20 && (1ULL << (c + 8)) <= n) c++;   // wider windows only while buckets keep >= 128 points (signed digits: profiles/r2_msm_c_sweep.txt)
     if (ctx->tune_msm_c > 0) c = ctx->tune_msm_c;    // experiment knob
     if (c < 6) c = 6;                                // segments of 64 buckets need c >= 6
     if (c > 22) c = 22;
