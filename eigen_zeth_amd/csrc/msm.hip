@@ -12,6 +12,8 @@
 // the MFMA limb-product formulation north_star mentions is not built.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstring>
 #include <vector>
 
@@ -209,6 +211,105 @@ FQ_HD fq2 fq2_make(const fq &a, const fq &b) {
     return r;
 }
 
+// ---- lazy (unreduced) arithmetic for the G1 bucket sums.  A point addition is eleven products with a dozen additions and
+// subtractions between them; in the canonical form above every one of those normalises and conditionally subtracts q (two
+// carry chains and a select, ~90 instructions -- half the instructions of a point addition).  R = 2^261 is 169 q, so a
+// Montgomery product only needs  a b < 169 q^2  to return a value < 2 q, and the 64-bit column accumulators take limbs up to
+// 2^30.  Between the products values therefore stay congruent but unreduced:
+//   N(k): limbs 0..7 < 2^29, value < k q (what lz_mul, lz_sub, lz_carry return);   W(k): limbs < 2^30 (lz_add / lz_dbl of N values)
+//   lz_sub<K>(a, b) = a - b + K q with ONE signed carry pass (K q >= b keeps it non-negative): ~45 two-cycle instructions.
+// The bounds of every step of the mixed addition are in jac_madd_lazy; results are made canonical once, when a bucket is stored.
+constexpr u32 FQ_QL[9] = {FQ_Q0, FQ_Q1, FQ_Q2, FQ_Q3, FQ_Q4, FQ_Q5, FQ_Q6, FQ_Q7, FQ_Q8};
+constexpr u32 fq_kq_limb(int K, int i) {            // limb i of K q (normalised limbs, the top one takes the rest)
+    u64 carry = 0, v = 0;
+    for (int j = 0; j <= i; j++) {
+        v = (u64)FQ_QL[j] * (u64)K + carry;
+        carry = v >> FQ_B;
+    }
+    return i == 8 ? (u32)v : (u32)v & FQ_MASK;
+}
+__device__ __forceinline__ fq lz_mul(const fq &a, const fq &b) {      // limbs < 2^30, a b < 169 q^2  ->  N(1 + a b / 169 q^2)
+    u32 m[9];
+    fq r;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (u64)m[i] * fq_q(k - i);
+        m[k] = ((u32)acc * FQ_INV29) & FQ_MASK;
+        acc += (u64)m[k] * FQ_Q0;
+        acc >>= FQ_B;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) {
+            acc += (u64)a.l[i] * b.l[k - i];
+            acc += (u64)m[i] * fq_q(k - i);
+        }
+        r.l[k - 9] = (u32)acc & FQ_MASK;
+        acc >>= FQ_B;
+    }
+    r.l[8] = (u32)acc;
+    return r;
+}
+__device__ __forceinline__ fq lz_add(const fq &a, const fq &b) {      // N + N -> W
+    fq r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+__device__ __forceinline__ fq lz_dbl(const fq &a) {                   // N -> W
+    fq r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] << 1;
+    return r;
+}
+__device__ __forceinline__ fq lz_quad(const fq &a) {                  // 4 a, carried: N -> N
+    fq r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const u32 v = (a.l[i] << 2) + c;
+        r.l[i] = i < 8 ? (v & FQ_MASK) : v;
+        c = v >> FQ_B;
+    }
+    return r;
+}
+template <int K>
+__device__ __forceinline__ fq lz_sub(const fq &a, const fq &b) {      // a - b + K q  (K q >= b):  -> N(a + K)
+    fq r;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int v = (int)a.l[i] - (int)b.l[i] + (int)fq_kq_limb(K, i) + c;
+        r.l[i] = i < 8 ? ((u32)v & FQ_MASK) : (u32)v;
+        c = v >> FQ_B;        // arithmetic shift: floor division
+    }
+    return r;
+}
+template <int K>
+__device__ __forceinline__ fq lz_sub2(const fq &a, const fq &b, const fq &d) {   // a - b - d + K q  (K q >= b + d)
+    fq r;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int v = (int)a.l[i] - (int)b.l[i] - (int)d.l[i] + (int)fq_kq_limb(K, i) + c;
+        r.l[i] = i < 8 ? ((u32)v & FQ_MASK) : (u32)v;
+        c = v >> FQ_B;
+    }
+    return r;
+}
+__device__ __forceinline__ bool lz_is_zero_mod_q(const fq &a) {       // a in N(2): congruent to 0 iff a is 0 or q
+    u32 z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { z |= a.l[i]; e |= a.l[i] ^ FQ_QL[i]; }
+    return z == 0 || e == 0;
+}
+__device__ __forceinline__ fq lz_canon(const fq &a) { return fq_mul(a, fq_one()); }   // a R / R mod q, fully reduced (limbs < 2^30, a < 169 q)
+
 // ---- one set of names over both fields, so that the curve code and the kernels are written once
 template <class F> struct FT;
 template <> struct FT<fq> {
@@ -312,6 +413,52 @@ FQ_HD jacT<F> jac_madd(const jacT<F> &p, const F &qx, const F &qy) {
     r.Z = f_sub(f_sub(f_sqr(f_add(p.Z, H)), Z1Z1), HH);
     return r;
 }
+// madd-2007-bl on lazy values (G1 bucket sums).  Invariant of the accumulator between calls (units of q):
+//   X in N(7), Y in N(5), Z in W(2.3);  the affine point is canonical.  Bounds of every step, with lz_mul -> 1 + a b / 169:
+//   Z1Z1, U2, t, S2 < 2;  H = U2 - X + 7q < 8.02;  HH < 1.38;  I = 4 HH < 5.52;  J = H I -> < 1.27;  V = X I -> < 1.23;
+//   r0 = S2 - Y + 5q < 6.02, rr = 2 r0 < 12.03 (W), rr^2 -> < 1.86;  X3 = rr^2 - J - 2V + 4q < 5.86  (J + 2V < 3.73);
+//   V - X3 + 6q < 7.23, rr (V - X3) -> < 1.52;  Y J -> < 1.04;  Y3 = .. - 2 Y J + 3q < 4.52;  Z3 = 2 (Z H) < 2.22 (W).
+// H == 0 mod q (the point equals +-the accumulator: doubling or infinity) is detected on HH, which lz_mul returns in
+// N(2) with exact limbs, and handled by the canonical code on canonicalised inputs.
+__device__ __forceinline__ jacT<fq> jac_madd_lazy(const jacT<fq> &p, const fq &qx, const fq &qy) {
+    if (fq_is_zero(p.Z)) {            // infinity is always the exact zero
+        jacT<fq> r;
+        r.X = qx;
+        r.Y = qy;
+        r.Z = fq_one();
+        return r;
+    }
+    const fq Z1Z1 = lz_mul(p.Z, p.Z);
+    const fq U2 = lz_mul(qx, Z1Z1);
+    const fq S2 = lz_mul(lz_mul(qy, p.Z), Z1Z1);
+    const fq H = lz_sub<7>(U2, p.X);
+    const fq HH = lz_mul(H, H);
+    if (lz_is_zero_mod_q(HH)) {
+        jacT<fq> c;
+        c.X = lz_canon(p.X);
+        c.Y = lz_canon(p.Y);
+        c.Z = lz_canon(p.Z);
+        return jac_madd(c, qx, qy);   // canonical: doubles or returns the exact infinity
+    }
+    const fq I = lz_quad(HH);
+    const fq J = lz_mul(H, I);
+    const fq rr = lz_dbl(lz_sub<5>(S2, p.Y));
+    const fq V = lz_mul(p.X, I);
+    jacT<fq> r;
+    r.X = lz_sub2<4>(lz_mul(rr, rr), J, lz_dbl(V));
+    r.Y = lz_sub<3>(lz_mul(rr, lz_sub<6>(V, r.X)), lz_dbl(lz_mul(p.Y, J)));
+    r.Z = lz_dbl(lz_mul(p.Z, H));
+    return r;
+}
+__device__ __forceinline__ jacT<fq> jac_canon(const jacT<fq> &p) {
+    jacT<fq> r;
+    r.X = lz_canon(p.X);
+    r.Y = lz_canon(p.Y);
+    r.Z = lz_canon(p.Z);
+    return r;
+}
+__device__ __forceinline__ jacT<fq2> jac_canon(const jacT<fq2> &p) { return p; }   // G2 sums stay canonical throughout
+
 // add-2007-bl: Jacobian + Jacobian
 template <class F>
 FQ_HD jacT<F> jac_add(const jacT<F> &p, const jacT<F> &q) {
@@ -636,7 +783,8 @@ __device__ __forceinline__ jacT<F> madd_packed(const jacT<F> &acc, const uint4 *
     unpack_point<F>(q, x, y);
     if (f_is_zero(x) && f_is_zero(y)) return acc;
     if (neg) y = f_sub(FT<F>::zero(), y);      // negative digit: add -P = (x, -y)
-    return jac_madd(acc, x, y);
+    if constexpr (std::is_same<F, fq>::value) return jac_madd_lazy(acc, x, y);   // unreduced between the products; canonical at the store
+    else return jac_madd(acc, x, y);
 }
 // Buckets with more than MSM_HEAVY points are not summed by one lane: real scalars are not uniform (the top window of
 // a 254-bit scalar has 2-12 significant bits, witnesses are full of small values), and one lane walking a million points
@@ -689,7 +837,7 @@ __global__ void __launch_bounds__(256) msm_bucket_kernel(const uint4 *mont, u64 
             if (k + 1 < cnt) acc = madd_packed<F>(acc, B, vb >> 31);
         }
     }
-    buckets[id] = acc;
+    buckets[id] = jac_canon(acc);
 }
 // one workgroup per chunk of a heavy bucket: lane t sums points t, t+256, ... of the chunk, LDS tree over the lanes
 template <class F>
@@ -711,7 +859,7 @@ __global__ void __launch_bounds__(256) msm_heavy_kernel(const uint4 *mont, u64 n
         for (int j = 0; j < NV; j++) q[j] = mont[pi * NV + j];
         acc = madd_packed<F>(acc, q, vi >> 31);
     }
-    sh[threadIdx.x] = acc;
+    sh[threadIdx.x] = jac_canon(acc);
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) sh[threadIdx.x] = jac_add(sh[threadIdx.x], sh[threadIdx.x + s]);
