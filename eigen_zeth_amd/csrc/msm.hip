@@ -782,9 +782,14 @@ __device__ __forceinline__ jacT<F> madd_packed(const jacT<F> &acc, const uint4 *
     F x, y;
     unpack_point<F>(q, x, y);
     if (f_is_zero(x) && f_is_zero(y)) return acc;
-    if (neg) y = f_sub(FT<F>::zero(), y);      // negative digit: add -P = (x, -y)
-    if constexpr (std::is_same<F, fq>::value) return jac_madd_lazy(acc, x, y);   // unreduced between the products; canonical at the store
-    else return jac_madd(acc, x, y);
+    // negative digit: add -P = (x, -y)
+    if constexpr (std::is_same<F, fq>::value) {
+        if (neg) y = lz_sub<1>(fq_zero(), y);  // q - y in (0, q]: one carry pass
+        return jac_madd_lazy(acc, x, y);       // unreduced between the products; canonical at the store
+    } else {
+        if (neg) y = f_sub(FT<F>::zero(), y);
+        return jac_madd(acc, x, y);
+    }
 }
 // Buckets with more than MSM_HEAVY points are not summed by one lane: real scalars are not uniform (the top window of
 // a 254-bit scalar has 2-12 significant bits, witnesses are full of small values), and one lane walking a million points
