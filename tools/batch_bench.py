@@ -2,6 +2,9 @@
 aggregate -> Groth16 wrap, through the engine (no gRPC).  usage: python tools/batch_bench.py [K=16] [logn=20] [air=chunk64]"""
 import json, os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get('ZP_PRE_TORCH'):      # experiment: does a torch CUDA context in the process change the batch time?
+    import torch
+    torch.cuda.init(); _t = torch.zeros(1 << 20, device='cuda'); torch.cuda.synchronize()
 from eigen_zeth_amd.service.engine import Engine, EngineConfig
 from eigen_zeth_amd.service.server import default_backend_factory
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 16
