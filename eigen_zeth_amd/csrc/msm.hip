@@ -343,14 +343,61 @@ FQ_HD bool f_eq(const fq2 &a, const fq2 &b) { return fq_eq(a.c0, b.c0) && fq_eq(
 FQ_HD fq2 f_add(const fq2 &a, const fq2 &b) { return fq2_make(fq_add(a.c0, b.c0), fq_add(a.c1, b.c1)); }
 FQ_HD fq2 f_sub(const fq2 &a, const fq2 &b) { return fq2_make(fq_sub(a.c0, b.c0), fq_sub(a.c1, b.c1)); }
 FQ_HD fq2 f_dbl(const fq2 &a) { return fq2_make(fq_dbl(a.c0), fq_dbl(a.c1)); }
-FQ_HD fq2 f_mul(const fq2 &a, const fq2 &b) {   // Karatsuba: 3 products
-    const fq t0 = fq_mul(a.c0, b.c0), t1 = fq_mul(a.c1, b.c1);
-    const fq t2 = fq_mul(fq_add(a.c0, a.c1), fq_add(b.c0, b.c1));
-    return fq2_make(fq_sub(t0, t1), fq_sub(fq_sub(t2, t0), t1));
+// (a b + c d) / R mod q with ONE Montgomery reduction: the two products share the column accumulators (27 terms of < 2^58 per
+// column stay below 2^64).  Limbs < 2^29 (one operand of each product may have limbs < 2^30), a b + c d < 169 q^2.
+FQ_HD fq fq_mul2(const fq &a, const fq &b, const fq &c, const fq &d) {
+    u32 m[9], t[9];
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (u64)a.l[i] * b.l[k - i];
+            acc += (u64)c.l[i] * d.l[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (u64)m[i] * fq_q(k - i);
+        m[k] = ((u32)acc * FQ_INV29) & FQ_MASK;
+        acc += (u64)m[k] * FQ_Q0;
+        acc >>= FQ_B;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) {
+            acc += (u64)a.l[i] * b.l[k - i];
+            acc += (u64)c.l[i] * d.l[k - i];
+            acc += (u64)m[i] * fq_q(k - i);
+        }
+        t[k - 9] = (u32)acc & FQ_MASK;
+        acc >>= FQ_B;
+    }
+    t[8] = (u32)acc;
+    return fq_norm_sub(t);   // (ab + cd + mq)/R < q (2q/R + 1) < 2q
 }
-FQ_HD fq2 f_sqr(const fq2 &a) {   // (a0+a1)(a0-a1) + 2 a0 a1 u
-    const fq m = fq_mul(a.c0, a.c1);
-    return fq2_make(fq_mul(fq_add(a.c0, a.c1), fq_sub(a.c0, a.c1)), fq_dbl(m));
+// q - a in (0, q] with one signed carry pass (a canonical); congruent to -a, limbs < 2^29
+FQ_HD fq fq_neg_lazy(const fq &a) {
+    fq r;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int v = (int)fq_q(i) - (int)a.l[i] + c;
+        r.l[i] = i < 8 ? ((u32)v & FQ_MASK) : (u32)v;
+        c = v >> FQ_B;
+    }
+    return r;
+}
+// F_q2 products with the reduction delayed over the two terms of each component (no Karatsuba: the same 486 limb products,
+// two Montgomery reductions instead of three and none of its five additions / subtractions):
+//   (a0 + a1 u)(b0 + b1 u) = (a0 b0 + (q - a1) b1) + (a0 b1 + a1 b0) u
+FQ_HD fq2 f_mul(const fq2 &a, const fq2 &b) {
+    return fq2_make(fq_mul2(a.c0, b.c0, fq_neg_lazy(a.c1), b.c1), fq_mul2(a.c0, b.c1, a.c1, b.c0));
+}
+FQ_HD fq2 f_sqr(const fq2 &a) {   // (a0 a0 + (q - a1) a1) + (a0 * 2 a1) u
+    fq d;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d.l[i] = a.c1.l[i] << 1;      // 2 a1, limbs < 2^30
+    return fq2_make(fq_mul2(a.c0, a.c0, fq_neg_lazy(a.c1), a.c1), fq_mul(a.c0, d));
 }
 FQ_HD fq2 f_to_mont(const fq2 &a) { return fq2_make(fq_to_mont(a.c0), fq_to_mont(a.c1)); }
 FQ_HD fq2 f_from_mont(const fq2 &a) { return fq2_make(fq_from_mont(a.c0), fq_from_mont(a.c1)); }
