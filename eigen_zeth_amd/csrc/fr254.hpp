@@ -116,6 +116,40 @@ GL_HD fr fr_mul(const fr &a, const fr &b) {
     t[8] = (u32)acc;
     return fr_norm_sub(t);
 }
+// (a0 b0 + a1 b1 + a2 b2) / R mod r with ONE Montgomery reduction: the three products share the column accumulators
+// (36 terms of < 2^58 per column stay below 2^64).  All limbs < 2^29; the sum is < 3 r^2 < R r, so the result is < 2 r.
+GL_HD fr fr_mul3(const fr &a0, const fr &b0, const fr &a1, const fr &b1, const fr &a2, const fr &b2) {
+    u32 m[9], t[9];
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (u64)a0.l[i] * b0.l[k - i];
+            acc += (u64)a1.l[i] * b1.l[k - i];
+            acc += (u64)a2.l[i] * b2.l[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (u64)m[i] * fr_p(k - i);
+        m[k] = ((u32)acc * FR_INV29) & FR_MASK;
+        acc += (u64)m[k] * fr_p(0);
+        acc >>= FR_B;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) {
+            acc += (u64)a0.l[i] * b0.l[k - i];
+            acc += (u64)a1.l[i] * b1.l[k - i];
+            acc += (u64)a2.l[i] * b2.l[k - i];
+            acc += (u64)m[i] * fr_p(k - i);
+        }
+        t[k - 9] = (u32)acc & FR_MASK;
+        acc >>= FR_B;
+    }
+    t[8] = (u32)acc;
+    return fr_norm_sub(t);
+}
 GL_HD fr fr_to_mont(const fr &a) { return fr_mul(a, fr_r2()); }
 GL_HD fr fr_from_mont(const fr &a) {
     fr one = fr_zero();

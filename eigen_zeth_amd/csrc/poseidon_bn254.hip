@@ -56,14 +56,20 @@ __device__ __forceinline__ fr full_round(fr s, int q, int e, bool on, u32 (*sh)[
         for (int i = 0; i < 9; i++) sh[q][e][i] = s.l[i];
     }
     __syncthreads();
-    if (on) {
-        fr acc = fr_zero();
-        for (int j = 0; j < T; j++) {
+    if (on) {   // row e of the matrix: three products per Montgomery reduction (fr_mul3), T = 3 k + rest
+        auto lds = [&](int j) {
             fr v;
 #pragma unroll
             for (int i = 0; i < 9; i++) v.l[i] = sh[q][j][i];
-            acc = fr_add(acc, fr_mul(fr_load(m + ((size_t)e * T + j) * 9), v));
-        }
+            return v;
+        };
+        const u32 *row = m + (size_t)e * T * 9;
+        fr acc = fr_zero();
+        int j = 0;
+        for (; j + 3 <= T; j += 3)
+            acc = fr_add(acc, fr_mul3(fr_load(row + (size_t)j * 9), lds(j), fr_load(row + (size_t)(j + 1) * 9), lds(j + 1),
+                                      fr_load(row + (size_t)(j + 2) * 9), lds(j + 2)));
+        for (; j < T; j++) acc = fr_add(acc, fr_mul(fr_load(row + (size_t)j * 9), lds(j)));
         s = acc;
     }
     __syncthreads();
