@@ -53,6 +53,8 @@ void zp_destroy(zp_ctx *ctx) {
     }
     for (int i = 0; i < 4; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    for (auto &kv : ctx->prove_pool) (void)hipFree(kv.second);
+    for (auto &kv : ctx->prove_fixed) (void)hipFree(kv.second);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->msm_arena) (void)hipFree(ctx->msm_arena);
     if (ctx->d_rc) (void)hipFree(ctx->d_rc);

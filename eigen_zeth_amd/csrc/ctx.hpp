@@ -71,6 +71,11 @@ struct zp_ctx {
     int tune_ntt_chunk_log = 0;   // 0 = 28: columns per launch such that a ping-pong scratch buffer is <= 2 GiB
     int tune_msm_c = 0;           // 0 = window width chosen from n
     int tune_msm_chunk_log = 0;   // 0 = default (2^24 points per Pippenger run)
+    // zp_stark_prove: device buffers kept between proofs (chunk after chunk has the same shapes; hipMalloc / hipFree of ~20 buffers
+    // cost milliseconds per proof) and the LDE of the two boundary selectors per (logn, logb, shift, root)
+    std::multimap<size_t, void *> prove_pool;
+    size_t prove_pool_bytes = 0;
+    std::map<std::string, u64 *> prove_fixed;
     // per-launch event profiling (zp_set_profiling)
     bool profiling = false;
     struct PassEv { hipEvent_t a, b; int radix_log; };

@@ -1,0 +1,496 @@
+// zp_stark_prove: the whole chunk-STARK prover behind ONE C-ABI call -- trace in HBM in, proof bytes out.
+// Serves GenChunkProof (proto/prover/v1/prover.proto:56-66; client src/prover/provider.rs:358-390): a host in any
+// language binds this entry point and needs neither the Python orchestration (eigen_zeth_amd/stark/prover.py, which stays
+// the readable statement of the protocol and the harness of the parity tests) nor a compiler -- the statement is the
+// constraint program blob.  Host C++ only: every O(trace) step is one of the library's own entry points (zp_lde,
+// zp_merkle_commit, zp_eval_quotient, zp_poly_eval_ext, zp_deep_quotient, zp_fri_fold, ...), the Fiat-Shamir transcript
+// runs through zp_poseidon_sponge.  The proof text is byte-identical to proof_to_json(prove(...)) of the Python
+// orchestration on the same inputs (tests/test_gpu_native_prover.py), Goldilocks-hash mode.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ctx.hpp"
+
+namespace {
+
+// ---- SHA-256 (FIPS 180-4) of the program blob: the AIR digest bound into the transcript
+struct Sha256 {
+    uint32_t h[8];
+    static uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    static void block(uint32_t *h, const uint8_t *p) {
+        static const uint32_t K[64] = {
+            0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+            0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+            0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+            0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+            0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+            0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+        uint32_t w[64];
+        for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+        for (int i = 16; i < 64; i++) {
+            const uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; i++) {
+            const uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            const uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    static void digest(const uint8_t *data, size_t len, uint8_t out[32]) {
+        uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+        size_t i = 0;
+        for (; i + 64 <= len; i += 64) block(h, data + i);
+        uint8_t tail[128];
+        const size_t rem = len - i;
+        memcpy(tail, data + i, rem);
+        tail[rem] = 0x80;
+        const size_t padded = rem + 1 + 8 <= 64 ? 64 : 128;
+        memset(tail + rem + 1, 0, padded - rem - 1);
+        const uint64_t bits = (uint64_t)len * 8;
+        for (int k = 0; k < 8; k++) tail[padded - 1 - k] = (uint8_t)(bits >> (8 * k));
+        block(h, tail);
+        if (padded == 128) block(h, tail + 64);
+        for (int k = 0; k < 8; k++) { out[4 * k] = (uint8_t)(h[k] >> 24); out[4 * k + 1] = (uint8_t)(h[k] >> 16); out[4 * k + 2] = (uint8_t)(h[k] >> 8); out[4 * k + 3] = (uint8_t)h[k]; }
+    }
+};
+
+// ---- the Fiat-Shamir sponge of stark/transcript.py (rate 8, capacity 4) on zp_poseidon_sponge
+struct Transcript {
+    zp_ctx *ctx;
+    u64 state[12];
+    std::vector<u64> pending, out;
+    int32_t rc = ZP_OK;
+    explicit Transcript(zp_ctx *c) : ctx(c) { memset(state, 0, sizeof state); }
+    void absorb(const u64 *v, size_t n) {
+        for (size_t i = 0; i < n; i++) pending.push_back(v[i] % GL_P);
+        out.clear();
+    }
+    void absorb(const std::vector<u64> &v) { absorb(v.data(), v.size()); }
+    void flush(size_t want) {
+        const size_t nblk = (pending.size() + 7) / 8;
+        std::vector<u64> blocks(nblk * 8, 0);
+        memcpy(blocks.data(), pending.data(), pending.size() * 8);
+        pending.clear();
+        const size_t extra = want > 8 ? (want + 7) / 8 - 1 : 0;
+        std::vector<u64> rates((1 + extra) * 8);
+        const int32_t r = zp_poseidon_sponge(ctx, (uint64_t *)state, (const uint64_t *)blocks.data(), nblk, extra, (uint64_t *)rates.data());
+        if (r != ZP_OK && rc == ZP_OK) rc = r;
+        out.assign(rates.begin(), rates.end());
+    }
+    std::vector<u64> squeeze(size_t n) {
+        std::vector<u64> res;
+        size_t at = 0;
+        while (res.size() < n) {
+            if (!pending.empty() || at >= out.size()) {
+                flush(n - res.size());
+                at = 0;
+                if (rc != ZP_OK) { res.resize(n, 0); return res; }
+            }
+            res.push_back(out[at++]);
+        }
+        out.erase(out.begin(), out.begin() + at);
+        return res;
+    }
+    e3 challenge() {
+        const std::vector<u64> v = squeeze(3);
+        return e3_make(v[0], v[1], v[2]);
+    }
+};
+
+// Device buffers of one proof.  They come from, and go back to, a per-ctx pool keyed by size: everything runs on the ctx
+// stream, so a buffer handed out again is only touched by work enqueued after its previous user.
+#define PROVE_POOL_CAP ((size_t)24 << 30)
+struct DevBufs {
+    zp_ctx *ctx;
+    std::vector<std::pair<void *, size_t>> bufs;
+    explicit DevBufs(zp_ctx *c) : ctx(c) {}
+    ~DevBufs() { for (auto &b : bufs) give_back(b.first, b.second); }
+    void give_back(void *p, size_t bytes) {
+        if (ctx->prove_pool_bytes + bytes <= PROVE_POOL_CAP) {
+            ctx->prove_pool.emplace(bytes, p);
+            ctx->prove_pool_bytes += bytes;
+        } else {
+            (void)zp_dev_free(ctx, p);
+        }
+    }
+    int32_t alloc(size_t elems, u64 **out) {
+        const size_t bytes = (elems ? elems : 1) * 8;
+        auto it = ctx->prove_pool.find(bytes);
+        void *p = nullptr;
+        if (it != ctx->prove_pool.end()) {
+            p = it->second;
+            ctx->prove_pool.erase(it);
+            ctx->prove_pool_bytes -= bytes;
+        } else {
+            int32_t r = zp_dev_alloc(ctx, bytes, &p);
+            if (r == ZP_ERR_NOMEM && !ctx->prove_pool.empty()) {      // give the pool back to the device and try once more
+                for (auto &kv : ctx->prove_pool) (void)zp_dev_free(ctx, kv.second);
+                ctx->prove_pool.clear();
+                ctx->prove_pool_bytes = 0;
+                r = zp_dev_alloc(ctx, bytes, &p);
+            }
+            if (r != ZP_OK) return r;
+        }
+        bufs.emplace_back(p, bytes);
+        *out = (u64 *)p;
+        return ZP_OK;
+    }
+    void release(u64 *p) {
+        for (size_t i = 0; i < bufs.size(); i++)
+            if (bufs[i].first == (void *)p) { give_back(bufs[i].first, bufs[i].second); bufs.erase(bufs.begin() + i); return; }
+    }
+    void forget(u64 *p) {      // ownership moves elsewhere (a ctx-level cache)
+        for (size_t i = 0; i < bufs.size(); i++)
+            if (bufs[i].first == (void *)p) { bufs.erase(bufs.begin() + i); return; }
+    }
+};
+
+// ---- JSON text exactly as json.dumps(proof, separators=(",", ":")) writes it
+void j_u64(std::string &s, u64 v) {
+    char b[24];
+    snprintf(b, sizeof b, "%llu", (unsigned long long)v);
+    s += b;
+}
+void j_list(std::string &s, const u64 *v, size_t n) {
+    s += '[';
+    for (size_t i = 0; i < n; i++) { if (i) s += ','; j_u64(s, v[i]); }
+    s += ']';
+}
+void j_e3list(std::string &s, const std::vector<u64> &v) {   // [[a,b,c],...]
+    s += '[';
+    for (size_t i = 0; i * 3 < v.size(); i++) { if (i) s += ','; j_list(s, &v[3 * i], 3); }
+    s += ']';
+}
+void j_opening(std::string &s, const u64 *vals, size_t W, const u64 *path, size_t depth) {   // {"values":[..],"path":[[4]..]}
+    s += "{\"values\":";
+    j_list(s, vals, W);
+    s += ",\"path\":[";
+    for (size_t d = 0; d < depth; d++) { if (d) s += ','; j_list(s, path + 4 * d, 4); }
+    s += "]}";
+}
+
+#define PV_TRY(expr)                                                    \
+    do {                                                                \
+        const int32_t rc_ = (expr);                                     \
+        if (rc_ != ZP_OK) return rc_;                                   \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int32_t zp_free_buffer(void *p) {
+    free(p);
+    return ZP_OK;
+}
+
+int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
+                       const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
+                       int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "stark_prove");
+    ZP_ARG(ctx, air_name && h_program && d_trace && out_json && out_len && (h_pubs || n_pubs == 0), "null pointer");
+    ZP_ARG(ctx, program_words >= 12, "constraint program shorter than its header");
+    static const unsigned char magic[8] = {'Z', 'P', 'A', 'I', 'R', '1', 0, 0};
+    ZP_ARG(ctx, memcmp(h_program, magic, 8) == 0, "not a ZPAIR1 constraint program");
+    const size_t W = h_program[1], W2 = h_program[2], n_pub_prog = h_program[4], n_chal = h_program[5], n_const = h_program[6],
+                 n_instr = h_program[7], K = h_program[8], n_s2 = h_program[10], Q = h_program[11];
+    ZP_ARG(ctx, n_const < (1u << 16) && n_instr < (1u << 24) && n_s2 < (1u << 16) && program_words == 12 + n_const + n_instr + 4 * n_s2,
+           "constraint program length does not match its header");
+    ZP_ARG(ctx, (size_t)n_pubs == n_pub_prog, "number of public inputs does not match the program");
+    ZP_ARG(ctx, W >= 1 && W < 4096 && W2 < 4096 && K >= 1 && Q >= 1 && Q <= 16, "program dimensions out of range");
+    ZP_ARG(ctx, logn >= 1 && logb >= 1 && logn + logb <= 30 && fri_logf >= 1 && fri_logf <= 4 && fri_final_log >= 0 && fri_final_log < logn &&
+                    n_queries >= 1 && n_queries <= 4096 && pow_bits >= 0 && pow_bits <= 40, "STARK parameters out of range");
+    ZP_ARG(ctx, Q <= ((size_t)1 << logb), "the blow-up must cover the quotient degree");
+    ZP_ARG(ctx, (n_s2 == 0) == (W2 == 0) && (n_s2 == 0 || n_chal == 3), "stage-2 table and widths disagree");
+    for (int i = 0; i < n_pubs; i++) ZP_ARG(ctx, h_pubs[i] < GL_P, "public input not canonical");
+    const u64 *stage2 = (const u64 *)h_program + 12 + n_const + n_instr;
+    size_t w2sum = 0;
+    for (size_t k = 0; k < n_s2; k++) {
+        const u64 kind = stage2[4 * k];
+        ZP_ARG(ctx, kind == 1 || kind == 2, "unknown stage-2 argument");
+        ZP_ARG(ctx, stage2[4 * k + 1] < W && stage2[4 * k + 2] < W && stage2[4 * k + 3] < W, "stage-2 column out of range");
+        w2sum += kind == 1 ? 3 : 9;
+    }
+    ZP_ARG(ctx, w2sum == W2, "stage-2 width does not match its table");
+
+    const int logm = logn + logb;
+    const size_t N = (size_t)1 << logn, M = (size_t)1 << logm, Wt = W + W2;
+    const u64 shift = ctx->coset_shift, root32 = ctx->root32;
+    const u64 wN = gl_root(root32, logn);
+    DevBufs dev(ctx);
+
+    // AIR digest: sha256 of the blob; the first 16 hex digits name it, four little-endian words go into the transcript
+    uint8_t dg[32];
+    Sha256::digest((const uint8_t *)h_program, program_words * 8, dg);
+    char dg_hex[17];
+    for (int i = 0; i < 8; i++) snprintf(dg_hex + 2 * i, 3, "%02x", dg[i]);
+    std::vector<u64> first = {(u64)logn, (u64)logb, (u64)W, (u64)W2, (u64)fri_logf, (u64)fri_final_log, (u64)n_queries, (u64)pow_bits, root32, shift};
+    for (int i = 0; i < 4; i++) {
+        u64 wd = 0;
+        for (int k = 0; k < 8; k++) wd |= (u64)dg[8 * i + k] << (8 * k);
+        first.push_back(wd % GL_P);
+    }
+    first.push_back((u64)n_pubs);
+    for (int i = 0; i < n_pubs; i++) first.push_back(h_pubs[i]);
+    Transcript tr(ctx);
+    tr.absorb(first);
+
+    // 1. commit the trace (ext / coef have room for the stage-2 columns behind the trace columns)
+    u64 *ext, *coef, *tree1;
+    PV_TRY(dev.alloc(Wt * M, &ext));
+    PV_TRY(dev.alloc(Wt * N, &coef));
+    PV_TRY(dev.alloc((2 * M - 1) * 4, &tree1));
+    PV_TRY(zp_lde(ctx, d_trace, (uint64_t *)ext, (uint64_t *)coef, logn, logb, (int32_t)W, shift));
+    PV_TRY(zp_merkle_commit(ctx, (const uint64_t *)ext, M, (int32_t)W, (uint64_t *)tree1));
+    u64 root1[4], root2[4] = {0, 0, 0, 0}, rootq[4];
+    PV_TRY(zp_d2h(ctx, root1, tree1 + (2 * M - 2) * 4, 32));
+    tr.absorb(root1, 4);
+    std::vector<u64> pubchal(h_pubs, h_pubs + n_pubs);
+    u64 *tree2 = nullptr;
+    if (n_s2) {
+        const e3 chal = tr.challenge();
+        PV_TRY(tr.rc);
+        u64 *s2;
+        PV_TRY(dev.alloc(W2 * N, &s2));
+        size_t at = 0;
+        for (size_t k = 0; k < n_s2; k++) {
+            const u64 *st = stage2 + 4 * k;
+            if (st[0] == 1) {
+                PV_TRY(zp_grand_product(ctx, d_trace + st[1] * N, d_trace + st[2] * N, N, (const uint64_t *)chal.c, (uint64_t *)(s2 + at * N)));
+                at += 3;
+            } else {
+                PV_TRY(zp_logup_columns(ctx, d_trace + st[1] * N, d_trace + st[2] * N, d_trace + st[3] * N, N, (const uint64_t *)chal.c, (uint64_t *)(s2 + at * N)));
+                at += 9;
+            }
+        }
+        PV_TRY(zp_lde(ctx, (const uint64_t *)s2, (uint64_t *)(ext + W * M), (uint64_t *)(coef + W * N), logn, logb, (int32_t)W2, shift));
+        PV_TRY(dev.alloc((2 * M - 1) * 4, &tree2));
+        PV_TRY(zp_merkle_commit(ctx, (const uint64_t *)(ext + W * M), M, (int32_t)W2, (uint64_t *)tree2));
+        PV_TRY(zp_d2h(ctx, root2, tree2 + (2 * M - 2) * 4, 32));
+        dev.release(s2);
+        tr.absorb(root2, 4);
+        for (int c = 0; c < 3; c++) pubchal.push_back(chal.c[c]);
+    }
+    const e3 alpha = tr.challenge();
+    PV_TRY(tr.rc);
+
+    // 2. constraint quotient on the coset
+    u64 *fixed, *dq, *dqcoef;
+    {
+        char key[96];
+        snprintf(key, sizeof key, "%d/%d/%llx/%llx", logn, logb, (unsigned long long)shift, (unsigned long long)root32);
+        auto it = ctx->prove_fixed.find(key);
+        if (it != ctx->prove_fixed.end()) {
+            fixed = it->second;
+        } else {                      // LDE of the boundary selectors L_first, L_last: once per domain
+            std::vector<u64> ind(2 * N, 0);
+            ind[0] = 1;
+            ind[N + N - 1] = 1;
+            u64 *dind;
+            PV_TRY(dev.alloc(2 * N, &dind));
+            PV_TRY(zp_h2d(ctx, dind, ind.data(), 2 * N * 8));
+            void *pf = nullptr;
+            PV_TRY(zp_dev_alloc(ctx, 2 * M * 8, &pf));
+            fixed = (u64 *)pf;
+            const int32_t r = zp_lde(ctx, (const uint64_t *)dind, (uint64_t *)fixed, nullptr, logn, logb, 2, shift);
+            if (r != ZP_OK) { (void)zp_dev_free(ctx, pf); return r; }
+            dev.release(dind);
+            ctx->prove_fixed[key] = fixed;
+        }
+    }
+    std::vector<u64> apow(3 * K);
+    {
+        e3 cur = e3_make(1, 0, 0);
+        for (size_t k = 0; k < K; k++) { memcpy(&apow[3 * k], cur.c, 24); cur = e3_mul(cur, alpha); }
+    }
+    std::vector<u64> zhinv((size_t)1 << logb);
+    {
+        const u64 sN = gl_pow(shift, (u64)N), wb = gl_root(root32, logb);
+        u64 p = 1;
+        for (size_t j = 0; j < zhinv.size(); j++) { zhinv[j] = gl_inv(gl_sub(gl_mul(sN, p), 1)); p = gl_mul(p, wb); }
+    }
+    PV_TRY(dev.alloc(3 * M, &dq));
+    PV_TRY(zp_eval_quotient(ctx, h_program, program_words, (const uint64_t *)ext, (const uint64_t *)fixed, logm, logb, (const uint64_t *)pubchal.data(),
+                            (int32_t)pubchal.size(), (const uint64_t *)apow.data(), (const uint64_t *)zhinv.data(), shift, gl_inv(wN), (uint64_t *)dq));
+    PV_TRY(dev.alloc(3 * M, &dqcoef));
+    PV_TRY(zp_intt(ctx, (const uint64_t *)dq, (uint64_t *)dqcoef, logm, 3));       // coefficients of q_c(shift X): c_i shift^i
+    int q_logn = logm;
+    size_t Wq = 3;
+    u64 *treeq;
+    PV_TRY(dev.alloc((2 * M - 1) * 4, &treeq));
+    if (Q > 1) {
+        // q(x) = sum_j (x / shift)^(jN) qt_j(x): the pieces are slices of the coefficient vector in hand; their LDEs get committed
+        u64 *pcoef, *pad, *pext;
+        PV_TRY(dev.alloc(3 * Q * N, &pcoef));
+        PV_TRY(dev.alloc(3 * Q * M, &pad));
+        PV_TRY(zp_dev_zero(ctx, pad, 3 * Q * M * 8));
+        for (size_t j = 0; j < Q; j++)
+            for (int c = 0; c < 3; c++) {
+                const u64 *src = dqcoef + c * M + j * N;
+                PV_TRY(zp_d2d(ctx, pcoef + (3 * j + c) * N, src, N * 8));
+                PV_TRY(zp_d2d(ctx, pad + (3 * j + c) * M, src, N * 8));
+            }
+        PV_TRY(dev.alloc(3 * Q * M, &pext));
+        PV_TRY(zp_ntt(ctx, (const uint64_t *)pad, (uint64_t *)pext, logm, (int32_t)(3 * Q)));
+        PV_TRY(zp_sync(ctx));
+        dev.release(pad);
+        dev.release(dq);
+        dev.release(dqcoef);
+        dq = pext;
+        dqcoef = pcoef;
+        q_logn = logn;
+        Wq = 3 * Q;
+    }
+    PV_TRY(zp_merkle_commit(ctx, (const uint64_t *)dq, M, (int32_t)Wq, (uint64_t *)treeq));
+    PV_TRY(zp_d2h(ctx, rootq, treeq + (2 * M - 2) * 4, 32));
+    tr.absorb(rootq, 4);
+    const e3 zeta = tr.challenge();
+    PV_TRY(tr.rc);
+
+    // 3. out-of-domain evaluations (coefficient buffers hold c_i shift^i: evaluate at z / shift)
+    const u64 sinv = gl_inv(shift);
+    const e3 zeta_w = e3_scale(zeta, wN);
+    const e3 zs = e3_scale(zeta, sinv), zws = e3_scale(zeta_w, sinv);
+    std::vector<u64> ev_all((Wt + Wq) * 3), ev_next(Wt * 3);
+    PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef, logn, (int32_t)Wt, (const uint64_t *)zs.c, (uint64_t *)ev_all.data()));
+    PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef, logn, (int32_t)Wt, (const uint64_t *)zws.c, (uint64_t *)ev_next.data()));
+    PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)dqcoef, q_logn, (int32_t)Wq, (const uint64_t *)zs.c, (uint64_t *)(ev_all.data() + Wt * 3)));
+    tr.absorb(ev_all);
+    tr.absorb(ev_next);
+    const e3 gamma = tr.challenge();
+    PV_TRY(tr.rc);
+
+    // 4. DEEP quotient
+    u64 *df;
+    PV_TRY(dev.alloc(3 * M, &df));
+    PV_TRY(zp_deep_quotient(ctx, (const uint64_t *)ext, (int32_t)Wt, (const uint64_t *)dq, (int32_t)Wq, logm, (int32_t)Wt, (const uint64_t *)zeta.c, (const uint64_t *)zeta_w.c, (const uint64_t *)gamma.c,
+                            (const uint64_t *)ev_all.data(), (const uint64_t *)ev_next.data(), shift, (uint64_t *)df));
+
+    // 5. FRI
+    struct Layer { int lg, f; u64 *tree, *data; u64 root[4]; };
+    std::vector<Layer> layers;
+    int cur = logm;
+    u64 cur_shift = shift;
+    u64 *dlayer = df;
+    while (cur > fri_final_log + logb) {
+        const int f = fri_logf < cur - (fri_final_log + logb) ? fri_logf : cur - (fri_final_log + logb);
+        Layer L;
+        L.lg = cur; L.f = f; L.data = dlayer;
+        const size_t m = (size_t)1 << (cur - f);
+        PV_TRY(dev.alloc((2 * m - 1) * 4, &L.tree));
+        PV_TRY(zp_merkle_commit(ctx, (const uint64_t *)dlayer, m, 3 << f, (uint64_t *)L.tree));   // leaf = the 2^f * 3 values folded together
+        PV_TRY(zp_d2h(ctx, L.root, L.tree + (2 * m - 2) * 4, 32));
+        tr.absorb(L.root, 4);
+        const e3 beta = tr.challenge();
+        PV_TRY(tr.rc);
+        u64 *next;
+        PV_TRY(dev.alloc((size_t)3 << (cur - f), &next));
+        PV_TRY(zp_fri_fold(ctx, (const uint64_t *)dlayer, (uint64_t *)next, cur, f, (const uint64_t *)beta.c, cur_shift));
+        layers.push_back(L);
+        dlayer = next;
+        cur_shift = gl_pow(cur_shift, (u64)1 << f);
+        cur -= f;
+    }
+    const int final_log = cur;
+    std::vector<u64> final_l((size_t)3 << final_log);
+    PV_TRY(zp_d2h(ctx, final_l.data(), dlayer, final_l.size() * 8));
+    tr.absorb(final_l);
+
+    // 6. proof of work, then the queries
+    u64 nonce = 0;
+    if (pow_bits) {
+        const std::vector<u64> seed = tr.squeeze(4);
+        PV_TRY(tr.rc);
+        PV_TRY(zp_pow_grind(ctx, (const uint64_t *)seed.data(), pow_bits, (uint64_t *)&nonce));
+        tr.absorb(&nonce, 1);
+    }
+    std::vector<u64> qidx = tr.squeeze((size_t)n_queries);
+    PV_TRY(tr.rc);
+    for (u64 &v : qidx) v &= (M - 1);
+    const size_t nq = (size_t)n_queries, depth = (size_t)logm;
+    std::vector<u64> v_tr(nq * W), p_tr(nq * depth * 4), v_s2, p_s2, v_q(nq * Wq), p_q(nq * depth * 4);
+    PV_TRY(zp_gather_rows(ctx, (const uint64_t *)ext, M, (int32_t)W, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)v_tr.data()));
+    PV_TRY(zp_merkle_open_batch(ctx, (const uint64_t *)tree1, M, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)p_tr.data()));
+    if (n_s2) {
+        v_s2.resize(nq * W2);
+        p_s2.resize(nq * depth * 4);
+        PV_TRY(zp_gather_rows(ctx, (const uint64_t *)(ext + W * M), M, (int32_t)W2, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)v_s2.data()));
+        PV_TRY(zp_merkle_open_batch(ctx, (const uint64_t *)tree2, M, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)p_s2.data()));
+    }
+    PV_TRY(zp_gather_rows(ctx, (const uint64_t *)dq, M, (int32_t)Wq, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)v_q.data()));
+    PV_TRY(zp_merkle_open_batch(ctx, (const uint64_t *)treeq, M, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)p_q.data()));
+    struct FriOpen { std::vector<u64> vals, paths; size_t width, depth; };
+    std::vector<FriOpen> fo(layers.size());
+    {
+        std::vector<u64> pos = qidx;
+        for (size_t li = 0; li < layers.size(); li++) {
+            const Layer &L = layers[li];
+            const size_t m = (size_t)1 << (L.lg - L.f);
+            for (u64 &p : pos) p &= (m - 1);
+            fo[li].width = (size_t)3 << L.f;
+            fo[li].depth = (size_t)(L.lg - L.f);
+            fo[li].vals.resize(nq * fo[li].width);
+            fo[li].paths.resize(nq * (fo[li].depth ? fo[li].depth : 1) * 4);
+            PV_TRY(zp_gather_rows(ctx, (const uint64_t *)L.data, m, (int32_t)fo[li].width, (const uint64_t *)pos.data(), n_queries, (uint64_t *)fo[li].vals.data()));
+            PV_TRY(zp_merkle_open_batch(ctx, (const uint64_t *)L.tree, m, (const uint64_t *)pos.data(), n_queries, (uint64_t *)fo[li].paths.data()));
+        }
+    }
+
+    // the proof text
+    std::string s;
+    s.reserve(nq * (Wt + Wq + 64) * 24 + (1 << 16));
+    s += "{\"air\":\"";
+    s += air_name;
+    s += "\",\"air_digest\":\"";
+    s += dg_hex;
+    s += "\",\"params\":{\"logn\":";
+    j_u64(s, (u64)logn); s += ",\"logb\":"; j_u64(s, (u64)logb); s += ",\"fri_logf\":"; j_u64(s, (u64)fri_logf);
+    s += ",\"fri_final_log\":"; j_u64(s, (u64)fri_final_log); s += ",\"n_queries\":"; j_u64(s, (u64)n_queries);
+    s += ",\"pow_bits\":"; j_u64(s, (u64)pow_bits);
+    s += "},\"root32\":"; j_u64(s, root32);
+    s += ",\"shift\":"; j_u64(s, shift);
+    s += ",\"publics\":"; j_list(s, (const u64 *)h_pubs, (size_t)n_pubs);
+    s += ",\"roots\":{\"trace\":"; j_list(s, root1, 4);
+    s += ",\"quotient\":"; j_list(s, rootq, 4);
+    if (n_s2) { s += ",\"stage2\":"; j_list(s, root2, 4); }
+    s += "},\"evals\":{\"z\":"; j_e3list(s, ev_all);
+    s += ",\"zw\":"; j_e3list(s, ev_next);
+    s += "},\"fri\":{\"roots\":[";
+    for (size_t li = 0; li < layers.size(); li++) { if (li) s += ','; j_list(s, layers[li].root, 4); }
+    s += "],\"final\":[";
+    for (int c = 0; c < 3; c++) { if (c) s += ','; j_list(s, &final_l[(size_t)c << final_log], (size_t)1 << final_log); }
+    s += "]},\"queries\":[";
+    for (size_t i = 0; i < nq; i++) {
+        if (i) s += ',';
+        s += "{\"index\":"; j_u64(s, qidx[i]);
+        s += ",\"trace\":"; j_opening(s, &v_tr[i * W], W, &p_tr[i * depth * 4], depth);
+        s += ",\"quotient\":"; j_opening(s, &v_q[i * Wq], Wq, &p_q[i * depth * 4], depth);
+        if (n_s2) { s += ",\"stage2\":"; j_opening(s, &v_s2[i * W2], W2, &p_s2[i * depth * 4], depth); }
+        s += ",\"fri\":[";
+        for (size_t li = 0; li < layers.size(); li++) {
+            if (li) s += ',';
+            j_opening(s, &fo[li].vals[i * fo[li].width], fo[li].width, &fo[li].paths[i * (fo[li].depth ? fo[li].depth : 1) * 4], fo[li].depth);
+        }
+        s += "]}";
+    }
+    s += ']';
+    if (pow_bits) { s += ",\"pow_nonce\":"; j_u64(s, nonce); }
+    s += '}';
+    char *buf = (char *)malloc(s.size() + 1);
+    if (!buf) { ctx->err = "out of host memory for the proof text"; return ZP_ERR_NOMEM; }
+    memcpy(buf, s.data(), s.size() + 1);
+    *out_json = buf;
+    *out_len = s.size();
+    return ZP_OK;
+}
+
+}  // extern "C"

@@ -57,6 +57,9 @@ SIGNATURES = {
     "zp_lde": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_poseidon_perm": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "zp_pow_grind": (C.c_int32, [_vp, _vp, C.c_int32, _vp]),
+    "zp_stark_prove": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "zp_free_buffer": (C.c_int32, [_vp]),
     "zp_poseidon_sponge": (C.c_int32, [_vp, _u64p, _u64p, C.c_size_t, C.c_size_t, _u64p]),
     "zp_deep_quotient_rows": (C.c_int32, [_vp, _vp, C.c_int32, C.c_size_t, _vp, C.c_int32, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, C.c_int32,
                                           _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, C.c_size_t]),
@@ -420,6 +423,18 @@ class Prover:
         ms = C.c_float(0)
         self._chk(self.lib.zp_hbm_copy_probe(self.ctx, _ptr(d_src), _ptr(d_dst), nbytes, reps, C.byref(ms)))
         return float(ms.value)
+
+    def stark_prove(self, air_name, program, d_trace, pubs, logn, logb, fri_logf, fri_final_log, n_queries, pow_bits):
+        """the whole chunk STARK in one C-ABI call (zp_stark_prove): device trace u64[W][2^logn] + constraint program blob -> proof text"""
+        prog = np.ascontiguousarray(np.asarray(program, dtype=np.uint64))
+        pb = np.ascontiguousarray(np.asarray(list(pubs) + [0], dtype=np.uint64))
+        out, n = C.c_void_p(), C.c_size_t(0)
+        self._chk(self.lib.zp_stark_prove(self.ctx, air_name.encode(), prog.ctypes.data, prog.size, _ptr(d_trace), pb.ctypes.data, len(pubs),
+                                          logn, logb, fri_logf, fri_final_log, n_queries, pow_bits, C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out.value, n.value).decode()
+        finally:
+            self.lib.zp_free_buffer(out)
 
     def poseidon_sponge(self, state, blocks, extra=0):
         """state: 12 ints, blocks: list of 8-int blocks -> (new state, [rate after absorbing, rate after each extra permutation])"""

@@ -34,7 +34,7 @@ class EngineConfig:
     def __init__(self, air="chunk64", logn=12, logb=1, chunks_per_block=1, n_queries=80, fri_logf=3, fri_final_log=5,
                  groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
                  witness_threads=8, prover_streams=8, pow_bits=20,
-                 final_air="chunk16", final_logn=10, final_logb=2, final_queries=50):
+                 final_air="chunk16", final_logn=10, final_logb=2, final_queries=50, native_prover=True):
         self.air, self.logn, self.logb = air, logn, logb
         self.chunks_per_block, self.n_queries, self.pow_bits = chunks_per_block, n_queries, pow_bits
         self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
@@ -44,6 +44,7 @@ class EngineConfig:
         self.prover_streams = prover_streams   # chunk proofs in flight on one GPU (each on its own ctx / stream); 8 measured best (profiles/r2_streams_sweep.txt)
         # the final STARK (BN128-hash mode, no grinding: 50 queries x blow-up 4 = 100 bits conjectured)
         self.final_air, self.final_logn, self.final_logb, self.final_queries = final_air, final_logn, final_logb, final_queries
+        self.native_prover = native_prover     # chunk proofs through zp_stark_prove (False: the Python orchestration, per-stage timings)
 
 
 class Engine:
@@ -199,16 +200,24 @@ class Engine:
             try:
                 tm = {"witness(host)": tw}
                 params = self.stark_params(ch["logn"])
-                proof = PR.prove(air, trace, pubs, params, be, timings=tm)
+                if self.cfg.native_prover and hasattr(be, "prove_native"):
+                    # one C-ABI call per chunk (zp_stark_prove): the orchestration runs in the library, Python only frames the result
+                    t0 = time.perf_counter()
+                    text = be.prove_native(air, trace, pubs, params)
+                    tm["total"] = time.perf_counter() - t0
+                    text = text[:-1] + ',"chunk":{"block":%d,"chunk":%d}}' % (ch["block"], ch["chunk"])
+                else:
+                    proof = PR.prove(air, trace, pubs, params, be, timings=tm)
+                    proof["chunk"] = {"block": ch["block"], "chunk": ch["chunk"]}
+                    text = PR.proof_to_json(proof)
             finally:
                 free_be.put(be)
                 ahead.release()
             del trace
-            proof["chunk"] = {"block": ch["block"], "chunk": ch["chunk"]}
             self.stage_timings["%s/%d" % (task_id, i)] = tm
             if self.metrics is not None:
                 self.metrics.record_proof(tm, ch["logn"], self.cfg.logb, air.width)
-            return {"chunk_id": i, "proof_key": "chunk-%s-%d" % (task_id, i), "proof": PR.proof_to_json(proof)}
+            return {"chunk_id": i, "proof_key": "chunk-%s-%d" % (task_id, i), "proof": text}
 
         with ThreadPoolExecutor(max_workers=max(1, min(self.cfg.witness_threads, len(chunks)))) as wpool, \
                 ThreadPoolExecutor(max_workers=n_streams) as ppool:

@@ -62,6 +62,17 @@ class HipBackend:
         self.p.poseidon_perm(self._perm_buf, 1)
         return [int(v) for v in self.p.download(self._perm_buf, (12,))]
 
+    def prove_native(self, air, trace, pubs, params):
+        """the whole chunk STARK through zp_stark_prove (one C-ABI call, orchestration in the library's host C++): proof TEXT,
+        byte-identical to proof_to_json(prove(...)) over this backend.  trace: host array or a device buffer from prefetch_trace."""
+        assert self.hash_mode == "gl" and params.hash == "gl"
+        d_tr = trace if isinstance(trace, native.DeviceBuffer) else self.p.upload(trace)
+        try:
+            return self.p.stark_prove(air.name, air.program(), d_tr, [int(v) for v in pubs], params.logn, params.logb, params.fri_logf,
+                                      params.fri_final_log, params.n_queries, params.pow_bits)
+        finally:
+            d_tr.free()
+
     def poseidon_sponge(self, state, blocks, extra):
         return self.p.poseidon_sponge(state, blocks, extra)
 

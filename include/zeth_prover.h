@@ -155,6 +155,19 @@ int32_t zp_merkle16_open_batch_bn254(zp_ctx *ctx, const uint64_t *d_tree, size_t
 int32_t zp_ntt_bn254(zp_ctx *ctx, uint64_t *d_data, int32_t logn, int32_t inverse, const uint64_t *h_coset);
 int32_t zp_qap_quotient_bn254(zp_ctx *ctx, uint64_t *d_a, uint64_t *d_b, uint64_t *d_c, int32_t logm, const uint64_t *h_coset);
 
+/* ---- the whole chunk STARK behind one call (serves GenChunkProof, prover.proto:56-66 / provider.rs:358-390) ----------
+ * d_trace u64[W][2^logn] column-major in HBM, the statement as a constraint program blob (layout above), h_pubs its public
+ * inputs.  Runs trace LDE + commitment, the stage-2 arguments of the program's table, the constraint quotient (in Q pieces),
+ * out-of-domain evaluations, DEEP quotient, FRI, proof-of-work grinding and the query openings on the ctx's GPU; the
+ * Fiat-Shamir transcript binds every parameter, the program's SHA-256 digest, the root of unity and the coset shift.
+ * *out_json receives a malloc'ed, NUL-terminated proof text (*out_len bytes) to be released with zp_free_buffer; it is
+ * byte-identical to what the Python orchestration (eigen_zeth_amd/stark/prover.py) writes for the same inputs and is what
+ * oracle/stark_verify.py checks.  Conjectured security = n_queries * logb + pow_bits bits.  air_name only labels the proof. */
+int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
+                       const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
+                       int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len);
+int32_t zp_free_buffer(void *p);
+
 /* ---- N5: FRI fold ------------------------------------------------------------------------------
  * d_in u64[3][2^logn] = f on shift*<w_n> (natural order);  d_out u64[3][2^(logn-logf)] =
  * sum_j beta^j g_j on shift^(2^logf)*<w_(n>>logf)>,  f(x) = sum_j x^j g_j(x^(2^logf)), logf in 1..4 */

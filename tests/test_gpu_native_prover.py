@@ -1,0 +1,69 @@
+"""zp_stark_prove -- the whole chunk STARK behind one C-ABI call -- against the Python orchestration over the same library:
+the proof text must be byte-identical, and it must pass the independent verifier."""
+import json
+
+import pytest
+
+from eigen_zeth_amd import native
+from eigen_zeth_amd.stark import air as AIR
+from eigen_zeth_amd.stark import prover as PR
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(prover, name, logn, params):
+    from eigen_zeth_amd.stark.backend_hip import HipBackend
+    air = AIR.get_air(name)
+    tr, pub = AIR.cubic_witness(logn, 11) if name == "cubic" else native.synth_trace(air.trace_kind, logn, air.width, 11)
+    ref = PR.proof_to_json(PR.prove(air, tr, pub, params, HipBackend(prover=prover, quotient="program")))
+    d_tr = prover.upload(tr)
+    got = prover.stark_prove(air.name, air.program(), d_tr, [int(v) for v in pub], params.logn, params.logb, params.fri_logf,
+                             params.fri_final_log, params.n_queries, params.pow_bits)
+    d_tr.free()
+    return air, ref, got
+
+
+@pytest.mark.parametrize("name,logn,logb,logf,final,nq,pow_bits", [
+    ("fib", 6, 1, 3, 3, 5, 0), ("wide8", 10, 2, 3, 4, 9, 6), ("perm", 8, 1, 2, 3, 6, 4), ("chunk16", 9, 1, 3, 3, 17, 8),
+    ("cubic", 8, 2, 3, 3, 6, 0), ("chunk64", 12, 1, 3, 5, 80, 12), ("wide32", 11, 1, 4, 2, 8, 0)])
+def test_native_prover_writes_the_same_proof(prover, tables, name, logn, logb, logf, final, nq, pow_bits):
+    from oracle import stark_verify as V
+    params = PR.StarkParams(logn, logb, logf, final, nq, pow_bits=pow_bits)
+    air, ref, got = _both(prover, name, logn, params)
+    assert got == ref
+    assert V.verify(json.loads(got), air.program(), *tables, V.expectation(params.to_dict()))
+
+
+def test_native_prover_2_20_verifies(prover, tables):
+    """the service's shape: chunk AIR, 2^20 rows, 100-bit parameters, one call"""
+    from oracle import stark_verify as V
+    air = AIR.get_air("chunk64")
+    tr, pub = native.synth_trace(air.trace_kind, 20, air.width, 5)
+    d_tr = prover.upload(tr)
+    params = PR.StarkParams(20, 1, 3, 5, 80, pow_bits=20)
+    js = prover.stark_prove(air.name, air.program(), d_tr, [int(v) for v in pub], 20, 1, 3, 5, 80, 20)
+    d_tr.free()
+    assert V.verify(json.loads(js), air.program(), *tables, V.expectation(params.to_dict()))
+
+
+def test_native_prover_rejects_bad_arguments(prover):
+    import numpy as np
+    air = AIR.get_air("fib")
+    tr, pub = native.synth_trace(air.trace_kind, 6, air.width, 1)
+    d_tr = prover.upload(tr)
+    prog = np.array(air.program(), dtype=np.uint64)
+    with pytest.raises(native.ZpError):
+        prover.stark_prove("fib", prog[:-1], d_tr, [int(v) for v in pub], 6, 1, 3, 3, 5, 0)       # truncated program
+    with pytest.raises(native.ZpError):
+        prover.stark_prove("fib", prog, d_tr, [int(v) for v in pub][:-1], 6, 1, 3, 3, 5, 0)       # wrong number of publics
+    with pytest.raises(native.ZpError):
+        prover.stark_prove("fib", prog, d_tr, [int(v) for v in pub], 6, 0, 3, 3, 5, 0)            # no blow-up
+    bad = prog.copy(); bad[0] ^= 1
+    with pytest.raises(native.ZpError):
+        prover.stark_prove("fib", bad, d_tr, [int(v) for v in pub], 6, 1, 3, 3, 5, 0)             # bad magic
+    cub = AIR.get_air("cubic")                     # degree-3 constraints: two quotient pieces need blow-up >= 2 ... and get it
+    trc, pubc = AIR.cubic_witness(6, 1)
+    d_c = prover.upload(trc)
+    assert AIR.quotient_chunks(cub) == 2
+    prover.stark_prove("cubic", cub.program(), d_c, [int(v) for v in pubc], 6, 1, 3, 3, 5, 0)
+    d_tr.free(); d_c.free()

@@ -18,3 +18,10 @@ for r in range(reps):
     proof = PR.prove(air, tr, pub, params, be, timings=tm)
     print(json.dumps({"air": name, "logn": logn, "rep": r, "witness_s": round(tw, 3), "proof_bytes": len(PR.proof_to_json(proof)),
                       "stages_ms": {k: round(v * 1e3, 2) for k, v in tm.items()}}), flush=True)
+if os.environ.get("ZP_NATIVE", "1") != "0":      # the same proof through zp_stark_prove (one C-ABI call)
+    for r in range(reps):
+        t0 = time.perf_counter()
+        text = be.prove_native(air, tr, pub, params)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"air": name, "logn": logn, "rep": r, "native_one_call_ms": round(dt * 1e3, 2), "proof_bytes": len(text),
+                          "same_text": text == PR.proof_to_json(proof)}), flush=True)
