@@ -21,8 +21,8 @@ st = p.stage_timings()
 p.set_profiling(False)
 acc = collections.OrderedDict()
 for e in st if isinstance(st, list) else st.get("stages", []):
-    acc.setdefault(e["name"], [0, 0.0])
-    acc[e["name"]][0] += 1
-    acc[e["name"]][1] += e["ms"]
+    acc.setdefault(e["stage"], [0, 0.0])
+    acc[e["stage"]][0] += 1
+    acc[e["stage"]][1] += e["ms"]
 print(json.dumps({"air": name, "logn": logn, "wall_ms_trace_resident": round(wall * 1e3, 2),
                   "gpu_ms_by_entry_point": {k: [v[0], round(v[1], 3)] for k, v in acc.items()}}))
