@@ -198,6 +198,15 @@ int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_prog
     if (!ctx) return ZP_ERR_ARG;
     ZpStage stage_(ctx, "stark_prove");
     ZP_ARG(ctx, air_name && h_program && d_trace && out_json && out_len && (h_pubs || n_pubs == 0), "null pointer");
+    {   // the name goes into the proof text verbatim: letters, digits, '_', '-', '.' only
+        const size_t nl = strlen(air_name);
+        bool ok = nl >= 1 && nl <= 64;
+        for (size_t i = 0; ok && i < nl; i++) {
+            const char ch = air_name[i];
+            ok = (ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || (ch >= '0' && ch <= '9') || ch == '_' || ch == '-' || ch == '.';
+        }
+        ZP_ARG(ctx, ok, "air_name must be 1..64 characters of [A-Za-z0-9_.-]");
+    }
     ZP_ARG(ctx, program_words >= 12, "constraint program shorter than its header");
     static const unsigned char magic[8] = {'Z', 'P', 'A', 'I', 'R', '1', 0, 0};
     ZP_ARG(ctx, memcmp(h_program, magic, 8) == 0, "not a ZPAIR1 constraint program");

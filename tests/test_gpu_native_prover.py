@@ -58,6 +58,8 @@ def test_native_prover_rejects_bad_arguments(prover):
         prover.stark_prove("fib", prog, d_tr, [int(v) for v in pub][:-1], 6, 1, 3, 3, 5, 0)       # wrong number of publics
     with pytest.raises(native.ZpError):
         prover.stark_prove("fib", prog, d_tr, [int(v) for v in pub], 6, 0, 3, 3, 5, 0)            # no blow-up
+    with pytest.raises(native.ZpError):
+        prover.stark_prove('fi"b', prog, d_tr, [int(v) for v in pub], 6, 1, 3, 3, 5, 0)           # a name that would break the JSON
     bad = prog.copy(); bad[0] ^= 1
     with pytest.raises(native.ZpError):
         prover.stark_prove("fib", bad, d_tr, [int(v) for v in pub], 6, 1, 3, 3, 5, 0)             # bad magic
