@@ -107,7 +107,7 @@ struct Transcript {
 
 // Device buffers of one proof.  They come from, and go back to, a per-ctx pool keyed by size: everything runs on the ctx
 // stream, so a buffer handed out again is only touched by work enqueued after its previous user.
-#define PROVE_POOL_CAP ((size_t)24 << 30)
+#define PROVE_POOL_CAP ((size_t)8 << 30)    /* per ctx: a 2^20 x 76 proof keeps ~3 GiB; 8 proving ctxs share one 288 GB GPU */
 struct DevBufs {
     zp_ctx *ctx;
     std::vector<std::pair<void *, size_t>> bufs;
