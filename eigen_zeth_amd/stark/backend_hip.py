@@ -3,6 +3,7 @@ No CPU fallback: construction fails without libzethprover.so and an MI355X."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -39,6 +40,8 @@ class HipBackend:
         self._up_lock, self._copy_lock = threading.Lock(), threading.Lock()
         if hash_mode == "bn128":
             self.p.install_poseidon_bn254(17)
+        if os.environ.get("ZP_MERKLE_COOP_LOG"):      # experiment knob: tree levels handled by the 12-lanes-per-node kernels
+            self.p.set_tuning("merkle_coop_log", int(os.environ["ZP_MERKLE_COOP_LOG"]))
 
     # ---- Merkle trees of the configured hash mode
     def _tree_alloc(self, M):
