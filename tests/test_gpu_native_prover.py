@@ -69,3 +69,34 @@ def test_native_prover_rejects_bad_arguments(prover):
     assert AIR.quotient_chunks(cub) == 2
     prover.stark_prove("cubic", cub.program(), d_c, [int(v) for v in pubc], 6, 1, 3, 3, 5, 0)
     d_tr.free(); d_c.free()
+
+
+def test_native_prover_follows_the_configured_constants(tables):
+    """another 2^32-th root of unity, another coset shift and an injected (non-default) MDS: the one-call prover and the Python
+    orchestration still write the same proof, and the verifier -- told the same constants -- accepts it"""
+    import numpy as np
+    from eigen_zeth_amd.stark.backend_hip import HipBackend
+    from oracle import stark_verify as V
+    rc, mds = tables
+    p = native.Prover(0)
+    try:
+        mds2 = np.array(mds, dtype=np.uint64).copy()
+        mds2[5] = (int(mds2[5]) + 3)              # no longer the compiled-in matrix: the LDS-staged generic path
+        p.set_constants(native.ZP_CONST_ROOT32, [native.ROOT32_ALT])
+        p.set_constants(native.ZP_CONST_COSET_SHIFT, [7])
+        p.set_constants(native.ZP_CONST_POSEIDON_MDS, mds2)
+        air = AIR.get_air("chunk16")
+        tr, pub = native.synth_trace(air.trace_kind, 8, air.width, 3)
+        params = PR.StarkParams(8, 1, 3, 3, 7, pow_bits=5)
+        ref = PR.proof_to_json(PR.prove(air, tr, pub, params, HipBackend(prover=p, quotient="program")))
+        d_tr = p.upload(tr)
+        got = p.stark_prove(air.name, air.program(), d_tr, [int(v) for v in pub], 8, 1, 3, 3, 7, 5)
+        d_tr.free()
+        assert got == ref
+        proof = json.loads(got)
+        assert proof["root32"] == native.ROOT32_ALT and proof["shift"] == 7
+        assert V.verify(proof, air.program(), rc, mds2, V.expectation(params.to_dict(), root32=native.ROOT32_ALT, shift=7))
+        with pytest.raises(V.Reject):
+            V.verify(proof, air.program(), rc, mds2, V.expectation(params.to_dict()))      # a verifier on the default domain refuses it
+    finally:
+        p.close()
