@@ -427,6 +427,35 @@ int32_t zp_poseidon_bn254_perm(zp_ctx *ctx, uint64_t *d_states, size_t count, in
     return ZP_OK;
 }
 
+// The width-17 sponge of the BN128-mode transcript (element 0 = capacity, 1..16 = rate), one host call per transcript step:
+// for each of the nblocks blocks of 16 elements the rate is overwritten with the block and the state permuted (nblocks = 0:
+// one permutation), then `extra` more permutations; h_rates receives the 16 rate elements after the absorption and after each
+// extra permutation.  h_state: 17 elements in/out.  All elements 4 words, standard form, < r.
+int32_t zp_poseidon_bn254_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "poseidon_bn254_sponge");
+    P254Table *tb;
+    ZP_TRY(table_for(ctx, 17, &tb));
+    ZP_ARG(ctx, h_state && h_rates && (h_blocks || nblocks == 0), "null pointer");
+    ZP_ARG(ctx, nblocks <= 65536 && extra <= 65536, "too many blocks");
+    for (size_t i = 0; i < 17; i++) ZP_ARG(ctx, fr_is_canonical_u64((const u64 *)h_state + 4 * i), "state element not reduced mod r");
+    for (size_t i = 0; i < nblocks * 16; i++) ZP_ARG(ctx, fr_is_canonical_u64((const u64 *)h_blocks + 4 * i), "block element not reduced mod r");
+    u64 *d = nullptr;
+    ZP_TRY(zpi_scratch(ctx, 3, 17 * 4, &d));
+    ZP_TRY(zpi_h2d_small(ctx, d, h_state, 17 * 32));
+    const size_t steps = (nblocks ? nblocks : 1) + extra;
+    for (size_t b = 0; b < steps; b++) {
+        if (b < nblocks) ZP_TRY(zpi_h2d_small(ctx, d + 4, h_blocks + b * 64, 16 * 32));
+        hipLaunchKernelGGL(poseidon254_perm_kernel<17>, dim3(1), dim3(64), 0, ctx->stream, d, (size_t)1, dev_of(tb));
+        ZP_HIP(ctx, hipGetLastError());
+        if (b + 1 >= (nblocks ? nblocks : 1)) {      // the rate after the absorption and after every extra permutation
+            const size_t k = b + 1 - (nblocks ? nblocks : 1);
+            ZP_TRY(zpi_d2h_small(ctx, h_rates + k * 64, d + 4, 16 * 32));
+        }
+    }
+    return zpi_d2h_small(ctx, h_state, d, 17 * 32);
+}
+
 // d_tree: u64[nodes][4], leaves first (M of them), then ceil(M/16), ... down to the single root (the last 4 words)
 size_t zp_merkle16_nodes(size_t M) {
     size_t n = M, total = M;

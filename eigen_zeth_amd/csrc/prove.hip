@@ -62,28 +62,60 @@ struct Sha256 {
     }
 };
 
-// ---- the Fiat-Shamir sponge of stark/transcript.py (rate 8, capacity 4) on zp_poseidon_sponge
+// ---- the Fiat-Shamir sponges of stark/transcript.py.  Goldilocks mode: Poseidon-12, rate 8 / capacity 4, on zp_poseidon_sponge.
+// BN128 mode: Poseidon-BN254 of width 17 (element 0 = capacity, 1..16 = rate) on zp_poseidon_bn254_sponge; Goldilocks values are
+// absorbed three to a field element (every absorb call padded on its own), a Merkle root is one element, and the challenges
+// are the three low 64-bit words of the rate elements, each reduced mod p.
 struct Transcript {
     zp_ctx *ctx;
-    u64 state[12];
-    std::vector<u64> pending, out;
+    bool bn;
+    u64 state[17 * 4];                 // GL: 12 words; BN: 17 elements of 4 words (standard form)
+    std::vector<u64> pending, out;     // GL: values; BN: pending holds 4 words per element
     int32_t rc = ZP_OK;
-    explicit Transcript(zp_ctx *c) : ctx(c) { memset(state, 0, sizeof state); }
+    Transcript(zp_ctx *c, bool bn_) : ctx(c), bn(bn_) { memset(state, 0, sizeof state); }
     void absorb(const u64 *v, size_t n) {
-        for (size_t i = 0; i < n; i++) pending.push_back(v[i] % GL_P);
+        if (!bn) {
+            for (size_t i = 0; i < n; i++) pending.push_back(v[i] % GL_P);
+        } else {
+            for (size_t i = 0; i < n; i += 3) {
+                pending.push_back(v[i] % GL_P);
+                pending.push_back(i + 1 < n ? v[i + 1] % GL_P : 0);
+                pending.push_back(i + 2 < n ? v[i + 2] % GL_P : 0);
+                pending.push_back(0);
+            }
+        }
         out.clear();
     }
     void absorb(const std::vector<u64> &v) { absorb(v.data(), v.size()); }
+    void absorb_root(const u64 *root4) {
+        if (!bn) { absorb(root4, 4); return; }
+        for (int k = 0; k < 4; k++) pending.push_back(root4[k]);
+        out.clear();
+    }
     void flush(size_t want) {
-        const size_t nblk = (pending.size() + 7) / 8;
-        std::vector<u64> blocks(nblk * 8, 0);
-        memcpy(blocks.data(), pending.data(), pending.size() * 8);
-        pending.clear();
-        const size_t extra = want > 8 ? (want + 7) / 8 - 1 : 0;
-        std::vector<u64> rates((1 + extra) * 8);
-        const int32_t r = zp_poseidon_sponge(ctx, (uint64_t *)state, (const uint64_t *)blocks.data(), nblk, extra, (uint64_t *)rates.data());
-        if (r != ZP_OK && rc == ZP_OK) rc = r;
-        out.assign(rates.begin(), rates.end());
+        const size_t per = bn ? 48 : 8;                    // challenge values one permutation yields
+        const size_t extra = want > per ? (want + per - 1) / per - 1 : 0;
+        if (!bn) {
+            const size_t nblk = (pending.size() + 7) / 8;
+            std::vector<u64> blocks(nblk * 8, 0);
+            memcpy(blocks.data(), pending.data(), pending.size() * 8);
+            pending.clear();
+            std::vector<u64> rates((1 + extra) * 8);
+            const int32_t r = zp_poseidon_sponge(ctx, (uint64_t *)state, (const uint64_t *)blocks.data(), nblk, extra, (uint64_t *)rates.data());
+            if (r != ZP_OK && rc == ZP_OK) rc = r;
+            out.assign(rates.begin(), rates.end());
+        } else {
+            const size_t nel = pending.size() / 4, nblk = (nel + 15) / 16;
+            std::vector<u64> blocks(nblk * 64, 0);
+            memcpy(blocks.data(), pending.data(), pending.size() * 8);
+            pending.clear();
+            std::vector<u64> rates((1 + extra) * 64);
+            const int32_t r = zp_poseidon_bn254_sponge(ctx, (uint64_t *)state, (const uint64_t *)blocks.data(), nblk, extra, (uint64_t *)rates.data());
+            if (r != ZP_OK && rc == ZP_OK) rc = r;
+            out.clear();
+            for (size_t e = 0; e < rates.size() / 4; e++)
+                for (int k = 0; k < 3; k++) out.push_back(rates[4 * e + k] % GL_P);
+        }
     }
     std::vector<u64> squeeze(size_t n) {
         std::vector<u64> res;
@@ -102,6 +134,31 @@ struct Transcript {
     e3 challenge() {
         const std::vector<u64> v = squeeze(3);
         return e3_make(v[0], v[1], v[2]);
+    }
+};
+
+// ---- Merkle trees of the two hash modes behind one set of calls
+struct Trees {
+    zp_ctx *ctx;
+    bool bn;
+    static size_t levels16(size_t M) { size_t l = 0; for (size_t n = M; n > 1; n = (n + 15) / 16) l++; return l; }
+    size_t tree_words(size_t M) const { return bn ? zp_merkle16_nodes(M) * 4 : (2 * M - 1) * 4; }
+    int32_t commit(const u64 *cols, size_t M, int W, u64 *tree) const {
+        return bn ? zp_merkle16_commit_bn254(ctx, (const uint64_t *)cols, M, W, (uint64_t *)tree)
+                  : zp_merkle_commit(ctx, (const uint64_t *)cols, M, W, (uint64_t *)tree);
+    }
+    int32_t root(const u64 *tree, size_t M, u64 *out4) const {
+        return zp_d2h(ctx, out4, tree + tree_words(M) - 4, 32);           // both layouts end with the root
+    }
+    size_t path_words(size_t M) const {          // per query
+        if (bn) return levels16(M) * 64;
+        size_t d = 0;
+        while (((size_t)1 << d) < M) d++;
+        return (d ? d : 1) * 4;
+    }
+    int32_t open(const u64 *tree, size_t M, const u64 *idx, int nq, u64 *out) const {
+        return bn ? zp_merkle16_open_batch_bn254(ctx, (const uint64_t *)tree, M, (const uint64_t *)idx, nq, (uint64_t *)out)
+                  : zp_merkle_open_batch(ctx, (const uint64_t *)tree, M, (const uint64_t *)idx, nq, (uint64_t *)out);
     }
 };
 
@@ -169,6 +226,42 @@ void j_e3list(std::string &s, const std::vector<u64> &v) {   // [[a,b,c],...]
     for (size_t i = 0; i * 3 < v.size(); i++) { if (i) s += ','; j_list(s, &v[3 * i], 3); }
     s += ']';
 }
+void j_dec256(std::string &s, const u64 *w4) {     // "decimal" of a 256-bit little-endian value, quoted
+    u64 v[4] = {w4[0], w4[1], w4[2], w4[3]};
+    char digits[80];
+    int n = 0;
+    while (v[0] | v[1] | v[2] | v[3]) {
+        unsigned __int128 rem = 0;
+        for (int k = 3; k >= 0; k--) {
+            const unsigned __int128 cur = (rem << 64) | v[k];
+            v[k] = (u64)(cur / 10);
+            rem = cur % 10;
+        }
+        digits[n++] = (char)('0' + (int)rem);
+    }
+    if (!n) digits[n++] = '0';
+    s += '"';
+    while (n) s += digits[--n];
+    s += '"';
+}
+void j_root(std::string &s, const u64 *root4, bool bn) {
+    if (!bn) { j_list(s, root4, 4); return; }
+    s += '[';
+    j_dec256(s, root4);
+    s += ']';
+}
+void j_opening_bn(std::string &s, const u64 *vals, size_t W, const u64 *path, size_t levels) {   // path: per level 16 digests as strings
+    s += "{\"values\":";
+    j_list(s, vals, W);
+    s += ",\"path\":[";
+    for (size_t l = 0; l < levels; l++) {
+        if (l) s += ',';
+        s += '[';
+        for (int c = 0; c < 16; c++) { if (c) s += ','; j_dec256(s, path + (l * 16 + c) * 4); }
+        s += ']';
+    }
+    s += "]}";
+}
 void j_opening(std::string &s, const u64 *vals, size_t W, const u64 *path, size_t depth) {   // {"values":[..],"path":[[4]..]}
     s += "{\"values\":";
     j_list(s, vals, W);
@@ -192,11 +285,10 @@ int32_t zp_free_buffer(void *p) {
     return ZP_OK;
 }
 
-int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
-                       const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
-                       int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
-    if (!ctx) return ZP_ERR_ARG;
-    ZpStage stage_(ctx, "stark_prove");
+static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
+                          const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
+                          int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
+    ZpStage stage_(ctx, bn ? "stark_prove_bn128" : "stark_prove");
     ZP_ARG(ctx, air_name && h_program && d_trace && out_json && out_len && (h_pubs || n_pubs == 0), "null pointer");
     {   // the name goes into the proof text verbatim: letters, digits, '_', '-', '.' only
         const size_t nl = strlen(air_name);
@@ -250,19 +342,20 @@ int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_prog
     }
     first.push_back((u64)n_pubs);
     for (int i = 0; i < n_pubs; i++) first.push_back(h_pubs[i]);
-    Transcript tr(ctx);
+    Transcript tr(ctx, bn);
+    const Trees T{ctx, bn};
     tr.absorb(first);
 
     // 1. commit the trace (ext / coef have room for the stage-2 columns behind the trace columns)
     u64 *ext, *coef, *tree1;
     PV_TRY(dev.alloc(Wt * M, &ext));
     PV_TRY(dev.alloc(Wt * N, &coef));
-    PV_TRY(dev.alloc((2 * M - 1) * 4, &tree1));
+    PV_TRY(dev.alloc(T.tree_words(M), &tree1));
     PV_TRY(zp_lde(ctx, d_trace, (uint64_t *)ext, (uint64_t *)coef, logn, logb, (int32_t)W, shift));
-    PV_TRY(zp_merkle_commit(ctx, (const uint64_t *)ext, M, (int32_t)W, (uint64_t *)tree1));
+    PV_TRY(T.commit(ext, M, (int)W, tree1));
     u64 root1[4], root2[4] = {0, 0, 0, 0}, rootq[4];
-    PV_TRY(zp_d2h(ctx, root1, tree1 + (2 * M - 2) * 4, 32));
-    tr.absorb(root1, 4);
+    PV_TRY(T.root(tree1, M, root1));
+    tr.absorb_root(root1);
     std::vector<u64> pubchal(h_pubs, h_pubs + n_pubs);
     u64 *tree2 = nullptr;
     if (n_s2) {
@@ -282,11 +375,11 @@ int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_prog
             }
         }
         PV_TRY(zp_lde(ctx, (const uint64_t *)s2, (uint64_t *)(ext + W * M), (uint64_t *)(coef + W * N), logn, logb, (int32_t)W2, shift));
-        PV_TRY(dev.alloc((2 * M - 1) * 4, &tree2));
-        PV_TRY(zp_merkle_commit(ctx, (const uint64_t *)(ext + W * M), M, (int32_t)W2, (uint64_t *)tree2));
-        PV_TRY(zp_d2h(ctx, root2, tree2 + (2 * M - 2) * 4, 32));
+        PV_TRY(dev.alloc(T.tree_words(M), &tree2));
+        PV_TRY(T.commit(ext + W * M, M, (int)W2, tree2));
+        PV_TRY(T.root(tree2, M, root2));
         dev.release(s2);
-        tr.absorb(root2, 4);
+        tr.absorb_root(root2);
         for (int c = 0; c < 3; c++) pubchal.push_back(chal.c[c]);
     }
     const e3 alpha = tr.challenge();
@@ -335,7 +428,7 @@ int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_prog
     int q_logn = logm;
     size_t Wq = 3;
     u64 *treeq;
-    PV_TRY(dev.alloc((2 * M - 1) * 4, &treeq));
+    PV_TRY(dev.alloc(T.tree_words(M), &treeq));
     if (Q > 1) {
         // q(x) = sum_j (x / shift)^(jN) qt_j(x): the pieces are slices of the coefficient vector in hand; their LDEs get committed
         u64 *pcoef, *pad, *pext;
@@ -359,9 +452,9 @@ int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_prog
         q_logn = logn;
         Wq = 3 * Q;
     }
-    PV_TRY(zp_merkle_commit(ctx, (const uint64_t *)dq, M, (int32_t)Wq, (uint64_t *)treeq));
-    PV_TRY(zp_d2h(ctx, rootq, treeq + (2 * M - 2) * 4, 32));
-    tr.absorb(rootq, 4);
+    PV_TRY(T.commit(dq, M, (int)Wq, treeq));
+    PV_TRY(T.root(treeq, M, rootq));
+    tr.absorb_root(rootq);
     const e3 zeta = tr.challenge();
     PV_TRY(tr.rc);
 
@@ -395,10 +488,10 @@ int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_prog
         Layer L;
         L.lg = cur; L.f = f; L.data = dlayer;
         const size_t m = (size_t)1 << (cur - f);
-        PV_TRY(dev.alloc((2 * m - 1) * 4, &L.tree));
-        PV_TRY(zp_merkle_commit(ctx, (const uint64_t *)dlayer, m, 3 << f, (uint64_t *)L.tree));   // leaf = the 2^f * 3 values folded together
-        PV_TRY(zp_d2h(ctx, L.root, L.tree + (2 * m - 2) * 4, 32));
-        tr.absorb(L.root, 4);
+        PV_TRY(dev.alloc(T.tree_words(m), &L.tree));
+        PV_TRY(T.commit(dlayer, m, 3 << f, L.tree));   // leaf = the 2^f * 3 values folded together
+        PV_TRY(T.root(L.tree, m, L.root));
+        tr.absorb_root(L.root);
         const e3 beta = tr.challenge();
         PV_TRY(tr.rc);
         u64 *next;
@@ -412,7 +505,7 @@ int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_prog
     const int final_log = cur;
     std::vector<u64> final_l((size_t)3 << final_log);
     PV_TRY(zp_d2h(ctx, final_l.data(), dlayer, final_l.size() * 8));
-    tr.absorb(final_l);
+    for (int c = 0; c < 3; c++) tr.absorb(&final_l[(size_t)c << final_log], (size_t)1 << final_log);   // plane by plane (BN128 mode pads every call)
 
     // 6. proof of work, then the queries
     u64 nonce = 0;
@@ -425,19 +518,19 @@ int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_prog
     std::vector<u64> qidx = tr.squeeze((size_t)n_queries);
     PV_TRY(tr.rc);
     for (u64 &v : qidx) v &= (M - 1);
-    const size_t nq = (size_t)n_queries, depth = (size_t)logm;
-    std::vector<u64> v_tr(nq * W), p_tr(nq * depth * 4), v_s2, p_s2, v_q(nq * Wq), p_q(nq * depth * 4);
+    const size_t nq = (size_t)n_queries, depth = (size_t)logm, pw = T.path_words(M);
+    std::vector<u64> v_tr(nq * W), p_tr(nq * pw), v_s2, p_s2, v_q(nq * Wq), p_q(nq * pw);
     PV_TRY(zp_gather_rows(ctx, (const uint64_t *)ext, M, (int32_t)W, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)v_tr.data()));
-    PV_TRY(zp_merkle_open_batch(ctx, (const uint64_t *)tree1, M, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)p_tr.data()));
+    PV_TRY(T.open(tree1, M, qidx.data(), n_queries, p_tr.data()));
     if (n_s2) {
         v_s2.resize(nq * W2);
-        p_s2.resize(nq * depth * 4);
+        p_s2.resize(nq * pw);
         PV_TRY(zp_gather_rows(ctx, (const uint64_t *)(ext + W * M), M, (int32_t)W2, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)v_s2.data()));
-        PV_TRY(zp_merkle_open_batch(ctx, (const uint64_t *)tree2, M, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)p_s2.data()));
+        PV_TRY(T.open(tree2, M, qidx.data(), n_queries, p_s2.data()));
     }
     PV_TRY(zp_gather_rows(ctx, (const uint64_t *)dq, M, (int32_t)Wq, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)v_q.data()));
-    PV_TRY(zp_merkle_open_batch(ctx, (const uint64_t *)treeq, M, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)p_q.data()));
-    struct FriOpen { std::vector<u64> vals, paths; size_t width, depth; };
+    PV_TRY(T.open(treeq, M, qidx.data(), n_queries, p_q.data()));
+    struct FriOpen { std::vector<u64> vals, paths; size_t width, depth, pw, m; };
     std::vector<FriOpen> fo(layers.size());
     {
         std::vector<u64> pos = qidx;
@@ -447,10 +540,12 @@ int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_prog
             for (u64 &p : pos) p &= (m - 1);
             fo[li].width = (size_t)3 << L.f;
             fo[li].depth = (size_t)(L.lg - L.f);
+            fo[li].m = m;
+            fo[li].pw = T.path_words(m);
             fo[li].vals.resize(nq * fo[li].width);
-            fo[li].paths.resize(nq * (fo[li].depth ? fo[li].depth : 1) * 4);
+            fo[li].paths.resize(nq * fo[li].pw);
             PV_TRY(zp_gather_rows(ctx, (const uint64_t *)L.data, m, (int32_t)fo[li].width, (const uint64_t *)pos.data(), n_queries, (uint64_t *)fo[li].vals.data()));
-            PV_TRY(zp_merkle_open_batch(ctx, (const uint64_t *)L.tree, m, (const uint64_t *)pos.data(), n_queries, (uint64_t *)fo[li].paths.data()));
+            PV_TRY(T.open(L.tree, m, pos.data(), n_queries, fo[li].paths.data()));
         }
     }
 
@@ -465,29 +560,34 @@ int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_prog
     j_u64(s, (u64)logn); s += ",\"logb\":"; j_u64(s, (u64)logb); s += ",\"fri_logf\":"; j_u64(s, (u64)fri_logf);
     s += ",\"fri_final_log\":"; j_u64(s, (u64)fri_final_log); s += ",\"n_queries\":"; j_u64(s, (u64)n_queries);
     s += ",\"pow_bits\":"; j_u64(s, (u64)pow_bits);
+    if (bn) s += ",\"hash\":\"bn128\"";
     s += "},\"root32\":"; j_u64(s, root32);
     s += ",\"shift\":"; j_u64(s, shift);
     s += ",\"publics\":"; j_list(s, (const u64 *)h_pubs, (size_t)n_pubs);
-    s += ",\"roots\":{\"trace\":"; j_list(s, root1, 4);
-    s += ",\"quotient\":"; j_list(s, rootq, 4);
-    if (n_s2) { s += ",\"stage2\":"; j_list(s, root2, 4); }
+    s += ",\"roots\":{\"trace\":"; j_root(s, root1, bn);
+    s += ",\"quotient\":"; j_root(s, rootq, bn);
+    if (n_s2) { s += ",\"stage2\":"; j_root(s, root2, bn); }
     s += "},\"evals\":{\"z\":"; j_e3list(s, ev_all);
     s += ",\"zw\":"; j_e3list(s, ev_next);
     s += "},\"fri\":{\"roots\":[";
-    for (size_t li = 0; li < layers.size(); li++) { if (li) s += ','; j_list(s, layers[li].root, 4); }
+    for (size_t li = 0; li < layers.size(); li++) { if (li) s += ','; j_root(s, layers[li].root, bn); }
     s += "],\"final\":[";
     for (int c = 0; c < 3; c++) { if (c) s += ','; j_list(s, &final_l[(size_t)c << final_log], (size_t)1 << final_log); }
     s += "]},\"queries\":[";
     for (size_t i = 0; i < nq; i++) {
         if (i) s += ',';
         s += "{\"index\":"; j_u64(s, qidx[i]);
-        s += ",\"trace\":"; j_opening(s, &v_tr[i * W], W, &p_tr[i * depth * 4], depth);
-        s += ",\"quotient\":"; j_opening(s, &v_q[i * Wq], Wq, &p_q[i * depth * 4], depth);
-        if (n_s2) { s += ",\"stage2\":"; j_opening(s, &v_s2[i * W2], W2, &p_s2[i * depth * 4], depth); }
+        auto opening = [&](const u64 *vals, size_t width, const u64 *path, size_t rows, size_t bin_depth) {
+            if (bn) j_opening_bn(s, vals, width, path, Trees::levels16(rows));
+            else j_opening(s, vals, width, path, bin_depth);
+        };
+        s += ",\"trace\":"; opening(&v_tr[i * W], W, &p_tr[i * pw], M, depth);
+        s += ",\"quotient\":"; opening(&v_q[i * Wq], Wq, &p_q[i * pw], M, depth);
+        if (n_s2) { s += ",\"stage2\":"; opening(&v_s2[i * W2], W2, &p_s2[i * pw], M, depth); }
         s += ",\"fri\":[";
         for (size_t li = 0; li < layers.size(); li++) {
             if (li) s += ',';
-            j_opening(s, &fo[li].vals[i * fo[li].width], fo[li].width, &fo[li].paths[i * (fo[li].depth ? fo[li].depth : 1) * 4], fo[li].depth);
+            opening(&fo[li].vals[i * fo[li].width], fo[li].width, &fo[li].paths[i * fo[li].pw], fo[li].m, fo[li].depth);
         }
         s += "]}";
     }
@@ -500,6 +600,24 @@ int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_prog
     *out_json = buf;
     *out_len = s.size();
     return ZP_OK;
+}
+
+int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
+                       const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
+                       int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
+    if (!ctx) return ZP_ERR_ARG;
+    return prove_impl(ctx, false, air_name, h_program, program_words, d_trace, h_pubs, n_pubs, logn, logb, fri_logf, fri_final_log, n_queries,
+                      pow_bits, out_json, out_len);
+}
+
+// the same prover in BN128-hash mode (the last STARK before the Groth16 wrap): 16-ary Poseidon-BN254 trees, transcript over the
+// BN254 scalar field, no grinding.  zp_set_poseidon_bn254(ctx, 17, ...) must have installed the tables.
+int32_t zp_stark_prove_bn128(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
+                             const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
+                             int32_t n_queries, char **out_json, size_t *out_len) {
+    if (!ctx) return ZP_ERR_ARG;
+    return prove_impl(ctx, true, air_name, h_program, program_words, d_trace, h_pubs, n_pubs, logn, logb, fri_logf, fri_final_log, n_queries, 0,
+                      out_json, out_len);
 }
 
 }  // extern "C"

@@ -59,6 +59,9 @@ SIGNATURES = {
     "zp_pow_grind": (C.c_int32, [_vp, _vp, C.c_int32, _vp]),
     "zp_stark_prove": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "zp_stark_prove_bn128": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "zp_poseidon_bn254_sponge": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp]),
     "zp_free_buffer": (C.c_int32, [_vp]),
     "zp_poseidon_sponge": (C.c_int32, [_vp, _u64p, _u64p, C.c_size_t, C.c_size_t, _u64p]),
     "zp_deep_quotient_rows": (C.c_int32, [_vp, _vp, C.c_int32, C.c_size_t, _vp, C.c_int32, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, C.c_int32,
@@ -435,6 +438,27 @@ class Prover:
             return C.string_at(out.value, n.value).decode()
         finally:
             self.lib.zp_free_buffer(out)
+
+    def stark_prove_bn128(self, air_name, program, d_trace, pubs, logn, logb, fri_logf, fri_final_log, n_queries):
+        """zp_stark_prove_bn128: the one-call prover in BN128-hash mode (install_poseidon_bn254(17) first)"""
+        prog = np.ascontiguousarray(np.asarray(program, dtype=np.uint64))
+        pb = np.ascontiguousarray(np.asarray(list(pubs) + [0], dtype=np.uint64))
+        out, n = C.c_void_p(), C.c_size_t(0)
+        self._chk(self.lib.zp_stark_prove_bn128(self.ctx, air_name.encode(), prog.ctypes.data, prog.size, _ptr(d_trace), pb.ctypes.data, len(pubs),
+                                                logn, logb, fri_logf, fri_final_log, n_queries, C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out.value, n.value).decode()
+        finally:
+            self.lib.zp_free_buffer(out)
+
+    def poseidon_bn254_sponge(self, state, blocks, extra=0):
+        """state: 17 ints, blocks: list of 16-int blocks -> (new state, [rates (16 ints) after absorbing and after each extra permutation])"""
+        st = self._fr_words(state)
+        bl = self._fr_words([v for b in blocks for v in b]) if blocks else np.zeros((1, 4), dtype=np.uint64)
+        rates = np.zeros(((1 + extra) * 16, 4), dtype=np.uint64)
+        self._chk(self.lib.zp_poseidon_bn254_sponge(self.ctx, st.ctypes.data, bl.ctypes.data, len(blocks), extra, rates.ctypes.data))
+        r = self._fr_ints(rates)
+        return self._fr_ints(st), [r[16 * k:16 * k + 16] for k in range(1 + extra)]
 
     def poseidon_sponge(self, state, blocks, extra=0):
         """state: 12 ints, blocks: list of 8-int blocks -> (new state, [rate after absorbing, rate after each extra permutation])"""

@@ -265,8 +265,10 @@ class Engine:
         fair = AIR.get_air(self.cfg.final_air)
         seed = int(hashlib.sha256(recursive_proof.encode()).hexdigest()[:8], 16)
         ftrace, fpubs = native.synth_trace(fair.trace_kind, self.cfg.final_logn, fair.width, seed)
-        fproof = PR.prove(fair, ftrace, fpubs, self.final_stark_params(), self.be_bn128)
-        final_stark = PR.proof_to_json(fproof)
+        if self.cfg.native_prover and hasattr(self.be_bn128, "prove_native"):
+            final_stark = self.be_bn128.prove_native(fair, ftrace, fpubs, self.final_stark_params())   # zp_stark_prove_bn128
+        else:
+            final_stark = PR.proof_to_json(PR.prove(fair, ftrace, fpubs, self.final_stark_params(), self.be_bn128))
         t_fs = time.perf_counter() - t0
         self.final_starks[batch_id] = final_stark
         while len(self.final_starks) > 4:

@@ -68,9 +68,12 @@ class HipBackend:
     def prove_native(self, air, trace, pubs, params):
         """the whole chunk STARK through zp_stark_prove (one C-ABI call, orchestration in the library's host C++): proof TEXT,
         byte-identical to proof_to_json(prove(...)) over this backend.  trace: host array or a device buffer from prefetch_trace."""
-        assert self.hash_mode == "gl" and params.hash == "gl"
+        assert self.hash_mode == params.hash
         d_tr = trace if isinstance(trace, native.DeviceBuffer) else self.p.upload(trace)
         try:
+            if self.hash_mode == "bn128":       # zp_stark_prove_bn128: 16-ary Poseidon-BN254 trees, transcript over F_r, no grinding
+                return self.p.stark_prove_bn128(air.name, air.program(), d_tr, [int(v) for v in pubs], params.logn, params.logb, params.fri_logf,
+                                                params.fri_final_log, params.n_queries)
             return self.p.stark_prove(air.name, air.program(), d_tr, [int(v) for v in pubs], params.logn, params.logb, params.fri_logf,
                                       params.fri_final_log, params.n_queries, params.pow_bits)
         finally:

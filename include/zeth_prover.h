@@ -136,6 +136,9 @@ int32_t zp_merkle_open(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx
  * zp_merkle16_open_bn254: h_path u64[levels][16][4] = per level the 16 digests of the group on the path (bottom-up).   */
 int32_t zp_set_poseidon_bn254(zp_ctx *ctx, int32_t t, int32_t rp, const uint64_t *h_rc, const uint64_t *h_mds);
 int32_t zp_poseidon_bn254_perm(zp_ctx *ctx, uint64_t *d_states, size_t count, int32_t t);
+/* the transcript sponge of the BN128 mode (width 17: element 0 capacity, 1..16 rate): absorb nblocks blocks of 16 elements, then
+ * `extra` more permutations; h_state 17 elements in/out, h_rates (1 + extra) * 16 elements */
+int32_t zp_poseidon_bn254_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates);
 size_t zp_merkle16_nodes(size_t M);
 int32_t zp_merkle16_commit_bn254(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, uint64_t *d_tree);
 int32_t zp_merkle16_open_bn254(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx, uint64_t *h_path);
@@ -166,6 +169,11 @@ int32_t zp_qap_quotient_bn254(zp_ctx *ctx, uint64_t *d_a, uint64_t *d_b, uint64_
 int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
                        const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
                        int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len);
+/* the same in BN128-hash mode (the last STARK before the Groth16 wrap): 16-ary Poseidon-BN254 trees, transcript over the BN254
+ * scalar field, no grinding (security = n_queries * logb); the t = 17 tables must be installed (zp_set_poseidon_bn254) */
+int32_t zp_stark_prove_bn128(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
+                             const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
+                             int32_t n_queries, char **out_json, size_t *out_len);
 int32_t zp_free_buffer(void *p);
 
 /* ---- N5: FRI fold ------------------------------------------------------------------------------

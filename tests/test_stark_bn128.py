@@ -89,3 +89,41 @@ def test_bn128_gpu_proof_2_16_verifies(prover, tables, bn_tables):
     params = PR.StarkParams(16, 2, 3, 5, 12, hash="bn128")
     proof = json.loads(PR.proof_to_json(PR.prove(air, tr, pub, params, HipBackend(prover=prover, hash_mode="bn128", quotient="program"))))
     assert V.verify(proof, air.program(), *tables, V.expectation(params.to_dict()), bn_tables)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,logn,logb,nq", [("fib", 6, 1, 5), ("chunk16", 8, 1, 6), ("wide8", 10, 2, 50), ("chunk16", 12, 2, 20)])
+def test_bn128_one_call_prover_writes_the_same_proof(prover, tables, bn_tables, name, logn, logb, nq):
+    """zp_stark_prove_bn128 against the Python orchestration over the same library, and the independent verifier"""
+    from eigen_zeth_amd.stark.backend_hip import HipBackend
+    air, tr, pub = _case(name, logn)
+    params = PR.StarkParams(logn, logb, 3, 3, nq, hash="bn128")
+    ref = PR.proof_to_json(PR.prove(air, tr, pub, params, HipBackend(prover=prover, hash_mode="bn128", quotient="program")))
+    d_tr = prover.upload(tr)
+    got = prover.stark_prove_bn128(air.name, air.program(), d_tr, [int(v) for v in pub], logn, logb, 3, 3, nq)
+    d_tr.free()
+    assert got == ref
+    assert V.verify(json.loads(got), air.program(), *tables, V.expectation(params.to_dict()), bn_tables)
+
+
+@pytest.mark.gpu
+def test_bn254_sponge_in_one_call_equals_permutation_by_permutation(prover, bn_tables):
+    import random
+    from oracle import oracle as O
+    prover.install_poseidon_bn254(17)
+    O.p254_set(17, bn_tables[2], bn_tables[0], bn_tables[1])
+    rnd = random.Random(4)
+    for nblocks, extra in ((0, 0), (0, 2), (1, 0), (3, 1)):
+        state = [rnd.randrange(V.R_BN254) for _ in range(17)]
+        blocks = [[rnd.randrange(V.R_BN254) for _ in range(16)] for _ in range(nblocks)]
+        st, rates = list(state), []
+        if not blocks:
+            st = O.p254_perm([st], 17)[0]
+        for b in blocks:
+            st = O.p254_perm([[st[0]] + b], 17)[0]
+        rates.append(st[1:])
+        for _ in range(extra):
+            st = O.p254_perm([st], 17)[0]
+            rates.append(st[1:])
+        got_state, got_rates = prover.poseidon_bn254_sponge(state, blocks, extra)
+        assert got_state == st and got_rates == rates
