@@ -503,6 +503,14 @@ def batch_proof_probe(logn, air_name="chunk64"):
                        % (air_name, air.width, logn, params.security_bits()),
            "wall_s": wall, "stages_ms": {k: round(v * 1e3, 2) for k, v in tm.items()},
            "witness_host_s": tw, "proof_bytes": len(PR.proof_to_json(proof))}
+    try:      # the same proof through the one-call prover (zp_stark_prove): what the engine uses per chunk
+        be.prove_native(air, tr, pub, params)
+        t0 = time.perf_counter()
+        text = be.prove_native(air, tr, pub, params)
+        out["one_call_prover"] = {"wall_s": time.perf_counter() - t0, "same_proof_text": text == PR.proof_to_json(proof),
+                                  "note": "zp_stark_prove: witness upload + the whole STARK in one C-ABI call (constraints through the program interpreter)"}
+    except Exception as e:
+        out["one_call_prover"] = {"error": repr(e)}
     del be, tr
     try:   # BASELINE metric (i): batch-proof wall-clock, GenBatchChunks -> GenFinalProof, through the engine
         out["batch"] = engine_batch_probe(16, logn, air_name)
