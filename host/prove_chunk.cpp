@@ -1,0 +1,61 @@
+// A compiled host above the C-ABI -- what a Rust prover service (the reference's side of the boundary is compiled code:
+// src/prover/provider.rs talks to such a service) does for one GenChunkProof, written in C++ because this image has no Rust
+// toolchain: load libzethprover.so's entry points, put the witness in HBM, call zp_stark_prove, hand the proof text on.
+// Nothing but include/zeth_prover.h is used -- no Python, no torch, no compiler at run time (the AIR is a data blob).
+//
+// usage: prove_chunk <program.bin> <trace.bin> <publics.bin> <logn> <logb> <fri_logf> <fri_final_log> <n_queries> <pow_bits> <out.json> [air_name]
+//   program.bin : the constraint program blob (u64 words, layout in the header)
+//   trace.bin   : u64[W][2^logn] column-major, canonical values
+//   publics.bin : u64[n_pub]
+// build: make -C host   (g++ -I../include prove_chunk.cpp -L../eigen_zeth_amd/csrc -lzethprover)
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/zeth_prover.h"
+
+static std::vector<uint64_t> read_words(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint64_t> v((size_t)n / 8);
+    if (n % 8 || fread(v.data(), 8, v.size(), f) != v.size()) { fprintf(stderr, "bad file %s\n", path); exit(2); }
+    fclose(f);
+    return v;
+}
+
+#define CHECK(call)                                                                                   \
+    do {                                                                                              \
+        const int32_t rc_ = (call);                                                                   \
+        if (rc_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, ctx ? zp_last_error(ctx) : "no context"); return 1; } \
+    } while (0)
+
+int main(int argc, char **argv) {
+    if (argc < 11) { fprintf(stderr, "usage: see the header of host/prove_chunk.cpp\n"); return 2; }
+    const std::vector<uint64_t> program = read_words(argv[1]), trace = read_words(argv[2]), pubs = read_words(argv[3]);
+    const int logn = atoi(argv[4]), logb = atoi(argv[5]), fri_logf = atoi(argv[6]), fri_final_log = atoi(argv[7]), n_queries = atoi(argv[8]),
+              pow_bits = atoi(argv[9]);
+    const char *air_name = argc > 11 ? argv[11] : "chunk";
+    zp_ctx *ctx = nullptr;
+    CHECK(zp_create(&ctx, 0));
+    void *d_trace = nullptr;
+    CHECK(zp_dev_alloc(ctx, trace.size() * 8, &d_trace));
+    CHECK(zp_h2d(ctx, d_trace, trace.data(), trace.size() * 8));
+    char *json = nullptr;
+    size_t len = 0;
+    CHECK(zp_stark_prove(ctx, air_name, program.data(), program.size(), (const uint64_t *)d_trace, pubs.data(), (int32_t)pubs.size(), logn, logb, fri_logf,
+                         fri_final_log, n_queries, pow_bits, &json, &len));
+    FILE *o = fopen(argv[10], "wb");
+    if (!o || fwrite(json, 1, len, o) != len) { fprintf(stderr, "cannot write %s\n", argv[10]); return 2; }
+    fclose(o);
+    zp_free_buffer(json);
+    zp_dev_free(ctx, d_trace);
+    zp_destroy(ctx);
+    printf("proof: %zu bytes -> %s\n", len, argv[10]);
+    return 0;
+}

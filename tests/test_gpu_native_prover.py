@@ -100,3 +100,30 @@ def test_native_prover_follows_the_configured_constants(tables):
             V.verify(proof, air.program(), rc, mds2, V.expectation(params.to_dict()))      # a verifier on the default domain refuses it
     finally:
         p.close()
+
+
+def test_compiled_host_proves_a_chunk_through_the_c_abi(tmp_path, prover, tables):
+    """host/prove_chunk.cpp -- a compiled host that uses nothing but include/zeth_prover.h (no Python, no torch): files in, proof
+    out; the proof is the text the Python orchestration writes and the independent verifier accepts it"""
+    import os
+    import subprocess
+    import numpy as np
+    from eigen_zeth_amd.stark.backend_hip import HipBackend
+    from oracle import stark_verify as V
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "host", "prove_chunk")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "host"), "-s"])
+    air = AIR.get_air("chunk16")
+    tr, pub = native.synth_trace(air.trace_kind, 10, air.width, 21)
+    params = PR.StarkParams(10, 1, 3, 3, 12, pow_bits=6)
+    np.asarray(air.program(), dtype=np.uint64).tofile(tmp_path / "program.bin")
+    np.ascontiguousarray(tr).tofile(tmp_path / "trace.bin")
+    np.asarray(pub, dtype=np.uint64).tofile(tmp_path / "publics.bin")
+    out = tmp_path / "proof.json"
+    r = subprocess.run([exe, str(tmp_path / "program.bin"), str(tmp_path / "trace.bin"), str(tmp_path / "publics.bin"), "10", "1", "3", "3", "12", "6",
+                        str(out), air.name], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = out.read_text()
+    assert text == PR.proof_to_json(PR.prove(air, tr, pub, params, HipBackend(prover=prover, quotient="program")))
+    assert V.verify(json.loads(text), air.program(), *tables, V.expectation(params.to_dict()))
