@@ -65,3 +65,13 @@ def test_integration_doc_lists_every_entry_point():
     declared = set(re.findall(r"^(?:int32_t|size_t|void|const char \*)\s*\*?(zp_[a-z0-9_]+)\(", hdr, re.M))
     bound = set(re.findall(r"pub fn (zp_[a-z0-9_]+)", doc))
     assert declared == bound, (declared - bound, bound - declared)
+
+
+def test_compiled_host_builds_against_the_header_alone():
+    """host/prove_chunk.cpp uses include/zeth_prover.h from a plain g++ translation unit and links the in-tree library"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "host"), "-s", "-B"])
+    assert os.path.exists(os.path.join(root, "host", "prove_chunk"))
+    src = open(os.path.join(root, "host", "prove_chunk.cpp")).read()
+    assert "#include \"../include/zeth_prover.h\"" in src and "import" not in src and "torch" not in src.replace("no torch", "")
