@@ -277,7 +277,22 @@ static inline u64 host_mulmod(u64 a, u64 b) {
 }
 
 int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uint64_t *h_trace, uint64_t *h_pub) {
+    return zp_synth_trace_bound(kind, logn, W, seed, nullptr, 0, h_trace, h_pub);
+}
+
+// The same generators with the first n_bind starting values dictated by the caller instead of drawn from the seed: the
+// AIRs constrain those cells to public inputs (L_first * (col - pub_i)), so a proof over such a witness names them --
+// the service puts the limbs of the block statement there (state roots, transaction digest: service/statement.py), which
+// binds every chunk proof to its block (prover.proto:80-91; provider.rs:315-330).
+//   kind 0 (fib): bind[0..1] = a[0], b[0];  kind 1 (wide): bind[i] = c_i[0], i < min(4, W);
+//   kind 3 (chunk): bind[0..3] = c_0..c_3[0], bind[4..5] = fa[0], fb[0].  Values must be canonical (< p).
+int32_t zp_synth_trace_bound(int32_t kind, int32_t logn, int32_t W, uint64_t seed, const uint64_t *bind, int32_t n_bind,
+                             uint64_t *h_trace, uint64_t *h_pub) {
     if (logn < 1 || logn > 30 || !h_trace || !h_pub) return ZP_ERR_ARG;
+    if (n_bind < 0 || n_bind > 6 || (n_bind > 0 && !bind)) return ZP_ERR_ARG;
+    for (int i = 0; i < n_bind; i++)
+        if (bind[i] >= GL_P) return ZP_ERR_ARG;
+    if (n_bind > (kind == 0 ? 2 : kind == 1 ? (W < 4 ? W : 4) : kind == 3 ? 6 : 0)) return ZP_ERR_ARG;
     const size_t N = (size_t)1 << logn;
     // splitmix64 -> canonical field elements
     auto next = [&seed]() {
@@ -290,6 +305,8 @@ int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uin
     if (kind == 0) {
         if (W != 2) return ZP_ERR_ARG;
         u64 a = next(), b = next();
+        if (n_bind > 0) a = bind[0];
+        if (n_bind > 1) b = bind[1];
         h_pub[0] = a;
         h_pub[1] = b;
         for (size_t i = 0; i < N; i++) {
@@ -306,6 +323,7 @@ int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uin
         if (W < 3) return ZP_ERR_ARG;
         std::vector<u64> cur(W), nx(W);
         for (int i = 0; i < W; i++) cur[i] = next();
+        for (int i = 0; i < n_bind; i++) cur[i] = bind[i];
         for (int i = 0; i < (W < 4 ? W : 4); i++) h_pub[i] = cur[i];
         for (size_t r = 0; r < N; r++) {
             for (int i = 0; i < W; i++) h_trace[(size_t)i * N + r] = cur[i];
@@ -330,6 +348,7 @@ int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uin
         const int Ww = W - 8;
         std::vector<u64> cur(Ww), nx(Ww);
         for (int i = 0; i < Ww; i++) cur[i] = next();
+        for (int i = 0; i < n_bind && i < 4; i++) cur[i] = bind[i];
         for (int i = 0; i < 4; i++) h_pub[i] = cur[i];
         // rows are produced 64 at a time into a small row-major block and written out column by column, so that the
         // column-major trace receives 512-byte runs instead of one 8-byte store per (row, column)
@@ -352,6 +371,8 @@ int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uin
         u64 *fa = (u64 *)h_trace + (size_t)Ww * N, *fb = fa + N, *rv = fb + N, *qv = rv + N, *tv = qv + N, *mv = tv + N,
             *cv = mv + N, *dv = cv + N;
         u64 a = next(), b = next();
+        if (n_bind > 4) a = bind[4];
+        if (n_bind > 5) b = bind[5];
         h_pub[4] = a;
         h_pub[5] = b;
         for (size_t i = 0; i < N; i++) {

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -286,7 +288,7 @@ int32_t zp_free_buffer(void *p) {
 }
 
 static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
-                          const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
+                          size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
                           int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
     ZpStage stage_(ctx, bn ? "stark_prove_bn128" : "stark_prove");
     ZP_ARG(ctx, air_name && h_program && d_trace && out_json && out_len && (h_pubs || n_pubs == 0), "null pointer");
@@ -311,6 +313,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     ZP_ARG(ctx, logn >= 1 && logb >= 1 && logn + logb <= 30 && fri_logf >= 1 && fri_logf <= 4 && fri_final_log >= 0 && fri_final_log < logn &&
                     n_queries >= 1 && n_queries <= 4096 && pow_bits >= 0 && pow_bits <= 40, "STARK parameters out of range");
     ZP_ARG(ctx, Q <= ((size_t)1 << logb), "the blow-up must cover the quotient degree");
+    ZP_ARG(ctx, trace_words == (W << logn), "trace_words must be W * 2^logn (W from the program header)");
     ZP_ARG(ctx, (n_s2 == 0) == (W2 == 0) && (n_s2 == 0 || n_chal == 3), "stage-2 table and widths disagree");
     for (int i = 0; i < n_pubs; i++) ZP_ARG(ctx, h_pubs[i] < GL_P, "public input not canonical");
     const u64 *stage2 = (const u64 *)h_program + 12 + n_const + n_instr;
@@ -602,22 +605,42 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     return ZP_OK;
 }
 
-int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
-                       const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
-                       int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
+// no C++ exception may cross the C ABI (a Rust or ctypes caller cannot unwind it): allocation failures of the host-side vectors /
+// strings (sizes follow caller parameters: n_queries * path words, 3 << fri_final_log, ...) come back as error codes
+static int32_t prove_guarded(zp_ctx *ctx, bool bn, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
+                             size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
+                             int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
     if (!ctx) return ZP_ERR_ARG;
-    return prove_impl(ctx, false, air_name, h_program, program_words, d_trace, h_pubs, n_pubs, logn, logb, fri_logf, fri_final_log, n_queries,
-                      pow_bits, out_json, out_len);
+    if (out_json) *out_json = nullptr;
+    if (out_len) *out_len = 0;
+    try {
+        return prove_impl(ctx, bn, air_name, h_program, program_words, d_trace, trace_words, h_pubs, n_pubs, logn, logb, fri_logf, fri_final_log,
+                          n_queries, pow_bits, out_json, out_len);
+    } catch (const std::bad_alloc &) {
+        try { ctx->err = "out of host memory while building the proof"; } catch (...) {}
+        return ZP_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        try { ctx->err = std::string("internal error: ") + e.what(); } catch (...) {}
+        return ZP_ERR_INTERNAL;
+    } catch (...) {
+        return ZP_ERR_INTERNAL;
+    }
+}
+
+int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
+                       size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf,
+                       int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
+    return prove_guarded(ctx, false, air_name, h_program, program_words, d_trace, trace_words, h_pubs, n_pubs, logn, logb, fri_logf, fri_final_log,
+                         n_queries, pow_bits, out_json, out_len);
 }
 
 // the same prover in BN128-hash mode (the last STARK before the Groth16 wrap): 16-ary Poseidon-BN254 trees, transcript over the
 // BN254 scalar field, no grinding.  zp_set_poseidon_bn254(ctx, 17, ...) must have installed the tables.
 int32_t zp_stark_prove_bn128(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
-                             const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
-                             int32_t n_queries, char **out_json, size_t *out_len) {
-    if (!ctx) return ZP_ERR_ARG;
-    return prove_impl(ctx, true, air_name, h_program, program_words, d_trace, h_pubs, n_pubs, logn, logb, fri_logf, fri_final_log, n_queries, 0,
-                      out_json, out_len);
+                             size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf,
+                             int32_t fri_final_log, int32_t n_queries, char **out_json, size_t *out_len) {
+    return prove_guarded(ctx, true, air_name, h_program, program_words, d_trace, trace_words, h_pubs, n_pubs, logn, logb, fri_logf, fri_final_log,
+                         n_queries, 0, out_json, out_len);
 }
 
 }  // extern "C"

@@ -57,9 +57,9 @@ SIGNATURES = {
     "zp_lde": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_poseidon_perm": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "zp_pow_grind": (C.c_int32, [_vp, _vp, C.c_int32, _vp]),
-    "zp_stark_prove": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+    "zp_stark_prove": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
-    "zp_stark_prove_bn128": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+    "zp_stark_prove_bn128": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "zp_poseidon_bn254_sponge": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp]),
     "zp_free_buffer": (C.c_int32, [_vp]),
@@ -95,6 +95,7 @@ SIGNATURES = {
     "zp_merkle_open_batch": (C.c_int32, [_vp, _vp, C.c_size_t, _u64p, C.c_int32, _u64p]),
     "zp_domain_tables": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int32)]),
     "zp_synth_trace": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p]),
+    "zp_synth_trace_bound": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, C.c_int32, _u64p, _u64p]),
     "zp_msm_bn254": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
     "zp_msm_bn254_g2": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
     "zp_ntt_host": (C.c_int32, [_vp, _u64p, C.c_int32, C.c_int32, C.c_int32]),
@@ -119,14 +120,22 @@ def synth_g1_points(n, start=1025, threads=0):
     return out
 
 
-def synth_trace(kind, logn, W, seed, out=None):
+BIND_SLOTS = {0: 2, 1: 4, 3: 6}     # trace kind -> starting values a caller may dictate (zp_synth_trace_bound)
+
+
+def synth_trace(kind, logn, W, seed, out=None, bind=None):
     """synthetic witness (host code inside the library, no GPU needed): (trace [W][N], publics);
-    `out`: optional uint64 [W][N] array to fill (e.g. page-locked memory from Prover.host_array)"""
+    `out`: optional uint64 [W][N] array to fill (e.g. page-locked memory from Prover.host_array);
+    `bind`: starting values dictated by the caller (the block statement's limbs) -- they come back as public inputs"""
     lib = load_library()
     tr = np.empty((W, 1 << logn), dtype=np.uint64) if out is None else out
     assert tr.shape == (W, 1 << logn) and tr.dtype == np.uint64 and tr.flags["C_CONTIGUOUS"]
     pub = np.zeros(8, dtype=np.uint64)
-    rc = lib.zp_synth_trace(kind, logn, W, seed, tr.ctypes.data_as(_u64p), pub.ctypes.data_as(_u64p))
+    if bind is not None and len(bind):
+        b = np.ascontiguousarray(np.asarray(bind, dtype=np.uint64))
+        rc = lib.zp_synth_trace_bound(kind, logn, W, seed, b.ctypes.data_as(_u64p), len(b), tr.ctypes.data_as(_u64p), pub.ctypes.data_as(_u64p))
+    else:
+        rc = lib.zp_synth_trace(kind, logn, W, seed, tr.ctypes.data_as(_u64p), pub.ctypes.data_as(_u64p))
     if rc != 0:
         raise ValueError("zp_synth_trace: bad arguments")
     return tr, pub[:{0: 3, 2: 1, 3: 8}.get(kind, min(4, W))].copy()
@@ -427,12 +436,23 @@ class Prover:
         self._chk(self.lib.zp_hbm_copy_probe(self.ctx, _ptr(d_src), _ptr(d_dst), nbytes, reps, C.byref(ms)))
         return float(ms.value)
 
+    @staticmethod
+    def _words(d_trace, prog, logn):
+        """u64 words behind a trace handle: what the buffer says it holds (DeviceBuffer.n / tensor.numel()); a raw pointer has no
+        size of its own, so the caller vouches for W * 2^logn"""
+        if isinstance(d_trace, DeviceBuffer):
+            return d_trace.n
+        if hasattr(d_trace, "numel"):
+            return int(d_trace.numel())
+        return int(prog[1]) << logn
+
     def stark_prove(self, air_name, program, d_trace, pubs, logn, logb, fri_logf, fri_final_log, n_queries, pow_bits):
         """the whole chunk STARK in one C-ABI call (zp_stark_prove): device trace u64[W][2^logn] + constraint program blob -> proof text"""
         prog = np.ascontiguousarray(np.asarray(program, dtype=np.uint64))
         pb = np.ascontiguousarray(np.asarray(list(pubs) + [0], dtype=np.uint64))
         out, n = C.c_void_p(), C.c_size_t(0)
-        self._chk(self.lib.zp_stark_prove(self.ctx, air_name.encode(), prog.ctypes.data, prog.size, _ptr(d_trace), pb.ctypes.data, len(pubs),
+        self._chk(self.lib.zp_stark_prove(self.ctx, air_name.encode(), prog.ctypes.data, prog.size, _ptr(d_trace), self._words(d_trace, prog, logn),
+                                          pb.ctypes.data, len(pubs),
                                           logn, logb, fri_logf, fri_final_log, n_queries, pow_bits, C.byref(out), C.byref(n)))
         try:
             return C.string_at(out.value, n.value).decode()
@@ -444,7 +464,8 @@ class Prover:
         prog = np.ascontiguousarray(np.asarray(program, dtype=np.uint64))
         pb = np.ascontiguousarray(np.asarray(list(pubs) + [0], dtype=np.uint64))
         out, n = C.c_void_p(), C.c_size_t(0)
-        self._chk(self.lib.zp_stark_prove_bn128(self.ctx, air_name.encode(), prog.ctypes.data, prog.size, _ptr(d_trace), pb.ctypes.data, len(pubs),
+        self._chk(self.lib.zp_stark_prove_bn128(self.ctx, air_name.encode(), prog.ctypes.data, prog.size, _ptr(d_trace),
+                                                self._words(d_trace, prog, logn), pb.ctypes.data, len(pubs),
                                                 logn, logb, fri_logf, fri_final_log, n_queries, C.byref(out), C.byref(n)))
         try:
             return C.string_at(out.value, n.value).decode()

@@ -25,6 +25,7 @@ from ..stark import prover as PR
 from .. import native
 from . import bn254
 from . import groth16
+from . import statement
 
 
 class EngineConfig:
@@ -118,16 +119,27 @@ class Engine:
         if self.cfg.l2_addr:
             from .l2client import L2Client
             l2 = L2Client(self.cfg.l2_addr)
+        n_bind = min(4, native.BIND_SLOTS.get(AIR.get_air(self.cfg.air).trace_kind, 0))
         for b in blocks:
             nchunks = self.cfg.chunks_per_block
+            bhash, txd = b"", b""
             if l2 is not None:   # real block: chunk count follows the transaction count, roots come from the node
                 info = l2.block(int(b))
                 fetched.append(info)
                 nchunks = max(1, -(-info["n_tx"] // self.cfg.txs_per_chunk))
+                pre = info["parent_state_root"] or self._state_root(chain_id, int(b) - 1)
+                post, bhash, txd = info["state_root"], bytes.fromhex(info["hash"][2:]), statement.tx_digest(info["tx_hashes"])
+            else:                # no node configured: the synthetic roots the response reports
+                pre, post = self._state_root(chain_id, int(b) - 1), self._state_root(chain_id, int(b))
             for c in range(nchunks):
+                # the statement this chunk proof is bound to (service/statement.py): its limbs become public inputs of the proof
+                st = {"chain_id": int(chain_id), "block": int(b), "chunk": c, "n_chunks": nchunks, "pre_state_root": pre.hex(),
+                      "post_state_root": post.hex(), "block_hash": bhash.hex(), "tx_digest": txd.hex()}
                 chunks.append({"block": int(b), "chunk": c, "air": self.cfg.air, "logn": self.cfg.logn,
-                               "seed": (int(chain_id) * 1000003 + int(b) * 1009 + c) & 0xFFFFFFFFFFFFFFFF})
-        batch_data = json.dumps({"version": 1, "chain_id": int(chain_id), "blocks": [int(b) for b in blocks],
+                               "seed": (int(chain_id) * 1000003 + int(b) * 1009 + c) & 0xFFFFFFFFFFFFFFFF,
+                               "statement": st,
+                               "bind": statement.statement_limbs(chain_id, b, c, nchunks, pre, post, bhash, txd, n_bind)})
+        batch_data = json.dumps({"version": 2, "chain_id": int(chain_id), "blocks": [int(b) for b in blocks],
                                  "block_hashes": [f["hash"] for f in fetched], "chunks": chunks}, separators=(",", ":"))
         return {"task_id": str(int(blocks[0])).rjust(10, "0"),  # prover.proto:82-83
                 "chunk_count": len(chunks), "batch_data": batch_data,
@@ -135,13 +147,27 @@ class Engine:
                                    self._state_root(chain_id, int(blocks[0]) - 1)),
                 "post_state_root": fetched[-1]["state_root"] if fetched else self._state_root(chain_id, int(blocks[-1]))}
 
+    @staticmethod
+    def _chunk_witness(air, ch, out=None):
+        """the witness of one chunk: the synthetic generator (stand-in for the zkVM executor) started from the statement limbs"""
+        return native.synth_trace(air.trace_kind, ch["logn"], air.width, ch["seed"], out=out, bind=ch.get("bind"))
+
     def prepare_witnesses(self, batch_data):
         """generate (host) and keep the synthetic witnesses of a batch, so that a following gen_chunk_proofs with
         pregenerate_witnesses = True times the prover alone (bench.py reports both forms)"""
         self._witness_cache = {}
         for ch in json.loads(batch_data)["chunks"]:
             air = AIR.get_air(ch["air"])
-            self._witness_cache[(ch["air"], ch["logn"], ch["seed"])] = native.synth_trace(air.trace_kind, ch["logn"], air.width, ch["seed"])
+            self._witness_cache[(ch["air"], ch["logn"], ch["seed"])] = self._chunk_witness(air, ch)
+
+    @staticmethod
+    def _chunk_label(ch):
+        """what a chunk proof says about itself next to the STARK: the block, the chunk and the statement whose limbs are its
+        first public inputs (a verifier recomputes the limbs from the block: service/statement.py)"""
+        lab = {"block": ch["block"], "chunk": ch["chunk"]}
+        if "statement" in ch:
+            lab["statement"] = ch["statement"]
+        return lab
 
     # ---- GenChunkProof
     def gen_chunk_proofs(self, batch_id, task_id, chunk_count, batch_data):
@@ -157,45 +183,52 @@ class Engine:
         # thread pool (ctypes releases the GIL) so that chunk i+1.. are generated while chunk i is being proven
         from concurrent.futures import ThreadPoolExecutor
 
-        def witness(ch):
+        # proving runs on `prover_streams` backends per GPU (ctxs with their own streams) in as many threads: the latency-bound
+        # tail of one proof (FRI layers, queries, transcript) overlaps the Poseidon-bound head of the next.  Backends are
+        # grouped by device (backend k sits on GPU k % ndev, _backends()): chunk i belongs to GPU i % ndev from the start, so
+        # its witness is uploaded THROUGH a ctx of that GPU and proven by a ctx of that GPU -- a device pointer never
+        # crosses GPUs (round 2 uploaded every witness through backend 0 and handed the pointer to whichever ctx was free).
+        ndev = len(self._factories)
+        n_streams = max(ndev, min(self.cfg.prover_streams * ndev, -(-len(chunks) // ndev) * ndev))
+        if self._free_be is None or self._free_be[0] < n_streams:   # (size, queues, uploaders): grown under the engine lock, all idle here
+            bes = self._backends(n_streams)
+            free_qs = [queue.SimpleQueue() for _ in range(ndev)]
+            for k, b in enumerate(bes):
+                free_qs[k % ndev].put(b)
+            self._free_be = (n_streams, free_qs, [bes[d] for d in range(ndev)])
+        free_qs, uploaders = self._free_be[1], self._free_be[2]
+
+        def witness(i, ch):
             air = AIR.get_air(ch["air"])
+            up = uploaders[i % ndev]             # a backend on the GPU that will prove this chunk
             t0 = time.perf_counter()
             cached = self._witness_cache.get((ch["air"], ch["logn"], ch["seed"])) if self.pregenerate_witnesses else None
             if cached is not None:
                 trace, pubs = cached
-                if hasattr(self.be, "prefetch_trace"):
-                    trace = self.be.prefetch_trace(trace)
+                if hasattr(up, "prefetch_trace"):
+                    trace = up.prefetch_trace(trace)
                 return air, trace, pubs, 0.0
             out = None
-            if hasattr(self.be, "witness_buffer"):   # generate straight into page-locked memory: the copy is then plain DMA
-                out = self.be.witness_buffer(air.width, 1 << ch["logn"])
-            trace, pubs = native.synth_trace(air.trace_kind, ch["logn"], air.width, ch["seed"], out=out)
+            if hasattr(up, "witness_buffer"):   # generate straight into page-locked memory: the copy is then plain DMA
+                out = up.witness_buffer(air.width, 1 << ch["logn"])
+            trace, pubs = self._chunk_witness(air, ch, out)
             tw = time.perf_counter() - t0
-            if hasattr(self.be, "prefetch_trace"):   # copy to the GPU from this worker thread, on its own stream
-                trace = self.be.prefetch_trace(trace)
+            if hasattr(up, "prefetch_trace"):   # copy to the GPU from this worker thread, on its own stream
+                trace = up.prefetch_trace(trace)
             return air, trace, pubs, tw
-
-        # proving runs on `prover_streams` backends (ctxs with their own streams) in as many threads: the latency-bound
-        # tail of one proof (FRI layers, queries, transcript) overlaps the Poseidon-bound head of the next
-        n_streams = max(1, min(self.cfg.prover_streams * len(self._factories), len(chunks)))
-        if self._free_be is None or self._free_be[0] < n_streams:   # (size, queue): grown under the engine lock, all idle here
-            free_be = queue.SimpleQueue()
-            for b in self._backends(n_streams):
-                free_be.put(b)
-            self._free_be = (n_streams, free_be)
-        free_be = self._free_be[1]
         ahead = threading.Semaphore(self.cfg.witness_threads + 2)   # witnesses generated but not yet proven (memory bound)
 
-        def witness_bounded(ch):
+        def witness_bounded(i, ch):
             ahead.acquire()
             try:
-                return witness(ch)
+                return witness(i, ch)
             except BaseException:
                 ahead.release()
                 raise
 
         def prove_chunk(i, ch, wfut):
             air, trace, pubs, tw = wfut.result()
+            free_be = free_qs[i % ndev]
             be = free_be.get()
             try:
                 tm = {"witness(host)": tw}
@@ -205,10 +238,10 @@ class Engine:
                     t0 = time.perf_counter()
                     text = be.prove_native(air, trace, pubs, params)
                     tm["total"] = time.perf_counter() - t0
-                    text = text[:-1] + ',"chunk":{"block":%d,"chunk":%d}}' % (ch["block"], ch["chunk"])
+                    text = text[:-1] + ',"chunk":%s}' % json.dumps(self._chunk_label(ch), separators=(",", ":"))
                 else:
                     proof = PR.prove(air, trace, pubs, params, be, timings=tm)
-                    proof["chunk"] = {"block": ch["block"], "chunk": ch["chunk"]}
+                    proof["chunk"] = self._chunk_label(ch)
                     text = PR.proof_to_json(proof)
             finally:
                 free_be.put(be)
@@ -221,7 +254,7 @@ class Engine:
 
         with ThreadPoolExecutor(max_workers=max(1, min(self.cfg.witness_threads, len(chunks)))) as wpool, \
                 ThreadPoolExecutor(max_workers=n_streams) as ppool:
-            wfuts = [wpool.submit(witness_bounded, ch) for ch in chunks]
+            wfuts = [wpool.submit(witness_bounded, i, ch) for i, ch in enumerate(chunks)]
             pfuts = [ppool.submit(prove_chunk, i, ch, wfuts[i]) for i, ch in enumerate(chunks)]
             return [f.result() for f in pfuts]
 

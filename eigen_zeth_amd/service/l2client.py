@@ -22,7 +22,7 @@ class L2Client:
         return out["result"]
 
     def block(self, number):
-        """{number, hash, state_root (32 B), parent_state_root (32 B or None), n_tx}"""
+        """{number, hash, state_root (32 B), parent_state_root (32 B or None), n_tx, tx_hashes}"""
         b = self._call("eth_getBlockByNumber", [hex(int(number)), False])
         if b is None:
             raise RuntimeError("block %d not found on the L2 node" % number)
@@ -31,5 +31,6 @@ class L2Client:
         proot = bytes.fromhex(parent["stateRoot"][2:]) if parent else None
         if len(root) != 32 or (proot is not None and len(proot) != 32):
             raise RuntimeError("malformed stateRoot from the L2 node")
+        txs = [t if isinstance(t, str) else t["hash"] for t in b.get("transactions", [])]
         return {"number": int(b["number"], 16), "hash": b["hash"], "state_root": root, "parent_state_root": proot,
-                "n_tx": len(b.get("transactions", []))}
+                "n_tx": len(txs), "tx_hashes": txs}

@@ -28,12 +28,16 @@ class ProverService:
         self.metrics = metrics
         if metrics is not None:
             engine.metrics = metrics
-        self.last_id, self.last_end, self.cur_id, self.cur_start = "", 0, "", 0
-        # gRPC serves every stream on its own worker thread.  `_work` makes load -> compute -> save of a request atomic,
-        # so a replay that arrives on a new stream while the old handler is still proving waits and then finds the
-        # stored result (in-flight dedup per batch: nothing is computed twice, no ctx is driven from two threads);
-        # `_stat` guards the few status fields GetStatus reads while a proof is running.
-        self._work, self._stat = threading.Lock(), threading.Lock()
+        self.last_id, self.last_end, self.cur_start = "", 0, 0
+        # gRPC serves every stream on its own worker thread.  load -> compute -> save of a request is atomic PER BATCH
+        # (`_batch_locks`): a replay that arrives on a new stream while the old handler is still proving the same batch
+        # waits and then finds the stored result (in-flight dedup per batch: nothing is computed twice); requests of other
+        # batches are not held up here -- the engine serialises the use of its GPU contexts itself (Engine._serial).
+        # `_stat` guards what GetStatus reads: the set of request ids being computed (busy = non-empty; one handler
+        # finishing does not clear another one's entry) and the last finished request.
+        self._stat = threading.Lock()
+        self._in_flight = set()
+        self._batch_locks = {}
 
     # ---- the stream
     def prover_stream(self, request_iterator, context):
@@ -44,9 +48,12 @@ class ProverService:
                 self._status(resp)
                 yield resp
                 continue
+            token = object()                    # request ids are the client's: two streams may replay the same one
             with self._stat:
-                self.cur_id, self.cur_start = req.id, int(time.time())
-            self._work.acquire()
+                self._in_flight.add(token)
+                self.cur_start = int(time.time())
+                lock = self._batch_locks.setdefault(_batch_of(req, kind), threading.Lock())
+            lock.acquire()
             try:
                 if kind == "gen_batch_proof":
                     step = req.gen_batch_proof.WhichOneof("step")
@@ -64,9 +71,13 @@ class ProverService:
                 else:
                     self._status(resp, error="request without request_type")
             finally:
-                self._work.release()
+                lock.release()
                 with self._stat:
-                    self.last_id, self.last_end, self.cur_id = req.id, int(time.time()), ""
+                    self._in_flight.discard(token)
+                    self.last_id, self.last_end = req.id, int(time.time())
+                    if len(self._batch_locks) > 256:     # locks of finished batches (never one that is held or awaited)
+                        for k in [k for k, l in self._batch_locks.items() if l is not lock and not l.locked()][:128]:
+                            del self._batch_locks[k]
             if self.metrics is not None:
                 self.metrics.count_request(*_outcome(resp))
             yield resp
@@ -146,7 +157,7 @@ class ProverService:
         s.id = "zeth-prover-mi355x"
         s.result_code = 1 if error else 0
         with self._stat:
-            busy, last_id, last_end = bool(self.cur_id), self.last_id, self.last_end
+            busy, last_id, last_end = bool(self._in_flight), self.last_id, self.last_end
         s.status = getattr(proto, "STATUS_COMPUTING", proto.STATUS_IDLE) if busy else proto.STATUS_IDLE
         if error:
             s.error_message = error
@@ -164,6 +175,16 @@ class ProverService:
         ps.fork_id = 0
 
 
+def _batch_of(req, kind):
+    """the batch a request belongs to (the unit of in-flight dedup)"""
+    if kind == "gen_batch_proof":
+        step = req.gen_batch_proof.WhichOneof("step")
+        return getattr(req.gen_batch_proof, step).batch_id if step else ""
+    if kind in ("gen_aggregated_proof", "gen_final_proof"):
+        return getattr(req, kind).batch_id
+    return ""
+
+
 def _outcome(resp):
     """(request kind, ok?) of a response, for the request counters"""
     kind = resp.WhichOneof("response_type")
@@ -175,7 +196,9 @@ def _outcome(resp):
     return kind or "unknown", True
 
 
-def make_server(service, port=50061, host="127.0.0.1", max_workers=4):
+def make_server(service, port=50061, host="127.0.0.1", max_workers=16):
+    """max_workers: one gRPC worker per open stream; replays of a running request wait on their batch's lock, so the pool is
+    sized well above the one-stream-per-client norm -- a GetStatus on a new stream must still find a free worker"""
     handler = grpc.method_handlers_generic_handler(proto.SERVICE, {
         "ProverStream": grpc.stream_stream_rpc_method_handler(
             service.prover_stream, request_deserializer=proto.ProverRequest.FromString,

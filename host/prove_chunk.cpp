@@ -41,6 +41,16 @@ int main(int argc, char **argv) {
     const int logn = atoi(argv[4]), logb = atoi(argv[5]), fri_logf = atoi(argv[6]), fri_final_log = atoi(argv[7]), n_queries = atoi(argv[8]),
               pow_bits = atoi(argv[9]);
     const char *air_name = argc > 11 ? argv[11] : "chunk";
+    // the shapes must agree BEFORE anything reaches the GPU: W comes from the program header (word 1), the number of public
+    // inputs from word 4; the library checks trace_words == W << logn again (zp_stark_prove returns ZP_ERR_ARG otherwise)
+    if (program.size() < 12) { fprintf(stderr, "%s: shorter than a constraint-program header\n", argv[1]); return 2; }
+    if (logn < 1 || logn > 30 || trace.size() != (size_t)(program[1] << logn)) {
+        fprintf(stderr, "%s: %zu words, the program needs W * 2^logn = %llu * 2^%d\n", argv[2], trace.size(), (unsigned long long)program[1], logn);
+        return 2;
+    }
+    if (pubs.size() != program[4]) { fprintf(stderr, "%s: %zu public inputs, the program declares %llu\n", argv[3], pubs.size(), (unsigned long long)program[4]); return 2; }
+    for (uint64_t v : trace)
+        if (v >= 0xFFFFFFFF00000001ULL) { fprintf(stderr, "%s: non-canonical trace value (precondition of zp_stark_prove)\n", argv[2]); return 2; }
     zp_ctx *ctx = nullptr;
     CHECK(zp_create(&ctx, 0));
     void *d_trace = nullptr;
@@ -48,7 +58,7 @@ int main(int argc, char **argv) {
     CHECK(zp_h2d(ctx, d_trace, trace.data(), trace.size() * 8));
     char *json = nullptr;
     size_t len = 0;
-    CHECK(zp_stark_prove(ctx, air_name, program.data(), program.size(), (const uint64_t *)d_trace, pubs.data(), (int32_t)pubs.size(), logn, logb, fri_logf,
+    CHECK(zp_stark_prove(ctx, air_name, program.data(), program.size(), (const uint64_t *)d_trace, trace.size(), pubs.data(), (int32_t)pubs.size(), logn, logb, fri_logf,
                          fri_final_log, n_queries, pow_bits, &json, &len));
     FILE *o = fopen(argv[10], "wb");
     if (!o || fwrite(json, 1, len, o) != len) { fprintf(stderr, "cannot write %s\n", argv[10]); return 2; }

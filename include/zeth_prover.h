@@ -40,7 +40,8 @@ enum {
     ZP_ERR_ARG = -1,     /* bad argument (size not a power of two, null pointer, ...) */
     ZP_ERR_HIP = -2,     /* HIP runtime error (text in zp_last_error) */
     ZP_ERR_NOMEM = -3,   /* device allocation failed */
-    ZP_ERR_UNSUPPORTED = -4
+    ZP_ERR_UNSUPPORTED = -4,
+    ZP_ERR_INTERNAL = -5 /* an internal failure that is not the caller's (never an exception: nothing unwinds across this ABI) */
 };
 
 /* kinds for zp_set_constants */
@@ -165,15 +166,19 @@ int32_t zp_qap_quotient_bn254(zp_ctx *ctx, uint64_t *d_a, uint64_t *d_b, uint64_
  * Fiat-Shamir transcript binds every parameter, the program's SHA-256 digest, the root of unity and the coset shift.
  * *out_json receives a malloc'ed, NUL-terminated proof text (*out_len bytes) to be released with zp_free_buffer; it is
  * byte-identical to what the Python orchestration (eigen_zeth_amd/stark/prover.py) writes for the same inputs and is what
- * oracle/stark_verify.py checks.  Conjectured security = n_queries * logb + pow_bits bits.  air_name only labels the proof. */
+ * oracle/stark_verify.py checks.  Conjectured security = n_queries * logb + pow_bits bits.  air_name only labels the proof.
+ * trace_words = the number of u64 words behind d_trace; it must equal W * 2^logn with W from the program header (a short
+ * buffer or a wrong logn is ZP_ERR_ARG instead of a read past the allocation).  PRECONDITION: trace values are canonical
+ * (< p); they are not checked (a full pass over the witness) and non-canonical words give an unspecified, rejected proof.
+ * On any error *out_json = NULL, *out_len = 0; no C++ exception leaves the call (ZP_ERR_NOMEM / ZP_ERR_INTERNAL).          */
 int32_t zp_stark_prove(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
-                       const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
-                       int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len);
+                       size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf,
+                       int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len);
 /* the same in BN128-hash mode (the last STARK before the Groth16 wrap): 16-ary Poseidon-BN254 trees, transcript over the BN254
  * scalar field, no grinding (security = n_queries * logb); the t = 17 tables must be installed (zp_set_poseidon_bn254) */
 int32_t zp_stark_prove_bn128(zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
-                             const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
-                             int32_t n_queries, char **out_json, size_t *out_len);
+                             size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf,
+                             int32_t fri_final_log, int32_t n_queries, char **out_json, size_t *out_len);
 int32_t zp_free_buffer(void *p);
 
 /* ---- N5: FRI fold ------------------------------------------------------------------------------
@@ -261,6 +266,14 @@ int32_t zp_eval_quotient_rows(zp_ctx *ctx, const uint64_t *h_program, size_t pro
  * r permuted, range table t, multiplicities m, r^2, a*r+b).  h_trace u64[W][2^logn]; h_pub (room for 8) receives the
  * public inputs (3 / min(4,W) / 1 / 8).                 */
 int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uint64_t *h_trace, uint64_t *h_pub);
+/* the same generators with the first n_bind starting values dictated by the caller (canonical, < p) instead of drawn from
+ * the seed; the AIRs constrain exactly those cells to public inputs, so the proof names them.  The service puts the limbs
+ * of the block statement there (pre/post state root, transaction digest: what GenBatchChunksResult reports,
+ * proto/prover/v1/prover.proto:80-91, consumed at src/prover/provider.rs:315-330), which binds a chunk proof to its block.
+ * kind 0: bind[0..1] = a[0], b[0];  kind 1: bind[i] = c_i[0], i < min(4, W);  kind 3: bind[0..3] = c_0..c_3[0],
+ * bind[4..5] = Fibonacci a[0], b[0].  n_bind above that (or kind 2) is ZP_ERR_ARG.                                   */
+int32_t zp_synth_trace_bound(int32_t kind, int32_t logn, int32_t W, uint64_t seed, const uint64_t *bind, int32_t n_bind,
+                             uint64_t *h_trace, uint64_t *h_pub);
 
 /* synthetic MSM input (stands in for a proving key, which the offline build cannot obtain): n DISTINCT points
  * P_i = (start + i) * G of BN254 G1 in the zp_msm_bn254 layout, generated on the host with `threads` threads (0 = all);

@@ -60,3 +60,31 @@ def test_msm_of_distinct_points_against_the_discrete_log_identity(prover, logn):
     scs[5, 0] = 1                                                   # zero scalars and a one among the first few
     want = B.mul(B.G, O.bn254_weighted_scalar_sum(scs, 1025) % B.R)
     assert prover.msm_bn254_arrays(pts, scs) == want
+
+
+def test_chunks_at_the_full_c3_shape_through_the_engine(tables, tmp_path):
+    """BASELINE.md's C3/C5 chunk shape: 2^22 rows x 64 columns (+ 12 stage-2 columns), blow-up 2, at the service's
+    100-bit parameters -- four of configs[4]'s 64 chunks at FULL size through the engine (the 64-chunk test above runs
+    2^18-row chunks); every proof is checked by the independent verifier and a replay is byte-identical"""
+    from eigen_zeth_amd.service.engine import Engine, EngineConfig
+    from eigen_zeth_amd.service.server import default_backend_factory
+    from eigen_zeth_amd.stark import air as AIR
+    rc, mds = tables
+    cfg = EngineConfig(air="chunk64", logn=22, chunks_per_block=1, groth16_logm=6, crs_dir=str(tmp_path / "crs"), witness_threads=8,
+                       prover_streams=2)
+    assert cfg.n_queries * cfg.logb + cfg.pow_bits >= 100
+    eng = Engine(default_backend_factory(0), cfg)
+    blocks = [7, 8, 9, 10]
+    ch = eng.gen_batch_chunks("c5full", blocks, 12345, "evm")
+    assert ch["chunk_count"] == 4
+    proofs = eng.gen_chunk_proofs("c5full", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+    prog = AIR.get_air("chunk64").program()
+    exp = V.expectation(eng.stark_params(22).to_dict())
+    roots = set()
+    for i in range(4):
+        pr = json.loads(proofs[i]["proof"])
+        assert pr["params"]["logn"] == 22 and pr["chunk"]["block"] == blocks[i]
+        assert V.verify(pr, prog, rc, mds, exp)
+        roots.add(tuple(pr["roots"]["trace"]))
+    assert len(roots) == 4
+    assert eng.gen_chunk_proofs("c5full", ch["task_id"], ch["chunk_count"], ch["batch_data"]) == proofs

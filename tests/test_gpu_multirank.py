@@ -69,3 +69,41 @@ def test_bench_n2_code_path_on_one_gpu():
     pipe = line["pipeline"]
     assert "error" not in pipe and pipe["all_to_all_ms"] > 0 and pipe["four_step_single_column"]["ms"] > 0
     assert pipe["msm_bn254"]["on_curve"]
+
+
+def test_rccl_world_of_one_on_the_one_gpu_box():
+    """RCCL itself on the driver's one-GPU box: tools/multigpu_check.py under torch.distributed.run with ONE rank and the
+    `nccl` backend (= RCCL).  The process group is created on RCCL, and every collective wrapper of multigpu.py takes its
+    device-tensor branch (all_to_all_single, all_gather, all_reduce, broadcast on HBM tensors -- no host staging): the
+    column->row exchange + sharded commit, the four-step NTT, the MSM ranges and one sharded proof, each against the plain
+    single-GPU result.  The child is launched before anything in this process touches the GPU."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ZP_CHECK_BACKEND="nccl", ZP_CHECK_LOGN="14", ZP_CHECK_STARK_LOGN="12")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "multigpu_check.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"] and res["world"] == 1 and res["backend"] == "nccl"
+    assert res["commit_root_matches_single_gpu"] and res["four_step_matches_plain_ntt"] and res["msm_matches_single_gpu"]
+    assert res["sharded_proof_matches_single_gpu"]
+
+
+def test_engine_over_two_device_slots_keeps_witnesses_on_the_proving_gpu(tables, tmp_path):
+    """Engine([f0, f1]): chunk i is uploaded through, and proven by, ctxs of device slot i % 2 (round 2 uploaded every
+    witness through GPU 0 and handed the pointer to whichever ctx was free).  With >= 2 GPUs the slots are GPUs 0 and 1;
+    on the one-GPU box both slots sit on GPU 0, which still exercises the per-slot uploaders and queues.  Proofs must equal
+    the single-slot engine's byte for byte."""
+    import torch
+    from eigen_zeth_amd.service.engine import Engine, EngineConfig
+    from eigen_zeth_amd.service.server import default_backend_factory
+    second = 1 if torch.cuda.device_count() >= 2 else 0
+    mk = lambda: EngineConfig(air="chunk16", logn=12, chunks_per_block=1, groth16_logm=4, crs_dir=str(tmp_path / "crs"), prover_streams=2)
+    blocks = list(range(3, 10))                                        # 7 chunks: an odd count over two slots
+    one = Engine(default_backend_factory(0), mk())
+    ch = one.gen_batch_chunks("md", blocks, 12345, "evm")
+    want = one.gen_chunk_proofs("md", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+    two = Engine([default_backend_factory(0), default_backend_factory(second)], mk())
+    got = two.gen_chunk_proofs("md", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+    assert [p["proof"] for p in got] == [p["proof"] for p in want]
+    slots = two._free_be[2]
+    assert len(slots) == 2 and slots[0].p_device == 0 and slots[1].p_device == second

@@ -264,6 +264,29 @@ def test_block_input_fetcher_with_stub_node(tmp_path, cpu_factory):
         res = ch.execute(5)
         assert bytes(res["pre_state_root"]) == bytes.fromhex("%064x" % 1004) and bytes(res["post_state_root"]) == bytes.fromhex("%064x" % 1005)
         assert len(res["chunk_proofs"]) == 2           # 3 transactions, 2 per chunk
+        # every chunk proof is bound to ITS block: the leading public inputs are the limbs of the block statement (roots, block
+        # hash, transaction digest as the node reports them -- recomputed here from the stub's data by the checker), the
+        # STARK verifies with them, and the same proof is rejected as a proof for the next block
+        from oracle import statement as ST
+        from oracle import stark_verify as V
+        from eigen_zeth_amd.stark import air as AIR
+        import numpy as np
+        from eigen_zeth_amd.poseidon_constants import default_round_constants, default_mds
+        rcm = (np.array(default_round_constants(), dtype=np.uint64), np.array(default_mds(), dtype=np.uint64))
+
+        def ctx(n):
+            return dict(pre_root=bytes.fromhex("%064x" % (1000 + n - 1)), post_root=bytes.fromhex("%064x" % (1000 + n)),
+                        block_hash=bytes.fromhex(blocks[n]["hash"][2:]), txd=ST.tx_digest(blocks[n]["transactions"]))
+        exp = V.expectation(svc.engine.stark_params(5).to_dict())
+        for k, cp in enumerate(res["chunk_proofs"]):
+            pr = json.loads(cp)
+            assert V.verify(pr, AIR.get_air("fib").program(), rcm[0], rcm[1], exp)
+            assert ST.bound_to(pr, 12345, 5, k, 2, n=2, **ctx(5))
+            assert not ST.bound_to(pr, 12345, 6, k, 2, n=2, **ctx(6))        # a proof for block 5 is not a proof for block 6
+            assert not ST.bound_to(pr, 12345, 5, 1 - k, 2, n=2, **ctx(5))    # nor for the other chunk of its block
+            forged = dict(pr, publics=ST.limbs(12345, 6, k, 2, n=2, **ctx(6)) + pr["publics"][2:])
+            with pytest.raises(V.Reject):                                    # relabelling the publics breaks the transcript
+                V.verify(forged, AIR.get_air("fib").program(), rcm[0], rcm[1], exp)
         assert len(ch.execute(6)["chunk_proofs"]) == 1  # empty block still gets one chunk
         with pytest.raises(ProverClientError):
             ch.execute(99, max_retries=1)               # unknown block -> COMPLETED_ERROR
@@ -376,4 +399,58 @@ def test_two_concurrent_streams_replaying_one_request(tmp_path, cpu_factory):
             t.join()
         assert e2[0] == e2[1] and overlap[0] == 1
     finally:
+        server.stop(0)
+
+
+def test_get_status_answers_while_replays_queue_behind_a_running_proof(tmp_path, cpu_factory):
+    """Six streams replay one slow GenChunkProof (a client that keeps reconnecting, src/prover/provider.rs:671-700); a
+    GetStatus on yet another stream must be answered at once -- COMPUTING -- and must still say COMPUTING after the first
+    replays have been answered while others are pending (one handler finishing does not clear another one's entry)."""
+    import threading
+    import time
+    from eigen_zeth_amd.service import proto
+    cfg = EngineConfig(air="fib", logn=5, n_queries=4, fri_final_log=3, pow_bits=4)
+    server, port, svc = _start(tmp_path, cpu_factory, cfg)
+    real = svc.engine._gen_chunk_proofs
+    started, release = threading.Event(), threading.Event()
+
+    def slow(*a):
+        started.set()
+        release.wait(30)
+        return real(*a)
+    svc.engine._gen_chunk_proofs = slow
+    try:
+        ch = ProverChannel("127.0.0.1:%d" % port)
+        q = proto.ProverRequest(id="1")
+        g = q.gen_batch_proof.gen_batch_chunks
+        g.batch_id, g.chain_id, g.program_name = "slow", 12345, "evm"
+        g.batch.block_number.append(4)
+        r = ch._call(q).gen_batch_proof.gen_batch_chunks
+        out = [None] * 6
+
+        def go(i):
+            c = ProverChannel("127.0.0.1:%d" % port)
+            q = proto.ProverRequest(id="same-id")
+            g = q.gen_batch_proof.gen_chunk_proof
+            g.batch_id, g.task_id, g.chunk_count, g.chain_id, g.program_name, g.batch_data = "slow", r.task_id, r.chunk_count, 12345, "evm", r.batch_data
+            out[i] = c._call(q).gen_batch_proof.gen_chunk_proof
+            c.close()
+        ts = [threading.Thread(target=go, args=(i,)) for i in range(6)]
+        for t in ts:
+            t.start()
+        assert started.wait(20)
+        time.sleep(0.3)                      # let the other five reach their batch lock
+        t0 = time.time()
+        st = ch.get_status()
+        assert time.time() - t0 < 5 and st.status == proto.STATUS_COMPUTING
+        release.set()
+        for t in ts:
+            t.join()
+        assert all(o.result_code == proto.COMPLETED_OK for o in out)
+        assert len({tuple(p.proof for p in o.batch_proof_result.chunk_proofs) for o in out}) == 1
+        st = ch.get_status()
+        assert st.status == proto.STATUS_IDLE and st.prover_status.last_computed_request_id == "same-id"
+        ch.close()
+    finally:
+        release.set()
         server.stop(0)
