@@ -9,6 +9,7 @@ import pytest
 from oracle import naive_bn254 as B
 from oracle import oracle as O
 from oracle import stark_verify as V
+from oracle import statement as ST
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +32,10 @@ def test_64_block_batch_through_the_engine(tables, tmp_path):
     seen = set()
     for i in (0, 17, 63):                                           # first, last (what the client forwards) and one inside
         pr = json.loads(proofs[i]["proof"])
-        assert pr["chunk"] == {"block": blocks[i], "chunk": 0}
+        assert pr["chunk"]["block"] == blocks[i] and pr["chunk"]["chunk"] == 0
+        st = pr["chunk"]["statement"]     # the proof is bound to its block: its leading publics are the statement's limbs
+        assert ST.bound_to(pr, 12345, blocks[i], 0, 1, bytes.fromhex(st["pre_state_root"]), bytes.fromhex(st["post_state_root"]))
+        assert not ST.bound_to(pr, 12345, blocks[i] + 1, 0, 1, bytes.fromhex(st["pre_state_root"]), bytes.fromhex(st["post_state_root"]))
         assert V.verify(pr, prog, rc, mds, exp)
         seen.add(tuple(pr["roots"]["trace"]))
     assert len(seen) == 3                                           # different blocks, different witnesses
