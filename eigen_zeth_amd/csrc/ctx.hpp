@@ -143,6 +143,11 @@ struct NttRunOpts {
     const CosetTable *post_scale = nullptr;  // multiply output i by table(i) (last pass)
     int in_valid_log = -1;                   // >=0: input columns have 2^in_valid_log elements, rest is zero
 };
+// the sparse periodic fixed columns (2..n_fixed-1) of a constraint program: table behind the stage-2 table,
+// per column [lp | n_entries << 8] then n_entries x (pos | is_pub << 63, value or public index)
+struct ZpFixedCol { int lp; size_t first_entry_word, n_entries; bool has_pub; };
+// validates the whole-blob length and the table; fills `cols` (empty for n_fixed == 2).  false: malformed
+bool zpi_program_fixed_table(const uint64_t *h_program, size_t program_words, std::vector<ZpFixedCol> *cols);
 int32_t zpi_twiddle_rows(zp_ctx *ctx, u64 *d_rows, int logn_row, int W, u64 row0, int logn_total, bool inverse);
 int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn, int logb, int W, u64 shift);
 int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, bool inverse,

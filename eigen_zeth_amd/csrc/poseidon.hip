@@ -210,6 +210,52 @@ __global__ void __launch_bounds__(256) pow_grind_kernel(const u64 *__restrict__ 
     if ((s[0] >> (64 - bits)) == 0) atomicMin((unsigned long long *)best, (unsigned long long)nonce);
 }
 
+// Round-by-round trace of permutations: the witness of a Poseidon AIR (stark/verifier_air.py).  lane = permutation k, block of 32
+// rows: states[e][32 k + r] = element e of the state BEFORE round r (r < 30), the output on rows 30 and 31;
+// cubes[e][32 k + r] = (state + round constant)^3 (rows 30, 31: state^3) -- the helper column that keeps x^7 at degree 3.
+// Canonical values throughout (they are committed).  Column stride in elements.
+__global__ void __launch_bounds__(128) poseidon_trace_kernel(const u64 *__restrict__ inputs, size_t count, u64 *__restrict__ states,
+                                                            u64 *__restrict__ cubes, size_t stride, const u64 *__restrict__ rc,
+                                                            const u32 *__restrict__ mds) {
+    __shared__ u32 smds[144];
+    if (threadIdx.x < 144 - 128) smds[128 + threadIdx.x] = mds[128 + threadIdx.x];
+    smds[threadIdx.x] = mds[threadIdx.x];
+    __syncthreads();
+    const size_t k = (size_t)blockIdx.x * 128 + threadIdx.x;
+    if (k >= count) return;
+    u64 s[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) s[j] = inputs[k * 12 + j];
+    const size_t row0 = 32 * k;
+#pragma unroll 1
+    for (int r = 0; r < 32; r++) {
+        const bool round = r < 30;
+        const bool full = r < 4 || r >= 26;
+        u64 y[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const u64 x = round ? gl_add(s[j], rc[r * 12 + j]) : s[j];
+            const u64 c = gl_mul(gl_mul(x, x), x);
+            states[(size_t)j * stride + row0 + r] = s[j];
+            cubes[(size_t)j * stride + row0 + r] = c;
+            y[j] = (full || j == 0) ? gl_mul(gl_mul(c, c), x) : x;
+        }
+        if (!round) continue;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            u64 alo = 0, ahi = 0;
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const u32 m = smds[i * 12 + j];
+                alo += (u64)m * (u32)y[j];
+                ahi += (u64)m * (u32)(y[j] >> 32);
+            }
+            const u64 mid = (alo >> 32) + ahi;
+            s[i] = gl_canon(gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u));
+        }
+    }
+}
+
 // leaf i = linear hash of (cols[0][i], cols[1][i], ... cols[W-1][i]);  lane = row
 template <bool DEFMDS>
 __global__ void __launch_bounds__(256) merkle_leaves_kernel(const u64 *__restrict__ cols, size_t M, int W,
@@ -445,6 +491,19 @@ int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count) {
     else
         hipLaunchKernelGGL(poseidon_perm_kernel<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream,
                            (u64 *)d_states, count, ctx->d_rc, ctx->d_mds);
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}
+
+int32_t zp_poseidon_trace(zp_ctx *ctx, const uint64_t *d_inputs, size_t count, uint64_t *d_states, uint64_t *d_cubes, size_t stride) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "poseidon_trace");
+    if (count == 0) return ZP_OK;
+    ZP_ARG(ctx, d_inputs && d_states && d_cubes, "null device pointer");
+    ZP_ARG(ctx, stride >= 32 * count, "column stride smaller than 32 rows per permutation");
+    ZP_TRY(zpi_poseidon_sync_tables(ctx));
+    hipLaunchKernelGGL(poseidon_trace_kernel, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, ctx->stream, (const u64 *)d_inputs, count,
+                       (u64 *)d_states, (u64 *)d_cubes, stride, ctx->d_rc, ctx->d_mds);
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
 }

@@ -306,7 +306,8 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     ZP_ARG(ctx, memcmp(h_program, magic, 8) == 0, "not a ZPAIR1 constraint program");
     const size_t W = h_program[1], W2 = h_program[2], n_pub_prog = h_program[4], n_chal = h_program[5], n_const = h_program[6],
                  n_instr = h_program[7], K = h_program[8], n_s2 = h_program[10], Q = h_program[11];
-    ZP_ARG(ctx, n_const < (1u << 16) && n_instr < (1u << 24) && n_s2 < (1u << 16) && program_words == 12 + n_const + n_instr + 4 * n_s2,
+    std::vector<ZpFixedCol> fxc;
+    ZP_ARG(ctx, n_const < (1u << 16) && n_instr < (1u << 24) && n_s2 < (1u << 16) && zpi_program_fixed_table(h_program, program_words, &fxc),
            "constraint program length does not match its header");
     ZP_ARG(ctx, (size_t)n_pubs == n_pub_prog, "number of public inputs does not match the program");
     ZP_ARG(ctx, W >= 1 && W < 4096 && W2 < 4096 && K >= 1 && Q >= 1 && Q <= 16, "program dimensions out of range");
@@ -391,24 +392,27 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     // 2. constraint quotient on the coset
     u64 *fixed, *dq, *dqcoef;
     {
-        char key[96];
-        snprintf(key, sizeof key, "%d/%d/%llx/%llx", logn, logb, (unsigned long long)shift, (unsigned long long)root32);
+        // the fixed columns on the evaluation domain (zp_fixed_columns: boundary selectors + one extended period of every sparse
+        // periodic column).  They depend on the domain and the program only -- cached per ctx -- unless a column holds public
+        // inputs (expected roots / indices of a verifier AIR): then they are rebuilt for this proof.
+        bool has_pub = false;
+        for (const ZpFixedCol &fc : fxc) has_pub |= fc.has_pub;
+        const size_t fwords = zp_fixed_columns_words(h_program, program_words, logn, logb);
+        ZP_ARG(ctx, fwords != 0, "fixed column longer than the trace");
+        char key[128];
+        snprintf(key, sizeof key, "%d/%d/%llx/%llx/%s", logn, logb, (unsigned long long)shift, (unsigned long long)root32, fxc.empty() ? "" : dg_hex);
         auto it = ctx->prove_fixed.find(key);
-        if (it != ctx->prove_fixed.end()) {
+        if (!has_pub && it != ctx->prove_fixed.end()) {
             fixed = it->second;
-        } else {                      // LDE of the boundary selectors L_first, L_last: once per domain
-            std::vector<u64> ind(2 * N, 0);
-            ind[0] = 1;
-            ind[N + N - 1] = 1;
-            u64 *dind;
-            PV_TRY(dev.alloc(2 * N, &dind));
-            PV_TRY(zp_h2d(ctx, dind, ind.data(), 2 * N * 8));
+        } else if (has_pub) {
+            PV_TRY(dev.alloc(fwords, &fixed));
+            PV_TRY(zp_fixed_columns(ctx, h_program, program_words, h_pubs, n_pubs, logn, logb, shift, (uint64_t *)fixed, fwords));
+        } else {
             void *pf = nullptr;
-            PV_TRY(zp_dev_alloc(ctx, 2 * M * 8, &pf));
+            PV_TRY(zp_dev_alloc(ctx, fwords * 8, &pf));
             fixed = (u64 *)pf;
-            const int32_t r = zp_lde(ctx, (const uint64_t *)dind, (uint64_t *)fixed, nullptr, logn, logb, 2, shift);
+            const int32_t r = zp_fixed_columns(ctx, h_program, program_words, h_pubs, n_pubs, logn, logb, shift, (uint64_t *)fixed, fwords);
             if (r != ZP_OK) { (void)zp_dev_free(ctx, pf); return r; }
-            dev.release(dind);
             ctx->prove_fixed[key] = fixed;
         }
     }

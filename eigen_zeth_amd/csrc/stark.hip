@@ -531,7 +531,7 @@ extern "C" int32_t zp_grand_product(zp_ctx *ctx, const uint64_t *d_a, const uint
 // accumulators (alpha^k planes) at its OUT instruction; one reduction and the 1/Z_H multiplication at the end.
 namespace {
 
-constexpr int QP_MAX_SLOTS = 24;   // 24 * 256 lanes * 8 B = 48 KiB of LDS per workgroup
+constexpr int QP_MAX_SLOTS = 32;   // 32 * 256 lanes * 8 B = 64 KiB of LDS per workgroup
 
 struct QProgArgs {
     const u64 *prog;      // device copy of the blob
@@ -543,6 +543,10 @@ struct QProgArgs {
     u64 nrows, sc, sf, so;   // rows of this launch (a window of the M-row domain), column strides of cols / fixed / out
     int wrap;                // 1: the window is the whole domain, the next row wraps mod M; 0: rows r + b are in the buffer (halo)
     int lb, n_const, n_instr, n_slots;
+    // fixed columns 2..: periodic, kept as ONE extended period each (2^(lp + logb) values) behind the two selector columns;
+    // fx_tab holds (offset, index mask) per column, row0 = the domain row of local row 0
+    const u64 *fixedx, *fx_tab;
+    u64 row0;
 };
 
 __global__ void __launch_bounds__(256) quotient_program_kernel(QProgArgs a) {
@@ -571,7 +575,10 @@ __global__ void __launch_bounds__(256) quotient_program_kernel(QProgArgs a) {
                 case 0: val = slots[idx * 256 + tid]; break;
                 case 1: val = a.cols[(u64)idx * a.sc + rr]; break;
                 case 2: val = a.cols[(u64)idx * a.sc + rn]; break;
-                case 3: val = a.fixedc[(u64)idx * a.sf + rr]; break;
+                case 3:
+                    if (idx < 2) val = a.fixedc[(u64)idx * a.sf + rr];
+                    else val = a.fixedx[a.fx_tab[2 * (idx - 2)] + ((a.row0 + rr) & a.fx_tab[2 * (idx - 2) + 1])];
+                    break;
                 case 4: val = a.pub[idx]; break;
                 case 5: val = consts[idx]; break;
                 default: val = xml; break;
@@ -597,6 +604,104 @@ __global__ void __launch_bounds__(256) quotient_program_kernel(QProgArgs a) {
 }
 
 }  // namespace
+
+bool zpi_program_fixed_table(const uint64_t *h_program, size_t program_words, std::vector<ZpFixedCol> *cols) {
+    if (program_words < 12) return false;
+    const u64 n_fixed = h_program[3], n_pub = h_program[4], n_const = h_program[6], n_instr = h_program[7], n_s2 = h_program[10];
+    if (n_fixed < 2 || n_fixed > 4096 || n_const > (1u << 16) || n_instr > (1u << 24) || n_s2 > (1u << 16)) return false;
+    size_t at = 12 + (size_t)n_const + (size_t)n_instr + 4 * (size_t)n_s2;
+    if (cols) cols->clear();
+    for (u64 k = 2; k < n_fixed; k++) {
+        if (at >= program_words) return false;
+        const u64 hd = h_program[at];
+        ZpFixedCol fc;
+        fc.lp = (int)(hd & 0xFF);
+        fc.n_entries = (size_t)(hd >> 8);
+        fc.first_entry_word = at + 1;
+        fc.has_pub = false;
+        if (fc.lp > 32 || fc.n_entries > ((size_t)1 << fc.lp) || at + 1 + 2 * fc.n_entries > program_words) return false;
+        for (size_t e = 0; e < fc.n_entries; e++) {
+            const u64 a = h_program[at + 1 + 2 * e], v = h_program[at + 2 + 2 * e];
+            const bool is_pub = (a >> 63) != 0;
+            if ((a & ~(1ULL << 63)) >= (1ULL << fc.lp)) return false;
+            if (is_pub ? v >= n_pub : v >= GL_P) return false;
+            fc.has_pub |= is_pub;
+        }
+        at += 1 + 2 * fc.n_entries;
+        if (cols) cols->push_back(fc);
+    }
+    return at == program_words;
+}
+
+// ---- the fixed columns of a statement on the evaluation domain: what zp_eval_quotient takes as d_fixed ------------------
+// Layout: [L_first: M][L_last: M][column 2: 2^(lp_2 + logb)][column 3: ...] -- a periodic column of period p = 2^lp is
+// f(x) = g(x^(N/p)) with g the interpolant of one period, and on the coset shift * <w_M> the point x^(N/p) runs over
+// shift^(N/p) * <w_(p b)>: ONE extended period (an LDE of p values with the coset shift shift^(N/p)) holds every value, row r
+// reads entry r mod p b.  Nothing of size M is built for them.
+extern "C" size_t zp_fixed_columns_words(const uint64_t *h_program, size_t program_words, int32_t logn, int32_t logb) {
+    std::vector<ZpFixedCol> fxc;
+    if (!h_program || logn < 0 || logb < 0 || logn + logb > 32 || !zpi_program_fixed_table(h_program, program_words, &fxc)) return 0;
+    size_t w = (size_t)2 << (logn + logb);
+    for (const ZpFixedCol &fc : fxc) {
+        if (fc.lp > logn) return 0;
+        w += (size_t)1 << (fc.lp + logb);
+    }
+    return w;
+}
+
+extern "C" int32_t zp_fixed_columns(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *h_pub, int32_t n_pub,
+                                    int32_t logn, int32_t logb, uint64_t shift, uint64_t *d_out, size_t out_words) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "fixed_columns");
+    ZP_ARG(ctx, h_program && d_out && logn >= 1 && logb >= 0 && logn + logb <= 32, "bad arguments");
+    std::vector<ZpFixedCol> fxc;
+    ZP_ARG(ctx, zpi_program_fixed_table(h_program, program_words, &fxc), "constraint program length does not match its header");
+    ZP_ARG(ctx, (u64)n_pub >= h_program[4] && (h_program[4] == 0 || h_pub), "public inputs missing");
+    const size_t need = zp_fixed_columns_words(h_program, program_words, logn, logb);
+    ZP_ARG(ctx, need != 0 && out_words >= need, "output buffer smaller than zp_fixed_columns_words()");
+    if (shift == 0) shift = ctx->coset_shift;
+    ZP_ARG(ctx, shift < GL_P, "shift not canonical");
+    const size_t N = (size_t)1 << logn, M = N << logb;
+    size_t in_words = 2 * N;
+    for (const ZpFixedCol &fc : fxc) in_words += (size_t)1 << fc.lp;
+    std::vector<u64> h(in_words, 0);
+    h[0] = 1;                      // L_first
+    h[N + N - 1] = 1;              // L_last
+    {
+        size_t at = 2 * N;
+        for (const ZpFixedCol &fc : fxc) {
+            for (size_t e = 0; e < fc.n_entries; e++) {
+                const u64 a = h_program[fc.first_entry_word + 2 * e], v = h_program[fc.first_entry_word + 2 * e + 1];
+                u64 val = v;
+                if (a >> 63) {
+                    val = h_pub[v];
+                    ZP_ARG(ctx, val < GL_P, "public input not canonical");
+                }
+                h[at + (a & ~(1ULL << 63))] = val;
+            }
+            at += (size_t)1 << fc.lp;
+        }
+    }
+    void *din = nullptr;
+    ZP_TRY(zp_dev_alloc(ctx, in_words * 8, &din));
+    int32_t rc = zp_h2d(ctx, din, h.data(), in_words * 8);
+    if (rc == ZP_OK) rc = zpi_lde(ctx, (const u64 *)din, (u64 *)d_out, nullptr, logn, logb, 2, shift);
+    size_t in_at = 2 * N, out_at = 2 * M;
+    for (size_t k = 0; rc == ZP_OK && k < fxc.size();) {      // consecutive columns of one period go through one LDE call
+        size_t j = k;
+        while (j < fxc.size() && fxc[j].lp == fxc[k].lp) j++;
+        const int lp = fxc[k].lp;
+        const u64 sh = gl_pow(shift, (u64)1 << (logn - lp));    // shift^(N/p)
+        if (logb == 0 && sh == 1) rc = zp_d2d(ctx, d_out + out_at, (const u64 *)din + in_at, ((j - k) << lp) * 8);
+        else rc = zpi_lde(ctx, (const u64 *)din + in_at, (u64 *)d_out + out_at, nullptr, lp, logb, (int)(j - k), sh);
+        in_at += (j - k) << lp;
+        out_at += (j - k) << (lp + logb);
+        k = j;
+    }
+    if (rc == ZP_OK) rc = zp_sync(ctx);
+    (void)zp_dev_free(ctx, din);
+    return rc;
+}
 
 extern "C" int32_t zp_eval_quotient_rows(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *d_cols,
                                          size_t stride_cols, const uint64_t *d_fixed, size_t stride_fixed, int32_t logm, int32_t logb,
@@ -629,11 +734,12 @@ extern "C" int32_t zp_eval_quotient_rows(zp_ctx *ctx, const uint64_t *h_program,
     ZP_ARG(ctx, memcmp(h_program, magic, 8) == 0, "not a ZPAIR1 constraint program");
     const u64 width = h_program[1], width2 = h_program[2], n_fixed = h_program[3], np = h_program[4], nchal = h_program[5];
     const u64 n_const = h_program[6], n_instr = h_program[7], n_cons = h_program[8], n_slots = h_program[9], n_s2 = h_program[10];
-    ZP_ARG(ctx, n_const < (1u << 16) && n_instr < (1u << 24) && n_s2 < (1u << 16) &&
-                    program_words == 12 + n_const + n_instr + 4 * n_s2, "constraint program length does not match its header");
-    ZP_ARG(ctx, n_slots >= 1 && n_slots <= (u64)QP_MAX_SLOTS, "constraint program needs more slots than the interpreter has (24)");
+    std::vector<ZpFixedCol> fxc;
+    ZP_ARG(ctx, n_const < (1u << 16) && n_instr < (1u << 24) && n_s2 < (1u << 16) && n_fixed >= 2 && n_fixed < 4096 &&
+                    zpi_program_fixed_table(h_program, program_words, &fxc), "constraint program length does not match its header");
+    ZP_ARG(ctx, n_slots >= 1 && n_slots <= (u64)QP_MAX_SLOTS, "constraint program needs more slots than the interpreter has (32)");
     ZP_ARG(ctx, (u64)n_pub == np + nchal && (np + nchal == 0 || h_pub), "n_pub must equal publics + challenges of the program");
-    ZP_ARG(ctx, n_fixed <= 2, "at most the two boundary selectors are supported as fixed columns");
+    for (const ZpFixedCol &fc : fxc) ZP_ARG(ctx, fc.lp <= logm - logb, "fixed column longer than the trace");
     ZP_ARG(ctx, shift < GL_P && w_last < GL_P, "shift / w_last not canonical");
     const uint64_t *consts = h_program + 12, *ins = consts + n_const;
     u64 outs = 0;
@@ -661,14 +767,23 @@ extern "C" int32_t zp_eval_quotient_rows(zp_ctx *ctx, const uint64_t *h_program,
     if (nrows == 0) return ZP_OK;
     NttPlan *pl;
     ZP_TRY(zpi_get_plan(ctx, logm, false, &pl));
-    // one upload: program | pub | apow | zhinv
-    const size_t np_all = (size_t)n_pub + 1, total = program_words + np_all + 3 * (size_t)n_cons + (size_t)b;
+    // one upload: program | pub | apow | zhinv | (offset, mask) of the periodic fixed columns
+    const size_t np_all = (size_t)n_pub + 1, total = program_words + np_all + 3 * (size_t)n_cons + (size_t)b + 2 * fxc.size() + 1;
     std::vector<u64> h(total);
     memcpy(h.data(), h_program, program_words * 8);
     for (int i = 0; i < n_pub; i++) h[program_words + i] = h_pub[i];
     h[program_words + n_pub] = 0;
     memcpy(h.data() + program_words + np_all, h_alpha_pows, 3 * (size_t)n_cons * 8);
     memcpy(h.data() + program_words + np_all + 3 * (size_t)n_cons, h_zhinv, (size_t)b * 8);
+    {
+        u64 *t = h.data() + program_words + np_all + 3 * (size_t)n_cons + (size_t)b, off = 0;
+        for (size_t k = 0; k < fxc.size(); k++) {
+            const u64 len = 1ULL << (fxc[k].lp + logb);
+            t[2 * k] = off;
+            t[2 * k + 1] = len - 1;
+            off += len;
+        }
+    }
     u64 *d;
     ZP_TRY(zpi_scratch(ctx, 3, total, &d));
     if (total * 8 <= ZP_SMALL_COPY) ZP_TRY(zpi_h2d_small(ctx, d, h.data(), total * 8));
@@ -683,6 +798,9 @@ extern "C" int32_t zp_eval_quotient_rows(zp_ctx *ctx, const uint64_t *h_program,
     a.pub = d + program_words;
     a.apow = a.pub + np_all;
     a.zhinv = a.apow + 3 * (size_t)n_cons;
+    a.fx_tab = a.zhinv + (size_t)b;
+    a.fixedx = (const u64 *)d_fixed + 2 * stride_fixed;
+    a.row0 = row0;
     a.xs_lo = pl->d_twl;
     a.xs_hi = pl->d_twh;
     a.out = (u64 *)d_out;

@@ -56,6 +56,7 @@ SIGNATURES = {
     "zp_twiddle_rows": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32]),
     "zp_lde": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "zp_poseidon_perm": (C.c_int32, [_vp, _vp, C.c_size_t]),
+    "zp_poseidon_trace": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t]),
     "zp_pow_grind": (C.c_int32, [_vp, _vp, C.c_int32, _vp]),
     "zp_stark_prove": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
@@ -80,6 +81,8 @@ SIGNATURES = {
     "zp_transpose": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t]),
     "zp_synth_g1_points": (C.c_int32, [C.c_uint64, C.c_size_t, _vp, C.c_int32]),
     "zp_hbm_copy_probe": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_int32, C.POINTER(C.c_float)]),
+    "zp_fixed_columns_words": (C.c_size_t, [_vp, C.c_size_t, C.c_int32, C.c_int32]),
+    "zp_fixed_columns": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _vp, C.c_size_t]),
     "zp_eval_quotient": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_uint64,
                                      C.c_uint64, _vp]),
     "zp_merkle_commit": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp]),
@@ -343,6 +346,9 @@ class Prover:
     def poseidon_perm(self, d_states, count):
         self._chk(self.lib.zp_poseidon_perm(self.ctx, _ptr(d_states), count))
 
+    def poseidon_trace(self, d_inputs, count, d_states, d_cubes, stride):
+        self._chk(self.lib.zp_poseidon_trace(self.ctx, _ptr(d_inputs), count, _ptr(d_states), _ptr(d_cubes), stride))
+
     def eval_quotient(self, program, d_cols, d_fixed, logm, logb, pubs, apow, zhinv, shift, w_last, d_out):
         """constraint program blob (numpy u64) interpreted on the GPU: quotient planes u64[3][2^logm] into d_out"""
         prog = np.ascontiguousarray(np.asarray(program, dtype=np.uint64))
@@ -351,6 +357,17 @@ class Prover:
         zh = np.ascontiguousarray(np.asarray(zhinv, dtype=np.uint64))
         self._chk(self.lib.zp_eval_quotient(self.ctx, prog.ctypes.data, prog.size, _ptr(d_cols), _ptr(d_fixed), logm, logb, pb.ctypes.data,
                                             len(pubs), ap.ctypes.data, zh.ctypes.data, shift, w_last, _ptr(d_out)))
+
+    def fixed_columns(self, program, pubs, logn, logb, shift=0):
+        """the d_fixed of eval_quotient for this statement (zp_fixed_columns): selectors + one extended period per periodic column"""
+        prog = np.ascontiguousarray(np.asarray(program, dtype=np.uint64))
+        pb = np.ascontiguousarray(np.asarray(list(pubs) + [0], dtype=np.uint64))
+        words = int(self.lib.zp_fixed_columns_words(prog.ctypes.data, prog.size, logn, logb))
+        if words == 0:
+            raise ValueError("malformed constraint program (or a fixed column longer than the trace)")
+        out = DeviceBuffer(self, words)
+        self._chk(self.lib.zp_fixed_columns(self.ctx, prog.ctypes.data, prog.size, pb.ctypes.data, len(pubs), logn, logb, shift, out.ptr, words))
+        return out
 
     # ---- BN128-hash mode (Poseidon over the BN254 scalar field); field elements = 4 little-endian u64 words
     @staticmethod

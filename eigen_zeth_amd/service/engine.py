@@ -3,9 +3,10 @@
 GenBatchChunks : synthetic executor -- the real zkVM executor/EVM program is not obtainable offline
                  (SURVEY.md par.7); every block becomes `chunks_per_block` chunks of a synthetic AIR.
 GenChunkProof  : one real STARK per chunk on the GPU backend (eigen_zeth_amd/stark).
-GenAggregated  : structural stand-in for the recursive aggregation circuits (not built): binds the two
-                 proofs by digest.
-GenFinalProof  : a real Groth16 proof over BN254 (service/groth16.py; G1 MSMs on the GPU) in the exact JSON
+GenAggregated  : a STARK over the Merkle-verifier AIR (stark/verifier_air.py): its witness is the verification trace of the
+                 two chunk proofs' query openings, its public inputs their roots and query indices.
+GenFinalProof  : a final STARK in BN128-hash mode over the same verifier AIR applied to the aggregated proof's STARK, then
+                 a real Groth16 proof over BN254 (service/groth16.py; G1 MSMs on the GPU) in the exact JSON
                  grammar eigen-zeth parses (src/settlement/ethereum/mod.rs:445-481), for a stand-in CIRCUIT
                  (an arithmetic chain binding the public input to the aggregated proof's digest) under a
                  locally generated CRS: the recursive-verifier circuit and its ceremony do not exist offline.
@@ -22,6 +23,7 @@ import time
 
 from ..stark import air as AIR
 from ..stark import prover as PR
+from ..stark import verifier_air as VA
 from .. import native
 from . import bn254
 from . import groth16
@@ -35,7 +37,8 @@ class EngineConfig:
     def __init__(self, air="chunk64", logn=12, logb=1, chunks_per_block=1, n_queries=80, fri_logf=3, fri_final_log=5,
                  groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
                  witness_threads=8, prover_streams=8, pow_bits=20,
-                 final_air="chunk16", final_logn=10, final_logb=2, final_queries=50, native_prover=True):
+                 final_air="chunk16", final_logn=10, final_logb=2, final_queries=50, native_prover=True,
+                 agg_queries=50, agg_pow_bits=0):
         self.air, self.logn, self.logb = air, logn, logb
         self.chunks_per_block, self.n_queries, self.pow_bits = chunks_per_block, n_queries, pow_bits
         self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
@@ -46,6 +49,8 @@ class EngineConfig:
         # the final STARK (BN128-hash mode, no grinding: 50 queries x blow-up 4 = 100 bits conjectured)
         self.final_air, self.final_logn, self.final_logb, self.final_queries = final_air, final_logn, final_logb, final_queries
         self.native_prover = native_prover     # chunk proofs through zp_stark_prove (False: the Python orchestration, per-stage timings)
+        # the aggregation STARK (Merkle-verifier AIR, degree-4 constraints: blow-up 4): 50 queries x 2 bits = 100 bits conjectured
+        self.agg_queries, self.agg_pow_bits = agg_queries, agg_pow_bits
 
 
 class Engine:
@@ -81,7 +86,12 @@ class Engine:
             self._be_bn = self._factory(hash_mode="bn128")
         return self._be_bn
 
-    def final_stark_params(self):
+    def final_stark_params(self, agg_stark=None):
+        """parameters of the final STARK (BN128-hash mode, Merkle-verifier AIR: blow-up 4, no grinding); its trace length follows
+        the shape of the aggregated proof's STARK (agg_stark: that proof object) -- without one, the configured stand-alone size"""
+        if agg_stark is not None:
+            sh = VA.Shape.of_proof(agg_stark, 1)
+            return VA.aggregation_params(sh, self.cfg.final_queries, self.cfg.fri_logf, self.cfg.fri_final_log, 0, hash="bn128")
         return PR.StarkParams(self.cfg.final_logn, self.cfg.final_logb, self.cfg.fri_logf, min(self.cfg.fri_final_log, self.cfg.final_logn - 1),
                               self.cfg.final_queries, 0, hash="bn128")
 
@@ -264,12 +274,69 @@ class Engine:
         return hashlib.sha256(s.encode()).hexdigest()
 
     def aggregate(self, batch_id, p1, p2):
+        with self._serial:
+            return self._aggregate(batch_id, p1, p2)
+
+    def _tables(self, be):
+        if hasattr(be, "rc"):
+            return be.rc, be.mds
+        return (be.p.get_constants(native.ZP_CONST_POSEIDON_RC, 360), be.p.get_constants(native.ZP_CONST_POSEIDON_MDS, 144))
+
+    @staticmethod
+    def _header(proof):
+        """an inner proof without its authentication paths: what stays outside the Merkle-verifier AIR (transcript, out-of-domain
+        identity, final layer -- checked from here) plus the opened values (for the DEEP / FRI-fold stage)"""
+        h = {k: v for k, v in proof.items() if k != "queries"}
+        h["opened"] = [{"index": q["index"], "trace": q["trace"]["values"], "quotient": q["quotient"]["values"],
+                        **({"stage2": q["stage2"]["values"]} if "stage2" in q else {}),
+                        "fri": [f["values"] for f in q["fri"]]} for q in proof["queries"]]
+        return h
+
+    def _prove_merkle_verifier(self, proofs, params_of, be, timings):
+        """STARK over the Merkle-verifier AIR (stark/verifier_air.py) for inner proof objects `proofs` of one shape"""
+        rc, mds = self._tables(be)
+        shape = VA.Shape.of_proof(proofs[0], len(proofs))
+        vair = VA.verifier_air(shape, rc, mds)
+        t0 = time.perf_counter()
+        trace, pubs = VA.build_witness(shape, proofs, be)       # raises ValueError: an opening does not verify -> no witness
+        timings["verifier-witness"] = time.perf_counter() - t0
+        params = params_of(shape)
+        t0 = time.perf_counter()
+        if self.cfg.native_prover and hasattr(be, "prove_native"):
+            text = be.prove_native(vair, trace, pubs, params)
+        else:
+            text = PR.proof_to_json(PR.prove(vair, trace, pubs, params, be))
+        timings["verifier-stark"] = time.perf_counter() - t0
+        return shape, vair, params, text
+
+    def _aggregate(self, batch_id, p1, p2):
+        """GenAggregatedProof: a STARK whose witness is the verification trace of the two recursive proofs' query openings (every
+        Poseidon permutation of their Merkle paths), public inputs = their roots and query indices (stark/verifier_air.py).  With
+        one chunk the client sends the same proof twice (provider.rs:386-387): it is then verified once."""
         if not p1 or not p2:
             raise ValueError("empty recursive proof")
-        return json.dumps({"kind": "aggregated-standin", "batch_id": batch_id,
-                           "inputs": [self._digest(p1), self._digest(p2)],
-                           "note": "recursive aggregation circuits are not built; this binds the two inputs by digest"},
-                          separators=(",", ":"))
+        try:
+            proofs = [json.loads(p1)] if p1 == p2 else [json.loads(p1), json.loads(p2)]
+            for pr in proofs:
+                if "queries" not in pr or "roots" not in pr:
+                    raise ValueError("not a chunk proof")
+        except (json.JSONDecodeError, TypeError) as e:
+            raise ValueError("recursive proof is not a chunk proof: %s" % e)
+        tm = {}
+        shape, vair, params, text = self._prove_merkle_verifier(
+            proofs, lambda sh: VA.aggregation_params(sh, self.cfg.agg_queries, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.agg_pow_bits),
+            self.be, tm)
+        self.stage_timings["aggregate/" + batch_id] = tm
+        if self.metrics is not None:
+            for k, v in tm.items():
+                self.metrics.record_stage(k, v)
+        head = json.dumps({"kind": "aggregated", "version": 1, "batch_id": batch_id,
+                           "statement": "for every query slot, inner proof and committed tree an opening of the public index hashes to "
+                                        "the public root (Merkle part of the verifier; DEEP / FRI-fold checks are not in the AIR yet)",
+                           "shape": dict(zip(("logn", "logb", "W", "W2", "Wq", "n_queries", "fri_logf", "fri_final_log", "n_proofs"), shape.key())),
+                           "slots": shape.n_slots(), "verifier_air_digest": vair.digest(),
+                           "inner": [self._header(pr) for pr in proofs]}, separators=(",", ":"))
+        return head[:-1] + ',"stark":' + text + "}"
 
     # ---- GenFinalProof
     def groth16_keys(self):
@@ -292,16 +359,20 @@ class Engine:
         if not recursive_proof:
             raise ValueError("empty recursive proof")
         # 1. the final STARK: BN128-hash mode (16-ary Poseidon-BN254 trees, transcript over the BN254 scalar field), the form a
-        #    Groth16 circuit over that field can verify.  The statement is a stand-in AIR whose witness is seeded by the
-        #    aggregated proof (the recursive-verifier AIR is not built); the wrap below binds its digest.
+        #    Groth16 circuit over that field can verify.  Its statement: the Merkle-verifier AIR over the aggregated proof's own
+        #    STARK -- every query opening of the aggregated proof hashes to its roots (public inputs: those roots and indices).
+        #    A recursive proof that is not an aggregated proof of this service (a client of another prover) cannot be verified
+        #    here and is an application error (the client retries: provider.rs:504-523).
         t0 = time.perf_counter()
-        fair = AIR.get_air(self.cfg.final_air)
-        seed = int(hashlib.sha256(recursive_proof.encode()).hexdigest()[:8], 16)
-        ftrace, fpubs = native.synth_trace(fair.trace_kind, self.cfg.final_logn, fair.width, seed)
-        if self.cfg.native_prover and hasattr(self.be_bn128, "prove_native"):
-            final_stark = self.be_bn128.prove_native(fair, ftrace, fpubs, self.final_stark_params())   # zp_stark_prove_bn128
-        else:
-            final_stark = PR.proof_to_json(PR.prove(fair, ftrace, fpubs, self.final_stark_params(), self.be_bn128))
+        try:
+            agg = json.loads(recursive_proof)
+            outer = agg["stark"]
+            if agg.get("kind") != "aggregated" or "queries" not in outer:
+                raise KeyError("kind")
+        except (json.JSONDecodeError, TypeError, KeyError) as e:
+            raise ValueError("recursive proof is not an aggregated proof of this prover (%s)" % e)
+        tmf = {}
+        fshape, fair, fp, final_stark = self._prove_merkle_verifier([outer], lambda sh: self.final_stark_params(outer), self.be_bn128, tmf)
         t_fs = time.perf_counter() - t0
         self.final_starks[batch_id] = final_stark
         while len(self.final_starks) > 4:
@@ -316,7 +387,8 @@ class Engine:
         rnd = (int.from_bytes(os.urandom(32), "big") % bn254.R or 1, int.from_bytes(os.urandom(32), "big") % bn254.R or 1)
         t0 = time.perf_counter()
         proof, pub = groth16.prove(circ, pk, w, self.be.msm_g1, rnd, getattr(self.be, "msm_g2", None), self.be.qap_quotient)
-        self.stage_timings["final/" + batch_id] = {"final_stark(bn128)": t_fs, "groth16": time.perf_counter() - t0}
+        self.stage_timings["final/" + batch_id] = {"final_stark(bn128)": t_fs, "groth16": time.perf_counter() - t0,
+                                                   **{"final/" + k: v for k, v in tmf.items()}}
         if self.metrics is not None:
             self.metrics.record_stage("groth16", self.stage_timings["final/" + batch_id]["groth16"])
         js = groth16.proof_to_json(proof, {"circuit": "arithmetic-chain(logm=%d), local CRS -- stand-in for the recursive-verifier circuit" % circ.logm,

@@ -75,11 +75,17 @@ class Air:
     """name, width, number of public inputs, constraint list (transition constraints already carry
     their XMinusLast factor)."""
 
-    def __init__(self, name, width, n_pub, constraints, trace_kind, stage2=None):
+    def __init__(self, name, width, n_pub, constraints, trace_kind, stage2=None, fixed_cols=None):
         self.name, self.width, self.n_pub = name, width, n_pub
         self.constraints = constraints
         self.trace_kind = trace_kind  # id understood by zp_synth_trace
-        self.n_fixed = 2
+        # fixed columns 0, 1 are the boundary selectors L_first, L_last; columns 2.. are SPARSE PERIODIC columns known to the
+        # verifier: FixedCol(lp, entries) has period 2^lp (lp = logn: not periodic) and is zero except at the listed positions,
+        # where it holds a constant or a public input.  Round constants, schedule selectors, per-row expected values (roots,
+        # indices) of a verifier AIR (stark/verifier_air.py) are such columns.  The verifier evaluates one at the out-of-domain
+        # point by the sparse Lagrange sum over the period-2^lp subgroup; the prover extends one period and tiles it.
+        self.fixed_cols = list(fixed_cols) if fixed_cols else []
+        self.n_fixed = 2 + len(self.fixed_cols)
         # stage 2 (committed after one F_{p^3} challenge g shared by all arguments): a list of
         #   {"kind": "perm", "a": col, "b": col}             -> grand-product column Z            (3 base columns)
         #   {"kind": "lookup", "a": col, "t": col, "m": col} -> LogUp columns h1, h2, running sum S (9 base columns)
@@ -110,6 +116,27 @@ class Air:
 
 
 STAGE2_WIDTH = {"perm": 3, "lookup": 9}
+
+
+class FixedCol:
+    """sparse periodic fixed column: period 2^lp, entries [(pos, value)] with value an int (constant) or Pub(i)"""
+
+    def __init__(self, lp, entries):
+        self.lp = int(lp)
+        self.entries = sorted(((int(pos), v) for pos, v in entries), key=lambda e: e[0])
+        assert all(0 <= pos < (1 << self.lp) for pos, _ in self.entries)
+        assert len({pos for pos, _ in self.entries}) == len(self.entries), "duplicate position in a fixed column"
+
+    def values(self, pubs):
+        """one period as a list of ints"""
+        out = [0] * (1 << self.lp)
+        for pos, v in self.entries:
+            out[pos] = int(pubs[v.i]) % P if isinstance(v, Pub) else int(v) % P
+        return out
+
+    @property
+    def public(self):
+        return any(isinstance(v, Pub) for _, v in self.entries)
 
 
 def transition(e):
@@ -216,6 +243,33 @@ def cubic_witness(logn, seed):
         tr[0, i], tr[1, i] = a, b
         a, b = (a * a * a + b) % P, (a * b + 7) % P
     return tr, np.array([a0, b0, int(tr[0, N - 1])], dtype=np.uint64)
+
+
+def periodic_air(logn):
+    """exercises the sparse periodic fixed columns: K (period 4, dense constants), S (period 8, one nonzero entry), PV (not
+    periodic: a public input at one row).   a' = a K + b,  b' = b^2 + K  (transitions);  a[0] = pub0;
+    S (a - b) = S c  (c carries a - b at every 8th row, anything elsewhere);  PV = L_first pub1  (identity between a
+    public-entry column and a selector: the prover's extension and the verifier's sparse evaluation must agree)."""
+    a, b, c, an, bn = Col(0), Col(1), Col(2), Col(0, True), Col(1, True)
+    K, S, PV = Fixed(2), Fixed(3), Fixed(4)
+    cs = [transition(an - (a * K + b)), transition(bn - (b * b + K)), L_FIRST * (a - Pub(0)), S * (a - b) - S * c,
+          PV - L_FIRST * Pub(1)]
+    fc = [FixedCol(2, [(0, 3), (1, 5), (2, 7), (3, 11)]), FixedCol(3, [(7, 1)]), FixedCol(logn, [(0, Pub(1))])]
+    return Air("periodic%d" % logn, 3, 2, cs, trace_kind=None, fixed_cols=fc)
+
+
+def periodic_witness(logn, seed):
+    import numpy as np
+    N = 1 << logn
+    tr = np.zeros((3, N), dtype=np.uint64)
+    a, b = (seed * 0x9E3779B97F4A7C15 + 1) % P, (seed * 0xC2B2AE3D27D4EB4F + 5) % P
+    a0 = a
+    kk = [3, 5, 7, 11]
+    for i in range(N):
+        tr[0, i], tr[1, i] = a, b
+        tr[2, i] = (a - b) % P if i % 8 == 7 else (i * 977 + seed) % P
+        a, b = (a * kk[i % 4] + b) % P, (b * b + kk[i % 4]) % P
+    return tr, np.array([a0, (seed * 31 + 9) % P], dtype=np.uint64)
 
 
 BUILTIN_AIRS = {"cubic": cubic_air, "perm": permutation_air, "fib": fibonacci_air, "wide8": lambda: wide_air(8), "wide32": lambda: wide_air(32),
@@ -325,10 +379,20 @@ def compile_program(air):
             s2 += [S2_PERM, st["a"], st["b"], 0]
         else:
             s2 += [S2_LOOKUP, st["a"], st["t"], st["m"]]
+    fx = []                       # sparse periodic fixed columns: [lp | n_entries << 8], then (pos | is_pub << 63, value or public index) pairs
+    for fc in air.fixed_cols:
+        assert fc.lp < 64 and len(fc.entries) < (1 << 40)
+        fx.append(fc.lp | (len(fc.entries) << 8))
+        for pos, v in fc.entries:
+            if isinstance(v, Pub):
+                assert v.i < air.n_pub
+                fx += [pos | (1 << 63), v.i]
+            else:
+                fx += [pos, int(v) % P]
     hdr = [PROGRAM_MAGIC, air.width, air.width2, air.n_fixed, air.n_pub, air.n_chal, len(consts), len(words),
            len(air.constraints), max(n_slots, 1), len(air.stage2), quotient_chunks(air)]
     assert len(hdr) == PROGRAM_HEADER_WORDS
-    return np.array(hdr + consts + words + s2, dtype=np.uint64)
+    return np.array(hdr + consts + words + s2 + fx, dtype=np.uint64)
 
 
 # ---------------------------------------------------------------------------------- code generation

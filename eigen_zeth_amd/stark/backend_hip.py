@@ -65,6 +65,28 @@ class HipBackend:
         self.p.poseidon_perm(self._perm_buf, 1)
         return [int(v) for v in self.p.download(self._perm_buf, (12,))]
 
+    def poseidon_perm_batch(self, states):
+        """states uint64 [B][12] -> permuted copy (one launch)"""
+        st = np.ascontiguousarray(np.asarray(states, dtype=np.uint64))
+        if st.shape[0] == 0:
+            return st.copy()
+        d = self.p.upload(st)
+        self.p.poseidon_perm(d, st.shape[0])
+        out = self.p.download(d, st.shape)
+        d.free()
+        return out
+
+    def poseidon_trace(self, inputs):
+        """inputs uint64 [B][12] -> (states [12][32 B], cubes [12][32 B]): round-by-round witness of a Poseidon AIR (zp_poseidon_trace)"""
+        a = np.ascontiguousarray(np.asarray(inputs, dtype=np.uint64))
+        B = a.shape[0]
+        d_in, d_out = self.p.upload(a), self.p.alloc(24 * 32 * B)
+        self.p.poseidon_trace(d_in, B, d_out, d_out.offset(12 * 32 * B), 32 * B)
+        out = self.p.download(d_out, (24, 32 * B))
+        d_in.free()
+        d_out.free()
+        return out[:12], out[12:]
+
     def prove_native(self, air, trace, pubs, params):
         """the whole chunk STARK through zp_stark_prove (one C-ABI call, orchestration in the library's host C++): proof TEXT,
         byte-identical to proof_to_json(prove(...)) over this backend.  trace: host array or a device buffer from prefetch_trace."""
@@ -158,7 +180,14 @@ class HipBackend:
         self._commit(d_cols, M, W, tree)
         return Commit(self._root(tree, M), tree)
 
-    def fixed_ext(self, logn, logb):
+    def fixed_ext(self, logn, logb, air=None, pubs=None):
+        if air is not None and air.fixed_cols:      # sparse periodic fixed columns: selectors + one extended period each (program mode)
+            key = (logn, logb, air.digest())
+            if any(fc.public for fc in air.fixed_cols):
+                return self.p.fixed_columns(air.program(), pubs, logn, logb, self.shift)
+            if key not in self._fixed:
+                self._fixed[key] = self.p.fixed_columns(air.program(), pubs, logn, logb, self.shift)
+            return self._fixed[key]
         key = (logn, logb)
         if key not in self._fixed:
             N = 1 << logn
@@ -185,7 +214,7 @@ class HipBackend:
 
     def quotient(self, air, c1, fixed, pubs, apow, zhinv, logn, logb, wlast):
         M = 1 << (logn + logb)
-        if self.quotient_mode == "program":
+        if self.quotient_mode == "program" or air.fixed_cols:     # periodic fixed columns exist in the interpreter only
             out = self.p.alloc(3 * M)
             self.p.eval_quotient(air.program(), c1.ext, fixed, logn + logb, logb, [int(v) for v in pubs], apow, zhinv, self.shift, wlast, out)
             return out

@@ -107,7 +107,7 @@ def prove(air, trace, pubs, params, be, timings=None):
 
     # 2. constraint quotient on the coset, committed as 3 base columns
     t0 = time.perf_counter()
-    fixed = be.fixed_ext(logn, logb)
+    fixed = be.fixed_ext(logn, logb, air, _ints(pubs)) if air.fixed_cols else be.fixed_ext(logn, logb)
     K = len(air.constraints)
     apow, cur = [], [1, 0, 0]
     for _ in range(K):

@@ -1,0 +1,335 @@
+"""The STARK-verifier AIR, stage A: the Merkle part of verifying chunk proofs, as constraints.
+
+Serves GenAggregatedProof (proto/prover/v1/prover.proto:115-126; client src/prover/provider.rs:422-451) and the final STARK
+of GenFinalProof (prover.proto:130-148; provider.rs:472-503): "aggregate(p1, p2)" is a STARK whose witness is the
+verification trace of the inner proofs' query openings -- every Poseidon permutation a verifier runs to check that the
+opened rows of the trace / stage-2 / quotient / FRI-layer commitments hash up to the roots the proofs name -- and whose
+public inputs are those roots and the query indices.  The reference holds no prover arithmetic, so the
+construction is this repo's own (parity unpinned); it follows the public recursive-STARK recipe.
+
+What the AIR proves (public inputs: per inner proof and tree the root, per query slot / proof / tree the leaf index):
+    for every query slot, inner proof and committed tree there are leaf values and an authentication path such that
+    linear_hash(leaf) hashed up the path, with the direction bits of the PUBLIC index, equals the PUBLIC root.
+The caller (oracle/aggregate_verify.py on the checking side) derives the indices from each inner proof's Fiat-Shamir
+transcript and checks the out-of-domain constraint identity and the final FRI layer from the proof headers; the DEEP /
+FRI-fold arithmetic at the queried points is NOT yet in the AIR (stage B): the aggregated proof carries the opened
+values for that check.
+
+Layout.  One Poseidon-12 permutation = one BLOCK of 32 rows: row r < 30 holds the state before round r, row 30 the
+output, row 31 a copy of it; the cubes (s_i + rc_i)^3 sit in 12 helper columns so that x^7 = cube^2 * x has degree 3.  Full
+and partial rounds share one constraint through the periodic selector FULL (degree 4 -> quotient in 3 pieces, blow-up 4).
+The link between block k (row 31) and block k+1 (row 0) is chosen by SCHEDULE selectors (sparse periodic fixed columns,
+stark/air.py FixedCol): sponge chaining of a leaf hash, a Merkle node (left / right by the direction bit, accumulated into the
+index), the final comparison with the root and the index.  The schedule is fixed by the shape of the inner proofs, so a
+prover cannot shorten a path or skip a comparison.  Everything is cyclic (no boundary constraints): the last link of the
+trace wraps to block 0."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import air as A
+from .air import Col, Fixed, FixedCol, Pub, Const
+
+P = A.P
+ROWS = 32          # rows per permutation block
+N_ROUNDS, N_FULL_HALF = 30, 4
+S0, U0, COL_D, COL_IDX, WIDTH = 0, 12, 24, 25, 26
+
+
+class Shape:
+    """what the Merkle part of a verifier needs to know about the inner proofs (all inner proofs of one aggregation share it)"""
+
+    def __init__(self, logn, logb, W, W2, Wq, n_queries, fri_logf, fri_final_log, n_proofs=2):
+        self.logn, self.logb, self.W, self.W2, self.Wq = logn, logb, W, W2, Wq
+        self.n_queries, self.fri_logf, self.fri_final_log, self.n_proofs = n_queries, fri_logf, fri_final_log, n_proofs
+        logm = logn + logb
+        self.trees = [("trace", W, logm)]
+        if W2:
+            self.trees.append(("stage2", W2, logm))
+        self.trees.append(("quotient", Wq, logm))
+        cur, stop, li = logm, fri_final_log + logb, 0
+        while cur > stop:
+            f = min(fri_logf, cur - stop)
+            self.trees.append(("fri%d" % li, 3 << f, cur - f))
+            cur -= f
+            li += 1
+        assert all(d >= 1 for (_, _, d) in self.trees)
+
+    @staticmethod
+    def of_proof(proof, n_proofs=2):
+        """shape of a proof object (dict as stark/prover.py writes it)"""
+        pr = proof["params"]
+        q0 = proof["queries"][0]
+        return Shape(pr["logn"], pr["logb"], len(q0["trace"]["values"]), len(q0["stage2"]["values"]) if "stage2" in q0 else 0,
+                     len(q0["quotient"]["values"]), pr["n_queries"], pr["fri_logf"], pr["fri_final_log"], n_proofs)
+
+    def key(self):
+        return (self.logn, self.logb, self.W, self.W2, self.Wq, self.n_queries, self.fri_logf, self.fri_final_log, self.n_proofs)
+
+    # ---- the block schedule
+    @staticmethod
+    def absorb_blocks(width):
+        return 0 if width <= 4 else -(-width // 8)
+
+    def blocks_per_proof(self):
+        return sum(self.absorb_blocks(w) + d for (_, w, d) in self.trees)
+
+    def layout(self):
+        """(k, periods, PB): k query slots per period, `periods` periods (a power of two), PB blocks per period (a power of
+        two >= k * n_proofs * blocks_per_proof); chosen to minimise the trace length 32 * PB * periods"""
+        bg = self.n_proofs * self.blocks_per_proof()
+        best = None
+        for j in range(0, 12):
+            periods = 1 << j
+            k = -(-self.n_queries // periods)
+            pb = 1
+            while pb < k * bg:
+                pb <<= 1
+            rows = ROWS * pb * periods
+            if best is None or rows < best[0]:
+                best = (rows, k, periods, pb)
+            if k == 1:
+                break
+        return best[1], best[2], best[3]
+
+    def logn_trace(self):
+        k, periods, pb = self.layout()
+        return (ROWS * pb * periods).bit_length() - 1
+
+    def n_slots(self):
+        k, periods, _ = self.layout()
+        return k * periods
+
+    def n_pub(self):
+        T = len(self.trees)
+        return self.n_proofs * T * 4 + self.n_slots() * self.n_proofs * T
+
+    def pub_root(self, p, t, i):
+        return (p * len(self.trees) + t) * 4 + i
+
+    def pub_index(self, slot, p, t):
+        T = len(self.trees)
+        return self.n_proofs * T * 4 + (slot * self.n_proofs + p) * T + t
+
+    def period_schedule(self):
+        """blocks of one period: list of dicts {kind: "absorb" | "node" | "idle", sub (slot within the period), p, t, level, first,
+        last}; idle blocks pad the period to PB"""
+        k, _, pb = self.layout()
+        out = []
+        for sub in range(k):
+            for p in range(self.n_proofs):
+                for t, (_, w, d) in enumerate(self.trees):
+                    a = self.absorb_blocks(w)
+                    for j in range(a):
+                        out.append({"kind": "absorb", "sub": sub, "p": p, "t": t, "j": j, "first": j == 0, "last": False})
+                    for lv in range(d):
+                        out.append({"kind": "node", "sub": sub, "p": p, "t": t, "level": lv, "first": a == 0 and lv == 0, "last": lv == d - 1})
+        out += [{"kind": "idle", "first": False, "last": False}] * (pb - len(out))
+        return out
+
+
+_AIR_CACHE = {}
+
+
+def verifier_air(shape, rc, mds):
+    """the AIR for inner proofs of `shape` under the Poseidon tables rc (360) / mds (144, row-major)"""
+    key = (shape.key(), hash(tuple(int(v) for v in rc)), hash(tuple(int(v) for v in mds)))
+    if key in _AIR_CACHE:
+        return _AIR_CACHE[key]
+    rc = [int(v) % P for v in rc]
+    mds = [int(v) % P for v in mds]
+    k, periods, pb = shape.layout()
+    lp = (ROWS * pb).bit_length() - 1            # log2 of the schedule period in rows
+    logn = shape.logn_trace()
+    sched = shape.period_schedule()
+    T = len(shape.trees)
+
+    # ---- fixed columns
+    fc = []
+    for i in range(12):
+        fc.append(FixedCol(5, [(r, rc[r * 12 + i]) for r in range(N_ROUNDS) if rc[r * 12 + i]]))
+    full_rows = [r for r in range(N_ROUNDS) if r < N_FULL_HALF or r >= N_ROUNDS - N_FULL_HALF]
+    fc.append(FixedCol(5, [(r, 1) for r in full_rows]))                   # FULL
+    fc.append(FixedCol(5, [(r, 1) for r in range(N_ROUNDS)]))             # ACT: rows with a round transition
+    fc.append(FixedCol(5, [(30, 1)]))                                     # CPY: row 30 -> 31 copies the output
+    RC = [Fixed(2 + i) for i in range(12)]
+    FULL, ACT, CPY = Fixed(14), Fixed(15), Fixed(16)
+    l_chain, l_node, l_final, cap0, wt = [], [], [], [], []
+    roots = [[] for _ in range(4)]
+    final_rows = []                                                       # (row in period, sub, p, t)
+    for b, blk in enumerate(sched):
+        row = b * ROWS + 31
+        nxt = sched[(b + 1) % len(sched)]
+        if blk["kind"] == "absorb":
+            (l_chain if nxt["kind"] == "absorb" and not nxt["first"] else l_node).append((row, 1))
+        elif blk["kind"] == "node":
+            if blk["last"]:
+                l_final.append((row, 1))
+                for i in range(4):
+                    roots[i].append((row, Pub(shape.pub_root(blk["p"], blk["t"], i))))
+                final_rows.append((row, blk["sub"], blk["p"], blk["t"]))
+            else:
+                l_node.append((row, 1))
+        if nxt["kind"] == "node" or nxt["first"]:
+            cap0.append((row, 1))                                         # capacity of the next block's input is zero
+        if nxt["kind"] == "node":
+            wt.append((row, 1 << nxt["level"]))                           # weight of the next block's direction bit
+    fc += [FixedCol(lp, l_chain), FixedCol(lp, l_node), FixedCol(lp, l_final), FixedCol(lp, cap0), FixedCol(lp, wt)]
+    L_CHAIN, L_NODE, L_FINAL, CAP0, WT = [Fixed(17 + i) for i in range(5)]
+    fc += [FixedCol(lp, roots[i]) for i in range(4)]
+    ROOT = [Fixed(22 + i) for i in range(4)]
+    idx_entries = []
+    for per in range(periods):
+        for (row, sub, p, t) in final_rows:
+            idx_entries.append((per * (ROWS * pb) + row, Pub(shape.pub_index(per * k + sub, p, t))))
+    fc.append(FixedCol(logn, idx_entries))
+    IDXV = Fixed(26)
+
+    # ---- constraints
+    s = [Col(S0 + i) for i in range(12)]
+    sn = [Col(S0 + i, True) for i in range(12)]
+    u = [Col(U0 + i) for i in range(12)]
+    d_n, idx, idx_n = Col(COL_D, True), Col(COL_IDX), Col(COL_IDX, True)
+    x = [s[i] + RC[i] for i in range(12)]
+    cs = [u[i] - x[i] * x[i] * x[i] for i in range(12)]                   # cubes (every row; rc = 0 on rows 30, 31)
+    y = [ACT * (u[0] * u[0] * x[0])]
+    for i in range(1, 12):                                                # S-box output: x^7 in full rounds, x in partial rounds (element 0: always x^7)
+        y.append(ACT * x[i] + FULL * (x[i] * (u[i] * u[i]) - x[i]))
+    for j in range(12):
+        acc = None
+        for i in range(12):
+            m = mds[j * 12 + i]
+            if m == 0:
+                continue
+            term = y[i] if m == 1 else Const(m) * y[i]
+            acc = term if acc is None else acc + term
+        cs.append(ACT * sn[j] - acc)                                      # round transition on rows 0..29
+    cs += [CPY * (sn[j] - s[j]) for j in range(12)]                       # row 31 = row 30
+    cs += [L_CHAIN * (sn[8 + i] - s[i]) for i in range(4)]                # sponge chaining: the digest becomes the next capacity
+    cs += [L_NODE * (sn[i] - s[i] + d_n * (sn[4 + i] - sn[i])) for i in range(4)]   # digest = left (bit 0) or right (bit 1) child
+    cs += [CAP0 * sn[8 + i] for i in range(4)]
+    cs.append(WT * (d_n * d_n - d_n))                                     # direction bits are bits
+    cs.append(idx_n - (ACT + CPY + L_CHAIN + L_NODE) * idx - WT * d_n)    # index: kept inside a block and an opening, + 2^level * bit
+    cs += [L_FINAL * s[i] - ROOT[i] for i in range(4)]                    # the top of the path is the public root
+    cs.append(L_FINAL * idx - IDXV)                                       # the direction bits spell the public index
+    air = A.Air("mverify", WIDTH, shape.n_pub(), cs, trace_kind=None, fixed_cols=fc)
+    air.shape = shape
+    assert A.quotient_chunks(air) <= 4
+    _AIR_CACHE[key] = air
+    return air
+
+
+# ---------------------------------------------------------------------------------------------------------------- witness
+def _opening(q, name):
+    if name.startswith("fri"):
+        return q["fri"][int(name[3:])]
+    return q[name]
+
+
+def expected_publics(shape, proofs):
+    """roots of every inner proof, then the leaf index of every (slot, proof, tree): slot g re-opens query g mod n_queries"""
+    pubs = []
+    for pr in proofs:
+        names = {"trace": pr["roots"]["trace"], "quotient": pr["roots"]["quotient"]}
+        if shape.W2:
+            names["stage2"] = pr["roots"]["stage2"]
+        for t, (name, _, _) in enumerate(shape.trees):
+            root = pr["fri"]["roots"][int(name[3:])] if name.startswith("fri") else names[name]
+            pubs += [int(v) for v in root]
+    for g in range(shape.n_slots()):
+        for pr in proofs:
+            j = pr["queries"][g % shape.n_queries]["index"]
+            for (_, _, depth) in shape.trees:
+                pubs.append(int(j) & ((1 << depth) - 1))
+    return pubs
+
+
+def build_witness(shape, proofs, be):
+    """(trace u64[26][N] host array, publics) for inner proof objects `proofs` (len = shape.n_proofs) of `shape`.
+    be: backend with poseidon_perm_batch(states [B][12]) and poseidon_trace(inputs [B][12]) -> (states [12][32 B], cubes
+    [12][32 B]).  Raises ValueError when an opening does not hash to its root -- there is no accepting witness for a proof
+    whose openings do not verify."""
+    assert len(proofs) == shape.n_proofs
+    for pr in proofs:
+        assert Shape.of_proof(pr, shape.n_proofs).key() == shape.key(), "inner proofs of different shapes"
+    k, periods, pb = shape.layout()
+    sched = shape.period_schedule()
+    nblk = pb * periods
+    N = ROWS * nblk
+    inputs = np.zeros((nblk, 12), dtype=np.uint64)
+    dbit = np.zeros(nblk, dtype=np.uint64)
+    idxv = np.zeros(nblk, dtype=np.uint64)
+    # openings: (first block, tree, leaf values, path, index); level-synchronous hashing over all openings at once
+    ops = []
+    for per in range(periods):
+        b = 0
+        while b < pb:
+            blk = sched[b]
+            if blk["kind"] == "idle" or not blk["first"]:
+                b += 1
+                continue
+            name, w, depth = shape.trees[blk["t"]]
+            q = proofs[blk["p"]]["queries"][(per * k + blk["sub"]) % shape.n_queries]
+            o = _opening(q, name)
+            vals = [int(v) for v in o["values"]]
+            path = [[int(v) for v in lv] for lv in o["path"]]
+            if len(vals) != w or len(path) != depth or any(len(lv) != 4 for lv in path):
+                raise ValueError("opening of %s has the wrong shape" % name)
+            ops.append({"b0": per * pb + b, "t": blk["t"], "p": blk["p"], "vals": vals, "path": path,
+                        "index": int(q["index"]) & ((1 << depth) - 1)})
+            b += Shape.absorb_blocks(w) + depth
+    # leaf hashing: absorb block j of every opening that has one
+    digest = [None] * len(ops)
+    max_a = max(Shape.absorb_blocks(w) for (_, w, _) in shape.trees)
+    cap = [[0, 0, 0, 0] for _ in ops]
+    for j in range(max_a):
+        sel = [i for i, o in enumerate(ops) if j < Shape.absorb_blocks(len(o["vals"]))]
+        if not sel:
+            break
+        st = np.zeros((len(sel), 12), dtype=np.uint64)
+        for r, i in enumerate(sel):
+            v = ops[i]["vals"][8 * j:8 * j + 8]
+            st[r, :len(v)] = np.array(v, dtype=np.uint64)
+            st[r, 8:] = np.array(cap[i], dtype=np.uint64)
+            inputs[ops[i]["b0"] + j] = st[r]
+        out = be.poseidon_perm_batch(st)
+        for r, i in enumerate(sel):
+            cap[i] = [int(v) for v in out[r, :4]]
+    for i, o in enumerate(ops):
+        a = Shape.absorb_blocks(len(o["vals"]))
+        digest[i] = cap[i] if a else (o["vals"] + [0, 0, 0, 0])[:4]
+    max_d = max(d for (_, _, d) in shape.trees)
+    for lv in range(max_d):
+        sel = [i for i, o in enumerate(ops) if lv < len(o["path"])]
+        st = np.zeros((len(sel), 12), dtype=np.uint64)
+        for r, i in enumerate(sel):
+            o = ops[i]
+            bit = (o["index"] >> lv) & 1
+            l, rgt = (o["path"][lv], digest[i]) if bit else (digest[i], o["path"][lv])
+            st[r, :4], st[r, 4:8] = np.array(l, dtype=np.uint64), np.array(rgt, dtype=np.uint64)
+            b = o["b0"] + Shape.absorb_blocks(len(o["vals"])) + lv
+            inputs[b] = st[r]
+            dbit[b] = bit
+            idxv[b] = o["index"] & ((2 << lv) - 1)
+        out = be.poseidon_perm_batch(st)
+        for r, i in enumerate(sel):
+            digest[i] = [int(v) for v in out[r, :4]]
+    pubs = expected_publics(shape, proofs)
+    for i, o in enumerate(ops):
+        want = pubs[shape.pub_root(o["p"], o["t"], 0):shape.pub_root(o["p"], o["t"], 0) + 4]
+        if digest[i] != want:
+            raise ValueError("an opening of the %s tree of inner proof %d does not hash to its root: no accepting witness"
+                             % (shape.trees[o["t"]][0], o["p"]))
+    states, cubes = be.poseidon_trace(inputs)
+    trace = np.zeros((WIDTH, N), dtype=np.uint64)
+    trace[S0:S0 + 12], trace[U0:U0 + 12] = states, cubes
+    trace[COL_D] = np.repeat(dbit, ROWS)
+    trace[COL_IDX] = np.repeat(idxv, ROWS)
+    return trace, np.array(pubs, dtype=np.uint64)
+
+
+def aggregation_params(shape, n_queries=50, fri_logf=3, fri_final_log=5, pow_bits=0, hash="gl"):
+    """STARK parameters of the proof over the verifier AIR: blow-up 4 (degree-4 constraints), so 2 bits per query"""
+    from .prover import StarkParams
+    logn = shape.logn_trace()
+    return StarkParams(logn, 2, fri_logf, min(fri_final_log, logn - 1), n_queries, pow_bits, hash=hash)

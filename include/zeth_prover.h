@@ -109,6 +109,11 @@ int32_t zp_lde(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t *d_c
 int32_t zp_poseidon_perm(zp_ctx *ctx, uint64_t *d_states, size_t count);
 /* proof-of-work grinding in front of a STARK's query phase: *h_nonce = the smallest n with
  * Poseidon(h_seed4[0..3] || n || 0^7)[0] >> (64 - bits) == 0   (bits in 0..40; 0 returns 0).     */
+/* Round-by-round trace of `count` permutations -- the witness columns of a Poseidon AIR (the STARK-verifier AIR of
+ * GenAggregatedProof / GenFinalProof, prover.proto:115-148): d_inputs u64[count][12]; permutation k fills rows 32k .. 32k+31 of
+ * 12 state columns (d_states + e * stride: the state BEFORE round r on row r < 30, the output on rows 30 and 31) and of 12
+ * cube columns (d_cubes + e * stride: (state + round constant)^3, state^3 on rows 30, 31).  stride >= 32 * count, in elements. */
+int32_t zp_poseidon_trace(zp_ctx *ctx, const uint64_t *d_inputs, size_t count, uint64_t *d_states, uint64_t *d_cubes, size_t stride);
 /* The Fiat-Shamir sponge (rate 8, capacity 4) in one launch: for each of the nblocks blocks of 8 the rate h_state[0..8) is
  * overwritten with the block and the state permuted (nblocks = 0: one permutation); then `extra` more permutations.
  * h_state (12 words) is updated; h_rates receives (1 + extra) * 8 words: the rate after the absorption and after each
@@ -253,6 +258,19 @@ int32_t zp_eval_quotient(zp_ctx *ctx, const uint64_t *h_program, size_t program_
                          const uint64_t *d_fixed, int32_t logm, int32_t logb, const uint64_t *h_pub, int32_t n_pub,
                          const uint64_t *h_alpha_pows, const uint64_t *h_zhinv, uint64_t shift, uint64_t w_last,
                          uint64_t *d_out);
+/* ---- fixed columns of a statement on the evaluation domain: the d_fixed of zp_eval_quotient -------------------------
+ * Fixed columns 0 and 1 are the boundary selectors L_first, L_last.  Columns 2 .. n_fixed-1 (program header word 3) are
+ * SPARSE PERIODIC columns the verifier knows: a table behind the stage-2 table holds, per column, one word
+ * [lp | n_entries << 8] and n_entries pairs (pos | is_pub << 63, value): the column has period 2^lp <= N (lp = logn: not
+ * periodic), is zero except at rows pos + k 2^lp, where it holds the constant `value` or, with is_pub, public input number
+ * `value`.  (Round constants, schedule selectors and per-row expected values of a verifier AIR are such columns.)
+ * zp_fixed_columns fills d_out (>= zp_fixed_columns_words() words; 0 = malformed program / lp > logn) with
+ *   [L_first: 2^(logn+logb)][L_last: 2^(logn+logb)][column 2: 2^(lp_2+logb)][column 3: ...]
+ * i.e. the two selectors extended to the whole coset and ONE extended period of every periodic column (a period-p column is
+ * g(x^(N/p)); on shift*<w_M> that is the extension of p values with coset shift shift^(N/p), read at row mod p*2^logb).   */
+size_t zp_fixed_columns_words(const uint64_t *h_program, size_t program_words, int32_t logn, int32_t logb);
+int32_t zp_fixed_columns(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *h_pub, int32_t n_pub,
+                         int32_t logn, int32_t logb, uint64_t shift, uint64_t *d_out, size_t out_words);
 /* the same for a window [row0, row0 + nrows) of the domain (a row shard): columns with explicit strides; unless the
  * window is the whole domain the caller appends the 2^logb halo rows (rows row0+nrows .. of the domain, wrapping to 0)
  * behind each column (stride_cols >= nrows + 2^logb); row0 and nrows are multiples of 2^logb.                      */

@@ -30,7 +30,28 @@ class Program:
             raise BadProgram("not a ZPAIR1 constraint program")
         (_, self.width, self.width2, self.n_fixed, self.n_pub, self.n_chal, n_const, n_instr, self.n_constraints,
          self.n_slots, n_s2, self.q_chunks) = w[:HEADER_WORDS]
-        if len(w) != HEADER_WORDS + n_const + n_instr + 4 * n_s2:
+        if self.n_fixed < 2 or len(w) < HEADER_WORDS + n_const + n_instr + 4 * n_s2:
+            raise BadProgram("length does not match the header")
+        # fixed columns 2.. : sparse periodic columns, [lp | n_entries << 8] then (pos | is_pub << 63, value or public index) pairs
+        self.fixed_cols = []
+        fa = HEADER_WORDS + n_const + n_instr + 4 * n_s2
+        for _ in range(self.n_fixed - 2):
+            if fa >= len(w):
+                raise BadProgram("fixed-column table truncated")
+            lp, ne = w[fa] & 0xFF, w[fa] >> 8
+            if lp > 40 or fa + 1 + 2 * ne > len(w):
+                raise BadProgram("fixed-column table truncated")
+            ent, seen = [], set()
+            for e in range(ne):
+                a, v = w[fa + 1 + 2 * e], w[fa + 2 + 2 * e]
+                pos, is_pub = a & ((1 << 63) - 1), a >> 63
+                if pos >= (1 << lp) or pos in seen or (is_pub and v >= self.n_pub) or (not is_pub and v >= P):
+                    raise BadProgram("bad fixed-column entry")
+                seen.add(pos)
+                ent.append((pos, bool(is_pub), v))
+            self.fixed_cols.append((lp, ent))
+            fa += 1 + 2 * ne
+        if fa != len(w):
             raise BadProgram("length does not match the header")
         at = HEADER_WORDS
         self.consts = w[at:at + n_const]
@@ -68,6 +89,47 @@ class Program:
 
     def digest(self):
         return self._sha.hex()[:16]
+
+    # ---- sparse periodic fixed columns (index k counts from fixed column 2)
+    def fixed_period(self, k, pubs):
+        """one period of column k as a list of ints"""
+        lp, ent = self.fixed_cols[k]
+        out = [0] * (1 << lp)
+        for pos, is_pub, v in ent:
+            out[pos] = int(pubs[v]) % P if is_pub else v
+        return out
+
+    def fixed_eval_ext(self, k, pubs, zeta, logn, root32):
+        """value at the F_{p^3} point zeta of the degree < N polynomial that agrees with column k on the N = 2^logn trace rows.
+        Periodic with period p = 2^lp means f(x) = g(x^(N/p)), g the interpolant of one period over the order-p subgroup:
+        g(y) = sum_e v_e (y^p - 1) w_p^pos / (p (y - w_p^pos)) -- a sum over the nonzero entries only."""
+        lp, ent = self.fixed_cols[k]
+        if lp > logn:
+            raise BadProgram("fixed column longer than the trace")
+        p = 1 << lp
+        y = NV.e3_pow(zeta, 1 << (logn - lp))
+        wp = NV.root(lp, root32) if lp else 1
+        yp = NV.e3_pow(y, p)
+        num = [(yp[0] - 1) % P, yp[1], yp[2]]
+        pinv = pow(p, P - 2, P)
+        terms = []
+        for pos, is_pub, v in ent:
+            val = int(pubs[v]) % P if is_pub else v
+            if val:
+                wj = pow(wp, pos, P)
+                terms.append((val * wj % P * pinv % P, [(y[0] - wj) % P, y[1], y[2]]))
+        # one inversion for all denominators (Montgomery's trick): prefix products, invert the total, walk back
+        pre, run = [], [1, 0, 0]
+        for _, den in terms:
+            pre.append(run)
+            run = NV.e3_mul(run, den)
+        inv = NV.e3_inv(run) if terms else [1, 0, 0]
+        acc = [0, 0, 0]
+        for (c, den), pr in zip(reversed(terms), reversed(pre)):
+            dinv = NV.e3_mul(inv, pr)
+            inv = NV.e3_mul(inv, den)
+            acc = NV.e3_add(acc, [t * c % P for t in dinv])
+        return NV.e3_mul(acc, num)
 
     def digest_words(self):
         return [int.from_bytes(self._sha[8 * i:8 * i + 8], "little") % P for i in range(4)]

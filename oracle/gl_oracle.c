@@ -259,6 +259,39 @@ void orc_poseidon_perm(u64 *states, size_t count, const u64 *rc, const u64 *mds)
     for (size_t i = 0; i < count; i++) poseidon_perm(states + i * PW, rc, mds);
 }
 
+/* Round-by-round trace of `count` permutations, the witness of a Poseidon AIR (32 rows per permutation):
+ * states[e][32 k + r] = element e of the state BEFORE round r (r < 30), the output on rows 30 and 31;
+ * cubes[e][32 k + r]  = (state + round constant)^3 on rows r < 30, state^3 on rows 30, 31.  Column stride = 32 * count. */
+void orc_poseidon_trace(const u64 *inputs, size_t count, u64 *states, u64 *cubes, const u64 *rc, const u64 *mds) {
+    const size_t n = 32 * count;
+#pragma omp parallel for schedule(static)
+    for (size_t k = 0; k < count; k++) {
+        u64 st[PW];
+        memcpy(st, inputs + k * PW, sizeof(st));
+        for (int r = 0; r < 32; r++) {
+            for (int i = 0; i < PW; i++) {
+                const u64 x = r < PRF + PRP ? gl_add(st[i], rc[r * PW + i]) : st[i];
+                states[(size_t)i * n + 32 * k + r] = st[i];
+                cubes[(size_t)i * n + 32 * k + r] = gl_mul(gl_mul(x, x), x);
+            }
+            if (r >= PRF + PRP) continue;
+            for (int i = 0; i < PW; i++) st[i] = gl_add(st[i], rc[r * PW + i]);
+            if (r < PRF / 2 || r >= PRF / 2 + PRP) {
+                for (int i = 0; i < PW; i++) st[i] = sbox7(st[i]);
+            } else {
+                st[0] = sbox7(st[0]);
+            }
+            u64 nx[PW];
+            for (int i = 0; i < PW; i++) {
+                u64 acc = 0;
+                for (int j = 0; j < PW; j++) acc = gl_add(acc, gl_mul(mds[i * PW + j], st[j]));
+                nx[i] = acc;
+            }
+            memcpy(st, nx, sizeof(nx));
+        }
+    }
+}
+
 /* linear hash of a row of `len` elements -> 4 elements.
  *  len <= 4 : identity, zero-padded (no permutation)
  *  else     : sponge, state = [rate 0..7 | capacity 8..11], capacity starts 0, each block of
@@ -611,7 +644,16 @@ int orc_quotient_program_rows(const u64 *prog, size_t prog_len, const u64 *cols,
     static const unsigned char magic[8] = {'Z', 'P', 'A', 'I', 'R', '1', 0, 0};
     if (memcmp(prog, magic, 8) != 0) return -1;
     const size_t n_const = prog[6], n_instr = prog[7], n_slots = prog[9], n_s2 = prog[10];
-    if (prog_len != 12 + n_const + n_instr + 4 * n_s2 || n_slots == 0 || n_slots > 4096) return -1;
+    if (n_slots == 0 || n_slots > 4096 || prog[3] < 2) return -1;
+    {   /* behind the stage-2 table: the sparse periodic fixed columns (2..n_fixed-1), [lp | n << 8] + n (pos, value) pairs each.
+           This evaluator takes them MATERIALISED (fixedc holds n_fixed full columns); only the length is checked here. */
+        size_t at = 12 + n_const + n_instr + 4 * n_s2;
+        for (u64 k = 2; k < prog[3]; k++) {
+            if (at >= prog_len) return -1;
+            at += 1 + 2 * (size_t)(prog[at] >> 8);
+        }
+        if (at != prog_len) return -1;
+    }
     const u64 *consts = prog + 12, *ins = consts + n_const;
     int bad = 0;
 #pragma omp parallel

@@ -50,6 +50,7 @@ def lib():
         L.orc_intt.argtypes = [_u64p, i32, i32, u64]
         L.orc_lde.argtypes = [_u64p, _u64p, i32, i32, i32, u64, u64]
         L.orc_poseidon_perm.argtypes = [_u64p, sz, _u64p, _u64p]
+        L.orc_poseidon_trace.argtypes = [_u64p, sz, _u64p, _u64p, _u64p, _u64p]
         L.orc_merkle_commit.argtypes = [_u64p, sz, i32, _u64p, _u64p, _u64p]
         L.orc_merkle_commit_rows.argtypes = [_u64p, sz, sz, _u64p, _u64p, _u64p]
         L.orc_linear_hash.argtypes = [_u64p, sz, _u64p, _u64p, _u64p]
@@ -135,6 +136,16 @@ def poseidon_perm(states, rc, mds):
     mds = _arr(mds)
     lib().orc_poseidon_perm(_p(s), s.shape[0], _p(rc), _p(mds))
     return s
+
+
+def poseidon_trace(inputs, rc, mds):
+    """inputs: uint64 [B][12] -> (states [12][32 B], cubes [12][32 B]): the round-by-round witness of a Poseidon AIR"""
+    a = _arr(inputs)
+    B = a.shape[0]
+    st = np.empty((12, 32 * B), dtype=np.uint64)
+    cu = np.empty((12, 32 * B), dtype=np.uint64)
+    lib().orc_poseidon_trace(_p(a), B, _p(st), _p(cu), _p(_arr(rc)), _p(_arr(mds)))
+    return st, cu
 
 
 def merkle_commit(cols, rc, mds):

@@ -10,6 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import oracle as O
+from .air_program import Program
 
 
 class Commit:
@@ -45,6 +46,12 @@ class CpuBackend:
 
     def poseidon_perm(self, state):
         return [int(v) for v in O.poseidon_perm(np.array([state], dtype=np.uint64), self.rc, self.mds)[0]]
+
+    def poseidon_perm_batch(self, states):
+        return O.poseidon_perm(np.asarray(states, dtype=np.uint64), self.rc, self.mds)
+
+    def poseidon_trace(self, inputs):
+        return O.poseidon_trace(np.asarray(inputs, dtype=np.uint64), self.rc, self.mds)
 
     def commit_trace(self, trace, logn, logb, extra_cols=0):
         W = trace.shape[0]
@@ -83,7 +90,10 @@ class CpuBackend:
         root, tree = self._tree(mat)
         return Commit(root, tree)
 
-    def fixed_ext(self, logn, logb):
+    def fixed_ext(self, logn, logb, air=None, pubs=None):
+        """LDE of every fixed column, materialised as u64[n_fixed][M]: the two boundary selectors, then the sparse periodic
+        columns of the statement (decoded from its program blob by the checker's own reader, tiled to N rows, extended like
+        any other column -- the definition, no period tricks)"""
         key = (logn, logb)
         if key not in self._fixed:
             N = 1 << logn
@@ -91,7 +101,16 @@ class CpuBackend:
             ind[0, 0] = 1
             ind[1, N - 1] = 1
             self._fixed[key] = O.lde(ind, logb, self.shift, self.root32)
-        return self._fixed[key]
+        sel = self._fixed[key]
+        prog = Program(air.program()) if air is not None else None
+        if prog is None or not prog.fixed_cols:
+            return sel
+        N = 1 << logn
+        extra = np.zeros((len(prog.fixed_cols), N), dtype=np.uint64)
+        for k in range(len(prog.fixed_cols)):
+            per = np.array(prog.fixed_period(k, [int(v) for v in pubs]), dtype=np.uint64)
+            extra[k] = np.tile(per, N // len(per))
+        return np.ascontiguousarray(np.concatenate([sel, O.lde(extra, logb, self.shift, self.root32)], axis=0))
 
     def quotient(self, air, c1, fixed, pubs, apow, zhinv, logn, logb, wlast):
         logm = logn + logb

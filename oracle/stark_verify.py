@@ -165,10 +165,13 @@ def expectation(params, root32=NV.ROOT32_DEFAULT, shift=NV.SHIFT_DEFAULT):
     return e
 
 
-def verify(proof, program, rc, mds, expect, bn_tables=None):
+def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False):
     """program: the constraint program blob (u64 words) of the statement;  expect: the verifier's own parameters
     {logn, logb, fri_logf, fri_final_log, n_queries, pow_bits, root32, shift [, hash]}.  hash = "bn128": the proof must be in
-    BN128-hash mode (16-ary Poseidon-BN254 trees + transcript); bn_tables = (rc, mds, rp) of the t = 17 instance."""
+    BN128-hash mode (16-ary Poseidon-BN254 trees + transcript); bn_tables = (rc, mds, rp) of the t = 17 instance.
+    header_only: check everything that needs no opening (parameters, transcript, out-of-domain constraint identity, final
+    FRI layer, proof of work) and return {"indices": the query indices the transcript dictates} -- the part of the verifier
+    that stays outside a Merkle-verifier AIR (oracle/aggregate_verify.py); proof["queries"] is not read."""
     rc = np.asarray(rc, dtype=np.uint64)
     mds = np.asarray(mds, dtype=np.uint64)
     air = program if isinstance(program, Program) else Program(program)
@@ -249,7 +252,8 @@ def verify(proof, program, rc, mds, expect, bn_tables=None):
     l_first = NV.e3_mul([v * ninv % P for v in zh], NV.e3_inv(_e3_sub(zeta, [1, 0, 0])))
     l_last = NV.e3_mul([v * ninv % P * wlast % P for v in zh], NV.e3_inv(_e3_sub(zeta, [wlast, 0, 0])))
     xml = _e3_sub(zeta, [wlast, 0, 0])
-    cs = air.evaluate_ext(ev_all[:Wt], ev_next, [l_first, l_last], list(pubs) + list(chal), xml)
+    fixed_z = [l_first, l_last] + [air.fixed_eval_ext(k, pubs, zeta, logn, root32) for k in range(len(air.fixed_cols))]
+    cs = air.evaluate_ext(ev_all[:Wt], ev_next, fixed_z, list(pubs) + list(chal), xml)
     lhs, ap = [0, 0, 0], [1, 0, 0]
     for c in cs:
         lhs = NV.e3_add(lhs, NV.e3_mul(ap, c))
@@ -285,7 +289,7 @@ def verify(proof, program, rc, mds, expect, bn_tables=None):
             raise Reject("proof-of-work nonce missing or wrong")
         tr.absorb([nonce])
     qidx = [v & (M - 1) for v in tr.squeeze(n_queries)]
-    if len(proof["queries"]) != n_queries or [qq["index"] for qq in proof["queries"]] != qidx:
+    if not header_only and (len(proof["queries"]) != n_queries or [qq["index"] for qq in proof["queries"]] != qidx):
         raise Reject("query indices do not follow the transcript")
 
     # ---- final layer is low degree: degree < 2^(final_log - logb) on its coset
@@ -299,6 +303,8 @@ def verify(proof, program, rc, mds, expect, bn_tables=None):
         if any(cf[(1 << (final_log - logb)):]):
             raise Reject("final FRI layer is not low degree")
 
+    if header_only:
+        return {"indices": qidx, "sched": sched, "W": W, "W2": W2, "Wq": 3 * Q}
     zeta_w = [v * wN % P for v in zeta]
     Wall = Wt + 3 * Q
     gp, cur = [], [1, 0, 0]

@@ -1,0 +1,126 @@
+"""The STARK-verifier AIR on the MI355X: witness kernel (zp_poseidon_trace), the aggregation STARK through the GPU backend and
+through zp_stark_prove (periodic fixed columns read as one extended period: zp_fixed_columns), byte-identical to the CPU
+checker's proof and accepted by the independent verifiers; then GenAggregatedProof / GenFinalProof through the engine at the
+service's parameters (proto/prover/v1/prover.proto:115-148; client src/prover/provider.rs:422-503)."""
+import copy
+import json
+
+import numpy as np
+import pytest
+
+from eigen_zeth_amd import native
+from eigen_zeth_amd.stark import air as AIR
+from eigen_zeth_amd.stark import prover as PR
+from eigen_zeth_amd.stark import verifier_air as VA
+from eigen_zeth_amd.stark.backend_hip import HipBackend
+from oracle import aggregate_verify as AV
+from oracle import oracle as O
+from oracle import stark_verify as V
+from oracle.stark_cpu import CpuBackend
+
+pytestmark = pytest.mark.gpu
+P = O.P
+
+
+@pytest.fixture(scope="module")
+def hip(prover):
+    return HipBackend(prover=prover)
+
+
+@pytest.mark.parametrize("count", [1, 5, 128, 129, 1000])
+def test_poseidon_trace_kernel_matches_oracle(prover, tables, count):
+    rc, mds = tables
+    x = O.random_field((count, 12), 900 + count)
+    x[0, :3] = np.array([0, P - 1, 1], dtype=np.uint64)
+    d_in, d_out = prover.upload(x), prover.alloc(24 * 32 * count)
+    prover.poseidon_trace(d_in, count, d_out, d_out.offset(12 * 32 * count), 32 * count)
+    got = prover.download(d_out, (24, 32 * count))
+    st, cu = O.poseidon_trace(x, rc, mds)
+    assert (got[:12] == st).all() and (got[12:] == cu).all()
+
+
+def test_poseidon_trace_kernel_injected_tables(prover, tables):
+    rc, mds = tables
+    rc2 = O.random_field((360,), 29)
+    mds2 = (O.random_field((144,), 30) % np.uint64(1 << 20)).astype(np.uint64)
+    x = O.random_field((70, 12), 31)
+    try:
+        prover.set_constants(native.ZP_CONST_POSEIDON_RC, rc2)
+        prover.set_constants(native.ZP_CONST_POSEIDON_MDS, mds2)
+        d_in, d_out = prover.upload(x), prover.alloc(24 * 32 * 70)
+        prover.poseidon_trace(d_in, 70, d_out, d_out.offset(12 * 32 * 70), 32 * 70)
+        got = prover.download(d_out, (24, 32 * 70))
+        st, cu = O.poseidon_trace(x, rc2, mds2)
+        assert (got[:12] == st).all() and (got[12:] == cu).all()
+    finally:
+        prover.set_constants(native.ZP_CONST_POSEIDON_RC, rc)
+        prover.set_constants(native.ZP_CONST_POSEIDON_MDS, mds)
+
+
+@pytest.mark.parametrize("airname,logn,nq", [("chunk16", 6, 4), ("wide8", 9, 6)])
+def test_aggregation_stark_gpu_equals_cpu_and_verifies(hip, tables, airname, logn, nq):
+    rc, mds = tables
+    cpu = CpuBackend(rc, mds)
+    air = AIR.get_air(airname)
+    params = PR.StarkParams(logn, 1, 2, 3, nq, pow_bits=4)
+    proofs = []
+    for seed in (3, 4):
+        tr, pub = native.synth_trace(air.trace_kind, logn, air.width, seed)
+        proofs.append(json.loads(PR.proof_to_json(PR.prove(air, tr, pub, params, hip))))
+    shape = VA.Shape.of_proof(proofs[0], 2)
+    vair = VA.verifier_air(shape, rc, mds)
+    t_gpu, pubs = VA.build_witness(shape, proofs, hip)
+    t_cpu, pubs_c = VA.build_witness(shape, proofs, cpu)
+    assert (t_gpu == t_cpu).all() and (pubs == pubs_c).all()
+    ap = VA.aggregation_params(shape, n_queries=5, fri_final_log=3)
+    p_cpu = PR.proof_to_json(PR.prove(vair, t_cpu, pubs, ap, cpu))
+    p_gpu = PR.proof_to_json(PR.prove(vair, t_gpu, pubs, ap, hip))
+    assert p_gpu == p_cpu
+    assert hip.prove_native(vair, t_gpu, pubs, ap) == p_cpu                    # zp_stark_prove: the same bytes
+    agg = {"kind": "aggregated", "inner": [{k: v for k, v in p.items() if k != "queries"} for p in proofs], "stark": json.loads(p_gpu)}
+    assert AV.verify(agg, air.program(), vair.program(), rc, mds, V.expectation(params.to_dict()), V.expectation(ap.to_dict()), shape.n_slots())
+    t_bad = t_gpu.copy()
+    t_bad[VA.S0 + 1, 32 * 3 + 7] = (int(t_bad[VA.S0 + 1, 32 * 3 + 7]) + 1) % P
+    with pytest.raises(V.Reject):
+        V.verify(json.loads(hip.prove_native(vair, t_bad, pubs, ap)), vair.program(), rc, mds, V.expectation(ap.to_dict()))
+
+
+def test_engine_aggregate_and_final_prove_what_they_name(tables, tmp_path):
+    """the service's path at its default security (80 queries + 20 bits inner, 50 queries x blow-up 4 for both recursion
+    layers), chunk AIR with 64 + 12 columns: the aggregated proof passes the checker's aggregate verifier, a tampered chunk
+    proof is refused (application error, no proof), the final STARK (BN128-hash mode) verifies under the verifier AIR of the
+    aggregated proof's shape with exactly its roots and indices as public inputs"""
+    from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
+    from eigen_zeth_amd.service.engine import Engine, EngineConfig
+    from eigen_zeth_amd.service.server import default_backend_factory
+    rc, mds = tables
+    cfg = EngineConfig(air="chunk64", logn=14, chunks_per_block=1, groth16_logm=6, crs_dir=str(tmp_path / "crs"))
+    eng = Engine(default_backend_factory(0), cfg)
+    ch = eng.gen_batch_chunks("agg", [11, 12, 13], 12345, "evm")
+    proofs = eng.gen_chunk_proofs("agg", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+    text = eng.aggregate("agg", proofs[0]["proof"], proofs[-1]["proof"])
+    agg = json.loads(text)
+    assert agg["kind"] == "aggregated" and "standin" not in text and len(agg["inner"]) == 2
+    sh = VA.Shape(*[agg["shape"][k] for k in ("logn", "logb", "W", "W2", "Wq", "n_queries", "fri_logf", "fri_final_log", "n_proofs")])
+    vair = VA.verifier_air(sh, rc, mds)
+    assert vair.digest() == agg["verifier_air_digest"]
+    inner_exp = V.expectation(eng.stark_params(14).to_dict())
+    outer_exp = V.expectation(VA.aggregation_params(sh, cfg.agg_queries, cfg.fri_logf, cfg.fri_final_log).to_dict())
+    assert outer_exp["n_queries"] * outer_exp["logb"] >= 100
+    assert AV.verify(agg, AIR.get_air("chunk64").program(), vair.program(), rc, mds, inner_exp, outer_exp, sh.n_slots())
+    bad = json.loads(proofs[0]["proof"])
+    bad["queries"][7]["trace"]["values"][3] ^= 1
+    with pytest.raises(ValueError, match="no accepting witness"):
+        eng.aggregate("agg2", json.dumps(bad), proofs[-1]["proof"])
+    # one chunk: the client sends the same proof twice -> verified once
+    one = json.loads(eng.aggregate("agg3", proofs[1]["proof"], proofs[1]["proof"]))
+    assert len(one["inner"]) == 1 and one["shape"]["n_proofs"] == 1
+    final, pub = eng.final("agg", text, "BN128", "479881985774944702531460751064278034642760119942")
+    fsp = json.loads(eng.final_starks["agg"])
+    fsh = VA.Shape.of_proof(agg["stark"], 1)
+    fair = VA.verifier_air(fsh, rc, mds)
+    assert fsp["air_digest"] == fair.digest() and [int(v) for v in fsp["publics"]] == VA.expected_publics(fsh, [agg["stark"]])
+    assert V.verify(fsp, fair.program(), rc, mds, V.expectation(eng.final_stark_params(agg["stark"]).to_dict()), bn254_poseidon_params(17))
+    with pytest.raises(ValueError):
+        eng.final("x", json.dumps({"kind": "something-else"}), "BN128", "1")
+    print("stage timings:", json.dumps({k: v for k, v in eng.stage_timings.items() if k.startswith(("aggregate", "final"))}))

@@ -80,8 +80,8 @@ def test_reference_fixture_grammar():
 
 
 def _start(tmp_path, backend_factory, cfg=None):
-    cfg = cfg or EngineConfig(air="wide8", logn=7, n_queries=6, fri_final_log=3, pow_bits=6)
-    cfg.final_logn, cfg.final_logb, cfg.final_queries = 6, 1, 5      # a small final STARK: the checker verifies it in Python
+    cfg = cfg or EngineConfig(air="wide8", logn=5, n_queries=3, fri_final_log=3, pow_bits=6)
+    cfg.agg_queries, cfg.final_queries = 2, 2                         # small recursion layers: the CPU checker proves and verifies them
     cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
     engine = Engine(backend_factory, cfg)
     svc = ProverService(engine, BatchStore(str(tmp_path)))
@@ -129,7 +129,27 @@ def _check_result(res, tables, block, svc=None):
         assert len(fs) == 1
         fsp = json.loads(fs[0])
         assert fsp["params"]["hash"] == "bn128" and len(fsp["roots"]["trace"]) == 1
-        assert V.verify(fsp, AIR.get_air(fsp["air"]).program(), rc, mds, V.expectation(svc.engine.final_stark_params().to_dict()),
+        # the recursion layers prove what they name.  (1) the aggregated proof: both chunk-proof headers verify (transcript,
+        # out-of-domain identity, final layer), the outer STARK's publics are their roots and transcript-derived indices, and
+        # the outer STARK verifies under the Merkle-verifier AIR of that shape
+        from eigen_zeth_amd.stark import verifier_air as VA
+        from oracle import aggregate_verify as AV
+        agg = json.loads(res["aggregated"])
+        assert agg["kind"] == "aggregated" and "standin" not in res["aggregated"]
+        inner_air = AIR.get_air(agg["inner"][0]["air"])
+        sh = VA.Shape(*[agg["shape"][k] for k in ("logn", "logb", "W", "W2", "Wq", "n_queries", "fri_logf", "fri_final_log", "n_proofs")])
+        vair = VA.verifier_air(sh, rc, mds)
+        assert vair.digest() == agg["verifier_air_digest"] and sh.n_slots() == agg["slots"]
+        inner_exp = V.expectation(svc.engine.stark_params(sh.logn).to_dict())
+        outer_exp = V.expectation(VA.aggregation_params(sh, svc.engine.cfg.agg_queries, svc.engine.cfg.fri_logf, svc.engine.cfg.fri_final_log).to_dict())
+        assert AV.verify(agg, inner_air.program(), vair.program(), rc, mds, inner_exp, outer_exp, sh.n_slots())
+        # (2) the final STARK (BN128-hash mode): the same verifier AIR over the aggregated proof's STARK -- its publics are that
+        # STARK's roots and query indices, and the independent verifier accepts it
+        fsh = VA.Shape.of_proof(agg["stark"], 1)
+        fair = VA.verifier_air(fsh, rc, mds)
+        assert fsp["air_digest"] == fair.digest()
+        assert [int(v) for v in fsp["publics"]] == VA.expected_publics(fsh, [agg["stark"]])
+        assert V.verify(fsp, fair.program(), rc, mds, V.expectation(svc.engine.final_stark_params(agg["stark"]).to_dict()),
                         bn254_poseidon_params(17))
     # ProofResult as eigen-zeth stores it (src/db/mod.rs:63-71): json with 32-number arrays
     stored = json.dumps({k: res[k] for k in ("block_number", "proof", "public_input", "pre_state_root", "post_state_root")})
@@ -299,7 +319,7 @@ def test_metrics_endpoint_counts_requests_and_stage_time(tmp_path, cpu_factory):
     """Prometheus text on /metrics with request counters, per-stage seconds and the HBM rate gauge"""
     import urllib.request
     from eigen_zeth_amd.service.metrics import Metrics
-    cfg = EngineConfig(air="chunk16", logn=6, n_queries=4, fri_final_log=3, pow_bits=4)
+    cfg = EngineConfig(air="chunk16", logn=5, n_queries=2, fri_final_log=3, pow_bits=4, agg_queries=2, final_queries=2)
     cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
     m = Metrics()
     httpd = m.serve(0)

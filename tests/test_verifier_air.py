@@ -1,0 +1,172 @@
+"""The STARK-verifier AIR, stage A (eigen_zeth_amd/stark/verifier_air.py): GenAggregatedProof and the final STARK prove what
+they name -- the Merkle part of verifying the inner proofs (proto/prover/v1/prover.proto:115-148; client
+src/prover/provider.rs:422-503).  CPU tests: the product's AIR / witness builder / orchestration over the checker's backend,
+judged by the checker's independent verifiers (oracle/stark_verify.py, oracle/aggregate_verify.py)."""
+import copy
+import json
+
+import numpy as np
+import pytest
+
+from eigen_zeth_amd import native
+from eigen_zeth_amd.stark import air as AIR
+from eigen_zeth_amd.stark import prover as PR
+from eigen_zeth_amd.stark import verifier_air as VA
+from oracle import aggregate_verify as AV
+from oracle import oracle as O
+from oracle import stark_verify as V
+from oracle.stark_cpu import CpuBackend
+
+P = O.P
+
+
+@pytest.fixture(scope="module")
+def cpu(tables):
+    return CpuBackend(*tables)
+
+
+@pytest.fixture(scope="module")
+def inner(cpu):
+    """two chunk16 proofs (trace + stage-2 + quotient + two FRI layers: every kind of tree, leaves of 16 / 12 / 3 / 12 / 6 values)"""
+    air = AIR.get_air("chunk16")
+    params = PR.StarkParams(6, 1, 2, 3, 4, pow_bits=4)
+    proofs = []
+    for seed in (3, 4):
+        tr, pub = native.synth_trace(air.trace_kind, 6, air.width, seed)
+        proofs.append(json.loads(PR.proof_to_json(PR.prove(air, tr, pub, params, cpu))))
+    return air, params, proofs
+
+
+@pytest.fixture(scope="module")
+def aggregated(cpu, inner, tables):
+    air, params, proofs = inner
+    shape = VA.Shape.of_proof(proofs[0], 2)
+    vair = VA.verifier_air(shape, *tables)
+    trace, pubs = VA.build_witness(shape, proofs, cpu)
+    ap = VA.aggregation_params(shape, n_queries=5, fri_final_log=3)
+    stark = PR.prove(vair, trace, pubs, ap, cpu)
+    header = lambda p: {k: v for k, v in p.items() if k != "queries"}
+    return shape, vair, ap, trace, pubs, {"kind": "aggregated", "inner": [header(p) for p in proofs], "stark": stark}
+
+
+def test_poseidon_trace_rows_are_the_round_states(tables):
+    rc, mds = tables
+    x = O.random_field((5, 12), 77)
+    st, cu = O.poseidon_trace(x, rc, mds)
+    assert st.shape == (12, 160) and (st[:, 0::32].T == x).all()
+    out = O.poseidon_perm(x, rc, mds)
+    assert (st[:, 30::32].T == out).all() and (st[:, 31::32].T == out).all()
+    for r in (0, 3, 4, 17, 29):                      # cubes: (state + round constant)^3
+        for e in (0, 5, 11):
+            v = (int(st[e, 32 + r]) + int(rc[12 * r + e])) % P
+            assert int(cu[e, 32 + r]) == pow(v, 3, P)
+    assert int(cu[2, 31]) == pow(int(st[2, 31]), 3, P)
+
+
+def test_layout_and_schedule(inner):
+    _, _, proofs = inner
+    shape = VA.Shape.of_proof(proofs[0], 2)
+    assert [t[0] for t in shape.trees] == ["trace", "stage2", "quotient", "fri0", "fri1"]
+    k, periods, pb = shape.layout()
+    assert periods & (periods - 1) == 0 and pb & (pb - 1) == 0 and k * periods >= shape.n_queries
+    assert k * 2 * shape.blocks_per_proof() <= pb
+    sched = shape.period_schedule()
+    assert len(sched) == pb and sum(b["kind"] != "idle" for b in sched) == k * 2 * shape.blocks_per_proof()
+    assert sum(b["last"] for b in sched) == k * 2 * len(shape.trees)      # one root comparison per (slot, proof, tree)
+    # the service's shapes: two 2^20-row chunk proofs fit a 2^20-row verifier trace, its own proof a 2^18-row final trace
+    big = VA.Shape(20, 1, 64, 12, 3, 80, 3, 5, 2)
+    assert big.logn_trace() == 20
+    assert VA.Shape(20, 2, 26, 0, 9, 50, 3, 5, 1).logn_trace() == 18
+
+
+def test_aggregated_proof_is_accepted_by_the_independent_verifier(inner, aggregated, tables):
+    rc, mds = tables
+    air, params, proofs = inner
+    shape, vair, ap, _, pubs, agg = aggregated
+    assert len(pubs) == shape.n_pub() and AIR.quotient_chunks(vair) == 3
+    assert V.verify(agg["stark"], vair.program(), rc, mds, V.expectation(ap.to_dict()))
+    assert AV.verify(agg, air.program(), vair.program(), rc, mds, V.expectation(params.to_dict()), V.expectation(ap.to_dict()), shape.n_slots())
+
+
+def test_tampered_inner_proof_has_no_accepting_witness(inner, cpu):
+    _, _, proofs = inner
+    shape = VA.Shape.of_proof(proofs[0], 2)
+    for mutate in (lambda p: p[1]["queries"][2]["trace"]["values"].__setitem__(5, p[1]["queries"][2]["trace"]["values"][5] ^ 1),
+                   lambda p: p[0]["queries"][1]["fri"][0]["path"][2].__setitem__(1, p[0]["queries"][1]["fri"][0]["path"][2][1] ^ 1),
+                   lambda p: p[0]["queries"][0]["stage2"]["path"][0].__setitem__(0, (p[0]["queries"][0]["stage2"]["path"][0][0] + 1) % P),
+                   lambda p: p[1]["roots"]["quotient"].__setitem__(3, (p[1]["roots"]["quotient"][3] + 1) % P),
+                   lambda p: p[0]["queries"][3].__setitem__("index", p[0]["queries"][3]["index"] ^ 2)):
+        bad = copy.deepcopy(proofs)
+        mutate(bad)
+        with pytest.raises(ValueError, match="no accepting witness"):
+            VA.build_witness(shape, bad, cpu)
+
+
+def test_forged_witnesses_are_rejected(inner, aggregated, cpu, tables):
+    """a prover that skips the witness builder's own check cannot get a proof accepted: every way of bending the trace or the
+    public inputs breaks a constraint (the out-of-domain identity fails in the independent verifier)"""
+    rc, mds = tables
+    shape, vair, ap, trace, pubs, _ = aggregated
+    exp = V.expectation(ap.to_dict())
+    prog = vair.program()
+
+    def rejected(tr, pb):
+        with pytest.raises(V.Reject):
+            V.verify(PR.prove(vair, tr, pb, ap, cpu), prog, rc, mds, exp)
+    t1 = trace.copy()
+    t1[VA.S0 + 3, 32 * 7 + 11] = (int(t1[VA.S0 + 3, 32 * 7 + 11]) + 1) % P            # one state cell inside a permutation
+    rejected(t1, pubs)
+    p2 = pubs.copy()
+    p2[shape.pub_root(1, 0, 2)] = (int(p2[shape.pub_root(1, 0, 2)]) + 1) % P          # claim another trace root for proof 1
+    rejected(trace, p2)
+    p3 = pubs.copy()
+    p3[shape.pub_index(1, 0, 0)] ^= 1                                                 # claim another leaf index
+    rejected(trace, p3)
+    # swap left and right at one node: flip the direction bit (and the accumulated index) but keep the hashes
+    sched = shape.period_schedule()
+    b = next(i for i, blk in enumerate(sched) if blk["kind"] == "node" and blk["level"] == 2)
+    t4 = trace.copy()
+    t4[VA.COL_D, 32 * b:32 * b + 32] ^= 1
+    rejected(t4, pubs)
+    t5 = trace.copy()
+    t5[VA.U0, 5] = (int(t5[VA.U0, 5]) + 1) % P                                        # a wrong cube
+    rejected(t5, pubs)
+
+
+def test_outer_publics_must_follow_the_inner_transcripts(inner, aggregated, tables):
+    rc, mds = tables
+    air, params, _ = inner
+    shape, vair, ap, _, _, agg = aggregated
+    args = (air.program(), vair.program(), rc, mds, V.expectation(params.to_dict()), V.expectation(ap.to_dict()), shape.n_slots())
+    bad = copy.deepcopy(agg)
+    bad["inner"][0]["evals"]["z"][0][0] ^= 1                   # a header that does not verify on its own
+    with pytest.raises(V.Reject):
+        AV.verify(bad, *args)
+    bad = copy.deepcopy(agg)
+    bad["inner"][1]["fri"]["final"][0][0] ^= 1                 # changes the transcript after the roots: other indices
+    with pytest.raises(V.Reject):
+        AV.verify(bad, *args)
+    bad = copy.deepcopy(agg)
+    bad["inner"] = bad["inner"][::-1]                          # the outer proof names proof 0's roots first
+    with pytest.raises(V.Reject, match="public inputs"):
+        AV.verify(bad, *args)
+    with pytest.raises(V.Reject):                              # fewer inner queries than the verifier requires
+        AV.verify(agg, air.program(), vair.program(), rc, mds, dict(V.expectation(params.to_dict()), n_queries=5), V.expectation(ap.to_dict()),
+                  shape.n_slots())
+
+
+def test_single_proof_shape_and_identity_leaves(cpu, tables):
+    """n_proofs = 1 (what the final STARK verifies: the aggregated proof's own STARK) and a tree whose leaves are not hashed
+    (a quotient of one piece: 3 values, identity-padded) right after an idle wrap-around"""
+    rc, mds = tables
+    air = AIR.get_air("fib")
+    params = PR.StarkParams(5, 1, 2, 3, 3, pow_bits=0)
+    tr, pub = native.synth_trace(air.trace_kind, 5, air.width, 9)
+    proof = json.loads(PR.proof_to_json(PR.prove(air, tr, pub, params, cpu)))
+    shape = VA.Shape.of_proof(proof, 1)
+    assert shape.trees[0][1] == 2 and VA.Shape.absorb_blocks(2) == 0             # the trace leaves of `fib` are identity leaves too
+    vair = VA.verifier_air(shape, rc, mds)
+    trace, pubs = VA.build_witness(shape, [proof], cpu)
+    ap = VA.aggregation_params(shape, n_queries=4, fri_final_log=3)
+    assert V.verify(PR.prove(vair, trace, pubs, ap, cpu), vair.program(), rc, mds, V.expectation(ap.to_dict()))
+    assert [int(v) for v in pubs] == VA.expected_publics(shape, [proof])
