@@ -140,6 +140,37 @@ def cpu_baseline(logn, budget_cols):
             "note": "CPU restatement, not the eigen-zkvm prover (parity unpinned, SURVEY.md 8c)"}
 
 
+def integer_roofline(prover, pass_rows, alg_bytes, elems_per_launch):
+    """the integer-VALU roofline next to the HBM one.  VALU instruction counts per unit come from the committed PMC
+    file (profiles/r3_integer_roofline.json, made by tools/integer_roofline.py from rocprofv3 --pmc SQ_INSTS_VALU runs: labelled
+    as such, not re-measured here); the issue ceiling is 1024 SIMDs x 64 lanes x clock / 4 cycles per instruction (every
+    instruction of these kernels is of the 4-cycle class: tools/ubench_isa.hip, profiles/r2_ubench_isa.txt).  frac_int = the time the
+    pure instruction issue of a launch needs / the measured launch time."""
+    path = os.path.join(ROOT, "profiles", "r3_integer_roofline.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "integer_roofline.json")
+    try:
+        tab = json.load(open(path))
+        info = prover.device_info()
+        clock = info["clock_khz"] * 1e3
+        simds = info["cus"] * 4
+        ceiling = simds * 64 * clock / tab.get("cycles_per_valu_instruction", 4.0)      # lane-instructions per second
+        rows = []
+        for r in pass_rows:
+            v = tab["ntt_valu_per_element_per_pass"].get(r["kernel"])
+            if v is None or not r["avg_launch_ms"]:
+                continue
+            issue_ms = elems_per_launch * v / ceiling * 1e3
+            rows.append({"kernel": r["kernel"], "valu_per_element": v, "issue_only_ms": issue_ms, "measured_ms": r["avg_launch_ms"],
+                         "frac_int": issue_ms / r["avg_launch_ms"]})
+        return {"source": os.path.relpath(path, ROOT) + " (PMC SQ_INSTS_VALU x 64 / units, separate profiler run)",
+                "issue_ceiling_lane_instr_per_s": ceiling, "clock_hz": clock, "simds": simds,
+                "cycles_per_valu_instruction": tab.get("cycles_per_valu_instruction", 4.0),
+                "ntt_passes": rows, "other_stages_valu_per_unit": tab.get("stages", {})}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,25 +272,50 @@ def main():
         plan = prover.ntt_plan(logn)
         npass = max(1, len(plan["passes"]))
         elems_total = world * cols * N * args.steps
-        # dominant kernel = the non-transposing radix pass (2 of the 3 launches per chunk at 2^24)
+        # Every launch of the timed region is one instantiation of ntt_pass2_kernel (one pass of the plan over chunk_cols
+        # columns).  The roofline figure is TIME-WEIGHTED over all of them: algorithmic bytes of all launches / summed launch
+        # time -- no instantiation is left out (round 2 reported the two cheaper ones only).  pass_timings() keys: radix log,
+        # negative = the transposing first pass.
         by_kind = {}
         for rl, ms in passes:
             by_kind.setdefault(rl, []).append(ms)
-        dom = max(by_kind, key=lambda k: sum(by_kind[k])) if by_kind else 0
-        launches = len(by_kind.get(dom, []))
-        avg_ms = sum(by_kind[dom]) / launches if launches else float("nan")
         chunk_cols = min(cols, max(1, (1 << int(os.environ.get("ZP_NTT_CHUNK_LOG", "27"))) >> logn))
         # algorithmic bytes of one launch: SURVEY 8d gives 16*N bytes per column transform (ideal single
         # pass); a launch does one of the `npass` passes over chunk_cols columns -> 16*N*chunk/npass
         alg_bytes = 16.0 * N * chunk_cols / npass
+        launches = sum(len(v) for v in by_kind.values())
+        total_ms = sum(sum(v) for v in by_kind.values())
+        avg_ms = total_ms / launches if launches else float("nan")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else float("nan")
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "ntt_traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch_dominant")
-            except Exception:
-                traffic = None
+        pass_rows = []
+        for i, ps in enumerate(plan["passes"]):
+            key = -ps["radix_log"] if i == 0 else ps["radix_log"]
+            first, last = i == 0, i == len(plan["passes"]) - 1
+            mode = 1 if first else (0 if last else 1)          # forward transform: table passes in the middle, plain last pass
+            logt = {1: 0, 2: 1, 4: 2, 8: 3, 16: 4, 32: 5}[ps["tile"]]
+            name = "ntt_pass2_kernel<%d, %d, %d, %d, %s, false, %d, false>" % (ps["rounds"][0], ps["rounds"][1], ps["rounds"][2], logt,
+                                                                                 "true" if first else "false", mode)
+            ms_l = by_kind.get(key, [])
+            if first and not ms_l:
+                ms_l = by_kind.get(ps["radix_log"], [])
+            a_ms = sum(ms_l) / len(ms_l) if ms_l else None
+            pass_rows.append({"kernel": name, "role": "transposing first pass (per-lane twiddle chain)" if first else
+                              ("plain last pass" if last else "pass with a per-tile twiddle table"),
+                              "launches": len(ms_l), "avg_launch_ms": a_ms,
+                              "frac": (alg_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if a_ms else None})
+        slowest = max((r for r in pass_rows if r["avg_launch_ms"]), key=lambda r: r["avg_launch_ms"], default=None)
+        traffic, traffic_src = None, None
+        for tp in ("r3_ntt_traffic.json", "ntt_traffic.json"):
+            tp = os.path.join(ROOT, "profiles", tp)
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get("hbm_bytes_per_launch_dominant")
+                    traffic_src = ("committed PMC measurement %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x 2 "
+                                   "per the gfx950 correction); not re-measured in this run" % os.path.relpath(tp, ROOT))
+                    break
+                except Exception:
+                    traffic = None
+        integer = integer_roofline(prover, pass_rows, alg_bytes, N * chunk_cols)
         out = {
             "metric": "goldilocks_ntt_field_elems_per_s",
             "value": elems_total / wall_max,
@@ -282,11 +338,12 @@ def main():
             "device_ms_per_step_min": per_step[0],
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ntt_pass2_kernel<%s> radix 2^%d (%s)" % ("4,4,0,4,false,false,{1,0}" if dom == 8 else "...", abs(dom), "transposing first pass" if dom < 0 else "non-transposing passes 2..m: MODE 1 = twiddle table, MODE 0 = plain last pass"),
+                "kernel": "ntt_pass2_kernel: all %d instantiations of the plan, time-weighted (slowest: %s)" % (len(pass_rows), slowest["kernel"] if slowest else "?"),
+                "passes": pass_rows,
                 "launch_columns": chunk_cols,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if launches else None,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "hbm_copy_ceiling_GBs": copy_gbs,
                 "frac_of_copy_ceiling": (achieved / copy_gbs) if (launches and copy_gbs) else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -294,6 +351,7 @@ def main():
                 "whole_transform_GBs": 16.0 * N * cols * args.steps / (dev_ms * 1e-3) / 1e9,
                 "whole_transform_frac": 16.0 * N * cols * args.steps / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "per_pass_avg_ms": {str(k): sum(v) / len(v) for k, v in sorted(by_kind.items())},
+                "integer": integer,
             },
         }
 
@@ -568,10 +626,11 @@ def cpu_stark_baseline(logn, air_name="chunk64"):
     be = CpuBackend(default_round_constants(), default_mds())
     tm = {}
     t0 = time.perf_counter()
-    PR.prove(air, tr, pub, PR.StarkParams(logn, 1, 3, 5, 32), be, timings=tm)
+    params = PR.StarkParams(logn, 1, 3, 5, 80, pow_bits=20)        # the GPU line's parameters: 80 queries + 20 grinding bits
+    PR.prove(air, tr, pub, params, be, timings=tm)
     wall = time.perf_counter() - t0
     return {"wall_s": wall, "cores": O.num_threads(), "kind": "port",
-            "sample": "same STARK (same AIR, 32 queries) at 2^%d rows on the CPU restatement (oracle/stark_cpu.py); the GPU line is at 2^20" % logn,
+            "sample": "same STARK (same AIR, same parameters: 80 queries + 20 grinding bits) at 2^%d rows on the CPU restatement (oracle/stark_cpu.py); the GPU line is at 2^20" % logn,
             "extrapolated_2^20_wall_s": wall * (1 << (20 - logn)) if logn < 20 else wall,
             "extrapolation": "linear in the row count (every stage is O(N) or O(N log N)): a lower bound for the CPU at 2^20",
             "stages_ms": {k: round(v * 1e3, 1) for k, v in tm.items()}}

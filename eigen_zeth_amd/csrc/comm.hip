@@ -1,0 +1,196 @@
+// Multi-GPU behind the C-ABI: RCCL over xGMI, called directly (BASELINE.json configs[3]).
+//
+// One process per GPU.  A compiled host (the reference's side of the boundary is Rust: src/prover/provider.rs:358-377 sends one
+// GenChunkProof per batch) shards ONE commitment over the GPUs of a node without Python or torch: columns are owned by ranks
+// (NTT / LDE need no exchange), leaf hashing needs whole rows, so there is exactly one exchange -- rank g sends rank h the
+// rows [h M/G, (h+1) M/G) of its columns.  xGMI is point-to-point (7 links per GPU), so the exchange is a grouped
+// ncclSend / ncclRecv all-to-all: every pairwise message rides its own link; the only other collective is the all-gather of
+// G x 32 bytes of sub-roots.  librccl is loaded at run time (dlopen), so the library has no link-time dependency on it and a
+// process that already carries an RCCL (a torch process) keeps using that one.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ctx.hpp"
+
+namespace {
+
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    if (r.h || r.ok) return r;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names)          // an RCCL that is already in the process (same SONAME) is reused
+        if ((r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
+    if (!r.h)
+        for (const char *n : names)
+            if ((r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!r.h) return r;
+#define ZP_SYM(name) r.name = (decltype(r.name))dlsym(r.h, "nccl" #name)
+    ZP_SYM(GetUniqueId); ZP_SYM(CommInitRank); ZP_SYM(CommDestroy); ZP_SYM(GroupStart); ZP_SYM(GroupEnd);
+    ZP_SYM(Send); ZP_SYM(Recv); ZP_SYM(AllGather); ZP_SYM(Broadcast); ZP_SYM(GetErrorString);
+#undef ZP_SYM
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllGather && r.Broadcast &&
+           r.GetErrorString;
+    return r;
+}
+
+}  // namespace
+
+struct zp_comm {
+    zp_ctx *ctx;
+    ncclComm_t comm;
+    int rank, world;
+};
+
+#define ZP_NCCL(c, call)                                                                       \
+    do {                                                                                       \
+        const ncclResult_t r_ = (call);                                                        \
+        if (r_ != ncclSuccess) {                                                               \
+            (c)->ctx->err = std::string(#call) + ": " + rccl().GetErrorString(r_);             \
+            return ZP_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+extern "C" {
+
+int32_t zp_comm_unique_id(uint8_t *out128) {
+    if (!out128 || !rccl().ok) return out128 ? ZP_ERR_UNSUPPORTED : ZP_ERR_ARG;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return ZP_ERR_HIP;
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(out128, &id, 128);
+    return ZP_OK;
+}
+
+int32_t zp_comm_create(zp_ctx *ctx, int32_t rank, int32_t world, const uint8_t *id128, zp_comm **out) {
+    if (!ctx || !out) return ZP_ERR_ARG;
+    *out = nullptr;
+    ZP_BIND(ctx);
+    ZP_ARG(ctx, id128 && world >= 1 && rank >= 0 && rank < world, "bad rank / world / id");
+    ZP_ARG(ctx, (world & (world - 1)) == 0, "world must be a power of two (row shards are halves of halves of the domain)");
+    if (!rccl().ok) { ctx->err = "librccl.so could not be loaded"; return ZP_ERR_UNSUPPORTED; }
+    zp_comm *c = new (std::nothrow) zp_comm();
+    if (!c) return ZP_ERR_NOMEM;
+    c->ctx = ctx; c->rank = rank; c->world = world; c->comm = nullptr;
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    const ncclResult_t r = rccl().CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        ctx->err = std::string("ncclCommInitRank: ") + rccl().GetErrorString(r);
+        delete c;
+        return ZP_ERR_HIP;
+    }
+    *out = c;
+    return ZP_OK;
+}
+
+int32_t zp_comm_destroy(zp_comm *c) {
+    if (!c) return ZP_OK;
+    ZP_BIND(c->ctx);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    delete c;
+    return ZP_OK;
+}
+
+int32_t zp_comm_rank(const zp_comm *c) { return c ? c->rank : -1; }
+int32_t zp_comm_world(const zp_comm *c) { return c ? c->world : -1; }
+
+// recv[h * words_per_peer ..) <- rank h's send[me * words_per_peer ..): one grouped send/recv, all links busy at once
+int32_t zp_comm_all_to_all(zp_comm *c, const uint64_t *d_send, uint64_t *d_recv, size_t words_per_peer) {
+    if (!c) return ZP_ERR_ARG;
+    ZpStage stage_(c->ctx, "comm_all_to_all");
+    ZP_ARG(c->ctx, d_send && d_recv && d_send != d_recv, "bad buffers");
+    if (words_per_peer == 0) return ZP_OK;
+    ZP_NCCL(c, rccl().GroupStart());
+    for (int h = 0; h < c->world; h++) {
+        ZP_NCCL(c, rccl().Send(d_send + (size_t)h * words_per_peer, words_per_peer, ncclUint64, h, c->comm, c->ctx->stream));
+        ZP_NCCL(c, rccl().Recv(d_recv + (size_t)h * words_per_peer, words_per_peer, ncclUint64, h, c->comm, c->ctx->stream));
+    }
+    ZP_NCCL(c, rccl().GroupEnd());
+    return ZP_OK;
+}
+
+int32_t zp_comm_all_gather(zp_comm *c, const uint64_t *d_send, uint64_t *d_recv, size_t words) {
+    if (!c) return ZP_ERR_ARG;
+    ZpStage stage_(c->ctx, "comm_all_gather");
+    ZP_ARG(c->ctx, d_send && d_recv, "bad buffers");
+    if (words == 0) return ZP_OK;
+    ZP_NCCL(c, rccl().AllGather(d_send, d_recv, words, ncclUint64, c->comm, c->ctx->stream));
+    return ZP_OK;
+}
+
+int32_t zp_comm_broadcast(zp_comm *c, uint64_t *d_buf, size_t words, int32_t root) {
+    if (!c) return ZP_ERR_ARG;
+    ZpStage stage_(c->ctx, "comm_broadcast");
+    ZP_ARG(c->ctx, d_buf && root >= 0 && root < c->world, "bad arguments");
+    if (words == 0) return ZP_OK;
+    ZP_NCCL(c, rccl().Broadcast(d_buf, d_buf, words, ncclUint64, root, c->comm, c->ctx->stream));
+    return ZP_OK;
+}
+
+// column shards -> row shards: d_cols u64[Wl][M] (this rank's columns, all rows) -> d_rows u64[G * Wl][M / G] (ALL columns in
+// rank order, this rank's rows): zp_pack_blocks, then one all-to-all; the received buffer already is the column-major matrix
+// zp_merkle_commit takes.  d_pack: scratch of Wl * M words.
+int32_t zp_exchange_columns_to_rows(zp_comm *c, const uint64_t *d_cols, size_t Wl, size_t M, uint64_t *d_pack, uint64_t *d_rows) {
+    if (!c) return ZP_ERR_ARG;
+    zp_ctx *ctx = c->ctx;
+    ZP_ARG(ctx, d_cols && d_pack && d_rows && Wl >= 1 && M % (size_t)c->world == 0 && (M / c->world) % 2 == 0, "bad arguments (M must split into even row shards)");
+    if (c->world == 1) return zp_d2d(ctx, d_rows, d_cols, Wl * M * 8);
+    ZP_TRY(zp_pack_blocks(ctx, d_cols, d_pack, Wl, M, c->world));
+    return zp_comm_all_to_all(c, d_pack, d_rows, Wl * (M / c->world));
+}
+
+// One Merkle commitment over the ranks: every rank hands in its Wl columns of the M-row matrix and gets the GLOBAL root (the
+// same root a single GPU computes over all G * Wl columns).  d_tree_local receives this rank's subtree over its M / G rows
+// ((2 M / G - 1) * 4 words, what zp_merkle_open_batch answers openings of local rows from); the G sub-roots are all-gathered
+// and the top log2 G levels hashed redundantly on every rank.
+int32_t zp_merkle_commit_sharded(zp_comm *c, const uint64_t *d_cols, size_t M, int32_t Wl, uint64_t *d_tree_local, uint64_t *h_root4) {
+    if (!c) return ZP_ERR_ARG;
+    zp_ctx *ctx = c->ctx;
+    ZP_ARG(ctx, d_cols && d_tree_local && h_root4 && Wl >= 1 && M >= (size_t)2 * c->world && (M & (M - 1)) == 0, "bad arguments");
+    const size_t G = (size_t)c->world, Ml = M / G;
+    void *pack = nullptr, *rows = nullptr, *sub = nullptr;
+    int32_t rc = zp_dev_alloc(ctx, (size_t)Wl * M * 8, &pack);
+    if (rc == ZP_OK) rc = zp_dev_alloc(ctx, (size_t)Wl * M * 8, &rows);
+    if (rc == ZP_OK) rc = zp_dev_alloc(ctx, G * 12 * 8, &sub);
+    if (rc == ZP_OK) rc = zp_exchange_columns_to_rows(c, d_cols, (size_t)Wl, M, (uint64_t *)pack, (uint64_t *)rows);
+    if (rc == ZP_OK) rc = zp_merkle_commit(ctx, (const uint64_t *)rows, Ml, (int32_t)(G * Wl), d_tree_local);
+    std::vector<u64> lvl(G * 4);
+    if (rc == ZP_OK) rc = zp_comm_all_gather(c, d_tree_local + (2 * Ml - 2) * 4, (uint64_t *)sub, 4);
+    if (rc == ZP_OK) rc = zp_d2h(ctx, lvl.data(), sub, G * 32);
+    for (size_t n = G; rc == ZP_OK && n > 1; n >>= 1) {       // top of the tree: node = P(left | right | 0)[0..4)
+        std::vector<u64> st((n / 2) * 12, 0);
+        for (size_t i = 0; i < n / 2; i++) memcpy(&st[12 * i], &lvl[8 * i], 64);
+        rc = zp_h2d(ctx, sub, st.data(), st.size() * 8);
+        if (rc == ZP_OK) rc = zp_poseidon_perm(ctx, (uint64_t *)sub, n / 2);
+        if (rc == ZP_OK) rc = zp_d2h(ctx, st.data(), sub, st.size() * 8);
+        for (size_t i = 0; i < n / 2; i++) memcpy(&lvl[4 * i], &st[12 * i], 32);
+    }
+    if (rc == ZP_OK) memcpy(h_root4, lvl.data(), 32);
+    if (pack) (void)zp_dev_free(ctx, pack);
+    if (rows) (void)zp_dev_free(ctx, rows);
+    if (sub) (void)zp_dev_free(ctx, sub);
+    return rc;
+}
+
+}  // extern "C"

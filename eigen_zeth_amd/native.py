@@ -99,6 +99,16 @@ SIGNATURES = {
     "zp_domain_tables": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int32)]),
     "zp_synth_trace": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p]),
     "zp_synth_trace_bound": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, C.c_int32, _u64p, _u64p]),
+    "zp_comm_unique_id": (C.c_int32, [_vp]),
+    "zp_comm_create": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, C.POINTER(_vp)]),
+    "zp_comm_destroy": (C.c_int32, [_vp]),
+    "zp_comm_rank": (C.c_int32, [_vp]),
+    "zp_comm_world": (C.c_int32, [_vp]),
+    "zp_comm_all_to_all": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
+    "zp_comm_all_gather": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
+    "zp_comm_broadcast": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32]),
+    "zp_exchange_columns_to_rows": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp]),
+    "zp_merkle_commit_sharded": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp, _u64p]),
     "zp_msm_bn254": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
     "zp_msm_bn254_g2": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
     "zp_ntt_host": (C.c_int32, [_vp, _u64p, C.c_int32, C.c_int32, C.c_int32]),
@@ -216,6 +226,49 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 makes it, every rank passes it to Comm)"""
+    buf = (C.c_uint8 * 128)()
+    rc = load_library().zp_comm_unique_id(buf)
+    if rc != 0:
+        raise ZpError(rc, "zp_comm_unique_id failed (librccl.so not loadable?)")
+    return bytes(buf)
+
+
+class Comm:
+    """zp_comm: this rank's Prover joined to an RCCL communicator (one process per GPU); collectives on the ctx stream"""
+
+    def __init__(self, prover, rank, world, unique_id):
+        self.prover, self.rank, self.world = prover, rank, world
+        h = _vp()
+        idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        prover._chk(prover.lib.zp_comm_create(prover.ctx, rank, world, idb, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.prover.lib.zp_comm_destroy(self.h)
+            self.h = None
+
+    def all_to_all(self, d_send, d_recv, words_per_peer):
+        self.prover._chk(self.prover.lib.zp_comm_all_to_all(self.h, _ptr(d_send), _ptr(d_recv), words_per_peer))
+
+    def all_gather(self, d_send, d_recv, words):
+        self.prover._chk(self.prover.lib.zp_comm_all_gather(self.h, _ptr(d_send), _ptr(d_recv), words))
+
+    def broadcast(self, d_buf, words, root=0):
+        self.prover._chk(self.prover.lib.zp_comm_broadcast(self.h, _ptr(d_buf), words, root))
+
+    def exchange_columns_to_rows(self, d_cols, Wl, M, d_pack, d_rows):
+        self.prover._chk(self.prover.lib.zp_exchange_columns_to_rows(self.h, _ptr(d_cols), Wl, M, _ptr(d_pack), _ptr(d_rows)))
+
+    def merkle_commit_sharded(self, d_cols, M, Wl, d_tree_local):
+        """-> the global root (4 ints)"""
+        root = (C.c_uint64 * 4)()
+        self.prover._chk(self.prover.lib.zp_merkle_commit_sharded(self.h, _ptr(d_cols), M, Wl, _ptr(d_tree_local), root))
+        return [int(v) for v in root]
 
 
 class Prover:

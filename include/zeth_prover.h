@@ -298,6 +298,32 @@ int32_t zp_synth_trace_bound(int32_t kind, int32_t logn, int32_t W, uint64_t see
  * start must exceed 1024.  Known discrete logs: sum_i s_i P_i = (sum_i s_i (start + i) mod r) * G.            */
 int32_t zp_synth_g1_points(uint64_t start, size_t n, uint32_t *h_points, int32_t threads);
 
+/* ---- multi-GPU: RCCL over xGMI behind the C-ABI (BASELINE.json configs[3]) ---------------------------------
+ * One process per GPU; a zp_comm joins this rank's ctx to the RCCL communicator of `world` ranks (a power of two).  Rank 0 makes
+ * the 128-byte id (zp_comm_unique_id) and hands it to the others out of band (a file, the service's own channel); every rank
+ * then calls zp_comm_create -- collectively.  All collectives run on the ctx stream; librccl.so is loaded at run time.
+ *   zp_comm_all_to_all : recv[h * w ..) <- rank h's send[me * w ..)   (grouped ncclSend/ncclRecv: each pair on its own link)
+ *   zp_comm_all_gather : recv[h * w ..) <- rank h's send[0 .. w)
+ *   zp_exchange_columns_to_rows : this rank's columns u64[Wl][M] -> ALL columns of this rank's rows u64[G*Wl][M/G]
+ *                                 (zp_pack_blocks + one all-to-all; d_pack = scratch of Wl*M words; the result is the
+ *                                 column-major matrix zp_merkle_commit takes)
+ *   zp_merkle_commit_sharded    : ONE Poseidon Merkle commitment over the ranks: columns in, the global root out (equal to the
+ *                                 single-GPU root over all G*Wl columns); d_tree_local = this rank's subtree over its M/G rows,
+ *                                 (2M/G - 1) * 4 words; the G sub-roots are all-gathered, the top log2 G levels hashed on
+ *                                 every rank.  Constraint / DEEP stages of a sharded proof take row windows:
+ *                                 zp_eval_quotient_rows, zp_deep_quotient_rows.                                              */
+typedef struct zp_comm zp_comm;
+int32_t zp_comm_unique_id(uint8_t *out128);
+int32_t zp_comm_create(zp_ctx *ctx, int32_t rank, int32_t world, const uint8_t *id128, zp_comm **out);
+int32_t zp_comm_destroy(zp_comm *comm);
+int32_t zp_comm_rank(const zp_comm *comm);
+int32_t zp_comm_world(const zp_comm *comm);
+int32_t zp_comm_all_to_all(zp_comm *comm, const uint64_t *d_send, uint64_t *d_recv, size_t words_per_peer);
+int32_t zp_comm_all_gather(zp_comm *comm, const uint64_t *d_send, uint64_t *d_recv, size_t words);
+int32_t zp_comm_broadcast(zp_comm *comm, uint64_t *d_buf, size_t words, int32_t root);
+int32_t zp_exchange_columns_to_rows(zp_comm *comm, const uint64_t *d_cols, size_t Wl, size_t M, uint64_t *d_pack, uint64_t *d_rows);
+int32_t zp_merkle_commit_sharded(zp_comm *comm, const uint64_t *d_cols, size_t M, int32_t Wl, uint64_t *d_tree_local, uint64_t *h_root4);
+
 /* ---- N6: BN254 (alt_bn128) G1 multi-scalar multiplication ---------------------------------------
  * d_points u32[n][16]: affine x (8 little-endian 32-bit limbs) then y, standard (non-Montgomery)
  * integers < q; (0,0) encodes the point at infinity.  d_scalars u32[n][8] little-endian, any 256-bit

@@ -1,0 +1,71 @@
+"""RCCL behind the C-ABI (csrc/comm.hip: zp_comm_*, zp_exchange_columns_to_rows, zp_merkle_commit_sharded) -- SURVEY.md 8e,
+BASELINE.json configs[3].  On the one-GPU box the communicator has one rank (RCCL init, grouped send/recv to self, all-gather
+and broadcast all execute); with >= 2 GPUs the compiled host host/commit_sharded runs one process per GPU and every rank must
+print the single-GPU root.  The multi-rank layout logic is the one the world-2 gloo tests pin (tests/test_multigpu_cpu.py)."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from eigen_zeth_amd import native
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_comm_world_of_one_collectives_and_sharded_commit(prover, tables):
+    rc, mds = tables
+    comm = native.Comm(prover, 0, 1, native.comm_unique_id())
+    try:
+        x = O.random_field((4, 1 << 10), 5)
+        d_x, d_y = prover.upload(x), prover.alloc(x.size)
+        comm.all_to_all(d_x, d_y, x.size)                       # one peer: the whole buffer goes to itself
+        assert (prover.download(d_y, x.shape) == x).all()
+        prover.memset(d_y, 0, x.size * 8)
+        comm.all_gather(d_x, d_y, x.size)
+        assert (prover.download(d_y, x.shape) == x).all()
+        comm.broadcast(d_y, x.size, 0)
+        assert (prover.download(d_y, x.shape) == x).all()
+        d_pack, d_rows = prover.alloc(x.size), prover.alloc(x.size)
+        comm.exchange_columns_to_rows(d_x, 4, 1 << 10, d_pack, d_rows)
+        assert (prover.download(d_rows, x.shape) == x).all()
+        # the sharded commitment of a world of one IS the plain commitment: whole tree and root against the oracle
+        M, W = 1 << 12, 9
+        cols = O.random_field((W, M), 6)
+        ref = O.merkle_commit(cols, rc, mds)
+        d_cols, d_tree = prover.upload(cols), prover.alloc((2 * M - 1) * 4)
+        root = comm.merkle_commit_sharded(d_cols, M, W, d_tree)
+        assert root == [int(v) for v in ref[-1]]
+        assert (prover.download(d_tree, ref.shape) == ref).all()
+    finally:
+        comm.close()
+
+
+def test_compiled_host_shards_one_commitment_over_the_visible_gpus(prover, tables):
+    """host/commit_sharded (C++ on include/zeth_prover.h alone): one process per GPU, RCCL id through a file; every rank prints
+    the root a single GPU commits.  World = the number of visible GPUs rounded down to a power of two (1 on the test box)."""
+    import torch
+    rc, mds = tables
+    exe = os.path.join(ROOT, "host", "commit_sharded")
+    assert os.path.exists(exe), "build first: make -C host"
+    n = torch.cuda.device_count()
+    world = 1
+    while world * 2 <= min(n, 4):
+        world *= 2
+    logn, logb, W = 12, 1, 8
+    x = O.random_field((W, 1 << logn), 77)
+    want = O.merkle_commit(O.lde(x, logb), rc, mds)[-1]
+    with tempfile.TemporaryDirectory() as td:
+        x.tofile(os.path.join(td, "trace.bin"))
+        idf = os.path.join(td, "rccl.id")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([exe, os.path.join(td, "trace.bin"), str(logn), str(logb), str(W), str(r), str(world), idf], env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+        outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+        words = so.split("root ")[1].split()[:4]
+        assert [int(w, 16) for w in words] == [int(v) for v in want], so
