@@ -498,6 +498,38 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
                "merkle_ms": e[2].elapsed_time(e[3]), "root": [hex(v) for v in root]}
         if world > 1:
             res["all_to_all_GBs_sent_per_gpu"] = sent / (res["all_to_all_ms"] * 1e-3) / 1e9
+    # the same sharded commitment with RCCL called DIRECTLY behind the C-ABI (csrc/comm.hip: zp_comm_create on an id made by rank
+    # 0, zp_merkle_commit_sharded = pack + grouped send/recv all-to-all + local subtree + all-gather of sub-roots + tree top) --
+    # what a compiled host uses; must give the root of the torch.distributed path above.  RCCL wants one rank per GPU, so the
+    # one-GPU rehearsal (gloo backend) skips it.
+    if world > 1 and dist.get_backend() == "nccl":
+        try:
+            from eigen_zeth_amd import native as _nat
+            rk = dist.get_rank()
+            msg = torch.zeros(129, dtype=torch.int64, device=dev)
+            if rk == 0:
+                try:
+                    msg[1:] = torch.tensor(list(_nat.comm_unique_id()), dtype=torch.int64)
+                    msg[0] = 1
+                except Exception:
+                    pass
+            multigpu.broadcast(msg, 0)
+            if int(msg[0].item()) == 1:
+                comm = _nat.Comm(prover, rk, world, bytes(int(v) for v in msg[1:].tolist()))
+                tl = torch.empty(((2 * Mloc - 1) * 4,), dtype=torch.int64, device=dev)
+                for it in range(2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    r2 = comm.merkle_commit_sharded(y, M, cols, tl)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                comm.close()
+                res["rccl_direct"] = {"sharded_commit_ms": dt * 1e3, "root_matches_torch_path": [hex(v) for v in r2] == res["root"],
+                                      "note": "zp_merkle_commit_sharded: exchange + hashing in one C-ABI call, wall-clock"}
+            else:
+                res["rccl_direct"] = {"error": "rank 0 could not make an RCCL id"}
+        except Exception as ex:
+            res["rccl_direct"] = {"error": repr(ex)}
     # one column of 2^28 elements split over the ranks (SURVEY 8e alternative): four-step NTT, three transposes
     try:
         flog = 28

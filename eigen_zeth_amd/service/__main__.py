@@ -21,11 +21,11 @@ def main():
     ap.add_argument("--l2-addr", default=None, help="L2 JSON-RPC (ZETH_L2_ADDR) to fetch block inputs from")
     ap.add_argument("--devices", default=None, help="comma-separated GPU ids to spread chunk proofs over (default: --device)")
     ap.add_argument("--metrics-port", type=int, default=None, help="serve Prometheus text metrics on /metrics")
-    ap.add_argument("--final-logn", type=int, default=16, help="log2 rows of the final STARK (BN128-hash mode) behind the Groth16 wrap")
-    ap.add_argument("--final-queries", type=int, default=50, help="queries of the final STARK (blow-up 4: 2 bits each, no grinding)")
+    ap.add_argument("--agg-queries", type=int, default=50, help="queries of the aggregation STARK over the Merkle-verifier AIR (blow-up 4: 2 bits each)")
+    ap.add_argument("--final-queries", type=int, default=50, help="queries of the final STARK (BN128-hash mode, Merkle-verifier AIR over the aggregated proof; blow-up 4, no grinding)")
     a = ap.parse_args()
     server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, logb=a.logb, chunks_per_block=a.chunks_per_block, l2_addr=a.l2_addr, n_queries=a.n_queries, pow_bits=a.pow_bits,
-                                                               final_logn=a.final_logn, final_queries=a.final_queries), a.device,
+                                                               agg_queries=a.agg_queries, final_queries=a.final_queries), a.device,
                          metrics_port=a.metrics_port,
                          devices=[int(x) for x in a.devices.split(',')] if a.devices else None)
     print("prover.v1.ProverService listening on %s:%d  (chunk STARKs: %d queries x blow-up %d + %d grinding bits = %d bits conjectured)"

@@ -259,8 +259,12 @@ def build_witness(shape, proofs, be):
     inputs = np.zeros((nblk, 12), dtype=np.uint64)
     dbit = np.zeros(nblk, dtype=np.uint64)
     idxv = np.zeros(nblk, dtype=np.uint64)
-    # openings: (first block, tree, leaf values, path, index); level-synchronous hashing over all openings at once
-    ops = []
+    # the openings as flat arrays (one row per opening: first block, absorb blocks, depth, index, padded values, path), then
+    # level-synchronous hashing: absorb block j / tree level lv of EVERY opening is one batched permutation call
+    max_w = max(8 * Shape.absorb_blocks(w) if w > 4 else 4 for (_, w, _) in shape.trees)
+    max_d = max(d for (_, _, d) in shape.trees)
+    b0l, al, dl, il, tl, pl, vl, pathl = [], [], [], [], [], [], [], []
+    zero_path = [[0, 0, 0, 0]]
     for per in range(periods):
         b = 0
         while b < pb:
@@ -271,55 +275,57 @@ def build_witness(shape, proofs, be):
             name, w, depth = shape.trees[blk["t"]]
             q = proofs[blk["p"]]["queries"][(per * k + blk["sub"]) % shape.n_queries]
             o = _opening(q, name)
-            vals = [int(v) for v in o["values"]]
-            path = [[int(v) for v in lv] for lv in o["path"]]
+            vals, path = o["values"], o["path"]
             if len(vals) != w or len(path) != depth or any(len(lv) != 4 for lv in path):
                 raise ValueError("opening of %s has the wrong shape" % name)
-            ops.append({"b0": per * pb + b, "t": blk["t"], "p": blk["p"], "vals": vals, "path": path,
-                        "index": int(q["index"]) & ((1 << depth) - 1)})
-            b += Shape.absorb_blocks(w) + depth
-    # leaf hashing: absorb block j of every opening that has one
-    digest = [None] * len(ops)
-    max_a = max(Shape.absorb_blocks(w) for (_, w, _) in shape.trees)
-    cap = [[0, 0, 0, 0] for _ in ops]
-    for j in range(max_a):
-        sel = [i for i, o in enumerate(ops) if j < Shape.absorb_blocks(len(o["vals"]))]
-        if not sel:
-            break
+            b0l.append(per * pb + b)
+            al.append(Shape.absorb_blocks(w))
+            dl.append(depth)
+            il.append(int(q["index"]) & ((1 << depth) - 1))
+            tl.append(blk["t"])
+            pl.append(blk["p"])
+            vl.append(list(vals) + [0] * (max_w - w))
+            pathl.append(list(path) + zero_path * (max_d - depth))
+            b += al[-1] + depth
+    b0, na, nd = np.array(b0l, dtype=np.int64), np.array(al, dtype=np.int64), np.array(dl, dtype=np.int64)
+    index = np.array(il, dtype=np.uint64)
+    try:
+        vals = np.array(vl, dtype=np.uint64)
+        paths = np.array(pathl, dtype=np.uint64)            # [openings][max_d][4]
+    except (OverflowError, ValueError, TypeError):
+        raise ValueError("opening values are not field elements")
+    nops = len(b0)
+    cap = np.zeros((nops, 4), dtype=np.uint64)
+    for j in range(int(na.max()) if nops else 0):
+        sel = np.nonzero(na > j)[0]
         st = np.zeros((len(sel), 12), dtype=np.uint64)
-        for r, i in enumerate(sel):
-            v = ops[i]["vals"][8 * j:8 * j + 8]
-            st[r, :len(v)] = np.array(v, dtype=np.uint64)
-            st[r, 8:] = np.array(cap[i], dtype=np.uint64)
-            inputs[ops[i]["b0"] + j] = st[r]
-        out = be.poseidon_perm_batch(st)
-        for r, i in enumerate(sel):
-            cap[i] = [int(v) for v in out[r, :4]]
-    for i, o in enumerate(ops):
-        a = Shape.absorb_blocks(len(o["vals"]))
-        digest[i] = cap[i] if a else (o["vals"] + [0, 0, 0, 0])[:4]
-    max_d = max(d for (_, _, d) in shape.trees)
+        st[:, :8] = vals[sel, 8 * j:8 * j + 8]
+        st[:, 8:] = cap[sel]
+        inputs[b0[sel] + j] = st
+        cap[sel] = be.poseidon_perm_batch(st)[:, :4]
+    digest = np.where((na > 0)[:, None], cap, vals[:, :4])     # leaves of <= 4 values are not hashed (identity, zero padded)
     for lv in range(max_d):
-        sel = [i for i, o in enumerate(ops) if lv < len(o["path"])]
+        sel = np.nonzero(nd > lv)[0]
+        if len(sel) == 0:
+            break
+        bit = (index[sel] >> np.uint64(lv)) & np.uint64(1)
+        sib, cur = paths[sel, lv], digest[sel]
         st = np.zeros((len(sel), 12), dtype=np.uint64)
-        for r, i in enumerate(sel):
-            o = ops[i]
-            bit = (o["index"] >> lv) & 1
-            l, rgt = (o["path"][lv], digest[i]) if bit else (digest[i], o["path"][lv])
-            st[r, :4], st[r, 4:8] = np.array(l, dtype=np.uint64), np.array(rgt, dtype=np.uint64)
-            b = o["b0"] + Shape.absorb_blocks(len(o["vals"])) + lv
-            inputs[b] = st[r]
-            dbit[b] = bit
-            idxv[b] = o["index"] & ((2 << lv) - 1)
-        out = be.poseidon_perm_batch(st)
-        for r, i in enumerate(sel):
-            digest[i] = [int(v) for v in out[r, :4]]
+        st[:, :4] = np.where(bit[:, None] == 1, sib, cur)
+        st[:, 4:8] = np.where(bit[:, None] == 1, cur, sib)
+        blk = b0[sel] + na[sel] + lv
+        inputs[blk] = st
+        dbit[blk] = bit
+        idxv[blk] = index[sel] & np.uint64((2 << lv) - 1)
+        digest[sel] = be.poseidon_perm_batch(st)[:, :4]
     pubs = expected_publics(shape, proofs)
-    for i, o in enumerate(ops):
-        want = pubs[shape.pub_root(o["p"], o["t"], 0):shape.pub_root(o["p"], o["t"], 0) + 4]
-        if digest[i] != want:
-            raise ValueError("an opening of the %s tree of inner proof %d does not hash to its root: no accepting witness"
-                             % (shape.trees[o["t"]][0], o["p"]))
+    T = len(shape.trees)
+    want = np.array(pubs[:shape.n_proofs * T * 4], dtype=np.uint64).reshape(shape.n_proofs, T, 4)
+    bad = np.nonzero((digest != want[np.array(pl, dtype=np.int64), np.array(tl, dtype=np.int64)]).any(axis=1))[0]
+    if len(bad):
+        o = int(bad[0])
+        raise ValueError("an opening of the %s tree of inner proof %d does not hash to its root: no accepting witness"
+                         % (shape.trees[tl[o]][0], pl[o]))
     states, cubes = be.poseidon_trace(inputs)
     trace = np.zeros((WIDTH, N), dtype=np.uint64)
     trace[S0:S0 + 12], trace[U0:U0 + 12] = states, cubes
