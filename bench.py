@@ -276,9 +276,10 @@ def main():
         # columns).  The roofline figure is TIME-WEIGHTED over all of them: algorithmic bytes of all launches / summed launch
         # time -- no instantiation is left out (round 2 reported the two cheaper ones only).  pass_timings() keys: radix log,
         # negative = the transposing first pass.
-        by_kind = {}
-        for rl, ms in passes:
+        by_kind, by_pass = {}, {}
+        for j, (rl, ms) in enumerate(passes):
             by_kind.setdefault(rl, []).append(ms)
+            by_pass.setdefault(j % npass, []).append(ms)       # launches are recorded in order: pass 0 .. npass-1 of every chunk of columns
         chunk_cols = min(cols, max(1, (1 << int(os.environ.get("ZP_NTT_CHUNK_LOG", "27"))) >> logn))
         # algorithmic bytes of one launch: SURVEY 8d gives 16*N bytes per column transform (ideal single
         # pass); a launch does one of the `npass` passes over chunk_cols columns -> 16*N*chunk/npass
@@ -289,15 +290,13 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else float("nan")
         pass_rows = []
         for i, ps in enumerate(plan["passes"]):
-            key = -ps["radix_log"] if i == 0 else ps["radix_log"]
             first, last = i == 0, i == len(plan["passes"]) - 1
             mode = 1 if first else (0 if last else 1)          # forward transform: table passes in the middle, plain last pass
             logt = {1: 0, 2: 1, 4: 2, 8: 3, 16: 4, 32: 5}[ps["tile"]]
             name = "ntt_pass2_kernel<%d, %d, %d, %d, %s, false, %d, false>" % (ps["rounds"][0], ps["rounds"][1], ps["rounds"][2], logt,
                                                                                  "true" if first else "false", mode)
-            ms_l = by_kind.get(key, [])
-            if first and not ms_l:
-                ms_l = by_kind.get(ps["radix_log"], [])
+            ms_l = by_pass.get(i, [])
+            assert all(abs(rl) == ps["radix_log"] for rl, _ in passes[i::npass]), "pass timings out of step with the plan"
             a_ms = sum(ms_l) / len(ms_l) if ms_l else None
             pass_rows.append({"kernel": name, "role": "transposing first pass (per-lane twiddle chain)" if first else
                               ("plain last pass" if last else "pass with a per-tile twiddle table"),
