@@ -605,7 +605,38 @@ def batch_proof_probe(logn, air_name="chunk64"):
         out["batch"] = engine_batch_probe(16, logn, air_name)
     except Exception as e:
         out["batch"] = {"error": repr(e)}
+    try:   # ... and REQUEST TO RESPONSE over the wire: the gRPC service + the mirror of eigen-zeth's client state machine
+        out["grpc_request_to_response"] = grpc_probe(logn, air_name)
+    except Exception as e:
+        out["grpc_request_to_response"] = {"error": repr(e)}
     return out
+
+
+def grpc_probe(logn, air_name, chunks_per_block=8, blocks=3):
+    """BASELINE metric (i) as the reference's client sees it: ProverChannel.execute(block) = GenBatchChunks -> GenChunkProof ->
+    GenAggregatedProof -> GenFinalProof over one bidi stream (src/prover/provider.rs:243-544, without its 1-s sleeps) against the
+    service on this GPU; one block of `chunks_per_block` chunks; the last of `blocks` blocks is reported (the first builds the CRS
+    and warms the pools).  The synthetic witness generator (host code) is inside, as it is in the service."""
+    import tempfile
+    from eigen_zeth_amd.service.client import ProverChannel
+    from eigen_zeth_amd.service.engine import EngineConfig
+    from eigen_zeth_amd.service.server import serve
+    tmp = tempfile.mkdtemp()
+    cfg = EngineConfig(air=air_name, logn=logn, chunks_per_block=chunks_per_block, groth16_logm=8, crs_dir=os.path.join(tmp, "crs"), witness_threads=16)
+    server, port = serve(0, "127.0.0.1", os.path.join(tmp, "state"), cfg, 0)
+    try:
+        ch = ProverChannel("127.0.0.1:%d" % port)
+        walls = []
+        for b in range(1, blocks + 1):
+            t0 = time.perf_counter()
+            res = ch.execute(b)
+            walls.append(time.perf_counter() - t0)
+        ch.close()
+        return {"wall_s": walls[-1], "all_blocks_wall_s": [round(w, 3) for w in walls], "chunks_per_block": chunks_per_block,
+                "chunk_rows_log2": logn, "proof_bytes": len(res["proof"]),
+                "note": "one block = %d chunk STARKs + aggregation STARK + final STARK (BN128) + Groth16 wrap, request to response over gRPC" % chunks_per_block}
+    finally:
+        server.stop(0)
 
 
 def engine_batch_probe(K, logn, air_name, device=0, tag=""):
