@@ -32,7 +32,8 @@ from . import statement
 
 class EngineConfig:
     """Default chunk-STARK security: 80 queries x blow-up 2 (1 bit each) + 20 bits of proof-of-work grinding = 100 bits
-    conjectured (stark/prover.py StarkParams.security_bits); every value is bound into the proof's transcript."""
+    CONJECTURED (ethSTARK-style, stark/prover.py StarkParams.security_bits; the provable FRI bound at these parameters is about
+    half of that); every value is bound into the proof's transcript."""
 
     def __init__(self, air="chunk64", logn=12, logb=1, chunks_per_block=1, n_queries=80, fri_logf=3, fri_final_log=5,
                  groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
