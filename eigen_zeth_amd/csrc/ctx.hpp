@@ -69,6 +69,7 @@ struct zp_ctx {
     int tune_ntt_maxl = 0;        // 0 = 9: largest log2 radix of one NTT pass (10: 1024-thread workgroups, two-pass plans up to 2^20)
     int tune_merkle_coop_log = 0; // 0 = 15: tree levels with <= 2^15 nodes go to the 12-lanes-per-node subtree kernel
     int tune_ntt_chunk_log = 0;   // 0 = 28: columns per launch such that a ping-pong scratch buffer is <= 2 GiB
+    int tune_p254_bulk_log = 0;   // 0 = 14: Poseidon-BN254 t = 17 launches of >= 2^14 permutations use the lane-per-permutation kernel (31 = never)
     int tune_msm_c = 0;           // 0 = window width chosen from n
     int tune_msm_chunk_log = 0;   // 0 = default (2^24 points per Pippenger run)
     // zp_stark_prove: device buffers kept between proofs (chunk after chunk has the same shapes; hipMalloc / hipFree of ~20 buffers

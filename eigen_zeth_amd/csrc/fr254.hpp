@@ -150,6 +150,42 @@ GL_HD fr fr_mul3(const fr &a0, const fr &b0, const fr &a1, const fr &b1, const f
     t[8] = (u32)acc;
     return fr_norm_sub(t);
 }
+// sum_{n < N} x[n] * c[n] / R mod r with ONE Montgomery reduction, N <= 6: the N products share the column accumulators
+// (at most 9 N + 9 terms of < 2^58 per column: 63 x 2^58 < 2^64 at N = 6).  c: N x 9 limbs, a wave-uniform table (scalar loads).
+// The sum is < 6 r^2 and R > 169 r, so the reduced value is < 2 r and fr_norm_sub makes it canonical.
+template <int N>
+GL_HD fr fr_dotc(const fr *x, const u32 *c) {
+    static_assert(N >= 1 && N <= 6, "at most six products per reduction");
+    u32 m[9], t[9];
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int n = 0; n < N; n++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) acc += (u64)x[n].l[i] * c[n * 9 + k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (u64)m[i] * fr_p(k - i);
+        m[k] = ((u32)acc * FR_INV29) & FR_MASK;
+        acc += (u64)m[k] * fr_p(0);
+        acc >>= FR_B;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int n = 0; n < N; n++) {
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) acc += (u64)x[n].l[i] * c[n * 9 + k - i];
+        }
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (u64)m[i] * fr_p(k - i);
+        t[k - 9] = (u32)acc & FR_MASK;
+        acc >>= FR_B;
+    }
+    t[8] = (u32)acc;
+    return fr_norm_sub(t);
+}
 GL_HD fr fr_to_mont(const fr &a) { return fr_mul(a, fr_r2()); }
 GL_HD fr fr_from_mont(const fr &a) {
     fr one = fr_zero();

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "ctx.hpp"
@@ -153,6 +154,155 @@ __device__ __forceinline__ fr perm_coop(fr s, int q, int e, bool on, u32 (*sh)[T
     return s;
 }
 
+// ---- bulk form, t = 17: ONE LANE PER PERMUTATION (launches of >= 2^14 permutations: the Merkle commitments of the final STARK).
+// The cooperative form above gives a wave three permutations (51 of 64 lanes) and makes the whole wave walk the three dependent
+// products of the ONE S-box of a partial round: 5 product steps per lane and round for 36 field products per permutation.  Here every
+// lane does exactly the products of its own permutation.  The 17-element state lives in LDS ([element][limb][lane]: conflict-free,
+// lane-private, no barriers) so that every loop over the state is ROLLED (dynamic LDS addresses; a loop over registers would have to
+// be unrolled for static indices: with the state in 153 VGPRs the kernel was 111 k multiply-adds, took 15 minutes to compile and
+// spilled).  Rows of a dense matrix and the row of a sparse round are dot products with six terms per Montgomery reduction
+// (fr_dotc), tables are wave-uniform (scalar loads).  The 17 rows of a dense matrix need all 17 inputs, so their results wait in
+// registers (a switch on the wave-uniform row index gives the rolled loop static register names) and go back to LDS together.
+// Same field values as the cooperative form, hence the same canonical words (both are checked against oracle/bn254_hash.c).
+#define P254_BULK_LDS (17 * 9 * 64)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {      // expanded at compile time: static register indices
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ void lds_put(u32 *st, int e, int lane, const fr &x) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) st[(e * 9 + i) * 64 + lane] = x.l[i];
+}
+__device__ __forceinline__ fr lds_get(const u32 *st, int e, int lane) {
+    fr x;
+#pragma unroll
+    for (int i = 0; i < 9; i++) x.l[i] = st[(e * 9 + i) * 64 + lane];
+    return x;
+}
+// sum_j row[j] * state[j] over the LDS-resident state, 6 + 6 + 5 terms; with HAS_FIRST `first` stands in for element 0 (the S-box
+// output of a partial round, not written back yet)
+template <bool HAS_FIRST>
+__device__ __forceinline__ fr dot17_lds(const u32 *st, int lane, const u32 *__restrict__ row, const fr &first) {
+    fr acc;
+#pragma unroll 1
+    for (int g = 0; g < 2; g++) {
+        fr x[6];
+#pragma unroll
+        for (int jj = 0; jj < 6; jj++) x[jj] = lds_get(st, g * 6 + jj, lane);
+        if (HAS_FIRST && g == 0) x[0] = first;
+        const fr d = fr_dotc<6>(x, row + g * 6 * 9);
+        acc = g == 0 ? d : fr_add(acc, d);
+    }
+    fr x[5];
+#pragma unroll
+    for (int jj = 0; jj < 5; jj++) x[jj] = lds_get(st, 12 + jj, lane);
+    return fr_add(acc, fr_dotc<5>(x, row + 12 * 9));
+}
+__device__ __forceinline__ void bulk_perm17(u32 *st, int lane, const P254Dev &d) {
+    const int rp = d.rp;
+    const fr zero = fr_zero();
+#pragma unroll 1
+    for (int r = 0; r < 8 + rp; r++) {
+        if (r < 4 || r >= 4 + rp) {         // full round: ARK -> x^5 -> dense matrix (the sparse form moves constants / matrices around them)
+            const u32 *c = r == 4 + rp ? d.rcb : d.rc + (size_t)r * 17 * 9;
+            const u32 *m = r == 3 ? d.pre : d.mds;
+#pragma unroll 1
+            for (int e = 0; e < 17; e++) lds_put(st, e, lane, sbox5(fr_add(lds_get(st, e, lane), fr_load(c + e * 9))));
+            fr o[17];
+#pragma unroll 1
+            for (int e = 0; e < 17; e++) {
+                const fr v = dot17_lds<false>(st, lane, m + (size_t)e * 17 * 9, zero);
+                switch (e) {                // wave-uniform: static register names for the rolled loop's results
+#define P254_CASE(K) case K: o[K] = v; break;
+                    P254_CASE(0) P254_CASE(1) P254_CASE(2) P254_CASE(3) P254_CASE(4) P254_CASE(5) P254_CASE(6) P254_CASE(7) P254_CASE(8)
+                    P254_CASE(9) P254_CASE(10) P254_CASE(11) P254_CASE(12) P254_CASE(13) P254_CASE(14) P254_CASE(15)
+                    default: o[16] = v; break;
+#undef P254_CASE
+                }
+            }
+            static_for<0, 17>([&](auto E) { lds_put(st, decltype(E)::value, lane, o[decltype(E)::value]); });
+        } else {                            // partial round j: s_0 <- (s_0 + a_j)^5; s_0' = m00 s_0 + sum_k v^_k s_k; s_k' = w_k s_0 + s_k
+            const u32 *sp = d.sp + (size_t)(r - 4) * 33 * 9;
+            const fr sg = sbox5(fr_add(lds_get(st, 0, lane), fr_load(d.a + (size_t)(r - 4) * 9)));
+            const fr n0 = dot17_lds<true>(st, lane, sp, sg);
+#pragma unroll 1
+            for (int k = 1; k < 17; k++) lds_put(st, k, lane, fr_add(fr_dotc<1>(&sg, sp + (16 + k) * 9), lds_get(st, k, lane)));
+            lds_put(st, 0, lane, n0);
+        }
+    }
+}
+
+// mode 0: states u64[count][17][4] permuted in place;  mode 1: leaves of the 16-ary tree (lane = row, column reads are coalesced
+// 512-byte runs);  mode 2: one tree level (16 children per node)
+template <int MODE>
+__global__ void __launch_bounds__(64) p254_bulk_kernel(const u64 *__restrict__ in, size_t n_in, int W, u64 *__restrict__ out, size_t count, P254Dev d) {
+    __shared__ u32 st[P254_BULK_LDS];
+    const int lane = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    const bool on = i < count;
+    const size_t ii = on ? i : 0;
+    if constexpr (MODE == 0) {
+#pragma unroll 1
+        for (int e = 0; e < 17; e++) {
+            u64 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = out[(ii * 17 + e) * 4 + k];
+            lds_put(st, e, lane, fr_to_mont(fr_from_u64(w)));
+        }
+        bulk_perm17(st, lane, d);
+#pragma unroll 1
+        for (int e = 0; e < 17; e++) {
+            u64 w[4];
+            fr_to_u64(fr_from_mont(lds_get(st, e, lane)), w);
+            if (on) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) out[(i * 17 + e) * 4 + k] = w[k];
+            }
+        }
+    } else {
+        lds_put(st, 0, lane, fr_zero());
+        if constexpr (MODE == 1) {          // in = cols u64[W][M], M = count = n_in; sponge over blocks of 16 packed elements
+            const int ne = (W + 2) / 3;
+#pragma unroll 1
+            for (int off = 0; off < ne || off == 0; off += 16) {
+#pragma unroll 1
+                for (int e = 1; e < 17; e++) {
+                    const int k = off + e - 1;
+                    u64 w[4] = {0, 0, 0, 0};
+                    if (k < ne) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++)
+                            if (3 * k + c < W) w[c] = in[(size_t)(3 * k + c) * n_in + ii];
+                    }
+                    lds_put(st, e, lane, fr_to_mont(fr_from_u64(w)));
+                }
+                bulk_perm17(st, lane, d);   // the digest (element 0) stays as the capacity of the next block
+            }
+        } else {                            // in = previous level u64[n_in][4]
+#pragma unroll 1
+            for (int e = 1; e < 17; e++) {
+                const size_t c = ii * 16 + (e - 1);
+                u64 w[4] = {0, 0, 0, 0};
+                if (c < n_in) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) w[k] = in[c * 4 + k];
+                }
+                lds_put(st, e, lane, fr_to_mont(fr_from_u64(w)));
+            }
+            bulk_perm17(st, lane, d);
+        }
+        u64 w[4];
+        fr_to_u64(fr_from_mont(lds_get(st, 0, lane)), w);
+        if (on) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) out[i * 4 + k] = w[k];
+        }
+    }
+}
+
 // states: u64[count][T][4] standard form, permuted in place
 template <int T>
 __global__ void __launch_bounds__(64) poseidon254_perm_kernel(u64 *states, size_t count, P254Dev d) {
@@ -257,6 +407,12 @@ int32_t table_for(zp_ctx *ctx, int t, P254Table **out) {
     ZP_ARG(ctx, tb->d_rc != nullptr, "Poseidon-BN254 tables not installed (zp_set_poseidon_bn254)");
     *out = tb;
     return ZP_OK;
+}
+// permutations from which the lane-per-permutation kernel takes over (zp_set_tuning "p254_bulk_log"; 0 = 2^14; 31 = never): one wave
+// on every SIMD of the chip takes 2^16 permutations, below ~2^14 the cooperative form's shorter dependency chains win
+int bulk_threshold(zp_ctx *ctx) {
+    const int lg = ctx->tune_p254_bulk_log > 0 ? ctx->tune_p254_bulk_log : 14;
+    return lg >= 31 ? 0x7FFFFFFF : (1 << lg);
 }
 P254Dev dev_of(const P254Table *tb) { return P254Dev{tb->d_rc, tb->d_mds, tb->d_pre, tb->d_a, tb->d_sp, tb->d_rcb, tb->rp}; }
 
@@ -420,6 +576,9 @@ int32_t zp_poseidon_bn254_perm(zp_ctx *ctx, uint64_t *d_states, size_t count, in
     if (t == 3)
         hipLaunchKernelGGL(poseidon254_perm_kernel<3>, dim3((unsigned)((count + 20) / 21)), dim3(64), 0, ctx->stream, (u64 *)d_states, count,
                            dev_of(tb));
+    else if (count >= (size_t)bulk_threshold(ctx))     // one lane per permutation once there are enough of them to fill the chip
+        hipLaunchKernelGGL(p254_bulk_kernel<0>, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, (const u64 *)nullptr, (size_t)0, 0,
+                           (u64 *)d_states, count, dev_of(tb));
     else
         hipLaunchKernelGGL(poseidon254_perm_kernel<17>, dim3((unsigned)((count + 2) / 3)), dim3(64), 0, ctx->stream, (u64 *)d_states, count,
                            dev_of(tb));
@@ -469,14 +628,23 @@ int32_t zp_merkle16_commit_bn254(zp_ctx *ctx, const uint64_t *d_cols, size_t M, 
     P254Table *tb;
     ZP_TRY(table_for(ctx, 17, &tb));
     ZP_ARG(ctx, d_cols && d_tree && M >= 1 && W >= 1, "bad arguments");
-    hipLaunchKernelGGL(merkle16_leaves_kernel, dim3((unsigned)((M + 2) / 3)), dim3(64), 0, ctx->stream, (const u64 *)d_cols, M, (int)W,
-                       (u64 *)d_tree, dev_of(tb));
+    const size_t bulk = (size_t)bulk_threshold(ctx);
+    if (M >= bulk)
+        hipLaunchKernelGGL(p254_bulk_kernel<1>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, ctx->stream, (const u64 *)d_cols, M, (int)W,
+                           (u64 *)d_tree, M, dev_of(tb));
+    else
+        hipLaunchKernelGGL(merkle16_leaves_kernel, dim3((unsigned)((M + 2) / 3)), dim3(64), 0, ctx->stream, (const u64 *)d_cols, M, (int)W,
+                           (u64 *)d_tree, dev_of(tb));
     ZP_HIP(ctx, hipGetLastError());
     size_t n = M, off = 0;
     while (n > 1) {
         const size_t nn = (n + 15) / 16;
-        hipLaunchKernelGGL(merkle16_level_kernel, dim3((unsigned)((nn + 2) / 3)), dim3(64), 0, ctx->stream, (const u64 *)d_tree + off * 4, n,
-                           (u64 *)d_tree + (off + n) * 4, nn, dev_of(tb));
+        if (nn >= bulk)
+            hipLaunchKernelGGL(p254_bulk_kernel<2>, dim3((unsigned)((nn + 63) / 64)), dim3(64), 0, ctx->stream, (const u64 *)d_tree + off * 4, n, 0,
+                               (u64 *)d_tree + (off + n) * 4, nn, dev_of(tb));
+        else
+            hipLaunchKernelGGL(merkle16_level_kernel, dim3((unsigned)((nn + 2) / 3)), dim3(64), 0, ctx->stream, (const u64 *)d_tree + off * 4, n,
+                               (u64 *)d_tree + (off + n) * 4, nn, dev_of(tb));
         ZP_HIP(ctx, hipGetLastError());
         off += n;
         n = nn;

@@ -80,3 +80,63 @@ def test_merkle16_batch_openings_equal_single_openings(prover):
         idx = sorted(set([0, M - 1, M // 2] + [int(v) for v in rng.integers(0, M, size=5)]))
         batch = prover.merkle16_open_batch_bn254(tree, M, idx)
         assert batch == [prover.merkle16_open_bn254(tree, M, i) for i in idx]
+
+
+def _commit16(p, cols):
+    W, M = cols.shape
+    d_cols = p.upload(cols)
+    nodes = p.merkle16_nodes(M)
+    d_tree = p.alloc(nodes * 4)
+    p.merkle16_commit_bn254(d_cols, M, W, d_tree)
+    out = p.download(d_tree, (nodes, 4))
+    d_cols.free()
+    d_tree.free()
+    return out
+
+
+def test_lane_per_permutation_kernel_equals_the_cooperative_one_and_the_oracle(p254):
+    """launches of >= 2^14 permutations (the commitments of the final STARK) take p254_bulk_kernel: one lane per permutation,
+    state in LDS, dot products of six terms per Montgomery reduction.  It must write the words of the cooperative kernel
+    (p254_bulk_log = 31 switches it off) and of the CPU checker (oracle/bn254_hash.c, textbook schedule)."""
+    rc, mds, rp = PC.bn254_poseidon_params(17)
+    O.p254_set(17, rp, rc, mds)
+    count = (1 << 14) + 37
+    g = np.random.default_rng(254)
+    st = g.integers(0, 1 << 62, size=(count, 17, 4), dtype=np.uint64)
+    st[:, :, 3] >>= 2                                   # < 2^252 < r
+    st[0, :3] = 0
+    st[0, 1, 0] = 1
+    d = p254.upload(st.reshape(-1))
+    p254._chk(p254.lib.zp_poseidon_bn254_perm(p254.ctx, d.ptr, count, 17))
+    bulk = p254.download(d, st.shape)
+    try:
+        p254.set_tuning("p254_bulk_log", 31)
+        p254.h2d(d, st.reshape(-1))
+        p254._chk(p254.lib.zp_poseidon_bn254_perm(p254.ctx, d.ptr, count, 17))
+        coop = p254.download(d, st.shape)
+    finally:
+        p254.set_tuning("p254_bulk_log", 0)
+    assert (bulk == coop).all()
+    sample = [0, 1, 63, 64, 8191, count - 1]
+    ints = lambda a: [sum(int(a[e, k]) << (64 * k) for k in range(4)) for e in range(17)]
+    want = O.p254_perm([ints(st[i]) for i in sample], 17)
+    assert [ints(bulk[i]) for i in sample] == want
+
+
+@pytest.mark.parametrize("M,W", [(1 << 14, 26), (1 << 14, 9), ((1 << 14) + 48, 50), (1 << 18, 4)])
+def test_merkle16_bulk_kernels_match_cooperative_and_oracle(p254, M, W):
+    """leaves (one and two sponge blocks per leaf, a leaf count that is no multiple of 64) and a tree level of 2^14 nodes
+    through the lane-per-permutation kernel: the whole tree equals the cooperative kernels' tree; up to 2^14 leaves it also
+    equals the CPU checker's tree node by node"""
+    rc, mds, rp = PC.bn254_poseidon_params(17)
+    O.p254_set(17, rp, rc, mds)
+    cols = O.random_field((W, M), 7000 + W)
+    bulk = _commit16(p254, cols)
+    try:
+        p254.set_tuning("p254_bulk_log", 31)
+        coop = _commit16(p254, cols)
+    finally:
+        p254.set_tuning("p254_bulk_log", 0)
+    assert (bulk == coop).all()
+    if M <= (1 << 14) + 64:
+        assert (bulk == O.merkle16_tree(cols)).all()
