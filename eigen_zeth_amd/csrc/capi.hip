@@ -51,7 +51,7 @@ void zp_destroy(zp_ctx *ctx) {
         if (c.d_lo) (void)hipFree(c.d_lo);
         if (c.d_hi) (void)hipFree(c.d_hi);
     }
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 6; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     for (auto &kv : ctx->prove_pool) (void)hipFree(kv.second);
     for (auto &kv : ctx->prove_fixed) (void)hipFree(kv.second);

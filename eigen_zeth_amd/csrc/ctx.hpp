@@ -55,8 +55,8 @@ struct zp_ctx {
     std::map<int, NttPlan> plans;  // key = logn*2 + inverse
     std::vector<CosetTable> cosets;
     // scratch (two ping-pong buffers, grown on demand)
-    u64 *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_elems[4] = {0, 0, 0, 0};
+    u64 *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0, 1: NTT ping-pong; 2: LDE coefficients; 3: small uploads; 4: fixed-column periods
+    size_t scratch_elems[6] = {0, 0, 0, 0, 0, 0};
     // pinned host staging for small transfers (pageable async copies lock/unlock host pages on every call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;

@@ -327,6 +327,48 @@ __global__ void __launch_bounds__(64) poseidon254_perm_kernel(u64 *states, size_
     }
 }
 
+// The width-17 transcript sponge as ONE launch (17 lanes cooperate on the one state): buf = [17 state elements][nblocks x 16 block
+// elements][(1 + extra) x 16 rate elements out], 4 words each, standard form.  For every block the rate (elements 1..16) is
+// overwritten with the block and the state permuted (no block: one permutation), then `extra` more permutations; the rate after the
+// absorption and after every extra permutation is written out.  A transcript step of k permutations costs one host round trip
+// instead of k launches with a copy between them.
+__global__ void __launch_bounds__(64) poseidon254_sponge_kernel(u64 *buf, int nblocks, int extra, P254Dev d) {
+    constexpr int T = 17;
+    __shared__ u32 sh[3][T][9];
+    const int e = threadIdx.x;
+    const bool on = e < T;
+    u64 *rates = buf + (size_t)(17 + (size_t)nblocks * 16) * 4;
+    fr s = fr_zero();
+    if (on) {
+        u64 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = buf[(size_t)e * 4 + k];
+        s = fr_to_mont(fr_from_u64(w));
+    }
+    const int absorb = nblocks > 0 ? nblocks : 1;
+    for (int b = 0; b < absorb + extra; b++) {
+        if (b < nblocks && on && e >= 1) {
+            u64 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = buf[(size_t)(17 + (size_t)b * 16 + (e - 1)) * 4 + k];
+            s = fr_to_mont(fr_from_u64(w));
+        }
+        s = perm_coop<T>(s, 0, on ? e : 0, on, sh, d);
+        if (b >= absorb - 1 && on && e >= 1) {
+            u64 w[4];
+            fr_to_u64(fr_from_mont(s), w);
+#pragma unroll
+            for (int k = 0; k < 4; k++) rates[((size_t)(b - (absorb - 1)) * 16 + (e - 1)) * 4 + k] = w[k];
+        }
+    }
+    if (on) {
+        u64 w[4];
+        fr_to_u64(fr_from_mont(s), w);
+#pragma unroll
+        for (int k = 0; k < 4; k++) buf[(size_t)e * 4 + k] = w[k];
+    }
+}
+
 // 16-ary Merkle tree, t = 17: state = [capacity, 16 inputs]; digest = state[0] after the permutation.
 // leaves: row i of the Goldilocks matrix cols[W][M], three values per field element (a + b 2^64 + c 2^128), sponge over
 // blocks of 16 elements with the digest as the next capacity.  nodes: 16 child digests (missing children = 0).
@@ -599,19 +641,17 @@ int32_t zp_poseidon_bn254_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t 
     ZP_ARG(ctx, nblocks <= 65536 && extra <= 65536, "too many blocks");
     for (size_t i = 0; i < 17; i++) ZP_ARG(ctx, fr_is_canonical_u64((const u64 *)h_state + 4 * i), "state element not reduced mod r");
     for (size_t i = 0; i < nblocks * 16; i++) ZP_ARG(ctx, fr_is_canonical_u64((const u64 *)h_blocks + 4 * i), "block element not reduced mod r");
+    // one upload (state | blocks), one launch walking the blocks on the device, one download (state, rates)
+    const size_t nrate = 1 + extra, words = (17 + nblocks * 16 + nrate * 16) * 4;
+    std::vector<u64> h(words, 0);
+    memcpy(h.data(), h_state, 17 * 32);
+    if (nblocks) memcpy(h.data() + 17 * 4, h_blocks, nblocks * 16 * 32);
     u64 *d = nullptr;
-    ZP_TRY(zpi_scratch(ctx, 3, 17 * 4, &d));
-    ZP_TRY(zpi_h2d_small(ctx, d, h_state, 17 * 32));
-    const size_t steps = (nblocks ? nblocks : 1) + extra;
-    for (size_t b = 0; b < steps; b++) {
-        if (b < nblocks) ZP_TRY(zpi_h2d_small(ctx, d + 4, h_blocks + b * 64, 16 * 32));
-        hipLaunchKernelGGL(poseidon254_perm_kernel<17>, dim3(1), dim3(64), 0, ctx->stream, d, (size_t)1, dev_of(tb));
-        ZP_HIP(ctx, hipGetLastError());
-        if (b + 1 >= (nblocks ? nblocks : 1)) {      // the rate after the absorption and after every extra permutation
-            const size_t k = b + 1 - (nblocks ? nblocks : 1);
-            ZP_TRY(zpi_d2h_small(ctx, h_rates + k * 64, d + 4, 16 * 32));
-        }
-    }
+    ZP_TRY(zpi_scratch(ctx, 3, words, &d));
+    ZP_TRY(zpi_h2d_small(ctx, d, h.data(), (17 + nblocks * 16) * 32));
+    hipLaunchKernelGGL(poseidon254_sponge_kernel, dim3(1), dim3(64), 0, ctx->stream, d, (int)nblocks, (int)extra, dev_of(tb));
+    ZP_HIP(ctx, hipGetLastError());
+    ZP_TRY(zpi_d2h_small(ctx, h_rates, d + (17 + nblocks * 16) * 4, nrate * 16 * 32));
     return zpi_d2h_small(ctx, h_state, d, 17 * 32);
 }
 

@@ -605,6 +605,11 @@ __global__ void __launch_bounds__(256) quotient_program_kernel(QProgArgs a) {
 
 }  // namespace
 
+__global__ void __launch_bounds__(256) scatter_pairs_kernel(u64 *__restrict__ dst, const u64 *__restrict__ pairs, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[pairs[2 * i]] = pairs[2 * i + 1];
+}
+
 bool zpi_program_fixed_table(const uint64_t *h_program, size_t program_words, std::vector<ZpFixedCol> *cols) {
     if (program_words < 12) return false;
     const u64 n_fixed = h_program[3], n_pub = h_program[4], n_const = h_program[6], n_instr = h_program[7], n_s2 = h_program[10];
@@ -664,9 +669,11 @@ extern "C" int32_t zp_fixed_columns(zp_ctx *ctx, const uint64_t *h_program, size
     const size_t N = (size_t)1 << logn, M = N << logb;
     size_t in_words = 2 * N;
     for (const ZpFixedCol &fc : fxc) in_words += (size_t)1 << fc.lp;
-    std::vector<u64> h(in_words, 0);
-    h[0] = 1;                      // L_first
-    h[N + N - 1] = 1;              // L_last
+    // the columns are sparse (a non-periodic public-input column of a verifier AIR has N rows and ~10^3 entries): the periods are
+    // built ON THE DEVICE -- zero fill, then one scatter of (index, value) pairs -- instead of N-word host vectors and their upload
+    std::vector<u64> pairs;
+    pairs.push_back(0); pairs.push_back(1);                      // L_first[0] = 1
+    pairs.push_back(N + N - 1); pairs.push_back(1);              // L_last[N - 1] = 1
     {
         size_t at = 2 * N;
         for (const ZpFixedCol &fc : fxc) {
@@ -677,14 +684,22 @@ extern "C" int32_t zp_fixed_columns(zp_ctx *ctx, const uint64_t *h_program, size
                     val = h_pub[v];
                     ZP_ARG(ctx, val < GL_P, "public input not canonical");
                 }
-                h[at + (a & ~(1ULL << 63))] = val;
+                pairs.push_back(at + (a & ~(1ULL << 63)));
+                pairs.push_back(val);
             }
             at += (size_t)1 << fc.lp;
         }
     }
-    void *din = nullptr;
-    ZP_TRY(zp_dev_alloc(ctx, in_words * 8, &din));
-    int32_t rc = zp_h2d(ctx, din, h.data(), in_words * 8);
+    u64 *din = nullptr;
+    ZP_TRY(zpi_scratch(ctx, 4, in_words + pairs.size(), &din));
+    u64 *dpairs = din + in_words;
+    int32_t rc = zp_dev_zero(ctx, din, in_words * 8);
+    if (rc == ZP_OK) rc = zp_h2d(ctx, dpairs, pairs.data(), pairs.size() * 8);
+    if (rc == ZP_OK) {
+        const size_t np = pairs.size() / 2;
+        hipLaunchKernelGGL(scatter_pairs_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, din, (const u64 *)dpairs, np);
+        if (hipGetLastError() != hipSuccess) rc = ZP_ERR_HIP;
+    }
     if (rc == ZP_OK) rc = zpi_lde(ctx, (const u64 *)din, (u64 *)d_out, nullptr, logn, logb, 2, shift);
     size_t in_at = 2 * N, out_at = 2 * M;
     for (size_t k = 0; rc == ZP_OK && k < fxc.size();) {      // consecutive columns of one period go through one LDE call
@@ -698,8 +713,6 @@ extern "C" int32_t zp_fixed_columns(zp_ctx *ctx, const uint64_t *h_program, size
         out_at += (j - k) << (lp + logb);
         k = j;
     }
-    if (rc == ZP_OK) rc = zp_sync(ctx);
-    (void)zp_dev_free(ctx, din);
     return rc;
 }
 
