@@ -87,6 +87,25 @@ class HipBackend:
         d_out.free()
         return out[:12], out[12:]
 
+    def verifier_trace_device(self, inputs, dbit, idxv):
+        """the 26-column trace of the Merkle-verifier AIR (stark/verifier_air.py) assembled IN HBM: zp_poseidon_trace writes the 24
+        state / cube columns of every permutation block, the direction-bit and index columns (one value per block, repeated over
+        its 32 rows) are the only host data.  Returns a device buffer shaped [26][32 * blocks] that commit_trace / prove_native
+        take as they take an uploaded witness (a 2^20-row trace is 218 MB: it never crosses PCIe)."""
+        a = np.ascontiguousarray(np.asarray(inputs, dtype=np.uint64))
+        B = a.shape[0]
+        N = 32 * B
+        d_in = self.p.upload(a)
+        d_tr = self.p.alloc(26 * N)
+        self.p.poseidon_trace(d_in, B, d_tr, d_tr.offset(12 * N), N)
+        tail = np.empty((2, N), dtype=np.uint64)
+        tail[0] = np.repeat(np.asarray(dbit, dtype=np.uint64), 32)
+        tail[1] = np.repeat(np.asarray(idxv, dtype=np.uint64), 32)
+        self.p.h2d(d_tr.offset(24 * N), tail)
+        d_in.free()
+        d_tr.shape = (26, N)
+        return d_tr
+
     def prove_native(self, air, trace, pubs, params):
         """the whole chunk STARK through zp_stark_prove (one C-ABI call, orchestration in the library's host C++): proof TEXT,
         byte-identical to proof_to_json(prove(...)) over this backend.  trace: host array or a device buffer from prefetch_trace."""

@@ -245,7 +245,8 @@ def expected_publics(shape, proofs):
 
 
 def build_witness(shape, proofs, be):
-    """(trace u64[26][N] host array, publics) for inner proof objects `proofs` (len = shape.n_proofs) of `shape`.
+    """(trace u64[26][N], publics) for inner proof objects `proofs` (len = shape.n_proofs) of `shape`; the trace is a host array,
+    or a device buffer of that shape when the backend assembles it in HBM (verifier_trace_device).
     be: backend with poseidon_perm_batch(states [B][12]) and poseidon_trace(inputs [B][12]) -> (states [12][32 B], cubes
     [12][32 B]).  Raises ValueError when an opening does not hash to its root -- there is no accepting witness for a proof
     whose openings do not verify."""
@@ -326,6 +327,8 @@ def build_witness(shape, proofs, be):
         o = int(bad[0])
         raise ValueError("an opening of the %s tree of inner proof %d does not hash to its root: no accepting witness"
                          % (shape.trees[tl[o]][0], pl[o]))
+    if hasattr(be, "verifier_trace_device"):      # GPU backend: the trace is assembled in HBM and stays there
+        return be.verifier_trace_device(inputs, dbit, idxv), np.array(pubs, dtype=np.uint64)
     states, cubes = be.poseidon_trace(inputs)
     trace = np.zeros((WIDTH, N), dtype=np.uint64)
     trace[S0:S0 + 12], trace[U0:U0 + 12] = states, cubes

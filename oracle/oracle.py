@@ -32,11 +32,49 @@ def build(force=False):
 _lib = None
 
 
+def _cpu_budget():
+    """threads the OpenMP loops of the checker should use: the CPUs this process may run on, capped by the CFS quota of its
+    cgroup.  A container can SEE every CPU of a large host (256 on the GPU boxes) and be throttled to 16 of them; a 256-thread
+    team with spinning barriers on a 16-CPU quota ran some checks 20-60 x slower, and erratically, from one box to the next."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    paths = ["/sys/fs/cgroup/cpu.max"]
+    try:
+        for line in open("/proc/self/cgroup"):
+            paths.insert(0, "/sys/fs/cgroup" + line.strip().split(":", 2)[-1].rstrip("/") + "/cpu.max")
+    except OSError:
+        pass
+    quota = None
+    for pth in paths:
+        try:
+            q, per = open(pth).read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+                break
+        except (OSError, ValueError):
+            continue
+    if quota is None:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):
             build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")      # idle workers sleep instead of spinning beside the GPU's host threads
+        if "OMP_NUM_THREADS" not in os.environ:
+            os.environ["OMP_NUM_THREADS"] = str(_cpu_budget())
         L = C.CDLL(_SO)
         u64, i32, sz = C.c_uint64, C.c_int, C.c_size_t
         for name in ("orc_add", "orc_sub", "orc_mul", "orc_pow"):

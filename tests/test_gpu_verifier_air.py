@@ -69,14 +69,15 @@ def test_aggregation_stark_gpu_equals_cpu_and_verifies(hip, tables, airname, log
         proofs.append(json.loads(PR.proof_to_json(PR.prove(air, tr, pub, params, hip))))
     shape = VA.Shape.of_proof(proofs[0], 2)
     vair = VA.verifier_air(shape, rc, mds)
-    t_gpu, pubs = VA.build_witness(shape, proofs, hip)
+    d_gpu, pubs = VA.build_witness(shape, proofs, hip)               # assembled in HBM (zp_poseidon_trace + two host columns)
+    t_gpu = hip.p.download(d_gpu, d_gpu.shape)
     t_cpu, pubs_c = VA.build_witness(shape, proofs, cpu)
     assert (t_gpu == t_cpu).all() and (pubs == pubs_c).all()
     ap = VA.aggregation_params(shape, n_queries=5, fri_final_log=3)
     p_cpu = PR.proof_to_json(PR.prove(vair, t_cpu, pubs, ap, cpu))
     p_gpu = PR.proof_to_json(PR.prove(vair, t_gpu, pubs, ap, hip))
     assert p_gpu == p_cpu
-    assert hip.prove_native(vair, t_gpu, pubs, ap) == p_cpu                    # zp_stark_prove: the same bytes
+    assert hip.prove_native(vair, d_gpu, pubs, ap) == p_cpu                    # zp_stark_prove on the device-resident trace: the same bytes
     agg = {"kind": "aggregated", "inner": [{k: v for k, v in p.items() if k != "queries"} for p in proofs], "stark": json.loads(p_gpu)}
     assert AV.verify(agg, air.program(), vair.program(), rc, mds, V.expectation(params.to_dict()), V.expectation(ap.to_dict()), shape.n_slots())
     t_bad = t_gpu.copy()
