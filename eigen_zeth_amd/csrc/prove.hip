@@ -345,10 +345,40 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         first.push_back(wd % GL_P);
     }
     first.push_back((u64)n_pubs);
-    for (int i = 0; i < n_pubs; i++) first.push_back(h_pubs[i]);
     Transcript tr(ctx, bn);
     const Trees T{ctx, bn};
-    tr.absorb(first);
+    if (n_pubs <= 64) {
+        for (int i = 0; i < n_pubs; i++) first.push_back(h_pubs[i]);
+        tr.absorb(first);
+    } else {
+        // a long public-input vector (a verifier AIR: every root, index and opened value of its inner proofs) enters the transcript
+        // as ONE commitment instead of thousands of dependent sponge permutations: Goldilocks mode: rows of 8 values (zero padded,
+        // row count a power of two >= 2), binary Poseidon tree;  BN128 mode: rows of 48 values, column-major, 16-ary tree
+        tr.absorb(first);
+        size_t Mp;
+        std::vector<u64> mat;
+        if (!bn) {
+            Mp = 2;
+            while (Mp * 8 < (size_t)n_pubs) Mp <<= 1;
+            mat.assign(Mp * 8, 0);
+            for (int i = 0; i < n_pubs; i++) mat[i] = h_pubs[i];
+        } else {
+            Mp = ((size_t)n_pubs + 47) / 48;
+            mat.assign(Mp * 48, 0);
+            for (int i = 0; i < n_pubs; i++) mat[(size_t)(i % 48) * Mp + (size_t)(i / 48)] = h_pubs[i];
+        }
+        u64 *dmat, *dtree;
+        PV_TRY(dev.alloc(mat.size(), &dmat));
+        PV_TRY(dev.alloc(T.tree_words(Mp), &dtree));
+        PV_TRY(zp_h2d(ctx, dmat, mat.data(), mat.size() * 8));
+        if (!bn) PV_TRY(zp_merkle_commit_rows(ctx, (const uint64_t *)dmat, Mp, 8, (uint64_t *)dtree));
+        else PV_TRY(T.commit(dmat, Mp, 48, dtree));
+        u64 rootp[4];
+        PV_TRY(T.root(dtree, Mp, rootp));
+        dev.release(dmat);
+        dev.release(dtree);
+        tr.absorb_root(rootp);
+    }
 
     // 1. commit the trace (ext / coef have room for the stage-2 columns behind the trace columns)
     u64 *ext, *coef, *tree1;

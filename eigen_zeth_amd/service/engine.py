@@ -285,12 +285,13 @@ class Engine:
 
     @staticmethod
     def _header(proof):
-        """an inner proof without its authentication paths: what stays outside the Merkle-verifier AIR (transcript, out-of-domain
-        identity, final layer -- checked from here) plus the opened values (for the DEEP / FRI-fold stage)"""
+        """an inner proof without its authentication paths: everything a verifier needs besides hashing -- transcript data, and per
+        query the index and the opened values of every tree (the public inputs of the Merkle-verifier STARK that replaces the paths)"""
         h = {k: v for k, v in proof.items() if k != "queries"}
-        h["opened"] = [{"index": q["index"], "trace": q["trace"]["values"], "quotient": q["quotient"]["values"],
-                        **({"stage2": q["stage2"]["values"]} if "stage2" in q else {}),
-                        "fri": [f["values"] for f in q["fri"]]} for q in proof["queries"]]
+        strip = lambda o: {k: v for k, v in o.items() if k != "path"}
+        h["queries"] = [{"index": q["index"], "trace": strip(q["trace"]), "quotient": strip(q["quotient"]),
+                         **({"stage2": strip(q["stage2"])} if "stage2" in q else {}),
+                         "fri": [strip(f) for f in q["fri"]]} for q in proof["queries"]]
         return h
 
     def _prove_merkle_verifier(self, proofs, params_of, be, timings):
@@ -332,8 +333,9 @@ class Engine:
             for k, v in tm.items():
                 self.metrics.record_stage(k, v)
         head = json.dumps({"kind": "aggregated", "version": 1, "batch_id": batch_id,
-                           "statement": "for every query slot, inner proof and committed tree an opening of the public index hashes to "
-                                        "the public root (Merkle part of the verifier; DEEP / FRI-fold checks are not in the AIR yet)",
+                           "statement": "for every query slot, inner proof and committed tree the public opened values hash, as a leaf and up "
+                                        "a path along the bits of the public index, to the public root (all hashing of the verifier; its "
+                                        "arithmetic -- transcript, out-of-domain identity, DEEP, FRI folds -- is checked natively on 'inner')",
                            "shape": dict(zip(("logn", "logb", "W", "W2", "Wq", "n_queries", "fri_logf", "fri_final_log", "n_proofs"), shape.key())),
                            "slots": shape.n_slots(), "verifier_air_digest": vair.digest(),
                            "inner": [self._header(pr) for pr in proofs]}, separators=(",", ":"))

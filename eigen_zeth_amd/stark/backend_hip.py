@@ -87,6 +87,23 @@ class HipBackend:
         d_out.free()
         return out[:12], out[12:]
 
+    def publics_digest(self, pubs):
+        """commitment to a long public-input vector (stark/prover.py: publics_rows): the root of its tree in this hash mode"""
+        from .prover import publics_rows
+        mat = publics_rows(pubs, self.hash_mode == "bn128")
+        if self.hash_mode == "bn128":
+            M = mat.shape[1]
+            d, tree = self.p.upload(mat), self._tree_alloc(M)
+            self.p.merkle16_commit_bn254(d, M, 48, tree)
+        else:
+            M = mat.shape[0]
+            d, tree = self.p.upload(mat), self._tree_alloc(M)
+            self.p.merkle_commit_rows(d, M, 8, tree)
+        root = self._root(tree, M)
+        d.free()
+        tree.free()
+        return root
+
     def verifier_trace_device(self, inputs, dbit, idxv):
         """the 26-column trace of the Merkle-verifier AIR (stark/verifier_air.py) assembled IN HBM: zp_poseidon_trace writes the 24
         state / cube columns of every permutation block, the direction-bit and index columns (one value per block, repeated over

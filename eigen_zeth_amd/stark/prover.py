@@ -15,6 +15,25 @@ from . import field as F
 from .transcript import Transcript, TranscriptBN128
 
 P = F.P
+PUBLICS_INLINE = 64     # public inputs beyond this many are absorbed through their Merkle digest (publics_rows)
+
+
+def publics_rows(pubs, bn):
+    """the matrix a long public-input vector is committed as: Goldilocks mode: rows of 8 values, row count a power of two
+    (>= 2), row-major [M][8];  BN128 mode: rows of 48 values (16 field elements), column-major [48][M].  Zero padded."""
+    import numpy as np
+    v = np.array([int(x) % P for x in pubs], dtype=np.uint64)
+    if not bn:
+        M = 2
+        while M * 8 < len(v):
+            M <<= 1
+        out = np.zeros((M, 8), dtype=np.uint64)
+        out.reshape(-1)[:len(v)] = v
+        return out
+    M = max(1, -(-len(v) // 48))
+    rows = np.zeros((M, 48), dtype=np.uint64)
+    rows.reshape(-1)[:len(v)] = v
+    return np.ascontiguousarray(rows.T)
 
 
 class StarkParams:
@@ -85,8 +104,16 @@ def prove(air, trace, pubs, params, be, timings=None):
     bn = params.hash == "bn128"
     assert getattr(be, "hash_mode", "gl") == params.hash, "backend and parameters disagree on the hash mode"
     tr = TranscriptBN128(be.poseidon_bn254_perm17) if bn else Transcript(be.poseidon_perm, getattr(be, "poseidon_sponge", None))
-    tr.absorb([logn, logb, W, W2, params.fri_logf, params.fri_final_log, params.n_queries, params.pow_bits,
-               int(root32), int(shift)] + air.digest_words() + [len(pubs)] + _ints(pubs))
+    head = [logn, logb, W, W2, params.fri_logf, params.fri_final_log, params.n_queries, params.pow_bits, int(root32), int(shift)] \
+        + air.digest_words() + [len(pubs)]
+    if len(pubs) <= PUBLICS_INLINE:
+        tr.absorb(head + _ints(pubs))
+    else:
+        # a long public-input vector (a verifier AIR names every root, index and opened value of its inner proofs: tens of
+        # thousands of values) enters the transcript as ONE commitment: a sequential sponge over it would be thousands of
+        # dependent permutations, the tree below is one parallel pass (rows of 8 / of 48 values, zero padded)
+        tr.absorb(head)
+        tr.absorb_root(be.publics_digest(_ints(pubs)))
     root_out = (lambda r: [str(int(r[0]))]) if bn else _ints      # a BN128 root is one 254-bit field element
 
     # 1. commit the trace

@@ -7,13 +7,17 @@ opened rows of the trace / stage-2 / quotient / FRI-layer commitments hash up to
 public inputs are those roots and the query indices.  The reference holds no prover arithmetic, so the
 construction is this repo's own (parity unpinned); it follows the public recursive-STARK recipe.
 
-What the AIR proves (public inputs: per inner proof and tree the root, per query slot / proof / tree the leaf index):
-    for every query slot, inner proof and committed tree there are leaf values and an authentication path such that
-    linear_hash(leaf) hashed up the path, with the direction bits of the PUBLIC index, equals the PUBLIC root.
-The caller (oracle/aggregate_verify.py on the checking side) derives the indices from each inner proof's Fiat-Shamir
-transcript and checks the out-of-domain constraint identity and the final FRI layer from the proof headers; the DEEP /
-FRI-fold arithmetic at the queried points is NOT yet in the AIR (stage B): the aggregated proof carries the opened
-values for that check.
+What the AIR proves (public inputs: per inner proof and tree the root; per query slot / proof / tree the leaf index and the
+OPENED VALUES):
+    for every query slot, inner proof and committed tree there is an authentication path such that linear_hash(the PUBLIC
+    leaf values) hashed up the path, with the direction bits of the PUBLIC index, equals the PUBLIC root.
+That is ALL the hashing of a verifier.  What is left of verifying an inner proof is arithmetic on public data -- replaying the
+Fiat-Shamir transcript (which yields the indices), the out-of-domain constraint identity, the DEEP quotient and every FRI fold
+at every query on the opened values, the final layer -- and the checker of an aggregated proof does exactly that natively
+(oracle/aggregate_verify.py: stark_verify.verify(trust_openings=True) on the inner proofs WITHOUT their paths) and requires
+the outer proof's public inputs to be those roots, indices and values.  So an accepted aggregated proof means both inner proofs
+verify: the Merkle work in the circuit, the field arithmetic outside it (putting that arithmetic into constraints too is what
+would make the recursion succinct in it: DESIGN.md par.7).
 
 Layout.  One Poseidon-12 permutation = one BLOCK of 32 rows: row r < 30 holds the state before round r, row 30 the
 output, row 31 a copy of it; the cubes (s_i + rc_i)^3 sit in 12 helper columns so that x^7 = cube^2 * x has degree 3.  Full
@@ -102,7 +106,7 @@ class Shape:
 
     def n_pub(self):
         T = len(self.trees)
-        return self.n_proofs * T * 4 + self.n_slots() * self.n_proofs * T
+        return self.n_proofs * T * 4 + self.n_slots() * self.n_proofs * (T + self.values_per_query())
 
     def pub_root(self, p, t, i):
         return (p * len(self.trees) + t) * 4 + i
@@ -110,6 +114,15 @@ class Shape:
     def pub_index(self, slot, p, t):
         T = len(self.trees)
         return self.n_proofs * T * 4 + (slot * self.n_proofs + p) * T + t
+
+    def values_per_query(self):
+        return sum(w for (_, w, _) in self.trees)
+
+    def pub_value(self, slot, p, t, k):
+        """public input number of opened value k of tree t of proof p in query slot `slot`"""
+        T = len(self.trees)
+        base = self.n_proofs * T * 4 + self.n_slots() * self.n_proofs * T
+        return base + (slot * self.n_proofs + p) * self.values_per_query() + sum(w for (_, w, _) in self.trees[:t]) + k
 
     def period_schedule(self):
         """blocks of one period: list of dicts {kind: "absorb" | "node" | "idle", sub (slot within the period), p, t, level, first,
@@ -184,12 +197,39 @@ def verifier_air(shape, rc, mds):
             idx_entries.append((per * (ROWS * pb) + row, Pub(shape.pub_index(per * k + sub, p, t))))
     fc.append(FixedCol(logn, idx_entries))
     IDXV = Fixed(26)
+    # the opened values are public: row 0 of absorb block j holds values 8j .. 8j+7 of the leaf in the rate (positions past the
+    # leaf width are zero: the padding of the sponge), row 0 of the first node block of an unhashed leaf (width <= 4) holds it as
+    # the left or right child
+    abs0, id0 = [], []
+    leaf = [[] for _ in range(8)]
+    for per in range(periods):
+        for b, blk in enumerate(sched):
+            if blk["kind"] == "idle":
+                continue
+            row = per * (ROWS * pb) + b * ROWS
+            w = shape.trees[blk["t"]][1]
+            slot = per * k + blk["sub"]
+            if blk["kind"] == "absorb":
+                for i in range(8):
+                    if 8 * blk["j"] + i < w:
+                        leaf[i].append((row, Pub(shape.pub_value(slot, blk["p"], blk["t"], 8 * blk["j"] + i))))
+            elif blk["first"]:
+                for i in range(w):
+                    leaf[i].append((row, Pub(shape.pub_value(slot, blk["p"], blk["t"], i))))
+    for b, blk in enumerate(sched):
+        if blk["kind"] == "absorb":
+            abs0.append((b * ROWS, 1))
+        elif blk["kind"] == "node" and blk["first"]:
+            id0.append((b * ROWS, 1))
+    fc += [FixedCol(lp, abs0), FixedCol(lp, id0)] + [FixedCol(logn, leaf[i]) for i in range(8)]
+    ABS0, ID0 = Fixed(27), Fixed(28)
+    LEAF = [Fixed(29 + i) for i in range(8)]
 
     # ---- constraints
     s = [Col(S0 + i) for i in range(12)]
     sn = [Col(S0 + i, True) for i in range(12)]
     u = [Col(U0 + i) for i in range(12)]
-    d_n, idx, idx_n = Col(COL_D, True), Col(COL_IDX), Col(COL_IDX, True)
+    d_c, d_n, idx, idx_n = Col(COL_D), Col(COL_D, True), Col(COL_IDX), Col(COL_IDX, True)
     x = [s[i] + RC[i] for i in range(12)]
     cs = [u[i] - x[i] * x[i] * x[i] for i in range(12)]                   # cubes (every row; rc = 0 on rows 30, 31)
     y = [ACT * (u[0] * u[0] * x[0])]
@@ -212,6 +252,8 @@ def verifier_air(shape, rc, mds):
     cs.append(idx_n - (ACT + CPY + L_CHAIN + L_NODE) * idx - WT * d_n)    # index: kept inside a block and an opening, + 2^level * bit
     cs += [L_FINAL * s[i] - ROOT[i] for i in range(4)]                    # the top of the path is the public root
     cs.append(L_FINAL * idx - IDXV)                                       # the direction bits spell the public index
+    cs += [ABS0 * s[i] + ID0 * (s[i] + d_c * (s[4 + i] - s[i])) - LEAF[i] for i in range(4)]   # the hashed values are the public ones
+    cs += [ABS0 * s[i] - LEAF[i] for i in range(4, 8)]
     air = A.Air("mverify", WIDTH, shape.n_pub(), cs, trace_kind=None, fixed_cols=fc)
     air.shape = shape
     assert A.quotient_chunks(air) <= 4
@@ -227,7 +269,8 @@ def _opening(q, name):
 
 
 def expected_publics(shape, proofs):
-    """roots of every inner proof, then the leaf index of every (slot, proof, tree): slot g re-opens query g mod n_queries"""
+    """roots of every inner proof, then the leaf index of every (slot, proof, tree), then the opened values of every (slot, proof,
+    tree): slot g re-opens query g mod n_queries"""
     pubs = []
     for pr in proofs:
         names = {"trace": pr["roots"]["trace"], "quotient": pr["roots"]["quotient"]}
@@ -241,6 +284,14 @@ def expected_publics(shape, proofs):
             j = pr["queries"][g % shape.n_queries]["index"]
             for (_, _, depth) in shape.trees:
                 pubs.append(int(j) & ((1 << depth) - 1))
+    for g in range(shape.n_slots()):
+        for pr in proofs:
+            q = pr["queries"][g % shape.n_queries]
+            for (name, w, _) in shape.trees:
+                vals = _opening(q, name)["values"]
+                if len(vals) != w:
+                    raise ValueError("opening of %s has the wrong shape" % name)
+                pubs += [int(v) for v in vals]
     return pubs
 
 

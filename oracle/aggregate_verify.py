@@ -3,19 +3,20 @@ product package).
 
 An aggregated proof (what GenAggregatedProof returns: proto/prover/v1/prover.proto:115-126, consumed at
 src/prover/provider.rs:436-451) holds
-    "inner": for every inner proof everything but its query openings' authentication paths  (air name / digest, parameters,
-             publics, roots, out-of-domain evaluations, FRI roots + final layer, proof-of-work nonce; and the opened VALUES)
+    "inner": every inner proof WITHOUT the authentication paths of its query openings (everything else: air name / digest,
+             parameters, publics, roots, out-of-domain evaluations, FRI roots + final layer, grinding nonce, and per query the
+             index and the opened values of every tree)
     "stark": a STARK over the Merkle-verifier AIR (the statement arrives as a constraint program blob, like every other AIR)
-             whose public inputs are the inner proofs' roots and the leaf index of every (slot, proof, tree).
-Accepting means:
-  1. every inner header verifies on its own: parameters are the verifier's, the Fiat-Shamir transcript is replayed, the
-     constraint identity holds at the out-of-domain point, the final FRI layer is low degree, the grinding nonce is valid
-     (stark_verify.verify(header_only=True)) -- this also yields the query indices the transcript dictates;
-  2. the public inputs of the outer STARK are exactly those roots and those indices (slot g re-opens query g mod n_queries);
-  3. the outer STARK verifies under the verifier-AIR program: for every slot / proof / tree an opening of the public index
-     hashes to the public root.
-NOT covered (stage B, not in the AIR yet): that the opened values satisfy the DEEP quotient and the FRI folds; the values
-travel in "inner" so that stage can be added on either side.  PARITY UNPINNED w.r.t. the external prover."""
+             whose public inputs are the inner proofs' roots, the leaf index and the opened values of every (slot, proof, tree).
+Accepting means BOTH INNER PROOFS VERIFY, the work split in two:
+  1. arithmetic, natively: every inner proof passes the whole verifier on the opened values as given -- parameters are the
+     verifier's, the Fiat-Shamir transcript is replayed (which dictates the query indices), the constraint identity holds at the
+     out-of-domain point, the DEEP quotient and every FRI fold are consistent at every query, the final layer is low degree, the
+     grinding nonce is valid (stark_verify.verify(trust_openings=True): everything but the Merkle paths);
+  2. the public inputs of the outer STARK are exactly those roots, indices and opened values (slot g re-opens query g mod n_queries);
+  3. hashing, in the circuit: the outer STARK verifies under the verifier-AIR program -- for every slot / proof / tree the public
+     values, hashed as a leaf and up a path along the bits of the public index, give the public root.
+PARITY UNPINNED w.r.t. the external prover."""
 from . import stark_verify as V
 from .air_program import Program
 
@@ -39,7 +40,7 @@ def verify(agg, inner_program, outer_program, rc, mds, inner_expect, outer_expec
     inner = agg["inner"]
     if not inner:
         raise V.Reject("no inner proofs")
-    heads = [V.verify(h, inner_program, rc, mds, inner_expect, header_only=True) for h in inner]
+    heads = [V.verify(h, inner_program, rc, mds, inner_expect, trust_openings=True) for h in inner]
     W2 = heads[0]["W2"]
     depths = tree_depths(inner_expect["logn"], inner_expect["logb"], W2, heads[0]["sched"])
     want = []
@@ -54,8 +55,13 @@ def verify(agg, inner_program, outer_program, rc, mds, inner_expect, outer_expec
         for hd in heads:
             j = hd["indices"][g % nq]
             want += [j & ((1 << d) - 1) for d in depths]
+    for g in range(n_slots):
+        for h in inner:
+            q = h["queries"][g % nq]
+            for part in [q["trace"]] + ([q["stage2"]] if W2 else []) + [q["quotient"]] + list(q["fri"]):
+                want += [int(v) for v in part["values"]]
     outer = agg["stark"]
     if [int(v) for v in outer["publics"]] != want:
-        raise V.Reject("the outer proof's public inputs are not the inner proofs' roots and query indices")
+        raise V.Reject("the outer proof's public inputs are not the inner proofs' roots, query indices and opened values")
     prog = outer_program if isinstance(outer_program, Program) else Program(outer_program)
     return V.verify(outer, prog, rc, mds, outer_expect)

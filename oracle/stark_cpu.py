@@ -47,6 +47,11 @@ class CpuBackend:
     def poseidon_perm(self, state):
         return [int(v) for v in O.poseidon_perm(np.array([state], dtype=np.uint64), self.rc, self.mds)[0]]
 
+    def publics_digest(self, pubs):
+        """root of the tree a long public-input vector is committed as (restated in oracle/stark_verify.py: publics_digest)"""
+        from .stark_verify import publics_digest
+        return publics_digest(pubs, self.rc, self.mds, self.hash_mode == "bn128")
+
     def poseidon_perm_batch(self, states):
         return O.poseidon_perm(np.asarray(states, dtype=np.uint64), self.rc, self.mds)
 

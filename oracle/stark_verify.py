@@ -109,6 +109,27 @@ def merkle16_verify(leaf_digest, M, index, path, root):
     return levels == len(path) and cur == int(root)
 
 
+PUBLICS_INLINE = 64
+
+
+def publics_digest(pubs, rc, mds, bn):
+    """more than PUBLICS_INLINE public inputs enter the transcript as one commitment.  Goldilocks mode: the values in rows of 8
+    (zero padded, row count a power of two >= 2), leaf = linear hash of a row, binary Poseidon tree -> root (4 elements).  BN128
+    mode: rows of 48 values (three to a field element, 16 elements to a leaf), 16-ary Poseidon-BN254 tree -> root (1 element)."""
+    v = [int(x) % P for x in pubs]
+    if not bn:
+        M = 2
+        while M * 8 < len(v):
+            M <<= 1
+        rows = np.zeros((M, 8), dtype=np.uint64)
+        rows.reshape(-1)[:len(v)] = np.array(v, dtype=np.uint64)
+        return [int(x) for x in O.merkle_commit_rows(rows, rc, mds)[-1]]
+    M = max(1, -(-len(v) // 48))
+    rows = np.zeros((M, 48), dtype=np.uint64)
+    rows.reshape(-1)[:len(v)] = np.array(v, dtype=np.uint64)
+    return [O._fr_ints(O.merkle16_tree(np.ascontiguousarray(rows.T))[-1])[0]]
+
+
 def fri_schedule(logn, logb, fri_logf, fri_final_log):
     """[(log size of the committed layer, log fold factor)], log size of the final layer sent in clear"""
     cur, stop, sched = logn + logb, fri_final_log + logb, []
@@ -165,13 +186,16 @@ def expectation(params, root32=NV.ROOT32_DEFAULT, shift=NV.SHIFT_DEFAULT):
     return e
 
 
-def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False):
+def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, trust_openings=False):
     """program: the constraint program blob (u64 words) of the statement;  expect: the verifier's own parameters
     {logn, logb, fri_logf, fri_final_log, n_queries, pow_bits, root32, shift [, hash]}.  hash = "bn128": the proof must be in
     BN128-hash mode (16-ary Poseidon-BN254 trees + transcript); bn_tables = (rc, mds, rp) of the t = 17 instance.
     header_only: check everything that needs no opening (parameters, transcript, out-of-domain constraint identity, final
     FRI layer, proof of work) and return {"indices": the query indices the transcript dictates} -- the part of the verifier
-    that stays outside a Merkle-verifier AIR (oracle/aggregate_verify.py); proof["queries"] is not read."""
+    that stays outside a Merkle-verifier AIR; proof["queries"] is not read.
+    trust_openings: run the WHOLE verifier -- transcript, identity, DEEP quotient and every FRI fold at every query -- on the opened
+    values as given, without their authentication paths (which a Merkle-verifier STARK vouches for: oracle/aggregate_verify.py);
+    returns the same dictionary instead of True."""
     rc = np.asarray(rc, dtype=np.uint64)
     mds = np.asarray(mds, dtype=np.uint64)
     air = program if isinstance(program, Program) else Program(program)
@@ -224,8 +248,14 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False):
         def opening_ok(values, m, idx, path, root):
             return bool(O.merkle_verify(O.linear_hash(np.array(values, dtype=np.uint64), rc, mds), m, idx, np.array(path, dtype=np.uint64),
                                         np.array(root, dtype=np.uint64), rc, mds))
-    tr.absorb([logn, logb, W, W2, expect["fri_logf"], expect["fri_final_log"], n_queries, pow_bits, root32, shift]
-              + air.digest_words() + [len(pubs)] + pubs)
+    if trust_openings:
+        opening_ok = lambda values, m, idx, path, root: all(0 <= int(v) < P for v in values)
+    head = [logn, logb, W, W2, expect["fri_logf"], expect["fri_final_log"], n_queries, pow_bits, root32, shift] + air.digest_words() + [len(pubs)]
+    if len(pubs) <= PUBLICS_INLINE:
+        tr.absorb(head + pubs)
+    else:
+        tr.absorb(head)
+        absorb_root(publics_digest(pubs, rc, mds, bn))
     absorb_root(proof["roots"]["trace"])
     chal = []
     if air.stage2:
@@ -317,9 +347,9 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False):
         tv, qv = qq["trace"]["values"], qq["quotient"]["values"]
         if len(tv) != W or len(qv) != 3 * Q:
             raise Reject("bad opening width")
-        if not opening_ok(tv, M, j, qq["trace"]["path"], proof["roots"]["trace"]):
+        if not opening_ok(tv, M, j, qq["trace"].get("path"), proof["roots"]["trace"]):
             raise Reject("trace opening does not verify")
-        if not opening_ok(qv, M, j, qq["quotient"]["path"], proof["roots"]["quotient"]):
+        if not opening_ok(qv, M, j, qq["quotient"].get("path"), proof["roots"]["quotient"]):
             raise Reject("quotient opening does not verify")
         s2v = []
         if air.stage2:
@@ -327,7 +357,7 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False):
             if s2 is None or len(s2["values"]) != W2:
                 raise Reject("missing stage-2 opening")
             s2v = s2["values"]
-            if not opening_ok(s2v, M, j, s2["path"], proof["roots"]["stage2"]):
+            if not opening_ok(s2v, M, j, s2.get("path"), proof["roots"]["stage2"]):
                 raise Reject("stage-2 opening does not verify")
         x = shift * pow(wM, j, P) % P
         vals = tv + s2v + qv
@@ -349,7 +379,7 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False):
             lv = fo["values"]
             if len(lv) != (3 << f):
                 raise Reject("bad FRI leaf width")
-            if not opening_ok(lv, m, row, fo["path"], proof["fri"]["roots"][li]):
+            if not opening_ok(lv, m, row, fo.get("path"), proof["fri"]["roots"][li]):
                 raise Reject("FRI opening does not verify (layer %d)" % li)
             pts = [[lv[c * (1 << f) + k] for c in range(3)] for k in range(1 << f)]
             if pts[k0] != expect:
@@ -360,4 +390,4 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False):
             cur_shift = pow(cur_shift, 1 << f, P)
         if [final[c][pos] for c in range(3)] != expect:
             raise Reject("final layer inconsistent with the last fold")
-    return True
+    return {"indices": qidx, "sched": sched, "W": W, "W2": W2, "Wq": 3 * Q} if trust_openings else True

@@ -20,6 +20,15 @@ from oracle.stark_cpu import CpuBackend
 P = O.P
 
 
+def strip_paths(proof):
+    """an inner proof as an aggregated proof carries it: everything but the authentication paths"""
+    h = copy.deepcopy(proof)
+    for q in h["queries"]:
+        for part in [q["trace"], q["quotient"]] + ([q["stage2"]] if "stage2" in q else []) + q["fri"]:
+            del part["path"]
+    return h
+
+
 @pytest.fixture(scope="module")
 def cpu(tables):
     return CpuBackend(*tables)
@@ -45,8 +54,7 @@ def aggregated(cpu, inner, tables):
     trace, pubs = VA.build_witness(shape, proofs, cpu)
     ap = VA.aggregation_params(shape, n_queries=5, fri_final_log=3)
     stark = PR.prove(vair, trace, pubs, ap, cpu)
-    header = lambda p: {k: v for k, v in p.items() if k != "queries"}
-    return shape, vair, ap, trace, pubs, {"kind": "aggregated", "inner": [header(p) for p in proofs], "stark": stark}
+    return shape, vair, ap, trace, pubs, {"kind": "aggregated", "inner": [strip_paths(p) for p in proofs], "stark": stark}
 
 
 def test_poseidon_trace_rows_are_the_round_states(tables):
@@ -131,6 +139,13 @@ def test_forged_witnesses_are_rejected(inner, aggregated, cpu, tables):
     t5 = trace.copy()
     t5[VA.U0, 5] = (int(t5[VA.U0, 5]) + 1) % P                                        # a wrong cube
     rejected(t5, pubs)
+    p6 = pubs.copy()
+    p6[shape.pub_value(2, 1, 0, 5)] = (int(p6[shape.pub_value(2, 1, 0, 5)]) + 1) % P   # claim another opened value than the hashed one
+    rejected(trace, p6)
+    p7 = pubs.copy()
+    p7[shape.pub_value(0, 0, 2, 1)] = (int(p7[shape.pub_value(0, 0, 2, 1)]) + 1) % P   # ... of an unhashed (3-value) quotient leaf
+    rejected(trace, p7)
+    assert len(pubs) > PR.PUBLICS_INLINE                                              # the publics enter the transcript through their digest
 
 
 def test_outer_publics_must_follow_the_inner_transcripts(inner, aggregated, tables):
@@ -149,6 +164,11 @@ def test_outer_publics_must_follow_the_inner_transcripts(inner, aggregated, tabl
     bad = copy.deepcopy(agg)
     bad["inner"] = bad["inner"][::-1]                          # the outer proof names proof 0's roots first
     with pytest.raises(V.Reject, match="public inputs"):
+        AV.verify(bad, *args)
+    bad = copy.deepcopy(agg)
+    v = bad["inner"][0]["queries"][1]["fri"][1]["values"]      # an opened value that is not the committed one: the inner proof's own
+    v[2] = (v[2] + 1) % P                                      # fold check fails natively (and it would not match the outer publics)
+    with pytest.raises(V.Reject):
         AV.verify(bad, *args)
     with pytest.raises(V.Reject):                              # fewer inner queries than the verifier requires
         AV.verify(agg, air.program(), vair.program(), rc, mds, dict(V.expectation(params.to_dict()), n_queries=5), V.expectation(ap.to_dict()),
