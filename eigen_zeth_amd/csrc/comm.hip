@@ -11,8 +11,11 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <functional>
 #include <vector>
 
 #include "ctx.hpp"
@@ -30,6 +33,7 @@ struct Rccl {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok = false;
 };
@@ -46,20 +50,74 @@ Rccl &rccl() {
     if (!r.h) return r;
 #define ZP_SYM(name) r.name = (decltype(r.name))dlsym(r.h, "nccl" #name)
     ZP_SYM(GetUniqueId); ZP_SYM(CommInitRank); ZP_SYM(CommDestroy); ZP_SYM(GroupStart); ZP_SYM(GroupEnd);
-    ZP_SYM(Send); ZP_SYM(Recv); ZP_SYM(AllGather); ZP_SYM(Broadcast); ZP_SYM(GetErrorString);
+    ZP_SYM(Send); ZP_SYM(Recv); ZP_SYM(AllGather); ZP_SYM(Broadcast); ZP_SYM(AllReduce); ZP_SYM(GetErrorString);
 #undef ZP_SYM
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllGather && r.Broadcast &&
-           r.GetErrorString;
+           r.AllReduce && r.GetErrorString;
     return r;
 }
 
 }  // namespace
 
+// A communicator WITHOUT RCCL for ranks that live in one process (threads, one ctx each -- on one GPU or several): every collective is
+// device-to-device copies between the ranks' buffers around a thread barrier.  RCCL refuses two ranks on one device, so this is how the
+// multi-rank logic of the sharded entry points (zp_merkle_commit_sharded, zp_stark_prove_sharded) is exercised on a one-GPU box; it is
+// also a legitimate transport for a single-process multi-GPU host (peer copies).
+struct zp_comm_group {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    unsigned gen = 0;
+    const void *ptr[64];
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const unsigned g = gen;
+        if (++waiting == world) {
+            waiting = 0;
+            gen++;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != g; });
+        }
+    }
+};
+
 struct zp_comm {
     zp_ctx *ctx;
     ncclComm_t comm;
     int rank, world;
+    zp_comm_group *local = nullptr;    // non-null: in-process group, no RCCL
 };
+
+namespace {
+
+__global__ void __launch_bounds__(256) sum_parts_kernel(u64 *__restrict__ dst, const u64 *__restrict__ parts, size_t words, int n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= words) return;
+    u64 a = 0;
+    for (int k = 0; k < n; k++) a += parts[(size_t)k * words + i];
+    dst[i] = a;
+}
+
+// in-process collectives: publish this rank's buffer, meet, copy what the collective says from the peers' buffers, meet again (so that
+// nobody reuses a buffer a peer is still reading).  All copies run on the calling rank's stream and are complete on return.
+int32_t local_exchange(zp_comm *c, const void *mine, const std::function<int32_t(const void *const *)> &copy) {
+    zp_comm_group *g = c->local;
+    ZP_HIP(c->ctx, hipStreamSynchronize(c->ctx->stream));       // what I hand out is complete
+    g->ptr[c->rank] = mine;
+    g->barrier();
+    const int32_t rc = copy(g->ptr);
+    const hipError_t e = hipStreamSynchronize(c->ctx->stream);
+    g->barrier();
+    if (rc != ZP_OK) return rc;
+    ZP_HIP(c->ctx, e);
+    return ZP_OK;
+}
+
+}  // namespace
+
+zp_ctx *zpi_comm_ctx(const zp_comm *comm) { return comm ? comm->ctx : nullptr; }
 
 #define ZP_NCCL(c, call)                                                                       \
     do {                                                                                       \
@@ -103,6 +161,31 @@ int32_t zp_comm_create(zp_ctx *ctx, int32_t rank, int32_t world, const uint8_t *
     return ZP_OK;
 }
 
+int32_t zp_comm_group_create(int32_t world, zp_comm_group **out) {
+    if (!out || world < 1 || world > 64 || (world & (world - 1)) != 0) return ZP_ERR_ARG;
+    zp_comm_group *g = new (std::nothrow) zp_comm_group();
+    if (!g) return ZP_ERR_NOMEM;
+    g->world = world;
+    *out = g;
+    return ZP_OK;
+}
+
+int32_t zp_comm_group_destroy(zp_comm_group *g) {
+    delete g;
+    return ZP_OK;
+}
+
+int32_t zp_comm_create_local(zp_ctx *ctx, int32_t rank, zp_comm_group *group, zp_comm **out) {
+    if (!ctx || !out) return ZP_ERR_ARG;
+    *out = nullptr;
+    ZP_ARG(ctx, group && rank >= 0 && rank < group->world, "bad rank / group");
+    zp_comm *c = new (std::nothrow) zp_comm();
+    if (!c) return ZP_ERR_NOMEM;
+    c->ctx = ctx; c->rank = rank; c->world = group->world; c->comm = nullptr; c->local = group;
+    *out = c;
+    return ZP_OK;
+}
+
 int32_t zp_comm_destroy(zp_comm *c) {
     if (!c) return ZP_OK;
     ZP_BIND(c->ctx);
@@ -121,6 +204,13 @@ int32_t zp_comm_all_to_all(zp_comm *c, const uint64_t *d_send, uint64_t *d_recv,
     ZpStage stage_(c->ctx, "comm_all_to_all");
     ZP_ARG(c->ctx, d_send && d_recv && d_send != d_recv, "bad buffers");
     if (words_per_peer == 0) return ZP_OK;
+    if (c->local)
+        return local_exchange(c, d_send, [&](const void *const *peer) -> int32_t {
+            for (int h = 0; h < c->world; h++)
+                ZP_HIP(c->ctx, hipMemcpyAsync(d_recv + (size_t)h * words_per_peer, (const u64 *)peer[h] + (size_t)c->rank * words_per_peer,
+                                              words_per_peer * 8, hipMemcpyDeviceToDevice, c->ctx->stream));
+            return ZP_OK;
+        });
     ZP_NCCL(c, rccl().GroupStart());
     for (int h = 0; h < c->world; h++) {
         ZP_NCCL(c, rccl().Send(d_send + (size_t)h * words_per_peer, words_per_peer, ncclUint64, h, c->comm, c->ctx->stream));
@@ -135,7 +225,40 @@ int32_t zp_comm_all_gather(zp_comm *c, const uint64_t *d_send, uint64_t *d_recv,
     ZpStage stage_(c->ctx, "comm_all_gather");
     ZP_ARG(c->ctx, d_send && d_recv, "bad buffers");
     if (words == 0) return ZP_OK;
+    if (c->local)
+        return local_exchange(c, d_send, [&](const void *const *peer) -> int32_t {
+            for (int h = 0; h < c->world; h++)
+                ZP_HIP(c->ctx, hipMemcpyAsync(d_recv + (size_t)h * words, peer[h], words * 8, hipMemcpyDeviceToDevice, c->ctx->stream));
+            return ZP_OK;
+        });
     ZP_NCCL(c, rccl().AllGather(d_send, d_recv, words, ncclUint64, c->comm, c->ctx->stream));
+    return ZP_OK;
+}
+
+// d_buf <- sum over the ranks of their d_buf (64-bit wrapping sums; the sharded prover adds vectors of which exactly one rank holds a
+// non-zero entry per position: the owner of a row answers, the others contribute zeros)
+int32_t zp_comm_all_reduce_sum(zp_comm *c, uint64_t *d_buf, size_t words) {
+    if (!c) return ZP_ERR_ARG;
+    ZpStage stage_(c->ctx, "comm_all_reduce");
+    ZP_ARG(c->ctx, d_buf != nullptr, "bad buffer");
+    if (words == 0) return ZP_OK;
+    if (c->local) {
+        void *tmp = nullptr;
+        ZP_TRY(zp_dev_alloc(c->ctx, (size_t)c->world * words * 8, &tmp));
+        int32_t rc = local_exchange(c, d_buf, [&](const void *const *peer) -> int32_t {
+            for (int h = 0; h < c->world; h++)
+                ZP_HIP(c->ctx, hipMemcpyAsync((u64 *)tmp + (size_t)h * words, peer[h], words * 8, hipMemcpyDeviceToDevice, c->ctx->stream));
+            return ZP_OK;
+        });
+        if (rc == ZP_OK) {     // every rank has read every buffer (second barrier of the exchange): now the sums may overwrite them
+            hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->ctx->stream, (u64 *)d_buf, (const u64 *)tmp, words,
+                               c->world);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->ctx->stream) != hipSuccess) rc = ZP_ERR_HIP;
+        }
+        (void)zp_dev_free(c->ctx, tmp);
+        return rc;
+    }
+    ZP_NCCL(c, rccl().AllReduce(d_buf, d_buf, words, ncclUint64, ncclSum, c->comm, c->ctx->stream));
     return ZP_OK;
 }
 
@@ -144,6 +267,11 @@ int32_t zp_comm_broadcast(zp_comm *c, uint64_t *d_buf, size_t words, int32_t roo
     ZpStage stage_(c->ctx, "comm_broadcast");
     ZP_ARG(c->ctx, d_buf && root >= 0 && root < c->world, "bad arguments");
     if (words == 0) return ZP_OK;
+    if (c->local)
+        return local_exchange(c, d_buf, [&](const void *const *peer) -> int32_t {
+            if (c->rank != root) ZP_HIP(c->ctx, hipMemcpyAsync(d_buf, peer[root], words * 8, hipMemcpyDeviceToDevice, c->ctx->stream));
+            return ZP_OK;
+        });
     ZP_NCCL(c, rccl().Broadcast(d_buf, d_buf, words, ncclUint64, root, c->comm, c->ctx->stream));
     return ZP_OK;
 }

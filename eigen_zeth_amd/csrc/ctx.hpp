@@ -149,6 +149,8 @@ struct NttRunOpts {
 struct ZpFixedCol { int lp; size_t first_entry_word, n_entries; bool has_pub; };
 // validates the whole-blob length and the table; fills `cols` (empty for n_fixed == 2).  false: malformed
 bool zpi_program_fixed_table(const uint64_t *h_program, size_t program_words, std::vector<ZpFixedCol> *cols);
+struct zp_comm;
+zp_ctx *zpi_comm_ctx(const zp_comm *comm);      // the ctx a communicator was created on (csrc/comm.hip)
 int32_t zpi_twiddle_rows(zp_ctx *ctx, u64 *d_rows, int logn_row, int W, u64 row0, int logn_total, bool inverse);
 int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn, int logb, int W, u64 shift);
 int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, bool inverse,

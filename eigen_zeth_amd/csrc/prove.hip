@@ -678,3 +678,541 @@ int32_t zp_stark_prove_bn128(zp_ctx *ctx, const char *air_name, const uint64_t *
 }
 
 }  // extern "C"
+
+// ======================================================================================================================
+// zp_stark_prove_sharded: ONE chunk STARK over the G ranks of a communicator (BASELINE configs[3]) -- what
+// eigen_zeth_amd/stark/sharded.py orchestrates in Python, behind one C-ABI call per rank, so that a compiled host (Rust: the side of
+// src/prover/provider.rs:358-377) can spread one GenChunkProof over the GPUs of a node.  Every rank passes ITS W/G trace columns and
+// ends with the same proof text, byte for byte the text zp_stark_prove writes for the whole trace on one GPU.
+//     trace LDE                  columns [W/G][N] -> [W/G][M]                         no exchange
+//     trace commitment           rows [W][M/G]: local subtree                          ONE all-to-all, all-gather of G sub-roots
+//     stage-2 columns            replicated (a handful of columns)                     broadcast of the witness columns they read
+//     constraint quotient        rows, with a blow-up halo (b rows of the next rank)   all-gather of G x Wt x b halo values
+//     quotient commitment        rows: local subtree                                   all-gather of the quotient rows, of G sub-roots
+//     out-of-domain evaluations  columns (coefficients never move)                     all-gather of the evaluations
+//     DEEP quotient              rows                                                  all-gather of the result: "gather before FRI"
+//     FRI, proof of work         replicated                                            none
+//     query openings             the owner of a row answers                            one all-reduce of values and sub-tree paths
+namespace {
+
+struct ShardTop {                       // the top log2 G levels of a row-sharded tree, known to every rank
+    std::vector<std::vector<u64>> levels;   // levels[l]: (G >> l) nodes of 4 words
+    u64 root[4];
+};
+
+int32_t shard_top(zp_ctx *ctx, const std::vector<u64> &subroots, int G, ShardTop *out) {
+    out->levels.clear();
+    std::vector<u64> lvl = subroots;
+    void *d = nullptr;
+    if (G > 1) PV_TRY(zp_dev_alloc(ctx, (size_t)(G / 2) * 12 * 8, &d));
+    int32_t rc = ZP_OK;
+    for (int n = G; rc == ZP_OK && n > 1; n >>= 1) {
+        out->levels.push_back(lvl);
+        std::vector<u64> st((size_t)(n / 2) * 12, 0);
+        for (int i = 0; i < n / 2; i++) memcpy(&st[12 * (size_t)i], &lvl[8 * (size_t)i], 64);
+        rc = zp_h2d(ctx, d, st.data(), st.size() * 8);
+        if (rc == ZP_OK) rc = zp_poseidon_perm(ctx, (uint64_t *)d, (size_t)(n / 2));
+        if (rc == ZP_OK) rc = zp_d2h(ctx, st.data(), d, st.size() * 8);
+        lvl.assign((size_t)(n / 2) * 4, 0);
+        for (int i = 0; i < n / 2; i++) memcpy(&lvl[4 * (size_t)i], &st[12 * (size_t)i], 32);
+    }
+    if (d) (void)zp_dev_free(ctx, d);
+    if (rc == ZP_OK) memcpy(out->root, lvl.data(), 32);
+    return rc;
+}
+
+// local subtree over `rows` u64[Wc][nloc] + all-gather of the sub-roots + the top of the tree
+int32_t shard_commit(zp_comm *comm, zp_ctx *ctx, DevBufs &dev, const u64 *rows, size_t nloc, int Wc, int G, u64 **tree_out, ShardTop *top) {
+    u64 *tree, *sub;
+    PV_TRY(dev.alloc((2 * nloc - 1) * 4, &tree));
+    PV_TRY(dev.alloc((size_t)G * 4, &sub));
+    PV_TRY(zp_merkle_commit(ctx, (const uint64_t *)rows, nloc, Wc, (uint64_t *)tree));
+    PV_TRY(zp_comm_all_gather(comm, (const uint64_t *)(tree + (2 * nloc - 2) * 4), (uint64_t *)sub, 4));
+    std::vector<u64> h((size_t)G * 4);
+    PV_TRY(zp_d2h(ctx, h.data(), sub, h.size() * 8));
+    dev.release(sub);
+    PV_TRY(shard_top(ctx, h, G, top));
+    *tree_out = tree;
+    return ZP_OK;
+}
+
+// [G][C][nloc] (what an all-gather of [C][nloc] row shards delivers) -> [C][G * nloc]
+int32_t shard_join(zp_ctx *ctx, const u64 *gathered, u64 *full, int C, size_t nloc, int G) {
+    for (int h = 0; h < G; h++)
+        ZP_HIP(ctx, hipMemcpy2DAsync(full + (size_t)h * nloc, (size_t)G * nloc * 8, gathered + (size_t)h * C * nloc, nloc * 8, nloc * 8, (size_t)C,
+                                     hipMemcpyDeviceToDevice, ctx->stream));
+    return ZP_OK;
+}
+
+int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words,
+                           const uint64_t *d_trace, size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb,
+                           int32_t fri_logf, int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
+    ZpStage stage_(ctx, "stark_prove_sharded");
+    const bool bn = false;
+    const int G = zp_comm_world(comm), rank = zp_comm_rank(comm);
+    ZP_ARG(ctx, air_name && h_program && d_trace && out_json && out_len && (h_pubs || n_pubs == 0), "null pointer");
+    {
+        const size_t nl = strlen(air_name);
+        bool ok = nl >= 1 && nl <= 64;
+        for (size_t i = 0; ok && i < nl; i++) {
+            const char ch = air_name[i];
+            ok = (ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || (ch >= '0' && ch <= '9') || ch == '_' || ch == '-' || ch == '.';
+        }
+        ZP_ARG(ctx, ok, "air_name must be 1..64 characters of [A-Za-z0-9_.-]");
+    }
+    ZP_ARG(ctx, program_words >= 12, "constraint program shorter than its header");
+    static const unsigned char magic[8] = {'Z', 'P', 'A', 'I', 'R', '1', 0, 0};
+    ZP_ARG(ctx, memcmp(h_program, magic, 8) == 0, "not a ZPAIR1 constraint program");
+    const size_t W = h_program[1], W2 = h_program[2], n_pub_prog = h_program[4], n_chal = h_program[5], n_const = h_program[6],
+                 n_instr = h_program[7], K = h_program[8], n_s2 = h_program[10], Q = h_program[11];
+    std::vector<ZpFixedCol> fxc;
+    ZP_ARG(ctx, n_const < (1u << 16) && n_instr < (1u << 24) && n_s2 < (1u << 16) && zpi_program_fixed_table(h_program, program_words, &fxc),
+           "constraint program length does not match its header");
+    ZP_ARG(ctx, (size_t)n_pubs == n_pub_prog, "number of public inputs does not match the program");
+    ZP_ARG(ctx, W >= 1 && W < 4096 && W2 < 4096 && K >= 1 && Q >= 1 && Q <= 16, "program dimensions out of range");
+    ZP_ARG(ctx, logn >= 1 && logb >= 1 && logn + logb <= 30 && fri_logf >= 1 && fri_logf <= 4 && fri_final_log >= 0 && fri_final_log < logn &&
+                    n_queries >= 1 && n_queries <= 4096 && pow_bits >= 0 && pow_bits <= 40, "STARK parameters out of range");
+    ZP_ARG(ctx, Q <= ((size_t)1 << logb), "the blow-up must cover the quotient degree");
+    ZP_ARG(ctx, (n_s2 == 0) == (W2 == 0) && (n_s2 == 0 || n_chal == 3), "stage-2 table and widths disagree");
+    for (int i = 0; i < n_pubs; i++) ZP_ARG(ctx, h_pubs[i] < GL_P, "public input not canonical");
+    const u64 *stage2 = (const u64 *)h_program + 12 + n_const + n_instr;
+    size_t w2sum = 0;
+    for (size_t k = 0; k < n_s2; k++) {
+        const u64 kind = stage2[4 * k];
+        ZP_ARG(ctx, kind == 1 || kind == 2, "unknown stage-2 argument");
+        ZP_ARG(ctx, stage2[4 * k + 1] < W && stage2[4 * k + 2] < W && stage2[4 * k + 3] < W, "stage-2 column out of range");
+        w2sum += kind == 1 ? 3 : 9;
+    }
+    ZP_ARG(ctx, w2sum == W2, "stage-2 width does not match its table");
+    const int logm = logn + logb;
+    const size_t N = (size_t)1 << logn, M = (size_t)1 << logm, Wt = W + W2, b = (size_t)1 << logb;
+    ZP_ARG(ctx, G >= 1 && W % (size_t)G == 0 && M % (size_t)G == 0, "trace columns and domain rows must split evenly over the ranks");
+    const size_t wl = W / G, nloc = M / G, r0 = (size_t)rank * nloc;
+    ZP_ARG(ctx, nloc >= b && nloc % b == 0 && nloc >= 2, "row shards must hold whole blow-up groups");
+    ZP_ARG(ctx, trace_words == (wl << logn), "trace_words must be (W / world) * 2^logn: this rank's columns");
+    const u64 shift = ctx->coset_shift, root32 = ctx->root32;
+    const u64 wN = gl_root(root32, logn);
+    DevBufs dev(ctx);
+
+    uint8_t dg[32];
+    Sha256::digest((const uint8_t *)h_program, program_words * 8, dg);
+    char dg_hex[17];
+    for (int i = 0; i < 8; i++) snprintf(dg_hex + 2 * i, 3, "%02x", dg[i]);
+    std::vector<u64> first = {(u64)logn, (u64)logb, (u64)W, (u64)W2, (u64)fri_logf, (u64)fri_final_log, (u64)n_queries, (u64)pow_bits, root32, shift};
+    for (int i = 0; i < 4; i++) {
+        u64 wd = 0;
+        for (int k = 0; k < 8; k++) wd |= (u64)dg[8 * i + k] << (8 * k);
+        first.push_back(wd % GL_P);
+    }
+    first.push_back((u64)n_pubs);
+    Transcript tr(ctx, bn);
+    const Trees T{ctx, bn};
+    if (n_pubs <= 64) {
+        for (int i = 0; i < n_pubs; i++) first.push_back(h_pubs[i]);
+        tr.absorb(first);
+    } else {            // long public vectors enter through their commitment (replicated: a few thousand permutations at most)
+        tr.absorb(first);
+        size_t Mp = 2;
+        while (Mp * 8 < (size_t)n_pubs) Mp <<= 1;
+        std::vector<u64> mat(Mp * 8, 0);
+        for (int i = 0; i < n_pubs; i++) mat[i] = h_pubs[i];
+        u64 *dmat, *dtree;
+        PV_TRY(dev.alloc(mat.size(), &dmat));
+        PV_TRY(dev.alloc(T.tree_words(Mp), &dtree));
+        PV_TRY(zp_h2d(ctx, dmat, mat.data(), mat.size() * 8));
+        PV_TRY(zp_merkle_commit_rows(ctx, (const uint64_t *)dmat, Mp, 8, (uint64_t *)dtree));
+        u64 rootp[4];
+        PV_TRY(T.root(dtree, Mp, rootp));
+        dev.release(dmat);
+        dev.release(dtree);
+        tr.absorb_root(rootp);
+    }
+
+    // 1. trace: LDE of my columns, ONE exchange columns -> rows, local subtree, sub-roots
+    u64 *ext, *coef_l, *tree1;
+    ShardTop top1, top2, topq;
+    PV_TRY(dev.alloc(Wt * nloc, &ext));            // [Wt][nloc]: ALL columns (trace, then stage 2), my rows
+    PV_TRY(dev.alloc(wl * N, &coef_l));            // coefficients of MY columns: they never move
+    {
+        u64 *extc, *pack;
+        PV_TRY(dev.alloc(wl * M, &extc));
+        PV_TRY(dev.alloc(wl * M, &pack));
+        PV_TRY(zp_lde(ctx, d_trace, (uint64_t *)extc, (uint64_t *)coef_l, logn, logb, (int32_t)wl, shift));
+        PV_TRY(zp_exchange_columns_to_rows(comm, (const uint64_t *)extc, wl, M, (uint64_t *)pack, (uint64_t *)ext));
+        PV_TRY(zp_sync(ctx));
+        dev.release(extc);
+        dev.release(pack);
+    }
+    PV_TRY(shard_commit(comm, ctx, dev, ext, nloc, (int)W, G, &tree1, &top1));
+    tr.absorb_root(top1.root);
+    std::vector<u64> pubchal(h_pubs, h_pubs + n_pubs);
+    u64 *tree2 = nullptr, *coef2 = nullptr;
+    if (n_s2) {
+        const e3 chal = tr.challenge();
+        PV_TRY(tr.rc);
+        u64 *s2, *colb, *ext2;
+        PV_TRY(dev.alloc(W2 * N, &s2));
+        PV_TRY(dev.alloc(3 * N, &colb));           // the (at most three) witness columns an argument reads, on every rank
+        auto column = [&](u64 idx, u64 *dst) -> int32_t {       // broadcast from the rank that owns it
+            const int owner = (int)(idx / wl);
+            if (owner == rank) PV_TRY(zp_d2d(ctx, dst, d_trace + (idx % wl) * N, N * 8));
+            return zp_comm_broadcast(comm, (uint64_t *)dst, N, owner);
+        };
+        size_t at = 0;
+        for (size_t k = 0; k < n_s2; k++) {
+            const u64 *st = stage2 + 4 * k;
+            PV_TRY(column(st[1], colb));
+            PV_TRY(column(st[2], colb + N));
+            if (st[0] == 1) {
+                PV_TRY(zp_grand_product(ctx, (const uint64_t *)colb, (const uint64_t *)(colb + N), N, (const uint64_t *)chal.c, (uint64_t *)(s2 + at * N)));
+                at += 3;
+            } else {
+                PV_TRY(column(st[3], colb + 2 * N));
+                PV_TRY(zp_logup_columns(ctx, (const uint64_t *)colb, (const uint64_t *)(colb + N), (const uint64_t *)(colb + 2 * N), N, (const uint64_t *)chal.c,
+                                        (uint64_t *)(s2 + at * N)));
+                at += 9;
+            }
+        }
+        PV_TRY(dev.alloc(W2 * M, &ext2));
+        PV_TRY(dev.alloc(W2 * N, &coef2));
+        PV_TRY(zp_lde(ctx, (const uint64_t *)s2, (uint64_t *)ext2, (uint64_t *)coef2, logn, logb, (int32_t)W2, shift));   // replicated: W2 << W
+        ZP_HIP(ctx, hipMemcpy2DAsync(ext + W * nloc, nloc * 8, ext2 + r0, M * 8, nloc * 8, W2, hipMemcpyDeviceToDevice, ctx->stream));
+        PV_TRY(zp_sync(ctx));
+        dev.release(s2);
+        dev.release(colb);
+        dev.release(ext2);
+        PV_TRY(shard_commit(comm, ctx, dev, ext + W * nloc, nloc, (int)W2, G, &tree2, &top2));
+        tr.absorb_root(top2.root);
+        for (int c = 0; c < 3; c++) pubchal.push_back(chal.c[c]);
+    }
+    const e3 alpha = tr.challenge();
+    PV_TRY(tr.rc);
+
+    // 2. constraint quotient on my rows (+ the b halo rows of the next rank)
+    u64 *dq_l;
+    {
+        const size_t fwords = zp_fixed_columns_words(h_program, program_words, logn, logb);
+        ZP_ARG(ctx, fwords != 0, "fixed column longer than the trace");
+        u64 *fixed, *fx_l;
+        PV_TRY(dev.alloc(fwords, &fixed));
+        PV_TRY(zp_fixed_columns(ctx, h_program, program_words, h_pubs, n_pubs, logn, logb, shift, (uint64_t *)fixed, fwords));
+        // my window of the two selectors, then the (whole, periodic) extra columns: the layout zp_eval_quotient_rows reads
+        PV_TRY(dev.alloc(2 * nloc + (fwords - 2 * M), &fx_l));
+        PV_TRY(zp_d2d(ctx, fx_l, fixed + r0, nloc * 8));
+        PV_TRY(zp_d2d(ctx, fx_l + nloc, fixed + M + r0, nloc * 8));
+        if (fwords > 2 * M) PV_TRY(zp_d2d(ctx, fx_l + 2 * nloc, fixed + 2 * M, (fwords - 2 * M) * 8));
+        std::vector<u64> apow(3 * K);
+        {
+            e3 cur = e3_make(1, 0, 0);
+            for (size_t k = 0; k < K; k++) { memcpy(&apow[3 * k], cur.c, 24); cur = e3_mul(cur, alpha); }
+        }
+        std::vector<u64> zhinv(b);
+        {
+            const u64 sN = gl_pow(shift, (u64)N), wb = gl_root(root32, logb);
+            u64 p = 1;
+            for (size_t j = 0; j < b; j++) { zhinv[j] = gl_inv(gl_sub(gl_mul(sN, p), 1)); p = gl_mul(p, wb); }
+        }
+        PV_TRY(dev.alloc(3 * nloc, &dq_l));
+        if (G == 1) {
+            PV_TRY(zp_eval_quotient_rows(ctx, h_program, program_words, (const uint64_t *)ext, nloc, (const uint64_t *)fx_l, nloc, logm, logb, 0, M,
+                                         (const uint64_t *)pubchal.data(), (int32_t)pubchal.size(), (const uint64_t *)apow.data(),
+                                         (const uint64_t *)zhinv.data(), shift, gl_inv(wN), (uint64_t *)dq_l, nloc));
+        } else {
+            u64 *heads, *allh, *buf;
+            PV_TRY(dev.alloc(Wt * b, &heads));
+            PV_TRY(dev.alloc((size_t)G * Wt * b, &allh));
+            PV_TRY(dev.alloc(Wt * (nloc + b), &buf));
+            ZP_HIP(ctx, hipMemcpy2DAsync(heads, b * 8, ext, nloc * 8, b * 8, Wt, hipMemcpyDeviceToDevice, ctx->stream));     // my first b rows
+            PV_TRY(zp_comm_all_gather(comm, (const uint64_t *)heads, (uint64_t *)allh, Wt * b));
+            ZP_HIP(ctx, hipMemcpy2DAsync(buf, (nloc + b) * 8, ext, nloc * 8, nloc * 8, Wt, hipMemcpyDeviceToDevice, ctx->stream));
+            ZP_HIP(ctx, hipMemcpy2DAsync(buf + nloc, (nloc + b) * 8, allh + (size_t)((rank + 1) % G) * Wt * b, b * 8, b * 8, Wt, hipMemcpyDeviceToDevice,
+                                         ctx->stream));                                                                 // ... of the next rank
+            PV_TRY(zp_eval_quotient_rows(ctx, h_program, program_words, (const uint64_t *)buf, nloc + b, (const uint64_t *)fx_l, nloc, logm, logb, r0,
+                                         nloc, (const uint64_t *)pubchal.data(), (int32_t)pubchal.size(), (const uint64_t *)apow.data(),
+                                         (const uint64_t *)zhinv.data(), shift, gl_inv(wN), (uint64_t *)dq_l, nloc));
+            PV_TRY(zp_sync(ctx));
+            dev.release(heads);
+            dev.release(allh);
+            dev.release(buf);
+        }
+        PV_TRY(zp_sync(ctx));
+        dev.release(fixed);
+        dev.release(fx_l);
+    }
+    // the quotient's coefficients are needed whole (its pieces are slices of them): gather the rows, transform on every rank
+    u64 *dqcoef, *dq_rows = dq_l, *treeq;
+    int q_logn = logm;
+    size_t Wq = 3;
+    {
+        u64 *gath, *dq_full;
+        PV_TRY(dev.alloc((size_t)G * 3 * nloc, &gath));
+        PV_TRY(dev.alloc(3 * M, &dq_full));
+        PV_TRY(zp_comm_all_gather(comm, (const uint64_t *)dq_l, (uint64_t *)gath, 3 * nloc));
+        PV_TRY(shard_join(ctx, gath, dq_full, 3, nloc, G));
+        PV_TRY(dev.alloc(3 * M, &dqcoef));
+        PV_TRY(zp_intt(ctx, (const uint64_t *)dq_full, (uint64_t *)dqcoef, logm, 3));
+        PV_TRY(zp_sync(ctx));
+        dev.release(gath);
+        dev.release(dq_full);
+    }
+    if (Q > 1) {
+        u64 *pcoef, *pad, *pext;
+        PV_TRY(dev.alloc(3 * Q * N, &pcoef));
+        PV_TRY(dev.alloc(3 * Q * M, &pad));
+        PV_TRY(zp_dev_zero(ctx, pad, 3 * Q * M * 8));
+        for (size_t j = 0; j < Q; j++)
+            for (int c = 0; c < 3; c++) {
+                const u64 *src = dqcoef + c * M + j * N;
+                PV_TRY(zp_d2d(ctx, pcoef + (3 * j + c) * N, src, N * 8));
+                PV_TRY(zp_d2d(ctx, pad + (3 * j + c) * M, src, N * 8));
+            }
+        PV_TRY(dev.alloc(3 * Q * M, &pext));
+        PV_TRY(zp_ntt(ctx, (const uint64_t *)pad, (uint64_t *)pext, logm, (int32_t)(3 * Q)));
+        PV_TRY(dev.alloc(3 * Q * nloc, &dq_rows));
+        ZP_HIP(ctx, hipMemcpy2DAsync(dq_rows, nloc * 8, pext + r0, M * 8, nloc * 8, 3 * Q, hipMemcpyDeviceToDevice, ctx->stream));   // my rows of the pieces
+        PV_TRY(zp_sync(ctx));
+        dev.release(pad);
+        dev.release(pext);
+        dev.release(dq_l);
+        dev.release(dqcoef);
+        dqcoef = pcoef;
+        q_logn = logn;
+        Wq = 3 * Q;
+    }
+    PV_TRY(shard_commit(comm, ctx, dev, dq_rows, nloc, (int)Wq, G, &treeq, &topq));
+    tr.absorb_root(topq.root);
+    const e3 zeta = tr.challenge();
+    PV_TRY(tr.rc);
+
+    // 3. out-of-domain evaluations: every rank evaluates ITS coefficient columns, the evaluations are all-gathered
+    const u64 sinv = gl_inv(shift);
+    const e3 zeta_w = e3_scale(zeta, wN);
+    const e3 zs = e3_scale(zeta, sinv), zws = e3_scale(zeta_w, sinv);
+    std::vector<u64> ev_all((Wt + Wq) * 3), ev_next(Wt * 3);
+    {
+        std::vector<u64> mine(2 * wl * 3), all((size_t)G * 2 * wl * 3);
+        PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef_l, logn, (int32_t)wl, (const uint64_t *)zs.c, (uint64_t *)mine.data()));
+        PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef_l, logn, (int32_t)wl, (const uint64_t *)zws.c, (uint64_t *)(mine.data() + wl * 3)));
+        u64 *dmine, *dall;
+        PV_TRY(dev.alloc(mine.size(), &dmine));
+        PV_TRY(dev.alloc(all.size(), &dall));
+        PV_TRY(zp_h2d(ctx, dmine, mine.data(), mine.size() * 8));
+        PV_TRY(zp_comm_all_gather(comm, (const uint64_t *)dmine, (uint64_t *)dall, mine.size()));
+        PV_TRY(zp_d2h(ctx, all.data(), dall, all.size() * 8));
+        dev.release(dmine);
+        dev.release(dall);
+        for (int h = 0; h < G; h++) {
+            memcpy(&ev_all[(size_t)h * wl * 3], &all[(size_t)h * 2 * wl * 3], wl * 24);
+            memcpy(&ev_next[(size_t)h * wl * 3], &all[(size_t)h * 2 * wl * 3 + wl * 3], wl * 24);
+        }
+    }
+    if (W2) {
+        PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef2, logn, (int32_t)W2, (const uint64_t *)zs.c, (uint64_t *)(ev_all.data() + W * 3)));
+        PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef2, logn, (int32_t)W2, (const uint64_t *)zws.c, (uint64_t *)(ev_next.data() + W * 3)));
+    }
+    PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)dqcoef, q_logn, (int32_t)Wq, (const uint64_t *)zs.c, (uint64_t *)(ev_all.data() + Wt * 3)));
+    tr.absorb(ev_all);
+    tr.absorb(ev_next);
+    const e3 gamma = tr.challenge();
+    PV_TRY(tr.rc);
+
+    // 4. DEEP quotient on my rows, gathered before FRI
+    u64 *df;
+    {
+        u64 *df_l, *gath;
+        PV_TRY(dev.alloc(3 * nloc, &df_l));
+        PV_TRY(dev.alloc((size_t)G * 3 * nloc, &gath));
+        PV_TRY(dev.alloc(3 * M, &df));
+        PV_TRY(zp_deep_quotient_rows(ctx, (const uint64_t *)ext, (int32_t)Wt, nloc, (const uint64_t *)dq_rows, (int32_t)Wq, nloc, logm, r0, nloc, (int32_t)Wt,
+                                     (const uint64_t *)zeta.c, (const uint64_t *)zeta_w.c, (const uint64_t *)gamma.c, (const uint64_t *)ev_all.data(),
+                                     (const uint64_t *)ev_next.data(), shift, (uint64_t *)df_l, nloc));
+        PV_TRY(zp_comm_all_gather(comm, (const uint64_t *)df_l, (uint64_t *)gath, 3 * nloc));
+        PV_TRY(shard_join(ctx, gath, df, 3, nloc, G));
+        PV_TRY(zp_sync(ctx));
+        dev.release(df_l);
+        dev.release(gath);
+    }
+
+    // 5. FRI (replicated: a layer of the DEEP quotient is 3 columns)
+    struct Layer { int lg, f; u64 *tree, *data; u64 root[4]; };
+    std::vector<Layer> layers;
+    int cur = logm;
+    u64 cur_shift = shift;
+    u64 *dlayer = df;
+    while (cur > fri_final_log + logb) {
+        const int f = fri_logf < cur - (fri_final_log + logb) ? fri_logf : cur - (fri_final_log + logb);
+        Layer L;
+        L.lg = cur; L.f = f; L.data = dlayer;
+        const size_t m = (size_t)1 << (cur - f);
+        PV_TRY(dev.alloc(T.tree_words(m), &L.tree));
+        PV_TRY(T.commit(dlayer, m, 3 << f, L.tree));
+        PV_TRY(T.root(L.tree, m, L.root));
+        tr.absorb_root(L.root);
+        const e3 beta = tr.challenge();
+        PV_TRY(tr.rc);
+        u64 *next;
+        PV_TRY(dev.alloc((size_t)3 << (cur - f), &next));
+        PV_TRY(zp_fri_fold(ctx, (const uint64_t *)dlayer, (uint64_t *)next, cur, f, (const uint64_t *)beta.c, cur_shift));
+        layers.push_back(L);
+        dlayer = next;
+        cur_shift = gl_pow(cur_shift, (u64)1 << f);
+        cur -= f;
+    }
+    const int final_log = cur;
+    std::vector<u64> final_l((size_t)3 << final_log);
+    PV_TRY(zp_d2h(ctx, final_l.data(), dlayer, final_l.size() * 8));
+    for (int c = 0; c < 3; c++) tr.absorb(&final_l[(size_t)c << final_log], (size_t)1 << final_log);
+
+    // 6. proof of work, then the queries: the owner of a row answers, one all-reduce spreads the answers
+    u64 nonce = 0;
+    if (pow_bits) {
+        const std::vector<u64> seed = tr.squeeze(4);
+        PV_TRY(tr.rc);
+        PV_TRY(zp_pow_grind(ctx, (const uint64_t *)seed.data(), pow_bits, (uint64_t *)&nonce));
+        tr.absorb(&nonce, 1);
+    }
+    std::vector<u64> qidx = tr.squeeze((size_t)n_queries);
+    PV_TRY(tr.rc);
+    for (u64 &v : qidx) v &= (M - 1);
+    const size_t nq = (size_t)n_queries, depth = (size_t)logm;
+    size_t dl = 0;
+    while (((size_t)1 << dl) < nloc) dl++;
+    const size_t pw = depth * 4;
+    std::vector<u64> v_tr(nq * W), p_tr(nq * pw), v_s2(nq * W2), p_s2(n_s2 ? nq * pw : 0), v_q(nq * Wq), p_q(nq * pw);
+    {
+        std::vector<int> own;
+        std::vector<u64> lidx;
+        for (size_t i = 0; i < nq; i++)
+            if (qidx[i] >= r0 && qidx[i] < r0 + nloc) { own.push_back((int)i); lidx.push_back(qidx[i] - r0); }
+        const size_t no = own.size();
+        // layout of the reduced vector: per query [W | W2 | Wq values | dl*4 path words of each of the (2 or 3) trees]
+        const size_t ntree = n_s2 ? 3 : 2, per = W + W2 + Wq + ntree * dl * 4;
+        std::vector<u64> red(nq * per, 0), tv(no * (W > Wq ? (W > W2 ? W : W2) : (Wq > W2 ? Wq : W2))), tp(no * dl * 4);
+        auto fill = [&](const u64 *mat, size_t Wc, size_t voff, const u64 *tree, size_t poff) -> int32_t {
+            if (!no) return ZP_OK;
+            PV_TRY(zp_gather_rows(ctx, (const uint64_t *)mat, nloc, (int32_t)Wc, (const uint64_t *)lidx.data(), (int32_t)no, (uint64_t *)tv.data()));
+            PV_TRY(zp_merkle_open_batch(ctx, (const uint64_t *)tree, nloc, (const uint64_t *)lidx.data(), (int32_t)no, (uint64_t *)tp.data()));
+            for (size_t k = 0; k < no; k++) {
+                memcpy(&red[(size_t)own[k] * per + voff], &tv[k * Wc], Wc * 8);
+                memcpy(&red[(size_t)own[k] * per + W + W2 + Wq + poff], &tp[k * dl * 4], dl * 32);
+            }
+            return ZP_OK;
+        };
+        PV_TRY(fill(ext, W, 0, tree1, 0));
+        if (n_s2) PV_TRY(fill(ext + W * nloc, W2, W, tree2, dl * 4));
+        PV_TRY(fill(dq_rows, Wq, W + W2, treeq, (ntree - 1) * dl * 4));
+        u64 *dred;
+        PV_TRY(dev.alloc(red.size(), &dred));
+        PV_TRY(zp_h2d(ctx, dred, red.data(), red.size() * 8));
+        PV_TRY(zp_comm_all_reduce_sum(comm, (uint64_t *)dred, red.size()));
+        PV_TRY(zp_d2h(ctx, red.data(), dred, red.size() * 8));
+        dev.release(dred);
+        auto paths = [&](std::vector<u64> &dst, size_t poff, const ShardTop &top) {
+            for (size_t i = 0; i < nq; i++) {
+                memcpy(&dst[i * pw], &red[i * per + W + W2 + Wq + poff], dl * 32);
+                u64 node = qidx[i] >> dl;
+                for (size_t l = 0; l < top.levels.size(); l++) {         // the top of the path comes from the all-gathered sub-roots
+                    memcpy(&dst[i * pw + (dl + l) * 4], &top.levels[l][(size_t)(node ^ 1) * 4], 32);
+                    node >>= 1;
+                }
+            }
+        };
+        for (size_t i = 0; i < nq; i++) {
+            memcpy(&v_tr[i * W], &red[i * per], W * 8);
+            if (W2) memcpy(&v_s2[i * W2], &red[i * per + W], W2 * 8);
+            memcpy(&v_q[i * Wq], &red[i * per + W + W2], Wq * 8);
+        }
+        paths(p_tr, 0, top1);
+        if (n_s2) paths(p_s2, dl * 4, top2);
+        paths(p_q, (ntree - 1) * dl * 4, topq);
+    }
+    struct FriOpen { std::vector<u64> vals, paths; size_t width, depth, pw, m; };
+    std::vector<FriOpen> fo(layers.size());
+    {
+        std::vector<u64> pos = qidx;
+        for (size_t li = 0; li < layers.size(); li++) {
+            const Layer &L = layers[li];
+            const size_t m = (size_t)1 << (L.lg - L.f);
+            for (u64 &p : pos) p &= (m - 1);
+            fo[li].width = (size_t)3 << L.f;
+            fo[li].depth = (size_t)(L.lg - L.f);
+            fo[li].m = m;
+            fo[li].pw = T.path_words(m);
+            fo[li].vals.resize(nq * fo[li].width);
+            fo[li].paths.resize(nq * fo[li].pw);
+            PV_TRY(zp_gather_rows(ctx, (const uint64_t *)L.data, m, (int32_t)fo[li].width, (const uint64_t *)pos.data(), n_queries, (uint64_t *)fo[li].vals.data()));
+            PV_TRY(T.open(L.tree, m, pos.data(), n_queries, fo[li].paths.data()));
+        }
+    }
+
+    // the proof text: exactly what zp_stark_prove writes
+    std::string s;
+    s.reserve(nq * (Wt + Wq + 64) * 24 + (1 << 16));
+    s += "{\"air\":\"";
+    s += air_name;
+    s += "\",\"air_digest\":\"";
+    s += dg_hex;
+    s += "\",\"params\":{\"logn\":";
+    j_u64(s, (u64)logn); s += ",\"logb\":"; j_u64(s, (u64)logb); s += ",\"fri_logf\":"; j_u64(s, (u64)fri_logf);
+    s += ",\"fri_final_log\":"; j_u64(s, (u64)fri_final_log); s += ",\"n_queries\":"; j_u64(s, (u64)n_queries);
+    s += ",\"pow_bits\":"; j_u64(s, (u64)pow_bits);
+    s += "},\"root32\":"; j_u64(s, root32);
+    s += ",\"shift\":"; j_u64(s, shift);
+    s += ",\"publics\":"; j_list(s, (const u64 *)h_pubs, (size_t)n_pubs);
+    s += ",\"roots\":{\"trace\":"; j_root(s, top1.root, bn);
+    s += ",\"quotient\":"; j_root(s, topq.root, bn);
+    if (n_s2) { s += ",\"stage2\":"; j_root(s, top2.root, bn); }
+    s += "},\"evals\":{\"z\":"; j_e3list(s, ev_all);
+    s += ",\"zw\":"; j_e3list(s, ev_next);
+    s += "},\"fri\":{\"roots\":[";
+    for (size_t li = 0; li < layers.size(); li++) { if (li) s += ','; j_root(s, layers[li].root, bn); }
+    s += "],\"final\":[";
+    for (int c = 0; c < 3; c++) { if (c) s += ','; j_list(s, &final_l[(size_t)c << final_log], (size_t)1 << final_log); }
+    s += "]},\"queries\":[";
+    for (size_t i = 0; i < nq; i++) {
+        if (i) s += ',';
+        s += "{\"index\":"; j_u64(s, qidx[i]);
+        s += ",\"trace\":"; j_opening(s, &v_tr[i * W], W, &p_tr[i * pw], depth);
+        s += ",\"quotient\":"; j_opening(s, &v_q[i * Wq], Wq, &p_q[i * pw], depth);
+        if (n_s2) { s += ",\"stage2\":"; j_opening(s, &v_s2[i * W2], W2, &p_s2[i * pw], depth); }
+        s += ",\"fri\":[";
+        for (size_t li = 0; li < layers.size(); li++) {
+            if (li) s += ',';
+            j_opening(s, &fo[li].vals[i * fo[li].width], fo[li].width, &fo[li].paths[i * fo[li].pw], fo[li].depth);
+        }
+        s += "]}";
+    }
+    s += ']';
+    if (pow_bits) { s += ",\"pow_nonce\":"; j_u64(s, nonce); }
+    s += '}';
+    char *buf = (char *)malloc(s.size() + 1);
+    if (!buf) { ctx->err = "out of host memory for the proof text"; return ZP_ERR_NOMEM; }
+    memcpy(buf, s.data(), s.size() + 1);
+    *out_json = buf;
+    *out_len = s.size();
+    return ZP_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t zp_stark_prove_sharded(zp_comm *comm, const char *air_name, const uint64_t *h_program, size_t program_words,
+                                          const uint64_t *d_trace_local, size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn,
+                                          int32_t logb, int32_t fri_logf, int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, char **out_json,
+                                          size_t *out_len) {
+    if (!comm) return ZP_ERR_ARG;
+    zp_ctx *ctx = zpi_comm_ctx(comm);
+    if (out_json) *out_json = nullptr;
+    if (out_len) *out_len = 0;
+    try {
+        return prove_sharded_impl(comm, ctx, air_name, h_program, program_words, d_trace_local, trace_words, h_pubs, n_pubs, logn, logb, fri_logf,
+                                  fri_final_log, n_queries, pow_bits, out_json, out_len);
+    } catch (const std::bad_alloc &) {
+        try { ctx->err = "out of host memory while building the proof"; } catch (...) {}
+        return ZP_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        try { ctx->err = std::string("internal error: ") + e.what(); } catch (...) {}
+        return ZP_ERR_INTERNAL;
+    } catch (...) {
+        return ZP_ERR_INTERNAL;
+    }
+}

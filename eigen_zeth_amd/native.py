@@ -107,6 +107,12 @@ SIGNATURES = {
     "zp_comm_all_to_all": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
     "zp_comm_all_gather": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
     "zp_comm_broadcast": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32]),
+    "zp_comm_all_reduce_sum": (C.c_int32, [_vp, _vp, C.c_size_t]),
+    "zp_comm_group_create": (C.c_int32, [C.c_int32, C.POINTER(_vp)]),
+    "zp_comm_group_destroy": (C.c_int32, [_vp]),
+    "zp_comm_create_local": (C.c_int32, [_vp, C.c_int32, _vp, C.POINTER(_vp)]),
+    "zp_stark_prove_sharded": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "zp_exchange_columns_to_rows": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp]),
     "zp_merkle_commit_sharded": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp, _u64p]),
     "zp_msm_bn254": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
@@ -237,15 +243,54 @@ def comm_unique_id():
     return bytes(buf)
 
 
-class Comm:
-    """zp_comm: this rank's Prover joined to an RCCL communicator (one process per GPU); collectives on the ctx stream"""
+class CommGroup:
+    """zp_comm_group: ranks that live in one process (threads, one Prover each); Comm(prover, rank, world, group=...) joins it"""
 
-    def __init__(self, prover, rank, world, unique_id):
+    def __init__(self, world):
+        self.world = world
+        h = _vp()
+        rc = load_library().zp_comm_group_create(world, C.byref(h))
+        if rc != 0:
+            raise ZpError(rc, "zp_comm_group_create: world must be a power of two <= 64")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            load_library().zp_comm_group_destroy(self.h)
+            self.h = None
+
+
+class Comm:
+    """zp_comm: this rank's Prover joined to an RCCL communicator (one process per GPU) or to an in-process CommGroup;
+    collectives on the ctx stream"""
+
+    def __init__(self, prover, rank, world, unique_id=None, group=None):
         self.prover, self.rank, self.world = prover, rank, world
         h = _vp()
-        idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
-        prover._chk(prover.lib.zp_comm_create(prover.ctx, rank, world, idb, C.byref(h)))
+        if group is not None:
+            assert group.world == world
+            prover._chk(prover.lib.zp_comm_create_local(prover.ctx, rank, group.h, C.byref(h)))
+        else:
+            idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+            prover._chk(prover.lib.zp_comm_create(prover.ctx, rank, world, idb, C.byref(h)))
         self.h = h
+
+    def all_reduce_sum(self, d_buf, words):
+        self.prover._chk(self.prover.lib.zp_comm_all_reduce_sum(self.h, _ptr(d_buf), words))
+
+    def stark_prove_sharded(self, air_name, program, d_trace_local, pubs, logn, logb, fri_logf, fri_final_log, n_queries, pow_bits):
+        """zp_stark_prove_sharded: this rank's W/world columns in, the whole proof text out (the same on every rank)"""
+        prog = np.ascontiguousarray(np.asarray(program, dtype=np.uint64))
+        pb = np.ascontiguousarray(np.asarray(list(pubs) + [0], dtype=np.uint64))
+        out, n = C.c_void_p(), C.c_size_t(0)
+        words = d_trace_local.n if isinstance(d_trace_local, DeviceBuffer) else (int(prog[1]) // self.world) << logn
+        self.prover._chk(self.prover.lib.zp_stark_prove_sharded(self.h, air_name.encode(), prog.ctypes.data, prog.size, _ptr(d_trace_local), words,
+                                                                pb.ctypes.data, len(pubs), logn, logb, fri_logf, fri_final_log, n_queries, pow_bits,
+                                                                C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out.value, n.value).decode()
+        finally:
+            self.prover.lib.zp_free_buffer(out)
 
     def close(self):
         if self.h:

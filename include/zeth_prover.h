@@ -311,8 +311,21 @@ int32_t zp_synth_g1_points(uint64_t start, size_t n, uint32_t *h_points, int32_t
  *                                 single-GPU root over all G*Wl columns); d_tree_local = this rank's subtree over its M/G rows,
  *                                 (2M/G - 1) * 4 words; the G sub-roots are all-gathered, the top log2 G levels hashed on
  *                                 every rank.  Constraint / DEEP stages of a sharded proof take row windows:
- *                                 zp_eval_quotient_rows, zp_deep_quotient_rows.                                              */
+ *                                 zp_eval_quotient_rows, zp_deep_quotient_rows.
+ *   zp_comm_all_reduce_sum      : buf <- sum over the ranks of buf (64-bit wrapping sums)
+ * A communicator WITHOUT RCCL for ranks that live in ONE process (threads, one ctx each, on one GPU or several): create a
+ * group (zp_comm_group_create(world)), then every rank's zp_comm_create_local(ctx, rank, group); its collectives are device-to-
+ * device copies around a thread barrier.  RCCL refuses two ranks on one device, so this is how the multi-rank logic of the sharded
+ * entry points is exercised on a one-GPU box; it is also a transport for a single-process multi-GPU host.
+ *   zp_stark_prove_sharded      : ONE chunk STARK over the ranks of a communicator: every rank passes ITS W/world trace columns
+ *                                 (d_trace_local u64[W/world][2^logn], trace_words = (W/world) << logn; rank r owns columns
+ *                                 [r W/world, (r+1) W/world)), all other arguments as zp_stark_prove, identical on every rank;
+ *                                 every rank receives the same proof text, byte for byte what zp_stark_prove writes for the whole
+ *                                 trace on one GPU.  Column-sharded: LDE, out-of-domain evaluations; row-sharded: the three
+ *                                 commitments, the constraint quotient (with a blow-up halo), the DEEP quotient; replicated: the
+ *                                 stage-2 columns, FRI.  Goldilocks-hash mode.  Collective: every rank must call it.                */
 typedef struct zp_comm zp_comm;
+typedef struct zp_comm_group zp_comm_group;
 int32_t zp_comm_unique_id(uint8_t *out128);
 int32_t zp_comm_create(zp_ctx *ctx, int32_t rank, int32_t world, const uint8_t *id128, zp_comm **out);
 int32_t zp_comm_destroy(zp_comm *comm);
@@ -321,6 +334,14 @@ int32_t zp_comm_world(const zp_comm *comm);
 int32_t zp_comm_all_to_all(zp_comm *comm, const uint64_t *d_send, uint64_t *d_recv, size_t words_per_peer);
 int32_t zp_comm_all_gather(zp_comm *comm, const uint64_t *d_send, uint64_t *d_recv, size_t words);
 int32_t zp_comm_broadcast(zp_comm *comm, uint64_t *d_buf, size_t words, int32_t root);
+int32_t zp_comm_all_reduce_sum(zp_comm *comm, uint64_t *d_buf, size_t words);
+int32_t zp_comm_group_create(int32_t world, zp_comm_group **out);
+int32_t zp_comm_group_destroy(zp_comm_group *group);
+int32_t zp_comm_create_local(zp_ctx *ctx, int32_t rank, zp_comm_group *group, zp_comm **out);
+int32_t zp_stark_prove_sharded(zp_comm *comm, const char *air_name, const uint64_t *h_program, size_t program_words,
+                               const uint64_t *d_trace_local, size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn,
+                               int32_t logb, int32_t fri_logf, int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, char **out_json,
+                               size_t *out_len);
 int32_t zp_exchange_columns_to_rows(zp_comm *comm, const uint64_t *d_cols, size_t Wl, size_t M, uint64_t *d_pack, uint64_t *d_rows);
 int32_t zp_merkle_commit_sharded(zp_comm *comm, const uint64_t *d_cols, size_t M, int32_t Wl, uint64_t *d_tree_local, uint64_t *h_root4);
 

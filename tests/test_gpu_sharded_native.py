@@ -1,0 +1,145 @@
+"""zp_stark_prove_sharded -- ONE chunk STARK over the ranks of a communicator, behind one C-ABI call per rank (csrc/prove.hip) --
+and the in-process communicator (zp_comm_group_create / zp_comm_create_local: collectives as device copies around a thread
+barrier).  RCCL refuses two ranks on one device, so the multi-rank logic runs here as G THREADS on the one GPU, each with its
+own ctx: every rank must return the text zp_stark_prove writes for the whole trace, byte for byte, which the independent
+verifier accepts.  With a world of one the same entry point also runs on RCCL.  Serves GenChunkProof for traces spread over the
+GPUs of a node (src/prover/provider.rs:358-390; BASELINE.json configs[3])."""
+import json
+import threading
+
+import numpy as np
+import pytest
+
+from eigen_zeth_amd import native
+from eigen_zeth_amd.stark import air as AIR
+from eigen_zeth_amd.stark import prover as PR
+from oracle import oracle as O
+from oracle import stark_verify as V
+
+pytestmark = pytest.mark.gpu
+
+
+def run_ranks(G, fn):
+    """fn(rank, prover, comm) on G threads, one Prover (ctx) + one local Comm each; returns the list of results"""
+    group = native.CommGroup(G)
+    out, err = [None] * G, [None] * G
+
+    def body(r):
+        p = None
+        try:
+            p = native.Prover(0)
+            c = native.Comm(p, r, G, group=group)
+            out[r] = fn(r, p, c)
+            c.close()
+        except BaseException as e:      # noqa: a failing rank must not leave the others waiting silently
+            err[r] = e
+        finally:
+            if p is not None:
+                p.close()
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    group.close()
+    assert not any(t.is_alive() for t in ts), "a rank is stuck in a collective"
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_local_group_collectives(G):
+    w = 1 << 10
+
+    def fn(r, p, c):
+        x = O.random_field((G, w), 100 + r)
+        d_x, d_y = p.upload(x), p.alloc(G * w)
+        c.all_to_all(d_x, d_y, w)
+        a2a = p.download(d_y, (G, w))
+        c.all_gather(d_x, d_y, w)                  # first row of every rank
+        ag = p.download(d_y, (G, w))
+        d_b = p.upload(x[0])
+        c.broadcast(d_b, w, G - 1)
+        bc = p.download(d_b, (w,))
+        one = np.zeros(w, dtype=np.uint64)
+        one[r::G] = x[1, r::G]                     # disjoint supports: the sum is the union
+        d_s = p.upload(one)
+        c.all_reduce_sum(d_s, w)
+        return x, a2a, ag, bc, p.download(d_s, (w,))
+    res = run_ranks(G, fn)
+    xs = [r[0] for r in res]
+    for r in range(G):
+        _, a2a, ag, bc, sm = res[r]
+        for h in range(G):
+            assert (a2a[h] == xs[h][r]).all()
+            assert (ag[h] == xs[h][0]).all()
+        assert (bc == xs[G - 1][0]).all()
+        want = np.zeros(w, dtype=np.uint64)
+        for h in range(G):
+            want[h::G] = xs[h][1, h::G]
+        assert (sm == want).all()
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_sharded_commit_over_local_ranks_equals_single_root(tables, G, prover):
+    rc, mds = tables
+    M, W = 1 << 12, 8
+    cols = O.random_field((W, M), 55)
+    want = [int(v) for v in O.merkle_commit(cols, rc, mds)[-1]]
+    wl = W // G
+
+    def fn(r, p, c):
+        d_cols, d_tree = p.upload(cols[r * wl:(r + 1) * wl]), p.alloc((2 * (M // G) - 1) * 4)
+        return c.merkle_commit_sharded(d_cols, M, wl, d_tree)
+    assert all(root == want for root in run_ranks(G, fn))
+
+
+CASES = [("chunk16", 10, 1, 2, 3, 8, 8, 2), ("chunk16", 10, 1, 2, 3, 8, 8, 4), ("wide8", 9, 2, 3, 3, 6, 0, 4), ("cubic", 8, 1, 2, 3, 6, 4, 2),
+         ("fib", 7, 1, 2, 3, 5, 0, 2), ("periodic9", 9, 2, 2, 3, 6, 4, 1), ("chunk64", 12, 1, 3, 4, 12, 8, 4)]
+
+
+@pytest.mark.parametrize("airname,logn,logb,logf,final_log,nq,pow_bits,G", CASES)
+def test_sharded_prover_over_local_ranks_equals_the_single_gpu_proof(prover, tables, airname, logn, logb, logf, final_log, nq, pow_bits, G):
+    """stage-2 arguments (permutation + LogUp: broadcast witness columns), a two-piece quotient (`cubic`), blow-up 4, identity
+    leaves (`fib`), periodic fixed columns (row windows of the selectors + whole periodic columns), 2 and 4 ranks"""
+    rc, mds = tables
+    if airname == "cubic":
+        air = AIR.get_air("cubic")
+        tr, pub = AIR.cubic_witness(logn, 5)
+    elif airname.startswith("periodic"):
+        air = AIR.periodic_air(logn)
+        tr, pub = AIR.periodic_witness(logn, 5)
+    else:
+        air = AIR.get_air(airname)
+        tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 21)
+    if air.width % G:
+        pytest.skip("columns do not split over %d ranks" % G)
+    d = prover.upload(tr)
+    single = prover.stark_prove(air.name, air.program(), d, [int(v) for v in pub], logn, logb, logf, final_log, nq, pow_bits)
+    d.free()
+    wl = air.width // G
+
+    def fn(r, p, c):
+        d_l = p.upload(np.ascontiguousarray(tr[r * wl:(r + 1) * wl]))
+        return c.stark_prove_sharded(air.name, air.program(), d_l, [int(v) for v in pub], logn, logb, logf, final_log, nq, pow_bits)
+    texts = run_ranks(G, fn)
+    assert all(t == single for t in texts)
+    params = PR.StarkParams(logn, logb, logf, final_log, nq, pow_bits)
+    assert V.verify(json.loads(texts[-1]), air.program(), rc, mds, V.expectation(params.to_dict()))
+
+
+def test_sharded_prover_on_rccl_with_a_world_of_one(prover, tables):
+    """the same entry point on a real RCCL communicator (one rank on the one-GPU box; the driver's multi-GPU node widens it through
+    host/prove_chunk --world)"""
+    air = AIR.get_air("chunk16")
+    tr, pub = native.synth_trace(air.trace_kind, 10, air.width, 3)
+    d = prover.upload(tr)
+    single = prover.stark_prove(air.name, air.program(), d, [int(v) for v in pub], 10, 1, 3, 3, 8, 8)
+    comm = native.Comm(prover, 0, 1, native.comm_unique_id())
+    try:
+        assert comm.stark_prove_sharded(air.name, air.program(), d, [int(v) for v in pub], 10, 1, 3, 3, 8, 8) == single
+    finally:
+        comm.close()
+        d.free()
