@@ -13,6 +13,11 @@ extern "C" {
 
 const char *zp_version(void) { return "zethprover-mi355x 0.1 (gfx950)"; }
 
+int32_t zp_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int32_t zp_create(zp_ctx **out, int32_t device) {
     if (!out) return ZP_ERR_ARG;
     *out = nullptr;

@@ -38,6 +38,7 @@ SIGNATURES = {
     "zp_destroy": (None, [_vp]),
     "zp_last_error": (C.c_char_p, [_vp]),
     "zp_version": (C.c_char_p, []),
+    "zp_device_count": (C.c_int32, []),
     "zp_set_stream": (C.c_int32, [_vp, _vp]),
     "zp_get_stream": (C.c_int32, [_vp, C.POINTER(C.c_void_p)]),
     "zp_sync": (C.c_int32, [_vp]),
@@ -232,6 +233,11 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def device_count():
+    """visible HIP devices, through the library (no torch: a process that loads the system RCCL must not import torch's copy later)"""
+    return int(load_library().zp_device_count())
 
 
 def comm_unique_id():

@@ -3,16 +3,22 @@
 // toolchain: load libzethprover.so's entry points, put the witness in HBM, call zp_stark_prove, hand the proof text on.
 // Nothing but include/zeth_prover.h is used -- no Python, no torch, no compiler at run time (the AIR is a data blob).
 //
-// usage: prove_chunk <program.bin> <trace.bin> <publics.bin> <logn> <logb> <fri_logf> <fri_final_log> <n_queries> <pow_bits> <out.json> [air_name]
+// usage: prove_chunk <program.bin> <trace.bin> <publics.bin> <logn> <logb> <fri_logf> <fri_final_log> <n_queries> <pow_bits> <out.json> [air_name
+//                     [rank world id-file]]
+//   with rank / world / id-file: ONE proof over `world` GPUs, one process per GPU (zp_stark_prove_sharded on an RCCL communicator; rank 0
+//   writes the 128-byte RCCL id to <id-file>, the others wait for it).  Rank r reads only ITS W/world columns of trace.bin and drives GPU r;
+//   every rank obtains the same proof text (rank 0 writes <out.json>), byte for byte the single-GPU text.
 //   program.bin : the constraint program blob (u64 words, layout in the header)
 //   trace.bin   : u64[W][2^logn] column-major, canonical values
 //   publics.bin : u64[n_pub]
 // build: make -C host   (g++ -I../include prove_chunk.cpp -L../eigen_zeth_amd/csrc -lzethprover)
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../include/zeth_prover.h"
@@ -41,8 +47,10 @@ int main(int argc, char **argv) {
     const int logn = atoi(argv[4]), logb = atoi(argv[5]), fri_logf = atoi(argv[6]), fri_final_log = atoi(argv[7]), n_queries = atoi(argv[8]),
               pow_bits = atoi(argv[9]);
     const char *air_name = argc > 11 ? argv[11] : "chunk";
+    const bool sharded = argc > 14;
+    const int rank = sharded ? atoi(argv[12]) : 0, world = sharded ? atoi(argv[13]) : 1;
     // the shapes must agree BEFORE anything reaches the GPU: W comes from the program header (word 1), the number of public
-    // inputs from word 4; the library checks trace_words == W << logn again (zp_stark_prove returns ZP_ERR_ARG otherwise)
+    // inputs from word 4; the library checks trace_words again (ZP_ERR_ARG otherwise)
     if (program.size() < 12) { fprintf(stderr, "%s: shorter than a constraint-program header\n", argv[1]); return 2; }
     if (logn < 1 || logn > 30 || trace.size() != (size_t)(program[1] << logn)) {
         fprintf(stderr, "%s: %zu words, the program needs W * 2^logn = %llu * 2^%d\n", argv[2], trace.size(), (unsigned long long)program[1], logn);
@@ -51,21 +59,50 @@ int main(int argc, char **argv) {
     if (pubs.size() != program[4]) { fprintf(stderr, "%s: %zu public inputs, the program declares %llu\n", argv[3], pubs.size(), (unsigned long long)program[4]); return 2; }
     for (uint64_t v : trace)
         if (v >= 0xFFFFFFFF00000001ULL) { fprintf(stderr, "%s: non-canonical trace value (precondition of zp_stark_prove)\n", argv[2]); return 2; }
+    if (world < 1 || rank < 0 || rank >= world || program[1] % (uint64_t)world) { fprintf(stderr, "bad rank / world (the %llu columns must split evenly)\n", (unsigned long long)program[1]); return 2; }
     zp_ctx *ctx = nullptr;
-    CHECK(zp_create(&ctx, 0));
+    CHECK(zp_create(&ctx, rank));                      // one process per GPU: rank r drives device r
+    const size_t wl = (size_t)program[1] / world, words = wl << logn;
+    const uint64_t *mine = trace.data() + (size_t)rank * words;        // this rank's columns (a real host would read only these)
     void *d_trace = nullptr;
-    CHECK(zp_dev_alloc(ctx, trace.size() * 8, &d_trace));
-    CHECK(zp_h2d(ctx, d_trace, trace.data(), trace.size() * 8));
+    CHECK(zp_dev_alloc(ctx, words * 8, &d_trace));
+    CHECK(zp_h2d(ctx, d_trace, mine, words * 8));
     char *json = nullptr;
     size_t len = 0;
-    CHECK(zp_stark_prove(ctx, air_name, program.data(), program.size(), (const uint64_t *)d_trace, trace.size(), pubs.data(), (int32_t)pubs.size(), logn, logb, fri_logf,
-                         fri_final_log, n_queries, pow_bits, &json, &len));
-    FILE *o = fopen(argv[10], "wb");
-    if (!o || fwrite(json, 1, len, o) != len) { fprintf(stderr, "cannot write %s\n", argv[10]); return 2; }
-    fclose(o);
+    zp_comm *comm = nullptr;
+    if (sharded) {
+        uint8_t id[128];
+        if (rank == 0) {
+            CHECK(zp_comm_unique_id(id));
+            FILE *f = fopen(argv[14], "wb");
+            if (!f || fwrite(id, 1, 128, f) != 128) { fprintf(stderr, "cannot write %s\n", argv[14]); return 2; }
+            fclose(f);
+        } else {
+            bool got = false;
+            for (int tries = 0; tries < 600 && !got; tries++) {
+                FILE *f = fopen(argv[14], "rb");
+                got = f && fread(id, 1, 128, f) == 128;
+                if (f) fclose(f);
+                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+            if (!got) { fprintf(stderr, "no RCCL id in %s after 60 s\n", argv[14]); return 2; }
+        }
+        CHECK(zp_comm_create(ctx, rank, world, id, &comm));
+        CHECK(zp_stark_prove_sharded(comm, air_name, program.data(), program.size(), (const uint64_t *)d_trace, words, pubs.data(), (int32_t)pubs.size(), logn,
+                                     logb, fri_logf, fri_final_log, n_queries, pow_bits, &json, &len));
+    } else {
+        CHECK(zp_stark_prove(ctx, air_name, program.data(), program.size(), (const uint64_t *)d_trace, trace.size(), pubs.data(), (int32_t)pubs.size(), logn, logb,
+                             fri_logf, fri_final_log, n_queries, pow_bits, &json, &len));
+    }
+    if (rank == 0) {
+        FILE *o = fopen(argv[10], "wb");
+        if (!o || fwrite(json, 1, len, o) != len) { fprintf(stderr, "cannot write %s\n", argv[10]); return 2; }
+        fclose(o);
+    }
     zp_free_buffer(json);
+    if (comm) zp_comm_destroy(comm);
     zp_dev_free(ctx, d_trace);
     zp_destroy(ctx);
-    printf("proof: %zu bytes -> %s\n", len, argv[10]);
+    printf("rank %d/%d proof: %zu bytes%s%s\n", rank, world, len, rank == 0 ? " -> " : "", rank == 0 ? argv[10] : "");
     return 0;
 }

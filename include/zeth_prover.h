@@ -57,6 +57,7 @@ int32_t zp_create(zp_ctx **out, int32_t device);
 void zp_destroy(zp_ctx *ctx);
 const char *zp_last_error(zp_ctx *ctx);
 const char *zp_version(void);
+int32_t zp_device_count(void);      /* visible HIP devices (0 without a GPU) */
 int32_t zp_set_stream(zp_ctx *ctx, void *hip_stream);
 int32_t zp_get_stream(zp_ctx *ctx, void **hip_stream);
 int32_t zp_sync(zp_ctx *ctx);

@@ -47,11 +47,10 @@ def test_comm_world_of_one_collectives_and_sharded_commit(prover, tables):
 def test_compiled_host_shards_one_commitment_over_the_visible_gpus(prover, tables):
     """host/commit_sharded (C++ on include/zeth_prover.h alone): one process per GPU, RCCL id through a file; every rank prints
     the root a single GPU commits.  World = the number of visible GPUs rounded down to a power of two (1 on the test box)."""
-    import torch
     rc, mds = tables
     exe = os.path.join(ROOT, "host", "commit_sharded")
     assert os.path.exists(exe), "build first: make -C host"
-    n = torch.cuda.device_count()
+    n = native.device_count()       # not torch: its wheel carries its own librccl, a second copy in this process (double free at exit)
     world = 1
     while world * 2 <= min(n, 4):
         world *= 2

@@ -127,3 +127,35 @@ def test_compiled_host_proves_a_chunk_through_the_c_abi(tmp_path, prover, tables
     text = out.read_text()
     assert text == PR.proof_to_json(PR.prove(air, tr, pub, params, HipBackend(prover=prover, quotient="program")))
     assert V.verify(json.loads(text), air.program(), *tables, V.expectation(params.to_dict()))
+
+
+def test_compiled_host_shards_one_proof_over_the_visible_gpus(tmp_path, prover, tables):
+    """host/prove_chunk with rank / world / id-file: one process per GPU on an RCCL communicator, zp_stark_prove_sharded; rank 0's
+    proof file must be the single-GPU proof text.  World = the visible GPUs rounded down to a power of two that divides the
+    column count (1 on the one-GPU box: RCCL with one rank; the multi-rank logic runs as threads in
+    tests/test_gpu_sharded_native.py)."""
+    import os
+    import subprocess
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "host", "prove_chunk")
+    air = AIR.get_air("chunk16")
+    tr, pub = native.synth_trace(air.trace_kind, 10, air.width, 23)
+    world = 1
+    while world * 2 <= min(native.device_count(), 4):
+        world *= 2
+    np.asarray(air.program(), dtype=np.uint64).tofile(tmp_path / "program.bin")
+    np.ascontiguousarray(tr).tofile(tmp_path / "trace.bin")
+    np.asarray(pub, dtype=np.uint64).tofile(tmp_path / "publics.bin")
+    out, idf = tmp_path / "proof.json", tmp_path / "rccl.id"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([exe, str(tmp_path / "program.bin"), str(tmp_path / "trace.bin"), str(tmp_path / "publics.bin"), "10", "1", "3", "3", "12",
+                               "6", str(out), air.name, str(r), str(world), str(idf)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+    d = prover.upload(tr)
+    single = prover.stark_prove(air.name, air.program(), d, [int(v) for v in pub], 10, 1, 3, 3, 12, 6)
+    d.free()
+    assert out.read_text() == single
