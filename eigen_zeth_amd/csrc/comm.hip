@@ -321,4 +321,42 @@ int32_t zp_merkle_commit_sharded(zp_comm *c, const uint64_t *d_cols, size_t M, i
     return rc;
 }
 
+// this rank's rows u64[Rl][C] of an (G Rl) x C matrix -> this rank's rows u64[C / G][G Rl] of its transpose: pack + ONE all-to-all
+// (zp_exchange_columns_to_rows) + the local transpose.  d_x is clobbered (it receives the exchanged blocks), d_z is the pack buffer.
+static int32_t sharded_transpose(zp_comm *c, uint64_t *d_x, uint64_t *d_y, uint64_t *d_z, size_t Rl, size_t C) {
+    zp_ctx *ctx = c->ctx;
+    const size_t G = (size_t)c->world;
+    if (G == 1) return zp_transpose(ctx, d_x, d_y, Rl, C);
+    ZP_TRY(zp_pack_blocks(ctx, d_x, d_z, Rl, C, c->world));
+    ZP_TRY(zp_comm_all_to_all(c, d_z, d_x, Rl * (C / G)));            // block h of d_x = rank h's rows, my columns: [G Rl][C / G]
+    return zp_transpose(ctx, d_x, d_y, G * Rl, C / G);
+}
+
+// Four-step NTT of ONE column of N = 2^logn elements split over the ranks (BASELINE.json configs[3] / SURVEY.md 8e: "RCCL all-to-all
+// over xGMI for the four-step NTT transpose").  N = N1 N2 (N1 = 2^(logn / 2)), input index i = i1 N2 + i2, output k = k1 + N1 k2:
+//     X[k1 + N1 k2] = sum_i2 w_N2^(i2 k2) w_N^(i2 k1) sum_i1 x[i1 N2 + i2] w_N1^(i1 k1)
+// Rank g holds the contiguous block [g N / G, (g + 1) N / G) of the column in d_data = rows i1 of the N1 x N2 matrix.  Steps:
+// transpose (all-to-all) -> N1-point transforms of the local N2 / G rows (zp_ntt) -> twiddle w_N^(i2 k1) (zp_twiddle_rows) ->
+// transpose (all-to-all) -> N2-point transforms of the local N1 / G rows -> with natural_output a third transpose, so that d_data
+// ends as this rank's contiguous block of the transform; without it d_data holds rows k1 in [g N1 / G, ..) of Y[k1][k2] =
+// X[k1 + N1 k2] (what a consumer that works on rows wants: one all-to-all less).  inverse != 0: the inverse transform, scaled by
+// 1 / N.  d_tmp: scratch of 2 N / G words.  Same result, bit for bit, as zp_ntt / zp_intt on the whole column on one GPU.
+int32_t zp_ntt_sharded(zp_comm *c, uint64_t *d_data, uint64_t *d_tmp, int32_t logn, int32_t inverse, int32_t natural_output) {
+    if (!c) return ZP_ERR_ARG;
+    zp_ctx *ctx = c->ctx;
+    const size_t G = (size_t)c->world;
+    const int l1 = logn / 2, l2 = logn - l1;
+    ZP_ARG(ctx, d_data && d_tmp && logn >= 2 && logn <= 40 && (G & (G - 1)) == 0 && ((size_t)1 << l1) >= 2 * G, "bad arguments (2^(logn/2) must be at least twice the world size)");
+    const size_t N1 = (size_t)1 << l1, N2 = (size_t)1 << l2, Nl = (N1 / G) * N2;
+    uint64_t *X = d_data, *Y = d_tmp, *Z = d_tmp + Nl;
+    ZP_TRY(sharded_transpose(c, X, Y, Z, N1 / G, N2));                         // Y [N2 / G][N1]: row i2, entries over i1
+    ZP_TRY((inverse ? zp_intt : zp_ntt)(ctx, Y, Y, l1, (int32_t)(N2 / G)));    // over i1 -> k1
+    ZP_TRY(zp_twiddle_rows(ctx, Y, l1, (int32_t)(N2 / G), (uint64_t)c->rank * (N2 / G), logn, inverse));
+    ZP_TRY(sharded_transpose(c, Y, X, Z, N2 / G, N1));                         // X [N1 / G][N2]: row k1, entries over i2
+    ZP_TRY((inverse ? zp_intt : zp_ntt)(ctx, X, X, l2, (int32_t)(N1 / G)));    // over i2 -> k2: Y[k1][k2]
+    if (!natural_output) return ZP_OK;
+    ZP_TRY(sharded_transpose(c, X, Y, Z, N1 / G, N2));                         // Y [N2 / G][N1]: k = k1 + N1 k2, my rows k2
+    return zp_d2d(ctx, X, Y, Nl * 8);
+}
+
 }  // extern "C"

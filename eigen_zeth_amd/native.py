@@ -115,6 +115,7 @@ SIGNATURES = {
     "zp_stark_prove_sharded": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "zp_exchange_columns_to_rows": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp]),
+    "zp_ntt_sharded": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32]),
     "zp_merkle_commit_sharded": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp, _u64p]),
     "zp_msm_bn254": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
     "zp_msm_bn254_g2": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
@@ -314,6 +315,11 @@ class Comm:
 
     def exchange_columns_to_rows(self, d_cols, Wl, M, d_pack, d_rows):
         self.prover._chk(self.prover.lib.zp_exchange_columns_to_rows(self.h, _ptr(d_cols), Wl, M, _ptr(d_pack), _ptr(d_rows)))
+
+    def ntt_sharded(self, d_data, d_tmp, logn, inverse=False, natural_output=True):
+        """four-step NTT of one column of 2^logn elements split over the ranks, in place on this rank's contiguous block
+        (d_tmp: scratch of 2 * 2^logn / world words)"""
+        self.prover._chk(self.prover.lib.zp_ntt_sharded(self.h, _ptr(d_data), _ptr(d_tmp), logn, int(bool(inverse)), int(bool(natural_output))))
 
     def merkle_commit_sharded(self, d_cols, M, Wl, d_tree_local):
         """-> the global root (4 ints)"""

@@ -118,21 +118,21 @@ def prove(circ, pk, w, msm_g1, rand, msm_g2, qap_quotient):
     hco = qap_quotient(a_ev, b_ev, c_ev, circ.logm, g)
     assert len(hco) == m and hco[m - 1] == 0
     r, s = rand
-    A1 = _g1_add(_g1_add(pk["alpha1"], msm_g1(pk["u1"], w)), bn254._pt_mul(bn254._Ops1, pk["delta1"], r))
-    B1 = _g1_add(_g1_add(pk["beta1"], msm_g1(pk["v1"], w)), bn254._pt_mul(bn254._Ops1, pk["delta1"], s))
-    B2 = pk["beta2"]
-    if msm_g2 is not None:                       # sum_j w_j [v_j(tau)]_2 as one G2 multi-scalar multiplication
-        B2 = _g2_add(B2, msm_g2(pk["v2"], w))
+    # the blinding terms ride in the multi-scalar multiplications (alpha, beta, delta as extra bases with scalars 1, r, s):
+    # no scalar multiplication is left to host code
+    A1 = msm_g1(pk["u1"] + [pk["alpha1"], pk["delta1"]], list(w) + [1, r])
+    B1 = msm_g1(pk["v1"] + [pk["beta1"], pk["delta1"]], list(w) + [1, s])
+    if msm_g2 is not None:                       # beta + sum_j w_j [v_j(tau)]_2 + s delta as one G2 multi-scalar multiplication
+        B2 = msm_g2(pk["v2"] + [pk["beta2"], pk["delta2"]], list(w) + [1, s])
     else:
+        B2 = pk["beta2"]
         for j, pt in enumerate(pk["v2"]):
             if pt is not None and w[j]:
                 B2 = _g2_add(B2, bn254._pt_mul(bn254._Ops2, pt, w[j]))
-    B2 = _g2_add(B2, bn254._pt_mul(bn254._Ops2, pk["delta2"], s))
+        B2 = _g2_add(B2, bn254._pt_mul(bn254._Ops2, pk["delta2"], s))
     priv = list(range(1 + circ.npub, circ.nwires))
-    Cp = msm_g1([pk["l1"][j] for j in priv] + pk["h1"], [w[j] for j in priv] + hco[:m - 1])
-    Cp = _g1_add(Cp, bn254._pt_mul(bn254._Ops1, A1, s))
-    Cp = _g1_add(Cp, bn254._pt_mul(bn254._Ops1, B1, r))
-    Cp = _g1_add(Cp, _neg(bn254._pt_mul(bn254._Ops1, pk["delta1"], r * s % R)))
+    Cp = msm_g1([pk["l1"][j] for j in priv] + pk["h1"] + [A1, B1, pk["delta1"]],
+                [w[j] for j in priv] + hco[:m - 1] + [s, r, (R - r * s % R) % R])
     return {"pi_a": A1, "pi_b": B2, "pi_c": Cp}, [w[1]]
 
 

@@ -127,6 +127,9 @@ class Shape:
     def period_schedule(self):
         """blocks of one period: list of dicts {kind: "absorb" | "node" | "idle", sub (slot within the period), p, t, level, first,
         last}; idle blocks pad the period to PB"""
+        cached = _SCHED_CACHE.get(self.key())
+        if cached is not None:
+            return cached
         k, _, pb = self.layout()
         out = []
         for sub in range(k):
@@ -138,10 +141,12 @@ class Shape:
                     for lv in range(d):
                         out.append({"kind": "node", "sub": sub, "p": p, "t": t, "level": lv, "first": a == 0 and lv == 0, "last": lv == d - 1})
         out += [{"kind": "idle", "first": False, "last": False}] * (pb - len(out))
+        _SCHED_CACHE[self.key()] = out          # tens of thousands of entries, fixed by the shape: built once (callers only read it)
         return out
 
 
 _AIR_CACHE = {}
+_SCHED_CACHE = {}
 
 
 def verifier_air(shape, rc, mds):

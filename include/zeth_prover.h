@@ -344,6 +344,12 @@ int32_t zp_stark_prove_sharded(zp_comm *comm, const char *air_name, const uint64
                                int32_t logb, int32_t fri_logf, int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, char **out_json,
                                size_t *out_len);
 int32_t zp_exchange_columns_to_rows(zp_comm *comm, const uint64_t *d_cols, size_t Wl, size_t M, uint64_t *d_pack, uint64_t *d_rows);
+/* four-step NTT of ONE column of 2^logn elements split over the ranks (BASELINE.json configs[3]: "RCCL all-to-all over xGMI for the
+ * four-step NTT transpose"; replaces the torch.distributed orchestration eigen_zeth_amd/multigpu.py:four_step_ntt): d_data = this
+ * rank's contiguous block of 2^logn / G elements, transformed in place (natural_output != 0: this rank's contiguous block of the
+ * transform, three all-to-alls; 0: rows k1 of Y[k1][k2] = X[k1 + N1 k2], two all-to-alls); d_tmp = scratch of 2 * 2^logn / G words;
+ * inverse != 0: inverse transform incl. 1/N.  Bit-identical to zp_ntt / zp_intt of the whole column on one GPU. */
+int32_t zp_ntt_sharded(zp_comm *comm, uint64_t *d_data, uint64_t *d_tmp, int32_t logn, int32_t inverse, int32_t natural_output);
 int32_t zp_merkle_commit_sharded(zp_comm *comm, const uint64_t *d_cols, size_t M, int32_t Wl, uint64_t *d_tree_local, uint64_t *h_root4);
 
 /* ---- N6: BN254 (alt_bn128) G1 multi-scalar multiplication ---------------------------------------

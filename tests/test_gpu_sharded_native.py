@@ -143,3 +143,30 @@ def test_sharded_prover_on_rccl_with_a_world_of_one(prover, tables):
     finally:
         comm.close()
         d.free()
+
+
+@pytest.mark.parametrize("G,logn", [(1, 9), (2, 12), (2, 17), (4, 13), (4, 20), (8, 16)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_four_step_ntt_over_the_ranks_equals_the_single_gpu_transform(G, logn, inverse):
+    """zp_ntt_sharded: one column of 2^logn elements split over G ranks (contiguous blocks), two / three all-to-all transposes --
+    against the oracle's NTT of the whole column (BASELINE.json configs[3]: the four-step NTT transpose)"""
+    N = 1 << logn
+    x = O.random_field((N,), 900 + logn)
+    want = O.intt(x.reshape(1, N))[0] if inverse else O.ntt(x.reshape(1, N))[0]
+    l1 = logn // 2
+    N1, N2 = 1 << l1, 1 << (logn - l1)
+
+    def fn(r, p, c):
+        blk = x[r * (N // G):(r + 1) * (N // G)]
+        d, t = p.upload(blk), p.alloc(2 * (N // G))
+        c.ntt_sharded(d, t, logn, inverse=inverse, natural_output=True)
+        nat = p.download(d, (N // G,))
+        p._chk(p.lib.zp_h2d(p.ctx, d.ptr, np.ascontiguousarray(blk).ctypes.data, blk.nbytes))
+        c.ntt_sharded(d, t, logn, inverse=inverse, natural_output=False)
+        rows = p.download(d, (N1 // G, N2))
+        return nat, rows
+    res = run_ranks(G, fn)
+    got = np.concatenate([r[0] for r in res])
+    assert (got == want).all()
+    Y = np.concatenate([r[1] for r in res])            # Y[k1][k2] = X[k1 + N1 k2]
+    assert (Y == want.reshape(N2, N1).T).all()
