@@ -501,6 +501,7 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
     # 0, zp_merkle_commit_sharded = pack + grouped send/recv all-to-all + local subtree + all-gather of sub-roots + tree top) --
     # what a compiled host uses; must give the root of the torch.distributed path above.  RCCL wants one rank per GPU, so the
     # one-GPU rehearsal (gloo backend) skips it.
+    direct_comm, grp1 = None, None
     if world > 1 and dist.get_backend() == "nccl":
         try:
             from eigen_zeth_amd import native as _nat
@@ -522,9 +523,10 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
                     r2 = comm.merkle_commit_sharded(y, M, cols, tl)
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
-                comm.close()
                 res["rccl_direct"] = {"sharded_commit_ms": dt * 1e3, "root_matches_torch_path": [hex(v) for v in r2] == res["root"],
                                       "note": "zp_merkle_commit_sharded: exchange + hashing in one C-ABI call, wall-clock"}
+                del tl
+                direct_comm = comm            # kept for the four-step NTT below, closed there
             else:
                 res["rccl_direct"] = {"error": "rank 0 could not make an RCCL id"}
         except Exception as ex:
@@ -542,9 +544,35 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
             torch.cuda.synchronize()
         res["four_step_single_column"] = {"logn": flog, "ms": f0.elapsed_time(f1),
                                           "elems_per_s": (1 << flog) / (f0.elapsed_time(f1) * 1e-3)}
+        # the same transform behind ONE C-ABI call per rank (zp_ntt_sharded: RCCL all-to-all per transpose; at N = 1 a
+        # communicator of one rank, the transposes are local) -- must give the torch.distributed result, element for element
+        if direct_comm is None and world == 1:
+            from eigen_zeth_amd import native as _nat
+            grp1 = _nat.CommGroup(1)
+            direct_comm = _nat.Comm(prover, 0, 1, group=grp1)
+        if direct_comm is not None:
+            want = multigpu.four_step_ntt(blk, flog, *ops)
+            tmp = torch.empty((2 * blk.numel(),), dtype=torch.int64, device=dev)
+            for it in range(2):
+                d = blk.clone()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                direct_comm.ntt_sharded(d, tmp, flog)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            res["four_step_single_column"]["c_abi"] = {"ms": dt * 1e3, "elems_per_s": (1 << flog) / dt, "equals_torch_path": bool(torch.equal(d, want)),
+                                                       "note": "zp_ntt_sharded, wall-clock incl. the copy back to the caller's buffer"}
+            del want, tmp, d
         del blk
     except Exception as ex:
         res["four_step_single_column"] = {"error": repr(ex)}
+    if direct_comm is not None:
+        try:
+            direct_comm.close()
+            if grp1 is not None:
+                grp1.close()
+        except Exception:
+            pass
     # BN254 MSM over the ranks: 2^22 points per GPU, partial sums all-gathered and added
     try:
         from eigen_zeth_amd.service import bn254
