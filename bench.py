@@ -550,7 +550,12 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
             from eigen_zeth_amd import native as _nat
             grp1 = _nat.CommGroup(1)
             direct_comm = _nat.Comm(prover, 0, 1, group=grp1)
-        if direct_comm is not None:
+        run_direct = direct_comm is not None
+        if world > 1:       # every rank or none: a rank whose communicator failed must not leave the others in a collective
+            flag = torch.tensor([1 if run_direct else 0], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            run_direct = bool(int(flag.item()))
+        if run_direct:
             want = multigpu.four_step_ntt(blk, flog, *ops)
             tmp = torch.empty((2 * blk.numel(),), dtype=torch.int64, device=dev)
             for it in range(2):

@@ -158,7 +158,9 @@ __global__ void __launch_bounds__(64) poseidon_perm_small_kernel(u64 *states, in
 // For every block: the rate (state[0..8)) is overwritten with the block, then one permutation (no block: one permutation);
 // then `extra` further permutations, the rate after each of the 1 + extra steps is written out.  Same 12-lanes-per-state form
 // as above: a transcript of k permutations costs one host round trip instead of k.
-__global__ void __launch_bounds__(64) poseidon_sponge_kernel(u64 *buf, int nblocks, int extra, const u64 *rc, const u32 *mds) {
+// caps (optional): the capacity (state[8..12)) after EVERY permutation, 4 words each -- with the blocks and the rates that is the
+// input state of every permutation of the step, what the verifier AIR's witness needs (stark/verifier_air.py: transcript blocks).
+__global__ void __launch_bounds__(64) poseidon_sponge_kernel(u64 *buf, int nblocks, int extra, const u64 *rc, const u32 *mds, u64 *caps) {
     __shared__ u64 sh[12];
     const int e = threadIdx.x;
     const bool on = e < 12;
@@ -188,6 +190,7 @@ __global__ void __launch_bounds__(64) poseidon_sponge_kernel(u64 *buf, int nbloc
         }
         s = gl_canon(s);
         if (b >= absorb - 1 && e < 8) rates[(size_t)(b - (absorb - 1)) * 8 + e] = s;
+        if (caps && on && e >= 8) caps[(size_t)b * 4 + (e - 8)] = s;
     }
     if (on) buf[e] = s;
 }
@@ -508,7 +511,8 @@ int32_t zp_poseidon_trace(zp_ctx *ctx, const uint64_t *d_inputs, size_t count, u
     return ZP_OK;
 }
 
-int32_t zp_poseidon_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates) {
+int32_t zp_poseidon_sponge_caps(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates,
+                                uint64_t *h_caps) {
     if (!ctx) return ZP_ERR_ARG;
     ZpStage stage_(ctx, "poseidon_sponge");
     ZP_ARG(ctx, h_state && h_rates && (h_blocks || nblocks == 0), "null pointer");
@@ -516,22 +520,28 @@ int32_t zp_poseidon_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blo
     for (int i = 0; i < 12; i++) ZP_ARG(ctx, h_state[i] < GL_P, "state not canonical");
     for (size_t i = 0; i < nblocks * 8; i++) ZP_ARG(ctx, h_blocks[i] < GL_P, "block not canonical");
     ZP_TRY(zpi_poseidon_sync_tables(ctx));
-    const size_t nin = 12 + nblocks * 8, nout = (1 + extra) * 8;
+    const size_t nin = 12 + nblocks * 8, nout = (1 + extra) * 8, ncap = h_caps ? ((nblocks ? nblocks : 1) + extra) * 4 : 0;
     u64 *d = nullptr;
-    ZP_TRY(zpi_scratch(ctx, 3, nin + nout, &d));
+    ZP_TRY(zpi_scratch(ctx, 3, nin + nout + ncap, &d));
     std::vector<u64> in(nin);
     memcpy(in.data(), h_state, 96);
     if (nblocks) memcpy(in.data() + 12, h_blocks, nblocks * 64);
     ZP_TRY(zpi_h2d_small(ctx, d, in.data(), nin * 8));
-    hipLaunchKernelGGL(poseidon_sponge_kernel, dim3(1), dim3(64), 0, ctx->stream, d, (int)nblocks, (int)extra, ctx->d_rc, ctx->d_mds);
+    hipLaunchKernelGGL(poseidon_sponge_kernel, dim3(1), dim3(64), 0, ctx->stream, d, (int)nblocks, (int)extra, ctx->d_rc, ctx->d_mds,
+                       h_caps ? d + nin + nout : (u64 *)nullptr);
     ZP_HIP(ctx, hipGetLastError());
-    std::vector<u64> out(12 + nout);
+    std::vector<u64> out(12 + nout + ncap);
     // state and rates are not adjacent (the blocks sit between them): two small copies
     ZP_TRY(zpi_d2h_small(ctx, out.data(), d, 96));
-    ZP_TRY(zpi_d2h_small(ctx, out.data() + 12, d + nin, nout * 8));
+    ZP_TRY(zpi_d2h_small(ctx, out.data() + 12, d + nin, (nout + ncap) * 8));
     memcpy(h_state, out.data(), 96);
     memcpy(h_rates, out.data() + 12, nout * 8);
+    if (h_caps) memcpy(h_caps, out.data() + 12 + nout, ncap * 8);
     return ZP_OK;
+}
+
+int32_t zp_poseidon_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates) {
+    return zp_poseidon_sponge_caps(ctx, h_state, h_blocks, nblocks, extra, h_rates, nullptr);
 }
 
 int32_t zp_pow_grind(zp_ctx *ctx, const uint64_t *h_seed4, int32_t bits, uint64_t *h_nonce) {

@@ -66,6 +66,7 @@ SIGNATURES = {
     "zp_poseidon_bn254_sponge": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp]),
     "zp_free_buffer": (C.c_int32, [_vp]),
     "zp_poseidon_sponge": (C.c_int32, [_vp, _u64p, _u64p, C.c_size_t, C.c_size_t, _u64p]),
+    "zp_poseidon_sponge_caps": (C.c_int32, [_vp, _u64p, _u64p, C.c_size_t, C.c_size_t, _u64p, _u64p]),
     "zp_deep_quotient_rows": (C.c_int32, [_vp, _vp, C.c_int32, C.c_size_t, _vp, C.c_int32, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, C.c_int32,
                                           _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, C.c_size_t]),
     "zp_eval_quotient_rows": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_size_t, C.c_size_t,
@@ -616,6 +617,16 @@ class Prover:
         self._chk(self.lib.zp_poseidon_sponge(self.ctx, st.ctypes.data_as(_u64p), bl.ctypes.data_as(_u64p), len(blocks), extra,
                                               rates.ctypes.data_as(_u64p)))
         return st.tolist(), rates.reshape(-1, 8).tolist()
+
+    def poseidon_sponge_caps(self, state, blocks, extra=0):
+        """poseidon_sponge that also returns the capacity after every permutation: (new state, rates, caps [(max(blocks, 1) + extra)][4])"""
+        st = np.array(state, dtype=np.uint64)
+        bl = np.ascontiguousarray(np.array(blocks, dtype=np.uint64).reshape(-1)) if blocks else np.zeros(1, dtype=np.uint64)
+        rates = np.zeros((1 + extra) * 8, dtype=np.uint64)
+        caps = np.zeros((max(len(blocks), 1) + extra) * 4, dtype=np.uint64)
+        self._chk(self.lib.zp_poseidon_sponge_caps(self.ctx, st.ctypes.data_as(_u64p), bl.ctypes.data_as(_u64p), len(blocks), extra,
+                                                   rates.ctypes.data_as(_u64p), caps.ctypes.data_as(_u64p)))
+        return st.tolist(), rates.reshape(-1, 8).tolist(), caps.reshape(-1, 4).tolist()
 
     def pow_grind(self, seed4, bits):
         sd = (C.c_uint64 * 4)(*[int(v) for v in seed4])

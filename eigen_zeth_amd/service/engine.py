@@ -294,13 +294,17 @@ class Engine:
                          "fri": [strip(f) for f in q["fri"]]} for q in proof["queries"]]
         return h
 
-    def _prove_merkle_verifier(self, proofs, params_of, be, timings):
-        """STARK over the Merkle-verifier AIR (stark/verifier_air.py) for inner proof objects `proofs` of one shape"""
+    def _prove_merkle_verifier(self, proofs, params_of, be, timings, inner_air):
+        """STARK over the verifier AIR (stark/verifier_air.py) for inner proof objects `proofs` of one shape, proofs of `inner_air`"""
         rc, mds = self._tables(be)
         shape = VA.Shape.of_proof(proofs[0], len(proofs))
+        for pr in proofs:
+            if pr.get("air_digest") != inner_air.digest():
+                raise ValueError("recursive proof is for another statement than this prover's")
         vair = VA.verifier_air(shape, rc, mds)
         t0 = time.perf_counter()
-        trace, pubs = VA.build_witness(shape, proofs, be)       # raises ValueError: an opening does not verify -> no witness
+        # raises ValueError: an opening does not hash to its root / the transcript does not give the indices -> no witness
+        trace, pubs = VA.build_witness(shape, proofs, be, inner_air.digest_words())
         timings["verifier-witness"] = time.perf_counter() - t0
         params = params_of(shape)
         t0 = time.perf_counter()
@@ -327,16 +331,18 @@ class Engine:
         tm = {}
         shape, vair, params, text = self._prove_merkle_verifier(
             proofs, lambda sh: VA.aggregation_params(sh, self.cfg.agg_queries, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.agg_pow_bits),
-            self.be, tm)
+            self.be, tm, AIR.get_air(self.cfg.air))
         self.stage_timings["aggregate/" + batch_id] = tm
         if self.metrics is not None:
             for k, v in tm.items():
                 self.metrics.record_stage(k, v)
         head = json.dumps({"kind": "aggregated", "version": 1, "batch_id": batch_id,
                            "statement": "for every query slot, inner proof and committed tree the public opened values hash, as a leaf and up "
-                                        "a path along the bits of the public index, to the public root (all hashing of the verifier; its "
-                                        "arithmetic -- transcript, out-of-domain identity, DEEP, FRI folds -- is checked natively on 'inner')",
-                           "shape": dict(zip(("logn", "logb", "W", "W2", "Wq", "n_queries", "fri_logf", "fri_final_log", "n_proofs"), shape.key())),
+                                        "a path along the bits of the public index, to the public root; the Fiat-Shamir sponge of every inner "
+                                        "proof absorbs the public blocks and yields the public rates, and its grinding hash the public digest "
+                                        "(all hashing of the verifier; its arithmetic -- out-of-domain identity, DEEP, FRI folds, challenges "
+                                        "read off the public rates -- is checked natively on 'inner')",
+                           "shape": shape.to_dict(),
                            "slots": shape.n_slots(), "verifier_air_digest": vair.digest(),
                            "inner": [self._header(pr) for pr in proofs]}, separators=(",", ":"))
         return head[:-1] + ',"stark":' + text + "}"
@@ -372,10 +378,11 @@ class Engine:
             outer = agg["stark"]
             if agg.get("kind") != "aggregated" or "queries" not in outer:
                 raise KeyError("kind")
-        except (json.JSONDecodeError, TypeError, KeyError) as e:
+            agg_air = VA.verifier_air(VA.Shape.from_dict(agg["shape"]), *self._tables(self.be_bn128))   # the statement of agg["stark"]
+        except (json.JSONDecodeError, TypeError, KeyError, AssertionError) as e:
             raise ValueError("recursive proof is not an aggregated proof of this prover (%s)" % e)
         tmf = {}
-        fshape, fair, fp, final_stark = self._prove_merkle_verifier([outer], lambda sh: self.final_stark_params(outer), self.be_bn128, tmf)
+        fshape, fair, fp, final_stark = self._prove_merkle_verifier([outer], lambda sh: self.final_stark_params(outer), self.be_bn128, tmf, agg_air)
         t_fs = time.perf_counter() - t0
         self.final_starks[batch_id] = final_stark
         while len(self.final_starks) > 4:

@@ -104,6 +104,23 @@ class HipBackend:
         tree.free()
         return root
 
+    def publics_digest_gl(self, pubs):
+        """the Goldilocks-mode digest whatever this backend's hash mode (the transcript of an INNER proof, replayed for the
+        verifier AIR's witness: stark/verifier_air.py)"""
+        from .prover import publics_rows
+        mat = publics_rows(pubs, False)
+        M = mat.shape[0]
+        d, tree = self.p.upload(mat), self.p.alloc((2 * M - 1) * 4)
+        try:
+            self.p.merkle_commit_rows(d, M, 8, tree)
+            return [int(v) for v in self.p.download(tree, (4,), offset_elems=(2 * M - 2) * 4)]
+        finally:
+            d.free()
+            tree.free()
+
+    def poseidon_sponge_caps(self, state, blocks, extra):
+        return self.p.poseidon_sponge_caps(state, blocks, extra)
+
     def verifier_trace_device(self, inputs, dbit, idxv):
         """the 26-column trace of the Merkle-verifier AIR (stark/verifier_air.py) assembled IN HBM: zp_poseidon_trace writes the 24
         state / cube columns of every permutation block, the direction-bit and index columns (one value per block, repeated over

@@ -19,6 +19,14 @@ the outer proof's public inputs to be those roots, indices and values.  So an ac
 verify: the Merkle work in the circuit, the field arithmetic outside it (putting that arithmetic into constraints too is what
 would make the recursion succinct in it: DESIGN.md par.7).
 
+The Fiat-Shamir transcripts of the inner proofs are in the circuit too (stage B, hashing part): every permutation of an inner
+proof's sponge is a block of the trace, chained through the capacity (or the whole state, between squeezes), with the absorbed
+blocks and the squeezed rates as public inputs -- and the grinding hash, seed and nonce in, digest out.  The checker replays a
+transcript WITHOUT hashing: it compares the blocks the protocol absorbs (parameters, AIR digest, public inputs or their digest,
+roots, out-of-domain evaluations, final layer, nonce) with the public ones and reads the challenges, the grinding digest and the
+query indices off the public rates (oracle/aggregate_verify.py).  A verifier of an aggregated proof hashes nothing but the
+public-input digest of the outer proof itself.
+
 Layout.  One Poseidon-12 permutation = one BLOCK of 32 rows: row r < 30 holds the state before round r, row 30 the
 output, row 31 a copy of it; the cubes (s_i + rc_i)^3 sit in 12 helper columns so that x^7 = cube^2 * x has degree 3.  Full
 and partial rounds share one constraint through the periodic selector FULL (degree 4 -> quotient in 3 pieces, blow-up 4).
@@ -43,10 +51,13 @@ S0, U0, COL_D, COL_IDX, WIDTH = 0, 12, 24, 25, 26
 class Shape:
     """what the Merkle part of a verifier needs to know about the inner proofs (all inner proofs of one aggregation share it)"""
 
-    def __init__(self, logn, logb, W, W2, Wq, n_queries, fri_logf, fri_final_log, n_proofs=2):
+    def __init__(self, logn, logb, W, W2, Wq, n_queries, fri_logf, fri_final_log, n_proofs=2, n_pub_inner=0, pow_bits=0):
+        """n_pub_inner / pow_bits: number of public inputs and grinding bits of an inner proof (they shape its transcript)"""
         self.logn, self.logb, self.W, self.W2, self.Wq = logn, logb, W, W2, Wq
         self.n_queries, self.fri_logf, self.fri_final_log, self.n_proofs = n_queries, fri_logf, fri_final_log, n_proofs
+        self.n_pub_inner, self.pow_bits = n_pub_inner, pow_bits
         logm = logn + logb
+        self.final_log = logm
         self.trees = [("trace", W, logm)]
         if W2:
             self.trees.append(("stage2", W2, logm))
@@ -57,6 +68,8 @@ class Shape:
             self.trees.append(("fri%d" % li, 3 << f, cur - f))
             cur -= f
             li += 1
+        self.final_log = cur                       # log2 of the FRI layer sent in clear
+        self.n_fri = li
         assert all(d >= 1 for (_, _, d) in self.trees)
 
     @staticmethod
@@ -65,10 +78,104 @@ class Shape:
         pr = proof["params"]
         q0 = proof["queries"][0]
         return Shape(pr["logn"], pr["logb"], len(q0["trace"]["values"]), len(q0["stage2"]["values"]) if "stage2" in q0 else 0,
-                     len(q0["quotient"]["values"]), pr["n_queries"], pr["fri_logf"], pr["fri_final_log"], n_proofs)
+                     len(q0["quotient"]["values"]), pr["n_queries"], pr["fri_logf"], pr["fri_final_log"], n_proofs,
+                     len(proof["publics"]), pr["pow_bits"])
+
+    KEY_NAMES = ("logn", "logb", "W", "W2", "Wq", "n_queries", "fri_logf", "fri_final_log", "n_proofs", "n_pub_inner", "pow_bits")
 
     def key(self):
-        return (self.logn, self.logb, self.W, self.W2, self.Wq, self.n_queries, self.fri_logf, self.fri_final_log, self.n_proofs)
+        return (self.logn, self.logb, self.W, self.W2, self.Wq, self.n_queries, self.fri_logf, self.fri_final_log, self.n_proofs,
+                self.n_pub_inner, self.pow_bits)
+
+    def to_dict(self):
+        return dict(zip(self.KEY_NAMES, self.key()))
+
+    @staticmethod
+    def from_dict(d):
+        return Shape(*[d[k] for k in Shape.KEY_NAMES])
+
+    # ---- the Fiat-Shamir transcript of one inner proof, as a list of permutations
+    def transcript_perms(self):
+        """the permutations of ONE inner proof's transcript in the order the protocol runs them (stark/prover.py; the sponge of
+        stark/transcript.py: absorb queues, a squeeze first absorbs what is queued in blocks of 8 that overwrite the rate -- one
+        bare permutation if nothing is queued -- and permutes again when its 8 outputs are used up).  List of dicts: n_in =
+        values absorbed by this permutation's block (0: the whole state is carried), first (the state before it is zero), out
+        (its rate is read by the protocol), pin / pout = offsets of its absorbed values / its 8 rate outputs in the proof's
+        section of the public inputs.  With grinding the LAST entry is the grinding hash (pow: seed || nonce in, digest out)."""
+        cached = _SCRIPT_CACHE.get(self.key())
+        if cached is not None:
+            return cached
+        from .prover import PUBLICS_INLINE
+        perms, st = [], {"queue": 0, "avail": 0}
+
+        def absorb(n):
+            st["queue"] += n
+            st["avail"] = 0
+
+        def squeeze(n):
+            for _ in range(n):
+                if st["queue"] or not st["avail"]:
+                    if not st["queue"]:
+                        perms.append({"n_in": 0})
+                    while st["queue"]:
+                        b = min(8, st["queue"])
+                        st["queue"] -= b
+                        perms.append({"n_in": b})
+                    perms[-1]["out"] = True
+                    st["avail"] = 8
+                st["avail"] -= 1
+        Wt = self.W + self.W2
+        absorb(10 + 4 + 1 + (self.n_pub_inner if self.n_pub_inner <= PUBLICS_INLINE else 4))
+        absorb(4)
+        if self.W2:
+            squeeze(3)
+            absorb(4)
+        squeeze(3)
+        absorb(4)
+        squeeze(3)
+        absorb(3 * (Wt + self.Wq) + 3 * Wt)
+        squeeze(3)
+        for _ in range(self.n_fri):
+            absorb(4)
+            squeeze(3)
+        absorb(3 << self.final_log)
+        if self.pow_bits:
+            squeeze(4)
+            absorb(1)
+        squeeze(self.n_queries)
+        if self.pow_bits:
+            perms.append({"n_in": 5, "out": True, "pow": True})
+        off = 0
+        for j, pm in enumerate(perms):
+            pm.setdefault("out", False)
+            pm.setdefault("pow", False)
+            pm["first"] = j == 0 or pm["pow"]
+            pm["pin"] = off
+            off += pm["n_in"]
+            if pm["out"]:
+                pm["pout"] = off
+                off += 8
+        _SCRIPT_CACHE[self.key()] = perms
+        return perms
+
+    def transcript_pubs_per_proof(self):
+        last = self.transcript_perms()[-1]
+        return last["pout"] + 8            # the last permutation of a transcript (queries or grinding) is always read
+
+    def transcript_block0(self):
+        """global block number of the first transcript block: the idle tail of the LAST period"""
+        k, periods, pb = self.layout()
+        return (periods - 1) * pb + k * self.n_proofs * self.blocks_per_proof()
+
+    def merkle_pubs(self):
+        T = len(self.trees)
+        return self.n_proofs * T * 4 + self.n_slots() * self.n_proofs * (T + self.values_per_query())
+
+    def pub_tin(self, p, j, i):
+        return self.merkle_pubs() + p * self.transcript_pubs_per_proof() + self.transcript_perms()[j]["pin"] + i
+
+    def pub_tout(self, p, j, i):
+        return self.merkle_pubs() + p * self.transcript_pubs_per_proof() + self.transcript_perms()[j]["pout"] + i
 
     # ---- the block schedule
     @staticmethod
@@ -82,12 +189,13 @@ class Shape:
         """(k, periods, PB): k query slots per period, `periods` periods (a power of two), PB blocks per period (a power of
         two >= k * n_proofs * blocks_per_proof); chosen to minimise the trace length 32 * PB * periods"""
         bg = self.n_proofs * self.blocks_per_proof()
+        tb = self.n_proofs * len(self.transcript_perms())      # transcript blocks: in the idle tail of the last period
         best = None
         for j in range(0, 12):
             periods = 1 << j
             k = -(-self.n_queries // periods)
             pb = 1
-            while pb < k * bg:
+            while pb < k * bg + tb:
                 pb <<= 1
             rows = ROWS * pb * periods
             if best is None or rows < best[0]:
@@ -105,8 +213,7 @@ class Shape:
         return k * periods
 
     def n_pub(self):
-        T = len(self.trees)
-        return self.n_proofs * T * 4 + self.n_slots() * self.n_proofs * (T + self.values_per_query())
+        return self.merkle_pubs() + self.n_proofs * self.transcript_pubs_per_proof()
 
     def pub_root(self, p, t, i):
         return (p * len(self.trees) + t) * 4 + i
@@ -147,6 +254,7 @@ class Shape:
 
 _AIR_CACHE = {}
 _SCHED_CACHE = {}
+_SCRIPT_CACHE = {}
 
 
 def verifier_air(shape, rc, mds):
@@ -226,9 +334,33 @@ def verifier_air(shape, rc, mds):
             abs0.append((b * ROWS, 1))
         elif blk["kind"] == "node" and blk["first"]:
             id0.append((b * ROWS, 1))
+    # the transcript blocks (idle tail of the last period, one run of consecutive blocks per inner proof): links through the
+    # capacity (absorbing permutation) or the whole state (a permutation between two squeezes), zero capacity before the first
+    # permutation and before the grinding hash; the absorbed blocks (row 0) and the rates the protocol reads (row 31) are public
+    tcap, trate, tcap0, tabs = [], [], [], []
+    perms = shape.transcript_perms()
+    for p in range(shape.n_proofs):
+        for j, pm in enumerate(perms):
+            row0 = ROWS * (shape.transcript_block0() + p * len(perms) + j)
+            if pm["first"]:
+                tcap0.append((row0 - 1, 1))
+            else:
+                tcap.append((row0 - 1, 1))
+                if pm["n_in"] == 0:
+                    trate.append((row0 - 1, 1))
+            if pm["n_in"]:
+                tabs.append((row0, 1))
+                for i in range(pm["n_in"]):
+                    leaf[i].append((row0, Pub(shape.pub_tin(p, j, i))))
+            if pm["out"]:
+                tabs.append((row0 + 31, 1))
+                for i in range(8):
+                    leaf[i].append((row0 + 31, Pub(shape.pub_tout(p, j, i))))
     fc += [FixedCol(lp, abs0), FixedCol(lp, id0)] + [FixedCol(logn, leaf[i]) for i in range(8)]
     ABS0, ID0 = Fixed(27), Fixed(28)
     LEAF = [Fixed(29 + i) for i in range(8)]
+    fc += [FixedCol(logn, tcap), FixedCol(logn, trate), FixedCol(logn, tcap0), FixedCol(logn, tabs)]
+    TCAP, TRATE, TCAP0, TABS = [Fixed(37 + i) for i in range(4)]
 
     # ---- constraints
     s = [Col(S0 + i) for i in range(12)]
@@ -252,13 +384,16 @@ def verifier_air(shape, rc, mds):
     cs += [CPY * (sn[j] - s[j]) for j in range(12)]                       # row 31 = row 30
     cs += [L_CHAIN * (sn[8 + i] - s[i]) for i in range(4)]                # sponge chaining: the digest becomes the next capacity
     cs += [L_NODE * (sn[i] - s[i] + d_n * (sn[4 + i] - sn[i])) for i in range(4)]   # digest = left (bit 0) or right (bit 1) child
-    cs += [CAP0 * sn[8 + i] for i in range(4)]
+    cs += [(CAP0 + TCAP0) * sn[8 + i] for i in range(4)]
+    cs += [TCAP * (sn[8 + i] - s[8 + i]) for i in range(4)]               # transcript sponge: the capacity runs through the permutations
+    cs += [TRATE * (sn[i] - s[i]) for i in range(8)]                      # ... and the rate too when nothing is absorbed in between
     cs.append(WT * (d_n * d_n - d_n))                                     # direction bits are bits
     cs.append(idx_n - (ACT + CPY + L_CHAIN + L_NODE) * idx - WT * d_n)    # index: kept inside a block and an opening, + 2^level * bit
     cs += [L_FINAL * s[i] - ROOT[i] for i in range(4)]                    # the top of the path is the public root
     cs.append(L_FINAL * idx - IDXV)                                       # the direction bits spell the public index
-    cs += [ABS0 * s[i] + ID0 * (s[i] + d_c * (s[4 + i] - s[i])) - LEAF[i] for i in range(4)]   # the hashed values are the public ones
-    cs += [ABS0 * s[i] - LEAF[i] for i in range(4, 8)]
+    # the hashed values are the public ones (leaves; absorbed blocks and read rates of the transcripts)
+    cs += [(ABS0 + TABS) * s[i] + ID0 * (s[i] + d_c * (s[4 + i] - s[i])) - LEAF[i] for i in range(4)]
+    cs += [(ABS0 + TABS) * s[i] - LEAF[i] for i in range(4, 8)]
     air = A.Air("mverify", WIDTH, shape.n_pub(), cs, trace_kind=None, fixed_cols=fc)
     air.shape = shape
     assert A.quotient_chunks(air) <= 4
@@ -273,9 +408,117 @@ def _opening(q, name):
     return q[name]
 
 
+class _RecordingSponge:
+    """the sponge of stark/transcript.py that keeps, for every permutation, the state it started from: [input state (12), values
+    absorbed by its block (0: state carried), the rate after it if the protocol reads it (else None)].  One device call per
+    transcript step when the backend has poseidon_sponge_caps (zp_poseidon_sponge_caps), else permutation by permutation."""
+
+    def __init__(self, be):
+        self.be, self.state, self.queue, self.avail, self.rec = be, [0] * 12, [], [], []
+
+    def absorb(self, vals):
+        self.queue += [int(v) % P for v in vals]
+        self.avail = []
+
+    def _flush(self):
+        blocks = [self.queue[i:i + 8] for i in range(0, len(self.queue), 8)]
+        self.queue = []
+        nin = [len(b) for b in blocks] or [0]
+        blocks = [b + [0] * (8 - len(b)) for b in blocks]
+        if hasattr(self.be, "poseidon_sponge_caps"):
+            new_state, _, caps = self.be.poseidon_sponge_caps(self.state, blocks, 0)
+            if blocks:
+                inputs = [blocks[i] + [int(v) for v in (self.state[8:] if i == 0 else caps[i - 1])] for i in range(len(blocks))]
+            else:
+                inputs = [list(self.state)]
+            self.state = [int(v) for v in new_state]
+        else:
+            inputs = []
+            if not blocks:
+                inputs.append(list(self.state))
+                self.state = [int(v) for v in self.be.poseidon_perm(self.state)]
+            for b in blocks:
+                inputs.append(b + list(self.state[8:]))
+                self.state = [int(v) for v in self.be.poseidon_perm(inputs[-1])]
+        for inp, n in zip(inputs, nin):
+            self.rec.append([inp, n, None])
+        self.rec[-1][2] = list(self.state[:8])
+        self.avail = list(self.state[:8])
+
+    def squeeze(self, n):
+        out = []
+        while len(out) < n:
+            if self.queue or not self.avail:
+                self._flush()
+            out.append(self.avail.pop(0))
+        return out
+
+
+def replay_transcript(shape, proof, digest_words, be):
+    """the Fiat-Shamir transcript of an inner proof, permutation by permutation: (input states [L][12] in the order of
+    shape.transcript_perms(), the proof's section of the public inputs).  digest_words: the inner AIR's digest as the prover
+    absorbs it (Air.digest_words()).  Raises ValueError when the transcript does not produce the proof's query indices or the
+    grinding nonce fails -- such a proof has no accepting witness."""
+    from .prover import PUBLICS_INLINE
+    pr = proof["params"]
+    pubs = [int(v) for v in proof["publics"]]
+    try:
+        tr = _RecordingSponge(be)
+        head = [pr["logn"], pr["logb"], shape.W, shape.W2, pr["fri_logf"], pr["fri_final_log"], pr["n_queries"], pr["pow_bits"],
+                int(proof["root32"]), int(proof["shift"])] + [int(v) for v in digest_words] + [len(pubs)]
+        if len(pubs) <= PUBLICS_INLINE:
+            tr.absorb(head + pubs)
+        else:
+            tr.absorb(head)
+            tr.absorb(be.publics_digest_gl(pubs))
+        tr.absorb(proof["roots"]["trace"])
+        if shape.W2:
+            tr.squeeze(3)
+            tr.absorb(proof["roots"]["stage2"])
+        tr.squeeze(3)
+        tr.absorb(proof["roots"]["quotient"])
+        tr.squeeze(3)
+        for r in proof["evals"]["z"] + proof["evals"]["zw"]:
+            tr.absorb(r)
+        tr.squeeze(3)
+        for root in proof["fri"]["roots"]:
+            tr.absorb(root)
+            tr.squeeze(3)
+        for c in range(3):
+            tr.absorb(proof["fri"]["final"][c])
+        pow_rec = None
+        if shape.pow_bits:
+            seed = tr.squeeze(4)
+            nonce = int(proof.get("pow_nonce", -1))
+            if not 0 <= nonce < P:
+                raise ValueError("grinding nonce missing")
+            pin = seed + [nonce] + [0] * 7
+            pout = [int(v) for v in be.poseidon_perm(pin)]
+            if pout[0] >> (64 - shape.pow_bits):
+                raise ValueError("the grinding nonce of an inner proof is wrong: no accepting witness")
+            pow_rec = [pin, 5, pout[:8]]
+            tr.absorb([nonce])
+        idx = [v & ((1 << (shape.logn + shape.logb)) - 1) for v in tr.squeeze(shape.n_queries)]
+    except (KeyError, TypeError, IndexError) as e:
+        raise ValueError("inner proof is malformed (%s)" % e)
+    if idx != [int(q["index"]) for q in proof["queries"]]:
+        raise ValueError("the query indices of an inner proof do not follow its transcript: no accepting witness")
+    rec = tr.rec + ([pow_rec] if pow_rec else [])
+    script = shape.transcript_perms()
+    if [(r[1], r[2] is not None) for r in rec] != [(pm["n_in"], pm["out"]) for pm in script]:
+        raise ValueError("inner proof does not have the shape the verifier AIR was built for")
+    tp = []
+    for inp, n, out in rec:
+        tp += inp[:n]
+        if out is not None:
+            tp += out
+    return [r[0] for r in rec], tp
+
+
 def expected_publics(shape, proofs):
-    """roots of every inner proof, then the leaf index of every (slot, proof, tree), then the opened values of every (slot, proof,
-    tree): slot g re-opens query g mod n_queries"""
+    """the Merkle part of the public inputs (the transcript part follows it: replay_transcript): roots of every inner proof, then
+    the leaf index of every (slot, proof, tree), then the opened values of every (slot, proof, tree): slot g re-opens query
+    g mod n_queries"""
     pubs = []
     for pr in proofs:
         names = {"trace": pr["roots"]["trace"], "quotient": pr["roots"]["quotient"]}
@@ -300,12 +543,14 @@ def expected_publics(shape, proofs):
     return pubs
 
 
-def build_witness(shape, proofs, be):
+def build_witness(shape, proofs, be, digest_words):
     """(trace u64[26][N], publics) for inner proof objects `proofs` (len = shape.n_proofs) of `shape`; the trace is a host array,
     or a device buffer of that shape when the backend assembles it in HBM (verifier_trace_device).
-    be: backend with poseidon_perm_batch(states [B][12]) and poseidon_trace(inputs [B][12]) -> (states [12][32 B], cubes
-    [12][32 B]).  Raises ValueError when an opening does not hash to its root -- there is no accepting witness for a proof
-    whose openings do not verify."""
+    be: backend with poseidon_perm_batch(states [B][12]), poseidon_trace(inputs [B][12]) -> (states [12][32 B], cubes
+    [12][32 B]), poseidon_perm / poseidon_sponge_caps and publics_digest_gl for the transcripts; digest_words: the inner AIR's
+    digest words (Air.digest_words(): the verifier of an inner proof knows its statement).  Raises ValueError when an opening
+    does not hash to its root, or the transcript does not give the proof's indices / grinding -- there is no accepting witness
+    for a proof that does not verify."""
     assert len(proofs) == shape.n_proofs
     for pr in proofs:
         assert Shape.of_proof(pr, shape.n_proofs).key() == shape.key(), "inner proofs of different shapes"
@@ -376,6 +621,13 @@ def build_witness(shape, proofs, be):
         idxv[blk] = index[sel] & np.uint64((2 << lv) - 1)
         digest[sel] = be.poseidon_perm_batch(st)[:, :4]
     pubs = expected_publics(shape, proofs)
+    L = len(shape.transcript_perms())
+    for p, pr in enumerate(proofs):                 # the transcripts: consecutive blocks in the idle tail of the last period
+        states, tp = replay_transcript(shape, pr, digest_words, be)
+        blk0 = shape.transcript_block0() + p * L
+        inputs[blk0:blk0 + L] = np.array(states, dtype=np.uint64)
+        pubs += tp
+    assert len(pubs) == shape.n_pub()
     T = len(shape.trees)
     want = np.array(pubs[:shape.n_proofs * T * 4], dtype=np.uint64).reshape(shape.n_proofs, T, 4)
     bad = np.nonzero((digest != want[np.array(pl, dtype=np.int64), np.array(tl, dtype=np.int64)]).any(axis=1))[0]

@@ -120,6 +120,11 @@ int32_t zp_poseidon_trace(zp_ctx *ctx, const uint64_t *d_inputs, size_t count, u
  * h_state (12 words) is updated; h_rates receives (1 + extra) * 8 words: the rate after the absorption and after each
  * extra permutation.  One host round trip per transcript step instead of one per permutation.                          */
 int32_t zp_poseidon_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates);
+/* the same step, also returning the capacity (state[8..12)) after EVERY permutation in h_caps ((max(nblocks, 1) + extra) * 4 words):
+ * with the blocks and the rates that is the input state of every permutation -- the witness of the transcript blocks of the
+ * verifier AIR (eigen_zeth_amd/stark/verifier_air.py; GenAggregatedProof, prover.proto:115-126). */
+int32_t zp_poseidon_sponge_caps(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates,
+                                uint64_t *h_caps);
 int32_t zp_pow_grind(zp_ctx *ctx, const uint64_t *h_seed4, int32_t bits, uint64_t *h_nonce);
 /* leaf i = linear hash (sponge, rate 8, capacity 4; rows of <= 4 elements are identity-padded) of
  * row i across the W columns of d_cols u64[W][M]; d_tree receives (2M-1)*4 u64: M leaves, then

@@ -10,12 +10,16 @@ src/prover/provider.rs:436-451) holds
              whose public inputs are the inner proofs' roots, the leaf index and the opened values of every (slot, proof, tree).
 Accepting means BOTH INNER PROOFS VERIFY, the work split in two:
   1. arithmetic, natively: every inner proof passes the whole verifier on the opened values as given -- parameters are the
-     verifier's, the Fiat-Shamir transcript is replayed (which dictates the query indices), the constraint identity holds at the
-     out-of-domain point, the DEEP quotient and every FRI fold are consistent at every query, the final layer is low degree, the
-     grinding nonce is valid (stark_verify.verify(trust_openings=True): everything but the Merkle paths);
+     verifier's, the constraint identity holds at the out-of-domain point, the DEEP quotient and every FRI fold are consistent at
+     every query, the final layer is low degree (stark_verify.verify(trust_openings=True): everything but the Merkle paths) --
+     with the Fiat-Shamir transcript READ, not hashed: the outer public inputs list, in protocol order, what every permutation
+     of the sponge absorbs and the rates the protocol reads (PublicSponge); the checker compares the absorbed blocks with the
+     proof's data and takes challenges, grinding digest and query indices from the public rates;
   2. the public inputs of the outer STARK are exactly those roots, indices and opened values (slot g re-opens query g mod n_queries);
   3. hashing, in the circuit: the outer STARK verifies under the verifier-AIR program -- for every slot / proof / tree the public
-     values, hashed as a leaf and up a path along the bits of the public index, give the public root.
+     values, hashed as a leaf and up a path along the bits of the public index, give the public root; the sponge permutations of
+     every transcript map the public blocks to the public rates (chained through the capacity), the grinding hash maps seed and
+     nonce to the public digest.  (The one hash left to the checker is the digest of the OUTER proof's own public inputs.)
 PARITY UNPINNED w.r.t. the external prover."""
 from . import stark_verify as V
 from .air_program import Program
@@ -33,14 +37,30 @@ def roots_of(proof, W2):
     return r + list(proof["fri"]["roots"])
 
 
-def verify(agg, inner_program, outer_program, rc, mds, inner_expect, outer_expect, n_slots):
+def verify(agg, inner_program, outer_program, rc, mds, inner_expect, outer_expect, n_slots, bn_tables=None):
     """agg: the aggregated proof (dict); inner_program / outer_program: constraint program blobs of the inner AIR and of the
     Merkle-verifier AIR; *_expect: the verifier's own STARK parameters for the two levels; n_slots: query slots of the outer
-    trace (a property of the verifier AIR's layout, given by whoever supplies its program)."""
+    trace (a property of the verifier AIR's layout, given by whoever supplies its program).  bn_tables: the Poseidon-BN254
+    tables when the OUTER proof is in BN128-hash mode (the final STARK over an aggregated proof's STARK: the inner proofs are
+    Goldilocks-mode either way)."""
     inner = agg["inner"]
     if not inner:
         raise V.Reject("no inner proofs")
-    heads = [V.verify(h, inner_program, rc, mds, inner_expect, trust_openings=True) for h in inner]
+    outer = agg["stark"]
+    # the Merkle part of the outer public inputs has a length the shapes fix; what follows it is the inner transcripts, proof by
+    # proof: absorbed blocks and read rates in protocol order.  Every inner proof is verified on a sponge that READS them.
+    probe = Program(inner_program) if not isinstance(inner_program, Program) else inner_program
+    sched, _ = V.fri_schedule(inner_expect["logn"], inner_expect["logb"], inner_expect["fri_logf"], inner_expect["fri_final_log"])
+    T = 2 + (1 if probe.width2 else 0) + len(sched)
+    per_query = probe.width + probe.width2 + 3 * probe.q_chunks + sum(3 << f for (_, f) in sched)
+    n_merkle = len(inner) * T * 4 + n_slots * len(inner) * (T + per_query)
+    sponge = V.PublicSponge([int(v) for v in outer["publics"]][n_merkle:])
+    heads = []
+    for h in inner:
+        sponge.queue, sponge.avail = [], []          # a fresh sponge per proof on the one stream
+        heads.append(V.verify(h, probe, rc, mds, inner_expect, trust_openings=True, public_transcript=sponge))
+    if sponge.pos != len(sponge.stream):
+        raise V.Reject("the outer proof's public inputs hold more transcript than the inner proofs have")
     W2 = heads[0]["W2"]
     depths = tree_depths(inner_expect["logn"], inner_expect["logb"], W2, heads[0]["sched"])
     want = []
@@ -60,8 +80,7 @@ def verify(agg, inner_program, outer_program, rc, mds, inner_expect, outer_expec
             q = h["queries"][g % nq]
             for part in [q["trace"]] + ([q["stage2"]] if W2 else []) + [q["quotient"]] + list(q["fri"]):
                 want += [int(v) for v in part["values"]]
-    outer = agg["stark"]
-    if [int(v) for v in outer["publics"]] != want:
+    if [int(v) for v in outer["publics"]][:n_merkle] != want:
         raise V.Reject("the outer proof's public inputs are not the inner proofs' roots, query indices and opened values")
     prog = outer_program if isinstance(outer_program, Program) else Program(outer_program)
-    return V.verify(outer, prog, rc, mds, outer_expect)
+    return V.verify(outer, prog, rc, mds, outer_expect, bn_tables)

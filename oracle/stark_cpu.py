@@ -52,6 +52,10 @@ class CpuBackend:
         from .stark_verify import publics_digest
         return publics_digest(pubs, self.rc, self.mds, self.hash_mode == "bn128")
 
+    def publics_digest_gl(self, pubs):
+        from .stark_verify import publics_digest
+        return publics_digest(pubs, self.rc, self.mds, False)
+
     def poseidon_perm_batch(self, states):
         return O.poseidon_perm(np.asarray(states, dtype=np.uint64), self.rc, self.mds)
 

@@ -52,6 +52,45 @@ class Sponge:
         return out
 
 
+class PublicSponge:
+    """the sponge above with NO hashing: every permutation is vouched for by a verifier-AIR STARK whose public inputs hold, in
+    protocol order, the values each permutation absorbs and the rate after every permutation the protocol reads
+    (oracle/aggregate_verify.py).  `stream` is that list; absorbing compares, squeezing reads."""
+
+    def __init__(self, stream):
+        self.stream, self.pos, self.queue, self.avail = [int(v) for v in stream], 0, [], []
+
+    def _take(self, n):
+        if self.pos + n > len(self.stream):
+            raise Reject("the public transcript is shorter than the protocol")
+        out = self.stream[self.pos:self.pos + n]
+        self.pos += n
+        return out
+
+    def absorb(self, vals):
+        self.queue.extend(int(v) % P for v in vals)
+        self.avail = []
+
+    def squeeze(self, n):
+        out = []
+        while len(out) < n:
+            if self.queue or not self.avail:
+                while self.queue:
+                    blk = self.queue[:8]
+                    del self.queue[:8]
+                    if self._take(len(blk)) != blk:
+                        raise Reject("the public transcript absorbs other values than the proof's")
+                self.avail = self._take(8)
+            out.append(self.avail.pop(0))
+        return out
+
+    def pow_digest(self, seed4, nonce):
+        """the grinding hash: seed || nonce in, the rate out"""
+        if self._take(5) != [int(v) for v in seed4] + [int(nonce)]:
+            raise Reject("the public grinding hash is over another seed or nonce")
+        return self._take(8)
+
+
 R_BN254 = NV.BN254_R
 
 
@@ -186,7 +225,7 @@ def expectation(params, root32=NV.ROOT32_DEFAULT, shift=NV.SHIFT_DEFAULT):
     return e
 
 
-def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, trust_openings=False):
+def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, trust_openings=False, public_transcript=None):
     """program: the constraint program blob (u64 words) of the statement;  expect: the verifier's own parameters
     {logn, logb, fri_logf, fri_final_log, n_queries, pow_bits, root32, shift [, hash]}.  hash = "bn128": the proof must be in
     BN128-hash mode (16-ary Poseidon-BN254 trees + transcript); bn_tables = (rc, mds, rp) of the t = 17 instance.
@@ -195,7 +234,9 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, t
     that stays outside a Merkle-verifier AIR; proof["queries"] is not read.
     trust_openings: run the WHOLE verifier -- transcript, identity, DEEP quotient and every FRI fold at every query -- on the opened
     values as given, without their authentication paths (which a Merkle-verifier STARK vouches for: oracle/aggregate_verify.py);
-    returns the same dictionary instead of True."""
+    returns the same dictionary instead of True.
+    public_transcript (Goldilocks mode, with trust_openings): a PublicSponge -- the transcript is READ from public inputs a
+    verifier-AIR STARK vouches for instead of being hashed here; the caller checks that the stream is used up."""
     rc = np.asarray(rc, dtype=np.uint64)
     mds = np.asarray(mds, dtype=np.uint64)
     air = program if isinstance(program, Program) else Program(program)
@@ -242,7 +283,7 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, t
         def opening_ok(values, m, idx, path, root):
             return merkle16_verify(O.merkle16_leaf(np.array(values, dtype=np.uint64)), m, idx, path, as_root(root))
     else:
-        tr = Sponge(perm)
+        tr = Sponge(perm) if public_transcript is None else public_transcript
         absorb_root = tr.absorb
 
         def opening_ok(values, m, idx, path, root):
@@ -315,10 +356,16 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, t
     if pow_bits:
         seed = tr.squeeze(4)
         nonce = proof.get("pow_nonce")
-        if nonce is None or not pow_ok(perm, seed, nonce, pow_bits):
+        if nonce is None or not 0 <= int(nonce) < P:
+            raise Reject("proof-of-work nonce missing or wrong")
+        if (public_transcript is None or bn) and not pow_ok(perm, seed, nonce, pow_bits):
             raise Reject("proof-of-work nonce missing or wrong")
         tr.absorb([nonce])
     qidx = [v & (M - 1) for v in tr.squeeze(n_queries)]
+    if pow_bits and public_transcript is not None and not bn:
+        # the grinding hash is the last permutation of a proof's public transcript: seed || nonce in, digest out
+        if public_transcript.pow_digest(seed, nonce)[0] >> (64 - pow_bits):
+            raise Reject("proof-of-work nonce missing or wrong")
     if not header_only and (len(proof["queries"]) != n_queries or [qq["index"] for qq in proof["queries"]] != qidx):
         raise Reject("query indices do not follow the transcript")
 

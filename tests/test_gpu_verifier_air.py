@@ -77,9 +77,9 @@ def test_aggregation_stark_gpu_equals_cpu_and_verifies(hip, tables, airname, log
         proofs.append(json.loads(PR.proof_to_json(PR.prove(air, tr, pub, params, hip))))
     shape = VA.Shape.of_proof(proofs[0], 2)
     vair = VA.verifier_air(shape, rc, mds)
-    d_gpu, pubs = VA.build_witness(shape, proofs, hip)               # assembled in HBM (zp_poseidon_trace + two host columns)
+    d_gpu, pubs = VA.build_witness(shape, proofs, hip, air.digest_words())               # assembled in HBM (zp_poseidon_trace + two host columns)
     t_gpu = hip.p.download(d_gpu, d_gpu.shape)
-    t_cpu, pubs_c = VA.build_witness(shape, proofs, cpu)
+    t_cpu, pubs_c = VA.build_witness(shape, proofs, cpu, air.digest_words())
     assert (t_gpu == t_cpu).all() and (pubs == pubs_c).all()
     ap = VA.aggregation_params(shape, n_queries=5, fri_final_log=3)
     p_cpu = PR.proof_to_json(PR.prove(vair, t_cpu, pubs, ap, cpu))
@@ -110,7 +110,7 @@ def test_engine_aggregate_and_final_prove_what_they_name(tables, tmp_path):
     text = eng.aggregate("agg", proofs[0]["proof"], proofs[-1]["proof"])
     agg = json.loads(text)
     assert agg["kind"] == "aggregated" and "standin" not in text and len(agg["inner"]) == 2
-    sh = VA.Shape(*[agg["shape"][k] for k in ("logn", "logb", "W", "W2", "Wq", "n_queries", "fri_logf", "fri_final_log", "n_proofs")])
+    sh = VA.Shape.from_dict(agg["shape"])
     vair = VA.verifier_air(sh, rc, mds)
     assert vair.digest() == agg["verifier_air_digest"]
     inner_exp = V.expectation(eng.stark_params(14).to_dict())
@@ -128,8 +128,14 @@ def test_engine_aggregate_and_final_prove_what_they_name(tables, tmp_path):
     fsp = json.loads(eng.final_starks["agg"])
     fsh = VA.Shape.of_proof(agg["stark"], 1)
     fair = VA.verifier_air(fsh, rc, mds)
-    assert fsp["air_digest"] == fair.digest() and [int(v) for v in fsp["publics"]] == VA.expected_publics(fsh, [agg["stark"]])
+    assert fsp["air_digest"] == fair.digest() and [int(v) for v in fsp["publics"]][:fsh.merkle_pubs()] == VA.expected_publics(fsh, [agg["stark"]])
     assert V.verify(fsp, fair.program(), rc, mds, V.expectation(eng.final_stark_params(agg["stark"]).to_dict()), bn254_poseidon_params(17))
+    # the final layer as a recursion layer: the aggregated proof's STARK without its paths + the final STARK = that STARK verifies
+    strip = lambda o: {k: v for k, v in o.items() if k != "path"}
+    hdr = dict(agg["stark"], queries=[{"index": q["index"], "trace": strip(q["trace"]), "quotient": strip(q["quotient"]),
+                                       "fri": [strip(f) for f in q["fri"]]} for q in agg["stark"]["queries"]])
+    assert AV.verify({"inner": [hdr], "stark": fsp}, vair.program(), fair.program(), rc, mds, outer_exp,
+                     V.expectation(eng.final_stark_params(agg["stark"]).to_dict()), fsh.n_slots(), bn254_poseidon_params(17))
     with pytest.raises(ValueError):
         eng.final("x", json.dumps({"kind": "something-else"}), "BN128", "1")
     print("stage timings:", json.dumps({k: v for k, v in eng.stage_timings.items() if k.startswith(("aggregate", "final"))}))

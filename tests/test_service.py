@@ -137,7 +137,7 @@ def _check_result(res, tables, block, svc=None):
         agg = json.loads(res["aggregated"])
         assert agg["kind"] == "aggregated" and "standin" not in res["aggregated"]
         inner_air = AIR.get_air(agg["inner"][0]["air"])
-        sh = VA.Shape(*[agg["shape"][k] for k in ("logn", "logb", "W", "W2", "Wq", "n_queries", "fri_logf", "fri_final_log", "n_proofs")])
+        sh = VA.Shape.from_dict(agg["shape"])
         vair = VA.verifier_air(sh, rc, mds)
         assert vair.digest() == agg["verifier_air_digest"] and sh.n_slots() == agg["slots"]
         inner_exp = V.expectation(svc.engine.stark_params(sh.logn).to_dict())
@@ -148,9 +148,16 @@ def _check_result(res, tables, block, svc=None):
         fsh = VA.Shape.of_proof(agg["stark"], 1)
         fair = VA.verifier_air(fsh, rc, mds)
         assert fsp["air_digest"] == fair.digest()
-        assert [int(v) for v in fsp["publics"]] == VA.expected_publics(fsh, [agg["stark"]])
+        assert [int(v) for v in fsp["publics"]][:fsh.merkle_pubs()] == VA.expected_publics(fsh, [agg["stark"]])
         assert V.verify(fsp, fair.program(), rc, mds, V.expectation(svc.engine.final_stark_params(agg["stark"]).to_dict()),
                         bn254_poseidon_params(17))
+        # ... and as a recursion layer: the aggregated proof's STARK without its paths + the final STARK = that STARK verifies
+        # (its arithmetic natively, its transcript read off the final STARK's public inputs, all hashing in the final STARK)
+        strip = lambda o: {k: v for k, v in o.items() if k != "path"}
+        hdr = dict(agg["stark"], queries=[{"index": q["index"], "trace": strip(q["trace"]), "quotient": strip(q["quotient"]),
+                                           "fri": [strip(f) for f in q["fri"]]} for q in agg["stark"]["queries"]])
+        assert AV.verify({"inner": [hdr], "stark": fsp}, vair.program(), fair.program(), rc, mds, outer_exp,
+                         V.expectation(svc.engine.final_stark_params(agg["stark"]).to_dict()), fsh.n_slots(), bn254_poseidon_params(17))
     # ProofResult as eigen-zeth stores it (src/db/mod.rs:63-71): json with 32-number arrays
     stored = json.dumps({k: res[k] for k in ("block_number", "proof", "public_input", "pre_state_root", "post_state_root")})
     assert len(json.loads(stored)["pre_state_root"]) == 32

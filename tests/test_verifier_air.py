@@ -51,7 +51,7 @@ def aggregated(cpu, inner, tables):
     air, params, proofs = inner
     shape = VA.Shape.of_proof(proofs[0], 2)
     vair = VA.verifier_air(shape, *tables)
-    trace, pubs = VA.build_witness(shape, proofs, cpu)
+    trace, pubs = VA.build_witness(shape, proofs, cpu, air.digest_words())
     ap = VA.aggregation_params(shape, n_queries=5, fri_final_log=3)
     stark = PR.prove(vair, trace, pubs, ap, cpu)
     return shape, vair, ap, trace, pubs, {"kind": "aggregated", "inner": [strip_paths(p) for p in proofs], "stark": stark}
@@ -77,14 +77,14 @@ def test_layout_and_schedule(inner):
     assert [t[0] for t in shape.trees] == ["trace", "stage2", "quotient", "fri0", "fri1"]
     k, periods, pb = shape.layout()
     assert periods & (periods - 1) == 0 and pb & (pb - 1) == 0 and k * periods >= shape.n_queries
-    assert k * 2 * shape.blocks_per_proof() <= pb
+    assert k * 2 * shape.blocks_per_proof() + 2 * len(shape.transcript_perms()) <= pb
     sched = shape.period_schedule()
     assert len(sched) == pb and sum(b["kind"] != "idle" for b in sched) == k * 2 * shape.blocks_per_proof()
     assert sum(b["last"] for b in sched) == k * 2 * len(shape.trees)      # one root comparison per (slot, proof, tree)
     # the service's shapes: two 2^20-row chunk proofs fit a 2^20-row verifier trace, its own proof a 2^18-row final trace
-    big = VA.Shape(20, 1, 64, 12, 3, 80, 3, 5, 2)
+    big = VA.Shape(20, 1, 64, 12, 3, 80, 3, 5, 2, 16, 20)
     assert big.logn_trace() == 20
-    assert VA.Shape(20, 2, 26, 0, 9, 50, 3, 5, 1).logn_trace() == 18
+    assert VA.Shape(20, 2, 26, 0, 9, 50, 3, 5, 1, big.n_pub(), 0).logn_trace() == 18
 
 
 def test_aggregated_proof_is_accepted_by_the_independent_verifier(inner, aggregated, tables):
@@ -97,7 +97,7 @@ def test_aggregated_proof_is_accepted_by_the_independent_verifier(inner, aggrega
 
 
 def test_tampered_inner_proof_has_no_accepting_witness(inner, cpu):
-    _, _, proofs = inner
+    air, _, proofs = inner
     shape = VA.Shape.of_proof(proofs[0], 2)
     for mutate in (lambda p: p[1]["queries"][2]["trace"]["values"].__setitem__(5, p[1]["queries"][2]["trace"]["values"][5] ^ 1),
                    lambda p: p[0]["queries"][1]["fri"][0]["path"][2].__setitem__(1, p[0]["queries"][1]["fri"][0]["path"][2][1] ^ 1),
@@ -107,7 +107,7 @@ def test_tampered_inner_proof_has_no_accepting_witness(inner, cpu):
         bad = copy.deepcopy(proofs)
         mutate(bad)
         with pytest.raises(ValueError, match="no accepting witness"):
-            VA.build_witness(shape, bad, cpu)
+            VA.build_witness(shape, bad, cpu, air.digest_words())
 
 
 def test_forged_witnesses_are_rejected(inner, aggregated, cpu, tables):
@@ -146,6 +146,25 @@ def test_forged_witnesses_are_rejected(inner, aggregated, cpu, tables):
     p7[shape.pub_value(0, 0, 2, 1)] = (int(p7[shape.pub_value(0, 0, 2, 1)]) + 1) % P   # ... of an unhashed (3-value) quotient leaf
     rejected(trace, p7)
     assert len(pubs) > PR.PUBLICS_INLINE                                              # the publics enter the transcript through their digest
+    # the transcripts: a claimed challenge that the sponge does not give, an absorbed value other than the hashed one, a cell of
+    # a transcript permutation, a broken capacity chain
+    perms = shape.transcript_perms()
+    j_out = next(j for j, pm in enumerate(perms) if pm["out"] and not pm["pow"])
+    p8 = pubs.copy()
+    p8[shape.pub_tout(1, j_out, 2)] = (int(p8[shape.pub_tout(1, j_out, 2)]) + 1) % P
+    rejected(trace, p8)
+    p9 = pubs.copy()
+    p9[shape.pub_tin(0, 1, 0)] = (int(p9[shape.pub_tin(0, 1, 0)]) + 1) % P
+    rejected(trace, p9)
+    blk = shape.transcript_block0() + len(perms) + 2                                  # proof 1, its third permutation
+    t10 = trace.copy()
+    t10[VA.S0 + 9, 32 * blk] = (int(t10[VA.S0 + 9, 32 * blk]) + 1) % P                # its capacity is not the previous permutation's
+    rejected(t10, pubs)
+    j_pow = len(perms) - 1
+    assert perms[j_pow]["pow"]
+    p11 = pubs.copy()
+    p11[shape.pub_tout(0, j_pow, 0)] = 1                                              # claim a grinding digest with more leading zeros
+    rejected(trace, p11)
 
 
 def test_outer_publics_must_follow_the_inner_transcripts(inner, aggregated, tables):
@@ -163,11 +182,19 @@ def test_outer_publics_must_follow_the_inner_transcripts(inner, aggregated, tabl
         AV.verify(bad, *args)
     bad = copy.deepcopy(agg)
     bad["inner"] = bad["inner"][::-1]                          # the outer proof names proof 0's roots first
-    with pytest.raises(V.Reject, match="public inputs"):
+    with pytest.raises(V.Reject, match="public inputs|public transcript"):
         AV.verify(bad, *args)
     bad = copy.deepcopy(agg)
     v = bad["inner"][0]["queries"][1]["fri"][1]["values"]      # an opened value that is not the committed one: the inner proof's own
     v[2] = (v[2] + 1) % P                                      # fold check fails natively (and it would not match the outer publics)
+    with pytest.raises(V.Reject):
+        AV.verify(bad, *args)
+    bad = copy.deepcopy(agg)
+    bad["inner"][0]["pow_nonce"] ^= 1                          # another nonce than the one the circuit hashed
+    with pytest.raises(V.Reject, match="transcript|grinding"):
+        AV.verify(bad, *args)
+    bad = copy.deepcopy(agg)                                   # a transcript section that is too long / too short
+    bad["stark"]["publics"] = list(bad["stark"]["publics"]) + [0]
     with pytest.raises(V.Reject):
         AV.verify(bad, *args)
     with pytest.raises(V.Reject):                              # fewer inner queries than the verifier requires
@@ -186,7 +213,7 @@ def test_single_proof_shape_and_identity_leaves(cpu, tables):
     shape = VA.Shape.of_proof(proof, 1)
     assert shape.trees[0][1] == 2 and VA.Shape.absorb_blocks(2) == 0             # the trace leaves of `fib` are identity leaves too
     vair = VA.verifier_air(shape, rc, mds)
-    trace, pubs = VA.build_witness(shape, [proof], cpu)
+    trace, pubs = VA.build_witness(shape, [proof], cpu, air.digest_words())
     ap = VA.aggregation_params(shape, n_queries=4, fri_final_log=3)
     assert V.verify(PR.prove(vair, trace, pubs, ap, cpu), vair.program(), rc, mds, V.expectation(ap.to_dict()))
-    assert [int(v) for v in pubs] == VA.expected_publics(shape, [proof])
+    assert [int(v) for v in pubs][:shape.merkle_pubs()] == VA.expected_publics(shape, [proof])

@@ -5,7 +5,7 @@ import collections, json, os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eigen_zeth_amd.service.engine import Engine, EngineConfig
 from eigen_zeth_amd.service.server import default_backend_factory
-from eigen_zeth_amd.stark import verifier_air as VA
+from eigen_zeth_amd.stark import air as AIR, verifier_air as VA
 
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 cfg = EngineConfig(air="chunk64", logn=logn, groth16_logm=8, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_rec_%d" % os.getuid()))
@@ -14,11 +14,11 @@ ch = eng.gen_batch_chunks("r", [1, 2], 12345, "evm")
 proofs = [json.loads(p["proof"]) for p in eng.gen_chunk_proofs("r", ch["task_id"], ch["chunk_count"], ch["batch_data"])]
 
 
-def profile(be, inner, params_of, label):
+def profile(be, inner, params_of, label, inner_air):
     rc, mds = eng._tables(be)
     shape = VA.Shape.of_proof(inner[0], len(inner))
     vair = VA.verifier_air(shape, rc, mds)
-    trace, pubs = VA.build_witness(shape, inner, be)
+    trace, pubs = VA.build_witness(shape, inner, be, inner_air.digest_words())
     params = params_of(shape)
     d = be.p.upload(trace)
     fn = be.p.stark_prove_bn128 if params.hash == "bn128" else be.p.stark_prove
@@ -42,5 +42,7 @@ def profile(be, inner, params_of, label):
     return json.loads(text)
 
 
-agg = profile(eng.be, proofs, lambda sh: VA.aggregation_params(sh, cfg.agg_queries, cfg.fri_logf, cfg.fri_final_log, cfg.agg_pow_bits), "aggregation (Goldilocks mode)")
-profile(eng.be_bn128, [agg], lambda sh: eng.final_stark_params(agg), "final (BN128-hash mode)")
+agg = profile(eng.be, proofs, lambda sh: VA.aggregation_params(sh, cfg.agg_queries, cfg.fri_logf, cfg.fri_final_log, cfg.agg_pow_bits), "aggregation (Goldilocks mode)",
+              AIR.get_air("chunk64"))
+profile(eng.be_bn128, [agg], lambda sh: eng.final_stark_params(agg), "final (BN128-hash mode)",
+        VA.verifier_air(VA.Shape.of_proof(proofs[0], len(proofs)), *eng._tables(eng.be)))
