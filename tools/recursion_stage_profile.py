@@ -20,7 +20,7 @@ def profile(be, inner, params_of, label, inner_air):
     vair = VA.verifier_air(shape, rc, mds)
     trace, pubs = VA.build_witness(shape, inner, be, inner_air.digest_words())
     params = params_of(shape)
-    d = be.p.upload(trace)
+    d = trace if hasattr(trace, "ptr") else be.p.upload(trace)      # the GPU backend assembles the trace in HBM
     fn = be.p.stark_prove_bn128 if params.hash == "bn128" else be.p.stark_prove
     args = (vair.name, vair.program(), d, [int(v) for v in pubs], params.logn, params.logb, params.fri_logf, params.fri_final_log, params.n_queries)
     if params.hash != "bn128":
