@@ -224,6 +224,8 @@ def main():
     logn, cols = args.logn, args.cols
     N = 1 << logn
     prover = Prover(local, stream=torch.cuda.current_stream().cuda_stream)
+    if os.environ.get("ZP_NTT_TW1"):          # A/B knob: 0 = per-lane twiddle chains in the first pass instead of the full table
+        prover.set_tuning("ntt_tw1", int(os.environ["ZP_NTT_TW1"]))
     if os.environ.get("ZP_NTT_CHUNK_LOG"):
         prover.set_tuning("ntt_chunk_log", int(os.environ["ZP_NTT_CHUNK_LOG"]))
     x = random_field_tensor(torch, (cols, N), dev, 0xE16E2E70 + 4 + rank)
@@ -291,14 +293,16 @@ def main():
         pass_rows = []
         for i, ps in enumerate(plan["passes"]):
             first, last = i == 0, i == len(plan["passes"]) - 1
-            mode = 1 if first else (0 if last else 1)          # forward transform: table passes in the middle, plain last pass
+            tw1 = first and plan.get("first_pass_table", False)
+            mode = (3 if tw1 else 1) if first else (0 if last else 1)   # forward transform: table passes in the middle, plain last pass
             logt = {1: 0, 2: 1, 4: 2, 8: 3, 16: 4, 32: 5}[ps["tile"]]
             name = "ntt_pass2_kernel<%d, %d, %d, %d, %s, false, %d, false>" % (ps["rounds"][0], ps["rounds"][1], ps["rounds"][2], logt,
                                                                                  "true" if first else "false", mode)
             ms_l = by_pass.get(i, [])
             assert all(abs(rl) == ps["radix_log"] for rl, _ in passes[i::npass]), "pass timings out of step with the plan"
             a_ms = sum(ms_l) / len(ms_l) if ms_l else None
-            pass_rows.append({"kernel": name, "role": "transposing first pass (per-lane twiddle chain)" if first else
+            pass_rows.append({"kernel": name, "role": ("transposing first pass (full twiddle table, shared by the columns through L2)" if tw1 else
+                                                       "transposing first pass (per-lane twiddle chain)") if first else
                               ("plain last pass" if last else "pass with a per-tile twiddle table"),
                               "launches": len(ms_l), "avg_launch_ms": a_ms,
                               "frac": (alg_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if a_ms else None})

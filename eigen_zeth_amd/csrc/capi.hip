@@ -51,6 +51,7 @@ void zp_destroy(zp_ctx *ctx) {
         if (kv.second.d_twl) (void)hipFree(kv.second.d_twl);
         if (kv.second.d_twh) (void)hipFree(kv.second.d_twh);
         if (kv.second.d_tws) (void)hipFree(kv.second.d_tws);
+        if (kv.second.d_tw1) (void)hipFree(kv.second.d_tw1);
     }
     for (auto &c : ctx->cosets) {
         if (c.d_lo) (void)hipFree(c.d_lo);
@@ -96,6 +97,7 @@ static void drop_plans(zp_ctx *ctx) {
         if (kv.second.d_twl) (void)hipFree(kv.second.d_twl);
         if (kv.second.d_twh) (void)hipFree(kv.second.d_twh);
         if (kv.second.d_tws) (void)hipFree(kv.second.d_tws);
+        if (kv.second.d_tw1) (void)hipFree(kv.second.d_tw1);
     }
     ctx->plans.clear();
 }
@@ -457,6 +459,7 @@ int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value) {
     else if (!strcmp(key, "ntt_chunk_log")) ctx->tune_ntt_chunk_log = value;
     else if (!strcmp(key, "ntt_maxl")) ctx->tune_ntt_maxl = value;
     else if (!strcmp(key, "ntt_order")) ctx->tune_ntt_order = value;
+    else if (!strcmp(key, "ntt_tw1")) ctx->tune_ntt_tw1 = value;
     else if (!strcmp(key, "merkle_coop_log")) ctx->tune_merkle_coop_log = value;
     else if (!strcmp(key, "p254_bulk_log")) ctx->tune_p254_bulk_log = value;
     else { ctx->err = "unknown tuning key"; return ZP_ERR_ARG; }
@@ -528,7 +531,9 @@ int32_t zp_ntt_plan_json(zp_ctx *ctx, int32_t logn, char *buf, size_t buflen) {
         s += "{\"radix_log\": " + std::to_string(p.L) + ", \"rounds\": [" + std::to_string(p.A1) + ", " +
              std::to_string(p.A2) + ", " + std::to_string(p.A3) + "], \"tile\": " + std::to_string(p.L == 8 ? (1 << ctx->tune_logt) : (1 << p.logT)) + "}";
     }
-    s += "], \"small_kernel\": ";
+    s += "], \"first_pass_table\": ";   // the transposing pass multiplies by the full precomputed table (MODE 3) instead of per-lane chains
+    s += (pl->npass >= 1 && logn > 12 && logn <= ctx->tune_ntt_tw1 && logn <= 28 && pl->pass[0].A3 == 0 && pl->pass[0].L >= 7) ? "true" : "false";
+    s += ", \"small_kernel\": ";
     s += (logn <= 12) ? "true" : "false";
     s += "}";
     ZP_ARG(ctx, s.size() + 1 <= buflen, "buffer too small");

@@ -26,6 +26,7 @@ struct NttPlan {
     u64 *d_twl = nullptr;     // 2^lb entries
     u64 *d_twh = nullptr;     // 2^(logn-lb) entries
     u64 *d_tws = nullptr;     // w_4096^e (direction matched), 4096 entries
+    u64 *d_tw1 = nullptr;     // first (transposing) pass: w^(u k) at [u * R + k], all 2^logn of them (null: per-lane chains)
     u64 w16[8];               // w_16^i (direction matched)
     u64 ninv = 1;
     int j0inv = 0;            // w_16 = (2^12)^j0 ; j0inv = j0^-1 mod 16 (0: not on the power-of-two path)
@@ -65,6 +66,7 @@ struct zp_ctx {
     void *msm_arena = nullptr;    // scratch of zp_msm_bn254*: grows to the largest run, freed by zp_destroy
     size_t msm_arena_bytes = 0;
     int tune_logt = 4, tune_tpw = 2, tune_logt9 = 5;   // tiles per workgroup: 2 measured best with the gl_asm.hpp arithmetic (profiles/r2_ntt_sweep.txt)
+    int tune_ntt_tw1 = 26;        // largest log size whose first pass multiplies by a full precomputed table (0: always the per-lane chain)
     int tune_ntt_order = 0;       // plan digit order: 0 auto (a radix-512 digit goes last), 1 larger radices first, 2 larger radices last
     int tune_ntt_maxl = 0;        // 0 = 9: largest log2 radix of one NTT pass (10: 1024-thread workgroups, two-pass plans up to 2^20)
     int tune_merkle_coop_log = 0; // 0 = 15: tree levels with <= 2^15 nodes go to the 12-lanes-per-node subtree kernel

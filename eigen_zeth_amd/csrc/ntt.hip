@@ -34,11 +34,13 @@ struct PassArgs {
     u64 in_valid;       // elements per input column that are real; the rest reads as zero
     const u64 *twl, *twh;
     const u64 *tws;
+    const u64 *tw1;        // transposing pass, table form: w^(u k) at [u * R + k] (MODE 3)
     const u64 *csl, *csh;  // coset post-scale tables (last pass of the inverse transform in LDE)
     u64 scale;
     int logn, logPprev, lb, cslb;
     int j0inv;  // w_16(user) = (2^12)^j0, j0inv = j0^-1 mod 16; 0 = root not a power of two path (generic twiddles)
     int flags;  // 1: inter-pass twiddle  2: multiply by `scale`  4: coset post-scale
+    int ncols;  // MODE 3: the grid is one-dimensional, columns of one launch
 };
 
 __device__ __forceinline__ constexpr int brev(int x, int bits) {
@@ -189,6 +191,12 @@ __device__ __forceinline__ void exchange2(u64 *v, u64 *lds, const u64 *twr, int 
 //  * TRANSPOSE=true (pass 1, Pprev = 1): s = u varies with the lane; w^(u*k) is a per-lane geometric
 //    chain walked in the order the shift butterflies deliver outputs: k_j = jr*i mod 2^A, so
 //    h^(k_j) = (h^jr)^i * (h^-(2^A))^floor(jr*i/2^A).
+//    Table form (MODE 3): the N factors w^(u*k) of a transform are the same for every column, so they are precomputed once per
+//    plan in the order of the transposing copy-out ([u][k]: 8 bytes per element, coalesced) and multiplied in while the tile
+//    leaves LDS -- one product per element instead of the chain's two and none of its exponent arithmetic.  What makes the
+//    extra 8 bytes per element affordable is that they are read from HBM once per 8 columns: the grid is one-dimensional and
+//    ordered so that the columns of one tile run next to each other on ONE XCD (workgroup id % 8 picks the XCD), and the
+//    table loads are cacheable, so 7 of 8 reads are hits in that XCD's L2.
 // MODE (non-transposing passes): 0 = plain last pass, 1 = multiply by the per-tile table,
 // 2 = table and the per-lane part of a coset power (last pass of the inverse transform in an LDE)
 template <int A1, int A2, int A3, int LOGT, bool TRANSPOSE, bool PADDED, int MODE, bool BIG = false>
@@ -205,7 +213,14 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     u64 *tab = lds + R * T;                    // R entries: per-tile inter-pass twiddles (HAS_TAB)
     u64 *twr1 = tab + (HAS_TAB ? R : 0);       // R entries:  w_R^e      (inter-round twiddles, first exchange)
     u64 *twr2 = twr1 + R;                      // R2 entries: w_(R2)^e   (second exchange, 3-round passes)
-    const u64 col = blockIdx.y;
+    constexpr bool TW1 = TRANSPOSE && MODE == 3;
+    // MODE 3: one-dimensional grid; workgroup id -> (XCD x = id % 8, j = id / 8): column = j % ncols, tile group = (j / ncols) * 8 + x
+    u64 col = blockIdx.y, wg_lin = blockIdx.x;
+    if constexpr (TW1) {
+        const u64 x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        col = j % (u64)a.ncols;
+        wg_lin = (j / (u64)a.ncols) * 8 + x;
+    }
     const int logNR = a.logn - L;
     const int logP = a.logPprev;
     const u64 N = 1ULL << a.logn;
@@ -213,7 +228,7 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     u64 *dst = a.out + col * a.out_cs;
     u64 v[16], vn[16];
     // twiddle-table entries fetched one tile ahead (raw lo/hi halves)
-    constexpr int NTW = TRANSPOSE ? (GRJ + 2) : (MODE == 2 ? TPL + 1 : TPL);
+    constexpr int NTW = TW1 ? 1 : TRANSPOSE ? (GRJ + 2) : (MODE == 2 ? TPL + 1 : TPL);
     u64 twl_c[NTW], twh_c[NTW], twl_n[NTW], twh_n[NTW];
 
     // Addressing: row j of a lane's 16 loads is  (uniform: column base + (j << POS1) rows + u0)  +  (lane: slot0 rows + t).
@@ -245,7 +260,9 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
             }
         }
         const u64 lm = (1ULL << a.lb) - 1;
-        if constexpr (TRANSPOSE) {
+        if constexpr (TW1) {
+            (void)tl; (void)th; (void)lm;
+        } else if constexpr (TRANSPOSE) {
             const int t = tid & (T - 1);
             const u64 u = u0 + t;
             const int jr = a.j0inv & ((1 << AJ) - 1);
@@ -277,8 +294,8 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     // Runs shorter than a 128-byte line (T < 16) are shared between neighbouring tiles: hand neighbours to workgroups
     // of the same XCD (blockIdx % 8 -- a speed hint only, MI355X_MICROARCH.md "Workgroup dispatch") so that the other
     // parts of a line are L2 hits; measured on the bare access pattern: 2.7 -> 4.8 TB/s (profiles/r2_ubench_mem.txt)
-    u64 wg = blockIdx.x;
-    if constexpr (LOGT < 4) {
+    u64 wg = wg_lin;
+    if constexpr (LOGT < 4 && !TW1) {
         if ((gridDim.x & 7u) == 0) wg = (u64)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     }
     const u64 tile0 = wg * tiles_per_wg;
@@ -340,7 +357,14 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
             const int gamma = g * NT + tid;
             const int t = gamma & (T - 1), o = gamma >> LOGT;
             const int klow = G::kof(o << AJ);
-            if constexpr (TRANSPOSE) {
+            if constexpr (TW1) {
+                const int jr = a.j0inv & ((1 << AJ) - 1);
+#pragma unroll
+                for (int i = 0; i < (1 << AJ); i++) {
+                    const int kj = (jr * i) & ((1 << AJ) - 1);
+                    lds[G::lpos(slot_of(o, kj, 0, AJ), t)] = v[g * (1 << AJ) + brev(i, AJ)];
+                }
+            } else if constexpr (TRANSPOSE) {
                 const int jr = a.j0inv & ((1 << AJ) - 1);  // odd, < 2^AJ: floor(jr*i/2^AJ) steps by 0 or 1
                 u64 w = gl_mul(twl_c[g], twh_c[g]);
                 const u64 hj = gl_mul(twl_c[GRJ], twh_c[GRJ]);
@@ -388,7 +412,23 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
                 }
             }
         }
-        if constexpr (TRANSPOSE) {
+        if constexpr (TW1) {
+            // v is dead (the tile sits in LDS): its registers take the 16 factors of the elements this lane copies out
+            const u64 *twb = a.tw1 + (u0 << L);
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = twb[i * NT + tid];       // cacheable: the other columns of this tile hit in L2
+            lds_barrier();
+            u64 *blk = dst + (u0 << L);
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const int ia = i * NT + tid, ib = (i + 1) * NT + tid;
+                u64 xa = lds[G::lpos(G::sigma_of_k(ia & ((1 << L) - 1)), ia >> L)];
+                u64 xb = lds[G::lpos(G::sigma_of_k(ib & ((1 << L) - 1)), ib >> L)];
+                gl_mul2(xa, v[i], xb, v[i + 1]);
+                ZP_STG(&blk[ia], xa);
+                ZP_STG(&blk[ib], xb);
+            }
+        } else if constexpr (TRANSPOSE) {
             lds_barrier();
             u64 *blk = dst + (u0 << L);
 #pragma unroll
@@ -468,6 +508,14 @@ __global__ void __launch_bounds__(256) twiddle_rows_kernel(u64 *rows, int logn_r
     rows[i] = gl_mul(rows[i], tw_lookup(lo, hi, lb, e));
 }
 
+// the table of the transposing pass (MODE 3): out[u * R + k] = w^(u k mod N), N = 2^logn, R = 2^L
+__global__ void __launch_bounds__(256) tw1_fill_kernel(u64 *out, int logn, int L, const u64 *lo, const u64 *hi, int lb) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >> logn) return;
+    const u64 u = i >> L, k = i & ((1ULL << L) - 1);
+    out[i] = tw_lookup(lo, hi, lb, (u * k) & ((1ULL << logn) - 1));
+}
+
 template <int A1, int A2, int A3, int LOGT, bool BIG = false>
 int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
     using G = Geo<A1, A2, A3, LOGT>;
@@ -480,6 +528,17 @@ int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
     // tile + (per-tile table: non-transposing passes with a multiplication) + (LDS copies of the inter-round twiddles, L <= 10)
     const bool has_tab = !transpose && (a.flags & 7) != 0;
     const size_t shmem = ((size_t)G::R * G::T + (has_tab ? G::R : 0) + (G::L <= 10 ? G::R + (1 << (A2 + A3)) : 0)) * sizeof(u64);
+    if constexpr (!BIG && A3 == 0) {
+        if (transpose && a.tw1 && (grid.x & 7u) == 0) {
+            const bool padded = a.in_valid != (1ULL << a.logn);
+            auto k = padded ? ntt_pass2_kernel<A1, A2, A3, LOGT, true, true, 3, false> : ntt_pass2_kernel<A1, A2, A3, LOGT, true, false, 3, false>;
+            PassArgs b = a;
+            b.ncols = W;
+            hipLaunchKernelGGL(k, dim3(grid.x * (unsigned)W), block, shmem, ctx->stream, b, tpw);
+            ZP_HIP(ctx, hipGetLastError());
+            return ZP_OK;
+        }
+    }
     if (transpose) {
         const bool padded = a.in_valid != (1ULL << a.logn);
         auto k = padded ? ntt_pass2_kernel<A1, A2, A3, LOGT, true, true, 1, BIG> : ntt_pass2_kernel<A1, A2, A3, LOGT, true, false, 1, BIG>;
@@ -759,6 +818,14 @@ int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, b
     if (wc < 1) wc = 1;
     if (wc > W) wc = W;
     const int m = pl->npass;
+    // the first pass's full table (8 bytes per element of ONE column, shared by all columns and all later calls of this size):
+    // built at the first use of a plan by radix-2^7 / 2^8 two-round passes below 2^29 rows
+    if (!pl->d_tw1 && logn <= ctx->tune_ntt_tw1 && logn <= 28 && pl->pass[0].A3 == 0 && pl->pass[0].L >= 7) {
+        ZP_HIP(ctx, hipMalloc((void **)&pl->d_tw1, N * sizeof(u64)));
+        hipLaunchKernelGGL(tw1_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, pl->d_tw1, logn, pl->pass[0].L,
+                           pl->d_twl, pl->d_twh, pl->lb);
+        ZP_HIP(ctx, hipGetLastError());
+    }
     u64 *s0 = nullptr, *s1 = nullptr;
     if (m >= 2) ZP_TRY(zpi_scratch(ctx, 0, (size_t)wc << logn, &s0));
     if (m >= 3) ZP_TRY(zpi_scratch(ctx, 1, (size_t)wc << logn, &s1));
@@ -781,6 +848,7 @@ int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, b
             a.twh = pl->d_twh;
             a.lb = pl->lb;
             a.tws = pl->d_tws;
+            a.tw1 = (i == 0 && logn <= ctx->tune_ntt_tw1) ? pl->d_tw1 : nullptr;
             a.scale = pl->ninv;
             a.logn = logn;
             a.logPprev = pl->pass[i].logPprev;
