@@ -123,6 +123,36 @@ def test_two_pass_ntt_plans_match_oracle(prover, maxl, logn, W):
         prover.set_tuning("ntt_maxl", 0)
 
 
+@pytest.mark.parametrize("logn,W", [(16, 3), (18, 9), (20, 8), (21, 5)])
+def test_first_pass_table_and_chain_forms_match_oracle(prover, logn, W):
+    """the transposing first pass in both forms -- MODE 3 (default: the N twiddles from one table shared by the columns, a
+    one-dimensional XCD-ordered grid, any column count) and the per-lane chain (knob ntt_tw1 = 0) -- forward, inverse and a
+    zero-padded LDE against the oracle"""
+    x = O.random_field((W, 1 << logn), 4300 + logn)
+    x[0, :4] = np.array([0, P - 1, 1, 2 ** 32], dtype=np.uint64)
+    ref = O.ntt(x)
+    ext = O.lde(x, 1) if logn <= 20 else None
+    d_in, d_out = prover.upload(x), prover.alloc(W << logn)
+    d_ext = prover.alloc(W << (logn + 1)) if ext is not None else None
+    try:
+        for tw1 in (26, 0):
+            prover.set_tuning("ntt_tw1", tw1)
+            assert prover.ntt_plan(logn)["first_pass_table"] == (tw1 > 0)
+            prover.ntt(d_in, d_out, logn, W)
+            assert (prover.download(d_out, (W, 1 << logn)) == ref).all()
+            prover.intt(d_out, d_out, logn, W)
+            assert (prover.download(d_out, (W, 1 << logn)) == x).all()
+            if ext is not None:
+                prover.lde(d_in, d_ext, logn, 1, W)
+                assert (prover.download(d_ext, (W, 2 << logn)) == ext).all()
+    finally:
+        prover.set_tuning("ntt_tw1", 26)
+        d_in.free()
+        d_out.free()
+        if d_ext is not None:
+            d_ext.free()
+
+
 def test_ntt_2p29_rows_uses_64bit_offsets(prover):
     """logn = 29 > 28: the BIG instantiation (64-bit lane offsets).  One 4 GiB column, size-independent properties:
     iNTT(NTT(x)) = x, X[0] = sum x, X[N/2] = alternating sum, and the transform of a delta is the powers of the root"""
