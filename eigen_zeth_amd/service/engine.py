@@ -324,8 +324,13 @@ class Engine:
         try:
             proofs = [json.loads(p1)] if p1 == p2 else [json.loads(p1), json.loads(p2)]
             for pr in proofs:
-                if "queries" not in pr or "roots" not in pr:
+                if not isinstance(pr, dict) or "queries" not in pr or "roots" not in pr or not isinstance(pr.get("params"), dict):
                     raise ValueError("not a chunk proof")
+                # this prover aggregates chunk proofs made under ITS security parameters (the text comes from the client: nothing
+                # below is sized by numbers it could choose freely)
+                lg = pr["params"].get("logn")
+                if not isinstance(lg, int) or not 1 <= lg <= 28 or pr["params"] != self.stark_params(lg).to_dict():
+                    raise ValueError("chunk proof was not made under this prover's parameters")
         except (json.JSONDecodeError, TypeError) as e:
             raise ValueError("recursive proof is not a chunk proof: %s" % e)
         tm = {}
@@ -379,7 +384,7 @@ class Engine:
             if agg.get("kind") != "aggregated" or "queries" not in outer:
                 raise KeyError("kind")
             agg_air = VA.verifier_air(VA.Shape.from_dict(agg["shape"]), *self._tables(self.be_bn128))   # the statement of agg["stark"]
-        except (json.JSONDecodeError, TypeError, KeyError, AssertionError) as e:
+        except (json.JSONDecodeError, TypeError, KeyError, AssertionError, ValueError) as e:
             raise ValueError("recursive proof is not an aggregated proof of this prover (%s)" % e)
         tmf = {}
         fshape, fair, fp, final_stark = self._prove_merkle_verifier([outer], lambda sh: self.final_stark_params(outer), self.be_bn128, tmf, agg_air)

@@ -92,7 +92,14 @@ class Shape:
 
     @staticmethod
     def from_dict(d):
-        return Shape(*[d[k] for k in Shape.KEY_NAMES])
+        """shape named by an aggregated proof (untrusted text: bounded before anything is sized by it)"""
+        v = [d[k] for k in Shape.KEY_NAMES]
+        lim = dict(zip(Shape.KEY_NAMES, (30, 8, 4096, 4096, 64, 4096, 8, 16, 64, 1 << 24, 64)))
+        if not all(isinstance(x, int) and not isinstance(x, bool) and 0 <= x <= lim[k] for k, x in zip(Shape.KEY_NAMES, v)):
+            raise ValueError("shape out of range")
+        if v[0] < 1 or v[1] < 1 or v[2] < 1 or v[4] < 1 or v[5] < 1 or v[6] < 1 or v[8] < 1 or v[0] + v[1] > 32:
+            raise ValueError("shape out of range")
+        return Shape(*v)
 
     # ---- the Fiat-Shamir transcript of one inner proof, as a list of permutations
     def transcript_perms(self):
