@@ -23,9 +23,11 @@ def main():
     ap.add_argument("--metrics-port", type=int, default=None, help="serve Prometheus text metrics on /metrics")
     ap.add_argument("--agg-queries", type=int, default=50, help="queries of the aggregation STARK over the Merkle-verifier AIR (blow-up 4: 2 bits each)")
     ap.add_argument("--final-queries", type=int, default=50, help="queries of the final STARK (BN128-hash mode, Merkle-verifier AIR over the aggregated proof; blow-up 4, no grinding)")
+    ap.add_argument("--aggregate-all-chunks", action="store_true",
+                    help="GenAggregatedProof verifies EVERY chunk proof of the batch when the request names its first and last one (default: the two named proofs, as the wire contract says)")
     a = ap.parse_args()
     server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, logb=a.logb, chunks_per_block=a.chunks_per_block, l2_addr=a.l2_addr, n_queries=a.n_queries, pow_bits=a.pow_bits,
-                                                               agg_queries=a.agg_queries, final_queries=a.final_queries), a.device,
+                                                               agg_queries=a.agg_queries, final_queries=a.final_queries, aggregate_all_chunks=a.aggregate_all_chunks), a.device,
                          metrics_port=a.metrics_port,
                          devices=[int(x) for x in a.devices.split(',')] if a.devices else None)
     print("prover.v1.ProverService listening on %s:%d  (chunk STARKs: %d queries x blow-up %d + %d grinding bits = %d bits conjectured)"

@@ -39,8 +39,14 @@ class EngineConfig:
                  groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
                  witness_threads=8, prover_streams=8, pow_bits=20,
                  final_air="chunk16", final_logn=10, final_logb=2, final_queries=50, native_prover=True,
-                 agg_queries=50, agg_pow_bits=0):
+                 agg_queries=50, agg_pow_bits=0, aggregate_all_chunks=False):
         self.air, self.logn, self.logb = air, logn, logb
+        # GenAggregatedProof names two proofs -- the client sends the first and the last chunk proof of a batch
+        # (src/prover/provider.rs:385-388).  False: exactly those two are verified (the wire contract taken literally).  True: when
+        # they ARE the first and last chunk proof of a batch this engine has just proven, every chunk proof of the batch is verified
+        # by the one aggregation STARK (n_proofs = chunk count: the final proof then covers the whole batch, at ~ chunk count / 2
+        # times the aggregation cost).
+        self.aggregate_all_chunks = aggregate_all_chunks
         self.chunks_per_block, self.n_queries, self.pow_bits = chunks_per_block, n_queries, pow_bits
         self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
         self.groth16_logm, self.crs_dir = groth16_logm, crs_dir
@@ -61,6 +67,7 @@ class Engine:
         self._be = None
         self._be_bn = None        # backend of the final STARK (BN128-hash mode), created at the first GenFinalProof
         self.final_starks = {}    # batch_id -> final STARK JSON of the most recent batches (inspection / tests)
+        self._batch_chunk_proofs = {}   # batch_id -> chunk proof texts of the most recent batches (cfg.aggregate_all_chunks)
         self.cfg = config or EngineConfig()
         self.stage_timings = {}
         self.metrics = None   # service/metrics.py Metrics, attached by serve()
@@ -267,7 +274,11 @@ class Engine:
                 ThreadPoolExecutor(max_workers=n_streams) as ppool:
             wfuts = [wpool.submit(witness_bounded, i, ch) for i, ch in enumerate(chunks)]
             pfuts = [ppool.submit(prove_chunk, i, ch, wfuts[i]) for i, ch in enumerate(chunks)]
-            return [f.result() for f in pfuts]
+            out = [f.result() for f in pfuts]
+        self._batch_chunk_proofs[batch_id] = [o["proof"] for o in out]
+        while len(self._batch_chunk_proofs) > 4:
+            self._batch_chunk_proofs.pop(next(iter(self._batch_chunk_proofs)))
+        return out
 
     # ---- GenAggregatedProof
     @staticmethod
@@ -322,7 +333,11 @@ class Engine:
         if not p1 or not p2:
             raise ValueError("empty recursive proof")
         try:
-            proofs = [json.loads(p1)] if p1 == p2 else [json.loads(p1), json.loads(p2)]
+            texts = [p1] if p1 == p2 else [p1, p2]
+            known = self._batch_chunk_proofs.get(batch_id)
+            if self.cfg.aggregate_all_chunks and known and len(known) > 2 and known[0] == p1 and known[-1] == p2:
+                texts = known                      # the whole batch, not only its two ends
+            proofs = [json.loads(t) for t in texts]
             for pr in proofs:
                 if not isinstance(pr, dict) or "queries" not in pr or "roots" not in pr or not isinstance(pr.get("params"), dict):
                     raise ValueError("not a chunk proof")

@@ -139,3 +139,35 @@ def test_engine_aggregate_and_final_prove_what_they_name(tables, tmp_path):
     with pytest.raises(ValueError):
         eng.final("x", json.dumps({"kind": "something-else"}), "BN128", "1")
     print("stage timings:", json.dumps({k: v for k, v in eng.stage_timings.items() if k.startswith(("aggregate", "final"))}))
+
+
+def test_engine_can_aggregate_every_chunk_of_a_batch(tables, tmp_path):
+    """aggregate_all_chunks: the request still names the first and the last chunk proof (src/prover/provider.rs:385-388), the
+    aggregation STARK verifies all of them (n_proofs = chunk count) and the final STARK sits on top as usual"""
+    from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
+    from eigen_zeth_amd.service.engine import Engine, EngineConfig
+    from eigen_zeth_amd.service.server import default_backend_factory
+    rc, mds = tables
+    cfg = EngineConfig(air="chunk16", logn=10, chunks_per_block=1, groth16_logm=6, crs_dir=str(tmp_path / "crs"), n_queries=12, pow_bits=4,
+                       agg_queries=6, final_queries=4, aggregate_all_chunks=True)
+    eng = Engine(default_backend_factory(0), cfg)
+    ch = eng.gen_batch_chunks("all", [21, 22, 23, 24, 25], 12345, "evm")
+    proofs = eng.gen_chunk_proofs("all", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+    assert len(proofs) == 5
+    text = eng.aggregate("all", proofs[0]["proof"], proofs[-1]["proof"])
+    agg = json.loads(text)
+    assert len(agg["inner"]) == 5 and agg["shape"]["n_proofs"] == 5
+    assert [h["chunk"] for h in agg["inner"]] == [json.loads(p["proof"])["chunk"] for p in proofs]
+    sh = VA.Shape.from_dict(agg["shape"])
+    vair = VA.verifier_air(sh, rc, mds)
+    inner_exp = V.expectation(eng.stark_params(10).to_dict())
+    outer_exp = V.expectation(VA.aggregation_params(sh, cfg.agg_queries, cfg.fri_logf, cfg.fri_final_log).to_dict())
+    assert AV.verify(agg, AIR.get_air("chunk16").program(), vair.program(), rc, mds, inner_exp, outer_exp, sh.n_slots())
+    # two proofs that are not the ends of a known batch: exactly those two
+    two = json.loads(eng.aggregate("all", proofs[1]["proof"], proofs[3]["proof"]))
+    assert len(two["inner"]) == 2
+    final, pub = eng.final("all", text, "BN128", "479881985774944702531460751064278034642760119942")
+    fsp = json.loads(eng.final_starks["all"])
+    fsh = VA.Shape.of_proof(agg["stark"], 1)
+    assert V.verify(fsp, VA.verifier_air(fsh, rc, mds).program(), rc, mds, V.expectation(eng.final_stark_params(agg["stark"]).to_dict()),
+                    bn254_poseidon_params(17))
