@@ -489,8 +489,14 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         q_logn = logn;
         Wq = 3 * Q;
     }
-    PV_TRY(T.commit(dq, M, (int)Wq, treeq));
-    PV_TRY(T.root(treeq, M, rootq));
+    // BN128 mode: 2^qg rows of the quotient per leaf (rows i, i + M', ...: the matrix reinterpreted as [Wq 2^qg][M'], like a FRI layer),
+    // qg the largest with Wq 2^qg <= 48 values = one width-17 permutation per leaf (stark/prover.py: bn128_rows_per_leaf_log)
+    int qg = 0;
+    if (bn)
+        while ((Wq << (qg + 1)) <= 48 && qg + 1 <= logm - 4) qg++;
+    const size_t Mq = M >> qg, Wqg = Wq << qg;
+    PV_TRY(T.commit(dq, Mq, (int)Wqg, treeq));
+    PV_TRY(T.root(treeq, Mq, rootq));
     tr.absorb_root(rootq);
     const e3 zeta = tr.challenge();
     PV_TRY(tr.rc);
@@ -556,7 +562,8 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     PV_TRY(tr.rc);
     for (u64 &v : qidx) v &= (M - 1);
     const size_t nq = (size_t)n_queries, depth = (size_t)logm, pw = T.path_words(M);
-    std::vector<u64> v_tr(nq * W), p_tr(nq * pw), v_s2, p_s2, v_q(nq * Wq), p_q(nq * pw);
+    const size_t pwq = T.path_words(Mq);
+    std::vector<u64> v_tr(nq * W), p_tr(nq * pw), v_s2, p_s2, v_q(nq * Wqg), p_q(nq * pwq);
     PV_TRY(zp_gather_rows(ctx, (const uint64_t *)ext, M, (int32_t)W, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)v_tr.data()));
     PV_TRY(T.open(tree1, M, qidx.data(), n_queries, p_tr.data()));
     if (n_s2) {
@@ -565,8 +572,12 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         PV_TRY(zp_gather_rows(ctx, (const uint64_t *)(ext + W * M), M, (int32_t)W2, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)v_s2.data()));
         PV_TRY(T.open(tree2, M, qidx.data(), n_queries, p_s2.data()));
     }
-    PV_TRY(zp_gather_rows(ctx, (const uint64_t *)dq, M, (int32_t)Wq, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)v_q.data()));
-    PV_TRY(T.open(treeq, M, qidx.data(), n_queries, p_q.data()));
+    {
+        std::vector<u64> qrows = qidx;
+        for (u64 &v : qrows) v &= (Mq - 1);
+        PV_TRY(zp_gather_rows(ctx, (const uint64_t *)dq, Mq, (int32_t)Wqg, (const uint64_t *)qrows.data(), n_queries, (uint64_t *)v_q.data()));
+        PV_TRY(T.open(treeq, Mq, qrows.data(), n_queries, p_q.data()));
+    }
     struct FriOpen { std::vector<u64> vals, paths; size_t width, depth, pw, m; };
     std::vector<FriOpen> fo(layers.size());
     {
@@ -619,7 +630,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
             else j_opening(s, vals, width, path, bin_depth);
         };
         s += ",\"trace\":"; opening(&v_tr[i * W], W, &p_tr[i * pw], M, depth);
-        s += ",\"quotient\":"; opening(&v_q[i * Wq], Wq, &p_q[i * pw], M, depth);
+        s += ",\"quotient\":"; opening(&v_q[i * Wqg], Wqg, &p_q[i * pwq], Mq, depth);
         if (n_s2) { s += ",\"stage2\":"; opening(&v_s2[i * W2], W2, &p_s2[i * pw], M, depth); }
         s += ",\"fri\":[";
         for (size_t li = 0; li < layers.size(); li++) {

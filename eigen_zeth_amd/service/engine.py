@@ -13,6 +13,8 @@ GenFinalProof  : a final STARK in BN128-hash mode over the same verifier AIR app
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import hashlib
 import json
 import queue
@@ -28,6 +30,19 @@ from .. import native
 from . import bn254
 from . import groth16
 from . import statement
+
+
+@contextlib.contextmanager
+def _no_cyclic_gc():
+    """parsing a 1-2 MB proof text makes a few hundred thousand small objects, none of them in a cycle: the generational collector
+    would walk them (and everything older) several times per request -- tens of milliseconds of a 100 ms request"""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class EngineConfig:
@@ -286,7 +301,7 @@ class Engine:
         return hashlib.sha256(s.encode()).hexdigest()
 
     def aggregate(self, batch_id, p1, p2):
-        with self._serial:
+        with self._serial, _no_cyclic_gc():
             return self._aggregate(batch_id, p1, p2)
 
     def _tables(self, be):
@@ -379,7 +394,7 @@ class Engine:
         return groth16.vk_to_json(self.groth16_keys()[2])
 
     def final(self, batch_id, recursive_proof, curve_name, aggregator_addr):
-        with self._serial:
+        with self._serial, _no_cyclic_gc():
             return self._final(batch_id, recursive_proof, curve_name, aggregator_addr)
 
     def _final(self, batch_id, recursive_proof, curve_name, aggregator_addr):

@@ -36,6 +36,18 @@ def publics_rows(pubs, bn):
     return np.ascontiguousarray(rows.T)
 
 
+def bn128_rows_per_leaf_log(width, logm):
+    """BN128-hash mode: a leaf of the QUOTIENT tree holds 2^g rows i, i + M', i + 2M', ... (M' = M / 2^g; the grouping of a FRI layer:
+    a free reinterpretation of the column-major matrix as [width 2^g][M']), g the largest with width * 2^g <= 48 values = 16 field
+    elements = ONE width-17 permutation per leaf.  A quotient of 3 pieces (9 columns) would otherwise spend a whole permutation on 3 of
+    16 rate elements per row: 4 rows per leaf cut the hashing of that tree by 4.  The verifier takes row j from position j / M' of
+    leaf j mod M'.  (Goldilocks mode: 1 row per leaf -- the verifier AIR's schedule is written for that.)"""
+    g = 0
+    while (width << (g + 1)) <= 48 and g + 1 <= logm - 4:
+        g += 1
+    return g
+
+
 class StarkParams:
     """Security (conjectured, ethSTARK-style): n_queries * logb + pow_bits bits -- each query of a rate-2^-logb code
     rejects a far word with probability 1 - 2^-logb, and the prover must grind pow_bits of Poseidon work before it
@@ -150,14 +162,14 @@ def prove(air, trace, pubs, params, be, timings=None):
     assert Q <= (1 << logb), "the blow-up must cover the quotient degree: constraints of degree d need blow-up >= d - 1"
     d_qcoef = be.coset_coefficients(d_q, logm, 3)   # coefficients of q_c(shift * X), c'_i = c_i shift^i, i < M
     if Q == 1:
-        cq = be.commit_cols(d_q, M, 3)
         q_logn, Wq = logm, 3
     else:
         # q(x) = sum_j (x / shift)^(jN) qt_j(x), qt_j(shift X) = sum_{i<N} c'_(jN+i) X^i: the pieces are slices of the
         # coefficient vector already in hand; their LDEs (3Q base columns, piece-major) are what gets committed and opened
         d_q, d_qcoef = be.split_quotient(d_qcoef, logn, logb, Q)
-        cq = be.commit_cols(d_q, M, 3 * Q)
         q_logn, Wq = logn, 3 * Q
+    qg = bn128_rows_per_leaf_log(Wq, logm) if bn else 0       # BN128 mode: 2^qg rows of the quotient per leaf
+    cq = be.commit_cols(d_q, M >> qg, Wq << qg)
     tick("merkle+intt(quotient)", t0)
     tr.absorb_root(cq.root)
     zeta = tr.challenge_e3()
@@ -214,8 +226,9 @@ def prove(air, trace, pubs, params, be, timings=None):
     if c2 is not None:
         q_s2_vals = be.gather_rows(be.column_view(c1.ext, W, M), M, W2, qidx)
         q_s2_paths = be.open_paths(c2.tree, M, qidx)
-    q_q_vals = be.gather_rows(d_q, M, Wq, qidx)
-    q_q_paths = be.open_paths(cq.tree, M, qidx)
+    q_rows = [j & ((M >> qg) - 1) for j in qidx]
+    q_q_vals = be.gather_rows(d_q, M >> qg, Wq << qg, q_rows)
+    q_q_paths = be.open_paths(cq.tree, M >> qg, q_rows)
     fri_open = []
     pos = list(qidx)
     for (lg, f, com, d_l) in layers:

@@ -169,6 +169,15 @@ def publics_digest(pubs, rc, mds, bn):
     return [O._fr_ints(O.merkle16_tree(np.ascontiguousarray(rows.T))[-1])[0]]
 
 
+def bn128_rows_per_leaf_log(width, logm):
+    """BN128-hash mode: a leaf of the quotient tree holds 2^g rows i, i + M / 2^g, ...; g is the largest with width * 2^g <= 48 values
+    (one width-17 permutation per leaf), capped so that the tree keeps at least 16 leaves"""
+    g = 0
+    while (width << (g + 1)) <= 48 and g + 1 <= logm - 4:
+        g += 1
+    return g
+
+
 def fri_schedule(logn, logb, fri_logf, fri_final_log):
     """[(log size of the committed layer, log fold factor)], log size of the final layer sent in clear"""
     cur, stop, sched = logn + logb, fri_final_log + logb, []
@@ -389,15 +398,17 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, t
         gp.append(cur)
         cur = NV.e3_mul(cur, gamma)
 
+    qg = bn128_rows_per_leaf_log(3 * Q, logm) if bn else 0        # BN128 mode: 2^qg rows of the quotient per leaf
     for qq in proof["queries"]:
         j = qq["index"]
-        tv, qv = qq["trace"]["values"], qq["quotient"]["values"]
-        if len(tv) != W or len(qv) != 3 * Q:
+        tv, qleaf = qq["trace"]["values"], qq["quotient"]["values"]
+        if len(tv) != W or len(qleaf) != (3 * Q) << qg:
             raise Reject("bad opening width")
         if not opening_ok(tv, M, j, qq["trace"].get("path"), proof["roots"]["trace"]):
             raise Reject("trace opening does not verify")
-        if not opening_ok(qv, M, j, qq["quotient"].get("path"), proof["roots"]["quotient"]):
+        if not opening_ok(qleaf, M >> qg, j & ((M >> qg) - 1), qq["quotient"].get("path"), proof["roots"]["quotient"]):
             raise Reject("quotient opening does not verify")
+        qv = [qleaf[(c << qg) + (j >> (logm - qg))] for c in range(3 * Q)]     # row j of the leaf's 2^qg rows
         s2v = []
         if air.stage2:
             s2 = qq.get("stage2")
