@@ -16,6 +16,7 @@ from __future__ import annotations
 import contextlib
 import gc
 import hashlib
+from concurrent.futures import ThreadPoolExecutor
 import json
 import queue
 import threading
@@ -83,6 +84,10 @@ class Engine:
         self._be_bn = None        # backend of the final STARK (BN128-hash mode), created at the first GenFinalProof
         self.final_starks = {}    # batch_id -> final STARK JSON of the most recent batches (inspection / tests)
         self._batch_chunk_proofs = {}   # batch_id -> chunk proof texts of the most recent batches (cfg.aggregate_all_chunks)
+        # chunk proofs this engine has just made, parsed and laid out as arrays for the verifier AIR's witness builder WHILE the
+        # other chunks of the batch are still being proven: (len, hash) of the text -> future of (text, object, prepared arrays)
+        self._prepared, self._prepared_lock = {}, threading.Lock()
+        self._prep_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="zp-prepare")
         self.cfg = config or EngineConfig()
         self.stage_timings = {}
         self.metrics = None   # service/metrics.py Metrics, attached by serve()
@@ -283,6 +288,7 @@ class Engine:
             self.stage_timings["%s/%d" % (task_id, i)] = tm
             if self.metrics is not None:
                 self.metrics.record_proof(tm, ch["logn"], self.cfg.logb, air.width)
+            self._remember_chunk_proof(text)
             return {"chunk_id": i, "proof_key": "chunk-%s-%d" % (task_id, i), "proof": text}
 
         with ThreadPoolExecutor(max_workers=max(1, min(self.cfg.witness_threads, len(chunks)))) as wpool, \
@@ -299,6 +305,41 @@ class Engine:
     @staticmethod
     def _digest(s):
         return hashlib.sha256(s.encode()).hexdigest()
+
+    @staticmethod
+    def _parse_and_prepare(text):
+        obj = json.loads(text)
+        if not isinstance(obj, dict) or "queries" not in obj or "roots" not in obj or not isinstance(obj.get("params"), dict):
+            raise ValueError("not a chunk proof")
+        pr, lim = obj["params"], {"logn": 28, "logb": 8, "fri_logf": 8, "fri_final_log": 16, "n_queries": 4096, "pow_bits": 64}
+        if any(not isinstance(pr.get(k), int) or isinstance(pr.get(k), bool) or not 0 <= pr[k] <= m for k, m in lim.items()) \
+                or pr["logn"] < 1 or pr["logb"] < 1 or pr["n_queries"] < 1 or pr["fri_logf"] < 1 or not isinstance(obj["queries"], list) \
+                or len(obj["queries"]) != pr["n_queries"]:
+            raise ValueError("chunk proof parameters out of range")       # nothing below is sized by numbers the text could choose freely
+        return text, obj, VA.prepare_proof(obj)
+
+    def _remember_chunk_proof(self, text):
+        """queue the parsing of a chunk proof this engine has just produced (a few milliseconds of host work per proof that a
+        later GenAggregatedProof would otherwise spend inside its own wall-clock)"""
+        key = (len(text), hash(text))
+        with self._prepared_lock:
+            self._prepared[key] = self._prep_pool.submit(self._parse_and_prepare, text)
+            while len(self._prepared) > 64:
+                self._prepared.pop(next(iter(self._prepared)))
+
+    def _parsed_chunk_proof(self, text):
+        """(object, prepared arrays) of a recursive proof text: from the cache when this engine made it, parsed here otherwise"""
+        with self._prepared_lock:
+            fut = self._prepared.get((len(text), hash(text)))
+        if fut is not None:
+            try:
+                t, obj, prep = fut.result()
+                if t == text:
+                    return obj, prep
+            except Exception:      # noqa: a proof that cannot be prepared is reported by the inline path below
+                pass
+        _, obj, prep = self._parse_and_prepare(text)
+        return obj, prep
 
     def aggregate(self, batch_id, p1, p2):
         with self._serial, _no_cyclic_gc():
@@ -320,7 +361,7 @@ class Engine:
                          "fri": [strip(f) for f in q["fri"]]} for q in proof["queries"]]
         return h
 
-    def _prove_merkle_verifier(self, proofs, params_of, be, timings, inner_air):
+    def _prove_merkle_verifier(self, proofs, params_of, be, timings, inner_air, prepared=None):
         """STARK over the verifier AIR (stark/verifier_air.py) for inner proof objects `proofs` of one shape, proofs of `inner_air`"""
         rc, mds = self._tables(be)
         shape = VA.Shape.of_proof(proofs[0], len(proofs))
@@ -330,7 +371,7 @@ class Engine:
         vair = VA.verifier_air(shape, rc, mds)
         t0 = time.perf_counter()
         # raises ValueError: an opening does not hash to its root / the transcript does not give the indices -> no witness
-        trace, pubs = VA.build_witness(shape, proofs, be, inner_air.digest_words())
+        trace, pubs = VA.build_witness(shape, proofs, be, inner_air.digest_words(), prepared)
         timings["verifier-witness"] = time.perf_counter() - t0
         params = params_of(shape)
         t0 = time.perf_counter()
@@ -352,21 +393,20 @@ class Engine:
             known = self._batch_chunk_proofs.get(batch_id)
             if self.cfg.aggregate_all_chunks and known and len(known) > 2 and known[0] == p1 and known[-1] == p2:
                 texts = known                      # the whole batch, not only its two ends
-            proofs = [json.loads(t) for t in texts]
+            parsed = [self._parsed_chunk_proof(t) for t in texts]
+            proofs, prepared = [a for a, _ in parsed], [b for _, b in parsed]
             for pr in proofs:
-                if not isinstance(pr, dict) or "queries" not in pr or "roots" not in pr or not isinstance(pr.get("params"), dict):
-                    raise ValueError("not a chunk proof")
                 # this prover aggregates chunk proofs made under ITS security parameters (the text comes from the client: nothing
                 # below is sized by numbers it could choose freely)
                 lg = pr["params"].get("logn")
                 if not isinstance(lg, int) or not 1 <= lg <= 28 or pr["params"] != self.stark_params(lg).to_dict():
                     raise ValueError("chunk proof was not made under this prover's parameters")
-        except (json.JSONDecodeError, TypeError) as e:
+        except (json.JSONDecodeError, TypeError, KeyError, IndexError) as e:
             raise ValueError("recursive proof is not a chunk proof: %s" % e)
         tm = {}
         shape, vair, params, text = self._prove_merkle_verifier(
             proofs, lambda sh: VA.aggregation_params(sh, self.cfg.agg_queries, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.agg_pow_bits),
-            self.be, tm, AIR.get_air(self.cfg.air))
+            self.be, tm, AIR.get_air(self.cfg.air), prepared)
         self.stage_timings["aggregate/" + batch_id] = tm
         if self.metrics is not None:
             for k, v in tm.items():

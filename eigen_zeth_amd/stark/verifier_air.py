@@ -550,7 +550,80 @@ def expected_publics(shape, proofs):
     return pubs
 
 
-def build_witness(shape, proofs, be, digest_words):
+def prepare_proof(proof):
+    """the query openings of an inner proof as arrays -- {"index": u64[nq], "values": [u64[nq][w] per tree], "paths": [u64[nq][depth][4]
+    per tree]} in the order of Shape.trees -- so that the witness builder touches no Python list per opening.  The service
+    prepares its own chunk proofs while the other chunks of the batch are still being proven (engine.py).  Raises ValueError for
+    ragged or out-of-range data."""
+    shape = Shape.of_proof(proof, 1)
+    qs = proof["queries"]
+    if len(qs) != shape.n_queries:
+        raise ValueError("inner proof has the wrong number of queries")
+    try:
+        out = {"index": np.array([int(q["index"]) for q in qs], dtype=np.uint64), "values": [], "paths": [], "key": shape.key()[:8]}
+        for (name, w, depth) in shape.trees:
+            ops = [_opening(q, name) for q in qs]
+            v = np.array([o["values"] for o in ops], dtype=np.uint64)
+            pth = np.array([o["path"] for o in ops], dtype=np.uint64)
+            if v.shape != (len(qs), w) or pth.shape != (len(qs), depth, 4):
+                raise ValueError("opening of %s has the wrong shape" % name)
+            out["values"].append(v)
+            out["paths"].append(pth)
+    except (OverflowError, TypeError, KeyError, IndexError) as e:
+        raise ValueError("opening values are not field elements (%s)" % e)
+    except ValueError as e:
+        raise ValueError("opening of a tree has the wrong shape (%s)" % e)
+    return out
+
+
+_OPS_CACHE = {}
+
+
+def _opening_table(shape):
+    """one row per opening of the schedule, in block order: first block, absorb blocks, depth, tree, proof, query number -- fixed by
+    the shape"""
+    cached = _OPS_CACHE.get(shape.key())
+    if cached is not None:
+        return cached
+    k, periods, pb = shape.layout()
+    sched = shape.period_schedule()
+    rows = []
+    for per in range(periods):
+        b = 0
+        while b < pb:
+            blk = sched[b]
+            if blk["kind"] == "idle" or not blk["first"]:
+                b += 1
+                continue
+            _, w, depth = shape.trees[blk["t"]]
+            a = Shape.absorb_blocks(w)
+            rows.append((per * pb + b, a, depth, blk["t"], blk["p"], (per * k + blk["sub"]) % shape.n_queries))
+            b += a + depth
+    tab = np.array(rows, dtype=np.int64).reshape(-1, 6)
+    out = {"b0": tab[:, 0], "na": tab[:, 1], "nd": tab[:, 2], "t": tab[:, 3], "p": tab[:, 4], "q": tab[:, 5],
+           "sel": {(p, t): np.nonzero((tab[:, 4] == p) & (tab[:, 3] == t))[0] for p in range(shape.n_proofs) for t in range(len(shape.trees))}}
+    _OPS_CACHE[shape.key()] = out
+    return out
+
+
+def _publics_from_arrays(shape, proofs, prepared):
+    """expected_publics() from prepared arrays (the same list, as one u64 array)"""
+    parts = []
+    for pr in proofs:
+        names = {"trace": pr["roots"]["trace"], "quotient": pr["roots"]["quotient"]}
+        if shape.W2:
+            names["stage2"] = pr["roots"]["stage2"]
+        for (name, _, _) in shape.trees:
+            root = pr["fri"]["roots"][int(name[3:])] if name.startswith("fri") else names[name]
+            parts.append(np.array([int(v) for v in root], dtype=np.uint64))
+    g = np.arange(shape.n_slots()) % shape.n_queries
+    masks = np.array([(1 << d) - 1 for (_, _, d) in shape.trees], dtype=np.uint64)
+    parts.append(np.stack([pp["index"][g][:, None] & masks[None, :] for pp in prepared], axis=1).reshape(-1))     # [slot][proof][tree]
+    parts.append(np.stack([np.concatenate([v[g] for v in pp["values"]], axis=1) for pp in prepared], axis=1).reshape(-1))
+    return np.concatenate(parts)
+
+
+def build_witness(shape, proofs, be, digest_words, prepared=None):
     """(trace u64[26][N], publics) for inner proof objects `proofs` (len = shape.n_proofs) of `shape`; the trace is a host array,
     or a device buffer of that shape when the backend assembles it in HBM (verifier_trace_device).
     be: backend with poseidon_perm_batch(states [B][12]), poseidon_trace(inputs [B][12]) -> (states [12][32 B], cubes
@@ -561,8 +634,9 @@ def build_witness(shape, proofs, be, digest_words):
     assert len(proofs) == shape.n_proofs
     for pr in proofs:
         assert Shape.of_proof(pr, shape.n_proofs).key() == shape.key(), "inner proofs of different shapes"
+    if prepared is None:
+        prepared = [prepare_proof(pr) for pr in proofs]
     k, periods, pb = shape.layout()
-    sched = shape.period_schedule()
     nblk = pb * periods
     N = ROWS * nblk
     inputs = np.zeros((nblk, 12), dtype=np.uint64)
@@ -572,37 +646,20 @@ def build_witness(shape, proofs, be, digest_words):
     # level-synchronous hashing: absorb block j / tree level lv of EVERY opening is one batched permutation call
     max_w = max(8 * Shape.absorb_blocks(w) if w > 4 else 4 for (_, w, _) in shape.trees)
     max_d = max(d for (_, _, d) in shape.trees)
-    b0l, al, dl, il, tl, pl, vl, pathl = [], [], [], [], [], [], [], []
-    zero_path = [[0, 0, 0, 0]]
-    for per in range(periods):
-        b = 0
-        while b < pb:
-            blk = sched[b]
-            if blk["kind"] == "idle" or not blk["first"]:
-                b += 1
-                continue
-            name, w, depth = shape.trees[blk["t"]]
-            q = proofs[blk["p"]]["queries"][(per * k + blk["sub"]) % shape.n_queries]
-            o = _opening(q, name)
-            vals, path = o["values"], o["path"]
-            if len(vals) != w or len(path) != depth or any(len(lv) != 4 for lv in path):
-                raise ValueError("opening of %s has the wrong shape" % name)
-            b0l.append(per * pb + b)
-            al.append(Shape.absorb_blocks(w))
-            dl.append(depth)
-            il.append(int(q["index"]) & ((1 << depth) - 1))
-            tl.append(blk["t"])
-            pl.append(blk["p"])
-            vl.append(list(vals) + [0] * (max_w - w))
-            pathl.append(list(path) + zero_path * (max_d - depth))
-            b += al[-1] + depth
-    b0, na, nd = np.array(b0l, dtype=np.int64), np.array(al, dtype=np.int64), np.array(dl, dtype=np.int64)
-    index = np.array(il, dtype=np.uint64)
-    try:
-        vals = np.array(vl, dtype=np.uint64)
-        paths = np.array(pathl, dtype=np.uint64)            # [openings][max_d][4]
-    except (OverflowError, ValueError, TypeError):
-        raise ValueError("opening values are not field elements")
+    ops = _opening_table(shape)
+    b0, na, nd, tl, pl = ops["b0"], ops["na"], ops["nd"], ops["t"], ops["p"]
+    vals = np.zeros((len(b0), max_w), dtype=np.uint64)
+    paths = np.zeros((len(b0), max_d, 4), dtype=np.uint64)            # [openings][max_d][4]
+    index = np.zeros(len(b0), dtype=np.uint64)
+    for p, pp in enumerate(prepared):
+        if pp["key"] != shape.key()[:8]:
+            raise ValueError("inner proofs of different shapes")
+        for t, (_, w, depth) in enumerate(shape.trees):
+            sel = ops["sel"][(p, t)]
+            q = ops["q"][sel]
+            vals[sel, :w] = pp["values"][t][q]
+            paths[sel, :depth] = pp["paths"][t][q]
+            index[sel] = pp["index"][q] & np.uint64((1 << depth) - 1)
     nops = len(b0)
     cap = np.zeros((nops, 4), dtype=np.uint64)
     for j in range(int(na.max()) if nops else 0):
@@ -627,29 +684,30 @@ def build_witness(shape, proofs, be, digest_words):
         dbit[blk] = bit
         idxv[blk] = index[sel] & np.uint64((2 << lv) - 1)
         digest[sel] = be.poseidon_perm_batch(st)[:, :4]
-    pubs = expected_publics(shape, proofs)
+    pub_parts = [_publics_from_arrays(shape, proofs, prepared)]
     L = len(shape.transcript_perms())
     for p, pr in enumerate(proofs):                 # the transcripts: consecutive blocks in the idle tail of the last period
         states, tp = replay_transcript(shape, pr, digest_words, be)
         blk0 = shape.transcript_block0() + p * L
         inputs[blk0:blk0 + L] = np.array(states, dtype=np.uint64)
-        pubs += tp
+        pub_parts.append(np.array(tp, dtype=np.uint64))
+    pubs = np.concatenate(pub_parts)
     assert len(pubs) == shape.n_pub()
     T = len(shape.trees)
-    want = np.array(pubs[:shape.n_proofs * T * 4], dtype=np.uint64).reshape(shape.n_proofs, T, 4)
-    bad = np.nonzero((digest != want[np.array(pl, dtype=np.int64), np.array(tl, dtype=np.int64)]).any(axis=1))[0]
+    want = pubs[:shape.n_proofs * T * 4].reshape(shape.n_proofs, T, 4)
+    bad = np.nonzero((digest != want[pl, tl]).any(axis=1))[0]
     if len(bad):
         o = int(bad[0])
         raise ValueError("an opening of the %s tree of inner proof %d does not hash to its root: no accepting witness"
                          % (shape.trees[tl[o]][0], pl[o]))
     if hasattr(be, "verifier_trace_device"):      # GPU backend: the trace is assembled in HBM and stays there
-        return be.verifier_trace_device(inputs, dbit, idxv), np.array(pubs, dtype=np.uint64)
+        return be.verifier_trace_device(inputs, dbit, idxv), pubs
     states, cubes = be.poseidon_trace(inputs)
     trace = np.zeros((WIDTH, N), dtype=np.uint64)
     trace[S0:S0 + 12], trace[U0:U0 + 12] = states, cubes
     trace[COL_D] = np.repeat(dbit, ROWS)
     trace[COL_IDX] = np.repeat(idxv, ROWS)
-    return trace, np.array(pubs, dtype=np.uint64)
+    return trace, pubs
 
 
 def aggregation_params(shape, n_queries=50, fri_logf=3, fri_final_log=5, pow_bits=0, hash="gl"):
