@@ -155,6 +155,20 @@ __device__ __forceinline__ fr perm_coop(fr s, int q, int e, bool on, u32 (*sh)[T
 }
 
 // ---- bulk form, t = 17: ONE LANE PER PERMUTATION (launches of >= 2^14 permutations: the Merkle commitments of the final STARK).
+// One sponge block of a leaf absorbs up to 56 Goldilocks values in its 16 rate elements: element k holds values base + 3k .. 3k+2 in
+// bits 0..191 and, in bits 192..223, 32-bit half number k of values base + 48 .. base + 55 (half 2i = low word of value 48 + i, half
+// 2i + 1 = its high word).  Below 2^224 < r.  Rows of at most 48 values pack as three per element.  (oracle/naive.py: pack_leaf_block)
+__device__ __forceinline__ void leaf_block_element(const u64 *__restrict__ cols, size_t M, size_t i, int W, int base, int k, u64 *w) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) w[c] = (base + 3 * k + c < W) ? cols[(size_t)(base + 3 * k + c) * M + i] : 0ULL;
+    const int x = base + 48 + (k >> 1);
+    w[3] = 0;
+    if (x < W) {
+        const u64 v = cols[(size_t)x * M + i];
+        w[3] = (k & 1) ? (v >> 32) : (v & 0xFFFFFFFFULL);
+    }
+}
+
 // The cooperative form above gives a wave three permutations (51 of 64 lanes) and makes the whole wave walk the three dependent
 // products of the ONE S-box of a partial round: 5 product steps per lane and round for 36 field products per permutation.  Here every
 // lane does exactly the products of its own permutation.  The 17-element state lives in LDS ([element][limb][lane]: conflict-free,
@@ -264,19 +278,13 @@ __global__ void __launch_bounds__(64) p254_bulk_kernel(const u64 *__restrict__ i
         }
     } else {
         lds_put(st, 0, lane, fr_zero());
-        if constexpr (MODE == 1) {          // in = cols u64[W][M], M = count = n_in; sponge over blocks of 16 packed elements
-            const int ne = (W + 2) / 3;
+        if constexpr (MODE == 1) {          // in = cols u64[W][M], M = count = n_in; sponge over blocks of 56 values in 16 elements
 #pragma unroll 1
-            for (int off = 0; off < ne || off == 0; off += 16) {
+            for (int base = 0; base < W || base == 0; base += 56) {
 #pragma unroll 1
                 for (int e = 1; e < 17; e++) {
-                    const int k = off + e - 1;
-                    u64 w[4] = {0, 0, 0, 0};
-                    if (k < ne) {
-#pragma unroll
-                        for (int c = 0; c < 3; c++)
-                            if (3 * k + c < W) w[c] = in[(size_t)(3 * k + c) * n_in + ii];
-                    }
+                    u64 w[4];
+                    leaf_block_element(in, (size_t)n_in, ii, W, base, e - 1, w);
                     lds_put(st, e, lane, fr_to_mont(fr_from_u64(w)));
                 }
                 bulk_perm17(st, lane, d);   // the digest (element 0) stays as the capacity of the next block
@@ -378,17 +386,11 @@ __global__ void __launch_bounds__(64) merkle16_leaves_kernel(const u64 *__restri
     const int q = threadIdx.x / T, e = threadIdx.x % T;
     const size_t i = (size_t)blockIdx.x * PPW + q;
     const bool on = q < PPW && i < M;
-    const int ne = (W + 2) / 3;                        // packed elements per row
     fr s = fr_zero();                                  // capacity 0
-    for (int off = 0; off < ne || off == 0; off += 16) {
+    for (int base = 0; base < W || base == 0; base += 56) {
         if (on && e >= 1) {
-            const int k = off + e - 1;                 // packed element index
-            u64 w[4] = {0, 0, 0, 0};
-            if (k < ne) {
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-                    if (3 * k + c < W) w[c] = cols[(size_t)(3 * k + c) * M + i];
-            }
+            u64 w[4];
+            leaf_block_element(cols, M, i, W, base, e - 1, w);
             s = fr_to_mont(fr_from_u64(w));
         }
         s = perm_coop<T>(s, q, e, on, sh, d);

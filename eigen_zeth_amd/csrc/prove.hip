@@ -384,11 +384,22 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     u64 *ext, *coef, *tree1;
     PV_TRY(dev.alloc(Wt * M, &ext));
     PV_TRY(dev.alloc(Wt * N, &coef));
-    PV_TRY(dev.alloc(T.tree_words(M), &tree1));
+    // BN128 mode: a leaf holds 2^g rows i, i + M', ... of its tree (the column-major matrix reinterpreted as [width 2^g][M'], like a
+    // FRI layer), g the largest with width 2^g <= 56 values = one width-17 permutation per leaf (stark/prover.py:
+    // bn128_rows_per_leaf_log; Goldilocks mode: g = 0)
+    auto rows_per_leaf_log = [&](size_t width) {
+        int g = 0;
+        if (bn && width)
+            while ((width << (g + 1)) <= 56 && g + 1 <= logm - 4) g++;
+        return g;
+    };
+    const int gt = rows_per_leaf_log(W), g2 = rows_per_leaf_log(W2);
+    const size_t Mt = M >> gt, Wtg = W << gt, M2 = M >> g2, W2g = W2 << g2;
+    PV_TRY(dev.alloc(T.tree_words(Mt), &tree1));
     PV_TRY(zp_lde(ctx, d_trace, (uint64_t *)ext, (uint64_t *)coef, logn, logb, (int32_t)W, shift));
-    PV_TRY(T.commit(ext, M, (int)W, tree1));
+    PV_TRY(T.commit(ext, Mt, (int)Wtg, tree1));
     u64 root1[4], root2[4] = {0, 0, 0, 0}, rootq[4];
-    PV_TRY(T.root(tree1, M, root1));
+    PV_TRY(T.root(tree1, Mt, root1));
     tr.absorb_root(root1);
     std::vector<u64> pubchal(h_pubs, h_pubs + n_pubs);
     u64 *tree2 = nullptr;
@@ -409,9 +420,9 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
             }
         }
         PV_TRY(zp_lde(ctx, (const uint64_t *)s2, (uint64_t *)(ext + W * M), (uint64_t *)(coef + W * N), logn, logb, (int32_t)W2, shift));
-        PV_TRY(dev.alloc(T.tree_words(M), &tree2));
-        PV_TRY(T.commit(ext + W * M, M, (int)W2, tree2));
-        PV_TRY(T.root(tree2, M, root2));
+        PV_TRY(dev.alloc(T.tree_words(M2), &tree2));
+        PV_TRY(T.commit(ext + W * M, M2, (int)W2g, tree2));
+        PV_TRY(T.root(tree2, M2, root2));
         dev.release(s2);
         tr.absorb_root(root2);
         for (int c = 0; c < 3; c++) pubchal.push_back(chal.c[c]);
@@ -491,9 +502,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     }
     // BN128 mode: 2^qg rows of the quotient per leaf (rows i, i + M', ...: the matrix reinterpreted as [Wq 2^qg][M'], like a FRI layer),
     // qg the largest with Wq 2^qg <= 48 values = one width-17 permutation per leaf (stark/prover.py: bn128_rows_per_leaf_log)
-    int qg = 0;
-    if (bn)
-        while ((Wq << (qg + 1)) <= 48 && qg + 1 <= logm - 4) qg++;
+    const int qg = rows_per_leaf_log(Wq);
     const size_t Mq = M >> qg, Wqg = Wq << qg;
     PV_TRY(T.commit(dq, Mq, (int)Wqg, treeq));
     PV_TRY(T.root(treeq, Mq, rootq));
@@ -561,16 +570,22 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     std::vector<u64> qidx = tr.squeeze((size_t)n_queries);
     PV_TRY(tr.rc);
     for (u64 &v : qidx) v &= (M - 1);
-    const size_t nq = (size_t)n_queries, depth = (size_t)logm, pw = T.path_words(M);
-    const size_t pwq = T.path_words(Mq);
-    std::vector<u64> v_tr(nq * W), p_tr(nq * pw), v_s2, p_s2, v_q(nq * Wqg), p_q(nq * pwq);
-    PV_TRY(zp_gather_rows(ctx, (const uint64_t *)ext, M, (int32_t)W, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)v_tr.data()));
-    PV_TRY(T.open(tree1, M, qidx.data(), n_queries, p_tr.data()));
+    const size_t nq = (size_t)n_queries, depth = (size_t)logm;
+    const size_t pwq = T.path_words(Mq), pwt = T.path_words(Mt), pw2 = T.path_words(M2);
+    std::vector<u64> v_tr(nq * Wtg), p_tr(nq * pwt), v_s2, p_s2, v_q(nq * Wqg), p_q(nq * pwq);
+    {
+        std::vector<u64> rows = qidx;
+        for (u64 &v : rows) v &= (Mt - 1);
+        PV_TRY(zp_gather_rows(ctx, (const uint64_t *)ext, Mt, (int32_t)Wtg, (const uint64_t *)rows.data(), n_queries, (uint64_t *)v_tr.data()));
+        PV_TRY(T.open(tree1, Mt, rows.data(), n_queries, p_tr.data()));
+    }
     if (n_s2) {
-        v_s2.resize(nq * W2);
-        p_s2.resize(nq * pw);
-        PV_TRY(zp_gather_rows(ctx, (const uint64_t *)(ext + W * M), M, (int32_t)W2, (const uint64_t *)qidx.data(), n_queries, (uint64_t *)v_s2.data()));
-        PV_TRY(T.open(tree2, M, qidx.data(), n_queries, p_s2.data()));
+        v_s2.resize(nq * W2g);
+        p_s2.resize(nq * pw2);
+        std::vector<u64> rows = qidx;
+        for (u64 &v : rows) v &= (M2 - 1);
+        PV_TRY(zp_gather_rows(ctx, (const uint64_t *)(ext + W * M), M2, (int32_t)W2g, (const uint64_t *)rows.data(), n_queries, (uint64_t *)v_s2.data()));
+        PV_TRY(T.open(tree2, M2, rows.data(), n_queries, p_s2.data()));
     }
     {
         std::vector<u64> qrows = qidx;
@@ -629,9 +644,9 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
             if (bn) j_opening_bn(s, vals, width, path, Trees::levels16(rows));
             else j_opening(s, vals, width, path, bin_depth);
         };
-        s += ",\"trace\":"; opening(&v_tr[i * W], W, &p_tr[i * pw], M, depth);
+        s += ",\"trace\":"; opening(&v_tr[i * Wtg], Wtg, &p_tr[i * pwt], Mt, depth);
         s += ",\"quotient\":"; opening(&v_q[i * Wqg], Wqg, &p_q[i * pwq], Mq, depth);
-        if (n_s2) { s += ",\"stage2\":"; opening(&v_s2[i * W2], W2, &p_s2[i * pw], M, depth); }
+        if (n_s2) { s += ",\"stage2\":"; opening(&v_s2[i * W2g], W2g, &p_s2[i * pw2], M2, depth); }
         s += ",\"fri\":[";
         for (size_t li = 0; li < layers.size(); li++) {
             if (li) s += ',';

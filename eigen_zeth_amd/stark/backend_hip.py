@@ -189,16 +189,17 @@ class HipBackend:
             up.release_host_array(trace)
         return buf
 
-    def commit_trace(self, trace, logn, logb, extra_cols=0):
-        """ext / coef are allocated with room for `extra_cols` stage-2 columns behind the trace columns"""
+    def commit_trace(self, trace, logn, logb, extra_cols=0, group=0):
+        """ext / coef are allocated with room for `extra_cols` stage-2 columns behind the trace columns; group: log2 of the rows
+        per leaf of the tree (BN128 mode: stark/prover.py bn128_rows_per_leaf_log)"""
         W = trace.shape[0]
         M = 1 << (logn + logb)
         d_tr = trace if isinstance(trace, native.DeviceBuffer) else self.p.upload(trace)
         ext, coef = self.p.alloc((W + extra_cols) * M), self.p.alloc((W + extra_cols) << logn)
-        tree = self._tree_alloc(M)
+        tree = self._tree_alloc(M >> group)
         self.p.lde(d_tr, ext, logn, logb, W, self.shift, d_coef=coef)
-        self._commit(ext, M, W, tree)
-        c = Commit(self._root(tree, M), tree, ext, coef)
+        self._commit(ext, M >> group, W << group, tree)
+        c = Commit(self._root(tree, M >> group), tree, ext, coef)
         if extra_cols:
             c.trace, c.W = d_tr, W   # stage 2 reads witness columns
         else:
@@ -208,7 +209,7 @@ class HipBackend:
     def column_view(self, d_mat, col, rows):
         return d_mat.offset(col * rows)
 
-    def commit_stage2(self, air, c1, chal, logn, logb):
+    def commit_stage2(self, air, c1, chal, logn, logb, group=0):
         """stage-2 witness columns (grand products Z, LogUp h1/h2/S) -> LDE into columns W.. of c1.ext / c1.coef -> their tree"""
         N, M, W, W2 = 1 << logn, 1 << (logn + logb), c1.W, air.width2
         d_s2 = self.p.alloc(W2 * N)
@@ -221,12 +222,12 @@ class HipBackend:
                 self.p.logup_columns(col("a"), col("t"), col("m"), N, chal, d_s2.offset(at * N))
             at += air_mod.STAGE2_WIDTH[st["kind"]]
         self.p.lde(d_s2, c1.ext.offset(W * M), logn, logb, W2, self.shift, d_coef=c1.coef.offset(W * N))
-        tree = self._tree_alloc(M)
-        self._commit(c1.ext.offset(W * M), M, W2, tree)
+        tree = self._tree_alloc(M >> group)
+        self._commit(c1.ext.offset(W * M), M >> group, W2 << group, tree)
         self.p.sync()
         d_s2.free()
         c1.trace.free()
-        return Commit(self._root(tree, M), tree)
+        return Commit(self._root(tree, M >> group), tree)
 
     def commit_cols(self, d_cols, M, W):
         tree = self._tree_alloc(M)

@@ -37,13 +37,13 @@ def publics_rows(pubs, bn):
 
 
 def bn128_rows_per_leaf_log(width, logm):
-    """BN128-hash mode: a leaf of the QUOTIENT tree holds 2^g rows i, i + M', i + 2M', ... (M' = M / 2^g; the grouping of a FRI layer:
-    a free reinterpretation of the column-major matrix as [width 2^g][M']), g the largest with width * 2^g <= 48 values = 16 field
-    elements = ONE width-17 permutation per leaf.  A quotient of 3 pieces (9 columns) would otherwise spend a whole permutation on 3 of
-    16 rate elements per row: 4 rows per leaf cut the hashing of that tree by 4.  The verifier takes row j from position j / M' of
-    leaf j mod M'.  (Goldilocks mode: 1 row per leaf -- the verifier AIR's schedule is written for that.)"""
+    """BN128-hash mode: a leaf of a committed tree (trace, stage 2, quotient) holds 2^g rows i, i + M', i + 2M', ... (M' = M / 2^g; the
+    grouping of a FRI layer: a free reinterpretation of the column-major matrix as [width 2^g][M']), g the largest with
+    width * 2^g <= 56 values = ONE width-17 permutation per leaf (56 values to a sponge block: oracle/naive.py pack_leaf_block).  The
+    verifier AIR's 26 columns: 2 rows per leaf; its 9-column quotient: 4 -- instead of a permutation per row.  The verifier takes
+    row j from position j / M' of leaf j mod M'.  (Goldilocks mode: 1 row per leaf -- the verifier AIR's schedule is written for that.)"""
     g = 0
-    while (width << (g + 1)) <= 48 and g + 1 <= logm - 4:
+    while (width << (g + 1)) <= 56 and g + 1 <= logm - 4:
         g += 1
     return g
 
@@ -131,7 +131,9 @@ def prove(air, trace, pubs, params, be, timings=None):
     # 1. commit the trace
     t0 = time.perf_counter()
     Wt = W + W2                      # committed base columns: trace, then the stage-2 columns
-    c1 = be.commit_trace(trace, logn, logb, W2)
+    gt = bn128_rows_per_leaf_log(W, logm) if bn else 0                    # BN128 mode: 2^g rows per leaf
+    g2 = bn128_rows_per_leaf_log(W2, logm) if (bn and W2) else 0
+    c1 = be.commit_trace(trace, logn, logb, W2, gt)
     tick("lde+merkle(trace)", t0)
     tr.absorb_root(c1.root)
     chal, c2 = [], None
@@ -139,7 +141,7 @@ def prove(air, trace, pubs, params, be, timings=None):
         # stage 2: a challenge that depends on the first commitment, then the grand-product column
         t0 = time.perf_counter()
         chal = tr.challenge_e3()
-        c2 = be.commit_stage2(air, c1, chal, logn, logb)
+        c2 = be.commit_stage2(air, c1, chal, logn, logb, g2)
         tick("grand-product+lde+merkle(stage2)", t0)
         tr.absorb_root(c2.root)
     alpha = tr.challenge_e3()
@@ -221,11 +223,13 @@ def prove(air, trace, pubs, params, be, timings=None):
         pow_nonce = int(be.pow_grind(tr.squeeze(4), params.pow_bits))
         tr.absorb([pow_nonce])
     qidx = tr.indices(params.n_queries, logm)
-    q_trace_vals = be.gather_rows(c1.ext, M, W, qidx)
-    q_trace_paths = be.open_paths(c1.tree, M, qidx)
+    t_rows = [j & ((M >> gt) - 1) for j in qidx]
+    q_trace_vals = be.gather_rows(c1.ext, M >> gt, W << gt, t_rows)
+    q_trace_paths = be.open_paths(c1.tree, M >> gt, t_rows)
     if c2 is not None:
-        q_s2_vals = be.gather_rows(be.column_view(c1.ext, W, M), M, W2, qidx)
-        q_s2_paths = be.open_paths(c2.tree, M, qidx)
+        s_rows = [j & ((M >> g2) - 1) for j in qidx]
+        q_s2_vals = be.gather_rows(be.column_view(c1.ext, W, M), M >> g2, W2 << g2, s_rows)
+        q_s2_paths = be.open_paths(c2.tree, M >> g2, s_rows)
     q_rows = [j & ((M >> qg) - 1) for j in qidx]
     q_q_vals = be.gather_rows(d_q, M >> qg, Wq << qg, q_rows)
     q_q_paths = be.open_paths(cq.tree, M >> qg, q_rows)

@@ -113,7 +113,8 @@ class ShardedBackend:
     def pow_grind(self, seed4, bits):
         return self.ops.pow_grind(seed4, bits)
 
-    def commit_trace(self, trace, logn, logb, extra_cols=0):
+    def commit_trace(self, trace, logn, logb, extra_cols=0, group=0):
+        assert group == 0, "Goldilocks mode only"
         """trace: the witness [W][N]; a rank reads only its W/G columns of it (plus, in stage 2, the few columns the
         permutation / lookup arguments name)"""
         N, M = 1 << logn, 1 << (logn + logb)
@@ -148,7 +149,8 @@ class ShardedBackend:
         MG.broadcast(t, owner, group=self.group)
         return t
 
-    def commit_stage2(self, air, c1, chal, logn, logb):
+    def commit_stage2(self, air, c1, chal, logn, logb, group=0):
+        assert group == 0, "Goldilocks mode only"
         N, M, W, W2 = 1 << logn, 1 << (logn + logb), c1.W, air.width2
         nloc = M // self.G
         parts = []

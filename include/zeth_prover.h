@@ -136,14 +136,14 @@ int32_t zp_merkle_commit_rows(zp_ctx *ctx, const uint64_t *d_rows, size_t M, siz
 int32_t zp_merkle_open(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx, uint64_t *h_path);
 
 /* ---- BN128-hash mode (the last recursive STARK before the Groth16 wrap): Poseidon over the BN254 scalar field F_r,
- * x^5, 8 full + rp partial rounds, widths t = 3 and t = 17; 16-ary Merkle tree over Goldilocks columns packed three to a
- * field element.  Field elements cross the ABI as 4 little-endian u64 words, standard form, < r.
+ * x^5, 8 full + rp partial rounds, widths t = 3 and t = 17; 16-ary Merkle tree over Goldilocks columns, 56 values to a sponge
+ * block of 16 field elements (three per element in bits 0..191, 32-bit halves of values 48..55 in bits 192..223).  Field elements cross the ABI as 4 little-endian u64 words, standard form, < r.
  * zp_set_poseidon_bn254 installs the tables of one width (h_rc: (8 + rp) * t elements round-major, h_mds: t * t row-major);
  * eigen_zeth_amd/poseidon_constants.py:bn254_poseidon_params derives them (Grain LFSR; the t = 3 set reproduces the
  * published vector poseidon([1, 2]) = 0x115cc0f5e7d690413df64c6b9662e9cf2a3617f2743245519e19607a4417189a).
  * zp_poseidon_bn254_perm: d_states u64[count][t][4] permuted in place.
  * zp_merkle16_commit_bn254: leaf i = sponge (16 elements per permutation, capacity = previous digest, first capacity 0)
- *   over row i of d_cols u64[W][M] packed as a + b 2^64 + c 2^128; node = digest of [0, 16 children] (missing = 0);
+ *   over row i of d_cols u64[W][M] in blocks of 56 values (a + b 2^64 + c 2^128 + half 2^192); node = digest of [0, 16 children] (missing = 0);
  *   d_tree u64[zp_merkle16_nodes(M)][4]: leaves, then each level, root last.
  * zp_merkle16_open_bn254: h_path u64[levels][16][4] = per level the 16 digests of the group on the path (bottom-up).   */
 int32_t zp_set_poseidon_bn254(zp_ctx *ctx, int32_t t, int32_t rp, const uint64_t *h_rc, const uint64_t *h_mds);

@@ -131,18 +131,17 @@ int orc_p254_perm(u64 *states, size_t count, int t) {
 
 /* leaf of row `row` (len Goldilocks values, stride between consecutive values): naive.py merkle16_leaf */
 static fe leaf_of(const p254_table *tb, const u64 *row, size_t len, size_t stride) {
-    const size_t ne = (len + 2) / 3;
     fe cap = {{0, 0, 0, 0}};
-    for (size_t off = 0; off < ne || off == 0; off += 16) {
+    for (size_t base = 0; base < len || base == 0; base += 56) {      /* 56 values per permutation: naive.py pack_leaf_block */
         fe s[MAXT];
         s[0] = cap;
         for (size_t e = 0; e < 16; e++) {
             u64 w[4] = {0, 0, 0, 0};
-            const size_t k = off + e;
-            if (k < ne)
-                for (int c = 0; c < 3; c++)
-                    if (3 * k + c < len) w[c] = row[(3 * k + c) * stride];
-            s[1 + e] = fe_from_words(w);      /* a + b 2^64 + c 2^128 < 2^192 < r */
+            for (int c = 0; c < 3; c++)
+                if (base + 3 * e + c < len) w[c] = row[(base + 3 * e + c) * stride];
+            const size_t x = base + 48 + (e >> 1);
+            if (x < len) w[3] = (e & 1) ? (row[x * stride] >> 32) : (row[x * stride] & 0xFFFFFFFFULL);
+            s[1 + e] = fe_from_words(w);      /* < 2^224 < r */
         }
         perm(tb, s);
         cap = s[0];

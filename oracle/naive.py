@@ -242,13 +242,28 @@ def pack3(vals):
     return [vals[i] + (vals[i + 1] << 64) + (vals[i + 2] << 128) for i in range(0, len(vals), 3)]
 
 
+LEAF_BLOCK = 56      # Goldilocks values one permutation of a leaf sponge absorbs
+
+
+def pack_leaf_block(vals):
+    """one sponge block of a 16-ary tree's leaf: up to 56 Goldilocks values in 16 field elements -- element e holds values 3e, 3e+1,
+    3e+2 in bits 0..191 (as pack3) and, in bits 192..223, 32-bit half number e of values 48..55 (half 2i = low word of value 48+i,
+    half 2i+1 = its high word).  Below 2^224 < r; rows of at most 48 values pack exactly as pack3."""
+    vals = list(vals) + [0] * (LEAF_BLOCK - len(vals))
+    out = []
+    for e in range(16):
+        x = vals[48 + (e >> 1)]
+        half = (x >> 32) if (e & 1) else (x & 0xFFFFFFFF)
+        out.append(vals[3 * e] + (vals[3 * e + 1] << 64) + (vals[3 * e + 2] << 128) + (half << 192))
+    return out
+
+
 def merkle16_leaf(row, rc, mds, rp):
-    """sponge over the packed row, 16 elements per permutation, the digest being the capacity of the next block"""
-    e = pack3(row)
+    """sponge over the row in blocks of 56 values (16 elements per permutation), the digest being the capacity of the next block"""
+    row = list(row)
     cap = 0
-    for off in range(0, max(len(e), 1), 16):
-        blk = e[off:off + 16]
-        cap = poseidon_bn254_perm([cap] + blk + [0] * (16 - len(blk)), rc, mds, rp)[0]
+    for off in range(0, max(len(row), 1), LEAF_BLOCK):
+        cap = poseidon_bn254_perm([cap] + pack_leaf_block(row[off:off + LEAF_BLOCK]), rc, mds, rp)[0]
     return cap
 
 

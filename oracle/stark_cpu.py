@@ -62,10 +62,10 @@ class CpuBackend:
     def poseidon_trace(self, inputs):
         return O.poseidon_trace(np.asarray(inputs, dtype=np.uint64), self.rc, self.mds)
 
-    def commit_trace(self, trace, logn, logb, extra_cols=0):
+    def commit_trace(self, trace, logn, logb, extra_cols=0, group=0):
         W = trace.shape[0]
         e1 = O.lde(trace, logb, self.shift, self.root32)
-        root, tree = self._tree(e1)
+        root, tree = self._tree(e1.reshape(W << group, -1))       # 2^group rows i, i + M', ... per leaf (BN128 mode)
         ext = np.zeros((W + extra_cols, e1.shape[1]), dtype=np.uint64)
         coef = np.zeros((W + extra_cols, trace.shape[1]), dtype=np.uint64)
         ext[:W], coef[:W] = e1, self._scaled_coef(trace)
@@ -80,7 +80,7 @@ class CpuBackend:
     def column_view(self, mat, col, rows):
         return np.asarray(mat).reshape(-1, rows)[col:]
 
-    def commit_stage2(self, air, c1, chal, logn, logb):
+    def commit_stage2(self, air, c1, chal, logn, logb, group=0):
         W = c1.W
         parts = []
         for st in air.stage2:
@@ -91,7 +91,8 @@ class CpuBackend:
         z = np.ascontiguousarray(np.concatenate(parts, axis=0))
         c1.ext[W:] = O.lde(z, logb, self.shift, self.root32)
         c1.coef[W:] = self._scaled_coef(z)
-        root, tree = self._tree(c1.ext[W:])
+        s2 = np.ascontiguousarray(c1.ext[W:])
+        root, tree = self._tree(s2.reshape(s2.shape[0] << group, -1))
         return Commit(root, tree)
 
     def commit_cols(self, cols, M, W):

@@ -170,12 +170,18 @@ def publics_digest(pubs, rc, mds, bn):
 
 
 def bn128_rows_per_leaf_log(width, logm):
-    """BN128-hash mode: a leaf of the quotient tree holds 2^g rows i, i + M / 2^g, ...; g is the largest with width * 2^g <= 48 values
-    (one width-17 permutation per leaf), capped so that the tree keeps at least 16 leaves"""
+    """BN128-hash mode: a leaf of a committed tree (trace, stage 2, quotient) holds 2^g rows i, i + M / 2^g, ...; g is the largest with
+    width * 2^g <= 56 values (one width-17 permutation per leaf: naive.py pack_leaf_block), capped so that the tree keeps at least
+    16 leaves"""
     g = 0
-    while (width << (g + 1)) <= 48 and g + 1 <= logm - 4:
+    while (width << (g + 1)) <= 56 and g + 1 <= logm - 4:
         g += 1
     return g
+
+
+def _row_of_leaf(leaf, width, g, j, logm):
+    """row j out of the 2^g rows a grouped leaf holds: column c of row j sits at position c 2^g + j / M'"""
+    return [leaf[(c << g) + (j >> (logm - g))] for c in range(width)]
 
 
 def fri_schedule(logn, logb, fri_logf, fri_final_log):
@@ -398,25 +404,26 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, t
         gp.append(cur)
         cur = NV.e3_mul(cur, gamma)
 
-    qg = bn128_rows_per_leaf_log(3 * Q, logm) if bn else 0        # BN128 mode: 2^qg rows of the quotient per leaf
+    # BN128 mode: 2^g rows per leaf of the trace / stage-2 / quotient trees
+    gt, g2, qg = [(bn128_rows_per_leaf_log(w, logm) if bn and w else 0) for w in (W, W2, 3 * Q)]
     for qq in proof["queries"]:
         j = qq["index"]
-        tv, qleaf = qq["trace"]["values"], qq["quotient"]["values"]
-        if len(tv) != W or len(qleaf) != (3 * Q) << qg:
+        tleaf, qleaf = qq["trace"]["values"], qq["quotient"]["values"]
+        if len(tleaf) != W << gt or len(qleaf) != (3 * Q) << qg:
             raise Reject("bad opening width")
-        if not opening_ok(tv, M, j, qq["trace"].get("path"), proof["roots"]["trace"]):
+        if not opening_ok(tleaf, M >> gt, j & ((M >> gt) - 1), qq["trace"].get("path"), proof["roots"]["trace"]):
             raise Reject("trace opening does not verify")
         if not opening_ok(qleaf, M >> qg, j & ((M >> qg) - 1), qq["quotient"].get("path"), proof["roots"]["quotient"]):
             raise Reject("quotient opening does not verify")
-        qv = [qleaf[(c << qg) + (j >> (logm - qg))] for c in range(3 * Q)]     # row j of the leaf's 2^qg rows
+        tv, qv = _row_of_leaf(tleaf, W, gt, j, logm), _row_of_leaf(qleaf, 3 * Q, qg, j, logm)
         s2v = []
         if air.stage2:
             s2 = qq.get("stage2")
-            if s2 is None or len(s2["values"]) != W2:
+            if s2 is None or len(s2["values"]) != W2 << g2:
                 raise Reject("missing stage-2 opening")
-            s2v = s2["values"]
-            if not opening_ok(s2v, M, j, s2.get("path"), proof["roots"]["stage2"]):
+            if not opening_ok(s2["values"], M >> g2, j & ((M >> g2) - 1), s2.get("path"), proof["roots"]["stage2"]):
                 raise Reject("stage-2 opening does not verify")
+            s2v = _row_of_leaf(s2["values"], W2, g2, j, logm)
         x = shift * pow(wM, j, P) % P
         vals = tv + s2v + qv
         A, B = [0, 0, 0], [0, 0, 0]

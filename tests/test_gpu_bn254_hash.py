@@ -36,7 +36,7 @@ def test_permutation_matches_the_definition(p254, t, count):
         assert g == NV.poseidon_bn254_perm(st, rc, mds, rp)
 
 
-@pytest.mark.parametrize("M,W", [(1, 5), (16, 3), (20, 50), (64, 49), (300, 7)])
+@pytest.mark.parametrize("M,W", [(1, 5), (16, 3), (20, 50), (64, 49), (300, 7), (33, 52), (17, 56), (40, 57), (5, 120)])
 def test_merkle16_tree_and_openings(p254, M, W):
     rc, mds, rp = PC.bn254_poseidon_params(17)
     cols = O.random_field((W, M), 5000 + M)
@@ -123,7 +123,7 @@ def test_lane_per_permutation_kernel_equals_the_cooperative_one_and_the_oracle(p
     assert [ints(bulk[i]) for i in sample] == want
 
 
-@pytest.mark.parametrize("M,W", [(1 << 14, 26), (1 << 14, 9), ((1 << 14) + 48, 50), (1 << 18, 4)])
+@pytest.mark.parametrize("M,W", [(1 << 14, 26), (1 << 14, 9), ((1 << 14) + 48, 50), (1 << 18, 4), (1 << 14, 52), ((1 << 14) + 5, 60)])
 def test_merkle16_bulk_kernels_match_cooperative_and_oracle(p254, M, W):
     """leaves (one and two sponge blocks per leaf, a leaf count that is no multiple of 64) and a tree level of 2^14 nodes
     through the lane-per-permutation kernel: the whole tree equals the cooperative kernels' tree; up to 2^14 leaves it also

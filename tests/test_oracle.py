@@ -198,7 +198,7 @@ def test_merkle16_c_restatement_matches_the_definition():
     from oracle import naive as NV
     rc, mds, rp = bn254_poseidon_params(17)
     O.p254_set(17, rp, rc, mds)
-    for W, M in ((1, 1), (3, 16), (50, 40), (100, 17)):
+    for W, M in ((1, 1), (3, 16), (48, 5), (50, 40), (52, 9), (56, 3), (57, 18), (100, 17), (120, 2)):    # one block = 56 values
         cols = O.random_field((W, M), 7 * W + M)
         tree = O.merkle16_tree(cols)
         lv = NV.merkle16_tree([[int(cols[c, i]) for c in range(W)] for i in range(M)], rc, mds, rp)
