@@ -33,10 +33,12 @@ def run(label, reps=5, **tune):
     gbs = 16.0 * N * cols / dt / 1e9
     print("%-34s %8.3f ms/transform  %7.1f Gelem/s  alg %6.0f GB/s  per-pass ms %s" % (label, dt * 1e3, cols * N / dt / 1e9, gbs, per), flush=True)
     for k in tune:
-        p.set_tuning(k, {"ntt_logt": 4, "ntt_tpw": 4}.get(k, 0))
+        p.set_tuning(k, {"ntt_logt": 4, "ntt_tpw": 2, "ntt_tw1": 26}.get(k, 0))
 
-run("default (T=16, tpw=4)")
-run("T=32 tpw=4", ntt_logt=5)
-run("T=16 tpw=1", ntt_tpw=1)
-run("T=16 tpw=2", ntt_tpw=2)
-run("T=16 tpw=8", ntt_tpw=8)
+run("warm-up")
+for rep in range(3):        # alternating, three times: the first measurements of a process run on a cold clock
+    run("T=16 tpw=2 (default), first-pass table", ntt_tpw=2)
+    run("T=16 tpw=1", ntt_tpw=1)
+    run("T=16 tpw=4", ntt_tpw=4)
+    run("T=32 tpw=2", ntt_logt=5)
+    run("first pass: per-lane chains", ntt_tw1=0)
