@@ -217,3 +217,32 @@ def test_single_proof_shape_and_identity_leaves(cpu, tables):
     ap = VA.aggregation_params(shape, n_queries=4, fri_final_log=3)
     assert V.verify(PR.prove(vair, trace, pubs, ap, cpu), vair.program(), rc, mds, V.expectation(ap.to_dict()))
     assert [int(v) for v in pubs][:shape.merkle_pubs()] == VA.expected_publics(shape, [proof])
+
+
+def test_untrusted_shapes_and_parameters_are_bounded(inner):
+    """what a recursive-proof text could choose freely sizes nothing: an aggregated proof's shape dictionary and a chunk proof's
+    parameters are range-checked before any schedule, table or array is built from them (service/engine.py)"""
+    from eigen_zeth_amd.service.engine import Engine
+    _, _, proofs = inner
+    shape = VA.Shape.of_proof(proofs[0], 2)
+    assert VA.Shape.from_dict(shape.to_dict()).key() == shape.key()
+    for k, v in (("logn", 99), ("W", -1), ("n_queries", True), ("n_proofs", 0), ("n_pub_inner", 1 << 40), ("logb", "1")):
+        with pytest.raises(ValueError):
+            VA.Shape.from_dict({**shape.to_dict(), k: v})
+    with pytest.raises(KeyError):
+        VA.Shape.from_dict({k: v for k, v in shape.to_dict().items() if k != "pow_bits"})
+    text = json.dumps(proofs[0])
+    assert Engine._parse_and_prepare(text)[2]["index"].shape == (shape.n_queries,)
+    for k, v in (("logn", 1 << 30), ("n_queries", 10 ** 9), ("logb", 0), ("fri_logf", -3), ("pow_bits", 1.5)):
+        bad = copy.deepcopy(proofs[0])
+        bad["params"][k] = v
+        with pytest.raises(ValueError, match="out of range"):
+            Engine._parse_and_prepare(json.dumps(bad))
+    bad = copy.deepcopy(proofs[0])
+    bad["queries"] = bad["queries"][:-1]                     # fewer openings than the parameters promise
+    with pytest.raises(ValueError):
+        Engine._parse_and_prepare(json.dumps(bad))
+    bad = copy.deepcopy(proofs[0])
+    bad["queries"][1]["trace"]["path"][0] = bad["queries"][1]["trace"]["path"][0][:3]      # a ragged authentication path
+    with pytest.raises(ValueError, match="shape"):
+        Engine._parse_and_prepare(json.dumps(bad))
