@@ -304,14 +304,17 @@ class Engine:
     @staticmethod
     def _parse_and_prepare(text):
         obj = json.loads(text)
+        whole = obj
+        if isinstance(obj, dict) and obj.get("kind") == "aggregated" and isinstance(obj.get("stark"), dict):
+            obj = obj["stark"]          # an aggregated proof is folded through ITS STARK (one recursion level up)
         if not isinstance(obj, dict) or "queries" not in obj or "roots" not in obj or not isinstance(obj.get("params"), dict):
-            raise ValueError("not a chunk proof")
+            raise ValueError("not a recursive proof of this prover")
         pr, lim = obj["params"], {"logn": 28, "logb": 8, "fri_logf": 8, "fri_final_log": 16, "n_queries": 4096, "pow_bits": 64}
         if any(not isinstance(pr.get(k), int) or isinstance(pr.get(k), bool) or not 0 <= pr[k] <= m for k, m in lim.items()) \
                 or pr["logn"] < 1 or pr["logb"] < 1 or pr["n_queries"] < 1 or pr["fri_logf"] < 1 or not isinstance(obj["queries"], list) \
                 or len(obj["queries"]) != pr["n_queries"]:
             raise ValueError("chunk proof parameters out of range")       # nothing below is sized by numbers the text could choose freely
-        return text, obj, VA.prepare_proof(obj)
+        return text, whole, VA.prepare_proof(obj)
 
     def _parsed_chunk_proof(self, text):
         """(object, prepared arrays) of a recursive proof text.  (Preparing the engine's own chunk proofs on a background thread
@@ -362,9 +365,11 @@ class Engine:
         return shape, vair, params, text
 
     def _aggregate(self, batch_id, p1, p2):
-        """GenAggregatedProof: a STARK whose witness is the verification trace of the two recursive proofs' query openings (every
-        Poseidon permutation of their Merkle paths), public inputs = their roots and query indices (stark/verifier_air.py).  With
-        one chunk the client sends the same proof twice (provider.rs:386-387): it is then verified once."""
+        """GenAggregatedProof: a STARK whose witness is the verification trace of the two recursive proofs (every Poseidon
+        permutation of their Merkle paths and transcripts), public inputs = their roots, indices, opened values and transcripts
+        (stark/verifier_air.py).  With one chunk the client sends the same proof twice (provider.rs:386-387): it is then verified
+        once.  The two proofs are chunk proofs (level 1) or aggregated proofs of one shape (level n + 1: their aggregation STARKs are
+        the inner proofs, what they aggregated travels along as "children") -- "recursive proofs" in the contract's words."""
         if not p1 or not p2:
             raise ValueError("empty recursive proof")
         try:
@@ -373,19 +378,38 @@ class Engine:
             if self.cfg.aggregate_all_chunks and known and len(known) > 2 and known[0] == p1 and known[-1] == p2:
                 texts = known                      # the whole batch, not only its two ends
             parsed = [self._parsed_chunk_proof(t) for t in texts]
-            proofs, prepared = [a for a, _ in parsed], [b for _, b in parsed]
-            for pr in proofs:
-                # this prover aggregates chunk proofs made under ITS security parameters (the text comes from the client: nothing
-                # below is sized by numbers it could choose freely)
-                lg = pr["params"].get("logn")
-                if not isinstance(lg, int) or not 1 <= lg <= 28 or pr["params"] != self.stark_params(lg).to_dict():
-                    raise ValueError("chunk proof was not made under this prover's parameters")
-        except (json.JSONDecodeError, TypeError, KeyError, IndexError) as e:
-            raise ValueError("recursive proof is not a chunk proof: %s" % e)
+            wholes, prepared = [a for a, _ in parsed], [b for _, b in parsed]
+            agg_params = lambda sh: VA.aggregation_params(sh, self.cfg.agg_queries, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.agg_pow_bits)
+            kinds = {w.get("kind", "chunk") for w in wholes}
+            if kinds == {"aggregated"}:
+                # recursion one level up: the inner proofs are the aggregation STARKs of the two aggregated proofs (same shape: they
+                # came out of this prover under its parameters); what they aggregated travels along as "children"
+                if len({json.dumps(w.get("shape"), sort_keys=True) for w in wholes}) != 1:
+                    raise ValueError("aggregated proofs of different shapes cannot be folded together")
+                below = VA.Shape.from_dict(wholes[0]["shape"])
+                inner_air = VA.verifier_air(below, *self._tables(self.be))
+                proofs = [w["stark"] for w in wholes]
+                for w, pr in zip(wholes, proofs):
+                    if w.get("verifier_air_digest") != inner_air.digest() or pr["params"] != agg_params(below).to_dict():
+                        raise ValueError("aggregated proof was not made under this prover's parameters")
+                children = [{k: w[k] for k in ("shape", "slots", "level", "inner", "children") if k in w} for w in wholes]
+                level = 1 + max(int(w.get("level", 1)) for w in wholes)
+                if level > 8:
+                    raise ValueError("recursion deeper than 8 levels")
+            elif kinds == {"chunk"}:
+                proofs, inner_air, children, level = wholes, AIR.get_air(self.cfg.air), None, 1
+                for pr in proofs:
+                    # this prover aggregates chunk proofs made under ITS security parameters (the text comes from the client:
+                    # nothing below is sized by numbers it could choose freely)
+                    lg = pr["params"].get("logn")
+                    if not isinstance(lg, int) or not 1 <= lg <= 28 or pr["params"] != self.stark_params(lg).to_dict():
+                        raise ValueError("chunk proof was not made under this prover's parameters")
+            else:
+                raise ValueError("a chunk proof and an aggregated proof cannot be folded together (aggregate the chunk proof first)")
+        except (json.JSONDecodeError, TypeError, KeyError, IndexError, AssertionError) as e:
+            raise ValueError("recursive proof is not a proof of this prover: %s" % e)
         tm = {}
-        shape, vair, params, text = self._prove_merkle_verifier(
-            proofs, lambda sh: VA.aggregation_params(sh, self.cfg.agg_queries, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.agg_pow_bits),
-            self.be, tm, AIR.get_air(self.cfg.air), prepared)
+        shape, vair, params, text = self._prove_merkle_verifier(proofs, agg_params, self.be, tm, inner_air, prepared)
         self.stage_timings["aggregate/" + batch_id] = tm
         if self.metrics is not None:
             for k, v in tm.items():
@@ -396,9 +420,10 @@ class Engine:
                                         "proof absorbs the public blocks and yields the public rates, and its grinding hash the public digest "
                                         "(all hashing of the verifier; its arithmetic -- out-of-domain identity, DEEP, FRI folds, challenges "
                                         "read off the public rates -- is checked natively on 'inner')",
-                           "shape": shape.to_dict(),
+                           "shape": shape.to_dict(), "level": level,
                            "slots": shape.n_slots(), "verifier_air_digest": vair.digest(),
-                           "inner": [self._header(pr) for pr in proofs]}, separators=(",", ":"))
+                           "inner": [self._header(pr) for pr in proofs],
+                           **({"children": children} if children else {})}, separators=(",", ":"))
         return head[:-1] + ',"stark":' + text + "}"
 
     # ---- GenFinalProof

@@ -37,16 +37,54 @@ def roots_of(proof, W2):
     return r + list(proof["fri"]["roots"])
 
 
+def verify_tree(agg, leaf_program, leaf_expect, rc, mds, program_of_shape, expect_of_shape, bn_tables=None):
+    """an aggregated proof of any level.  Level 1 aggregates chunk proofs (verify below).  Level n + 1 aggregates two aggregated
+    proofs of level <= n: its "inner" are THEIR aggregation STARKs without paths, its "children" what those aggregated.  Accepting
+    means every chunk proof at the leaves verifies: the outer STARK + native arithmetic vouch for the two aggregation STARKs one
+    level down (verify), and each of those, now known to verify, vouches for the hashing of ITS inner proofs, whose arithmetic is
+    checked natively against its public inputs (check_inner) -- and so on down to the chunk proofs.
+    program_of_shape(shape dict) -> (program blob of the verifier AIR for inner proofs of that shape, its query slots);
+    expect_of_shape(shape dict) -> the verifier's STARK parameters of a proof over that AIR."""
+    def node_ok(node, stark_publics):
+        """node = {"shape", "inner", ["children"]}: inner proofs vouched for by a STARK whose public inputs are stark_publics"""
+        kids = node.get("children")
+        if not kids:
+            check_inner(node["inner"], stark_publics, leaf_program, rc, mds, leaf_expect, program_of_shape(node["shape"])[1])
+            return
+        if len(kids) != len(node["inner"]) or len({repr(sorted(k["shape"].items())) for k in kids}) != 1:
+            raise V.Reject("children do not match the inner proofs")
+        prog_below, _ = program_of_shape(kids[0]["shape"])
+        check_inner(node["inner"], stark_publics, prog_below, rc, mds, expect_of_shape(kids[0]["shape"]), program_of_shape(node["shape"])[1])
+        for kid, hdr in zip(kids, node["inner"]):
+            node_ok(kid, hdr["publics"])            # hdr (an aggregation STARK one level down) verifies: its publics are facts
+    top_prog, _ = program_of_shape(agg["shape"])
+    node_ok(agg, agg["stark"]["publics"])
+    prog = top_prog if isinstance(top_prog, Program) else Program(top_prog)
+    return V.verify(agg["stark"], prog, rc, mds, expect_of_shape(agg["shape"]), bn_tables)
+
+
+def check_inner(inner, outer_publics, inner_program, rc, mds, inner_expect, n_slots):
+    """steps 1 and 2 of verify(): the inner proofs (without paths) pass the native part of the verifier with their transcripts
+    read off `outer_publics`, and `outer_publics` are exactly their roots, indices, opened values and transcripts.  Returns
+    nothing; whoever calls it must have a reason to believe a STARK with these public inputs verifies."""
+    _check_inner(inner, [int(v) for v in outer_publics], inner_program, rc, mds, inner_expect, n_slots)
+
+
 def verify(agg, inner_program, outer_program, rc, mds, inner_expect, outer_expect, n_slots, bn_tables=None):
     """agg: the aggregated proof (dict); inner_program / outer_program: constraint program blobs of the inner AIR and of the
     Merkle-verifier AIR; *_expect: the verifier's own STARK parameters for the two levels; n_slots: query slots of the outer
     trace (a property of the verifier AIR's layout, given by whoever supplies its program).  bn_tables: the Poseidon-BN254
     tables when the OUTER proof is in BN128-hash mode (the final STARK over an aggregated proof's STARK: the inner proofs are
     Goldilocks-mode either way)."""
-    inner = agg["inner"]
+    outer = agg["stark"]
+    _check_inner(agg["inner"], [int(v) for v in outer["publics"]], inner_program, rc, mds, inner_expect, n_slots)
+    prog = outer_program if isinstance(outer_program, Program) else Program(outer_program)
+    return V.verify(outer, prog, rc, mds, outer_expect, bn_tables)
+
+
+def _check_inner(inner, outer_publics, inner_program, rc, mds, inner_expect, n_slots):
     if not inner:
         raise V.Reject("no inner proofs")
-    outer = agg["stark"]
     # the Merkle part of the outer public inputs has a length the shapes fix; what follows it is the inner transcripts, proof by
     # proof: absorbed blocks and read rates in protocol order.  Every inner proof is verified on a sponge that READS them.
     probe = Program(inner_program) if not isinstance(inner_program, Program) else inner_program
@@ -54,7 +92,7 @@ def verify(agg, inner_program, outer_program, rc, mds, inner_expect, outer_expec
     T = 2 + (1 if probe.width2 else 0) + len(sched)
     per_query = probe.width + probe.width2 + 3 * probe.q_chunks + sum(3 << f for (_, f) in sched)
     n_merkle = len(inner) * T * 4 + n_slots * len(inner) * (T + per_query)
-    sponge = V.PublicSponge([int(v) for v in outer["publics"]][n_merkle:])
+    sponge = V.PublicSponge(outer_publics[n_merkle:])
     heads = []
     for h in inner:
         sponge.queue, sponge.avail = [], []          # a fresh sponge per proof on the one stream
@@ -80,7 +118,5 @@ def verify(agg, inner_program, outer_program, rc, mds, inner_expect, outer_expec
             q = h["queries"][g % nq]
             for part in [q["trace"]] + ([q["stage2"]] if W2 else []) + [q["quotient"]] + list(q["fri"]):
                 want += [int(v) for v in part["values"]]
-    if [int(v) for v in outer["publics"]][:n_merkle] != want:
+    if outer_publics[:n_merkle] != want:
         raise V.Reject("the outer proof's public inputs are not the inner proofs' roots, query indices and opened values")
-    prog = outer_program if isinstance(outer_program, Program) else Program(outer_program)
-    return V.verify(outer, prog, rc, mds, outer_expect, bn_tables)

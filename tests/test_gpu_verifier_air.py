@@ -171,3 +171,40 @@ def test_engine_can_aggregate_every_chunk_of_a_batch(tables, tmp_path):
     fsh = VA.Shape.of_proof(agg["stark"], 1)
     assert V.verify(fsp, VA.verifier_air(fsh, rc, mds).program(), rc, mds, V.expectation(eng.final_stark_params(agg["stark"]).to_dict()),
                     bn254_poseidon_params(17))
+
+
+def test_engine_folds_aggregated_proofs_again(tables, tmp_path):
+    """GenAggregatedProof on two AGGREGATED proofs (level 2): the service's output passes the checker's tree verifier down to the
+    four chunk proofs, GenFinalProof sits on top of it as on any aggregated proof, and mixed inputs are an application error"""
+    from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
+    from eigen_zeth_amd.service.engine import Engine, EngineConfig
+    from eigen_zeth_amd.service.server import default_backend_factory
+    rc, mds = tables
+    cfg = EngineConfig(air="chunk16", logn=10, chunks_per_block=1, groth16_logm=6, crs_dir=str(tmp_path / "crs"), n_queries=12, pow_bits=4,
+                       agg_queries=6, final_queries=4)
+    eng = Engine(default_backend_factory(0), cfg)
+    ch = eng.gen_batch_chunks("t", [31, 32, 33, 34], 12345, "evm")
+    proofs = eng.gen_chunk_proofs("t", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+    ab = eng.aggregate("t", proofs[0]["proof"], proofs[1]["proof"])
+    cd = eng.aggregate("t", proofs[2]["proof"], proofs[3]["proof"])
+    top_text = eng.aggregate("t", ab, cd)
+    top = json.loads(top_text)
+    assert top["level"] == 2 and len(top["children"]) == 2 and [len(c["inner"]) for c in top["children"]] == [2, 2]
+    assert top["inner"][0]["air_digest"] == json.loads(ab)["verifier_air_digest"]
+
+    def program_of_shape(d):
+        sh = VA.Shape.from_dict(d)
+        return VA.verifier_air(sh, rc, mds).program(), sh.n_slots()
+
+    def expect_of_shape(d):
+        return V.expectation(VA.aggregation_params(VA.Shape.from_dict(d), cfg.agg_queries, cfg.fri_logf, cfg.fri_final_log).to_dict())
+    args = (AIR.get_air("chunk16").program(), V.expectation(eng.stark_params(10).to_dict()), rc, mds, program_of_shape, expect_of_shape)
+    assert AV.verify_tree(top, *args)
+    assert AV.verify_tree(json.loads(ab), *args)
+    with pytest.raises(ValueError, match="cannot be folded"):
+        eng.aggregate("t", ab, proofs[2]["proof"])
+    final, pub = eng.final("t", top_text, "BN128", "479881985774944702531460751064278034642760119942")
+    fsp = json.loads(eng.final_starks["t"])
+    fsh = VA.Shape.of_proof(top["stark"], 1)
+    assert V.verify(fsp, VA.verifier_air(fsh, rc, mds).program(), rc, mds, V.expectation(eng.final_stark_params(top["stark"]).to_dict()),
+                    bn254_poseidon_params(17))

@@ -246,3 +246,54 @@ def test_untrusted_shapes_and_parameters_are_bounded(inner):
     bad["queries"][1]["trace"]["path"][0] = bad["queries"][1]["trace"]["path"][0][:3]      # a ragged authentication path
     with pytest.raises(ValueError, match="shape"):
         Engine._parse_and_prepare(json.dumps(bad))
+
+
+def test_aggregated_proofs_fold_again(inner, aggregated, cpu, tables):
+    """recursion one level up: two aggregated proofs (each over two chunk proofs) are folded through their aggregation STARKs; the
+    checker walks the tree -- outer STARK + native arithmetic for the two aggregation STARKs, then, for each of them, native
+    arithmetic for ITS chunk proofs against its (now vouched-for) public inputs.  A chunk proof tampered at a leaf, a child
+    attached to the wrong parent, or a child STARK whose publics were edited are all refused."""
+    rc, mds = tables
+    air, params, proofs = inner
+    shape1, vair1, ap1, _, _, aggA = aggregated
+    more = []
+    for seed in (5, 6):
+        tr, pub = native.synth_trace(air.trace_kind, 6, air.width, seed)
+        more.append(json.loads(PR.proof_to_json(PR.prove(air, tr, pub, params, cpu))))
+    trB, pubsB = VA.build_witness(shape1, more, cpu, air.digest_words())
+    aggB = {"shape": shape1.to_dict(), "inner": [strip_paths(p) for p in more], "stark": PR.prove(vair1, trB, pubsB, ap1, cpu)}
+    A = {"shape": shape1.to_dict(), "inner": aggA["inner"], "stark": json.loads(PR.proof_to_json(aggA["stark"]))}
+    B = dict(aggB, stark=json.loads(PR.proof_to_json(aggB["stark"])))
+    shape2 = VA.Shape.of_proof(A["stark"], 2)
+    vair2 = VA.verifier_air(shape2, rc, mds)
+    tr2, pubs2 = VA.build_witness(shape2, [A["stark"], B["stark"]], cpu, vair1.digest_words())
+    ap2 = VA.aggregation_params(shape2, n_queries=4, fri_final_log=3)
+    top = {"shape": shape2.to_dict(), "level": 2, "inner": [strip_paths(A["stark"]), strip_paths(B["stark"])],
+           "children": [{"shape": A["shape"], "inner": A["inner"]}, {"shape": B["shape"], "inner": B["inner"]}],
+           "stark": json.loads(PR.proof_to_json(PR.prove(vair2, tr2, pubs2, ap2, cpu)))}
+
+    def program_of_shape(d):
+        sh = VA.Shape.from_dict(d)
+        return VA.verifier_air(sh, rc, mds).program(), sh.n_slots()
+
+    def expect_of_shape(d):
+        return V.expectation((ap1 if d == shape1.to_dict() else ap2).to_dict())
+    args = (air.program(), V.expectation(params.to_dict()), rc, mds, program_of_shape, expect_of_shape)
+    assert AV.verify_tree(top, *args)
+    assert AV.verify_tree(dict(A), *args)                                   # a level-1 proof through the same entry
+    bad = copy.deepcopy(top)
+    bad["children"][1]["inner"][0]["evals"]["z"][2][1] ^= 1                  # a chunk proof at a leaf
+    with pytest.raises(V.Reject):
+        AV.verify_tree(bad, *args)
+    bad = copy.deepcopy(top)
+    bad["children"] = bad["children"][::-1]                                  # children under the wrong parents
+    with pytest.raises(V.Reject):
+        AV.verify_tree(bad, *args)
+    bad = copy.deepcopy(top)
+    bad["inner"][0]["publics"][3] = (bad["inner"][0]["publics"][3] + 1) % P  # an aggregation STARK claiming other public inputs
+    with pytest.raises(V.Reject):
+        AV.verify_tree(bad, *args)
+    bad = copy.deepcopy(top)
+    del bad["children"]                                                      # the chunk proofs withheld
+    with pytest.raises((V.Reject, KeyError, ValueError)):
+        AV.verify_tree(bad, *args)
