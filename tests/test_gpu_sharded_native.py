@@ -97,7 +97,7 @@ def test_sharded_commit_over_local_ranks_equals_single_root(tables, G, prover):
 
 
 CASES = [("chunk16", 10, 1, 2, 3, 8, 8, 2), ("chunk16", 10, 1, 2, 3, 8, 8, 4), ("wide8", 9, 2, 3, 3, 6, 0, 4), ("cubic", 8, 1, 2, 3, 6, 4, 2),
-         ("fib", 7, 1, 2, 3, 5, 0, 2), ("periodic9", 9, 2, 2, 3, 6, 4, 1), ("chunk64", 12, 1, 3, 4, 12, 8, 4)]
+         ("fib", 7, 1, 2, 3, 5, 0, 2), ("periodic9", 9, 2, 2, 3, 6, 4, 1), ("chunk64", 12, 1, 3, 4, 12, 8, 4), ("chunk64", 14, 1, 3, 5, 16, 8, 8)]      # the last: 8 ranks, the width the driver's node has
 
 
 @pytest.mark.parametrize("airname,logn,logb,logf,final_log,nq,pow_bits,G", CASES)
