@@ -49,7 +49,7 @@ def run_ranks(G, fn):
     return out
 
 
-@pytest.mark.parametrize("G", [2, 4])
+@pytest.mark.parametrize("G", [2, 4, 8])
 def test_local_group_collectives(G):
     w = 1 << 10
 
@@ -82,7 +82,7 @@ def test_local_group_collectives(G):
         assert (sm == want).all()
 
 
-@pytest.mark.parametrize("G", [2, 4])
+@pytest.mark.parametrize("G", [2, 4, 8])
 def test_sharded_commit_over_local_ranks_equals_single_root(tables, G, prover):
     rc, mds = tables
     M, W = 1 << 12, 8
