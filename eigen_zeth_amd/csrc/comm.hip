@@ -11,11 +11,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <functional>
+#include <thread>
 #include <vector>
 
 #include "ctx.hpp"
@@ -35,6 +37,8 @@ struct Rccl {
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;                  // optional: the watchdog's way out of a collective a peer never joins
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;  // optional
     bool ok = false;
 };
 
@@ -51,6 +55,7 @@ Rccl &rccl() {
 #define ZP_SYM(name) r.name = (decltype(r.name))dlsym(r.h, "nccl" #name)
     ZP_SYM(GetUniqueId); ZP_SYM(CommInitRank); ZP_SYM(CommDestroy); ZP_SYM(GroupStart); ZP_SYM(GroupEnd);
     ZP_SYM(Send); ZP_SYM(Recv); ZP_SYM(AllGather); ZP_SYM(Broadcast); ZP_SYM(AllReduce); ZP_SYM(GetErrorString);
+    ZP_SYM(CommAbort); ZP_SYM(CommGetAsyncError);
 #undef ZP_SYM
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllGather && r.Broadcast &&
            r.AllReduce && r.GetErrorString;
@@ -70,16 +75,37 @@ struct zp_comm_group {
     int waiting = 0;
     unsigned gen = 0;
     const void *ptr[64];
-    void barrier() {
+    // A rank that fails -- inside a collective or anywhere between two of them (zp_comm_abort) -- POISONS the group: every rank that is
+    // waiting in a barrier wakes with ZP_ERR_COMM and every later collective returns it at once.  A rank that never arrives (a crashed
+    // thread, a host that forgot the call) is caught by the barrier's timeout, which poisons the group the same way.  Nobody waits for ever.
+    bool poisoned = false;
+    int timeout_ms = 120000;
+    void fail() {
+        std::lock_guard<std::mutex> lk(mu);
+        poisoned = true;
+        cv.notify_all();
+    }
+    bool dead() {
+        std::lock_guard<std::mutex> lk(mu);
+        return poisoned;
+    }
+    int32_t barrier() {         // ZP_OK: every rank arrived; ZP_ERR_COMM: the group is dead (a peer failed or did not arrive in time)
         std::unique_lock<std::mutex> lk(mu);
+        if (poisoned) return ZP_ERR_COMM;
         const unsigned g = gen;
         if (++waiting == world) {
             waiting = 0;
             gen++;
             cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return gen != g; });
+            return ZP_OK;
         }
+        const bool woke = cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return gen != g || poisoned; });
+        if (woke && gen != g && !poisoned) return ZP_OK;
+        if (!poisoned) {        // timed out: take everybody else down too
+            poisoned = true;
+            cv.notify_all();
+        }
+        return ZP_ERR_COMM;
     }
 };
 
@@ -88,6 +114,8 @@ struct zp_comm {
     ncclComm_t comm;
     int rank, world;
     zp_comm_group *local = nullptr;    // non-null: in-process group, no RCCL
+    bool dead = false;                 // aborted (zp_comm_abort, the watchdog): every later collective is ZP_ERR_COMM
+    int timeout_ms = 120000;           // RCCL: > 0 = a collective returns when it is complete on the stream, or ZP_ERR_COMM after this long
 };
 
 namespace {
@@ -100,31 +128,90 @@ __global__ void __launch_bounds__(256) sum_parts_kernel(u64 *__restrict__ dst, c
     dst[i] = a;
 }
 
+const char *const kDeadText = "communicator is dead: a peer rank failed, aborted or did not arrive in time";
+
 // in-process collectives: publish this rank's buffer, meet, copy what the collective says from the peers' buffers, meet again (so that
-// nobody reuses a buffer a peer is still reading).  All copies run on the calling rank's stream and are complete on return.
+// nobody reuses a buffer a peer is still reading).  All copies run on the calling rank's stream and are complete on return.  A rank
+// whose own step fails still tells the others (poison) before it returns: no rank is left waiting at a barrier.
 int32_t local_exchange(zp_comm *c, const void *mine, const std::function<int32_t(const void *const *)> &copy) {
     zp_comm_group *g = c->local;
-    ZP_HIP(c->ctx, hipStreamSynchronize(c->ctx->stream));       // what I hand out is complete
+    int32_t rc = ZP_OK;
+    hipError_t e = hipStreamSynchronize(c->ctx->stream);       // what I hand out is complete
+    if (e != hipSuccess) {
+        c->ctx->err = std::string("hipStreamSynchronize before a collective: ") + hipGetErrorString(e);
+        rc = ZP_ERR_HIP;
+        g->fail();
+    }
     g->ptr[c->rank] = mine;
-    g->barrier();
-    const int32_t rc = copy(g->ptr);
-    const hipError_t e = hipStreamSynchronize(c->ctx->stream);
-    g->barrier();
+    const int32_t b1 = g->barrier();
+    if (b1 == ZP_OK && rc == ZP_OK) {
+        rc = copy(g->ptr);
+        e = hipStreamSynchronize(c->ctx->stream);
+        if (rc == ZP_OK && e != hipSuccess) {
+            c->ctx->err = std::string("hipStreamSynchronize after a collective: ") + hipGetErrorString(e);
+            rc = ZP_ERR_HIP;
+        }
+        if (rc != ZP_OK) g->fail();
+    }
+    const int32_t b2 = g->barrier();
     if (rc != ZP_OK) return rc;
-    ZP_HIP(c->ctx, e);
+    if (b1 != ZP_OK || b2 != ZP_OK) {
+        c->ctx->err = kDeadText;
+        return ZP_ERR_COMM;
+    }
     return ZP_OK;
+}
+
+// RCCL: the collective is on the stream.  With a timeout the call returns when the stream has drained -- or aborts the communicator when
+// a peer never joins (its kernel would spin for ever and hipStreamSynchronize with it) or RCCL reports an asynchronous error.
+int32_t rccl_wait(zp_comm *c) {
+    if (c->timeout_ms <= 0) return ZP_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->ctx->stream);
+        if (q == hipSuccess) return ZP_OK;
+        if (q != hipErrorNotReady) {
+            c->ctx->err = std::string("stream failed during a collective: ") + hipGetErrorString(q);
+            c->dead = true;
+            if (rccl().CommAbort && c->comm) { (void)rccl().CommAbort(c->comm); c->comm = nullptr; }
+            return ZP_ERR_HIP;
+        }
+        ncclResult_t ae = ncclSuccess;
+        const bool async_bad = rccl().CommGetAsyncError && (spins & 255) == 255 && rccl().CommGetAsyncError(c->comm, &ae) == ncclSuccess && ae != ncclSuccess &&
+                               ae != ncclInProgress;
+        const bool late = std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(c->timeout_ms);
+        if (async_bad || late) {
+            c->ctx->err = async_bad ? std::string("RCCL asynchronous error: ") + rccl().GetErrorString(ae)
+                                    : std::string("collective did not complete within the communicator's timeout; communicator aborted");
+            c->dead = true;
+            if (rccl().CommAbort && c->comm) { (void)rccl().CommAbort(c->comm); c->comm = nullptr; }
+            return ZP_ERR_COMM;
+        }
+        if (++spins < 2000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
 }
 
 }  // namespace
 
 zp_ctx *zpi_comm_ctx(const zp_comm *comm) { return comm ? comm->ctx : nullptr; }
 
+// this rank cannot go on (rc != ZP_OK, ctx->err already says why): take the communicator down so that no peer waits for it, return rc
+int32_t zpi_comm_fail(zp_comm *c, int32_t rc) {
+    if (!c || rc == ZP_OK) return rc;
+    c->dead = true;
+    if (c->local) c->local->fail();
+    else if (c->comm && rccl().CommAbort) { (void)rccl().CommAbort(c->comm); c->comm = nullptr; }
+    return rc;
+}
+
 #define ZP_NCCL(c, call)                                                                       \
     do {                                                                                       \
         const ncclResult_t r_ = (call);                                                        \
         if (r_ != ncclSuccess) {                                                               \
             (c)->ctx->err = std::string(#call) + ": " + rccl().GetErrorString(r_);             \
-            return ZP_ERR_HIP;                                                                 \
+            return zpi_comm_fail((c), ZP_ERR_HIP);                                             \
         }                                                                                      \
     } while (0)
 
@@ -189,9 +276,31 @@ int32_t zp_comm_create_local(zp_ctx *ctx, int32_t rank, zp_comm_group *group, zp
 int32_t zp_comm_destroy(zp_comm *c) {
     if (!c) return ZP_OK;
     ZP_BIND(c->ctx);
-    (void)hipStreamSynchronize(c->ctx->stream);
+    if (!c->dead) (void)hipStreamSynchronize(c->ctx->stream);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     delete c;
+    return ZP_OK;
+}
+
+// A rank that fails BETWEEN collectives (out of memory, a bad argument only it sees) calls this before it gives up: in-process peers wake
+// from their barrier with ZP_ERR_COMM, RCCL peers run into their timeout (the aborted rank's kernels are gone).  Idempotent.
+int32_t zp_comm_abort(zp_comm *c) {
+    if (!c) return ZP_ERR_ARG;
+    (void)zpi_comm_fail(c, ZP_ERR_COMM);
+    return ZP_OK;
+}
+
+// how long a collective may wait for its peers (default 120 000 ms).  In-process group: the barrier timeout of the WHOLE group.  RCCL:
+// this rank's watchdog; 0 = asynchronous collectives (return after the enqueue, no watchdog: the caller synchronises the stream itself).
+int32_t zp_comm_set_timeout_ms(zp_comm *c, int32_t ms) {
+    if (!c || ms < 0) return ZP_ERR_ARG;
+    if (c->local) {
+        if (ms == 0) return ZP_ERR_ARG;
+        std::lock_guard<std::mutex> lk(c->local->mu);
+        c->local->timeout_ms = ms;
+    } else {
+        c->timeout_ms = ms;
+    }
     return ZP_OK;
 }
 
@@ -204,6 +313,7 @@ int32_t zp_comm_all_to_all(zp_comm *c, const uint64_t *d_send, uint64_t *d_recv,
     ZpStage stage_(c->ctx, "comm_all_to_all");
     ZP_ARG(c->ctx, d_send && d_recv && d_send != d_recv, "bad buffers");
     if (words_per_peer == 0) return ZP_OK;
+    if (c->dead || (c->local && c->local->dead())) { c->ctx->err = kDeadText; return ZP_ERR_COMM; }
     if (c->local)
         return local_exchange(c, d_send, [&](const void *const *peer) -> int32_t {
             for (int h = 0; h < c->world; h++)
@@ -212,12 +322,21 @@ int32_t zp_comm_all_to_all(zp_comm *c, const uint64_t *d_send, uint64_t *d_recv,
             return ZP_OK;
         });
     ZP_NCCL(c, rccl().GroupStart());
-    for (int h = 0; h < c->world; h++) {
-        ZP_NCCL(c, rccl().Send(d_send + (size_t)h * words_per_peer, words_per_peer, ncclUint64, h, c->comm, c->ctx->stream));
-        ZP_NCCL(c, rccl().Recv(d_recv + (size_t)h * words_per_peer, words_per_peer, ncclUint64, h, c->comm, c->ctx->stream));
+    ncclResult_t bad = ncclSuccess;       // a failed send / recv must not leave this thread's RCCL group open: GroupEnd runs either way
+    const char *what = "";
+    for (int h = 0; h < c->world && bad == ncclSuccess; h++) {
+        bad = rccl().Send(d_send + (size_t)h * words_per_peer, words_per_peer, ncclUint64, h, c->comm, c->ctx->stream);
+        what = "ncclSend";
+        if (bad != ncclSuccess) break;
+        bad = rccl().Recv(d_recv + (size_t)h * words_per_peer, words_per_peer, ncclUint64, h, c->comm, c->ctx->stream);
+        what = "ncclRecv";
     }
-    ZP_NCCL(c, rccl().GroupEnd());
-    return ZP_OK;
+    const ncclResult_t ge = rccl().GroupEnd();
+    if (bad != ncclSuccess || ge != ncclSuccess) {
+        c->ctx->err = std::string(bad != ncclSuccess ? what : "ncclGroupEnd") + ": " + rccl().GetErrorString(bad != ncclSuccess ? bad : ge);
+        return zpi_comm_fail(c, ZP_ERR_HIP);
+    }
+    return rccl_wait(c);
 }
 
 int32_t zp_comm_all_gather(zp_comm *c, const uint64_t *d_send, uint64_t *d_recv, size_t words) {
@@ -225,6 +344,7 @@ int32_t zp_comm_all_gather(zp_comm *c, const uint64_t *d_send, uint64_t *d_recv,
     ZpStage stage_(c->ctx, "comm_all_gather");
     ZP_ARG(c->ctx, d_send && d_recv, "bad buffers");
     if (words == 0) return ZP_OK;
+    if (c->dead || (c->local && c->local->dead())) { c->ctx->err = kDeadText; return ZP_ERR_COMM; }
     if (c->local)
         return local_exchange(c, d_send, [&](const void *const *peer) -> int32_t {
             for (int h = 0; h < c->world; h++)
@@ -232,7 +352,7 @@ int32_t zp_comm_all_gather(zp_comm *c, const uint64_t *d_send, uint64_t *d_recv,
             return ZP_OK;
         });
     ZP_NCCL(c, rccl().AllGather(d_send, d_recv, words, ncclUint64, c->comm, c->ctx->stream));
-    return ZP_OK;
+    return rccl_wait(c);
 }
 
 // d_buf <- sum over the ranks of their d_buf (64-bit wrapping sums; the sharded prover adds vectors of which exactly one rank holds a
@@ -242,9 +362,13 @@ int32_t zp_comm_all_reduce_sum(zp_comm *c, uint64_t *d_buf, size_t words) {
     ZpStage stage_(c->ctx, "comm_all_reduce");
     ZP_ARG(c->ctx, d_buf != nullptr, "bad buffer");
     if (words == 0) return ZP_OK;
+    if (c->dead || (c->local && c->local->dead())) { c->ctx->err = kDeadText; return ZP_ERR_COMM; }
     if (c->local) {
         void *tmp = nullptr;
-        ZP_TRY(zp_dev_alloc(c->ctx, (size_t)c->world * words * 8, &tmp));
+        {   // allocate BEFORE the ranks meet; a rank that cannot must say so, or its peers would wait at the barrier
+            const int32_t arc = zp_dev_alloc(c->ctx, (size_t)c->world * words * 8, &tmp);
+            if (arc != ZP_OK) return zpi_comm_fail(c, arc);
+        }
         int32_t rc = local_exchange(c, d_buf, [&](const void *const *peer) -> int32_t {
             for (int h = 0; h < c->world; h++)
                 ZP_HIP(c->ctx, hipMemcpyAsync((u64 *)tmp + (size_t)h * words, peer[h], words * 8, hipMemcpyDeviceToDevice, c->ctx->stream));
@@ -253,13 +377,13 @@ int32_t zp_comm_all_reduce_sum(zp_comm *c, uint64_t *d_buf, size_t words) {
         if (rc == ZP_OK) {     // every rank has read every buffer (second barrier of the exchange): now the sums may overwrite them
             hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->ctx->stream, (u64 *)d_buf, (const u64 *)tmp, words,
                                c->world);
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->ctx->stream) != hipSuccess) rc = ZP_ERR_HIP;
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->ctx->stream) != hipSuccess) rc = zpi_comm_fail(c, ZP_ERR_HIP);
         }
         (void)zp_dev_free(c->ctx, tmp);
         return rc;
     }
     ZP_NCCL(c, rccl().AllReduce(d_buf, d_buf, words, ncclUint64, ncclSum, c->comm, c->ctx->stream));
-    return ZP_OK;
+    return rccl_wait(c);
 }
 
 int32_t zp_comm_broadcast(zp_comm *c, uint64_t *d_buf, size_t words, int32_t root) {
@@ -267,13 +391,14 @@ int32_t zp_comm_broadcast(zp_comm *c, uint64_t *d_buf, size_t words, int32_t roo
     ZpStage stage_(c->ctx, "comm_broadcast");
     ZP_ARG(c->ctx, d_buf && root >= 0 && root < c->world, "bad arguments");
     if (words == 0) return ZP_OK;
+    if (c->dead || (c->local && c->local->dead())) { c->ctx->err = kDeadText; return ZP_ERR_COMM; }
     if (c->local)
         return local_exchange(c, d_buf, [&](const void *const *peer) -> int32_t {
             if (c->rank != root) ZP_HIP(c->ctx, hipMemcpyAsync(d_buf, peer[root], words * 8, hipMemcpyDeviceToDevice, c->ctx->stream));
             return ZP_OK;
         });
     ZP_NCCL(c, rccl().Broadcast(d_buf, d_buf, words, ncclUint64, root, c->comm, c->ctx->stream));
-    return ZP_OK;
+    return rccl_wait(c);
 }
 
 // column shards -> row shards: d_cols u64[Wl][M] (this rank's columns, all rows) -> d_rows u64[G * Wl][M / G] (ALL columns in
@@ -284,7 +409,8 @@ int32_t zp_exchange_columns_to_rows(zp_comm *c, const uint64_t *d_cols, size_t W
     zp_ctx *ctx = c->ctx;
     ZP_ARG(ctx, d_cols && d_pack && d_rows && Wl >= 1 && M % (size_t)c->world == 0 && (M / c->world) % 2 == 0, "bad arguments (M must split into even row shards)");
     if (c->world == 1) return zp_d2d(ctx, d_rows, d_cols, Wl * M * 8);
-    ZP_TRY(zp_pack_blocks(ctx, d_cols, d_pack, Wl, M, c->world));
+    const int32_t prc = zp_pack_blocks(ctx, d_cols, d_pack, Wl, M, c->world);
+    if (prc != ZP_OK) return zpi_comm_fail(c, prc);        // the peers are on their way into the all-to-all
     return zp_comm_all_to_all(c, d_pack, d_rows, Wl * (M / c->world));
 }
 
@@ -315,6 +441,7 @@ int32_t zp_merkle_commit_sharded(zp_comm *c, const uint64_t *d_cols, size_t M, i
         for (size_t i = 0; i < n / 2; i++) memcpy(&lvl[4 * i], &st[12 * i], 32);
     }
     if (rc == ZP_OK) memcpy(h_root4, lvl.data(), 32);
+    else (void)zpi_comm_fail(c, rc);                       // whatever failed here, no peer may wait for this rank
     if (pack) (void)zp_dev_free(ctx, pack);
     if (rows) (void)zp_dev_free(ctx, rows);
     if (sub) (void)zp_dev_free(ctx, sub);
@@ -327,7 +454,8 @@ static int32_t sharded_transpose(zp_comm *c, uint64_t *d_x, uint64_t *d_y, uint6
     zp_ctx *ctx = c->ctx;
     const size_t G = (size_t)c->world;
     if (G == 1) return zp_transpose(ctx, d_x, d_y, Rl, C);
-    ZP_TRY(zp_pack_blocks(ctx, d_x, d_z, Rl, C, c->world));
+    const int32_t prc = zp_pack_blocks(ctx, d_x, d_z, Rl, C, c->world);
+    if (prc != ZP_OK) return zpi_comm_fail(c, prc);
     ZP_TRY(zp_comm_all_to_all(c, d_z, d_x, Rl * (C / G)));            // block h of d_x = rank h's rows, my columns: [G Rl][C / G]
     return zp_transpose(ctx, d_x, d_y, G * Rl, C / G);
 }
@@ -341,8 +469,12 @@ static int32_t sharded_transpose(zp_comm *c, uint64_t *d_x, uint64_t *d_y, uint6
 // ends as this rank's contiguous block of the transform; without it d_data holds rows k1 in [g N1 / G, ..) of Y[k1][k2] =
 // X[k1 + N1 k2] (what a consumer that works on rows wants: one all-to-all less).  inverse != 0: the inverse transform, scaled by
 // 1 / N.  d_tmp: scratch of 2 N / G words.  Same result, bit for bit, as zp_ntt / zp_intt on the whole column on one GPU.
+static int32_t ntt_sharded_impl(zp_comm *c, uint64_t *d_data, uint64_t *d_tmp, int32_t logn, int32_t inverse, int32_t natural_output);
 int32_t zp_ntt_sharded(zp_comm *c, uint64_t *d_data, uint64_t *d_tmp, int32_t logn, int32_t inverse, int32_t natural_output) {
     if (!c) return ZP_ERR_ARG;
+    return zpi_comm_fail(c, ntt_sharded_impl(c, d_data, d_tmp, logn, inverse, natural_output));   // an error on this rank frees the peers
+}
+static int32_t ntt_sharded_impl(zp_comm *c, uint64_t *d_data, uint64_t *d_tmp, int32_t logn, int32_t inverse, int32_t natural_output) {
     zp_ctx *ctx = c->ctx;
     const size_t G = (size_t)c->world;
     const int l1 = logn / 2, l2 = logn - l1;

@@ -153,6 +153,7 @@ struct ZpFixedCol { int lp; size_t first_entry_word, n_entries; bool has_pub; };
 bool zpi_program_fixed_table(const uint64_t *h_program, size_t program_words, std::vector<ZpFixedCol> *cols);
 struct zp_comm;
 zp_ctx *zpi_comm_ctx(const zp_comm *comm);      // the ctx a communicator was created on (csrc/comm.hip)
+int32_t zpi_comm_fail(zp_comm *comm, int32_t rc);   // rc != ZP_OK: kill the communicator (no peer waits for this rank); returns rc
 int32_t zpi_twiddle_rows(zp_ctx *ctx, u64 *d_rows, int logn_row, int W, u64 row0, int logn_total, bool inverse);
 int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn, int logb, int W, u64 shift);
 int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, bool inverse,

@@ -1229,16 +1229,18 @@ extern "C" int32_t zp_stark_prove_sharded(zp_comm *comm, const char *air_name, c
     zp_ctx *ctx = zpi_comm_ctx(comm);
     if (out_json) *out_json = nullptr;
     if (out_len) *out_len = 0;
+    // Whatever stops this rank -- a failed allocation, a HIP error, an exception -- its peers are inside the same call, heading for
+    // the next collective: zpi_comm_fail takes the communicator down so that they return ZP_ERR_COMM instead of waiting for ever.
     try {
-        return prove_sharded_impl(comm, ctx, air_name, h_program, program_words, d_trace_local, trace_words, h_pubs, n_pubs, logn, logb, fri_logf,
-                                  fri_final_log, n_queries, pow_bits, out_json, out_len);
+        return zpi_comm_fail(comm, prove_sharded_impl(comm, ctx, air_name, h_program, program_words, d_trace_local, trace_words, h_pubs, n_pubs, logn, logb,
+                                                      fri_logf, fri_final_log, n_queries, pow_bits, out_json, out_len));
     } catch (const std::bad_alloc &) {
         try { ctx->err = "out of host memory while building the proof"; } catch (...) {}
-        return ZP_ERR_NOMEM;
+        return zpi_comm_fail(comm, ZP_ERR_NOMEM);
     } catch (const std::exception &e) {
         try { ctx->err = std::string("internal error: ") + e.what(); } catch (...) {}
-        return ZP_ERR_INTERNAL;
+        return zpi_comm_fail(comm, ZP_ERR_INTERNAL);
     } catch (...) {
-        return ZP_ERR_INTERNAL;
+        return zpi_comm_fail(comm, ZP_ERR_INTERNAL);
     }
 }

@@ -106,6 +106,8 @@ SIGNATURES = {
     "zp_comm_destroy": (C.c_int32, [_vp]),
     "zp_comm_rank": (C.c_int32, [_vp]),
     "zp_comm_world": (C.c_int32, [_vp]),
+    "zp_comm_abort": (C.c_int32, [_vp]),
+    "zp_comm_set_timeout_ms": (C.c_int32, [_vp, C.c_int32]),
     "zp_comm_all_to_all": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
     "zp_comm_all_gather": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
     "zp_comm_broadcast": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32]),
@@ -304,6 +306,13 @@ class Comm:
         if self.h:
             self.prover.lib.zp_comm_destroy(self.h)
             self.h = None
+
+    def abort(self):
+        """zp_comm_abort: this rank gives up; no peer is left waiting for it (they return ZP_ERR_COMM)"""
+        self.prover._chk(self.prover.lib.zp_comm_abort(self.h))
+
+    def set_timeout_ms(self, ms):
+        self.prover._chk(self.prover.lib.zp_comm_set_timeout_ms(self.h, int(ms)))
 
     def all_to_all(self, d_send, d_recv, words_per_peer):
         self.prover._chk(self.prover.lib.zp_comm_all_to_all(self.h, _ptr(d_send), _ptr(d_recv), words_per_peer))

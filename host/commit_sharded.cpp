@@ -2,11 +2,12 @@
 // prover service does when it spreads ONE chunk proof's commitment stage over G GPUs (src/prover/provider.rs:358-377 sends one
 // GenChunkProof; BASELINE.json configs[3] shards its columns 8-way).  One process per GPU:
 //
-//   commit_sharded <trace.bin> <logn> <logb> <W> <rank> <world> <id-file>
+//   commit_sharded <trace.bin> <logn> <logb> <W> <rank> <world> <id-file> [run-nonce]
 //
 // trace.bin: u64[W][2^logn] column-major (canonical).  Rank r owns columns [r W/G, (r+1) W/G): it extends them (zp_lde, no
 // exchange), then zp_merkle_commit_sharded packs, runs the one RCCL all-to-all, hashes its M/G rows, all-gathers the sub-roots
-// and finishes the tree.  Rank 0 writes the 128-byte RCCL id to <id-file> (the others wait for it); every rank prints the
+// and finishes the tree.  Rank 0 publishes the 128-byte RCCL id in <id-file> (host/rendezvous.hpp: atomic, tagged with the run's
+// nonce, removed once the communicator stands; the others wait for it); every rank prints the
 // global root -- equal to the root a single GPU commits over all W columns.
 #include <chrono>
 #include <cstdint>
@@ -17,6 +18,7 @@
 #include <vector>
 
 #include "../include/zeth_prover.h"
+#include "rendezvous.hpp"
 
 #define CHECK(call)                                                                                   \
     do {                                                                                              \
@@ -25,7 +27,7 @@
     } while (0)
 
 int main(int argc, char **argv) {
-    if (argc < 8) { fprintf(stderr, "usage: commit_sharded <trace.bin> <logn> <logb> <W> <rank> <world> <id-file>\n"); return 2; }
+    if (argc < 8) { fprintf(stderr, "usage: commit_sharded <trace.bin> <logn> <logb> <W> <rank> <world> <id-file> [run-nonce]\n"); return 2; }
     const int logn = atoi(argv[2]), logb = atoi(argv[3]), W = atoi(argv[4]), rank = atoi(argv[5]), world = atoi(argv[6]);
     if (logn < 1 || logn > 28 || logb < 0 || logb > 4 || W < 1 || world < 1 || rank < 0 || rank >= world || W % world) {
         fprintf(stderr, "bad arguments (W must be a multiple of world)\n");
@@ -44,23 +46,17 @@ int main(int argc, char **argv) {
     zp_ctx *ctx = nullptr;
     CHECK(zp_create(&ctx, rank));           // one process per GPU: rank r drives device r
     uint8_t id[128];
+    const uint64_t nonce = argc > 8 ? strtoull(argv[8], nullptr, 0) : 0;
     if (rank == 0) {
         CHECK(zp_comm_unique_id(id));
-        FILE *f = fopen(argv[7], "wb");
-        if (!f || fwrite(id, 1, 128, f) != 128) { fprintf(stderr, "cannot write %s\n", argv[7]); return 2; }
-        fclose(f);
-    } else {
-        bool got = false;
-        for (int tries = 0; tries < 600 && !got; tries++) {
-            FILE *f = fopen(argv[7], "rb");
-            got = f && fread(id, 1, 128, f) == 128;
-            if (f) fclose(f);
-            if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
-        }
-        if (!got) { fprintf(stderr, "no RCCL id in %s after 60 s\n", argv[7]); return 2; }
+        if (!zp_rendezvous::publish(argv[7], nonce, id)) { fprintf(stderr, "cannot write %s\n", argv[7]); return 2; }
+    } else if (!zp_rendezvous::await(argv[7], nonce, id)) {
+        fprintf(stderr, "no RCCL id of this run in %s after 60 s\n", argv[7]);
+        return 2;
     }
     zp_comm *comm = nullptr;
     CHECK(zp_comm_create(ctx, rank, world, id, &comm));
+    if (rank == 0) zp_rendezvous::retire(argv[7]);
     void *d_in = nullptr, *d_ext = nullptr, *d_tree = nullptr;
     CHECK(zp_dev_alloc(ctx, Wl * N * 8, &d_in));
     CHECK(zp_dev_alloc(ctx, Wl * M * 8, &d_ext));

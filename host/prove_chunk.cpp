@@ -4,9 +4,9 @@
 // Nothing but include/zeth_prover.h is used -- no Python, no torch, no compiler at run time (the AIR is a data blob).
 //
 // usage: prove_chunk <program.bin> <trace.bin> <publics.bin> <logn> <logb> <fri_logf> <fri_final_log> <n_queries> <pow_bits> <out.json> [air_name
-//                     [rank world id-file]]
+//                     [rank world id-file [run-nonce]]]
 //   with rank / world / id-file: ONE proof over `world` GPUs, one process per GPU (zp_stark_prove_sharded on an RCCL communicator; rank 0
-//   writes the 128-byte RCCL id to <id-file>, the others wait for it).  Rank r reads only ITS W/world columns of trace.bin and drives GPU r;
+//   publishes the 128-byte RCCL id in <id-file>, the others wait for the record that carries this run's nonce: host/rendezvous.hpp).  Rank r reads only ITS W/world columns of trace.bin and drives GPU r;
 //   every rank obtains the same proof text (rank 0 writes <out.json>), byte for byte the single-GPU text.
 //   program.bin : the constraint program blob (u64 words, layout in the header)
 //   trace.bin   : u64[W][2^logn] column-major, canonical values
@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../include/zeth_prover.h"
+#include "rendezvous.hpp"
 
 static std::vector<uint64_t> read_words(const char *path) {
     FILE *f = fopen(path, "rb");
@@ -52,6 +53,7 @@ int main(int argc, char **argv) {
     // the shapes must agree BEFORE anything reaches the GPU: W comes from the program header (word 1), the number of public
     // inputs from word 4; the library checks trace_words again (ZP_ERR_ARG otherwise)
     if (program.size() < 12) { fprintf(stderr, "%s: shorter than a constraint-program header\n", argv[1]); return 2; }
+    if (program[1] < 1 || program[1] >= 4096) { fprintf(stderr, "%s: width %llu out of range\n", argv[1], (unsigned long long)program[1]); return 2; }   // before it is shifted
     if (logn < 1 || logn > 30 || trace.size() != (size_t)(program[1] << logn)) {
         fprintf(stderr, "%s: %zu words, the program needs W * 2^logn = %llu * 2^%d\n", argv[2], trace.size(), (unsigned long long)program[1], logn);
         return 2;
@@ -72,22 +74,16 @@ int main(int argc, char **argv) {
     zp_comm *comm = nullptr;
     if (sharded) {
         uint8_t id[128];
+        const uint64_t nonce = argc > 15 ? strtoull(argv[15], nullptr, 0) : 0;
         if (rank == 0) {
             CHECK(zp_comm_unique_id(id));
-            FILE *f = fopen(argv[14], "wb");
-            if (!f || fwrite(id, 1, 128, f) != 128) { fprintf(stderr, "cannot write %s\n", argv[14]); return 2; }
-            fclose(f);
-        } else {
-            bool got = false;
-            for (int tries = 0; tries < 600 && !got; tries++) {
-                FILE *f = fopen(argv[14], "rb");
-                got = f && fread(id, 1, 128, f) == 128;
-                if (f) fclose(f);
-                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
-            }
-            if (!got) { fprintf(stderr, "no RCCL id in %s after 60 s\n", argv[14]); return 2; }
+            if (!zp_rendezvous::publish(argv[14], nonce, id)) { fprintf(stderr, "cannot write %s\n", argv[14]); return 2; }
+        } else if (!zp_rendezvous::await(argv[14], nonce, id)) {
+            fprintf(stderr, "no RCCL id of this run in %s after 60 s\n", argv[14]);
+            return 2;
         }
         CHECK(zp_comm_create(ctx, rank, world, id, &comm));
+        if (rank == 0) zp_rendezvous::retire(argv[14]);
         CHECK(zp_stark_prove_sharded(comm, air_name, program.data(), program.size(), (const uint64_t *)d_trace, words, pubs.data(), (int32_t)pubs.size(), logn,
                                      logb, fri_logf, fri_final_log, n_queries, pow_bits, &json, &len));
     } else {

@@ -41,7 +41,8 @@ enum {
     ZP_ERR_HIP = -2,     /* HIP runtime error (text in zp_last_error) */
     ZP_ERR_NOMEM = -3,   /* device allocation failed */
     ZP_ERR_UNSUPPORTED = -4,
-    ZP_ERR_INTERNAL = -5 /* an internal failure that is not the caller's (never an exception: nothing unwinds across this ABI) */
+    ZP_ERR_INTERNAL = -5, /* an internal failure that is not the caller's (never an exception: nothing unwinds across this ABI) */
+    ZP_ERR_COMM = -6      /* the communicator is dead: a peer rank failed, aborted or did not reach a collective within the timeout */
 };
 
 /* kinds for zp_set_constants */
@@ -329,7 +330,12 @@ int32_t zp_synth_g1_points(uint64_t start, size_t n, uint32_t *h_points, int32_t
  *                                 every rank receives the same proof text, byte for byte what zp_stark_prove writes for the whole
  *                                 trace on one GPU.  Column-sharded: LDE, out-of-domain evaluations; row-sharded: the three
  *                                 commitments, the constraint quotient (with a blow-up halo), the DEEP quotient; replicated: the
- *                                 stage-2 columns, FRI.  Goldilocks-hash mode.  Collective: every rank must call it.                */
+ *                                 stage-2 columns, FRI.  Goldilocks-hash mode.  Collective: every rank must call it.
+ * FAILURE: no rank waits for ever.  A rank whose step fails inside a collective or a sharded entry point takes the communicator down
+ * before it returns its own error; its peers return ZP_ERR_COMM (in-process group: at once, woken from the barrier; RCCL: when their
+ * watchdog expires and aborts the communicator, ncclCommAbort).  A host whose rank fails BETWEEN collectives calls zp_comm_abort.  A
+ * dead communicator answers every later collective with ZP_ERR_COMM; destroy it and build a new one.  zp_comm_set_timeout_ms: how long
+ * a collective waits for its peers (default 120 000; RCCL: 0 = asynchronous collectives without a watchdog).                         */
 typedef struct zp_comm zp_comm;
 typedef struct zp_comm_group zp_comm_group;
 int32_t zp_comm_unique_id(uint8_t *out128);
@@ -337,6 +343,8 @@ int32_t zp_comm_create(zp_ctx *ctx, int32_t rank, int32_t world, const uint8_t *
 int32_t zp_comm_destroy(zp_comm *comm);
 int32_t zp_comm_rank(const zp_comm *comm);
 int32_t zp_comm_world(const zp_comm *comm);
+int32_t zp_comm_abort(zp_comm *comm);
+int32_t zp_comm_set_timeout_ms(zp_comm *comm, int32_t ms);
 int32_t zp_comm_all_to_all(zp_comm *comm, const uint64_t *d_send, uint64_t *d_recv, size_t words_per_peer);
 int32_t zp_comm_all_gather(zp_comm *comm, const uint64_t *d_send, uint64_t *d_recv, size_t words);
 int32_t zp_comm_broadcast(zp_comm *comm, uint64_t *d_buf, size_t words, int32_t root);

@@ -60,10 +60,14 @@ def test_compiled_host_shards_one_commitment_over_the_visible_gpus(prover, table
     with tempfile.TemporaryDirectory() as td:
         x.tofile(os.path.join(td, "trace.bin"))
         idf = os.path.join(td, "rccl.id")
+        with open(idf, "wb") as f:      # a stale id file of an earlier run (another nonce) must not be taken for this run's (host/rendezvous.hpp)
+            f.write(b"ZPRCCLID" + (1).to_bytes(8, "little") + bytes(128))
+        nonce = str(0x5EED0000 + os.getpid())
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs = [subprocess.Popen([exe, os.path.join(td, "trace.bin"), str(logn), str(logb), str(W), str(r), str(world), idf], env=env,
+        procs = [subprocess.Popen([exe, os.path.join(td, "trace.bin"), str(logn), str(logb), str(W), str(r), str(world), idf, nonce], env=env,
                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
         outs = [p.communicate(timeout=300) for p in procs]
+        assert not os.path.exists(idf), "rank 0 retires its id record once the communicator stands"
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, so + se
         words = so.split("root ")[1].split()[:4]

@@ -148,9 +148,10 @@ def test_compiled_host_shards_one_proof_over_the_visible_gpus(tmp_path, prover, 
     np.ascontiguousarray(tr).tofile(tmp_path / "trace.bin")
     np.asarray(pub, dtype=np.uint64).tofile(tmp_path / "publics.bin")
     out, idf = tmp_path / "proof.json", tmp_path / "rccl.id"
+    idf.write_bytes(bytes(128))          # a stale id file in the old bare format: ignored (host/rendezvous.hpp)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([exe, str(tmp_path / "program.bin"), str(tmp_path / "trace.bin"), str(tmp_path / "publics.bin"), "10", "1", "3", "3", "12",
-                               "6", str(out), air.name, str(r), str(world), str(idf)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                               "6", str(out), air.name, str(r), str(world), str(idf), str(0xC0DE0000 + os.getpid())], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(world)]
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (so, se) in zip(procs, outs):
