@@ -532,7 +532,7 @@ int32_t zp_ntt_plan_json(zp_ctx *ctx, int32_t logn, char *buf, size_t buflen) {
              std::to_string(p.A2) + ", " + std::to_string(p.A3) + "], \"tile\": " + std::to_string(p.L == 8 ? (1 << ctx->tune_logt) : (1 << p.logT)) + "}";
     }
     s += "], \"first_pass_table\": ";   // the transposing pass multiplies by the full precomputed table (MODE 3) instead of per-lane chains
-    s += (pl->npass >= 1 && logn > 12 && logn <= ctx->tune_ntt_tw1 && logn <= 28 && pl->pass[0].A3 == 0 && pl->pass[0].L >= 7) ? "true" : "false";
+    s += (pl->npass >= 1 && logn > 12 && !pl->tw1_unavailable && logn <= ctx->tune_ntt_tw1 && logn <= 28 && pl->pass[0].A3 == 0 && pl->pass[0].L >= 7) ? "true" : "false";
     s += ", \"small_kernel\": ";
     s += (logn <= 12) ? "true" : "false";
     s += "}";

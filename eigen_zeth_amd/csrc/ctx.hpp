@@ -27,6 +27,7 @@ struct NttPlan {
     u64 *d_twh = nullptr;     // 2^(logn-lb) entries
     u64 *d_tws = nullptr;     // w_4096^e (direction matched), 4096 entries
     u64 *d_tw1 = nullptr;     // first (transposing) pass: w^(u k) at [u * R + k], all 2^logn of them (null: per-lane chains)
+    bool tw1_unavailable = false;   // its allocation failed once: the per-lane chain kernel serves this plan
     u64 w16[8];               // w_16^i (direction matched)
     u64 ninv = 1;
     int j0inv = 0;            // w_16 = (2^12)^j0 ; j0inv = j0^-1 mod 16 (0: not on the power-of-two path)

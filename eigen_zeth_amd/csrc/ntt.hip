@@ -820,11 +820,18 @@ int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, b
     const int m = pl->npass;
     // the first pass's full table (8 bytes per element of ONE column, shared by all columns and all later calls of this size):
     // built at the first use of a plan by radix-2^7 / 2^8 two-round passes below 2^29 rows
-    if (!pl->d_tw1 && logn <= ctx->tune_ntt_tw1 && logn <= 28 && pl->pass[0].A3 == 0 && pl->pass[0].L >= 7) {
-        ZP_HIP(ctx, hipMalloc((void **)&pl->d_tw1, N * sizeof(u64)));
-        hipLaunchKernelGGL(tw1_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, pl->d_tw1, logn, pl->pass[0].L,
-                           pl->d_twl, pl->d_twh, pl->lb);
-        ZP_HIP(ctx, hipGetLastError());
+    if (!pl->d_tw1 && !pl->tw1_unavailable && logn <= ctx->tune_ntt_tw1 && logn <= 28 && pl->pass[0].A3 == 0 && pl->pass[0].L >= 7) {
+        if (hipMalloc((void **)&pl->d_tw1, N * sizeof(u64)) != hipSuccess) {
+            // the table is an optimisation (8 bytes per row, per plan, per ctx): without it the first pass multiplies by per-lane
+            // twiddle chains (MODE 1), same results.  Clear the sticky error and do not try again for this plan.
+            (void)hipGetLastError();
+            pl->d_tw1 = nullptr;
+            pl->tw1_unavailable = true;
+        } else {
+            hipLaunchKernelGGL(tw1_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, pl->d_tw1, logn, pl->pass[0].L,
+                               pl->d_twl, pl->d_twh, pl->lb);
+            ZP_HIP(ctx, hipGetLastError());
+        }
     }
     u64 *s0 = nullptr, *s1 = nullptr;
     if (m >= 2) ZP_TRY(zpi_scratch(ctx, 0, (size_t)wc << logn, &s0));

@@ -101,6 +101,8 @@ SIGNATURES = {
     "zp_domain_tables": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int32)]),
     "zp_synth_trace": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p]),
     "zp_synth_trace_bound": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, C.c_int32, _u64p, _u64p]),
+    "zp_verifier_arith_host": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
+    "zp_verifier_arith_trace": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "zp_comm_unique_id": (C.c_int32, [_vp]),
     "zp_comm_create": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, C.POINTER(_vp)]),
     "zp_comm_destroy": (C.c_int32, [_vp]),
@@ -242,6 +244,38 @@ class DeviceBuffer:
 def device_count():
     """visible HIP devices, through the library (no torch: a process that loads the system RCCL must not import torch's copy later)"""
     return int(load_library().zp_device_count())
+
+
+def _arith_args(desc, a):
+    """contiguous arrays of the arithmetic-witness inputs (stark/verifier_air.py: build_witness -> arith_in)"""
+    d = np.ascontiguousarray(np.asarray(desc, dtype=np.uint64))
+    vals = np.ascontiguousarray(a["vals"], dtype=np.uint64)
+    index = np.ascontiguousarray(a["index"], dtype=np.uint64)
+    dbit = np.ascontiguousarray(a["dbit"], dtype=np.uint64)
+    blk_op = np.ascontiguousarray(a["blk_op"], dtype=np.int64)
+    aps = np.ascontiguousarray(np.asarray(a["aps"], dtype=np.uint64))
+    fin = np.ascontiguousarray(a["fin"], dtype=np.uint64)
+    assert vals.shape[1] == int(d[7]) and vals.shape[0] == int(d[8]) and len(dbit) == int(d[1]) * int(d[2]) == len(blk_op)
+    assert aps.shape == (int(d[4]), int(d[9])) and fin.size == int(d[2]) * int(d[3]) * int(d[4]) * 3
+    return d, vals, index, dbit, blk_op, aps, fin
+
+
+def _arith_error(rc):
+    if rc in (-10, -11):
+        return ValueError("the opened values of an inner proof are inconsistent (%s): no accepting witness"
+                          % ("a FRI layer does not hold the value the layer before it claims" if rc == -10 else "the last fold does not give its final layer"))
+    return ZpError(rc, "zp_verifier_arith: malformed descriptor or inputs")
+
+
+def verifier_arith_host(desc, a, threads=0):
+    """zp_verifier_arith_host: the 21 arithmetic columns of the verifier trace as a host array u64[21][N] -- host code, no GPU needed"""
+    d, vals, index, dbit, blk_op, aps, fin = _arith_args(desc, a)
+    out = np.empty((21, 32 * len(dbit)), dtype=np.uint64)
+    rc = load_library().zp_verifier_arith_host(d.ctypes.data, d.size, vals.ctypes.data, index.ctypes.data, dbit.ctypes.data, blk_op.ctypes.data,
+                                               aps.ctypes.data, fin.ctypes.data, out.ctypes.data, threads)
+    if rc != 0:
+        raise _arith_error(rc)
+    return out
 
 
 def comm_unique_id():
@@ -462,6 +496,15 @@ class Prover:
 
     def lde(self, d_in, d_out, logn, logb, W, shift=0, d_coef=None):
         self._chk(self.lib.zp_lde(self.ctx, _ptr(d_in), _ptr(d_out), _ptr(d_coef), logn, logb, W, shift))
+
+    def verifier_arith_trace(self, desc, a, d_out, threads=0):
+        """zp_verifier_arith_trace: the 21 arithmetic columns of the verifier trace written in HBM at d_out (u64[21][N])"""
+        d, vals, index, dbit, blk_op, aps, fin = _arith_args(desc, a)
+        rc = self.lib.zp_verifier_arith_trace(self.ctx, d.ctypes.data, d.size, vals.ctypes.data, index.ctypes.data, dbit.ctypes.data, blk_op.ctypes.data,
+                                              aps.ctypes.data, fin.ctypes.data, _ptr(d_out), threads)
+        if rc in (-10, -11):
+            raise _arith_error(rc)
+        self._chk(rc)
 
     def poseidon_perm(self, d_states, count):
         self._chk(self.lib.zp_poseidon_perm(self.ctx, _ptr(d_states), count))

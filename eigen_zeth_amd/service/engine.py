@@ -334,14 +334,10 @@ class Engine:
 
     @staticmethod
     def _header(proof):
-        """an inner proof without its authentication paths: everything a verifier needs besides hashing -- transcript data, and per
-        query the index and the opened values of every tree (the public inputs of the Merkle-verifier STARK that replaces the paths)"""
-        h = {k: v for k, v in proof.items() if k != "queries"}
-        strip = lambda o: {k: v for k, v in o.items() if k != "path"}
-        h["queries"] = [{"index": q["index"], "trace": strip(q["trace"]), "quotient": strip(q["quotient"]),
-                         **({"stage2": strip(q["stage2"])} if "stage2" in q else {}),
-                         "fri": [strip(f) for f in q["fri"]]} for q in proof["queries"]]
-        return h
+        """an inner proof as an aggregated proof carries it: everything a verifier reads WITHOUT an opening -- parameters, publics, roots,
+        out-of-domain evaluations, FRI roots, final layer, grinding nonce.  The query openings (values and paths) stay with the prover: the
+        verifier-AIR STARK vouches for everything that happens at the queries (stark/verifier_air.py)."""
+        return {k: v for k, v in proof.items() if k != "queries"}
 
     def _prove_merkle_verifier(self, proofs, params_of, be, timings, inner_air, prepared=None):
         """STARK over the verifier AIR (stark/verifier_air.py) for inner proof objects `proofs` of one shape, proofs of `inner_air`"""
@@ -379,14 +375,14 @@ class Engine:
                 texts = known                      # the whole batch, not only its two ends
             parsed = [self._parsed_chunk_proof(t) for t in texts]
             wholes, prepared = [a for a, _ in parsed], [b for _, b in parsed]
-            agg_params = lambda sh: VA.aggregation_params(sh, self.cfg.agg_queries, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.agg_pow_bits)
+            agg_params = self._agg_params
             kinds = {w.get("kind", "chunk") for w in wholes}
             if kinds == {"aggregated"}:
                 # recursion one level up: the inner proofs are the aggregation STARKs of the two aggregated proofs (same shape: they
                 # came out of this prover under its parameters); what they aggregated travels along as "children"
                 if len({json.dumps(w.get("shape"), sort_keys=True) for w in wholes}) != 1:
                     raise ValueError("aggregated proofs of different shapes cannot be folded together")
-                below = VA.Shape.from_dict(wholes[0]["shape"])
+                below = self._own_shape(wholes[0])          # before anything is sized by it
                 inner_air = VA.verifier_air(below, *self._tables(self.be))
                 proofs = [w["stark"] for w in wholes]
                 for w, pr in zip(wholes, proofs):
@@ -415,16 +411,58 @@ class Engine:
             for k, v in tm.items():
                 self.metrics.record_stage(k, v)
         head = json.dumps({"kind": "aggregated", "version": 1, "batch_id": batch_id,
-                           "statement": "for every query slot, inner proof and committed tree the public opened values hash, as a leaf and up "
-                                        "a path along the bits of the public index, to the public root; the Fiat-Shamir sponge of every inner "
-                                        "proof absorbs the public blocks and yields the public rates, and its grinding hash the public digest "
-                                        "(all hashing of the verifier; its arithmetic -- out-of-domain identity, DEEP, FRI folds, challenges "
-                                        "read off the public rates -- is checked natively on 'inner')",
+                           "statement": "for every query slot, inner proof and committed tree there are values that hash, as a leaf and up a path "
+                                        "along the bits of the public index, to the public root; they give the DEEP quotient at the query point, "
+                                        "every FRI layer's opened coset interpolates the value the layer before claims and folds to the next, the "
+                                        "last fold is the public final-layer value; the Fiat-Shamir sponge of every inner proof absorbs the public "
+                                        "blocks and yields the public rates, its grinding hash the public digest (what is left to the checker per "
+                                        "inner proof: the out-of-domain identity, the final layer's degree, reading the transcript -- on 'inner', "
+                                        "which holds no openings)",
                            "shape": shape.to_dict(), "level": level,
                            "slots": shape.n_slots(), "verifier_air_digest": vair.digest(),
                            "inner": [self._header(pr) for pr in proofs],
                            **({"children": children} if children else {})}, separators=(",", ":"))
         return head[:-1] + ',"stark":' + text + "}"
+
+    def _agg_params(self, sh):
+        return VA.aggregation_params(sh, self.cfg.agg_queries, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.agg_pow_bits)
+
+    def _own_shape(self, node, depth=0):
+        """The shape an aggregated proof names is CLIENT TEXT, and a verifier AIR is sized by it (schedule, transcript script and
+        fixed-column entry lists grow with queries x proofs x widths): it is accepted only when it is a shape THIS prover makes.
+        Level 1: inner proofs are chunk proofs of the configured AIR under the engine's STARK parameters (any trace length, 1..64
+        proofs).  Level n + 1: inner proofs are aggregation STARKs over the shape of the level below (named by "children"), under the
+        engine's aggregation parameters.  Returns the Shape; ValueError otherwise -- nothing is built before this has passed."""
+        if not isinstance(node, dict) or not isinstance(node.get("shape"), dict) or depth > 8:
+            raise ValueError("aggregated proof names no shape")
+        d = node["shape"]
+        if sorted(d) != sorted(VA.Shape.KEY_NAMES) or any(not isinstance(v, int) or isinstance(v, bool) for v in d.values()):
+            raise ValueError("malformed shape")
+        if not 1 <= d["n_proofs"] <= 64 or not 1 <= d["logn"] <= 28:
+            raise ValueError("shape out of range")
+        kids = node.get("children")
+        if not kids:
+            air = AIR.get_air(self.cfg.air)
+            sp = self.stark_params(d["logn"]).to_dict()
+            want = dict(d, logb=sp["logb"], W=air.width, W2=air.width2, Wq=3 * AIR.quotient_chunks(air), n_queries=sp["n_queries"],
+                        fri_logf=sp["fri_logf"], fri_final_log=sp["fri_final_log"], n_pub_inner=air.n_pub, pow_bits=sp["pow_bits"],
+                        root32=int(self.be.root32), shift=int(self.be.shift))
+        else:
+            if not isinstance(kids, list) or len(kids) != d["n_proofs"] or d["n_proofs"] > 2:
+                raise ValueError("children do not match the shape")
+            below = self._own_shape(kids[0], depth + 1)
+            if any(not isinstance(k, dict) or k.get("shape") != kids[0]["shape"] for k in kids):
+                raise ValueError("children of different shapes")
+            ap = self._agg_params(below).to_dict()
+            want = dict(d, logn=ap["logn"], logb=ap["logb"], W=VA.WIDTH, W2=0, Wq=3 * VA.Q_PIECES, n_queries=ap["n_queries"], fri_logf=ap["fri_logf"],
+                        fri_final_log=ap["fri_final_log"], n_pub_inner=below.n_pub(), pow_bits=ap["pow_bits"], root32=int(self.be.root32),
+                        shift=int(self.be.shift))
+        if d != want:
+            raise ValueError("aggregated proof was not made under this prover's parameters (shape)")
+        shape = VA.Shape.from_dict(d)
+        if shape.logn_trace() > 26:
+            raise ValueError("aggregation of this size is not served")
+        return shape
 
     # ---- GenFinalProof
     def groth16_keys(self):
@@ -457,7 +495,12 @@ class Engine:
             outer = agg["stark"]
             if agg.get("kind") != "aggregated" or "queries" not in outer:
                 raise KeyError("kind")
-            agg_air = VA.verifier_air(VA.Shape.from_dict(agg["shape"]), *self._tables(self.be_bn128))   # the statement of agg["stark"]
+            agg_shape = self._own_shape(agg)                # client text: only a shape this prover makes is ever built
+            if outer.get("params") != self._agg_params(agg_shape).to_dict():
+                raise ValueError("aggregated proof was not made under this prover's aggregation parameters")
+            agg_air = VA.verifier_air(agg_shape, *self._tables(self.be_bn128))   # the statement of agg["stark"]
+            if agg.get("verifier_air_digest") != agg_air.digest() or outer.get("air_digest") != agg_air.digest():
+                raise ValueError("aggregated proof is over another verifier AIR")
         except (json.JSONDecodeError, TypeError, KeyError, AssertionError, ValueError) as e:
             raise ValueError("recursive proof is not an aggregated proof of this prover (%s)" % e)
         tmf = {}

@@ -49,10 +49,15 @@ class ProverService:
                 yield resp
                 continue
             token = object()                    # request ids are the client's: two streams may replay the same one
+            bkey = _batch_of(req, kind)
             with self._stat:
                 self._in_flight.add(token)
                 self.cur_start = int(time.time())
-                lock = self._batch_locks.setdefault(_batch_of(req, kind), threading.Lock())
+                # [lock, users]: a handler counts itself in BEFORE it leaves _stat, so a lock somebody is about to take is never
+                # pruned (a fresh lock for the same batch would let two handlers run load -> compute -> save side by side)
+                ent = self._batch_locks.setdefault(bkey, [threading.Lock(), 0])
+                ent[1] += 1
+                lock = ent[0]
             lock.acquire()
             try:
                 if kind == "gen_batch_proof":
@@ -75,8 +80,9 @@ class ProverService:
                 with self._stat:
                     self._in_flight.discard(token)
                     self.last_id, self.last_end = req.id, int(time.time())
-                    if len(self._batch_locks) > 256:     # locks of finished batches (never one that is held or awaited)
-                        for k in [k for k, l in self._batch_locks.items() if l is not lock and not l.locked()][:128]:
+                    ent[1] -= 1
+                    if len(self._batch_locks) > 256:     # locks of finished batches: nobody holds or awaits them (users == 0)
+                        for k in [k for k, e in self._batch_locks.items() if e[1] == 0][:128]:
                             del self._batch_locks[k]
             if self.metrics is not None:
                 self.metrics.count_request(*_outcome(resp))

@@ -121,24 +121,44 @@ class HipBackend:
     def poseidon_sponge_caps(self, state, blocks, extra):
         return self.p.poseidon_sponge_caps(state, blocks, extra)
 
-    def verifier_trace_device(self, inputs, dbit, idxv):
-        """the 26-column trace of the Merkle-verifier AIR (stark/verifier_air.py) assembled IN HBM: zp_poseidon_trace writes the 24
-        state / cube columns of every permutation block, the direction-bit and index columns (one value per block, repeated over
-        its 32 rows) are the only host data.  Returns a device buffer shaped [26][32 * blocks] that commit_trace / prove_native
-        take as they take an uploaded witness (a 2^20-row trace is 218 MB: it never crosses PCIe)."""
+    def verifier_trace_device(self, inputs, dbit, idxv, arith):
+        """the trace of the verifier AIR (stark/verifier_air.py) assembled IN HBM: zp_poseidon_trace writes the 24 state / cube columns of
+        every permutation block; the direction-bit and index columns (one value per block, repeated over its 32 rows) and the arithmetic
+        columns (`arith`: host array u64[WIDTH - 26][N], or a device buffer of that shape from verifier_arith_columns) follow.
+        Returns a device buffer shaped [WIDTH][32 * blocks] that commit_trace / prove_native take as they take an uploaded witness."""
+        from . import verifier_air as VA
         a = np.ascontiguousarray(np.asarray(inputs, dtype=np.uint64))
         B = a.shape[0]
         N = 32 * B
         d_in = self.p.upload(a)
-        d_tr = self.p.alloc(26 * N)
+        d_tr = self.p.alloc(VA.WIDTH * N)
         self.p.poseidon_trace(d_in, B, d_tr, d_tr.offset(12 * N), N)
         tail = np.empty((2, N), dtype=np.uint64)
         tail[0] = np.repeat(np.asarray(dbit, dtype=np.uint64), 32)
         tail[1] = np.repeat(np.asarray(idxv, dtype=np.uint64), 32)
         self.p.h2d(d_tr.offset(24 * N), tail)
+        if isinstance(arith, native.DeviceBuffer):
+            self.p.d2d(d_tr.offset(VA.HR0 * N), arith, (VA.WIDTH - VA.HR0) * N * 8)
+            arith.free()
+        else:
+            assert tuple(arith.shape) == (VA.WIDTH - VA.HR0, N)
+            self.p.h2d(d_tr.offset(VA.HR0 * N), arith)
         d_in.free()
-        d_tr.shape = (26, N)
+        d_tr.shape = (VA.WIDTH, N)
         return d_tr
+
+    def verifier_arith_columns(self, shape, arith_in):
+        """the 21 arithmetic columns of the verifier trace, built by the library (host walk + expansion kernel: zp_verifier_arith_trace) into a
+        device buffer u64[21][N] that verifier_trace_device splices behind the hashing columns"""
+        from . import verifier_air as VA
+        N = 32 * len(arith_in["dbit"])
+        d = self.p.alloc((VA.WIDTH - VA.HR0) * N)
+        try:
+            self.p.verifier_arith_trace(VA.arith_descriptor(shape), arith_in, d)
+        except BaseException:
+            d.free()
+            raise
+        return d
 
     def prove_native(self, air, trace, pubs, params):
         """the whole chunk STARK through zp_stark_prove (one C-ABI call, orchestration in the library's host C++): proof TEXT,

@@ -1,4 +1,8 @@
-"""The STARK-verifier AIR, stage A: the Merkle part of verifying chunk proofs, as constraints.
+"""The STARK-verifier AIR: verifying chunk proofs at their queries -- Merkle paths, transcripts AND the field arithmetic -- as constraints.
+
+(Round 4: the opened values are PRIVATE.  The DEEP quotient, every FRI fold and the evaluation points of a query are constraints over the
+values the permutation blocks hash; see "Arithmetic" below.  The paragraphs up to there describe the hashing part, which is unchanged except
+that the opened values are no longer public inputs.)
 
 Serves GenAggregatedProof (proto/prover/v1/prover.proto:115-126; client src/prover/provider.rs:422-451) and the final STARK
 of GenFinalProof (prover.proto:130-148; provider.rs:472-503): "aggregate(p1, p2)" is a STARK whose witness is the
@@ -7,17 +11,16 @@ opened rows of the trace / stage-2 / quotient / FRI-layer commitments hash up to
 public inputs are those roots and the query indices.  The reference holds no prover arithmetic, so the
 construction is this repo's own (parity unpinned); it follows the public recursive-STARK recipe.
 
-What the AIR proves (public inputs: per inner proof and tree the root; per query slot / proof / tree the leaf index and the
-OPENED VALUES):
-    for every query slot, inner proof and committed tree there is an authentication path such that linear_hash(the PUBLIC
-    leaf values) hashed up the path, with the direction bits of the PUBLIC index, equals the PUBLIC root.
-That is ALL the hashing of a verifier.  What is left of verifying an inner proof is arithmetic on public data -- replaying the
-Fiat-Shamir transcript (which yields the indices), the out-of-domain constraint identity, the DEEP quotient and every FRI fold
-at every query on the opened values, the final layer -- and the checker of an aggregated proof does exactly that natively
-(oracle/aggregate_verify.py: stark_verify.verify(trust_openings=True) on the inner proofs WITHOUT their paths) and requires
-the outer proof's public inputs to be those roots, indices and values.  So an accepted aggregated proof means both inner proofs
-verify: the Merkle work in the circuit, the field arithmetic outside it (putting that arithmetic into constraints too is what
-would make the recursion succinct in it: DESIGN.md par.7).
+What the AIR proves (public inputs: per inner proof and tree the root; per query slot / proof / tree the leaf index; the transcripts;
+a few constants per inner proof that its header determines):
+    for every query slot, inner proof and committed tree there are leaf values and an authentication path such that linear_hash(values)
+    hashed up the path, with the direction bits of the PUBLIC index, equals the PUBLIC root -- and those values satisfy the verifier's
+    arithmetic at that query: they give the DEEP quotient at the query point, every FRI layer's opened coset holds the value the layer before
+    it claims and folds to the value the next layer holds, the last fold is the public final-layer value.
+What is left of verifying an inner proof needs no opening: reading the Fiat-Shamir transcript (which yields challenges and indices), the
+out-of-domain constraint identity, the low-degree test of the final layer -- the checker of an aggregated proof does exactly that on the
+inner proofs' HEADERS (oracle/aggregate_verify.py: stark_verify.verify(header_only=True)) and requires the outer proof's public inputs to be
+what the headers dictate.  So an accepted aggregated proof means both inner proofs verify, and it carries none of their openings.
 
 The Fiat-Shamir transcripts of the inner proofs are in the circuit too (stage B, hashing part): every permutation of an inner
 proof's sponge is a block of the trace, chained through the capacity (or the whole state, between squeezes), with the absorbed
@@ -34,7 +37,29 @@ The link between block k (row 31) and block k+1 (row 0) is chosen by SCHEDULE se
 stark/air.py FixedCol): sponge chaining of a leaf hash, a Merkle node (left / right by the direction bit, accumulated into the
 index), the final comparison with the root and the index.  The schedule is fixed by the shape of the inner proofs, so a
 prover cannot shorten a path or skip a comparison.  Everything is cyclic (no boundary constraints): the last link of the
-trace wraps to block 0."""
+trace wraps to block 0.
+
+Arithmetic (21 more columns; constraints stay at degree 4).  Per query slot and inner proof the blocks of the committed trees follow one
+another -- trace, [stage 2], quotient, FRI layer 0, 1, ... -- each as its leaf (absorb blocks) and then its path (node blocks).  Next to them:
+  HR[8]   the 8 rate values of the current absorb block (an unhashed leaf: its <= 4 values), constant over the block, bound to the state at row 0;
+  X       the evaluation point spelled by the direction bits of the current path: X' = X (1 + d (c_l - 1)), c_l = w^(2^l) a fixed column --
+          the quotient tree's path gives x = shift w_M^index, the path of FRI layer l its coset base point x_l = shift_l w_(lg)^row;
+  XQN, XQ the point the NEXT layer is queried at (x_l^(2^f), accumulated along the same bits) and the latched copy of the previous one;
+  ACA     phase A (trace / stage-2 / quotient leaves): Horner accumulator H <- H g^n + sum_i v_i g^(n-1-i) over the opened values, g = 1/gamma,
+          so that sum_k gamma^k v_k = gamma^(K-1) H (the public powers of g sit in fixed columns: 8 values per row of ONE absorb block);
+  ACB     the snapshot of H after the trace + stage-2 values (the second DEEP sum runs over those only).
+  At the end of the quotient path:  F(x) = (gamma^(Wall-1) H - E_z) / (x - zeta) + (gamma^(Wall+Wt-1) H_B - E_zw) / (x - zeta w), with the two inverses as
+  witnesses (in HR of that block) and E_z = sum_k gamma^k ev_k(zeta), E_zw likewise PUBLIC (O(columns) work per inner proof for whoever checks the
+  public inputs, like the out-of-domain identity).  ACA <- -F(x).
+  FRI layer l (leaf = the 2^f points of one coset, 3 x 2^f values in ceil(3 2^f / 8) absorb blocks): on rows j < 2^f of each absorb block
+  D_j = (1 / 2^f) sum_k w_f^(-jk) (the block's values, as F_p^3 components) -- a fixed linear map, 24 fixed columns -- is accumulated twice:
+      ACA += tau^j D_j        tau = x_q / x_l   (base field): the interpolant of the coset at the QUERY point = the opened value the previous
+                                                  layer (or the DEEP quotient) claims -- ACA must be 0 when the layer's path ends;
+      ACB += xi^j beta^j D_j  xi = 1 / x_l: the fold at beta (public powers of beta in fixed columns), handed on as -ACA of the next layer;
+  xi and tau are witnesses held over the layer's blocks and checked against X when its path ends (xi X = 1, tau X = XQ); after the last layer
+  ACB must be the PUBLIC value of the final layer at the query's position (a lookup for the checker, no arithmetic).
+So the checker of an aggregated proof runs, per inner proof, the transcript READ, the out-of-domain identity, the low-degree test of the final layer
+and O(columns) sums -- nothing per query but the index bookkeeping; the inner proofs' opened values are not part of the aggregated proof."""
 from __future__ import annotations
 
 import numpy as np
@@ -45,32 +70,44 @@ from .air import Col, Fixed, FixedCol, Pub, Const
 P = A.P
 ROWS = 32          # rows per permutation block
 N_ROUNDS, N_FULL_HALF = 30, 4
-S0, U0, COL_D, COL_IDX, WIDTH = 0, 12, 24, 25, 26
+S0, U0, COL_D, COL_IDX = 0, 12, 24, 25
+HR0, ACA0, ACB0, COL_XI, COL_TPX, COL_TAU, COL_TPT, COL_X, COL_XQ, COL_XQN, WIDTH = 26, 34, 37, 40, 41, 42, 43, 44, 45, 46, 47
+Q_PIECES = 3       # degree-4 constraints: the quotient of a proof over this AIR is committed in 3 pieces (9 base columns), blow-up 4
+ROOT32_DEFAULT, SHIFT_DEFAULT = 1753635133440165772, 49
+# the arithmetic section of the public inputs, per inner proof: g^1..g^8 (g = 1 / gamma), then six F_p^3 constants, then beta_l^j
+AP_G, AP_CA, AP_CB, AP_EZA, AP_EZB, AP_ZETA, AP_ZETAW, AP_BETA = 0, 24, 27, 30, 33, 36, 39, 42
 
 
 class Shape:
     """what the Merkle part of a verifier needs to know about the inner proofs (all inner proofs of one aggregation share it)"""
 
-    def __init__(self, logn, logb, W, W2, Wq, n_queries, fri_logf, fri_final_log, n_proofs=2, n_pub_inner=0, pow_bits=0):
-        """n_pub_inner / pow_bits: number of public inputs and grinding bits of an inner proof (they shape its transcript)"""
+    def __init__(self, logn, logb, W, W2, Wq, n_queries, fri_logf, fri_final_log, n_proofs=2, n_pub_inner=0, pow_bits=0, root32=None, shift=None):
+        """n_pub_inner / pow_bits: number of public inputs and grinding bits of an inner proof (they shape its transcript); root32 / shift:
+        the evaluation domain of the inner proofs (2^32-th root of unity, coset shift: constants of the arithmetic constraints)"""
         self.logn, self.logb, self.W, self.W2, self.Wq = logn, logb, W, W2, Wq
         self.n_queries, self.fri_logf, self.fri_final_log, self.n_proofs = n_queries, fri_logf, fri_final_log, n_proofs
         self.n_pub_inner, self.pow_bits = n_pub_inner, pow_bits
+        self.root32 = ROOT32_DEFAULT if root32 is None else int(root32)
+        self.shift = SHIFT_DEFAULT if shift is None else int(shift)
         logm = logn + logb
         self.final_log = logm
         self.trees = [("trace", W, logm)]
         if W2:
             self.trees.append(("stage2", W2, logm))
         self.trees.append(("quotient", Wq, logm))
+        self.t_quot = len(self.trees) - 1          # trees 0 .. t_quot carry the values of the DEEP sums, the FRI layers follow
         cur, stop, li = logm, fri_final_log + logb, 0
+        self.fri = []                              # (log size of the committed layer, log fold factor)
         while cur > stop:
             f = min(fri_logf, cur - stop)
             self.trees.append(("fri%d" % li, 3 << f, cur - f))
+            self.fri.append((cur, f))
             cur -= f
             li += 1
         self.final_log = cur                       # log2 of the FRI layer sent in clear
         self.n_fri = li
         assert all(d >= 1 for (_, _, d) in self.trees)
+        assert li >= 1 and logm >= 2, "the arithmetic constraints need at least one committed FRI layer"
 
     @staticmethod
     def of_proof(proof, n_proofs=2):
@@ -79,13 +116,13 @@ class Shape:
         q0 = proof["queries"][0]
         return Shape(pr["logn"], pr["logb"], len(q0["trace"]["values"]), len(q0["stage2"]["values"]) if "stage2" in q0 else 0,
                      len(q0["quotient"]["values"]), pr["n_queries"], pr["fri_logf"], pr["fri_final_log"], n_proofs,
-                     len(proof["publics"]), pr["pow_bits"])
+                     len(proof["publics"]), pr["pow_bits"], int(proof["root32"]), int(proof["shift"]))
 
-    KEY_NAMES = ("logn", "logb", "W", "W2", "Wq", "n_queries", "fri_logf", "fri_final_log", "n_proofs", "n_pub_inner", "pow_bits")
+    KEY_NAMES = ("logn", "logb", "W", "W2", "Wq", "n_queries", "fri_logf", "fri_final_log", "n_proofs", "n_pub_inner", "pow_bits", "root32", "shift")
 
     def key(self):
         return (self.logn, self.logb, self.W, self.W2, self.Wq, self.n_queries, self.fri_logf, self.fri_final_log, self.n_proofs,
-                self.n_pub_inner, self.pow_bits)
+                self.n_pub_inner, self.pow_bits, self.root32, self.shift)
 
     def to_dict(self):
         return dict(zip(self.KEY_NAMES, self.key()))
@@ -94,11 +131,13 @@ class Shape:
     def from_dict(d):
         """shape named by an aggregated proof (untrusted text: bounded before anything is sized by it)"""
         v = [d[k] for k in Shape.KEY_NAMES]
-        lim = dict(zip(Shape.KEY_NAMES, (30, 8, 4096, 4096, 64, 4096, 8, 16, 64, 1 << 24, 64)))
+        lim = dict(zip(Shape.KEY_NAMES, (30, 8, 4096, 4096, 64, 4096, 4, 16, 64, 1 << 24, 64, P - 1, P - 1)))
         if not all(isinstance(x, int) and not isinstance(x, bool) and 0 <= x <= lim[k] for k, x in zip(Shape.KEY_NAMES, v)):
             raise ValueError("shape out of range")
-        if v[0] < 1 or v[1] < 1 or v[2] < 1 or v[4] < 1 or v[5] < 1 or v[6] < 1 or v[8] < 1 or v[0] + v[1] > 32:
+        if v[0] < 1 or v[1] < 1 or v[2] < 1 or v[4] < 1 or v[5] < 1 or v[6] < 1 or v[8] < 1 or v[0] + v[1] > 32 or v[11] < 2 or v[12] < 1:
             raise ValueError("shape out of range")
+        if v[0] + v[1] <= v[7] + v[1] or v[0] + v[1] < 2:
+            raise ValueError("shape without a committed FRI layer")
         return Shape(*v)
 
     # ---- the Fiat-Shamir transcript of one inner proof, as a list of permutations
@@ -175,8 +214,33 @@ class Shape:
         return (periods - 1) * pb + k * self.n_proofs * self.blocks_per_proof()
 
     def merkle_pubs(self):
+        """roots of every inner proof, then the leaf index of every (slot, proof, tree) -- the opened values are private"""
         T = len(self.trees)
-        return self.n_proofs * T * 4 + self.n_slots() * self.n_proofs * (T + self.values_per_query())
+        return self.n_proofs * T * 4 + self.n_slots() * self.n_proofs * T
+
+    # ---- the arithmetic section: per inner proof, then one final-layer value per (slot, proof)
+    def arith_pubs_per_proof(self):
+        return AP_BETA + sum(3 * ((1 << f) - 1) for (_, f) in self.fri)
+
+    def arith_base(self):
+        return self.merkle_pubs() + self.n_proofs * self.transcript_pubs_per_proof()
+
+    def pub_arith(self, p, off):
+        return self.arith_base() + p * self.arith_pubs_per_proof() + off
+
+    def ap_beta(self, li, j, c):
+        """offset (within a proof's arithmetic section) of component c of beta_li^j, 1 <= j < 2^f"""
+        return AP_BETA + sum(3 * ((1 << f) - 1) for (_, f) in self.fri[:li]) + 3 * (j - 1) + c
+
+    def pub_finv(self, slot, p, c):
+        """component c of the final-layer value of proof p at the position of query slot `slot`"""
+        return self.arith_base() + self.n_proofs * self.arith_pubs_per_proof() + (slot * self.n_proofs + p) * 3 + c
+
+    def deep_blocks(self, t):
+        """the leaf blocks of tree t <= t_quot as (number of values n in the block) -- absorb blocks, or ONE entry for an unhashed leaf"""
+        w = self.trees[t][1]
+        a = self.absorb_blocks(w)
+        return [min(8, w - 8 * j) for j in range(a)] if a else [w]
 
     def pub_tin(self, p, j, i):
         return self.merkle_pubs() + p * self.transcript_pubs_per_proof() + self.transcript_perms()[j]["pin"] + i
@@ -220,7 +284,7 @@ class Shape:
         return k * periods
 
     def n_pub(self):
-        return self.merkle_pubs() + self.n_proofs * self.transcript_pubs_per_proof()
+        return self.arith_base() + self.n_proofs * self.arith_pubs_per_proof() + self.n_slots() * self.n_proofs * 3
 
     def pub_root(self, p, t, i):
         return (p * len(self.trees) + t) * 4 + i
@@ -231,12 +295,6 @@ class Shape:
 
     def values_per_query(self):
         return sum(w for (_, w, _) in self.trees)
-
-    def pub_value(self, slot, p, t, k):
-        """public input number of opened value k of tree t of proof p in query slot `slot`"""
-        T = len(self.trees)
-        base = self.n_proofs * T * 4 + self.n_slots() * self.n_proofs * T
-        return base + (slot * self.n_proofs + p) * self.values_per_query() + sum(w for (_, w, _) in self.trees[:t]) + k
 
     def period_schedule(self):
         """blocks of one period: list of dicts {kind: "absorb" | "node" | "idle", sub (slot within the period), p, t, level, first,
@@ -264,6 +322,44 @@ _SCHED_CACHE = {}
 _SCRIPT_CACHE = {}
 
 
+def _root_of_unity(shape, logk):
+    """the primitive 2^logk-th root of unity of the inner proofs' domain"""
+    return pow(shape.root32, 1 << (32 - logk), P)
+
+
+def tree_points(shape, t):
+    """for tree t >= t_quot: (x0, [c_l], xq0, [cq_l]) -- the point its path spells is x0 prod_l c_l^bit_l (the quotient tree: the query
+    point x = shift w_M^index; FRI layer li: the base point of the opened coset, shift_li w_lg^row) and the point the NEXT layer is queried
+    at, xq0 prod_l cq_l^bit_l (= the same point for the quotient tree, its 2^f-th power for a FRI layer)"""
+    depth = shape.trees[t][2]
+    if t == shape.t_quot:
+        lg = shape.logn + shape.logb
+        cs = [_root_of_unity(shape, lg - l) for l in range(depth)]
+        return shape.shift, cs, shape.shift, cs
+    li = t - shape.t_quot - 1
+    lg, f = shape.fri[li]
+    sh = pow(shape.shift, 1 << sum(ff for (_, ff) in shape.fri[:li]), P)
+    cs = [_root_of_unity(shape, lg - l) for l in range(depth)]
+    return sh, cs, pow(sh, 1 << f, P), [pow(c, 1 << f, P) for c in cs]
+
+
+def fold_coefficients(shape, li, blk):
+    """FRI layer li, absorb block blk: {(row j, component c, rate position k): coefficient} of D_j = (1/2^f) sum_k' w_f^(-j k') pts[k'] restricted to
+    the values this block holds -- flattened leaf value v = 8 blk + k is component v div 2^f of point v mod 2^f"""
+    _, f = shape.fri[li]
+    n, out = 1 << f, {}
+    winv = pow(_root_of_unity(shape, f), P - 2, P)
+    ninv = pow(n, P - 2, P)
+    for k in range(8):
+        v = 8 * blk + k
+        if v >= 3 * n:
+            break
+        c, kp = divmod(v, n)
+        for j in range(n):
+            out[(j, c, k)] = ninv * pow(winv, (j * kp) % n, P) % P
+    return out
+
+
 def verifier_air(shape, rc, mds):
     """the AIR for inner proofs of `shape` under the Poseidon tables rc (360) / mds (144, row-major)"""
     key = (shape.key(), hash(tuple(int(v) for v in rc)), hash(tuple(int(v) for v in mds)))
@@ -275,7 +371,7 @@ def verifier_air(shape, rc, mds):
     lp = (ROWS * pb).bit_length() - 1            # log2 of the schedule period in rows
     logn = shape.logn_trace()
     sched = shape.period_schedule()
-    T = len(shape.trees)
+    T, TQ = len(shape.trees), shape.t_quot
 
     # ---- fixed columns
     fc = []
@@ -290,6 +386,19 @@ def verifier_air(shape, rc, mds):
     l_chain, l_node, l_final, cap0, wt = [], [], [], [], []
     roots = [[] for _ in range(4)]
     final_rows = []                                                       # (row in period, sub, p, t)
+    # arithmetic selectors (all periodic with the schedule)
+    hupd, intree, xinit, clm1, xqinit, clqm1, powrow, abs0f, lka, lkb, snapsel, qfin, frifin, lastfin = ([] for _ in range(14))
+    fcoef = [[[] for _ in range(8)] for _ in range(3)]                    # F[c][k]: the inverse-DFT rows of the folds
+    gp = [[] for _ in range(3)]                                           # GP: g^n on H-update links; beta^j on the fold rows
+    gcol = [[[] for _ in range(3)] for _ in range(8)]                     # G[i]: g^(n-1-i) on H-update links; six constants on QFIN rows
+
+    def e3_pub_or_one(dst, row, p, off, one):
+        """F_p^3 entry: the constant 1 or three public inputs of proof p's arithmetic section"""
+        if one:
+            dst[0].append((row, 1))
+        else:
+            for c in range(3):
+                dst[c].append((row, Pub(shape.pub_arith(p, off + c))))
     for b, blk in enumerate(sched):
         row = b * ROWS + 31
         nxt = sched[(b + 1) % len(sched)]
@@ -307,6 +416,61 @@ def verifier_air(shape, rc, mds):
             cap0.append((row, 1))                                         # capacity of the next block's input is zero
         if nxt["kind"] == "node":
             wt.append((row, 1 << nxt["level"]))                           # weight of the next block's direction bit
+        # ---- arithmetic: what the link row of block b does
+        tree_end = blk["kind"] == "node" and blk["last"]
+        if blk["kind"] != "idle" and not tree_end:
+            intree.append((row, 1))
+        t = blk.get("t", -1)
+        is_snap = tree_end and t == TQ - 1
+        is_qfin = tree_end and t == TQ
+        is_frifin = tree_end and t > TQ
+        if is_snap:
+            snapsel.append((row, 1))
+        if is_qfin:
+            qfin.append((row, 1))
+            for i, off in enumerate((AP_CA, AP_CB, AP_EZA, AP_EZB, AP_ZETA, AP_ZETAW)):
+                e3_pub_or_one(gcol[i], row, blk["p"], off, False)
+        if is_frifin:
+            frifin.append((row, 1))
+            if t == T - 1:
+                lastfin.append((row, 1))
+        nt = nxt.get("t", -1)
+        nxt_tree_start = nxt["kind"] != "idle" and (nxt["j"] == 0 if nxt["kind"] == "absorb" else nxt["first"])
+        nxt_leaf = nxt["kind"] != "idle" and nt <= TQ and (nxt["kind"] == "absorb" or nxt["first"])     # a block that holds DEEP values
+        if nxt_leaf:
+            hupd.append((row, 1))
+            n = shape.deep_blocks(nt)[nxt["j"] if nxt["kind"] == "absorb" else 0]
+            if not (nt == 0 and nxt_tree_start):                          # the first leaf block of a group starts H afresh: GP = 0
+                e3_pub_or_one(gp, row, nxt["p"], AP_G + 3 * (n - 1), False)
+            for i in range(n):
+                e3_pub_or_one(gcol[i], row, nxt["p"], AP_G + 3 * (n - 2 - i), n - 1 - i == 0)
+        if nxt_tree_start and nt >= TQ:
+            x0, _, xq0, _ = tree_points(shape, nt)
+            xinit.append((row, x0))
+            xqinit.append((row, xq0))
+        if nxt["kind"] == "node" and nt >= TQ:
+            _, cs_, _, cqs_ = tree_points(shape, nt)
+            if cs_[nxt["level"]] != 1:
+                clm1.append((row, (cs_[nxt["level"]] - 1) % P))
+            if cqs_[nxt["level"]] != 1:
+                clqm1.append((row, (cqs_[nxt["level"]] - 1) % P))
+        if blk["kind"] != "idle":
+            if not (nxt_leaf or is_qfin or is_frifin):
+                lka.append((row, 1))
+            if not (is_snap or is_qfin or is_frifin):
+                lkb.append((row, 1))
+        # ---- arithmetic: the fold rows inside an absorb block of a FRI layer
+        if blk["kind"] == "absorb" and t > TQ:
+            li = t - TQ - 1
+            R = 1 << shape.fri[li][1]
+            r0 = b * ROWS
+            abs0f.append((r0, 1))
+            for j in range(R - 1):
+                powrow.append((r0 + j, 1))
+            for j in range(R):
+                e3_pub_or_one(gp, r0 + j, blk["p"], shape.ap_beta(li, j, 0) if j else 0, j == 0)
+            for (j, c, kk), v in fold_coefficients(shape, li, blk["j"]).items():
+                fcoef[c][kk].append((r0 + j, v))
     fc += [FixedCol(lp, l_chain), FixedCol(lp, l_node), FixedCol(lp, l_final), FixedCol(lp, cap0), FixedCol(lp, wt)]
     L_CHAIN, L_NODE, L_FINAL, CAP0, WT = [Fixed(17 + i) for i in range(5)]
     fc += [FixedCol(lp, roots[i]) for i in range(4)]
@@ -317,30 +481,21 @@ def verifier_air(shape, rc, mds):
             idx_entries.append((per * (ROWS * pb) + row, Pub(shape.pub_index(per * k + sub, p, t))))
     fc.append(FixedCol(logn, idx_entries))
     IDXV = Fixed(26)
-    # the opened values are public: row 0 of absorb block j holds values 8j .. 8j+7 of the leaf in the rate (positions past the
-    # leaf width are zero: the padding of the sponge), row 0 of the first node block of an unhashed leaf (width <= 4) holds it as
-    # the left or right child
+    # row 0 of a leaf block: absorb block j holds values 8j .. 8j+7 of the leaf in the rate, the first node block of an unhashed leaf
+    # (width <= 4) holds it as the left or right child -- PRIVATE: the HR registers copy them, nothing names them
     abs0, id0 = [], []
     leaf = [[] for _ in range(8)]
-    for per in range(periods):
-        for b, blk in enumerate(sched):
-            if blk["kind"] == "idle":
-                continue
-            row = per * (ROWS * pb) + b * ROWS
-            w = shape.trees[blk["t"]][1]
-            slot = per * k + blk["sub"]
-            if blk["kind"] == "absorb":
-                for i in range(8):
-                    if 8 * blk["j"] + i < w:
-                        leaf[i].append((row, Pub(shape.pub_value(slot, blk["p"], blk["t"], 8 * blk["j"] + i))))
-            elif blk["first"]:
-                for i in range(w):
-                    leaf[i].append((row, Pub(shape.pub_value(slot, blk["p"], blk["t"], i))))
     for b, blk in enumerate(sched):
         if blk["kind"] == "absorb":
             abs0.append((b * ROWS, 1))
         elif blk["kind"] == "node" and blk["first"]:
             id0.append((b * ROWS, 1))
+    # the public final-layer value the last fold of (slot, proof) must give sits in LEAF[0..2] on that group's last row
+    for per in range(periods):
+        for (row, sub, p, t) in final_rows:
+            if t == T - 1:
+                for c in range(3):
+                    leaf[c].append((per * (ROWS * pb) + row, Pub(shape.pub_finv(per * k + sub, p, c))))
     # the transcript blocks (idle tail of the last period, one run of consecutive blocks per inner proof): links through the
     # capacity (absorbing permutation) or the whole state (a permutation between two squeezes), zero capacity before the first
     # permutation and before the grinding hash; the absorbed blocks (row 0) and the rates the protocol reads (row 31) are public
@@ -368,8 +523,20 @@ def verifier_air(shape, rc, mds):
     LEAF = [Fixed(29 + i) for i in range(8)]
     fc += [FixedCol(logn, tcap), FixedCol(logn, trate), FixedCol(logn, tcap0), FixedCol(logn, tabs)]
     TCAP, TRATE, TCAP0, TABS = [Fixed(37 + i) for i in range(4)]
+    nf = 2 + len(fc)
 
-    # ---- constraints
+    def add(entries):
+        nonlocal nf
+        fc.append(FixedCol(lp, entries))
+        nf += 1
+        return Fixed(nf - 1)
+    HUPD, INTREE, XINIT, CLM1, XQINIT, CLQM1, POWROW, ABS0F, LKA, LKB, SNAPSEL, QFIN, FRIFIN, LASTFIN = \
+        [add(e) for e in (hupd, intree, xinit, clm1, xqinit, clqm1, powrow, abs0f, lka, lkb, snapsel, qfin, frifin, lastfin)]
+    FC = [[add(fcoef[c][kk]) for kk in range(8)] for c in range(3)]
+    GP = [add(gp[c]) for c in range(3)]
+    G = [[add(gcol[i][c]) for c in range(3)] for i in range(8)]
+
+    # ---- constraints: hashing
     s = [Col(S0 + i) for i in range(12)]
     sn = [Col(S0 + i, True) for i in range(12)]
     u = [Col(U0 + i) for i in range(12)]
@@ -395,15 +562,74 @@ def verifier_air(shape, rc, mds):
     cs += [TCAP * (sn[8 + i] - s[8 + i]) for i in range(4)]               # transcript sponge: the capacity runs through the permutations
     cs += [TRATE * (sn[i] - s[i]) for i in range(8)]                      # ... and the rate too when nothing is absorbed in between
     cs.append(WT * (d_n * d_n - d_n))                                     # direction bits are bits
-    cs.append(idx_n - (ACT + CPY + L_CHAIN + L_NODE) * idx - WT * d_n)    # index: kept inside a block and an opening, + 2^level * bit
+    INBLK = ACT + CPY                                                     # rows 0 .. 30 of every block
+    cs.append(idx_n - (INBLK + L_CHAIN + L_NODE) * idx - WT * d_n)        # index: kept inside a block and an opening, + 2^level * bit
     cs += [L_FINAL * s[i] - ROOT[i] for i in range(4)]                    # the top of the path is the public root
     cs.append(L_FINAL * idx - IDXV)                                       # the direction bits spell the public index
-    # the hashed values are the public ones (leaves; absorbed blocks and read rates of the transcripts)
-    cs += [(ABS0 + TABS) * s[i] + ID0 * (s[i] + d_c * (s[4 + i] - s[i])) - LEAF[i] for i in range(4)]
-    cs += [(ABS0 + TABS) * s[i] - LEAF[i] for i in range(4, 8)]
+    # the absorbed blocks and the read rates of the transcripts are the public ones
+    cs += [TABS * (s[i] - LEAF[i]) for i in range(8)]
+
+    # ---- constraints: arithmetic on the (private) opened values
+    hr = [Col(HR0 + i) for i in range(8)]
+    hrn = [Col(HR0 + i, True) for i in range(8)]
+    aca, acan = [Col(ACA0 + c) for c in range(3)], [Col(ACA0 + c, True) for c in range(3)]
+    acb, acbn = [Col(ACB0 + c) for c in range(3)], [Col(ACB0 + c, True) for c in range(3)]
+    xi, xin, tpx, tpxn = Col(COL_XI), Col(COL_XI, True), Col(COL_TPX), Col(COL_TPX, True)
+    tau, taun, tpt, tptn = Col(COL_TAU), Col(COL_TAU, True), Col(COL_TPT), Col(COL_TPT, True)
+    X, Xn, XQ, XQn, XQN, XQNn = Col(COL_X), Col(COL_X, True), Col(COL_XQ), Col(COL_XQ, True), Col(COL_XQN), Col(COL_XQN, True)
+    # the registers: constant inside a block, the leaf's values at its row 0
+    cs += [INBLK * (hrn[i] - hr[i]) for i in range(8)]
+    cs += [ABS0 * (hr[i] - s[i]) + ID0 * (hr[i] - (s[i] + d_c * (s[4 + i] - s[i]))) for i in range(4)]
+    cs += [ABS0 * (hr[i] - s[i]) + ID0 * hr[i] for i in range(4, 8)]
+    # evaluation points along the paths
+    KEEP = INBLK + INTREE
+    cs.append(Xn - (KEEP * X + XINIT) * (1 + d_n * CLM1))
+    cs.append(XQNn - (KEEP * XQN + XQINIT) * (1 + d_n * CLQM1))
+    cs.append(XQn - KEEP * XQ - L_FINAL * XQN)                             # the query point of the next layer is latched where a path ends
+    # xi = 1 / x_l and tau = x_q / x_l are held over a layer's blocks; their powers run down the fold rows
+    cs.append(KEEP * (xin - xi))
+    cs.append(KEEP * (taun - tau))
+    cs.append(ABS0F * (tpx - 1))
+    cs.append(ABS0F * (tpt - 1))
+    cs.append(POWROW * (tpxn - tpx * xi))
+    cs.append(POWROW * (tptn - tpt * tau))
+    cs.append(FRIFIN * (xi * X - 1))
+    cs.append(FRIFIN * (tau * X - XQ))
+    # D_j of the fold rows (zero elsewhere: the coefficient columns are)
+    D = []
+    for c in range(3):
+        acc = None
+        for kk in range(8):
+            if fcoef[c][kk]:
+                term = FC[c][kk] * hr[kk]
+                acc = term if acc is None else acc + term
+        D.append(acc if acc is not None else Const(0))
+    i1, i2 = hr[0:3], hr[3:6]
+    CA_, CB_, EZA_, EZB_, ZETA_, ZETAW_ = G[0], G[1], G[2], G[3], G[4], G[5]
+    horner = A.e3x_mul(aca, GP)                                            # H g^n ...
+    for c in range(3):
+        acc = horner[c]
+        for i in range(8):
+            acc = acc + hrn[i] * G[i][c]                                   # ... + sum_i v_i g^(n-1-i): the NEXT row's registers hold the block's values
+        horner[c] = acc
+    ta = A.e3x_mul(CA_, aca)
+    tb = A.e3x_mul(CB_, acb)
+    fx = A.e3x_mul([ta[c] - EZA_[c] for c in range(3)], i1)
+    fx2 = A.e3x_mul([tb[c] - EZB_[c] for c in range(3)], i2)
+    bd = A.e3x_mul(GP, D)                                                  # beta^j D_j
+    for c in range(3):
+        cs.append(acan[c] - (INBLK + LKA) * aca[c] - HUPD * horner[c] - tpt * D[c] + QFIN * (fx[c] + fx2[c]) + (FRIFIN - LASTFIN) * acb[c])
+        cs.append(acbn[c] - (INBLK + LKB) * acb[c] - SNAPSEL * aca[c] - tpx * bd[c])
+    cs += [FRIFIN * aca[c] for c in range(3)]                             # the interpolant of the coset at the query point IS the claimed value
+    cs += [LASTFIN * (acb[c] - LEAF[c]) for c in range(3)]                # the last fold is the public final-layer value
+    one = [Const(1), Const(0), Const(0)]
+    inv1 = A.e3x_mul([X - ZETA_[0], Const(0) - ZETA_[1], Const(0) - ZETA_[2]], i1)
+    inv2 = A.e3x_mul([X - ZETAW_[0], Const(0) - ZETAW_[1], Const(0) - ZETAW_[2]], i2)
+    cs += [QFIN * (inv1[c] - one[c]) for c in range(3)]
+    cs += [QFIN * (inv2[c] - one[c]) for c in range(3)]
     air = A.Air("mverify", WIDTH, shape.n_pub(), cs, trace_kind=None, fixed_cols=fc)
     air.shape = shape
-    assert A.quotient_chunks(air) <= 4
+    assert A.quotient_chunks(air) <= Q_PIECES
     _AIR_CACHE[key] = air
     return air
 
@@ -484,13 +710,13 @@ def replay_transcript(shape, proof, digest_words, be):
             tr.absorb(proof["roots"]["stage2"])
         tr.squeeze(3)
         tr.absorb(proof["roots"]["quotient"])
-        tr.squeeze(3)
+        chal = {"zeta": tr.squeeze(3), "betas": []}
         for r in proof["evals"]["z"] + proof["evals"]["zw"]:
             tr.absorb(r)
-        tr.squeeze(3)
+        chal["gamma"] = tr.squeeze(3)
         for root in proof["fri"]["roots"]:
             tr.absorb(root)
-            tr.squeeze(3)
+            chal["betas"].append(tr.squeeze(3))
         for c in range(3):
             tr.absorb(proof["fri"]["final"][c])
         pow_rec = None
@@ -519,13 +745,57 @@ def replay_transcript(shape, proof, digest_words, be):
         tp += inp[:n]
         if out is not None:
             tp += out
-    return [r[0] for r in rec], tp
+    return [r[0] for r in rec], tp, chal
+
+
+def arith_publics(shape, proof, chal):
+    """the arithmetic section of ONE inner proof's public inputs (layout: AP_*): powers of g = 1 / gamma, the two DEEP constants
+    gamma^(Wall-1), gamma^(Wall+Wt-1), the public halves of the two DEEP sums E_z = sum_k gamma^k ev_k(zeta), E_zw = sum_k gamma^(Wall+k) ev_k(zeta w),
+    zeta, zeta w, and beta_l^j for every layer.  O(columns) field operations -- whoever checks the public inputs redoes exactly this."""
+    from . import field as F
+    gamma, zeta = F.e3(chal["gamma"]), F.e3(chal["zeta"])
+    g = F.e3_inv(gamma)
+    out, cur = [], [1, 0, 0]
+    for _ in range(8):
+        cur = F.e3_mul(cur, g)
+        out += cur
+    Wt = shape.W + shape.W2
+    Wall = Wt + shape.Wq
+    ev_all, ev_next = proof["evals"]["z"], proof["evals"]["zw"]
+    if len(ev_all) != Wall or len(ev_next) != Wt:
+        raise ValueError("inner proof has the wrong number of out-of-domain evaluations")
+    eza, ezb, gk = [0, 0, 0], [0, 0, 0], [1, 0, 0]
+    pw = []
+    for k in range(Wall + Wt):
+        pw.append(gk)
+        gk = F.e3_mul(gk, gamma)
+    for k in range(Wall):
+        eza = F.e3_add(eza, F.e3_mul(pw[k], F.e3(ev_all[k])))
+    for k in range(Wt):
+        ezb = F.e3_add(ezb, F.e3_mul(pw[Wall + k], F.e3(ev_next[k])))
+    wN = pow(shape.root32, 1 << (32 - shape.logn), P)
+    out += pw[Wall - 1] + pw[Wall + Wt - 1] + eza + ezb + zeta + F.e3_scale(zeta, wN)
+    for (_, f), beta in zip(shape.fri, chal["betas"]):
+        cur = [1, 0, 0]
+        for _ in range((1 << f) - 1):
+            cur = F.e3_mul(cur, F.e3(beta))
+            out += cur
+    assert len(out) == shape.arith_pubs_per_proof()
+    return out
+
+
+def final_values(shape, proof, indices):
+    """the final-layer value at the position of every query index: [len(indices)][3]"""
+    fin = proof["fri"]["final"]
+    m = (1 << shape.final_log) - 1
+    if len(fin) != 3 or any(len(pl) != m + 1 for pl in fin):
+        raise ValueError("inner proof has a final layer of the wrong size")
+    return [[int(fin[c][int(j) & m]) for c in range(3)] for j in indices]
 
 
 def expected_publics(shape, proofs):
     """the Merkle part of the public inputs (the transcript part follows it: replay_transcript): roots of every inner proof, then
-    the leaf index of every (slot, proof, tree), then the opened values of every (slot, proof, tree): slot g re-opens query
-    g mod n_queries"""
+    the leaf index of every (slot, proof, tree): slot g re-opens query g mod n_queries.  The opened values are private."""
     pubs = []
     for pr in proofs:
         names = {"trace": pr["roots"]["trace"], "quotient": pr["roots"]["quotient"]}
@@ -539,14 +809,6 @@ def expected_publics(shape, proofs):
             j = pr["queries"][g % shape.n_queries]["index"]
             for (_, _, depth) in shape.trees:
                 pubs.append(int(j) & ((1 << depth) - 1))
-    for g in range(shape.n_slots()):
-        for pr in proofs:
-            q = pr["queries"][g % shape.n_queries]
-            for (name, w, _) in shape.trees:
-                vals = _opening(q, name)["values"]
-                if len(vals) != w:
-                    raise ValueError("opening of %s has the wrong shape" % name)
-                pubs += [int(v) for v in vals]
     return pubs
 
 
@@ -619,11 +881,10 @@ def _publics_from_arrays(shape, proofs, prepared):
     g = np.arange(shape.n_slots()) % shape.n_queries
     masks = np.array([(1 << d) - 1 for (_, _, d) in shape.trees], dtype=np.uint64)
     parts.append(np.stack([pp["index"][g][:, None] & masks[None, :] for pp in prepared], axis=1).reshape(-1))     # [slot][proof][tree]
-    parts.append(np.stack([np.concatenate([v[g] for v in pp["values"]], axis=1) for pp in prepared], axis=1).reshape(-1))
     return np.concatenate(parts)
 
 
-def build_witness(shape, proofs, be, digest_words, prepared=None):
+def build_witness(shape, proofs, be, digest_words, prepared=None, keep=None):
     """(trace u64[26][N], publics) for inner proof objects `proofs` (len = shape.n_proofs) of `shape`; the trace is a host array,
     or a device buffer of that shape when the backend assembles it in HBM (verifier_trace_device).
     be: backend with poseidon_perm_batch(states [B][12]), poseidon_trace(inputs [B][12]) -> (states [12][32 B], cubes
@@ -686,11 +947,18 @@ def build_witness(shape, proofs, be, digest_words, prepared=None):
         digest[sel] = be.poseidon_perm_batch(st)[:, :4]
     pub_parts = [_publics_from_arrays(shape, proofs, prepared)]
     L = len(shape.transcript_perms())
+    chals = []
     for p, pr in enumerate(proofs):                 # the transcripts: consecutive blocks in the idle tail of the last period
-        states, tp = replay_transcript(shape, pr, digest_words, be)
+        states, tp, chal = replay_transcript(shape, pr, digest_words, be)
+        chals.append(chal)
         blk0 = shape.transcript_block0() + p * L
         inputs[blk0:blk0 + L] = np.array(states, dtype=np.uint64)
         pub_parts.append(np.array(tp, dtype=np.uint64))
+    aps = [arith_publics(shape, pr, ch) for pr, ch in zip(proofs, chals)]
+    pub_parts += [np.array(a, dtype=np.uint64) for a in aps]
+    gq = np.arange(shape.n_slots()) % shape.n_queries
+    fin = np.stack([np.array(final_values(shape, pr, pp["index"][gq]), dtype=np.uint64) for pr, pp in zip(proofs, prepared)], axis=1)
+    pub_parts.append(fin.reshape(-1))                                 # [slot][proof][3]
     pubs = np.concatenate(pub_parts)
     assert len(pubs) == shape.n_pub()
     T = len(shape.trees)
@@ -700,14 +968,233 @@ def build_witness(shape, proofs, be, digest_words, prepared=None):
         o = int(bad[0])
         raise ValueError("an opening of the %s tree of inner proof %d does not hash to its root: no accepting witness"
                          % (shape.trees[tl[o]][0], pl[o]))
+    # the arithmetic columns: DEEP quotient, folds and evaluation points of every query (raises when an inner proof's values are
+    # inconsistent: a wrong DEEP value, a fold that does not give the next layer's value, a last fold that is not the final layer)
+    if "blk_op" not in ops:
+        ops["blk_op"] = block_openings(shape, ops)
+    arith_in = {"vals": vals, "index": index, "dbit": dbit, "blk_op": ops["blk_op"], "aps": aps, "fin": fin}
+    if keep is not None:
+        keep["arith_in"] = arith_in                                  # tests: the inputs of the arithmetic builders
+    if hasattr(be, "verifier_arith_columns"):
+        arith = be.verifier_arith_columns(shape, arith_in)           # native: same columns (tests compare the two)
+    else:
+        arith = arith_columns(shape, arith_in)
     if hasattr(be, "verifier_trace_device"):      # GPU backend: the trace is assembled in HBM and stays there
-        return be.verifier_trace_device(inputs, dbit, idxv), pubs
+        return be.verifier_trace_device(inputs, dbit, idxv, arith), pubs
     states, cubes = be.poseidon_trace(inputs)
     trace = np.zeros((WIDTH, N), dtype=np.uint64)
     trace[S0:S0 + 12], trace[U0:U0 + 12] = states, cubes
     trace[COL_D] = np.repeat(dbit, ROWS)
     trace[COL_IDX] = np.repeat(idxv, ROWS)
+    trace[HR0:] = arith
     return trace, pubs
+
+
+_DESC_CACHE = {}
+ARITH_DESC_MAGIC = int.from_bytes(b"PZVARITH", "little")
+
+
+def arith_descriptor(shape):
+    """the schedule of the arithmetic columns as data for the native builder (zp_verifier_arith_host / zp_verifier_arith_trace; layout in
+    csrc/recursion.hip): header | one word per block of a period | one record per committed tree | the inverse-DFT tables of the folds"""
+    cached = _DESC_CACHE.get(shape.key())
+    if cached is not None:
+        return cached
+    k, periods, pb = shape.layout()
+    sched = shape.period_schedule()
+    T, TQ = len(shape.trees), shape.t_quot
+    max_w = max(8 * Shape.absorb_blocks(w) if w > 4 else 4 for (_, w, _) in shape.trees)
+    KIND = {"idle": 0, "absorb": 1, "node": 2}
+    blk_words = []
+    for blk in sched:
+        if blk["kind"] == "idle":
+            blk_words.append(0)
+            continue
+        jl = blk["j"] if blk["kind"] == "absorb" else blk["level"]
+        blk_words.append(KIND[blk["kind"]] | blk["t"] << 2 | jl << 8 | int(bool(blk["first"])) << 16 | int(bool(blk["last"])) << 17 | blk["p"] << 18 |
+                         blk["sub"] << 34)
+    tree_words, fold_words, n_fold = [], [], 0
+    for t, (_, w, depth) in enumerate(shape.trees):
+        rec = [w, depth, 0, 0, 0, 0, 0, 0] + [0] * 64
+        if t >= TQ:
+            x0, cs_, xq0, cqs_ = tree_points(shape, t)
+            rec[2], rec[3] = x0, xq0
+            rec[8:8 + depth] = cs_
+            rec[40:40 + depth] = cqs_
+        if t > TQ:
+            li = t - TQ - 1
+            lg, f = shape.fri[li]
+            rec[4], rec[5], rec[6], rec[7] = lg, f, shape.ap_beta(li, 1, 0), n_fold
+            for bj in range(Shape.absorb_blocks(w)):
+                tab = [0] * (16 * 3 * 8)
+                for (j, c, kk), v in fold_coefficients(shape, li, bj).items():
+                    tab[(j * 3 + c) * 8 + kk] = v
+                fold_words += tab
+                n_fold += 1
+        tree_words += rec
+    n_open = shape.n_slots() * shape.n_proofs * T
+    hdr = [ARITH_DESC_MAGIC, pb, periods, k, shape.n_proofs, T, TQ, max_w, n_open, shape.arith_pubs_per_proof(), n_fold, 0]
+    desc = np.array(hdr + blk_words + tree_words + fold_words, dtype=np.uint64)
+    _DESC_CACHE[shape.key()] = desc
+    return desc
+
+
+def block_openings(shape, ops):
+    """block -> opening (row of _opening_table), -1 for idle / transcript blocks"""
+    k, periods, pb = shape.layout()
+    blk_op = np.full(pb * periods, -1, dtype=np.int64)
+    ends = ops["b0"] + ops["na"] + ops["nd"]
+    for o in range(len(ops["b0"])):
+        blk_op[ops["b0"][o]:ends[o]] = o
+    return blk_op
+
+
+def link_roles(shape, blk, nxt):
+    """what the link row between schedule blocks blk -> nxt does to the arithmetic registers: the selector values the AIR puts on that row
+    (verifier_air() lists the same conditions)"""
+    TQ, T = shape.t_quot, len(shape.trees)
+    tree_end = blk["kind"] == "node" and blk["last"]
+    t, nt = blk.get("t", -1), nxt.get("t", -1)
+    r = {"keep": blk["kind"] != "idle" and not tree_end, "tree_end": tree_end, "snap": tree_end and t == TQ - 1, "qfin": tree_end and t == TQ,
+         "frifin": tree_end and t > TQ, "lastfin": tree_end and t == T - 1}
+    r["tree_start"] = nxt["kind"] != "idle" and (nxt["j"] == 0 if nxt["kind"] == "absorb" else nxt["first"])
+    r["leaf"] = nxt["kind"] != "idle" and nt <= TQ and (nxt["kind"] == "absorb" or nxt["first"])
+    r["lka"] = blk["kind"] != "idle" and not (r["leaf"] or r["qfin"] or r["frifin"])
+    r["lkb"] = blk["kind"] != "idle" and not (r["snap"] or r["qfin"] or r["frifin"])
+    return r
+
+
+def arith_columns(shape, a):
+    """The 21 arithmetic columns u64[21][N] (HR, ACA, ACB, XI, TPX, TAU, TPT, X, XQ, XQN) -- the REFERENCE builder: it walks the blocks in
+    schedule order and applies, link by link and fold row by fold row, exactly the transitions the constraints state (Python integers; the
+    native builder behind be.verifier_arith_columns produces the same columns).  a: {"vals" [openings][max_w], "index" [openings], "dbit"
+    [blocks], "blk_op" [blocks] = block_openings(), "aps" per-proof arithmetic publics, "fin" [slots][proofs][3]}."""
+    from . import field as F
+    k, periods, pb = shape.layout()
+    nblk = pb * periods
+    sched = shape.period_schedule()
+    TQ, T = shape.t_quot, len(shape.trees)
+    blk_op = a["blk_op"]                                # block -> opening
+    vals, index, dbit = a["vals"], a["index"], a["dbit"]
+    N = ROWS * nblk
+    out = np.zeros((WIDTH - HR0, N), dtype=np.uint64)
+    C = {"hr": 0, "aca": ACA0 - HR0, "acb": ACB0 - HR0, "xi": COL_XI - HR0, "tpx": COL_TPX - HR0, "tau": COL_TAU - HR0, "tpt": COL_TPT - HR0,
+         "x": COL_X - HR0, "xq": COL_XQ - HR0, "xqn": COL_XQN - HR0}
+    pts = {t: tree_points(shape, t) for t in range(TQ, T)}
+    coefs = {}
+    ap = [[int(v) for v in x] for x in a["aps"]]
+    e3at = lambda p, off: ap[p][off:off + 3]
+    # registers at the END (row 31) of the previous block; the walk starts behind an idle block (all zero)
+    X = XQ = XQN = XI = TAU = 0
+    ACA, ACB, HR = [0, 0, 0], [0, 0, 0], [0] * 8
+    prev = sched[-1]
+    for gb in range(nblk):
+        per, b = divmod(gb, pb)
+        blk = sched[b]
+        lr = link_roles(shape, prev, blk)
+        o = int(blk_op[gb])
+        d = int(dbit[gb])
+        t = blk.get("t", -1)
+        p = blk.get("p", 0)
+        # ---- the link: registers at row 0 of this block
+        x0 = xq0 = cm1 = cqm1 = 0
+        if t >= TQ:
+            tx0, tcs, txq0, tcqs = pts[t]
+            if lr["tree_start"]:
+                x0, xq0 = tx0, txq0
+            if blk["kind"] == "node":
+                cm1, cqm1 = tcs[blk["level"]] - 1, tcqs[blk["level"]] - 1
+        keep = 1 if lr["keep"] else 0
+        nXQ = (keep * XQ + (XQN if lr["tree_end"] else 0)) % P
+        X = (keep * X + x0) * (1 + d * cm1) % P
+        XQN = (keep * XQN + xq0) * (1 + d * cqm1) % P
+        XQ = nXQ
+        # the registers of this block
+        nHR = [0] * 8
+        if blk["kind"] == "absorb":
+            nHR = [int(v) for v in vals[o, 8 * blk["j"]:8 * blk["j"] + 8]]
+            nHR += [0] * (8 - len(nHR))
+        elif blk["kind"] == "node" and blk["first"]:
+            w = shape.trees[t][1]
+            nHR = [int(v) for v in vals[o, :4]] + [0] * 4
+            assert w <= 4
+        elif blk["kind"] == "node" and blk["last"] and t == TQ:
+            zeta, zeta_w = e3at(p, AP_ZETA), e3at(p, AP_ZETAW)
+            i1 = F.e3_inv(F.e3_sub([X, 0, 0], zeta))
+            i2 = F.e3_inv(F.e3_sub([X, 0, 0], zeta_w))
+            nHR = i1 + i2 + [0, 0]
+        nACA = [ACA[c] if lr["lka"] else 0 for c in range(3)]
+        nACB = [ACB[c] if lr["lkb"] else 0 for c in range(3)]
+        if lr["leaf"]:                                # H <- H g^n + sum_i v_i g^(n-1-i)
+            n = shape.deep_blocks(t)[blk["j"] if blk["kind"] == "absorb" else 0]
+            first_of_group = t == 0 and lr["tree_start"]
+            h = [0, 0, 0] if first_of_group else F.e3_mul(ACA, e3at(p, AP_G + 3 * (n - 1)))
+            for i in range(n):
+                gi = [1, 0, 0] if n - 1 - i == 0 else e3at(p, AP_G + 3 * (n - 2 - i))
+                h = F.e3_add(h, F.e3_scale(gi, nHR[i]))
+            nACA = h
+        if lr["snap"]:
+            nACB = list(ACA)
+        if lr["qfin"]:                                # -F(x) from H, H_B and the two inverses (in the registers of the block that ends)
+            pp = prev["p"]
+            fa = F.e3_mul(F.e3_sub(F.e3_mul(e3at(pp, AP_CA), ACA), e3at(pp, AP_EZA)), HR[0:3])
+            fb = F.e3_mul(F.e3_sub(F.e3_mul(e3at(pp, AP_CB), ACB), e3at(pp, AP_EZB)), HR[3:6])
+            nACA = F.e3_sub([0, 0, 0], F.e3_add(fa, fb))
+        if lr["frifin"]:
+            if any(ACA):
+                raise ValueError("the opened values of an inner proof are inconsistent (a FRI layer does not hold the value the layer before "
+                                 "it claims): no accepting witness")
+            if lr["lastfin"]:
+                slot = (gb - 1) // pb * k + prev["sub"]
+                if [int(v) for v in a["fin"][slot][prev["p"]]] != ACB:
+                    raise ValueError("the last fold of an inner proof does not give its final layer: no accepting witness")
+            else:
+                nACA = F.e3_sub([0, 0, 0], ACB)
+        # xi, tau: held inside a tree; chosen where a FRI layer starts
+        if not keep:
+            XI = TAU = 0
+            if t > TQ and lr["tree_start"]:
+                lg, f = shape.fri[t - TQ - 1]
+                row = int(index[o])
+                xl = pts[t][0] * pow(_root_of_unity(shape, lg), row, P) % P
+                XI = pow(xl, P - 2, P)
+                TAU = XQ * XI % P
+        ACA, ACB, HR = nACA, nACB, nHR
+        # ---- rows of this block
+        r0 = gb * ROWS
+        rows = slice(r0, r0 + ROWS)
+        for i in range(8):
+            out[C["hr"] + i, rows] = HR[i]
+        out[C["xi"], rows], out[C["tau"], rows], out[C["x"], rows], out[C["xq"], rows], out[C["xqn"], rows] = XI, TAU, X, XQ, XQN
+        if blk["kind"] == "absorb" and t > TQ:        # the fold rows
+            li = t - TQ - 1
+            R = 1 << shape.fri[li][1]
+            key = (li, blk["j"])
+            if key not in coefs:
+                coefs[key] = fold_coefficients(shape, li, blk["j"])
+            cf = coefs[key]
+            tpx = tpt = 1
+            for j in range(R):
+                D = [0, 0, 0]
+                for (jj, c, kk), v in cf.items():
+                    if jj == j:
+                        D[c] = (D[c] + v * HR[kk]) % P
+                bj = [1, 0, 0] if j == 0 else e3at(p, shape.ap_beta(li, j, 0))
+                for c in range(3):
+                    out[C["aca"] + c, r0 + j], out[C["acb"] + c, r0 + j] = ACA[c], ACB[c]
+                out[C["tpx"], r0 + j], out[C["tpt"], r0 + j] = tpx, tpt
+                ACA = F.e3_add(ACA, F.e3_scale(D, tpt))
+                ACB = F.e3_add(ACB, F.e3_scale(F.e3_mul(bj, D), tpx))
+                if j < R - 1:
+                    tpx, tpt = tpx * XI % P, tpt * TAU % P
+            for c in range(3):
+                out[C["aca"] + c, r0 + R:r0 + ROWS], out[C["acb"] + c, r0 + R:r0 + ROWS] = ACA[c], ACB[c]
+            out[C["tpx"], r0 + R:r0 + ROWS], out[C["tpt"], r0 + R:r0 + ROWS] = tpx, tpt
+        else:
+            for c in range(3):
+                out[C["aca"] + c, rows], out[C["acb"] + c, rows] = ACA[c], ACB[c]
+        prev = blk
+    return out
 
 
 def aggregation_params(shape, n_queries=50, fri_logf=3, fri_final_log=5, pow_bits=0, hash="gl"):

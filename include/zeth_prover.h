@@ -305,6 +305,24 @@ int32_t zp_synth_trace_bound(int32_t kind, int32_t logn, int32_t W, uint64_t see
  * start must exceed 1024.  Known discrete logs: sum_i s_i P_i = (sum_i s_i (start + i) mod r) * G.            */
 int32_t zp_synth_g1_points(uint64_t start, size_t n, uint32_t *h_points, int32_t threads);
 
+/* ---- witness of the STARK-verifier AIR: its arithmetic columns (GenAggregatedProof / the final STARK of GenFinalProof:
+ * proto/prover/v1/prover.proto:115-148, src/prover/provider.rs:422-503; the AIR is eigen_zeth_amd/stark/verifier_air.py) -----------------
+ * Besides the permutation blocks (zp_poseidon_trace) the verifier trace has 21 columns that carry the field arithmetic of a verifier at
+ * the queries of its inner proofs: registers copying the opened values, the Horner accumulator of the DEEP sums, the evaluation points
+ * spelled by the path bits, the interpolation / fold accumulators of every FRI layer.  desc: the schedule of the AIR as data (u64 words:
+ * header, one word per block of a period, one record per committed tree, the inverse-DFT tables of the folds; built by
+ * verifier_air.arith_descriptor).  vals u64[openings][max_w]: the opened values; index u64[openings]: leaf indices; dbit u64[blocks]:
+ * direction bit of every block; blk_op i64[blocks]: block -> opening (-1: none); arith_pubs u64[proofs][ap_n], final_vals
+ * u64[slots][proofs][3]: the arithmetic public inputs.  Output u64[21][32 * blocks].  Returns -10 / -11 when the opened values are
+ * inconsistent (a FRI layer does not hold the value the layer before claims / the last fold is not the final layer): such inner proofs
+ * have no accepting witness.  zp_verifier_arith_host needs no GPU (the walk is host code either way; periods run on `threads` threads,
+ * 0 = all); zp_verifier_arith_trace expands the per-block records in HBM.                                                              */
+int32_t zp_verifier_arith_host(const uint64_t *desc, size_t desc_words, const uint64_t *vals, const uint64_t *index, const uint64_t *dbit,
+                               const int64_t *blk_op, const uint64_t *arith_pubs, const uint64_t *final_vals, uint64_t *h_out, int32_t threads);
+int32_t zp_verifier_arith_trace(zp_ctx *ctx, const uint64_t *desc, size_t desc_words, const uint64_t *vals, const uint64_t *index,
+                                const uint64_t *dbit, const int64_t *blk_op, const uint64_t *arith_pubs, const uint64_t *final_vals,
+                                uint64_t *d_out, int32_t threads);
+
 /* ---- multi-GPU: RCCL over xGMI behind the C-ABI (BASELINE.json configs[3]) ---------------------------------
  * One process per GPU; a zp_comm joins this rank's ctx to the RCCL communicator of `world` ranks (a power of two).  Rank 0 makes
  * the 128-byte id (zp_comm_unique_id) and hands it to the others out of band (a file, the service's own channel); every rank

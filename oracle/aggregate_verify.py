@@ -3,23 +3,25 @@ product package).
 
 An aggregated proof (what GenAggregatedProof returns: proto/prover/v1/prover.proto:115-126, consumed at
 src/prover/provider.rs:436-451) holds
-    "inner": every inner proof WITHOUT the authentication paths of its query openings (everything else: air name / digest,
-             parameters, publics, roots, out-of-domain evaluations, FRI roots + final layer, grinding nonce, and per query the
-             index and the opened values of every tree)
-    "stark": a STARK over the Merkle-verifier AIR (the statement arrives as a constraint program blob, like every other AIR)
-             whose public inputs are the inner proofs' roots, the leaf index and the opened values of every (slot, proof, tree).
+    "inner": the HEADER of every inner proof -- air name / digest, parameters, publics, roots, out-of-domain evaluations, FRI roots + final
+             layer, grinding nonce.  NO query openings (round 4: the opened values are private witnesses of the verifier AIR)
+    "stark": a STARK over the verifier AIR (the statement arrives as a constraint program blob, like every other AIR) whose public inputs
+             are the inner proofs' roots, the leaf index of every (slot, proof, tree), their transcripts, and the constants of the
+             arithmetic constraints (arithmetic_publics) + the final-layer value at every query's position.
 Accepting means BOTH INNER PROOFS VERIFY, the work split in two:
-  1. arithmetic, natively: every inner proof passes the whole verifier on the opened values as given -- parameters are the
-     verifier's, the constraint identity holds at the out-of-domain point, the DEEP quotient and every FRI fold are consistent at
-     every query, the final layer is low degree (stark_verify.verify(trust_openings=True): everything but the Merkle paths) --
-     with the Fiat-Shamir transcript READ, not hashed: the outer public inputs list, in protocol order, what every permutation
-     of the sponge absorbs and the rates the protocol reads (PublicSponge); the checker compares the absorbed blocks with the
-     proof's data and takes challenges, grinding digest and query indices from the public rates;
-  2. the public inputs of the outer STARK are exactly those roots, indices and opened values (slot g re-opens query g mod n_queries);
-  3. hashing, in the circuit: the outer STARK verifies under the verifier-AIR program -- for every slot / proof / tree the public
-     values, hashed as a leaf and up a path along the bits of the public index, give the public root; the sponge permutations of
-     every transcript map the public blocks to the public rates (chained through the capacity), the grinding hash maps seed and
-     nonce to the public digest.  (The one hash left to the checker is the digest of the OUTER proof's own public inputs.)
+  1. per inner proof, natively, what needs no opening: parameters are the verifier's, the constraint identity holds at the out-of-domain
+     point, the final layer is low degree, grinding (stark_verify.verify(header_only=True)) -- with the Fiat-Shamir transcript READ, not
+     hashed: the outer public inputs list, in protocol order, what every permutation of the sponge absorbs and the rates the protocol
+     reads (PublicSponge); the checker compares the absorbed blocks with the header's data and takes challenges, grinding digest and
+     query indices from the public rates;
+  2. the public inputs of the outer STARK are exactly what the headers dictate (roots, indices, transcripts, arithmetic constants, final-layer
+     values: slot g re-opens query g mod n_queries);
+  3. everything at the queries, in the circuit: the outer STARK verifies under the verifier-AIR program -- for every slot / proof / tree
+     there are values that hash, as a leaf and up a path along the bits of the public index, to the public root; those values give the
+     DEEP quotient at the query point, every layer's opened coset interpolates the value the previous layer claims and folds to the next
+     one's, the last fold is the public final-layer value; the sponge permutations of every transcript map the public blocks to the
+     public rates, the grinding hash maps seed and nonce to the public digest.  (The one hash left to the checker is the digest of the OUTER
+     proof's own public inputs.)
 PARITY UNPINNED w.r.t. the external prover."""
 from . import stark_verify as V
 from .air_program import Program
@@ -82,21 +84,65 @@ def verify(agg, inner_program, outer_program, rc, mds, inner_expect, outer_expec
     return V.verify(outer, prog, rc, mds, outer_expect, bn_tables)
 
 
+def _e3_pow_list(base, n):
+    """[base^1 .. base^n] in F_p^3"""
+    out, cur = [], [1, 0, 0]
+    for _ in range(n):
+        cur = V.NV.e3_mul(cur, base)
+        out.append(cur)
+    return out
+
+
+def arithmetic_publics(h, head, expect):
+    """What the verifier AIR takes as PUBLIC per inner proof for its arithmetic constraints -- everything a verifier derives from the proof's
+    header alone (the checker's own restatement; the product computes the same list in stark/verifier_air.py:arith_publics):
+    g^1..g^8 with g = 1/gamma; gamma^(Wall-1); gamma^(Wall+Wt-1); E_z = sum_k gamma^k ev_k(zeta); E_zw = sum_k gamma^(Wall+k) ev_k(zeta w); zeta; zeta w;
+    beta_l^j (1 <= j < 2^f) for every committed FRI layer.  O(columns) field operations."""
+    NV = V.NV
+    gamma, zeta = [int(v) for v in head["gamma"]], [int(v) for v in head["zeta"]]
+    out = [v for e in _e3_pow_list(NV.e3_inv(gamma), 8) for v in e]
+    Wt, Wall = head["W"] + head["W2"], head["W"] + head["W2"] + head["Wq"]
+    gp = [[1, 0, 0]] + _e3_pow_list(gamma, Wall + Wt - 1)
+    eza, ezb = [0, 0, 0], [0, 0, 0]
+    for k in range(Wall):
+        eza = NV.e3_add(eza, NV.e3_mul(gp[k], [int(v) for v in h["evals"]["z"][k]]))
+    for k in range(Wt):
+        ezb = NV.e3_add(ezb, NV.e3_mul(gp[Wall + k], [int(v) for v in h["evals"]["zw"][k]]))
+    wN = NV.root(expect["logn"], expect["root32"])
+    out += gp[Wall - 1] + gp[Wall + Wt - 1] + eza + ezb + zeta + [v * wN % V.P for v in zeta]
+    for (_, f), beta in zip(head["sched"], head["betas"]):
+        out += [v for e in _e3_pow_list([int(v) for v in beta], (1 << f) - 1) for v in e]
+    return out
+
+
 def _check_inner(inner, outer_publics, inner_program, rc, mds, inner_expect, n_slots):
+    """The inner proofs arrive as HEADERS: parameters, publics, roots, out-of-domain evaluations, FRI roots, final layer, grinding nonce -- no
+    query openings at all.  The verifier-AIR STARK vouches for everything that happens at the queries (paths, DEEP quotient, folds); what is
+    checked here, natively, is the part of a verifier that needs no opening (stark_verify.verify(header_only=True): parameters, the transcript
+    READ off the public inputs, the out-of-domain constraint identity, the low-degree test of the final layer, grinding) and that the outer
+    public inputs are what the headers dictate: roots; the leaf index of every (slot, proof, tree), from the transcript's query indices; the
+    transcripts; the arithmetic constants (arithmetic_publics); the final-layer value at every query's position (a lookup)."""
     if not inner:
         raise V.Reject("no inner proofs")
-    # the Merkle part of the outer public inputs has a length the shapes fix; what follows it is the inner transcripts, proof by
-    # proof: absorbed blocks and read rates in protocol order.  Every inner proof is verified on a sponge that READS them.
     probe = Program(inner_program) if not isinstance(inner_program, Program) else inner_program
-    sched, _ = V.fri_schedule(inner_expect["logn"], inner_expect["logb"], inner_expect["fri_logf"], inner_expect["fri_final_log"])
+    sched, final_log = V.fri_schedule(inner_expect["logn"], inner_expect["logb"], inner_expect["fri_logf"], inner_expect["fri_final_log"])
+    if not sched:
+        raise V.Reject("inner proofs without a committed FRI layer are not aggregated")
     T = 2 + (1 if probe.width2 else 0) + len(sched)
-    per_query = probe.width + probe.width2 + 3 * probe.q_chunks + sum(3 << f for (_, f) in sched)
-    n_merkle = len(inner) * T * 4 + n_slots * len(inner) * (T + per_query)
-    sponge = V.PublicSponge(outer_publics[n_merkle:])
+    n_merkle = len(inner) * T * 4 + n_slots * len(inner) * T
+    for h in inner:
+        if "queries" in h:
+            raise V.Reject("an aggregated proof carries no openings of its inner proofs")
+    # first pass: lengths (the transcript section is delimited by what follows it, whose length the shapes fix)
+    n_arith = 42 + sum(3 * ((1 << f) - 1) for (_, f) in sched)
+    n_tail = len(inner) * n_arith + n_slots * len(inner) * 3
+    if len(outer_publics) < n_merkle + n_tail:
+        raise V.Reject("the outer proof has too few public inputs")
+    sponge = V.PublicSponge(outer_publics[n_merkle:len(outer_publics) - n_tail])
     heads = []
     for h in inner:
         sponge.queue, sponge.avail = [], []          # a fresh sponge per proof on the one stream
-        heads.append(V.verify(h, probe, rc, mds, inner_expect, trust_openings=True, public_transcript=sponge))
+        heads.append(V.verify(h, probe, rc, mds, inner_expect, header_only=True, public_transcript=sponge))
     if sponge.pos != len(sponge.stream):
         raise V.Reject("the outer proof's public inputs hold more transcript than the inner proofs have")
     W2 = heads[0]["W2"]
@@ -113,10 +159,15 @@ def _check_inner(inner, outer_publics, inner_program, rc, mds, inner_expect, n_s
         for hd in heads:
             j = hd["indices"][g % nq]
             want += [j & ((1 << d) - 1) for d in depths]
-    for g in range(n_slots):
-        for h in inner:
-            q = h["queries"][g % nq]
-            for part in [q["trace"]] + ([q["stage2"]] if W2 else []) + [q["quotient"]] + list(q["fri"]):
-                want += [int(v) for v in part["values"]]
     if outer_publics[:n_merkle] != want:
-        raise V.Reject("the outer proof's public inputs are not the inner proofs' roots, query indices and opened values")
+        raise V.Reject("the outer proof's public inputs are not the inner proofs' roots and query indices")
+    tail = []
+    for h, hd in zip(inner, heads):
+        tail += arithmetic_publics(h, hd, inner_expect)
+    mask = (1 << final_log) - 1
+    for g in range(n_slots):
+        for h, hd in zip(inner, heads):
+            pos = hd["indices"][g % nq] & mask
+            tail += [int(h["fri"]["final"][c][pos]) for c in range(3)]
+    if outer_publics[len(outer_publics) - n_tail:] != tail:
+        raise V.Reject("the outer proof's arithmetic public inputs are not what the inner proofs' headers dictate")

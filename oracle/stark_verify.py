@@ -396,7 +396,7 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, t
             raise Reject("final FRI layer is not low degree")
 
     if header_only:
-        return {"indices": qidx, "sched": sched, "W": W, "W2": W2, "Wq": 3 * Q}
+        return {"indices": qidx, "sched": sched, "W": W, "W2": W2, "Wq": 3 * Q, "zeta": zeta, "gamma": gamma, "betas": betas}
     zeta_w = [v * wN % P for v in zeta]
     Wall = Wt + 3 * Q
     gp, cur = [], [1, 0, 0]

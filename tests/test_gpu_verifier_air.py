@@ -23,11 +23,8 @@ P = O.P
 
 
 def strip_paths(proof):
-    h = copy.deepcopy(proof)
-    for q in h["queries"]:
-        for part in [q["trace"], q["quotient"]] + ([q["stage2"]] if "stage2" in q else []) + q["fri"]:
-            del part["path"]
-    return h
+    """an inner proof as an aggregated proof carries it: the header, no openings"""
+    return {k: copy.deepcopy(v) for k, v in proof.items() if k != "queries"}
 
 
 @pytest.fixture(scope="module")
@@ -77,7 +74,7 @@ def test_aggregation_stark_gpu_equals_cpu_and_verifies(hip, tables, airname, log
         proofs.append(json.loads(PR.proof_to_json(PR.prove(air, tr, pub, params, hip))))
     shape = VA.Shape.of_proof(proofs[0], 2)
     vair = VA.verifier_air(shape, rc, mds)
-    d_gpu, pubs = VA.build_witness(shape, proofs, hip, air.digest_words())               # assembled in HBM (zp_poseidon_trace + two host columns)
+    d_gpu, pubs = VA.build_witness(shape, proofs, hip, air.digest_words())               # assembled in HBM (zp_poseidon_trace, native arithmetic columns)
     t_gpu = hip.p.download(d_gpu, d_gpu.shape)
     t_cpu, pubs_c = VA.build_witness(shape, proofs, cpu, air.digest_words())
     assert (t_gpu == t_cpu).all() and (pubs == pubs_c).all()
@@ -131,9 +128,8 @@ def test_engine_aggregate_and_final_prove_what_they_name(tables, tmp_path):
     assert fsp["air_digest"] == fair.digest() and [int(v) for v in fsp["publics"]][:fsh.merkle_pubs()] == VA.expected_publics(fsh, [agg["stark"]])
     assert V.verify(fsp, fair.program(), rc, mds, V.expectation(eng.final_stark_params(agg["stark"]).to_dict()), bn254_poseidon_params(17))
     # the final layer as a recursion layer: the aggregated proof's STARK without its paths + the final STARK = that STARK verifies
-    strip = lambda o: {k: v for k, v in o.items() if k != "path"}
-    hdr = dict(agg["stark"], queries=[{"index": q["index"], "trace": strip(q["trace"]), "quotient": strip(q["quotient"]),
-                                       "fri": [strip(f) for f in q["fri"]]} for q in agg["stark"]["queries"]])
+    assert all("queries" not in h for h in agg["inner"])           # succinct: the aggregated proof carries headers + ONE STARK
+    hdr = {k: v for k, v in agg["stark"].items() if k != "queries"}
     assert AV.verify({"inner": [hdr], "stark": fsp}, vair.program(), fair.program(), rc, mds, outer_exp,
                      V.expectation(eng.final_stark_params(agg["stark"]).to_dict()), fsh.n_slots(), bn254_poseidon_params(17))
     with pytest.raises(ValueError):

@@ -20,20 +20,15 @@ REF_PROTO = "/root/reference/proto/prover/v1/prover.proto"
 
 
 def parse_proof_like_eigen_zeth(js):
-    """the grammar of parse_proof / parse_public_input (ethereum/mod.rs:445-481): decimal strings"""
-    v = json.loads(js)
-    out = [int(v["pi_a"]["x"]), int(v["pi_a"]["y"]), int(v["pi_b"]["x"][0]), int(v["pi_b"]["x"][1]),
-           int(v["pi_b"]["y"][0]), int(v["pi_b"]["y"][1]), int(v["pi_c"]["x"]), int(v["pi_c"]["y"])]
-    for s in (v["pi_a"]["x"], v["pi_b"]["y"][1], v["pi_c"]["y"]):
-        assert isinstance(s, str) and s.isdigit()
-    assert all(0 <= x < 2 ** 256 for x in out)
-    return out
+    """parse_proof (ethereum/mod.rs:445-474) through the product's mirror of the consumer (service/consumer.py, pinned on the reference's
+    own vectors by tests/test_ref_proofs.py): the eight U256 in the order the contract receives them"""
+    from eigen_zeth_amd.service import consumer
+    return list(consumer.parse_proof(js).as_u256_tuple())
 
 
 def parse_public_input_like_eigen_zeth(js):
-    v = json.loads(js)
-    assert isinstance(v[0], str) and v[0].isdigit()
-    return int(v[0])
+    from eigen_zeth_amd.service import consumer
+    return consumer.parse_public_input(js)[0]
 
 
 def test_schema_matches_reference_proto_text():
@@ -153,9 +148,8 @@ def _check_result(res, tables, block, svc=None):
                         bn254_poseidon_params(17))
         # ... and as a recursion layer: the aggregated proof's STARK without its paths + the final STARK = that STARK verifies
         # (its arithmetic natively, its transcript read off the final STARK's public inputs, all hashing in the final STARK)
-        strip = lambda o: {k: v for k, v in o.items() if k != "path"}
-        hdr = dict(agg["stark"], queries=[{"index": q["index"], "trace": strip(q["trace"]), "quotient": strip(q["quotient"]),
-                                           "fri": [strip(f) for f in q["fri"]]} for q in agg["stark"]["queries"]])
+        assert all("queries" not in h for h in agg["inner"]) and '"values"' not in res["aggregated"].split('"stark":')[0]   # headers only
+        hdr = {k: v for k, v in agg["stark"].items() if k != "queries"}
         assert AV.verify({"inner": [hdr], "stark": fsp}, vair.program(), fair.program(), rc, mds, outer_exp,
                          V.expectation(svc.engine.final_stark_params(agg["stark"]).to_dict()), fsh.n_slots(), bn254_poseidon_params(17))
     # ProofResult as eigen-zeth stores it (src/db/mod.rs:63-71): json with 32-number arrays

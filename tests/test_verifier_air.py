@@ -1,7 +1,8 @@
-"""The STARK-verifier AIR, stage A (eigen_zeth_amd/stark/verifier_air.py): GenAggregatedProof and the final STARK prove what
-they name -- the Merkle part of verifying the inner proofs (proto/prover/v1/prover.proto:115-148; client
-src/prover/provider.rs:422-503).  CPU tests: the product's AIR / witness builder / orchestration over the checker's backend,
-judged by the checker's independent verifiers (oracle/stark_verify.py, oracle/aggregate_verify.py)."""
+"""The STARK-verifier AIR (eigen_zeth_amd/stark/verifier_air.py): GenAggregatedProof and the final STARK prove what they name -- everything a
+verifier of the inner proofs does at their queries: Merkle paths, DEEP quotient, FRI folds, with the opened values PRIVATE -- plus their
+Fiat-Shamir transcripts (proto/prover/v1/prover.proto:115-148; client src/prover/provider.rs:422-503).  CPU tests: the product's AIR /
+witness builder / orchestration over the checker's backend, judged by the checker's independent verifiers (oracle/stark_verify.py,
+oracle/aggregate_verify.py)."""
 import copy
 import json
 
@@ -21,12 +22,8 @@ P = O.P
 
 
 def strip_paths(proof):
-    """an inner proof as an aggregated proof carries it: everything but the authentication paths"""
-    h = copy.deepcopy(proof)
-    for q in h["queries"]:
-        for part in [q["trace"], q["quotient"]] + ([q["stage2"]] if "stage2" in q else []) + q["fri"]:
-            del part["path"]
-    return h
+    """an inner proof as an aggregated proof carries it: its header -- no query openings at all"""
+    return {k: copy.deepcopy(v) for k, v in proof.items() if k != "queries"}
 
 
 @pytest.fixture(scope="module")
@@ -139,12 +136,35 @@ def test_forged_witnesses_are_rejected(inner, aggregated, cpu, tables):
     t5 = trace.copy()
     t5[VA.U0, 5] = (int(t5[VA.U0, 5]) + 1) % P                                        # a wrong cube
     rejected(t5, pubs)
+    # ---- the arithmetic on the private openings
     p6 = pubs.copy()
-    p6[shape.pub_value(2, 1, 0, 5)] = (int(p6[shape.pub_value(2, 1, 0, 5)]) + 1) % P   # claim another opened value than the hashed one
+    p6[shape.pub_arith(1, VA.AP_EZA)] = (int(p6[shape.pub_arith(1, VA.AP_EZA)]) + 1) % P   # another E_z: the DEEP value no longer matches layer 0
     rejected(trace, p6)
     p7 = pubs.copy()
-    p7[shape.pub_value(0, 0, 2, 1)] = (int(p7[shape.pub_value(0, 0, 2, 1)]) + 1) % P   # ... of an unhashed (3-value) quotient leaf
+    p7[shape.pub_finv(2, 0, 1)] = (int(p7[shape.pub_finv(2, 0, 1)]) + 1) % P               # another final-layer value than the last fold gives
     rejected(trace, p7)
+    p12 = pubs.copy()
+    p12[shape.pub_arith(0, shape.ap_beta(0, 1, 0))] = (int(p12[shape.pub_arith(0, shape.ap_beta(0, 1, 0))]) + 1) % P      # fold at another beta
+    rejected(trace, p12)
+    p13 = pubs.copy()
+    p13[shape.pub_arith(0, VA.AP_G + 3)] = (int(p13[shape.pub_arith(0, VA.AP_G + 3)]) + 1) % P    # a wrong power of 1 / gamma
+    rejected(trace, p13)
+    fri_abs = next(i for i, blk in enumerate(sched) if blk["kind"] == "absorb" and blk["t"] == shape.t_quot + 1)
+    for col, row in ((VA.HR0 + 2, 32 * fri_abs + 3),         # a register that is not the hashed value
+                     (VA.ACA0, 32 * fri_abs + 1),             # a partial sum of the interpolation
+                     (VA.ACB0 + 1, 32 * fri_abs + 2),         # ... of the fold
+                     (VA.COL_TPX, 32 * fri_abs + 1),          # a power of 1 / x
+                     (VA.COL_TAU, 32 * fri_abs + 5),          # tau changed in the middle of a layer
+                     (VA.COL_X, 32 * (fri_abs + 2) + 7)):     # the evaluation point changed inside a block
+        tt = trace.copy()
+        tt[col, row] = (int(tt[col, row]) + 1) % P
+        rejected(tt, pubs)
+    # an opened value changed TOGETHER with every hash above it would need a second preimage; changed alone (registers and state of its
+    # absorb block, rest of the permutation untouched) it breaks the round constraints
+    t14 = trace.copy()
+    t14[VA.S0 + 1, 32 * fri_abs] = (int(t14[VA.S0 + 1, 32 * fri_abs]) + 1) % P
+    t14[VA.HR0 + 1, 32 * fri_abs:32 * fri_abs + 32] = t14[VA.S0 + 1, 32 * fri_abs]
+    rejected(t14, pubs)
     assert len(pubs) > PR.PUBLICS_INLINE                                              # the publics enter the transcript through their digest
     # the transcripts: a claimed challenge that the sponge does not give, an absorbed value other than the hashed one, a cell of
     # a transcript permutation, a broken capacity chain
@@ -185,8 +205,12 @@ def test_outer_publics_must_follow_the_inner_transcripts(inner, aggregated, tabl
     with pytest.raises(V.Reject, match="public inputs|public transcript"):
         AV.verify(bad, *args)
     bad = copy.deepcopy(agg)
-    v = bad["inner"][0]["queries"][1]["fri"][1]["values"]      # an opened value that is not the committed one: the inner proof's own
-    v[2] = (v[2] + 1) % P                                      # fold check fails natively (and it would not match the outer publics)
+    bad["inner"][0]["queries"] = []                            # an aggregated proof carries no openings
+    with pytest.raises(V.Reject, match="no openings"):
+        AV.verify(bad, *args)
+    assert all("queries" not in h for h in agg["inner"])
+    bad = copy.deepcopy(agg)
+    bad["inner"][1]["evals"]["zw"][3][2] ^= 1                  # changes E_zw (and the transcript): the arithmetic publics no longer follow
     with pytest.raises(V.Reject):
         AV.verify(bad, *args)
     bad = copy.deepcopy(agg)
@@ -297,3 +321,39 @@ def test_aggregated_proofs_fold_again(inner, aggregated, cpu, tables):
     del bad["children"]                                                      # the chunk proofs withheld
     with pytest.raises((V.Reject, KeyError, ValueError)):
         AV.verify_tree(bad, *args)
+
+
+@pytest.mark.parametrize("case", ["chunk16", "fib-single"])
+def test_native_arithmetic_builder_equals_the_reference_walk(cpu, tables, inner, case):
+    """zp_verifier_arith_host (csrc/recursion.hip: host C++ walk over the schedule descriptor + expansion; needs no GPU) writes the same 21
+    columns as the readable reference (verifier_air.arith_columns), for mixed fold factors, stage-2 trees, unhashed leaves and a
+    one-proof shape; inconsistent openings are refused by both"""
+    if case == "chunk16":
+        air, _, proofs = inner
+    else:
+        air = AIR.get_air("fib")
+        tr, pub = native.synth_trace(air.trace_kind, 5, air.width, 9)
+        proofs = [json.loads(PR.proof_to_json(PR.prove(air, tr, pub, PR.StarkParams(5, 1, 2, 3, 3, pow_bits=0), cpu)))]
+    shape = VA.Shape.of_proof(proofs[0], len(proofs))
+    keep = {}
+    trace, _ = VA.build_witness(shape, proofs, cpu, air.digest_words(), keep=keep)
+    got = native.verifier_arith_host(VA.arith_descriptor(shape), keep["arith_in"], threads=3)
+    assert got.shape == (VA.WIDTH - VA.HR0, trace.shape[1]) and (got == trace[VA.HR0:]).all()
+    assert (native.verifier_arith_host(VA.arith_descriptor(shape), keep["arith_in"], threads=1) == got).all()
+    # a final-layer value that the last fold does not give / an opened value of a FRI leaf that the interpolation does not reproduce
+    bad = dict(keep["arith_in"], fin=keep["arith_in"]["fin"].copy())
+    bad["fin"][1, 0, 2] ^= np.uint64(1)
+    with pytest.raises(ValueError, match="no accepting witness"):
+        native.verifier_arith_host(VA.arith_descriptor(shape), bad)
+    with pytest.raises(ValueError, match="no accepting witness"):
+        VA.arith_columns(shape, bad)
+    ops = VA._opening_table(shape)
+    o = int(ops["sel"][(0, shape.t_quot + 1)][1])
+    bad = dict(keep["arith_in"], vals=keep["arith_in"]["vals"].copy())
+    bad["vals"][o, 1] = (int(bad["vals"][o, 1]) + 1) % P
+    with pytest.raises(ValueError, match="no accepting witness"):
+        native.verifier_arith_host(VA.arith_descriptor(shape), bad)
+    with pytest.raises(ValueError, match="no accepting witness"):
+        VA.arith_columns(shape, bad)
+    with pytest.raises(native.ZpError):
+        native.verifier_arith_host(VA.arith_descriptor(shape)[:-1], keep["arith_in"])
