@@ -3,11 +3,16 @@
 
 One step = one pass of the hot path over one batch: a natural-order forward NTT (zp_ntt through the
 C-ABI) of the rank's column shard u64[cols][2^logn], resident in HBM before the timed region.
-Columns are independent, so ranks shard columns with no data-path collective ("scaling": "weak":
-every GPU always owns `--cols` columns).  Rank 0 prints ONE JSON line.
+Columns are independent, so ranks shard columns with no data-path collective.  "scaling": "weak" (default): every GPU
+always owns `--cols` columns.  --scaling strong: BASELINE configs[3] as stated -- `--cols` columns IN TOTAL, cols / N per GPU
+(64 columns, 8 per GPU on 8 GPUs).  Rank 0 prints ONE JSON line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--logn 24] [--cols 64]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--logn 24] [--cols 64] [--scaling weak|strong]
   N > 1 is launched by torch.distributed.run (one process per GPU, RCCL for the barrier/MAX only).
+
+The exchange step the path really has -- column shards -> row shards before leaf hashing, ONE all-to-all over xGMI -- is timed in its own
+K-step loops ("pipeline.exchange": the bare all-to-all with GB/s per link, and the whole sharded commitment zp_merkle_commit_sharded;
+median + min), on the RCCL communicator behind the C-ABI (a communicator of one rank at N = 1).
 
 Extra objects on the line: "roofline" (dominant kernel, HIP-event timing of every pass launch taken
 live inside this run), "cpu_baseline" (oracle/ CPU restatement timed on this host, rank 0, N=1) and
@@ -177,10 +182,16 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=24)
-    ap.add_argument("--cols", type=int, default=64, help="columns per GPU")
+    ap.add_argument("--cols", type=int, default=64, help="columns per GPU (--scaling weak) or in total (--scaling strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --cols columns per GPU; strong: --cols columns in total, cols / N per GPU (BASELINE configs[3]: 64 columns, 8 per GPU)")
     ap.add_argument("--stark-logn", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4]-on-one-GPU probe (64 chunks x 2^22 rows + the wrap's 2^26-point MSMs)")
+    ap.add_argument("--c5-chunks", type=int, default=64)
+    ap.add_argument("--c5-logn", type=int, default=22)
+    ap.add_argument("--c5-msm-log", type=int, default=26)
     ap.add_argument("--stage-roofline", action="store_true",
                     help="cpu_baseline leg also times every hot-path stage on GPU and CPU restatement (tools/stage_roofline.py)")
     ap.add_argument("--child-probe", default=None, help=argparse.SUPPRESS)
@@ -190,7 +201,10 @@ def main():
         # the engine-level probe in a process of its own, as the service runs: WITHOUT torch.  With torch's CUDA context in the
         # process the library runs on the HIP runtime bundled with the torch wheel and the 8-stream batch measured 0.76 s
         # instead of 0.53 s (profiles/r2_pretorch.txt); torch is plumbing of this benchmark, not of the prover service.
-        print(json.dumps(batch_proof_probe(int(args.child_probe))), flush=True)
+        if args.child_probe.startswith("config5"):
+            print(json.dumps(config5_probe(*[int(v) for v in args.child_probe.split(":")[1:]])), flush=True)
+        else:
+            print(json.dumps(batch_proof_probe(int(args.child_probe))), flush=True)
         return
 
     import torch
@@ -222,6 +236,10 @@ def main():
     from eigen_zeth_amd.native import Prover
 
     logn, cols = args.logn, args.cols
+    if args.scaling == "strong":
+        if cols % world:
+            raise SystemExit("--scaling strong: %d columns do not split over %d GPUs" % (cols, world))
+        cols //= world
     N = 1 << logn
     prover = Prover(local, stream=torch.cuda.current_stream().cuda_stream)
     if os.environ.get("ZP_NTT_TW1"):          # A/B knob: 0 = per-lane twiddle chains in the first pass instead of the full table
@@ -328,13 +346,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": wall_max * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "forward NTT, natural order in/out, 2^%d rows x %d columns per GPU (column-major u64), "
-                                   "BASELINE configs[3] shape on one GPU" % (logn, cols),
-                       "logn": logn, "cols_per_gpu": cols, "sharding": "columns, no data-path collective",
+            "config": {"workload": ("forward NTT, natural order in/out, 2^%d rows x %d columns per GPU (column-major u64), "
+                                    "BASELINE configs[3] shape on one GPU" % (logn, cols)) if args.scaling == "weak" else
+                                   ("forward NTT, natural order in/out, 2^%d rows x %d columns in total, %d per GPU (column-major u64): BASELINE "
+                                    "configs[3] as stated" % (logn, cols * world, cols)),
+                       "logn": logn, "cols_per_gpu": cols, "cols_total": cols * world, "sharding": "columns, no data-path collective",
                        "plan": plan},
             "device_ms_per_step": dev_ms / args.steps,
             "device_ms_per_step_median": per_step[len(per_step) // 2],
@@ -383,7 +403,7 @@ def main():
         del x
         torch.cuda.empty_cache()
         try:   # every rank takes part (all-to-all); reported by rank 0, outside the K timed steps
-            pipe = pipeline_probe(torch, dist, prover, dev, logn, min(cols, 32), world)
+            pipe = pipeline_probe(torch, dist, prover, dev, logn, min(cols, 32), world, args.steps)
         except Exception as e:
             pipe = {"error": repr(e)}
 
@@ -423,6 +443,17 @@ def main():
                 extra["batch_proof"]["process"] = "child process without torch (the service's configuration)"
             except Exception as e:
                 extra["batch_proof"] = {"error": repr(e)}
+            if not args.no_config5:
+                # BASELINE configs[4] on ONE GPU: 64 chunks x 2^22 rows x (64 + 12) columns, recursion, the wrap's MSM sizes
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-probe", "config5:%d:%d:%d" % (args.c5_chunks, args.c5_logn, args.c5_msm_log)],
+                                       capture_output=True, text=True, timeout=1500)
+                    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                    if r.returncode != 0 or not lines:
+                        raise RuntimeError("config5 probe failed: " + (r.stderr or r.stdout)[-600:])
+                    extra["batch_proof"]["config5_one_gpu"] = json.loads(lines[-1])
+                except Exception as e:
+                    extra["batch_proof"]["config5_one_gpu"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:
             extra["cpu_baseline"] = cpu_baseline(logn, 32)
             try:
@@ -450,7 +481,54 @@ def main():
         dist.destroy_process_group()
 
 
-def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
+def _stats(ms):
+    ms = sorted(ms)
+    return {"median_ms": ms[len(ms) // 2], "min_ms": ms[0], "max_ms": ms[-1], "steps": len(ms)}
+
+
+def exchange_probe(torch, comm, prover, y, M, cols, world, steps, barrier):
+    """THE exchange step of the path, timed like the headline: `steps` timed repetitions after 2 warm-ups, barrier before each, wall-clock per
+    call (a collective of this library returns when it is complete on the stream), median / min / max.
+      all_to_all        the packed column shards [G][cols][M/G] through zp_comm_all_to_all (grouped ncclSend/ncclRecv: every pairwise message on
+                        its own xGMI link): per-peer message = 8 cols M / G bytes; GB/s per link = that / time
+      sharded_commit    zp_merkle_commit_sharded: pack + all-to-all + local subtree over M/G rows of all G cols columns + all-gather of sub-roots
+    At N = 1 the communicator has one rank (send / recv to self): the code path, not xGMI."""
+    dev = y.device
+    Mloc = M // world
+    words_per_peer = cols * Mloc
+    pack = torch.empty((cols * M,), dtype=torch.int64, device=dev)
+    rows = torch.empty((cols * M,), dtype=torch.int64, device=dev)
+    tl = torch.empty(((2 * Mloc - 1) * 4,), dtype=torch.int64, device=dev)
+    prover.pack_blocks(y, pack, cols, M, world) if world > 1 else pack.copy_(y.reshape(-1))
+    a2a, com, root = [], [], None
+    for it in range(steps + 2):
+        barrier()
+        t0 = time.perf_counter()
+        comm.all_to_all(pack, rows, words_per_peer)
+        torch.cuda.synchronize()
+        if it >= 2:
+            a2a.append((time.perf_counter() - t0) * 1e3)
+    for it in range(steps + 2):
+        barrier()
+        t0 = time.perf_counter()
+        root = comm.merkle_commit_sharded(y, M, cols, tl)
+        torch.cuda.synchronize()
+        if it >= 2:
+            com.append((time.perf_counter() - t0) * 1e3)
+    per_peer = 8.0 * words_per_peer
+    st = _stats(a2a)
+    res = {"world": world, "rows": M, "cols_per_gpu": cols,
+           "all_to_all": dict(st, per_peer_message_bytes=per_peer, GBs_per_link_median=per_peer / (st["median_ms"] * 1e-3) / 1e9,
+                              GBs_per_link_best=per_peer / (st["min_ms"] * 1e-3) / 1e9,
+                              GBs_out_per_gpu_median=(world - 1) * per_peer / (st["median_ms"] * 1e-3) / 1e9,
+                              xgmi_link_peak_GBs_bidirectional=153.0,
+                              note="per-rank wall-clock around zp_comm_all_to_all; at N = 1 a copy to self, not a link"),
+           "sharded_commit": dict(_stats(com), root=[hex(v) for v in root])}
+    del pack, rows, tl
+    return res
+
+
+def pipeline_probe(torch, dist, prover, dev, logn, cols, world, steps=10):
     """commit stage of one trace shard: LDE (blow-up 2) of this rank's columns, then -- for N > 1 -- the
     column->row all-to-all over xGMI (eigen_zeth_amd/multigpu.py), then Poseidon leaf hashing + Merkle
     subtree of the local rows and the all-gather of sub-roots.  Timed once after one warm-up."""
@@ -506,10 +584,10 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
     # what a compiled host uses; must give the root of the torch.distributed path above.  RCCL wants one rank per GPU, so the
     # one-GPU rehearsal (gloo backend) skips it.
     direct_comm, grp1 = None, None
-    if world > 1 and dist.get_backend() == "nccl":
+    if (world > 1 and dist.get_backend() == "nccl") or (world == 1 and os.environ.get("ZP_BENCH_BACKEND", "nccl") == "nccl"):
         try:
             from eigen_zeth_amd import native as _nat
-            rk = dist.get_rank()
+            rk = dist.get_rank() if world > 1 else 0
             msg = torch.zeros(129, dtype=torch.int64, device=dev)
             if rk == 0:
                 try:
@@ -517,9 +595,11 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
                     msg[0] = 1
                 except Exception:
                     pass
-            multigpu.broadcast(msg, 0)
+            if world > 1:
+                multigpu.broadcast(msg, 0)
             if int(msg[0].item()) == 1:
                 comm = _nat.Comm(prover, rk, world, bytes(int(v) for v in msg[1:].tolist()))
+                comm.set_timeout_ms(60000)          # a peer that never arrives ends the probe with an error instead of the watchdog
                 tl = torch.empty(((2 * Mloc - 1) * 4,), dtype=torch.int64, device=dev)
                 for it in range(2):
                     torch.cuda.synchronize()
@@ -530,6 +610,16 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world):
                 res["rccl_direct"] = {"sharded_commit_ms": dt * 1e3, "root_matches_torch_path": [hex(v) for v in r2] == res["root"],
                                       "note": "zp_merkle_commit_sharded: exchange + hashing in one C-ABI call, wall-clock"}
                 del tl
+
+                def _barrier():
+                    torch.cuda.synchronize()
+                    if world > 1:
+                        dist.barrier()
+                try:
+                    res["exchange"] = exchange_probe(torch, comm, prover, y, M, cols, world, steps, _barrier)
+                    res["exchange"]["root_matches_torch_path"] = res["exchange"]["sharded_commit"]["root"] == res["root"]
+                except Exception as ex:
+                    res["exchange"] = {"error": repr(ex)}
                 direct_comm = comm            # kept for the four-step NTT below, closed there
             else:
                 res["rccl_direct"] = {"error": "rank 0 could not make an RCCL id"}
@@ -711,6 +801,108 @@ def engine_batch_probe(K, logn, air_name, device=0, tag=""):
                 "stark_security_bits": eng.stark_params(logn).security_bits(),
                 "note": "wall_s = prover only (witnesses pre-generated); the synthetic generator is host code (about 0.2 s per 2^20 x 64 chunk)"})
     return res
+
+
+def config5_probe(K=64, logn=22, msm_log=26, air_name="chunk64"):
+    """BASELINE configs[4] on ONE GPU (64 chunk-sized STARKs as C3 -- 2^22 rows x 64 + 12 columns -- + the Groth16 wrap's
+    2^26-point MSMs), through service/engine.py as the service runs it (no gRPC, no torch), at the service's default security:
+      chunk proofs        K x zp_stark_prove on 8 streams, witnesses from the synthetic generator (host code standing in for the executor)
+      recursion           the client's contract: GenAggregatedProof(first, last) -> GenFinalProof (final STARK in BN128-hash mode + wrap);
+                          and the fold of ALL K chunk proofs as a binary tree of GenAggregatedProof calls (K - 1 aggregation STARKs) under one
+                          final proof -- what a batch-covering proof costs with this prover's pairwise aggregation
+      the wrap's MSMs     four G1 + one G2 multi-scalar multiplications of 2^msm_log points beside it: the wrap circuit of this build is a
+                          stand-in of 2^8 constraints, so the MSM sizes BASELINE names are timed on synthetic points, labelled
+    One warm-up batch of 8 chunks first (CRS, buffer pools, plan tables)."""
+    import ctypes as C
+    import random
+    import tempfile
+    import numpy as np
+    from eigen_zeth_amd.native import DeviceBuffer
+    from eigen_zeth_amd.service import bn254
+    from eigen_zeth_amd.service.engine import Engine, EngineConfig
+    from eigen_zeth_amd.service.server import default_backend_factory
+    cfg = EngineConfig(air=air_name, logn=logn, groth16_logm=8, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_c5_%d" % os.getuid()),
+                       witness_threads=6)           # 2 GiB of page-locked witness per chunk in flight at 2^22 x 64
+    eng = Engine(default_backend_factory(0), cfg)
+    eng.groth16_keys()
+    out = {"workload": "%d chunks x 2^%d rows x (64 + 12) columns, %d bits conjectured; recursion; 4 G1 + 1 G2 MSMs of 2^%d points"
+                       % (K, logn, eng.stark_params(logn).security_bits(), msm_log)}
+    addr = "479881985774944702531460751064278034642760119942"
+
+    def batch(n, label, tree):
+        r = {}
+        t0 = time.perf_counter()
+        ch = eng.gen_batch_chunks(label, list(range(1, n + 1)), 12345, "evm")
+        proofs = eng.gen_chunk_proofs(label, ch["task_id"], ch["chunk_count"], ch["batch_data"])
+        t1 = time.perf_counter()
+        agg = eng.aggregate(label, proofs[0]["proof"], proofs[-1]["proof"])
+        t2 = time.perf_counter()
+        eng.final(label, agg, "BN128", addr)
+        t3 = time.perf_counter()
+        wit = sum(v.get("witness(host)", 0.0) for k, v in eng.stage_timings.items() if k.startswith(ch["task_id"] + "/"))
+        r.update({"chunk_proofs_s": t1 - t0, "witness_generator_cpu_s_summed_over_threads": wit, "aggregate_first_last_s": t2 - t1, "final_s": t3 - t2,
+                  "wall_s": t3 - t0, "aggregated_proof_bytes": len(agg)})
+        if tree and n >= 4:
+            t0 = time.perf_counter()
+            level = [p["proof"] for p in proofs]
+            n_aggs = 0
+            while len(level) > 1:
+                nxt = []
+                for i in range(0, len(level) - 1, 2):
+                    nxt.append(eng.aggregate(label, level[i], level[i + 1]))
+                    n_aggs += 1
+                if len(level) % 2:
+                    nxt.append(level[-1])
+                level = nxt
+            t1 = time.perf_counter()
+            eng.final(label, level[0], "BN128", addr)
+            t2 = time.perf_counter()
+            r["fold_all_chunks"] = {"aggregation_starks": n_aggs, "fold_s": t1 - t0, "final_s": t2 - t1, "top_proof_bytes": len(level[0]),
+                                    "wall_s_chunks_plus_fold_plus_final": r["chunk_proofs_s"] + (t2 - t0)}
+        return r
+    batch(8 if K >= 8 else K, "warm", False)
+    out["batch"] = batch(K, "c5", True)
+    out["wall_s"] = out["batch"]["wall_s"]
+    # ---- the MSM sizes of a 2^26-constraint wrap, on the same GPU
+    try:
+        p = eng.be.p
+        rnd, g = random.Random(3), np.random.default_rng(7)
+        n, chunk = 1 << msm_log, 1 << min(msm_log, 20)
+        t1 = np.array([[(c >> (32 * k)) & 0xFFFFFFFF for c in pt for k in range(8)] for pt in [bn254.g1_mul(rnd.randrange(1, bn254.R)) for _ in range(32)]],
+                      dtype=np.uint32)
+        t2 = np.array([[(c >> (32 * k)) & 0xFFFFFFFF for c in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]) for k in range(8)]
+                       for pt in [bn254.g2_mul(rnd.randrange(1, bn254.R)) for _ in range(16)]], dtype=np.uint32)
+        scs = g.integers(0, 1 << 32, size=(n, 8), dtype=np.uint64).astype(np.uint32)
+        scs[:, 7] &= 0x1FFFFFFF
+        d_s = DeviceBuffer(p, scs.size // 2)
+        p._chk(p.lib.zp_h2d(p.ctx, d_s.ptr, scs.ctypes.data, scs.nbytes))
+        del scs
+
+        def tiled(tab, words):             # one 2^20-point slice from the host, replicated on the device
+            sl = np.ascontiguousarray(tab[g.integers(0, len(tab), size=chunk)])
+            d = DeviceBuffer(p, n * words // 2)
+            p._chk(p.lib.zp_h2d(p.ctx, d.ptr, sl.ctypes.data, sl.nbytes))
+            for i in range(1, n // chunk):
+                p._chk(p.lib.zp_d2d(p.ctx, d.offset(i * chunk * words // 2), d.ptr, sl.nbytes))
+            return d
+        d_p1, d_p2 = tiled(t1, 16), tiled(t2, 32)
+        o1, o2 = (C.c_uint32 * 16)(), (C.c_uint32 * 32)()
+        p._chk(p.lib.zp_msm_bn254(p.ctx, d_p1.ptr, d_s.ptr, n, o1))
+        ta = time.perf_counter()
+        for _ in range(4):
+            p._chk(p.lib.zp_msm_bn254(p.ctx, d_p1.ptr, d_s.ptr, n, o1))
+        tb = time.perf_counter()
+        p._chk(p.lib.zp_msm_bn254_g2(p.ctx, d_p2.ptr, d_s.ptr, n, o2))
+        tc = time.perf_counter()
+        out["wrap_msm_sizes"] = {"points": n, "g1_4x_s": tb - ta, "g2_1x_s": tc - tb,
+                                 "note": "synthetic points (a 2^20-point slice of a 32 / 16-point table, tiled) and uniform 253-bit scalars; NOT part of wall_s: "
+                                         "the wrap circuit of this build has 2^8 constraints"}
+        out["wall_s_plus_wrap_msm_sizes"] = out["wall_s"] + (tc - ta)
+        for d in (d_s, d_p1, d_p2):
+            d.free()
+    except Exception as e:
+        out["wrap_msm_sizes"] = {"error": repr(e)}
+    return out
 
 
 def cpu_stark_baseline(logn, air_name="chunk64"):
