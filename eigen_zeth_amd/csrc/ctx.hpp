@@ -80,6 +80,8 @@ struct zp_ctx {
     std::multimap<size_t, void *> prove_pool;
     size_t prove_pool_bytes = 0;
     std::map<std::string, u64 *> prove_fixed;
+    struct DigestEntry { std::vector<uint64_t> words; uint8_t dg[32]; };
+    std::vector<DigestEntry> digest_cache;   // SHA-256 of the large constraint programs seen last (csrc/prove.hip: program_digest)
     // per-launch event profiling (zp_set_profiling)
     bool profiling = false;
     struct PassEv { hipEvent_t a, b; int radix_log; };

@@ -64,6 +64,25 @@ struct Sha256 {
     }
 };
 
+// The program of a verifier AIR is megabytes (one table entry per scheduled row of every sparse column) and the same blob comes back proof
+// after proof: its digest is kept per ctx next to a copy of the blob (compared word for word: a cache hit is a memcmp, not a trust decision).
+void program_digest(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, uint8_t dg[32]) {
+    if (program_words < (1u << 14)) {                     // small statements: hashing is cheaper than remembering
+        Sha256::digest((const uint8_t *)h_program, program_words * 8, dg);
+        return;
+    }
+    for (auto &e : ctx->digest_cache)
+        if (e.words.size() == program_words && memcmp(e.words.data(), h_program, program_words * 8) == 0) {
+            memcpy(dg, e.dg, 32);
+            return;
+        }
+    Sha256::digest((const uint8_t *)h_program, program_words * 8, dg);
+    if (ctx->digest_cache.size() >= 4) ctx->digest_cache.erase(ctx->digest_cache.begin());
+    ctx->digest_cache.emplace_back();
+    ctx->digest_cache.back().words.assign(h_program, h_program + program_words);
+    memcpy(ctx->digest_cache.back().dg, dg, 32);
+}
+
 // ---- the Fiat-Shamir sponges of stark/transcript.py.  Goldilocks mode: Poseidon-12, rate 8 / capacity 4, on zp_poseidon_sponge.
 // BN128 mode: Poseidon-BN254 of width 17 (element 0 = capacity, 1..16 = rate) on zp_poseidon_bn254_sponge; Goldilocks values are
 // absorbed three to a field element (every absorb call padded on its own), a Merkle root is one element, and the challenges
@@ -335,7 +354,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
 
     // AIR digest: sha256 of the blob; the first 16 hex digits name it, four little-endian words go into the transcript
     uint8_t dg[32];
-    Sha256::digest((const uint8_t *)h_program, program_words * 8, dg);
+    program_digest(ctx, h_program, program_words, dg);
     char dg_hex[17];
     for (int i = 0; i < 8; i++) snprintf(dg_hex + 2 * i, 3, "%02x", dg[i]);
     std::vector<u64> first = {(u64)logn, (u64)logb, (u64)W, (u64)W2, (u64)fri_logf, (u64)fri_final_log, (u64)n_queries, (u64)pow_bits, root32, shift};
@@ -821,7 +840,7 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     DevBufs dev(ctx);
 
     uint8_t dg[32];
-    Sha256::digest((const uint8_t *)h_program, program_words * 8, dg);
+    program_digest(ctx, h_program, program_words, dg);
     char dg_hex[17];
     for (int i = 0; i < 8; i++) snprintf(dg_hex + 2 * i, 3, "%02x", dg[i]);
     std::vector<u64> first = {(u64)logn, (u64)logb, (u64)W, (u64)W2, (u64)fri_logf, (u64)fri_final_log, (u64)n_queries, (u64)pow_bits, root32, shift};

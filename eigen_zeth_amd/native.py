@@ -101,6 +101,10 @@ SIGNATURES = {
     "zp_domain_tables": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int32)]),
     "zp_synth_trace": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p]),
     "zp_synth_trace_bound": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, C.c_int32, _u64p, _u64p]),
+    "zp_json_key_span": (C.c_int32, [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "zp_proof_queries_scan": (C.c_int32, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int32), _vp, _vp, C.c_int32]),
+    "zp_proof_queries_parse": (C.c_int32, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "zp_verifier_arith_host": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "zp_verifier_arith_trace": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "zp_comm_unique_id": (C.c_int32, [_vp]),
@@ -244,6 +248,41 @@ class DeviceBuffer:
 def device_count():
     """visible HIP devices, through the library (no torch: a process that loads the system RCCL must not import torch's copy later)"""
     return int(load_library().zp_device_count())
+
+
+def json_key_span(data, key):
+    """(begin, end) of the value of member `key` of the JSON object in `data` (bytes), or None"""
+    b, e = C.c_size_t(0), C.c_size_t(0)
+    if load_library().zp_json_key_span(data, len(data), key.encode(), C.byref(b), C.byref(e)) != 0:
+        return None
+    return b.value, e.value
+
+
+def parse_proof_queries(data):
+    """The query openings of a proof text (bytes) as arrays, parsed by the library (csrc/proofparse.hip): returns (q_begin, q_end, {"index":
+    u64[nq], "values": [u64[nq][w] per tree], "paths": [u64[nq][depth][4] per tree], "has_stage2", "n_fri"}) with the trees in the order trace,
+    [stage2], quotient, fri0 ..; None when the text is not in the grammar the provers write (the caller then uses its JSON parser)."""
+    lib = load_library()
+    qb, qe = C.c_size_t(0), C.c_size_t(0)
+    nq, s2, nf = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    w, d = np.zeros(48, dtype=np.int32), np.zeros(48, dtype=np.int32)
+    if lib.zp_proof_queries_scan(data, len(data), C.byref(qb), C.byref(qe), C.byref(nq), C.byref(s2), C.byref(nf), w.ctypes.data, d.ctypes.data, 48) != 0:
+        return None
+    T, n = 2 + s2.value + nf.value, nq.value
+    w, d = w[:T].copy(), d[:T].copy()
+    index = np.empty(n, dtype=np.uint64)
+    values = np.empty(n * int(w.sum()), dtype=np.uint64)
+    paths = np.empty(n * int(d.sum()) * 4, dtype=np.uint64)
+    if lib.zp_proof_queries_parse(data, qb.value, qe.value, n, s2.value, nf.value, w.ctypes.data, d.ctypes.data, index.ctypes.data, values.ctypes.data,
+                                  paths.ctypes.data) != 0:
+        return None
+    vs, ps, vo, po = [], [], 0, 0
+    for t in range(T):
+        vs.append(values[vo:vo + n * int(w[t])].reshape(n, int(w[t])))
+        ps.append(paths[po:po + n * int(d[t]) * 4].reshape(n, int(d[t]), 4))
+        vo += n * int(w[t])
+        po += n * int(d[t]) * 4
+    return qb.value, qe.value, {"index": index, "values": vs, "paths": ps, "has_stage2": bool(s2.value), "n_fri": nf.value}
 
 
 def _arith_args(desc, a):

@@ -55,7 +55,7 @@ class EngineConfig:
                  groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
                  witness_threads=8, prover_streams=8, pow_bits=20,
                  final_air="chunk16", final_logn=10, final_logb=2, final_queries=50, native_prover=True,
-                 agg_queries=50, agg_pow_bits=0, aggregate_all_chunks=False):
+                 agg_queries=50, agg_pow_bits=0, aggregate_all_chunks=False, groth16_seed=None):
         self.air, self.logn, self.logb = air, logn, logb
         # GenAggregatedProof names two proofs -- the client sends the first and the last chunk proof of a batch
         # (src/prover/provider.rs:385-388).  False: exactly those two are verified (the wire contract taken literally).  True: when
@@ -63,6 +63,11 @@ class EngineConfig:
         # by the one aggregation STARK (n_proofs = chunk count: the final proof then covers the whole batch, at ~ chunk count / 2
         # times the aggregation cost).
         self.aggregate_all_chunks = aggregate_all_chunks
+        # Blinding of the final Groth16 proof.  None (the service default): fresh (r, s) from the OS per proof -- zero knowledge.  A string:
+        # (r, s) = SHA-256(seed | final-STARK digest | recursive proof | aggregator address | "r" / "s") -- every run, on any backend, writes
+        # the SAME proof.json for the same request ("identical proof/proof.json" of BASELINE.json made testable).  A test /
+        # reproduction mode: blinding that anybody can recompute hides nothing.
+        self.groth16_seed = groth16_seed
         self.chunks_per_block, self.n_queries, self.pow_bits = chunks_per_block, n_queries, pow_bits
         self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
         self.groth16_logm, self.crs_dir = groth16_logm, crs_dir
@@ -77,6 +82,8 @@ class EngineConfig:
 
 
 class Engine:
+    FAST_PARSE_MIN = 1 << 16      # proof texts from this size on have their openings parsed by the library (csrc/proofparse.hip)
+
     def __init__(self, backend_factory, config=None):
         self._factories = list(backend_factory) if isinstance(backend_factory, (list, tuple)) else [backend_factory]
         self._factory = self._factories[0]
@@ -302,18 +309,49 @@ class Engine:
         return hashlib.sha256(s.encode()).hexdigest()
 
     @staticmethod
+    def _check_params(obj, n_queries_seen):
+        pr, lim = obj["params"], {"logn": 28, "logb": 8, "fri_logf": 8, "fri_final_log": 16, "n_queries": 4096, "pow_bits": 64}
+        if any(not isinstance(pr.get(k), int) or isinstance(pr.get(k), bool) or not 0 <= pr[k] <= m for k, m in lim.items()) \
+                or pr["logn"] < 1 or pr["logb"] < 1 or pr["n_queries"] < 1 or pr["fri_logf"] < 1 or n_queries_seen != pr["n_queries"]:
+            raise ValueError("chunk proof parameters out of range")       # nothing below is sized by numbers the text could choose freely
+
+    @staticmethod
     def _parse_and_prepare(text):
+        """(text, whole object, prepared opening arrays) of a recursive proof text.  The openings of a proof in the provers' own grammar are
+        parsed by the library (csrc/proofparse.hip: no Python object per number); any other text goes through the JSON module, which also
+        words the errors."""
+        fast = None
+        data = text.encode() if isinstance(text, str) else text
+        if len(data) >= Engine.FAST_PARSE_MIN:
+            span = None
+            if data.startswith(b'{"kind":"aggregated"'):
+                span = native.json_key_span(data, "stark")       # an aggregated proof is folded through ITS STARK (one recursion level up)
+            inner = data[span[0]:span[1]] if span else data
+            got = VA.prepare_proof_text(inner)
+            if got is not None:
+                obj, arr = got
+                if "roots" in obj:
+                    Engine._check_params(obj, len(arr["index"]))
+                    prep = VA.prepared_from_arrays(obj, arr)
+                    if span:
+                        whole = json.loads(data[:span[0]] + b"null" + data[span[1]:])
+                        if not isinstance(whole, dict) or whole.get("kind") != "aggregated":
+                            raise ValueError("not a recursive proof of this prover")
+                        whole["stark"] = obj
+                    else:
+                        whole = obj
+                    fast = (text, whole, prep)
+        if fast is not None:
+            return fast
         obj = json.loads(text)
         whole = obj
         if isinstance(obj, dict) and obj.get("kind") == "aggregated" and isinstance(obj.get("stark"), dict):
             obj = obj["stark"]          # an aggregated proof is folded through ITS STARK (one recursion level up)
         if not isinstance(obj, dict) or "queries" not in obj or "roots" not in obj or not isinstance(obj.get("params"), dict):
             raise ValueError("not a recursive proof of this prover")
-        pr, lim = obj["params"], {"logn": 28, "logb": 8, "fri_logf": 8, "fri_final_log": 16, "n_queries": 4096, "pow_bits": 64}
-        if any(not isinstance(pr.get(k), int) or isinstance(pr.get(k), bool) or not 0 <= pr[k] <= m for k, m in lim.items()) \
-                or pr["logn"] < 1 or pr["logb"] < 1 or pr["n_queries"] < 1 or pr["fri_logf"] < 1 or not isinstance(obj["queries"], list) \
-                or len(obj["queries"]) != pr["n_queries"]:
-            raise ValueError("chunk proof parameters out of range")       # nothing below is sized by numbers the text could choose freely
+        if not isinstance(obj["queries"], list):
+            raise ValueError("chunk proof parameters out of range")
+        Engine._check_params(obj, len(obj["queries"]))
         return text, whole, VA.prepare_proof(obj)
 
     def _parsed_chunk_proof(self, text):
@@ -491,7 +529,7 @@ class Engine:
         #    here and is an application error (the client retries: provider.rs:504-523).
         t0 = time.perf_counter()
         try:
-            agg = json.loads(recursive_proof)
+            _, agg, prep = self._parse_and_prepare(recursive_proof)
             outer = agg["stark"]
             if agg.get("kind") != "aggregated" or "queries" not in outer:
                 raise KeyError("kind")
@@ -504,7 +542,7 @@ class Engine:
         except (json.JSONDecodeError, TypeError, KeyError, AssertionError, ValueError) as e:
             raise ValueError("recursive proof is not an aggregated proof of this prover (%s)" % e)
         tmf = {}
-        fshape, fair, fp, final_stark = self._prove_merkle_verifier([outer], lambda sh: self.final_stark_params(outer), self.be_bn128, tmf, agg_air)
+        fshape, fair, fp, final_stark = self._prove_merkle_verifier([outer], lambda sh: self.final_stark_params(outer), self.be_bn128, tmf, agg_air, [prep])
         t_fs = time.perf_counter() - t0
         self.final_starks[batch_id] = final_stark
         while len(self.final_starks) > 4:
@@ -516,7 +554,11 @@ class Engine:
         w = circ.witness(h % bn254.R)
         # fresh blinding per proof (zero knowledge); replays of a request are answered from the batch store (server.py),
         # which keeps the finished proof, so the client still sees one proof per batch
-        rnd = (int.from_bytes(os.urandom(32), "big") % bn254.R or 1, int.from_bytes(os.urandom(32), "big") % bn254.R or 1)
+        if self.cfg.groth16_seed is None:
+            rnd = (int.from_bytes(os.urandom(32), "big") % bn254.R or 1, int.from_bytes(os.urandom(32), "big") % bn254.R or 1)
+        else:
+            det = lambda tag: int(hashlib.sha256(("%s|%s|%064x|%s" % (self.cfg.groth16_seed, fs_digest, h, tag)).encode()).hexdigest(), 16) % bn254.R or 1
+            rnd = (det("r"), det("s"))
         t0 = time.perf_counter()
         proof, pub = groth16.prove(circ, pk, w, self.be.msm_g1, rnd, getattr(self.be, "msm_g2", None), self.be.qap_quotient)
         self.stage_timings["final/" + batch_id] = {"final_stark(bn128)": t_fs, "groth16": time.perf_counter() - t0,

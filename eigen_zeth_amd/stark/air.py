@@ -102,12 +102,17 @@ class Air:
             self._program = compile_program(self)
         return self._program
 
+    def _sha(self):
+        if getattr(self, "_digest", None) is None:       # the program of a verifier AIR is megabytes: hashed once per object
+            self._digest = hashlib.sha256(self.program().tobytes()).digest()
+        return self._digest
+
     def digest(self):
-        return hashlib.sha256(self.program().tobytes()).hexdigest()[:16]
+        return self._sha().hex()[:16]
 
     def digest_words(self):
         """the digest as four u64 words (absorbed into the Fiat-Shamir transcript)"""
-        h = hashlib.sha256(self.program().tobytes()).digest()
+        h = self._sha()
         return [int.from_bytes(h[8 * i:8 * i + 8], "little") % P for i in range(4)]
 
     @property

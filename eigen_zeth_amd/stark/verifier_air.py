@@ -838,6 +838,56 @@ def prepare_proof(proof):
     return out
 
 
+def prepare_proof_text(text):
+    """(proof object WITHOUT its query openings but with "queries": n placeholders, prepared arrays) from a proof TEXT: the openings -- 97 % of
+    the text -- are parsed by the library (native.parse_proof_queries: csrc/proofparse.hip), the header by the JSON module.  The object keeps
+    a list of {"index": j} per query (what the witness builder and the shape need besides the arrays).  None when the text is not in the
+    provers' own grammar: the caller falls back to json.loads + prepare_proof (which reports what is wrong)."""
+    import json
+    from .. import native
+    data = text.encode() if isinstance(text, str) else text
+    got = native.parse_proof_queries(data)
+    if got is None:
+        return None
+    qb, qe, arr = got
+    try:
+        obj = json.loads(data[:qb] + b"[]" + data[qe:])
+    except ValueError:
+        return None
+    if not isinstance(obj, dict) or not isinstance(obj.get("params"), dict):
+        return None
+    return obj, arr
+
+
+def prepared_from_arrays(proof, arr):
+    """the dictionary prepare_proof() returns, from natively parsed arrays; proof["queries"] becomes the list of {"index"} the other code reads"""
+    pr = proof["params"]
+    T = len(arr["values"])
+    W = arr["values"][0].shape[1]
+    W2 = arr["values"][1].shape[1] if arr["has_stage2"] else 0
+    Wq = arr["values"][1 + (1 if arr["has_stage2"] else 0)].shape[1]
+    shape = Shape(pr["logn"], pr["logb"], W, W2, Wq, pr["n_queries"], pr["fri_logf"], pr["fri_final_log"], 1, len(proof["publics"]), pr["pow_bits"],
+                  int(proof["root32"]), int(proof["shift"]))
+    if len(arr["index"]) != shape.n_queries or T != len(shape.trees):
+        raise ValueError("inner proof has the wrong number of queries or commitments")
+    for t, (name, w, depth) in enumerate(shape.trees):
+        if arr["values"][t].shape != (shape.n_queries, w) or arr["paths"][t].shape != (shape.n_queries, depth, 4):
+            raise ValueError("opening of %s has the wrong shape" % name)
+    proof["queries"] = _QueryStubs(arr)
+    return {"index": arr["index"], "values": arr["values"], "paths": arr["paths"], "key": shape.key()[:8]}
+
+
+class _QueryStubs(list):
+    """proof["queries"] of a natively parsed proof: per query {"index": j} (+ the leaf widths Shape.of_proof reads from query 0)"""
+
+    def __init__(self, arr):
+        names = ["trace"] + (["stage2"] if arr["has_stage2"] else []) + ["quotient"]
+        q0 = {"index": int(arr["index"][0])}
+        for t, n in enumerate(names):
+            q0[n] = {"values": [0] * arr["values"][t].shape[1]}
+        super().__init__([q0] + [{"index": int(j)} for j in arr["index"][1:]])
+
+
 _OPS_CACHE = {}
 
 

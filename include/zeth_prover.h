@@ -305,6 +305,19 @@ int32_t zp_synth_trace_bound(int32_t kind, int32_t logn, int32_t W, uint64_t see
  * start must exceed 1024.  Known discrete logs: sum_i s_i P_i = (sum_i s_i (start + i) mod r) * G.            */
 int32_t zp_synth_g1_points(uint64_t start, size_t n, uint32_t *h_points, int32_t threads);
 
+/* ---- recursive-proof TEXT -> arrays (GenAggregatedProof / GenFinalProof take their inner proofs as strings: proto/prover/v1/prover.proto:
+ * 115-148, sent verbatim by src/prover/provider.rs:422-433,472-483).  Host code, no ctx.  97 % of a proof text is the decimal numbers of its
+ * query openings: zp_proof_queries_scan finds the "queries" array of a proof object and sizes it (queries, stage-2 tree or not, FRI layers,
+ * per tree -- trace, [stage2], quotient, fri0 .. -- leaf width and path length; every query alike), zp_proof_queries_parse writes index
+ * u64[nq], values (per tree a block u64[nq][w_t]) and paths (per tree a block u64[nq][d_t][4]).  The caller reads the rest of the text (the
+ * header: kilobytes) with its own JSON parser after cutting [q_begin, q_end) out.  zp_json_key_span: the byte span of the value of a member of
+ * the top-level object (the "stark" of an aggregated proof).  Strict: any other grammar is ZP_ERR_ARG (the caller falls back to its parser). */
+int32_t zp_json_key_span(const char *text, size_t len, const char *key, size_t *begin, size_t *end);
+int32_t zp_proof_queries_scan(const char *text, size_t len, size_t *q_begin, size_t *q_end, int32_t *n_queries, int32_t *has_stage2, int32_t *n_fri,
+                              int32_t *widths, int32_t *depths, int32_t max_trees);
+int32_t zp_proof_queries_parse(const char *text, size_t q_begin, size_t q_end, int32_t n_queries, int32_t has_stage2, int32_t n_fri,
+                               const int32_t *widths, const int32_t *depths, uint64_t *index, uint64_t *values, uint64_t *paths);
+
 /* ---- witness of the STARK-verifier AIR: its arithmetic columns (GenAggregatedProof / the final STARK of GenFinalProof:
  * proto/prover/v1/prover.proto:115-148, src/prover/provider.rs:422-503; the AIR is eigen_zeth_amd/stark/verifier_air.py) -----------------
  * Besides the permutation blocks (zp_poseidon_trace) the verifier trace has 21 columns that carry the field arithmetic of a verifier at

@@ -357,3 +357,51 @@ def test_native_arithmetic_builder_equals_the_reference_walk(cpu, tables, inner,
         VA.arith_columns(shape, bad)
     with pytest.raises(native.ZpError):
         native.verifier_arith_host(VA.arith_descriptor(shape)[:-1], keep["arith_in"])
+
+
+def test_native_proof_text_parser_equals_the_json_path(inner, cpu, tables, monkeypatch):
+    """csrc/proofparse.hip: the openings of a proof text as arrays -- the same arrays prepare_proof() makes from json.loads, for the C++ writer's
+    and the Python writer's spelling (with and without whitespace), with and without a stage-2 tree; anything else is refused (None: the
+    caller's JSON path then words the error); the engine's fast path gives the same aggregated proof as its JSON path"""
+    from eigen_zeth_amd.service.engine import Engine
+    air, params, proofs = inner
+    fib = AIR.get_air("fib")
+    tr, pub = native.synth_trace(fib.trace_kind, 5, fib.width, 9)
+    fibp = json.loads(PR.proof_to_json(PR.prove(fib, tr, pub, PR.StarkParams(5, 1, 2, 3, 3, pow_bits=0), cpu)))
+    for pr in (proofs[0], proofs[1], fibp):
+        want = VA.prepare_proof(pr)
+        for text in (PR.proof_to_json(pr), json.dumps(pr, indent=1), json.dumps(dict(pr, chunk={"block": 1, "queries": "decoy"}))):
+            got = VA.prepare_proof_text(text)
+            assert got is not None
+            obj, arr = got
+            prep = VA.prepared_from_arrays(obj, arr)
+            assert (prep["index"] == want["index"]).all() and prep["key"] == want["key"]
+            assert all((a == b).all() for a, b in zip(prep["values"], want["values"])) and all((a == b).all() for a, b in zip(prep["paths"], want["paths"]))
+            assert {k: v for k, v in obj.items() if k != "queries"} == {k: v for k, v in json.loads(text).items() if k != "queries"}
+            assert [q["index"] for q in obj["queries"]] == [q["index"] for q in pr["queries"]]
+            assert VA.Shape.of_proof(obj, 2).key() == VA.Shape.of_proof(pr, 2).key()
+    good = PR.proof_to_json(proofs[0])
+    bad = copy.deepcopy(proofs[0])
+    bad["queries"][2]["trace"]["values"] = bad["queries"][2]["trace"]["values"][:-1]          # ragged
+    assert VA.prepare_proof_text(json.dumps(bad)) is None
+    bad = copy.deepcopy(proofs[0])
+    bad["queries"][1]["fri"][0]["path"][1] = bad["queries"][1]["fri"][0]["path"][1][:3]
+    assert VA.prepare_proof_text(json.dumps(bad)) is None
+    for broken in (good.replace('"index":', '"index":-', 1), good.replace('"values":[', '"values":[1.5,', 1), good[:-2], good.replace('"queries"', '"q"'),
+                   good.replace('"values":[', '"values":[18446744073709551616,', 1), "[1,2]", ""):
+        assert VA.prepare_proof_text(broken) is None
+    doc = b'{"a":[1,{"stark":2}],"stark":{"x":"}"} ,"z":1}'
+    sb, se = native.json_key_span(doc, "stark")
+    assert doc[sb:se] == b'{"x":"}"}'                        # the top-level member, not the nested one; braces inside strings do not count
+    assert native.json_key_span(b'{"a":1}', "stark") is None
+    # the engine: the two paths give the same prepared arrays (and therefore the same aggregation)
+    monkeypatch.setattr(Engine, "FAST_PARSE_MIN", 0)
+    _, whole_f, prep_f = Engine._parse_and_prepare(good)
+    monkeypatch.setattr(Engine, "FAST_PARSE_MIN", 1 << 40)
+    _, whole_s, prep_s = Engine._parse_and_prepare(good)
+    assert all((a == b).all() for a, b in zip(prep_f["values"] + prep_f["paths"] + [prep_f["index"]], prep_s["values"] + prep_s["paths"] + [prep_s["index"]]))
+    assert {k: v for k, v in whole_f.items() if k != "queries"} == {k: v for k, v in whole_s.items() if k != "queries"}
+    shape = VA.Shape.of_proof(whole_f, 1)
+    t1, p1 = VA.build_witness(shape, [whole_f], cpu, air.digest_words(), [prep_f])
+    t2, p2 = VA.build_witness(shape, [whole_s], cpu, air.digest_words(), [prep_s])
+    assert (t1 == t2).all() and (p1 == p2).all()
