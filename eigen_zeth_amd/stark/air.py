@@ -281,8 +281,14 @@ BUILTIN_AIRS = {"cubic": cubic_air, "perm": permutation_air, "fib": fibonacci_ai
                 "wide64": lambda: wide_air(64), "chunk16": lambda: chunk_air(16), "chunk64": lambda: chunk_air(64)}
 
 
+_BUILTIN_CACHE = {}
+
+
 def get_air(name):
-    return BUILTIN_AIRS[name]()
+    """the built-in AIR of that name -- ONE object per name (its program blob and digest are computed once; callers treat AIRs as read-only)"""
+    if name not in _BUILTIN_CACHE:
+        _BUILTIN_CACHE[name] = BUILTIN_AIRS[name]()
+    return _BUILTIN_CACHE[name]
 
 
 # ---------------------------------------------------------------------------------- constraint program (AIR as data)
