@@ -822,7 +822,7 @@ def config5_probe(K=64, logn=22, msm_log=26, air_name="chunk64"):
     from eigen_zeth_amd.service.engine import Engine, EngineConfig
     from eigen_zeth_amd.service.server import default_backend_factory
     cfg = EngineConfig(air=air_name, logn=logn, groth16_logm=8, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_c5_%d" % os.getuid()),
-                       witness_threads=6)           # 2 GiB of page-locked witness per chunk in flight at 2^22 x 64
+                       witness_threads=12)          # 2 GiB of page-locked witness per chunk in flight at 2^22 x 64 (14 in flight at most)
     eng = Engine(default_backend_factory(0), cfg)
     eng.groth16_keys()
     out = {"workload": "%d chunks x 2^%d rows x (64 + 12) columns, %d bits conjectured; recursion; 4 G1 + 1 G2 MSMs of 2^%d points"
@@ -840,7 +840,10 @@ def config5_probe(K=64, logn=22, msm_log=26, air_name="chunk64"):
         eng.final(label, agg, "BN128", addr)
         t3 = time.perf_counter()
         wit = sum(v.get("witness(host)", 0.0) for k, v in eng.stage_timings.items() if k.startswith(ch["task_id"] + "/"))
-        r.update({"chunk_proofs_s": t1 - t0, "witness_generator_cpu_s_summed_over_threads": wit, "aggregate_first_last_s": t2 - t1, "final_s": t3 - t2,
+        prv = sum(v.get("total", 0.0) for k, v in eng.stage_timings.items() if k.startswith(ch["task_id"] + "/"))
+        r.update({"chunk_proofs_s": t1 - t0, "witness_generator_cpu_s_summed_over_threads": wit, "witness_threads": cfg.witness_threads,
+                  "zp_stark_prove_s_summed_over_streams": prv, "prover_streams": cfg.prover_streams,
+                  "aggregate_first_last_s": t2 - t1, "final_s": t3 - t2,
                   "wall_s": t3 - t0, "aggregated_proof_bytes": len(agg)})
         if tree and n >= 4:
             t0 = time.perf_counter()
