@@ -22,14 +22,19 @@ constexpr int NCOL = 21;   // HR[8], ACA[3], ACB[3], XI, TPX, TAU, TPT, X, XQ, X
 constexpr int C_ACA = 8, C_ACB = 11, C_XI = 14, C_TPX = 15, C_TAU = 16, C_TPT = 17, C_X = 18, C_XQ = 19, C_XQN = 20;
 constexpr int ROWS = 32, MAXR = 16;
 constexpr u64 MAGIC = 0x4854495241565A50ULL;   // "PZVARITH" little-endian
-constexpr int HDR = 12, TREE_WORDS = 8 + 64, FOLD_WORDS = MAXR * 3 * 8;
+constexpr int HDR = 26, TREE_WORDS = 8 + 64, FOLD_WORDS = MAXR * 3 * 8;
+constexpr u64 PUBLICS_INLINE = 64;     // longer public-input vectors enter a transcript through their commitment (stark/prover.py)
 // offsets inside one proof's arithmetic public inputs (stark/verifier_air.py AP_*)
 constexpr int AP_G = 0, AP_CA = 24, AP_CB = 27, AP_EZA = 30, AP_EZB = 33, AP_ZETA = 36, AP_ZETAW = 39;
 
 struct Blk { int kind, t, jl, first, last, p, sub; };   // kind: 0 idle, 1 absorb, 2 node
 struct Desc {
     u64 pb, periods, k, n_proofs, T, TQ, max_w, n_open, ap_n, n_fold;
-    const u64 *blk, *tree, *fold;
+    // the inner proofs' shape (what the hashing part of the witness and the transcripts need)
+    u64 n_queries, L, tblock0, W, W2, Wq, final_log, n_pub_inner, pow_bits, logn, logb, fri_logf, fri_final_log, root32, shift;
+    const u64 *blk, *tree, *fold, *script;     // script: L words  n_in | out << 8 | first << 9 | pow << 10
+    u64 n_slots() const { return k * periods; }
+    u64 n_fri() const { return T - TQ - 1; }
     Blk at(u64 b) const {
         const u64 w = blk[b];
         return Blk{(int)(w & 3), (int)((w >> 2) & 63), (int)((w >> 8) & 255), (int)((w >> 16) & 1), (int)((w >> 17) & 1), (int)((w >> 18) & 0xFFFF),
@@ -42,13 +47,21 @@ bool parse(const uint64_t *d, size_t words, Desc *o) {
     if (!d || words < HDR || d[0] != MAGIC) return false;
     o->pb = d[1]; o->periods = d[2]; o->k = d[3]; o->n_proofs = d[4]; o->T = d[5]; o->TQ = d[6]; o->max_w = d[7]; o->n_open = d[8]; o->ap_n = d[9];
     o->n_fold = d[10];
+    o->n_queries = d[11]; o->L = d[12]; o->tblock0 = d[13]; o->W = d[14]; o->W2 = d[15]; o->Wq = d[16]; o->final_log = d[17]; o->n_pub_inner = d[18];
+    o->pow_bits = d[19]; o->logn = d[20]; o->logb = d[21]; o->fri_logf = d[22]; o->fri_final_log = d[23]; o->root32 = d[24]; o->shift = d[25];
+    if (o->n_queries < 1 || o->n_queries > 4096 || o->L < 1 || o->L > (1u << 20) || o->W < 1 || o->W > 4096 || o->W2 > 4096 || o->Wq < 1 || o->Wq > 64 ||
+        o->final_log > 20 || o->n_pub_inner > (1u << 24) || o->pow_bits > 64 || o->logn < 1 || o->logb < 1 || o->logn + o->logb > 32 || o->fri_logf < 1 ||
+        o->fri_logf > 4 || o->root32 >= GL_P || o->shift >= GL_P)
+        return false;
     if (o->pb < 1 || o->pb > (1u << 24) || o->periods < 1 || o->periods > (1u << 16) || o->T < 3 || o->T > 62 || o->TQ < 1 || o->TQ + 1 >= o->T ||
         o->n_proofs < 1 || o->n_proofs > 64 || o->max_w < 4 || o->max_w > 4096 || o->n_fold > 4096 || o->ap_n < 42 || o->ap_n > (1u << 20))
         return false;
-    if (words != HDR + o->pb + o->T * TREE_WORDS + o->n_fold * FOLD_WORDS) return false;
+    if (words != HDR + o->pb + o->T * TREE_WORDS + o->n_fold * FOLD_WORDS + o->L) return false;
     o->blk = (const u64 *)d + HDR;
     o->tree = o->blk + o->pb;
     o->fold = o->tree + o->T * TREE_WORDS;
+    o->script = o->fold + o->n_fold * FOLD_WORDS;
+    if (o->tblock0 + o->n_proofs * o->L > o->pb * o->periods) return false;
     for (u64 b = 0; b < o->pb; b++) {
         const Blk k = o->at(b);
         if (k.kind > 2 || (k.kind && ((u64)k.t >= o->T || (u64)k.p >= o->n_proofs))) return false;
@@ -291,6 +304,368 @@ struct Records {
 
 }  // namespace
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The WHOLE witness of the verifier AIR behind one call (zp_recursion_witness): openings hashed level-synchronously on the GPU, the inner
+// transcripts replayed, the public inputs assembled, the permutation blocks traced, the arithmetic columns walked and expanded -- the trace
+// u64[47][N] is assembled in HBM.  Port of stark/verifier_air.py:build_witness (which stays the readable form and the CPU checker's path).
+
+__global__ void __launch_bounds__(256) block_fill_kernel(u64 *__restrict__ out, const u64 *__restrict__ per_block, u64 N) {
+    const u64 row = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (row < N) out[row] = per_block[row >> 5];
+}
+
+struct DevTmp {       // a device scratch buffer that frees itself
+    zp_ctx *ctx;
+    void *p = nullptr;
+    explicit DevTmp(zp_ctx *c) : ctx(c) {}
+    int32_t alloc(size_t bytes) { return zp_dev_alloc(ctx, bytes ? bytes : 8, &p); }
+    ~DevTmp() { if (p) (void)zp_dev_free(ctx, p); }
+};
+
+// one batched permutation of host states through the device
+int32_t perm_batch(zp_ctx *ctx, DevTmp &scratch, u64 *states, size_t count) {
+    if (!count) return ZP_OK;
+    ZP_TRY(zp_h2d(ctx, scratch.p, states, count * 96));
+    ZP_TRY(zp_poseidon_perm(ctx, (uint64_t *)scratch.p, count));
+    return zp_d2h(ctx, states, scratch.p, count * 96);
+}
+
+// the sponge of stark/transcript.py that records, for every permutation, its input state, the number of values its block absorbed and
+// (when the protocol reads it) the rate after it
+struct RecSponge {
+    zp_ctx *ctx;
+    u64 state[12];
+    std::vector<u64> queue, avail;
+    struct Rec { u64 in[12]; int n_in; bool has_out; u64 out[8]; };
+    std::vector<Rec> rec;
+    int32_t rc = ZP_OK;
+    explicit RecSponge(zp_ctx *c) : ctx(c) { memset(state, 0, sizeof state); }
+    void absorb(const u64 *v, size_t n) { queue.insert(queue.end(), v, v + n); avail.clear(); }
+    void flush() {
+        const size_t nb = (queue.size() + 7) / 8;
+        std::vector<u64> blocks(nb * 8, 0), rates(8), caps((nb ? nb : 1) * 4);
+        memcpy(blocks.data(), queue.data(), queue.size() * 8);
+        std::vector<int> nin;
+        for (size_t i = 0; i < nb; i++) nin.push_back((int)(queue.size() - 8 * i < 8 ? queue.size() - 8 * i : 8));
+        u64 before[12];
+        memcpy(before, state, sizeof before);
+        queue.clear();
+        if (rc == ZP_OK) rc = zp_poseidon_sponge_caps(ctx, (uint64_t *)state, (const uint64_t *)blocks.data(), nb, 0, (uint64_t *)rates.data(), (uint64_t *)caps.data());
+        if (rc != ZP_OK) return;
+        if (nb == 0) {
+            Rec r; memcpy(r.in, before, sizeof before); r.n_in = 0; r.has_out = false;
+            rec.push_back(r);
+        }
+        for (size_t i = 0; i < nb; i++) {
+            Rec r;
+            memcpy(r.in, &blocks[8 * i], 64);
+            memcpy(r.in + 8, i == 0 ? before + 8 : &caps[4 * (i - 1)], 32);
+            r.n_in = nin[i]; r.has_out = false;
+            rec.push_back(r);
+        }
+        rec.back().has_out = true;
+        memcpy(rec.back().out, state, 64);
+        avail.assign(state, state + 8);
+    }
+    void squeeze(size_t n, u64 *out) {
+        size_t got = 0;
+        while (got < n && rc == ZP_OK) {
+            if (!queue.empty() || avail.empty()) flush();
+            if (rc != ZP_OK) break;
+            out[got++] = avail.front();
+            avail.erase(avail.begin());
+        }
+    }
+};
+
+struct Chal { e3 zeta, gamma; std::vector<e3> betas; };
+
+// the layout of one inner proof's transcript stream (caller-supplied; see include/zeth_prover.h)
+struct Stream {
+    static constexpr int MAX_T = 62;
+    const u64 *digest, *pubs, *root[MAX_T], *ev_z, *ev_zw, *final_l;
+    u64 nonce;
+};
+
+bool slice_stream(const Desc &D, const u64 *s, size_t words, Stream *o) {
+    const u64 Wt = D.W + D.W2, nfri = D.n_fri();
+    size_t need = 4 + D.n_pub_inner + 4 * D.T + 3 * (Wt + D.Wq) + 3 * Wt + ((size_t)3 << D.final_log) + (D.pow_bits ? 1 : 0);
+    if (words != need || D.T > (u64)Stream::MAX_T) return false;
+    o->digest = s; s += 4;
+    o->pubs = s; s += D.n_pub_inner;
+    for (u64 t = 0; t <= D.TQ; t++) { o->root[t] = s; s += 4; }          // trace, [stage2], quotient
+    o->ev_z = s; s += 3 * (Wt + D.Wq);
+    o->ev_zw = s; s += 3 * Wt;
+    for (u64 l = 0; l < nfri; l++) { o->root[D.TQ + 1 + l] = s; s += 4; }
+    o->final_l = s; s += (size_t)3 << D.final_log;
+    o->nonce = D.pow_bits ? *s : 0;
+    return true;
+}
+
+// Goldilocks-mode commitment to a long public-input vector (stark/prover.py publics_rows: rows of 8, zero padded, a power of two >= 2 of them)
+int32_t publics_digest(zp_ctx *ctx, const u64 *pubs, size_t n, u64 out4[4]) {
+    size_t M = 2;
+    while (M * 8 < n) M <<= 1;
+    std::vector<u64> rows(M * 8, 0);
+    memcpy(rows.data(), pubs, n * 8);
+    DevTmp d(ctx), tree(ctx);
+    ZP_TRY(d.alloc(rows.size() * 8));
+    ZP_TRY(tree.alloc((2 * M - 1) * 32));
+    ZP_TRY(zp_h2d(ctx, d.p, rows.data(), rows.size() * 8));
+    ZP_TRY(zp_merkle_commit_rows(ctx, (const uint64_t *)d.p, M, 8, (uint64_t *)tree.p));
+    return zp_d2h(ctx, out4, (const char *)tree.p + (2 * M - 2) * 32, 32);
+}
+
+// replay of one inner transcript: fills `states` (L x 12: the inputs of its permutation blocks), appends its section of the public inputs
+// to `tp`, returns the challenges.  -14: the transcript does not give the proof's indices / the grinding nonce fails; -12: wrong shape.
+int32_t replay(zp_ctx *ctx, const Desc &D, const Stream &st, const u64 *index, DevTmp &scratch, std::vector<u64> &states, std::vector<u64> &tp, Chal *ch) {
+    RecSponge tr(ctx);
+    std::vector<u64> head = {D.logn, D.logb, D.W, D.W2, D.fri_logf, D.fri_final_log, D.n_queries, D.pow_bits, D.root32, D.shift,
+                             st.digest[0], st.digest[1], st.digest[2], st.digest[3], D.n_pub_inner};
+    if (D.n_pub_inner <= PUBLICS_INLINE) {
+        head.insert(head.end(), st.pubs, st.pubs + D.n_pub_inner);
+        tr.absorb(head.data(), head.size());
+    } else {
+        u64 dg[4];
+        ZP_TRY(publics_digest(ctx, st.pubs, D.n_pub_inner, dg));
+        tr.absorb(head.data(), head.size());
+        tr.absorb(dg, 4);
+    }
+    const u64 Wt = D.W + D.W2;
+    u64 tmp[8];
+    tr.absorb(st.root[0], 4);
+    if (D.W2) { tr.squeeze(3, tmp); tr.absorb(st.root[1], 4); }
+    tr.squeeze(3, tmp);                                       // alpha
+    tr.absorb(st.root[D.TQ], 4);
+    tr.squeeze(3, ch->zeta.c);
+    tr.absorb(st.ev_z, 3 * (Wt + D.Wq));
+    tr.absorb(st.ev_zw, 3 * Wt);
+    tr.squeeze(3, ch->gamma.c);
+    for (u64 l = 0; l < D.n_fri(); l++) {
+        tr.absorb(st.root[D.TQ + 1 + l], 4);
+        e3 b;
+        tr.squeeze(3, b.c);
+        ch->betas.push_back(b);
+    }
+    tr.absorb(st.final_l, (size_t)3 << D.final_log);
+    bool have_pow = false;
+    RecSponge::Rec powrec;
+    if (D.pow_bits) {
+        u64 seed[4];
+        tr.squeeze(4, seed);
+        ZP_TRY(tr.rc);
+        if (st.nonce >= GL_P) return -14;
+        u64 pin[12] = {seed[0], seed[1], seed[2], seed[3], st.nonce, 0, 0, 0, 0, 0, 0, 0}, pout[12];
+        memcpy(pout, pin, sizeof pin);
+        ZP_TRY(perm_batch(ctx, scratch, pout, 1));
+        if (pout[0] >> (64 - D.pow_bits)) return -14;
+        memcpy(powrec.in, pin, sizeof pin); powrec.n_in = 5; powrec.has_out = true; memcpy(powrec.out, pout, 64);
+        have_pow = true;
+        tr.absorb(&st.nonce, 1);
+    }
+    std::vector<u64> idx(D.n_queries);
+    tr.squeeze(D.n_queries, idx.data());
+    ZP_TRY(tr.rc);
+    const u64 mask = ((u64)1 << (D.logn + D.logb)) - 1;
+    for (u64 q = 0; q < D.n_queries; q++)
+        if ((idx[q] & mask) != index[q]) return -14;
+    if (have_pow) tr.rec.push_back(powrec);
+    if (tr.rec.size() != D.L) return -12;
+    for (u64 j = 0; j < D.L; j++) {
+        const u64 w = D.script[j];
+        const RecSponge::Rec &r = tr.rec[j];
+        if ((u64)r.n_in != (w & 255) || r.has_out != (((w >> 8) & 1) != 0)) return -12;
+        states.insert(states.end(), r.in, r.in + 12);
+        tp.insert(tp.end(), r.in, r.in + r.n_in);
+        if (r.has_out) tp.insert(tp.end(), r.out, r.out + 8);
+    }
+    return ZP_OK;
+}
+
+// the arithmetic section of one inner proof's public inputs (stark/verifier_air.py: arith_publics)
+void arith_publics(const Desc &D, const Stream &st, const Chal &ch, u64 *out) {
+    const e3 g = e3_inv(ch.gamma);
+    e3 cur = e3_make(1, 0, 0);
+    for (int e = 0; e < 8; e++) { cur = e3_mul(cur, g); memcpy(out + AP_G + 3 * e, cur.c, 24); }
+    const u64 Wt = D.W + D.W2, Wall = Wt + D.Wq;
+    e3 eza = e3_make(0, 0, 0), ezb = eza, gk = e3_make(1, 0, 0), ca = gk, cb = gk;
+    for (u64 k = 0; k < Wall + Wt; k++) {
+        if (k < Wall) eza = e3_add(eza, e3_mul(gk, e3_make(st.ev_z[3 * k], st.ev_z[3 * k + 1], st.ev_z[3 * k + 2])));
+        else ezb = e3_add(ezb, e3_mul(gk, e3_make(st.ev_zw[3 * (k - Wall)], st.ev_zw[3 * (k - Wall) + 1], st.ev_zw[3 * (k - Wall) + 2])));
+        if (k == Wall - 1) ca = gk;
+        if (k == Wall + Wt - 1) cb = gk;
+        gk = e3_mul(gk, ch.gamma);
+    }
+    const u64 wN = gl_root(D.root32, (int)D.logn);
+    memcpy(out + AP_CA, ca.c, 24); memcpy(out + AP_CB, cb.c, 24); memcpy(out + AP_EZA, eza.c, 24); memcpy(out + AP_EZB, ezb.c, 24);
+    memcpy(out + AP_ZETA, ch.zeta.c, 24);
+    const e3 zw = e3_scale(ch.zeta, wN);
+    memcpy(out + AP_ZETAW, zw.c, 24);
+    for (u64 l = 0; l < D.n_fri(); l++) {
+        const u64 *tr = D.tr((int)(D.TQ + 1 + l));
+        e3 b = e3_make(1, 0, 0);
+        for (u64 j = 1; j < ((u64)1 << tr[5]); j++) { b = e3_mul(b, ch.betas[l]); memcpy(out + tr[6] + 3 * (j - 1), b.c, 24); }
+    }
+}
+
+int32_t records_to_device(zp_ctx *ctx, Records &rec, u64 nblk, u64 *d_out) {
+    const u64 N = nblk * ROWS;
+    DevTmp dA(ctx), dE(ctx), dF(ctx), dR(ctx);
+    ZP_TRY(dA.alloc(rec.A.size() * 8)); ZP_TRY(dE.alloc(rec.E.size() * 8)); ZP_TRY(dF.alloc(rec.F.size() * 8)); ZP_TRY(dR.alloc((rec.R.size() + 7) / 8 * 8));
+    ZP_TRY(zp_h2d(ctx, dA.p, rec.A.data(), rec.A.size() * 8));
+    ZP_TRY(zp_h2d(ctx, dE.p, rec.E.data(), rec.E.size() * 8));
+    ZP_TRY(zp_h2d(ctx, dF.p, rec.F.data(), rec.F.size() * 8));
+    ZP_TRY(zp_h2d(ctx, dR.p, rec.R.data(), rec.R.size()));
+    hipLaunchKernelGGL(arith_expand_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_out, (const u64 *)dA.p, (const u64 *)dE.p, (const u64 *)dF.p,
+                       (const unsigned char *)dR.p, N);
+    if (hipGetLastError() != hipSuccess) { ctx->err = "arith_expand_kernel launch failed"; return ZP_ERR_HIP; }
+    return zp_sync(ctx);      // the records are freed on return
+}
+
+int32_t recursion_witness(zp_ctx *ctx, const Desc &D, const uint64_t *const *h_index, const uint64_t *const *h_values, const uint64_t *const *h_paths,
+                          const uint64_t *const *h_stream, const size_t *stream_words, u64 *d_trace, u64 *h_pubs, size_t pubs_words, int threads) {
+    const u64 pb = D.pb, nblk = D.pb * D.periods, N = nblk * ROWS, T = D.T, NP = D.n_proofs, nq = D.n_queries, nslots = D.n_slots();
+    // ---- the transcript script fixes the size of a proof's transcript section
+    u64 tp_per = 0;
+    for (u64 j = 0; j < D.L; j++) tp_per += (D.script[j] & 255) + (((D.script[j] >> 8) & 1) ? 8 : 0);
+    const u64 n_merkle = NP * T * 4 + nslots * NP * T, n_pub = n_merkle + NP * tp_per + NP * D.ap_n + nslots * NP * 3;
+    ZP_ARG(ctx, pubs_words == n_pub, "public-input buffer does not have the size the descriptor dictates");
+    std::vector<Stream> st(NP);
+    for (u64 p = 0; p < NP; p++) ZP_ARG(ctx, h_index[p] && h_values[p] && h_paths[p] && h_stream[p] && slice_stream(D, (const u64 *)h_stream[p], stream_words[p], &st[p]), "bad transcript stream");
+    // offsets of the per-tree blocks inside a proof's values / paths arrays (layout of zp_proof_queries_parse)
+    std::vector<u64> voff(T), poff(T), wv(T), dv(T);
+    {
+        u64 vo = 0, po = 0;
+        for (u64 t = 0; t < T; t++) { wv[t] = D.tr((int)t)[0]; dv[t] = D.tr((int)t)[1]; voff[t] = vo; poff[t] = po; vo += nq * wv[t]; po += nq * dv[t] * 4; }
+    }
+    // ---- the opening table: one row per opening of the schedule, in block order (stark/verifier_air.py: _opening_table)
+    struct Op { u64 b0, na, nd, t, p, q; };
+    std::vector<Op> ops;
+    ops.reserve(D.n_open);
+    std::vector<int64_t> blk_op(nblk, -1);
+    for (u64 per = 0; per < D.periods; per++)
+        for (u64 b = 0; b < pb;) {
+            const Blk k = D.at(b);
+            const bool start = k.kind != 0 && (k.kind == 1 ? k.jl == 0 : k.first != 0);
+            if (!start) { b++; continue; }
+            const u64 w = wv[k.t], na = w <= 4 ? 0 : (w + 7) / 8, nd = dv[k.t];
+            if (b + na + nd > pb) return ZP_ERR_ARG;
+            for (u64 i = 0; i < na + nd; i++) blk_op[per * pb + b + i] = (int64_t)ops.size();
+            ops.push_back(Op{per * pb + b, na, nd, (u64)k.t, (u64)k.p, (per * D.k + (u64)k.sub) % nq});
+            b += na + nd;
+        }
+    ZP_ARG(ctx, ops.size() == D.n_open, "descriptor and schedule disagree on the number of openings");
+    const u64 no = ops.size(), mw = D.max_w;
+    u64 max_d = 0, max_na = 0;
+    for (const Op &o : ops) { if (o.nd > max_d) max_d = o.nd; if (o.na > max_na) max_na = o.na; }
+    std::vector<u64> vals(no * mw, 0), index(no), inputs(nblk * 12, 0), dbit(nblk, 0), idxv(nblk, 0), digest(no * 4), cap(no * 4, 0);
+    for (u64 o = 0; o < no; o++) {
+        const Op &op = ops[o];
+        memcpy(&vals[o * mw], (const u64 *)h_values[op.p] + voff[op.t] + op.q * wv[op.t], wv[op.t] * 8);
+        index[o] = ((const u64 *)h_index[op.p])[op.q] & (((u64)1 << op.nd) - 1);
+    }
+    DevTmp scratch(ctx);
+    ZP_TRY(scratch.alloc((no > 1 ? no : 1) * 96));
+    std::vector<u64> stt(no * 12);
+    std::vector<u64> sel;
+    sel.reserve(no);
+    // ---- leaf hashes: absorb block j of every opening in one batch
+    for (u64 j = 0; j < max_na; j++) {
+        sel.clear();
+        for (u64 o = 0; o < no; o++) if (ops[o].na > j) sel.push_back(o);
+        for (size_t i = 0; i < sel.size(); i++) {
+            const u64 o = sel[i];
+            u64 *s = &stt[i * 12];
+            const u64 room = mw - 8 * j;
+            for (u64 e = 0; e < 8; e++) s[e] = e < room ? vals[o * mw + 8 * j + e] : 0;
+            memcpy(s + 8, &cap[o * 4], 32);
+            memcpy(&inputs[(ops[o].b0 + j) * 12], s, 96);
+        }
+        ZP_TRY(perm_batch(ctx, scratch, stt.data(), sel.size()));
+        for (size_t i = 0; i < sel.size(); i++) memcpy(&cap[sel[i] * 4], &stt[i * 12], 32);
+    }
+    for (u64 o = 0; o < no; o++) memcpy(&digest[o * 4], ops[o].na ? &cap[o * 4] : &vals[o * mw], 32);     // unhashed leaves: identity, zero padded
+    // ---- paths: tree level lv of every opening in one batch
+    for (u64 lv = 0; lv < max_d; lv++) {
+        sel.clear();
+        for (u64 o = 0; o < no; o++) if (ops[o].nd > lv) sel.push_back(o);
+        if (sel.empty()) break;
+        for (size_t i = 0; i < sel.size(); i++) {
+            const u64 o = sel[i];
+            const Op &op = ops[o];
+            const u64 bit = (index[o] >> lv) & 1;
+            const u64 *sib = (const u64 *)h_paths[op.p] + poff[op.t] + (op.q * op.nd + lv) * 4, *cur = &digest[o * 4];
+            u64 *s = &stt[i * 12];
+            memcpy(s, bit ? sib : cur, 32);
+            memcpy(s + 4, bit ? cur : sib, 32);
+            memset(s + 8, 0, 32);
+            const u64 blk = op.b0 + op.na + lv;
+            memcpy(&inputs[blk * 12], s, 96);
+            dbit[blk] = bit;
+            idxv[blk] = index[o] & (((u64)2 << lv) - 1);
+        }
+        ZP_TRY(perm_batch(ctx, scratch, stt.data(), sel.size()));
+        for (size_t i = 0; i < sel.size(); i++) memcpy(&digest[sel[i] * 4], &stt[i * 12], 32);
+    }
+    for (u64 o = 0; o < no; o++)
+        if (memcmp(&digest[o * 4], st[ops[o].p].root[ops[o].t], 32) != 0) {
+            ctx->err = "an opening of an inner proof does not hash to its root: no accepting witness";
+            return -13;
+        }
+    // ---- public inputs: roots | indices | transcripts | arithmetic constants | final-layer values
+    u64 *pub = h_pubs;
+    for (u64 p = 0; p < NP; p++)
+        for (u64 t = 0; t < T; t++) { memcpy(pub, st[p].root[t], 32); pub += 4; }
+    for (u64 g = 0; g < nslots; g++)
+        for (u64 p = 0; p < NP; p++)
+            for (u64 t = 0; t < T; t++) *pub++ = ((const u64 *)h_index[p])[g % nq] & (((u64)1 << dv[t]) - 1);
+    std::vector<u64> aps(NP * D.ap_n, 0), fin(nslots * NP * 3);
+    for (u64 p = 0; p < NP; p++) {
+        std::vector<u64> states, tp;
+        Chal ch;
+        const int32_t r = replay(ctx, D, st[p], (const u64 *)h_index[p], scratch, states, tp, &ch);
+        if (r == -14) ctx->err = "the transcript of an inner proof does not give its query indices or its grinding nonce fails: no accepting witness";
+        if (r == -12) ctx->err = "an inner proof does not have the shape the verifier AIR was built for";
+        if (r != ZP_OK) return r;
+        if (tp.size() != tp_per) { ctx->err = "transcript section of the wrong size"; return ZP_ERR_INTERNAL; }
+        memcpy(&inputs[(D.tblock0 + p * D.L) * 12], states.data(), states.size() * 8);
+        memcpy(pub, tp.data(), tp.size() * 8);
+        pub += tp.size();
+        arith_publics(D, st[p], ch, &aps[p * D.ap_n]);
+    }
+    memcpy(pub, aps.data(), aps.size() * 8);
+    pub += aps.size();
+    const u64 fmask = ((u64)1 << D.final_log) - 1, fl = (u64)1 << D.final_log;
+    for (u64 g = 0; g < nslots; g++)
+        for (u64 p = 0; p < NP; p++) {
+            const u64 pos = ((const u64 *)h_index[p])[g % nq] & fmask;
+            for (int c = 0; c < 3; c++) fin[(g * NP + p) * 3 + c] = st[p].final_l[c * fl + pos];
+        }
+    memcpy(pub, fin.data(), fin.size() * 8);
+    // ---- the arithmetic columns
+    Records rec(nblk);
+    const int rc = walk_all(D, vals.data(), index.data(), dbit.data(), blk_op.data(), aps.data(), fin.data(), rec.view(), threads);
+    if (rc == -12) { ctx->err = "arithmetic-witness inputs do not match the descriptor"; return ZP_ERR_ARG; }
+    if (rc != 0) { ctx->err = "the opened values of an inner proof are inconsistent: no accepting witness"; return rc; }
+    // ---- the trace in HBM: 24 permutation columns, direction bit, index, 21 arithmetic columns
+    DevTmp d_in(ctx), d_pb(ctx);
+    ZP_TRY(d_in.alloc(inputs.size() * 8));
+    ZP_TRY(zp_h2d(ctx, d_in.p, inputs.data(), inputs.size() * 8));
+    ZP_TRY(zp_poseidon_trace(ctx, (const uint64_t *)d_in.p, nblk, (uint64_t *)d_trace, (uint64_t *)(d_trace + 12 * N), N));
+    ZP_TRY(d_pb.alloc(2 * nblk * 8));
+    ZP_TRY(zp_h2d(ctx, d_pb.p, dbit.data(), nblk * 8));
+    ZP_TRY(zp_h2d(ctx, (u64 *)d_pb.p + nblk, idxv.data(), nblk * 8));
+    for (int c = 0; c < 2; c++) {
+        hipLaunchKernelGGL(block_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_trace + (24 + c) * N, (const u64 *)d_pb.p + c * nblk, N);
+        if (hipGetLastError() != hipSuccess) { ctx->err = "block_fill_kernel launch failed"; return ZP_ERR_HIP; }
+    }
+    return records_to_device(ctx, rec, nblk, d_trace + 26 * N);
+}
+
+}  // namespace
+
 extern "C" {
 
 // Host-only (no GPU, no ctx): h_out u64[21][32 * blocks].  0 = ok; ZP_ERR_ARG: malformed descriptor; -10 / -11: the opened values are
@@ -321,36 +696,43 @@ int32_t zp_verifier_arith_trace(zp_ctx *ctx, const uint64_t *desc, size_t desc_w
     ZP_ARG(ctx, parse(desc, desc_words, &D), "malformed arithmetic-witness descriptor");
     ZP_ARG(ctx, vals && index && dbit && blk_op && arith_pubs && final_vals && d_out, "null pointer");
     try {
-        const u64 nblk = D.pb * D.periods, N = nblk * ROWS;
+        const u64 nblk = D.pb * D.periods;
         Records rec(nblk);
         const int rc = walk_all(D, (const u64 *)vals, (const u64 *)index, (const u64 *)dbit, blk_op, (const u64 *)arith_pubs, (const u64 *)final_vals,
                                 rec.view(), threads);
         if (rc == -12) { ctx->err = "arithmetic-witness inputs do not match the descriptor"; return ZP_ERR_ARG; }
         if (rc != 0) { ctx->err = "the opened values of an inner proof are inconsistent: no accepting witness"; return rc; }
-        void *dA = nullptr, *dE = nullptr, *dF = nullptr, *dR = nullptr;
-        int32_t r = zp_dev_alloc(ctx, rec.A.size() * 8, &dA);
-        if (r == ZP_OK) r = zp_dev_alloc(ctx, rec.E.size() * 8, &dE);
-        if (r == ZP_OK) r = zp_dev_alloc(ctx, rec.F.size() * 8, &dF);
-        if (r == ZP_OK) r = zp_dev_alloc(ctx, (rec.R.size() + 7) / 8 * 8, &dR);
-        if (r == ZP_OK) r = zp_h2d(ctx, dA, rec.A.data(), rec.A.size() * 8);
-        if (r == ZP_OK) r = zp_h2d(ctx, dE, rec.E.data(), rec.E.size() * 8);
-        if (r == ZP_OK) r = zp_h2d(ctx, dF, rec.F.data(), rec.F.size() * 8);
-        if (r == ZP_OK) r = zp_h2d(ctx, dR, rec.R.data(), rec.R.size());
-        if (r == ZP_OK) {
-            hipLaunchKernelGGL(arith_expand_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, (u64 *)d_out, (const u64 *)dA, (const u64 *)dE,
-                               (const u64 *)dF, (const unsigned char *)dR, N);
-            if (hipGetLastError() != hipSuccess) { ctx->err = "arith_expand_kernel launch failed"; r = ZP_ERR_HIP; }
-        }
-        if (r == ZP_OK) r = zp_sync(ctx);      // the records are freed below
-        if (dA) (void)zp_dev_free(ctx, dA);
-        if (dE) (void)zp_dev_free(ctx, dE);
-        if (dF) (void)zp_dev_free(ctx, dF);
-        if (dR) (void)zp_dev_free(ctx, dR);
-        return r;
+        return records_to_device(ctx, rec, nblk, (u64 *)d_out);
     } catch (...) {
         ctx->err = "out of host memory";
         return ZP_ERR_NOMEM;
     }
+}
+
+// The whole witness of the verifier AIR (see include/zeth_prover.h).
+int32_t zp_recursion_witness(zp_ctx *ctx, const uint64_t *desc, size_t desc_words, const uint64_t *const *h_index, const uint64_t *const *h_values,
+                             const uint64_t *const *h_paths, const uint64_t *const *h_stream, const size_t *stream_words, uint64_t *d_trace,
+                             uint64_t *h_pubs, size_t pubs_words, int32_t threads) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "recursion_witness");
+    Desc D;
+    ZP_ARG(ctx, parse(desc, desc_words, &D), "malformed witness descriptor");
+    ZP_ARG(ctx, h_index && h_values && h_paths && h_stream && stream_words && d_trace && h_pubs, "null pointer");
+    try {
+        return recursion_witness(ctx, D, h_index, h_values, h_paths, h_stream, stream_words, (u64 *)d_trace, (u64 *)h_pubs, pubs_words, threads);
+    } catch (...) {
+        ctx->err = "out of host memory";
+        return ZP_ERR_NOMEM;
+    }
+}
+
+// number of public inputs of a proof over the verifier AIR the descriptor belongs to (0: malformed descriptor)
+size_t zp_recursion_publics_words(const uint64_t *desc, size_t desc_words) {
+    Desc D;
+    if (!parse(desc, desc_words, &D)) return 0;
+    u64 tp_per = 0;
+    for (u64 j = 0; j < D.L; j++) tp_per += (D.script[j] & 255) + (((D.script[j] >> 8) & 1) ? 8 : 0);
+    return (size_t)(D.n_proofs * D.T * 4 + D.n_slots() * D.n_proofs * D.T + D.n_proofs * tp_per + D.n_proofs * D.ap_n + D.n_slots() * D.n_proofs * 3);
 }
 
 }  // extern "C"

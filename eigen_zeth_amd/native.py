@@ -107,6 +107,8 @@ SIGNATURES = {
     "zp_proof_queries_parse": (C.c_int32, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "zp_verifier_arith_host": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "zp_verifier_arith_trace": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
+    "zp_recursion_witness": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int32]),
+    "zp_recursion_publics_words": (C.c_size_t, [_vp, C.c_size_t]),
     "zp_comm_unique_id": (C.c_int32, [_vp]),
     "zp_comm_create": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, C.POINTER(_vp)]),
     "zp_comm_destroy": (C.c_int32, [_vp]),
@@ -544,6 +546,24 @@ class Prover:
         if rc in (-10, -11):
             raise _arith_error(rc)
         self._chk(rc)
+
+    def recursion_witness(self, desc, index, values, paths, streams, d_trace, threads=0):
+        """zp_recursion_witness: the whole verifier-AIR witness of inner proofs given as arrays (per proof: index u64[nq], values / paths in
+        the layout of zp_proof_queries_parse, the transcript stream); the trace is written at d_trace, the public inputs are returned"""
+        d = np.ascontiguousarray(np.asarray(desc, dtype=np.uint64))
+        n = len(index)
+        keep = [[np.ascontiguousarray(a, dtype=np.uint64) for a in arrs] for arrs in (index, values, paths, streams)]
+        ptrs = [(C.c_void_p * n)(*[a.ctypes.data for a in arrs]) for arrs in keep]
+        sw = (C.c_size_t * n)(*[a.size for a in keep[3]])
+        npub = int(self.lib.zp_recursion_publics_words(d.ctypes.data, d.size))
+        if npub == 0:
+            raise ZpError(-1, "malformed witness descriptor")
+        pubs = np.empty(npub, dtype=np.uint64)
+        rc = self.lib.zp_recursion_witness(self.ctx, d.ctypes.data, d.size, ptrs[0], ptrs[1], ptrs[2], ptrs[3], sw, _ptr(d_trace), pubs.ctypes.data, npub, threads)
+        if rc in (-10, -11, -13, -14):
+            raise ValueError((self.lib.zp_last_error(self.ctx) or b"inner proof does not verify: no accepting witness").decode())
+        self._chk(rc)
+        return pubs
 
     def poseidon_perm(self, d_states, count):
         self._chk(self.lib.zp_poseidon_perm(self.ctx, _ptr(d_states), count))

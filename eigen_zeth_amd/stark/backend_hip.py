@@ -147,6 +147,27 @@ class HipBackend:
         d_tr.shape = (VA.WIDTH, N)
         return d_tr
 
+    def recursion_witness(self, shape, proofs, prepared, digest_words):
+        """(device trace u64[WIDTH][N], public inputs) of the verifier AIR through ONE library call (zp_recursion_witness: hashing walk,
+        transcript replays, public inputs, trace assembly in HBM) -- what VA.build_witness does step by step in Python"""
+        from . import verifier_air as VA
+        k, periods, pb = shape.layout()
+        N = 32 * pb * periods
+        index, values, paths, streams = [], [], [], []
+        for pr, pp in zip(proofs, prepared):
+            index.append(pp["index"])
+            values.append(np.concatenate([np.ascontiguousarray(v).reshape(-1) for v in pp["values"]]))
+            paths.append(np.concatenate([np.ascontiguousarray(v).reshape(-1) for v in pp["paths"]]))
+            streams.append(VA.transcript_stream(shape, pr, digest_words))
+        d_tr = self.p.alloc(VA.WIDTH * N)
+        try:
+            pubs = self.p.recursion_witness(VA.arith_descriptor(shape), index, values, paths, streams, d_tr)
+        except BaseException:
+            d_tr.free()
+            raise
+        d_tr.shape = (VA.WIDTH, N)
+        return d_tr, pubs
+
     def verifier_arith_columns(self, shape, arith_in):
         """the 21 arithmetic columns of the verifier trace, built by the library (host walk + expansion kernel: zp_verifier_arith_trace) into a
         device buffer u64[21][N] that verifier_trace_device splices behind the hashing columns"""

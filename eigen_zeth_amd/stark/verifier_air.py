@@ -748,6 +748,37 @@ def replay_transcript(shape, proof, digest_words, be):
     return [r[0] for r in rec], tp, chal
 
 
+def transcript_stream(shape, proof, digest_words):
+    """what an inner proof's transcript absorbs, in protocol order, as one u64 array -- the form the native witness builder takes
+    (zp_recursion_witness; layout in include/zeth_prover.h): AIR digest words | public inputs | roots of trace, [stage2], quotient |
+    evaluations at zeta | at zeta w | FRI roots | final layer (3 planes) | grinding nonce (if any)"""
+    try:
+        out = [int(v) for v in digest_words] + [int(v) for v in proof["publics"]] + [int(v) for v in proof["roots"]["trace"]]
+        if shape.W2:
+            out += [int(v) for v in proof["roots"]["stage2"]]
+        out += [int(v) for v in proof["roots"]["quotient"]]
+        for r in proof["evals"]["z"] + proof["evals"]["zw"]:
+            if len(r) != 3:
+                raise ValueError("inner proof is malformed (evaluation)")
+            out += [int(v) for v in r]
+        for root in proof["fri"]["roots"]:
+            out += [int(v) for v in root]
+        for c in range(3):
+            out += [int(v) for v in proof["fri"]["final"][c]]
+        if shape.pow_bits:
+            nonce = int(proof.get("pow_nonce", -1))
+            if not 0 <= nonce < P:
+                raise ValueError("grinding nonce missing")
+            out.append(nonce)
+        Wt = shape.W + shape.W2
+        want = 4 + shape.n_pub_inner + 4 * len(shape.trees) + 3 * (Wt + shape.Wq) + 3 * Wt + (3 << shape.final_log) + (1 if shape.pow_bits else 0)
+        if len(out) != want or any(not 0 <= v < P for v in out):
+            raise ValueError("inner proof does not have the shape the verifier AIR was built for")
+        return np.array(out, dtype=np.uint64)
+    except (KeyError, TypeError, IndexError, OverflowError) as e:
+        raise ValueError("inner proof is malformed (%s)" % e)
+
+
 def arith_publics(shape, proof, chal):
     """the arithmetic section of ONE inner proof's public inputs (layout: AP_*): powers of g = 1 / gamma, the two DEEP constants
     gamma^(Wall-1), gamma^(Wall+Wt-1), the public halves of the two DEEP sums E_z = sum_k gamma^k ev_k(zeta), E_zw = sum_k gamma^(Wall+k) ev_k(zeta w),
@@ -947,6 +978,11 @@ def build_witness(shape, proofs, be, digest_words, prepared=None, keep=None):
         assert Shape.of_proof(pr, shape.n_proofs).key() == shape.key(), "inner proofs of different shapes"
     if prepared is None:
         prepared = [prepare_proof(pr) for pr in proofs]
+    for pp in prepared:
+        if pp["key"] != shape.key()[:8]:
+            raise ValueError("inner proofs of different shapes")
+    if hasattr(be, "recursion_witness") and keep is None:
+        return be.recursion_witness(shape, proofs, prepared, digest_words)      # the same witness through ONE library call (csrc/recursion.hip)
     k, periods, pb = shape.layout()
     nblk = pb * periods
     N = ROWS * nblk
@@ -1046,7 +1082,8 @@ ARITH_DESC_MAGIC = int.from_bytes(b"PZVARITH", "little")
 
 def arith_descriptor(shape):
     """the schedule of the arithmetic columns as data for the native builder (zp_verifier_arith_host / zp_verifier_arith_trace; layout in
-    csrc/recursion.hip): header | one word per block of a period | one record per committed tree | the inverse-DFT tables of the folds"""
+    csrc/recursion.hip): header (schedule sizes + the inner proofs' shape) | one word per block of a period | one record per committed tree |
+    the inverse-DFT tables of the folds | the transcript script (one word per permutation of an inner proof's sponge)"""
     cached = _DESC_CACHE.get(shape.key())
     if cached is not None:
         return cached
@@ -1083,8 +1120,11 @@ def arith_descriptor(shape):
                 n_fold += 1
         tree_words += rec
     n_open = shape.n_slots() * shape.n_proofs * T
-    hdr = [ARITH_DESC_MAGIC, pb, periods, k, shape.n_proofs, T, TQ, max_w, n_open, shape.arith_pubs_per_proof(), n_fold, 0]
-    desc = np.array(hdr + blk_words + tree_words + fold_words, dtype=np.uint64)
+    script = [pm["n_in"] | int(pm["out"]) << 8 | int(pm["first"]) << 9 | int(pm["pow"]) << 10 for pm in shape.transcript_perms()]
+    hdr = [ARITH_DESC_MAGIC, pb, periods, k, shape.n_proofs, T, TQ, max_w, n_open, shape.arith_pubs_per_proof(), n_fold, shape.n_queries, len(script),
+           shape.transcript_block0(), shape.W, shape.W2, shape.Wq, shape.final_log, shape.n_pub_inner, shape.pow_bits, shape.logn, shape.logb,
+           shape.fri_logf, shape.fri_final_log, shape.root32, shape.shift]
+    desc = np.array(hdr + blk_words + tree_words + fold_words + script, dtype=np.uint64)
     _DESC_CACHE[shape.key()] = desc
     return desc
 

@@ -336,6 +336,22 @@ int32_t zp_verifier_arith_trace(zp_ctx *ctx, const uint64_t *desc, size_t desc_w
                                 const uint64_t *dbit, const int64_t *blk_op, const uint64_t *arith_pubs, const uint64_t *final_vals,
                                 uint64_t *d_out, int32_t threads);
 
+/* The WHOLE witness of the verifier AIR behind one call -- what a host does for GenAggregatedProof / the final STARK between parsing the
+ * inner proofs and zp_stark_prove(_bn128): every opening hashed (leaf sponge + path) level-synchronously on the GPU, the inner Fiat-Shamir
+ * transcripts replayed (zp_poseidon_sponge_caps), the public inputs assembled, the permutation blocks traced (zp_poseidon_trace), the
+ * arithmetic columns walked and expanded: d_trace u64[47][32 * blocks] is assembled in HBM, h_pubs receives the public inputs
+ * (zp_recursion_publics_words(desc) words: roots | leaf indices | transcripts | arithmetic constants | final-layer values).
+ * desc: verifier_air.arith_descriptor(shape).  Per inner proof p: h_index[p] u64[nq], h_values[p] / h_paths[p] in the layout of
+ * zp_proof_queries_parse (trees in the order trace, [stage2], quotient, fri0 ..), h_stream[p] = what its transcript absorbs, in protocol
+ * order: AIR digest words[4] | public inputs | roots of trace, [stage2], quotient (4 each) | evaluations at zeta ((W + W2 + Wq) x 3) | at
+ * zeta w ((W + W2) x 3) | FRI roots (4 each) | final layer (3 planes) | grinding nonce (if the proofs grind).
+ * Returns -13: an opening does not hash to its root; -14: the transcript does not give the proof's query indices / the nonce fails;
+ * -10 / -11: the opened values are inconsistent (zp_verifier_arith_host) -- inner proofs that do not verify have no accepting witness. */
+int32_t zp_recursion_witness(zp_ctx *ctx, const uint64_t *desc, size_t desc_words, const uint64_t *const *h_index, const uint64_t *const *h_values,
+                             const uint64_t *const *h_paths, const uint64_t *const *h_stream, const size_t *stream_words, uint64_t *d_trace,
+                             uint64_t *h_pubs, size_t pubs_words, int32_t threads);
+size_t zp_recursion_publics_words(const uint64_t *desc, size_t desc_words);
+
 /* ---- multi-GPU: RCCL over xGMI behind the C-ABI (BASELINE.json configs[3]) ---------------------------------
  * One process per GPU; a zp_comm joins this rank's ctx to the RCCL communicator of `world` ranks (a power of two).  Rank 0 makes
  * the 128-byte id (zp_comm_unique_id) and hands it to the others out of band (a file, the service's own channel); every rank

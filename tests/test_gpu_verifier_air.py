@@ -75,9 +75,20 @@ def test_aggregation_stark_gpu_equals_cpu_and_verifies(hip, tables, airname, log
     shape = VA.Shape.of_proof(proofs[0], 2)
     vair = VA.verifier_air(shape, rc, mds)
     d_gpu, pubs = VA.build_witness(shape, proofs, hip, air.digest_words())               # assembled in HBM (zp_poseidon_trace, native arithmetic columns)
-    t_gpu = hip.p.download(d_gpu, d_gpu.shape)
+    t_gpu = hip.p.download(d_gpu, d_gpu.shape)                                           # ... through ONE library call: zp_recursion_witness
     t_cpu, pubs_c = VA.build_witness(shape, proofs, cpu, air.digest_words())
     assert (t_gpu == t_cpu).all() and (pubs == pubs_c).all()
+    d_step, pubs_s = VA.build_witness(shape, proofs, hip, air.digest_words(), keep={})   # the step-by-step path over the same GPU backend
+    assert (hip.p.download(d_step, d_step.shape) == t_cpu).all() and (pubs_s == pubs_c).all()
+    d_step.free()
+    for mutate, what in ((lambda p: p[1]["queries"][1]["fri"][0]["values"].__setitem__(2, p[1]["queries"][1]["fri"][0]["values"][2] ^ 1), "hash"),
+                         (lambda p: p[0]["queries"][2]["trace"]["path"][1].__setitem__(0, p[0]["queries"][2]["trace"]["path"][1][0] ^ 1), "hash"),
+                         (lambda p: p[0]["queries"][0].__setitem__("index", p[0]["queries"][0]["index"] ^ 1), "transcript"),
+                         (lambda p: p[1]["evals"]["z"][1].__setitem__(0, p[1]["evals"]["z"][1][0] ^ 1), "transcript")):
+        bad = copy.deepcopy(proofs)
+        mutate(bad)
+        with pytest.raises(ValueError, match="no accepting witness"):                     # refused by the library, whatever is wrong
+            VA.build_witness(shape, bad, hip, air.digest_words())
     ap = VA.aggregation_params(shape, n_queries=5, fri_final_log=3)
     p_cpu = PR.proof_to_json(PR.prove(vair, t_cpu, pubs, ap, cpu))
     p_gpu = PR.proof_to_json(PR.prove(vair, t_gpu, pubs, ap, hip))
