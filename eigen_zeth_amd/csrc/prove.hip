@@ -306,6 +306,20 @@ int32_t zp_free_buffer(void *p) {
     return ZP_OK;
 }
 
+// SHA-256 of a constraint program blob: the AIR digest.  out32 = the 32 digest bytes (a proof text names the first 8 as 16 hex digits);
+// out_words4 (may be NULL) = the four little-endian 64-bit words, each reduced mod p, that the provers absorb into the transcript.
+int32_t zp_program_digest(const uint64_t *h_program, size_t program_words, uint8_t *out32, uint64_t *out_words4) {
+    if (!h_program || !out32 || program_words == 0) return ZP_ERR_ARG;
+    Sha256::digest((const uint8_t *)h_program, program_words * 8, out32);
+    if (out_words4)
+        for (int i = 0; i < 4; i++) {
+            uint64_t w = 0;
+            for (int b = 7; b >= 0; b--) w = (w << 8) | out32[8 * i + b];
+            out_words4[i] = w % GL_P;
+        }
+    return ZP_OK;
+}
+
 static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
                           size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
                           int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {

@@ -107,6 +107,7 @@ SIGNATURES = {
     "zp_proof_queries_parse": (C.c_int32, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "zp_verifier_arith_host": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "zp_verifier_arith_trace": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
+    "zp_program_digest": (C.c_int32, [_vp, C.c_size_t, _vp, _vp]),
     "zp_recursion_witness": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int32]),
     "zp_recursion_publics_words": (C.c_size_t, [_vp, C.c_size_t]),
     "zp_comm_unique_id": (C.c_int32, [_vp]),

@@ -46,6 +46,22 @@ def _no_cyclic_gc():
             gc.enable()
 
 
+AGGREGATED_STATEMENT = ("for every query slot, inner proof and committed tree there are values that hash, as a leaf and up a path "
+                        "along the bits of the public index, to the public root; they give the DEEP quotient at the query point, "
+                        "every FRI layer's opened coset interpolates the value the layer before claims and folds to the next, the "
+                        "last fold is the public final-layer value; the Fiat-Shamir sponge of every inner proof absorbs the public "
+                        "blocks and yields the public rates, its grinding hash the public digest (what is left to the checker per "
+                        "inner proof: the out-of-domain identity, the final layer's degree, reading the transcript -- on 'inner', "
+                        "which holds no openings)")
+
+
+def aggregated_head(batch_id, shape, level, vair_digest):
+    """the text an aggregated proof starts with, up to (not including) its "inner" member -- one definition for the engine and for the files a
+    compiled host works from (tools/export_recursion_shape.py -> host/aggregate.cpp)"""
+    return json.dumps({"kind": "aggregated", "version": 1, "batch_id": batch_id, "statement": AGGREGATED_STATEMENT, "shape": shape.to_dict(),
+                       "level": level, "slots": shape.n_slots(), "verifier_air_digest": vair_digest}, separators=(",", ":"))[:-1]
+
+
 class EngineConfig:
     """Default chunk-STARK security: 80 queries x blow-up 2 (1 bit each) + 20 bits of proof-of-work grinding = 100 bits
     CONJECTURED (ethSTARK-style, stark/prover.py StarkParams.security_bits; the provable FRI bound at these parameters is about
@@ -448,19 +464,11 @@ class Engine:
         if self.metrics is not None:
             for k, v in tm.items():
                 self.metrics.record_stage(k, v)
-        head = json.dumps({"kind": "aggregated", "version": 1, "batch_id": batch_id,
-                           "statement": "for every query slot, inner proof and committed tree there are values that hash, as a leaf and up a path "
-                                        "along the bits of the public index, to the public root; they give the DEEP quotient at the query point, "
-                                        "every FRI layer's opened coset interpolates the value the layer before claims and folds to the next, the "
-                                        "last fold is the public final-layer value; the Fiat-Shamir sponge of every inner proof absorbs the public "
-                                        "blocks and yields the public rates, its grinding hash the public digest (what is left to the checker per "
-                                        "inner proof: the out-of-domain identity, the final layer's degree, reading the transcript -- on 'inner', "
-                                        "which holds no openings)",
-                           "shape": shape.to_dict(), "level": level,
-                           "slots": shape.n_slots(), "verifier_air_digest": vair.digest(),
-                           "inner": [self._header(pr) for pr in proofs],
-                           **({"children": children} if children else {})}, separators=(",", ":"))
-        return head[:-1] + ',"stark":' + text + "}"
+        head = aggregated_head(batch_id, shape, level, vair.digest())
+        head += ',"inner":' + json.dumps([self._header(pr) for pr in proofs], separators=(",", ":"))
+        if children:
+            head += ',"children":' + json.dumps(children, separators=(",", ":"))
+        return head + ',"stark":' + text + "}"
 
     def _agg_params(self, sh):
         return VA.aggregation_params(sh, self.cfg.agg_queries, self.cfg.fri_logf, self.cfg.fri_final_log, self.cfg.agg_pow_bits)

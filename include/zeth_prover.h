@@ -192,6 +192,10 @@ int32_t zp_stark_prove_bn128(zp_ctx *ctx, const char *air_name, const uint64_t *
                              size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf,
                              int32_t fri_final_log, int32_t n_queries, char **out_json, size_t *out_len);
 int32_t zp_free_buffer(void *p);
+/* the AIR digest of a constraint program blob (host code, no ctx): SHA-256, out32 = the digest bytes (a proof's "air_digest" is the hex of the
+ * first 8), out_words4 (or NULL) = the four 64-bit words (little-endian, mod p) a prover absorbs into its transcript and a verifier-AIR
+ * witness builder needs for the inner proofs' statement (zp_recursion_witness: the head of the transcript stream). */
+int32_t zp_program_digest(const uint64_t *h_program, size_t program_words, uint8_t *out32, uint64_t *out_words4);
 
 /* ---- N5: FRI fold ------------------------------------------------------------------------------
  * d_in u64[3][2^logn] = f on shift*<w_n> (natural order);  d_out u64[3][2^(logn-logf)] =

@@ -72,6 +72,8 @@ def test_compiled_host_builds_against_the_header_alone():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-C", os.path.join(root, "host"), "-s", "-B"])
-    assert os.path.exists(os.path.join(root, "host", "prove_chunk"))
+    assert os.path.exists(os.path.join(root, "host", "prove_chunk")) and os.path.exists(os.path.join(root, "host", "aggregate"))
+    agg = open(os.path.join(root, "host", "aggregate.cpp")).read()
+    assert "#include \"../include/zeth_prover.h\"" in agg and "Python.h" not in agg and "torch" not in agg.replace("no torch", "")
     src = open(os.path.join(root, "host", "prove_chunk.cpp")).read()
     assert "#include \"../include/zeth_prover.h\"" in src and "import" not in src and "torch" not in src.replace("no torch", "")

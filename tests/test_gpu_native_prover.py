@@ -160,3 +160,45 @@ def test_compiled_host_shards_one_proof_over_the_visible_gpus(tmp_path, prover, 
     single = prover.stark_prove(air.name, air.program(), d, [int(v) for v in pub], 10, 1, 3, 3, 12, 6)
     d.free()
     assert out.read_text() == single
+
+
+def test_compiled_host_answers_gen_aggregated_proof_like_the_service(tmp_path, tables):
+    """host/aggregate (C++ on include/zeth_prover.h alone: zp_proof_queries_scan / _parse, zp_program_digest, zp_recursion_witness,
+    zp_stark_prove; the verifier AIR and its witness schedule as data files from tools/export_recursion_shape.py) writes, for the two
+    chunk proofs of a GenAggregatedProof request (prover.proto:115-126), BYTE FOR BYTE the aggregated proof the Python service's engine
+    answers -- and the checker accepts it"""
+    import os
+    import subprocess
+    import sys
+    from eigen_zeth_amd.service.engine import Engine, EngineConfig
+    from eigen_zeth_amd.service.server import default_backend_factory
+    from eigen_zeth_amd.stark import verifier_air as VA
+    from oracle import aggregate_verify as AV
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import export_recursion_shape as EX
+    rc, mds = tables
+    cfg = EngineConfig(air="chunk64", logn=12, chunks_per_block=1, groth16_logm=6, crs_dir=str(tmp_path / "crs"), n_queries=24, pow_bits=8, agg_queries=10)
+    eng = Engine(default_backend_factory(0), cfg)
+    ch = eng.gen_batch_chunks("b", [7, 8], 12345, "evm")
+    proofs = eng.gen_chunk_proofs("b", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+    want = eng.aggregate("batch-7", proofs[0]["proof"], proofs[1]["proof"])
+    shape, vair, ap = EX.export(str(tmp_path / "shape"), logn=12, n_proofs=2, cfg=cfg)
+    (tmp_path / "p1.json").write_text(proofs[0]["proof"])
+    (tmp_path / "p2.json").write_text(proofs[1]["proof"])
+    exe = os.path.join(root, "host", "aggregate")
+    r = subprocess.run([exe, str(tmp_path / "shape"), "batch-7", str(tmp_path / "p1.json"), str(tmp_path / "p2.json"), str(tmp_path / "agg.json")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = (tmp_path / "agg.json").read_text()
+    assert got == want
+    agg = json.loads(got)
+    assert AV.verify(agg, AIR.get_air("chunk64").program(), vair.program(), rc, mds, V.expectation(eng.stark_params(12).to_dict()),
+                     V.expectation(ap.to_dict()), shape.n_slots())
+    # a proof of the request tampered with: the compiled host refuses as the service does (no accepting witness)
+    bad = json.loads(proofs[1]["proof"])
+    bad["queries"][3]["quotient"]["values"][1] ^= 1
+    (tmp_path / "p2.json").write_text(json.dumps(bad, separators=(",", ":")))
+    r = subprocess.run([exe, str(tmp_path / "shape"), "batch-7", str(tmp_path / "p1.json"), str(tmp_path / "p2.json"), str(tmp_path / "agg2.json")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no accepting witness" in r.stderr and not (tmp_path / "agg2.json").exists()
