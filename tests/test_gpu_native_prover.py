@@ -174,6 +174,7 @@ def test_compiled_host_answers_gen_aggregated_proof_like_the_service(tmp_path, t
     from eigen_zeth_amd.service.server import default_backend_factory
     from eigen_zeth_amd.stark import verifier_air as VA
     from oracle import aggregate_verify as AV
+    from oracle import stark_verify as V
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import export_recursion_shape as EX
