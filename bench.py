@@ -151,9 +151,8 @@ def integer_roofline(prover, pass_rows, alg_bytes, elems_per_launch):
     as such, not re-measured here); the issue ceiling is 1024 SIMDs x 64 lanes x clock / 4 cycles per instruction (every
     instruction of these kernels is of the 4-cycle class: tools/ubench_isa.hip, profiles/r2_ubench_isa.txt).  frac_int = the time the
     pure instruction issue of a launch needs / the measured launch time."""
-    path = os.path.join(ROOT, "profiles", "r3_integer_roofline.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "integer_roofline.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r4_integer_roofline.json", "r3_integer_roofline.json", "integer_roofline.json"))
+                 if os.path.exists(q)), os.path.join(ROOT, "profiles", "integer_roofline.json"))
     try:
         tab = json.load(open(path))
         info = prover.device_info()
@@ -326,7 +325,7 @@ def main():
                               "frac": (alg_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if a_ms else None})
         slowest = max((r for r in pass_rows if r["avg_launch_ms"]), key=lambda r: r["avg_launch_ms"], default=None)
         traffic, traffic_src = None, None
-        for tp in ("r3_ntt_traffic.json", "ntt_traffic.json"):
+        for tp in ("r4_ntt_traffic.json", "r3_ntt_traffic.json", "ntt_traffic.json"):
             tp = os.path.join(ROOT, "profiles", tp)
             if os.path.exists(tp):
                 try:

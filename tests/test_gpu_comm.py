@@ -72,3 +72,21 @@ def test_compiled_host_shards_one_commitment_over_the_visible_gpus(prover, table
         assert p.returncode == 0, so + se
         words = so.split("root ")[1].split()[:4]
         assert [int(w, 16) for w in words] == [int(v) for v in want], so
+
+
+def test_an_aborted_rccl_communicator_refuses_collectives(prover):
+    """zp_comm_abort on an RCCL communicator (one rank on this box): ncclCommAbort takes it down, every later collective answers ZP_ERR_COMM
+    instead of waiting for peers that will never come; zp_comm_set_timeout_ms arms the watchdog of the RCCL path (csrc/comm.hip: rccl_wait)"""
+    comm = native.Comm(prover, 0, 1, native.comm_unique_id())
+    try:
+        comm.set_timeout_ms(5000)
+        d_x, d_y = prover.upload(O.random_field((4,), 3)), prover.alloc(4)
+        comm.all_gather(d_x, d_y, 4)
+        assert (prover.download(d_y, (4,)) == prover.download(d_x, (4,))).all()
+        comm.abort()
+        with pytest.raises(native.ZpError) as e:
+            comm.all_gather(d_x, d_y, 4)
+        assert e.value.code == -6                 # ZP_ERR_COMM
+        comm.abort()                              # idempotent
+    finally:
+        comm.close()

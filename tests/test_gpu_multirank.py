@@ -71,6 +71,29 @@ def test_bench_n2_code_path_on_one_gpu():
     assert pipe["msm_bn254"]["on_curve"]
 
 
+def test_bench_strong_scaling_mode_and_the_timed_exchange_loops():
+    """(i) bench.py --gpus 2 --scaling strong rehearsed over gloo: BASELINE configs[3] as stated -- `--cols` columns IN TOTAL, cols / N per
+    GPU -- and the line says so; (ii) bench.py at N = 1 on RCCL: the exchange step of the path timed in its own K-step loops on the
+    communicator behind the C-ABI (a communicator of one rank here: send / recv to self, all-gather, the code path a SCALE run takes)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ZP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--logn", "18", "--cols", "16", "--scaling", "strong", "--no-pipeline", "--no-cpu"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["config"]["cols_per_gpu"] == 8 and line["config"]["cols_total"] == 16 and line["n_gpus"] == 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--logn", "18", "--cols", "16", "--no-cpu", "--no-config5",
+           "--stark-logn", "12"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ex = line["pipeline"]["exchange"]
+    assert "error" not in ex and ex["world"] == 1 and ex["all_to_all"]["steps"] == 3 and ex["all_to_all"]["median_ms"] > 0
+    assert ex["sharded_commit"]["min_ms"] > 0 and ex["root_matches_torch_path"]
+
+
 def test_rccl_world_of_one_on_the_one_gpu_box():
     """RCCL itself on the driver's one-GPU box: tools/multigpu_check.py under torch.distributed.run with ONE rank and the
     `nccl` backend (= RCCL).  The process group is created on RCCL, and every collective wrapper of multigpu.py takes its

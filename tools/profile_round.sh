@@ -7,7 +7,7 @@ TAG=${1:-rX}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_bench -- python3 $ROOT/bench.py --no-cpu --no-pipeline --steps 10 > $OUT/${TAG}_bench_under_profiler.json 2> $OUT/${TAG}_bench_under_profiler.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_bench -- python3 $ROOT/bench.py --no-cpu --no-pipeline --no-config5 --steps 10 > $OUT/${TAG}_bench_under_profiler.json 2> $OUT/${TAG}_bench_under_profiler.err
 cp $(ls $OUT/prof_${TAG}_bench/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 echo "kernel stats done"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/prof_${TAG}_sq -- python3 $ROOT/tools/pmc_ntt.py > /dev/null 2>&1
@@ -17,6 +17,12 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG
 python3 $ROOT/tools/pmc_summary.py $OUT/prof_${TAG}_fetch ntt_pass2 > $OUT/${TAG}_pmc_fetch_ntt.json
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_write -- python3 $ROOT/tools/pmc_ntt.py > /dev/null 2>&1
 python3 $ROOT/tools/pmc_summary.py $OUT/prof_${TAG}_write ntt_pass2 > $OUT/${TAG}_pmc_write_ntt.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_lfetch -- python3 $ROOT/tools/pmc_lde.py > /dev/null 2>&1
+python3 $ROOT/tools/pmc_summary.py $OUT/prof_${TAG}_lfetch ntt_pass2 > $OUT/${TAG}_pmc_fetch_lde.json
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_lwrite -- python3 $ROOT/tools/pmc_lde.py > /dev/null 2>&1
+python3 $ROOT/tools/pmc_summary.py $OUT/prof_${TAG}_lwrite ntt_pass2 > $OUT/${TAG}_pmc_write_lde.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_lstats -- python3 $ROOT/tools/pmc_lde.py > /dev/null 2>&1
+cp $(ls $OUT/prof_${TAG}_lstats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_lde_kernel_stats.csv
 echo "traffic done"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/prof_${TAG}_pos -- python3 $ROOT/tools/hash_bench.py > /dev/null 2>&1
 python3 $ROOT/tools/pmc_summary.py $OUT/prof_${TAG}_pos > $OUT/${TAG}_pmc_sq_poseidon.json
@@ -37,4 +43,7 @@ json.dump({"per_kernel": rows, "hbm_bytes_per_launch_dominant": worst["fetch_byt
            "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (KiB units); FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md"},
           open("$OUT/${TAG}_ntt_traffic.json", "w"), indent=1)
 PY
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_rec -- python3 $ROOT/tools/recursion_bench.py 20 3 > $OUT/${TAG}_recursion_under_profiler.txt 2>&1
+cp $(ls $OUT/prof_${TAG}_rec/*/*kernel_stats.csv | head -1) $OUT/${TAG}_recursion_kernel_stats.csv
+echo "recursion done"
 rm -rf $OUT/prof_${TAG}_*
