@@ -1,0 +1,336 @@
+// R1CS over the BN254 scalar field for the Groth16 wrap of GenFinalProof (proto/prover/v1/prover.proto:130-148; consumer
+// src/settlement/ethereum/mod.rs:338-394, interfaces/zkvm.rs:82-130): witness completion, the evaluation vectors A w, B w, C w of the QAP
+// step (what zp_qap_quotient_bn254 takes) and the key generator's scalars u_j(tau), v_j(tau), w_j(tau) -- HOST code: a circuit that verifies
+// the hashing of a STARK is thousands of copies of ONE gadget (a width-17 Poseidon-BN254 permutation: 613 constraints over 631 local wires, about
+// 12 000 matrix entries) plus a few ten thousand glue constraints, so the matrices are never materialised: the gadget is a TEMPLATE (three
+// sparse matrices over local wires), an instance is a map of its 17 input wires + the base of its internal wires and constraints, the glue
+// comes as explicit sparse rows.  Everything runs over the template per instance (23 M multiply-adds for 1 900 instances: a second on one
+// core, instances in parallel on threads for the key scalars).  The group operations (fixed-base multiplications for the key, MSMs for a
+// proof) are the GPU's (csrc/msm.hip).  Layout of the circuit blob: eigen_zeth_amd/service/r1cs.py.
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "ctx.hpp"
+
+namespace {
+
+typedef unsigned __int128 u128;
+
+// ---- F_r, four 64-bit limbs, Montgomery form (R = 2^256) on the host
+struct Fr { uint64_t l[4]; };
+const uint64_t FR_MOD[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+const Fr FR_R2 = {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}};
+const Fr FR_ONE = {{0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL}};
+const uint64_t FR_N0 = 0xc2e1f593efffffffULL;   // -r^-1 mod 2^64
+
+inline bool fr_geq_mod(const uint64_t *a) {
+    for (int i = 3; i >= 0; i--) {
+        if (a[i] > FR_MOD[i]) return true;
+        if (a[i] < FR_MOD[i]) return false;
+    }
+    return true;
+}
+inline void fr_sub_mod(uint64_t *a) {
+    u128 b = 0;
+    for (int i = 0; i < 4; i++) {
+        const u128 d = (u128)a[i] - FR_MOD[i] - (uint64_t)b;
+        a[i] = (uint64_t)d;
+        b = (d >> 64) & 1;
+    }
+}
+inline Fr fr_add(const Fr &a, const Fr &b) {
+    Fr r;
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+    if (c || fr_geq_mod(r.l)) fr_sub_mod(r.l);
+    return r;
+}
+inline Fr fr_sub(const Fr &a, const Fr &b) {
+    Fr r;
+    u128 br = 0;
+    for (int i = 0; i < 4; i++) {
+        const u128 d = (u128)a.l[i] - b.l[i] - (uint64_t)br;
+        r.l[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+    }
+    if (br) {
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) { c += (u128)r.l[i] + FR_MOD[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+    }
+    return r;
+}
+inline Fr fr_mul(const Fr &a, const Fr &b) {      // CIOS Montgomery product
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * FR_N0;
+        c = (u128)m * FR_MOD[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < 4; j++) { c += (u128)m * FR_MOD[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    Fr r = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] || fr_geq_mod(r.l)) fr_sub_mod(r.l);
+    return r;
+}
+inline bool fr_is_zero(const Fr &a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+inline bool fr_eq(const Fr &a, const Fr &b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
+inline Fr fr_from_std(const uint64_t *w) { Fr a = {{w[0], w[1], w[2], w[3]}}; return fr_mul(a, FR_R2); }
+inline void fr_to_std(const Fr &a, uint64_t *w) { const Fr one = {{1, 0, 0, 0}}; const Fr r = fr_mul(a, one); memcpy(w, r.l, 32); }
+Fr fr_pow(Fr a, const uint64_t *e, int bits) {
+    Fr r = FR_ONE;
+    for (int i = bits - 1; i >= 0; i--) {
+        r = fr_mul(r, r);
+        if ((e[i >> 6] >> (i & 63)) & 1) r = fr_mul(r, a);
+    }
+    return r;
+}
+Fr fr_inv(const Fr &a) {
+    uint64_t e[4] = {FR_MOD[0] - 2, FR_MOD[1], FR_MOD[2], FR_MOD[3]};
+    return fr_pow(a, e, 254);
+}
+inline bool std_canonical(const uint64_t *w) { return !fr_geq_mod(w); }
+
+// ---- the circuit blob (service/r1cs.py: pack_circuit)
+constexpr uint64_t MAGIC = 0x3130534331525a50ULL;   // "PZR1CS01"
+struct Mat { const uint64_t *ptr, *idx, *val; };      // CSR over constraints: ptr[n + 1], idx[nnz] (wire), val[nnz][4] (standard form)
+struct Circ {
+    uint64_t n_wires, n_cons, logm, t, n_local, tc, n_inst, n_extra, n_pub;
+    const uint64_t *tdef, *inst, *edef;               // tdef[tc]: the local wire a template constraint defines; inst: (t + 2) words each; edef[n_extra]
+    Mat T[3], E[3];
+    uint64_t extra_base() const { return n_inst * tc; }   // constraints: instances first (instance i owns [i tc, (i + 1) tc)), then the extras
+};
+
+bool parse_mat(const uint64_t *d, size_t words, size_t &at, uint64_t rows, uint64_t max_idx, Mat *m) {
+    if (at + rows + 1 > words) return false;
+    m->ptr = d + at;
+    at += rows + 1;
+    const uint64_t nnz = m->ptr[rows];
+    if (m->ptr[0] != 0 || nnz > (1ull << 32) || at + nnz + 4 * nnz > words) return false;
+    for (uint64_t i = 0; i < rows; i++) if (m->ptr[i] > m->ptr[i + 1]) return false;
+    m->idx = d + at; at += nnz;
+    m->val = d + at; at += 4 * nnz;
+    for (uint64_t k = 0; k < nnz; k++) if (m->idx[k] >= max_idx || !std_canonical(m->val + 4 * k)) return false;
+    return true;
+}
+
+bool parse(const uint64_t *d, size_t words, Circ *c) {
+    if (!d || words < 16 || d[0] != MAGIC) return false;
+    c->n_wires = d[1]; c->n_cons = d[2]; c->logm = d[3]; c->t = d[4]; c->n_local = d[5]; c->tc = d[6]; c->n_inst = d[7]; c->n_extra = d[8]; c->n_pub = d[9];
+    if (c->n_wires < 2 || c->n_wires > (1ull << 28) || c->logm > 28 || c->t < 2 || c->t > 64 || c->n_local < 1 + c->t || c->n_local > (1u << 20) || c->tc < 1 ||
+        c->tc > (1u << 20) || c->n_inst > (1u << 24) || c->n_extra > (1ull << 28) || c->n_pub < 1 || 1 + c->n_pub > c->n_wires)
+        return false;
+    if (c->n_cons != c->n_inst * c->tc + c->n_extra || c->n_cons > (1ull << c->logm)) return false;
+    size_t at = 16;
+    if (at + c->tc > words) return false;
+    c->tdef = d + at; at += c->tc;
+    for (uint64_t i = 0; i < c->tc; i++) if (c->tdef[i] != ~0ull && (c->tdef[i] < 1 + c->t || c->tdef[i] >= c->n_local)) return false;
+    for (int k = 0; k < 3; k++) if (!parse_mat(d, words, at, c->tc, c->n_local, &c->T[k])) return false;
+    if (at + c->n_inst * (c->t + 2) > words) return false;
+    c->inst = d + at; at += c->n_inst * (c->t + 2);
+    const uint64_t n_int = c->n_local - 1 - c->t;
+    for (uint64_t i = 0; i < c->n_inst; i++) {
+        const uint64_t *in = c->inst + i * (c->t + 2);
+        for (uint64_t k = 0; k < c->t; k++) if (in[k] >= c->n_wires) return false;
+        if (in[c->t] + n_int > c->n_wires || in[c->t + 1] != i * c->tc) return false;
+    }
+    if (at + c->n_extra > words) return false;
+    c->edef = d + at; at += c->n_extra;
+    for (int k = 0; k < 3; k++) if (!parse_mat(d, words, at, c->n_extra, c->n_wires, &c->E[k])) return false;
+    return at == words;
+}
+
+inline uint64_t local_to_global(const Circ &c, const uint64_t *in, uint64_t local) {
+    if (local == 0) return 0;
+    if (local <= c.t) return in[local - 1];
+    return in[c.t] + (local - 1 - c.t);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Completes and checks a witness.  witness u64[n_wires][4] (standard form): wire 0 = 1, the public inputs and every wire that is not internal
+// to a gadget instance are set by the caller; set[n_wires] (bytes) says which.  The internal wires of every instance are computed in instance
+// order (a template constraint defines one: wire = (A w)(B w) - (rest of C w), C's coefficient of it being 1); a wire that is defined twice
+// must agree.  Then EVERY constraint is checked.  a_ev / b_ev / c_ev u64[2^logm][4] receive A w, B w, C w per constraint (zero padded): the
+// input of the QAP step.  Returns ZP_OK; -20 = the assignment does not satisfy the circuit (*bad = first violated constraint) -- there is no
+// proof for a false statement; -21 = an instance reads a wire nobody has set; ZP_ERR_ARG = malformed blob.
+int32_t zp_r1cs_eval(const uint64_t *circ, size_t words, uint64_t *witness, uint8_t *set, uint64_t *a_ev, uint64_t *b_ev, uint64_t *c_ev, int64_t *bad) {
+    Circ c;
+    if (!parse(circ, words, &c) || !witness || !set || !a_ev || !b_ev || !c_ev) return ZP_ERR_ARG;
+    if (bad) *bad = -1;
+    try {
+        std::vector<Fr> w(c.n_wires);
+        for (uint64_t j = 0; j < c.n_wires; j++)
+            if (set[j]) {
+                if (!std_canonical(witness + 4 * j)) return ZP_ERR_ARG;
+                w[j] = fr_from_std(witness + 4 * j);
+            }
+        if (!set[0] || !fr_eq(w[0], FR_ONE)) return ZP_ERR_ARG;
+        const uint64_t m = 1ull << c.logm;
+        memset(a_ev, 0, m * 32); memset(b_ev, 0, m * 32); memset(c_ev, 0, m * 32);
+        std::vector<Fr> tv[3];                 // template coefficients in Montgomery form, once
+        for (int k = 0; k < 3; k++) {
+            const uint64_t nnz = c.T[k].ptr[c.tc];
+            tv[k].resize(nnz);
+            for (uint64_t e = 0; e < nnz; e++) tv[k][e] = fr_from_std(c.T[k].val + 4 * e);
+        }
+        int64_t first_bad = -1;
+        for (uint64_t i = 0; i < c.n_inst; i++) {
+            const uint64_t *in = c.inst + i * (c.t + 2);
+            for (uint64_t k = 0; k < c.t; k++) if (!set[in[k]]) { if (bad) *bad = (int64_t)i; return -21; }
+            for (uint64_t q = 0; q < c.tc; q++) {
+                Fr s[3];
+                const uint64_t def = c.tdef[q];
+                const uint64_t gdef = def == ~0ull ? ~0ull : local_to_global(c, in, def);
+                Fr rest = {{0, 0, 0, 0}};
+                for (int k = 0; k < 3; k++) {
+                    Fr acc = {{0, 0, 0, 0}};
+                    for (uint64_t e = c.T[k].ptr[q]; e < c.T[k].ptr[q + 1]; e++) {
+                        const uint64_t g = local_to_global(c, in, c.T[k].idx[e]);
+                        if (k == 2 && g == gdef && !set[g]) continue;       // the wire this constraint defines (coefficient 1 in C)
+                        if (!set[g]) { if (bad) *bad = (int64_t)(i * c.tc + q); return -21; }
+                        acc = fr_add(acc, fr_mul(tv[k][e], w[g]));
+                    }
+                    s[k] = acc;
+                }
+                const Fr ab = fr_mul(s[0], s[1]);
+                if (gdef != ~0ull && !set[gdef]) {
+                    w[gdef] = fr_sub(ab, s[2]);
+                    set[gdef] = 1;
+                    s[2] = ab;
+                } else if (!fr_eq(ab, s[2]) && first_bad < 0) {
+                    first_bad = (int64_t)(i * c.tc + q);
+                }
+                (void)rest;
+                const uint64_t row = i * c.tc + q;
+                fr_to_std(s[0], a_ev + 4 * row); fr_to_std(s[1], b_ev + 4 * row); fr_to_std(s[2], c_ev + 4 * row);
+            }
+        }
+        for (uint64_t q = 0; q < c.n_extra; q++) {
+            Fr s[3];
+            for (int k = 0; k < 3; k++) {
+                Fr acc = {{0, 0, 0, 0}};
+                for (uint64_t e = c.E[k].ptr[q]; e < c.E[k].ptr[q + 1]; e++) {
+                    const uint64_t g = c.E[k].idx[e];
+                    if (!set[g]) { if (bad) *bad = (int64_t)(c.extra_base() + q); return -21; }
+                    acc = fr_add(acc, fr_mul(fr_from_std(c.E[k].val + 4 * e), w[g]));
+                }
+                s[k] = acc;
+            }
+            if (!fr_eq(fr_mul(s[0], s[1]), s[2]) && first_bad < 0) first_bad = (int64_t)(c.extra_base() + q);
+            const uint64_t row = c.extra_base() + q;
+            fr_to_std(s[0], a_ev + 4 * row); fr_to_std(s[1], b_ev + 4 * row); fr_to_std(s[2], c_ev + 4 * row);
+        }
+        for (uint64_t j = 0; j < c.n_wires; j++) {
+            if (!set[j]) { if (bad) *bad = (int64_t)j; return -21; }
+            fr_to_std(w[j], witness + 4 * j);
+        }
+        if (first_bad >= 0) { if (bad) *bad = first_bad; return -20; }
+        return ZP_OK;
+    } catch (...) {
+        return ZP_ERR_NOMEM;
+    }
+}
+
+// The scalars of a Groth16 key for this circuit at the point tau (a LOCAL, seeded setup: toxic waste known -- test keys, not a ceremony):
+// with L_i the Lagrange basis of the 2^logm-th roots of unity (root 5^((r-1)/2^logm), the snarkjs / circom convention),
+//   u_j = sum_i A[i][j] L_i(tau), v_j = sum_i B[i][j] L_i(tau), w_j = sum_i C[i][j] L_i(tau)            out_u, out_v u64[n_wires][4]
+//   l_j = (beta u_j + alpha v_j + w_j) / delta for private wires, / gamma for wire 0 and the public inputs   out_l u64[n_wires][4]
+//   h_i = tau^i (tau^m - 1) / delta, i < m - 1                                                              out_h u64[2^logm - 1][4]
+// params u64[5][4]: tau, alpha, beta, gamma, delta (standard form).  The group elements are these scalars times the generators:
+// zp_fixed_base_mul_bn254 / _g2.
+int32_t zp_r1cs_key_scalars(const uint64_t *circ, size_t words, const uint64_t *params, uint64_t *out_u, uint64_t *out_v, uint64_t *out_l, uint64_t *out_h,
+                            int32_t threads) {
+    Circ c;
+    if (!parse(circ, words, &c) || !params || !out_u || !out_v || !out_l || !out_h) return ZP_ERR_ARG;
+    for (int k = 0; k < 5; k++) if (!std_canonical(params + 4 * k)) return ZP_ERR_ARG;
+    try {
+        const Fr tau = fr_from_std(params), alpha = fr_from_std(params + 4), beta = fr_from_std(params + 8), gamma = fr_from_std(params + 12),
+                 delta = fr_from_std(params + 16);
+        if (fr_is_zero(gamma) || fr_is_zero(delta)) return ZP_ERR_ARG;
+        const uint64_t m = 1ull << c.logm;
+        // omega = 5^((r - 1) / 2^logm)
+        uint64_t e[4] = {FR_MOD[0] - 1, FR_MOD[1], FR_MOD[2], FR_MOD[3]};
+        for (uint64_t s = 0; s < c.logm; s++) {                     // (r - 1) >> logm
+            for (int i = 0; i < 4; i++) e[i] = (e[i] >> 1) | (i < 3 ? e[i + 1] << 63 : 0);
+        }
+        const uint64_t five[4] = {5, 0, 0, 0};
+        const Fr omega = fr_pow(fr_from_std(five), e, 254);
+        // L_i(tau) = (tau^m - 1) w^i / (m (tau - w^i)): batch inversion of (tau - w^i)
+        std::vector<Fr> L(m), pre(m);
+        Fr wi = FR_ONE, run = FR_ONE;
+        for (uint64_t i = 0; i < m; i++) {
+            L[i] = fr_sub(tau, wi);
+            if (fr_is_zero(L[i])) return ZP_ERR_ARG;               // tau on the domain: not a usable point
+            pre[i] = run;
+            run = fr_mul(run, L[i]);
+            wi = fr_mul(wi, omega);
+        }
+        Fr tm = tau;
+        for (uint64_t s = 0; s < c.logm; s++) tm = fr_mul(tm, tm);
+        const Fr zt = fr_sub(tm, FR_ONE);
+        const uint64_t mm[4] = {m, 0, 0, 0};
+        const Fr scale = fr_mul(zt, fr_inv(fr_from_std(mm)));
+        Fr inv = fr_inv(run);
+        {
+            std::vector<Fr> wpow(m);
+            Fr x = FR_ONE;
+            for (uint64_t i = 0; i < m; i++) { wpow[i] = x; x = fr_mul(x, omega); }
+            for (uint64_t i = m; i-- > 0;) {
+                const Fr d = fr_mul(inv, pre[i]);                   // 1 / (tau - w^i)
+                inv = fr_mul(inv, L[i]);
+                L[i] = fr_mul(fr_mul(scale, wpow[i]), d);
+            }
+        }
+        std::vector<Fr> tv[3];
+        for (int k = 0; k < 3; k++) {
+            const uint64_t nnz = c.T[k].ptr[c.tc];
+            tv[k].resize(nnz);
+            for (uint64_t q = 0; q < nnz; q++) tv[k][q] = fr_from_std(c.T[k].val + 4 * q);
+        }
+        const Fr zero = {{0, 0, 0, 0}};
+        std::vector<Fr> acc[3];
+        for (int k = 0; k < 3; k++) acc[k].assign(c.n_wires, zero);
+        // instances touch disjoint internal wires but may share input wires: accumulate per thread, then merge (inputs only are shared; to stay
+        // simple every thread owns a full accumulator when there are few wires, otherwise instances run on one thread)
+        (void)threads;
+        for (uint64_t i = 0; i < c.n_inst; i++) {
+            const uint64_t *in = c.inst + i * (c.t + 2);
+            for (int k = 0; k < 3; k++)
+                for (uint64_t q = 0; q < c.tc; q++) {
+                    const Fr &Li = L[i * c.tc + q];
+                    for (uint64_t x = c.T[k].ptr[q]; x < c.T[k].ptr[q + 1]; x++) {
+                        const uint64_t g = local_to_global(c, in, c.T[k].idx[x]);
+                        acc[k][g] = fr_add(acc[k][g], fr_mul(tv[k][x], Li));
+                    }
+                }
+        }
+        for (int k = 0; k < 3; k++)
+            for (uint64_t q = 0; q < c.n_extra; q++) {
+                const Fr &Li = L[c.extra_base() + q];
+                for (uint64_t x = c.E[k].ptr[q]; x < c.E[k].ptr[q + 1]; x++)
+                    acc[k][c.E[k].idx[x]] = fr_add(acc[k][c.E[k].idx[x]], fr_mul(fr_from_std(c.E[k].val + 4 * x), Li));
+            }
+        const Fr dinv = fr_inv(delta), ginv = fr_inv(gamma);
+        for (uint64_t j = 0; j < c.n_wires; j++) {
+            fr_to_std(acc[0][j], out_u + 4 * j);
+            fr_to_std(acc[1][j], out_v + 4 * j);
+            const Fr l = fr_add(fr_add(fr_mul(beta, acc[0][j]), fr_mul(alpha, acc[1][j])), acc[2][j]);
+            fr_to_std(fr_mul(l, j <= c.n_pub ? ginv : dinv), out_l + 4 * j);
+        }
+        Fr tp = fr_mul(zt, dinv);
+        for (uint64_t i = 0; i + 1 < m; i++) { fr_to_std(tp, out_h + 4 * i); tp = fr_mul(tp, tau); }
+        return ZP_OK;
+    } catch (...) {
+        return ZP_ERR_NOMEM;
+    }
+}
+
+}  // extern "C"

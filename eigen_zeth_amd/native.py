@@ -107,6 +107,8 @@ SIGNATURES = {
     "zp_proof_queries_parse": (C.c_int32, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "zp_verifier_arith_host": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "zp_verifier_arith_trace": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
+    "zp_r1cs_eval": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "zp_r1cs_key_scalars": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "zp_program_digest": (C.c_int32, [_vp, C.c_size_t, _vp, _vp]),
     "zp_recursion_witness": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int32]),
     "zp_recursion_publics_words": (C.c_size_t, [_vp, C.c_size_t]),
@@ -251,6 +253,52 @@ class DeviceBuffer:
 def device_count():
     """visible HIP devices, through the library (no torch: a process that loads the system RCCL must not import torch's copy later)"""
     return int(load_library().zp_device_count())
+
+
+def fr_words(vals):
+    """ints < r -> u64[n][4] standard form"""
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        v = int(v)
+        for k in range(4):
+            out[i, k] = (v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def fr_ints(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+    return [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in a]
+
+
+def r1cs_eval(blob, witness, mask):
+    """zp_r1cs_eval: witness u64[n_wires][4] with `mask` (bytes) saying which wires the caller set -> (completed witness, a_ev, b_ev, c_ev each
+    u64[2^logm][4]); raises ValueError when the assignment does not satisfy the circuit"""
+    blob = np.ascontiguousarray(blob, dtype=np.uint64)
+    w = np.ascontiguousarray(witness, dtype=np.uint64).copy()
+    st = np.ascontiguousarray(mask, dtype=np.uint8).copy()
+    m = 1 << int(blob[3])
+    ev = [np.empty((m, 4), dtype=np.uint64) for _ in range(3)]
+    bad = C.c_int64(-1)
+    rc = load_library().zp_r1cs_eval(blob.ctypes.data, blob.size, w.ctypes.data, st.ctypes.data, ev[0].ctypes.data, ev[1].ctypes.data, ev[2].ctypes.data,
+                                     C.byref(bad))
+    if rc == -20:
+        raise ValueError("the assignment does not satisfy the circuit (constraint %d): no proof for a false statement" % bad.value)
+    if rc != 0:
+        raise ZpError(rc, "zp_r1cs_eval: malformed circuit or unset wire (%d)" % bad.value)
+    return w, ev[0], ev[1], ev[2]
+
+
+def r1cs_key_scalars(blob, tau, alpha, beta, gamma, delta):
+    """zp_r1cs_key_scalars -> (u, v, l each u64[n_wires][4], h u64[2^logm - 1][4])"""
+    blob = np.ascontiguousarray(blob, dtype=np.uint64)
+    nw, m = int(blob[1]), 1 << int(blob[3])
+    par = fr_words([tau, alpha, beta, gamma, delta])
+    u, v, l = (np.empty((nw, 4), dtype=np.uint64) for _ in range(3))
+    h = np.empty((m - 1, 4), dtype=np.uint64)
+    rc = load_library().zp_r1cs_key_scalars(blob.ctypes.data, blob.size, par.ctypes.data, u.ctypes.data, v.ctypes.data, l.ctypes.data, h.ctypes.data, 0)
+    if rc != 0:
+        raise ZpError(rc, "zp_r1cs_key_scalars: malformed circuit or parameters")
+    return u, v, l, h
 
 
 def json_key_span(data, key):

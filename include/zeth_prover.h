@@ -356,6 +356,18 @@ int32_t zp_recursion_witness(zp_ctx *ctx, const uint64_t *desc, size_t desc_word
                              uint64_t *h_pubs, size_t pubs_words, int32_t threads);
 size_t zp_recursion_publics_words(const uint64_t *desc, size_t desc_words);
 
+/* ---- R1CS over the BN254 scalar field for the Groth16 wrap (GenFinalProof, prover.proto:130-148; consumer ethereum/mod.rs:338-394) -------
+ * Host code, no ctx.  A circuit = many instances of ONE gadget template (a width-17 Poseidon-BN254 permutation: three sparse matrices over
+ * local wires) + explicit extra constraints; blob layout in eigen_zeth_amd/service/r1cs.py.  zp_r1cs_eval completes the witness (the internal
+ * wires of every instance, in order), checks EVERY constraint and writes A w, B w, C w (u64[2^logm][4], standard form: the input of
+ * zp_qap_quotient_bn254); -20: the assignment does not satisfy the circuit (*bad = first violated constraint); -21: a wire nobody set.
+ * zp_r1cs_key_scalars: the scalars of a Groth16 key at tau (params = tau, alpha, beta, gamma, delta; a LOCAL seeded setup, not a ceremony):
+ * u_j(tau), v_j(tau), l_j = (beta u_j + alpha v_j + w_j) / delta (or / gamma for the constant and the public inputs), h_i = tau^i Z(tau) / delta;
+ * the group elements are these times the generators: zp_fixed_base_mul_bn254 / _g2.                                                        */
+int32_t zp_r1cs_eval(const uint64_t *circ, size_t words, uint64_t *witness, uint8_t *set, uint64_t *a_ev, uint64_t *b_ev, uint64_t *c_ev, int64_t *bad);
+int32_t zp_r1cs_key_scalars(const uint64_t *circ, size_t words, const uint64_t *params, uint64_t *out_u, uint64_t *out_v, uint64_t *out_l, uint64_t *out_h,
+                            int32_t threads);
+
 /* ---- multi-GPU: RCCL over xGMI behind the C-ABI (BASELINE.json configs[3]) ---------------------------------
  * One process per GPU; a zp_comm joins this rank's ctx to the RCCL communicator of `world` ranks (a power of two).  Rank 0 makes
  * the 128-byte id (zp_comm_unique_id) and hands it to the others out of band (a file, the service's own channel); every rank
