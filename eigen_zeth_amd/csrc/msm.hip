@@ -17,6 +17,8 @@
 #include <cstring>
 #include <vector>
 
+#include <thread>
+
 #include "ctx.hpp"
 
 namespace {
@@ -1170,6 +1172,145 @@ extern "C" int32_t zp_msm_bn254_g2(zp_ctx *ctx, const uint32_t *d_points, const 
     if (!ctx) return ZP_ERR_ARG;
     ZpStage stage_(ctx, "msm_bn254_g2");
     return msm_run<fq2>(ctx, d_points, d_scalars, n, h_out);
+}
+
+// ---- fixed-base multiplication: out_i = s_i * B for ONE base B -- the group elements of a Groth16 key ([u_j(tau)]_1, [v_j(tau)]_2, ...: millions of
+// scalars times the generator; zp_r1cs_key_scalars makes the scalars).  An MSM sums; this does not.  Table T[w][d] = d 2^(8w) B (32 windows of
+// 8 bits, 255 entries each, affine, Montgomery form, built on the host with one batched inversion), lane = scalar: 32 table additions
+// (Jacobian += affine), result stored in Jacobian form; the host turns the results affine with batched inversions on threads (one field
+// inversion per 1 024 points) and writes them in the layout zp_msm_bn254 / _g2 read.  Setup work: run once per key, not per proof.
+namespace {
+
+template <class F>
+__global__ void __launch_bounds__(256) fixed_base_kernel(const uint4 *__restrict__ table, const u32 *__restrict__ scalars, u64 n, jacT<F> *__restrict__ out) {
+    constexpr int NV = FT<F>::WORDS / 2;
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    u32 sc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) sc[k] = scalars[i * 8 + k];
+    jacT<F> acc = jac_inf<F>();
+    for (int w = 0; w < 32; w++) {
+        const u32 d = (sc[w >> 2] >> (8 * (w & 3))) & 255u;
+        if (d == 0) continue;
+        uint4 q[NV];
+        const uint4 *src = table + ((size_t)w * 256 + d) * NV;
+#pragma unroll
+        for (int k = 0; k < NV; k++) q[k] = src[k];
+        F x, y;
+        unpack_point<F>(q, x, y);
+        acc = jac_madd(acc, x, y);
+    }
+    out[i] = acc;
+}
+
+// Jacobian -> affine, standard form, packed words ((0, 0) for the point at infinity): Montgomery's trick over runs of `run` points
+template <class F>
+void batch_to_affine_host(const jacT<F> *pts, size_t n, u32 *out_words, int threads) {
+    constexpr int W2 = 2 * FT<F>::WORDS;
+    const size_t run = 1024, nrun = (n + run - 1) / run;
+    int T = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (T < 1) T = 1;
+    if (T > 32) T = 32;
+    if ((size_t)T > nrun) T = (int)(nrun ? nrun : 1);
+    auto work = [&](size_t r0, size_t r1) {
+        std::vector<F> pre(run);
+        for (size_t r = r0; r < r1; r++) {
+            const size_t a = r * run, b = a + run < n ? a + run : n;
+            F acc = FT<F>::one();
+            for (size_t i = a; i < b; i++) {
+                pre[i - a] = acc;
+                if (!f_is_zero(pts[i].Z)) acc = f_mul(acc, pts[i].Z);
+            }
+            F inv = f_inv_host(acc);
+            for (size_t i = b; i-- > a;) {
+                u32 *o = out_words + i * W2;
+                if (f_is_zero(pts[i].Z)) { memset(o, 0, W2 * 4); continue; }
+                const F zi = f_mul(inv, pre[i - a]);          // 1 / Z_i
+                inv = f_mul(inv, pts[i].Z);
+                const F zi2 = f_sqr(zi);
+                FT<F>::to_words(f_from_mont(f_mul(pts[i].X, zi2)), o);
+                FT<F>::to_words(f_from_mont(f_mul(pts[i].Y, f_mul(zi2, zi))), o + FT<F>::WORDS);
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; t++) {
+        const size_t r0 = nrun * t / T, r1 = nrun * (t + 1) / T;
+        if (r0 < r1) pool.emplace_back(work, r0, r1);
+    }
+    for (auto &th : pool) th.join();
+}
+
+template <class F>
+int32_t fixed_base_run(zp_ctx *ctx, const uint32_t *h_base, const uint32_t *h_scalars, size_t n, uint32_t *h_points, int32_t threads) {
+    constexpr int NV = FT<F>::WORDS / 2, W2 = 2 * FT<F>::WORDS;
+    ZP_ARG(ctx, h_base && (n == 0 || (h_scalars && h_points)), "null pointer");
+    if (n == 0) return ZP_OK;
+    F bx = f_to_mont(FT<F>::from_words(h_base)), by = f_to_mont(FT<F>::from_words(h_base + FT<F>::WORDS));
+    ZP_ARG(ctx, !(f_is_zero(bx) && f_is_zero(by)), "the base is the point at infinity");
+    // the table in Jacobian form on the host: T[w][d] = T[w][d - 1] + B_w, B_(w+1) = 256 B_w
+    std::vector<jacT<F>> tab((size_t)32 * 256);
+    jacT<F> bw;
+    bw.X = bx; bw.Y = by; bw.Z = FT<F>::one();
+    for (int w = 0; w < 32; w++) {
+        tab[(size_t)w * 256] = jac_inf<F>();
+        for (int d = 1; d < 256; d++) tab[(size_t)w * 256 + d] = jac_add(tab[(size_t)w * 256 + d - 1], bw);
+        bw = jac_add(tab[(size_t)w * 256 + 255], bw);
+    }
+    std::vector<u32> tw(tab.size() * W2), tm(tab.size() * W2);
+    batch_to_affine_host<F>(tab.data(), tab.size(), tw.data(), threads);
+    for (size_t e = 0; e < tab.size(); e++) {       // back to Montgomery form, the kernel's input (infinity stays (0, 0))
+        FT<F>::to_words(f_to_mont(FT<F>::from_words(&tw[e * W2])), &tm[e * W2]);
+        FT<F>::to_words(f_to_mont(FT<F>::from_words(&tw[e * W2 + FT<F>::WORDS])), &tm[e * W2 + FT<F>::WORDS]);
+    }
+    void *d_tab = nullptr, *d_sc = nullptr, *d_out = nullptr;
+    int32_t rc = zp_dev_alloc(ctx, tm.size() * 4, &d_tab);
+    if (rc == ZP_OK) rc = zp_dev_alloc(ctx, n * 32, &d_sc);
+    if (rc == ZP_OK) rc = zp_dev_alloc(ctx, n * sizeof(jacT<F>), &d_out);
+    if (rc == ZP_OK) rc = zp_h2d(ctx, d_tab, tm.data(), tm.size() * 4);
+    if (rc == ZP_OK) rc = zp_h2d(ctx, d_sc, h_scalars, n * 32);
+    std::vector<jacT<F>> res;
+    if (rc == ZP_OK) {
+        hipLaunchKernelGGL(fixed_base_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)d_tab, (const u32 *)d_sc, (u64)n,
+                           (jacT<F> *)d_out);
+        if (hipGetLastError() != hipSuccess) { ctx->err = "fixed_base_kernel launch failed"; rc = ZP_ERR_HIP; }
+        (void)NV;
+    }
+    if (rc == ZP_OK) {
+        res.resize(n);
+        rc = zp_d2h(ctx, res.data(), d_out, n * sizeof(jacT<F>));
+    }
+    if (d_tab) (void)zp_dev_free(ctx, d_tab);
+    if (d_sc) (void)zp_dev_free(ctx, d_sc);
+    if (d_out) (void)zp_dev_free(ctx, d_out);
+    if (rc != ZP_OK) return rc;
+    batch_to_affine_host<F>(res.data(), n, h_points, threads);
+    return ZP_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t zp_fixed_base_mul_bn254(zp_ctx *ctx, const uint32_t *h_base, const uint32_t *h_scalars, size_t n, uint32_t *h_points, int32_t threads) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "fixed_base_mul_bn254");
+    try {
+        return fixed_base_run<fq>(ctx, h_base, h_scalars, n, h_points, threads);
+    } catch (...) {
+        ctx->err = "out of host memory";
+        return ZP_ERR_NOMEM;
+    }
+}
+
+extern "C" int32_t zp_fixed_base_mul_bn254_g2(zp_ctx *ctx, const uint32_t *h_base, const uint32_t *h_scalars, size_t n, uint32_t *h_points, int32_t threads) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "fixed_base_mul_bn254_g2");
+    try {
+        return fixed_base_run<fq2>(ctx, h_base, h_scalars, n, h_points, threads);
+    } catch (...) {
+        ctx->err = "out of host memory";
+        return ZP_ERR_NOMEM;
+    }
 }
 
 // ---- synthetic MSM inputs: n DISTINCT points P_i = (start + i) * G of BN254 G1 (host code, this file's own field

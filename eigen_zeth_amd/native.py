@@ -107,6 +107,8 @@ SIGNATURES = {
     "zp_proof_queries_parse": (C.c_int32, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "zp_verifier_arith_host": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "zp_verifier_arith_trace": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
+    "zp_fixed_base_mul_bn254": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_int32]),
+    "zp_fixed_base_mul_bn254_g2": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_int32]),
     "zp_r1cs_eval": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zp_r1cs_key_scalars": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "zp_program_digest": (C.c_int32, [_vp, C.c_size_t, _vp, _vp]),
@@ -873,6 +875,16 @@ class Prover:
         return lo.value, hi.value, lb.value
 
     # ---- N6
+    def fixed_base_mul(self, base_words, scalars, g2=False):
+        """zp_fixed_base_mul_bn254(_g2): scalars u64[n][4] / u32[n][8] (standard form) times ONE base point (u32[16] / u32[32], affine) -> points
+        u32[n][16] / u32[n][32] in the MSM layout ((0, 0) = infinity)"""
+        sc = np.ascontiguousarray(scalars).view(np.uint32).reshape(-1, 8)
+        base = np.ascontiguousarray(base_words, dtype=np.uint32)
+        out = np.empty((sc.shape[0], 32 if g2 else 16), dtype=np.uint32)
+        fn = self.lib.zp_fixed_base_mul_bn254_g2 if g2 else self.lib.zp_fixed_base_mul_bn254
+        self._chk(fn(self.ctx, base.ctypes.data, sc.ctypes.data, sc.shape[0], out.ctypes.data, 0))
+        return out
+
     def msm_bn254(self, points_xy, scalars):
         """points_xy: list of (x, y) ints ((0,0) = infinity); scalars: ints.  Returns (x, y) or None."""
         n = len(points_xy)

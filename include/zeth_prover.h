@@ -441,6 +441,13 @@ int32_t zp_msm_bn254(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_sc
 int32_t zp_msm_bn254_g2(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scalars, size_t n,
                         uint32_t *h_out);
 
+/* fixed-base multiplication: h_points[i] = h_scalars[i] * B for ONE base point B (h_base: affine, the layout of an MSM point; G1: u32[16], G2:
+ * u32[32]) -- the group elements of a Groth16 key from the scalars of zp_r1cs_key_scalars (an MSM sums, this does not).  Host buffers in and
+ * out (h_scalars u32[n][8], h_points in the MSM layout, (0, 0) = infinity); 32 table additions per scalar on the GPU, the Jacobian results made
+ * affine on `threads` host threads (0 = all) with batched inversions.  Key-generation work: once per key, not per proof.                  */
+int32_t zp_fixed_base_mul_bn254(zp_ctx *ctx, const uint32_t *h_base, const uint32_t *h_scalars, size_t n, uint32_t *h_points, int32_t threads);
+int32_t zp_fixed_base_mul_bn254_g2(zp_ctx *ctx, const uint32_t *h_base, const uint32_t *h_scalars, size_t n, uint32_t *h_points, int32_t threads);
+
 /* ---- host-buffer conveniences (H2D + compute + D2H + sync), the form a non-GPU-aware host uses */
 int32_t zp_ntt_host(zp_ctx *ctx, uint64_t *h_cols, int32_t logn, int32_t W, int32_t inverse);
 int32_t zp_lde_host(zp_ctx *ctx, const uint64_t *h_in, uint64_t *h_out, int32_t logn, int32_t logb,
