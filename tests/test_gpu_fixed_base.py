@@ -38,7 +38,7 @@ def test_fixed_base_g1_and_g2_match_double_and_add(prover):
     p1 = prover.fixed_base_mul(G1W, sw)
     p2 = prover.fixed_base_mul(_g2_words(), sw, g2=True)
     for i, s in enumerate(scal):
-        assert _pt1(p1[i]) == (B.mul(B.G1, s) if s else None), i
+        assert _pt1(p1[i]) == (B.mul((1, 2), s) if s else None), i
         assert _pt2(p2[i]) == (B.mul_g2(B.G2, s) if s else None), i
 
 
@@ -57,4 +57,4 @@ def test_fixed_base_at_size_against_the_msm(prover):
     got = prover.msm_bn254_arrays(pts, w)
     si = [int(a[0]) | int(a[2]) << 128 for a in sw]
     wi = [sum(int(w[i, k]) << (32 * k) for k in range(8)) for i in range(n)]
-    assert got == B.mul(B.G1, sum(a * b for a, b in zip(si, wi)) % B.R)
+    assert got == B.mul((1, 2), sum(a * b for a, b in zip(si, wi)) % B.R)
