@@ -7,6 +7,7 @@
 // comes as explicit sparse rows.  Everything runs over the template per instance (23 M multiply-adds for 1 900 instances: a second on one
 // core, instances in parallel on threads for the key scalars).  The group operations (fixed-base multiplications for the key, MSMs for a
 // proof) are the GPU's (csrc/msm.hip).  Layout of the circuit blob: eigen_zeth_amd/service/r1cs.py.
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -100,8 +101,8 @@ inline bool std_canonical(const uint64_t *w) { return !fr_geq_mod(w); }
 constexpr uint64_t MAGIC = 0x3130534331525a50ULL;   // "PZR1CS01"
 struct Mat { const uint64_t *ptr, *idx, *val; };      // CSR over constraints: ptr[n + 1], idx[nnz] (wire), val[nnz][4] (standard form)
 struct Circ {
-    uint64_t n_wires, n_cons, logm, t, n_local, tc, n_inst, n_extra, n_pub;
-    const uint64_t *tdef, *inst, *edef;               // tdef[tc]: the local wire a template constraint defines; inst: (t + 2) words each; edef[n_extra]
+    uint64_t n_wires, n_cons, logm, t, n_local, tc, n_inst, n_extra, n_pub, n_waves;
+    const uint64_t *tdef, *inst, *edef, *waves;      // waves[n_waves + 1]: instances [waves[k], waves[k + 1]) read only wires set before wave k               // tdef[tc]: the local wire a template constraint defines; inst: (t + 2) words each; edef[n_extra]
     Mat T[3], E[3];
     uint64_t extra_base() const { return n_inst * tc; }   // constraints: instances first (instance i owns [i tc, (i + 1) tc)), then the extras
 };
@@ -122,6 +123,7 @@ bool parse_mat(const uint64_t *d, size_t words, size_t &at, uint64_t rows, uint6
 bool parse(const uint64_t *d, size_t words, Circ *c) {
     if (!d || words < 16 || d[0] != MAGIC) return false;
     c->n_wires = d[1]; c->n_cons = d[2]; c->logm = d[3]; c->t = d[4]; c->n_local = d[5]; c->tc = d[6]; c->n_inst = d[7]; c->n_extra = d[8]; c->n_pub = d[9];
+    c->n_waves = d[10];
     if (c->n_wires < 2 || c->n_wires > (1ull << 28) || c->logm > 28 || c->t < 2 || c->t > 64 || c->n_local < 1 + c->t || c->n_local > (1u << 20) || c->tc < 1 ||
         c->tc > (1u << 20) || c->n_inst > (1u << 24) || c->n_extra > (1ull << 28) || c->n_pub < 1 || 1 + c->n_pub > c->n_wires)
         return false;
@@ -139,8 +141,13 @@ bool parse(const uint64_t *d, size_t words, Circ *c) {
         for (uint64_t k = 0; k < c->t; k++) if (in[k] >= c->n_wires) return false;
         if (in[c->t] + n_int > c->n_wires || in[c->t + 1] != i * c->tc) return false;
     }
+    if (c->n_waves < 1 || c->n_waves > c->n_inst + 1 || at + c->n_waves + 1 > words) return false;
+    c->waves = d + at; at += c->n_waves + 1;
+    if (c->waves[0] != 0 || c->waves[c->n_waves] != c->n_inst) return false;
+    for (uint64_t k = 0; k < c->n_waves; k++) if (c->waves[k] > c->waves[k + 1]) return false;
     if (at + c->n_extra > words) return false;
     c->edef = d + at; at += c->n_extra;
+    for (uint64_t q = 0; q < c->n_extra; q++) if (c->edef[q] != ~0ull && c->edef[q] >= c->n_wires) return false;
     for (int k = 0; k < 3; k++) if (!parse_mat(d, words, at, c->n_extra, c->n_wires, &c->E[k])) return false;
     return at == words;
 }
@@ -181,21 +188,24 @@ int32_t zp_r1cs_eval(const uint64_t *circ, size_t words, uint64_t *witness, uint
             tv[k].resize(nnz);
             for (uint64_t e = 0; e < nnz; e++) tv[k][e] = fr_from_std(c.T[k].val + 4 * e);
         }
-        int64_t first_bad = -1;
-        for (uint64_t i = 0; i < c.n_inst; i++) {
+        std::atomic<int64_t> first_bad{-1}, unset{-1};
+        auto note = [](std::atomic<int64_t> &slot, int64_t v) {          // keep the smallest index
+            int64_t cur = slot.load();
+            while ((cur < 0 || v < cur) && !slot.compare_exchange_weak(cur, v)) {}
+        };
+        auto run_instance = [&](uint64_t i) {
             const uint64_t *in = c.inst + i * (c.t + 2);
-            for (uint64_t k = 0; k < c.t; k++) if (!set[in[k]]) { if (bad) *bad = (int64_t)i; return -21; }
+            for (uint64_t k = 0; k < c.t; k++) if (!set[in[k]]) { note(unset, (int64_t)(i * c.tc)); return; }
             for (uint64_t q = 0; q < c.tc; q++) {
                 Fr s[3];
                 const uint64_t def = c.tdef[q];
                 const uint64_t gdef = def == ~0ull ? ~0ull : local_to_global(c, in, def);
-                Fr rest = {{0, 0, 0, 0}};
                 for (int k = 0; k < 3; k++) {
                     Fr acc = {{0, 0, 0, 0}};
                     for (uint64_t e = c.T[k].ptr[q]; e < c.T[k].ptr[q + 1]; e++) {
                         const uint64_t g = local_to_global(c, in, c.T[k].idx[e]);
                         if (k == 2 && g == gdef && !set[g]) continue;       // the wire this constraint defines (coefficient 1 in C)
-                        if (!set[g]) { if (bad) *bad = (int64_t)(i * c.tc + q); return -21; }
+                        if (!set[g]) { note(unset, (int64_t)(i * c.tc + q)); return; }
                         acc = fr_add(acc, fr_mul(tv[k][e], w[g]));
                     }
                     s[k] = acc;
@@ -205,26 +215,52 @@ int32_t zp_r1cs_eval(const uint64_t *circ, size_t words, uint64_t *witness, uint
                     w[gdef] = fr_sub(ab, s[2]);
                     set[gdef] = 1;
                     s[2] = ab;
-                } else if (!fr_eq(ab, s[2]) && first_bad < 0) {
-                    first_bad = (int64_t)(i * c.tc + q);
+                } else if (!fr_eq(ab, s[2])) {
+                    note(first_bad, (int64_t)(i * c.tc + q));
                 }
-                (void)rest;
                 const uint64_t row = i * c.tc + q;
                 fr_to_std(s[0], a_ev + 4 * row); fr_to_std(s[1], b_ev + 4 * row); fr_to_std(s[2], c_ev + 4 * row);
             }
+        };
+        // instances of one wave read only wires set before it and define disjoint (their own internal) wires: threads
+        int T = (int)std::thread::hardware_concurrency();
+        if (T < 1) T = 1;
+        if (T > 32) T = 32;
+        for (uint64_t wv = 0; wv < c.n_waves; wv++) {
+            const uint64_t i0 = c.waves[wv], i1 = c.waves[wv + 1];
+            if (i1 - i0 < 4 || T == 1) {
+                for (uint64_t i = i0; i < i1; i++) run_instance(i);
+            } else {
+                std::atomic<uint64_t> next{i0};
+                auto body = [&]() { for (;;) { const uint64_t i = next.fetch_add(1); if (i >= i1) return; run_instance(i); } };
+                std::vector<std::thread> pool;
+                const int nt = (uint64_t)T < i1 - i0 ? T : (int)(i1 - i0);
+                for (int k = 0; k < nt; k++) pool.emplace_back(body);
+                for (auto &th : pool) th.join();
+            }
+            if (unset.load() >= 0) { if (bad) *bad = unset.load(); return -21; }
         }
-        for (uint64_t q = 0; q < c.n_extra; q++) {
+        for (uint64_t q = 0; q < c.n_extra; q++) {          // in order: an extra constraint may define a wire (C's coefficient of it being 1)
             Fr s[3];
+            const uint64_t gdef = c.edef[q];
             for (int k = 0; k < 3; k++) {
                 Fr acc = {{0, 0, 0, 0}};
                 for (uint64_t e = c.E[k].ptr[q]; e < c.E[k].ptr[q + 1]; e++) {
                     const uint64_t g = c.E[k].idx[e];
+                    if (k == 2 && g == gdef && !set[g]) continue;
                     if (!set[g]) { if (bad) *bad = (int64_t)(c.extra_base() + q); return -21; }
                     acc = fr_add(acc, fr_mul(fr_from_std(c.E[k].val + 4 * e), w[g]));
                 }
                 s[k] = acc;
             }
-            if (!fr_eq(fr_mul(s[0], s[1]), s[2]) && first_bad < 0) first_bad = (int64_t)(c.extra_base() + q);
+            const Fr ab = fr_mul(s[0], s[1]);
+            if (gdef != ~0ull && !set[gdef]) {
+                w[gdef] = fr_sub(ab, s[2]);
+                set[gdef] = 1;
+                s[2] = ab;
+            } else if (!fr_eq(ab, s[2])) {
+                note(first_bad, (int64_t)(c.extra_base() + q));
+            }
             const uint64_t row = c.extra_base() + q;
             fr_to_std(s[0], a_ev + 4 * row); fr_to_std(s[1], b_ev + 4 * row); fr_to_std(s[2], c_ev + 4 * row);
         }
@@ -232,7 +268,7 @@ int32_t zp_r1cs_eval(const uint64_t *circ, size_t words, uint64_t *witness, uint
             if (!set[j]) { if (bad) *bad = (int64_t)j; return -21; }
             fr_to_std(w[j], witness + 4 * j);
         }
-        if (first_bad >= 0) { if (bad) *bad = first_bad; return -20; }
+        if (first_bad.load() >= 0) { if (bad) *bad = first_bad.load(); return -20; }
         return ZP_OK;
     } catch (...) {
         return ZP_ERR_NOMEM;

@@ -11,8 +11,10 @@ poseidon_constants.bn254_poseidon_params).  t = 17: 8 x 17 + 68 = 204 S-boxes ->
 Blob layout (u64 words; "PZR1CS01"):
   [0] magic [1] n_wires [2] n_constraints [3] logm [4] t [5] n_local [6] template constraints tc [7] instances [8] extra constraints [9] n_pub, [10..16) 0
   template: def[tc] (the local wire constraint q defines), then for A, B, C: ptr[tc + 1], idx[nnz], val[nnz][4] (standard form)
-  instances: per instance t input wires (global), the global index of its first internal wire, its first constraint (= i * tc)
-  extras: def[n_extra] (unused: ~0), then for A, B, C: ptr[n_extra + 1], idx[nnz] (global wires), val[nnz][4]
+  instances: per instance t input wires (global), the global index of its first internal wire, its first constraint (= i * tc); then
+             waves[n_waves + 1] ([10] = n_waves): the instances of wave k, [waves[k], waves[k + 1]), read only wires that the caller set or an
+             earlier wave defined -- they are evaluated in parallel
+  extras: def[n_extra] (the global wire extra constraint q defines, ~0: none), then for A, B, C: ptr[n_extra + 1], idx[nnz] (global wires), val[nnz][4]
 Constraint numbering: instance i owns [i tc, (i + 1) tc), the extras follow.  Wire 0 = 1, wires 1..n_pub the public inputs."""
 from __future__ import annotations
 
@@ -105,6 +107,7 @@ class Circuit:
         self.tpl, self.n_pub = template, n_pub
         self.n_wires = 1 + n_pub
         self.instances, self.extras = [], []
+        self._out_wave = {}
 
     def new_wire(self):
         self.n_wires += 1
@@ -116,14 +119,20 @@ class Circuit:
         return list(range(first, first + n))
 
     def add_instance(self, inputs):
+        """wave of the instance = 1 + the latest wave among the instances whose OUTPUT wires it reads (0 if it reads only caller-set wires)"""
         assert len(inputs) == self.tpl.t and all(0 <= w < self.n_wires for w in inputs)
         base = self.n_wires
         self.n_wires += self.tpl.n_internal
-        self.instances.append((list(inputs), base))
-        return base + (self.tpl.out - 1 - self.tpl.t)
+        wave = 1 + max([self._out_wave.get(w, -1) for w in inputs])
+        self.instances.append((list(inputs), base, wave))
+        out = base + (self.tpl.out - 1 - self.tpl.t)
+        self._out_wave[out] = wave
+        return out
 
-    def add_constraint(self, A, B, C):
-        self.extras.append((A, B, C))
+    def add_constraint(self, A, B, C, defines=None):
+        """defines: a wire (coefficient 1 in C) that this constraint DEFINES when nobody has set it: value = (A w)(B w) - (rest of C w)"""
+        assert defines is None or C.get(defines) == 1
+        self.extras.append((A, B, C, defines))
 
     @property
     def n_constraints(self):
@@ -137,13 +146,17 @@ class Circuit:
 
     def pack(self):
         tpl, tc = self.tpl, len(self.tpl.cons)
-        hdr = [MAGIC, self.n_wires, self.n_constraints, self.logm(), tpl.t, tpl.n_local, tc, len(self.instances), len(self.extras), self.n_pub] + [0] * 6
+        self.instances.sort(key=lambda it: it[2])            # by wave (stable: constraint numbering follows this order)
+        n_waves = (self.instances[-1][2] + 1) if self.instances else 1
+        bounds = [sum(1 for it in self.instances if it[2] < k) for k in range(n_waves + 1)]
+        hdr = [MAGIC, self.n_wires, self.n_constraints, self.logm(), tpl.t, tpl.n_local, tc, len(self.instances), len(self.extras), self.n_pub, n_waves] + [0] * 5
         body = [c[3] for c in tpl.cons]
         for k in range(3):
             body += _csr([c[k] for c in tpl.cons])
-        for i, (inputs, base) in enumerate(self.instances):
+        for i, (inputs, base, _) in enumerate(self.instances):
             body += inputs + [base, i * tc]
-        body += [NONE] * len(self.extras)
+        body += bounds
+        body += [NONE if e[3] is None else e[3] for e in self.extras]
         for k in range(3):
             body += _csr([e[k] for e in self.extras])
         return np.array(hdr + body, dtype=np.uint64)
@@ -154,18 +167,18 @@ class Circuit:
 
     def rows(self):
         """every constraint as (A, B, C) over GLOBAL wires, in blob order"""
-        for inputs, base in self.instances:
+        for inputs, base, _ in self.instances:
             for (A, B, C, _) in self.tpl.cons:
                 yield tuple({self.local_to_global(inputs, base, k): v for k, v in M.items()} for M in (A, B, C))
         for e in self.extras:
-            yield e
+            yield e[:3]
 
     def complete(self, w):
         """w: dict {global wire: value} of the caller-set wires -> full assignment list, or raises ValueError on a violated constraint"""
         w = dict(w)
         w[0] = 1
         dot = lambda M: sum(c * w[k] for k, c in M.items()) % R
-        for inputs, base in self.instances:
+        for inputs, base, _ in sorted(self.instances, key=lambda it: it[2]):
             for (A, B, C, d) in self.tpl.cons:
                 g = lambda M: {self.local_to_global(inputs, base, k): v for k, v in M.items()}
                 gd = self.local_to_global(inputs, base, d)
@@ -175,7 +188,9 @@ class Circuit:
                     w[gd] = (ab - sum(c * w[k] for k, c in Cg.items() if k != gd)) % R
                 elif ab != dot(Cg):
                     raise ValueError("constraint violated")
-        for (A, B, C) in self.extras:
-            if dot(A) * dot(B) % R != dot(C):
+        for (A, B, C, d) in self.extras:
+            if d is not None and d not in w:
+                w[d] = (dot(A) * dot(B) - sum(c * w[k] for k, c in C.items() if k != d)) % R
+            elif dot(A) * dot(B) % R != dot(C):
                 raise ValueError("constraint violated")
         return [w[j] for j in range(self.n_wires)]
