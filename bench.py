@@ -748,7 +748,7 @@ def grpc_probe(logn, air_name, chunks_per_block=8, blocks=3):
     from eigen_zeth_amd.service.engine import EngineConfig
     from eigen_zeth_amd.service.server import serve
     tmp = tempfile.mkdtemp()
-    cfg = EngineConfig(air=air_name, logn=logn, chunks_per_block=chunks_per_block, groth16_logm=8, crs_dir=os.path.join(tmp, "crs"), witness_threads=16)
+    cfg = EngineConfig(air=air_name, logn=logn, chunks_per_block=chunks_per_block, crs_dir=os.path.join(tmp, "crs"), witness_threads=16)
     server, port = serve(0, "127.0.0.1", os.path.join(tmp, "state"), cfg, 0)
     try:
         ch = ProverChannel("127.0.0.1:%d" % port)
@@ -774,7 +774,7 @@ def engine_batch_probe(K, logn, air_name, device=0, tag=""):
     import tempfile
     from eigen_zeth_amd.service.engine import Engine, EngineConfig
     from eigen_zeth_amd.service.server import default_backend_factory
-    cfg = EngineConfig(air=air_name, logn=logn, groth16_logm=8,
+    cfg = EngineConfig(air=air_name, logn=logn,
                        crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_bench_%d%s" % (os.getuid(), tag)), witness_threads=16)
     eng = Engine(default_backend_factory(device), cfg)
     eng.groth16_keys()
@@ -820,7 +820,7 @@ def config5_probe(K=64, logn=22, msm_log=26, air_name="chunk64"):
     from eigen_zeth_amd.service import bn254
     from eigen_zeth_amd.service.engine import Engine, EngineConfig
     from eigen_zeth_amd.service.server import default_backend_factory
-    cfg = EngineConfig(air=air_name, logn=logn, groth16_logm=8, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_c5_%d" % os.getuid()),
+    cfg = EngineConfig(air=air_name, logn=logn, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_c5_%d" % os.getuid()),
                        witness_threads=12)          # 2 GiB of page-locked witness per chunk in flight at 2^22 x 64 (14 in flight at most)
     eng = Engine(default_backend_factory(0), cfg)
     eng.groth16_keys()

@@ -6,10 +6,10 @@ GenChunkProof  : one real STARK per chunk on the GPU backend (eigen_zeth_amd/sta
 GenAggregated  : a STARK over the Merkle-verifier AIR (stark/verifier_air.py): its witness is the verification trace of the
                  two chunk proofs' query openings, its public inputs their roots and query indices.
 GenFinalProof  : a final STARK in BN128-hash mode over the same verifier AIR applied to the aggregated proof's STARK, then
-                 a real Groth16 proof over BN254 (service/groth16.py; G1 MSMs on the GPU) in the exact JSON
-                 grammar eigen-zeth parses (src/settlement/ethereum/mod.rs:445-481), for a stand-in CIRCUIT
-                 (an arithmetic chain binding the public input to the aggregated proof's digest) under a
-                 locally generated CRS: the recursive-verifier circuit and its ceremony do not exist offline.
+                 a Groth16 proof over BN254 (service/groth16.py: QAP step and MSMs on the GPU) of a circuit that verifies the HASHING of
+                 that STARK's verifier (service/wrap_circuit.py: leaf sponges and 16-ary paths at every query, one public input), in
+                 the exact JSON grammar eigen-zeth parses (src/settlement/ethereum/mod.rs:445-481) -- under a locally generated,
+                 seeded key: a ceremony does not exist offline.
 """
 from __future__ import annotations
 
@@ -31,6 +31,7 @@ from .. import native
 from . import bn254
 from . import groth16
 from . import statement
+from . import wrap_circuit as WC
 
 
 @contextlib.contextmanager
@@ -68,7 +69,7 @@ class EngineConfig:
     half of that); every value is bound into the proof's transcript."""
 
     def __init__(self, air="chunk64", logn=12, logb=1, chunks_per_block=1, n_queries=80, fri_logf=3, fri_final_log=5,
-                 groth16_logm=6, crs_dir=None, l2_addr=None, txs_per_chunk=64,
+                 crs_dir=None, l2_addr=None, txs_per_chunk=64,
                  witness_threads=8, prover_streams=8, pow_bits=20,
                  final_air="chunk16", final_logn=10, final_logb=2, final_queries=50, native_prover=True,
                  agg_queries=50, agg_pow_bits=0, aggregate_all_chunks=False, groth16_seed=None):
@@ -86,7 +87,7 @@ class EngineConfig:
         self.groth16_seed = groth16_seed
         self.chunks_per_block, self.n_queries, self.pow_bits = chunks_per_block, n_queries, pow_bits
         self.fri_logf, self.fri_final_log = fri_logf, fri_final_log
-        self.groth16_logm, self.crs_dir = groth16_logm, crs_dir
+        self.crs_dir = crs_dir          # (unused since round 4: wrap keys are made in memory per engine; kept for callers that pass it)
         self.l2_addr, self.txs_per_chunk = l2_addr, txs_per_chunk   # optional block-input fetcher
         self.witness_threads = witness_threads
         self.prover_streams = prover_streams   # chunk proofs in flight on one GPU (each on its own ctx / stream); 8 measured best (profiles/r2_streams_sweep.txt)
@@ -110,7 +111,7 @@ class Engine:
         self.cfg = config or EngineConfig()
         self.stage_timings = {}
         self.metrics = None   # service/metrics.py Metrics, attached by serve()
-        self._g16 = None
+        self._g16 = {}            # final-STARK layout -> (wrap circuit, Groth16 key)
         self._extra_be, self._be_lock = [], threading.Lock()
         # One request at a time per engine: every backend (zp_ctx: scratch buffers, pinned staging, buffer pools,
         # last-error slot) is single-threaded by contract, and backend 0 also serves state roots, witness uploads
@@ -511,15 +512,37 @@ class Engine:
         return shape
 
     # ---- GenFinalProof
-    def groth16_keys(self):
-        if self._g16 is None:
-            circ = groth16.Circuit(self.cfg.groth16_logm)
-            pk, vk = groth16.load_or_setup(circ, self.cfg.crs_dir or os.path.join(os.path.expanduser("~"), ".cache", "zeth_prover_crs"))
-            self._g16 = (circ, pk, vk)
-        return self._g16
+    def wrap_layout(self, n_proofs=2, logn=None):
+        """the layout of the final STARK this engine makes over an aggregation of `n_proofs` chunk proofs of 2^logn rows -- what sizes the wrap
+        circuit (service/wrap_circuit.py); derived from the configuration alone, so that the key can be made before the first request"""
+        air = AIR.get_air(self.cfg.air)
+        sp = self.stark_params(logn)
+        chunk_shape = VA.Shape(sp.logn, sp.logb, air.width, air.width2, 3 * AIR.quotient_chunks(air), sp.n_queries, sp.fri_logf, sp.fri_final_log, n_proofs,
+                               air.n_pub, sp.pow_bits, int(self.be.root32), int(self.be.shift))
+        ap = self._agg_params(chunk_shape)
+        agg_shape = VA.Shape(ap.logn, ap.logb, VA.WIDTH, 0, 3 * VA.Q_PIECES, ap.n_queries, ap.fri_logf, ap.fri_final_log, 1, chunk_shape.n_pub(), ap.pow_bits,
+                             int(self.be.root32), int(self.be.shift))
+        fp = VA.aggregation_params(agg_shape, self.cfg.final_queries, self.cfg.fri_logf, self.cfg.fri_final_log, 0, hash="bn128")
+        return WC.Layout(fp, VA.WIDTH, 3 * VA.Q_PIECES)
 
-    def verifying_key_json(self):
-        return groth16.vk_to_json(self.groth16_keys()[2])
+    def _wrap_key(self, layout):
+        """(wrap circuit, Groth16 key) for a final-STARK layout: built once per layout (seconds at the service's size: the circuit in Python,
+        the key's scalars on the host, its group elements on the GPU) and kept -- key generation is setup, not proving"""
+        k = layout.key()
+        if k not in self._g16:
+            wc = WC.wrap_circuit(layout)
+            key = groth16.Key(wc.blob)
+            if hasattr(self.be, "p"):          # the GPU backend: the key's points are made now and stay in HBM
+                key.load_points(self.be)
+            self._g16[k] = (wc, key)
+        return self._g16[k]
+
+    def groth16_keys(self, n_proofs=2, logn=None):
+        """make (or fetch) the wrap circuit and key for the usual request -- two chunk proofs of the configured size"""
+        return self._wrap_key(self.wrap_layout(n_proofs, logn))
+
+    def verifying_key_json(self, n_proofs=2, logn=None):
+        return groth16.vk_to_json(self.groth16_keys(n_proofs, logn)[1].vk)
 
     def final(self, batch_id, recursive_proof, curve_name, aggregator_addr):
         with self._serial, _no_cyclic_gc():
@@ -556,23 +579,31 @@ class Engine:
         while len(self.final_starks) > 4:
             self.final_starks.pop(next(iter(self.final_starks)))
         fs_digest = hashlib.sha256(final_stark.encode()).hexdigest()
-        # 2. the Groth16 wrap
-        h = int(hashlib.sha256((fs_digest + "|" + recursive_proof + "|" + (aggregator_addr or "")).encode()).hexdigest(), 16)
-        circ, pk, vk = self.groth16_keys()
-        w = circ.witness(h % bn254.R)
+        # 2. the Groth16 wrap: an R1CS that verifies the hashing of that STARK's verifier at its queries (service/wrap_circuit.py); its one
+        #    public input commits to the roots, indices and leaf elements it vouches for, and to the aggregator address of the request
+        t0 = time.perf_counter()
+        wc, key = self._wrap_key(WC.Layout.of_air(fair, fp))
+        try:
+            aux = int(aggregator_addr or "0")
+        except ValueError:
+            aux = int(hashlib.sha256((aggregator_addr or "").encode()).hexdigest(), 16)
+        w0, mask = wc.assign(json.loads(final_stark), aux)
+        wf, a_ev, b_ev, c_ev = native.r1cs_eval(wc.blob, w0, mask)       # ValueError: the openings do not hash to the roots -> no witness
+        t_wit = time.perf_counter() - t0
         # fresh blinding per proof (zero knowledge); replays of a request are answered from the batch store (server.py),
         # which keeps the finished proof, so the client still sees one proof per batch
         if self.cfg.groth16_seed is None:
             rnd = (int.from_bytes(os.urandom(32), "big") % bn254.R or 1, int.from_bytes(os.urandom(32), "big") % bn254.R or 1)
         else:
-            det = lambda tag: int(hashlib.sha256(("%s|%s|%064x|%s" % (self.cfg.groth16_seed, fs_digest, h, tag)).encode()).hexdigest(), 16) % bn254.R or 1
+            det = lambda tag: int(hashlib.sha256(("%s|%s|%s|%s" % (self.cfg.groth16_seed, fs_digest, aggregator_addr or "", tag)).encode()).hexdigest(), 16) % bn254.R or 1
             rnd = (det("r"), det("s"))
         t0 = time.perf_counter()
-        proof, pub = groth16.prove(circ, pk, w, self.be.msm_g1, rnd, getattr(self.be, "msm_g2", None), self.be.qap_quotient)
-        self.stage_timings["final/" + batch_id] = {"final_stark(bn128)": t_fs, "groth16": time.perf_counter() - t0,
+        proof, pub = groth16.prove(key, wf, a_ev, b_ev, c_ev, self.be, rnd)
+        self.stage_timings["final/" + batch_id] = {"final_stark(bn128)": t_fs, "wrap-witness": t_wit, "groth16": time.perf_counter() - t0,
                                                    **{"final/" + k: v for k, v in tmf.items()}}
         if self.metrics is not None:
             self.metrics.record_stage("groth16", self.stage_timings["final/" + batch_id]["groth16"])
-        js = groth16.proof_to_json(proof, {"circuit": "arithmetic-chain(logm=%d), local CRS -- stand-in for the recursive-verifier circuit" % circ.logm,
+        js = groth16.proof_to_json(proof, {"circuit": "final-stark-hashing: %d constraints (2^%d domain), %d wires, key %s (local seeded setup)"
+                                                      % (wc.c.n_constraints, wc.c.logm(), wc.c.n_wires, key.digest[:16]),
                                             "final_stark_sha256": fs_digest})
         return js, json.dumps([str(pub[0])])

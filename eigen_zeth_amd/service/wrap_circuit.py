@@ -8,7 +8,8 @@ csrc/poseidon_bn254.hip, oracle/naive.py:pack_leaf_block), and per tree level th
   * the leaf sponge (width-17 Poseidon-BN254, capacity = element 0) of the leaf elements gives the leaf digest,
   * at every level the digest computed so far sits at position (index >> 4 level) & 15 of the group -- the position selected by the BITS of
     j_q --, and the group hashes ([0, 16 children] -> element 0) to the digest of the next level, the last one being the tree's root,
-  * d = the root of a 16-ary Poseidon tree over the list  roots | per query: j_q, then the leaf elements of every tree.
+  * d = the root of a 16-ary Poseidon tree over the list  roots | aux | per query: j_q, then the leaf elements of every tree
+    (aux: one more field element the proof is bound to -- the aggregator address of the request).
 So d commits to everything the rest of a verifier needs -- roots, indices, opened values -- and the circuit vouches that those values ARE the
 leaves under those roots at those indices.  What stays outside (checked natively by whoever holds the final STARK: oracle/wrap_verify.py):
 recomputing d from the final STARK's data, the packing of values into elements, the transcript, and the field arithmetic (out-of-domain
@@ -91,7 +92,8 @@ class WrapCircuit:
         self.Z = Z
         T = len(layout.trees)
         self.roots = c.new_wires(T)
-        data = list(self.roots)
+        self.aux = c.new_wire()                                     # what else the proof is bound to (the aggregator address of the request)
+        data = list(self.roots) + [self.aux]
         self.q = []
         for _ in range(layout.n_queries):
             j = c.new_wire()
@@ -136,11 +138,11 @@ class WrapCircuit:
         self.blob = c.pack()
 
     # ---- assignment
-    def data_values(self, proof):
-        """the list the public input commits to, from a final STARK: roots | per query: index, leaf elements of every tree"""
+    def data_values(self, proof, aux=0):
+        """the list the public input commits to, from a final STARK: roots | aux | per query: index, leaf elements of every tree"""
         lay = self.layout
         roots = [proof["roots"]["trace"], proof["roots"]["quotient"]] + list(proof["fri"]["roots"])
-        out = [int(r[0]) for r in roots]
+        out = [int(r[0]) for r in roots] + [int(aux) % R]
         if len(proof["queries"]) != lay.n_queries or len(roots) != len(lay.trees):
             raise ValueError("final STARK does not have the shape the wrap circuit was built for")
         for qq in proof["queries"]:
@@ -154,12 +156,12 @@ class WrapCircuit:
                     out += pack_leaf_block(vals[LEAF_BLOCK * b:LEAF_BLOCK * (b + 1)])
         return out
 
-    def assign(self, proof):
+    def assign(self, proof, aux=0):
         """(witness u64[n_wires][4], mask) with every caller-set wire filled from the final STARK; the gadgets' internal wires, the digests they
         produce and the public input are left to zp_r1cs_eval -- which refuses (ValueError) when the STARK's openings do not hash to its roots"""
         from .. import native
         lay = self.layout
-        vals = {0: 1, self.Z: 0}
+        vals = {0: 1, self.Z: 0, self.aux: int(aux) % R}
         roots = [proof["roots"]["trace"], proof["roots"]["quotient"]] + list(proof["fri"]["roots"])
         for w, r in zip(self.roots, roots):
             vals[w] = int(r[0])

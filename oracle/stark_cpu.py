@@ -189,6 +189,13 @@ class CpuBackend:
         from . import naive_bn254 as B1
         return B1.msm([p if p is not None else (0, 0) for p in points], scalars)
 
+    def groth16_prove(self, key, witness, rand):
+        """the checker's Groth16 prover: by the trapdoor of the (seeded, test-only) key -- oracle/groth16_trapdoor.py.  key: an object with
+        toxic / u / v / l (u64[n][4] arrays) / n_pub; the same group elements the GPU's transforms and MSMs must give"""
+        from . import groth16_trapdoor as GT
+        ints = lambda a: [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in a]
+        return GT.prove(key.toxic, ints(key.u), ints(key.v), ints(key.l), key.n_pub, witness, rand)
+
     def qap_quotient(self, a_ev, b_ev, c_ev, logm, coset):
         from . import naive
         return naive.qap_quotient(a_ev, b_ev, c_ev)       # definition level; independent of the coset the GPU path evaluates on

@@ -114,17 +114,3 @@ def test_bad_arguments(prover):
     with pytest.raises(ZpError):      # the coset shift 1 lies in the domain: Z vanishes
         prover.qap_quotient_bn254([1] * 4, [1] * 4, [1] * 4, 2, 1)
     d.free()
-
-
-def test_groth16_proof_with_gpu_qap_verifies(prover):
-    """the wrap's H comes from zp_qap_quotient_bn254: proof verifies under the pairing check"""
-    from eigen_zeth_amd.service import groth16, bn254
-    from eigen_zeth_amd.stark.backend_hip import HipBackend
-    from oracle import groth16_verify as GV
-    be = HipBackend(prover=prover)
-    circ = groth16.Circuit(logm=6)
-    pk, vk = groth16.setup(circ)
-    w = circ.witness(123456789)
-    proof, pub = groth16.prove(circ, pk, w, be.msm_g1, (11, 13), be.msm_g2, be.qap_quotient)
-    assert GV.verify(vk, proof, pub)
-    assert not GV.verify(vk, proof, [(pub[0] + 1) % bn254.R])

@@ -19,7 +19,7 @@ def test_64_block_batch_through_the_engine(tables, tmp_path):
     from eigen_zeth_amd.service.server import default_backend_factory
     from eigen_zeth_amd.stark import air as AIR
     rc, mds = tables
-    cfg = EngineConfig(air="chunk64", logn=18, chunks_per_block=1, groth16_logm=6, crs_dir=str(tmp_path / "crs"), witness_threads=8)
+    cfg = EngineConfig(air="chunk64", logn=18, chunks_per_block=1, crs_dir=str(tmp_path / "crs"), witness_threads=8)
     assert cfg.n_queries * cfg.logb + cfg.pow_bits >= 100          # the service default security level
     eng = Engine(default_backend_factory(0), cfg)
     blocks = list(range(1, 65))
@@ -74,7 +74,7 @@ def test_chunks_at_the_full_c3_shape_through_the_engine(tables, tmp_path):
     from eigen_zeth_amd.service.server import default_backend_factory
     from eigen_zeth_amd.stark import air as AIR
     rc, mds = tables
-    cfg = EngineConfig(air="chunk64", logn=22, chunks_per_block=1, groth16_logm=6, crs_dir=str(tmp_path / "crs"), witness_threads=8,
+    cfg = EngineConfig(air="chunk64", logn=22, chunks_per_block=1, crs_dir=str(tmp_path / "crs"), witness_threads=8,
                        prover_streams=2)
     assert cfg.n_queries * cfg.logb + cfg.pow_bits >= 100
     eng = Engine(default_backend_factory(0), cfg)

@@ -120,7 +120,7 @@ def test_engine_over_two_device_slots_keeps_witnesses_on_the_proving_gpu(tables,
     from eigen_zeth_amd.service.engine import Engine, EngineConfig
     from eigen_zeth_amd.service.server import default_backend_factory
     second = 1 if native.device_count() >= 2 else 0
-    mk = lambda: EngineConfig(air="chunk16", logn=12, chunks_per_block=1, groth16_logm=4, crs_dir=str(tmp_path / "crs"), prover_streams=2)
+    mk = lambda: EngineConfig(air="chunk16", logn=12, chunks_per_block=1, crs_dir=str(tmp_path / "crs"), prover_streams=2)
     blocks = list(range(3, 10))                                        # 7 chunks: an odd count over two slots
     one = Engine(default_backend_factory(0), mk())
     ch = one.gen_batch_chunks("md", blocks, 12345, "evm")

@@ -179,7 +179,7 @@ def test_compiled_host_answers_gen_aggregated_proof_like_the_service(tmp_path, t
     sys.path.insert(0, os.path.join(root, "tools"))
     import export_recursion_shape as EX
     rc, mds = tables
-    cfg = EngineConfig(air="chunk64", logn=12, chunks_per_block=1, groth16_logm=6, crs_dir=str(tmp_path / "crs"), n_queries=24, pow_bits=8, agg_queries=10)
+    cfg = EngineConfig(air="chunk64", logn=12, chunks_per_block=1, crs_dir=str(tmp_path / "crs"), n_queries=24, pow_bits=8, agg_queries=10)
     eng = Engine(default_backend_factory(0), cfg)
     ch = eng.gen_batch_chunks("b", [7, 8], 12345, "evm")
     proofs = eng.gen_chunk_proofs("b", ch["task_id"], ch["chunk_count"], ch["batch_data"])

@@ -111,7 +111,7 @@ def test_engine_aggregate_and_final_prove_what_they_name(tables, tmp_path):
     from eigen_zeth_amd.service.engine import Engine, EngineConfig
     from eigen_zeth_amd.service.server import default_backend_factory
     rc, mds = tables
-    cfg = EngineConfig(air="chunk64", logn=14, chunks_per_block=1, groth16_logm=6, crs_dir=str(tmp_path / "crs"))
+    cfg = EngineConfig(air="chunk64", logn=14, chunks_per_block=1, crs_dir=str(tmp_path / "crs"))
     eng = Engine(default_backend_factory(0), cfg)
     ch = eng.gen_batch_chunks("agg", [11, 12, 13], 12345, "evm")
     proofs = eng.gen_chunk_proofs("agg", ch["task_id"], ch["chunk_count"], ch["batch_data"])
@@ -155,7 +155,7 @@ def test_engine_can_aggregate_every_chunk_of_a_batch(tables, tmp_path):
     from eigen_zeth_amd.service.engine import Engine, EngineConfig
     from eigen_zeth_amd.service.server import default_backend_factory
     rc, mds = tables
-    cfg = EngineConfig(air="chunk16", logn=10, chunks_per_block=1, groth16_logm=6, crs_dir=str(tmp_path / "crs"), n_queries=12, pow_bits=4,
+    cfg = EngineConfig(air="chunk16", logn=10, chunks_per_block=1, crs_dir=str(tmp_path / "crs"), n_queries=12, pow_bits=4,
                        agg_queries=6, final_queries=4, aggregate_all_chunks=True)
     eng = Engine(default_backend_factory(0), cfg)
     ch = eng.gen_batch_chunks("all", [21, 22, 23, 24, 25], 12345, "evm")
@@ -187,7 +187,7 @@ def test_engine_folds_aggregated_proofs_again(tables, tmp_path):
     from eigen_zeth_amd.service.engine import Engine, EngineConfig
     from eigen_zeth_amd.service.server import default_backend_factory
     rc, mds = tables
-    cfg = EngineConfig(air="chunk16", logn=10, chunks_per_block=1, groth16_logm=6, crs_dir=str(tmp_path / "crs"), n_queries=12, pow_bits=4,
+    cfg = EngineConfig(air="chunk16", logn=10, chunks_per_block=1, crs_dir=str(tmp_path / "crs"), n_queries=12, pow_bits=4,
                        agg_queries=6, final_queries=4)
     eng = Engine(default_backend_factory(0), cfg)
     ch = eng.gen_batch_chunks("t", [31, 32, 33, 34], 12345, "evm")

@@ -1,0 +1,78 @@
+"""The Groth16 wrap on the MI355X (GenFinalProof, proto/prover/v1/prover.proto:130-148): the key's group elements from
+zp_fixed_base_mul_bn254(_g2), H from zp_qap_quotient_bn254 with its coefficients left in HBM as MSM scalars, five MSMs over key points
+resident in HBM -- the proof must be, byte for byte, the one the checker's trapdoor prover computes with three scalar multiplications
+(oracle/groth16_trapdoor.py: same key scalars, same blinding), pass the pairing check, and its public input must be the commitment
+oracle/wrap_verify.py recomputes from the final STARK.  Then the same through the engine at the service's parameters (a 2^21-domain circuit)."""
+import json
+
+import pytest
+
+from eigen_zeth_amd import native
+from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
+from eigen_zeth_amd.service import groth16 as G16
+from eigen_zeth_amd.service import wrap_circuit as WC
+from eigen_zeth_amd.stark import air as AIR
+from eigen_zeth_amd.stark import prover as PR
+from eigen_zeth_amd.stark.backend_hip import HipBackend
+from oracle import groth16_verify as GV
+from oracle import stark_verify as V
+from oracle import wrap_verify as WV
+from oracle.stark_cpu import CpuBackend
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_groth16_of_the_wrap_circuit_equals_the_trapdoor_proof(tables):
+    bn = bn254_poseidon_params(17)
+    hip = HipBackend(0, hash_mode="bn128")
+    cpu = CpuBackend(*tables, hash_mode="bn128", bn_tables=bn)
+    air = AIR.get_air("wide8")
+    tr, pub = native.synth_trace(air.trace_kind, 8, air.width, 5)
+    params = PR.StarkParams(8, 2, 3, 3, 6, pow_bits=0, hash="bn128")
+    proof = json.loads(hip.prove_native(air, tr, pub, params))
+    assert V.verify(proof, air.program(), *tables, V.expectation(params.to_dict()), bn)
+    wc = WC.wrap_circuit(WC.Layout.of_air(air, params))
+    aux = 12345
+    wf, a, b, c = native.r1cs_eval(wc.blob, *wc.assign(proof, aux))
+    key = G16.Key(wc.blob)
+    rand = (0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA0987654321)
+    p_gpu, pubs = G16.prove(key, wf, a, b, c, hip, rand)
+    p_cpu, pubs_c = G16.prove(key, wf, a, b, c, cpu, rand)
+    assert pubs == pubs_c == [WV.public_input(proof, aux, bn)]
+    assert p_gpu == p_cpu                                   # QAP transforms + five MSMs on the GPU = three scalar multiplications by the trapdoor
+    assert WV.verify(key.vk, p_gpu, pubs, proof, aux, bn)
+    assert not GV.verify(key.vk, p_gpu, [(pubs[0] + 1) % G16.R])
+    print("wrap circuit: %d constraints, domain 2^%d, %d wires" % (wc.c.n_constraints, wc.c.logm(), wc.c.n_wires))
+
+
+def test_engine_final_proof_wraps_the_final_stark(tables, tmp_path):
+    """GenFinalProof at the service's default parameters: the Groth16 proof verifies under the engine's key, its public input commits to THIS
+    final STARK and the request's aggregator address, the same request with deterministic blinding gives the same proof.json, and a final
+    STARK with a flipped digest has no witness"""
+    from eigen_zeth_amd.service.engine import Engine, EngineConfig
+    from eigen_zeth_amd.service.server import default_backend_factory
+    from eigen_zeth_amd.service import consumer as CS
+    bn = bn254_poseidon_params(17)
+    cfg = EngineConfig(air="chunk64", logn=14, chunks_per_block=1, groth16_seed="test")
+    eng = Engine(default_backend_factory(0), cfg)
+    ch = eng.gen_batch_chunks("w", [3, 4], 12345, "evm")
+    proofs = eng.gen_chunk_proofs("w", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+    agg = eng.aggregate("w", proofs[0]["proof"], proofs[1]["proof"])
+    addr = "479881985774944702531460751064278034642760119942"
+    js, pub_js = eng.final("w", agg, "BN128", addr)
+    fs = json.loads(eng.final_starks["w"])
+    pr = CS.parse_proof(js)
+    pub = CS.parse_public_input(pub_js)
+    proof = {"pi_a": tuple(pr.a), "pi_b": (pr.b.x, pr.b.y), "pi_c": tuple(pr.c)}
+    vk = json.loads(eng.verifying_key_json(2, 14))
+    g1 = lambda d: (int(d["x"]), int(d["y"]))
+    g2 = lambda d: ((int(d["x"][0]), int(d["x"][1])), (int(d["y"][0]), int(d["y"][1])))
+    vkp = {"alpha1": g1(vk["alpha1"]), "beta2": g2(vk["beta2"]), "gamma2": g2(vk["gamma2"]), "delta2": g2(vk["delta2"]), "ic": [g1(p) for p in vk["ic"]]}
+    assert WV.verify(vkp, proof, pub, fs, int(addr), bn)
+    meta = json.loads(js)
+    assert "final-stark-hashing" in meta["circuit"] and "2^21" in meta["circuit"]
+    js2, pub2 = eng.final("w", agg, "BN128", addr)
+    assert js2 == js and pub2 == pub_js                       # deterministic blinding: the same proof.json
+    js3, pub3 = eng.final("w", agg, "BN128", "1")
+    assert pub3 != pub_js                                     # another aggregator address: another statement
+    print("final stage timings:", json.dumps({k: round(v * 1e3, 1) for k, v in eng.stage_timings["final/w"].items()}))

@@ -77,7 +77,7 @@ def test_reference_fixture_grammar():
 def _start(tmp_path, backend_factory, cfg=None):
     cfg = cfg or EngineConfig(air="wide8", logn=5, n_queries=3, fri_final_log=3, pow_bits=6)
     cfg.agg_queries, cfg.final_queries = 2, 2                         # small recursion layers: the CPU checker proves and verifies them
-    cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
+    cfg.crs_dir = str(tmp_path / "crs")
     engine = Engine(backend_factory, cfg)
     svc = ProverService(engine, BatchStore(str(tmp_path)))
     server, port = make_server(svc, port=0)
@@ -117,6 +117,7 @@ def _check_result(res, tables, block, svc=None):
         proof = {"pi_a": (pts[0], pts[1]), "pi_b": ((pts[2], pts[3]), (pts[4], pts[5])), "pi_c": (pts[6], pts[7])}
         assert GV.verify(vkp, proof, [pub])
         assert not GV.verify(vkp, proof, [(pub + 1) % bn254.R])
+        assert "final-stark-hashing" in json.loads(res["proof"])["circuit"]
         # ... and it names (by digest) a final STARK in BN128-hash mode that the independent verifier accepts
         import hashlib
         from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
@@ -124,6 +125,11 @@ def _check_result(res, tables, block, svc=None):
         assert len(fs) == 1
         fsp = json.loads(fs[0])
         assert fsp["params"]["hash"] == "bn128" and len(fsp["roots"]["trace"]) == 1
+        # the wrap's one public input IS the commitment to this final STARK's roots, query indices and opened leaves (and to the aggregator
+        # address of the request): recomputed by the checker from the STARK alone (oracle/wrap_verify.py)
+        from oracle import wrap_verify as WV
+        from eigen_zeth_amd.service.client import DEFAULT_AGGREGATOR_ADDR
+        assert pub == WV.public_input(fsp, int(DEFAULT_AGGREGATOR_ADDR), bn254_poseidon_params(17))
         # the recursion layers prove what they name.  (1) the aggregated proof: both chunk-proof headers verify (transcript,
         # out-of-domain identity, final layer), the outer STARK's publics are their roots and transcript-derived indices, and
         # the outer STARK verifies under the Merkle-verifier AIR of that shape
@@ -321,7 +327,7 @@ def test_metrics_endpoint_counts_requests_and_stage_time(tmp_path, cpu_factory):
     import urllib.request
     from eigen_zeth_amd.service.metrics import Metrics
     cfg = EngineConfig(air="chunk16", logn=5, n_queries=2, fri_final_log=3, pow_bits=4, agg_queries=2, final_queries=2)
-    cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
+    cfg.crs_dir = str(tmp_path / "crs")
     m = Metrics()
     httpd = m.serve(0)
     svc = ProverService(Engine(cpu_factory, cfg), BatchStore(str(tmp_path)), m)
@@ -350,7 +356,7 @@ def test_chunk_proofs_identical_across_streams_and_devices(tmp_path, cpu_factory
     def run(factories, streams):
         cfg = EngineConfig(air="chunk16", logn=6, n_queries=4, fri_final_log=3, pow_bits=4, chunks_per_block=1, prover_streams=streams,
                            witness_threads=3)
-        cfg.groth16_logm, cfg.crs_dir = 4, str(tmp_path / "crs")
+        cfg.crs_dir = str(tmp_path / "crs")
         eng = Engine(factories, cfg)
         ch = eng.gen_batch_chunks("b", [3, 4, 5, 6, 7], 12345, "evm")
         return eng.gen_chunk_proofs("b", ch["task_id"], ch["chunk_count"], ch["batch_data"])

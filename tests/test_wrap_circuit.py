@@ -1,0 +1,158 @@
+"""The Groth16 wrap's circuit and the R1CS machinery under it (CPU tests: everything here is host code of the library or Python).
+
+* service/r1cs.py + csrc/r1cs.hip: the Poseidon-BN254 (t = 17) gadget template computes the permutation the oracle computes; zp_r1cs_eval
+  completes a witness exactly as the Python reference does and gives A w, B w, C w per constraint; zp_r1cs_key_scalars matches the
+  definition of a Groth16 key's scalars.
+* service/wrap_circuit.py over a real final-STARK-shaped proof (BN128-hash mode, from the CPU checker's backend): the witness completes, the
+  public input is what oracle/wrap_verify.py recomputes from the STARK on its own, a flipped Merkle digest / opened value / index has NO
+  satisfying witness, and a Groth16 proof of it (the checker's trapdoor prover under the product's key scalars) passes the pairing check."""
+import copy
+import json
+
+import numpy as np
+import pytest
+
+from eigen_zeth_amd import native
+from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
+from eigen_zeth_amd.service import groth16 as G16
+from eigen_zeth_amd.service import r1cs as R1
+from eigen_zeth_amd.service import wrap_circuit as WC
+from eigen_zeth_amd.stark import air as AIR
+from eigen_zeth_amd.stark import prover as PR
+from oracle import groth16_verify as GV
+from oracle import naive as NV
+from oracle import stark_verify as V
+from oracle import wrap_verify as WV
+from oracle.stark_cpu import CpuBackend
+
+R = R1.R
+
+
+@pytest.fixture(scope="module")
+def bn():
+    return bn254_poseidon_params(17)
+
+
+@pytest.fixture(scope="module")
+def small():
+    """two chained permutation gadgets + glue: pub = out2, a boolean wire"""
+    c = R1.Circuit(R1.poseidon_template(17))
+    ins = c.new_wires(17)
+    o1 = c.add_instance(ins)
+    more = c.new_wires(16)
+    o2 = c.add_instance([o1] + more)
+    b = c.new_wire()
+    c.add_constraint({o2: 1}, {0: 1}, {1: 1}, defines=1)
+    c.add_constraint({b: 1}, {b: 1}, {b: 1})
+    vals = {ins[i]: i * 7 + 3 for i in range(17)}
+    vals.update({more[i]: i * i + 11 for i in range(16)})
+    vals[b] = 1
+    return c, ins, more, o1, o2, b, vals
+
+
+def _arrays(c, vals):
+    w = np.zeros((c.n_wires, 4), dtype=np.uint64)
+    mask = np.zeros(c.n_wires, dtype=np.uint8)
+    for k, v in list(vals.items()) + [(0, 1)]:
+        w[k] = native.fr_words([v])[0]
+        mask[k] = 1
+    return w, mask
+
+
+def test_gadget_is_the_permutation_and_eval_matches_the_reference(small, bn):
+    c, ins, more, o1, o2, b, vals = small
+    rc, mds, rp = bn
+    tpl = c.tpl
+    assert len(tpl.cons) == 3 * (8 * 17 + 68) + 1 == 613 and tpl.n_local == 631
+    d1 = NV.poseidon_bn254_perm([vals[w] for w in ins], rc, mds, rp)[0]
+    d2 = NV.poseidon_bn254_perm([d1] + [vals[w] for w in more], rc, mds, rp)[0]
+    full = c.complete(vals)
+    assert full[o1] == d1 and full[o2] == d2 and full[1] == d2
+    blob = c.pack()
+    wf, a, bb, cc = native.r1cs_eval(blob, *_arrays(c, vals))
+    assert native.fr_ints(wf) == full
+    dot = lambda M: sum(cf * full[k] for k, cf in M.items()) % R
+    ai, bi, ci = native.fr_ints(a), native.fr_ints(bb), native.fr_ints(cc)
+    rows = list(c.rows())
+    for q, (A, B, C) in enumerate(rows):
+        assert ai[q] == dot(A) and bi[q] == dot(B) and ci[q] == dot(C) and ai[q] * bi[q] % R == ci[q], q
+    assert not any(ai[len(rows):]) and len(ai) == 1 << c.logm()
+    bad = dict(vals)
+    bad[b] = 2                                                   # not a bit
+    with pytest.raises(ValueError, match="does not satisfy"):
+        native.r1cs_eval(blob, *_arrays(c, bad))
+    w, mask = _arrays(c, vals)
+    mask[more[3]] = 0                                            # a wire nobody set
+    with pytest.raises(native.ZpError):
+        native.r1cs_eval(blob, w, mask)
+    with pytest.raises(native.ZpError):
+        native.r1cs_eval(blob[:-3], *_arrays(c, vals))
+
+
+def test_key_scalars_match_the_definition(small):
+    c = small[0]
+    blob = c.pack()
+    tau, al, be, ga, de = 123456789, 5, 7, 11, 13
+    u, v, l, h = native.r1cs_key_scalars(blob, tau, al, be, ga, de)
+    m, om = 1 << c.logm(), pow(5, (R - 1) >> c.logm(), R)
+    zt = (pow(tau, m, R) - 1) % R
+    rows = list(c.rows())
+    L = [zt * pow(om, i, R) % R * pow(m, -1, R) % R * pow((tau - pow(om, i, R)) % R, -1, R) % R for i in range(len(rows))]
+    uu, vv, ww = [0] * c.n_wires, [0] * c.n_wires, [0] * c.n_wires
+    for i, (A, B, C) in enumerate(rows):
+        for k, cf in A.items():
+            uu[k] = (uu[k] + cf * L[i]) % R
+        for k, cf in B.items():
+            vv[k] = (vv[k] + cf * L[i]) % R
+        for k, cf in C.items():
+            ww[k] = (ww[k] + cf * L[i]) % R
+    assert native.fr_ints(u) == uu and native.fr_ints(v) == vv
+    li = native.fr_ints(l)
+    for j in range(c.n_wires):
+        assert li[j] == (be * uu[j] + al * vv[j] + ww[j]) * pow(ga if j <= 1 else de, -1, R) % R
+    hi = native.fr_ints(h)
+    assert len(hi) == m - 1 and hi[0] == zt * pow(de, -1, R) % R and hi[7] == pow(tau, 7, R) * zt * pow(de, -1, R) % R
+    with pytest.raises(native.ZpError):                           # tau on the domain is not a usable point
+        native.r1cs_key_scalars(blob, 1, al, be, ga, de)
+
+
+@pytest.fixture(scope="module")
+def final_like(tables, bn):
+    """a BN128-hash-mode STARK with the tree kinds a final STARK has (grouped trace / quotient leaves, two FRI layers of different widths)"""
+    cpu = CpuBackend(*tables, hash_mode="bn128", bn_tables=bn)
+    air = AIR.get_air("wide8")
+    tr, pub = native.synth_trace(air.trace_kind, 6, air.width, 5)
+    params = PR.StarkParams(6, 2, 2, 3, 3, pow_bits=0, hash="bn128")
+    proof = json.loads(PR.proof_to_json(PR.prove(air, tr, pub, params, cpu)))
+    return cpu, air, params, proof
+
+
+def test_wrap_circuit_over_a_bn128_stark(final_like, tables, bn):
+    cpu, air, params, proof = final_like
+    rc, mds = tables
+    assert V.verify(proof, air.program(), rc, mds, V.expectation(params.to_dict()), bn)
+    lay = WC.Layout.of_air(air, params)
+    assert [t[0] for t in lay.trees] == ["trace", "quotient", "fri0", "fri1"]
+    wc = WC.wrap_circuit(lay)
+    aux = 479881985774944702531460751064278034642760119942
+    wf, a, b, c = native.r1cs_eval(wc.blob, *wc.assign(proof, aux))
+    d = native.fr_ints(wf[1:2])[0]
+    assert d == WV.public_input(proof, aux, bn) != WV.public_input(proof, aux + 1, bn)
+    # no satisfying witness for a STARK whose openings do not hash to its roots
+    for mutate in (lambda p: p["queries"][1]["fri"][0]["path"][0].__setitem__(3, str((int(p["queries"][1]["fri"][0]["path"][0][3]) + 1) % R)),
+                   lambda p: p["queries"][0]["trace"]["values"].__setitem__(2, p["queries"][0]["trace"]["values"][2] ^ 1),
+                   lambda p: p["queries"][2].__setitem__("index", p["queries"][2]["index"] ^ 1),
+                   lambda p: p["roots"]["quotient"].__setitem__(0, str((int(p["roots"]["quotient"][0]) + 1) % R))):
+        bad = copy.deepcopy(proof)
+        mutate(bad)
+        with pytest.raises(ValueError, match="does not satisfy"):
+            native.r1cs_eval(wc.blob, *wc.assign(bad, aux))
+    # a Groth16 proof of the statement: the product's key (scalars by zp_r1cs_key_scalars), the checker's trapdoor prover, the pairing check
+    key = G16.Key(wc.blob)
+    proof_g, pubs = G16.prove(key, wf, a, b, c, cpu, (11, 13))
+    assert pubs == [d] and WV.verify(key.vk, proof_g, pubs, proof, aux, bn)
+    assert not GV.verify(key.vk, proof_g, [(d + 1) % R])
+    with pytest.raises(V.Reject):
+        WV.verify(key.vk, proof_g, pubs, proof, aux + 1, bn)
+    js = json.loads(G16.proof_to_json(proof_g))
+    assert js["protocol"] == "groth16" and js["curve"] == "BN128" and js["pi_b"]["x"][0].isdigit()

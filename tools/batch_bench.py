@@ -10,7 +10,7 @@ from eigen_zeth_amd.service.server import default_backend_factory
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 air = sys.argv[3] if len(sys.argv) > 3 else "chunk64"
-cfg = EngineConfig(air=air, logn=logn, groth16_logm=8, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs"), witness_threads=16, prover_streams=int(os.environ.get('ZP_STREAMS', '8')))
+cfg = EngineConfig(air=air, logn=logn, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs"), witness_threads=16, prover_streams=int(os.environ.get('ZP_STREAMS', '8')))
 eng = Engine(default_backend_factory(0), cfg)
 eng.pregenerate_witnesses = bool(os.environ.get("ZP_PREGEN"))
 eng.be

@@ -14,7 +14,7 @@ from eigen_zeth_amd.service.server import default_backend_factory
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 mlog = int(sys.argv[3]) if len(sys.argv) > 3 else 26
-cfg = EngineConfig(air="chunk64", logn=logn, groth16_logm=8, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_c5"), witness_threads=16)
+cfg = EngineConfig(air="chunk64", logn=logn, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_c5"), witness_threads=16)
 eng = Engine(default_backend_factory(0), cfg)
 eng.groth16_keys()
 p = eng.be.p

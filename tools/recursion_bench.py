@@ -8,7 +8,7 @@ from eigen_zeth_amd.service.server import default_backend_factory
 
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-cfg = EngineConfig(air="chunk64", logn=logn, groth16_logm=8, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_rec_%d" % os.getuid()))
+cfg = EngineConfig(air="chunk64", logn=logn, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_rec_%d" % os.getuid()))
 eng = Engine(default_backend_factory(0), cfg)
 ch = eng.gen_batch_chunks("r", [1, 2], 12345, "evm")
 proofs = eng.gen_chunk_proofs("r", ch["task_id"], ch["chunk_count"], ch["batch_data"])

@@ -11,7 +11,7 @@ blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cpb = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 tmp = tempfile.mkdtemp()
-cfg = EngineConfig(air="chunk64", logn=logn, chunks_per_block=cpb, groth16_logm=8, crs_dir=os.path.join(tmp, "crs"), witness_threads=8)
+cfg = EngineConfig(air="chunk64", logn=logn, chunks_per_block=cpb, crs_dir=os.path.join(tmp, "crs"), witness_threads=8)
 server, port = serve(0, "127.0.0.1", os.path.join(tmp, "state"), cfg, 0, metrics_port=0)
 ch = ProverChannel("127.0.0.1:%d" % port)
 for b in range(1, blocks + 1):
