@@ -334,20 +334,39 @@ int32_t zp_r1cs_key_scalars(const uint64_t *circ, size_t words, const uint64_t *
         const Fr zero = {{0, 0, 0, 0}};
         std::vector<Fr> acc[3];
         for (int k = 0; k < 3; k++) acc[k].assign(c.n_wires, zero);
-        // instances touch disjoint internal wires but may share input wires: accumulate per thread, then merge (inputs only are shared; to stay
-        // simple every thread owns a full accumulator when there are few wires, otherwise instances run on one thread)
-        (void)threads;
-        for (uint64_t i = 0; i < c.n_inst; i++) {
-            const uint64_t *in = c.inst + i * (c.t + 2);
-            for (int k = 0; k < 3; k++)
-                for (uint64_t q = 0; q < c.tc; q++) {
-                    const Fr &Li = L[i * c.tc + q];
-                    for (uint64_t x = c.T[k].ptr[q]; x < c.T[k].ptr[q + 1]; x++) {
-                        const uint64_t g = local_to_global(c, in, c.T[k].idx[x]);
-                        acc[k][g] = fr_add(acc[k][g], fr_mul(tv[k][x], Li));
+        // instances own their internal wires (no two write the same accumulator) but share input wires and the constant: a thread adds the
+        // internal ones in place and keeps what it has for shared wires in a list of its own, merged afterwards
+        int T = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+        if (T < 1) T = 1;
+        if (T > 32) T = 32;
+        if ((uint64_t)T > c.n_inst) T = (int)(c.n_inst ? c.n_inst : 1);
+        struct Shared { uint64_t g; int k; Fr v; };
+        std::vector<std::vector<Shared>> side(T);
+        auto work = [&](int tid, uint64_t i0, uint64_t i1) {
+            for (uint64_t i = i0; i < i1; i++) {
+                const uint64_t *in = c.inst + i * (c.t + 2);
+                for (int k = 0; k < 3; k++)
+                    for (uint64_t q = 0; q < c.tc; q++) {
+                        const Fr &Li = L[i * c.tc + q];
+                        for (uint64_t x = c.T[k].ptr[q]; x < c.T[k].ptr[q + 1]; x++) {
+                            const uint64_t lw = c.T[k].idx[x];
+                            const Fr v = fr_mul(tv[k][x], Li);
+                            if (lw <= c.t) side[tid].push_back(Shared{local_to_global(c, in, lw), k, v});
+                            else { Fr &a = acc[k][in[c.t] + (lw - 1 - c.t)]; a = fr_add(a, v); }
+                        }
                     }
-                }
+            }
+        };
+        {
+            std::vector<std::thread> pool;
+            for (int tid = 0; tid < T; tid++) {
+                const uint64_t i0 = c.n_inst * tid / T, i1 = c.n_inst * (tid + 1) / T;
+                if (i0 < i1) pool.emplace_back(work, tid, i0, i1);
+            }
+            for (auto &th : pool) th.join();
         }
+        for (const auto &lst : side)
+            for (const Shared &e : lst) acc[e.k][e.g] = fr_add(acc[e.k][e.g], e.v);
         for (int k = 0; k < 3; k++)
             for (uint64_t q = 0; q < c.n_extra; q++) {
                 const Fr &Li = L[c.extra_base() + q];

@@ -258,18 +258,13 @@ def device_count():
 
 
 def fr_words(vals):
-    """ints < r -> u64[n][4] standard form"""
-    out = np.zeros((len(vals), 4), dtype=np.uint64)
-    for i, v in enumerate(vals):
-        v = int(v)
-        for k in range(4):
-            out[i, k] = (v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
-    return out
+    """ints < 2^256 -> u64[n][4] (little-endian words, standard form)"""
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint64).reshape(-1, 4).copy()
 
 
 def fr_ints(a):
-    a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
-    return [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in a]
+    raw = np.ascontiguousarray(np.asarray(a, dtype=np.uint64).reshape(-1, 4)).tobytes()
+    return [int.from_bytes(raw[i:i + 32], "little") for i in range(0, len(raw), 32)]
 
 
 def r1cs_eval(blob, witness, mask):

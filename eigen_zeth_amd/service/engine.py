@@ -601,6 +601,9 @@ class Engine:
         proof, pub = groth16.prove(key, wf, a_ev, b_ev, c_ev, self.be, rnd)
         self.stage_timings["final/" + batch_id] = {"final_stark(bn128)": t_fs, "wrap-witness": t_wit, "groth16": time.perf_counter() - t0,
                                                    **{"final/" + k: v for k, v in tmf.items()}}
+        self.wrap_info = {"constraints": wc.c.n_constraints, "qap_domain_log2": wc.c.logm(), "wires": wc.c.n_wires,
+                          "msm_points": {"A (G1)": wc.c.n_wires + 2, "B (G1)": wc.c.n_wires + 2, "B (G2)": wc.c.n_wires + 2, "C: l (G1)": wc.c.n_wires,
+                                         "C: h (G1)": (1 << wc.c.logm()) - 1}}
         if self.metrics is not None:
             self.metrics.record_stage("groth16", self.stage_timings["final/" + batch_id]["groth16"])
         js = groth16.proof_to_json(proof, {"circuit": "final-stark-hashing: %d constraints (2^%d domain), %d wires, key %s (local seeded setup)"
