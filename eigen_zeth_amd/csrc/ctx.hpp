@@ -62,6 +62,8 @@ struct zp_ctx {
     // pinned host staging for small transfers (pageable async copies lock/unlock host pages on every call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    void *g16_pinned = nullptr;        // zp_groth16_prove: page-locked home of A w, B w, C w and the witness (kept between proofs)
+    size_t g16_pinned_bytes = 0;
     int num_cu = 256;
     // experiment knobs (zp_set_tuning): not part of the stable surface
     void *msm_arena = nullptr;    // scratch of zp_msm_bn254*: grows to the largest run, freed by zp_destroy
@@ -82,6 +84,7 @@ struct zp_ctx {
     std::map<std::string, u64 *> prove_fixed;
     struct DigestEntry { std::vector<uint64_t> words; uint8_t dg[32]; };
     std::vector<DigestEntry> digest_cache;   // SHA-256 of the large constraint programs seen last (csrc/prove.hip: program_digest)
+    std::vector<u64> last_openings;          // BN128-hash mode: roots, query indices, opened values and paths of the last proof, binary (zp_stark_openings)
     // per-launch event profiling (zp_set_profiling)
     bool profiling = false;
     struct PassEv { hipEvent_t a, b; int radix_log; };
@@ -154,6 +157,10 @@ struct NttRunOpts {
 struct ZpFixedCol { int lp; size_t first_entry_word, n_entries; bool has_pub; };
 // validates the whole-blob length and the table; fills `cols` (empty for n_fixed == 2).  false: malformed
 bool zpi_program_fixed_table(const uint64_t *h_program, size_t program_words, std::vector<ZpFixedCol> *cols);
+// device buffers from / back to the per-ctx pool of zp_stark_prove (csrc/prove.hip): everything runs on the ctx stream, so reuse is ordered
+int32_t zpi_pool_alloc(zp_ctx *ctx, size_t bytes, void **out);
+void zpi_pool_release(zp_ctx *ctx, void *p, size_t bytes);
+void zpi_sha256(const uint8_t *data, size_t len, uint8_t *out32);
 struct zp_comm;
 zp_ctx *zpi_comm_ctx(const zp_comm *comm);      // the ctx a communicator was created on (csrc/comm.hip)
 int32_t zpi_comm_fail(zp_comm *comm, int32_t rc);   // rc != ZP_OK: kill the communicator (no peer waits for this rank); returns rc

@@ -299,6 +299,21 @@ void j_opening(std::string &s, const u64 *vals, size_t W, const u64 *path, size_
 
 }  // namespace
 
+int32_t zpi_pool_alloc(zp_ctx *ctx, size_t bytes, void **out) {
+    DevBufs b(ctx);
+    u64 *p = nullptr;
+    const int32_t rc = b.alloc((bytes + 7) / 8, &p);
+    if (rc != ZP_OK) return rc;
+    b.forget(p);
+    *out = p;
+    return ZP_OK;
+}
+void zpi_pool_release(zp_ctx *ctx, void *p, size_t bytes) {
+    DevBufs b(ctx);
+    b.give_back(p, ((bytes + 7) / 8 ? (bytes + 7) / 8 : 1) * 8);
+}
+void zpi_sha256(const uint8_t *data, size_t len, uint8_t *out32) { Sha256::digest(data, len, out32); }
+
 extern "C" {
 
 int32_t zp_free_buffer(void *p) {
@@ -645,6 +660,30 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         }
     }
 
+    if (bn) {       // the same openings in binary, for the Groth16 wrap's witness (zp_stark_openings -> zp_wrap_assign): no text round trip
+        std::vector<u64> &rec = ctx->last_openings;
+        rec.clear();
+        const size_t ntr = 2 + (n_s2 ? 1 : 0) + layers.size();
+        rec.insert(rec.end(), {0x31304e45504f5a50ULL /* "PZOPEN01" */, (u64)nq, (u64)ntr, (u64)logm});
+        auto shape = [&](size_t width, size_t rows) { rec.insert(rec.end(), {(u64)width, (u64)rows, (u64)Trees::levels16(rows)}); };
+        shape(Wtg, Mt); shape(Wqg, Mq);
+        if (n_s2) shape(W2g, M2);
+        for (size_t li = 0; li < layers.size(); li++) shape(fo[li].width, fo[li].m);
+        rec.insert(rec.end(), root1, root1 + 4); rec.insert(rec.end(), rootq, rootq + 4);
+        if (n_s2) rec.insert(rec.end(), root2, root2 + 4);
+        for (size_t li = 0; li < layers.size(); li++) rec.insert(rec.end(), layers[li].root, layers[li].root + 4);
+        for (size_t i = 0; i < nq; i++) {
+            rec.push_back(qidx[i]);
+            auto put = [&](const std::vector<u64> &v, size_t w, const std::vector<u64> &p, size_t pw) {
+                rec.insert(rec.end(), v.begin() + i * w, v.begin() + (i + 1) * w);
+                rec.insert(rec.end(), p.begin() + i * pw, p.begin() + (i + 1) * pw);
+            };
+            put(v_tr, Wtg, p_tr, pwt); put(v_q, Wqg, p_q, pwq);
+            if (n_s2) put(v_s2, W2g, p_s2, pw2);
+            for (size_t li = 0; li < layers.size(); li++) put(fo[li].vals, fo[li].width, fo[li].paths, fo[li].pw);
+        }
+    }
+
     // the proof text
     std::string s;
     s.reserve(nq * (Wt + Wq + 64) * 24 + (1 << 16));
@@ -734,6 +773,24 @@ int32_t zp_stark_prove_bn128(zp_ctx *ctx, const char *air_name, const uint64_t *
                              int32_t fri_final_log, int32_t n_queries, char **out_json, size_t *out_len) {
     return prove_guarded(ctx, true, air_name, h_program, program_words, d_trace, trace_words, h_pubs, n_pubs, logn, logb, fri_logf, fri_final_log,
                          n_queries, 0, out_json, out_len);
+}
+
+// Binary openings of the LAST proof zp_stark_prove_bn128 made on this ctx (what its text carries under "roots", "fri.roots" and "queries"):
+//   [0] "PZOPEN01" [1] n_queries [2] n_trees [3] log2 of the LDE size (bits of a query index), then per tree (trace, quotient, [stage 2], FRI
+//   layers): values per leaf, leaves, levels of the 16-ary tree; per tree the root (4 words); per query: the index, then per tree values[width]
+//   and path[levels][16][4].  *out points into the ctx (valid until the next proof on it); ZP_ERR_ARG when there is none.
+int32_t zp_stark_openings(zp_ctx *ctx, const uint64_t **out, size_t *words) {
+    if (!ctx || !out || !words) return ZP_ERR_ARG;
+    ZP_ARG(ctx, !ctx->last_openings.empty(), "no BN128-mode proof has been made on this ctx");
+    *out = (const uint64_t *)ctx->last_openings.data();
+    *words = ctx->last_openings.size();
+    return ZP_OK;
+}
+
+int32_t zp_sha256(const uint8_t *data, size_t len, uint8_t *out32) {
+    if ((!data && len) || !out32) return ZP_ERR_ARG;
+    Sha256::digest(data, len, out32);
+    return ZP_OK;
 }
 
 }  // extern "C"

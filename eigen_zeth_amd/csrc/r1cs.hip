@@ -8,6 +8,7 @@
 // core, instances in parallel on threads for the key scalars).  The group operations (fixed-base multiplications for the key, MSMs for a
 // proof) are the GPU's (csrc/msm.hip).  Layout of the circuit blob: eigen_zeth_amd/service/r1cs.py.
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -384,6 +385,222 @@ int32_t zp_r1cs_key_scalars(const uint64_t *circ, size_t words, const uint64_t *
         for (uint64_t i = 0; i + 1 < m; i++) { fr_to_std(tp, out_h + 4 * i); tp = fr_mul(tp, tau); }
         return ZP_OK;
     } catch (...) {
+        return ZP_ERR_NOMEM;
+    }
+}
+
+}  // extern "C"
+
+// ======================================================================================================================
+// The Groth16 wrap behind two calls (GenFinalProof, proto/prover/v1/prover.proto:130-148; src/prover/provider.rs:472-503): what
+// eigen_zeth_amd/service/groth16.py orchestrated in Python through round 3.
+//   zp_wrap_assign   : the caller-set wires of the wrap circuit from the binary openings of the final STARK (zp_stark_openings), driven by the
+//                      assignment script the circuit builder writes beside the circuit blob (service/wrap_circuit.py: WrapCircuit.script)
+//   zp_groth16_prove : witness completion + A w, B w, C w (zp_r1cs_eval), the QAP quotient on the GPU, five MSMs over the key's points in HBM,
+//                      the blinding terms -> the three proof elements
+namespace {
+
+constexpr uint64_t SCRIPT_MAGIC = 0x3153504152575a50ULL;   // "PZWRAPS1"
+constexpr uint64_t OPEN_MAGIC = 0x31304e45504f5a50ULL;     // "PZOPEN01"
+
+struct OpenTree { uint64_t width, leaves, levels; const uint64_t *root; size_t off; };   // off: word offset of this tree's part inside a query record
+struct Openings {
+    uint64_t nq, ntr, logm;
+    std::vector<OpenTree> tr;
+    const uint64_t *q0;
+    size_t qwords;
+    const uint64_t *query(uint64_t q) const { return q0 + q * qwords; }
+};
+bool parse_openings(const uint64_t *d, size_t words, Openings *o) {
+    if (!d || words < 4 || d[0] != OPEN_MAGIC) return false;
+    o->nq = d[1]; o->ntr = d[2]; o->logm = d[3];
+    if (o->nq < 1 || o->nq > 4096 || o->ntr < 2 || o->ntr > 64 || o->logm > 40 || words < 4 + 7 * o->ntr) return false;
+    size_t off = 1;
+    o->tr.resize(o->ntr);
+    for (uint64_t t = 0; t < o->ntr; t++) {
+        OpenTree &T = o->tr[t];
+        T.width = d[4 + 3 * t]; T.leaves = d[5 + 3 * t]; T.levels = d[6 + 3 * t];
+        if (T.width < 1 || T.width > (1u << 16) || T.leaves < 1 || T.leaves > (1ull << 40) || (T.leaves & (T.leaves - 1)) || T.levels > 12) return false;
+        T.root = d + 4 + 3 * o->ntr + 4 * t;
+        T.off = off;
+        off += T.width + T.levels * 64;
+    }
+    o->qwords = off;
+    o->q0 = d + 4 + 7 * o->ntr;
+    return words == 4 + 7 * o->ntr + o->nq * off;
+}
+
+// one sponge block of a leaf: 56 Goldilocks values in 16 field elements (csrc/poseidon_bn254.hip: leaf_block_element)
+void pack_element(const uint64_t *vals, uint64_t width, uint64_t block, int e, uint64_t *w4) {
+    const uint64_t base = 56 * block;
+    for (int c = 0; c < 3; c++) w4[c] = base + 3 * e + c < width ? vals[base + 3 * e + c] : 0;
+    const uint64_t x = base + 48 + (e >> 1);
+    w4[3] = 0;
+    if (x < width) w4[3] = (e & 1) ? (vals[x] >> 32) : (vals[x] & 0xFFFFFFFFull);
+}
+
+}  // namespace
+
+extern "C" {
+
+// script: [0] "PZWRAPS1" [1] entries [2] wires set in all [3] n_queries [4] n_trees [5] index bits, per tree (width, leaves, levels), then per entry six
+// words: op, first wire, count, a, b, c --
+//   0 constant a                      1 aux                                  2 root of tree b               3 index of query a
+//   4 bits 0..count-1 of that index   5 elements of block c of the leaf (query a, tree b)                    6 the 16 digests of level c on the path
+//   7 one-hot of the position at level c (16)       8 / 9 one-hot of its low / high two bits (4)
+// out_idx u64[cap], out_val u64[cap][4] (standard form) receive the wires and their values; *n_set their number ([2] of the script).
+int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64_t *openings, size_t open_words, const uint64_t *aux4, uint64_t *out_idx,
+                       uint64_t *out_val, size_t cap, size_t *n_set) {
+    Openings o;
+    if (!script || script_words < 6 || script[0] != SCRIPT_MAGIC || !aux4 || !out_idx || !out_val || !n_set || !parse_openings(openings, open_words, &o))
+        return ZP_ERR_ARG;
+    const uint64_t ne = script[1], total = script[2];
+    if (script[3] != o.nq || script[4] != o.ntr || script[5] != o.logm || ne > (1ull << 28) || script_words != 6 + 3 * o.ntr + 6 * ne || total > cap ||
+        !std_canonical(aux4))
+        return ZP_ERR_ARG;
+    for (uint64_t t = 0; t < o.ntr; t++)
+        if (script[6 + 3 * t] != o.tr[t].width || script[7 + 3 * t] != o.tr[t].leaves || script[8 + 3 * t] != o.tr[t].levels) return ZP_ERR_ARG;   // another layout
+    const uint64_t *e = script + 6 + 3 * o.ntr;
+    size_t n = 0;
+    for (uint64_t k = 0; k < ne; k++, e += 6) {
+        const uint64_t op = e[0], wire = e[1], cnt = e[2], a = e[3], b = e[4], c = e[5];
+        if (cnt < 1 || cnt > 64 || n + cnt > total || op > 9) return ZP_ERR_ARG;
+        if (op >= 3 && a >= o.nq) return ZP_ERR_ARG;
+        if ((op == 2 || op >= 5) && b >= o.ntr) return ZP_ERR_ARG;
+        const uint64_t *q = op >= 3 ? o.query(a) : nullptr;
+        const OpenTree *T = (op == 2 || op >= 5) ? &o.tr[b] : nullptr;
+        uint64_t pos = 0;
+        if (op >= 6) {
+            if (c >= T->levels) return ZP_ERR_ARG;
+            pos = ((q[0] & (T->leaves - 1)) >> (4 * c)) & 15;
+        }
+        if ((op == 5 && (cnt != 16 || 56 * c >= T->width)) || ((op == 6 || op == 7) && cnt != 16) || (op >= 8 && cnt != 4) || (op == 4 && cnt > 64) ||
+            ((op == 1 || op == 2 || op == 3) && cnt != 1))
+            return ZP_ERR_ARG;
+        for (uint64_t i = 0; i < cnt; i++, n++) {
+            uint64_t *v = out_val + 4 * n;
+            out_idx[n] = wire + i;
+            v[0] = v[1] = v[2] = v[3] = 0;
+            switch (op) {
+                case 0: v[0] = a; break;
+                case 1: memcpy(v, aux4, 32); break;
+                case 2: memcpy(v, T->root, 32); break;
+                case 3: v[0] = q[0]; break;
+                case 4: v[0] = (q[0] >> i) & 1; break;
+                case 5: pack_element(q + T->off, T->width, c, (int)i, v); break;
+                case 6: memcpy(v, q + T->off + T->width + (c * 16 + i) * 4, 32); break;
+                case 7: v[0] = pos == i; break;
+                case 8: v[0] = (pos & 3) == i; break;
+                default: v[0] = (pos >> 2) == i; break;
+            }
+        }
+    }
+    if (n != total) return ZP_ERR_ARG;
+    *n_set = n;
+    return ZP_OK;
+}
+
+// One Groth16 proof.  circ: the circuit blob; d_u1x, d_v1x (G1, u32[n_wires + 2][16]): [u_j]_1 | alpha_1 | delta_1 and [v_j]_1 | beta_1 | delta_1;
+// d_v2x (G2, u32[n_wires + 2][32]): [v_j]_2 | beta_2 | delta_2; d_l1 (G1, u32[n_wires][16], infinity at wire 0 and the public inputs: those are
+// the verifier's); d_h1 (G1, u32[2^logm - 1][16]) -- device-resident key points in the MSM layout; h_delta1 u32[16].
+// set_idx / set_val: the n_set caller-set wires (zp_wrap_assign; wire 0 = 1 among them).  h_r, h_s: the blinding scalars (4 words each, standard
+// form).  out_a u32[16], out_b u32[32], out_c u32[16]: pi_a, pi_b, pi_c (affine, standard form); out_pub u64[n_pub][4]: the public inputs the proof
+// is for; h_ms (may be NULL) double[3]: milliseconds of witness completion, QAP step, MSMs.  -20 / -21 as zp_r1cs_eval (*bad): no proof for a
+// false statement.
+int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const uint32_t *d_u1x, const uint32_t *d_v1x, const uint32_t *d_v2x,
+                         const uint32_t *d_l1, const uint32_t *d_h1, const uint32_t *h_delta1, const uint64_t *set_idx, const uint64_t *set_val, size_t n_set,
+                         const uint64_t *h_r, const uint64_t *h_s, uint32_t *out_a, uint32_t *out_b, uint32_t *out_c, uint64_t *out_pub, double *h_ms,
+                         int64_t *bad) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
+    Circ c;
+    ZP_ARG(ctx, parse(circ, words, &c), "malformed circuit blob");
+    ZP_ARG(ctx, d_u1x && d_v1x && d_v2x && d_l1 && d_h1 && h_delta1 && set_idx && set_val && h_r && h_s && out_a && out_b && out_c && out_pub, "null argument");
+    ZP_ARG(ctx, std_canonical(h_r) && std_canonical(h_s), "blinding scalars must be below the group order");
+    if (bad) *bad = -1;
+    const size_t n = c.n_wires, m = (size_t)1 << c.logm;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
+    void *d_abc = nullptr, *d_sc = nullptr, *d_tail = nullptr;
+    const size_t abc_bytes = 3 * m * 32, sc_bytes = (n + 2) * 32, tail_bytes = 5 * (64 + 32);
+    int32_t rc = ZP_OK;
+    try {
+        // the three evaluation vectors go straight into page-locked memory: 3 x 2^logm x 32 bytes are uploaded in one piece
+        if (ctx->g16_pinned_bytes < abc_bytes + sc_bytes) {         // its own buffer: the ctx's staging buffer carries the small copies of the calls below
+            if (ctx->g16_pinned) { ZP_HIP(ctx, hipStreamSynchronize(ctx->stream)); ZP_HIP(ctx, hipHostFree(ctx->g16_pinned)); }
+            ctx->g16_pinned = nullptr;
+            ctx->g16_pinned_bytes = 0;
+            ZP_HIP(ctx, hipHostMalloc(&ctx->g16_pinned, abc_bytes + sc_bytes, hipHostMallocPortable));
+            ctx->g16_pinned_bytes = abc_bytes + sc_bytes;
+        }
+        void *pin = ctx->g16_pinned;
+        uint64_t *a_ev = (uint64_t *)pin, *b_ev = a_ev + 4 * m, *c_ev = b_ev + 4 * m, *w = c_ev + 4 * m;
+        std::vector<uint8_t> set(n, 0);
+        memset(w, 0, n * 32);
+        for (size_t k = 0; k < n_set; k++) {
+            ZP_ARG(ctx, set_idx[k] < n, "a set wire is outside the circuit");
+            memcpy(w + 4 * set_idx[k], set_val + 4 * k, 32);
+            set[set_idx[k]] = 1;
+        }
+        rc = zp_r1cs_eval(circ, words, w, set.data(), a_ev, b_ev, c_ev, bad);
+        if (rc == -20) ctx->err = "the assignment does not satisfy the circuit: no proof for a false statement";
+        if (rc == -21) ctx->err = "a wire of the circuit has no value";
+        if (rc != ZP_OK) return rc;
+        memcpy(out_pub, w + 4, c.n_pub * 32);
+        const uint64_t one[4] = {1, 0, 0, 0};
+        memcpy(w + 4 * n, one, 32);
+        memcpy(w + 4 * (n + 1), h_r, 32);
+        const auto t1 = now();
+        ZP_TRY(zpi_pool_alloc(ctx, abc_bytes, &d_abc));
+        rc = zpi_pool_alloc(ctx, sc_bytes, &d_sc);
+        if (rc == ZP_OK) rc = zpi_pool_alloc(ctx, tail_bytes, &d_tail);
+        auto done = [&](int32_t r) {
+            if (d_abc) zpi_pool_release(ctx, d_abc, abc_bytes);
+            if (d_sc) zpi_pool_release(ctx, d_sc, sc_bytes);
+            if (d_tail) zpi_pool_release(ctx, d_tail, tail_bytes);
+            return r;
+        };
+        if (rc != ZP_OK) return done(rc);
+        uint64_t *da = (uint64_t *)d_abc, *db = da + 4 * m, *dc = db + 4 * m;
+        if (hipMemcpyAsync(d_abc, a_ev, abc_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(d_sc, w, sc_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            ctx->err = "upload of the evaluation vectors failed";
+            return done(ZP_ERR_HIP);
+        }
+        // H = (A B - C) / Z: its coefficients replace A's evaluations and are the scalars of the h MSM
+        const uint64_t coset[4] = {7, 0, 0, 0};
+        if ((rc = zp_qap_quotient_bn254(ctx, da, db, dc, (int32_t)c.logm, coset)) != ZP_OK) return done(rc);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "QAP step failed"; return done(ZP_ERR_HIP); }
+        const auto t2 = now();
+        uint32_t A1[16], B1[16], Cl[16], Ch[16];
+        const uint32_t *sc = (const uint32_t *)d_sc;
+        if ((rc = zp_msm_bn254(ctx, d_u1x, sc, n + 2, A1)) != ZP_OK) return done(rc);            // alpha + sum_j w_j u_j + r delta
+        if ((rc = zpi_h2d_small(ctx, (uint64_t *)d_sc + 4 * (n + 1), h_s, 32)) != ZP_OK) return done(rc);
+        if ((rc = zp_msm_bn254(ctx, d_v1x, sc, n + 2, B1)) != ZP_OK) return done(rc);            // beta + sum_j w_j v_j + s delta
+        if ((rc = zp_msm_bn254_g2(ctx, d_v2x, sc, n + 2, out_b)) != ZP_OK) return done(rc);
+        if ((rc = zp_msm_bn254(ctx, d_l1, sc, n, Cl)) != ZP_OK) return done(rc);
+        if ((rc = zp_msm_bn254(ctx, d_h1, (const uint32_t *)da, m - 1, Ch)) != ZP_OK) return done(rc);     // sum_i H_i [tau^i Z(tau) / delta]
+        // pi_c = Cl + Ch + s A + r B1 - r s delta: one more (five-point) MSM
+        const Fr fr_r = fr_from_std(h_r), fr_s = fr_from_std(h_s);
+        const Fr zero = {{0, 0, 0, 0}};
+        uint64_t tsc[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        memcpy(tsc[2], h_s, 32);
+        memcpy(tsc[3], h_r, 32);
+        fr_to_std(fr_sub(zero, fr_mul(fr_r, fr_s)), tsc[4]);
+        uint32_t tpt[5][16];
+        memcpy(tpt[0], Cl, 64); memcpy(tpt[1], Ch, 64); memcpy(tpt[2], A1, 64); memcpy(tpt[3], B1, 64); memcpy(tpt[4], h_delta1, 64);
+        if ((rc = zpi_h2d_small(ctx, d_tail, tpt, sizeof tpt)) != ZP_OK) return done(rc);
+        if ((rc = zpi_h2d_small(ctx, (uint8_t *)d_tail + sizeof tpt, tsc, sizeof tsc)) != ZP_OK) return done(rc);
+        if ((rc = zp_msm_bn254(ctx, (const uint32_t *)d_tail, (const uint32_t *)((uint8_t *)d_tail + sizeof tpt), 5, out_c)) != ZP_OK) return done(rc);
+        memcpy(out_a, A1, 64);
+        if (h_ms) { h_ms[0] = ms(t0, t1); h_ms[1] = ms(t1, t2); h_ms[2] = ms(t2, now()); }
+        return done(ZP_OK);
+    } catch (...) {
+        if (d_abc) zpi_pool_release(ctx, d_abc, abc_bytes);
+        if (d_sc) zpi_pool_release(ctx, d_sc, sc_bytes);
+        if (d_tail) zpi_pool_release(ctx, d_tail, tail_bytes);
+        ctx->err = "out of host memory in zp_groth16_prove";
         return ZP_ERR_NOMEM;
     }
 }

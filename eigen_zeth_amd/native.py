@@ -111,6 +111,10 @@ SIGNATURES = {
     "zp_fixed_base_mul_bn254_g2": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_int32]),
     "zp_r1cs_eval": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zp_r1cs_key_scalars": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
+    "zp_stark_openings": (C.c_int32, [_vp, _vp, _vp]),
+    "zp_wrap_assign": (C.c_int32, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "zp_groth16_prove": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "zp_sha256": (C.c_int32, [_vp, C.c_size_t, _vp]),
     "zp_program_digest": (C.c_int32, [_vp, C.c_size_t, _vp, _vp]),
     "zp_recursion_witness": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int32]),
     "zp_recursion_publics_words": (C.c_size_t, [_vp, C.c_size_t]),
@@ -283,6 +287,30 @@ def r1cs_eval(blob, witness, mask):
     if rc != 0:
         raise ZpError(rc, "zp_r1cs_eval: malformed circuit or unset wire (%d)" % bad.value)
     return w, ev[0], ev[1], ev[2]
+
+
+def wrap_assign(script, openings, aux):
+    """zp_wrap_assign: (wire indices u64[n], values u64[n][4]) of the caller-set wires of the wrap circuit, from the binary openings of a final STARK"""
+    script = np.ascontiguousarray(script, dtype=np.uint64)
+    openings = np.ascontiguousarray(openings, dtype=np.uint64)
+    cap = int(script[2])
+    idx, val = np.empty(cap, dtype=np.uint64), np.empty((cap, 4), dtype=np.uint64)
+    a = fr_words([int(aux)])
+    n = C.c_size_t(0)
+    rc = load_library().zp_wrap_assign(script.ctypes.data, script.size, openings.ctypes.data, openings.size, a.ctypes.data, idx.ctypes.data, val.ctypes.data, cap,
+                                       C.byref(n))
+    if rc != 0:
+        raise ValueError("final STARK does not have the shape the wrap circuit was built for")
+    return idx[:n.value], val[:n.value]
+
+
+def sha256(data):
+    out = (C.c_uint8 * 32)()
+    buf = bytes(data)
+    rc = load_library().zp_sha256(buf, len(buf), out)
+    if rc != 0:
+        raise ZpError(rc, "zp_sha256")
+    return bytes(out)
 
 
 def r1cs_key_scalars(blob, tau, alpha, beta, gamma, delta):
@@ -870,6 +898,33 @@ class Prover:
         return lo.value, hi.value, lb.value
 
     # ---- N6
+    def stark_openings(self):
+        """zp_stark_openings: the binary openings of the last BN128-mode proof of this ctx (a copy)"""
+        ptr, n = C.c_void_p(), C.c_size_t(0)
+        self._chk(self.lib.zp_stark_openings(self.ctx, C.byref(ptr), C.byref(n)))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(n.value,)).copy()
+
+    def groth16_prove(self, blob, dev, delta1_words, set_idx, set_val, r, s):
+        """zp_groth16_prove -> (pi_a u32[16], pi_b u32[32], pi_c u32[16], public inputs [int], [ms witness, ms QAP, ms MSMs]); dev: name -> device
+        buffer of the key's points (u1x, v1x, v2x, l1, h1); ValueError when the assignment does not satisfy the circuit"""
+        blob = np.ascontiguousarray(blob, dtype=np.uint64)
+        set_idx = np.ascontiguousarray(set_idx, dtype=np.uint64)
+        set_val = np.ascontiguousarray(set_val, dtype=np.uint64)
+        d1 = np.ascontiguousarray(delta1_words, dtype=np.uint32)
+        rw, sw = fr_words([r]), fr_words([s])
+        a, b, c = np.zeros(16, dtype=np.uint32), np.zeros(32, dtype=np.uint32), np.zeros(16, dtype=np.uint32)
+        n_pub = int(blob[9])
+        pub = np.zeros((n_pub, 4), dtype=np.uint64)
+        ms = (C.c_double * 3)()
+        bad = C.c_int64(-1)
+        rc = self.lib.zp_groth16_prove(self.ctx, blob.ctypes.data, blob.size, _ptr(dev["u1x"]), _ptr(dev["v1x"]), _ptr(dev["v2x"]), _ptr(dev["l1"]), _ptr(dev["h1"]),
+                                       d1.ctypes.data, set_idx.ctypes.data, set_val.ctypes.data, set_idx.size, rw.ctypes.data, sw.ctypes.data, a.ctypes.data,
+                                       b.ctypes.data, c.ctypes.data, pub.ctypes.data, ms, C.byref(bad))
+        if rc == -20:
+            raise ValueError("the assignment does not satisfy the circuit (constraint %d): no proof for a false statement" % bad.value)
+        self._chk(rc)
+        return a, b, c, fr_ints(pub), [float(x) for x in ms]
+
     def fixed_base_mul(self, base_words, scalars, g2=False):
         """zp_fixed_base_mul_bn254(_g2): scalars u64[n][4] / u32[n][8] (standard form) times ONE base point (u32[16] / u32[32], affine) -> points
         u32[n][16] / u32[n][32] in the MSM layout ((0, 0) = infinity)"""

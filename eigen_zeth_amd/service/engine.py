@@ -587,8 +587,11 @@ class Engine:
             aux = int(aggregator_addr or "0")
         except ValueError:
             aux = int(hashlib.sha256((aggregator_addr or "").encode()).hexdigest(), 16)
-        w0, mask = wc.assign(json.loads(final_stark), aux)
-        wf, a_ev, b_ev, c_ev = native.r1cs_eval(wc.blob, w0, mask)       # ValueError: the openings do not hash to the roots -> no witness
+        if self.cfg.native_prover and hasattr(self.be_bn128, "stark_openings"):
+            openings = self.be_bn128.stark_openings()       # the prover's own binary record of what the text carries: no text round trip
+        else:
+            openings = WC.openings_record(json.loads(final_stark), wc.layout)
+        set_idx, set_val = native.wrap_assign(wc.script, openings, aux % bn254.R)
         t_wit = time.perf_counter() - t0
         # fresh blinding per proof (zero knowledge); replays of a request are answered from the batch store (server.py),
         # which keeps the finished proof, so the client still sees one proof per batch
@@ -598,15 +601,14 @@ class Engine:
             det = lambda tag: int(hashlib.sha256(("%s|%s|%s|%s" % (self.cfg.groth16_seed, fs_digest, aggregator_addr or "", tag)).encode()).hexdigest(), 16) % bn254.R or 1
             rnd = (det("r"), det("s"))
         t0 = time.perf_counter()
-        proof, pub = groth16.prove(key, wf, a_ev, b_ev, c_ev, self.be, rnd)
-        self.stage_timings["final/" + batch_id] = {"final_stark(bn128)": t_fs, "wrap-witness": t_wit, "groth16": time.perf_counter() - t0,
+        proof, pub, g16_ms = groth16.prove(key, set_idx, set_val, self.be, rnd)      # ValueError: the openings do not hash to the roots -> no witness
+        self.stage_timings["final/" + batch_id] = {"final_stark(bn128)": t_fs, "wrap-assign": t_wit, "groth16": time.perf_counter() - t0,
+                                                   "groth16/witness": g16_ms[0] / 1e3, "groth16/qap": g16_ms[1] / 1e3, "groth16/msm": g16_ms[2] / 1e3,
                                                    **{"final/" + k: v for k, v in tmf.items()}}
         self.wrap_info = {"constraints": wc.c.n_constraints, "qap_domain_log2": wc.c.logm(), "wires": wc.c.n_wires,
                           "msm_points": {"A (G1)": wc.c.n_wires + 2, "B (G1)": wc.c.n_wires + 2, "B (G2)": wc.c.n_wires + 2, "C: l (G1)": wc.c.n_wires,
                                          "C: h (G1)": (1 << wc.c.logm()) - 1}}
         if self.metrics is not None:
             self.metrics.record_stage("groth16", self.stage_timings["final/" + batch_id]["groth16"])
-        js = groth16.proof_to_json(proof, {"circuit": "final-stark-hashing: %d constraints (2^%d domain), %d wires, key %s (local seeded setup)"
-                                                      % (wc.c.n_constraints, wc.c.logm(), wc.c.n_wires, key.digest[:16]),
-                                            "final_stark_sha256": fs_digest})
+        js = groth16.proof_to_json(proof, {"circuit": groth16.circuit_text(wc, key), "final_stark_sha256": fs_digest})
         return js, json.dumps([str(pub[0])])

@@ -2,9 +2,8 @@
 
 The circuit is service/wrap_circuit.py: an R1CS that verifies all the hashing of the final STARK's verifier at its queries (1.28 M constraints
 at the service's parameters), with ONE public input -- the Poseidon commitment to the roots, indices and leaf elements it vouches for -- so the
-output still satisfies `[U256; 1]` (src/settlement/ethereum/mod.rs:474-481).  What is real: the prover -- witness completion and A w, B w, C w on
-the host (zp_r1cs_eval), the QAP quotient on the GPU (zp_qap_quotient_bn254), five multi-scalar multiplications on the GPU over key points
-resident in HBM (zp_msm_bn254 / _g2) -- and proofs that verify under a pairing check (oracle/groth16_verify.py in tests).  What is NOT available
+output still satisfies `[U256; 1]` (src/settlement/ethereum/mod.rs:474-481).  What is real: the prover -- ONE library call (zp_groth16_prove: witness completion and A w, B w, C w,
+the QAP quotient on the GPU, five multi-scalar multiplications on the GPU over key points resident in HBM, the blinding terms) -- and proofs that verify under a pairing check (oracle/groth16_verify.py in tests).  What is NOT available
 offline: a ceremony.  The key comes from a LOCAL setup with a published seed (toxic waste known -- test keys; its scalars by
 zp_r1cs_key_scalars, its group elements by zp_fixed_base_mul_bn254 / _g2 on the GPU), so a proof made here cannot verify under the key in
 the reference's contracts/EigenZkVM.json.  The JSON emitted follows the grammar eigen-zeth parses (src/settlement/ethereum/mod.rs:445-481).
@@ -83,52 +82,37 @@ class Key:
         return dev
 
 
-def prove(key, witness, a_ev, b_ev, c_ev, be, rand):
-    """witness u64[n_wires][4] (complete), a_ev / b_ev / c_ev u64[2^logm][4] from zp_r1cs_eval; rand = (r, s).
-    Returns ({"pi_a", "pi_b", "pi_c"}, [public inputs as ints])."""
-    pub = native.fr_ints(witness[1:1 + key.n_pub])
-    if hasattr(be, "groth16_prove"):                 # a backend that proves another way (the CPU checker: by the trapdoor)
-        return be.groth16_prove(key, native.fr_ints(witness), rand), pub
-    p = be.p
-    dev = key.load_points(be)
-    n, m = key.n_wires, 1 << key.logm
-    r, s = rand
-    # H = (A B - C) / Z on the GPU, its coefficients stay in HBM and are the scalars of the h MSM
-    d_a, d_b, d_c = p.upload(a_ev.reshape(-1)), p.upload(b_ev.reshape(-1)), p.upload(c_ev.reshape(-1))
-    cw = native.fr_words([QAP_COSET])
-    p._chk(p.lib.zp_qap_quotient_bn254(p.ctx, d_a.ptr, d_b.ptr, d_c.ptr, key.logm, cw.ctypes.data))
-    # the witness as MSM scalars, two extra entries for the blinding terms that ride in the MSMs: [w | 1 | r or s]
-    sc = np.concatenate([witness, native.fr_words([1, r])])
-    d_s = p.upload(sc.reshape(-1))
+def _g1_point(w):
+    x = sum(int(w[k]) << (32 * k) for k in range(8))
+    y = sum(int(w[8 + k]) << (32 * k) for k in range(8))
+    return None if (x == 0 and y == 0) else (x, y)
 
-    def msm(points, count, g2=False):
-        import ctypes as C
-        out = (C.c_uint32 * (32 if g2 else 16))()
-        fn = p.lib.zp_msm_bn254_g2 if g2 else p.lib.zp_msm_bn254
-        p._chk(fn(p.ctx, points[0].ptr, d_s.ptr, count, out))
-        if g2:
-            v = [sum(int(out[8 * c + k]) << (32 * k) for k in range(8)) for c in range(4)]
-            return None if not any(v) else ((v[0], v[1]), (v[2], v[3]))
-        x = sum(int(out[k]) << (32 * k) for k in range(8))
-        y = sum(int(out[8 + k]) << (32 * k) for k in range(8))
-        return None if (x == 0 and y == 0) else (x, y)
-    A1 = msm(dev["u1x"], n + 2)                                          # alpha + sum_j w_j u_j + r delta
-    last = native.fr_words([s])
-    p._chk(p.lib.zp_h2d(p.ctx, d_s.offset(4 * (n + 1)), last.ctypes.data, 32))
-    B1 = msm(dev["v1x"], n + 2)                                          # beta + sum_j w_j v_j + s delta
-    B2 = msm(dev["v2x"], n + 2, g2=True)
-    Cl = msm(dev["l1"], n)                                               # the key's l points of the public wires are infinity
-    import ctypes as C
-    out = (C.c_uint32 * 16)()
-    p._chk(p.lib.zp_msm_bn254(p.ctx, dev["h1"][0].ptr, d_a.ptr, m - 1, out))      # sum_i H_i [tau^i Z(tau) / delta]
-    hx = sum(int(out[k]) << (32 * k) for k in range(8))
-    hy = sum(int(out[8 + k]) << (32 * k) for k in range(8))
-    Ch = None if (hx == 0 and hy == 0) else (hx, hy)
-    tail = be.msm_g1([A1, B1, dev["delta1"]], [s, r, (R - r * s % R) % R])
-    Cp = bn254._pt_add(bn254._Ops1, bn254._pt_add(bn254._Ops1, Cl, Ch), tail)
-    for d in (d_a, d_b, d_c, d_s):
-        d.free()
-    return {"pi_a": A1, "pi_b": B2, "pi_c": Cp}, pub
+
+def _g2_point(w):
+    v = [sum(int(w[8 * c + k]) << (32 * k) for k in range(8)) for c in range(4)]
+    return None if not any(v) else ((v[0], v[1]), (v[2], v[3]))
+
+
+def prove(key, set_idx, set_val, be, rand):
+    """set_idx u64[n], set_val u64[n][4]: the caller-set wires (zp_wrap_assign, or WrapCircuit.assign's witness where its mask is set);
+    rand = (r, s).  Returns ({"pi_a", "pi_b", "pi_c"}, [public inputs as ints], [ms witness, ms QAP, ms MSMs]).  ONE library call on a GPU
+    backend (zp_groth16_prove); ValueError when the assignment does not satisfy the circuit."""
+    if hasattr(be, "groth16_prove"):                 # a backend that proves another way (the CPU checker: by the trapdoor)
+        w = np.zeros((key.n_wires, 4), dtype=np.uint64)
+        mask = np.zeros(key.n_wires, dtype=np.uint8)
+        w[set_idx.astype(np.int64)] = set_val
+        mask[set_idx.astype(np.int64)] = 1
+        wf, _, _, _ = native.r1cs_eval(key.blob, w, mask)
+        return be.groth16_prove(key, native.fr_ints(wf), rand), native.fr_ints(wf[1:1 + key.n_pub]), [0.0, 0.0, 0.0]
+    dev = key.load_points(be)
+    a, b, c, pub, ms = be.p.groth16_prove(key.blob, {k: v[0] for k, v in dev.items() if k != "delta1"}, _g1_words(dev["delta1"]), set_idx, set_val, *rand)
+    return {"pi_a": _g1_point(a), "pi_b": _g2_point(b), "pi_c": _g1_point(c)}, pub, ms
+
+
+def circuit_text(wc, key):
+    """the "circuit" member of a final proof: what was proven, under which key"""
+    return ("final-stark-hashing: %d constraints (2^%d domain), %d wires, key %s (local seeded setup)"
+            % (wc.c.n_constraints, wc.c.logm(), wc.c.n_wires, key.digest[:16]))
 
 
 def proof_to_json(proof, extra=None):

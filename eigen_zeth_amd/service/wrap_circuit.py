@@ -94,10 +94,13 @@ class WrapCircuit:
         self.roots = c.new_wires(T)
         self.aux = c.new_wire()                                     # what else the proof is bound to (the aggregator address of the request)
         data = list(self.roots) + [self.aux]
+        # the assignment script (zp_wrap_assign: op, first wire, count, query, tree, block / level): how assign() below fills the caller-set wires
+        ops = [(0, 0, 1, 1, 0, 0), (0, Z, 1, 0, 0, 0), (1, self.aux, 1, 0, 0, 0)] + [(2, w, 1, 0, t, 0) for t, w in enumerate(self.roots)]
         self.q = []
-        for _ in range(layout.n_queries):
+        for qi in range(layout.n_queries):
             j = c.new_wire()
             bits = c.new_wires(layout.logm)
+            ops += [(3, j, 1, qi, 0, 0), (4, bits[0], len(bits), qi, 0, 0)]
             for b in bits:
                 c.add_constraint({b: 1}, {b: 1}, {b: 1})          # bits
             c.add_constraint({b: (1 << k) % R for k, b in enumerate(bits)}, {0: 1}, {j: 1})
@@ -107,15 +110,17 @@ class WrapCircuit:
                 nb = Layout.blocks(width)
                 elems = [c.new_wires(16) for _ in range(nb)]
                 cap = Z
-                for blk in elems:
+                for b, blk in enumerate(elems):
                     cap = c.add_instance([cap] + blk)             # leaf sponge: capacity chained
                     data += blk
+                    ops.append((5, blk[0], 16, qi, t, b))
                 cur, lv = cap, []
                 a = n_leaves.bit_length() - 1
                 for l, _n in enumerate(Layout.levels(n_leaves)):
                     cb = [bits[4 * l + i] if 4 * l + i < a else None for i in range(4)]      # position bits of this level (None: constant 0)
                     sib, child, onehot = c.new_wires(16), c.new_wires(16), c.new_wires(16)
                     e_lo, e_hi = c.new_wires(4), c.new_wires(4)
+                    ops += [(6, sib[0], 16, qi, t, l), (6, child[0], 16, qi, t, l), (7, onehot[0], 16, qi, t, l), (8, e_lo[0], 4, qi, t, l), (9, e_hi[0], 4, qi, t, l)]
                     sel = lambda bit, want: ({0: 1} if not want else {}) if bit is None else ({bit: 1} if want else {0: 1, bit: R - 1})
                     for v in range(4):
                         c.add_constraint(sel(cb[0], v & 1), sel(cb[1], v >> 1), {e_lo[v]: 1})
@@ -136,6 +141,10 @@ class WrapCircuit:
             level = [c.add_instance([Z] + level[i:i + 16]) for i in range(0, len(level), 16)]
         c.add_constraint({level[0]: 1}, {0: 1}, {1: 1}, defines=1)       # the public input IS that root
         self.blob = c.pack()
+        hdr = [int.from_bytes(b"PZWRAPS1", "little"), len(ops), sum(o[2] for o in ops), layout.n_queries, T, layout.logm]
+        for (_, width, n_leaves) in layout.trees:
+            hdr += [width, n_leaves, len(Layout.levels(n_leaves))]
+        self.script = np.array(hdr + [x for o in ops for x in o], dtype=np.uint64)
 
     # ---- assignment
     def data_values(self, proof, aux=0):
@@ -198,6 +207,30 @@ class WrapCircuit:
         w[ids] = native.fr_words(list(vals.values()))
         mask[ids] = 1
         return w, mask
+
+
+def openings_record(proof, layout):
+    """the binary openings record of a BN128-mode proof OBJECT (what zp_stark_openings hands out after zp_stark_prove_bn128; layout at its
+    definition in csrc/prove.hip) -- for proofs made by the Python orchestration or the CPU checker, which keep no such record"""
+    w4 = lambda v: [(int(v) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    roots = [proof["roots"]["trace"], proof["roots"]["quotient"]] + list(proof["fri"]["roots"])
+    if len(proof["queries"]) != layout.n_queries or len(roots) != len(layout.trees):
+        raise ValueError("final STARK does not have the shape the wrap circuit was built for")
+    rec = [int.from_bytes(b"PZOPEN01", "little"), layout.n_queries, len(layout.trees), layout.logm]
+    for (_, width, n_leaves) in layout.trees:
+        rec += [width, n_leaves, len(Layout.levels(n_leaves))]
+    for r in roots:
+        rec += w4(r[0])
+    for qq in proof["queries"]:
+        rec.append(int(qq["index"]))
+        for (name, width, n_leaves), part in zip(layout.trees, [qq["trace"], qq["quotient"]] + list(qq["fri"])):
+            if len(part["values"]) != width or len(part["path"]) != len(Layout.levels(n_leaves)) or any(len(g) != 16 for g in part["path"]):
+                raise ValueError("opening of %s has the wrong shape" % name)
+            rec += [int(v) for v in part["values"]]
+            for grp in part["path"]:
+                for d in grp:
+                    rec += w4(d)
+    return np.array(rec, dtype=np.uint64)
 
 
 def wrap_circuit(layout):

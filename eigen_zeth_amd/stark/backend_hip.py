@@ -181,6 +181,10 @@ class HipBackend:
             raise
         return d
 
+    def stark_openings(self):
+        """the binary openings of the last BN128-mode proof prove_native made on this backend (zp_stark_openings)"""
+        return self.p.stark_openings()
+
     def prove_native(self, air, trace, pubs, params):
         """the whole chunk STARK through zp_stark_prove (one C-ABI call, orchestration in the library's host C++): proof TEXT,
         byte-identical to proof_to_json(prove(...)) over this backend.  trace: host array or a device buffer from prefetch_trace."""

@@ -368,6 +368,28 @@ int32_t zp_r1cs_eval(const uint64_t *circ, size_t words, uint64_t *witness, uint
 int32_t zp_r1cs_key_scalars(const uint64_t *circ, size_t words, const uint64_t *params, uint64_t *out_u, uint64_t *out_v, uint64_t *out_l, uint64_t *out_h,
                             int32_t threads);
 
+/* ---- the Groth16 wrap behind two calls (GenFinalProof: prover.proto:130-148, src/prover/provider.rs:472-503; the consumer of the result is
+ * src/settlement/ethereum/mod.rs:338-394) ------------------------------------------------------------------------------------------------------
+ * zp_stark_openings: roots, query indices, opened values and 16-ary paths of the LAST zp_stark_prove_bn128 proof of this ctx, in binary (what its
+ *   text carries; layout at the definition, csrc/prove.hip); *out points into the ctx until the next proof on it.
+ * zp_wrap_assign: the caller-set wires of the wrap circuit (service/wrap_circuit.py) from those openings, driven by the assignment script the
+ *   circuit builder writes beside the circuit blob; aux4 = the extra field element the proof is bound to (the aggregator address), standard form.
+ *   out_idx u64[cap], out_val u64[cap][4]; *n_set = wires written.
+ * zp_groth16_prove: witness completion + A w, B w, C w (zp_r1cs_eval), the QAP quotient, five MSMs over the key's device-resident points
+ *   (d_u1x, d_v1x: u32[n_wires + 2][16] = [u_j]_1 | alpha_1 | delta_1, [v_j]_1 | beta_1 | delta_1; d_v2x: u32[n_wires + 2][32] = [v_j]_2 | beta_2 |
+ *   delta_2; d_l1: u32[n_wires][16], infinity at the constant and the public inputs; d_h1: u32[2^logm - 1][16]; h_delta1 u32[16]) and the blinding
+ *   terms for (h_r, h_s).  out_a u32[16], out_b u32[32], out_c u32[16] = pi_a, pi_b, pi_c; out_pub u64[n_pub][4]; h_ms (may be NULL) double[3] =
+ *   milliseconds of witness, QAP, MSMs.  -20 / -21 as zp_r1cs_eval: a false statement has no proof.
+ * zp_sha256: SHA-256 of a byte string (the digests proof texts name; the deterministic blinding of a test run).                                    */
+int32_t zp_stark_openings(zp_ctx *ctx, const uint64_t **out, size_t *words);
+int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64_t *openings, size_t open_words, const uint64_t *aux4, uint64_t *out_idx,
+                       uint64_t *out_val, size_t cap, size_t *n_set);
+int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const uint32_t *d_u1x, const uint32_t *d_v1x, const uint32_t *d_v2x,
+                         const uint32_t *d_l1, const uint32_t *d_h1, const uint32_t *h_delta1, const uint64_t *set_idx, const uint64_t *set_val, size_t n_set,
+                         const uint64_t *h_r, const uint64_t *h_s, uint32_t *out_a, uint32_t *out_b, uint32_t *out_c, uint64_t *out_pub, double *h_ms,
+                         int64_t *bad);
+int32_t zp_sha256(const uint8_t *data, size_t len, uint8_t *out32);
+
 /* ---- multi-GPU: RCCL over xGMI behind the C-ABI (BASELINE.json configs[3]) ---------------------------------
  * One process per GPU; a zp_comm joins this rank's ctx to the RCCL communicator of `world` ranks (a power of two).  Rank 0 makes
  * the 128-byte id (zp_comm_unique_id) and hands it to the others out of band (a file, the service's own channel); every rank

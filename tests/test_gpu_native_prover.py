@@ -203,3 +203,45 @@ def test_compiled_host_answers_gen_aggregated_proof_like_the_service(tmp_path, t
     r = subprocess.run([exe, str(tmp_path / "shape"), "batch-7", str(tmp_path / "p1.json"), str(tmp_path / "p2.json"), str(tmp_path / "agg2.json")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no accepting witness" in r.stderr and not (tmp_path / "agg2.json").exists()
+
+
+def test_compiled_host_answers_gen_final_proof_like_the_service(tmp_path, tables):
+    """host/aggregate final (C++ on include/zeth_prover.h alone: zp_recursion_witness one level up, zp_stark_prove_bn128, zp_stark_openings,
+    zp_wrap_assign, zp_groth16_prove over key files) writes, for a GenFinalProof request (prover.proto:130-148) under the service's
+    deterministic blinding, BYTE FOR BYTE the proof and public input the Python service's engine answers -- and they pass the pairing check and
+    the recomputation of the public input from the final STARK"""
+    import os
+    import subprocess
+    import sys
+    from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
+    from eigen_zeth_amd.service import consumer as CS
+    from eigen_zeth_amd.service.engine import Engine, EngineConfig
+    from eigen_zeth_amd.service.server import default_backend_factory
+    from oracle import wrap_verify as WV
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import export_recursion_shape as EX
+    cfg = EngineConfig(air="chunk64", logn=12, chunks_per_block=1, n_queries=24, pow_bits=8, agg_queries=10, final_queries=6, groth16_seed="host-test")
+    eng = Engine(default_backend_factory(0), cfg)
+    ch = eng.gen_batch_chunks("b", [7, 8], 12345, "evm")
+    proofs = eng.gen_chunk_proofs("b", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+    agg = eng.aggregate("b", proofs[0]["proof"], proofs[1]["proof"])
+    addr = "479881985774944702531460751064278034642760119942"
+    want_js, want_pub = eng.final("b", agg, "BN128", addr)
+    wc, key, fp = EX.export_final(str(tmp_path / "final"), eng, n_proofs=2, logn=12)
+    (tmp_path / "agg.json").write_text(agg)
+    exe = os.path.join(root, "host", "aggregate")
+    args = [exe, "final", str(tmp_path / "final"), str(tmp_path / "agg.json"), addr, "host-test", str(tmp_path / "proof.json"), str(tmp_path / "public.json")]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout.strip())
+    assert (tmp_path / "proof.json").read_text() == want_js and (tmp_path / "public.json").read_text() == want_pub
+    pr = CS.parse_proof(want_js)
+    proof = {"pi_a": tuple(pr.a), "pi_b": (pr.b.x, pr.b.y), "pi_c": tuple(pr.c)}
+    assert WV.verify(key.vk, proof, CS.parse_public_input(want_pub), json.loads(eng.final_starks["b"]), int(addr), bn254_poseidon_params(17))
+    # an aggregated proof tampered with has no witness one level up: the host refuses as the service does
+    bad = json.loads(agg)
+    bad["stark"]["queries"][2]["trace"]["values"][5] ^= 1
+    (tmp_path / "agg.json").write_text(json.dumps(bad, separators=(",", ":")))
+    r = subprocess.run(args[:6] + [str(tmp_path / "proof2.json"), str(tmp_path / "public2.json")], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not (tmp_path / "proof2.json").exists()

@@ -5,6 +5,7 @@ resident in HBM -- the proof must be, byte for byte, the one the checker's trapd
 oracle/wrap_verify.py recomputes from the final STARK.  Then the same through the engine at the service's parameters (a 2^21-domain circuit)."""
 import json
 
+import numpy as np
 import pytest
 
 from eigen_zeth_amd import native
@@ -33,15 +34,24 @@ def test_gpu_groth16_of_the_wrap_circuit_equals_the_trapdoor_proof(tables):
     assert V.verify(proof, air.program(), *tables, V.expectation(params.to_dict()), bn)
     wc = WC.wrap_circuit(WC.Layout.of_air(air, params))
     aux = 12345
-    wf, a, b, c = native.r1cs_eval(wc.blob, *wc.assign(proof, aux))
+    # the caller-set wires from the prover's own binary openings record = what the Python reference assignment reads out of the proof text
+    w0, mask = wc.assign(proof, aux)
+    set_idx, set_val = native.wrap_assign(wc.script, hip.stark_openings(), aux)
+    assert (hip.stark_openings() == WC.openings_record(proof, wc.layout)).all()
+    assert sorted(set_idx.tolist()) == np.flatnonzero(mask).tolist() and (w0[set_idx.astype(np.int64)] == set_val).all()
     key = G16.Key(wc.blob)
     rand = (0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA0987654321)
-    p_gpu, pubs = G16.prove(key, wf, a, b, c, hip, rand)
-    p_cpu, pubs_c = G16.prove(key, wf, a, b, c, cpu, rand)
+    p_gpu, pubs, ms = G16.prove(key, set_idx, set_val, hip, rand)          # ONE library call: zp_groth16_prove
+    p_cpu, pubs_c, _ = G16.prove(key, set_idx, set_val, cpu, rand)
     assert pubs == pubs_c == [WV.public_input(proof, aux, bn)]
     assert p_gpu == p_cpu                                   # QAP transforms + five MSMs on the GPU = three scalar multiplications by the trapdoor
     assert WV.verify(key.vk, p_gpu, pubs, proof, aux, bn)
     assert not GV.verify(key.vk, p_gpu, [(pubs[0] + 1) % G16.R])
+    bad = set_val.copy()
+    bad[int(np.flatnonzero(set_idx == np.uint64(wc.q[1]["trees"][2]["levels"][0]["sib"][5]))[0]), 0] ^= np.uint64(1)      # one digest of one path
+    with pytest.raises(ValueError, match="does not satisfy"):
+        G16.prove(key, set_idx, bad, hip, rand)
+    print("zp_groth16_prove ms (witness, QAP, MSMs):", [round(x, 2) for x in ms])
     print("wrap circuit: %d constraints, domain 2^%d, %d wires" % (wc.c.n_constraints, wc.c.logm(), wc.c.n_wires))
 
 

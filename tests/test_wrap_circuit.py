@@ -135,9 +135,22 @@ def test_wrap_circuit_over_a_bn128_stark(final_like, tables, bn):
     assert [t[0] for t in lay.trees] == ["trace", "quotient", "fri0", "fri1"]
     wc = WC.wrap_circuit(lay)
     aux = 479881985774944702531460751064278034642760119942
-    wf, a, b, c = native.r1cs_eval(wc.blob, *wc.assign(proof, aux))
+    w0, mask = wc.assign(proof, aux)
+    wf, a, b, c = native.r1cs_eval(wc.blob, w0, mask)
     d = native.fr_ints(wf[1:2])[0]
     assert d == WV.public_input(proof, aux, bn) != WV.public_input(proof, aux + 1, bn)
+    # the library's assignment (zp_wrap_assign over the circuit's script and the binary openings) sets the same wires to the same values
+    rec = WC.openings_record(proof, lay)
+    set_idx, set_val = native.wrap_assign(wc.script, rec, aux)
+    assert sorted(set_idx.tolist()) == np.flatnonzero(mask).tolist() and (w0[set_idx.astype(np.int64)] == set_val).all()
+    for cut in (rec[:-1], rec[1:], np.concatenate([rec[:1], rec[1:2] + np.uint64(1), rec[2:]])):
+        with pytest.raises(ValueError):
+            native.wrap_assign(wc.script, cut, aux)
+    with pytest.raises(ValueError):
+        native.wrap_assign(wc.script[:-6], rec, aux)
+    lay2 = WC.Layout.of_air(air, PR.StarkParams(6, 2, 2, 3, 4, pow_bits=0, hash="bn128"))
+    with pytest.raises(ValueError):                                # the script of another layout
+        native.wrap_assign(WC.wrap_circuit(lay2).script, rec, aux)
     # no satisfying witness for a STARK whose openings do not hash to its roots
     for mutate in (lambda p: p["queries"][1]["fri"][0]["path"][0].__setitem__(3, str((int(p["queries"][1]["fri"][0]["path"][0][3]) + 1) % R)),
                    lambda p: p["queries"][0]["trace"]["values"].__setitem__(2, p["queries"][0]["trace"]["values"][2] ^ 1),
@@ -149,7 +162,7 @@ def test_wrap_circuit_over_a_bn128_stark(final_like, tables, bn):
             native.r1cs_eval(wc.blob, *wc.assign(bad, aux))
     # a Groth16 proof of the statement: the product's key (scalars by zp_r1cs_key_scalars), the checker's trapdoor prover, the pairing check
     key = G16.Key(wc.blob)
-    proof_g, pubs = G16.prove(key, wf, a, b, c, cpu, (11, 13))
+    proof_g, pubs, _ = G16.prove(key, set_idx, set_val, cpu, (11, 13))
     assert pubs == [d] and WV.verify(key.vk, proof_g, pubs, proof, aux, bn)
     assert not GV.verify(key.vk, proof_g, [(d + 1) % R])
     with pytest.raises(V.Reject):
