@@ -62,7 +62,7 @@ void zp_destroy(zp_ctx *ctx) {
     for (auto &kv : ctx->prove_pool) (void)hipFree(kv.second);
     for (auto &kv : ctx->prove_fixed) (void)hipFree(kv.second);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->g16_pinned) (void)hipHostFree(ctx->g16_pinned);
+    zpi_g16_cache_free(ctx);
     if (ctx->msm_arena) (void)hipFree(ctx->msm_arena);
     if (ctx->d_rc) (void)hipFree(ctx->d_rc);
     if (ctx->d_mds) (void)hipFree(ctx->d_mds);

@@ -39,6 +39,7 @@ struct CosetTable {  // shift^i * pre, i < 2^logn, two-level
     u64 *d_lo = nullptr, *d_hi = nullptr;
 };
 
+struct ZpG16Cache;
 struct zp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // where every launch of this ctx goes
@@ -62,8 +63,7 @@ struct zp_ctx {
     // pinned host staging for small transfers (pageable async copies lock/unlock host pages on every call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
-    void *g16_pinned = nullptr;        // zp_groth16_prove: page-locked home of A w, B w, C w and the witness (kept between proofs)
-    size_t g16_pinned_bytes = 0;
+    ZpG16Cache *g16_cache = nullptr;   // zp_r1cs_eval_device: the circuit last used, in HBM (csrc/r1cs.hip; freed by zpi_g16_cache_free)
     int num_cu = 256;
     // experiment knobs (zp_set_tuning): not part of the stable surface
     void *msm_arena = nullptr;    // scratch of zp_msm_bn254*: grows to the largest run, freed by zp_destroy
@@ -161,6 +161,9 @@ bool zpi_program_fixed_table(const uint64_t *h_program, size_t program_words, st
 int32_t zpi_pool_alloc(zp_ctx *ctx, size_t bytes, void **out);
 void zpi_pool_release(zp_ctx *ctx, void *p, size_t bytes);
 void zpi_sha256(const uint8_t *data, size_t len, uint8_t *out32);
+void zpi_g16_cache_free(zp_ctx *ctx);
+int32_t zpi_r1cs_poseidon17(zp_ctx *ctx, const u64 *d_inst, size_t i0, size_t count, u64 *d_w, unsigned char *d_set, u64 *d_a, u64 *d_b, u64 *d_c,
+                            unsigned long long *d_flags, int *rp_out);
 struct zp_comm;
 zp_ctx *zpi_comm_ctx(const zp_comm *comm);      // the ctx a communicator was created on (csrc/comm.hip)
 int32_t zpi_comm_fail(zp_comm *comm, int32_t rc);   // rc != ZP_OK: kill the communicator (no peer waits for this rank); returns rc

@@ -335,6 +335,85 @@ __global__ void __launch_bounds__(64) poseidon254_perm_kernel(u64 *states, size_
     }
 }
 
+// R1CS witness of the width-17 gadget (eigen_zeth_amd/service/r1cs.py: poseidon_template; csrc/r1cs.hip: zp_r1cs_eval_device): an instance of the
+// gadget is a permutation whose every S-box leaves three internal wires (x^2, x^4, x^5 of its input x) and three constraint rows
+// (x, x, x^2), (x^2, x^2, x^4), (x^4, x, x^5) -- the S-boxes numbered in the TEXTBOOK order (rounds, then elements) --, and one last wire / row for
+// element 0 of the output (out, 1, out).  So the witness and A w, B w, C w of an instance are the intermediate values of the permutation: 17 lanes
+// per instance walk the textbook schedule (not the sparse form: the template's linear combinations are the textbook's) and write them out.
+// inst: per instance 17 input wires, the first internal wire, the first row.  flags[1] <- the smallest row of an instance that reads an unset wire.
+__global__ void __launch_bounds__(64) r1cs_poseidon17_kernel(const u64 *__restrict__ inst, size_t i0, size_t count, u64 *__restrict__ w, unsigned char *__restrict__ set,
+                                                             u64 *__restrict__ a_ev, u64 *__restrict__ b_ev, u64 *__restrict__ c_ev, unsigned long long *flags, P254Dev d) {
+    constexpr int T = 17, PPW = 3;
+    __shared__ u32 sh[PPW][T][9];
+    const int q = threadIdx.x / T, e = threadIdx.x % T;
+    const size_t local = (size_t)blockIdx.x * PPW + q;
+    const bool on = q < PPW && local < count;
+    const u64 *in = inst + (i0 + (on ? local : 0)) * (T + 2);
+    const u64 base = in[T], row0 = in[T + 1];
+    fr s = fr_zero();
+    if (on) {
+        const u64 wire = in[e];
+        if (!set[wire]) atomicMin(&flags[1], (unsigned long long)row0);
+        u64 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = w[wire * 4 + k];
+        s = fr_to_mont(fr_from_u64(v));
+    }
+    auto put = [](u64 *dst, u64 index, const fr &mont) {
+        u64 v[4];
+        fr_to_u64(fr_from_mont(mont), v);
+#pragma unroll
+        for (int k = 0; k < 4; k++) dst[index * 4 + k] = v[k];
+    };
+    const int rp = d.rp;
+    for (int r = 0; r < 8 + rp; r++) {
+        const bool full = r < 4 || r >= 4 + rp;
+        if (on) {
+            s = fr_add(s, fr_load(d.rc + ((size_t)r * T + e) * 9));
+            if (full || e == 0) {
+                const u64 k = r < 4 ? (u64)r * T + e : !full ? (u64)(4 * T + (r - 4)) : (u64)(4 * T + rp + (r - 4 - rp) * T + e);
+                const fr x = s, x2 = fr_mul(x, x), x4 = fr_mul(x2, x2), x5 = fr_mul(x4, x);
+                put(w, base + 3 * k, x2); put(w, base + 3 * k + 1, x4); put(w, base + 3 * k + 2, x5);
+                set[base + 3 * k] = 1; set[base + 3 * k + 1] = 1; set[base + 3 * k + 2] = 1;
+                const u64 row = row0 + 3 * k;
+                put(a_ev, row, x); put(b_ev, row, x); put(c_ev, row, x2);
+                put(a_ev, row + 1, x2); put(b_ev, row + 1, x2); put(c_ev, row + 1, x4);
+                put(a_ev, row + 2, x4); put(b_ev, row + 2, x); put(c_ev, row + 2, x5);
+                s = x5;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; i++) sh[q][e][i] = s.l[i];
+        }
+        __syncthreads();
+        if (on) {
+            auto lds = [&](int j) {
+                fr v;
+#pragma unroll
+                for (int i = 0; i < 9; i++) v.l[i] = sh[q][j][i];
+                return v;
+            };
+            const u32 *row = d.mds + (size_t)e * T * 9;
+            fr acc = fr_zero();
+            int j = 0;
+            for (; j + 3 <= T; j += 3)
+                acc = fr_add(acc, fr_mul3(fr_load(row + (size_t)j * 9), lds(j), fr_load(row + (size_t)(j + 1) * 9), lds(j + 1), fr_load(row + (size_t)(j + 2) * 9), lds(j + 2)));
+            for (; j < T; j++) acc = fr_add(acc, fr_mul(fr_load(row + (size_t)j * 9), lds(j)));
+            s = acc;
+        }
+        __syncthreads();
+    }
+    if (on && e == 0) {
+        const u64 k = (u64)(8 * T + rp);                  // S-boxes in all
+        put(w, base + 3 * k, s);
+        set[base + 3 * k] = 1;
+        fr one = fr_zero();
+        one.l[0] = 1;
+        put(a_ev, row0 + 3 * k, s); put(c_ev, row0 + 3 * k, s);
+        u64 *b = b_ev + (row0 + 3 * k) * 4;
+        b[0] = 1; b[1] = 0; b[2] = 0; b[3] = 0;
+    }
+}
+
 // The width-17 transcript sponge as ONE launch (17 lanes cooperate on the one state): buf = [17 state elements][nblocks x 16 block
 // elements][(1 + extra) x 16 rate elements out], 4 words each, standard form.  For every block the rate (elements 1..16) is
 // overwritten with the block and the state permuted (no block: one permutation), then `extra` more permutations; the rate after the
@@ -741,3 +820,17 @@ int32_t zp_merkle16_open_batch_bn254(zp_ctx *ctx, const uint64_t *d_tree, size_t
 }
 
 }  // extern "C"
+
+// csrc/r1cs.hip: the instances [i0, i0 + count) of the width-17 gadget (d_inst: the instance table of a circuit blob in HBM); the t = 17 tables
+// must be installed.  Template numbers checked by the caller: 17 inputs, 8 * 17 + rp S-boxes -> 3 (8 * 17 + rp) + 1 internal wires and rows.
+int32_t zpi_r1cs_poseidon17(zp_ctx *ctx, const u64 *d_inst, size_t i0, size_t count, u64 *d_w, unsigned char *d_set, u64 *d_a, u64 *d_b, u64 *d_c,
+                            unsigned long long *d_flags, int *rp_out) {
+    const P254Table *tb = &g_tables[1];
+    ZP_ARG(ctx, tb->t == 17 && tb->d_rc && tb->d_mds, "the width-17 Poseidon-BN254 tables are not installed (zp_set_poseidon_bn254)");
+    if (rp_out) *rp_out = tb->rp;
+    if (count == 0) return ZP_OK;
+    hipLaunchKernelGGL(r1cs_poseidon17_kernel, dim3((unsigned)((count + 2) / 3)), dim3(64), 0, ctx->stream, d_inst, i0, count, d_w, d_set, d_a, d_b, d_c, d_flags,
+                       dev_of(tb));
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}

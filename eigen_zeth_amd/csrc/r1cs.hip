@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "fr254.hpp"
 
 namespace {
 
@@ -439,6 +440,268 @@ void pack_element(const uint64_t *vals, uint64_t width, uint64_t block, int e, u
     if (x < width) w4[3] = (e & 1) ? (vals[x] >> 32) : (vals[x] & 0xFFFFFFFFull);
 }
 
+
+// ---- witness completion and A w, B w, C w ON THE GPU (zp_r1cs_eval_device): the caller-set wires are scattered into the witness in HBM, the
+// instances of the gadget are evaluated wave by wave by the permutation kernel of csrc/poseidon_bn254.hip (an instance's internal wires and
+// rows ARE the intermediate values of its permutation), the explicit constraints by a sparse-row kernel.  Nothing but the few thousand set
+// wires crosses PCIe, and the witness is where the MSMs read their scalars.
+__global__ void __launch_bounds__(256) r1cs_scatter_kernel(const u64 *__restrict__ idx, const u64 *__restrict__ val, size_t n, u64 *__restrict__ w,
+                                                           unsigned char *__restrict__ set) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 j = idx[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[j * 4 + k] = val[i * 4 + k];
+    set[j] = 1;
+}
+struct DevMat { const u64 *ptr, *idx, *val; };
+// sum of one sparse row over the witness, standard form in and out (coefficient to Montgomery form, times the standard-form wire = standard form)
+__device__ fr r1cs_row(const DevMat &m, u64 q, const u64 *w, const unsigned char *set, u64 skip, bool *unset) {
+    fr acc = fr_zero();
+    for (u64 e = m.ptr[q]; e < m.ptr[q + 1]; e++) {
+        const u64 g = m.idx[e];
+        if (g == skip) continue;
+        if (!set[g]) *unset = true;
+        acc = fr_add(acc, fr_mul(fr_to_mont(fr_from_u64(m.val + 4 * e)), fr_from_u64(w + 4 * g)));
+    }
+    return acc;
+}
+__device__ void r1cs_store(u64 *dst, u64 index, const fr &x) {
+    u64 v[4];
+    fr_to_u64(x, v);
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[index * 4 + k] = v[k];
+}
+// the extra constraints that DEFINE a wire nobody set, in order, by one lane (a handful per circuit: the public input of the wrap)
+__global__ void r1cs_define_kernel(DevMat A, DevMat B, DevMat C, const u64 *__restrict__ defs, size_t n_defs, const u64 *__restrict__ edef, u64 row_base, u64 *w,
+                                   unsigned char *set, unsigned long long *flags) {
+    if (blockIdx.x || threadIdx.x) return;
+    for (size_t k = 0; k < n_defs; k++) {
+        const u64 q = defs[k], g = edef[q];
+        if (set[g]) continue;
+        bool unset = false;
+        const fr a = r1cs_row(A, q, w, set, ~0ull, &unset), b = r1cs_row(B, q, w, set, ~0ull, &unset), rest = r1cs_row(C, q, w, set, g, &unset);
+        if (unset) { atomicMin(&flags[1], (unsigned long long)(row_base + q)); continue; }
+        r1cs_store(w, g, fr_sub(fr_mul(fr_to_mont(a), b), rest));
+        set[g] = 1;
+    }
+}
+__global__ void __launch_bounds__(256) r1cs_extras_kernel(DevMat A, DevMat B, DevMat C, size_t n_extra, u64 row_base, const u64 *__restrict__ w,
+                                                          const unsigned char *__restrict__ set, u64 *__restrict__ a_ev, u64 *__restrict__ b_ev,
+                                                          u64 *__restrict__ c_ev, unsigned long long *flags) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_extra) return;
+    bool unset = false;
+    const fr a = r1cs_row(A, q, w, set, ~0ull, &unset), b = r1cs_row(B, q, w, set, ~0ull, &unset), c = r1cs_row(C, q, w, set, ~0ull, &unset);
+    if (unset) { atomicMin(&flags[1], (unsigned long long)(row_base + q)); return; }
+    const fr ab = fr_mul(fr_to_mont(a), b);
+    u32 diff = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) diff |= ab.l[i] ^ c.l[i];
+    if (diff) atomicMin(&flags[0], (unsigned long long)(row_base + q));
+    r1cs_store(a_ev, row_base + q, a); r1cs_store(b_ev, row_base + q, b); r1cs_store(c_ev, row_base + q, c);
+}
+__global__ void __launch_bounds__(256) r1cs_allset_kernel(const unsigned char *__restrict__ set, size_t n, unsigned long long *flags) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < n && !set[j]) atomicMin(&flags[2], (unsigned long long)j);
+}
+
+}  // namespace
+
+// the circuit a ctx evaluated last, kept in HBM (the blob as it came, the list of its defining extra constraints); `checked`: the gadget template
+// of the blob has been compared with the kernel on one instance (zp_r1cs_eval_device)
+struct ZpG16Cache {
+    std::vector<uint64_t> words;
+    u64 *d_blob = nullptr, *d_defs = nullptr;
+    size_t n_defs = 0;
+    bool checked = false;
+};
+void zpi_g16_cache_free(zp_ctx *ctx) {
+    if (!ctx->g16_cache) return;
+    if (ctx->g16_cache->d_blob) (void)hipFree(ctx->g16_cache->d_blob);
+    if (ctx->g16_cache->d_defs) (void)hipFree(ctx->g16_cache->d_defs);
+    delete ctx->g16_cache;
+    ctx->g16_cache = nullptr;
+}
+
+namespace {
+
+// device evaluation of the parsed circuit c (its blob resident at d_blob): d_w u64[>= n_wires][4] and d_set are overwritten; d_a / d_b / d_c
+// u64[2^logm][4].  flags (host, 3 words): first violated row, first row that reads an unset wire, first wire left unset -- ~0 = none.
+int32_t eval_device(zp_ctx *ctx, const Circ &c, const uint64_t *circ, const u64 *d_blob, const u64 *d_defs, size_t n_defs, const u64 *d_idx, const u64 *d_val,
+                    size_t n_set, u64 *d_w, unsigned char *d_set, u64 *d_a, u64 *d_b, u64 *d_c, unsigned long long *d_flags, unsigned long long *h_flags) {
+    const size_t m = (size_t)1 << c.logm;
+    ZP_HIP(ctx, hipMemsetAsync(d_w, 0, c.n_wires * 32, ctx->stream));
+    ZP_HIP(ctx, hipMemsetAsync(d_set, 0, c.n_wires, ctx->stream));
+    ZP_HIP(ctx, hipMemsetAsync(d_a, 0, m * 32, ctx->stream));
+    ZP_HIP(ctx, hipMemsetAsync(d_b, 0, m * 32, ctx->stream));
+    ZP_HIP(ctx, hipMemsetAsync(d_c, 0, m * 32, ctx->stream));
+    ZP_HIP(ctx, hipMemsetAsync(d_flags, 0xFF, 24, ctx->stream));
+    hipLaunchKernelGGL(r1cs_scatter_kernel, dim3((unsigned)((n_set + 255) / 256)), dim3(256), 0, ctx->stream, d_idx, d_val, n_set, d_w, d_set);
+    ZP_HIP(ctx, hipGetLastError());
+    const u64 *d_inst = d_blob + (c.inst - circ);
+    for (uint64_t wv = 0; wv < c.n_waves; wv++)
+        ZP_TRY(zpi_r1cs_poseidon17(ctx, d_inst, c.waves[wv], c.waves[wv + 1] - c.waves[wv], d_w, d_set, d_a, d_b, d_c, d_flags, nullptr));
+    DevMat E[3];
+    for (int k = 0; k < 3; k++) E[k] = DevMat{d_blob + (c.E[k].ptr - circ), d_blob + (c.E[k].idx - circ), d_blob + (c.E[k].val - circ)};
+    if (n_defs) {
+        hipLaunchKernelGGL(r1cs_define_kernel, dim3(1), dim3(64), 0, ctx->stream, E[0], E[1], E[2], d_defs, n_defs, d_blob + (c.edef - circ), (u64)c.extra_base(), d_w,
+                           d_set, d_flags);
+        ZP_HIP(ctx, hipGetLastError());
+    }
+    if (c.n_extra) {
+        hipLaunchKernelGGL(r1cs_extras_kernel, dim3((unsigned)((c.n_extra + 255) / 256)), dim3(256), 0, ctx->stream, E[0], E[1], E[2], (size_t)c.n_extra,
+                           (u64)c.extra_base(), (const u64 *)d_w, (const unsigned char *)d_set, d_a, d_b, d_c, d_flags);
+        ZP_HIP(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(r1cs_allset_kernel, dim3((unsigned)((c.n_wires + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned char *)d_set, (size_t)c.n_wires, d_flags);
+    ZP_HIP(ctx, hipGetLastError());
+    return zpi_d2h_small(ctx, h_flags, d_flags, 24);
+}
+
+// the circuit in HBM (cached per ctx by content) + the one-time comparison of its gadget template with the kernel: ONE instance with arbitrary
+// inputs through the host's generic evaluator (zp_r1cs_eval over the blob's own template matrices) and through the kernel
+int32_t circuit_on_device(zp_ctx *ctx, const Circ &c, const uint64_t *circ, size_t words, ZpG16Cache **out) {
+    ZpG16Cache *g = ctx->g16_cache;
+    if (g && g->words.size() == words && memcmp(g->words.data(), circ, words * 8) == 0 && g->checked) { *out = g; return ZP_OK; }
+    zpi_g16_cache_free(ctx);
+    const uint64_t n_int = c.n_local - 1 - c.t;
+    ZP_ARG(ctx, c.t == 17 && c.tc == n_int && c.tc >= 3 * 8 * 17 + 1 && (c.tc - 1 - 3 * 8 * 17) % 3 == 0,
+           "the circuit's gadget is not the width-17 Poseidon permutation the device evaluator knows");
+    g = new ZpG16Cache();
+    ctx->g16_cache = g;
+    g->words.assign(circ, circ + words);
+    std::vector<u64> defs;
+    for (uint64_t q = 0; q < c.n_extra; q++) if (c.edef[q] != ~0ull) defs.push_back(q);
+    g->n_defs = defs.size();
+    ZP_HIP(ctx, hipMalloc((void **)&g->d_blob, words * 8));
+    ZP_HIP(ctx, hipMemcpyAsync(g->d_blob, circ, words * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (g->n_defs) {
+        ZP_HIP(ctx, hipMalloc((void **)&g->d_defs, g->n_defs * 8));
+        ZP_HIP(ctx, hipMemcpyAsync(g->d_defs, defs.data(), g->n_defs * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // the mini circuit: the blob's template, one instance on wires 2..18 (wire 1: the public input, unused), no extras
+    const size_t tpl_words = (size_t)(c.inst - circ) - 16;
+    std::vector<uint64_t> mini(16, 0);
+    uint64_t lm = 1;
+    while ((1ull << lm) < c.tc + 1) lm++;
+    const uint64_t nw = 2 + 17 + n_int;
+    mini[0] = MAGIC; mini[1] = nw; mini[2] = c.tc; mini[3] = lm; mini[4] = 17; mini[5] = c.n_local; mini[6] = c.tc; mini[7] = 1; mini[8] = 0; mini[9] = 1; mini[10] = 1;
+    mini.insert(mini.end(), circ + 16, circ + 16 + tpl_words);
+    const size_t inst_at = mini.size();
+    for (uint64_t k = 0; k < 17; k++) mini.push_back(2 + k);
+    mini.push_back(19); mini.push_back(0);
+    mini.push_back(0); mini.push_back(1);                  // waves
+    for (int k = 0; k < 3; k++) mini.push_back(0);          // three empty matrices: ptr[1] = {0}
+    Circ mc;
+    if (!parse(mini.data(), mini.size(), &mc)) { ctx->err = "internal: mini circuit"; return ZP_ERR_INTERNAL; }
+    const size_t mm = (size_t)1 << lm;
+    std::vector<uint64_t> w(nw * 4, 0), ha(mm * 4), hb(mm * 4), hc(mm * 4), sidx(19), sval(19 * 4, 0);
+    std::vector<uint8_t> set(nw, 0);
+    w[0] = 1; set[0] = set[1] = 1;
+    sidx[0] = 0; sval[0] = 1; sidx[1] = 1;
+    for (uint64_t k = 0; k < 17; k++) {
+        uint64_t *v = &w[(2 + k) * 4];
+        for (int i = 0; i < 4; i++) v[i] = 0x9E3779B97F4A7C15ull * (k * 4 + i + 1) ^ (0xD1B54A32D192ED03ull >> (k + i));
+        v[3] &= 0x0FFFFFFFFFFFFFFFull;                      // < r
+        set[2 + k] = 1;
+        sidx[2 + k] = 2 + k;
+        memcpy(&sval[(2 + k) * 4], v, 32);
+    }
+    int64_t bad = -1;
+    if (zp_r1cs_eval(mini.data(), mini.size(), w.data(), set.data(), ha.data(), hb.data(), hc.data(), &bad) != ZP_OK) {
+        ctx->err = "the circuit's gadget template is not evaluable";
+        return ZP_ERR_ARG;
+    }
+    void *d = nullptr;
+    const size_t bytes = mini.size() * 8 + 19 * 40 + nw * 33 + 3 * mm * 32 + 64;
+    ZP_TRY(zpi_pool_alloc(ctx, bytes + 64, &d));
+    u64 *d_mini = (u64 *)d, *d_idx = d_mini + mini.size(), *d_val = d_idx + 19, *d_w = d_val + 19 * 4, *d_a = d_w + nw * 4, *d_b = d_a + mm * 4, *d_c = d_b + mm * 4;
+    unsigned long long *d_flags = (unsigned long long *)(d_c + mm * 4);
+    unsigned char *d_set = (unsigned char *)(d_flags + 4);
+    unsigned long long hf[3];
+    int32_t rc = ZP_OK;
+    std::vector<uint64_t> ga(mm * 4), gb(mm * 4), gc(mm * 4), gw(nw * 4);
+    if (hipMemcpyAsync(d_mini, mini.data(), mini.size() * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_idx, sidx.data(), 19 * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_val, sval.data(), 19 * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = ZP_ERR_HIP;
+    if (rc == ZP_OK) rc = eval_device(ctx, mc, mini.data(), d_mini, nullptr, 0, d_idx, d_val, 19, d_w, d_set, d_a, d_b, d_c, d_flags, hf);
+    if (rc == ZP_OK && (hipMemcpyAsync(ga.data(), d_a, mm * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                        hipMemcpyAsync(gb.data(), d_b, mm * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                        hipMemcpyAsync(gc.data(), d_c, mm * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                        hipMemcpyAsync(gw.data(), d_w, nw * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = ZP_ERR_HIP;
+    zpi_pool_release(ctx, d, bytes + 64);
+    (void)inst_at;
+    if (rc != ZP_OK) return rc;
+    if (hf[0] != ~0ull || hf[1] != ~0ull || hf[2] != ~0ull || ga != ha || gb != hb || gc != hc || gw != w) {
+        ctx->err = "the circuit's gadget template is not the width-17 Poseidon permutation of the installed tables (device evaluator refuses it)";
+        return ZP_ERR_ARG;
+    }
+    g->checked = true;
+    *out = g;
+    return ZP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// zp_r1cs_eval on the GPU: the n_set caller-set wires in (host), the complete witness d_w u64[n_wires][4] and A w, B w, C w (d_a, d_b, d_c
+// u64[2^logm][4]) out in HBM, the public inputs to the host.  Same results, same refusals (-20 / -21, *bad) as zp_r1cs_eval.  The gadget of the
+// circuit must be the width-17 Poseidon permutation of the installed tables (compared with the kernel once per circuit and ctx).
+int32_t zp_r1cs_eval_device(zp_ctx *ctx, const uint64_t *circ, size_t words, const uint64_t *set_idx, const uint64_t *set_val, size_t n_set, uint64_t *d_w,
+                            uint64_t *d_a, uint64_t *d_b, uint64_t *d_c, uint64_t *out_pub, int64_t *bad) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_BIND(ctx);
+    Circ c;
+    ZP_ARG(ctx, parse(circ, words, &c), "malformed circuit blob");
+    ZP_ARG(ctx, set_idx && set_val && d_w && d_a && d_b && d_c && out_pub && n_set >= 1 && n_set <= c.n_wires, "bad argument");
+    if (bad) *bad = -1;
+    bool one = false;
+    for (size_t k = 0; k < n_set; k++) {
+        ZP_ARG(ctx, set_idx[k] < c.n_wires && std_canonical(set_val + 4 * k), "a set wire is outside the circuit or its value is not below the modulus");
+        if (set_idx[k] == 0) one = set_val[4 * k] == 1 && !(set_val[4 * k + 1] | set_val[4 * k + 2] | set_val[4 * k + 3]);
+    }
+    ZP_ARG(ctx, one, "wire 0 must be set to 1");
+    ZpG16Cache *g = nullptr;
+    ZP_TRY(circuit_on_device(ctx, c, circ, words, &g));
+    void *d = nullptr;
+    const size_t bytes = n_set * 40 + c.n_wires + 64;
+    ZP_TRY(zpi_pool_alloc(ctx, bytes, &d));
+    u64 *d_idx = (u64 *)d, *d_val = d_idx + n_set;
+    unsigned long long *d_flags = (unsigned long long *)(d_val + 4 * n_set);
+    unsigned char *d_set = (unsigned char *)(d_flags + 4);
+    unsigned long long hf[3] = {~0ull, ~0ull, ~0ull};
+    int32_t rc = ZP_OK;
+    if (hipMemcpyAsync(d_idx, set_idx, n_set * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_val, set_val, n_set * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        ctx->err = "upload of the set wires failed";
+        rc = ZP_ERR_HIP;
+    }
+    if (rc == ZP_OK) rc = eval_device(ctx, c, circ, g->d_blob, g->d_defs, g->n_defs, d_idx, d_val, n_set, (u64 *)d_w, d_set, (u64 *)d_a, (u64 *)d_b, (u64 *)d_c, d_flags, hf);
+    if (rc == ZP_OK) rc = zpi_d2h_small(ctx, out_pub, (u64 *)d_w + 4, c.n_pub * 32);
+    zpi_pool_release(ctx, d, bytes);
+    if (rc != ZP_OK) return rc;
+    if (hf[1] != ~0ull || hf[2] != ~0ull) {
+        if (bad) *bad = (int64_t)(hf[1] != ~0ull ? hf[1] : hf[2]);
+        ctx->err = "a wire of the circuit has no value";
+        return -21;
+    }
+    if (hf[0] != ~0ull) {
+        if (bad) *bad = (int64_t)hf[0];
+        ctx->err = "the assignment does not satisfy the circuit: no proof for a false statement";
+        return -20;
+    }
+    return ZP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
 }  // namespace
 
 extern "C" {
@@ -526,32 +789,6 @@ int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const 
     const size_t abc_bytes = 3 * m * 32, sc_bytes = (n + 2) * 32, tail_bytes = 5 * (64 + 32);
     int32_t rc = ZP_OK;
     try {
-        // the three evaluation vectors go straight into page-locked memory: 3 x 2^logm x 32 bytes are uploaded in one piece
-        if (ctx->g16_pinned_bytes < abc_bytes + sc_bytes) {         // its own buffer: the ctx's staging buffer carries the small copies of the calls below
-            if (ctx->g16_pinned) { ZP_HIP(ctx, hipStreamSynchronize(ctx->stream)); ZP_HIP(ctx, hipHostFree(ctx->g16_pinned)); }
-            ctx->g16_pinned = nullptr;
-            ctx->g16_pinned_bytes = 0;
-            ZP_HIP(ctx, hipHostMalloc(&ctx->g16_pinned, abc_bytes + sc_bytes, hipHostMallocPortable));
-            ctx->g16_pinned_bytes = abc_bytes + sc_bytes;
-        }
-        void *pin = ctx->g16_pinned;
-        uint64_t *a_ev = (uint64_t *)pin, *b_ev = a_ev + 4 * m, *c_ev = b_ev + 4 * m, *w = c_ev + 4 * m;
-        std::vector<uint8_t> set(n, 0);
-        memset(w, 0, n * 32);
-        for (size_t k = 0; k < n_set; k++) {
-            ZP_ARG(ctx, set_idx[k] < n, "a set wire is outside the circuit");
-            memcpy(w + 4 * set_idx[k], set_val + 4 * k, 32);
-            set[set_idx[k]] = 1;
-        }
-        rc = zp_r1cs_eval(circ, words, w, set.data(), a_ev, b_ev, c_ev, bad);
-        if (rc == -20) ctx->err = "the assignment does not satisfy the circuit: no proof for a false statement";
-        if (rc == -21) ctx->err = "a wire of the circuit has no value";
-        if (rc != ZP_OK) return rc;
-        memcpy(out_pub, w + 4, c.n_pub * 32);
-        const uint64_t one[4] = {1, 0, 0, 0};
-        memcpy(w + 4 * n, one, 32);
-        memcpy(w + 4 * (n + 1), h_r, 32);
-        const auto t1 = now();
         ZP_TRY(zpi_pool_alloc(ctx, abc_bytes, &d_abc));
         rc = zpi_pool_alloc(ctx, sc_bytes, &d_sc);
         if (rc == ZP_OK) rc = zpi_pool_alloc(ctx, tail_bytes, &d_tail);
@@ -563,11 +800,11 @@ int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const 
         };
         if (rc != ZP_OK) return done(rc);
         uint64_t *da = (uint64_t *)d_abc, *db = da + 4 * m, *dc = db + 4 * m;
-        if (hipMemcpyAsync(d_abc, a_ev, abc_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(d_sc, w, sc_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-            ctx->err = "upload of the evaluation vectors failed";
-            return done(ZP_ERR_HIP);
-        }
+        // the witness is completed where the MSMs read it: [w | 1 | r or s] (two extra scalars for the blinding terms that ride in the MSMs)
+        if ((rc = zp_r1cs_eval_device(ctx, circ, words, set_idx, set_val, n_set, (uint64_t *)d_sc, da, db, dc, out_pub, bad)) != ZP_OK) return done(rc);
+        uint64_t ext[8] = {1, 0, 0, 0, h_r[0], h_r[1], h_r[2], h_r[3]};
+        if ((rc = zpi_h2d_small(ctx, (uint64_t *)d_sc + 4 * n, ext, 64)) != ZP_OK) return done(rc);
+        const auto t1 = now();
         // H = (A B - C) / Z: its coefficients replace A's evaluations and are the scalars of the h MSM
         const uint64_t coset[4] = {7, 0, 0, 0};
         if ((rc = zp_qap_quotient_bn254(ctx, da, db, dc, (int32_t)c.logm, coset)) != ZP_OK) return done(rc);

@@ -115,6 +115,7 @@ SIGNATURES = {
     "zp_wrap_assign": (C.c_int32, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t, _vp]),
     "zp_groth16_prove": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zp_sha256": (C.c_int32, [_vp, C.c_size_t, _vp]),
+    "zp_r1cs_eval_device": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zp_program_digest": (C.c_int32, [_vp, C.c_size_t, _vp, _vp]),
     "zp_recursion_witness": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int32]),
     "zp_recursion_publics_words": (C.c_size_t, [_vp, C.c_size_t]),
@@ -903,6 +904,26 @@ class Prover:
         ptr, n = C.c_void_p(), C.c_size_t(0)
         self._chk(self.lib.zp_stark_openings(self.ctx, C.byref(ptr), C.byref(n)))
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(n.value,)).copy()
+
+    def r1cs_eval_device(self, blob, set_idx, set_val):
+        """zp_r1cs_eval_device -> (witness, a_ev, b_ev, c_ev downloaded, public inputs): the GPU's witness completion, for comparison with r1cs_eval"""
+        blob = np.ascontiguousarray(blob, dtype=np.uint64)
+        set_idx = np.ascontiguousarray(set_idx, dtype=np.uint64)
+        set_val = np.ascontiguousarray(set_val, dtype=np.uint64)
+        n, m, n_pub = int(blob[1]), 1 << int(blob[3]), int(blob[9])
+        dw, da, db, dc = self.alloc(4 * n), self.alloc(4 * m), self.alloc(4 * m), self.alloc(4 * m)
+        pub = np.zeros((n_pub, 4), dtype=np.uint64)
+        bad = C.c_int64(-1)
+        try:
+            rc = self.lib.zp_r1cs_eval_device(self.ctx, blob.ctypes.data, blob.size, set_idx.ctypes.data, set_val.ctypes.data, set_idx.size, dw.ptr, da.ptr, db.ptr,
+                                              dc.ptr, pub.ctypes.data, C.byref(bad))
+            if rc == -20:
+                raise ValueError("the assignment does not satisfy the circuit (constraint %d): no proof for a false statement" % bad.value)
+            self._chk(rc)
+            return self.download(dw, (n, 4)), self.download(da, (m, 4)), self.download(db, (m, 4)), self.download(dc, (m, 4)), fr_ints(pub)
+        finally:
+            for d in (dw, da, db, dc):
+                d.free()
 
     def groth16_prove(self, blob, dev, delta1_words, set_idx, set_val, r, s):
         """zp_groth16_prove -> (pi_a u32[16], pi_b u32[32], pi_c u32[16], public inputs [int], [ms witness, ms QAP, ms MSMs]); dev: name -> device

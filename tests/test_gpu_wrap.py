@@ -39,6 +39,18 @@ def test_gpu_groth16_of_the_wrap_circuit_equals_the_trapdoor_proof(tables):
     set_idx, set_val = native.wrap_assign(wc.script, hip.stark_openings(), aux)
     assert (hip.stark_openings() == WC.openings_record(proof, wc.layout)).all()
     assert sorted(set_idx.tolist()) == np.flatnonzero(mask).tolist() and (w0[set_idx.astype(np.int64)] == set_val).all()
+    # witness completion and A w, B w, C w on the GPU (zp_r1cs_eval_device: the gadget instances by the permutation kernel, the glue by a sparse-row
+    # kernel) = the host's generic evaluation of the same blob (zp_r1cs_eval), word for word
+    wf, a, b, c = native.r1cs_eval(wc.blob, w0, mask)
+    gw, ga, gb, gc, gpub = hip.p.r1cs_eval_device(wc.blob, set_idx, set_val)
+    assert (gw == wf).all() and (ga == a).all() and (gb == b).all() and (gc == c).all() and gpub == native.fr_ints(wf[1:2])
+    with pytest.raises(native.ZpError):                                    # a wire nobody set
+        hip.p.r1cs_eval_device(wc.blob, set_idx[:-1], set_val[:-1])
+    other = wc.blob.copy()
+    at = 16 + int(other[6]) + (int(other[6]) + 1) + int(other[16 + int(other[6]) + int(other[6])])      # first coefficient of the template's A matrix
+    other[at] ^= np.uint64(2)
+    with pytest.raises(native.ZpError, match="gadget"):                   # another gadget than the kernel's: refused, not mis-evaluated
+        hip.p.r1cs_eval_device(other, set_idx, set_val)
     key = G16.Key(wc.blob)
     rand = (0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA0987654321)
     p_gpu, pubs, ms = G16.prove(key, set_idx, set_val, hip, rand)          # ONE library call: zp_groth16_prove
