@@ -851,12 +851,54 @@ struct HeavyLists {
     uint2 *chunks;   // (bucket id, chunk number)
     uint4 *heavy;    // (bucket id, first chunk slot, number of chunks, 0)
 };
+// Lanes of a wave sum buckets of EQUAL size: a wave runs as long as its largest bucket, and with ~4-64 points per bucket (Poisson) the largest
+// of 64 is 1.3-1.6 times the mean -- that much of the bucket kernel was lanes waiting.  The (window, bucket) ids are therefore counting-sorted by
+// their point count, largest first (bin MSM_HEAVY + 1: the heavy buckets, which only append to the heavy lists), and lane i takes order[i].
+//   msm_order_hist : histogram of min(count, MSM_HEAVY + 1) over all buckets (LDS, then one global atomic per bin and block)
+//   msm_order_scan : exclusive scan from the largest bin down (one block)
+//   msm_order_fill : rank inside the block (LDS), one reservation per bin and block, order[pos] = id
+#define MSM_OBINS (MSM_HEAVY + 2)
+__global__ void __launch_bounds__(256) msm_order_hist_kernel(const u32 *counts, u64 nb, u32 *hist) {
+    __shared__ u32 h[MSM_OBINS];
+    for (int i = threadIdx.x; i < MSM_OBINS; i += 256) h[i] = 0;
+    __syncthreads();
+    for (u64 id = (u64)blockIdx.x * 256 + threadIdx.x; id < nb; id += (u64)gridDim.x * 256) {
+        const u32 cnt = counts[id];
+        atomicAdd(&h[cnt > MSM_HEAVY ? MSM_HEAVY + 1 : cnt], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MSM_OBINS; i += 256)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+__global__ void __launch_bounds__(64) msm_order_scan_kernel(const u32 *hist, u32 *cursor) {
+    if (threadIdx.x) return;
+    u32 run = 0;
+    for (int b = MSM_OBINS - 1; b >= 0; b--) { cursor[b] = run; run += hist[b]; }
+}
+__global__ void __launch_bounds__(256) msm_order_fill_kernel(const u32 *counts, u64 nb, u32 *cursor, u32 *order) {
+    __shared__ u32 h[MSM_OBINS], base[MSM_OBINS];
+    const u64 id = (u64)blockIdx.x * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < MSM_OBINS; i += 256) h[i] = 0;
+    __syncthreads();
+    u32 bin = 0, rank = 0;
+    if (id < nb) {
+        const u32 cnt = counts[id];
+        bin = cnt > MSM_HEAVY ? MSM_HEAVY + 1 : cnt;
+        rank = atomicAdd(&h[bin], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MSM_OBINS; i += 256)
+        if (h[i]) base[i] = atomicAdd(&cursor[i], h[i]);
+    __syncthreads();
+    if (id < nb) order[base[bin] + rank] = (u32)id;
+}
 template <class F>
 __global__ void __launch_bounds__(256) msm_bucket_kernel(const uint4 *mont, u64 n, int c, int nwin, const u32 *starts,
-                                                        const u32 *counts, const u32 *sorted, jacT<F> *buckets, HeavyLists hl) {
+                                                        const u32 *counts, const u32 *sorted, const u32 *order, jacT<F> *buckets, HeavyLists hl) {
     constexpr int NV = FT<F>::WORDS / 2;
-    const u64 id = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (id >= ((u64)nwin << c)) return;
+    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= ((u64)nwin << c)) return;
+    const u64 id = order[gid];
     const u64 w = id >> c;
     const u32 st = starts[id], cnt = counts[id];
     if (cnt > MSM_HEAVY) {
@@ -1045,7 +1087,7 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     const u64 max_slices = (u64)nwin * n / MSM_FSLICE + ncoarse + 1;
     const u64 max_heavy = (u64)nwin * n / MSM_HEAVY + 1, max_chunks = (u64)nwin * n / MSM_HCHUNK + max_heavy + 1;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t sz_counts = al((nb * 3 + ncoarse * 3 + 8 + max_slices * 2) * 4), sz_sorted = al((u64)nwin * n * 4 * 3),
+    const size_t sz_counts = al((nb * 4 + 2 * MSM_OBINS + ncoarse * 3 + 8 + max_slices * 2) * 4), sz_sorted = al((u64)nwin * n * 4 * 3),
                  sz_mont = al((u64)n * NV * 16), sz_buckets = al((nb + nwin * nseg + nwin) * sizeof(J)),
                  sz_hl = al(16 + max_chunks * sizeof(uint2) + max_heavy * sizeof(uint4)), sz_partial = al(max_chunks * sizeof(J));
     char *arena = nullptr;
@@ -1058,7 +1100,8 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     J *d_partial = (J *)(arena + sz_counts + sz_sorted + sz_mont + sz_buckets + sz_hl);
     d_starts = d_counts + nb;
     u32 *d_fcursor = d_starts + nb;
-    u32 *d_ccounts = d_fcursor + nb, *d_cstarts = d_ccounts + ncoarse, *d_ccursor = d_cstarts + ncoarse;
+    u32 *d_order = d_fcursor + nb, *d_ohist = d_order + nb;     // bucket ids sorted by size | MSM_OBINS histogram bins, then as many cursors
+    u32 *d_ccounts = d_ohist + 2 * MSM_OBINS, *d_cstarts = d_ccounts + ncoarse, *d_ccursor = d_cstarts + ncoarse;
     u32 *d_slice_count = d_ccursor + ncoarse;
     uint2 *d_slices = (uint2 *)(((uintptr_t)(d_slice_count + 4) + 7) & ~(uintptr_t)7);
     u32 *d_pidx = d_sorted + (u64)nwin * n, *d_pfine = d_pidx + (u64)nwin * n;
@@ -1090,13 +1133,19 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     if (he == hipSuccess && nslices)
         hipLaunchKernelGGL(msm_fine_scatter_kernel, dim3(nslices), dim3(256), 0, ctx->stream, d_pidx, d_pfine, (u64)n, g, d_slices,
                            d_cstarts, d_ccounts, d_fcursor, d_sorted);
+    if (he == hipSuccess) he = hipMemsetAsync(d_ohist, 0, 2 * MSM_OBINS * 4, ctx->stream);
+    if (he == hipSuccess) {
+        hipLaunchKernelGGL(msm_order_hist_kernel, dim3(256), dim3(256), 0, ctx->stream, (const u32 *)d_counts, nb, d_ohist);
+        hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, (const u32 *)d_ohist, d_ohist + MSM_OBINS);
+        hipLaunchKernelGGL(msm_order_fill_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)d_counts, nb, d_ohist + MSM_OBINS, d_order);
+    }
     HeavyLists hl;
     hl.counters = d_hl;
     hl.heavy = (uint4 *)(d_hl + 4);
     hl.chunks = (uint2 *)(hl.heavy + max_heavy);
     ZP_HIP(ctx, hipMemsetAsync(d_hl, 0, 16, ctx->stream));
     hipLaunchKernelGGL(msm_bucket_kernel<F>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const uint4 *)d_mont, (u64)n, c, nwin, d_starts, d_counts, d_sorted, d_buckets, hl);
+                       (const uint4 *)d_mont, (u64)n, c, nwin, d_starts, d_counts, d_sorted, (const u32 *)d_order, d_buckets, hl);
     u32 hcnt[2] = {0, 0};
     if (he == hipSuccess) he = hipMemcpyAsync(hcnt, d_hl, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);

@@ -454,6 +454,14 @@ __global__ void __launch_bounds__(256) r1cs_scatter_kernel(const u64 *__restrict
     for (int k = 0; k < 4; k++) w[j * 4 + k] = val[i * 4 + k];
     set[j] = 1;
 }
+// out[k] = w[wires[k]]: the scalars of an MSM over the key points of a SUBSET of the wires (those with a non-zero column in B)
+__global__ void __launch_bounds__(256) r1cs_gather_kernel(const u64 *__restrict__ w, const u32 *__restrict__ wires, size_t n, u64 *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 j = wires[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[i * 4 + k] = w[j * 4 + k];
+}
 struct DevMat { const u64 *ptr, *idx, *val; };
 // sum of one sparse row over the witness, standard form in and out (coefficient to Montgomery form, times the standard-form wire = standard form)
 __device__ fr r1cs_row(const DevMat &m, u64 q, const u64 *w, const unsigned char *set, u64 skip, bool *unset) {
@@ -763,22 +771,23 @@ int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64
     return ZP_OK;
 }
 
-// One Groth16 proof.  circ: the circuit blob; d_u1x, d_v1x (G1, u32[n_wires + 2][16]): [u_j]_1 | alpha_1 | delta_1 and [v_j]_1 | beta_1 | delta_1;
-// d_v2x (G2, u32[n_wires + 2][32]): [v_j]_2 | beta_2 | delta_2; d_l1 (G1, u32[n_wires][16], infinity at wire 0 and the public inputs: those are
+// One Groth16 proof.  circ: the circuit blob; d_u1x (G1, u32[n_wires + 2][16]): [u_j]_1 | alpha_1 | delta_1; d_v_wires u32[n_v]: the wires with a
+// non-zero column in B, ascending (a third of the gadget's wires never stand in B: their key points would be infinity); d_v1x (G1, u32[n_v + 2][16]):
+// [v_j]_1 of those wires | beta_1 | delta_1; d_v2x (G2, u32[n_v + 2][32]): [v_j]_2 of those wires | beta_2 | delta_2; d_l1 (G1, u32[n_wires][16], infinity at wire 0 and the public inputs: those are
 // the verifier's); d_h1 (G1, u32[2^logm - 1][16]) -- device-resident key points in the MSM layout; h_delta1 u32[16].
 // set_idx / set_val: the n_set caller-set wires (zp_wrap_assign; wire 0 = 1 among them).  h_r, h_s: the blinding scalars (4 words each, standard
 // form).  out_a u32[16], out_b u32[32], out_c u32[16]: pi_a, pi_b, pi_c (affine, standard form); out_pub u64[n_pub][4]: the public inputs the proof
-// is for; h_ms (may be NULL) double[3]: milliseconds of witness completion, QAP step, MSMs.  -20 / -21 as zp_r1cs_eval (*bad): no proof for a
+// is for; h_ms (may be NULL) double[8]: milliseconds of witness completion, QAP step, all MSMs, then the MSMs one by one (A, B in G1, B in G2, l, h).  -20 / -21 as zp_r1cs_eval (*bad): no proof for a
 // false statement.
-int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const uint32_t *d_u1x, const uint32_t *d_v1x, const uint32_t *d_v2x,
-                         const uint32_t *d_l1, const uint32_t *d_h1, const uint32_t *h_delta1, const uint64_t *set_idx, const uint64_t *set_val, size_t n_set,
+int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const uint32_t *d_u1x, const uint32_t *d_v_wires, size_t n_v, const uint32_t *d_v1x,
+                         const uint32_t *d_v2x, const uint32_t *d_l1, const uint32_t *d_h1, const uint32_t *h_delta1, const uint64_t *set_idx, const uint64_t *set_val, size_t n_set,
                          const uint64_t *h_r, const uint64_t *h_s, uint32_t *out_a, uint32_t *out_b, uint32_t *out_c, uint64_t *out_pub, double *h_ms,
                          int64_t *bad) {
     if (!ctx) return ZP_ERR_ARG;
     ZP_BIND(ctx);
     Circ c;
     ZP_ARG(ctx, parse(circ, words, &c), "malformed circuit blob");
-    ZP_ARG(ctx, d_u1x && d_v1x && d_v2x && d_l1 && d_h1 && h_delta1 && set_idx && set_val && h_r && h_s && out_a && out_b && out_c && out_pub, "null argument");
+    ZP_ARG(ctx, d_u1x && d_v_wires && n_v >= 1 && n_v <= c.n_wires && d_v1x && d_v2x && d_l1 && d_h1 && h_delta1 && set_idx && set_val && h_r && h_s && out_a && out_b && out_c && out_pub, "null argument");
     ZP_ARG(ctx, std_canonical(h_r) && std_canonical(h_s), "blinding scalars must be below the group order");
     if (bad) *bad = -1;
     const size_t n = c.n_wires, m = (size_t)1 << c.logm;
@@ -786,7 +795,7 @@ int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const 
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = now();
     void *d_abc = nullptr, *d_sc = nullptr, *d_tail = nullptr;
-    const size_t abc_bytes = 3 * m * 32, sc_bytes = (n + 2) * 32, tail_bytes = 5 * (64 + 32);
+    const size_t abc_bytes = 3 * m * 32, sc_bytes = (n + 2 + n_v + 2) * 32, tail_bytes = 5 * (64 + 32);
     int32_t rc = ZP_OK;
     try {
         ZP_TRY(zpi_pool_alloc(ctx, abc_bytes, &d_abc));
@@ -804,6 +813,10 @@ int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const 
         if ((rc = zp_r1cs_eval_device(ctx, circ, words, set_idx, set_val, n_set, (uint64_t *)d_sc, da, db, dc, out_pub, bad)) != ZP_OK) return done(rc);
         uint64_t ext[8] = {1, 0, 0, 0, h_r[0], h_r[1], h_r[2], h_r[3]};
         if ((rc = zpi_h2d_small(ctx, (uint64_t *)d_sc + 4 * n, ext, 64)) != ZP_OK) return done(rc);
+        uint64_t *d_scv = (uint64_t *)d_sc + 4 * (n + 2);                          // [w_j of the wires in B | 1 | s]
+        hipLaunchKernelGGL(r1cs_gather_kernel, dim3((unsigned)((n_v + 255) / 256)), dim3(256), 0, ctx->stream, (const u64 *)d_sc, d_v_wires, n_v, (u64 *)d_scv);
+        memcpy(ext + 4, h_s, 32);
+        if ((rc = zpi_h2d_small(ctx, d_scv + 4 * n_v, ext, 64)) != ZP_OK) return done(rc);
         const auto t1 = now();
         // H = (A B - C) / Z: its coefficients replace A's evaluations and are the scalars of the h MSM
         const uint64_t coset[4] = {7, 0, 0, 0};
@@ -813,11 +826,15 @@ int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const 
         uint32_t A1[16], B1[16], Cl[16], Ch[16];
         const uint32_t *sc = (const uint32_t *)d_sc;
         if ((rc = zp_msm_bn254(ctx, d_u1x, sc, n + 2, A1)) != ZP_OK) return done(rc);            // alpha + sum_j w_j u_j + r delta
-        if ((rc = zpi_h2d_small(ctx, (uint64_t *)d_sc + 4 * (n + 1), h_s, 32)) != ZP_OK) return done(rc);
-        if ((rc = zp_msm_bn254(ctx, d_v1x, sc, n + 2, B1)) != ZP_OK) return done(rc);            // beta + sum_j w_j v_j + s delta
-        if ((rc = zp_msm_bn254_g2(ctx, d_v2x, sc, n + 2, out_b)) != ZP_OK) return done(rc);
+        const auto t3 = now();
+        if ((rc = zp_msm_bn254(ctx, d_v1x, (const uint32_t *)d_scv, n_v + 2, B1)) != ZP_OK) return done(rc);   // beta + sum_j w_j v_j + s delta
+        const auto t4 = now();
+        if ((rc = zp_msm_bn254_g2(ctx, d_v2x, (const uint32_t *)d_scv, n_v + 2, out_b)) != ZP_OK) return done(rc);
+        const auto t5 = now();
         if ((rc = zp_msm_bn254(ctx, d_l1, sc, n, Cl)) != ZP_OK) return done(rc);
+        const auto t6 = now();
         if ((rc = zp_msm_bn254(ctx, d_h1, (const uint32_t *)da, m - 1, Ch)) != ZP_OK) return done(rc);     // sum_i H_i [tau^i Z(tau) / delta]
+        const auto t7 = now();
         // pi_c = Cl + Ch + s A + r B1 - r s delta: one more (five-point) MSM
         const Fr fr_r = fr_from_std(h_r), fr_s = fr_from_std(h_s);
         const Fr zero = {{0, 0, 0, 0}};
@@ -831,7 +848,10 @@ int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const 
         if ((rc = zpi_h2d_small(ctx, (uint8_t *)d_tail + sizeof tpt, tsc, sizeof tsc)) != ZP_OK) return done(rc);
         if ((rc = zp_msm_bn254(ctx, (const uint32_t *)d_tail, (const uint32_t *)((uint8_t *)d_tail + sizeof tpt), 5, out_c)) != ZP_OK) return done(rc);
         memcpy(out_a, A1, 64);
-        if (h_ms) { h_ms[0] = ms(t0, t1); h_ms[1] = ms(t1, t2); h_ms[2] = ms(t2, now()); }
+        if (h_ms) {
+            h_ms[0] = ms(t0, t1); h_ms[1] = ms(t1, t2); h_ms[2] = ms(t2, now());
+            h_ms[3] = ms(t2, t3); h_ms[4] = ms(t3, t4); h_ms[5] = ms(t4, t5); h_ms[6] = ms(t5, t6); h_ms[7] = ms(t6, t7);
+        }
         return done(ZP_OK);
     } catch (...) {
         if (d_abc) zpi_pool_release(ctx, d_abc, abc_bytes);

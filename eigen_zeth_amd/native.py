@@ -113,7 +113,7 @@ SIGNATURES = {
     "zp_r1cs_key_scalars": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "zp_stark_openings": (C.c_int32, [_vp, _vp, _vp]),
     "zp_wrap_assign": (C.c_int32, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t, _vp]),
-    "zp_groth16_prove": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "zp_groth16_prove": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zp_sha256": (C.c_int32, [_vp, C.c_size_t, _vp]),
     "zp_r1cs_eval_device": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zp_program_digest": (C.c_int32, [_vp, C.c_size_t, _vp, _vp]),
@@ -927,7 +927,7 @@ class Prover:
 
     def groth16_prove(self, blob, dev, delta1_words, set_idx, set_val, r, s):
         """zp_groth16_prove -> (pi_a u32[16], pi_b u32[32], pi_c u32[16], public inputs [int], [ms witness, ms QAP, ms MSMs]); dev: name -> device
-        buffer of the key's points (u1x, v1x, v2x, l1, h1); ValueError when the assignment does not satisfy the circuit"""
+        buffer of the key's points (u1x, v1x, v2x, l1, h1) + "v_wires" (device u32 list of the wires in B) and "n_v"; ValueError when the assignment does not satisfy the circuit"""
         blob = np.ascontiguousarray(blob, dtype=np.uint64)
         set_idx = np.ascontiguousarray(set_idx, dtype=np.uint64)
         set_val = np.ascontiguousarray(set_val, dtype=np.uint64)
@@ -936,9 +936,10 @@ class Prover:
         a, b, c = np.zeros(16, dtype=np.uint32), np.zeros(32, dtype=np.uint32), np.zeros(16, dtype=np.uint32)
         n_pub = int(blob[9])
         pub = np.zeros((n_pub, 4), dtype=np.uint64)
-        ms = (C.c_double * 3)()
+        ms = (C.c_double * 8)()
         bad = C.c_int64(-1)
-        rc = self.lib.zp_groth16_prove(self.ctx, blob.ctypes.data, blob.size, _ptr(dev["u1x"]), _ptr(dev["v1x"]), _ptr(dev["v2x"]), _ptr(dev["l1"]), _ptr(dev["h1"]),
+        rc = self.lib.zp_groth16_prove(self.ctx, blob.ctypes.data, blob.size, _ptr(dev["u1x"]), _ptr(dev["v_wires"]), int(dev["n_v"]), _ptr(dev["v1x"]),
+                                       _ptr(dev["v2x"]), _ptr(dev["l1"]), _ptr(dev["h1"]),
                                        d1.ctypes.data, set_idx.ctypes.data, set_val.ctypes.data, set_idx.size, rw.ctypes.data, sw.ctypes.data, a.ctypes.data,
                                        b.ctypes.data, c.ctypes.data, pub.ctypes.data, ms, C.byref(bad))
         if rc == -20:

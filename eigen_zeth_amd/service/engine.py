@@ -604,6 +604,7 @@ class Engine:
         proof, pub, g16_ms = groth16.prove(key, set_idx, set_val, self.be, rnd)      # ValueError: the openings do not hash to the roots -> no witness
         self.stage_timings["final/" + batch_id] = {"final_stark(bn128)": t_fs, "wrap-assign": t_wit, "groth16": time.perf_counter() - t0,
                                                    "groth16/witness": g16_ms[0] / 1e3, "groth16/qap": g16_ms[1] / 1e3, "groth16/msm": g16_ms[2] / 1e3,
+                                                   **({"groth16/msm/" + k: v / 1e3 for k, v in zip(("A", "B1", "B2", "l", "h"), g16_ms[3:8])} if len(g16_ms) >= 8 else {}),
                                                    **{"final/" + k: v for k, v in tmf.items()}}
         self.wrap_info = {"constraints": wc.c.n_constraints, "qap_domain_log2": wc.c.logm(), "wires": wc.c.n_wires,
                           "msm_points": {"A (G1)": wc.c.n_wires + 2, "B (G1)": wc.c.n_wires + 2, "B (G2)": wc.c.n_wires + 2, "C: l (G1)": wc.c.n_wires,

@@ -45,7 +45,8 @@ def _g2_words(p):
 
 class Key:
     """toxic: {tau, alpha, beta, gamma, delta}; u, v, l: u64[n_wires][4]; h: u64[m - 1][4] (the key's SCALARS); vk: the verifying key's points;
-    dev: device-resident point arrays of a GPU backend (u1x = [u_j]_1 | alpha_1 | delta_1, v1x likewise with beta_1, v2x in G2, l1, h1)"""
+    dev: device-resident point arrays of a GPU backend (u1x = [u_j]_1 | alpha_1 | delta_1; v_wires: the wires with a non-zero column in B, v1x =
+    [v_j]_1 of those | beta_1 | delta_1, v2x the same in G2; l1, h1)"""
 
     def __init__(self, circuit_blob, seed=DEFAULT_SEED):
         self.blob = np.ascontiguousarray(circuit_blob, dtype=np.uint64)
@@ -71,12 +72,18 @@ class Key:
         l_priv = self.l.copy()
         l_priv[:1 + self.n_pub] = 0                       # the public part of C is the verifier's (IC), not the prover's
         dev = {}
-        for name, sc, is_g2 in (("u1x", np.concatenate([self.u, tail_a]), False), ("v1x", np.concatenate([self.v, tail_b]), False),
-                                ("v2x", np.concatenate([self.v, tail_b]), True), ("l1", l_priv, False), ("h1", self.h, False)):
+        # a third of the gadget's wires (the x^4 of every S-box) never stand in B: the B side of the key holds the other wires only
+        v_wires = np.flatnonzero((self.v != 0).any(axis=1)).astype(np.uint32)
+        vs = np.concatenate([self.v[v_wires], tail_b])
+        for name, sc, is_g2 in (("u1x", np.concatenate([self.u, tail_a]), False), ("v1x", vs, False), ("v2x", vs, True), ("l1", l_priv, False),
+                                ("h1", self.h, False)):
             pts = p.fixed_base_mul(g2 if is_g2 else g1, sc, g2=is_g2)
             d = p.alloc(pts.size // 2)
             p._chk(p.lib.zp_h2d(p.ctx, d.ptr, pts.ctypes.data, pts.nbytes))
             dev[name] = (d, pts.shape[0])
+        d = p.alloc((v_wires.size + 1) // 2)
+        p._chk(p.lib.zp_h2d(p.ctx, d.ptr, v_wires.ctypes.data, v_wires.nbytes))
+        dev["v_wires"] = (d, int(v_wires.size))
         dev["delta1"] = bn254.g1_mul(t["delta"])
         self.dev = dev
         return dev
@@ -105,7 +112,9 @@ def prove(key, set_idx, set_val, be, rand):
         wf, _, _, _ = native.r1cs_eval(key.blob, w, mask)
         return be.groth16_prove(key, native.fr_ints(wf), rand), native.fr_ints(wf[1:1 + key.n_pub]), [0.0, 0.0, 0.0]
     dev = key.load_points(be)
-    a, b, c, pub, ms = be.p.groth16_prove(key.blob, {k: v[0] for k, v in dev.items() if k != "delta1"}, _g1_words(dev["delta1"]), set_idx, set_val, *rand)
+    handles = {k: v[0] for k, v in dev.items() if k != "delta1"}
+    handles["n_v"] = dev["v_wires"][1]
+    a, b, c, pub, ms = be.p.groth16_prove(key.blob, handles, _g1_words(dev["delta1"]), set_idx, set_val, *rand)
     return {"pi_a": _g1_point(a), "pi_b": _g2_point(b), "pi_c": _g1_point(c)}, pub, ms
 
 

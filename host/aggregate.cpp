@@ -229,9 +229,12 @@ static int run_final(int argc, char **argv) {
     }
     // the key's points: files -> HBM
     const size_t n_wires = circ[1], m = (size_t)1 << circ[3];
-    struct KeyPart { const char *file; size_t bytes; void *dev; } parts[5] = {{"/key_u1x.bin", (n_wires + 2) * 64, nullptr}, {"/key_v1x.bin", (n_wires + 2) * 64, nullptr},
-                                                                               {"/key_v2x.bin", (n_wires + 2) * 128, nullptr}, {"/key_l1.bin", n_wires * 64, nullptr},
-                                                                               {"/key_h1.bin", (m - 1) * 64, nullptr}};
+    const std::string vw = read_text((dir + "/key_v_wires.bin").c_str());          // the wires with a non-zero column in B
+    const size_t n_v = vw.size() / 4;
+    if (vw.size() % 4 || n_v < 1 || n_v > n_wires) { fprintf(stderr, "bad key_v_wires.bin\n"); return 2; }
+    struct KeyPart { const char *file; size_t bytes; void *dev; } parts[6] = {{"/key_u1x.bin", (n_wires + 2) * 64, nullptr}, {"/key_v1x.bin", (n_v + 2) * 64, nullptr},
+                                                                               {"/key_v2x.bin", (n_v + 2) * 128, nullptr}, {"/key_l1.bin", n_wires * 64, nullptr},
+                                                                               {"/key_h1.bin", (m - 1) * 64, nullptr}, {"/key_v_wires.bin", n_v * 4, nullptr}};
     for (KeyPart &kp : parts) {
         const std::string raw = read_text((dir + kp.file).c_str());
         if (raw.size() != kp.bytes) { fprintf(stderr, "%s: %zu bytes, expected %zu\n", kp.file, raw.size(), kp.bytes); return 2; }
@@ -242,9 +245,9 @@ static int run_final(int argc, char **argv) {
     if (d1.size() != 64) { fprintf(stderr, "bad key_delta1.bin\n"); return 2; }
     uint32_t pa[16], pb[32], pc[16];
     std::vector<uint64_t> pub(4 * circ[9]);
-    double ms[3];
+    double ms[8];
     int64_t bad = -1;
-    CHECK(zp_groth16_prove(ctx, circ.data(), circ.size(), (const uint32_t *)parts[0].dev, (const uint32_t *)parts[1].dev, (const uint32_t *)parts[2].dev,
+    CHECK(zp_groth16_prove(ctx, circ.data(), circ.size(), (const uint32_t *)parts[0].dev, (const uint32_t *)parts[5].dev, n_v, (const uint32_t *)parts[1].dev, (const uint32_t *)parts[2].dev,
                            (const uint32_t *)parts[3].dev, (const uint32_t *)parts[4].dev, (const uint32_t *)d1.data(), set_idx.data(), set_val.data(), n_set, r, sc,
                            pa, pb, pc, pub.data(), ms, &bad));
     // the text eigen-zeth parses (src/settlement/ethereum/mod.rs:445-481), written as json.dumps writes it

@@ -381,18 +381,18 @@ int32_t zp_r1cs_key_scalars(const uint64_t *circ, size_t words, const uint64_t *
  *   results and refusals (-20 / -21, *bad) as zp_r1cs_eval.  The circuit's gadget must be the width-17 Poseidon permutation of the installed tables:
  *   it is compared with the kernel on one instance, once per circuit and ctx (ZP_ERR_ARG otherwise).
  * zp_groth16_prove: witness completion + A w, B w, C w (zp_r1cs_eval_device), the QAP quotient, five MSMs over the key's device-resident points
- *   (d_u1x, d_v1x: u32[n_wires + 2][16] = [u_j]_1 | alpha_1 | delta_1, [v_j]_1 | beta_1 | delta_1; d_v2x: u32[n_wires + 2][32] = [v_j]_2 | beta_2 |
- *   delta_2; d_l1: u32[n_wires][16], infinity at the constant and the public inputs; d_h1: u32[2^logm - 1][16]; h_delta1 u32[16]) and the blinding
- *   terms for (h_r, h_s).  out_a u32[16], out_b u32[32], out_c u32[16] = pi_a, pi_b, pi_c; out_pub u64[n_pub][4]; h_ms (may be NULL) double[3] =
- *   milliseconds of witness, QAP, MSMs.  -20 / -21 as zp_r1cs_eval: a false statement has no proof.
+ *   (d_u1x: u32[n_wires + 2][16] = [u_j]_1 | alpha_1 | delta_1; d_v_wires u32[n_v]: the wires with a non-zero column in B, ascending -- the B side of
+ *   the key holds only those: d_v1x u32[n_v + 2][16] = [v_j]_1 | beta_1 | delta_1, d_v2x u32[n_v + 2][32] = [v_j]_2 | beta_2 | delta_2; d_l1: u32[n_wires][16], infinity at the constant and the public inputs; d_h1: u32[2^logm - 1][16]; h_delta1 u32[16]) and the blinding
+ *   terms for (h_r, h_s).  out_a u32[16], out_b u32[32], out_c u32[16] = pi_a, pi_b, pi_c; out_pub u64[n_pub][4]; h_ms (may be NULL) double[8] =
+ *   milliseconds of witness, QAP, all MSMs, then A, B (G1), B (G2), l, h one by one.  -20 / -21 as zp_r1cs_eval: a false statement has no proof.
  * zp_sha256: SHA-256 of a byte string (the digests proof texts name; the deterministic blinding of a test run).                                    */
 int32_t zp_stark_openings(zp_ctx *ctx, const uint64_t **out, size_t *words);
 int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64_t *openings, size_t open_words, const uint64_t *aux4, uint64_t *out_idx,
                        uint64_t *out_val, size_t cap, size_t *n_set);
 int32_t zp_r1cs_eval_device(zp_ctx *ctx, const uint64_t *circ, size_t words, const uint64_t *set_idx, const uint64_t *set_val, size_t n_set, uint64_t *d_w,
                             uint64_t *d_a, uint64_t *d_b, uint64_t *d_c, uint64_t *out_pub, int64_t *bad);
-int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const uint32_t *d_u1x, const uint32_t *d_v1x, const uint32_t *d_v2x,
-                         const uint32_t *d_l1, const uint32_t *d_h1, const uint32_t *h_delta1, const uint64_t *set_idx, const uint64_t *set_val, size_t n_set,
+int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const uint32_t *d_u1x, const uint32_t *d_v_wires, size_t n_v, const uint32_t *d_v1x,
+                         const uint32_t *d_v2x, const uint32_t *d_l1, const uint32_t *d_h1, const uint32_t *h_delta1, const uint64_t *set_idx, const uint64_t *set_val, size_t n_set,
                          const uint64_t *h_r, const uint64_t *h_s, uint32_t *out_a, uint32_t *out_b, uint32_t *out_c, uint64_t *out_pub, double *h_ms,
                          int64_t *bad);
 int32_t zp_sha256(const uint8_t *data, size_t len, uint8_t *out32);

@@ -48,7 +48,7 @@ def export_final(out, eng, n_proofs=2, logn=None):
                                                                         the verifier AIR over it is what the final STARK proves
       <out>/poseidon_bn254_t17.bin   [rp, rc words, mds words]: the tables zp_set_poseidon_bn254 takes
       <out>/wrap_circuit.bin, wrap_script.bin                            the R1CS of the wrap and its assignment script
-      <out>/key_u1x.bin, key_v1x.bin, key_v2x.bin, key_l1.bin, key_h1.bin, key_delta1.bin   the proving key's points (MSM layout)
+      <out>/key_u1x.bin, key_v_wires.bin, key_v1x.bin, key_v2x.bin, key_l1.bin, key_h1.bin, key_delta1.bin   the proving key (points in the MSM layout)
       <out>/final.txt    line 1: logn logb fri_logf fri_final_log n_queries of the final STARK; line 2: the "circuit" text of the proof"""
     from eigen_zeth_amd import native
     from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
@@ -80,6 +80,7 @@ def export_final(out, eng, n_proofs=2, logn=None):
     for name in ("u1x", "v1x", "v2x", "l1", "h1"):
         d, n = dev[name]
         w("key_%s.bin" % name, be.p.download(d, (n * (32 if name == "v2x" else 16) // 2,)))
+    w("key_v_wires.bin", be.p.download(dev["v_wires"][0], ((dev["v_wires"][1] + 1) // 2,)).view(np.uint32)[:dev["v_wires"][1]], np.uint32)
     w("key_delta1.bin", G16._g1_words(dev["delta1"]), np.uint32)
     with open(os.path.join(out, "final.txt"), "w") as f:
         f.write("%d %d %d %d %d\n" % (fp.logn, fp.logb, fp.fri_logf, fp.fri_final_log, fp.n_queries))
