@@ -606,8 +606,9 @@ class Engine:
                                                    "groth16/witness": g16_ms[0] / 1e3, "groth16/qap": g16_ms[1] / 1e3, "groth16/msm": g16_ms[2] / 1e3,
                                                    **({"groth16/msm/" + k: v / 1e3 for k, v in zip(("A", "B1", "B2", "l", "h"), g16_ms[3:8])} if len(g16_ms) >= 8 else {}),
                                                    **{"final/" + k: v for k, v in tmf.items()}}
+        n_v = key.dev["v_wires"][1] if key.dev else int((key.v != 0).any(axis=1).sum())      # wires with a non-zero column in B
         self.wrap_info = {"constraints": wc.c.n_constraints, "qap_domain_log2": wc.c.logm(), "wires": wc.c.n_wires,
-                          "msm_points": {"A (G1)": wc.c.n_wires + 2, "B (G1)": wc.c.n_wires + 2, "B (G2)": wc.c.n_wires + 2, "C: l (G1)": wc.c.n_wires,
+                          "msm_points": {"A (G1)": wc.c.n_wires + 2, "B (G1)": n_v + 2, "B (G2)": n_v + 2, "C: l (G1)": wc.c.n_wires,
                                          "C: h (G1)": (1 << wc.c.logm()) - 1}}
         if self.metrics is not None:
             self.metrics.record_stage("groth16", self.stage_timings["final/" + batch_id]["groth16"])
