@@ -20,12 +20,15 @@
 
 #include "ctx.hpp"
 #include "gl_asm.hpp"
+#include "gl_limb.hpp"
 
 // the data of a pass is touched exactly once: non-temporal loads/stores (measured +1 % on the 2^24 bench, same results)
 #define ZP_LDG(p) __builtin_nontemporal_load(p)
 #define ZP_STG(p, v) __builtin_nontemporal_store(v, p)
 
 namespace {
+
+typedef __attribute__((ext_vector_type(4))) int zp_i32x4;
 
 struct PassArgs {
     const u64 *in;
@@ -177,6 +180,86 @@ __device__ __forceinline__ void exchange2(u64 *v, u64 *lds, const u64 *twr, int 
     }
 }
 
+// ---- the same two building blocks on four signed 24-bit-position limbs (gl_limb.hpp): butterflies are carry-free 32-bit adds, every
+// twiddle 2^(24 j) a renaming of limbs, and the canonical 64-bit value comes back inside the twiddle product that follows a round
+template <int E>
+__device__ __forceinline__ gl_l4 mul_c16_l4(const gl_l4 &d) { return gl_l4_mul_c16<E>(d); }
+__device__ __forceinline__ gl_l4 mul_c16_l4(int e, const gl_l4 &d) {   // e is a constant after unrolling
+    switch (e) {
+        case 0: return d;
+        case 1: return gl_l4_mul_c16<1>(d);
+        case 2: return gl_l4_mul_c16<2>(d);
+        case 3: return gl_l4_mul_c16<3>(d);
+        case 4: return gl_l4_mul_c16<4>(d);
+        case 5: return gl_l4_mul_c16<5>(d);
+        case 6: return gl_l4_mul_c16<6>(d);
+        default: return gl_l4_mul_c16<7>(d);
+    }
+}
+// x[p] receives DFT_c[brev(p)] of the canonical values v[0 .. 2^A), |limbs| < 2^(24 + A)
+template <int A>
+__device__ __forceinline__ void dif_shift_l4(const u64 *v, gl_l4 *x) {
+    static_assert(A >= 2 && A <= 4, "radix 4, 8 or 16");
+#pragma unroll
+    for (int i = 0; i < (1 << A); i++) x[i] = gl_l4_from(v[i]);
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int half = 1 << (A - 1 - s);
+#pragma unroll
+        for (int t = 0; t < (1 << (A - 1)); t++) {
+            const int i0 = (t / half) * 2 * half + (t % half);
+            const gl_l4 a = x[i0], b = x[i0 + half];
+            x[i0] = gl_l4_add(a, b);
+            x[i0 + half] = mul_c16_l4((t % half) * (8 / half), gl_l4_sub(a, b));
+        }
+    }
+}
+// the LDS record of a factor: balanced words of w B^i, i < 4 (32 bytes)
+__device__ __forceinline__ gl_w4 w4_load(const gl_w4 *p) {
+    const zp_i32x4 a = *(const zp_i32x4 *)p->lo, b = *(const zp_i32x4 *)p->hi;
+    gl_w4 w;
+    w.lo[0] = a.x; w.lo[1] = a.y; w.lo[2] = a.z; w.lo[3] = a.w;
+    w.hi[0] = b.x; w.hi[1] = b.y; w.hi[2] = b.z; w.hi[3] = b.w;
+    return w;
+}
+__device__ __forceinline__ void w4_store(gl_w4 *p, const u64 w0, const u64 w1, const u64 w2, const u64 w3) {
+    i32 l[4], h[4];
+    gl_l4_balance(w0, l[0], h[0]);
+    gl_l4_balance(w1, l[1], h[1]);
+    gl_l4_balance(w2, l[2], h[2]);
+    gl_l4_balance(w3, l[3], h[3]);
+    zp_i32x4 a = {l[0], l[1], l[2], l[3]}, b = {h[0], h[1], h[2], h[3]};
+    *(zp_i32x4 *)p->lo = a;
+    *(zp_i32x4 *)p->hi = b;
+}
+// twr4: LDS records of w_(2^(POS+A))^e
+template <typename G, int A, int POS, int ANEXT, int POSNEXT>
+__device__ __forceinline__ void exchange2_l4(const gl_l4 *x, u64 *v, u64 *lds, const gl_w4 *twr4, int j0inv, int tid) {
+    constexpr int GR = 16 >> A;
+#pragma unroll
+    for (int g = 0; g < GR; g++) {
+        const int gamma = g * G::NT + tid;
+        const int t = gamma & (G::T - 1), o = gamma >> G::LT;
+        const int rho = o & ((1 << POS) - 1);
+#pragma unroll
+        for (int p = 0; p < (1 << A); p++) {
+            const int kj = (j0inv * brev(p, A)) & ((1 << A) - 1);  // wave-uniform
+            const u64 y = p == 0 ? gl_l4_canon(x[g * (1 << A)]) : gl_l4_mul(x[g * (1 << A) + p], w4_load(twr4 + kj * rho));
+            lds[G::lpos(slot_of(o, kj, POS, A), t)] = y;
+        }
+    }
+    lds_barrier();
+    constexpr int GN = 16 >> ANEXT;
+#pragma unroll
+    for (int g = 0; g < GN; g++) {
+        const int gamma = g * G::NT + tid;
+        const int t = gamma & (G::T - 1), o = gamma >> G::LT;
+#pragma unroll
+        for (int j = 0; j < (1 << ANEXT); j++)
+            v[g * (1 << ANEXT) + j] = lds[G::lpos(slot_of(o, j, POSNEXT, ANEXT), t)];
+    }
+}
+
 // Pass kernel, second generation.
 //  * A workgroup walks `tiles_per_wg` consecutive tiles of one column.  ALL vector global loads of
 //    tile i+1 (16 data elements per lane + the few twiddle-table entries it needs) are issued at the
@@ -199,8 +282,11 @@ __device__ __forceinline__ void exchange2(u64 *v, u64 *lds, const u64 *twr, int 
 //    table loads are cacheable, so 7 of 8 reads are hits in that XCD's L2.
 // MODE (non-transposing passes): 0 = plain last pass, 1 = multiply by the per-tile table,
 // 2 = table and the per-lane part of a coset power (last pass of the inverse transform in an LDE)
-template <int A1, int A2, int A3, int LOGT, bool TRANSPOSE, bool PADDED, int MODE, bool BIG = false>
-__global__ void __launch_bounds__((1 << (A1 + A2 + A3 + LOGT)) / 16, 4)   // 4 waves per SIMD: 128 VGPRs, of which v116..v127 are the scratch window of gl_asm.hpp
+// LIMB: the register butterflies and the twiddle products that follow them on the limb form of gl_limb.hpp (16 values x 4 limbs live
+// between the rounds: 3 waves per SIMD, 168 VGPRs); the per-tile table and the LDS copies of the inter-round twiddles hold 32-byte
+// records (the balanced words of w, w 2^24, w 2^48, w 2^72).  Not for the per-lane twiddle chain of a first pass without its table.
+template <int A1, int A2, int A3, int LOGT, bool TRANSPOSE, bool PADDED, int MODE, bool BIG = false, bool LIMB = false>
+__global__ void __launch_bounds__((1 << (A1 + A2 + A3 + LOGT)) / 16, LIMB ? 3 : 4)   // 4 waves per SIMD: 128 VGPRs, of which v116..v127 are the scratch window of gl_asm.hpp
 ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     using G = Geo<A1, A2, A3, LOGT>;
     constexpr int L = G::L, R = G::R, T = G::T, NT = G::NT, AJ = G::AJ;
@@ -210,10 +296,12 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     constexpr bool TWR_LDS = L <= 10;          // radix 2^11 / 2^12: the 128 KiB tile leaves no room, twiddles come from L2
     constexpr int TPL = (R + NT - 1) / NT;     // per-tile table entries a lane prepares
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int REC = LIMB ? 4 : 1;          // u64 per table entry (LIMB: a 32-byte gl_w4 record)
     u64 *tab = lds + R * T;                    // R entries: per-tile inter-pass twiddles (HAS_TAB)
-    u64 *twr1 = tab + (HAS_TAB ? R : 0);       // R entries:  w_R^e      (inter-round twiddles, first exchange)
-    u64 *twr2 = twr1 + R;                      // R2 entries: w_(R2)^e   (second exchange, 3-round passes)
+    u64 *twr1 = tab + (HAS_TAB ? R * REC : 0); // R entries:  w_R^e      (inter-round twiddles, first exchange)
+    u64 *twr2 = twr1 + R * REC;                // R2 entries: w_(R2)^e   (second exchange, 3-round passes)
     constexpr bool TW1 = TRANSPOSE && MODE == 3;
+    static_assert(!LIMB || (TWR_LDS && (TW1 || !TRANSPOSE)), "limb form: LDS twiddle copies, no per-lane twiddle chain");
     // MODE 3: one-dimensional grid; workgroup id -> (XCD x = id % 8, j = id / 8): column = j % ncols, tile group = (j / ncols) * 8 + x
     u64 col = blockIdx.y, wg_lin = blockIdx.x;
     if constexpr (TW1) {
@@ -304,7 +392,22 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     u64 kfac[TPL];
     {
         const int tid0 = threadIdx.x;
-        if constexpr (TWR_LDS) {
+        if constexpr (LIMB) {
+            // w 2^(24 i) = w_R^(e + i rot): 2^12 = w_16^(j0inv), so 2^24 = w_R^(j0inv R / 8) -- four entries of the same table
+            for (int e = tid0; e < R; e += NT) {
+                const int rot = (a.j0inv * (R / 8)) & (R - 1);
+                w4_store((gl_w4 *)twr1 + e, a.tws[e << (12 - L)], a.tws[((e + rot) & (R - 1)) << (12 - L)],
+                         a.tws[((e + 2 * rot) & (R - 1)) << (12 - L)], a.tws[((e + 3 * rot) & (R - 1)) << (12 - L)]);
+            }
+            if constexpr (G::J >= 3) {
+                constexpr int L2 = A2 + A3;
+                for (int e = tid0; e < R2; e += NT) {
+                    const int rot = (a.j0inv * (R2 / 8)) & (R2 - 1);
+                    w4_store((gl_w4 *)twr2 + e, a.tws[e << (12 - L2)], a.tws[((e + rot) & (R2 - 1)) << (12 - L2)],
+                             a.tws[((e + 2 * rot) & (R2 - 1)) << (12 - L2)], a.tws[((e + 3 * rot) & (R2 - 1)) << (12 - L2)]);
+                }
+            }
+        } else if constexpr (TWR_LDS) {
             if (tid0 < R) twr1[tid0] = a.tws[tid0 << (12 - L)];
             if constexpr (G::J >= 3) {
                 if (tid0 < R2) twr2[tid0] = a.tws[tid0 << (12 - (A2 + A3))];
@@ -340,8 +443,25 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
         if constexpr (HAS_TAB) {
 #pragma unroll
             for (int j = 0; j < TPL; j++)
-                if (tid + j * NT < R) tab[tid + j * NT] = gl_mul(gl_mul(twl_c[j], twh_c[j]), kfac[j]);
+                if (tid + j * NT < R) {
+                    const u64 w = gl_mul(gl_mul(twl_c[j], twh_c[j]), kfac[j]);
+                    if constexpr (LIMB) w4_store((gl_w4 *)tab + tid + j * NT, w, gl_shl12<2>(w), gl_shl12<4>(w), gl_shl12<6>(w));
+                    else tab[tid + j * NT] = w;
+                }
         }
+        gl_l4 x[LIMB ? 16 : 1];                // LIMB: the outputs of a round (the last one: x, else v)
+        if constexpr (LIMB) {
+#pragma unroll
+            for (int g = 0; g < (16 >> A1); g++) dif_shift_l4<A1>(v + g * (1 << A1), x + g * (1 << A1));
+            exchange2_l4<G, A1, G::POS1, A2, G::POS2>(x, v, lds, (const gl_w4 *)twr1, a.j0inv, tid);
+#pragma unroll
+            for (int g = 0; g < (16 >> A2); g++) dif_shift_l4<A2>(v + g * (1 << A2), x + g * (1 << A2));
+            if constexpr (G::J >= 3) {
+                exchange2_l4<G, A2, G::POS2, A3, 0>(x, v, lds, (const gl_w4 *)twr2, a.j0inv, tid);
+#pragma unroll
+                for (int g = 0; g < (16 >> A3); g++) dif_shift_l4<A3>(v + g * (1 << A3), x + g * (1 << A3));
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < (16 >> A1); g++) dif_shift<A1>(v + g * (1 << A1));
         exchange2<G, A1, G::POS1, A2, G::POS2, TWR_LDS ? 0 : 12 - L>(v, lds, TWR_LDS ? twr1 : a.tws, a.j0inv, tid);
@@ -351,6 +471,7 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
             exchange2<G, A2, G::POS2, A3, 0, TWR_LDS ? 0 : 12 - (A2 + A3)>(v, lds, TWR_LDS ? twr2 : a.tws, a.j0inv, tid);
 #pragma unroll
             for (int g = 0; g < (16 >> A3); g++) dif_shift<A3>(v + g * (1 << A3));
+        }
         }
 #pragma unroll
         for (int g = 0; g < GRJ; g++) {
@@ -362,7 +483,8 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
 #pragma unroll
                 for (int i = 0; i < (1 << AJ); i++) {
                     const int kj = (jr * i) & ((1 << AJ) - 1);
-                    lds[G::lpos(slot_of(o, kj, 0, AJ), t)] = v[g * (1 << AJ) + brev(i, AJ)];
+                    if constexpr (LIMB) lds[G::lpos(slot_of(o, kj, 0, AJ), t)] = gl_l4_canon(x[g * (1 << AJ) + brev(i, AJ)]);
+                    else lds[G::lpos(slot_of(o, kj, 0, AJ), t)] = v[g * (1 << AJ) + brev(i, AJ)];
                 }
             } else if constexpr (TRANSPOSE) {
                 const int jr = a.j0inv & ((1 << AJ) - 1);  // odd, < 2^AJ: floor(jr*i/2^AJ) steps by 0 or 1
@@ -395,8 +517,20 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
                 for (int p = 0; p < (1 << AJ); p += 2) {
                     const int kja = (a.j0inv * brev(p, AJ)) & ((1 << AJ) - 1), kjb = (a.j0inv * brev(p + 1, AJ)) & ((1 << AJ) - 1);
                     const int ka = klow + (kja << (L - AJ)), kb = klow + (kjb << (L - AJ));
-                    u64 xa = v[g * (1 << AJ) + p], xb = v[g * (1 << AJ) + p + 1];
-                    if constexpr (MODE >= 1) gl_mul2(xa, tab[ka], xb, tab[kb]);
+                    u64 xa, xb;
+                    if constexpr (LIMB) {
+                        if constexpr (MODE >= 1) {
+                            xa = gl_l4_mul(x[g * (1 << AJ) + p], w4_load((const gl_w4 *)tab + ka));
+                            xb = gl_l4_mul(x[g * (1 << AJ) + p + 1], w4_load((const gl_w4 *)tab + kb));
+                        } else {
+                            xa = gl_l4_canon(x[g * (1 << AJ) + p]);
+                            xb = gl_l4_canon(x[g * (1 << AJ) + p + 1]);
+                        }
+                    } else {
+                        xa = v[g * (1 << AJ) + p];
+                        xb = v[g * (1 << AJ) + p + 1];
+                        if constexpr (MODE >= 1) gl_mul2(xa, tab[ka], xb, tab[kb]);
+                    }
                     if constexpr (MODE == 2) gl_mul2(xa, cw, xb, cw);
                     u64 *const ua = sbase + ((u64)(kja << (L - AJ)) << logP), *const ub = sbase + ((u64)(kjb << (L - AJ)) << logP);   // uniform
                     u64 *pa, *pb;
@@ -527,11 +661,16 @@ int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
     dim3 grid((unsigned)(tiles / tpw), (unsigned)W), block(G::NT);
     // tile + (per-tile table: non-transposing passes with a multiplication) + (LDS copies of the inter-round twiddles, L <= 10)
     const bool has_tab = !transpose && (a.flags & 7) != 0;
-    const size_t shmem = ((size_t)G::R * G::T + (has_tab ? G::R : 0) + (G::L <= 10 ? G::R + (1 << (A2 + A3)) : 0)) * sizeof(u64);
+    // limb-form butterflies (gl_limb.hpp; knob ntt_limb): every pass with LDS twiddle copies except a first pass without its table
+    constexpr bool CAN_LIMB = !BIG && G::L <= 8;      // (radix 2^9 and up: tiles of 64 / 128 KiB leave no room for the 32-byte table records)
+    const bool limb = CAN_LIMB && ctx->tune_ntt_limb != 0 && !(transpose && !(A3 == 0 && a.tw1 && (grid.x & 7u) == 0));
+    const size_t rec = limb ? 4 : 1;
+    const size_t shmem = ((size_t)G::R * G::T + (has_tab ? G::R * rec : 0) + (G::L <= 10 ? (G::R + (1 << (A2 + A3))) * rec : 0)) * sizeof(u64);
     if constexpr (!BIG && A3 == 0) {
         if (transpose && a.tw1 && (grid.x & 7u) == 0) {
             const bool padded = a.in_valid != (1ULL << a.logn);
-            auto k = padded ? ntt_pass2_kernel<A1, A2, A3, LOGT, true, true, 3, false> : ntt_pass2_kernel<A1, A2, A3, LOGT, true, false, 3, false>;
+            auto k = limb ? (padded ? ntt_pass2_kernel<A1, A2, A3, LOGT, true, true, 3, false, CAN_LIMB> : ntt_pass2_kernel<A1, A2, A3, LOGT, true, false, 3, false, CAN_LIMB>)
+                          : (padded ? ntt_pass2_kernel<A1, A2, A3, LOGT, true, true, 3, false> : ntt_pass2_kernel<A1, A2, A3, LOGT, true, false, 3, false>);
             PassArgs b = a;
             b.ncols = W;
             hipLaunchKernelGGL(k, dim3(grid.x * (unsigned)W), block, shmem, ctx->stream, b, tpw);
@@ -545,9 +684,12 @@ int32_t launch_pass2(zp_ctx *ctx, const PassArgs &a, bool transpose, int W) {
         if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a, tpw);
     } else {
-        auto k = (a.flags & 4) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 2, BIG>
-                 : (a.flags & 3) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 1, BIG>
-                                 : ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 0, BIG>;
+        auto k = limb ? ((a.flags & 4) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 2, BIG, CAN_LIMB>
+                         : (a.flags & 3) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 1, BIG, CAN_LIMB>
+                                         : ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 0, BIG, CAN_LIMB>)
+                      : ((a.flags & 4) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 2, BIG>
+                         : (a.flags & 3) ? ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 1, BIG>
+                                         : ntt_pass2_kernel<A1, A2, A3, LOGT, false, false, 0, BIG>);
         if (shmem > 65536) ZP_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, a, tpw);
     }

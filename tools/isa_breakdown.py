@@ -7,16 +7,21 @@ out and its instructions are binned; counts are per ELEMENT per pass (loop body 
 instruction except the plain 32-bit add / mov / logic forms (2 cycles)."""
 import collections, re, sys
 
-KERNELS = {"first pass (transposing, full twiddle table)": "ILi4ELi4ELi0ELi4ELb1ELb0ELi3ELb0EE",
-           "middle pass (per-tile twiddle table)": "ILi4ELi4ELi0ELi4ELb0ELb0ELi1ELb0EE",
-           "last pass (plain)": "ILi4ELi4ELi0ELi4ELb0ELb0ELi0ELb0EE",
-           "LDE: zero-padded first pass of the forward transform (2^25: radix 512)": "ILi4ELi3ELi0ELi5ELb1ELb1ELi3ELb0EE",
-           "LDE: last pass of the inverse transform (coset powers folded in)": "ILi4ELi4ELi0ELi4ELb0ELb0ELi2ELb0EE"}
+SHAPES = {"first pass (transposing, full twiddle table)": "ILi4ELi4ELi0ELi4ELb1ELb0ELi3ELb0E",
+          "middle pass (per-tile twiddle table)": "ILi4ELi4ELi0ELi4ELb0ELb0ELi1ELb0E",
+          "last pass (plain)": "ILi4ELi4ELi0ELi4ELb0ELb0ELi0ELb0E",
+          "LDE: zero-padded first pass of the forward transform (2^25: radix 512)": "ILi4ELi3ELi0ELi5ELb1ELb1ELi3ELb0E",
+          "LDE: last pass of the inverse transform (coset powers folded in)": "ILi4ELi4ELi0ELi4ELb0ELb0ELi2ELb0E"}
+# every shape in both arithmetic forms: limbs of gl_limb.hpp (the default, knob ntt_limb) and the canonical carry chains of gl_asm.hpp
+KERNELS = {}
+for _t, _k in SHAPES.items():
+    KERNELS[_t + " -- limb form"] = _k + "Lb1EE"
+    KERNELS[_t + " -- canonical form"] = _k + "Lb0EE"
 
 
 def classify(op):
-    if op.startswith("v_mad_u64_u32"):
-        return "valu: v_mad_u64_u32 (32x32+64 multiply-add)"
+    if op.startswith("v_mad_u64_u32") or op.startswith("v_mad_i64_i32"):
+        return "valu: v_mad_u64_u32 / v_mad_i64_i32 (32x32+64 multiply-add)"
     if re.match(r"v_(add|sub|subrev)(c|b)?_co_", op) or re.match(r"v_(addc|subb|subbrev)_", op):
         return "valu: add / sub with carry (chains of the modular add, sub, reduction)"
     if op.startswith("v_cndmask") or op.startswith("v_cmp"):
