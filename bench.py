@@ -846,6 +846,11 @@ def config5_probe(K=64, logn=22, msm_log=26, air_name="chunk64"):
         prv = sum(v.get("total", 0.0) for k, v in eng.stage_timings.items() if k.startswith(ch["task_id"] + "/"))
         r["groth16_wrap"] = getattr(eng, "wrap_info", None)
         r["final_stages_s"] = {k: round(v, 4) for k, v in eng.stage_timings.get("final/" + label, {}).items()}
+        wdev = [v["witness(device)"] for k, v in eng.stage_timings.items() if k.startswith(ch["task_id"] + "/") and "witness(device)" in v]
+        r["witness"] = {"mode": cfg.witness, "chunks_from_the_host_generator": n - len(wdev), "chunks_filled_in_hbm": len(wdev),
+                        "fill_from_checkpoints_s_summed": sum(wdev),
+                        "note": "device mode: the recurrences of the batch are walked once on the GPU (one wave per chunk, csrc/synth.hip) while the first "
+                                "witness_threads chunks come from the host generator and are proven; the same traces word for word (tests/test_gpu_synth.py)"}
         r.update({"chunk_proofs_s": t1 - t0, "witness_generator_cpu_s_summed_over_threads": wit, "witness_threads": cfg.witness_threads,
                   "zp_stark_prove_s_summed_over_streams": prv, "prover_streams": cfg.prover_streams,
                   "aggregate_first_last_s": t2 - t1, "final_s": t3 - t2,

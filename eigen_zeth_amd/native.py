@@ -101,6 +101,9 @@ SIGNATURES = {
     "zp_domain_tables": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int32)]),
     "zp_synth_trace": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p]),
     "zp_synth_trace_bound": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, C.c_int32, _u64p, _u64p]),
+    "zp_synth_checkpoint_words": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "zp_synth_checkpoints": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _u64p, _u64p, C.c_int32, C.c_void_p]),
+    "zp_synth_trace_device": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _u64p, C.c_int32, C.c_void_p, C.c_void_p, _u64p]),
     "zp_json_key_span": (C.c_int32, [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "zp_proof_queries_scan": (C.c_int32, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_int32), _vp, _vp, C.c_int32]),
@@ -609,6 +612,33 @@ class Prover:
 
     def twiddle_rows(self, d_rows, logn_row, W, row0, logn_total, inverse=False):
         self._chk(self.lib.zp_twiddle_rows(self.ctx, _ptr(d_rows), logn_row, W, row0, logn_total, 1 if inverse else 0))
+
+    # ---- synthetic witnesses generated in HBM (csrc/synth.hip): the traces of synth_trace, word for word
+    def synth_checkpoints(self, kind, logn, W, seeds, binds=None):
+        """checkpoints of the wide-mix recurrences of len(seeds) chunks (one wave per chunk, synchronous): a DeviceBuffer holding
+        synth_checkpoint_words words per chunk; binds: per chunk the starting values a caller dictates (all of the same length)"""
+        words = int(self.lib.zp_synth_checkpoint_words(kind, logn, W))
+        if words == 0:
+            raise ValueError("zp_synth_checkpoints: this kind / shape has no recurrence columns")
+        s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
+        nb = len(binds[0]) if binds is not None and len(binds) else 0
+        b = np.ascontiguousarray(np.asarray(binds, dtype=np.uint64).reshape(len(s), nb)) if nb else None
+        d = DeviceBuffer(self, words * len(s))
+        self._chk(self.lib.zp_synth_checkpoints(self.ctx, kind, logn, W, len(s), s.ctypes.data_as(_u64p), b.ctypes.data_as(_u64p) if nb else None, nb, d.ptr))
+        d.words_per_chunk = words
+        return d
+
+    def synth_trace_device(self, kind, logn, W, seed, bind=None, ckpt=None, ckpt_index=0, out=None):
+        """(device trace [W][2^logn], publics): zp_synth_trace_device on this ctx's stream; ckpt: the buffer of synth_checkpoints and this chunk's
+        position in it (None: made inside the call)"""
+        d = out if out is not None else DeviceBuffer(self, W << logn)
+        d.shape = (W, 1 << logn)
+        pub = np.zeros(8, dtype=np.uint64)
+        b = np.ascontiguousarray(np.asarray(bind, dtype=np.uint64)) if bind is not None and len(bind) else None
+        cp = (ckpt.ptr + 8 * ckpt.words_per_chunk * int(ckpt_index)) if ckpt is not None else None
+        self._chk(self.lib.zp_synth_trace_device(self.ctx, kind, logn, W, seed, b.ctypes.data_as(_u64p) if b is not None else None, len(b) if b is not None else 0,
+                                                 cp, d.ptr, pub.ctypes.data_as(_u64p)))
+        return d, pub[:{0: 3, 2: 1, 3: 8}.get(kind, min(4, W))].copy()
 
     def lde(self, d_in, d_out, logn, logb, W, shift=0, d_coef=None):
         self._chk(self.lib.zp_lde(self.ctx, _ptr(d_in), _ptr(d_out), _ptr(d_coef), logn, logb, W, shift))

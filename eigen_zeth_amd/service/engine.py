@@ -72,7 +72,7 @@ class EngineConfig:
                  crs_dir=None, l2_addr=None, txs_per_chunk=64,
                  witness_threads=8, prover_streams=8, pow_bits=20,
                  final_air="chunk16", final_logn=10, final_logb=2, final_queries=50, native_prover=True,
-                 agg_queries=50, agg_pow_bits=0, aggregate_all_chunks=False, groth16_seed=None):
+                 agg_queries=50, agg_pow_bits=0, aggregate_all_chunks=False, groth16_seed=None, witness="device"):
         self.air, self.logn, self.logb = air, logn, logb
         # GenAggregatedProof names two proofs -- the client sends the first and the last chunk proof of a batch
         # (src/prover/provider.rs:385-388).  False: exactly those two are verified (the wire contract taken literally).  True: when
@@ -90,6 +90,12 @@ class EngineConfig:
         self.crs_dir = crs_dir          # (unused since round 4: wrap keys are made in memory per engine; kept for callers that pass it)
         self.l2_addr, self.txs_per_chunk = l2_addr, txs_per_chunk   # optional block-input fetcher
         self.witness_threads = witness_threads
+        # where the synthetic witnesses (the stand-in for the zkVM executor) are made.  "host": zp_synth_trace_bound on witness_threads
+        # threads, uploaded from page-locked memory.  "device": the same traces generated in HBM (csrc/synth.hip) on backends that can --
+        # the recurrences of the whole batch are walked once, one wave per chunk, while the first witness_threads chunks still come from
+        # the host generator and are being proven; every later chunk is filled from its checkpoints in a few milliseconds.
+        assert witness in ("host", "device")
+        self.witness = witness
         self.prover_streams = prover_streams   # chunk proofs in flight on one GPU (each on its own ctx / stream); 8 measured best (profiles/r2_streams_sweep.txt)
         # the final STARK (BN128-hash mode, no grinding: 50 queries x blow-up 4 = 100 bits conjectured)
         self.final_air, self.final_logn, self.final_logb, self.final_queries = final_air, final_logn, final_logb, final_queries
@@ -256,6 +262,22 @@ class Engine:
             self._free_be = (n_streams, free_qs, [bes[d] for d in range(ndev)])
         free_qs, uploaders = self._free_be[1], self._free_be[2]
 
+        # device-made witnesses: one recurrence walk per GPU over the chunks it will prove, started now on a thread of its own
+        n_host = min(len(chunks), self.cfg.witness_threads)
+        dev_witness = (self.cfg.witness == "device" and not self.pregenerate_witnesses and len(chunks) > n_host
+                       and all(hasattr(u, "synth_checkpoints") for u in uploaders)
+                       and len({(ch["air"], ch["logn"], len(ch.get("bind") or [])) for ch in chunks}) == 1
+                       and AIR.get_air(chunks[0]["air"]).trace_kind in (1, 3))
+        ck_futs, ck_pool = {}, None
+        if dev_witness:
+            ck_pool = ThreadPoolExecutor(max_workers=ndev)
+            air0 = AIR.get_air(chunks[0]["air"])
+            for d in range(ndev):
+                mine = [i for i in range(n_host, len(chunks)) if i % ndev == d]
+                if mine:
+                    ck_futs[d] = (ck_pool.submit(uploaders[d].synth_checkpoints, air0, chunks[0]["logn"], [chunks[i]["seed"] for i in mine],
+                                                 [chunks[i].get("bind") or [] for i in mine]), {i: k for k, i in enumerate(mine)})
+
         def witness(i, ch):
             air = AIR.get_air(ch["air"])
             up = uploaders[i % ndev]             # a backend on the GPU that will prove this chunk
@@ -265,7 +287,13 @@ class Engine:
                 trace, pubs = cached
                 if hasattr(up, "prefetch_trace"):
                     trace = up.prefetch_trace(trace)
-                return air, trace, pubs, 0.0
+                return air, trace, pubs, 0.0, "host"
+            if dev_witness and i >= n_host:
+                fut, index = ck_futs[i % ndev]
+                ck = fut.result()
+                t0 = time.perf_counter()
+                trace, pubs = up.synth_trace_device(air, ch["logn"], ch["seed"], ch.get("bind"), ck, index[i])
+                return air, trace, pubs, time.perf_counter() - t0, "device"
             out = None
             if hasattr(up, "witness_buffer"):   # generate straight into page-locked memory: the copy is then plain DMA
                 out = up.witness_buffer(air.width, 1 << ch["logn"])
@@ -273,7 +301,7 @@ class Engine:
             tw = time.perf_counter() - t0
             if hasattr(up, "prefetch_trace"):   # copy to the GPU from this worker thread, on its own stream
                 trace = up.prefetch_trace(trace)
-            return air, trace, pubs, tw
+            return air, trace, pubs, tw, "host"
         ahead = threading.Semaphore(self.cfg.witness_threads + 2)   # witnesses generated but not yet proven (memory bound)
 
         def witness_bounded(i, ch):
@@ -285,11 +313,11 @@ class Engine:
                 raise
 
         def prove_chunk(i, ch, wfut):
-            air, trace, pubs, tw = wfut.result()
+            air, trace, pubs, tw, where = wfut.result()
             free_be = free_qs[i % ndev]
             be = free_be.get()
             try:
-                tm = {"witness(host)": tw}
+                tm = {"witness(%s)" % where: tw}
                 params = self.stark_params(ch["logn"])
                 if self.cfg.native_prover and hasattr(be, "prove_native"):
                     # one C-ABI call per chunk (zp_stark_prove): the orchestration runs in the library, Python only frames the result
@@ -315,6 +343,10 @@ class Engine:
             wfuts = [wpool.submit(witness_bounded, i, ch) for i, ch in enumerate(chunks)]
             pfuts = [ppool.submit(prove_chunk, i, ch, wfuts[i]) for i, ch in enumerate(chunks)]
             out = [f.result() for f in pfuts]
+        if ck_pool is not None:
+            for fut, _ in ck_futs.values():
+                fut.result().free()
+            ck_pool.shutdown()
         self._batch_chunk_proofs[batch_id] = [o["proof"] for o in out]
         while len(self._batch_chunk_proofs) > 4:
             self._batch_chunk_proofs.pop(next(iter(self._batch_chunk_proofs)))

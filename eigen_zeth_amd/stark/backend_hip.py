@@ -218,6 +218,30 @@ class HipBackend:
                 self._up.pooling = True
         return self._up
 
+    # ---- synthetic witnesses generated in HBM (csrc/synth.hip): a third ctx, so that the recurrence walk of a batch (a second or so)
+    # never holds the ctx the uploads of host-made witnesses go through
+    def _generator(self):
+        with self._up_lock:
+            if getattr(self, "_gen", None) is None:
+                self._gen = native.Prover(self.p_device)
+                self._gen.pooling = True
+                self._gen_lock = threading.Lock()
+        return self._gen
+
+    def synth_checkpoints(self, air, logn, seeds, binds):
+        """checkpoints of the wide-mix recurrences of a batch of chunks (synchronous; call from a worker thread)"""
+        g = self._generator()
+        with self._gen_lock:
+            return g.synth_checkpoints(air.trace_kind, logn, air.width, seeds, binds)
+
+    def synth_trace_device(self, air, logn, seed, bind, ckpt, index):
+        """the witness of one chunk from its checkpoints, as a device buffer prove_native / commit_trace accept"""
+        g = self._generator()
+        with self._gen_lock:
+            d, pubs = g.synth_trace_device(air.trace_kind, logn, air.width, seed, bind=bind, ckpt=ckpt, ckpt_index=index)
+            g.sync()            # the proof runs on another ctx's stream
+        return d, pubs
+
     def witness_buffer(self, W, N):
         """page-locked host array for a witness generator to fill (pooled); pass it to prefetch_trace"""
         return self._uploader().host_array((W, N))

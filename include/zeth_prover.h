@@ -304,6 +304,19 @@ int32_t zp_synth_trace(int32_t kind, int32_t logn, int32_t W, uint64_t seed, uin
 int32_t zp_synth_trace_bound(int32_t kind, int32_t logn, int32_t W, uint64_t seed, const uint64_t *bind, int32_t n_bind,
                              uint64_t *h_trace, uint64_t *h_pub);
 
+/* the same traces generated IN HBM (csrc/synth.hip), word for word what zp_synth_trace_bound writes: for batches whose host generator
+ * would bound the prover (64 chunks of 2^22 x 76: 60 CPU-seconds).  The wide-mix columns are a recurrence over the rows, so a trace is
+ * filled from CHECKPOINTS of that recurrence (the row at every 4096-th position): zp_synth_checkpoints walks the recurrences of n_chunks
+ * chunks at once, one wave per chunk (h_seeds[n_chunks], h_bind[n_chunks][n_bind]; d_ckpt holds n_chunks x zp_synth_checkpoint_words
+ * words, chunk after chunk; synchronous), zp_synth_trace_device(.., d_ckpt of that chunk, ..) fills d_trace u64[W][2^logn] from them on
+ * the ctx stream (asynchronous; h_pub is written before it returns).  d_ckpt = NULL: the checkpoints of the one chunk are made inside the
+ * call (kinds 0 and 2 have no recurrence column and need none).  kind 1 / 3: at most 256 wide-mix columns.                            */
+size_t zp_synth_checkpoint_words(int32_t kind, int32_t logn, int32_t W);
+int32_t zp_synth_checkpoints(zp_ctx *ctx, int32_t kind, int32_t logn, int32_t W, int32_t n_chunks, const uint64_t *h_seeds,
+                             const uint64_t *h_bind, int32_t n_bind, uint64_t *d_ckpt);
+int32_t zp_synth_trace_device(zp_ctx *ctx, int32_t kind, int32_t logn, int32_t W, uint64_t seed, const uint64_t *h_bind, int32_t n_bind,
+                              const uint64_t *d_ckpt, uint64_t *d_trace, uint64_t *h_pub);
+
 /* synthetic MSM input (stands in for a proving key, which the offline build cannot obtain): n DISTINCT points
  * P_i = (start + i) * G of BN254 G1 in the zp_msm_bn254 layout, generated on the host with `threads` threads (0 = all);
  * start must exceed 1024.  Known discrete logs: sum_i s_i P_i = (sum_i s_i (start + i) mod r) * G.            */
