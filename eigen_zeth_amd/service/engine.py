@@ -72,7 +72,8 @@ class EngineConfig:
                  crs_dir=None, l2_addr=None, txs_per_chunk=64,
                  witness_threads=8, prover_streams=8, pow_bits=20,
                  final_air="chunk16", final_logn=10, final_logb=2, final_queries=50, native_prover=True,
-                 agg_queries=50, agg_pow_bits=0, aggregate_all_chunks=False, groth16_seed=None, witness="device"):
+                 agg_queries=50, agg_pow_bits=0, aggregate_all_chunks=False, groth16_seed=None, witness="device",
+                 speculate_recursion=False):
         self.air, self.logn, self.logb = air, logn, logb
         # GenAggregatedProof names two proofs -- the client sends the first and the last chunk proof of a batch
         # (src/prover/provider.rs:385-388).  False: exactly those two are verified (the wire contract taken literally).  True: when
@@ -96,6 +97,15 @@ class EngineConfig:
         # the host generator and are being proven; every later chunk is filled from its checkpoints in a few milliseconds.
         assert witness in ("host", "device")
         self.witness = witness
+        # The reference's client always follows GenChunkProof with GenAggregatedProof(first chunk proof, last chunk proof) and GenFinalProof of
+        # the result (src/prover/provider.rs:385-388, 422-503).  True: a batch of >= 4 chunks proves its first and last chunk FIRST and, on a
+        # backend of its own, makes that aggregated proof and its final STARK while the other chunks are still being proven; the two requests
+        # that follow are then answered from what is already there (same texts, byte for byte: both proofs are deterministic) and only the
+        # Groth16 wrap -- which needs the request's aggregator address and fresh blinding -- is left.  Any other request is computed as before.
+        # OFF by default: measured on one MI355X (profiles/r4_speculation_ab.txt) the two recursion STARKs are 0.15 s of GPU-saturating work
+        # (Merkle commitments), not idle latency -- made during the chunk proofs they slow those by what they take (16 chunks of 2^20 rows:
+        # 0.336 + 0.229 s in sequence, 0.500 + 0.043 s overlapped; BASELINE configs[4]: 7.51 against 7.45 s).
+        self.speculate_recursion = speculate_recursion
         self.prover_streams = prover_streams   # chunk proofs in flight on one GPU (each on its own ctx / stream); 8 measured best (profiles/r2_streams_sweep.txt)
         # the final STARK (BN128-hash mode, no grinding: 50 queries x blow-up 4 = 100 bits conjectured)
         self.final_air, self.final_logn, self.final_logb, self.final_queries = final_air, final_logn, final_logb, final_queries
@@ -125,6 +135,8 @@ class Engine:
         # (src/prover/provider.rs:671-700): the replay waits here, it never drives the same ctx concurrently.
         self._serial = threading.RLock()
         self._free_be = None    # engine-owned pool of idle proving backends, shared by all calls
+        self._be_spec = None    # backend of the speculative aggregation (cfg.speculate_recursion): never in the proving pool
+        self._spec = {}         # "agg": ((sha(p1), sha(p2)), text, timings), "final": (sha(aggregated text), final-STARK tuple)
         self.pregenerate_witnesses = False   # measurement hook (bench.py): witnesses made by prepare_witnesses() are reused
         self._witness_cache = {}
 
@@ -262,9 +274,21 @@ class Engine:
             self._free_be = (n_streams, free_qs, [bes[d] for d in range(ndev)])
         free_qs, uploaders = self._free_be[1], self._free_be[2]
 
+        # processing order: with speculation the two proofs the client aggregates -- the first and the last -- are proven first
+        order = list(range(len(chunks)))
+        speculate = (self.cfg.speculate_recursion and len(chunks) >= 4 and not self.cfg.aggregate_all_chunks and self.cfg.native_prover
+                     and hasattr(self.be, "prove_native"))
+        if speculate:
+            order = [0, len(chunks) - 1] + order[1:-1]
+        self._spec = {}
+        spec_pool = ThreadPoolExecutor(max_workers=1) if speculate else None
+        spec_state = {"texts": {}, "fut": None, "lock": threading.Lock()}
         # device-made witnesses: one recurrence walk per GPU over the chunks it will prove, started now on a thread of its own
         n_host = min(len(chunks), self.cfg.witness_threads)
-        dev_witness = (self.cfg.witness == "device" and not self.pregenerate_witnesses and len(chunks) > n_host
+        host_set = set(order[:n_host])
+        # (the walk is one wave per chunk and takes what ONE chunk takes -- 0.4 s at 2^20 rows, 1.6 s at 2^22 -- whatever the chunk count: it pays
+        # where the host threads would need more than two rounds of chunks)
+        dev_witness = (self.cfg.witness == "device" and not self.pregenerate_witnesses and len(chunks) > 2 * n_host
                        and all(hasattr(u, "synth_checkpoints") for u in uploaders)
                        and len({(ch["air"], ch["logn"], len(ch.get("bind") or [])) for ch in chunks}) == 1
                        and AIR.get_air(chunks[0]["air"]).trace_kind in (1, 3))
@@ -273,7 +297,7 @@ class Engine:
             ck_pool = ThreadPoolExecutor(max_workers=ndev)
             air0 = AIR.get_air(chunks[0]["air"])
             for d in range(ndev):
-                mine = [i for i in range(n_host, len(chunks)) if i % ndev == d]
+                mine = [i for i in range(len(chunks)) if i not in host_set and i % ndev == d]
                 if mine:
                     ck_futs[d] = (ck_pool.submit(uploaders[d].synth_checkpoints, air0, chunks[0]["logn"], [chunks[i]["seed"] for i in mine],
                                                  [chunks[i].get("bind") or [] for i in mine]), {i: k for k, i in enumerate(mine)})
@@ -288,7 +312,7 @@ class Engine:
                 if hasattr(up, "prefetch_trace"):
                     trace = up.prefetch_trace(trace)
                 return air, trace, pubs, 0.0, "host"
-            if dev_witness and i >= n_host:
+            if dev_witness and i not in host_set:
                 fut, index = ck_futs[i % ndev]
                 ck = fut.result()
                 t0 = time.perf_counter()
@@ -336,13 +360,22 @@ class Engine:
             self.stage_timings["%s/%d" % (task_id, i)] = tm
             if self.metrics is not None:
                 self.metrics.record_proof(tm, ch["logn"], self.cfg.logb, air.width)
+            if speculate and i in (0, len(chunks) - 1):
+                with spec_state["lock"]:
+                    spec_state["texts"][i] = text
+                    if len(spec_state["texts"]) == 2 and spec_state["fut"] is None:
+                        spec_state["fut"] = spec_pool.submit(self._speculate, batch_id, spec_state["texts"][0], spec_state["texts"][len(chunks) - 1])
             return {"chunk_id": i, "proof_key": "chunk-%s-%d" % (task_id, i), "proof": text}
 
         with ThreadPoolExecutor(max_workers=max(1, min(self.cfg.witness_threads, len(chunks)))) as wpool, \
                 ThreadPoolExecutor(max_workers=n_streams) as ppool:
-            wfuts = [wpool.submit(witness_bounded, i, ch) for i, ch in enumerate(chunks)]
-            pfuts = [ppool.submit(prove_chunk, i, ch, wfuts[i]) for i, ch in enumerate(chunks)]
-            out = [f.result() for f in pfuts]
+            wfuts = {i: wpool.submit(witness_bounded, i, chunks[i]) for i in order}
+            pfuts = {i: ppool.submit(prove_chunk, i, chunks[i], wfuts[i]) for i in order}
+            out = [pfuts[i].result() for i in range(len(chunks))]
+        if spec_pool is not None:
+            if spec_state["fut"] is not None:
+                spec_state["fut"].result()         # never raises (_speculate keeps what it has); the next request finds it finished
+            spec_pool.shutdown()
         if ck_pool is not None:
             for fut, _ in ck_futs.values():
                 fut.result().free()
@@ -351,6 +384,23 @@ class Engine:
         while len(self._batch_chunk_proofs) > 4:
             self._batch_chunk_proofs.pop(next(iter(self._batch_chunk_proofs)))
         return out
+
+    def _speculate(self, batch_id, p_first, p_last):
+        """the aggregated proof of (first, last) and its final STARK, made while the rest of the batch is proven (cfg.speculate_recursion);
+        kept under the digests of their inputs.  Whatever fails here is simply not there when the request comes."""
+        try:
+            if self._be_spec is None:
+                self._be_spec = self._factory()
+            t0 = time.perf_counter()
+            text = self._aggregate(batch_id, p_first, p_last, be=self._be_spec)
+            tm = dict(self.stage_timings.get("aggregate/" + batch_id, {}))
+            tm["made-during-chunk-proofs"] = time.perf_counter() - t0
+            self._spec["agg"] = ((self._digest(p_first), self._digest(p_last)), text, tm)
+            t0 = time.perf_counter()
+            fin = self._final_stark(text)
+            self._spec["final"] = (self._digest(text), fin + (time.perf_counter() - t0,))
+        except Exception:       # a proof that does not aggregate is reported when the client asks for it, by the ordinary path
+            pass
 
     # ---- GenAggregatedProof
     @staticmethod
@@ -447,7 +497,7 @@ class Engine:
         timings["verifier-stark"] = time.perf_counter() - t0
         return shape, vair, params, text
 
-    def _aggregate(self, batch_id, p1, p2):
+    def _aggregate(self, batch_id, p1, p2, be=None):
         """GenAggregatedProof: a STARK whose witness is the verification trace of the two recursive proofs (every Poseidon
         permutation of their Merkle paths and transcripts), public inputs = their roots, indices, opened values and transcripts
         (stark/verifier_air.py).  With one chunk the client sends the same proof twice (provider.rs:386-387): it is then verified
@@ -455,6 +505,12 @@ class Engine:
         the inner proofs, what they aggregated travels along as "children") -- "recursive proofs" in the contract's words."""
         if not p1 or not p2:
             raise ValueError("empty recursive proof")
+        if be is None:
+            hit = self._spec.get("agg")
+            if hit is not None and hit[0] == (self._digest(p1), self._digest(p2)):      # made while the batch was being proven
+                self.stage_timings["aggregate/" + batch_id] = dict(hit[2], **{"answered-from-speculation": 1.0})
+                return hit[1]
+            be = self.be
         try:
             texts = [p1] if p1 == p2 else [p1, p2]
             known = self._batch_chunk_proofs.get(batch_id)
@@ -492,7 +548,7 @@ class Engine:
         except (json.JSONDecodeError, TypeError, KeyError, IndexError, AssertionError) as e:
             raise ValueError("recursive proof is not a proof of this prover: %s" % e)
         tm = {}
-        shape, vair, params, text = self._prove_merkle_verifier(proofs, agg_params, self.be, tm, inner_air, prepared)
+        shape, vair, params, text = self._prove_merkle_verifier(proofs, agg_params, be, tm, inner_air, prepared)
         self.stage_timings["aggregate/" + batch_id] = tm
         if self.metrics is not None:
             for k, v in tm.items():
@@ -591,6 +647,17 @@ class Engine:
         #    A recursive proof that is not an aggregated proof of this service (a client of another prover) cannot be verified
         #    here and is an application error (the client retries: provider.rs:504-523).
         t0 = time.perf_counter()
+        hit = self._spec.get("final")
+        if hit is not None and hit[0] == self._digest(recursive_proof):       # made while the batch was being proven
+            fshape, fair, fp, final_stark, tmf, openings, t_made = hit[1]
+            tmf = dict(tmf, **{"made-during-chunk-proofs": t_made, "answered-from-speculation": 1.0})
+        else:
+            fshape, fair, fp, final_stark, tmf, openings = self._final_stark(recursive_proof)
+        t_fs = time.perf_counter() - t0
+        return self._final_wrap(batch_id, aggregator_addr, fair, fp, final_stark, tmf, openings, t_fs)
+
+    def _final_stark(self, recursive_proof):
+        """(shape, AIR, parameters, text, timings, binary openings) of the final STARK over an aggregated proof text"""
         try:
             _, agg, prep = self._parse_and_prepare(recursive_proof)
             outer = agg["stark"]
@@ -606,7 +673,12 @@ class Engine:
             raise ValueError("recursive proof is not an aggregated proof of this prover (%s)" % e)
         tmf = {}
         fshape, fair, fp, final_stark = self._prove_merkle_verifier([outer], lambda sh: self.final_stark_params(outer), self.be_bn128, tmf, agg_air, [prep])
-        t_fs = time.perf_counter() - t0
+        openings = None
+        if self.cfg.native_prover and hasattr(self.be_bn128, "stark_openings"):
+            openings = self.be_bn128.stark_openings()       # the prover's own binary record of what the text carries: no text round trip
+        return fshape, fair, fp, final_stark, tmf, openings
+
+    def _final_wrap(self, batch_id, aggregator_addr, fair, fp, final_stark, tmf, openings, t_fs):
         self.final_starks[batch_id] = final_stark
         while len(self.final_starks) > 4:
             self.final_starks.pop(next(iter(self.final_starks)))
@@ -619,9 +691,7 @@ class Engine:
             aux = int(aggregator_addr or "0")
         except ValueError:
             aux = int(hashlib.sha256((aggregator_addr or "").encode()).hexdigest(), 16)
-        if self.cfg.native_prover and hasattr(self.be_bn128, "stark_openings"):
-            openings = self.be_bn128.stark_openings()       # the prover's own binary record of what the text carries: no text round trip
-        else:
+        if openings is None:
             openings = WC.openings_record(json.loads(final_stark), wc.layout)
         set_idx, set_val = native.wrap_assign(wc.script, openings, aux % bn254.R)
         t_wit = time.perf_counter() - t0
