@@ -313,8 +313,9 @@ def main():
             tw1 = first and plan.get("first_pass_table", False)
             mode = (3 if tw1 else 1) if first else (0 if last else 1)   # forward transform: table passes in the middle, plain last pass
             logt = {1: 0, 2: 1, 4: 2, 8: 3, 16: 4, 32: 5}[ps["tile"]]
-            name = "ntt_pass2_kernel<%d, %d, %d, %d, %s, false, %d, false>" % (ps["rounds"][0], ps["rounds"][1], ps["rounds"][2], logt,
-                                                                                 "true" if first else "false", mode)
+            # <A1, A2, A3, LOGT, TRANSPOSE, PADDED, MODE, BIG, LIMB>: the canonical-arithmetic instantiations (knob ntt_limb = 0, the default)
+            name = "ntt_pass2_kernel<%d, %d, %d, %d, %s, false, %d, false, false>" % (ps["rounds"][0], ps["rounds"][1], ps["rounds"][2], logt,
+                                                                                        "true" if first else "false", mode)
             ms_l = by_pass.get(i, [])
             assert all(abs(rl) == ps["radix_log"] for rl, _ in passes[i::npass]), "pass timings out of step with the plan"
             a_ms = sum(ms_l) / len(ms_l) if ms_l else None
