@@ -462,6 +462,7 @@ int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value) {
     else if (!strcmp(key, "ntt_order")) ctx->tune_ntt_order = value;
     else if (!strcmp(key, "ntt_tw1")) ctx->tune_ntt_tw1 = value;
     else if (!strcmp(key, "ntt_limb")) ctx->tune_ntt_limb = value;
+    else if (!strcmp(key, "lde_seam")) ctx->tune_lde_seam = value;
     else if (!strcmp(key, "merkle_coop_log")) ctx->tune_merkle_coop_log = value;
     else if (!strcmp(key, "p254_bulk_log")) ctx->tune_p254_bulk_log = value;
     else { ctx->err = "unknown tuning key"; return ZP_ERR_ARG; }
@@ -531,7 +532,7 @@ int32_t zp_ntt_plan_json(zp_ctx *ctx, int32_t logn, char *buf, size_t buflen) {
         const NttPass &p = pl->pass[i];
         if (i) s += ", ";
         s += "{\"radix_log\": " + std::to_string(p.L) + ", \"rounds\": [" + std::to_string(p.A1) + ", " +
-             std::to_string(p.A2) + ", " + std::to_string(p.A3) + "], \"tile\": " + std::to_string(p.L == 8 ? (1 << ctx->tune_logt) : (1 << p.logT)) + "}";
+             std::to_string(p.A2) + ", " + std::to_string(p.A3) + "], \"tile\": " + std::to_string(p.L == 8 ? (1 << ctx->tune_logt) : p.L == 9 ? (1 << ctx->tune_logt9) : (1 << p.logT)) + "}";
     }
     s += "], \"first_pass_table\": ";   // the transposing pass multiplies by the full precomputed table (MODE 3) instead of per-lane chains
     s += (pl->npass >= 1 && logn > 12 && !pl->tw1_unavailable && logn <= ctx->tune_ntt_tw1 && logn <= 28 && pl->pass[0].A3 == 0 && pl->pass[0].L >= 7) ? "true" : "false";

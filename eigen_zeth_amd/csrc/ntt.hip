@@ -196,12 +196,10 @@ __device__ __forceinline__ gl_l4 mul_c16_l4(int e, const gl_l4 &d) {   // e is a
         default: return gl_l4_mul_c16<7>(d);
     }
 }
-// x[p] receives DFT_c[brev(p)] of the canonical values v[0 .. 2^A), |limbs| < 2^(24 + A)
+// the A butterfly levels on limb-form values: x[p] <- DFT_c[brev(p)], limbs grow by one bit per level
 template <int A>
-__device__ __forceinline__ void dif_shift_l4(const u64 *v, gl_l4 *x) {
+__device__ __forceinline__ void dif_levels_l4(gl_l4 *x) {
     static_assert(A >= 2 && A <= 4, "radix 4, 8 or 16");
-#pragma unroll
-    for (int i = 0; i < (1 << A); i++) x[i] = gl_l4_from(v[i]);
 #pragma unroll
     for (int s = 0; s < A; s++) {
         const int half = 1 << (A - 1 - s);
@@ -213,6 +211,13 @@ __device__ __forceinline__ void dif_shift_l4(const u64 *v, gl_l4 *x) {
             x[i0 + half] = mul_c16_l4((t % half) * (8 / half), gl_l4_sub(a, b));
         }
     }
+}
+// x[p] receives DFT_c[brev(p)] of the canonical values v[0 .. 2^A), |limbs| < 2^(24 + A)
+template <int A>
+__device__ __forceinline__ void dif_shift_l4(const u64 *v, gl_l4 *x) {
+#pragma unroll
+    for (int i = 0; i < (1 << A); i++) x[i] = gl_l4_from(v[i]);
+    dif_levels_l4<A>(x);
 }
 // the LDS record of a factor: balanced words of w B^i, i < 4 (32 bytes)
 __device__ __forceinline__ gl_w4 w4_load(const gl_w4 *p) {
@@ -582,6 +587,147 @@ ntt_pass2_kernel(PassArgs a, int tiles_per_wg) {
     }
 }
 
+// ---- the seam of an extension (blow-up 2): the LAST pass of the inverse transform and the FIRST pass of the zero-padded forward transform
+// in one kernel.  The inverse's last radix-256 pass delivers a tile of coefficients { k N/256 + c : k < 256, c in 16 consecutive } -- and
+// the forward transform of 2N points starts with a radix-256 pass over { r 2N/256 + u : r < 128 } (rows 128.. are the zero padding): the
+// same index set, k = 2 r + (u >> log(N/256)), c = u mod N/256.  So one inverse tile IS two forward tiles (k even / k odd), and the
+// scaled coefficients never have to leave the CU: they are handed over through the tile's LDS (the 128 non-zero rows of both forward
+// tiles = the 4 096 elements of the inverse tile), each lane picks up its 2 x 8 non-zero inputs, and the two forward tiles go through
+// the first-pass body (first butterfly level of a half-zero register file: a copy and a shift).  Per column this saves the write and
+// the read of the coefficient buffer (16 N of 136 N bytes; 8 N when the caller wants the coefficients: `coef`), and one launch.
+// Inverse side = ntt_pass2_kernel<4,4,0,4,false,false,2>, forward side = <4,4,0,4,true,true,3>: the same values, bit for bit.
+struct SeamArgs {
+    const u64 *in;          // input of the inverse transform's last pass, columns of N
+    u64 *out;               // output of the forward transform's first pass, columns of 2N
+    u64 *coef;              // scaled coefficients c_i shift^i, columns of N (may be null)
+    const u64 *tws_i, *tws_f;   // w_4096^e of the inverse / the forward plan
+    const u64 *tw1;         // the forward plan's first-pass table, [u * 256 + k]
+    const u64 *csl, *csh;   // coset table of the inverse transform's post-scale
+    u64 scale;              // 1 / N
+    int logn, cslb, j0inv_i, j0inv_f, ncols;
+};
+// No prefetch of the next tile (unlike ntt_pass2_kernel): a tile is three bodies of integer work per load, the other workgroups of the CU cover
+// the one exposed load latency, and the 32 registers it would hold keep the kernel at 128 VGPRs = four waves per SIMD (with them it spilled).
+// (The limb form of gl_limb.hpp was tried here too, this kernel being bound by its integer work: 64 more live registers -- 0.77 ms at two waves
+// per SIMD, 1.37 ms spilling at three, against 0.70 ms: profiles/r4_lde_seam_ab.txt.  Removed.)
+__global__ void __launch_bounds__(256, 4) lde_seam_kernel(SeamArgs a, int tiles_per_wg) {
+    using G = Geo<4, 4, 0, 4>;
+    constexpr int L = 8, R = 256, T = 16, NT = 256, LOGT = 4;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    u64 *tab = lds + R * T;        // 1/N shift^(k N/256)
+    u64 *twr_i = tab + R;          // inter-round twiddles of the inverse pass
+    u64 *twr_f = twr_i + R;        // ... of the forward pass
+    const u64 x8 = blockIdx.x & 7u, jj = blockIdx.x >> 3;
+    const u64 col = jj % (u64)a.ncols, wg = (jj / (u64)a.ncols) * 8 + x8;
+    const int logNR = a.logn - L;                      // log(N / 256): the inverse pass's Pprev, and the split of u
+    const u64 N = 1ULL << a.logn;
+    const u64 *src = a.in + col * N;
+    u64 *dst = a.out + col * (2 * N);
+    u64 *cdst = a.coef ? a.coef + col * N : nullptr;
+    u64 v[16];
+    u64 cw_c[2];                                       // raw halves of shift^c for this lane's column c
+    auto fetch_tile = [&](u64 *r, u64 *cwr, u64 u0, int tid) {
+        const int t = tid & (T - 1), o = tid >> LOGT;
+        const u32 slot0 = (u32)slot_of(o, 0, G::POS1, 4);
+        const u32 lane_bytes = (((u32)slot0 << logNR) + (u32)t) << 3;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const u64 *rowp = src + (((u64)j << G::POS1) << logNR) + u0;      // wave-uniform
+            r[j] = ZP_LDG((const u64 *)((const char *)rowp + lane_bytes));
+        }
+        const u64 c = u0 + (u64)t;
+        cwr[0] = a.csl[c & ((1ULL << a.cslb) - 1)];
+        cwr[1] = a.csh[c >> a.cslb];
+    };
+    const u64 tile0 = wg * tiles_per_wg;
+    {
+        const int tid0 = threadIdx.x;
+        twr_i[tid0] = a.tws_i[tid0 << (12 - L)];
+        twr_f[tid0] = a.tws_f[tid0 << (12 - L)];
+        const u64 ek = (u64)tid0 << logNR;
+        tab[tid0] = gl_mul(a.scale, gl_mul(a.csl[ek & ((1ULL << a.cslb) - 1)], a.csh[ek >> a.cslb]));
+    }
+    lds_barrier();
+#pragma clang loop unroll(disable)
+    for (int it = 0; it < tiles_per_wg; it++) {
+        const u64 u0 = (tile0 + it) << LOGT;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        fetch_tile(v, cw_c, u0, tid);
+        const int t = tid & (T - 1), o = tid >> LOGT;
+        // ---- inverse transform, last pass (radix 256, plain last pass of the plan: no inter-pass twiddle; 1/N and the coset power)
+        dif_shift<4>(v);
+        exchange2<G, 4, G::POS1, 4, G::POS2, 0>(v, lds, twr_i, a.j0inv_i, tid);
+        dif_shift<4>(v);
+        const u64 cw = gl_mul(cw_c[0], cw_c[1]);       // shift^c
+        lds_barrier();                                  // the exchange's reads are done: the tile becomes the hand-over buffer
+#pragma unroll
+        for (int p = 0; p < 16; p += 2) {
+            const int kja = (a.j0inv_i * brev(p, 4)) & 15, kjb = (a.j0inv_i * brev(p + 1, 4)) & 15;
+            const int ka = o + (kja << 4), kb = o + (kjb << 4);           // klow = o for <4,4,0>
+            u64 xa = v[p], xb = v[p + 1];
+            gl_mul2(xa, tab[ka], xb, tab[kb]);
+            gl_mul2(xa, cw, xb, cw);
+            if (cdst) {
+                ZP_STG((u64 *)((char *)(cdst + ((u64)ka << logNR) + u0) + (t << 3)), xa);
+                ZP_STG((u64 *)((char *)(cdst + ((u64)kb << logNR) + u0) + (t << 3)), xb);
+            }
+            // forward tile par = k & 1, row r = k >> 1: [par][r][t]
+            lds[(((ka & 1) << 7) + (ka >> 1)) * T + t] = xa;
+            lds[(((kb & 1) << 7) + (kb >> 1)) * T + t] = xb;
+        }
+        lds_barrier();
+        // this lane's non-zero inputs of both forward tiles: rows r = 16 j + o, j < 8 (rows 128.. are the padding)
+        u64 f1[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            v[j] = lds[((j << 4) + o) * T + t];
+            f1[j] = lds[(128 + (j << 4) + o) * T + t];
+        }
+        lds_barrier();
+        // ---- forward transform of 2N points, first pass, tiles u0f = par * N/256 + u0
+#pragma unroll 1
+        for (int par = 0; par < 2; par++) {
+            if (par) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = f1[j];
+            }
+            // first butterfly level of a half-zero register file: (x + 0, (x - 0) 2^(12 j)); then two radix-8 halves
+#pragma unroll
+            for (int j = 1; j < 8; j++) v[8 + j] = mul_c16(j, v[j]);
+            v[8] = v[0];
+            dif_shift<3>(v);
+            dif_shift<3>(v + 8);
+            exchange2<G, 4, G::POS1, 4, G::POS2, 0>(v, lds, twr_f, a.j0inv_f, tid);
+            dif_shift<4>(v);
+            {
+                const int jr = a.j0inv_f & 15;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int kj = (jr * i) & 15;
+                    lds[G::lpos(slot_of(o, kj, 0, 4), t)] = v[brev(i, 4)];
+                }
+            }
+            const u64 u0f = ((u64)par << logNR) + u0;
+            const u64 *twb = a.tw1 + (u0f << L);
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = twb[i * NT + tid];       // cacheable: the other columns of this tile hit in L2
+            lds_barrier();
+            u64 *blk = dst + (u0f << L);
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const int ia = i * NT + tid, ib = (i + 1) * NT + tid;
+                u64 xa = lds[G::lpos(G::sigma_of_k(ia & ((1 << L) - 1)), ia >> L)];
+                u64 xb = lds[G::lpos(G::sigma_of_k(ib & ((1 << L) - 1)), ib >> L)];
+                gl_mul2(xa, v[i], xb, v[i + 1]);
+                ZP_STG(&blk[ia], xa);
+                ZP_STG(&blk[ib], xb);
+            }
+            lds_barrier();      // the tile is reused by the second forward tile / the next inverse tile
+        }
+    }
+}
+
 // ---- small transforms (N <= 4096): one workgroup per column, radix-2 DIF stages in LDS
 struct SmallArgs {
     const u64 *in;
@@ -916,6 +1062,68 @@ int32_t zpi_get_coset(zp_ctx *ctx, int logn, u64 shift, u64 pre, CosetTable **ou
     return ZP_OK;
 }
 
+// pass i of a plan over w columns: cur (column stride cur_cs, in_valid real elements per column) -> nxt (column stride N)
+static int32_t run_one_pass(zp_ctx *ctx, NttPlan *pl, int i, bool inverse, const NttRunOpts &opts, const u64 *cur, u64 cur_cs, u64 in_valid, u64 *nxt, int w) {
+    const int logn = pl->logn, m = pl->npass;
+    const bool last = (i == m - 1);
+    PassArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = cur;
+    a.out = nxt;
+    a.in_cs = cur_cs;
+    a.out_cs = 1ULL << logn;
+    a.in_valid = in_valid;
+    a.twl = pl->d_twl;
+    a.twh = pl->d_twh;
+    a.lb = pl->lb;
+    a.tws = pl->d_tws;
+    a.tw1 = (i == 0 && logn <= ctx->tune_ntt_tw1) ? pl->d_tw1 : nullptr;
+    a.scale = pl->ninv;
+    a.logn = logn;
+    a.logPprev = pl->pass[i].logPprev;
+    a.j0inv = pl->j0inv;
+    a.flags = last ? 0 : 1;
+    if (last && inverse) a.flags |= 2;
+    if (last && opts.post_scale) {
+        a.flags |= 4;
+        a.csl = opts.post_scale->d_lo;
+        a.csh = opts.post_scale->d_hi;
+        a.cslb = opts.post_scale->lb;
+    }
+    zp_ctx::PassEv ev;
+    if (ctx->profiling) {
+        ZP_HIP(ctx, hipEventCreate(&ev.a));
+        ZP_HIP(ctx, hipEventCreate(&ev.b));
+        ev.radix_log = (i == 0) ? -pl->pass[i].L : pl->pass[i].L;
+        ZP_HIP(ctx, hipEventRecord(ev.a, ctx->stream));
+    }
+    ZP_TRY(dispatch_pass(ctx, pl->pass[i], a, i == 0, w));
+    if (ctx->profiling) {
+        ZP_HIP(ctx, hipEventRecord(ev.b, ctx->stream));
+        ctx->pass_events.push_back(ev);
+    }
+    return ZP_OK;
+}
+// the first pass's full table (8 bytes per element of ONE column, shared by all columns and all later calls of this size):
+// built at the first use of a plan by radix-2^7 / 2^8 two-round passes below 2^29 rows
+static int32_t ensure_tw1(zp_ctx *ctx, NttPlan *pl) {
+    const int logn = pl->logn;
+    if (!pl->d_tw1 && !pl->tw1_unavailable && logn > 12 && logn <= ctx->tune_ntt_tw1 && logn <= 28 && pl->pass[0].A3 == 0 && pl->pass[0].L >= 7) {
+        if (hipMalloc((void **)&pl->d_tw1, sizeof(u64) << logn) != hipSuccess) {
+            // the table is an optimisation (8 bytes per row, per plan, per ctx): without it the first pass multiplies by per-lane
+            // twiddle chains (MODE 1), same results.  Clear the sticky error and do not try again for this plan.
+            (void)hipGetLastError();
+            pl->d_tw1 = nullptr;
+            pl->tw1_unavailable = true;
+        } else {
+            hipLaunchKernelGGL(tw1_fill_kernel, dim3((unsigned)(((1ULL << logn) + 255) / 256)), dim3(256), 0, ctx->stream, pl->d_tw1, logn, pl->pass[0].L,
+                               pl->d_twl, pl->d_twh, pl->lb);
+            ZP_HIP(ctx, hipGetLastError());
+        }
+    }
+    return ZP_OK;
+}
+
 int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, bool inverse,
                     const NttRunOpts &opts) {
     ZP_ARG(ctx, logn >= 0 && logn <= 32, "logn must be in [0,32]");
@@ -960,21 +1168,7 @@ int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, b
     if (wc < 1) wc = 1;
     if (wc > W) wc = W;
     const int m = pl->npass;
-    // the first pass's full table (8 bytes per element of ONE column, shared by all columns and all later calls of this size):
-    // built at the first use of a plan by radix-2^7 / 2^8 two-round passes below 2^29 rows
-    if (!pl->d_tw1 && !pl->tw1_unavailable && logn <= ctx->tune_ntt_tw1 && logn <= 28 && pl->pass[0].A3 == 0 && pl->pass[0].L >= 7) {
-        if (hipMalloc((void **)&pl->d_tw1, N * sizeof(u64)) != hipSuccess) {
-            // the table is an optimisation (8 bytes per row, per plan, per ctx): without it the first pass multiplies by per-lane
-            // twiddle chains (MODE 1), same results.  Clear the sticky error and do not try again for this plan.
-            (void)hipGetLastError();
-            pl->d_tw1 = nullptr;
-            pl->tw1_unavailable = true;
-        } else {
-            hipLaunchKernelGGL(tw1_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, pl->d_tw1, logn, pl->pass[0].L,
-                               pl->d_twl, pl->d_twh, pl->lb);
-            ZP_HIP(ctx, hipGetLastError());
-        }
-    }
+    ZP_TRY(ensure_tw1(ctx, pl));
     u64 *s0 = nullptr, *s1 = nullptr;
     if (m >= 2) ZP_TRY(zpi_scratch(ctx, 0, (size_t)wc << logn, &s0));
     if (m >= 3) ZP_TRY(zpi_scratch(ctx, 1, (size_t)wc << logn, &s1));
@@ -986,42 +1180,7 @@ int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, b
         for (int i = 0; i < m; i++) {
             const bool last = (i == m - 1);
             u64 *nxt = last ? d_out + ((u64)c0 << logn) : ((i & 1) ? s1 : s0);
-            PassArgs a;
-            memset(&a, 0, sizeof(a));
-            a.in = cur;
-            a.out = nxt;
-            a.in_cs = cur_cs;
-            a.out_cs = N;
-            a.in_valid = (i == 0) ? in_valid : N;
-            a.twl = pl->d_twl;
-            a.twh = pl->d_twh;
-            a.lb = pl->lb;
-            a.tws = pl->d_tws;
-            a.tw1 = (i == 0 && logn <= ctx->tune_ntt_tw1) ? pl->d_tw1 : nullptr;
-            a.scale = pl->ninv;
-            a.logn = logn;
-            a.logPprev = pl->pass[i].logPprev;
-            a.j0inv = pl->j0inv;
-            a.flags = last ? 0 : 1;
-            if (last && inverse) a.flags |= 2;
-            if (last && opts.post_scale) {
-                a.flags |= 4;
-                a.csl = opts.post_scale->d_lo;
-                a.csh = opts.post_scale->d_hi;
-                a.cslb = opts.post_scale->lb;
-            }
-            zp_ctx::PassEv ev;
-            if (ctx->profiling) {
-                ZP_HIP(ctx, hipEventCreate(&ev.a));
-                ZP_HIP(ctx, hipEventCreate(&ev.b));
-                ev.radix_log = (i == 0) ? -pl->pass[i].L : pl->pass[i].L;
-                ZP_HIP(ctx, hipEventRecord(ev.a, ctx->stream));
-            }
-            ZP_TRY(dispatch_pass(ctx, pl->pass[i], a, i == 0, w));
-            if (ctx->profiling) {
-                ZP_HIP(ctx, hipEventRecord(ev.b, ctx->stream));
-                ctx->pass_events.push_back(ev);
-            }
+            ZP_TRY(run_one_pass(ctx, pl, i, inverse, opts, cur, cur_cs, (i == 0) ? in_valid : N, nxt, w));
             cur = nxt;
             cur_cs = N;
         }
@@ -1044,6 +1203,83 @@ int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn,
     int wc = (int)((1ULL << (ctx->tune_ntt_chunk_log > 0 ? ctx->tune_ntt_chunk_log : 27)) >> logn);
     if (wc < 1) wc = 1;
     if (wc > W) wc = W;
+    // ---- blow-up 2 with matching radix-256 passes on both sides of the seam: the inverse transform's last pass and the forward
+    // transform's first pass run as ONE kernel (lde_seam_kernel) and the scaled coefficients never travel (knob lde_seam)
+    // Measured (profiles/r4_lde_seam_ab.txt, 2^24 x 32): 19.5 -> 18.7 ms without the coefficient store -- the fused kernel does three tile
+    // bodies of integer work for three units of traffic and is bound by the former (0.70 ms against 0.73 ms for the two launches it replaces,
+    // and the forward transform's remaining passes run on fewer launches): a pass of this library is BALANCED between its integer work and its
+    // traffic, so taking away either alone buys little.  On by default where the caller does not want the coefficients (knob lde_seam: 0 never,
+    // 1 default, 2 always).
+    if (logb == 1 && (ctx->tune_lde_seam == 2 || (ctx->tune_lde_seam == 1 && !d_coef)) && ctx->tune_logt == 4 && logn >= 16 && logn + 1 <= 28 && logn + 1 <= ctx->tune_ntt_tw1) {
+        NttPlan *pi, *pf;
+        ZP_TRY(zpi_get_plan(ctx, logn, true, &pi));
+        ZP_TRY(zpi_get_plan(ctx, logn + 1, false, &pf));
+        ZP_TRY(ensure_tw1(ctx, pf));
+        const NttPass &li = pi->pass[pi->npass - 1], &ff = pf->pass[0];
+        const int tpw = 2;
+        if (pi->npass >= 2 && pf->npass >= 2 && li.L == 8 && li.A1 == 4 && li.A2 == 4 && li.A3 == 0 && ff.L == 8 && ff.A1 == 4 && ff.A2 == 4 && ff.A3 == 0 &&
+            pf->d_tw1 && (((N >> 12) / tpw) & 7u) == 0) {
+            const int mi = pi->npass, mf = pf->npass;
+            const int wf = wc >= 2 ? wc / 2 : 1;                      // columns per forward sub-chunk (2N rows each)
+            size_t need = (size_t)wc << logn;
+            if (((size_t)wf << (logn + 1)) > need) need = (size_t)wf << (logn + 1);
+            u64 *s0 = nullptr, *s1 = nullptr, *s2 = nullptr;
+            ZP_TRY(zpi_scratch(ctx, 0, need, &s0));
+            ZP_TRY(zpi_scratch(ctx, 1, need, &s1));
+            if (mf >= 3) ZP_TRY(zpi_scratch(ctx, 2, (size_t)wf << (logn + 1), &s2));
+            NttRunOpts none;
+            for (int c0 = 0; c0 < W; c0 += wc) {
+                const int w = (W - c0 < wc) ? (W - c0) : wc;
+                const u64 *cur = d_in + (u64)c0 * N;
+                for (int i = 0; i + 1 < mi; i++) {                     // the inverse transform up to its last pass
+                    u64 *nxt = (i & 1) ? s1 : s0;
+                    ZP_TRY(run_one_pass(ctx, pi, i, true, none, cur, N, N, nxt, w));
+                    cur = nxt;
+                }
+                u64 *seam_out = (cur == s0) ? s1 : s0;
+                for (int h0 = 0; h0 < w; h0 += wf) {
+                    const int wh = (w - h0 < wf) ? (w - h0) : wf;
+                    SeamArgs sa;
+                    memset(&sa, 0, sizeof(sa));
+                    sa.in = cur + (u64)h0 * N;
+                    sa.out = seam_out;
+                    sa.coef = d_coef ? d_coef + (u64)(c0 + h0) * N : nullptr;
+                    sa.tws_i = pi->d_tws;
+                    sa.tws_f = pf->d_tws;
+                    sa.tw1 = pf->d_tw1;
+                    sa.csl = ct->d_lo;
+                    sa.csh = ct->d_hi;
+                    sa.cslb = ct->lb;
+                    sa.scale = pi->ninv;
+                    sa.logn = logn;
+                    sa.j0inv_i = pi->j0inv;
+                    sa.j0inv_f = pf->j0inv;
+                    sa.ncols = wh;
+                    zp_ctx::PassEv ev;
+                    if (ctx->profiling) {
+                        ZP_HIP(ctx, hipEventCreate(&ev.a));
+                        ZP_HIP(ctx, hipEventCreate(&ev.b));
+                        ev.radix_log = 88;                              // the seam: inverse radix 2^8 + forward radix 2^8
+                        ZP_HIP(ctx, hipEventRecord(ev.a, ctx->stream));
+                    }
+                    hipLaunchKernelGGL(lde_seam_kernel, dim3((unsigned)(((N >> 12) / tpw) * (u64)wh)), dim3(256), (size_t)(256 * 16 + 3 * 256) * sizeof(u64), ctx->stream, sa, tpw);
+                    ZP_HIP(ctx, hipGetLastError());
+                    if (ctx->profiling) {
+                        ZP_HIP(ctx, hipEventRecord(ev.b, ctx->stream));
+                        ctx->pass_events.push_back(ev);
+                    }
+                    const u64 *fc = seam_out;                           // the forward transform from its second pass on
+                    u64 *out = d_out + ((u64)(c0 + h0) << (logn + 1));
+                    for (int i = 1; i < mf; i++) {
+                        u64 *nxt = (i == mf - 1) ? out : s2;
+                        ZP_TRY(run_one_pass(ctx, pf, i, false, none, fc, 2 * N, 2 * N, nxt, wh));
+                        fc = nxt;
+                    }
+                }
+            }
+            return ZP_OK;
+        }
+    }
     u64 *scaled = nullptr;
     if (!d_coef) ZP_TRY(zpi_scratch(ctx, 2, (size_t)wc << logn, &scaled));
     for (int c0 = 0; c0 < W; c0 += wc) {

@@ -55,3 +55,33 @@ def test_limb_form_equals_canonical_form_at_the_bench_plan(prover):
     finally:
         prover.set_tuning("ntt_limb", 0)
     assert (prover.download(d_a, (W, 1 << logn)) == prover.download(d_b, (W, 1 << logn))).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seam", [0, 2])
+def test_lde_seam_kernel_and_the_two_launch_form_match_the_oracle(prover, seam):
+    """blow-up 2 at a size whose plans meet in radix-256 passes (2^16): the fused seam kernel (knob lde_seam = 2: also with the coefficient store)
+    and the two-launch form (0), extension and scaled coefficients against the oracle"""
+    from oracle import oracle as O
+    logn, W = 16, 5
+    x = O.random_field((W, 1 << logn), 0x5EA0 + seam)
+    d_in, d_out, d_coef = prover.upload(x), prover.alloc(W << (logn + 1)), prover.alloc(W << logn)
+    prover.set_tuning("lde_seam", seam)
+    try:
+        prover.lde(d_in, d_out, logn, 1, W)
+        a = prover.download(d_out, (W, 1 << (logn + 1)))
+        prover.lde(d_in, d_out, logn, 1, W, d_coef=d_coef)
+        b = prover.download(d_out, (W, 1 << (logn + 1)))
+        c = prover.download(d_coef, (W, 1 << logn))
+    finally:
+        prover.set_tuning("lde_seam", 1)
+    want = O.lde(x, 1)
+    assert (a == want).all() and (b == want).all()
+    coef = O.intt(x)
+    from eigen_zeth_amd import native
+    s = int(prover.get_constants(native.ZP_CONST_COSET_SHIFT, 1)[0])
+    P = 0xFFFFFFFF00000001
+    pw = np.ones(1 << logn, dtype=object)
+    for i in range(1, 1 << logn):
+        pw[i] = pw[i - 1] * s % P
+    assert all(int(c[0, i]) == int(coef[0, i]) * int(pw[i]) % P for i in range(0, 1 << logn, 257))
