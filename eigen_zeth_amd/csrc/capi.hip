@@ -463,6 +463,7 @@ int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value) {
     else if (!strcmp(key, "ntt_tw1")) ctx->tune_ntt_tw1 = value;
     else if (!strcmp(key, "ntt_limb")) ctx->tune_ntt_limb = value;
     else if (!strcmp(key, "lde_seam")) ctx->tune_lde_seam = value;
+    else if (!strcmp(key, "seam_tpw")) ctx->tune_seam_tpw = value;
     else if (!strcmp(key, "merkle_coop_log")) ctx->tune_merkle_coop_log = value;
     else if (!strcmp(key, "p254_bulk_log")) ctx->tune_p254_bulk_log = value;
     else { ctx->err = "unknown tuning key"; return ZP_ERR_ARG; }

@@ -314,10 +314,13 @@ class Engine:
                 return air, trace, pubs, 0.0, "host"
             if dev_witness and i not in host_set:
                 fut, index = ck_futs[i % ndev]
-                ck = fut.result()
-                t0 = time.perf_counter()
-                trace, pubs = up.synth_trace_device(air, ch["logn"], ch["seed"], ch.get("bind"), ck, index[i])
-                return air, trace, pubs, time.perf_counter() - t0, "device"
+                try:
+                    ck = fut.result()
+                    t0 = time.perf_counter()
+                    trace, pubs = up.synth_trace_device(air, ch["logn"], ch["seed"], ch.get("bind"), ck, index[i])
+                    return air, trace, pubs, time.perf_counter() - t0, "device"
+                except native.ZpError:          # (device memory, say): the host generator makes the same trace
+                    t0 = time.perf_counter()
             out = None
             if hasattr(up, "witness_buffer"):   # generate straight into page-locked memory: the copy is then plain DMA
                 out = up.witness_buffer(air.width, 1 << ch["logn"])
@@ -378,7 +381,10 @@ class Engine:
             spec_pool.shutdown()
         if ck_pool is not None:
             for fut, _ in ck_futs.values():
-                fut.result().free()
+                try:
+                    fut.result().free()
+                except native.ZpError:
+                    pass
             ck_pool.shutdown()
         self._batch_chunk_proofs[batch_id] = [o["proof"] for o in out]
         while len(self._batch_chunk_proofs) > 4:
@@ -395,7 +401,7 @@ class Engine:
             text = self._aggregate(batch_id, p_first, p_last, be=self._be_spec)
             tm = dict(self.stage_timings.get("aggregate/" + batch_id, {}))
             tm["made-during-chunk-proofs"] = time.perf_counter() - t0
-            self._spec["agg"] = ((self._digest(p_first), self._digest(p_last)), text, tm)
+            self._spec["agg"] = ((batch_id, self._digest(p_first), self._digest(p_last)), text, tm)
             t0 = time.perf_counter()
             fin = self._final_stark(text)
             self._spec["final"] = (self._digest(text), fin + (time.perf_counter() - t0,))
@@ -507,7 +513,7 @@ class Engine:
             raise ValueError("empty recursive proof")
         if be is None:
             hit = self._spec.get("agg")
-            if hit is not None and hit[0] == (self._digest(p1), self._digest(p2)):      # made while the batch was being proven
+            if hit is not None and hit[0] == (batch_id, self._digest(p1), self._digest(p2)):      # made while this batch was being proven
                 self.stage_timings["aggregate/" + batch_id] = dict(hit[2], **{"answered-from-speculation": 1.0})
                 return hit[1]
             be = self.be
