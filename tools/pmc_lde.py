@@ -6,9 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from eigen_zeth_amd.native import Prover
 logn, cols = 24, 8
+keep_coef = not (len(sys.argv) > 1 and sys.argv[1] == "nocoef")      # "nocoef": the caller does not want the coefficients -> the fused seam kernel
 p = Prover(0)
 x = np.random.default_rng(1).integers(0, 2**63, size=(cols, 1 << logn), dtype=np.uint64)
 d = p.upload(x); o = p.alloc(cols << (logn + 1)); c = p.alloc(cols << logn)
 for _ in range(3):
-    p.lde(d, o, logn, 1, cols, d_coef=c)
+    p.lde(d, o, logn, 1, cols, d_coef=c if keep_coef else None)
 p.sync()
