@@ -1215,6 +1215,7 @@ int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn,
         ZP_TRY(zpi_get_plan(ctx, logn, true, &pi));
         ZP_TRY(zpi_get_plan(ctx, logn + 1, false, &pf));
         ZP_TRY(ensure_tw1(ctx, pf));
+        ZP_TRY(ensure_tw1(ctx, pi));
         const NttPass &li = pi->pass[pi->npass - 1], &ff = pf->pass[0];
         const int tpw = ctx->tune_seam_tpw >= 1 ? ctx->tune_seam_tpw : 2;
         if (pi->npass >= 2 && pf->npass >= 2 && li.L == 8 && li.A1 == 4 && li.A2 == 4 && li.A3 == 0 && ff.L == 8 && ff.A1 == 4 && ff.A2 == 4 && ff.A3 == 0 &&
