@@ -1217,7 +1217,7 @@ int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn,
         ZP_TRY(ensure_tw1(ctx, pf));
         ZP_TRY(ensure_tw1(ctx, pi));
         const NttPass &li = pi->pass[pi->npass - 1], &ff = pf->pass[0];
-        const int tpw = ctx->tune_seam_tpw >= 1 ? ctx->tune_seam_tpw : 2;
+        const int tpw = (ctx->tune_seam_tpw == 1 || ctx->tune_seam_tpw == 4) ? ctx->tune_seam_tpw : 2;     // a power of two: divides the tile count
         if (pi->npass >= 2 && pf->npass >= 2 && li.L == 8 && li.A1 == 4 && li.A2 == 4 && li.A3 == 0 && ff.L == 8 && ff.A1 == 4 && ff.A2 == 4 && ff.A3 == 0 &&
             pf->d_tw1 && (((N >> 12) / tpw) & 7u) == 0) {
             const int mi = pi->npass, mf = pf->npass;
