@@ -63,6 +63,10 @@ void zp_destroy(zp_ctx *ctx) {
     for (auto &kv : ctx->prove_fixed) (void)hipFree(kv.second);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     zpi_g16_cache_free(ctx);
+    for (zp_ctx *&h : ctx->msm_helpers) {
+        if (h) zp_destroy(h);
+        h = nullptr;
+    }
     if (ctx->msm_arena) (void)hipFree(ctx->msm_arena);
     if (ctx->d_rc) (void)hipFree(ctx->d_rc);
     if (ctx->d_mds) (void)hipFree(ctx->d_mds);
@@ -463,6 +467,7 @@ int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value) {
     else if (!strcmp(key, "ntt_tw1")) ctx->tune_ntt_tw1 = value;
     else if (!strcmp(key, "ntt_limb")) ctx->tune_ntt_limb = value;
     else if (!strcmp(key, "lde_seam")) ctx->tune_lde_seam = value;
+    else if (!strcmp(key, "g16_parallel")) ctx->tune_g16_parallel = value;
     else if (!strcmp(key, "seam_tpw")) ctx->tune_seam_tpw = value;
     else if (!strcmp(key, "merkle_coop_log")) ctx->tune_merkle_coop_log = value;
     else if (!strcmp(key, "p254_bulk_log")) ctx->tune_p254_bulk_log = value;

@@ -63,6 +63,7 @@ struct zp_ctx {
     // pinned host staging for small transfers (pageable async copies lock/unlock host pages on every call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    zp_ctx *msm_helpers[4] = {nullptr, nullptr, nullptr, nullptr};   // zp_groth16_prove: ctxs (streams, MSM arenas) of the MSMs that run beside the first one
     ZpG16Cache *g16_cache = nullptr;   // zp_r1cs_eval_device: the circuit last used, in HBM (csrc/r1cs.hip; freed by zpi_g16_cache_free)
     int num_cu = 256;
     // experiment knobs (zp_set_tuning): not part of the stable surface
@@ -74,6 +75,7 @@ struct zp_ctx {
     int tune_ntt_limb = 0;        // 1: register butterflies on the four-limb form of gl_limb.hpp (bit-identical, 17-35 % fewer VALU cycles, but 168 VGPRs and 48 KiB of LDS: 3 workgroups per CU instead of 4 -- measured 4 % slower, profiles/r4_ntt_limb_ab.txt)
     int tune_lde_seam = 1;        // blow-up 2 with radix-256 passes on both sides of the seam: the inverse transform's last pass and the forward one's first in ONE kernel (0: two launches through the coefficient buffer)
     int tune_seam_tpw = 2;        // inverse tiles per workgroup of the seam kernel
+    int tune_g16_parallel = 1;    // zp_groth16_prove: the five MSMs of a proof on five streams at once (0: one after the other)
     int tune_ntt_order = 0;       // plan digit order: 0 auto (a radix-512 digit goes last), 1 larger radices first, 2 larger radices last
     int tune_ntt_maxl = 0;        // 0 = 9: largest log2 radix of one NTT pass (10: 1024-thread workgroups, two-pass plans up to 2^20)
     int tune_merkle_coop_log = 0; // 0 = 15: tree levels with <= 2^15 nodes go to the 12-lanes-per-node subtree kernel

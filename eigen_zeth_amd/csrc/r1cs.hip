@@ -825,15 +825,46 @@ int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const 
         const auto t2 = now();
         uint32_t A1[16], B1[16], Cl[16], Ch[16];
         const uint32_t *sc = (const uint32_t *)d_sc;
-        if ((rc = zp_msm_bn254(ctx, d_u1x, sc, n + 2, A1)) != ZP_OK) return done(rc);            // alpha + sum_j w_j u_j + r delta
-        const auto t3 = now();
-        if ((rc = zp_msm_bn254(ctx, d_v1x, (const uint32_t *)d_scv, n_v + 2, B1)) != ZP_OK) return done(rc);   // beta + sum_j w_j v_j + s delta
-        const auto t4 = now();
-        if ((rc = zp_msm_bn254_g2(ctx, d_v2x, (const uint32_t *)d_scv, n_v + 2, out_b)) != ZP_OK) return done(rc);
-        const auto t5 = now();
-        if ((rc = zp_msm_bn254(ctx, d_l1, sc, n, Cl)) != ZP_OK) return done(rc);
-        const auto t6 = now();
-        if ((rc = zp_msm_bn254(ctx, d_h1, (const uint32_t *)da, m - 1, Ch)) != ZP_OK) return done(rc);     // sum_i H_i [tau^i Z(tau) / delta]
+        // The five MSMs are independent and, at 1-2 M points, each is a chain of short launches with two host round trips: they run on five
+        // streams at once -- A on this ctx, the others on helper ctxs of their own (stream + Pippenger arena, kept for the life of the ctx);
+        // everything they read was finished by the synchronisation above.  Knob g16_parallel (0: one after the other).
+        int32_t rcs[5] = {ZP_OK, ZP_OK, ZP_OK, ZP_OK, ZP_OK};
+        double tms[5] = {0, 0, 0, 0, 0};
+        zp_ctx *hc[5] = {ctx, ctx, ctx, ctx, ctx};
+        bool par = ctx->tune_g16_parallel != 0;
+        for (int i = 0; par && i < 4; i++) {
+            if (!ctx->msm_helpers[i] && zp_create(&ctx->msm_helpers[i], ctx->device) != ZP_OK) par = false;
+            if (par) {
+                ctx->msm_helpers[i]->tune_msm_c = ctx->tune_msm_c;
+                ctx->msm_helpers[i]->tune_msm_chunk_log = ctx->tune_msm_chunk_log;
+                hc[i + 1] = ctx->msm_helpers[i];
+            }
+        }
+        if (!par) for (int i = 1; i < 5; i++) hc[i] = ctx;
+        auto job = [&](int k) {
+            const auto ta = now();
+            switch (k) {
+                case 0: rcs[0] = zp_msm_bn254(hc[0], d_u1x, sc, n + 2, A1); break;                                  // alpha + sum_j w_j u_j + r delta
+                case 1: rcs[1] = zp_msm_bn254(hc[1], d_v1x, (const uint32_t *)d_scv, n_v + 2, B1); break;          // beta + sum_j w_j v_j + s delta
+                case 2: rcs[2] = zp_msm_bn254_g2(hc[2], d_v2x, (const uint32_t *)d_scv, n_v + 2, out_b); break;
+                case 3: rcs[3] = zp_msm_bn254(hc[3], d_l1, sc, n, Cl); break;
+                default: rcs[4] = zp_msm_bn254(hc[4], d_h1, (const uint32_t *)da, m - 1, Ch); break;               // sum_i H_i [tau^i Z(tau) / delta]
+            }
+            tms[k] = ms(ta, now());
+        };
+        if (par) {
+            std::thread th[4];
+            for (int k = 1; k < 5; k++) th[k - 1] = std::thread(job, k);
+            job(0);
+            for (auto &x : th) x.join();
+        } else {
+            for (int k = 0; k < 5; k++) job(k);
+        }
+        for (int k = 0; k < 5; k++)
+            if (rcs[k] != ZP_OK) {
+                if (hc[k] != ctx) ctx->err = hc[k]->err;
+                return done(rcs[k]);
+            }
         const auto t7 = now();
         // pi_c = Cl + Ch + s A + r B1 - r s delta: one more (five-point) MSM
         const Fr fr_r = fr_from_std(h_r), fr_s = fr_from_std(h_s);
@@ -850,7 +881,8 @@ int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const 
         memcpy(out_a, A1, 64);
         if (h_ms) {
             h_ms[0] = ms(t0, t1); h_ms[1] = ms(t1, t2); h_ms[2] = ms(t2, now());
-            h_ms[3] = ms(t2, t3); h_ms[4] = ms(t3, t4); h_ms[5] = ms(t4, t5); h_ms[6] = ms(t5, t6); h_ms[7] = ms(t6, t7);
+            for (int k = 0; k < 5; k++) h_ms[3 + k] = tms[k];       // each MSM on its own clock (they overlap; h_ms[2] is their wall time + the tail)
+            (void)t7;
         }
         return done(ZP_OK);
     } catch (...) {

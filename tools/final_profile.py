@@ -16,3 +16,11 @@ for rep in range(4):
     eng.final("w", agg, "BN128", str(1000 + rep))
     print(json.dumps({"rep": rep, "final_ms": round((time.perf_counter() - t0) * 1e3, 1),
                       "stages_ms": {k: round(v * 1e3, 2) for k, v in eng.stage_timings["final/w"].items()}}), flush=True)
+# the five MSMs of the wrap one after the other instead of on five streams (knob g16_parallel)
+eng.be.p.set_tuning("g16_parallel", 0)
+for rep in range(3):
+    t0 = time.perf_counter()
+    eng.final("w", agg, "BN128", str(2000 + rep))
+    print(json.dumps({"g16_parallel": 0, "rep": rep, "final_ms": round((time.perf_counter() - t0) * 1e3, 1),
+                      "stages_ms": {k: round(v * 1e3, 2) for k, v in eng.stage_timings["final/w"].items() if k.startswith("groth16")}}), flush=True)
+eng.be.p.set_tuning("g16_parallel", 1)
