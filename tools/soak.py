@@ -7,7 +7,7 @@ from eigen_zeth_amd.service.server import default_backend_factory
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 logn = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-cfg = EngineConfig(air="chunk64", logn=logn, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_soak"), witness_threads=16)
+cfg = EngineConfig(air="chunk64", logn=logn, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_soak"), witness_threads=int(os.environ.get("ZP_SOAK_WT", "16")))
 eng = Engine(default_backend_factory(0), cfg)
 eng.groth16_keys()
 first = None
