@@ -299,7 +299,7 @@ def main():
         for j, (rl, ms) in enumerate(passes):
             by_kind.setdefault(rl, []).append(ms)
             by_pass.setdefault(j % npass, []).append(ms)       # launches are recorded in order: pass 0 .. npass-1 of every chunk of columns
-        chunk_cols = min(cols, max(1, (1 << int(os.environ.get("ZP_NTT_CHUNK_LOG", "27"))) >> logn))
+        chunk_cols = min(cols, max(1, (1 << int(os.environ.get("ZP_NTT_CHUNK_LOG", "28"))) >> logn))
         # algorithmic bytes of one launch: SURVEY 8d gives 16*N bytes per column transform (ideal single
         # pass); a launch does one of the `npass` passes over chunk_cols columns -> 16*N*chunk/npass
         alg_bytes = 16.0 * N * chunk_cols / npass

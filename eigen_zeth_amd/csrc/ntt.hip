@@ -1161,9 +1161,10 @@ int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, b
         return ZP_OK;
     }
 
-    // chunk the columns so that each ping-pong scratch buffer stays <= 1 GiB (measured: 2^27-element chunks run 10 % faster
-    // than 2^28 at 2^24 rows, 2^26 is best at 2^22 rows -- tools/ntt_chunk_sweep.py, profiles/r2_chunk_sweep.txt)
-    const u64 cap_elems = 1ULL << (ctx->tune_ntt_chunk_log > 0 ? ctx->tune_ntt_chunk_log : 27);
+    // chunk the columns so that each ping-pong scratch buffer stays <= 2 GiB.  2^28 elements per launch since round 4 (profiles/r4_chunk_sweep.txt:
+    // NTT 2^20 .. 2^25 0-3 % faster than at 2^27, the first pass's shared twiddle table now serving 16 columns of a tile; 2^29 adds nothing.
+    // Round 2, before that table, measured the opposite: profiles/r2_chunk_sweep.txt)
+    const u64 cap_elems = 1ULL << (ctx->tune_ntt_chunk_log > 0 ? ctx->tune_ntt_chunk_log : 28);
     int wc = (int)(cap_elems >> logn);
     if (wc < 1) wc = 1;
     if (wc > W) wc = W;
@@ -1200,7 +1201,7 @@ int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn,
     CosetTable *ct;
     ZP_TRY(zpi_get_coset(ctx, logn, shift, 1, &ct));
     // columns go in chunks so that the scaled-coefficient buffer stays <= 2 GiB
-    int wc = (int)((1ULL << (ctx->tune_ntt_chunk_log > 0 ? ctx->tune_ntt_chunk_log : 27)) >> logn);
+    int wc = (int)((1ULL << (ctx->tune_ntt_chunk_log > 0 ? ctx->tune_ntt_chunk_log : 28)) >> logn);
     if (wc < 1) wc = 1;
     if (wc > W) wc = W;
     // ---- blow-up 2 with matching radix-256 passes on both sides of the seam: the inverse transform's last pass and the forward
