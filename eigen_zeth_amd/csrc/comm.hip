@@ -429,17 +429,13 @@ int32_t zp_merkle_commit_sharded(zp_comm *c, const uint64_t *d_cols, size_t M, i
     if (rc == ZP_OK) rc = zp_dev_alloc(ctx, G * 12 * 8, &sub);
     if (rc == ZP_OK) rc = zp_exchange_columns_to_rows(c, d_cols, (size_t)Wl, M, (uint64_t *)pack, (uint64_t *)rows);
     if (rc == ZP_OK) rc = zp_merkle_commit(ctx, (const uint64_t *)rows, Ml, (int32_t)(G * Wl), d_tree_local);
-    std::vector<u64> lvl(G * 4);
+    std::vector<u64> lvl(4);
+    void *top = nullptr;                                     // the top log2(G) levels: the tree over the G sub-roots, on the device in one call
     if (rc == ZP_OK) rc = zp_comm_all_gather(c, d_tree_local + (2 * Ml - 2) * 4, (uint64_t *)sub, 4);
-    if (rc == ZP_OK) rc = zp_d2h(ctx, lvl.data(), sub, G * 32);
-    for (size_t n = G; rc == ZP_OK && n > 1; n >>= 1) {       // top of the tree: node = P(left | right | 0)[0..4)
-        std::vector<u64> st((n / 2) * 12, 0);
-        for (size_t i = 0; i < n / 2; i++) memcpy(&st[12 * i], &lvl[8 * i], 64);
-        rc = zp_h2d(ctx, sub, st.data(), st.size() * 8);
-        if (rc == ZP_OK) rc = zp_poseidon_perm(ctx, (uint64_t *)sub, n / 2);
-        if (rc == ZP_OK) rc = zp_d2h(ctx, st.data(), sub, st.size() * 8);
-        for (size_t i = 0; i < n / 2; i++) memcpy(&lvl[4 * i], &st[12 * i], 32);
-    }
+    if (rc == ZP_OK) rc = zp_dev_alloc(ctx, (2 * G - 1) * 32, &top);
+    if (rc == ZP_OK) rc = zp_merkle_commit_rows(ctx, (const uint64_t *)sub, G, 4, (uint64_t *)top);       // leaves of 4 values are their own digests
+    if (rc == ZP_OK) rc = zp_d2h(ctx, lvl.data(), (const uint64_t *)top + (2 * G - 2) * 4, 32);
+    if (top) (void)zp_dev_free(ctx, top);
     if (rc == ZP_OK) memcpy(h_root4, lvl.data(), 32);
     else (void)zpi_comm_fail(c, rc);                       // whatever failed here, no peer may wait for this rank
     if (pack) (void)zp_dev_free(ctx, pack);
