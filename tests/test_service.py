@@ -481,3 +481,55 @@ def test_get_status_answers_while_replays_queue_behind_a_running_proof(tmp_path,
     finally:
         release.set()
         server.stop(0)
+
+
+def test_hybrid_witness_selection_gives_the_same_batch(tmp_path, cpu_factory):
+    """EngineConfig.witness = "device": the first witness_threads chunks (in processing order) come from the host generator, the others are
+    filled from checkpoints of ONE walk per GPU -- here on a stand-in backend whose "device" fill is the host generator itself, so that the
+    control flow (which chunk takes which path, the index of a chunk in its GPU's checkpoint buffer, the fall-back when the fill fails)
+    runs without a GPU.  The batch must not depend on the path a witness took."""
+    from eigen_zeth_amd import native
+    calls = {"ckpt": [], "fill": [], "fail": 0}
+
+    class Ckpt:
+        def __init__(self, seeds, binds):
+            self.seeds, self.binds = list(seeds), [list(b) for b in binds]
+
+        def free(self):
+            pass
+
+    def factory(fail_fills=False):
+        def make(hash_mode="gl"):
+            be = cpu_factory(hash_mode)
+
+            def synth_checkpoints(air, logn, seeds, binds):
+                calls["ckpt"].append(len(seeds))
+                return Ckpt(seeds, binds)
+
+            def synth_trace_device(air, logn, seed, bind, ck, index):
+                assert ck.seeds[index] == seed and ck.binds[index] == list(bind or [])      # the chunk's own slot of the buffer
+                if fail_fills:
+                    calls["fail"] += 1
+                    raise native.ZpError(-3, "no device memory (stand-in)")
+                calls["fill"].append(seed)
+                return native.synth_trace(air.trace_kind, logn, air.width, seed, bind=bind)
+
+            be.synth_checkpoints, be.synth_trace_device = synth_checkpoints, synth_trace_device
+            return be
+        return make
+
+    def run(fac, witness):
+        cfg = EngineConfig(air="chunk16", logn=6, n_queries=4, fri_final_log=3, pow_bits=4, chunks_per_block=1, prover_streams=2, witness_threads=2,
+                           witness=witness)
+        cfg.crs_dir = str(tmp_path / "crs")
+        eng = Engine(fac, cfg)
+        ch = eng.gen_batch_chunks("b", [3, 4, 5, 6, 7, 8, 9], 12345, "evm")
+        return eng.gen_chunk_proofs("b", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+    host = run(cpu_factory, "host")
+    dev = run(factory(), "device")
+    assert dev == host
+    assert calls["ckpt"] == [5] and len(calls["fill"]) == 5            # 7 chunks, 2 witness threads: two from the host, five filled
+    calls["ckpt"].clear()
+    assert run([factory(), factory()], "device") == host                # two GPUs: one walk each over the chunks it proves
+    assert sorted(calls["ckpt"]) == [2, 3]
+    assert run(factory(fail_fills=True), "device") == host and calls["fail"] == 5      # every fill fails: the host generator takes over
