@@ -175,6 +175,28 @@ def integer_roofline(prover, pass_rows, alg_bytes, elems_per_launch):
         return {"error": repr(e)}
 
 
+_REAL_STDOUT = [None]
+
+
+def _quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries loaded on the way print banners to the C-level stdout (RCCL: five lines of versions
+    at the first communicator): from here on file descriptor 1 is stderr, and emit() writes the result line to the real stdout."""
+    sys.stdout.flush()
+    _REAL_STDOUT[0] = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # what C code buffered for stdout goes where fd 1 points now (stderr), not behind the result line
+    except Exception:
+        pass
+    fd = _REAL_STDOUT[0] if _REAL_STDOUT[0] is not None else 1
+    os.write(fd, (line + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +217,8 @@ def main():
                     help="cpu_baseline leg also times every hot-path stage on GPU and CPU restatement (tools/stage_roofline.py)")
     ap.add_argument("--child-probe", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if not args.child_probe:
+        _quiet_stdout()
 
     if args.child_probe:
         # the engine-level probe in a process of its own, as the service runs: WITHOUT torch.  With torch's CUDA context in the
@@ -389,7 +413,7 @@ def main():
             with out_lock:
                 if rank == 0 and not printed[0]:
                     out["pipeline"] = {"error": "multi-rank probes did not finish within %d s; line printed by the watchdog" % PROBE_LIMIT_S}
-                    print(json.dumps(out), flush=True)
+                    emit(json.dumps(out))
                     printed[0] = True
             os._exit(3)      # a stalled collective is a failure: the line above carries the headline, the exit code says so
         watchdog = threading.Timer(2 if wd_test else PROBE_LIMIT_S, bail)
@@ -474,7 +498,7 @@ def main():
         with out_lock:
             if not printed[0]:
                 out.update(extra)
-                print(json.dumps(out), flush=True)
+                emit(json.dumps(out))
                 printed[0] = True
     if world > 1:
         dist.barrier()
