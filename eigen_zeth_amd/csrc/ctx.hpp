@@ -88,6 +88,7 @@ struct zp_ctx {
     std::multimap<size_t, void *> prove_pool;
     size_t prove_pool_bytes = 0;
     std::map<std::string, u64 *> prove_fixed;
+    std::map<std::string, void *> air_kernels;   // 64-hex-digit program digest -> generated constraint kernel (AIR plug-in ABI): zp_stark_set_air_kernel
     struct DigestEntry { std::vector<uint64_t> words; uint8_t dg[32]; };
     std::vector<DigestEntry> digest_cache;   // SHA-256 of the large constraint programs seen last (csrc/prove.hip: program_digest)
     std::vector<u64> last_openings;          // BN128-hash mode: roots, query indices, opened values and paths of the last proof, binary (zp_stark_openings)

@@ -65,6 +65,7 @@ SIGNATURES = {
                                          C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "zp_poseidon_bn254_sponge": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp]),
     "zp_free_buffer": (C.c_int32, [_vp]),
+    "zp_stark_set_air_kernel": (C.c_int32, [C.c_void_p, _u64p, C.c_size_t, C.c_void_p]),
     "zp_poseidon_sponge": (C.c_int32, [_vp, _u64p, _u64p, C.c_size_t, C.c_size_t, _u64p]),
     "zp_poseidon_sponge_caps": (C.c_int32, [_vp, _u64p, _u64p, C.c_size_t, C.c_size_t, _u64p, _u64p]),
     "zp_deep_quotient_rows": (C.c_int32, [_vp, _vp, C.c_int32, C.c_size_t, _vp, C.c_int32, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, C.c_int32,
@@ -929,6 +930,12 @@ class Prover:
         return lo.value, hi.value, lb.value
 
     # ---- N6
+    def set_air_kernel(self, program, fn):
+        """zp_stark_set_air_kernel: the generated constraint kernel (a ctypes function of the AIR's library, or None) for proofs of `program`"""
+        blob = np.ascontiguousarray(program, dtype=np.uint64)
+        addr = C.cast(fn, C.c_void_p).value if fn is not None else None
+        self._chk(self.lib.zp_stark_set_air_kernel(self.ctx, blob.ctypes.data_as(_u64p), blob.size, addr))
+
     def stark_openings(self):
         """zp_stark_openings: the binary openings of the last BN128-mode proof of this ctx (a copy)"""
         ptr, n = C.c_void_p(), C.c_size_t(0)

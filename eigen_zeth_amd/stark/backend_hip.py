@@ -27,6 +27,7 @@ class HipBackend:
         hash_mode: "gl" = Poseidon-Goldilocks binary trees; "bn128" = Poseidon-BN254 16-ary trees + transcript (final STARK)"""
         assert quotient in ("kernel", "program") and hash_mode in ("gl", "bn128")
         self.quotient_mode = quotient
+        self._native_kernels = set()
         self.hash_mode = hash_mode
         self.p = prover or native.Prover(device)
         self.p.pooling = True   # chunk after chunk has the same shapes: reuse device buffers
@@ -189,6 +190,10 @@ class HipBackend:
         """the whole chunk STARK through zp_stark_prove (one C-ABI call, orchestration in the library's host C++): proof TEXT,
         byte-identical to proof_to_json(prove(...)) over this backend.  trace: host array or a device buffer from prefetch_trace."""
         assert self.hash_mode == params.hash
+        if self.quotient_mode == "kernel" and not air.fixed_cols and air.name not in self._native_kernels:
+            # the one-call prover evaluates this AIR's constraints through its generated kernel too (zp_stark_set_air_kernel)
+            self.p.set_air_kernel(air.program(), self._airlib(air))
+            self._native_kernels.add(air.name)
         d_tr = trace if isinstance(trace, native.DeviceBuffer) else self.p.upload(trace)
         try:
             if self.hash_mode == "bn128":       # zp_stark_prove_bn128: 16-ary Poseidon-BN254 trees, transcript over F_r, no grinding

@@ -245,3 +245,24 @@ def test_compiled_host_answers_gen_final_proof_like_the_service(tmp_path, tables
     (tmp_path / "agg.json").write_text(json.dumps(bad, separators=(",", ":")))
     r = subprocess.run(args[:6] + [str(tmp_path / "proof2.json"), str(tmp_path / "public2.json")], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and not (tmp_path / "proof2.json").exists()
+
+
+def test_one_call_prover_through_the_generated_constraint_kernel(prover, tables):
+    """zp_stark_set_air_kernel: with the AIR's generated kernel registered the one-call prover writes the proof text it writes through the
+    interpreter; NULL forgets the kernel; a program it was not registered for is not affected"""
+    from eigen_zeth_amd.stark import air as AIR
+    from eigen_zeth_amd.stark.backend_hip import HipBackend
+    be = HipBackend(prover=prover)
+    for name, logn in (("chunk64", 12), ("wide8", 10), ("perm", 9), ("fib", 9)):
+        air = AIR.get_air(name)
+        tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 5)
+        d = prover.upload(tr)
+        args = (air.name, air.program(), d, [int(v) for v in pub], logn, 1, 3, 3, 10, 4)
+        prover.set_air_kernel(air.program(), None)
+        a = prover.stark_prove(*args)
+        prover.set_air_kernel(air.program(), be._airlib(air))
+        b = prover.stark_prove(*args)
+        prover.set_air_kernel(air.program(), None)
+        c = prover.stark_prove(*args)
+        d.free()
+        assert a == b == c
