@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import subprocess
 import threading
 
 import numpy as np
@@ -191,8 +192,12 @@ class HipBackend:
         byte-identical to proof_to_json(prove(...)) over this backend.  trace: host array or a device buffer from prefetch_trace."""
         assert self.hash_mode == params.hash
         if self.quotient_mode == "kernel" and not air.fixed_cols and air.name not in self._native_kernels:
-            # the one-call prover evaluates this AIR's constraints through its generated kernel too (zp_stark_set_air_kernel)
-            self.p.set_air_kernel(air.program(), self._airlib(air))
+            # the one-call prover evaluates this AIR's constraints through its generated kernel too (zp_stark_set_air_kernel); a host without the
+            # AIR's library (and without a compiler to make it) simply stays with the interpreter: same proofs
+            try:
+                self.p.set_air_kernel(air.program(), self._airlib(air))
+            except (OSError, RuntimeError, AttributeError, subprocess.CalledProcessError):
+                pass
             self._native_kernels.add(air.name)
         d_tr = trace if isinstance(trace, native.DeviceBuffer) else self.p.upload(trace)
         try:
