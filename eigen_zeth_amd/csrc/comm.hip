@@ -107,6 +107,34 @@ struct zp_comm_group {
         }
         return ZP_ERR_COMM;
     }
+    // The closing rendezvous of a collective.  Unlike barrier() it COUNTS ARRIVALS EVEN WHEN THE GROUP IS POISONED: a rank that wakes with
+    // ZP_ERR_COMM must not return (its caller may free or reuse the buffer it published) while a third rank is still copying from that
+    // buffer -- every rank synchronises its own stream first, then waits here until all of them have, or for drain_ms at most (a rank that
+    // never comes).  Returns what barrier() would: ZP_OK only when everybody arrived and nobody failed.
+    int drain_waiting = 0;
+    unsigned drain_gen = 0;
+    int drain_ms = 5000;
+    int32_t closing_barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const unsigned g = drain_gen;
+        if (++drain_waiting == world) {
+            drain_waiting = 0;
+            drain_gen++;
+            cv.notify_all();
+            return poisoned ? ZP_ERR_COMM : ZP_OK;
+        }
+        const int wait_ms = poisoned ? (drain_ms < timeout_ms ? drain_ms : timeout_ms) : timeout_ms;
+        auto arrived = [&] { return drain_gen != g; };
+        bool woke = cv.wait_for(lk, std::chrono::milliseconds(wait_ms), [&] { return arrived() || poisoned; });
+        if (woke && !arrived() && poisoned)        // poisoned while waiting: give the ranks still copying drain_ms to arrive
+            woke = cv.wait_for(lk, std::chrono::milliseconds(drain_ms < timeout_ms ? drain_ms : timeout_ms), arrived);
+        if (!arrived()) {       // somebody never came: the group is dead (and this generation's count is void)
+            poisoned = true;
+            cv.notify_all();
+            return ZP_ERR_COMM;
+        }
+        return poisoned ? ZP_ERR_COMM : ZP_OK;
+    }
 };
 
 struct zp_comm {
@@ -153,7 +181,9 @@ int32_t local_exchange(zp_comm *c, const void *mine, const std::function<int32_t
         }
         if (rc != ZP_OK) g->fail();
     }
-    const int32_t b2 = g->barrier();
+    // every rank's own copies are complete here (or were never issued); nobody leaves before every peer has stopped reading.  When the
+    // opening barrier failed it failed for every rank (it needs all of them), so nobody copies and there is nothing to wait for.
+    const int32_t b2 = (b1 == ZP_OK) ? g->closing_barrier() : ZP_ERR_COMM;
     if (rc != ZP_OK) return rc;
     if (b1 != ZP_OK || b2 != ZP_OK) {
         c->ctx->err = kDeadText;

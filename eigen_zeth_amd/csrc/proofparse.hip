@@ -100,7 +100,7 @@ bool each_member(Cur &c, F f) {
 
 constexpr int MAX_TREES = 48;
 
-struct Sizes { int n_queries = 0, has_stage2 = 0, n_fri = 0, w[MAX_TREES], d[MAX_TREES]; };
+struct Sizes { int n_queries = 0, has_stage2 = 0, n_fri = 0, w[MAX_TREES] = {}, d[MAX_TREES] = {}; };
 
 // one opening {"values":[..],"path":[[4]..]}: counts (vals == nullptr) or writes
 bool opening(Cur &c, int *w, int *depth, uint64_t *vals, uint64_t *path) {
@@ -108,6 +108,7 @@ bool opening(Cur &c, int *w, int *depth, uint64_t *vals, uint64_t *path) {
     bool got_v = false, got_p = false;
     each_member(c, [&](const char *b, const char *e) {
         if (c.key_is(b, e, "values")) {
+            if (got_v) { c.ok = false; return; }   // a repeated key is not this grammar (and must not restart a count)
             got_v = true;
             if (!c.need('[')) return;
             if (!c.eat(']'))
@@ -121,6 +122,7 @@ bool opening(Cur &c, int *w, int *depth, uint64_t *vals, uint64_t *path) {
                     break;
                 }
         } else if (c.key_is(b, e, "path")) {
+            if (got_p) { c.ok = false; return; }
             got_p = true;
             if (!c.need('[')) return;
             if (!c.eat(']'))
@@ -155,16 +157,23 @@ bool query(Cur &c, Sizes &sz, bool first, uint64_t *index, uint64_t **vals, uint
     Sizes me;
     each_member(c, [&](const char *b, const char *e) {
         auto one = [&](int t) {
-            if (vals) { int w = sz.w[t], d = sz.d[t]; opening(c, &w, &d, vals[t], paths[t]); }
+            if (t < 0 || t >= MAX_TREES) { c.ok = false; return; }
+            if (vals) {
+                // write mode: only the trees the caller sized exist (their pointers are the only initialised ones)
+                if (t >= 2 + sz.has_stage2 + sz.n_fri) { c.ok = false; return; }
+                int w = sz.w[t], d = sz.d[t];
+                opening(c, &w, &d, vals[t], paths[t]);
+            }
             else opening(c, &me.w[t], &me.d[t], nullptr, nullptr);
         };
         const int tq = vals ? 1 + sz.has_stage2 : 2;        // while sizing, slot 1 is kept free for a stage-2 opening (compacted below)
-        if (c.key_is(b, e, "index")) { got_i = true; uint64_t v; if (c.u64v(&v) && index) *index = v; }
-        else if (c.key_is(b, e, "trace")) { got_t = true; one(0); }
-        else if (c.key_is(b, e, "stage2")) { got_s = true; if (vals && !sz.has_stage2) { c.ok = false; return; } one(1); }
-        else if (c.key_is(b, e, "quotient")) { got_q = true; one(tq); }
+        auto once = [&](bool &got) { if (got) c.ok = false; got = true; return c.ok; };   // a repeated key is an error in both passes
+        if (c.key_is(b, e, "index")) { if (!once(got_i)) return; uint64_t v; if (c.u64v(&v) && index) *index = v; }
+        else if (c.key_is(b, e, "trace")) { if (!once(got_t)) return; one(0); }
+        else if (c.key_is(b, e, "stage2")) { if (!once(got_s)) return; if (vals && !sz.has_stage2) { c.ok = false; return; } one(1); }
+        else if (c.key_is(b, e, "quotient")) { if (!once(got_q)) return; one(tq); }
         else if (c.key_is(b, e, "fri")) {
-            got_f = true;
+            if (!once(got_f)) return;
             int li = 0;
             if (!c.need('[')) return;
             if (!c.eat(']'))
@@ -230,7 +239,6 @@ int32_t zp_proof_queries_scan(const char *text, size_t len, size_t *q_begin, siz
     if (zp_json_key_span(text, len, "queries", &b, &e) != ZP_OK) return ZP_ERR_ARG;
     Cur c{text + b, text + e};
     Sizes sz;
-    memset(sz.w, 0, sizeof sz.w); memset(sz.d, 0, sizeof sz.d);
     int nq = 0;
     if (!c.need('[')) return ZP_ERR_ARG;
     if (!c.eat(']'))
@@ -257,7 +265,7 @@ int32_t zp_proof_queries_parse(const char *text, size_t q_begin, size_t q_end, i
     if (T > MAX_TREES) return ZP_ERR_ARG;
     Sizes sz;
     sz.n_queries = n_queries; sz.has_stage2 = has_stage2 ? 1 : 0; sz.n_fri = n_fri;
-    uint64_t *vb[MAX_TREES], *pb[MAX_TREES];
+    uint64_t *vb[MAX_TREES] = {}, *pb[MAX_TREES] = {};
     size_t vo = 0, po = 0;
     for (int t = 0; t < T; t++) {
         if (widths[t] < 0 || depths[t] < 0) return ZP_ERR_ARG;
@@ -269,7 +277,7 @@ int32_t zp_proof_queries_parse(const char *text, size_t q_begin, size_t q_end, i
     Cur c{text + q_begin, text + q_end};
     if (!c.need('[')) return ZP_ERR_ARG;
     for (int q = 0; q < n_queries; q++) {
-        uint64_t *v[MAX_TREES], *p[MAX_TREES];
+        uint64_t *v[MAX_TREES] = {}, *p[MAX_TREES] = {};
         for (int t = 0; t < T; t++) { v[t] = vb[t] + (size_t)q * sz.w[t]; p[t] = pb[t] + (size_t)q * sz.d[t] * 4; }
         if (!query(c, sz, false, index + q, v, p)) return ZP_ERR_ARG;
         if (q + 1 < n_queries && !c.need(',')) return ZP_ERR_ARG;

@@ -841,7 +841,8 @@ int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const 
             }
         }
         if (!par) for (int i = 1; i < 5; i++) hc[i] = ctx;
-        auto job = [&](int k) {
+        auto job = [&](int k) noexcept {       // runs on helper threads: nothing may escape (an exception there would end the process)
+          try {
             const auto ta = now();
             switch (k) {
                 case 0: rcs[0] = zp_msm_bn254(hc[0], d_u1x, sc, n + 2, A1); break;                                  // alpha + sum_j w_j u_j + r delta
@@ -851,18 +852,28 @@ int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const 
                 default: rcs[4] = zp_msm_bn254(hc[4], d_h1, (const uint32_t *)da, m - 1, Ch); break;               // sum_i H_i [tau^i Z(tau) / delta]
             }
             tms[k] = ms(ta, now());
+          } catch (...) {
+            rcs[k] = ZP_ERR_INTERNAL;
+          }
         };
         if (par) {
+            // a thread that cannot be started (EAGAIN) is not fatal: the ones already running are joined, the remaining MSMs run here
             std::thread th[4];
-            for (int k = 1; k < 5; k++) th[k - 1] = std::thread(job, k);
+            int started = 0;
+            try {
+                for (int k = 1; k < 5; k++) { th[k - 1] = std::thread(job, k); started = k; }
+            } catch (...) {
+            }
             job(0);
-            for (auto &x : th) x.join();
+            for (int k = started + 1; k < 5; k++) { hc[k] = ctx; job(k); }
+            for (int k = 1; k <= started; k++) th[k - 1].join();
         } else {
             for (int k = 0; k < 5; k++) job(k);
         }
         for (int k = 0; k < 5; k++)
             if (rcs[k] != ZP_OK) {
-                if (hc[k] != ctx) ctx->err = hc[k]->err;
+                if (rcs[k] == ZP_ERR_INTERNAL && hc[k]->err.empty()) ctx->err = "exception in an MSM of zp_groth16_prove";
+                else if (hc[k] != ctx) ctx->err = hc[k]->err;
                 return done(rcs[k]);
             }
         const auto t7 = now();

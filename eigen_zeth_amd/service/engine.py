@@ -135,6 +135,7 @@ class Engine:
         # (src/prover/provider.rs:671-700): the replay waits here, it never drives the same ctx concurrently.
         self._serial = threading.RLock()
         self._free_be = None    # engine-owned pool of idle proving backends, shared by all calls
+        self._tables_cache = None
         self._be_spec = None    # backend of the speculative aggregation (cfg.speculate_recursion): never in the proving pool
         self._spec = {}         # "agg": ((sha(p1), sha(p2)), text, timings), "final": (sha(aggregated text), final-STARK tuple)
         self.pregenerate_witnesses = False   # measurement hook (bench.py): witnesses made by prepare_witnesses() are reused
@@ -281,6 +282,8 @@ class Engine:
         if speculate:
             order = [0, len(chunks) - 1] + order[1:-1]
         self._spec = {}
+        if speculate:
+            self._tables(self.be)       # read on this thread, before a speculation thread exists (one thread per ctx)
         spec_pool = ThreadPoolExecutor(max_workers=1) if speculate else None
         spec_state = {"texts": {}, "fut": None, "lock": threading.Lock()}
         # device-made witnesses: one recurrence walk per GPU over the chunks it will prove, started now on a thread of its own
@@ -370,22 +373,25 @@ class Engine:
                         spec_state["fut"] = spec_pool.submit(self._speculate, batch_id, spec_state["texts"][0], spec_state["texts"][len(chunks) - 1])
             return {"chunk_id": i, "proof_key": "chunk-%s-%d" % (task_id, i), "proof": text}
 
-        with ThreadPoolExecutor(max_workers=max(1, min(self.cfg.witness_threads, len(chunks)))) as wpool, \
-                ThreadPoolExecutor(max_workers=n_streams) as ppool:
-            wfuts = {i: wpool.submit(witness_bounded, i, chunks[i]) for i in order}
-            pfuts = {i: ppool.submit(prove_chunk, i, chunks[i], wfuts[i]) for i in order}
-            out = [pfuts[i].result() for i in range(len(chunks))]
-        if spec_pool is not None:
-            if spec_state["fut"] is not None:
-                spec_state["fut"].result()         # never raises (_speculate keeps what it has); the next request finds it finished
-            spec_pool.shutdown()
-        if ck_pool is not None:
-            for fut, _ in ck_futs.values():
-                try:
-                    fut.result().free()
-                except native.ZpError:
-                    pass
-            ck_pool.shutdown()
+        try:
+            with ThreadPoolExecutor(max_workers=max(1, min(self.cfg.witness_threads, len(chunks)))) as wpool, \
+                    ThreadPoolExecutor(max_workers=n_streams) as ppool:
+                wfuts = {i: wpool.submit(witness_bounded, i, chunks[i]) for i in order}
+                pfuts = {i: ppool.submit(prove_chunk, i, chunks[i], wfuts[i]) for i in order}
+                out = [pfuts[i].result() for i in range(len(chunks))]
+        finally:
+            # whatever a chunk proof raised: the speculation thread is joined, the device checkpoints are freed, both pools end
+            if spec_pool is not None:
+                if spec_state["fut"] is not None:
+                    spec_state["fut"].result()     # never raises (_speculate keeps what it has); the next request finds it finished
+                spec_pool.shutdown()
+            if ck_pool is not None:
+                for fut, _ in ck_futs.values():
+                    try:
+                        fut.result().free()
+                    except Exception:              # the walk itself failed (nothing to free), or the free did: the ctx reports it on its next call
+                        pass
+                ck_pool.shutdown()
         self._batch_chunk_proofs[batch_id] = [o["proof"] for o in out]
         while len(self._batch_chunk_proofs) > 4:
             self._batch_chunk_proofs.pop(next(iter(self._batch_chunk_proofs)))
@@ -471,9 +477,13 @@ class Engine:
             return self._aggregate(batch_id, p1, p2)
 
     def _tables(self, be):
+        """the Poseidon tables of this prover (configuration: the same for every backend of the engine).  Read ONCE, from the caller's own
+        backend, and kept: the speculation thread (which has a backend of its own) never calls into a ctx another thread is proving on."""
         if hasattr(be, "rc"):
             return be.rc, be.mds
-        return (be.p.get_constants(native.ZP_CONST_POSEIDON_RC, 360), be.p.get_constants(native.ZP_CONST_POSEIDON_MDS, 144))
+        if self._tables_cache is None:
+            self._tables_cache = (be.p.get_constants(native.ZP_CONST_POSEIDON_RC, 360), be.p.get_constants(native.ZP_CONST_POSEIDON_MDS, 144))
+        return self._tables_cache
 
     @staticmethod
     def _header(proof):
