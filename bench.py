@@ -145,32 +145,49 @@ def cpu_baseline(logn, budget_cols):
             "note": "CPU restatement, not the eigen-zkvm prover (parity unpinned, SURVEY.md 8c)"}
 
 
-def integer_roofline(prover, pass_rows, alg_bytes, elems_per_launch):
-    """the integer-VALU roofline next to the HBM one.  VALU instruction counts per unit come from the committed PMC
-    file (profiles/r3_integer_roofline.json, made by tools/integer_roofline.py from rocprofv3 --pmc SQ_INSTS_VALU runs: labelled
-    as such, not re-measured here); the issue ceiling is 1024 SIMDs x 64 lanes x clock / 4 cycles per instruction (every
-    instruction of these kernels is of the 4-cycle class: tools/ubench_isa.hip, profiles/r2_ubench_isa.txt).  frac_int = the time the
-    pure instruction issue of a launch needs / the measured launch time."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r4_integer_roofline.json", "r3_integer_roofline.json", "integer_roofline.json"))
-                 if os.path.exists(q)), os.path.join(ROOT, "profiles", "integer_roofline.json"))
+def integer_roofline(prover, pass_rows, alg_bytes, elems_per_launch, launches_per_step=None, ms_per_step=None):
+    """the integer-VALU roofline next to the HBM one.  VALU instruction counts per element come from the committed PMC
+    file (profiles/r5_integer_roofline.json, made by tools/integer_roofline.py from a rocprofv3 --pmc SQ_INSTS_VALU run: labelled
+    as such, not re-measured here; the counts equal the static ISA counts of profiles/r4_ntt_isa_breakdown.txt); the issue ceiling is
+    1024 SIMDs x 64 lanes x clock / 4 cycles per instruction (every instruction of these kernels is of the 4-cycle class:
+    tools/ubench_isa.hip, profiles/r2_ubench_isa.txt).  frac_int = the time the pure instruction issue of a launch needs / the
+    measured launch time: a number in (0, 1] -- anything above 1 is a unit error in the table (round 4's file divided the count of a
+    16-column launch by 8 columns), and the bench refuses to print it.  `plan` = the same over all launches of one step."""
+    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r5_integer_roofline.json",)) if os.path.exists(q)), None)
     try:
+        if path is None:
+            raise FileNotFoundError("profiles/r5_integer_roofline.json")
         tab = json.load(open(path))
         info = prover.device_info()
         clock = info["clock_khz"] * 1e3
         simds = info["cus"] * 4
         ceiling = simds * 64 * clock / tab.get("cycles_per_valu_instruction", 4.0)      # lane-instructions per second
-        rows = []
+        rows, plan_issue, plan_valu, covered = [], 0.0, 0.0, True
         for r in pass_rows:
             v = tab["ntt_valu_per_element_per_pass"].get(r["kernel"])
             if v is None or not r["avg_launch_ms"]:
+                covered = False
                 continue
             issue_ms = elems_per_launch * v / ceiling * 1e3
+            frac = issue_ms / r["avg_launch_ms"]
+            if not 0.0 < frac <= 1.0:
+                raise ValueError("frac_int %.3f outside (0, 1] for %s: the VALU table's unit does not match the launch" % (frac, r["kernel"]))
             rows.append({"kernel": r["kernel"], "valu_per_element": v, "issue_only_ms": issue_ms, "measured_ms": r["avg_launch_ms"],
-                         "frac_int": issue_ms / r["avg_launch_ms"]})
-        return {"source": os.path.relpath(path, ROOT) + " (PMC SQ_INSTS_VALU x 64 / units, separate profiler run)",
+                         "frac_int": frac})
+            plan_issue += issue_ms * (r["launches"] / float(launches_per_step[1]) if launches_per_step else 0.0)
+            plan_valu += v
+        plan = None
+        if covered and launches_per_step and ms_per_step:
+            # launches_per_step = (launches of ONE pass in a step, steps timed): issue-only time of a whole step
+            plan = {"valu_per_element_all_passes": plan_valu, "issue_only_ms_per_step": plan_issue, "measured_ms_per_step": ms_per_step,
+                    "frac_int": plan_issue / ms_per_step}
+            if not 0.0 < plan["frac_int"] <= 1.0:
+                raise ValueError("plan-level frac_int %.3f outside (0, 1]" % plan["frac_int"])
+        return {"source": os.path.relpath(path, ROOT) + " (PMC SQ_INSTS_VALU x 64 / elements of the launch, separate profiler run)",
                 "issue_ceiling_lane_instr_per_s": ceiling, "clock_hz": clock, "simds": simds,
                 "cycles_per_valu_instruction": tab.get("cycles_per_valu_instruction", 4.0),
-                "ntt_passes": rows, "other_stages_valu_per_unit": tab.get("stages", {})}
+                "table_elements_per_launch_log2": tab.get("ntt_elements_per_launch_log2"),
+                "ntt_passes": rows, "plan": plan, "other_stages_valu_per_unit": tab.get("stages", {})}
     except Exception as e:
         return {"error": repr(e)}
 
@@ -204,8 +221,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=24)
     ap.add_argument("--cols", type=int, default=64, help="columns per GPU (--scaling weak) or in total (--scaling strong)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: --cols columns per GPU; strong: --cols columns in total, cols / N per GPU (BASELINE configs[3]: 64 columns, 8 per GPU)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="weak: --cols columns per GPU; strong: --cols columns in total, cols / N per GPU (BASELINE configs[3]: 64 columns, 8 per GPU). "
+                         "Default: weak on one GPU, STRONG with --gpus > 1 -- the driver passes no flags, and configs[3] is one 2^24 x 64 trace sharded over the GPUs")
     ap.add_argument("--stark-logn", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
@@ -217,6 +235,8 @@ def main():
                     help="cpu_baseline leg also times every hot-path stage on GPU and CPU restatement (tools/stage_roofline.py)")
     ap.add_argument("--child-probe", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
     if not args.child_probe:
         _quiet_stdout()
 
@@ -350,7 +370,7 @@ def main():
                               "frac": (alg_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if a_ms else None})
         slowest = max((r for r in pass_rows if r["avg_launch_ms"]), key=lambda r: r["avg_launch_ms"], default=None)
         traffic, traffic_src = None, None
-        for tp in ("r4_ntt_traffic.json", "r3_ntt_traffic.json", "ntt_traffic.json"):
+        for tp in ("r5_ntt_traffic.json", "r4_ntt_traffic.json"):
             tp = os.path.join(ROOT, "profiles", tp)
             if os.path.exists(tp):
                 try:
@@ -360,7 +380,7 @@ def main():
                     break
                 except Exception:
                     traffic = None
-        integer = integer_roofline(prover, pass_rows, alg_bytes, N * chunk_cols)
+        integer = integer_roofline(prover, pass_rows, alg_bytes, N * chunk_cols, launches_per_step=(None, args.steps), ms_per_step=dev_ms / args.steps)
         out = {
             "metric": "goldilocks_ntt_field_elems_per_s",
             "value": elems_total / wall_max,
@@ -718,7 +738,23 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world, steps=10):
     except Exception as ex:
         res["msm_bn254"] = {"error": repr(ex)}
     perms = ((Wtot + 7) // 8) * Mloc + (Mloc - 1)
+    # lde_ms is the extension AS THE PROVERS ISSUE IT since round 5 (csrc/prove.hip, stark/backend_hip.py: no coefficient store, the
+    # out-of-domain evaluations read the extension -- zp_ood_eval); the form that also stores the scaled coefficients (what rounds 1-4's
+    # provers called) is timed beside it under its own label
+    res["lde_form"] = "zp_lde without a coefficient store = the prover's call (round 5); path: %s" % json.dumps(prover.ntt_plan(logn).get("lde"))
     res["lde_GBs_algorithmic"] = 8.0 * N * 3 * cols / (res["lde_ms"] * 1e-3) / 1e9
+    try:
+        coef = torch.empty((cols, N), dtype=torch.int64, device=dev)
+        prover.lde(x, y, logn, 1, cols, d_coef=coef)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        prover.lde(x, y, logn, 1, cols, d_coef=coef)
+        e1.record()
+        torch.cuda.synchronize()
+        res["lde_with_coefficient_store_ms"] = e0.elapsed_time(e1)
+        del coef
+    except Exception as ex:
+        res["lde_with_coefficient_store_ms"] = repr(ex)
     res["poseidon_perms_per_s_per_gpu"] = perms / (res["merkle_ms"] * 1e-3)
     return res
 

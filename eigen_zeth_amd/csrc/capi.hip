@@ -469,6 +469,7 @@ int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value) {
     else if (!strcmp(key, "lde_seam")) ctx->tune_lde_seam = value;
     else if (!strcmp(key, "g16_parallel")) ctx->tune_g16_parallel = value;
     else if (!strcmp(key, "seam_tpw")) ctx->tune_seam_tpw = value;
+    else if (!strcmp(key, "lde_seam_plans")) ctx->tune_lde_seam_plans = value;
     else if (!strcmp(key, "merkle_coop_log")) ctx->tune_merkle_coop_log = value;
     else if (!strcmp(key, "p254_bulk_log")) ctx->tune_p254_bulk_log = value;
     else { ctx->err = "unknown tuning key"; return ZP_ERR_ARG; }
@@ -544,6 +545,11 @@ int32_t zp_ntt_plan_json(zp_ctx *ctx, int32_t logn, char *buf, size_t buflen) {
     s += (pl->npass >= 1 && logn > 12 && !pl->tw1_unavailable && logn <= ctx->tune_ntt_tw1 && logn <= 28 && pl->pass[0].A3 == 0 && pl->pass[0].L >= 7) ? "true" : "false";
     s += ", \"small_kernel\": ";
     s += (logn <= 12) ? "true" : "false";
+    if (logn + 1 <= 32) {     // the extension (blow-up 2) of columns of this size, as the provers issue it (no coefficient store since round 5)
+        std::string l;
+        ZP_TRY(zpi_lde_plan_json(ctx, logn, 0, &l));
+        s += ", \"lde\": " + l;
+    }
     s += "}";
     ZP_ARG(ctx, s.size() + 1 <= buflen, "buffer too small");
     memcpy(buf, s.c_str(), s.size() + 1);

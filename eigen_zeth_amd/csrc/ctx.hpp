@@ -75,6 +75,7 @@ struct zp_ctx {
     int tune_ntt_limb = 0;        // 1: register butterflies on the four-limb form of gl_limb.hpp (bit-identical, 17-35 % fewer VALU cycles, but 168 VGPRs and 48 KiB of LDS: 3 workgroups per CU instead of 4 -- measured 4 % slower, profiles/r4_ntt_limb_ab.txt)
     int tune_lde_seam = 1;        // blow-up 2 with radix-256 passes on both sides of the seam: the inverse transform's last pass and the forward one's first in ONE kernel (0: two launches through the coefficient buffer)
     int tune_seam_tpw = 2;        // inverse tiles per workgroup of the seam kernel
+    int tune_lde_seam_plans = 1;  // the fused extension may use plans made for it (an inverse plan ending / a forward plan starting in a radix-256 pass) where the default plans do not meet in one (0: default plans only)
     int tune_g16_parallel = 1;    // zp_groth16_prove: the five MSMs of a proof on five streams at once (0: one after the other)
     int tune_ntt_order = 0;       // plan digit order: 0 auto (a radix-512 digit goes last), 1 larger radices first, 2 larger radices last
     int tune_ntt_maxl = 0;        // 0 = 9: largest log2 radix of one NTT pass (10: 1024-thread workgroups, two-pass plans up to 2^20)
@@ -152,6 +153,8 @@ int32_t zpi_d2h_small(zp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 int32_t zpi_h2d_small(zp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 #define ZP_SMALL_COPY (4u << 20)
 int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out);
+int32_t zpi_get_plan_role(zp_ctx *ctx, int logn, bool inverse, int role, NttPlan **out);   // role 1 / 2: ends / starts with a radix-256 pass (csrc/ntt.hip)
+int32_t zpi_lde_plan_json(zp_ctx *ctx, int logn, int want_coef, std::string *out);           // which path zp_lde takes at this size
 int32_t zpi_get_coset(zp_ctx *ctx, int logn, u64 shift, u64 pre, CosetTable **out);
 int32_t zpi_poseidon_sync_tables(zp_ctx *ctx);
 // run the transform on W columns; in/out column strides are 2^logn (or in_valid for zero-padded input)

@@ -17,6 +17,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "ctx.hpp"
 #include "gl_asm.hpp"
@@ -964,10 +965,31 @@ static int32_t upload(zp_ctx *ctx, const std::vector<u64> &h, u64 **d) {
     return ZP_OK;
 }
 
-int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
+// role (the two sides of an extension's seam, zpi_lde): 0 = the default plan; 1 = a plan that ENDS in a radix-256 pass (the inverse
+// transform in front of lde_seam_kernel); 2 = one that STARTS with a radix-256 pass (the forward transform behind it).  The digit 8 is
+// fixed, the other logn - 8 bits are split over as few passes as the default plan would use for them, the first of them >= 7 where that
+// leaves >= 5 for the rest (a first pass of radix >= 2^7 takes its twiddles from the shared table).  ZP_ERR_UNSUPPORTED when that takes
+// more passes than the default plan (the caller then runs the two transforms unfused).
+int32_t zpi_get_plan_role(zp_ctx *ctx, int logn, bool inverse, int role, NttPlan **out) {
     const int maxl = (ctx->tune_ntt_maxl >= 6 && ctx->tune_ntt_maxl <= 12) ? ctx->tune_ntt_maxl : 9;
     const int order = ctx->tune_ntt_order;          // 0: auto, 1: larger digits first, 2: larger digits last
-    const int key = ((logn * 2 + (inverse ? 1 : 0)) * 16 + maxl) * 4 + (order & 3);
+    const int key = (((logn * 2 + (inverse ? 1 : 0)) * 16 + maxl) * 4 + (order & 3)) * 4 + (role & 3);
+    int rdig[6], nr = 0;
+    if (role) {
+        const int r = logn - 8, m_default = (logn + maxl - 1) / maxl;
+        if (logn <= 12 || r < 5 || maxl != 9) return ZP_ERR_UNSUPPORTED;
+        nr = (r + maxl - 1) / maxl;
+        if (1 + nr > m_default || nr > 4) return ZP_ERR_UNSUPPORTED;
+        int rem = r;
+        for (int i = 0; i < nr; i++) {
+            int d = (rem + (nr - i) - 1) / (nr - i);                        // balanced, larger first
+            if (i == 0 && nr >= 2 && d < 7 && rem - 7 >= 5 * (nr - 1)) d = 7;
+            rdig[i] = d;
+            rem -= d;
+        }
+        for (int i = 0; i < nr; i++)
+            if (rdig[i] < 5 || rdig[i] > 9) return ZP_ERR_UNSUPPORTED;
+    }
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) {
         *out = &it->second;
@@ -996,7 +1018,17 @@ int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
     tws[0] = 1;
     for (int i = 1; i < 4096; i++) tws[i] = gl_mul(tws[i - 1], w4096);
     ZP_TRY(upload(ctx, tws, &pl.d_tws));
-    if (logn > 12) {
+    if (logn > 12 && role) {
+        int logP = 0;
+        pl.npass = nr + 1;
+        for (int i = 0; i < pl.npass; i++) {
+            NttPass &p = pl.pass[i];
+            p.L = role == 1 ? (i < nr ? rdig[i] : 8) : (i == 0 ? 8 : rdig[i - 1]);
+            split_digit(p);
+            p.logPprev = logP;
+            logP += p.L;
+        }
+    } else if (logn > 12) {
         const int m = (logn + maxl - 1) / maxl;
         int rem = logn;
         int logP = 0;
@@ -1032,6 +1064,31 @@ int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) {
     auto ins = ctx->plans.emplace(key, pl);
     *out = &ins.first->second;
     return ZP_OK;
+}
+
+int32_t zpi_get_plan(zp_ctx *ctx, int logn, bool inverse, NttPlan **out) { return zpi_get_plan_role(ctx, logn, inverse, 0, out); }
+
+// the two plans of a fused extension (blow-up 2) of 2^logn-row columns: the default plans where they already meet in radix-256 passes,
+// else the seam-role plans (knob lde_seam_plans: 0 = default plans only).  false: no fused path at this size.
+static bool seam_plans(zp_ctx *ctx, int logn, NttPlan **pi, NttPlan **pf) {
+    auto fits = [](const NttPlan *i, const NttPlan *f) {
+        const NttPass &li = i->pass[i->npass - 1], &ff = f->pass[0];
+        return i->npass >= 2 && f->npass >= 2 && li.L == 8 && li.A1 == 4 && li.A2 == 4 && li.A3 == 0 && ff.L == 8 && ff.A1 == 4 && ff.A2 == 4 && ff.A3 == 0;
+    };
+    NttPlan *di = nullptr, *df = nullptr;
+    if (zpi_get_plan(ctx, logn, true, &di) != ZP_OK || zpi_get_plan(ctx, logn + 1, false, &df) != ZP_OK) return false;
+    NttPlan *ci = di, *cf = df;
+    // measured on one box (profiles/r5_lde_seam_plans_ab.txt): the seam plans win 1-3 % from 2^21 rows on ((7,6,8)+(8,7,7) .. (8,7,8)+(8,8,8)) and LOSE
+    // 5-11 % at 2^19 / 2^20, where fixing one digit at 8 leaves radix-32 passes ((6,5,8)+(8,7,5), (7,5,8)+(8,7,6)): default from 2^21 (knob 2: always)
+    if (!fits(ci, cf) && (ctx->tune_lde_seam_plans == 2 || (ctx->tune_lde_seam_plans == 1 && logn >= 21))) {
+        const NttPass &li = di->pass[di->npass - 1], &ff = df->pass[0];
+        if (!(di->npass >= 2 && li.L == 8 && li.A3 == 0) && zpi_get_plan_role(ctx, logn, true, 1, &ci) != ZP_OK) return false;
+        if (!(df->npass >= 2 && ff.L == 8 && ff.A3 == 0) && zpi_get_plan_role(ctx, logn + 1, false, 2, &cf) != ZP_OK) return false;
+    }
+    if (!fits(ci, cf)) return false;
+    *pi = ci;
+    *pf = cf;
+    return true;
 }
 
 int32_t zpi_get_coset(zp_ctx *ctx, int logn, u64 shift, u64 pre, CosetTable **out) {
@@ -1212,15 +1269,14 @@ int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn,
     // traffic, so taking away either alone buys little.  On by default where the caller does not want the coefficients (knob lde_seam: 0 never,
     // 1 default, 2 always).
     if (logb == 1 && (ctx->tune_lde_seam == 2 || (ctx->tune_lde_seam == 1 && !d_coef)) && ctx->tune_logt == 4 && logn >= 16 && logn + 1 <= 28 && logn + 1 <= ctx->tune_ntt_tw1) {
-        NttPlan *pi, *pf;
-        ZP_TRY(zpi_get_plan(ctx, logn, true, &pi));
-        ZP_TRY(zpi_get_plan(ctx, logn + 1, false, &pf));
-        ZP_TRY(ensure_tw1(ctx, pf));
-        ZP_TRY(ensure_tw1(ctx, pi));
-        const NttPass &li = pi->pass[pi->npass - 1], &ff = pf->pass[0];
+        NttPlan *pi = nullptr, *pf = nullptr;
+        const bool have = seam_plans(ctx, logn, &pi, &pf);
+        if (have) {
+            ZP_TRY(ensure_tw1(ctx, pf));
+            ZP_TRY(ensure_tw1(ctx, pi));
+        }
         const int tpw = (ctx->tune_seam_tpw == 1 || ctx->tune_seam_tpw == 4) ? ctx->tune_seam_tpw : 2;     // a power of two: divides the tile count
-        if (pi->npass >= 2 && pf->npass >= 2 && li.L == 8 && li.A1 == 4 && li.A2 == 4 && li.A3 == 0 && ff.L == 8 && ff.A1 == 4 && ff.A2 == 4 && ff.A3 == 0 &&
-            pf->d_tw1 && (((N >> 12) / tpw) & 7u) == 0) {
+        if (have && pf->d_tw1 && (((N >> 12) / tpw) & 7u) == 0) {
             const int mi = pi->npass, mf = pf->npass;
             const int wf = wc >= 2 ? wc / 2 : 1;                      // columns per forward sub-chunk (2N rows each)
             size_t need = (size_t)wc << logn;
@@ -1299,6 +1355,28 @@ int32_t zpi_lde(zp_ctx *ctx, const u64 *d_in, u64 *d_out, u64 *d_coef, int logn,
         fwd.in_valid_log = logn;  // zero padding is implicit: rows >= N read as 0
         ZP_TRY(zpi_ntt_run(ctx, sc, out, logn + logb, w, false, fwd));
     }
+    return ZP_OK;
+}
+
+// what zp_lde(blow-up 2) does at this size, as JSON (zp_ntt_plan_json's "lde" member): whether the seam kernel is taken and the radices
+// on both sides of it
+int32_t zpi_lde_plan_json(zp_ctx *ctx, int logn, int want_coef, std::string *out) {
+    NttPlan *pi = nullptr, *pf = nullptr;
+    const int tpw = (ctx->tune_seam_tpw == 1 || ctx->tune_seam_tpw == 4) ? ctx->tune_seam_tpw : 2;
+    bool seam = (ctx->tune_lde_seam == 2 || (ctx->tune_lde_seam == 1 && !want_coef)) && ctx->tune_logt == 4 && logn >= 16 && logn + 1 <= 28 &&
+                logn + 1 <= ctx->tune_ntt_tw1 && seam_plans(ctx, logn, &pi, &pf) && ((((1ULL << logn) >> 12) / tpw) & 7u) == 0;
+    if (!seam) {
+        if (logn + 1 > 32) return ZP_ERR_ARG;
+        ZP_TRY(zpi_get_plan(ctx, logn, true, &pi));
+        ZP_TRY(zpi_get_plan(ctx, logn + 1, false, &pf));
+    }
+    auto digits = [](const NttPlan *p) {
+        std::string d = "[";
+        for (int i = 0; i < p->npass; i++) d += (i ? ", " : "") + std::to_string(p->pass[i].L);
+        return d + "]";
+    };
+    *out = std::string("{\"blowup\": 2, \"coefficients_stored\": ") + (want_coef ? "true" : "false") + ", \"seam_fused\": " + (seam ? "true" : "false") +
+           ", \"inverse_radix_logs\": " + digits(pi) + ", \"forward_radix_logs\": " + digits(pf) + "}";
     return ZP_OK;
 }
 

@@ -455,10 +455,11 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         tr.absorb_root(rootp);
     }
 
-    // 1. commit the trace (ext / coef have room for the stage-2 columns behind the trace columns)
-    u64 *ext, *coef, *tree1;
+    // 1. commit the trace (ext has room for the stage-2 columns behind the trace columns).  No coefficient buffer since round 5: the
+    //    out-of-domain evaluations come from the resident extension (zp_ood_eval), so the extensions run without their coefficient
+    //    store -- on the fused seam kernel where the plan allows it (csrc/ntt.hip) -- and W N 8 bytes per proof are never written
+    u64 *ext, *tree1;
     PV_TRY(dev.alloc(Wt * M, &ext));
-    PV_TRY(dev.alloc(Wt * N, &coef));
     // BN128 mode: a leaf holds 2^g rows i, i + M', ... of its tree (the column-major matrix reinterpreted as [width 2^g][M'], like a
     // FRI layer), g the largest with width 2^g <= 56 values = one width-17 permutation per leaf (stark/prover.py:
     // bn128_rows_per_leaf_log; Goldilocks mode: g = 0)
@@ -471,7 +472,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     const int gt = rows_per_leaf_log(W), g2 = rows_per_leaf_log(W2);
     const size_t Mt = M >> gt, Wtg = W << gt, M2 = M >> g2, W2g = W2 << g2;
     PV_TRY(dev.alloc(T.tree_words(Mt), &tree1));
-    PV_TRY(zp_lde(ctx, d_trace, (uint64_t *)ext, (uint64_t *)coef, logn, logb, (int32_t)W, shift));
+    PV_TRY(zp_lde(ctx, d_trace, (uint64_t *)ext, nullptr, logn, logb, (int32_t)W, shift));
     PV_TRY(T.commit(ext, Mt, (int)Wtg, tree1));
     u64 root1[4], root2[4] = {0, 0, 0, 0}, rootq[4];
     PV_TRY(T.root(tree1, Mt, root1));
@@ -494,7 +495,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
                 at += 9;
             }
         }
-        PV_TRY(zp_lde(ctx, (const uint64_t *)s2, (uint64_t *)(ext + W * M), (uint64_t *)(coef + W * N), logn, logb, (int32_t)W2, shift));
+        PV_TRY(zp_lde(ctx, (const uint64_t *)s2, (uint64_t *)(ext + W * M), nullptr, logn, logb, (int32_t)W2, shift));
         PV_TRY(dev.alloc(T.tree_words(M2), &tree2));
         PV_TRY(T.commit(ext + W * M, M2, (int)W2g, tree2));
         PV_TRY(T.root(tree2, M2, root2));
@@ -575,24 +576,20 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         PV_TRY(zp_eval_quotient(ctx, h_program, program_words, (const uint64_t *)ext, (const uint64_t *)fixed, logm, logb, (const uint64_t *)pubchal.data(),
                                 (int32_t)pubchal.size(), (const uint64_t *)apow.data(), (const uint64_t *)zhinv.data(), shift, gl_inv(wN), (uint64_t *)dq));
     }
-    PV_TRY(dev.alloc(3 * M, &dqcoef));
-    PV_TRY(zp_intt(ctx, (const uint64_t *)dq, (uint64_t *)dqcoef, logm, 3));       // coefficients of q_c(shift X): c_i shift^i
     int q_logn = logm;
     size_t Wq = 3;
     u64 *treeq;
     PV_TRY(dev.alloc(T.tree_words(M), &treeq));
     if (Q > 1) {
-        // q(x) = sum_j (x / shift)^(jN) qt_j(x): the pieces are slices of the coefficient vector in hand; their LDEs get committed
-        u64 *pcoef, *pad, *pext;
-        PV_TRY(dev.alloc(3 * Q * N, &pcoef));
+        // q(x) = sum_j (x / shift)^(jN) qt_j(x): the pieces are slices of the coefficient vector of q(shift X) (c_i shift^i); their LDEs get
+        // committed.  (Q == 1: the quotient is committed as it stands and never leaves the evaluation form.)
+        u64 *pad, *pext;
+        PV_TRY(dev.alloc(3 * M, &dqcoef));
+        PV_TRY(zp_intt(ctx, (const uint64_t *)dq, (uint64_t *)dqcoef, logm, 3));
         PV_TRY(dev.alloc(3 * Q * M, &pad));
         PV_TRY(zp_dev_zero(ctx, pad, 3 * Q * M * 8));
         for (size_t j = 0; j < Q; j++)
-            for (int c = 0; c < 3; c++) {
-                const u64 *src = dqcoef + c * M + j * N;
-                PV_TRY(zp_d2d(ctx, pcoef + (3 * j + c) * N, src, N * 8));
-                PV_TRY(zp_d2d(ctx, pad + (3 * j + c) * M, src, N * 8));
-            }
+            for (int c = 0; c < 3; c++) PV_TRY(zp_d2d(ctx, pad + (3 * j + c) * M, dqcoef + c * M + j * N, N * 8));
         PV_TRY(dev.alloc(3 * Q * M, &pext));
         PV_TRY(zp_ntt(ctx, (const uint64_t *)pad, (uint64_t *)pext, logm, (int32_t)(3 * Q)));
         PV_TRY(zp_sync(ctx));
@@ -600,7 +597,6 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         dev.release(dq);
         dev.release(dqcoef);
         dq = pext;
-        dqcoef = pcoef;
         q_logn = logn;
         Wq = 3 * Q;
     }
@@ -614,14 +610,14 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     const e3 zeta = tr.challenge();
     PV_TRY(tr.rc);
 
-    // 3. out-of-domain evaluations (coefficient buffers hold c_i shift^i: evaluate at z / shift)
-    const u64 sinv = gl_inv(shift);
+    // 3. out-of-domain evaluations, from the committed extensions themselves (barycentric form, zp_ood_eval): a polynomial of degree < 2^d
+    //    is read on the 2^d-point sub-coset of its extension (row stride M / 2^d); the trace and stage-2 columns at zeta and zeta w in ONE pass
     const e3 zeta_w = e3_scale(zeta, wN);
-    const e3 zs = e3_scale(zeta, sinv), zws = e3_scale(zeta_w, sinv);
     std::vector<u64> ev_all((Wt + Wq) * 3), ev_next(Wt * 3);
-    PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef, logn, (int32_t)Wt, (const uint64_t *)zs.c, (uint64_t *)ev_all.data()));
-    PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef, logn, (int32_t)Wt, (const uint64_t *)zws.c, (uint64_t *)ev_next.data()));
-    PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)dqcoef, q_logn, (int32_t)Wq, (const uint64_t *)zs.c, (uint64_t *)(ev_all.data() + Wt * 3)));
+    PV_TRY(zp_ood_eval(ctx, (const uint64_t *)ext, M, (size_t)1 << logb, (int32_t)Wt, logn, shift, (const uint64_t *)zeta.c, 1, (uint64_t *)ev_all.data(),
+                       (uint64_t *)ev_next.data()));
+    PV_TRY(zp_ood_eval(ctx, (const uint64_t *)dq, M, (size_t)1 << (logm - q_logn), (int32_t)Wq, q_logn, shift, (const uint64_t *)zeta.c, 0,
+                       (uint64_t *)(ev_all.data() + Wt * 3), nullptr));
     tr.absorb(ev_all);
     tr.absorb(ev_next);
     const e3 gamma = tr.challenge();
@@ -1001,15 +997,15 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     }
 
     // 1. trace: LDE of my columns, ONE exchange columns -> rows, local subtree, sub-roots
-    u64 *ext, *coef_l, *tree1;
+    u64 *ext, *tree1;
     ShardTop top1, top2, topq;
     PV_TRY(dev.alloc(Wt * nloc, &ext));            // [Wt][nloc]: ALL columns (trace, then stage 2), my rows
-    PV_TRY(dev.alloc(wl * N, &coef_l));            // coefficients of MY columns: they never move
+    // (no coefficient buffer since round 5: my columns' out-of-domain evaluations come from d_trace itself, zp_ood_eval on the trace domain)
     {
         u64 *extc, *pack;
         PV_TRY(dev.alloc(wl * M, &extc));
         PV_TRY(dev.alloc(wl * M, &pack));
-        PV_TRY(zp_lde(ctx, d_trace, (uint64_t *)extc, (uint64_t *)coef_l, logn, logb, (int32_t)wl, shift));
+        PV_TRY(zp_lde(ctx, d_trace, (uint64_t *)extc, nullptr, logn, logb, (int32_t)wl, shift));
         PV_TRY(zp_exchange_columns_to_rows(comm, (const uint64_t *)extc, wl, M, (uint64_t *)pack, (uint64_t *)ext));
         PV_TRY(zp_sync(ctx));
         dev.release(extc);
@@ -1018,11 +1014,11 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     PV_TRY(shard_commit(comm, ctx, dev, ext, nloc, (int)W, G, &tree1, &top1));
     tr.absorb_root(top1.root);
     std::vector<u64> pubchal(h_pubs, h_pubs + n_pubs);
-    u64 *tree2 = nullptr, *coef2 = nullptr;
+    u64 *tree2 = nullptr, *s2 = nullptr;          // s2: the stage-2 columns on the trace domain (replicated), kept for their out-of-domain evaluations
     if (n_s2) {
         const e3 chal = tr.challenge();
         PV_TRY(tr.rc);
-        u64 *s2, *colb, *ext2;
+        u64 *colb, *ext2;
         PV_TRY(dev.alloc(W2 * N, &s2));
         PV_TRY(dev.alloc(3 * N, &colb));           // the (at most three) witness columns an argument reads, on every rank
         auto column = [&](u64 idx, u64 *dst) -> int32_t {       // broadcast from the rank that owns it
@@ -1046,11 +1042,9 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
             }
         }
         PV_TRY(dev.alloc(W2 * M, &ext2));
-        PV_TRY(dev.alloc(W2 * N, &coef2));
-        PV_TRY(zp_lde(ctx, (const uint64_t *)s2, (uint64_t *)ext2, (uint64_t *)coef2, logn, logb, (int32_t)W2, shift));   // replicated: W2 << W
+        PV_TRY(zp_lde(ctx, (const uint64_t *)s2, (uint64_t *)ext2, nullptr, logn, logb, (int32_t)W2, shift));   // replicated: W2 << W
         ZP_HIP(ctx, hipMemcpy2DAsync(ext + W * nloc, nloc * 8, ext2 + r0, M * 8, nloc * 8, W2, hipMemcpyDeviceToDevice, ctx->stream));
         PV_TRY(zp_sync(ctx));
-        dev.release(s2);
         dev.release(colb);
         dev.release(ext2);
         PV_TRY(shard_commit(comm, ctx, dev, ext + W * nloc, nloc, (int)W2, G, &tree2, &top2));
@@ -1111,43 +1105,37 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
         dev.release(fixed);
         dev.release(fx_l);
     }
-    // the quotient's coefficients are needed whole (its pieces are slices of them): gather the rows, transform on every rank
-    u64 *dqcoef, *dq_rows = dq_l, *treeq;
+    // the quotient is needed whole on every rank: for its out-of-domain evaluation and, with Q > 1, for the coefficients its pieces are slices of
+    u64 *dq_whole, *dq_rows = dq_l, *treeq;       // dq_whole: u64[Wq][M], the committed quotient columns (all rows)
     int q_logn = logm;
     size_t Wq = 3;
     {
-        u64 *gath, *dq_full;
+        u64 *gath;
         PV_TRY(dev.alloc((size_t)G * 3 * nloc, &gath));
-        PV_TRY(dev.alloc(3 * M, &dq_full));
+        PV_TRY(dev.alloc(3 * M, &dq_whole));
         PV_TRY(zp_comm_all_gather(comm, (const uint64_t *)dq_l, (uint64_t *)gath, 3 * nloc));
-        PV_TRY(shard_join(ctx, gath, dq_full, 3, nloc, G));
-        PV_TRY(dev.alloc(3 * M, &dqcoef));
-        PV_TRY(zp_intt(ctx, (const uint64_t *)dq_full, (uint64_t *)dqcoef, logm, 3));
+        PV_TRY(shard_join(ctx, gath, dq_whole, 3, nloc, G));
         PV_TRY(zp_sync(ctx));
         dev.release(gath);
-        dev.release(dq_full);
     }
     if (Q > 1) {
-        u64 *pcoef, *pad, *pext;
-        PV_TRY(dev.alloc(3 * Q * N, &pcoef));
+        u64 *dqcoef, *pad, *pext;
+        PV_TRY(dev.alloc(3 * M, &dqcoef));
+        PV_TRY(zp_intt(ctx, (const uint64_t *)dq_whole, (uint64_t *)dqcoef, logm, 3));
         PV_TRY(dev.alloc(3 * Q * M, &pad));
         PV_TRY(zp_dev_zero(ctx, pad, 3 * Q * M * 8));
         for (size_t j = 0; j < Q; j++)
-            for (int c = 0; c < 3; c++) {
-                const u64 *src = dqcoef + c * M + j * N;
-                PV_TRY(zp_d2d(ctx, pcoef + (3 * j + c) * N, src, N * 8));
-                PV_TRY(zp_d2d(ctx, pad + (3 * j + c) * M, src, N * 8));
-            }
+            for (int c = 0; c < 3; c++) PV_TRY(zp_d2d(ctx, pad + (3 * j + c) * M, dqcoef + c * M + j * N, N * 8));
         PV_TRY(dev.alloc(3 * Q * M, &pext));
         PV_TRY(zp_ntt(ctx, (const uint64_t *)pad, (uint64_t *)pext, logm, (int32_t)(3 * Q)));
         PV_TRY(dev.alloc(3 * Q * nloc, &dq_rows));
         ZP_HIP(ctx, hipMemcpy2DAsync(dq_rows, nloc * 8, pext + r0, M * 8, nloc * 8, 3 * Q, hipMemcpyDeviceToDevice, ctx->stream));   // my rows of the pieces
         PV_TRY(zp_sync(ctx));
         dev.release(pad);
-        dev.release(pext);
         dev.release(dq_l);
         dev.release(dqcoef);
-        dqcoef = pcoef;
+        dev.release(dq_whole);
+        dq_whole = pext;
         q_logn = logn;
         Wq = 3 * Q;
     }
@@ -1156,15 +1144,13 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     const e3 zeta = tr.challenge();
     PV_TRY(tr.rc);
 
-    // 3. out-of-domain evaluations: every rank evaluates ITS coefficient columns, the evaluations are all-gathered
-    const u64 sinv = gl_inv(shift);
+    // 3. out-of-domain evaluations (barycentric form, zp_ood_eval): every rank evaluates ITS trace columns from their values on the trace
+    //    domain (d_trace: shift 1, stride 1), the evaluations are all-gathered; the replicated stage-2 columns and quotient on every rank
     const e3 zeta_w = e3_scale(zeta, wN);
-    const e3 zs = e3_scale(zeta, sinv), zws = e3_scale(zeta_w, sinv);
     std::vector<u64> ev_all((Wt + Wq) * 3), ev_next(Wt * 3);
     {
         std::vector<u64> mine(2 * wl * 3), all((size_t)G * 2 * wl * 3);
-        PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef_l, logn, (int32_t)wl, (const uint64_t *)zs.c, (uint64_t *)mine.data()));
-        PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef_l, logn, (int32_t)wl, (const uint64_t *)zws.c, (uint64_t *)(mine.data() + wl * 3)));
+        PV_TRY(zp_ood_eval(ctx, d_trace, N, 1, (int32_t)wl, logn, 1, (const uint64_t *)zeta.c, 1, (uint64_t *)mine.data(), (uint64_t *)(mine.data() + wl * 3)));
         u64 *dmine, *dall;
         PV_TRY(dev.alloc(mine.size(), &dmine));
         PV_TRY(dev.alloc(all.size(), &dall));
@@ -1179,10 +1165,15 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
         }
     }
     if (W2) {
-        PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef2, logn, (int32_t)W2, (const uint64_t *)zs.c, (uint64_t *)(ev_all.data() + W * 3)));
-        PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)coef2, logn, (int32_t)W2, (const uint64_t *)zws.c, (uint64_t *)(ev_next.data() + W * 3)));
+        PV_TRY(zp_ood_eval(ctx, (const uint64_t *)s2, N, 1, (int32_t)W2, logn, 1, (const uint64_t *)zeta.c, 1, (uint64_t *)(ev_all.data() + W * 3),
+                           (uint64_t *)(ev_next.data() + W * 3)));
+        PV_TRY(zp_sync(ctx));
+        dev.release(s2);
     }
-    PV_TRY(zp_poly_eval_ext(ctx, (const uint64_t *)dqcoef, q_logn, (int32_t)Wq, (const uint64_t *)zs.c, (uint64_t *)(ev_all.data() + Wt * 3)));
+    PV_TRY(zp_ood_eval(ctx, (const uint64_t *)dq_whole, M, (size_t)1 << (logm - q_logn), (int32_t)Wq, q_logn, shift, (const uint64_t *)zeta.c, 0,
+                       (uint64_t *)(ev_all.data() + Wt * 3), nullptr));
+    PV_TRY(zp_sync(ctx));
+    dev.release(dq_whole);
     tr.absorb(ev_all);
     tr.absorb(ev_next);
     const e3 gamma = tr.challenge();

@@ -54,6 +54,126 @@ __global__ void __launch_bounds__(256) poly_eval_ext_kernel(EvalArgs a) {
     if (t < 3) a.partial[(chunk * a.W + col) * 3 + t] = red[t][0];
 }
 
+// ---- p_c(z) (and p_c(z w)) FROM VALUES: barycentric evaluation ------------------------------------------
+// Column c holds P_c(y) = p_c(shift y), deg P_c < n = 2^logn, at y_i = w^i (w of order n), row i at cols[c * cs + i * rs]:
+//     P(y) = (y^n - 1) / n * sum_i P(w^i) u_i(y),       u_i(y) = w^i / (y - w^i)
+// and, the domain being a group,  sum_i P(w^i) w^i / (y w - w^i) = sum_j P(w^(j+1)) u_j(y): the evaluation at the NEXT point y w uses
+// the same weights on the column rotated by one row.  So one pass over the resident extension gives both out-of-domain evaluations of
+// a STARK -- no coefficient buffer is kept for them (round 4 kept 8 N bytes per column and read them twice, csrc/prove.hip), and the
+// LDE that made the columns may run without its coefficient store (the fused seam kernel, csrc/ntt.hip).
+// (1) bary_weights_kernel: u[3][n] for one y, two rows per lane and ONE base-field inversion for both (as deep_quotient_kernel);
+//     a vanishing denominator (y on the domain: excluded by the protocol) raises a flag the host turns into an error.
+// (2) bary_dot_kernel: a block owns BY_ROWS rows x BY_CB columns: a lane loads u_i once and uses it for the BY_CB columns (each
+//     twice: row i for y, row i + 1 for y w); unreduced 160-bit accumulators, one reduction per lane; lanes are summed with wave
+//     shuffles, the four waves through LDS; one partial per (block, column).  (3) bary_reduce_kernel sums the partials of a column.
+#define BY_CB 4
+#define BY_J 16
+#define BY_ROWS (256 * BY_J)
+struct BaryWArgs {
+    u64 *u;                 // [3][n]
+    unsigned int *flag;
+    const u64 *twl, *twh;   // w^e
+    u64 y[3];
+    u64 n;
+    int lb;
+};
+__global__ void __launch_bounds__(256) bary_weights_kernel(BaryWArgs a) {
+    const u64 i0 = ((u64)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i0 >= a.n) return;
+    const bool two = i0 + 1 < a.n;
+    const u64 lm = (1ULL << a.lb) - 1;
+    const u64 w0 = gl_mul(a.twl[i0 & lm], a.twh[i0 >> a.lb]);
+    const u64 w1 = two ? gl_mul(a.twl[(i0 + 1) & lm], a.twh[(i0 + 1) >> a.lb]) : w0;
+    const e3 d0 = e3_make(gl_sub(a.y[0], w0), a.y[1], a.y[2]), d1 = e3_make(gl_sub(a.y[0], w1), a.y[1], a.y[2]);
+    u64 det0, det1;
+    const e3 adj0 = e3_adj(d0, &det0), adj1 = e3_adj(d1, &det1);
+    if (det0 == 0 || det1 == 0) atomicOr(a.flag, 1u);
+    const u64 m0 = det0 ? det0 : 1, m1 = det1 ? det1 : 1;
+    const u64 inv01 = gl_inv(gl_mul(m0, m1));
+    const e3 u0 = e3_scale(adj0, gl_mul(w0, gl_mul(inv01, m1))), u1 = e3_scale(adj1, gl_mul(w1, gl_mul(inv01, m0)));
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        a.u[(u64)c * a.n + i0] = u0.c[c];
+        if (two) a.u[(u64)c * a.n + i0 + 1] = u1.c[c];
+    }
+}
+
+struct BaryArgs {
+    const u64 *cols;
+    const u64 *u;       // [3][n]
+    u64 *partial;       // [blocks][W][6]
+    u64 cs, rs, n;
+    int W;
+};
+__device__ __forceinline__ u64 wave_sum_gl(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = gl_add(v, (u64)__shfl_xor((unsigned long long)v, o));
+    return v;
+}
+template <bool NEXT>
+__global__ void __launch_bounds__(256) bary_dot_kernel(BaryArgs a) {
+    __shared__ u64 red[4][BY_CB * 6];
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.y * BY_CB;
+    const u64 row0 = (u64)blockIdx.x * BY_ROWS;
+    gl_acc acc[BY_CB][NEXT ? 6 : 3];
+#pragma unroll
+    for (int c = 0; c < BY_CB; c++)
+#pragma unroll
+        for (int k = 0; k < (NEXT ? 6 : 3); k++) acc[c][k] = gl_acc_zero();
+#pragma unroll 2
+    for (int j = 0; j < BY_J; j++) {
+        const u64 i = row0 + (u64)j * 256 + t;
+        if (i < a.n) {
+            const u64 u0 = a.u[i], u1 = a.u[a.n + i], u2 = a.u[2 * a.n + i];
+            const u64 inext = (i + 1) & (a.n - 1);
+#pragma unroll
+            for (int c = 0; c < BY_CB; c++) {
+                if (c0 + c < a.W) {
+                    const u64 *col = a.cols + (u64)(c0 + c) * a.cs;
+                    const u64 v = col[i * a.rs];
+                    gl_acc_mac(acc[c][0], v, u0);
+                    gl_acc_mac(acc[c][1], v, u1);
+                    gl_acc_mac(acc[c][2], v, u2);
+                    if constexpr (NEXT) {
+                        const u64 vn = col[inext * a.rs];
+                        gl_acc_mac(acc[c][3], vn, u0);
+                        gl_acc_mac(acc[c][4], vn, u1);
+                        gl_acc_mac(acc[c][5], vn, u2);
+                    }
+                }
+            }
+        }
+    }
+    const int wv = t >> 6, ln = t & 63;
+#pragma unroll
+    for (int c = 0; c < BY_CB; c++)
+#pragma unroll
+        for (int k = 0; k < (NEXT ? 6 : 3); k++) {
+            const u64 r = wave_sum_gl(gl_acc_reduce(acc[c][k]));
+            if (ln == 0) red[wv][c * 6 + k] = r;
+        }
+    __syncthreads();
+    if (t < BY_CB * 6) {
+        const int c = t / 6, k = t % 6;
+        if (c0 + c < a.W && (NEXT || k < 3)) {
+            const u64 r = gl_add(gl_add(red[0][t], red[1][t]), gl_add(red[2][t], red[3][t]));
+            a.partial[((u64)blockIdx.x * a.W + (c0 + c)) * 6 + k] = r;
+        }
+    }
+}
+// out[w * 6 + k] = sum over blocks of partial[b][w][k]; one workgroup per (column, component)
+__global__ void __launch_bounds__(256) bary_reduce_kernel(const u64 *partial, u64 *out, u64 blocks, int W6) {
+    __shared__ u64 red[4];
+    const int t = threadIdx.x;
+    u64 s = 0;
+    for (u64 b = t; b < blocks; b += 256) s = gl_add(s, partial[b * (u64)W6 + blockIdx.x]);
+    s = wave_sum_gl(s);
+    if ((t & 63) == 0) red[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) out[blockIdx.x] = gl_add(gl_add(red[0], red[1]), gl_add(red[2], red[3]));
+}
+
 // ---- DEEP quotient ---------------------------------------------------------------------------------
 // F(x) = sum_{k<Wa+Wb} g^k (p_k(x) - e_k)/(x - z) + sum_{k<nnext} g^(Wa+Wb+k) (p_k(x) - e'_k)/(x - zw)
 // on x = shift * w_M^r.  lane = row; column reads are coalesced; g^k and the constant terms are uniform.
@@ -192,6 +312,63 @@ int32_t zp_poly_eval_ext(zp_ctx *ctx, const uint64_t *d_coef, int32_t logn, int3
             acc = e3_add(acc, to_e3(&part[(ch * W + c) * 3]));
         }
         memcpy(h_out + c * 3, acc.c, 24);
+    }
+    return ZP_OK;
+}
+
+int32_t zp_ood_eval(zp_ctx *ctx, const uint64_t *d_cols, size_t col_stride, size_t row_stride, int32_t W, int32_t logn, uint64_t shift,
+                    const uint64_t z[3], int32_t want_next, uint64_t *h_ev_z, uint64_t *h_ev_zw) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "ood_eval");
+    ZP_ARG(ctx, logn >= 0 && logn <= 32 && W >= 0, "logn/W out of range");
+    if (W == 0) return ZP_OK;
+    ZP_ARG(ctx, d_cols && z && h_ev_z && (h_ev_zw || !want_next), "null pointer");
+    ZP_ARG(ctx, z[0] < GL_P && z[1] < GL_P && z[2] < GL_P, "point not canonical");
+    ZP_ARG(ctx, row_stride >= 1 && col_stride >= (((size_t)1 << logn) - 1) * row_stride + 1, "strides do not hold a column");
+    if (shift == 0) shift = ctx->coset_shift;
+    ZP_ARG(ctx, shift < GL_P, "shift not canonical");
+    const u64 n = 1ULL << logn;
+    NttPlan *pl;
+    ZP_TRY(zpi_get_plan(ctx, logn, false, &pl));
+    const e3 y = e3_scale(to_e3(z), gl_inv(shift));          // the columns hold P(w^i) = p(shift w^i): evaluate P at z / shift
+    const u64 blocks = (n + BY_ROWS - 1) / BY_ROWS;
+    const size_t W6 = (size_t)W * 6;
+    // scratch 5: [u: 3 n][flag: 1 word][sums: W6][partials: blocks W6]
+    u64 *d_u = nullptr;
+    ZP_TRY(zpi_scratch(ctx, 5, 3 * (size_t)n + 1 + W6 + (size_t)blocks * W6, &d_u));
+    u64 *d_flag = d_u + 3 * n, *d_sum = d_flag + 1, *d_part = d_sum + W6;
+    ZP_HIP(ctx, hipMemsetAsync(d_flag, 0, 8, ctx->stream));
+    if (!want_next) ZP_HIP(ctx, hipMemsetAsync(d_part, 0, (size_t)blocks * W6 * 8, ctx->stream));   // components 3..5 are not written
+    BaryWArgs wa;
+    wa.u = d_u; wa.flag = (unsigned int *)d_flag; wa.twl = pl->d_twl; wa.twh = pl->d_twh; wa.lb = pl->lb; wa.n = n;
+    memcpy(wa.y, y.c, 24);
+    hipLaunchKernelGGL(bary_weights_kernel, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, ctx->stream, wa);
+    ZP_HIP(ctx, hipGetLastError());
+    BaryArgs a;
+    a.cols = (const u64 *)d_cols; a.u = d_u; a.partial = d_part; a.cs = col_stride; a.rs = row_stride; a.n = n; a.W = W;
+    const dim3 grid((unsigned)blocks, (unsigned)((W + BY_CB - 1) / BY_CB));
+    if (want_next) hipLaunchKernelGGL(bary_dot_kernel<true>, grid, dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(bary_dot_kernel<false>, grid, dim3(256), 0, ctx->stream, a);
+    ZP_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(bary_reduce_kernel, dim3((unsigned)W6), dim3(256), 0, ctx->stream, (const u64 *)d_part, d_sum, blocks, (int)W6);
+    ZP_HIP(ctx, hipGetLastError());
+    std::vector<u64> sums(1 + W6);
+    ZP_TRY(zpi_d2h_small(ctx, sums.data(), d_flag, sums.size() * 8));
+    if (sums[0] != 0) {
+        ctx->err = "bad argument: the evaluation point lies on the evaluation domain";
+        return ZP_ERR_ARG;
+    }
+    // (y^n - 1) / n
+    e3 yn = y;
+    for (int i = 0; i < logn; i++) yn = e3_mul(yn, yn);
+    const e3 fac = e3_scale(e3_make(gl_sub(yn.c[0], 1), yn.c[1], yn.c[2]), gl_inv(n % GL_P));
+    for (int c = 0; c < W; c++) {
+        const e3 ez = e3_mul(fac, to_e3(&sums[1 + (size_t)c * 6]));
+        memcpy(h_ev_z + (size_t)c * 3, ez.c, 24);
+        if (want_next) {
+            const e3 ezw = e3_mul(fac, to_e3(&sums[1 + (size_t)c * 6 + 3]));
+            memcpy(h_ev_zw + (size_t)c * 3, ezw.c, 24);
+        }
     }
     return ZP_OK;
 }

@@ -93,6 +93,7 @@ SIGNATURES = {
     "zp_merkle_open": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _u64p]),
     "zp_fri_fold": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, _u64p, C.c_uint64]),
     "zp_poly_eval_ext": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _u64p, _u64p]),
+    "zp_ood_eval": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_uint64, _u64p, C.c_int32, _u64p, _u64p]),
     "zp_deep_quotient": (C.c_int32, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, _u64p, _u64p, _u64p,
                                      _u64p, _u64p, C.c_uint64, _vp]),
     "zp_grand_product": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _u64p, _vp]),
@@ -873,6 +874,15 @@ class Prover:
         out = np.zeros((W, 3), dtype=np.uint64)
         self._chk(self.lib.zp_poly_eval_ext(self.ctx, _ptr(d_coef), logn, W, zz, out.ctypes.data_as(_u64p)))
         return out
+
+    def ood_eval(self, d_cols, col_stride, row_stride, W, logn, shift, z, want_next=False):
+        """(p_c(z))[W][3] and, with want_next, (p_c(z w))[W][3] from the columns' VALUES on the coset shift <w> (barycentric form)"""
+        zz = (C.c_uint64 * 3)(*[int(v) for v in z])
+        out = np.zeros((W, 3), dtype=np.uint64)
+        nxt = np.zeros((W, 3), dtype=np.uint64) if want_next else None
+        self._chk(self.lib.zp_ood_eval(self.ctx, _ptr(d_cols), col_stride, row_stride, W, logn, int(shift), zz, 1 if want_next else 0,
+                                       out.ctypes.data_as(_u64p), nxt.ctypes.data_as(_u64p) if want_next else None))
+        return (out, nxt) if want_next else out
 
     def deep_quotient(self, d_cols_a, Wa, d_cols_b, Wb, logm, n_next, z, zw, gamma, ev_z, ev_zw, shift, d_out):
         a3 = lambda v: (C.c_uint64 * 3)(*[int(x) for x in v])

@@ -269,16 +269,16 @@ class HipBackend:
         return buf
 
     def commit_trace(self, trace, logn, logb, extra_cols=0, group=0):
-        """ext / coef are allocated with room for `extra_cols` stage-2 columns behind the trace columns; group: log2 of the rows
+        """ext is allocated with room for `extra_cols` stage-2 columns behind the trace columns; group: log2 of the rows
         per leaf of the tree (BN128 mode: stark/prover.py bn128_rows_per_leaf_log)"""
         W = trace.shape[0]
         M = 1 << (logn + logb)
         d_tr = trace if isinstance(trace, native.DeviceBuffer) else self.p.upload(trace)
-        ext, coef = self.p.alloc((W + extra_cols) * M), self.p.alloc((W + extra_cols) << logn)
+        ext = self.p.alloc((W + extra_cols) * M)
         tree = self._tree_alloc(M >> group)
-        self.p.lde(d_tr, ext, logn, logb, W, self.shift, d_coef=coef)
+        self.p.lde(d_tr, ext, logn, logb, W, self.shift)         # no coefficient store: the out-of-domain evaluations read ext (ood_evals)
         self._commit(ext, M >> group, W << group, tree)
-        c = Commit(self._root(tree, M >> group), tree, ext, coef)
+        c = Commit(self._root(tree, M >> group), tree, ext)
         if extra_cols:
             c.trace, c.W = d_tr, W   # stage 2 reads witness columns
         else:
@@ -289,7 +289,7 @@ class HipBackend:
         return d_mat.offset(col * rows)
 
     def commit_stage2(self, air, c1, chal, logn, logb, group=0):
-        """stage-2 witness columns (grand products Z, LogUp h1/h2/S) -> LDE into columns W.. of c1.ext / c1.coef -> their tree"""
+        """stage-2 witness columns (grand products Z, LogUp h1/h2/S) -> LDE into columns W.. of c1.ext -> their tree"""
         N, M, W, W2 = 1 << logn, 1 << (logn + logb), c1.W, air.width2
         d_s2 = self.p.alloc(W2 * N)
         at = 0
@@ -300,7 +300,7 @@ class HipBackend:
             else:
                 self.p.logup_columns(col("a"), col("t"), col("m"), N, chal, d_s2.offset(at * N))
             at += air_mod.STAGE2_WIDTH[st["kind"]]
-        self.p.lde(d_s2, c1.ext.offset(W * M), logn, logb, W2, self.shift, d_coef=c1.coef.offset(W * N))
+        self.p.lde(d_s2, c1.ext.offset(W * M), logn, logb, W2, self.shift)
         tree = self._tree_alloc(M >> group)
         self._commit(c1.ext.offset(W * M), M >> group, W2 << group, tree)
         self.p.sync()
@@ -366,31 +366,32 @@ class HipBackend:
             b.free()
         return out
 
-    def coset_coefficients(self, d_planes, logm, W):
-        out = self.p.alloc(W << logm)
-        self.p.intt(d_planes, out, logm, W)
-        return out
-
-    def split_quotient(self, d_coef, logn, logb, Q):
-        """d_coef u64[3][M] (coefficients of q(shift X)) -> (LDEs of the Q pieces u64[3Q][M], their coefficients u64[3Q][N]),
-        piece-major.  Piece j of plane c = coefficients [jN, (j+1)N): zero-padded to M and transformed."""
+    def quotient_pieces(self, d_q, logn, logb, Q):
+        """d_q u64[3][M] (the quotient on the coset) -> LDEs of its Q pieces u64[3Q][M], piece-major.  Piece j of plane c =
+        coefficients [jN, (j+1)N) of q_c(shift X): one inverse transform, slices zero-padded to M, one forward transform."""
         N, M = 1 << logn, 1 << (logn + logb)
-        coef = self.p.alloc(3 * Q * N)
+        d_coef = self.p.alloc(3 * M)
+        self.p.intt(d_q, d_coef, logn + logb, 3)
         pad = self.p.alloc(3 * Q * M)
         self.p.memset(pad, 0, 3 * Q * M * 8)
         for j in range(Q):
             for c in range(3):
-                src = d_coef.offset(c * M + j * N)
-                self.p.d2d(coef.offset((3 * j + c) * N), src, N * 8)
-                self.p.d2d(pad.offset((3 * j + c) * M), src, N * 8)
+                self.p.d2d(pad.offset((3 * j + c) * M), d_coef.offset(c * M + j * N), N * 8)
         ext = self.p.alloc(3 * Q * M)
         self.p.ntt(pad, ext, logn + logb, 3 * Q)
         self.p.sync()
         pad.free()
-        return ext, coef
+        d_coef.free()
+        return ext
 
-    def eval_ext(self, d_coef, logn, W, point):
-        return self.p.poly_eval_ext(d_coef, logn, W, point)
+    def ood_evals(self, c1, Wt, d_q, Wq, q_logn, logn, logb, zeta, zeta_w):
+        """(p_k(zeta))[Wt], (p_k(zeta w))[Wt], (q_k(zeta))[Wq] from the resident extensions (zp_ood_eval, barycentric form): a
+        polynomial of degree < 2^d is read on the 2^d-point sub-coset of its extension (row stride M / 2^d); zeta_w is implied"""
+        logm = logn + logb
+        M = 1 << logm
+        ev_z, ev_zw = self.p.ood_eval(c1.ext, M, 1 << logb, Wt, logn, self.shift, zeta, want_next=True)
+        ev_q = self.p.ood_eval(d_q, M, 1 << (logm - q_logn), Wq, q_logn, self.shift, zeta)
+        return ev_z, ev_zw, ev_q
 
     def deep(self, d_a, Wa, d_b, Wb, logm, n_next, z, zw, gamma, ev_z, ev_zw):
         out = self.p.alloc(3 << logm)

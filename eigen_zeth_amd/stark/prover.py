@@ -162,13 +162,12 @@ def prove(air, trace, pubs, params, be, timings=None):
     t0 = time.perf_counter()
     Q = air_mod.quotient_chunks(air)                 # pieces of degree < N the quotient is committed in
     assert Q <= (1 << logb), "the blow-up must cover the quotient degree: constraints of degree d need blow-up >= d - 1"
-    d_qcoef = be.coset_coefficients(d_q, logm, 3)   # coefficients of q_c(shift * X), c'_i = c_i shift^i, i < M
     if Q == 1:
-        q_logn, Wq = logm, 3
+        q_logn, Wq = logm, 3                         # committed as it stands: the quotient never leaves the evaluation form
     else:
-        # q(x) = sum_j (x / shift)^(jN) qt_j(x), qt_j(shift X) = sum_{i<N} c'_(jN+i) X^i: the pieces are slices of the
-        # coefficient vector already in hand; their LDEs (3Q base columns, piece-major) are what gets committed and opened
-        d_q, d_qcoef = be.split_quotient(d_qcoef, logn, logb, Q)
+        # q(x) = sum_j (x / shift)^(jN) qt_j(x), qt_j(shift X) = sum_{i<N} c'_(jN+i) X^i with c' the coefficients of q_c(shift X): the
+        # pieces are slices of that vector; their LDEs (3Q base columns, piece-major) are what gets committed and opened
+        d_q = be.quotient_pieces(d_q, logn, logb, Q)
         q_logn, Wq = logn, 3 * Q
     qg = bn128_rows_per_leaf_log(Wq, logm) if bn else 0       # BN128 mode: 2^qg rows of the quotient per leaf
     cq = be.commit_cols(d_q, M >> qg, Wq << qg)
@@ -179,11 +178,10 @@ def prove(air, trace, pubs, params, be, timings=None):
     # 3. out-of-domain evaluations
     t0 = time.perf_counter()
     zeta_w = F.e3_scale(zeta, wN)
-    # every coefficient buffer holds c_i * shift^i (what the LDE has in hand): p(z) = sum_i (c_i shift^i) (z / shift)^i
-    sinv = F.inv(shift)
-    ev_z = be.eval_ext(c1.coef, logn, Wt, F.e3_scale(zeta, sinv))
-    ev_zw = be.eval_ext(c1.coef, logn, Wt, F.e3_scale(zeta_w, sinv))
-    ev_q = be.eval_ext(d_qcoef, q_logn, Wq, F.e3_scale(zeta, sinv))
+    # p_k(zeta), p_k(zeta w) for the Wt committed base columns, q-columns at zeta.  The backend decides how: the GPU backend reads
+    # the resident extensions (barycentric form, zp_ood_eval: no coefficient buffer is kept since round 5), the CPU checker's
+    # backend interpolates and evaluates the coefficient form (the definition)
+    ev_z, ev_zw, ev_q = be.ood_evals(c1, Wt, d_q, Wq, q_logn, logn, logb, zeta, zeta_w)
     tick("ood-evals", t0)
     ev_all = [_ints(r) for r in ev_z] + [_ints(r) for r in ev_q]
     ev_next = [_ints(r) for r in ev_zw]

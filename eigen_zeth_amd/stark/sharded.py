@@ -207,6 +207,20 @@ class ShardedBackend:
         r0 = self.rank * nloc
         return ShardMat(ext[:, r0:r0 + nloc].contiguous(), M, r0, nloc, 0, 3 * Q), pieces
 
+    def quotient_pieces(self, q, logn, logb, Q):
+        """stark/prover.py's hook: the LDEs of the quotient's Q pieces (my rows); their coefficient slices are kept for ood_evals"""
+        ext, self._qcoef = self.split_quotient(self.coset_coefficients(q, logn + logb, 3), logn, logb, Q)
+        return ext
+
+    def ood_evals(self, c1, Wt, d_q, Wq, q_logn, logn, logb, zeta, zeta_w):
+        """this torch.distributed orchestration stays on the coefficient route (every rank evaluates the coefficient columns it owns,
+        the evaluations are all-gathered); the C++ sharded prover (csrc/prove.hip) reads values instead (zp_ood_eval)"""
+        sinv = F.inv(self.shift)
+        zs, zws = F.e3_scale(zeta, sinv), F.e3_scale(zeta_w, sinv)
+        ev_z, ev_zw = self.eval_ext(c1.coef, logn, Wt, zs), self.eval_ext(c1.coef, logn, Wt, zws)
+        qcoef = self._qcoef if q_logn == logn and Wq > 3 else self.coset_coefficients(d_q, logn + logb, 3)
+        return ev_z, ev_zw, self.eval_ext(qcoef, q_logn, Wq, zs)
+
     def eval_ext(self, coef, logn, W, point):
         if not isinstance(coef, ShardCoef):
             return self.ops.eval_ext(coef, logn, W, point)

@@ -219,6 +219,15 @@ int32_t zp_fri_fold(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t 
  * zp_merkle_open_batch: h_paths[nq][log2 M][4], bottom-up siblings for every queried leaf.        */
 int32_t zp_poly_eval_ext(zp_ctx *ctx, const uint64_t *d_coef, int32_t logn, int32_t W, const uint64_t z[3],
                          uint64_t *h_out);
+/* Out-of-domain evaluations FROM VALUES (barycentric form; round 5: the provers keep no coefficient buffers for this any more).
+ * Column c is a polynomial p_c of degree < 2^logn given by its values on the coset shift*<w>, w of order 2^logn:
+ *   d_cols[c * col_stride + i * row_stride] = p_c(shift * w^i)      (row_stride = 2^logb reads the 2^logn-point sub-coset of an
+ *   extension committed on shift*<w_(2^(logn+logb))>; shift == 1 with row_stride == 1 reads a trace on its own domain;
+ *   shift == 0 selects the ctx default).
+ * h_ev_z[W][3] = p_c(z); with want_next != 0 also h_ev_zw[W][3] = p_c(z * w) (the same weights on the column rotated by one
+ * row).  One pass over the columns.  ZP_ERR_ARG when z lies on the domain (a protocol excludes it; probability 2^-128).       */
+int32_t zp_ood_eval(zp_ctx *ctx, const uint64_t *d_cols, size_t col_stride, size_t row_stride, int32_t W, int32_t logn,
+                    uint64_t shift, const uint64_t z[3], int32_t want_next, uint64_t *h_ev_z, uint64_t *h_ev_zw);
 int32_t zp_deep_quotient(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa, const uint64_t *d_cols_b, int32_t Wb,
                          int32_t logm, int32_t n_next, const uint64_t z[3], const uint64_t zw[3],
                          const uint64_t gamma[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t shift,

@@ -143,16 +143,28 @@ class CpuBackend:
     def coset_coefficients(self, planes, logm, W):
         return O.intt(np.asarray(planes).reshape(W, 1 << logm), self.root32)
 
-    def split_quotient(self, coef, logn, logb, Q):
+    def quotient_pieces(self, q, logn, logb, Q):
+        """LDEs of the Q degree-<N pieces of the quotient (slices of the coefficient vector of q(shift X)), piece-major"""
         N, M = 1 << logn, 1 << (logn + logb)
-        c = np.asarray(coef).reshape(3, M)
-        pieces = np.ascontiguousarray(np.stack([c[p, j * N:(j + 1) * N] for j in range(Q) for p in range(3)]))
+        c = self.coset_coefficients(q, logn + logb, 3)
         pad = np.zeros((3 * Q, M), dtype=np.uint64)
-        pad[:, :N] = pieces
-        return O.ntt(pad, self.root32), pieces
+        pad[:, :N] = np.stack([c[p, j * N:(j + 1) * N] for j in range(Q) for p in range(3)])
+        return O.ntt(pad, self.root32)
 
     def eval_ext(self, coef, logn, W, point):
         return O.poly_eval_e3_cols(np.ascontiguousarray(np.asarray(coef).reshape(-1, 1 << logn)[:W]), point)
+
+    def ood_evals(self, c1, Wt, q, Wq, q_logn, logn, logb, zeta, zeta_w):
+        """out-of-domain evaluations BY THE DEFINITION: interpolate (the coefficients of p(shift X): trace columns from the trace, quotient
+        columns from their committed values on the sub-coset of 2^q_logn points), then evaluate the coefficient form at z / shift.  (The
+        product reads the extensions in the barycentric form instead: a different route to the same field elements.)"""
+        sinv = pow(self.shift, O.P - 2, O.P)
+        zs, zws = [v * sinv % O.P for v in zeta], [v * sinv % O.P for v in zeta_w]
+        ev_z, ev_zw = self.eval_ext(c1.coef, logn, Wt, zs), self.eval_ext(c1.coef, logn, Wt, zws)
+        logm = logn + logb
+        sub = np.ascontiguousarray(np.asarray(q).reshape(Wq, 1 << logm)[:, ::1 << (logm - q_logn)])
+        ev_q = self.eval_ext(self.coset_coefficients(sub, q_logn, Wq), q_logn, Wq, zs)
+        return ev_z, ev_zw, ev_q
 
     def deep(self, a, Wa, b, Wb, logm, n_next, z, zw, gamma, ev_z, ev_zw):
         return O.deep_quotient(np.ascontiguousarray(np.asarray(a).reshape(-1, 1 << logm)[:Wa]), np.asarray(b).reshape(Wb, 1 << logm), n_next, z, zw,

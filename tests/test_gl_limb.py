@@ -85,3 +85,47 @@ def test_lde_seam_kernel_and_the_two_launch_form_match_the_oracle(prover, seam):
     for i in range(1, 1 << logn):
         pw[i] = pw[i - 1] * s % P
     assert all(int(c[0, i]) == int(coef[0, i]) * int(pw[i]) % P for i in range(0, 1 << logn, 257))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logn", [16, 17, 18, 19, 20, 21, 22, 23])
+def test_lde_seam_plans_at_the_provers_sizes(prover, logn):
+    """round 5: the fused extension where the DEFAULT plans do not meet in radix-256 passes -- an inverse plan that ENDS in one and a forward
+    plan that STARTS with one (csrc/ntt.hip zpi_get_plan_role; knob lde_seam_plans).  The extension a prover issues (no coefficient store)
+    against the oracle, with the seam plans on (default) and off, with and without the coefficient store; zp_ntt_plan_json says which path
+    a size takes: by default fused at 2^16 and from 2^21 on (2^22 = the chunk size of BASELINE configs[2] / [4]); forced (knob 2) also at
+    2^19 / 2^20, where it measured slower; never where a seam plan would cost a pass more (2^17, 2^18)."""
+    from oracle import oracle as O
+    W = 3 if logn >= 21 else 6
+    x = O.random_field((W, 1 << logn), 0x5EA5 + logn)
+    want = O.lde(x, 1)
+    d_in, d_out, d_coef = prover.upload(x), prover.alloc(W << (logn + 1)), prover.alloc(W << logn)
+    plan = prover.ntt_plan(logn)["lde"]
+    assert plan["seam_fused"] == (logn == 16 or logn >= 21), plan     # default: from 2^21 on (below, the seam plans measured slower: profiles/r5_lde_seam_plans_ab.txt)
+    prover.set_tuning("lde_seam_plans", 2)                            # forced: wherever a seam plan costs no extra pass
+    forced = prover.ntt_plan(logn)["lde"]
+    prover.set_tuning("lde_seam_plans", 1)
+    assert forced["seam_fused"] == (logn not in (17, 18)), forced
+    if forced["seam_fused"]:
+        assert forced["inverse_radix_logs"][-1] == 8 and forced["forward_radix_logs"][0] == 8
+        assert sum(forced["inverse_radix_logs"]) == logn and sum(forced["forward_radix_logs"]) == logn + 1
+    try:
+        for knob in (2, 1, 0):
+            prover.set_tuning("lde_seam_plans", knob)
+            prover.memset(d_out, 0, (W << (logn + 1)) * 8)
+            prover.lde(d_in, d_out, logn, 1, W)
+            assert (prover.download(d_out, (W, 1 << (logn + 1))) == want).all(), "lde_seam_plans=%d" % knob
+        prover.set_tuning("lde_seam_plans", 2)
+        prover.set_tuning("lde_seam", 2)              # the fused kernel WITH the coefficient store, on the seam plans
+        prover.lde(d_in, d_out, logn, 1, W, d_coef=d_coef)
+        assert (prover.download(d_out, (W, 1 << (logn + 1))) == want).all()
+        prover.set_tuning("lde_seam", 0)
+        c0 = prover.alloc(W << logn)
+        prover.lde(d_in, d_out, logn, 1, W, d_coef=c0)
+        assert (prover.download(d_coef, (W, 1 << logn)) == prover.download(c0, (W, 1 << logn))).all()
+        c0.free()
+    finally:
+        prover.set_tuning("lde_seam", 1)
+        prover.set_tuning("lde_seam_plans", 1)
+    for d in (d_in, d_out, d_coef):
+        d.free()

@@ -2,7 +2,7 @@
 size on the one-GPU box.
 
 * BASELINE.json configs[3]'s one-GPU leg (what `python bench.py` reports): zp_ntt / zp_intt / zp_lde (blow-up 2) of 2^24 rows x 64
-  columns with the DEFAULT plan (three radix-256 passes, 8-column XCD-ordered launches: the workgroup -> (XCD, column, tile) map of
+  columns with the DEFAULT plan (three radix-256 passes, 16-column XCD-ordered launches (2^28 elements per launch): the workgroup -> (XCD, column, tile) map of
   csrc/ntt.hip depends on the column count of a launch, so one column of a W = 2 launch does not exercise it).  EVERY column is
   compared with oracle.ntt / intt / lde.  Host memory stays at a few GiB: slices of 8 columns are generated from their seed, uploaded
   into the resident matrix, and generated again when their transform is compared.

@@ -41,6 +41,42 @@ def test_poly_eval_ext_matches_oracle(prover, logn, W):
         assert got[c].tolist() == [O.poly_eval(coef[c], 7), 0, 0]
 
 
+@pytest.mark.parametrize("logn,logb,W", [(0, 0, 1), (1, 1, 2), (4, 1, 1), (9, 0, 9), (12, 1, 3), (13, 2, 5), (16, 1, 6), (20, 1, 2)])
+def test_ood_eval_from_values_matches_the_coefficient_definition(prover, logn, logb, W):
+    """zp_ood_eval (barycentric form over the resident extension, round 5) against the oracle's definition: interpolate, then evaluate the
+    coefficient form -- at zeta and at zeta w, from the 2^logn-point sub-coset of an extension with blow-up 2^logb (row stride 2^logb),
+    on the coset (shift 49) and on the trace domain itself (shift 1), for a full ext point and a base-field point"""
+    n, M = 1 << logn, 1 << (logn + logb)
+    x = O.random_field((W, n), 0x00D0 + logn)
+    coef = O.intt(x)                                                   # p_c(w^i) = x[c][i]
+    wn = pow(O.ROOT32_DEFAULT, 1 << (32 - logn), P) if logn else 1
+    for shift in (49, 1):
+        # the columns as an extension would hold them: values of p on shift <w_M>, so that rows 0, 2^logb, ... are p(shift w_n^i)
+        sc = np.array([[int(c) * pow(shift, i, P) % P for i, c in enumerate(row)] for row in coef.tolist()], dtype=np.uint64) if logn <= 13 else None
+        if sc is None:      # large sizes: the library's own LDE lays the extension down (it is compared with the oracle elsewhere)
+            if shift == 1:
+                continue
+            d_ext = prover.alloc(W * M)
+            prover.lde(prover.upload(x), d_ext, logn, logb, W, shift)
+        else:
+            pad = np.zeros((W, M), dtype=np.uint64)
+            pad[:, :n] = sc
+            d_ext = prover.upload(O.ntt(pad))
+        for z in (O.random_field((3,), 0x00D1 + logn).tolist(), [12345, 0, 0]):
+            zw = [v * wn % P for v in z]
+            got_z, got_zw = prover.ood_eval(d_ext, M, 1 << logb, W, logn, shift, z, want_next=True)
+            assert (got_z == O.poly_eval_e3_cols(coef, z)).all()
+            assert (got_zw == O.poly_eval_e3_cols(coef, zw)).all()
+            assert (prover.ood_eval(d_ext, M, 1 << logb, W, logn, shift, z) == got_z).all()
+        d_ext.free()
+    # a point ON the domain is refused (the protocol excludes it), not answered with garbage
+    if logn >= 1:
+        d = prover.upload(x)
+        with pytest.raises(native.ZpError):
+            prover.ood_eval(d, n, 1, W, logn, 1, [pow(wn, 3, P), 0, 0])
+        d.free()
+
+
 @pytest.mark.parametrize("logm,Wa,Wb,nn", [(6, 3, 0, 0), (10, 5, 3, 5), (12, 4, 3, 2)])
 def test_deep_quotient_matches_oracle(prover, logm, Wa, Wb, nn):
     a = O.random_field((Wa, 1 << logm), 50)

@@ -2,8 +2,10 @@
 (tools/pmc_summary.py output) -> profiles/<tag>_integer_roofline.json, which bench.py reads for the `roofline.integer` block
 of the bench line ("report the integer-VALU fraction next to the HBM one").  Measurement tool.
 
-usage: python tools/integer_roofline.py OUT.json ntt=SQ_NTT.json poseidon=SQ_POSEIDON.json [stark=SQ_STARK.json] [msm=SQ_MSM.json]
-Units: NTT pass = field elements of the launch (pmc_ntt.py: 2^24 rows, 8-column launches = 2^27); Poseidon = permutations
+usage: python tools/integer_roofline.py OUT.json ntt=SQ_NTT.json ntt_elems_log=28 poseidon=SQ_POSEIDON.json [stark=SQ_STARK.json] [msm=SQ_MSM.json]
+Units: NTT pass = field elements of ONE LAUNCH = 2^ntt_elems_log, which the caller states (tools/pmc_ntt.py: 2^24 rows x 16 columns = 2^28 since
+the launches were widened in round 4; rounds 1-3: 8 columns = 2^27.  Round 4's file divided by the old 2^27 and printed twice the true
+count: the tool now refuses to guess, and cross-checks the figure against the launch's wave count); Poseidon = permutations
 (hash_bench.py: 2^22 x 32 commit and a 2^22-state batch); quotient = LDE rows (stark_bench.py chunk64 2^20: 2^21 rows);
 MSM bucket kernel = point additions of the launch are not counted by the profiler, so the MSM row is per input point."""
 import json
@@ -11,6 +13,7 @@ import sys
 
 out_path = sys.argv[1]
 src = dict(a.split("=", 1) for a in sys.argv[2:])
+ntt_elems_log = int(src.pop("ntt_elems_log")) if "ntt" in src else None      # KeyError: say how many elements a launch of the PMC run had
 res = {"cycles_per_valu_instruction": 4.0,
        "note": "SQ_INSTS_VALU counts wave instructions: x 64 lanes / units of the launch = lane instructions per unit; every hot "
                "instruction of these kernels issues in 4 cycles per wave per SIMD (tools/ubench_isa.hip)",
@@ -26,7 +29,13 @@ if "ntt" in src:
     for k in d:
         if k.startswith("ntt_pass2_kernel"):
             v, ms = valu(d, k)
-            res["ntt_valu_per_element_per_pass"][k] = v * 64 / float(1 << 27)
+            # every lane of a pass kernel carries 16 elements per tile, a workgroup walks 1, 2 or 4 tiles: waves x 64 x 16 x tiles = elements
+            waves = d[k].get("SQ_WAVES", {}).get("mean")
+            if waves:
+                tiles = (1 << ntt_elems_log) / (waves * 64 * 16)
+                assert tiles in (1.0, 2.0, 4.0, 8.0), "ntt_elems_log=%d does not match the launch (%g waves): %g tiles per workgroup" % (ntt_elems_log, waves, tiles)
+            res["ntt_valu_per_element_per_pass"][k] = v * 64 / float(1 << ntt_elems_log)
+    res["ntt_elements_per_launch_log2"] = ntt_elems_log
 if "poseidon" in src:
     d = json.load(open(src["poseidon"]))
     for k, units, label in (("poseidon_perm_kernel<true>", 1 << 22, "poseidon_perm (batch of 2^22 states)"),

@@ -100,9 +100,9 @@ def run(logn=22, W=32, cpu=None):
             "each row also reads row+blowup (served by L2)")
         # OOD evaluation + DEEP
         z = [5, 6, 7]
-        t = timed(lambda: p.poly_eval_ext(c1.coef, logn, W, z))
-        rec("OOD evaluation (all columns at one point)", t, 8.0 * N * W, N * W, "coefficients/s",
-            cpu_timed(lambda: O.poly_eval_e3_cols(cc1.coef, z)), W << clogn)
+        t = timed(lambda: p.ood_eval(c1.ext, M, 2, W, logn, 49, z, want_next=True))
+        rec("OOD evaluation (all columns at zeta and zeta w, from the extension: zp_ood_eval)", t, 8.0 * N * W, N * W, "rows x columns/s",
+            cpu_timed(lambda: O.poly_eval_e3_cols(cc1.coef, z)), W << clogn, "the CPU leg evaluates the coefficient form at one point")
         ev = _field(np.random.default_rng(8), (W + 3, 3)); ev2 = _field(np.random.default_rng(9), (W, 3))
         d_q = hold["q"]; d_f = p.alloc(3 * M)
         t = timed(lambda: p.deep_quotient(c1.ext, W, d_q, 3, logn + 1, W, z, [1, 2, 3], [4, 5, 6], ev, ev2, 49, d_f))
