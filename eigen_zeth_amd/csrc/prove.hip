@@ -92,6 +92,7 @@ struct Transcript {
     bool bn;
     u64 state[17 * 4];                 // GL: 12 words; BN: 17 elements of 4 words (standard form)
     std::vector<u64> pending, out;     // GL: values; BN: pending holds 4 words per element
+    std::vector<u64> log_blocks, last_rates;   // BN: every absorbed block (16 elements x 4 words) in order; the rate elements of the latest flush (the wrap circuit's transcript gadgets: zp_wrap_assign)
     int32_t rc = ZP_OK;
     Transcript(zp_ctx *c, bool bn_) : ctx(c), bn(bn_) { memset(state, 0, sizeof state); }
     void absorb(const u64 *v, size_t n) {
@@ -133,6 +134,8 @@ struct Transcript {
             std::vector<u64> rates((1 + extra) * 64);
             const int32_t r = zp_poseidon_bn254_sponge(ctx, (uint64_t *)state, (const uint64_t *)blocks.data(), nblk, extra, (uint64_t *)rates.data());
             if (r != ZP_OK && rc == ZP_OK) rc = r;
+            log_blocks.insert(log_blocks.end(), blocks.begin(), blocks.end());
+            last_rates = rates;
             out.clear();
             for (size_t e = 0; e < rates.size() / 4; e++)
                 for (int k = 0; k < 3; k++) out.push_back(rates[4 * e + k] % GL_P);
@@ -716,7 +719,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         std::vector<u64> &rec = ctx->last_openings;
         rec.clear();
         const size_t ntr = 2 + (n_s2 ? 1 : 0) + layers.size();
-        rec.insert(rec.end(), {0x31304e45504f5a50ULL /* "PZOPEN01" */, (u64)nq, (u64)ntr, (u64)logm});
+        rec.insert(rec.end(), {0x32304e45504f5a50ULL /* "PZOPEN02" */, (u64)nq, (u64)ntr, (u64)logm});
         auto shape = [&](size_t width, size_t rows) { rec.insert(rec.end(), {(u64)width, (u64)rows, (u64)Trees::levels16(rows)}); };
         shape(Wtg, Mt); shape(Wqg, Mq);
         if (n_s2) shape(W2g, M2);
@@ -734,6 +737,11 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
             if (n_s2) put(v_s2, W2g, p_s2, pw2);
             for (size_t li = 0; li < layers.size(); li++) put(fo[li].vals, fo[li].width, fo[li].paths, fo[li].pw);
         }
+        // the transcript (round 5: the wrap circuit hashes it too): every absorbed block, then the rate elements the indices were read from
+        rec.push_back((u64)(tr.log_blocks.size() / 64));
+        rec.push_back((u64)(tr.last_rates.size() / 64));
+        rec.insert(rec.end(), tr.log_blocks.begin(), tr.log_blocks.end());
+        rec.insert(rec.end(), tr.last_rates.begin(), tr.last_rates.end());
     }
 
     // the proof text

@@ -401,8 +401,8 @@ int32_t zp_r1cs_key_scalars(const uint64_t *circ, size_t words, const uint64_t *
 //                      the blinding terms -> the three proof elements
 namespace {
 
-constexpr uint64_t SCRIPT_MAGIC = 0x3153504152575a50ULL;   // "PZWRAPS1"
-constexpr uint64_t OPEN_MAGIC = 0x31304e45504f5a50ULL;     // "PZOPEN01"
+constexpr uint64_t SCRIPT_MAGIC = 0x3253504152575a50ULL;   // "PZWRAPS2" (round 5: the transcript section)
+constexpr uint64_t OPEN_MAGIC = 0x32304e45504f5a50ULL;     // "PZOPEN02"
 
 struct OpenTree { uint64_t width, leaves, levels; const uint64_t *root; size_t off; };   // off: word offset of this tree's part inside a query record
 struct Openings {
@@ -410,6 +410,11 @@ struct Openings {
     std::vector<OpenTree> tr;
     const uint64_t *q0;
     size_t qwords;
+    // the transcript of the proof (round 5): every block of 16 field elements its sponge absorbed, in order, then the 16 rate elements of the
+    // last absorbing permutation and of the squeeze-only permutations behind it (csrc/prove.hip writes them, service/wrap_circuit.py
+    // TranscriptLog states them); 4 words per element
+    uint64_t n_blocks, n_rates;
+    const uint64_t *blocks, *rates;
     const uint64_t *query(uint64_t q) const { return q0 + q * qwords; }
 };
 bool parse_openings(const uint64_t *d, size_t words, Openings *o) {
@@ -428,8 +433,17 @@ bool parse_openings(const uint64_t *d, size_t words, Openings *o) {
     }
     o->qwords = off;
     o->q0 = d + 4 + 7 * o->ntr;
-    return words == 4 + 7 * o->ntr + o->nq * off;
+    const size_t at = 4 + 7 * o->ntr + o->nq * off;
+    if (words < at + 2) return false;
+    o->n_blocks = d[at]; o->n_rates = d[at + 1];
+    if (o->n_blocks < 1 || o->n_blocks > 4096 || o->n_rates < 1 || o->n_rates > 256) return false;
+    o->blocks = d + at + 2;
+    o->rates = o->blocks + o->n_blocks * 64;
+    return words == at + 2 + (o->n_blocks + o->n_rates) * 64;
 }
+// the scalar field's modulus r, little-endian words, and bit i of a 4-word value
+constexpr uint64_t FR_R[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+inline uint64_t bit_of(const uint64_t *w4, unsigned i) { return (w4[i >> 6] >> (i & 63)) & 1; }
 
 // one sponge block of a leaf: 56 Goldilocks values in 16 field elements (csrc/poseidon_bn254.hip: leaf_block_element)
 void pack_element(const uint64_t *vals, uint64_t width, uint64_t block, int e, uint64_t *w4) {
@@ -719,6 +733,10 @@ extern "C" {
 //   0 constant a                      1 aux                                  2 root of tree b               3 index of query a
 //   4 bits 0..count-1 of that index   5 elements of block c of the leaf (query a, tree b)                    6 the 16 digests of level c on the path
 //   7 one-hot of the position at level c (16)       8 / 9 one-hot of its low / high two bits (4)
+//   10 elements b .. b + count - 1 of absorbed block a of the transcript            11 the 16 rate elements of squeeze permutation a
+//   12 bits c .. c + count - 1 of rate element b of squeeze permutation a           13 entries c .. of that element's "equal to r so far" chain
+//      (walking down from bit 253 over the positions where r has a 1: the AND of the element's bits there, first position excluded)
+//   14 the 30 partial products of the top 32 bits of 64-bit word c of that element (bits 32..33, 32..34, ... 32..62 of the word)
 // out_idx u64[cap], out_val u64[cap][4] (standard form) receive the wires and their values; *n_set their number ([2] of the script).
 int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64_t *openings, size_t open_words, const uint64_t *aux4, uint64_t *out_idx,
                        uint64_t *out_val, size_t cap, size_t *n_set) {
@@ -726,16 +744,46 @@ int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64
     if (!script || script_words < 6 || script[0] != SCRIPT_MAGIC || !aux4 || !out_idx || !out_val || !n_set || !parse_openings(openings, open_words, &o))
         return ZP_ERR_ARG;
     const uint64_t ne = script[1], total = script[2];
-    if (script[3] != o.nq || script[4] != o.ntr || script[5] != o.logm || ne > (1ull << 28) || script_words != 6 + 3 * o.ntr + 6 * ne || total > cap ||
+    if (script[3] != o.nq || script[4] != o.ntr || script[5] != o.logm || ne > (1ull << 28) || script_words != 8 + 3 * o.ntr + 6 * ne || total > cap ||
         !std_canonical(aux4))
         return ZP_ERR_ARG;
     for (uint64_t t = 0; t < o.ntr; t++)
         if (script[6 + 3 * t] != o.tr[t].width || script[7 + 3 * t] != o.tr[t].leaves || script[8 + 3 * t] != o.tr[t].levels) return ZP_ERR_ARG;   // another layout
-    const uint64_t *e = script + 6 + 3 * o.ntr;
+    if (script[6 + 3 * o.ntr] != o.n_blocks || script[7 + 3 * o.ntr] != o.n_rates) return ZP_ERR_ARG;                                              // another transcript
+    for (uint64_t i = 0; i < (o.n_blocks + o.n_rates) * 16; i++)
+        if (!std_canonical(o.blocks + 4 * i)) return ZP_ERR_ARG;
+    // positions of r's one-bits below the top one, walking down: the chain of op 13
+    unsigned ones[254], n_ones = 0;
+    for (int i = 252; i >= 0; i--)
+        if (bit_of(FR_R, (unsigned)i)) ones[n_ones++] = (unsigned)i;
+    const uint64_t *e = script + 8 + 3 * o.ntr;
     size_t n = 0;
     for (uint64_t k = 0; k < ne; k++, e += 6) {
         const uint64_t op = e[0], wire = e[1], cnt = e[2], a = e[3], b = e[4], c = e[5];
-        if (cnt < 1 || cnt > 64 || n + cnt > total || op > 9) return ZP_ERR_ARG;
+        if (cnt < 1 || cnt > 64 || n + cnt > total || op > 14) return ZP_ERR_ARG;
+        if (op >= 10) {
+            if (op == 10 ? (a >= o.n_blocks || b + cnt > 16) : a >= o.n_rates) return ZP_ERR_ARG;
+            if ((op == 11 && cnt != 16) || (op >= 12 && b >= 16) || (op == 12 && c + cnt > 254) || (op == 13 && c + cnt > n_ones) || (op == 14 && (cnt != 30 || c >= 3)))
+                return ZP_ERR_ARG;
+            const uint64_t *el = op == 10 ? o.blocks + (a * 16 + b) * 4 : o.rates + (a * 16 + (op == 11 ? 0 : b)) * 4;
+            for (uint64_t i = 0; i < cnt; i++, n++) {
+                uint64_t *v = out_val + 4 * n;
+                out_idx[n] = wire + i;
+                v[0] = v[1] = v[2] = v[3] = 0;
+                if (op <= 11) memcpy(v, el + 4 * i, 32);
+                else if (op == 12) v[0] = bit_of(el, (unsigned)(c + i));
+                else if (op == 13) {
+                    uint64_t p = bit_of(el, 253);
+                    for (uint64_t t = 0; t <= c + i; t++) p &= bit_of(el, ones[t]);
+                    v[0] = p;
+                } else {
+                    uint64_t p = 1;
+                    for (uint64_t t = 0; t <= i + 1; t++) p &= bit_of(el, (unsigned)(64 * c + 32 + t));
+                    v[0] = p;
+                }
+            }
+            continue;
+        }
         if (op >= 3 && a >= o.nq) return ZP_ERR_ARG;
         if ((op == 2 || op >= 5) && b >= o.ntr) return ZP_ERR_ARG;
         const uint64_t *q = op >= 3 ? o.query(a) : nullptr;

@@ -123,6 +123,7 @@ class Engine:
         self._be = None
         self._be_bn = None        # backend of the final STARK (BN128-hash mode), created at the first GenFinalProof
         self.final_starks = {}    # batch_id -> final STARK JSON of the most recent batches (inspection / tests)
+        self.final_programs = {}  # batch_id -> constraint program of that final STARK's statement
         self._batch_chunk_proofs = {}   # batch_id -> chunk proof texts of the most recent batches (cfg.aggregate_all_chunks)
         self.cfg = config or EngineConfig()
         self.stage_timings = {}
@@ -627,7 +628,7 @@ class Engine:
         agg_shape = VA.Shape(ap.logn, ap.logb, VA.WIDTH, 0, 3 * VA.Q_PIECES, ap.n_queries, ap.fri_logf, ap.fri_final_log, 1, chunk_shape.n_pub(), ap.pow_bits,
                              int(self.be.root32), int(self.be.shift))
         fp = VA.aggregation_params(agg_shape, self.cfg.final_queries, self.cfg.fri_logf, self.cfg.fri_final_log, 0, hash="bn128")
-        return WC.Layout(fp, VA.WIDTH, 3 * VA.Q_PIECES)
+        return WC.Layout(fp, VA.WIDTH, 3 * VA.Q_PIECES, agg_shape.n_pub())     # = Layout.of_air(the final STARK's verifier AIR, fp)
 
     def _wrap_key(self, layout):
         """(wrap circuit, Groth16 key) for a final-STARK layout: built once per layout (seconds at the service's size: the circuit in Python,
@@ -696,8 +697,11 @@ class Engine:
 
     def _final_wrap(self, batch_id, aggregator_addr, fair, fp, final_stark, tmf, openings, t_fs):
         self.final_starks[batch_id] = final_stark
+        self.final_programs[batch_id] = fair.program()         # the statement of that STARK (a checker recomputes the wrap's public input from both)
         while len(self.final_starks) > 4:
-            self.final_starks.pop(next(iter(self.final_starks)))
+            k0 = next(iter(self.final_starks))
+            self.final_starks.pop(k0)
+            self.final_programs.pop(k0, None)
         fs_digest = hashlib.sha256(final_stark.encode()).hexdigest()
         # 2. the Groth16 wrap: an R1CS that verifies the hashing of that STARK's verifier at its queries (service/wrap_circuit.py); its one
         #    public input commits to the roots, indices and leaf elements it vouches for, and to the aggregator address of the request
@@ -707,8 +711,11 @@ class Engine:
             aux = int(aggregator_addr or "0")
         except ValueError:
             aux = int(hashlib.sha256((aggregator_addr or "").encode()).hexdigest(), 16)
-        if openings is None:
-            openings = WC.openings_record(json.loads(final_stark), wc.layout)
+        if openings is None:      # a final STARK made by the Python orchestration: its transcript is replayed for the record (the one-call prover logs it)
+            fs = json.loads(final_stark)
+            tlog = WC.TranscriptLog(fs, wc.layout, WC.head_values(fair, fp, fs["root32"], fs["shift"]), getattr(self.be_bn128, "publics_digest", None),
+                                    getattr(self.be_bn128, "poseidon_bn254_perm17", WC.perm17))
+            openings = WC.openings_record(fs, wc.layout, tlog)
         set_idx, set_val = native.wrap_assign(wc.script, openings, aux % bn254.R)
         t_wit = time.perf_counter() - t0
         # fresh blinding per proof (zero knowledge); replays of a request are answered from the batch store (server.py),

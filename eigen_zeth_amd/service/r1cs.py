@@ -45,11 +45,15 @@ def _lc_scale(a, s):
 
 
 class Template:
-    """cons: list of (A, B, C, def_wire) with A, B, C dicts {local wire: coefficient}; n_local wires; out = the local wire of output element 0"""
+    """cons: list of (A, B, C, def_wire) with A, B, C dicts {local wire: coefficient}; n_local wires; out = the local wire of output element 0;
+    out_lcs[i] = output element i as a linear combination of local wires (the last linear layer over the last round's S-box outputs): a
+    circuit that needs more of the output state than element 0 -- a sponge that is SQUEEZED -- ties wires of its own to them
+    (Circuit.output_lc)"""
 
-    def __init__(self, t, n_local, cons, out):
+    def __init__(self, t, n_local, cons, out, out_lcs=None):
         self.t, self.n_local, self.cons, self.out = t, n_local, cons, out
         self.n_internal = n_local - 1 - t
+        self.out_lcs = out_lcs
 
 
 def poseidon_template(t=17):
@@ -79,7 +83,7 @@ def poseidon_template(t=17):
     out = nw
     nw += 1
     cons.append((state[0], {0: 1}, {out: 1}, out))
-    _TEMPLATES[t] = Template(t, nw, cons, out)
+    _TEMPLATES[t] = Template(t, nw, cons, out, [dict(lc) for lc in state])
     return _TEMPLATES[t]
 
 
@@ -107,7 +111,7 @@ class Circuit:
         self.tpl, self.n_pub = template, n_pub
         self.n_wires = 1 + n_pub
         self.instances, self.extras = [], []
-        self._out_wave = {}
+        self._out_wave, self._by_out = {}, {}
 
     def new_wire(self):
         self.n_wires += 1
@@ -127,7 +131,13 @@ class Circuit:
         self.instances.append((list(inputs), base, wave))
         out = base + (self.tpl.out - 1 - self.tpl.t)
         self._out_wave[out] = wave
+        self._by_out[out] = (list(inputs), base)
         return out
+
+    def output_lc(self, out_wire, i):
+        """element i of the output state of the instance whose element-0 wire is `out_wire`, as a linear combination of GLOBAL wires"""
+        inputs, base = self._by_out[out_wire]
+        return {self.local_to_global(inputs, base, k): v for k, v in self.tpl.out_lcs[i].items()}
 
     def add_constraint(self, A, B, C, defines=None):
         """defines: a wire (coefficient 1 in C) that this constraint DEFINES when nobody has set it: value = (A w)(B w) - (rest of C w)"""

@@ -240,7 +240,7 @@ def expectation(params, root32=NV.ROOT32_DEFAULT, shift=NV.SHIFT_DEFAULT):
     return e
 
 
-def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, trust_openings=False, public_transcript=None):
+def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, trust_openings=False, public_transcript=None, trust_indices=False):
     """program: the constraint program blob (u64 words) of the statement;  expect: the verifier's own parameters
     {logn, logb, fri_logf, fri_final_log, n_queries, pow_bits, root32, shift [, hash]}.  hash = "bn128": the proof must be in
     BN128-hash mode (16-ary Poseidon-BN254 trees + transcript); bn_tables = (rc, mds, rp) of the t = 17 instance.
@@ -250,6 +250,8 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, t
     trust_openings: run the WHOLE verifier -- transcript, identity, DEEP quotient and every FRI fold at every query -- on the opened
     values as given, without their authentication paths (which a Merkle-verifier STARK vouches for: oracle/aggregate_verify.py);
     returns the same dictionary instead of True.
+    trust_indices (with trust_openings): the query indices are taken as the proof states them, not compared with the transcript's -- for a
+    proof whose Groth16 wrap hashes the transcript in its circuit and binds the indices there (oracle/wrap_verify.py: verify_rest).
     public_transcript (Goldilocks mode, with trust_openings): a PublicSponge -- the transcript is READ from public inputs a
     verifier-AIR STARK vouches for instead of being hashed here; the caller checks that the stream is used up."""
     rc = np.asarray(rc, dtype=np.uint64)
@@ -381,7 +383,13 @@ def verify(proof, program, rc, mds, expect, bn_tables=None, header_only=False, t
         # the grinding hash is the last permutation of a proof's public transcript: seed || nonce in, digest out
         if public_transcript.pow_digest(seed, nonce)[0] >> (64 - pow_bits):
             raise Reject("proof-of-work nonce missing or wrong")
-    if not header_only and (len(proof["queries"]) != n_queries or [qq["index"] for qq in proof["queries"]] != qidx):
+    if trust_indices and not trust_openings:
+        raise ValueError("trust_indices is for openings a circuit vouches for")
+    if trust_indices:
+        if len(proof["queries"]) != n_queries or any(not isinstance(qq["index"], int) or not 0 <= qq["index"] < M for qq in proof["queries"]):
+            raise Reject("malformed query indices")
+        qidx = [qq["index"] for qq in proof["queries"]]
+    elif not header_only and (len(proof["queries"]) != n_queries or [qq["index"] for qq in proof["queries"]] != qidx):
         raise Reject("query indices do not follow the transcript")
 
     # ---- final layer is low degree: degree < 2^(final_log - logb) on its coset

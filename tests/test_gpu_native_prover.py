@@ -238,7 +238,7 @@ def test_compiled_host_answers_gen_final_proof_like_the_service(tmp_path, tables
     assert (tmp_path / "proof.json").read_text() == want_js and (tmp_path / "public.json").read_text() == want_pub
     pr = CS.parse_proof(want_js)
     proof = {"pi_a": tuple(pr.a), "pi_b": (pr.b.x, pr.b.y), "pi_c": tuple(pr.c)}
-    assert WV.verify(key.vk, proof, CS.parse_public_input(want_pub), json.loads(eng.final_starks["b"]), int(addr), bn254_poseidon_params(17))
+    assert WV.verify(key.vk, proof, CS.parse_public_input(want_pub), json.loads(eng.final_starks["b"]), int(addr), bn254_poseidon_params(17), eng.final_programs["b"])
     # an aggregated proof tampered with has no witness one level up: the host refuses as the service does
     bad = json.loads(agg)
     bad["stark"]["queries"][2]["trace"]["values"][5] ^= 1

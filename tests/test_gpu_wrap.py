@@ -35,9 +35,12 @@ def test_gpu_groth16_of_the_wrap_circuit_equals_the_trapdoor_proof(tables):
     wc = WC.wrap_circuit(WC.Layout.of_air(air, params))
     aux = 12345
     # the caller-set wires from the prover's own binary openings record = what the Python reference assignment reads out of the proof text
-    w0, mask = wc.assign(proof, aux)
+    tlog = WC.TranscriptLog(proof, wc.layout, WC.head_values(air, params, proof["root32"], proof["shift"]))      # the sponge, replayed on the host
+    assert tlog.indices == [q["index"] for q in proof["queries"]]
+    w0, mask = wc.assign(proof, aux, tlog)
     set_idx, set_val = native.wrap_assign(wc.script, hip.stark_openings(), aux)
-    assert (hip.stark_openings() == WC.openings_record(proof, wc.layout)).all()
+    # the one-call prover's own log of its transcript (absorbed blocks, final rates) = the replay, word for word
+    assert (hip.stark_openings() == WC.openings_record(proof, wc.layout, tlog)).all()
     assert sorted(set_idx.tolist()) == np.flatnonzero(mask).tolist() and (w0[set_idx.astype(np.int64)] == set_val).all()
     # witness completion and A w, B w, C w on the GPU (zp_r1cs_eval_device: the gadget instances by the permutation kernel, the glue by a sparse-row
     # kernel) = the host's generic evaluation of the same blob (zp_r1cs_eval), word for word
@@ -55,9 +58,16 @@ def test_gpu_groth16_of_the_wrap_circuit_equals_the_trapdoor_proof(tables):
     rand = (0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA0987654321)
     p_gpu, pubs, ms = G16.prove(key, set_idx, set_val, hip, rand)          # ONE library call: zp_groth16_prove
     p_cpu, pubs_c, _ = G16.prove(key, set_idx, set_val, cpu, rand)
-    assert pubs == pubs_c == [WV.public_input(proof, aux, bn)]
+    assert pubs == pubs_c == [WV.public_input(proof, aux, bn, air.program())]
     assert p_gpu == p_cpu                                   # QAP transforms + five MSMs on the GPU = three scalar multiplications by the trapdoor
-    assert WV.verify(key.vk, p_gpu, pubs, proof, aux, bn)
+    assert WV.verify(key.vk, p_gpu, pubs, proof, aux, bn, air.program())
+    assert WV.verify_rest(proof, air.program(), *tables, V.expectation(params.to_dict()), bn)
+    # stage B-1: the openings of query 1 offered for query 0 (valid leaves and paths, wrong place) -- no witness
+    moved = json.loads(json.dumps(proof))
+    moved["queries"][0] = json.loads(json.dumps(proof["queries"][1]))
+    mi, mv = native.wrap_assign(wc.script, WC.openings_record(moved, wc.layout, tlog), aux)
+    with pytest.raises(ValueError, match="does not satisfy"):
+        G16.prove(key, mi, mv, hip, rand)
     assert not GV.verify(key.vk, p_gpu, [(pubs[0] + 1) % G16.R])
     bad = set_val.copy()
     bad[int(np.flatnonzero(set_idx == np.uint64(wc.q[1]["trees"][2]["levels"][0]["sib"][5]))[0]), 0] ^= np.uint64(1)      # one digest of one path
@@ -90,9 +100,11 @@ def test_engine_final_proof_wraps_the_final_stark(tables, tmp_path):
     g1 = lambda d: (int(d["x"]), int(d["y"]))
     g2 = lambda d: ((int(d["x"][0]), int(d["x"][1])), (int(d["y"][0]), int(d["y"][1])))
     vkp = {"alpha1": g1(vk["alpha1"]), "beta2": g2(vk["beta2"]), "gamma2": g2(vk["gamma2"]), "delta2": g2(vk["delta2"]), "ic": [g1(p) for p in vk["ic"]]}
-    assert WV.verify(vkp, proof, pub, fs, int(addr), bn)
+    assert WV.verify(vkp, proof, pub, fs, int(addr), bn, eng.final_programs["w"])
+    fp = eng.final_stark_params(json.loads(agg)["stark"])
+    assert WV.verify_rest(fs, eng.final_programs["w"], *tables, V.expectation(fp.to_dict(), fs["root32"], fs["shift"]), bn)
     meta = json.loads(js)
-    assert "final-stark-hashing" in meta["circuit"] and "2^21" in meta["circuit"]
+    assert "final-stark-hashing+transcript" in meta["circuit"] and "2^21" in meta["circuit"] and "test key" in meta["circuit"]
     js2, pub2 = eng.final("w", agg, "BN128", addr)
     assert js2 == js and pub2 == pub_js                       # deterministic blinding: the same proof.json
     js3, pub3 = eng.final("w", agg, "BN128", "1")

@@ -117,7 +117,7 @@ def _check_result(res, tables, block, svc=None):
         proof = {"pi_a": (pts[0], pts[1]), "pi_b": ((pts[2], pts[3]), (pts[4], pts[5])), "pi_c": (pts[6], pts[7])}
         assert GV.verify(vkp, proof, [pub])
         assert not GV.verify(vkp, proof, [(pub + 1) % bn254.R])
-        assert "final-stark-hashing" in json.loads(res["proof"])["circuit"]
+        assert "final-stark-hashing+transcript" in json.loads(res["proof"])["circuit"]
         # ... and it names (by digest) a final STARK in BN128-hash mode that the independent verifier accepts
         import hashlib
         from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
@@ -129,7 +129,8 @@ def _check_result(res, tables, block, svc=None):
         # address of the request): recomputed by the checker from the STARK alone (oracle/wrap_verify.py)
         from oracle import wrap_verify as WV
         from eigen_zeth_amd.service.client import DEFAULT_AGGREGATOR_ADDR
-        assert pub == WV.public_input(fsp, int(DEFAULT_AGGREGATOR_ADDR), bn254_poseidon_params(17))
+        fs_id = [k for k, v in svc.engine.final_starks.items() if v == fs[0]][0]
+        assert pub == WV.public_input(fsp, int(DEFAULT_AGGREGATOR_ADDR), bn254_poseidon_params(17), svc.engine.final_programs[fs_id])
         # the recursion layers prove what they name.  (1) the aggregated proof: both chunk-proof headers verify (transcript,
         # out-of-domain identity, final layer), the outer STARK's publics are their roots and transcript-derived indices, and
         # the outer STARK verifies under the Merkle-verifier AIR of that shape

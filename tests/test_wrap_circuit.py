@@ -135,12 +135,18 @@ def test_wrap_circuit_over_a_bn128_stark(final_like, tables, bn):
     assert [t[0] for t in lay.trees] == ["trace", "quotient", "fri0", "fri1"]
     wc = WC.wrap_circuit(lay)
     aux = 479881985774944702531460751064278034642760119942
-    w0, mask = wc.assign(proof, aux)
+    # the transcript of the proof, replayed by the product's own sponge (its permutation = the checker's)
+    head = WC.head_values(air, params, proof["root32"], proof["shift"])
+    tlog = WC.TranscriptLog(proof, lay, head)
+    assert WC.perm17(list(range(17))) == NV.poseidon_bn254_perm(list(range(17)), *bn)
+    assert tlog.indices == [q["index"] for q in proof["queries"]] and tlog.data == WV.transcript_data(proof, air.program(), bn)
+    assert len(tlog.blocks) == len(wc.tblocks) == 9 and len(tlog.rates) == 1
+    w0, mask = wc.assign(proof, aux, tlog)
     wf, a, b, c = native.r1cs_eval(wc.blob, w0, mask)
     d = native.fr_ints(wf[1:2])[0]
-    assert d == WV.public_input(proof, aux, bn) != WV.public_input(proof, aux + 1, bn)
+    assert d == WV.public_input(proof, aux, bn, air.program()) != WV.public_input(proof, aux + 1, bn, air.program())
     # the library's assignment (zp_wrap_assign over the circuit's script and the binary openings) sets the same wires to the same values
-    rec = WC.openings_record(proof, lay)
+    rec = WC.openings_record(proof, lay, tlog)
     set_idx, set_val = native.wrap_assign(wc.script, rec, aux)
     assert sorted(set_idx.tolist()) == np.flatnonzero(mask).tolist() and (w0[set_idx.astype(np.int64)] == set_val).all()
     for cut in (rec[:-1], rec[1:], np.concatenate([rec[:1], rec[1:2] + np.uint64(1), rec[2:]])):
@@ -159,13 +165,79 @@ def test_wrap_circuit_over_a_bn128_stark(final_like, tables, bn):
         bad = copy.deepcopy(proof)
         mutate(bad)
         with pytest.raises(ValueError, match="does not satisfy"):
-            native.r1cs_eval(wc.blob, *wc.assign(bad, aux))
+            native.r1cs_eval(wc.blob, *wc.assign(bad, aux, tlog))
     # a Groth16 proof of the statement: the product's key (scalars by zp_r1cs_key_scalars), the checker's trapdoor prover, the pairing check
     key = G16.Key(wc.blob)
     proof_g, pubs, _ = G16.prove(key, set_idx, set_val, cpu, (11, 13))
-    assert pubs == [d] and WV.verify(key.vk, proof_g, pubs, proof, aux, bn)
+    assert pubs == [d] and WV.verify(key.vk, proof_g, pubs, proof, aux, bn, air.program())
     assert not GV.verify(key.vk, proof_g, [(d + 1) % R])
     with pytest.raises(V.Reject):
-        WV.verify(key.vk, proof_g, pubs, proof, aux + 1, bn)
+        WV.verify(key.vk, proof_g, pubs, proof, aux + 1, bn, air.program())
     js = json.loads(G16.proof_to_json(proof_g))
     assert js["protocol"] == "groth16" and js["curve"] == "BN128" and js["pi_b"]["x"][0].isdigit()
+    # what the holder of the final STARK still checks natively: the arithmetic, at the indices as given
+    assert WV.verify_rest(proof, air.program(), rc, mds, V.expectation(params.to_dict()), bn)
+
+
+def test_indices_are_bound_by_the_transcript_in_the_circuit(final_like, tables, bn):
+    """stage B-1 (round 5): a final STARK whose query indices are ALTERED -- with openings and authentication paths that are consistent with the
+    new positions, i.e. a proof round 4's circuit had a witness for -- has no witness any more: the bits that select the path positions are the
+    transcript's.  Neither has one whose transcript data (an out-of-domain evaluation, the final layer, a parameter) differs from what was
+    hashed.  The checker's side: with the arithmetic checked at the indices as given (verify_rest), only d and the pairing stand between an
+    index swap and acceptance -- and d's circuit refuses it."""
+    cpu, air, params, proof = final_like
+    rc, mds = tables
+    lay = WC.Layout.of_air(air, params)
+    wc = WC.wrap_circuit(lay)
+    aux = 7
+    head = WC.head_values(air, params, proof["root32"], proof["shift"])
+    tlog = WC.TranscriptLog(proof, lay, head)
+    # (a) re-open the SAME commitments at another position: the prover of `proof` can do that for any index (it holds the trees) -- here the
+    # openings of query 1 stand in for query 0 (valid paths, valid leaves, wrong place to look)
+    moved = copy.deepcopy(proof)
+    moved["queries"][0] = copy.deepcopy(proof["queries"][1])
+    assert moved["queries"][0]["index"] != proof["queries"][0]["index"]
+    with pytest.raises(ValueError, match="does not satisfy"):
+        native.r1cs_eval(wc.blob, *wc.assign(moved, aux, tlog))
+    # ... and claiming the rate elements that WOULD give those indices does not help: they are tied to the sponge's output state
+    forged = copy.deepcopy(tlog)
+    e = forged.rates[0][0]
+    forged.rates[0][0] = (e & ~((1 << lay.logm) - 1)) | moved["queries"][0]["index"]
+    forged.indices[0] = moved["queries"][0]["index"]
+    with pytest.raises(ValueError, match="does not satisfy"):
+        native.r1cs_eval(wc.blob, *wc.assign(moved, aux, forged))
+    # (b) transcript data that is not what was absorbed
+    for field in ("z", "final", "head"):
+        bad, tl = copy.deepcopy(proof), None
+        if field == "z":
+            bad["evals"]["z"][3][1] ^= 1
+            tl = WC.TranscriptLog(bad, lay, head)                  # an honest replay of the altered data: other indices come out
+            assert tl.indices != tlog.indices
+        elif field == "final":
+            bad["fri"]["final"][2][5] ^= 1
+            tl = WC.TranscriptLog(bad, lay, head)
+        else:
+            tl = WC.TranscriptLog(bad, lay, head[:6] + [head[6] + 1] + head[7:])     # another n_queries in the parameter block
+        with pytest.raises(ValueError, match="does not satisfy"):
+            native.r1cs_eval(wc.blob, *wc.assign(bad, aux, tl))      # the openings are those of the old indices
+        # the data alone (indices kept as the old transcript gave them): the sponge's output no longer has those bits
+        keep = copy.deepcopy(tl)
+        keep.rates, keep.indices = tlog.rates, tlog.indices
+        with pytest.raises(ValueError, match="does not satisfy"):
+            native.r1cs_eval(wc.blob, *wc.assign(bad, aux, keep))
+    # (c) a non-canonical decomposition (value + r) of a rate element is refused by the < r chain: flip the witness bits by hand
+    w0, mask = wc.assign(proof, aux, tlog)
+    bits = wc.ebits[(0, 0)]
+    alt = tlog.rates[0][0] + R
+    if alt < (1 << 254):
+        for i, bw in enumerate(bits):
+            w0[bw] = native.fr_words([(alt >> i) & 1])[0]
+        with pytest.raises(ValueError, match="does not satisfy"):
+            native.r1cs_eval(wc.blob, w0, mask)
+    # the checker: d differs for the moved proof, so the honest Groth16 proof does not cover it
+    assert WV.public_input(moved, aux, bn, air.program()) != WV.public_input(proof, aux, bn, air.program())
+    # ... which is ALL that stands in its way: the arithmetic at the moved position is that of a genuine opening, so verify_rest (which takes the
+    # indices as given) accepts it -- exactly why the indices had to be bound inside the circuit
+    assert WV.verify_rest(moved, air.program(), rc, mds, V.expectation(params.to_dict()), bn)
+    with pytest.raises(V.Reject):                                  # (the full verifier, which hashes the transcript itself, refuses it)
+        V.verify(moved, air.program(), rc, mds, V.expectation(params.to_dict()), bn)
