@@ -1,0 +1,156 @@
+// The out-of-domain side of a constraint program, on the host: what a VERIFIER does with a statement at the point zeta.
+// GenFinalProof (proto/prover/v1/prover.proto:130-148; src/prover/provider.rs:472-503) wraps an aggregated proof the CLIENT hands in: before
+// the service spends a final STARK and a Groth16 proof on it, it checks natively what the final STARK's witness does not cover -- the
+// aggregation STARK's constraint identity at its out-of-domain point (eigen_zeth_amd/stark/verifier.py; round-4 advisor item: "a
+// pairing-valid final proof can be produced over an aggregated proof whose arithmetic is false").  The verifier AIR of an aggregation has
+// ~10^2 fixed columns with ~4 x 10^5 sparse entries: their values at zeta are sums over the entries with one F_{p^3} inversion each --
+// seconds in Python, milliseconds here (one shared inversion per column by Montgomery's trick, columns spread over threads).
+// No reference counterpart (the prover behind the gRPC boundary is external); the checker's own statement of the same: oracle/air_program.py
+// (fixed_eval_ext, evaluate_ext) -- the tests compare the two.
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "ctx.hpp"
+
+namespace {
+
+inline e3 e3_base(u64 v) { return e3_make(v, 0, 0); }
+inline e3 e3_pow2k(e3 a, int k) { for (int i = 0; i < k; i++) a = e3_mul(a, a); return a; }
+
+// g(y) (y^p - 1) form of one sparse periodic column at zeta: sum_e v_e w_p^pos / (p (y - w_p^pos)) * (y^p - 1), y = zeta^(N / p)
+bool fixed_col_at(const uint64_t *prog, const ZpFixedCol &fc, const uint64_t *pubs, int logn, u64 root32, const e3 &zeta, const e3 &zh, e3 *out) {
+    if (fc.lp > logn) return false;
+    const e3 y = e3_pow2k(zeta, logn - fc.lp);
+    const u64 wp = fc.lp ? gl_root(root32, fc.lp) : 1;
+    const u64 pinv = gl_inv((1ULL << fc.lp) % GL_P);
+    std::vector<e3> den, pre;
+    std::vector<u64> coef;
+    den.reserve(fc.n_entries); coef.reserve(fc.n_entries);
+    for (size_t e = 0; e < fc.n_entries; e++) {
+        const u64 a = prog[fc.first_entry_word + 2 * e], v = prog[fc.first_entry_word + 2 * e + 1];
+        const u64 val = (a >> 63) ? pubs[v] % GL_P : v;
+        if (!val) continue;
+        const u64 wj = gl_pow(wp, a & ~(1ULL << 63));
+        coef.push_back(gl_mul(gl_mul(val, wj), pinv));
+        den.push_back(e3_make(gl_sub(y.c[0], wj), y.c[1], y.c[2]));
+    }
+    e3 run = e3_base(1);
+    pre.resize(den.size());
+    for (size_t i = 0; i < den.size(); i++) { pre[i] = run; run = e3_mul(run, den[i]); }
+    u64 det;
+    const e3 adj = e3_adj(run, &det);
+    if (!den.empty() && det == 0) return false;              // zeta on the domain
+    e3 inv = den.empty() ? e3_base(1) : e3_scale(adj, gl_inv(det));
+    e3 acc = e3_base(0);
+    for (size_t i = den.size(); i-- > 0;) {
+        const e3 dinv = e3_mul(inv, pre[i]);
+        inv = e3_mul(inv, den[i]);
+        acc = e3_add(acc, e3_scale(dinv, coef[i]));
+    }
+    *out = e3_mul(acc, zh);
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Values of the K constraints of a program at the out-of-domain point of a proof over a trace of 2^logn rows.
+//   h_pubchal u64[n_pubchal]: the public inputs, then the stage-2 challenge components (what the prover's interpreter reads as K_PUB)
+//   zeta[3]; h_ev_z / h_ev_zw u64[W + W2][3]: the committed columns' evaluations at zeta / zeta w
+//   h_out u64[K][3]: constraint k at zeta (numerators: the caller combines them with its alpha powers and compares with q(zeta) Z_H(zeta))
+// Fixed columns: 0 / 1 the first-row / last-row selectors (Lagrange basis polynomials), then the sparse periodic columns; "x - last" is
+// zeta - w^(N-1).  ZP_ERR_ARG: malformed program, non-canonical input, zeta on the trace domain.  threads <= 0: one per core, at most 16.
+int32_t zp_program_eval_ext(const uint64_t *h_program, size_t program_words, const uint64_t *h_pubchal, int32_t n_pubchal, int32_t logn, uint64_t root32,
+                            const uint64_t zeta3[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t *h_out, int32_t threads) {
+    try {
+        if (!h_program || !zeta3 || !h_ev_z || !h_ev_zw || !h_out || program_words < 12 || logn < 1 || logn > 32 || n_pubchal < 0 || (n_pubchal && !h_pubchal))
+            return ZP_ERR_ARG;
+        static const unsigned char magic[8] = {'Z', 'P', 'A', 'I', 'R', '1', 0, 0};
+        if (memcmp(h_program, magic, 8) != 0) return ZP_ERR_ARG;
+        const size_t W = h_program[1], W2 = h_program[2], n_fixed = h_program[3], n_pub = h_program[4], n_chal = h_program[5], n_const = h_program[6],
+                     n_instr = h_program[7], K = h_program[8], n_slots = h_program[9];
+        std::vector<ZpFixedCol> fxc;
+        if (!zpi_program_fixed_table(h_program, program_words, &fxc) || W < 1 || W >= 4096 || W2 >= 4096 || n_slots > (1u << 16) || K < 1 ||
+            (size_t)n_pubchal != n_pub + n_chal || root32 == 0 || root32 >= GL_P)
+            return ZP_ERR_ARG;
+        for (int i = 0; i < 3; i++)
+            if (zeta3[i] >= GL_P) return ZP_ERR_ARG;
+        for (int i = 0; i < n_pubchal; i++)
+            if (h_pubchal[i] >= GL_P) return ZP_ERR_ARG;
+        const size_t Wt = W + W2;
+        for (size_t i = 0; i < Wt * 3; i++)
+            if (h_ev_z[i] >= GL_P || h_ev_zw[i] >= GL_P) return ZP_ERR_ARG;
+        const e3 zeta = e3_make(zeta3[0], zeta3[1], zeta3[2]);
+        const u64 N = 1ULL << logn, wN = gl_root(root32, logn), wlast = gl_pow(wN, N - 1), ninv = gl_inv(N % GL_P);
+        const e3 zN = e3_pow2k(zeta, logn), zh = e3_make(gl_sub(zN.c[0], 1), zN.c[1], zN.c[2]);
+        std::vector<e3> fixed(n_fixed);
+        {
+            u64 d0, d1;
+            const e3 a0 = e3_adj(e3_make(gl_sub(zeta.c[0], 1), zeta.c[1], zeta.c[2]), &d0), a1 = e3_adj(e3_make(gl_sub(zeta.c[0], wlast), zeta.c[1], zeta.c[2]), &d1);
+            if (d0 == 0 || d1 == 0) return ZP_ERR_ARG;
+            fixed[0] = e3_mul(e3_scale(zh, ninv), e3_scale(a0, gl_inv(d0)));
+            fixed[1] = e3_mul(e3_scale(zh, gl_mul(ninv, wlast)), e3_scale(a1, gl_inv(d1)));
+        }
+        // the sparse columns over threads (columns differ a lot in length: hand them out one at a time)
+        unsigned nt = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+        nt = nt < 1 ? 1 : nt > 16 ? 16 : nt;
+        if (fxc.size() < 8) nt = 1;
+        std::vector<int> bad(nt, 0);
+        auto work = [&](unsigned t) noexcept {
+            try {
+                for (size_t k = t; k < fxc.size(); k += nt)
+                    if (!fixed_col_at(h_program, fxc[k], h_pubchal, logn, root32, zeta, zh, &fixed[2 + k])) { bad[t] = 1; return; }
+            } catch (...) { bad[t] = 2; }
+        };
+        {
+            std::vector<std::thread> th;
+            unsigned started = 0;
+            try { for (unsigned t = 1; t < nt; t++) { th.emplace_back(work, t); started = t; } } catch (...) {}
+            work(0);
+            for (unsigned t = started + 1; t < nt; t++) work(t);      // threads that could not be started: their share runs here
+            for (auto &x : th) x.join();
+        }
+        for (int b : bad)
+            if (b) return b == 2 ? ZP_ERR_NOMEM : ZP_ERR_ARG;
+        const e3 xml = e3_make(gl_sub(zeta.c[0], wlast), zeta.c[1], zeta.c[2]);
+        // the three-address code in F_{p^3} (layout: stark/air.py compile_program; the prover's interpreter: csrc/stark.hip quotient_program_kernel)
+        const uint64_t *consts = h_program + 12, *ins = consts + n_const;
+        std::vector<e3> slot(n_slots ? n_slots : 1, e3_base(0));
+        size_t k_out = 0;
+        bool ok = true;
+        auto operand = [&](u64 kind, u64 idx) -> e3 {
+            switch (kind) {
+                case 0: if (idx >= slot.size()) { ok = false; return e3_base(0); } return slot[idx];
+                case 1: if (idx >= Wt) { ok = false; return e3_base(0); } return e3_make(h_ev_z[3 * idx], h_ev_z[3 * idx + 1], h_ev_z[3 * idx + 2]);
+                case 2: if (idx >= Wt) { ok = false; return e3_base(0); } return e3_make(h_ev_zw[3 * idx], h_ev_zw[3 * idx + 1], h_ev_zw[3 * idx + 2]);
+                case 3: if (idx >= n_fixed) { ok = false; return e3_base(0); } return fixed[idx];
+                case 4: if (idx >= (size_t)n_pubchal) { ok = false; return e3_base(0); } return e3_base(h_pubchal[idx]);
+                case 5: if (idx >= n_const) { ok = false; return e3_base(0); } return e3_base(consts[idx] % GL_P);
+                case 6: return xml;
+                default: ok = false; return e3_base(0);
+            }
+        };
+        for (size_t i = 0; i < n_instr && ok; i++) {
+            const u64 w = ins[i], op = w & 0xFF, d = (w >> 8) & 0xFFFF, ka = (w >> 24) & 0xF, ia = (w >> 28) & 0xFFFF, kb = (w >> 44) & 0xF, ib = (w >> 48) & 0xFFFF;
+            const e3 a = operand(ka, ia);
+            if (op == 4) {                     // OUT: constraint k_out is this value
+                if (k_out >= K) return ZP_ERR_ARG;
+                memcpy(h_out + 3 * k_out++, a.c, 24);
+                continue;
+            }
+            const e3 b = operand(kb, ib);
+            if (d >= slot.size()) return ZP_ERR_ARG;
+            if (op == 1) slot[d] = e3_add(a, b);
+            else if (op == 2) slot[d] = e3_sub(a, b);
+            else if (op == 3) slot[d] = e3_mul(a, b);
+            else return ZP_ERR_ARG;
+        }
+        return ok && k_out == K ? ZP_OK : ZP_ERR_ARG;
+    } catch (...) {
+        return ZP_ERR_NOMEM;
+    }
+}
+
+}  // extern "C"

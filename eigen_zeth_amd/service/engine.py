@@ -32,6 +32,7 @@ from . import bn254
 from . import groth16
 from . import statement
 from . import wrap_circuit as WC
+from ..stark import verifier as SV
 
 
 @contextlib.contextmanager
@@ -73,8 +74,11 @@ class EngineConfig:
                  witness_threads=8, prover_streams=8, pow_bits=20,
                  final_air="chunk16", final_logn=10, final_logb=2, final_queries=50, native_prover=True,
                  agg_queries=50, agg_pow_bits=0, aggregate_all_chunks=False, groth16_seed=None, witness="device",
-                 speculate_recursion=False):
+                 speculate_recursion=False, verify_before_wrap=True):
         self.air, self.logn, self.logb = air, logn, logb
+        # GenFinalProof: check natively, before the final STARK and the wrap are made, what no query of the aggregation STARK covers (its
+        # constraint identity at the out-of-domain point, its final layer, its grinding: stark/verifier.py).  Off only for timing experiments.
+        self.verify_before_wrap = verify_before_wrap
         # GenAggregatedProof names two proofs -- the client sends the first and the last chunk proof of a batch
         # (src/prover/provider.rs:385-388).  False: exactly those two are verified (the wire contract taken literally).  True: when
         # they ARE the first and last chunk proof of a batch this engine has just proven, every chunk proof of the batch is verified
@@ -686,9 +690,16 @@ class Engine:
             agg_air = VA.verifier_air(agg_shape, *self._tables(self.be_bn128))   # the statement of agg["stark"]
             if agg.get("verifier_air_digest") != agg_air.digest() or outer.get("air_digest") != agg_air.digest():
                 raise ValueError("aggregated proof is over another verifier AIR")
+            # The text is the client's.  The final STARK below proves the aggregation STARK's QUERY phase (its witness does not exist when a
+            # path, the DEEP quotient or a fold fails); what no query covers -- the constraint identity at the out-of-domain point, the final
+            # layer's degree, the grinding -- is checked here, natively, before anything is proven (stark/verifier.py; round-4 advisor item)
+            t0 = time.perf_counter()
+            if self.cfg.verify_before_wrap:
+                SV.verify_header(outer, agg_air, self._agg_params(agg_shape), self.be)
+            t_hdr = time.perf_counter() - t0
         except (json.JSONDecodeError, TypeError, KeyError, AssertionError, ValueError) as e:
             raise ValueError("recursive proof is not an aggregated proof of this prover (%s)" % e)
-        tmf = {}
+        tmf = {"verify-aggregated-header": t_hdr}
         fshape, fair, fp, final_stark = self._prove_merkle_verifier([outer], lambda sh: self.final_stark_params(outer), self.be_bn128, tmf, agg_air, [prep])
         openings = None
         if self.cfg.native_prover and hasattr(self.be_bn128, "stark_openings"):

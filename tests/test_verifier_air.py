@@ -405,3 +405,53 @@ def test_native_proof_text_parser_equals_the_json_path(inner, cpu, tables, monke
     t1, p1 = VA.build_witness(shape, [whole_f], cpu, air.digest_words(), [prep_f])
     t2, p2 = VA.build_witness(shape, [whole_s], cpu, air.digest_words(), [prep_s])
     assert (t1 == t2).all() and (p1 == p2).all()
+
+
+def test_product_header_verifier_agrees_with_the_checker(inner, aggregated, cpu, tables):
+    """stark/verifier.py (what Engine.final() runs on the client's aggregated proof before wrapping it; constraint identity through the library's
+    zp_program_eval_ext) against the checker's verifier in header-only mode: same verdict and same transcript outputs on a chunk proof (stage-2
+    columns, grinding, inline public inputs) and on an aggregation STARK over two of them (a verifier AIR: ~10^2 sparse fixed columns, some with
+    public-input entries, thousands of public inputs entering through their commitment); and it refuses what the queries do not cover."""
+    from eigen_zeth_amd.stark import verifier as SV
+    air, params, proofs = inner
+    rc, mds = tables
+    want = V.verify(proofs[0], air.program(), rc, mds, V.expectation(params.to_dict()), header_only=True)
+    got = SV.verify_header(proofs[0], air, params, cpu)
+    assert got["indices"] == want["indices"] and got["zeta"] == want["zeta"] and got["gamma"] == want["gamma"] and got["betas"] == want["betas"]
+    shape, vair, ap, _, _, agg = aggregated
+    outer = json.loads(PR.proof_to_json(agg["stark"]))
+    NV = V.NV
+    want = V.verify(outer, vair.program(), rc, mds, V.expectation(ap.to_dict()), header_only=True)
+    got = SV.verify_header(outer, vair, ap, cpu)
+    assert got["indices"] == want["indices"] and got["zeta"] == want["zeta"]
+    # the library's evaluation of the statement at zeta = the checker's own interpreter over F_{p^3}, constraint by constraint
+    from oracle.air_program import Program
+    prog = Program(vair.program())
+    Wt = vair.width + vair.width2
+    zeta, N = want["zeta"], 1 << ap.logn
+    wlast = pow(NV.root(ap.logn, outer["root32"]), N - 1, V.P)
+    zh = [(v - (1 if i == 0 else 0)) % V.P for i, v in enumerate(NV.e3_pow(zeta, N))]
+    ninv = pow(N, V.P - 2, V.P)
+    l_first = NV.e3_mul([v * ninv % V.P for v in zh], NV.e3_inv([(zeta[0] - 1) % V.P, zeta[1], zeta[2]]))
+    l_last = NV.e3_mul([v * ninv % V.P * wlast % V.P for v in zh], NV.e3_inv([(zeta[0] - wlast) % V.P, zeta[1], zeta[2]]))
+    fixed_z = [l_first, l_last] + [prog.fixed_eval_ext(k, outer["publics"], zeta, ap.logn, outer["root32"]) for k in range(len(prog.fixed_cols))]
+    cs = prog.evaluate_ext(outer["evals"]["z"][:Wt], outer["evals"]["zw"], fixed_z, list(outer["publics"]), [(zeta[0] - wlast) % V.P, zeta[1], zeta[2]])
+    lib = native.program_eval_ext(vair.program(), outer["publics"], ap.logn, outer["root32"], zeta, outer["evals"]["z"][:Wt], outer["evals"]["zw"], threads=3)
+    assert lib.tolist() == [[int(v) % V.P for v in c] for c in cs]
+    # refused: an evaluation that is not the polynomial's, a final layer of too high a degree, another security level, a trimmed program
+    for mutate, why in ((lambda p: p["evals"]["z"][1].__setitem__(0, (p["evals"]["z"][1][0] + 1) % V.P), "identity"),
+                        (lambda p: p["evals"]["zw"][0].__setitem__(2, (p["evals"]["zw"][0][2] + 1) % V.P), "identity"),
+                        (lambda p: p["fri"]["final"][0].__setitem__(3, (p["fri"]["final"][0][3] + 1) % V.P), "low degree"),
+                        (lambda p: p["params"].__setitem__("n_queries", 1), "parameters"),
+                        (lambda p: p["publics"].__setitem__(7, (p["publics"][7] + 1) % V.P), "identity"),
+                        (lambda p: p["roots"].__setitem__("quotient", p["roots"]["quotient"][:3]), "root")):
+        bad = copy.deepcopy(outer)
+        mutate(bad)
+        with pytest.raises(SV.Reject, match=why):
+            SV.verify_header(bad, vair, ap, cpu)
+        with pytest.raises((V.Reject, KeyError, IndexError, ValueError, TypeError)):
+            V.verify(bad, vair.program(), rc, mds, V.expectation(ap.to_dict()), header_only=True)
+    with pytest.raises(ValueError):
+        native.program_eval_ext(vair.program()[:-2], outer["publics"], ap.logn, outer["root32"], zeta, outer["evals"]["z"][:Wt], outer["evals"]["zw"])
+    with pytest.raises(ValueError):                                  # zeta on the trace domain
+        native.program_eval_ext(vair.program(), outer["publics"], ap.logn, outer["root32"], [1, 0, 0], outer["evals"]["z"][:Wt], outer["evals"]["zw"])
