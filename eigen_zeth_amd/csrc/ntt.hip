@@ -1408,6 +1408,21 @@ __global__ void __launch_bounds__(256) hbm_copy_kernel(const zp_u32x4 *__restric
     for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
+// the same copy with default-policy (cacheable) loads and stores: which of the two the chip streams faster is measured, not assumed
+// (knob copy_nt: 1 = non-temporal, the round 1-4 probe; 0 = default policy; knob copy_grid: workgroups, 0 = 2048)
+__global__ void __launch_bounds__(256) hbm_copy_plain_kernel(const zp_u32x4 *__restrict__ in, zp_u32x4 *__restrict__ out, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const zp_u32x4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
+        out[i] = a;
+        out[i + stride] = b;
+        out[i + 2 * stride] = c;
+        out[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) out[i] = in[i];
+}
+
 extern "C" int32_t zp_hbm_copy_probe(zp_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int32_t reps, float *ms_per_copy) {
     if (!ctx) return ZP_ERR_ARG;
     ZP_BIND(ctx);
@@ -1415,10 +1430,12 @@ extern "C" int32_t zp_hbm_copy_probe(zp_ctx *ctx, const void *d_src, void *d_dst
     hipEvent_t e0, e1;
     ZP_HIP(ctx, hipEventCreate(&e0));
     ZP_HIP(ctx, hipEventCreate(&e1));
-    hipLaunchKernelGGL(hbm_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const zp_u32x4 *)d_src, (zp_u32x4 *)d_dst, bytes / 16);
+    const unsigned grid = ctx->tune_copy_grid > 0 ? (unsigned)ctx->tune_copy_grid : 2048u;
+    auto k = ctx->tune_copy_nt ? hbm_copy_kernel : hbm_copy_plain_kernel;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, ctx->stream, (const zp_u32x4 *)d_src, (zp_u32x4 *)d_dst, bytes / 16);
     ZP_HIP(ctx, hipEventRecord(e0, ctx->stream));
     for (int r = 0; r < reps; r++)
-        hipLaunchKernelGGL(hbm_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const zp_u32x4 *)d_src, (zp_u32x4 *)d_dst, bytes / 16);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, ctx->stream, (const zp_u32x4 *)d_src, (zp_u32x4 *)d_dst, bytes / 16);
     ZP_HIP(ctx, hipEventRecord(e1, ctx->stream));
     ZP_HIP(ctx, hipEventSynchronize(e1));
     float ms = 0.f;

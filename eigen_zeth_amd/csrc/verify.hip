@@ -24,6 +24,14 @@ bool fixed_col_at(const uint64_t *prog, const ZpFixedCol &fc, const uint64_t *pu
     const e3 y = e3_pow2k(zeta, logn - fc.lp);
     const u64 wp = fc.lp ? gl_root(root32, fc.lp) : 1;
     const u64 pinv = gl_inv((1ULL << fc.lp) % GL_P);
+    // w_p^pos from a two-level table (2 x 2^(lp/2) entries): one product per entry instead of a 64-step power
+    const int lb = (fc.lp + 1) / 2;
+    std::vector<u64> lo((size_t)1 << lb), hi((size_t)1 << (fc.lp - lb));
+    lo[0] = 1;
+    for (size_t i = 1; i < lo.size(); i++) lo[i] = gl_mul(lo[i - 1], wp);
+    const u64 wl = gl_mul(lo.back(), wp);
+    hi[0] = 1;
+    for (size_t i = 1; i < hi.size(); i++) hi[i] = gl_mul(hi[i - 1], wl);
     std::vector<e3> den, pre;
     std::vector<u64> coef;
     den.reserve(fc.n_entries); coef.reserve(fc.n_entries);
@@ -31,7 +39,8 @@ bool fixed_col_at(const uint64_t *prog, const ZpFixedCol &fc, const uint64_t *pu
         const u64 a = prog[fc.first_entry_word + 2 * e], v = prog[fc.first_entry_word + 2 * e + 1];
         const u64 val = (a >> 63) ? pubs[v] % GL_P : v;
         if (!val) continue;
-        const u64 wj = gl_pow(wp, a & ~(1ULL << 63));
+        const u64 pos = a & ~(1ULL << 63);
+        const u64 wj = gl_mul(lo[pos & (((u64)1 << lb) - 1)], hi[pos >> lb]);
         coef.push_back(gl_mul(gl_mul(val, wj), pinv));
         den.push_back(e3_make(gl_sub(y.c[0], wj), y.c[1], y.c[2]));
     }

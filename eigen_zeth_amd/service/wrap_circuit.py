@@ -118,8 +118,10 @@ R_BITS = [(R >> i) & 1 for i in range(254)]
 def perm17(state):
     """the width-17 Poseidon-BN254 permutation on Python integers (tables: poseidon_constants.bn254_poseidon_params) -- for the reference
     assignment of small circuits and for openings records of proofs that were not made by the library's one-call prover"""
-    from ..poseidon_constants import bn254_poseidon_params
-    rc, mds, rp = bn254_poseidon_params(17)
+    if "p17" not in _CACHE:            # (the tables come out of the Grain LFSR: seconds to regenerate)
+        from ..poseidon_constants import bn254_poseidon_params
+        _CACHE["p17"] = bn254_poseidon_params(17)
+    rc, mds, rp = _CACHE["p17"]
     st = [int(v) % R for v in state]
     for r in range(8 + rp):
         st = [(v + rc[r * 17 + i]) % R for i, v in enumerate(st)]
