@@ -472,6 +472,8 @@ int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value) {
     else if (!strcmp(key, "lde_seam_plans")) ctx->tune_lde_seam_plans = value;
     else if (!strcmp(key, "copy_grid")) ctx->tune_copy_grid = value;
     else if (!strcmp(key, "copy_nt")) ctx->tune_copy_nt = value;
+    else if (!strcmp(key, "copy_block")) ctx->tune_copy_block = value;
+    else if (!strcmp(key, "copy_unroll")) ctx->tune_copy_unroll = value;
     else if (!strcmp(key, "merkle_coop_log")) ctx->tune_merkle_coop_log = value;
     else if (!strcmp(key, "p254_bulk_log")) ctx->tune_p254_bulk_log = value;
     else { ctx->err = "unknown tuning key"; return ZP_ERR_ARG; }

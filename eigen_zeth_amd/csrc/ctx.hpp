@@ -75,7 +75,7 @@ struct zp_ctx {
     int tune_ntt_limb = 0;        // 1: register butterflies on the four-limb form of gl_limb.hpp (bit-identical, 17-35 % fewer VALU cycles, but 168 VGPRs and 48 KiB of LDS: 3 workgroups per CU instead of 4 -- measured 4 % slower, profiles/r4_ntt_limb_ab.txt)
     int tune_lde_seam = 1;        // blow-up 2 with radix-256 passes on both sides of the seam: the inverse transform's last pass and the forward one's first in ONE kernel (0: two launches through the coefficient buffer)
     int tune_seam_tpw = 2;        // inverse tiles per workgroup of the seam kernel
-    int tune_copy_grid = 0, tune_copy_nt = 1;   // zp_hbm_copy_probe: workgroups (0 = 2048) and load/store policy (1 = non-temporal) of the ceiling measurement
+    int tune_copy_grid = 0, tune_copy_nt = 1, tune_copy_block = 0, tune_copy_unroll = 0;   // zp_hbm_copy_probe: workgroups (0 = 256: one per CU), policy (1 = non-temporal), lanes per workgroup (0 = 256), 16-byte loads in flight per lane (0 = 4)
     int tune_lde_seam_plans = 1;  // the fused extension may use plans made for it (an inverse plan ending / a forward plan starting in a radix-256 pass) where the default plans do not meet in one (0: default plans only)
     int tune_g16_parallel = 1;    // zp_groth16_prove: the five MSMs of a proof on five streams at once (0: one after the other)
     int tune_ntt_order = 0;       // plan digit order: 0 auto (a radix-512 digit goes last), 1 larger radices first, 2 larger radices last

@@ -1391,34 +1391,26 @@ int32_t zpi_twiddle_rows(zp_ctx *ctx, u64 *d_rows, int logn_row, int W, u64 row0
     return ZP_OK;
 }
 
-// ---- measurement: what this device sustains on a plain copy, with this library's own kernel (16 bytes per lane,
-// non-temporal, 2048 workgroups each keeping four loads in flight) -- the ceiling bench.py prints next to the vendor peak
+// ---- measurement: what this device sustains on a plain copy, with this library's own kernel (16 bytes per lane, one persistent workgroup
+// per CU by default since round 5) -- the ceiling bench.py prints next to the vendor peak
 typedef __attribute__((ext_vector_type(4))) unsigned int zp_u32x4;
-__global__ void __launch_bounds__(256) hbm_copy_kernel(const zp_u32x4 *__restrict__ in, zp_u32x4 *__restrict__ out, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const zp_u32x4 a = __builtin_nontemporal_load(in + i), b = __builtin_nontemporal_load(in + i + stride);
-        const zp_u32x4 c = __builtin_nontemporal_load(in + i + 2 * stride), d = __builtin_nontemporal_load(in + i + 3 * stride);
-        __builtin_nontemporal_store(a, out + i);
-        __builtin_nontemporal_store(b, out + i + stride);
-        __builtin_nontemporal_store(c, out + i + 2 * stride);
-        __builtin_nontemporal_store(d, out + i + 3 * stride);
-    }
-    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
-}
-
-// the same copy with default-policy (cacheable) loads and stores: which of the two the chip streams faster is measured, not assumed
-// (knob copy_nt: 1 = non-temporal, the round 1-4 probe; 0 = default policy; knob copy_grid: workgroups, 0 = 2048)
-__global__ void __launch_bounds__(256) hbm_copy_plain_kernel(const zp_u32x4 *__restrict__ in, zp_u32x4 *__restrict__ out, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const zp_u32x4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
-        out[i] = a;
-        out[i + stride] = b;
-        out[i + 2 * stride] = c;
-        out[i + 3 * stride] = d;
+// U loads of 16 bytes in flight per lane, then U stores; NT: non-temporal policy (the data is touched once) or the default one.  Which grid,
+// block size, depth and policy stream fastest is MEASURED (tools/ntt_r5_ab.py -> profiles/r5_ntt_ab.txt; knobs copy_grid / copy_block /
+// copy_unroll / copy_nt): round 5 found one workgroup per CU (256 x 256 lanes, 4 in flight) at 5.6 TB/s against 4.9 for the 2048-workgroup
+// grid of rounds 1-4 -- fewer concurrent streams, not more, is what HBM3E wants.
+template <int U, bool NT>
+__global__ void __launch_bounds__(1024) hbm_copy_kernel(const zp_u32x4 *__restrict__ in, zp_u32x4 *__restrict__ out, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        zp_u32x4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) v[k] = NT ? __builtin_nontemporal_load(in + i + k * stride) : in[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            if (NT) __builtin_nontemporal_store(v[k], out + i + k * stride);
+            else out[i + k * stride] = v[k];
+        }
     }
     for (; i < n16; i += stride) out[i] = in[i];
 }
@@ -1430,12 +1422,14 @@ extern "C" int32_t zp_hbm_copy_probe(zp_ctx *ctx, const void *d_src, void *d_dst
     hipEvent_t e0, e1;
     ZP_HIP(ctx, hipEventCreate(&e0));
     ZP_HIP(ctx, hipEventCreate(&e1));
-    const unsigned grid = ctx->tune_copy_grid > 0 ? (unsigned)ctx->tune_copy_grid : 2048u;
-    auto k = ctx->tune_copy_nt ? hbm_copy_kernel : hbm_copy_plain_kernel;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, ctx->stream, (const zp_u32x4 *)d_src, (zp_u32x4 *)d_dst, bytes / 16);
+    const unsigned grid = ctx->tune_copy_grid > 0 ? (unsigned)ctx->tune_copy_grid : 256u;
+    const unsigned block = (ctx->tune_copy_block == 512 || ctx->tune_copy_block == 1024) ? (unsigned)ctx->tune_copy_block : 256u;
+    const bool u8 = ctx->tune_copy_unroll == 8;
+    auto k = ctx->tune_copy_nt ? (u8 ? hbm_copy_kernel<8, true> : hbm_copy_kernel<4, true>) : (u8 ? hbm_copy_kernel<8, false> : hbm_copy_kernel<4, false>);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), 0, ctx->stream, (const zp_u32x4 *)d_src, (zp_u32x4 *)d_dst, bytes / 16);
     ZP_HIP(ctx, hipEventRecord(e0, ctx->stream));
     for (int r = 0; r < reps; r++)
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, ctx->stream, (const zp_u32x4 *)d_src, (zp_u32x4 *)d_dst, bytes / 16);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(block), 0, ctx->stream, (const zp_u32x4 *)d_src, (zp_u32x4 *)d_dst, bytes / 16);
     ZP_HIP(ctx, hipEventRecord(e1, ctx->stream));
     ZP_HIP(ctx, hipEventSynchronize(e1));
     float ms = 0.f;

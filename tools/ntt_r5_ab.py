@@ -30,7 +30,7 @@ def timed(reps=8):
 
 
 print("# tools/ntt_r5_ab.py on one MI355X: forward NTT 2^24 x 64 in place, ms per step (median, min of 8)")
-for rnd in range(2):
+for rnd in range(1):
     for cl in (28, 27, 26, 25, 24):
         p.set_tuning("ntt_chunk_log", cl)
         med, mn = timed()
@@ -45,8 +45,12 @@ p.set_tuning("ntt_maxl", 0)
 p.set_tuning("ntt_chunk_log", 0)
 src, dst = p.alloc(1 << 28), p.alloc(1 << 28)          # 2 GiB each
 for nt in (1, 0):
-    for grid in (2048, 256, 512, 1024, 4096, 8192, 16384):
+    for grid, block, un in ((2048, 256, 4), (256, 256, 4), (256, 256, 8), (256, 512, 4), (256, 512, 8), (256, 1024, 4), (512, 256, 4), (512, 512, 4), (512, 256, 8),
+                            (768, 256, 4), (1024, 256, 4), (1024, 256, 8), (4096, 256, 4)):
         p.set_tuning("copy_nt", nt)
         p.set_tuning("copy_grid", grid)
-        ms = p.hbm_copy_probe(src, dst, 8 << 28, reps=5)
-        print("plain copy 2 GiB -> 2 GiB, %s, %5d workgroups x 256 lanes x 16 B x 4 in flight: %.3f ms = %.0f GB/s (read + write)" % ("non-temporal" if nt else "default policy", grid, ms, 2.0 * (8 << 28) / ms / 1e6), flush=True)
+        p.set_tuning("copy_block", block)
+        p.set_tuning("copy_unroll", un)
+        ms = min(p.hbm_copy_probe(src, dst, 8 << 28, reps=5) for _ in range(3))
+        print("plain copy 2 GiB -> 2 GiB, %s, %5d workgroups x %4d lanes x 16 B x %d in flight: %.3f ms = %.0f GB/s (read + write)"
+              % ("non-temporal" if nt else "default policy", grid, block, un, ms, 2.0 * (8 << 28) / ms / 1e6), flush=True)
