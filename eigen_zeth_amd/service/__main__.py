@@ -1,4 +1,4 @@
-"""python -m eigen_zeth_amd.service [--port 50061] [--state-dir DIR] [--air chunk64] [--logn 20]"""
+"""python -m eigen_zeth_amd.service [--port 50061] [--state-dir DIR] [--air chunk64] [--logn 20] [--no-prewarm]"""
 import argparse
 import time
 
@@ -25,11 +25,14 @@ def main():
     ap.add_argument("--final-queries", type=int, default=50, help="queries of the final STARK (BN128-hash mode, Merkle-verifier AIR over the aggregated proof; blow-up 4, no grinding)")
     ap.add_argument("--aggregate-all-chunks", action="store_true",
                     help="GenAggregatedProof verifies EVERY chunk proof of the batch when the request names its first and last one (default: the two named proofs, as the wire contract says)")
+    ap.add_argument("--no-prewarm", action="store_true",
+                    help="open the port at once; the first request then also pays for the wrap key, the transform plans and tables, the kernels (seconds). "
+                         "Default: one synthetic batch is proven end to end before the port opens")
     a = ap.parse_args()
     server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, logb=a.logb, chunks_per_block=a.chunks_per_block, l2_addr=a.l2_addr, n_queries=a.n_queries, pow_bits=a.pow_bits,
                                                                agg_queries=a.agg_queries, final_queries=a.final_queries, aggregate_all_chunks=a.aggregate_all_chunks), a.device,
                          metrics_port=a.metrics_port,
-                         devices=[int(x) for x in a.devices.split(',')] if a.devices else None)
+                         devices=[int(x) for x in a.devices.split(',')] if a.devices else None, prewarm=not a.no_prewarm)
     print("prover.v1.ProverService listening on %s:%d  (chunk STARKs: %d queries x blow-up %d + %d grinding bits = %d bits conjectured)"
           % (a.host, port, a.n_queries, 1 << a.logb, a.pow_bits, a.n_queries * a.logb + a.pow_bits), flush=True)
     try:

@@ -650,6 +650,33 @@ class Engine:
         """make (or fetch) the wrap circuit and key for the usual request -- two chunk proofs of the configured size"""
         return self._wrap_key(self.wrap_layout(n_proofs, logn))
 
+    def prewarm(self, n_chunks=None):
+        """everything a first request would otherwise pay for, done at service start: the wrap circuit and its key (seconds: the circuit is built on
+        the host, the key's points on the GPU), and -- by proving one synthetic batch of the configured shape end to end and throwing it away --
+        the proving backends and their streams, transform plans and twiddle tables, coset tables, fixed-column extensions, the device buffer
+        pools, the generated constraint kernels, the verifier AIRs of both recursion layers.  Round 4 measured 2.8-5.8 s for the first block
+        against 0.65 s in the steady state (profiles/r4_service_e2e.txt).  Returns the seconds it took, by part."""
+        t0 = time.perf_counter()
+        self.groth16_keys()
+        t_key = time.perf_counter() - t0
+        cfg_l2, self.cfg.l2_addr = self.cfg.l2_addr, None            # no node is asked for blocks that do not exist
+        try:
+            n = max(2, n_chunks or min(8, self.cfg.prover_streams))
+            blocks = list(range(1, 1 + -(-n // max(1, self.cfg.chunks_per_block))))
+            ch = self.gen_batch_chunks("__prewarm__", blocks, 0, "evm")
+            proofs = self.gen_chunk_proofs("__prewarm__", ch["task_id"], ch["chunk_count"], ch["batch_data"])
+            t_chunks = time.perf_counter() - t0 - t_key
+            agg = self.aggregate("__prewarm__", proofs[0]["proof"], proofs[-1]["proof"])
+            self.final("__prewarm__", agg, "BN128", "0")
+        finally:
+            self.cfg.l2_addr = cfg_l2
+            for d in (self._batch_chunk_proofs, self.final_starks, self.final_programs):
+                d.pop("__prewarm__", None)
+            for k in [k for k in self.stage_timings if "__prewarm__" in k]:
+                self.stage_timings.pop(k, None)
+        total = time.perf_counter() - t0
+        return {"wrap_key_s": t_key, "chunk_proofs_s": t_chunks, "recursion_s": total - t_key - t_chunks, "total_s": total}
+
     def verifying_key_json(self, n_proofs=2, logn=None):
         return groth16.vk_to_json(self.groth16_keys(n_proofs, logn)[1].vk)
 

@@ -224,11 +224,14 @@ def default_backend_factory(device=0):
     return make
 
 
-def serve(port=50061, host="127.0.0.1", state_dir="prover_state", config=None, device=0, metrics_port=None, devices=None):
-    """devices: GPUs the chunk proofs of a batch are spread over (default: just `device`)"""
+def serve(port=50061, host="127.0.0.1", state_dir="prover_state", config=None, device=0, metrics_port=None, devices=None, prewarm=False):
+    """devices: GPUs the chunk proofs of a batch are spread over (default: just `device`).  prewarm: build keys, plans, tables and kernels
+    before the port opens (Engine.prewarm: one synthetic batch proven end to end), so that the first block costs what every block costs"""
     devs = list(devices) if devices else [device]
     engine = Engine([default_backend_factory(d) for d in devs], config or EngineConfig())
     engine.be  # fail at start-up, not at the first request, when no GPU is present
+    if prewarm:
+        engine.prewarm_report = engine.prewarm()
     metrics = None
     if metrics_port is not None:
         from .metrics import Metrics
