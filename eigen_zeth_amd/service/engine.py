@@ -720,14 +720,40 @@ class Engine:
             # The text is the client's.  The final STARK below proves the aggregation STARK's QUERY phase (its witness does not exist when a
             # path, the DEEP quotient or a fold fails); what no query covers -- the constraint identity at the out-of-domain point, the final
             # layer's degree, the grinding -- is checked here, natively, before anything is proven (stark/verifier.py; round-4 advisor item)
-            t0 = time.perf_counter()
+            # It runs BESIDE the final STARK (host arithmetic + a handful of sponge calls on self.be; the final STARK runs on be_bn128, another
+            # ctx) and is joined before anything leaves this function: a header that does not verify raises, whatever the STARK did meanwhile.
+            hdr = {"t": 0.0, "err": None}
+
+            def check_header():
+                t0 = time.perf_counter()
+                try:
+                    SV.verify_header(outer, agg_air, self._agg_params(agg_shape), self.be)
+                except Exception as e:          # re-raised on the engine's thread below
+                    hdr["err"] = e
+                hdr["t"] = time.perf_counter() - t0
+            th = None
             if self.cfg.verify_before_wrap:
-                SV.verify_header(outer, agg_air, self._agg_params(agg_shape), self.be)
-            t_hdr = time.perf_counter() - t0
+                if self.be_bn128 is not self.be and hasattr(self.be, "p"):
+                    th = threading.Thread(target=check_header, name="verify-aggregated-header")
+                    th.start()
+                else:                           # one ctx for both (the CPU checker's backend in tests): one after the other
+                    check_header()
+                    if hdr["err"] is not None:
+                        raise hdr["err"]
         except (json.JSONDecodeError, TypeError, KeyError, AssertionError, ValueError) as e:
             raise ValueError("recursive proof is not an aggregated proof of this prover (%s)" % e)
-        tmf = {"verify-aggregated-header": t_hdr}
-        fshape, fair, fp, final_stark = self._prove_merkle_verifier([outer], lambda sh: self.final_stark_params(outer), self.be_bn128, tmf, agg_air, [prep])
+        tmf = {}
+        try:
+            fshape, fair, fp, final_stark = self._prove_merkle_verifier([outer], lambda sh: self.final_stark_params(outer), self.be_bn128, tmf, agg_air, [prep])
+        finally:
+            if th is not None:
+                th.join()
+        if hdr["err"] is not None:
+            e = hdr["err"]
+            if isinstance(e, ValueError):
+                raise ValueError("recursive proof is not an aggregated proof of this prover (%s)" % e)
+            raise e
+        tmf["verify-aggregated-header(beside the final STARK)" if th is not None else "verify-aggregated-header"] = hdr["t"]
         openings = None
         if self.cfg.native_prover and hasattr(self.be_bn128, "stark_openings"):
             openings = self.be_bn128.stark_openings()       # the prover's own binary record of what the text carries: no text round trip

@@ -109,4 +109,21 @@ def test_engine_final_proof_wraps_the_final_stark(tables, tmp_path):
     assert js2 == js and pub2 == pub_js                       # deterministic blinding: the same proof.json
     js3, pub3 = eng.final("w", agg, "BN128", "1")
     assert pub3 != pub_js                                     # another aggregator address: another statement
+    assert any(k.startswith("final/verify-aggregated-header") for k in eng.stage_timings["final/w"])
+    # an aggregated proof whose STARK fails what NO QUERY covers is refused before it is wrapped: a final layer that is not low degree passes every
+    # fold of the verifier AIR (the last fold is compared with the layer as given), so only the native header check (stark/verifier.py) stands
+    # in its way -- round 4's engine wrapped such a text into a pairing-valid proof
+    from eigen_zeth_amd.stark import verifier as SV
+    bad = json.loads(agg)
+    with pytest.raises(ValueError):            # (a text altered by hand also changes its transcript, so the witness builder may speak first; a
+        b2 = json.loads(agg)                   # consistently forged proof -- false trace, honest transcript -- is what only the header check stops)
+        b2["stark"]["evals"]["z"][0][0] ^= 1
+        eng.final("w", json.dumps(b2, separators=(",", ":")), "BN128", addr)
+    ap = eng._agg_params(eng._own_shape(bad))
+    from eigen_zeth_amd.stark import verifier_air as VA
+    vair = VA.verifier_air(eng._own_shape(bad), *eng._tables(eng.be))
+    assert SV.verify_header(bad["stark"], vair, ap, eng.be)["indices"] == [q["index"] for q in bad["stark"]["queries"]]
+    bad["stark"]["evals"]["zw"][3][1] ^= 1
+    with pytest.raises(SV.Reject, match="identity"):
+        SV.verify_header(bad["stark"], vair, ap, eng.be)
     print("final stage timings:", json.dumps({k: round(v * 1e3, 1) for k, v in eng.stage_timings["final/w"].items()}))
