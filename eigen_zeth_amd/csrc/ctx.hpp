@@ -80,6 +80,7 @@ struct zp_ctx {
     int tune_g16_parallel = 1;    // zp_groth16_prove: the five MSMs of a proof on five streams at once (0: one after the other)
     int tune_ntt_order = 0;       // plan digit order: 0 auto (a radix-512 digit goes last), 1 larger radices first, 2 larger radices last
     int tune_ntt_maxl = 0;        // 0 = 9: largest log2 radix of one NTT pass (10: 1024-thread workgroups, two-pass plans up to 2^20)
+    int tune_merkle_top_wave = 0; // 1: the subtree kernel of the small tree levels exchanges a node's state by wave shuffles (no LDS, one barrier per level) instead of LDS + two barriers per round
     int tune_merkle_coop_log = 0; // 0 = 15: tree levels with <= 2^15 nodes go to the 12-lanes-per-node subtree kernel
     int tune_ntt_chunk_log = 0;   // 0 = 28: columns per launch such that a ping-pong scratch buffer is <= 2 GiB
     int tune_p254_bulk_log = 0;   // 0 = 14: Poseidon-BN254 t = 17 launches of >= 2^14 permutations use the lane-per-permutation kernel (31 = never)

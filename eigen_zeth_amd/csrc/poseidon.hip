@@ -422,6 +422,55 @@ __global__ void __launch_bounds__(768) merkle_subtree_kernel(u64 *prev, size_t c
     }
 }
 
+// The same subtree walk with the state exchanged by WAVE SHUFFLES instead of LDS + two workgroup barriers per round (round 5; knob
+// merkle_top_wave): a node's 12 state words sit in 12 lanes of one 16-lane row (four nodes per wave, lanes 12..15 of a row idle), a round's row
+// sum gathers them with twelve 64-bit shuffles whose source lane (row base + (e + k) mod 12) and coefficient m[e][(e + k) mod 12] are fixed per
+// lane for the whole kernel, and nothing synchronises inside a permutation -- one workgroup barrier per tree LEVEL (the next level reads what
+// other waves wrote) instead of sixty.  64 parents per 1024-thread workgroup and level, as the LDS form.  Same values (tests/test_gpu_parity.py
+// compares every node of small trees with the oracle under both knob settings).
+__global__ void __launch_bounds__(1024) merkle_subtree_wave_kernel(u64 *prev, size_t cnt, int nlev, const u64 *rc, const u32 *mds) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int node = wv * 4 + (lane >> 4), e = lane & 15, rowbase = lane & ~15;
+    const bool word = e < 12;
+    const int ee = word ? e : 11;
+    int src[12];
+    u32 m[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const int j = (ee + k) % 12;
+        src[k] = rowbase + j;
+        m[k] = word ? mds[ee * 12 + j] : 0u;
+    }
+    size_t first = (size_t)blockIdx.x * 128;
+    size_t width = cnt < 128 ? cnt : 128;
+    for (int l = 0; l < nlev; l++) {
+        const size_t half = width >> 1;
+        u64 *next = prev + cnt * 4;
+        const bool on = (size_t)node < half && word;
+        u64 s = (on && e < 8) ? prev[(first + 2 * (size_t)node) * 4 + e] : 0ULL;
+        for (int r = 0; r < 30; r++) {
+            s = gl_add_weak(s, rc[r * 12 + ee]);
+            if (r < 4 || r >= 26 || e == 0) s = sbox7(s);
+            u64 alo = 0, ahi = 0;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const u64 v = (u64)__shfl((unsigned long long)s, src[k]);
+                alo += (u64)m[k] * (u32)v;
+                ahi += (u64)m[k] * (u32)(v >> 32);
+            }
+            const u64 mid = (alo >> 32) + ahi;
+            s = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
+        }
+        if (on && e < 4) next[((first >> 1) + (size_t)node) * 4 + e] = gl_canon(s);
+        __threadfence_block();
+        __syncthreads();
+        prev = next;
+        cnt >>= 1;
+        first >>= 1;
+        width = half;
+    }
+}
+
 int32_t tree_levels(zp_ctx *ctx, u64 *tree, size_t M) {
     u64 *prev = tree;
     size_t cnt = M;
@@ -432,8 +481,12 @@ int32_t tree_levels(zp_ctx *ctx, u64 *tree, size_t M) {
             int lg = 0;
             while (((size_t)1 << lg) < cnt) lg++;
             const int nlev = lg < 7 ? lg : 7;
-            hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(cnt < 128 ? 1 : cnt / 128)), dim3(768), 0, ctx->stream,
-                               prev, cnt, nlev, ctx->d_rc, ctx->d_mds);
+            if (ctx->tune_merkle_top_wave)
+                hipLaunchKernelGGL(merkle_subtree_wave_kernel, dim3((unsigned)(cnt < 128 ? 1 : cnt / 128)), dim3(1024), 0, ctx->stream, prev, cnt, nlev,
+                                   ctx->d_rc, ctx->d_mds);
+            else
+                hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(cnt < 128 ? 1 : cnt / 128)), dim3(768), 0, ctx->stream,
+                                   prev, cnt, nlev, ctx->d_rc, ctx->d_mds);
             ZP_HIP(ctx, hipGetLastError());
             for (int l = 0; l < nlev; l++) {
                 prev += cnt * 4;

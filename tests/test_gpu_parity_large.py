@@ -68,6 +68,27 @@ def test_merkle_cooperative_threshold_lowered(prover, tables, M, W):
     assert (_commit(prover, cols) == ref).all()
 
 
+@pytest.mark.parametrize("M,W", [(1 << 15, 8), (1 << 10, 5), (1 << 7, 12), (64, 9), (4, 8), (2, 3)])
+def test_merkle_top_levels_by_wave_shuffles(prover, tables, M, W):
+    """knob merkle_top_wave (round 5): the subtree kernel of the small levels with the permutation state exchanged by 64-bit wave shuffles
+    (12 lanes of a 16-lane row per node, one workgroup barrier per LEVEL) instead of LDS and two barriers per round -- every node of the tree
+    against the oracle, for the default and for an injected MDS matrix, next to the LDS form"""
+    rc, mds = tables
+    cols = O.random_field((W, M), 3400 + W)
+    ref = O.merkle_commit(cols, rc, mds)
+    try:
+        for knob in (1, 0):
+            prover.set_tuning("merkle_top_wave", knob)
+            assert (_commit(prover, cols) == ref).all(), knob
+        mds2 = (O.random_field((144,), 21) % np.uint64(1 << 20)).astype(np.uint64)
+        prover.set_constants(native.ZP_CONST_POSEIDON_MDS, mds2)
+        prover.set_tuning("merkle_top_wave", 1)
+        assert (_commit(prover, cols) == O.merkle_commit(cols, rc, mds2)).all()
+    finally:
+        prover.set_constants(native.ZP_CONST_POSEIDON_MDS, mds)
+        prover.set_tuning("merkle_top_wave", 0)
+
+
 def test_config1_ntt_and_merkle_2p20_rows_bit_exact_vs_cpu(prover, tables):
     """BASELINE.json configs[1]: "2^20-row Goldilocks NTT + Poseidon Merkle on 1 MI355X, bit-exact vs CPU" -- the whole
     NTT output, the whole LDE (blow-up 2) and EVERY node of the 2^21-leaf x 32-column tree against the CPU oracle"""
