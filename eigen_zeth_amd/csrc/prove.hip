@@ -549,7 +549,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     }
     PV_TRY(dev.alloc(3 * M, &dq));
     zp_air_quotient_fn plug = nullptr;
-    if (fxc.empty() && !ctx->air_kernels.empty()) {
+    if (!ctx->air_kernels.empty()) {       // (round 5: generated kernels read the sparse periodic fixed columns too -- one extended period each, zp_fixed_columns' layout)
         auto it = ctx->air_kernels.find(digest_hex64(h_program, program_words));
         if (it != ctx->air_kernels.end()) plug = (zp_air_quotient_fn)it->second;
     }

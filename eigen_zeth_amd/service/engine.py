@@ -634,6 +634,19 @@ class Engine:
         fp = VA.aggregation_params(agg_shape, self.cfg.final_queries, self.cfg.fri_logf, self.cfg.fri_final_log, 0, hash="bn128")
         return WC.Layout(fp, VA.WIDTH, 3 * VA.Q_PIECES, agg_shape.n_pub())     # = Layout.of_air(the final STARK's verifier AIR, fp)
 
+    def recursion_airs(self, n_proofs=2, logn=None):
+        """(the verifier AIR the aggregation STARK proves, the one the final STARK proves) for the usual request -- two chunk proofs of the
+        configured size; statements made per shape (stark/verifier_air.py)"""
+        air = AIR.get_air(self.cfg.air)
+        sp = self.stark_params(logn)
+        chunk_shape = VA.Shape(sp.logn, sp.logb, air.width, air.width2, 3 * AIR.quotient_chunks(air), sp.n_queries, sp.fri_logf, sp.fri_final_log, n_proofs,
+                               air.n_pub, sp.pow_bits, int(self.be.root32), int(self.be.shift))
+        ap = self._agg_params(chunk_shape)
+        agg_shape = VA.Shape(ap.logn, ap.logb, VA.WIDTH, 0, 3 * VA.Q_PIECES, ap.n_queries, ap.fri_logf, ap.fri_final_log, 1, chunk_shape.n_pub(), ap.pow_bits,
+                             int(self.be.root32), int(self.be.shift))
+        tables = self._tables(self.be)
+        return VA.verifier_air(chunk_shape, *tables), VA.verifier_air(agg_shape, *tables)
+
     def _wrap_key(self, layout):
         """(wrap circuit, Groth16 key) for a final-STARK layout: built once per layout (seconds at the service's size: the circuit in Python,
         the key's scalars on the host, its group elements on the GPU) and kept -- key generation is setup, not proving"""
@@ -650,7 +663,7 @@ class Engine:
         """make (or fetch) the wrap circuit and key for the usual request -- two chunk proofs of the configured size"""
         return self._wrap_key(self.wrap_layout(n_proofs, logn))
 
-    def prewarm(self, n_chunks=None):
+    def prewarm(self, n_chunks=None, compile_kernels=True):
         """everything a first request would otherwise pay for, done at service start: the wrap circuit and its key (seconds: the circuit is built on
         the host, the key's points on the GPU), and -- by proving one synthetic batch of the configured shape end to end and throwing it away --
         the proving backends and their streams, transform plans and twiddle tables, coset tables, fixed-column extensions, the device buffer
@@ -659,6 +672,14 @@ class Engine:
         t0 = time.perf_counter()
         self.groth16_keys()
         t_key = time.perf_counter() - t0
+        # generated constraint kernels for the two recursion programs (hipcc at the first start on a host, a file afterwards); a host without a
+        # compiler keeps the interpreter
+        t_k = time.perf_counter()
+        kernels = None
+        if compile_kernels and hasattr(self.be, "compile_air_kernel"):
+            agg_air, fin_air = self.recursion_airs()
+            kernels = [self.be.compile_air_kernel(agg_air), self.be_bn128.compile_air_kernel(fin_air)]
+        t_k = time.perf_counter() - t_k
         cfg_l2, self.cfg.l2_addr = self.cfg.l2_addr, None            # no node is asked for blocks that do not exist
         try:
             n = max(2, n_chunks or min(8, self.cfg.prover_streams))
@@ -675,7 +696,8 @@ class Engine:
             for k in [k for k in self.stage_timings if "__prewarm__" in k]:
                 self.stage_timings.pop(k, None)
         total = time.perf_counter() - t0
-        return {"wrap_key_s": t_key, "chunk_proofs_s": t_chunks, "recursion_s": total - t_key - t_chunks, "total_s": total}
+        return {"wrap_key_s": t_key, "recursion_kernels_s": t_k, "recursion_kernels": kernels, "chunk_proofs_s": t_chunks - t_k,
+                "recursion_s": total - t_key - t_chunks, "total_s": total}
 
     def verifying_key_json(self, n_proofs=2, logn=None):
         return groth16.vk_to_json(self.groth16_keys(n_proofs, logn)[1].vk)

@@ -455,8 +455,18 @@ def emit_quotient_source(air, target="hip"):
     body = []
     for (i, nxt) in sorted(em.cols):
         body.append("    const u64 c%d%s = cols[(u64)%d * M + %s];" % (i, "n" if nxt else "", i, "rn" if nxt else "r"))
+    # fixed columns 0 / 1 (the boundary selectors) are whole columns; the sparse periodic ones behind them are ONE extended period each
+    # (zp_fixed_columns: column i >= 2 of period 2^lp holds 2^lp * b values at offset 2 M + b * sum of the earlier periods; row r reads r mod 2^lp b)
+    prefix, acc = {}, 0
+    for k, fc in enumerate(air.fixed_cols):
+        prefix[2 + k] = (acc, 1 << fc.lp)
+        acc += 1 << fc.lp
     for i in sorted(em.fixed):
-        body.append("    const u64 f%d = fixedc[(u64)%d * M + r];" % (i, i))
+        if i < 2:
+            body.append("    const u64 f%d = fixedc[(u64)%d * M + r];" % (i, i))
+        else:
+            off, per = prefix[i]
+            body.append("    const u64 f%d = fixedc[2 * M + b * %dULL + (r & (b * %dULL - 1))];" % (i, off, per))
     body += em.lines
     # random linear combination with alpha^k as three unreduced 160-bit dot products (gl_acc), reduced once
     body.append("    gl_acc s0 = gl_acc_zero(), s1 = gl_acc_zero(), s2 = gl_acc_zero();")

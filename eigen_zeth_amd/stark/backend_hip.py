@@ -191,14 +191,17 @@ class HipBackend:
         """the whole chunk STARK through zp_stark_prove (one C-ABI call, orchestration in the library's host C++): proof TEXT,
         byte-identical to proof_to_json(prove(...)) over this backend.  trace: host array or a device buffer from prefetch_trace."""
         assert self.hash_mode == params.hash
-        if self.quotient_mode == "kernel" and not air.fixed_cols and air.name not in self._native_kernels:
+        kkey = (air.name, air.digest())
+        if self.quotient_mode == "kernel" and kkey not in self._native_kernels and (not air.fixed_cols or os.path.exists(build_airs.lib_path(air))):
             # the one-call prover evaluates this AIR's constraints through its generated kernel too (zp_stark_set_air_kernel); a host without the
-            # AIR's library (and without a compiler to make it) simply stays with the interpreter: same proofs
+            # AIR's library (and without a compiler to make it) simply stays with the interpreter: same proofs.  An AIR made per shape (a
+            # verifier AIR: sparse periodic fixed columns) is never compiled on the way -- its library exists when somebody asked for it
+            # (compile_air_kernel: the service's prewarm does, for the two recursion programs it will prove)
             try:
                 self.p.set_air_kernel(air.program(), self._airlib(air))
             except (OSError, RuntimeError, AttributeError, subprocess.CalledProcessError):
                 pass
-            self._native_kernels.add(air.name)
+            self._native_kernels.add(kkey)
         d_tr = trace if isinstance(trace, native.DeviceBuffer) else self.p.upload(trace)
         try:
             if self.hash_mode == "bn128":       # zp_stark_prove_bn128: 16-ary Poseidon-BN254 trees, transcript over F_r, no grinding
@@ -336,14 +339,25 @@ class HipBackend:
 
     # ---- N4: generated constraint kernel
     def _airlib(self, air):
-        if air.name not in self._airlibs:
+        k = (air.name, air.digest())
+        if k not in self._airlibs:
             lib = C.CDLL(build_airs.build_air(air))
             fn = getattr(lib, air.symbol)
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_int, C.c_uint64,
                                                                                                  C.c_uint64, C.c_void_p]
-            self._airlibs[air.name] = fn
-        return self._airlibs[air.name]
+            self._airlibs[k] = fn
+        return self._airlibs[k]
+
+    def compile_air_kernel(self, air):
+        """generate, compile (hipcc: seconds to a minute for a verifier AIR) and load the constraint kernel of `air` and hand it to the one-call
+        prover of this ctx; returns False on a host without a compiler (the interpreter then serves: same proofs)"""
+        try:
+            self.p.set_air_kernel(air.program(), self._airlib(air))
+            self._native_kernels.add((air.name, air.digest()))
+            return True
+        except (OSError, RuntimeError, AttributeError, subprocess.CalledProcessError):
+            return False
 
     def quotient(self, air, c1, fixed, pubs, apow, zhinv, logn, logb, wlast):
         M = 1 << (logn + logb)

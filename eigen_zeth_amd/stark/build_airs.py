@@ -9,14 +9,19 @@ GEN = os.path.join(HERE, "generated")
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 
 
+def _stem(air):
+    """built-in AIRs: their name.  AIRs made per shape (the verifier AIRs of the recursion layers: one name, many statements): name + digest"""
+    return air.name + ("_" + air.digest() if air.fixed_cols else "")
+
+
 def lib_path(air):
-    return os.path.join(GEN, "libzpair_%s.so" % air.name)
+    return os.path.join(GEN, "libzpair_%s.so" % _stem(air))
 
 
 def build_air(air, force=False):
     from .air import emit_quotient_source
     os.makedirs(GEN, exist_ok=True)
-    src = os.path.join(GEN, air.name + ".hip")
+    src = os.path.join(GEN, _stem(air) + ".hip")
     code = emit_quotient_source(air, "hip")
     if force or not os.path.exists(src) or open(src).read() != code:
         with open(src, "w") as f:

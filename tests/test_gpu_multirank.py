@@ -65,7 +65,8 @@ def test_bench_n2_code_path_on_one_gpu():
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    # no --scaling flag, as the driver runs it: with N > 1 that means STRONG since round 5 (BASELINE configs[3] is ONE trace sharded over the GPUs)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["config"]["cols_per_gpu"] == 8 and line["config"]["cols_total"] == 16
     pipe = line["pipeline"]
     assert "error" not in pipe and pipe["all_to_all_ms"] > 0 and pipe["four_step_single_column"]["ms"] > 0
     assert pipe["msm_bn254"]["on_curve"]

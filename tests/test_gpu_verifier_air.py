@@ -94,6 +94,14 @@ def test_aggregation_stark_gpu_equals_cpu_and_verifies(hip, tables, airname, log
     p_gpu = PR.proof_to_json(PR.prove(vair, t_gpu, pubs, ap, hip))
     assert p_gpu == p_cpu
     assert hip.prove_native(vair, d_gpu, pubs, ap) == p_cpu                    # zp_stark_prove on the device-resident trace: the same bytes
+    if airname == "chunk16":
+        # round 5: the verifier AIR through a GENERATED constraint kernel (sparse periodic fixed columns read as one extended period each):
+        # compiled on request (the service's prewarm does it for its two recursion programs), then the one-call prover gives the same bytes
+        from eigen_zeth_amd.stark.backend_hip import HipBackend
+        hk = HipBackend(0)
+        assert hk.compile_air_kernel(vair)
+        assert hk.prove_native(vair, t_cpu, pubs, ap) == p_cpu
+        t = hk.p.stage_timings() if hasattr(hk.p, "stage_timings") else None
     agg = {"kind": "aggregated", "inner": [strip_paths(p) for p in proofs], "stark": json.loads(p_gpu)}
     assert AV.verify(agg, air.program(), vair.program(), rc, mds, V.expectation(params.to_dict()), V.expectation(ap.to_dict()), shape.n_slots())
     t_bad = t_gpu.copy()

@@ -33,7 +33,7 @@ echo "quotient done"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/prof_${TAG}_msm -- python3 $ROOT/tools/msm_bench.py 22 > /dev/null 2>&1
 python3 $ROOT/tools/pmc_summary.py $OUT/prof_${TAG}_msm msm > $OUT/${TAG}_pmc_sq_msm.json
 echo "msm done"
-python3 $ROOT/tools/integer_roofline.py $OUT/${TAG}_integer_roofline.json ntt=$OUT/${TAG}_pmc_sq_ntt.json poseidon=$OUT/${TAG}_pmc_sq_poseidon.json stark=$OUT/${TAG}_pmc_sq_quotient.json msm=$OUT/${TAG}_pmc_sq_msm.json > /dev/null
+python3 $ROOT/tools/integer_roofline.py $OUT/${TAG}_integer_roofline.json ntt=$OUT/${TAG}_pmc_sq_ntt.json ntt_elems_log=28 poseidon=$OUT/${TAG}_pmc_sq_poseidon.json stark=$OUT/${TAG}_pmc_sq_quotient.json msm=$OUT/${TAG}_pmc_sq_msm.json > /dev/null
 python3 - <<PY
 import json
 f = json.load(open("$OUT/${TAG}_pmc_fetch_ntt.json")); w = json.load(open("$OUT/${TAG}_pmc_write_ntt.json"))
@@ -43,6 +43,22 @@ json.dump({"per_kernel": rows, "hbm_bytes_per_launch_dominant": worst["fetch_byt
            "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (KiB units); FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md"},
           open("$OUT/${TAG}_ntt_traffic.json", "w"), indent=1)
 PY
+# the two-pass plan (two radix-4096 passes, 1024-thread workgroups, 128-KiB tiles of 4 columns: knob ntt_maxl = 12) under the same counters: what
+# stops it -- instruction issue, LDS, or the bandwidth of its 32-byte runs (round-4 review item 3: the A/B with counters)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/prof_${TAG}_sq2p -- python3 $ROOT/tools/pmc_ntt.py ntt_maxl=12 > /dev/null 2>&1
+python3 $ROOT/tools/pmc_summary.py $OUT/prof_${TAG}_sq2p ntt_pass2 > $OUT/${TAG}_pmc_sq_ntt_two_pass.json
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT/prof_${TAG}_lds2p -- python3 $ROOT/tools/pmc_ntt.py ntt_maxl=12 > /dev/null 2>&1 || true
+python3 $ROOT/tools/pmc_summary.py $OUT/prof_${TAG}_lds2p ntt_pass2 > $OUT/${TAG}_pmc_lds_ntt_two_pass.json || true
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT/prof_${TAG}_lds3p -- python3 $ROOT/tools/pmc_ntt.py > /dev/null 2>&1 || true
+python3 $ROOT/tools/pmc_summary.py $OUT/prof_${TAG}_lds3p ntt_pass2 > $OUT/${TAG}_pmc_lds_ntt.json || true
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_fetch2p -- python3 $ROOT/tools/pmc_ntt.py ntt_maxl=12 > /dev/null 2>&1
+python3 $ROOT/tools/pmc_summary.py $OUT/prof_${TAG}_fetch2p ntt_pass2 > $OUT/${TAG}_pmc_fetch_ntt_two_pass.json
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_write2p -- python3 $ROOT/tools/pmc_ntt.py ntt_maxl=12 > /dev/null 2>&1
+python3 $ROOT/tools/pmc_summary.py $OUT/prof_${TAG}_write2p ntt_pass2 > $OUT/${TAG}_pmc_write_ntt_two_pass.json
+echo "two-pass counters done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_ood -- python3 $ROOT/tools/stark_bench.py chunk64 22 1 > $OUT/${TAG}_stark_chunk64_2p22.txt 2>&1
+cp $(ls $OUT/prof_${TAG}_ood/*/*kernel_stats.csv | head -1) $OUT/${TAG}_stark_chunk64_2p22_kernel_stats.csv
+echo "chunk proof stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_rec -- python3 $ROOT/tools/recursion_bench.py 20 3 > $OUT/${TAG}_recursion_under_profiler.txt 2>&1
 cp $(ls $OUT/prof_${TAG}_rec/*/*kernel_stats.csv | head -1) $OUT/${TAG}_recursion_kernel_stats.csv
 echo "recursion done"
