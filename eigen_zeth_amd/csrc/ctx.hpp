@@ -58,8 +58,12 @@ struct zp_ctx {
     std::map<int, NttPlan> plans;  // key = logn*2 + inverse
     std::vector<CosetTable> cosets;
     // scratch (two ping-pong buffers, grown on demand)
-    u64 *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0, 1: NTT ping-pong; 2: LDE coefficients; 3: small uploads; 4: fixed-column periods
+    u64 *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0, 1: NTT ping-pong; 2: LDE coefficients; 3: small uploads; 4: fixed-column periods; 5: zp_ood_eval's weight vector
     size_t scratch_elems[6] = {0, 0, 0, 0, 0, 0};
+    // zp_ood_eval: the barycentric weights last made (scratch 5) are for this domain size and point
+    bool ood_valid = false;
+    int ood_logn = -1;
+    u64 ood_y[3] = {0, 0, 0}, ood_root32 = 0;
     // pinned host staging for small transfers (pageable async copies lock/unlock host pages on every call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;

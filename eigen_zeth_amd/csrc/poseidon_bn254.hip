@@ -419,7 +419,9 @@ __global__ void __launch_bounds__(64) r1cs_poseidon17_kernel(const u64 *__restri
 // overwritten with the block and the state permuted (no block: one permutation), then `extra` more permutations; the rate after the
 // absorption and after every extra permutation is written out.  A transcript step of k permutations costs one host round trip
 // instead of k launches with a copy between them.
-__global__ void __launch_bounds__(64) poseidon254_sponge_kernel(u64 *buf, int nblocks, int extra, P254Dev d) {
+// caps (may be null): the capacity element after EVERY permutation, in order -- what a circuit that re-hashes the transcript with all its
+// gadgets side by side (service/wrap_circuit.py: every gadget's capacity input a caller-set wire) has to be told
+__global__ void __launch_bounds__(64) poseidon254_sponge_kernel(u64 *buf, int nblocks, int extra, u64 *caps, P254Dev d) {
     constexpr int T = 17;
     __shared__ u32 sh[3][T][9];
     const int e = threadIdx.x;
@@ -441,6 +443,12 @@ __global__ void __launch_bounds__(64) poseidon254_sponge_kernel(u64 *buf, int nb
             s = fr_to_mont(fr_from_u64(w));
         }
         s = perm_coop<T>(s, 0, on ? e : 0, on, sh, d);
+        if (caps && e == 0) {
+            u64 w[4];
+            fr_to_u64(fr_from_mont(s), w);
+#pragma unroll
+            for (int k = 0; k < 4; k++) caps[(size_t)b * 4 + k] = w[k];
+        }
         if (b >= absorb - 1 && on && e >= 1) {
             u64 w[4];
             fr_to_u64(fr_from_mont(s), w);
@@ -714,6 +722,12 @@ int32_t zp_poseidon_bn254_perm(zp_ctx *ctx, uint64_t *d_states, size_t count, in
 // one permutation), then `extra` more permutations; h_rates receives the 16 rate elements after the absorption and after each
 // extra permutation.  h_state: 17 elements in/out.  All elements 4 words, standard form, < r.
 int32_t zp_poseidon_bn254_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates) {
+    return zp_poseidon_bn254_sponge_caps(ctx, h_state, h_blocks, nblocks, extra, h_rates, nullptr);
+}
+
+// the same, also handing out the capacity element after every permutation: h_caps u64[max(nblocks, 1) + extra][4] (may be NULL)
+int32_t zp_poseidon_bn254_sponge_caps(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates,
+                                      uint64_t *h_caps) {
     if (!ctx) return ZP_ERR_ARG;
     ZpStage stage_(ctx, "poseidon_bn254_sponge");
     P254Table *tb;
@@ -723,15 +737,17 @@ int32_t zp_poseidon_bn254_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t 
     for (size_t i = 0; i < 17; i++) ZP_ARG(ctx, fr_is_canonical_u64((const u64 *)h_state + 4 * i), "state element not reduced mod r");
     for (size_t i = 0; i < nblocks * 16; i++) ZP_ARG(ctx, fr_is_canonical_u64((const u64 *)h_blocks + 4 * i), "block element not reduced mod r");
     // one upload (state | blocks), one launch walking the blocks on the device, one download (state, rates)
-    const size_t nrate = 1 + extra, words = (17 + nblocks * 16 + nrate * 16) * 4;
+    const size_t nrate = 1 + extra, nperm = (nblocks ? nblocks : 1) + extra, words = (17 + nblocks * 16 + nrate * 16 + nperm) * 4;
     std::vector<u64> h(words, 0);
     memcpy(h.data(), h_state, 17 * 32);
     if (nblocks) memcpy(h.data() + 17 * 4, h_blocks, nblocks * 16 * 32);
     u64 *d = nullptr;
     ZP_TRY(zpi_scratch(ctx, 3, words, &d));
     ZP_TRY(zpi_h2d_small(ctx, d, h.data(), (17 + nblocks * 16) * 32));
-    hipLaunchKernelGGL(poseidon254_sponge_kernel, dim3(1), dim3(64), 0, ctx->stream, d, (int)nblocks, (int)extra, dev_of(tb));
+    u64 *d_caps = d + (17 + nblocks * 16 + nrate * 16) * 4;
+    hipLaunchKernelGGL(poseidon254_sponge_kernel, dim3(1), dim3(64), 0, ctx->stream, d, (int)nblocks, (int)extra, h_caps ? d_caps : (u64 *)nullptr, dev_of(tb));
     ZP_HIP(ctx, hipGetLastError());
+    if (h_caps) ZP_TRY(zpi_d2h_small(ctx, h_caps, d_caps, nperm * 32));
     ZP_TRY(zpi_d2h_small(ctx, h_rates, d + (17 + nblocks * 16) * 4, nrate * 16 * 32));
     return zpi_d2h_small(ctx, h_state, d, 17 * 32);
 }

@@ -92,7 +92,7 @@ struct Transcript {
     bool bn;
     u64 state[17 * 4];                 // GL: 12 words; BN: 17 elements of 4 words (standard form)
     std::vector<u64> pending, out;     // GL: values; BN: pending holds 4 words per element
-    std::vector<u64> log_blocks, last_rates;   // BN: every absorbed block (16 elements x 4 words) in order; the rate elements of the latest flush (the wrap circuit's transcript gadgets: zp_wrap_assign)
+    std::vector<u64> log_blocks, last_rates, log_caps;   // BN: every absorbed block (16 elements x 4 words) in order; the rate elements of the latest flush; the capacity after every permutation (the wrap circuit's transcript gadgets: zp_wrap_assign)
     int32_t rc = ZP_OK;
     Transcript(zp_ctx *c, bool bn_) : ctx(c), bn(bn_) { memset(state, 0, sizeof state); }
     void absorb(const u64 *v, size_t n) {
@@ -131,10 +131,12 @@ struct Transcript {
             std::vector<u64> blocks(nblk * 64, 0);
             memcpy(blocks.data(), pending.data(), pending.size() * 8);
             pending.clear();
-            std::vector<u64> rates((1 + extra) * 64);
-            const int32_t r = zp_poseidon_bn254_sponge(ctx, (uint64_t *)state, (const uint64_t *)blocks.data(), nblk, extra, (uint64_t *)rates.data());
+            std::vector<u64> rates((1 + extra) * 64), caps(((nblk ? nblk : 1) + extra) * 4);
+            const int32_t r = zp_poseidon_bn254_sponge_caps(ctx, (uint64_t *)state, (const uint64_t *)blocks.data(), nblk, extra, (uint64_t *)rates.data(),
+                                                            (uint64_t *)caps.data());
             if (r != ZP_OK && rc == ZP_OK) rc = r;
             log_blocks.insert(log_blocks.end(), blocks.begin(), blocks.end());
+            log_caps.insert(log_caps.end(), caps.begin(), caps.end());
             last_rates = rates;
             out.clear();
             for (size_t e = 0; e < rates.size() / 4; e++)
@@ -481,7 +483,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     PV_TRY(T.root(tree1, Mt, root1));
     tr.absorb_root(root1);
     std::vector<u64> pubchal(h_pubs, h_pubs + n_pubs);
-    u64 *tree2 = nullptr;
+    u64 *tree2 = nullptr, *s2_kept = nullptr;
     if (n_s2) {
         const e3 chal = tr.challenge();
         PV_TRY(tr.rc);
@@ -502,7 +504,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         PV_TRY(dev.alloc(T.tree_words(M2), &tree2));
         PV_TRY(T.commit(ext + W * M, M2, (int)W2g, tree2));
         PV_TRY(T.root(tree2, M2, root2));
-        dev.release(s2);
+        s2_kept = s2;                         // the stage-2 columns on the trace domain: read once more for their out-of-domain evaluations
         tr.absorb_root(root2);
         for (int c = 0; c < 3; c++) pubchal.push_back(chal.c[c]);
     }
@@ -613,12 +615,19 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     const e3 zeta = tr.challenge();
     PV_TRY(tr.rc);
 
-    // 3. out-of-domain evaluations, from the committed extensions themselves (barycentric form, zp_ood_eval): a polynomial of degree < 2^d
-    //    is read on the 2^d-point sub-coset of its extension (row stride M / 2^d); the trace and stage-2 columns at zeta and zeta w in ONE pass
+    // 3. out-of-domain evaluations FROM VALUES (barycentric form, zp_ood_eval): a polynomial of degree < 2^d is read on a 2^d-point domain it is
+    //    known on; the trace and stage-2 columns at zeta and zeta w in ONE pass
     const e3 zeta_w = e3_scale(zeta, wN);
     std::vector<u64> ev_all((Wt + Wq) * 3), ev_next(Wt * 3);
-    PV_TRY(zp_ood_eval(ctx, (const uint64_t *)ext, M, (size_t)1 << logb, (int32_t)Wt, logn, shift, (const uint64_t *)zeta.c, 1, (uint64_t *)ev_all.data(),
-                       (uint64_t *)ev_next.data()));
+    // (the witness columns are read where they lie CONTIGUOUSLY -- the trace itself and the stage-2 columns, on the trace domain: shift 1, stride 1,
+    // 8 N bytes per column; the same numbers as from the 2^logn-point sub-coset of the extension (row stride 2^logb), which costs 16 N)
+    PV_TRY(zp_ood_eval(ctx, d_trace, N, 1, (int32_t)W, logn, 1, (const uint64_t *)zeta.c, 1, (uint64_t *)ev_all.data(), (uint64_t *)ev_next.data()));
+    if (W2) {
+        PV_TRY(zp_ood_eval(ctx, (const uint64_t *)s2_kept, N, 1, (int32_t)W2, logn, 1, (const uint64_t *)zeta.c, 1, (uint64_t *)(ev_all.data() + W * 3),
+                           (uint64_t *)(ev_next.data() + W * 3)));
+        PV_TRY(zp_sync(ctx));
+        dev.release(s2_kept);
+    }
     PV_TRY(zp_ood_eval(ctx, (const uint64_t *)dq, M, (size_t)1 << (logm - q_logn), (int32_t)Wq, q_logn, shift, (const uint64_t *)zeta.c, 0,
                        (uint64_t *)(ev_all.data() + Wt * 3), nullptr));
     tr.absorb(ev_all);
@@ -742,6 +751,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         rec.push_back((u64)(tr.last_rates.size() / 64));
         rec.insert(rec.end(), tr.log_blocks.begin(), tr.log_blocks.end());
         rec.insert(rec.end(), tr.last_rates.begin(), tr.last_rates.end());
+        rec.insert(rec.end(), tr.log_caps.begin(), tr.log_caps.end());         // one per permutation: n_blocks + (n_rates - 1)
     }
 
     // the proof text

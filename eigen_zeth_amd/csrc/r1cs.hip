@@ -414,7 +414,7 @@ struct Openings {
     // last absorbing permutation and of the squeeze-only permutations behind it (csrc/prove.hip writes them, service/wrap_circuit.py
     // TranscriptLog states them); 4 words per element
     uint64_t n_blocks, n_rates;
-    const uint64_t *blocks, *rates;
+    const uint64_t *blocks, *rates, *caps;      // caps: the capacity after every permutation (n_blocks + n_rates - 1 of them)
     const uint64_t *query(uint64_t q) const { return q0 + q * qwords; }
 };
 bool parse_openings(const uint64_t *d, size_t words, Openings *o) {
@@ -439,7 +439,8 @@ bool parse_openings(const uint64_t *d, size_t words, Openings *o) {
     if (o->n_blocks < 1 || o->n_blocks > 4096 || o->n_rates < 1 || o->n_rates > 256) return false;
     o->blocks = d + at + 2;
     o->rates = o->blocks + o->n_blocks * 64;
-    return words == at + 2 + (o->n_blocks + o->n_rates) * 64;
+    o->caps = o->rates + o->n_rates * 64;
+    return words == at + 2 + (o->n_blocks + o->n_rates) * 64 + (o->n_blocks + o->n_rates - 1) * 4;
 }
 // the scalar field's modulus r, little-endian words, and bit i of a 4-word value
 constexpr uint64_t FR_R[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
@@ -737,6 +738,7 @@ extern "C" {
 //   12 bits c .. c + count - 1 of rate element b of squeeze permutation a           13 entries c .. of that element's "equal to r so far" chain
 //      (walking down from bit 253 over the positions where r has a 1: the AND of the element's bits there, first position excluded)
 //   14 the 30 partial products of the top 32 bits of 64-bit word c of that element (bits 32..33, 32..34, ... 32..62 of the word)
+//   15 the capacity element after permutation a of the transcript (absorbing permutations in order, then the squeeze-only ones)
 // out_idx u64[cap], out_val u64[cap][4] (standard form) receive the wires and their values; *n_set their number ([2] of the script).
 int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64_t *openings, size_t open_words, const uint64_t *aux4, uint64_t *out_idx,
                        uint64_t *out_val, size_t cap, size_t *n_set) {
@@ -750,7 +752,7 @@ int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64
     for (uint64_t t = 0; t < o.ntr; t++)
         if (script[6 + 3 * t] != o.tr[t].width || script[7 + 3 * t] != o.tr[t].leaves || script[8 + 3 * t] != o.tr[t].levels) return ZP_ERR_ARG;   // another layout
     if (script[6 + 3 * o.ntr] != o.n_blocks || script[7 + 3 * o.ntr] != o.n_rates) return ZP_ERR_ARG;                                              // another transcript
-    for (uint64_t i = 0; i < (o.n_blocks + o.n_rates) * 16; i++)
+    for (uint64_t i = 0; i < (o.n_blocks + o.n_rates) * 16 + (o.n_blocks + o.n_rates - 1); i++)
         if (!std_canonical(o.blocks + 4 * i)) return ZP_ERR_ARG;
     // positions of r's one-bits below the top one, walking down: the chain of op 13
     unsigned ones[254], n_ones = 0;
@@ -760,7 +762,14 @@ int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64
     size_t n = 0;
     for (uint64_t k = 0; k < ne; k++, e += 6) {
         const uint64_t op = e[0], wire = e[1], cnt = e[2], a = e[3], b = e[4], c = e[5];
-        if (cnt < 1 || cnt > 64 || n + cnt > total || op > 14) return ZP_ERR_ARG;
+        if (cnt < 1 || cnt > 64 || n + cnt > total || op > 15) return ZP_ERR_ARG;
+        if (op == 15) {                      // the capacity after permutation a of the transcript
+            if (cnt != 1 || a >= o.n_blocks + o.n_rates - 1) return ZP_ERR_ARG;
+            out_idx[n] = wire;
+            memcpy(out_val + 4 * n, o.caps + 4 * a, 32);
+            n++;
+            continue;
+        }
         if (op >= 10) {
             if (op == 10 ? (a >= o.n_blocks || b + cnt > 16) : a >= o.n_rates) return ZP_ERR_ARG;
             if ((op == 11 && cnt != 16) || (op >= 12 && b >= 16) || (op == 12 && c + cnt > 254) || (op == 13 && c + cnt > n_ones) || (op == 14 && (cnt != 30 || c >= 3)))

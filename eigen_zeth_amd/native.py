@@ -64,6 +64,7 @@ SIGNATURES = {
     "zp_stark_prove_bn128": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "zp_poseidon_bn254_sponge": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp]),
+    "zp_poseidon_bn254_sponge_caps": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp]),
     "zp_free_buffer": (C.c_int32, [_vp]),
     "zp_stark_set_air_kernel": (C.c_int32, [C.c_void_p, _u64p, C.c_size_t, C.c_void_p]),
     "zp_poseidon_sponge": (C.c_int32, [_vp, _u64p, _u64p, C.c_size_t, C.c_size_t, _u64p]),

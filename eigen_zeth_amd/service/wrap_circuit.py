@@ -167,16 +167,18 @@ class TranscriptLog:
             raise ValueError("final STARK does not have the shape the wrap circuit was built for")
         self.data = [e for sg, spec in zip(segs, layout.transcript_segments()) for e, kind in zip(sg, [k for k, cnt in spec for _ in range(cnt)])
                      if not isinstance(kind, tuple)]      # everything absorbed besides the roots, in order
-        self.blocks, state = [], [0] * 17
+        self.blocks, self.caps, state = [], [], [0] * 17          # caps: the capacity element after every permutation, in order
         for sg in segs:
             for off in range(0, len(sg), 16):
                 blk = sg[off:off + 16] + [0] * (16 - len(sg[off:off + 16]))
                 self.blocks.append(blk)
                 state = perm([state[0]] + blk)
+                self.caps.append(state[0])
         self.rates = [state[1:]]
         for _ in range(layout.squeeze_perms() - 1):
             state = perm(state)
             self.rates.append(state[1:])
+            self.caps.append(state[0])
         vals = [((e >> (64 * k)) & 0xFFFFFFFFFFFFFFFF) % P for rate in self.rates for e in rate for k in range(3)]
         self.indices = [v & ((1 << layout.logm) - 1) for v in vals[:layout.n_queries]]
 
@@ -201,8 +203,19 @@ class WrapCircuit:
         ops = [(0, 0, 1, 1, 0, 0), (0, Z, 1, 0, 0, 0), (1, self.aux, 1, 0, 0, 0)] + [(2, w, 1, 0, t, 0) for t, w in enumerate(self.roots)]
 
         # ---- stage B-1: the transcript sponge.  One gadget per absorbed block; the roots in it are the root wires above, the rest new data wires
-        self.tdata, self.tblocks = [], []          # data wires in absorb order; per block its 16 input wires
-        cap, nblk = Z, 0
+        # Every gadget's CAPACITY input is a caller-set wire (the prover knows the capacity after every permutation of its own sponge) tied to
+        # its predecessor's output by one linear constraint: the gadgets then read caller-set wires only, i.e. they are all evaluated side by
+        # side in the first wave of zp_r1cs_eval -- chained through their output wires the 23 + 1 permutations were 24 dependent single-instance
+        # launches (16 ms of the 21 ms witness completion at the service's size).
+        self.tdata, self.tblocks, self.tcaps = [], [], []          # data wires in absorb order; per block its 16 input wires; the capacity wires
+        cap, nblk, prev_out = Z, 0, None
+
+        def next_cap(prev_out, k):
+            w = c.new_wire()
+            ops.append((15, w, 1, k, 0, 0))
+            c.add_constraint({prev_out: 1}, {0: 1}, {w: 1})
+            self.tcaps.append(w)
+            return w
         for seg in layout.transcript_segments():
             wires, fresh = [], set()
             for kind, cnt in seg:
@@ -225,9 +238,12 @@ class WrapCircuit:
                         k2 += 1
                     ops.append((10, blk[k], k2 - k + 1, nblk, k, 0))
                     k = k2 + 1
-                cap = c.add_instance([cap] + blk)
+                if prev_out is not None:
+                    cap = next_cap(prev_out, nblk - 1)
+                prev_out = c.add_instance([cap] + blk)
                 self.tblocks.append(blk)
                 nblk += 1
+        cap = prev_out
         data += self.tdata
         # the rate the indices are read from: caller-set wires tied to the instance's output state (an R1CS gadget exposes element 0 only)
         self.rates = []
@@ -239,7 +255,7 @@ class WrapCircuit:
                 c.add_constraint(c.output_lc(cap, 1 + i), {0: 1}, {rate[i]: 1})
             self.rates.append(rate)
             if k + 1 < n_sq:
-                cap = c.add_instance([cap] + rate)                # squeeze-only permutation: the whole state goes round
+                cap = c.add_instance([next_cap(cap, nblk - 1 + k)] + rate)   # squeeze-only permutation: the whole state goes round
         # canonical bit decompositions of the rate elements that carry an index; 64-bit word w of element e = bits 64 w .. 64 w + 63
         self.ebits = {}
         n_q = layout.n_queries
@@ -367,6 +383,8 @@ class WrapCircuit:
         for k, rate in enumerate(self.rates):
             for w, v in zip(rate, tlog.rates[k]):
                 vals[w] = v
+        for w, v in zip(self.tcaps, tlog.caps):          # capacity wire k = the capacity after permutation k (the last permutation's is not an input of anything)
+            vals[w] = v
         # bits and chains follow the rate elements (wire numbers: bits, then the < r chain, then per used word the 30 partial products)
         for (k, e), bits in self.ebits.items():
             v = tlog.rates[k][e]
@@ -448,6 +466,9 @@ def openings_record(proof, layout, tlog):
     for blk in tlog.blocks + tlog.rates:
         for e in blk:
             rec += w4(e)
+    assert len(tlog.caps) == len(tlog.blocks) + len(tlog.rates) - 1
+    for e in tlog.caps:
+        rec += w4(e)
     return np.array(rec, dtype=np.uint64)
 
 

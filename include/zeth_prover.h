@@ -152,6 +152,11 @@ int32_t zp_poseidon_bn254_perm(zp_ctx *ctx, uint64_t *d_states, size_t count, in
 /* the transcript sponge of the BN128 mode (width 17: element 0 capacity, 1..16 rate): absorb nblocks blocks of 16 elements, then
  * `extra` more permutations; h_state 17 elements in/out, h_rates (1 + extra) * 16 elements */
 int32_t zp_poseidon_bn254_sponge(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra, uint64_t *h_rates);
+/* the same, also handing out the capacity element (element 0) after EVERY permutation, in order: h_caps u64[max(nblocks, 1) + extra][4]
+ * (may be NULL).  The wrap circuit re-hashes the final STARK's transcript with all its gadgets side by side: each gadget's capacity input is
+ * a caller-set wire, tied to its predecessor's output by a constraint (service/wrap_circuit.py).                                        */
+int32_t zp_poseidon_bn254_sponge_caps(zp_ctx *ctx, uint64_t *h_state, const uint64_t *h_blocks, size_t nblocks, size_t extra,
+                                      uint64_t *h_rates, uint64_t *h_caps);
 size_t zp_merkle16_nodes(size_t M);
 int32_t zp_merkle16_commit_bn254(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, uint64_t *d_tree);
 int32_t zp_merkle16_open_bn254(zp_ctx *ctx, const uint64_t *d_tree, size_t M, size_t idx, uint64_t *h_path);
