@@ -95,6 +95,7 @@ struct zp_ctx {
     std::multimap<size_t, void *> prove_pool;
     size_t prove_pool_bytes = 0;
     std::map<std::string, u64 *> prove_fixed;
+    size_t prove_fixed_bytes = 0;
     std::map<std::string, void *> air_kernels;   // 64-hex-digit program digest -> generated constraint kernel (AIR plug-in ABI): zp_stark_set_air_kernel
     struct DigestEntry { std::vector<uint64_t> words; uint8_t dg[32]; };
     std::vector<DigestEntry> digest_cache;   // SHA-256 of the large constraint programs seen last (csrc/prove.hip: program_digest)
@@ -173,6 +174,9 @@ struct NttRunOpts {
 struct ZpFixedCol { int lp; size_t first_entry_word, n_entries; bool has_pub; };
 // validates the whole-blob length and the table; fills `cols` (empty for n_fixed == 2).  false: malformed
 bool zpi_program_fixed_table(const uint64_t *h_program, size_t program_words, std::vector<ZpFixedCol> *cols);
+// zp_fixed_columns; only_pub: refresh just the columns that hold public inputs inside a buffer whose other columns are already built
+int32_t zpi_fixed_columns_build(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *h_pub, int32_t n_pub, int32_t logn, int32_t logb,
+                                uint64_t shift, uint64_t *d_out, size_t out_words, bool only_pub);
 // device buffers from / back to the per-ctx pool of zp_stark_prove (csrc/prove.hip): everything runs on the ctx stream, so reuse is ordered
 int32_t zpi_pool_alloc(zp_ctx *ctx, size_t bytes, void **out);
 void zpi_pool_release(zp_ctx *ctx, void *p, size_t bytes);

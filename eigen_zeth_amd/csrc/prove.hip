@@ -515,8 +515,8 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     u64 *fixed, *dq, *dqcoef;
     {
         // the fixed columns on the evaluation domain (zp_fixed_columns: boundary selectors + one extended period of every sparse
-        // periodic column).  They depend on the domain and the program only -- cached per ctx -- unless a column holds public
-        // inputs (expected roots / indices of a verifier AIR): then they are rebuilt for this proof.
+        // periodic column).  They depend on the domain and the program only -- cached per ctx --; columns that hold public
+        // inputs (expected roots / indices of a verifier AIR) are refreshed per proof.
         bool has_pub = false;
         for (const ZpFixedCol &fc : fxc) has_pub |= fc.has_pub;
         const size_t fwords = zp_fixed_columns_words(h_program, program_words, logn, logb);
@@ -524,18 +524,30 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         char key[128];
         snprintf(key, sizeof key, "%d/%d/%llx/%llx/%s", logn, logb, (unsigned long long)shift, (unsigned long long)root32, fxc.empty() ? "" : dg_hex);
         auto it = ctx->prove_fixed.find(key);
-        if (!has_pub && it != ctx->prove_fixed.end()) {
+        if (it != ctx->prove_fixed.end()) {
             fixed = it->second;
-        } else if (has_pub) {
-            PV_TRY(dev.alloc(fwords, &fixed));
-            PV_TRY(zp_fixed_columns(ctx, h_program, program_words, h_pubs, n_pubs, logn, logb, shift, (uint64_t *)fixed, fwords));
+            // round 5: the statement's buffer is kept in either case; columns that hold public inputs (expected roots, indices, transcript
+            // words of a verifier AIR: 37 of 104 at the service's size) are refreshed in place for this proof, the others stay
+            if (has_pub) {
+                ZpStage stage_fx(ctx, "fixed_columns");
+                PV_TRY(zpi_fixed_columns_build(ctx, h_program, program_words, h_pubs, n_pubs, logn, logb, shift, (uint64_t *)fixed, fwords, true));
+            }
         } else {
+            // (a verifier AIR's columns are gigabytes -- 91 full-length columns at the service's size: 3 GB --; a ctx that has met many shapes
+            // starts over rather than grow without bound)
+            if (ctx->prove_fixed_bytes + fwords * 8 > ((size_t)24 << 30) && !ctx->prove_fixed.empty()) {
+                PV_TRY(zp_sync(ctx));
+                for (auto &kv : ctx->prove_fixed) (void)hipFree(kv.second);
+                ctx->prove_fixed.clear();
+                ctx->prove_fixed_bytes = 0;
+            }
             void *pf = nullptr;
             PV_TRY(zp_dev_alloc(ctx, fwords * 8, &pf));
             fixed = (u64 *)pf;
             const int32_t r = zp_fixed_columns(ctx, h_program, program_words, h_pubs, n_pubs, logn, logb, shift, (uint64_t *)fixed, fwords);
             if (r != ZP_OK) { (void)zp_dev_free(ctx, pf); return r; }
             ctx->prove_fixed[key] = fixed;
+            ctx->prove_fixed_bytes += fwords * 8;
         }
     }
     std::vector<u64> apow(3 * K);

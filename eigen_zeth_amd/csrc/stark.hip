@@ -862,10 +862,11 @@ extern "C" size_t zp_fixed_columns_words(const uint64_t *h_program, size_t progr
     return w;
 }
 
-extern "C" int32_t zp_fixed_columns(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *h_pub, int32_t n_pub,
-                                    int32_t logn, int32_t logb, uint64_t shift, uint64_t *d_out, size_t out_words) {
-    if (!ctx) return ZP_ERR_ARG;
-    ZpStage stage_(ctx, "fixed_columns");
+// only_pub: (re)build just the columns that hold public inputs, into a buffer whose other columns are already there -- the provers keep a
+// statement's fixed columns per ctx and refresh the public ones per proof (a verifier AIR at the service's size: 52 + 15 of its 104 sparse
+// columns and both selectors never change; round 5)
+int32_t zpi_fixed_columns_build(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *h_pub, int32_t n_pub, int32_t logn, int32_t logb,
+                                uint64_t shift, uint64_t *d_out, size_t out_words, bool only_pub) {
     ZP_ARG(ctx, h_program && d_out && logn >= 1 && logb >= 0 && logn + logb <= 32, "bad arguments");
     std::vector<ZpFixedCol> fxc;
     ZP_ARG(ctx, zpi_program_fixed_table(h_program, program_words, &fxc), "constraint program length does not match its header");
@@ -875,16 +876,23 @@ extern "C" int32_t zp_fixed_columns(zp_ctx *ctx, const uint64_t *h_program, size
     if (shift == 0) shift = ctx->coset_shift;
     ZP_ARG(ctx, shift < GL_P, "shift not canonical");
     const size_t N = (size_t)1 << logn, M = N << logb;
-    size_t in_words = 2 * N;
-    for (const ZpFixedCol &fc : fxc) in_words += (size_t)1 << fc.lp;
+    auto wanted = [&](const ZpFixedCol &fc) { return !only_pub || fc.has_pub; };
+    // input staging holds the selected columns only, one after the other
+    size_t in_words = only_pub ? 0 : 2 * N;
+    for (const ZpFixedCol &fc : fxc)
+        if (wanted(fc)) in_words += (size_t)1 << fc.lp;
+    if (in_words == 0) return ZP_OK;
     // the columns are sparse (a non-periodic public-input column of a verifier AIR has N rows and ~10^3 entries): the periods are
     // built ON THE DEVICE -- zero fill, then one scatter of (index, value) pairs -- instead of N-word host vectors and their upload
     std::vector<u64> pairs;
-    pairs.push_back(0); pairs.push_back(1);                      // L_first[0] = 1
-    pairs.push_back(N + N - 1); pairs.push_back(1);              // L_last[N - 1] = 1
+    if (!only_pub) {
+        pairs.push_back(0); pairs.push_back(1);                      // L_first[0] = 1
+        pairs.push_back(N + N - 1); pairs.push_back(1);              // L_last[N - 1] = 1
+    }
     {
-        size_t at = 2 * N;
+        size_t at = only_pub ? 0 : 2 * N;
         for (const ZpFixedCol &fc : fxc) {
+            if (!wanted(fc)) continue;
             for (size_t e = 0; e < fc.n_entries; e++) {
                 const u64 a = h_program[fc.first_entry_word + 2 * e], v = h_program[fc.first_entry_word + 2 * e + 1];
                 u64 val = v;
@@ -902,17 +910,18 @@ extern "C" int32_t zp_fixed_columns(zp_ctx *ctx, const uint64_t *h_program, size
     ZP_TRY(zpi_scratch(ctx, 4, in_words + pairs.size(), &din));
     u64 *dpairs = din + in_words;
     int32_t rc = zp_dev_zero(ctx, din, in_words * 8);
-    if (rc == ZP_OK) rc = zp_h2d(ctx, dpairs, pairs.data(), pairs.size() * 8);
-    if (rc == ZP_OK) {
+    if (rc == ZP_OK && !pairs.empty()) rc = zp_h2d(ctx, dpairs, pairs.data(), pairs.size() * 8);
+    if (rc == ZP_OK && !pairs.empty()) {
         const size_t np = pairs.size() / 2;
         hipLaunchKernelGGL(scatter_pairs_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, din, (const u64 *)dpairs, np);
         if (hipGetLastError() != hipSuccess) rc = ZP_ERR_HIP;
     }
-    if (rc == ZP_OK) rc = zpi_lde(ctx, (const u64 *)din, (u64 *)d_out, nullptr, logn, logb, 2, shift);
-    size_t in_at = 2 * N, out_at = 2 * M;
-    for (size_t k = 0; rc == ZP_OK && k < fxc.size();) {      // consecutive columns of one period go through one LDE call
+    if (rc == ZP_OK && !only_pub) rc = zpi_lde(ctx, (const u64 *)din, (u64 *)d_out, nullptr, logn, logb, 2, shift);
+    size_t in_at = only_pub ? 0 : 2 * N, out_at = 2 * M;
+    for (size_t k = 0; rc == ZP_OK && k < fxc.size();) {      // consecutive SELECTED columns of one period go through one LDE call
+        if (!wanted(fxc[k])) { out_at += (size_t)1 << (fxc[k].lp + logb); k++; continue; }
         size_t j = k;
-        while (j < fxc.size() && fxc[j].lp == fxc[k].lp) j++;
+        while (j < fxc.size() && fxc[j].lp == fxc[k].lp && wanted(fxc[j])) j++;
         const int lp = fxc[k].lp;
         const u64 sh = gl_pow(shift, (u64)1 << (logn - lp));    // shift^(N/p)
         if (logb == 0 && sh == 1) rc = zp_d2d(ctx, d_out + out_at, (const u64 *)din + in_at, ((j - k) << lp) * 8);
@@ -922,6 +931,13 @@ extern "C" int32_t zp_fixed_columns(zp_ctx *ctx, const uint64_t *h_program, size
         k = j;
     }
     return rc;
+}
+
+extern "C" int32_t zp_fixed_columns(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *h_pub, int32_t n_pub,
+                                    int32_t logn, int32_t logb, uint64_t shift, uint64_t *d_out, size_t out_words) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZpStage stage_(ctx, "fixed_columns");
+    return zpi_fixed_columns_build(ctx, h_program, program_words, h_pub, n_pub, logn, logb, shift, d_out, out_words, false);
 }
 
 extern "C" int32_t zp_eval_quotient_rows(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const uint64_t *d_cols,

@@ -118,6 +118,20 @@ class EngineConfig:
         self.agg_queries, self.agg_pow_bits = agg_queries, agg_pow_bits
 
 
+def recursion_airs_for(cfg, root32, shift, rc, mds, n_proofs=2, logn=None):
+    """(the verifier AIR an aggregation STARK over `n_proofs` chunk proofs of 2^logn rows proves, the one the final STARK over THAT proof proves) under
+    the configuration `cfg` -- statements made per shape (stark/verifier_air.py).  No backend needed: __graft_entry__.build() calls this to
+    compile the generated constraint kernels of the default service's recursion programs ahead of time (they travel with the tree)."""
+    air = AIR.get_air(cfg.air)
+    lg = cfg.logn if logn is None else logn
+    chunk_shape = VA.Shape(lg, cfg.logb, air.width, air.width2, 3 * AIR.quotient_chunks(air), cfg.n_queries, cfg.fri_logf, cfg.fri_final_log, n_proofs,
+                           air.n_pub, cfg.pow_bits, int(root32), int(shift))
+    ap = VA.aggregation_params(chunk_shape, cfg.agg_queries, cfg.fri_logf, cfg.fri_final_log, cfg.agg_pow_bits)
+    agg_shape = VA.Shape(ap.logn, ap.logb, VA.WIDTH, 0, 3 * VA.Q_PIECES, ap.n_queries, ap.fri_logf, ap.fri_final_log, 1, chunk_shape.n_pub(), ap.pow_bits,
+                         int(root32), int(shift))
+    return VA.verifier_air(chunk_shape, rc, mds), VA.verifier_air(agg_shape, rc, mds)
+
+
 class Engine:
     FAST_PARSE_MIN = 1 << 16      # proof texts from this size on have their openings parsed by the library (csrc/proofparse.hip)
 
@@ -636,16 +650,8 @@ class Engine:
 
     def recursion_airs(self, n_proofs=2, logn=None):
         """(the verifier AIR the aggregation STARK proves, the one the final STARK proves) for the usual request -- two chunk proofs of the
-        configured size; statements made per shape (stark/verifier_air.py)"""
-        air = AIR.get_air(self.cfg.air)
-        sp = self.stark_params(logn)
-        chunk_shape = VA.Shape(sp.logn, sp.logb, air.width, air.width2, 3 * AIR.quotient_chunks(air), sp.n_queries, sp.fri_logf, sp.fri_final_log, n_proofs,
-                               air.n_pub, sp.pow_bits, int(self.be.root32), int(self.be.shift))
-        ap = self._agg_params(chunk_shape)
-        agg_shape = VA.Shape(ap.logn, ap.logb, VA.WIDTH, 0, 3 * VA.Q_PIECES, ap.n_queries, ap.fri_logf, ap.fri_final_log, 1, chunk_shape.n_pub(), ap.pow_bits,
-                             int(self.be.root32), int(self.be.shift))
-        tables = self._tables(self.be)
-        return VA.verifier_air(chunk_shape, *tables), VA.verifier_air(agg_shape, *tables)
+        configured size"""
+        return recursion_airs_for(self.cfg, self.be.root32, self.be.shift, *self._tables(self.be), n_proofs=n_proofs, logn=logn)
 
     def _wrap_key(self, layout):
         """(wrap circuit, Groth16 key) for a final-STARK layout: built once per layout (seconds at the service's size: the circuit in Python,
