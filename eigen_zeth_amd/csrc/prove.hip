@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -253,21 +254,33 @@ void j_e3list(std::string &s, const std::vector<u64> &v) {   // [[a,b,c],...]
     s += ']';
 }
 void j_dec256(std::string &s, const u64 *w4) {     // "decimal" of a 256-bit little-endian value, quoted
+    // 19 digits at a time (10^19 < 2^64): five long divisions instead of 78 -- a BN128-mode proof text carries ~20 000 such numbers
+    // (16 digests per level of every authentication path), and digit-by-digit they were 8 ms of a 93 ms final STARK
+    constexpr u64 TEN19 = 10000000000000000000ULL;
     u64 v[4] = {w4[0], w4[1], w4[2], w4[3]};
-    char digits[80];
+    u64 chunk[5];
     int n = 0;
     while (v[0] | v[1] | v[2] | v[3]) {
         unsigned __int128 rem = 0;
         for (int k = 3; k >= 0; k--) {
             const unsigned __int128 cur = (rem << 64) | v[k];
-            v[k] = (u64)(cur / 10);
-            rem = cur % 10;
+            v[k] = (u64)(cur / TEN19);
+            rem = cur % TEN19;
         }
-        digits[n++] = (char)('0' + (int)rem);
+        chunk[n++] = (u64)rem;
     }
-    if (!n) digits[n++] = '0';
     s += '"';
-    while (n) s += digits[--n];
+    if (!n) {
+        s += '0';
+    } else {
+        char b[24];
+        snprintf(b, sizeof b, "%llu", (unsigned long long)chunk[n - 1]);
+        s += b;
+        for (int k = n - 2; k >= 0; k--) {
+            snprintf(b, sizeof b, "%019llu", (unsigned long long)chunk[k]);
+            s += b;
+        }
+    }
     s += '"';
 }
 void j_root(std::string &s, const u64 *root4, bool bn) {
@@ -412,6 +425,15 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     const u64 shift = ctx->coset_shift, root32 = ctx->root32;
     const u64 wN = gl_root(root32, logn);
     DevBufs dev(ctx);
+    // measurement aid (ZP_PROVE_TRACE=1): host-clock milliseconds since entry at the stage boundaries, the stream drained at each -- where the
+    // wall time of a proof goes that the per-entry-point GPU times do not show
+    static const bool trace_on = getenv("ZP_PROVE_TRACE") != nullptr;
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!trace_on) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[prove %s 2^%d] %-28s %8.3f ms\n", air_name, logn, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
+    };
 
     // AIR digest: sha256 of the blob; the first 16 hex digits name it, four little-endian words go into the transcript
     uint8_t dg[32];
@@ -460,6 +482,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         tr.absorb_root(rootp);
     }
 
+    mark("transcript head");
     // 1. commit the trace (ext has room for the stage-2 columns behind the trace columns).  No coefficient buffer since round 5: the
     //    out-of-domain evaluations come from the resident extension (zp_ood_eval), so the extensions run without their coefficient
     //    store -- on the fused seam kernel where the plan allows it (csrc/ntt.hip) -- and W N 8 bytes per proof are never written
@@ -511,6 +534,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     const e3 alpha = tr.challenge();
     PV_TRY(tr.rc);
 
+    mark("trace (+stage 2) committed");
     // 2. constraint quotient on the coset
     u64 *fixed, *dq, *dqcoef;
     {
@@ -550,6 +574,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
             ctx->prove_fixed_bytes += fwords * 8;
         }
     }
+    mark("fixed columns");
     std::vector<u64> apow(3 * K);
     {
         e3 cur = e3_make(1, 0, 0);
@@ -564,7 +589,11 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     PV_TRY(dev.alloc(3 * M, &dq));
     zp_air_quotient_fn plug = nullptr;
     if (!ctx->air_kernels.empty()) {       // (round 5: generated kernels read the sparse periodic fixed columns too -- one extended period each, zp_fixed_columns' layout)
-        auto it = ctx->air_kernels.find(digest_hex64(h_program, program_words));
+        // (the digest computed above -- through the per-ctx cache, a memcmp for a program seen before -- not a second SHA-256 of the blob:
+        // for a verifier AIR's 7 MB that second hash was 16 ms of every recursion STARK, round 5)
+        char hex[65];
+        for (int i = 0; i < 32; i++) snprintf(hex + 2 * i, 3, "%02x", dg[i]);
+        auto it = ctx->air_kernels.find(std::string(hex, 64));
         if (it != ctx->air_kernels.end()) plug = (zp_air_quotient_fn)it->second;
     }
     if (plug) {
@@ -593,6 +622,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         PV_TRY(zp_eval_quotient(ctx, h_program, program_words, (const uint64_t *)ext, (const uint64_t *)fixed, logm, logb, (const uint64_t *)pubchal.data(),
                                 (int32_t)pubchal.size(), (const uint64_t *)apow.data(), (const uint64_t *)zhinv.data(), shift, gl_inv(wN), (uint64_t *)dq));
     }
+    mark("quotient evaluated");
     int q_logn = logm;
     size_t Wq = 3;
     u64 *treeq;
@@ -627,6 +657,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     const e3 zeta = tr.challenge();
     PV_TRY(tr.rc);
 
+    mark("quotient committed");
     // 3. out-of-domain evaluations FROM VALUES (barycentric form, zp_ood_eval): a polynomial of degree < 2^d is read on a 2^d-point domain it is
     //    known on; the trace and stage-2 columns at zeta and zeta w in ONE pass
     const e3 zeta_w = e3_scale(zeta, wN);
@@ -647,6 +678,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     const e3 gamma = tr.challenge();
     PV_TRY(tr.rc);
 
+    mark("out-of-domain evaluations");
     // 4. DEEP quotient
     u64 *df;
     PV_TRY(dev.alloc(3 * M, &df));
@@ -683,6 +715,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     PV_TRY(zp_d2h(ctx, final_l.data(), dlayer, final_l.size() * 8));
     for (int c = 0; c < 3; c++) tr.absorb(&final_l[(size_t)c << final_log], (size_t)1 << final_log);   // plane by plane (BN128 mode pads every call)
 
+    mark("DEEP + FRI");
     // 6. proof of work, then the queries
     u64 nonce = 0;
     if (pow_bits) {
@@ -766,6 +799,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
         rec.insert(rec.end(), tr.log_caps.begin(), tr.log_caps.end());         // one per permutation: n_blocks + (n_rates - 1)
     }
 
+    mark("queries opened");
     // the proof text
     std::string s;
     s.reserve(nq * (Wt + Wq + 64) * 24 + (1 << 16));
@@ -811,6 +845,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     s += ']';
     if (pow_bits) { s += ",\"pow_nonce\":"; j_u64(s, nonce); }
     s += '}';
+    mark("proof text");
     char *buf = (char *)malloc(s.size() + 1);
     if (!buf) { ctx->err = "out of host memory for the proof text"; return ZP_ERR_NOMEM; }
     memcpy(buf, s.data(), s.size() + 1);

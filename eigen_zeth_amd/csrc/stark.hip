@@ -1004,16 +1004,19 @@ extern "C" int32_t zp_eval_quotient_rows(zp_ctx *ctx, const uint64_t *h_program,
     if (nrows == 0) return ZP_OK;
     NttPlan *pl;
     ZP_TRY(zpi_get_plan(ctx, logm, false, &pl));
-    // one upload: program | pub | apow | zhinv | (offset, mask) of the periodic fixed columns
-    const size_t np_all = (size_t)n_pub + 1, total = program_words + np_all + 3 * (size_t)n_cons + (size_t)b + 2 * fxc.size() + 1;
+    // one upload: program (header, constants, instructions -- NOT the sparse columns' entry tables behind them: the kernel never reads those,
+    // and for a verifier AIR they are 7 MB of the blob; round 5: this upload was 16 ms of a 63 ms aggregation STARK) | pub | apow | zhinv |
+    // (offset, mask) of the periodic fixed columns
+    const size_t pw = 12 + (size_t)n_const + (size_t)n_instr;
+    const size_t np_all = (size_t)n_pub + 1, total = pw + np_all + 3 * (size_t)n_cons + (size_t)b + 2 * fxc.size() + 1;
     std::vector<u64> h(total);
-    memcpy(h.data(), h_program, program_words * 8);
-    for (int i = 0; i < n_pub; i++) h[program_words + i] = h_pub[i];
-    h[program_words + n_pub] = 0;
-    memcpy(h.data() + program_words + np_all, h_alpha_pows, 3 * (size_t)n_cons * 8);
-    memcpy(h.data() + program_words + np_all + 3 * (size_t)n_cons, h_zhinv, (size_t)b * 8);
+    memcpy(h.data(), h_program, pw * 8);
+    for (int i = 0; i < n_pub; i++) h[pw + i] = h_pub[i];
+    h[pw + n_pub] = 0;
+    memcpy(h.data() + pw + np_all, h_alpha_pows, 3 * (size_t)n_cons * 8);
+    memcpy(h.data() + pw + np_all + 3 * (size_t)n_cons, h_zhinv, (size_t)b * 8);
     {
-        u64 *t = h.data() + program_words + np_all + 3 * (size_t)n_cons + (size_t)b, off = 0;
+        u64 *t = h.data() + pw + np_all + 3 * (size_t)n_cons + (size_t)b, off = 0;
         for (size_t k = 0; k < fxc.size(); k++) {
             const u64 len = 1ULL << (fxc[k].lp + logb);
             t[2 * k] = off;
@@ -1032,7 +1035,7 @@ extern "C" int32_t zp_eval_quotient_rows(zp_ctx *ctx, const uint64_t *h_program,
     a.prog = d;
     a.cols = (const u64 *)d_cols;
     a.fixedc = (const u64 *)d_fixed;
-    a.pub = d + program_words;
+    a.pub = d + pw;
     a.apow = a.pub + np_all;
     a.zhinv = a.apow + 3 * (size_t)n_cons;
     a.fx_tab = a.zhinv + (size_t)b;
