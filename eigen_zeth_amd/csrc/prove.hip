@@ -238,10 +238,26 @@ struct DevBufs {
 };
 
 // ---- JSON text exactly as json.dumps(proof, separators=(",", ":")) writes it
+// a chunk proof's text is ~150 000 decimal numbers: two digits per division from a table instead of snprintf (6.4 -> ~2 ms of a 90 ms proof at 2^22 rows)
 void j_u64(std::string &s, u64 v) {
+    static const char D2[201] =
+        "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869"
+        "707172737475767778798081828384858687888990919293949596979899";
     char b[24];
-    snprintf(b, sizeof b, "%llu", (unsigned long long)v);
-    s += b;
+    int at = 24;
+    while (v >= 100) {
+        const unsigned r = (unsigned)(v % 100);
+        v /= 100;
+        b[--at] = D2[2 * r + 1];
+        b[--at] = D2[2 * r];
+    }
+    if (v >= 10) {
+        b[--at] = D2[2 * v + 1];
+        b[--at] = D2[2 * v];
+    } else {
+        b[--at] = (char)('0' + v);
+    }
+    s.append(b + at, (size_t)(24 - at));
 }
 void j_list(std::string &s, const u64 *v, size_t n) {
     s += '[';
