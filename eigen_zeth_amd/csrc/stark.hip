@@ -818,34 +818,6 @@ __global__ void __launch_bounds__(256) scatter_pairs_kernel(u64 *__restrict__ ds
     if (i < n) dst[pairs[2 * i]] = pairs[2 * i + 1];
 }
 
-bool zpi_program_fixed_table(const uint64_t *h_program, size_t program_words, std::vector<ZpFixedCol> *cols) {
-    if (program_words < 12) return false;
-    const u64 n_fixed = h_program[3], n_pub = h_program[4], n_const = h_program[6], n_instr = h_program[7], n_s2 = h_program[10];
-    if (n_fixed < 2 || n_fixed > 4096 || n_const > (1u << 16) || n_instr > (1u << 24) || n_s2 > (1u << 16)) return false;
-    size_t at = 12 + (size_t)n_const + (size_t)n_instr + 4 * (size_t)n_s2;
-    if (cols) cols->clear();
-    for (u64 k = 2; k < n_fixed; k++) {
-        if (at >= program_words) return false;
-        const u64 hd = h_program[at];
-        ZpFixedCol fc;
-        fc.lp = (int)(hd & 0xFF);
-        fc.n_entries = (size_t)(hd >> 8);
-        fc.first_entry_word = at + 1;
-        fc.has_pub = false;
-        if (fc.lp > 32 || fc.n_entries > ((size_t)1 << fc.lp) || at + 1 + 2 * fc.n_entries > program_words) return false;
-        for (size_t e = 0; e < fc.n_entries; e++) {
-            const u64 a = h_program[at + 1 + 2 * e], v = h_program[at + 2 + 2 * e];
-            const bool is_pub = (a >> 63) != 0;
-            if ((a & ~(1ULL << 63)) >= (1ULL << fc.lp)) return false;
-            if (is_pub ? v >= n_pub : v >= GL_P) return false;
-            fc.has_pub |= is_pub;
-        }
-        at += 1 + 2 * fc.n_entries;
-        if (cols) cols->push_back(fc);
-    }
-    return at == program_words;
-}
-
 // ---- the fixed columns of a statement on the evaluation domain: what zp_eval_quotient takes as d_fixed ------------------
 // Layout: [L_first: M][L_last: M][column 2: 2^(lp_2 + logb)][column 3: ...] -- a periodic column of period p = 2^lp is
 // f(x) = g(x^(N/p)) with g the interpolant of one period, and on the coset shift * <w_M> the point x^(N/p) runs over

@@ -63,16 +63,48 @@ bool fixed_col_at(const uint64_t *prog, const ZpFixedCol &fc, const uint64_t *pu
 
 }  // namespace
 
+// The table of sparse periodic fixed columns behind a program's stage-2 table (layout: stark/air.py compile_program): validates the whole-blob
+// length and every entry; fills `cols`.  Lives in this host-only translation unit so that everything that PARSES a program blob builds
+// under the host sanitizers (tests/test_verify_fuzz.py).
+bool zpi_program_fixed_table(const uint64_t *h_program, size_t program_words, std::vector<ZpFixedCol> *cols) {
+    if (program_words < 12) return false;
+    const u64 n_fixed = h_program[3], n_pub = h_program[4], n_const = h_program[6], n_instr = h_program[7], n_s2 = h_program[10];
+    if (n_fixed < 2 || n_fixed > 4096 || n_const > (1u << 16) || n_instr > (1u << 24) || n_s2 > (1u << 16)) return false;
+    size_t at = 12 + (size_t)n_const + (size_t)n_instr + 4 * (size_t)n_s2;
+    if (cols) cols->clear();
+    for (u64 k = 2; k < n_fixed; k++) {
+        if (at >= program_words) return false;
+        const u64 hd = h_program[at];
+        ZpFixedCol fc;
+        fc.lp = (int)(hd & 0xFF);
+        fc.n_entries = (size_t)(hd >> 8);
+        fc.first_entry_word = at + 1;
+        fc.has_pub = false;
+        if (fc.lp > 32 || fc.n_entries > ((size_t)1 << fc.lp) || at + 1 + 2 * fc.n_entries > program_words) return false;
+        for (size_t e = 0; e < fc.n_entries; e++) {
+            const u64 a = h_program[at + 1 + 2 * e], v = h_program[at + 2 + 2 * e];
+            const bool is_pub = (a >> 63) != 0;
+            if ((a & ~(1ULL << 63)) >= (1ULL << fc.lp)) return false;
+            if (is_pub ? v >= n_pub : v >= GL_P) return false;
+            fc.has_pub |= is_pub;
+        }
+        at += 1 + 2 * fc.n_entries;
+        if (cols) cols->push_back(fc);
+    }
+    return at == program_words;
+}
+
 extern "C" {
 
 // Values of the K constraints of a program at the out-of-domain point of a proof over a trace of 2^logn rows.
 //   h_pubchal u64[n_pubchal]: the public inputs, then the stage-2 challenge components (what the prover's interpreter reads as K_PUB)
-//   zeta[3]; h_ev_z / h_ev_zw u64[W + W2][3]: the committed columns' evaluations at zeta / zeta w
-//   h_out u64[K][3]: constraint k at zeta (numerators: the caller combines them with its alpha powers and compares with q(zeta) Z_H(zeta))
+//   zeta[3]; h_ev_z / h_ev_zw u64[n_cols][3]: the committed columns' evaluations at zeta / zeta w (n_cols must be the program's W + W2)
+//   h_out u64[n_out][3]: constraint k at zeta (n_out must be the program's K) (numerators: the caller combines them with its alpha powers and compares with q(zeta) Z_H(zeta))
 // Fixed columns: 0 / 1 the first-row / last-row selectors (Lagrange basis polynomials), then the sparse periodic columns; "x - last" is
 // zeta - w^(N-1).  ZP_ERR_ARG: malformed program, non-canonical input, zeta on the trace domain.  threads <= 0: one per core, at most 16.
 int32_t zp_program_eval_ext(const uint64_t *h_program, size_t program_words, const uint64_t *h_pubchal, int32_t n_pubchal, int32_t logn, uint64_t root32,
-                            const uint64_t zeta3[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t *h_out, int32_t threads) {
+                            const uint64_t zeta3[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, int32_t n_cols, uint64_t *h_out, int32_t n_out,
+                            int32_t threads) {
     try {
         if (!h_program || !zeta3 || !h_ev_z || !h_ev_zw || !h_out || program_words < 12 || logn < 1 || logn > 32 || n_pubchal < 0 || (n_pubchal && !h_pubchal))
             return ZP_ERR_ARG;
@@ -84,6 +116,9 @@ int32_t zp_program_eval_ext(const uint64_t *h_program, size_t program_words, con
         if (!zpi_program_fixed_table(h_program, program_words, &fxc) || W < 1 || W >= 4096 || W2 >= 4096 || n_slots > (1u << 16) || K < 1 ||
             (size_t)n_pubchal != n_pub + n_chal || root32 == 0 || root32 >= GL_P)
             return ZP_ERR_ARG;
+        // the caller's arrays are sized by ITS idea of the statement: they must be the program's (a blob with another width or constraint count
+        // would be read / written past them)
+        if (n_cols < 0 || (size_t)n_cols != W + W2 || n_out < 0 || (size_t)n_out != K) return ZP_ERR_ARG;
         for (int i = 0; i < 3; i++)
             if (zeta3[i] >= GL_P) return ZP_ERR_ARG;
         for (int i = 0; i < n_pubchal; i++)

@@ -94,7 +94,7 @@ SIGNATURES = {
     "zp_merkle_open": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _u64p]),
     "zp_fri_fold": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, _u64p, C.c_uint64]),
     "zp_poly_eval_ext": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _u64p, _u64p]),
-    "zp_program_eval_ext": (C.c_int32, [_u64p, C.c_size_t, _u64p, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p, _u64p, _u64p, C.c_int32]),
+    "zp_program_eval_ext": (C.c_int32, [_u64p, C.c_size_t, _u64p, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p, _u64p, C.c_int32, _u64p, C.c_int32, C.c_int32]),
     "zp_ood_eval": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_uint64, _u64p, C.c_int32, _u64p, _u64p]),
     "zp_deep_quotient": (C.c_int32, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, _u64p, _u64p, _u64p,
                                      _u64p, _u64p, C.c_uint64, _vp]),
@@ -320,7 +320,10 @@ def program_eval_ext(program, pubchal, logn, root32, zeta, ev_z, ev_zw, threads=
     ez, ezw = np.ascontiguousarray(np.asarray(ev_z, dtype=np.uint64)), np.ascontiguousarray(np.asarray(ev_zw, dtype=np.uint64))
     out = np.zeros((int(prog[8]), 3), dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(_u64p)
-    rc = load_library().zp_program_eval_ext(p(prog), prog.size, p(pc), len(pubchal), logn, int(root32), p(z), p(ez), p(ezw), p(out), threads)
+    if ez.shape != ezw.shape or ez.ndim != 2 or ez.shape[1] != 3:
+        raise ValueError("zp_program_eval_ext: evaluations must be two [columns][3] arrays")
+    rc = load_library().zp_program_eval_ext(p(prog), prog.size, p(pc), len(pubchal), logn, int(root32), p(z), p(ez), p(ezw), ez.shape[0], p(out), out.shape[0],
+                                            threads)
     if rc != 0:
         raise ValueError("zp_program_eval_ext: malformed program or evaluations (%d)" % rc)
     return out

@@ -227,11 +227,12 @@ int32_t zp_poly_eval_ext(zp_ctx *ctx, const uint64_t *d_coef, int32_t logn, int3
 /* The verifier's side of a constraint program at the out-of-domain point (host code; csrc/verify.hip): the values of its K constraints
  * at zeta from the committed columns' evaluations -- what GenFinalProof's service checks natively on the aggregated proof a client hands
  * in (prover.proto:130-148) before it wraps it.  h_pubchal u64[n_pub + n_chal]: public inputs, then stage-2 challenge components;
- * h_ev_z / h_ev_zw u64[W + W2][3]; h_out u64[K][3].  Fixed columns 0 / 1 = first-row / last-row selectors, then the sparse periodic
+ * h_ev_z / h_ev_zw u64[n_cols][3]; h_out u64[n_out][3] -- n_cols / n_out are the sizes of the CALLER's arrays and must equal the program's W + W2 / K (a
+ * blob of another shape is refused, not read past them).  Fixed columns 0 / 1 = first-row / last-row selectors, then the sparse periodic
  * columns of the program (one shared inversion per column); threads <= 0: one per core (at most 16).  No ctx: nothing touches a GPU. */
 int32_t zp_program_eval_ext(const uint64_t *h_program, size_t program_words, const uint64_t *h_pubchal, int32_t n_pubchal, int32_t logn,
-                            uint64_t root32, const uint64_t zeta[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, uint64_t *h_out,
-                            int32_t threads);
+                            uint64_t root32, const uint64_t zeta[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, int32_t n_cols,
+                            uint64_t *h_out, int32_t n_out, int32_t threads);
 /* Out-of-domain evaluations FROM VALUES (barycentric form; round 5: the provers keep no coefficient buffers for this any more).
  * Column c is a polynomial p_c of degree < 2^logn given by its values on the coset shift*<w>, w of order 2^logn:
  *   d_cols[c * col_stride + i * row_stride] = p_c(shift * w^i)      (row_stride = 2^logb reads the 2^logn-point sub-coset of an
