@@ -10,6 +10,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -527,6 +530,13 @@ int32_t records_to_device(zp_ctx *ctx, Records &rec, u64 nblk, u64 *d_out) {
 int32_t recursion_witness(zp_ctx *ctx, const Desc &D, const uint64_t *const *h_index, const uint64_t *const *h_values, const uint64_t *const *h_paths,
                           const uint64_t *const *h_stream, const size_t *stream_words, u64 *d_trace, u64 *h_pubs, size_t pubs_words, int threads) {
     const u64 pb = D.pb, nblk = D.pb * D.periods, N = nblk * ROWS, T = D.T, NP = D.n_proofs, nq = D.n_queries, nslots = D.n_slots();
+    static const bool trace_on = getenv("ZP_PROVE_TRACE") != nullptr;      // measurement aid: host-clock ms since entry at the stage boundaries
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!trace_on) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[recursion witness] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
+    };
     // ---- the transcript script fixes the size of a proof's transcript section
     u64 tp_per = 0;
     for (u64 j = 0; j < D.L; j++) tp_per += (D.script[j] & 255) + (((D.script[j] >> 8) & 1) ? 8 : 0);
@@ -566,6 +576,7 @@ int32_t recursion_witness(zp_ctx *ctx, const Desc &D, const uint64_t *const *h_i
         memcpy(&vals[o * mw], (const u64 *)h_values[op.p] + voff[op.t] + op.q * wv[op.t], wv[op.t] * 8);
         index[o] = ((const u64 *)h_index[op.p])[op.q] & (((u64)1 << op.nd) - 1);
     }
+    mark("opening table");
     DevTmp scratch(ctx);
     ZP_TRY(scratch.alloc((no > 1 ? no : 1) * 96));
     std::vector<u64> stt(no * 12);
@@ -586,6 +597,7 @@ int32_t recursion_witness(zp_ctx *ctx, const Desc &D, const uint64_t *const *h_i
         ZP_TRY(perm_batch(ctx, scratch, stt.data(), sel.size()));
         for (size_t i = 0; i < sel.size(); i++) memcpy(&cap[sel[i] * 4], &stt[i * 12], 32);
     }
+    mark("leaf hashes");
     for (u64 o = 0; o < no; o++) memcpy(&digest[o * 4], ops[o].na ? &cap[o * 4] : &vals[o * mw], 32);     // unhashed leaves: identity, zero padded
     // ---- paths: tree level lv of every opening in one batch
     for (u64 lv = 0; lv < max_d; lv++) {
@@ -614,6 +626,7 @@ int32_t recursion_witness(zp_ctx *ctx, const Desc &D, const uint64_t *const *h_i
             ctx->err = "an opening of an inner proof does not hash to its root: no accepting witness";
             return -13;
         }
+    mark("paths");
     // ---- public inputs: roots | indices | transcripts | arithmetic constants | final-layer values
     u64 *pub = h_pubs;
     for (u64 p = 0; p < NP; p++)
@@ -644,11 +657,13 @@ int32_t recursion_witness(zp_ctx *ctx, const Desc &D, const uint64_t *const *h_i
             for (int c = 0; c < 3; c++) fin[(g * NP + p) * 3 + c] = st[p].final_l[c * fl + pos];
         }
     memcpy(pub, fin.data(), fin.size() * 8);
+    mark("transcripts replayed");
     // ---- the arithmetic columns
     Records rec(nblk);
     const int rc = walk_all(D, vals.data(), index.data(), dbit.data(), blk_op.data(), aps.data(), fin.data(), rec.view(), threads);
     if (rc == -12) { ctx->err = "arithmetic-witness inputs do not match the descriptor"; return ZP_ERR_ARG; }
     if (rc != 0) { ctx->err = "the opened values of an inner proof are inconsistent: no accepting witness"; return rc; }
+    mark("arithmetic columns (host)");
     // ---- the trace in HBM: 24 permutation columns, direction bit, index, 21 arithmetic columns
     DevTmp d_in(ctx), d_pb(ctx);
     ZP_TRY(d_in.alloc(inputs.size() * 8));
@@ -661,7 +676,9 @@ int32_t recursion_witness(zp_ctx *ctx, const Desc &D, const uint64_t *const *h_i
         hipLaunchKernelGGL(block_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_trace + (24 + c) * N, (const u64 *)d_pb.p + c * nblk, N);
         if (hipGetLastError() != hipSuccess) { ctx->err = "block_fill_kernel launch failed"; return ZP_ERR_HIP; }
     }
-    return records_to_device(ctx, rec, nblk, d_trace + 26 * N);
+    const int32_t rrc = records_to_device(ctx, rec, nblk, d_trace + 26 * N);
+    mark("trace assembled in HBM");
+    return rrc;
 }
 
 }  // namespace
