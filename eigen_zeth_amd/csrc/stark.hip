@@ -465,9 +465,24 @@ int32_t zp_gather_rows(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W,
     ZP_ARG(ctx, d_cols && h_idx && h_out, "null pointer");
     for (int i = 0; i < nq; i++) ZP_ARG(ctx, h_idx[i] < M, "row index out of range");
     u64 *d = nullptr;
+    const u64 total = (u64)nq * W;
+    if ((total + (u64)nq) * 8 <= ZP_SMALL_COPY) {
+        // query openings are a few hundred kilobytes: indices in and rows out through the page-locked, device-visible staging buffer -- the
+        // kernel reads and writes it directly: one launch, two synchronisations (round 5; before: copy kernels in and out, four synchronisations)
+        void *stv = nullptr;
+        ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ZP_TRY(zpi_pinned(ctx, (size_t)(total + (u64)nq) * 8, &stv));
+        u64 *st = (u64 *)stv;
+        memcpy(st, h_idx, (size_t)nq * 8);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const u64 *)d_cols, (u64)M, (int)W, (const u64 *)st, (int)nq, st + nq);
+        ZP_HIP(ctx, hipGetLastError());
+        ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(h_out, st + nq, (size_t)total * 8);
+        return ZP_OK;
+    }
     ZP_TRY(zpi_scratch(ctx, 3, (size_t)nq * (W + 1), &d));
     ZP_TRY(zpi_h2d_small(ctx, d, h_idx, (size_t)nq * 8));
-    const u64 total = (u64)nq * W;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const u64 *)d_cols, (u64)M, (int)W, d, (int)nq, d + nq);
     ZP_HIP(ctx, hipGetLastError());
@@ -490,6 +505,19 @@ int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, cons
     for (int i = 0; i < nq; i++) ZP_ARG(ctx, h_idx[i] < M, "leaf index out of range");
     u64 *d = nullptr;
     const u64 total = (u64)nq * depth * 4;
+    if ((total + (u64)nq) * 8 <= ZP_SMALL_COPY) {      // as zp_gather_rows: through the staging buffer, one launch
+        void *stv = nullptr;
+        ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ZP_TRY(zpi_pinned(ctx, (size_t)(total + (u64)nq) * 8, &stv));
+        u64 *st = (u64 *)stv;
+        memcpy(st, h_idx, (size_t)nq * 8);
+        hipLaunchKernelGGL(merkle_paths_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const u64 *)d_tree, (u64)M, depth, (const u64 *)st, (int)nq, st + nq);
+        ZP_HIP(ctx, hipGetLastError());
+        ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(h_paths, st + nq, (size_t)total * 8);
+        return ZP_OK;
+    }
     ZP_TRY(zpi_scratch(ctx, 3, (size_t)nq + total, &d));
     ZP_TRY(zpi_h2d_small(ctx, d, h_idx, (size_t)nq * 8));
     hipLaunchKernelGGL(merkle_paths_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
