@@ -184,6 +184,7 @@ void zpi_sha256(const uint8_t *data, size_t len, uint8_t *out32);
 void zpi_g16_cache_free(zp_ctx *ctx);
 int32_t zpi_r1cs_poseidon17(zp_ctx *ctx, const u64 *d_inst, size_t i0, size_t count, u64 *d_w, unsigned char *d_set, u64 *d_a, u64 *d_b, u64 *d_c,
                             unsigned long long *d_flags, int *rp_out);
+int32_t zpi_merkle16_levels_bn254(zp_ctx *ctx, u64 *d_tree, size_t n);   // the levels above n digests at the head of a 16-ary tree buffer (csrc/poseidon_bn254.hip)
 struct zp_comm;
 zp_ctx *zpi_comm_ctx(const zp_comm *comm);      // the ctx a communicator was created on (csrc/comm.hip)
 int32_t zpi_comm_fail(zp_comm *comm, int32_t rc);   // rc != ZP_OK: kill the communicator (no peer waits for this rank); returns rc

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -35,7 +37,19 @@ struct P254Table {    // device tables of one instance, Montgomery form, 9 x u32
     u32 *d_rcb = nullptr;   // [t][9]       constants of the first full round after the partial rounds (+ the carried rest)
 };
 struct P254Dev { const u32 *rc, *mds, *pre, *a, *sp, *rcb; int rp; };
-P254Table g_tables[2];      // [0]: t = 3, [1]: t = 17  (per process; the tables are public constants)
+// Installed tables: per DEVICE (a single-process multi-GPU host has a ctx per GPU), [0]: t = 3, [1]: t = 17; public constants, shared by
+// every ctx of the device.  A published table is never changed or freed: installing the same constants again is a no-op (the ranks of a
+// sharded proof all install before they prove), installing different ones publishes a new table and retires the old one, which a kernel
+// of another ctx may still be reading (a few hundred KiB per retired table; only tests install twice).
+constexpr int P254_MAX_DEV = 64;
+const P254Table *g_tables[P254_MAX_DEV][2];
+std::vector<u32> g_installed[P254_MAX_DEV][2];      // rc | mds as installed (Montgomery words): what "the same constants" is compared with
+std::mutex g_tables_mu;
+const P254Table *table_of(const zp_ctx *ctx, int k) {
+    if (ctx->device < 0 || ctx->device >= P254_MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    return g_tables[ctx->device][k];
+}
 
 __device__ __forceinline__ fr fr_load(const u32 *p) {
     fr r;
@@ -532,10 +546,10 @@ __global__ void __launch_bounds__(256) merkle16_paths_kernel(const u64 *__restri
     out[i] = c < n ? tree[(off + c) * 4 + word] : 0ULL;
 }
 
-int32_t table_for(zp_ctx *ctx, int t, P254Table **out) {
-    P254Table *tb = t == 3 ? &g_tables[0] : t == 17 ? &g_tables[1] : nullptr;
-    ZP_ARG(ctx, tb != nullptr, "Poseidon-BN254 width must be 3 or 17");
-    ZP_ARG(ctx, tb->d_rc != nullptr, "Poseidon-BN254 tables not installed (zp_set_poseidon_bn254)");
+int32_t table_for(zp_ctx *ctx, int t, const P254Table **out) {
+    ZP_ARG(ctx, t == 3 || t == 17, "Poseidon-BN254 width must be 3 or 17");
+    const P254Table *tb = table_of(ctx, t == 3 ? 0 : 1);
+    ZP_ARG(ctx, tb != nullptr && tb->d_rc != nullptr, "Poseidon-BN254 tables not installed on this device (zp_set_poseidon_bn254)");
     *out = tb;
     return ZP_OK;
 }
@@ -674,10 +688,15 @@ int32_t zp_set_poseidon_bn254(zp_ctx *ctx, int32_t t, int32_t rp, const uint64_t
         const fr m = fr_to_mont(fr_from_u64(w));
         memcpy((i < nrc ? rc.data() + 9 * i : md.data() + 9 * (i - nrc)), m.l, 36);
     }
-    P254Table *tb = t == 3 ? &g_tables[0] : &g_tables[1];
-    ZP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (u32 **pp : {&tb->d_rc, &tb->d_mds, &tb->d_pre, &tb->d_a, &tb->d_sp, &tb->d_rcb})
-        if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+    ZP_ARG(ctx, ctx->device >= 0 && ctx->device < P254_MAX_DEV, "device ordinal out of range");
+    std::vector<u32> key(rc);
+    key.insert(key.end(), md.begin(), md.end());
+    key.push_back((u32)rp);
+    std::lock_guard<std::mutex> lk(g_tables_mu);           // installs are serialised; readers take the published pointer (table_of)
+    const int slot = t == 3 ? 0 : 1;
+    if (g_tables[ctx->device][slot] && g_installed[ctx->device][slot] == key) return ZP_OK;      // the same constants: nothing to do
+    std::unique_ptr<P254Table> own(new P254Table());       // published below; dropped (its device buffers with it: a failed install is rare) on an error return
+    P254Table *tb = own.get();
     if (t == 17) {                                  // sparse form of the partial rounds
         FrVec frc(nrc), fm(nm), pre, a, sp, rcb;
         for (size_t i = 0; i < nrc; i++) memcpy(frc[i].l, &rc[i * 9], 36);
@@ -694,13 +713,15 @@ int32_t zp_set_poseidon_bn254(zp_ctx *ctx, int32_t t, int32_t rp, const uint64_t
     ZP_HIP(ctx, hipMemcpy(tb->d_mds, md.data(), md.size() * 4, hipMemcpyHostToDevice));
     tb->t = t;
     tb->rp = rp;
+    g_tables[ctx->device][slot] = own.release();                   // (the table it replaces stays allocated: see g_tables)
+    g_installed[ctx->device][slot] = std::move(key);
     return ZP_OK;
 }
 
 int32_t zp_poseidon_bn254_perm(zp_ctx *ctx, uint64_t *d_states, size_t count, int32_t t) {
     if (!ctx) return ZP_ERR_ARG;
     ZpStage stage_(ctx, "poseidon_bn254_perm");
-    P254Table *tb;
+    const P254Table *tb;
     ZP_TRY(table_for(ctx, t, &tb));
     if (count == 0) return ZP_OK;
     ZP_ARG(ctx, d_states != nullptr, "null device pointer");
@@ -730,7 +751,7 @@ int32_t zp_poseidon_bn254_sponge_caps(zp_ctx *ctx, uint64_t *h_state, const uint
                                       uint64_t *h_caps) {
     if (!ctx) return ZP_ERR_ARG;
     ZpStage stage_(ctx, "poseidon_bn254_sponge");
-    P254Table *tb;
+    const P254Table *tb;
     ZP_TRY(table_for(ctx, 17, &tb));
     ZP_ARG(ctx, h_state && h_rates && (h_blocks || nblocks == 0), "null pointer");
     ZP_ARG(ctx, nblocks <= 65536 && extra <= 65536, "too many blocks");
@@ -762,7 +783,7 @@ size_t zp_merkle16_nodes(size_t M) {
 int32_t zp_merkle16_commit_bn254(zp_ctx *ctx, const uint64_t *d_cols, size_t M, int32_t W, uint64_t *d_tree) {
     if (!ctx) return ZP_ERR_ARG;
     ZpStage stage_(ctx, "merkle16_commit_bn254");
-    P254Table *tb;
+    const P254Table *tb;
     ZP_TRY(table_for(ctx, 17, &tb));
     ZP_ARG(ctx, d_cols && d_tree && M >= 1 && W >= 1, "bad arguments");
     const size_t bulk = (size_t)bulk_threshold(ctx);
@@ -773,20 +794,7 @@ int32_t zp_merkle16_commit_bn254(zp_ctx *ctx, const uint64_t *d_cols, size_t M, 
         hipLaunchKernelGGL(merkle16_leaves_kernel, dim3((unsigned)((M + 2) / 3)), dim3(64), 0, ctx->stream, (const u64 *)d_cols, M, (int)W,
                            (u64 *)d_tree, dev_of(tb));
     ZP_HIP(ctx, hipGetLastError());
-    size_t n = M, off = 0;
-    while (n > 1) {
-        const size_t nn = (n + 15) / 16;
-        if (nn >= bulk)
-            hipLaunchKernelGGL(p254_bulk_kernel<2>, dim3((unsigned)((nn + 63) / 64)), dim3(64), 0, ctx->stream, (const u64 *)d_tree + off * 4, n, 0,
-                               (u64 *)d_tree + (off + n) * 4, nn, dev_of(tb));
-        else
-            hipLaunchKernelGGL(merkle16_level_kernel, dim3((unsigned)((nn + 2) / 3)), dim3(64), 0, ctx->stream, (const u64 *)d_tree + off * 4, n,
-                               (u64 *)d_tree + (off + n) * 4, nn, dev_of(tb));
-        ZP_HIP(ctx, hipGetLastError());
-        off += n;
-        n = nn;
-    }
-    return ZP_OK;
+    return zpi_merkle16_levels_bn254(ctx, (u64 *)d_tree, M);
 }
 
 // opening of leaf idx: for every level the 16 digests of the group the path passes through (the verifier re-hashes the
@@ -837,12 +845,34 @@ int32_t zp_merkle16_open_batch_bn254(zp_ctx *ctx, const uint64_t *d_tree, size_t
 
 }  // extern "C"
 
+// the levels above n digests that already lie at the head of d_tree (u64[zp_merkle16_nodes(n)][4]): what zp_merkle16_commit_bn254 runs after its
+// leaves, and what a row-sharded commitment runs on the all-gathered sub-tree digests (csrc/prove.hip: shard_commit_bn)
+int32_t zpi_merkle16_levels_bn254(zp_ctx *ctx, u64 *d_tree, size_t n) {
+    const P254Table *tb;
+    ZP_TRY(table_for(ctx, 17, &tb));
+    const size_t bulk = (size_t)bulk_threshold(ctx);
+    size_t off = 0;
+    while (n > 1) {
+        const size_t nn = (n + 15) / 16;
+        if (nn >= bulk)
+            hipLaunchKernelGGL(p254_bulk_kernel<2>, dim3((unsigned)((nn + 63) / 64)), dim3(64), 0, ctx->stream, (const u64 *)d_tree + off * 4, n, 0,
+                               (u64 *)d_tree + (off + n) * 4, nn, dev_of(tb));
+        else
+            hipLaunchKernelGGL(merkle16_level_kernel, dim3((unsigned)((nn + 2) / 3)), dim3(64), 0, ctx->stream, (const u64 *)d_tree + off * 4, n,
+                               (u64 *)d_tree + (off + n) * 4, nn, dev_of(tb));
+        ZP_HIP(ctx, hipGetLastError());
+        off += n;
+        n = nn;
+    }
+    return ZP_OK;
+}
+
 // csrc/r1cs.hip: the instances [i0, i0 + count) of the width-17 gadget (d_inst: the instance table of a circuit blob in HBM); the t = 17 tables
 // must be installed.  Template numbers checked by the caller: 17 inputs, 8 * 17 + rp S-boxes -> 3 (8 * 17 + rp) + 1 internal wires and rows.
 int32_t zpi_r1cs_poseidon17(zp_ctx *ctx, const u64 *d_inst, size_t i0, size_t count, u64 *d_w, unsigned char *d_set, u64 *d_a, u64 *d_b, u64 *d_c,
                             unsigned long long *d_flags, int *rp_out) {
-    const P254Table *tb = &g_tables[1];
-    ZP_ARG(ctx, tb->t == 17 && tb->d_rc && tb->d_mds, "the width-17 Poseidon-BN254 tables are not installed (zp_set_poseidon_bn254)");
+    const P254Table *tb = table_of(ctx, 1);
+    ZP_ARG(ctx, tb && tb->t == 17 && tb->d_rc && tb->d_mds, "the width-17 Poseidon-BN254 tables are not installed (zp_set_poseidon_bn254)");
     if (rp_out) *rp_out = tb->rp;
     if (count == 0) return ZP_OK;
     hipLaunchKernelGGL(r1cs_poseidon17_kernel, dim3((unsigned)((count + 2) / 3)), dim3(64), 0, ctx->stream, d_inst, i0, count, d_w, d_set, d_a, d_b, d_c, d_flags,

@@ -189,6 +189,30 @@ struct Trees {
     }
 };
 
+// the binary openings record of a BN128-mode proof ("PZOPEN02": zp_stark_openings documents the layout), kept on the ctx.  trees: trace,
+// quotient, [stage 2], FRI layers
+struct TreeOut { size_t width, rows; const u64 *root; const std::vector<u64> *vals, *paths; size_t pw; };
+void openings_record(zp_ctx *ctx, const Transcript &tr, const std::vector<u64> &qidx, int logm, const std::vector<TreeOut> &trees) {
+    std::vector<u64> &rec = ctx->last_openings;
+    rec.clear();
+    rec.insert(rec.end(), {0x32304e45504f5a50ULL /* "PZOPEN02" */, (u64)qidx.size(), (u64)trees.size(), (u64)logm});
+    for (const TreeOut &t : trees) rec.insert(rec.end(), {(u64)t.width, (u64)t.rows, (u64)Trees::levels16(t.rows)});
+    for (const TreeOut &t : trees) rec.insert(rec.end(), t.root, t.root + 4);
+    for (size_t i = 0; i < qidx.size(); i++) {
+        rec.push_back(qidx[i]);
+        for (const TreeOut &t : trees) {
+            rec.insert(rec.end(), t.vals->begin() + i * t.width, t.vals->begin() + (i + 1) * t.width);
+            rec.insert(rec.end(), t.paths->begin() + i * t.pw, t.paths->begin() + (i + 1) * t.pw);
+        }
+    }
+    // the transcript (round 5: the wrap circuit hashes it too): every absorbed block, then the rate elements the indices were read from
+    rec.push_back((u64)(tr.log_blocks.size() / 64));
+    rec.push_back((u64)(tr.last_rates.size() / 64));
+    rec.insert(rec.end(), tr.log_blocks.begin(), tr.log_blocks.end());
+    rec.insert(rec.end(), tr.last_rates.begin(), tr.last_rates.end());
+    rec.insert(rec.end(), tr.log_caps.begin(), tr.log_caps.end());         // one per permutation: n_blocks + (n_rates - 1)
+}
+
 // Device buffers of one proof.  They come from, and go back to, a per-ctx pool keyed by size: everything runs on the ctx
 // stream, so a buffer handed out again is only touched by work enqueued after its previous user.
 #define PROVE_POOL_CAP ((size_t)8 << 30)    /* per ctx: a 2^20 x 76 proof keeps ~3 GiB; 8 proving ctxs share one 288 GB GPU */
@@ -786,33 +810,10 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     }
 
     if (bn) {       // the same openings in binary, for the Groth16 wrap's witness (zp_stark_openings -> zp_wrap_assign): no text round trip
-        std::vector<u64> &rec = ctx->last_openings;
-        rec.clear();
-        const size_t ntr = 2 + (n_s2 ? 1 : 0) + layers.size();
-        rec.insert(rec.end(), {0x32304e45504f5a50ULL /* "PZOPEN02" */, (u64)nq, (u64)ntr, (u64)logm});
-        auto shape = [&](size_t width, size_t rows) { rec.insert(rec.end(), {(u64)width, (u64)rows, (u64)Trees::levels16(rows)}); };
-        shape(Wtg, Mt); shape(Wqg, Mq);
-        if (n_s2) shape(W2g, M2);
-        for (size_t li = 0; li < layers.size(); li++) shape(fo[li].width, fo[li].m);
-        rec.insert(rec.end(), root1, root1 + 4); rec.insert(rec.end(), rootq, rootq + 4);
-        if (n_s2) rec.insert(rec.end(), root2, root2 + 4);
-        for (size_t li = 0; li < layers.size(); li++) rec.insert(rec.end(), layers[li].root, layers[li].root + 4);
-        for (size_t i = 0; i < nq; i++) {
-            rec.push_back(qidx[i]);
-            auto put = [&](const std::vector<u64> &v, size_t w, const std::vector<u64> &p, size_t pw) {
-                rec.insert(rec.end(), v.begin() + i * w, v.begin() + (i + 1) * w);
-                rec.insert(rec.end(), p.begin() + i * pw, p.begin() + (i + 1) * pw);
-            };
-            put(v_tr, Wtg, p_tr, pwt); put(v_q, Wqg, p_q, pwq);
-            if (n_s2) put(v_s2, W2g, p_s2, pw2);
-            for (size_t li = 0; li < layers.size(); li++) put(fo[li].vals, fo[li].width, fo[li].paths, fo[li].pw);
-        }
-        // the transcript (round 5: the wrap circuit hashes it too): every absorbed block, then the rate elements the indices were read from
-        rec.push_back((u64)(tr.log_blocks.size() / 64));
-        rec.push_back((u64)(tr.last_rates.size() / 64));
-        rec.insert(rec.end(), tr.log_blocks.begin(), tr.log_blocks.end());
-        rec.insert(rec.end(), tr.last_rates.begin(), tr.last_rates.end());
-        rec.insert(rec.end(), tr.log_caps.begin(), tr.log_caps.end());         // one per permutation: n_blocks + (n_rates - 1)
+        std::vector<TreeOut> trees = {{Wtg, Mt, root1, &v_tr, &p_tr, pwt}, {Wqg, Mq, rootq, &v_q, &p_q, pwq}};
+        if (n_s2) trees.push_back({W2g, M2, root2, &v_s2, &p_s2, pw2});
+        for (size_t li = 0; li < layers.size(); li++) trees.push_back({fo[li].width, fo[li].m, layers[li].root, &fo[li].vals, &fo[li].paths, fo[li].pw});
+        openings_record(ctx, tr, qidx, logm, trees);
     }
 
     mark("queries opened");
@@ -985,6 +986,27 @@ int32_t shard_commit(zp_comm *comm, zp_ctx *ctx, DevBufs &dev, const u64 *rows, 
     return ZP_OK;
 }
 
+// BN128 mode (16-ary Poseidon-BN254 trees), one row per leaf: the local tree over my nloc = 16^h c rows holds the global tree's nodes of
+// levels 0..h under my rows (a group of 16 nodes of level k < h covers 16^(k+1) aligned rows: inside one shard); the c nodes of level h go
+// through ONE all-gather and every rank finishes the few levels above them (`top`: a 16-ary tree whose "leaves" are the G c digests)
+struct ShardTopBn {
+    u64 *ltree = nullptr, *top = nullptr;    // device: local tree (zp_merkle16_nodes(nloc) nodes), top tree (zp_merkle16_nodes(G c) nodes)
+    size_t h = 0, ntop = 0;                  // local levels that are global levels; nodes of level h in the whole tree
+    u64 root[4];
+};
+int32_t shard_commit_bn(zp_comm *comm, zp_ctx *ctx, DevBufs &dev, const u64 *rows, size_t nloc, int Wc, int G, ShardTopBn *out) {
+    size_t h = 0, c = nloc, off = 0;
+    while (c >= 16 && c % 16 == 0) { off += c; c /= 16; h++; }
+    out->h = h;
+    out->ntop = (size_t)G * c;
+    PV_TRY(dev.alloc(zp_merkle16_nodes(nloc) * 4, &out->ltree));
+    PV_TRY(dev.alloc(zp_merkle16_nodes(out->ntop) * 4, &out->top));
+    PV_TRY(zp_merkle16_commit_bn254(ctx, (const uint64_t *)rows, nloc, Wc, (uint64_t *)out->ltree));
+    PV_TRY(zp_comm_all_gather(comm, (const uint64_t *)(out->ltree + off * 4), (uint64_t *)out->top, c * 4));
+    PV_TRY(zpi_merkle16_levels_bn254(ctx, out->top, out->ntop));
+    return zp_d2h(ctx, out->root, out->top + (zp_merkle16_nodes(out->ntop) - 1) * 4, 32);
+}
+
 // [G][C][nloc] (what an all-gather of [C][nloc] row shards delivers) -> [C][G * nloc]
 int32_t shard_join(zp_ctx *ctx, const u64 *gathered, u64 *full, int C, size_t nloc, int G) {
     for (int h = 0; h < G; h++)
@@ -995,11 +1017,10 @@ int32_t shard_join(zp_ctx *ctx, const u64 *gathered, u64 *full, int C, size_t nl
 
 int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, const uint64_t *h_program, size_t program_words,
                            const uint64_t *d_trace, size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb,
-                           int32_t fri_logf, int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
-    ZpStage stage_(ctx, "stark_prove_sharded");
-    const bool bn = false;
+                           int32_t fri_logf, int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, bool bn, char **out_json, size_t *out_len) {
+    ZpStage stage_(ctx, bn ? "stark_prove_sharded_bn128" : "stark_prove_sharded");
     const int G = zp_comm_world(comm), rank = zp_comm_rank(comm);
-    ZP_ARG(ctx, air_name && h_program && d_trace && out_json && out_len && (h_pubs || n_pubs == 0), "null pointer");
+    ZP_ARG(ctx, air_name && h_program && out_json && out_len && (h_pubs || n_pubs == 0), "null pointer");
     {
         const size_t nl = strlen(air_name);
         bool ok = nl >= 1 && nl <= 64;
@@ -1035,10 +1056,14 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     ZP_ARG(ctx, w2sum == W2, "stage-2 width does not match its table");
     const int logm = logn + logb;
     const size_t N = (size_t)1 << logn, M = (size_t)1 << logm, Wt = W + W2, b = (size_t)1 << logb;
-    ZP_ARG(ctx, G >= 1 && W % (size_t)G == 0 && M % (size_t)G == 0, "trace columns and domain rows must split evenly over the ranks");
-    const size_t wl = W / G, nloc = M / G, r0 = (size_t)rank * nloc;
+    ZP_ARG(ctx, G >= 1 && M % (size_t)G == 0, "the domain rows must split evenly over the ranks");
+    // columns: rank r owns [r wl, min((r + 1) wl, W)), wl = ceil(W / G) -- the last ranks may hold fewer (a 47-column verifier AIR over
+    // 8 ranks: 6,6,6,6,6,6,6,5) or none; the exchange moves wl columns per rank, the missing ones as zeros (they land behind column W)
+    const size_t wl = (W + (size_t)G - 1) / (size_t)G, nloc = M / G, r0 = (size_t)rank * nloc;
+    const size_t wr = (size_t)rank * wl >= W ? 0 : (W - (size_t)rank * wl < wl ? W - (size_t)rank * wl : wl);      // my real columns
+    ZP_ARG(ctx, d_trace || wr == 0, "null pointer");
     ZP_ARG(ctx, nloc >= b && nloc % b == 0 && nloc >= 2, "row shards must hold whole blow-up groups");
-    ZP_ARG(ctx, trace_words == (wl << logn), "trace_words must be (W / world) * 2^logn: this rank's columns");
+    ZP_ARG(ctx, trace_words == (wr << logn), "trace_words must be (this rank's columns) * 2^logn: ceil(W / world) columns per rank, the tail ranks fewer");
     const u64 shift = ctx->coset_shift, root32 = ctx->root32;
     const u64 wN = gl_root(root32, logn);
     DevBufs dev(ctx);
@@ -1061,15 +1086,24 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
         tr.absorb(first);
     } else {            // long public vectors enter through their commitment (replicated: a few thousand permutations at most)
         tr.absorb(first);
-        size_t Mp = 2;
-        while (Mp * 8 < (size_t)n_pubs) Mp <<= 1;
-        std::vector<u64> mat(Mp * 8, 0);
-        for (int i = 0; i < n_pubs; i++) mat[i] = h_pubs[i];
+        size_t Mp;
+        std::vector<u64> mat;
+        if (!bn) {
+            Mp = 2;
+            while (Mp * 8 < (size_t)n_pubs) Mp <<= 1;
+            mat.assign(Mp * 8, 0);
+            for (int i = 0; i < n_pubs; i++) mat[i] = h_pubs[i];
+        } else {        // BN128 mode: rows of 48 values, column-major, 16-ary tree (as in prove_impl)
+            Mp = ((size_t)n_pubs + 47) / 48;
+            mat.assign(Mp * 48, 0);
+            for (int i = 0; i < n_pubs; i++) mat[(size_t)(i % 48) * Mp + (size_t)(i / 48)] = h_pubs[i];
+        }
         u64 *dmat, *dtree;
         PV_TRY(dev.alloc(mat.size(), &dmat));
         PV_TRY(dev.alloc(T.tree_words(Mp), &dtree));
         PV_TRY(zp_h2d(ctx, dmat, mat.data(), mat.size() * 8));
-        PV_TRY(zp_merkle_commit_rows(ctx, (const uint64_t *)dmat, Mp, 8, (uint64_t *)dtree));
+        if (!bn) PV_TRY(zp_merkle_commit_rows(ctx, (const uint64_t *)dmat, Mp, 8, (uint64_t *)dtree));
+        else PV_TRY(T.commit(dmat, Mp, 48, dtree));
         u64 rootp[4];
         PV_TRY(T.root(dtree, Mp, rootp));
         dev.release(dmat);
@@ -1078,23 +1112,47 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     }
 
     // 1. trace: LDE of my columns, ONE exchange columns -> rows, local subtree, sub-roots
-    u64 *ext, *tree1;
+    u64 *ext, *tree1 = nullptr;
     ShardTop top1, top2, topq;
-    PV_TRY(dev.alloc(Wt * nloc, &ext));            // [Wt][nloc]: ALL columns (trace, then stage 2), my rows
+    // BN128 mode (the last STARK before the Groth16 wrap, zp_stark_prove_bn128's text): a leaf of a narrow tree holds 2^g rows i, i + M', ...
+    // (prove_impl: rows_per_leaf_log) -- rows of DIFFERENT shards.  The trace tree is the sharded one and must have one row per leaf
+    // (W > 28: the 47-column verifier AIR this mode exists for); the stage-2 and quotient trees are narrow, their columns are whole on
+    // every rank anyway (stage 2 is replicated, the quotient is gathered for its out-of-domain evaluation), and 2^g rows per leaf make
+    // them M / 2^g permutations against the trace tree's M: they are committed and opened replicated, exactly as prove_impl does
+    auto rows_per_leaf_log = [&](size_t width) {
+        int g = 0;
+        if (bn && width)
+            while ((width << (g + 1)) <= 56 && g + 1 <= logm - 4) g++;
+        return g;
+    };
+    ZP_ARG(ctx, !bn || rows_per_leaf_log(W) == 0, "BN128 mode shards the trace tree by rows: it needs one row per leaf (more than 28 trace columns)");
+    ShardTopBn bt1;
+    u64 root1[4], root2[4] = {0, 0, 0, 0}, rootq[4];
+    PV_TRY(dev.alloc((Wt > (size_t)G * wl ? Wt : (size_t)G * wl) * nloc, &ext));   // [Wt][nloc]: ALL columns (trace, then stage 2), my rows (room for the exchange's zero columns)
     // (no coefficient buffer since round 5: my columns' out-of-domain evaluations come from d_trace itself, zp_ood_eval on the trace domain)
     {
         u64 *extc, *pack;
         PV_TRY(dev.alloc(wl * M, &extc));
         PV_TRY(dev.alloc(wl * M, &pack));
-        PV_TRY(zp_lde(ctx, d_trace, (uint64_t *)extc, nullptr, logn, logb, (int32_t)wl, shift));
+        if (wr < wl) PV_TRY(zp_dev_zero(ctx, extc + wr * M, (wl - wr) * M * 8));
+        if (wr) PV_TRY(zp_lde(ctx, d_trace, (uint64_t *)extc, nullptr, logn, logb, (int32_t)wr, shift));
         PV_TRY(zp_exchange_columns_to_rows(comm, (const uint64_t *)extc, wl, M, (uint64_t *)pack, (uint64_t *)ext));
         PV_TRY(zp_sync(ctx));
         dev.release(extc);
         dev.release(pack);
     }
-    PV_TRY(shard_commit(comm, ctx, dev, ext, nloc, (int)W, G, &tree1, &top1));
-    tr.absorb_root(top1.root);
+    if (bn) {
+        PV_TRY(shard_commit_bn(comm, ctx, dev, ext, nloc, (int)W, G, &bt1));
+        memcpy(root1, bt1.root, 32);
+    } else {
+        PV_TRY(shard_commit(comm, ctx, dev, ext, nloc, (int)W, G, &tree1, &top1));
+        memcpy(root1, top1.root, 32);
+    }
+    tr.absorb_root(root1);
     std::vector<u64> pubchal(h_pubs, h_pubs + n_pubs);
+    const int g2 = rows_per_leaf_log(W2);
+    const size_t M2 = M >> g2, W2g = W2 << g2;
+    u64 *ext2_kept = nullptr;                     // BN128 mode: the stage-2 extension, whole (its tree's leaves mix rows of all shards)
     u64 *tree2 = nullptr, *s2 = nullptr;          // s2: the stage-2 columns on the trace domain (replicated), kept for their out-of-domain evaluations
     if (n_s2) {
         const e3 chal = tr.challenge();
@@ -1127,9 +1185,17 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
         ZP_HIP(ctx, hipMemcpy2DAsync(ext + W * nloc, nloc * 8, ext2 + r0, M * 8, nloc * 8, W2, hipMemcpyDeviceToDevice, ctx->stream));
         PV_TRY(zp_sync(ctx));
         dev.release(colb);
-        dev.release(ext2);
-        PV_TRY(shard_commit(comm, ctx, dev, ext + W * nloc, nloc, (int)W2, G, &tree2, &top2));
-        tr.absorb_root(top2.root);
+        if (bn) {
+            ext2_kept = ext2;
+            PV_TRY(dev.alloc(T.tree_words(M2), &tree2));
+            PV_TRY(T.commit(ext2, M2, (int)W2g, tree2));
+            PV_TRY(T.root(tree2, M2, root2));
+        } else {
+            dev.release(ext2);
+            PV_TRY(shard_commit(comm, ctx, dev, ext + W * nloc, nloc, (int)W2, G, &tree2, &top2));
+            memcpy(root2, top2.root, 32);
+        }
+        tr.absorb_root(root2);
         for (int c = 0; c < 3; c++) pubchal.push_back(chal.c[c]);
     }
     const e3 alpha = tr.challenge();
@@ -1220,8 +1286,17 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
         q_logn = logn;
         Wq = 3 * Q;
     }
-    PV_TRY(shard_commit(comm, ctx, dev, dq_rows, nloc, (int)Wq, G, &treeq, &topq));
-    tr.absorb_root(topq.root);
+    const int qg = rows_per_leaf_log(Wq);
+    const size_t Mq = M >> qg, Wqg = Wq << qg;
+    if (bn) {
+        PV_TRY(dev.alloc(T.tree_words(Mq), &treeq));
+        PV_TRY(T.commit(dq_whole, Mq, (int)Wqg, treeq));
+        PV_TRY(T.root(treeq, Mq, rootq));
+    } else {
+        PV_TRY(shard_commit(comm, ctx, dev, dq_rows, nloc, (int)Wq, G, &treeq, &topq));
+        memcpy(rootq, topq.root, 32);
+    }
+    tr.absorb_root(rootq);
     const e3 zeta = tr.challenge();
     PV_TRY(tr.rc);
 
@@ -1230,8 +1305,8 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     const e3 zeta_w = e3_scale(zeta, wN);
     std::vector<u64> ev_all((Wt + Wq) * 3), ev_next(Wt * 3);
     {
-        std::vector<u64> mine(2 * wl * 3), all((size_t)G * 2 * wl * 3);
-        PV_TRY(zp_ood_eval(ctx, d_trace, N, 1, (int32_t)wl, logn, 1, (const uint64_t *)zeta.c, 1, (uint64_t *)mine.data(), (uint64_t *)(mine.data() + wl * 3)));
+        std::vector<u64> mine(2 * wl * 3, 0), all((size_t)G * 2 * wl * 3);
+        if (wr) PV_TRY(zp_ood_eval(ctx, d_trace, N, 1, (int32_t)wr, logn, 1, (const uint64_t *)zeta.c, 1, (uint64_t *)mine.data(), (uint64_t *)(mine.data() + wl * 3)));
         u64 *dmine, *dall;
         PV_TRY(dev.alloc(mine.size(), &dmine));
         PV_TRY(dev.alloc(all.size(), &dall));
@@ -1241,8 +1316,10 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
         dev.release(dmine);
         dev.release(dall);
         for (int h = 0; h < G; h++) {
-            memcpy(&ev_all[(size_t)h * wl * 3], &all[(size_t)h * 2 * wl * 3], wl * 24);
-            memcpy(&ev_next[(size_t)h * wl * 3], &all[(size_t)h * 2 * wl * 3 + wl * 3], wl * 24);
+            const size_t c0 = (size_t)h * wl, have = c0 >= W ? 0 : (W - c0 < wl ? W - c0 : wl);
+            if (!have) break;
+            memcpy(&ev_all[c0 * 3], &all[(size_t)h * 2 * wl * 3], have * 24);
+            memcpy(&ev_next[c0 * 3], &all[(size_t)h * 2 * wl * 3 + wl * 3], have * 24);
         }
     }
     if (W2) {
@@ -1254,7 +1331,7 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     PV_TRY(zp_ood_eval(ctx, (const uint64_t *)dq_whole, M, (size_t)1 << (logm - q_logn), (int32_t)Wq, q_logn, shift, (const uint64_t *)zeta.c, 0,
                        (uint64_t *)(ev_all.data() + Wt * 3), nullptr));
     PV_TRY(zp_sync(ctx));
-    dev.release(dq_whole);
+    if (!bn) dev.release(dq_whole);               // BN128 mode opens its queries from the whole columns
     tr.absorb(ev_all);
     tr.absorb(ev_next);
     const e3 gamma = tr.challenge();
@@ -1321,30 +1398,37 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     const size_t nq = (size_t)n_queries, depth = (size_t)logm;
     size_t dl = 0;
     while (((size_t)1 << dl) < nloc) dl++;
-    const size_t pw = depth * 4;
-    std::vector<u64> v_tr(nq * W), p_tr(nq * pw), v_s2(nq * W2), p_s2(n_s2 ? nq * pw : 0), v_q(nq * Wq), p_q(nq * pw);
+    // words of one path: Goldilocks mode `depth` digests; BN128 mode 16 digests per level of the 16-ary tree
+    const size_t pwt = bn ? Trees::levels16(M) * 64 : depth * 4, pw2 = bn ? T.path_words(M2) : depth * 4, pwq = bn ? T.path_words(Mq) : depth * 4;
+    const size_t ltw = bn ? bt1.h * 64 : dl * 4;          // ... of which the owner of the row supplies (the levels inside its sub-tree)
+    std::vector<u64> v_tr(nq * W), p_tr(nq * pwt), v_s2(nq * W2g), p_s2(n_s2 ? nq * pw2 : 0), v_q(nq * Wqg), p_q(nq * pwq);
     {
         std::vector<int> own;
         std::vector<u64> lidx;
         for (size_t i = 0; i < nq; i++)
             if (qidx[i] >= r0 && qidx[i] < r0 + nloc) { own.push_back((int)i); lidx.push_back(qidx[i] - r0); }
         const size_t no = own.size();
-        // layout of the reduced vector: per query [W | W2 | Wq values | dl*4 path words of each of the (2 or 3) trees]
-        const size_t ntree = n_s2 ? 3 : 2, per = W + W2 + Wq + ntree * dl * 4;
-        std::vector<u64> red(nq * per, 0), tv(no * (W > Wq ? (W > W2 ? W : W2) : (Wq > W2 ? Wq : W2))), tp(no * dl * 4);
+        // layout of the reduced vector: per query [W | W2 | Wq values | local path words of each of the (2 or 3) trees]; BN128 mode: the trace
+        // tree alone is sharded: [W values | local path words]
+        const size_t ntree = bn ? 1 : n_s2 ? 3 : 2, nval = bn ? W : W + W2 + Wq, per = nval + ntree * ltw;
+        const size_t lpw = bn ? Trees::levels16(nloc) * 64 : dl * 4;     // what the local tree's opening returns per query
+        std::vector<u64> red(nq * per, 0), tv(no * (W > Wq ? (W > W2 ? W : W2) : (Wq > W2 ? Wq : W2))), tp(no * lpw);
         auto fill = [&](const u64 *mat, size_t Wc, size_t voff, const u64 *tree, size_t poff) -> int32_t {
             if (!no) return ZP_OK;
             PV_TRY(zp_gather_rows(ctx, (const uint64_t *)mat, nloc, (int32_t)Wc, (const uint64_t *)lidx.data(), (int32_t)no, (uint64_t *)tv.data()));
-            PV_TRY(zp_merkle_open_batch(ctx, (const uint64_t *)tree, nloc, (const uint64_t *)lidx.data(), (int32_t)no, (uint64_t *)tp.data()));
+            if (bn) PV_TRY(zp_merkle16_open_batch_bn254(ctx, (const uint64_t *)tree, nloc, (const uint64_t *)lidx.data(), (int32_t)no, (uint64_t *)tp.data()));
+            else PV_TRY(zp_merkle_open_batch(ctx, (const uint64_t *)tree, nloc, (const uint64_t *)lidx.data(), (int32_t)no, (uint64_t *)tp.data()));
             for (size_t k = 0; k < no; k++) {
                 memcpy(&red[(size_t)own[k] * per + voff], &tv[k * Wc], Wc * 8);
-                memcpy(&red[(size_t)own[k] * per + W + W2 + Wq + poff], &tp[k * dl * 4], dl * 32);
+                memcpy(&red[(size_t)own[k] * per + nval + poff], &tp[k * lpw], ltw * 8);     // the first bt1.h levels / all dl levels
             }
             return ZP_OK;
         };
-        PV_TRY(fill(ext, W, 0, tree1, 0));
-        if (n_s2) PV_TRY(fill(ext + W * nloc, W2, W, tree2, dl * 4));
-        PV_TRY(fill(dq_rows, Wq, W + W2, treeq, (ntree - 1) * dl * 4));
+        PV_TRY(fill(ext, W, 0, bn ? bt1.ltree : tree1, 0));
+        if (!bn) {
+            if (n_s2) PV_TRY(fill(ext + W * nloc, W2, W, tree2, ltw));
+            PV_TRY(fill(dq_rows, Wq, W + W2, treeq, (ntree - 1) * ltw));
+        }
         u64 *dred;
         PV_TRY(dev.alloc(red.size(), &dred));
         PV_TRY(zp_h2d(ctx, dred, red.data(), red.size() * 8));
@@ -1353,22 +1437,46 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
         dev.release(dred);
         auto paths = [&](std::vector<u64> &dst, size_t poff, const ShardTop &top) {
             for (size_t i = 0; i < nq; i++) {
-                memcpy(&dst[i * pw], &red[i * per + W + W2 + Wq + poff], dl * 32);
+                memcpy(&dst[i * pwt], &red[i * per + nval + poff], dl * 32);
                 u64 node = qidx[i] >> dl;
                 for (size_t l = 0; l < top.levels.size(); l++) {         // the top of the path comes from the all-gathered sub-roots
-                    memcpy(&dst[i * pw + (dl + l) * 4], &top.levels[l][(size_t)(node ^ 1) * 4], 32);
+                    memcpy(&dst[i * pwt + (dl + l) * 4], &top.levels[l][(size_t)(node ^ 1) * 4], 32);
                     node >>= 1;
                 }
             }
         };
         for (size_t i = 0; i < nq; i++) {
             memcpy(&v_tr[i * W], &red[i * per], W * 8);
+            if (bn) continue;
             if (W2) memcpy(&v_s2[i * W2], &red[i * per + W], W2 * 8);
             memcpy(&v_q[i * Wq], &red[i * per + W + W2], Wq * 8);
         }
-        paths(p_tr, 0, top1);
-        if (n_s2) paths(p_s2, dl * 4, top2);
-        paths(p_q, (ntree - 1) * dl * 4, topq);
+        if (!bn) {
+            paths(p_tr, 0, top1);
+            if (n_s2) paths(p_s2, ltw, top2);
+            paths(p_q, (ntree - 1) * ltw, topq);
+        } else {
+            // trace: the levels above the shards from the replicated top tree (its "leaves" are the nodes of level h)
+            const size_t tlv = Trees::levels16(bt1.ntop);
+            ZP_ARG(ctx, bt1.h + tlv == Trees::levels16(M), "internal: levels of the sharded 16-ary tree do not add up");
+            std::vector<u64> tidx(nq), topp(nq * tlv * 64);
+            for (size_t i = 0; i < nq; i++) tidx[i] = qidx[i] >> (4 * bt1.h);
+            PV_TRY(zp_merkle16_open_batch_bn254(ctx, (const uint64_t *)bt1.top, bt1.ntop, (const uint64_t *)tidx.data(), n_queries, (uint64_t *)topp.data()));
+            for (size_t i = 0; i < nq; i++) {
+                memcpy(&p_tr[i * pwt], &red[i * per + nval], ltw * 8);
+                memcpy(&p_tr[i * pwt + ltw], &topp[i * tlv * 64], tlv * 64 * 8);
+            }
+            // stage 2 and quotient: replicated trees over whole columns, opened as prove_impl opens them
+            std::vector<u64> rows(nq);
+            if (n_s2) {
+                for (size_t i = 0; i < nq; i++) rows[i] = qidx[i] & (M2 - 1);
+                PV_TRY(zp_gather_rows(ctx, (const uint64_t *)ext2_kept, M2, (int32_t)W2g, (const uint64_t *)rows.data(), n_queries, (uint64_t *)v_s2.data()));
+                PV_TRY(T.open(tree2, M2, rows.data(), n_queries, p_s2.data()));
+            }
+            for (size_t i = 0; i < nq; i++) rows[i] = qidx[i] & (Mq - 1);
+            PV_TRY(zp_gather_rows(ctx, (const uint64_t *)dq_whole, Mq, (int32_t)Wqg, (const uint64_t *)rows.data(), n_queries, (uint64_t *)v_q.data()));
+            PV_TRY(T.open(treeq, Mq, rows.data(), n_queries, p_q.data()));
+        }
     }
     struct FriOpen { std::vector<u64> vals, paths; size_t width, depth, pw, m; };
     std::vector<FriOpen> fo(layers.size());
@@ -1389,7 +1497,14 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
         }
     }
 
-    // the proof text: exactly what zp_stark_prove writes
+    if (bn) {       // every rank keeps the binary openings record (zp_stark_openings), as zp_stark_prove_bn128 does
+        std::vector<TreeOut> trees = {{W, M, root1, &v_tr, &p_tr, pwt}, {Wqg, Mq, rootq, &v_q, &p_q, pwq}};
+        if (n_s2) trees.push_back({W2g, M2, root2, &v_s2, &p_s2, pw2});
+        for (size_t li = 0; li < layers.size(); li++) trees.push_back({fo[li].width, fo[li].m, layers[li].root, &fo[li].vals, &fo[li].paths, fo[li].pw});
+        openings_record(ctx, tr, qidx, logm, trees);
+    }
+
+    // the proof text: exactly what zp_stark_prove / zp_stark_prove_bn128 writes
     std::string s;
     s.reserve(nq * (Wt + Wq + 64) * 24 + (1 << 16));
     s += "{\"air\":\"";
@@ -1400,12 +1515,13 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     j_u64(s, (u64)logn); s += ",\"logb\":"; j_u64(s, (u64)logb); s += ",\"fri_logf\":"; j_u64(s, (u64)fri_logf);
     s += ",\"fri_final_log\":"; j_u64(s, (u64)fri_final_log); s += ",\"n_queries\":"; j_u64(s, (u64)n_queries);
     s += ",\"pow_bits\":"; j_u64(s, (u64)pow_bits);
+    if (bn) s += ",\"hash\":\"bn128\"";
     s += "},\"root32\":"; j_u64(s, root32);
     s += ",\"shift\":"; j_u64(s, shift);
     s += ",\"publics\":"; j_list(s, (const u64 *)h_pubs, (size_t)n_pubs);
-    s += ",\"roots\":{\"trace\":"; j_root(s, top1.root, bn);
-    s += ",\"quotient\":"; j_root(s, topq.root, bn);
-    if (n_s2) { s += ",\"stage2\":"; j_root(s, top2.root, bn); }
+    s += ",\"roots\":{\"trace\":"; j_root(s, root1, bn);
+    s += ",\"quotient\":"; j_root(s, rootq, bn);
+    if (n_s2) { s += ",\"stage2\":"; j_root(s, root2, bn); }
     s += "},\"evals\":{\"z\":"; j_e3list(s, ev_all);
     s += ",\"zw\":"; j_e3list(s, ev_next);
     s += "},\"fri\":{\"roots\":[";
@@ -1416,13 +1532,17 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     for (size_t i = 0; i < nq; i++) {
         if (i) s += ',';
         s += "{\"index\":"; j_u64(s, qidx[i]);
-        s += ",\"trace\":"; j_opening(s, &v_tr[i * W], W, &p_tr[i * pw], depth);
-        s += ",\"quotient\":"; j_opening(s, &v_q[i * Wq], Wq, &p_q[i * pw], depth);
-        if (n_s2) { s += ",\"stage2\":"; j_opening(s, &v_s2[i * W2], W2, &p_s2[i * pw], depth); }
+        auto opening = [&](const u64 *vals, size_t width, const u64 *path, size_t rows, size_t bin_depth) {
+            if (bn) j_opening_bn(s, vals, width, path, Trees::levels16(rows));
+            else j_opening(s, vals, width, path, bin_depth);
+        };
+        s += ",\"trace\":"; opening(&v_tr[i * W], W, &p_tr[i * pwt], M, depth);
+        s += ",\"quotient\":"; opening(&v_q[i * Wqg], Wqg, &p_q[i * pwq], Mq, depth);
+        if (n_s2) { s += ",\"stage2\":"; opening(&v_s2[i * W2g], W2g, &p_s2[i * pw2], M2, depth); }
         s += ",\"fri\":[";
         for (size_t li = 0; li < layers.size(); li++) {
             if (li) s += ',';
-            j_opening(s, &fo[li].vals[i * fo[li].width], fo[li].width, &fo[li].paths[i * fo[li].pw], fo[li].depth);
+            opening(&fo[li].vals[i * fo[li].width], fo[li].width, &fo[li].paths[i * fo[li].pw], fo[li].m, fo[li].depth);
         }
         s += "]}";
     }
@@ -1439,10 +1559,10 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
 
 }  // namespace
 
-extern "C" int32_t zp_stark_prove_sharded(zp_comm *comm, const char *air_name, const uint64_t *h_program, size_t program_words,
-                                          const uint64_t *d_trace_local, size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn,
-                                          int32_t logb, int32_t fri_logf, int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, char **out_json,
-                                          size_t *out_len) {
+namespace {
+int32_t prove_sharded_guarded(zp_comm *comm, bool bn, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace_local,
+                              size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf,
+                              int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
     if (!comm) return ZP_ERR_ARG;
     zp_ctx *ctx = zpi_comm_ctx(comm);
     if (out_json) *out_json = nullptr;
@@ -1451,7 +1571,7 @@ extern "C" int32_t zp_stark_prove_sharded(zp_comm *comm, const char *air_name, c
     // the next collective: zpi_comm_fail takes the communicator down so that they return ZP_ERR_COMM instead of waiting for ever.
     try {
         return zpi_comm_fail(comm, prove_sharded_impl(comm, ctx, air_name, h_program, program_words, d_trace_local, trace_words, h_pubs, n_pubs, logn, logb,
-                                                      fri_logf, fri_final_log, n_queries, pow_bits, out_json, out_len));
+                                                      fri_logf, fri_final_log, n_queries, pow_bits, bn, out_json, out_len));
     } catch (const std::bad_alloc &) {
         try { ctx->err = "out of host memory while building the proof"; } catch (...) {}
         return zpi_comm_fail(comm, ZP_ERR_NOMEM);
@@ -1461,4 +1581,24 @@ extern "C" int32_t zp_stark_prove_sharded(zp_comm *comm, const char *air_name, c
     } catch (...) {
         return zpi_comm_fail(comm, ZP_ERR_INTERNAL);
     }
+}
+}  // namespace
+
+extern "C" int32_t zp_stark_prove_sharded(zp_comm *comm, const char *air_name, const uint64_t *h_program, size_t program_words,
+                                          const uint64_t *d_trace_local, size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn,
+                                          int32_t logb, int32_t fri_logf, int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, char **out_json,
+                                          size_t *out_len) {
+    return prove_sharded_guarded(comm, false, air_name, h_program, program_words, d_trace_local, trace_words, h_pubs, n_pubs, logn, logb, fri_logf,
+                                 fri_final_log, n_queries, pow_bits, out_json, out_len);
+}
+
+// the sharded prover in BN128-hash mode: zp_stark_prove_bn128's text (and openings record, on every rank) from W/world columns per rank.
+// The trace tree is sharded by rows and must have one row per leaf (more than 28 trace columns: the verifier AIR of the final STARK);
+// zp_set_poseidon_bn254(ctx, 17, ...) on every rank's ctx.
+extern "C" int32_t zp_stark_prove_sharded_bn128(zp_comm *comm, const char *air_name, const uint64_t *h_program, size_t program_words,
+                                                const uint64_t *d_trace_local, size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs,
+                                                int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log, int32_t n_queries,
+                                                char **out_json, size_t *out_len) {
+    return prove_sharded_guarded(comm, true, air_name, h_program, program_words, d_trace_local, trace_words, h_pubs, n_pubs, logn, logb, fri_logf,
+                                 fri_final_log, n_queries, 0, out_json, out_len);
 }

@@ -142,6 +142,8 @@ SIGNATURES = {
     "zp_comm_create_local": (C.c_int32, [_vp, C.c_int32, _vp, C.POINTER(_vp)]),
     "zp_stark_prove_sharded": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "zp_stark_prove_sharded_bn128": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                 C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "zp_exchange_columns_to_rows": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp]),
     "zp_ntt_sharded": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32]),
     "zp_merkle_commit_sharded": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32, _vp, _u64p]),
@@ -462,15 +464,25 @@ class Comm:
     def all_reduce_sum(self, d_buf, words):
         self.prover._chk(self.prover.lib.zp_comm_all_reduce_sum(self.h, _ptr(d_buf), words))
 
-    def stark_prove_sharded(self, air_name, program, d_trace_local, pubs, logn, logb, fri_logf, fri_final_log, n_queries, pow_bits):
-        """zp_stark_prove_sharded: this rank's W/world columns in, the whole proof text out (the same on every rank)"""
+    def my_columns(self, width):
+        """the trace columns of this rank, (first, count): ceil(width / world) per rank, the tail ranks fewer (include/zeth_prover.h)"""
+        wl = -(-width // self.world)
+        first = min(self.rank * wl, width)
+        return first, min(wl, width - first)
+
+    def stark_prove_sharded(self, air_name, program, d_trace_local, pubs, logn, logb, fri_logf, fri_final_log, n_queries, pow_bits=0, bn128=False):
+        """zp_stark_prove_sharded (bn128: zp_stark_prove_sharded_bn128): this rank's columns in, the whole proof text out (the same on every rank)"""
         prog = np.ascontiguousarray(np.asarray(program, dtype=np.uint64))
         pb = np.ascontiguousarray(np.asarray(list(pubs) + [0], dtype=np.uint64))
         out, n = C.c_void_p(), C.c_size_t(0)
-        words = d_trace_local.n if isinstance(d_trace_local, DeviceBuffer) else (int(prog[1]) // self.world) << logn
-        self.prover._chk(self.prover.lib.zp_stark_prove_sharded(self.h, air_name.encode(), prog.ctypes.data, prog.size, _ptr(d_trace_local), words,
-                                                                pb.ctypes.data, len(pubs), logn, logb, fri_logf, fri_final_log, n_queries, pow_bits,
-                                                                C.byref(out), C.byref(n)))
+        words = d_trace_local.n if isinstance(d_trace_local, DeviceBuffer) else self.my_columns(int(prog[1]))[1] << logn
+        head = (self.h, air_name.encode(), prog.ctypes.data, prog.size, _ptr(d_trace_local), words, pb.ctypes.data, len(pubs), logn, logb, fri_logf,
+                fri_final_log, n_queries)
+        if bn128:
+            assert pow_bits == 0
+            self.prover._chk(self.prover.lib.zp_stark_prove_sharded_bn128(*head, C.byref(out), C.byref(n)))
+        else:
+            self.prover._chk(self.prover.lib.zp_stark_prove_sharded(*head, pow_bits, C.byref(out), C.byref(n)))
         try:
             return C.string_at(out.value, n.value).decode()
         finally:

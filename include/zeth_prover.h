@@ -457,13 +457,21 @@ int32_t zp_sha256(const uint8_t *data, size_t len, uint8_t *out32);
  * group (zp_comm_group_create(world)), then every rank's zp_comm_create_local(ctx, rank, group); its collectives are device-to-
  * device copies around a thread barrier.  RCCL refuses two ranks on one device, so this is how the multi-rank logic of the sharded
  * entry points is exercised on a one-GPU box; it is also a transport for a single-process multi-GPU host.
- *   zp_stark_prove_sharded      : ONE chunk STARK over the ranks of a communicator: every rank passes ITS W/world trace columns
- *                                 (d_trace_local u64[W/world][2^logn], trace_words = (W/world) << logn; rank r owns columns
- *                                 [r W/world, (r+1) W/world)), all other arguments as zp_stark_prove, identical on every rank;
+ *   zp_stark_prove_sharded      : ONE chunk STARK over the ranks of a communicator: every rank passes ITS trace columns: with
+ *                                 wl = ceil(W / world), rank r owns columns [r wl, min((r+1) wl, W)) (d_trace_local u64[its
+ *                                 columns][2^logn], trace_words = columns << logn; W need not divide: the tail ranks hold fewer
+ *                                 columns, or none), all other arguments as zp_stark_prove, identical on every rank;
  *                                 every rank receives the same proof text, byte for byte what zp_stark_prove writes for the whole
  *                                 trace on one GPU.  Column-sharded: LDE, out-of-domain evaluations; row-sharded: the three
  *                                 commitments, the constraint quotient (with a blow-up halo), the DEEP quotient; replicated: the
  *                                 stage-2 columns, FRI.  Goldilocks-hash mode.  Collective: every rank must call it.
+ *   zp_stark_prove_sharded_bn128: the same in BN128-hash mode (the last STARK before the Groth16 wrap, src/prover/provider.rs:431-
+ *                                 451): zp_stark_prove_bn128's text, byte for byte, on every rank, and its openings record
+ *                                 (zp_stark_openings) on every rank's ctx.  The 16-ary trace tree is sharded by rows (local
+ *                                 sub-trees of 16^h c rows, ONE all-gather of their c top digests, the levels above replicated),
+ *                                 which needs one row per leaf: more than 28 trace columns (the 47-column verifier AIR); the
+ *                                 narrow stage-2 and quotient trees, whose leaves hold rows of every shard, are built replicated
+ *                                 from columns every rank holds whole anyway.  zp_set_poseidon_bn254(ctx, 17, ..) on every ctx.
  * FAILURE: no rank waits for ever.  A rank whose step fails inside a collective or a sharded entry point takes the communicator down
  * before it returns its own error; its peers return ZP_ERR_COMM (in-process group: at once, woken from the barrier; RCCL: when their
  * watchdog expires and aborts the communicator, ncclCommAbort).  A host whose rank fails BETWEEN collectives calls zp_comm_abort.  A
@@ -489,6 +497,9 @@ int32_t zp_stark_prove_sharded(zp_comm *comm, const char *air_name, const uint64
                                const uint64_t *d_trace_local, size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn,
                                int32_t logb, int32_t fri_logf, int32_t fri_final_log, int32_t n_queries, int32_t pow_bits, char **out_json,
                                size_t *out_len);
+int32_t zp_stark_prove_sharded_bn128(zp_comm *comm, const char *air_name, const uint64_t *h_program, size_t program_words,
+                                     const uint64_t *d_trace_local, size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn,
+                                     int32_t logb, int32_t fri_logf, int32_t fri_final_log, int32_t n_queries, char **out_json, size_t *out_len);
 int32_t zp_exchange_columns_to_rows(zp_comm *comm, const uint64_t *d_cols, size_t Wl, size_t M, uint64_t *d_pack, uint64_t *d_rows);
 /* four-step NTT of ONE column of 2^logn elements split over the ranks (BASELINE.json configs[3]: "RCCL all-to-all over xGMI for the
  * four-step NTT transpose"; replaces the torch.distributed orchestration eigen_zeth_amd/multigpu.py:four_step_ntt): d_data = this

@@ -130,6 +130,104 @@ def test_sharded_prover_over_local_ranks_equals_the_single_gpu_proof(prover, tab
     assert V.verify(json.loads(texts[-1]), air.program(), rc, mds, V.expectation(params.to_dict()))
 
 
+def test_sharded_prover_takes_columns_that_do_not_divide_over_the_ranks(prover, tables):
+    """ceil(W / G) columns per rank, the tail ranks fewer or none (periodic AIR: 3 columns over 2 and 4 ranks -> 2+1, 1+1+1+0)"""
+    rc, mds = tables
+    logn = 9
+    air = AIR.periodic_air(logn)
+    tr, pub = AIR.periodic_witness(logn, 5)
+    assert air.width == 3
+    d = prover.upload(tr)
+    single = prover.stark_prove(air.name, air.program(), d, [int(v) for v in pub], logn, 2, 2, 3, 6, 4)
+    d.free()
+    for G in (2, 4):
+        def fn(r, p, c):
+            first, count = c.my_columns(air.width)
+            d_l = p.upload(np.ascontiguousarray(tr[first:first + count])) if count else None
+            return c.stark_prove_sharded(air.name, air.program(), d_l, [int(v) for v in pub], logn, 2, 2, 3, 6, 4)
+        assert all(t == single for t in run_ranks(G, fn))
+
+
+# ---- BN128-hash mode: the last STARK before the Groth16 wrap over the ranks (zp_stark_prove_sharded_bn128) -----------------------------
+
+@pytest.fixture(scope="module")
+def bn_tables():
+    from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
+    return bn254_poseidon_params(17)
+
+
+def _bn_ranks(G, air, tr, pub, args):
+    def fn(r, p, c):
+        p.install_poseidon_bn254(17)
+        first, count = c.my_columns(air.width)
+        d_l = p.upload(np.ascontiguousarray(tr[first:first + count]))
+        text = c.stark_prove_sharded(air.name, air.program(), d_l, [int(v) for v in pub], *args, bn128=True)
+        return text, p.stark_openings()
+    return run_ranks(G, fn)
+
+
+@pytest.mark.parametrize("logn,logb,logf,final_log,nq,G", [(10, 1, 3, 3, 8, 2), (10, 2, 2, 3, 6, 4), (12, 1, 4, 4, 10, 8), (13, 1, 3, 5, 12, 4)])
+def test_sharded_bn128_prover_equals_the_single_gpu_proof(prover, tables, bn_tables, logn, logb, logf, final_log, nq, G):
+    """chunk64 (64 columns: one row per 16-ary leaf; permutation + LogUp: the stage-2 and quotient trees hold 2^g rows of DIFFERENT shards
+    per leaf and are built replicated): every rank's text and binary openings record == zp_stark_prove_bn128's; the verifier accepts"""
+    air = AIR.get_air("chunk64")
+    tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 21)
+    prover.install_poseidon_bn254(17)
+    d = prover.upload(tr)
+    single = prover.stark_prove_bn128(air.name, air.program(), d, [int(v) for v in pub], logn, logb, logf, final_log, nq)
+    rec = prover.stark_openings()
+    d.free()
+    res = _bn_ranks(G, air, tr, pub, (logn, logb, logf, final_log, nq))
+    assert all(t == single for t, _ in res)
+    assert all((o == rec).all() for _, o in res)
+    params = PR.StarkParams(logn, logb, logf, final_log, nq, hash="bn128")
+    assert V.verify(json.loads(res[-1][0]), air.program(), *tables, V.expectation(params.to_dict()), bn_tables)
+
+
+def test_sharded_bn128_refuses_a_trace_tree_with_several_rows_per_leaf(prover):
+    """16 columns: zp_stark_prove_bn128 packs 2 rows (i, i + M/2) into a leaf -- rows of two shards; the sharded entry says so on every rank"""
+    air = AIR.get_air("chunk16")
+    tr, pub = native.synth_trace(air.trace_kind, 8, air.width, 2)
+
+    def fn(r, p, c):
+        p.install_poseidon_bn254(17)
+        d_l = p.upload(np.ascontiguousarray(tr[r * 8:(r + 1) * 8]))
+        with pytest.raises(native.ZpError, match="one row per leaf"):
+            c.stark_prove_sharded(air.name, air.program(), d_l, [int(v) for v in pub], 8, 1, 2, 3, 5, bn128=True)
+        return True
+    assert all(_ranks_ok for _ranks_ok in run_ranks(2, fn))
+
+
+@pytest.mark.parametrize("G", [2, 8])
+def test_sharded_bn128_final_stark_of_the_verifier_air(prover, tables, bn_tables, G):
+    """the shape this mode exists for: the 47-column verifier AIR (a prime: 24 + 23 columns over two ranks, 6 x 7 + 5 over eight; hundreds of
+    public inputs: the BN128-mode digest of the publics) over two chunk proofs -- GenFinalProof's STARK (src/prover/provider.rs:431-451)"""
+    from eigen_zeth_amd.stark import verifier_air as VA
+    from eigen_zeth_amd.stark.backend_hip import HipBackend
+    rc, mds = tables
+    hip = HipBackend(prover=prover)
+    air = AIR.get_air("chunk16")
+    params = PR.StarkParams(6, 1, 2, 3, 4, pow_bits=4)
+    proofs = []
+    for seed in (3, 4):
+        tr, pub = native.synth_trace(air.trace_kind, 6, air.width, seed)
+        proofs.append(json.loads(PR.proof_to_json(PR.prove(air, tr, pub, params, hip))))
+    shape = VA.Shape.of_proof(proofs[0], 2)
+    vair = VA.verifier_air(shape, rc, mds)
+    d_w, pubs = VA.build_witness(shape, proofs, hip, air.digest_words())
+    t = prover.download(d_w, d_w.shape)
+    ap = VA.aggregation_params(shape, n_queries=5, fri_final_log=3)
+    args = (ap.logn, ap.logb, ap.fri_logf, ap.fri_final_log, ap.n_queries)
+    assert vair.width == 47 and len(pubs) > 64
+    prover.install_poseidon_bn254(17)
+    single = prover.stark_prove_bn128(vair.name, vair.program(), d_w, [int(v) for v in pubs], *args)
+    rec = prover.stark_openings()
+    res = _bn_ranks(G, vair, t, pubs, args)
+    assert all(txt == single for txt, _ in res) and all((o == rec).all() for _, o in res)
+    fp = PR.StarkParams(*args, hash="bn128")
+    assert V.verify(json.loads(single), vair.program(), rc, mds, V.expectation(fp.to_dict()), bn_tables)
+
+
 def test_sharded_prover_on_rccl_with_a_world_of_one(prover, tables):
     """the same entry point on a real RCCL communicator (one rank on the one-GPU box; the driver's multi-GPU node widens it through
     host/prove_chunk --world)"""
