@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ctx.hpp"
+#include "wave_xchg.hpp"
 
 namespace {
 
@@ -78,6 +79,62 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(FoldArgs a) {
     for (int c = 0; c < 3; c++) a.out[(u64)c * m + i] = acc.c[c];
 }
 
+// The fold by 16 with a coset SPREAD OVER THE 16 LANES OF A DPP ROW (zp_set_tuning "fri_fold_lanes"; the A/B against the register form above is
+// profiles/r5_dpp_ab.txt): lane k of a row holds input i + m k, the four DIF levels are lane exchanges (ds_swizzle 8, 4; DPP quad permutes 2, 1),
+// every lane raises gamma to ITS exponent and the sixteen terms are summed by four more exchanges.  Same result, bit for bit; what it costs:
+// a row reads sixteen addresses m apart (four outputs per wave: 8-byte accesses where the register form reads 512-byte runs), both sides of
+// every butterfly run in every lane, and the powers of gamma are 5-7 extension products per lane against ONE per input in Horner's form.
+template <int LH>
+__device__ __forceinline__ u64 fold_stage(u64 x, int kk, const u64 *tws) {
+    const u64 y = lane_xor<LH>(x);
+    const int i = kk & ((1 << LH) - 1);
+    if (!((kk >> LH) & 1)) return gl_add(x, y);
+    const u64 d = gl_sub(y, x);
+    return i ? gl_mul(d, tws[(u64)(i * (8 >> LH)) << 8]) : d;          // w_16^-e = w_4096^-(256 e), e = i 8 / half
+}
+
+__global__ void __launch_bounds__(256) fri_fold_lanes_kernel(FoldArgs a, const u64 *__restrict__ tws) {
+    const u64 n = 1ULL << a.logn, m = n >> 4;
+    const int kk = threadIdx.x & 15;
+    const u64 i0 = ((u64)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool on = i0 < m;
+    const u64 i = on ? i0 : m - 1;                       // idle rows follow the exchanges on a valid address and store nothing
+    u64 v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        u64 x = a.in[(u64)c * n + i + m * (u64)kk];
+        x = fold_stage<3>(x, kk, tws);
+        x = fold_stage<2>(x, kk, tws);
+        x = fold_stage<1>(x, kk, tws);
+        x = fold_stage<0>(x, kk, tws);
+        v[c] = x;                                        // 16 cof_{brev(kk)}, plane c
+    }
+    const u64 wi = gl_mul(a.twl[i & ((1ULL << a.lb) - 1)], a.twh[i >> a.lb]);
+    const e3 gamma = e3_scale(e3_make(a.beta[0], a.beta[1], a.beta[2]), gl_mul(a.shift_inv, wi));
+    const int j = brev(kk, 4);
+    e3 pw = e3_make(1, 0, 0), g = gamma;                 // gamma^j by squaring
+#pragma unroll
+    for (int bit = 0; bit < 4; bit++) {
+        if ((j >> bit) & 1) pw = e3_mul(pw, g);
+        if (bit < 3) g = e3_mul(g, g);
+    }
+    e3 term = e3_mul(e3_make(v[0], v[1], v[2]), pw);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {                        // sum over the row
+        u64 x = term.c[c];
+        x = gl_add(x, lane_xor<3>(x));
+        x = gl_add(x, lane_xor<2>(x));
+        x = gl_add(x, lane_xor<1>(x));
+        x = gl_add(x, lane_xor<0>(x));
+        term.c[c] = x;
+    }
+    if (on && kk == 0) {
+        const e3 r = e3_scale(term, a.finv);
+#pragma unroll
+        for (int c = 0; c < 3; c++) a.out[(u64)c * m + i0] = r.c[c];
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t zp_fri_fold(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int32_t logn, int32_t logf,
@@ -105,6 +162,13 @@ extern "C" int32_t zp_fri_fold(zp_ctx *ctx, const uint64_t *d_in, uint64_t *d_ou
     a.finv = gl_inv(1ULL << logf);
     const u64 m = 1ULL << (logn - logf);
     dim3 grid((unsigned)((m + 255) / 256)), block(256);
+    // DPP rows where they measured faster (profiles/r5_dpp_ab.txt: up to 2^16 inputs the fold is latency-bound and sixteen times the lanes win
+    // 1.56x; at 2^20 and above the scattered reads and the per-lane powers lose 2-4x)
+    if (logf == 4 && (ctx->tune_fri_fold_lanes == 1 || (ctx->tune_fri_fold_lanes == 0 && logn <= 16))) {
+        hipLaunchKernelGGL(fri_fold_lanes_kernel, dim3((unsigned)((m * 16 + 255) / 256)), block, 0, ctx->stream, a, (const u64 *)pl->d_tws);
+        ZP_HIP(ctx, hipGetLastError());
+        return ZP_OK;
+    }
     switch (logf) {
         case 1: hipLaunchKernelGGL(fri_fold_kernel<1>, grid, block, 0, ctx->stream, a); break;
         case 2: hipLaunchKernelGGL(fri_fold_kernel<2>, grid, block, 0, ctx->stream, a); break;

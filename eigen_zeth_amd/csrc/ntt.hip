@@ -20,6 +20,7 @@
 #include <string>
 
 #include "ctx.hpp"
+#include "wave_xchg.hpp"
 #include "gl_asm.hpp"
 #include "gl_limb.hpp"
 
@@ -740,6 +741,21 @@ struct SmallArgs {
     int logn, cslb, flags;
 };
 
+// one DIF stage of half 2^LH inside a wave: lane l holds element l of a 64-element block; the lane with bit LH clear keeps the sum, its
+// partner the twiddled difference.  Every lane walks both sides (the wave executes the sum and the product under complementary masks):
+// twice the arithmetic per element of the LDS form, no LDS traffic and no barrier
+template <int LH>
+__device__ __forceinline__ u64 wave_stage(u64 x, int lane, const u64 *tws) {
+    const u64 y = lane_xor<LH>(x);
+    const int i = lane & ((1 << LH) - 1);
+    if (!((lane >> LH) & 1)) return gl_add(x, y);
+    const u64 d = gl_sub(y, x);
+    return i ? gl_mul(d, tws[(u64)i << (12 - (LH + 1))]) : d;
+}
+
+// WAVE: the last min(logn, 6) stages (halves 32 .. 1) run inside a wave on lane exchanges (zp_set_tuning "ntt_small_wave"; the A/B against
+// the all-LDS form is profiles/r5_dpp_ab.txt)
+template <bool WAVE>
 __global__ void __launch_bounds__(256) ntt_small_kernel(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
@@ -748,7 +764,8 @@ __global__ void __launch_bounds__(256) ntt_small_kernel(SmallArgs a) {
     u64 *dst = a.out + (u64)blockIdx.x * a.out_cs;
     for (int i = tid; i < n; i += 256) lds[i] = (u64)i < a.in_valid ? src[i] : 0ULL;
     __syncthreads();
-    for (int s = 0; s < a.logn; s++) {
+    const int lds_stages = WAVE ? (a.logn > 6 ? a.logn - 6 : 0) : a.logn;
+    for (int s = 0; s < lds_stages; s++) {
         const int lh = a.logn - 1 - s;  // log2(half)
         const int half = 1 << lh;
         for (int b = tid; b < (n >> 1); b += 256) {
@@ -760,6 +777,27 @@ __global__ void __launch_bounds__(256) ntt_small_kernel(SmallArgs a) {
             lds[i1] = i ? gl_mul(d, a.tws[(u64)i << (12 - (lh + 1))]) : d;
         }
         __syncthreads();
+    }
+    if constexpr (WAVE) {
+        const int lane = tid & 63;
+        for (int base = (tid >> 6) << 6; base < n; base += 256) {       // (n < 64: one partial block; lanes >= n carry zeros nobody stores)
+            u64 x = base + lane < n ? lds[base + lane] : 0ULL;
+            const int top = a.logn < 6 ? a.logn : 6;                    // stages with half 2^(top-1) .. 1
+            if (top >= 6) x = wave_stage<5>(x, lane, a.tws);
+            if (top >= 5) x = wave_stage<4>(x, lane, a.tws);
+            if (top >= 4) x = wave_stage<3>(x, lane, a.tws);
+            if (top >= 3) x = wave_stage<2>(x, lane, a.tws);
+            if (top >= 2) x = wave_stage<1>(x, lane, a.tws);
+            if (top >= 1) x = wave_stage<0>(x, lane, a.tws);
+            const int i = base + lane;
+            if (i < n) {
+                const int k = brev(i, a.logn);
+                if (a.flags & 2) x = gl_mul(x, a.scale);
+                if (a.flags & 4) x = gl_mul(x, tw_lookup(a.csl, a.csh, a.cslb, (u64)k));
+                dst[k] = x;
+            }
+        }
+        return;
     }
     for (int i = tid; i < n; i += 256) {
         const int k = brev(i, a.logn);
@@ -1213,7 +1251,11 @@ int32_t zpi_ntt_run(zp_ctx *ctx, const u64 *d_in, u64 *d_out, int logn, int W, b
             a.cslb = opts.post_scale->lb;
         }
         // in place is safe: a block owns its column and loads all of it into LDS before storing
-        hipLaunchKernelGGL(ntt_small_kernel, dim3((unsigned)W), dim3(256), (size_t)N * sizeof(u64), ctx->stream, a);
+        // in-wave stages where they measured faster (profiles/r5_dpp_ab.txt: <= 64 points 1.1-1.75x; from 2^8 points the doubled arithmetic loses)
+        if (ctx->tune_ntt_small_wave == 1 || (ctx->tune_ntt_small_wave == 0 && logn <= 6))
+            hipLaunchKernelGGL(ntt_small_kernel<true>, dim3((unsigned)W), dim3(256), (size_t)N * sizeof(u64), ctx->stream, a);
+        else
+            hipLaunchKernelGGL(ntt_small_kernel<false>, dim3((unsigned)W), dim3(256), (size_t)N * sizeof(u64), ctx->stream, a);
         ZP_HIP(ctx, hipGetLastError());
         return ZP_OK;
     }
