@@ -8,8 +8,9 @@ offline: a ceremony.  The key comes from a LOCAL setup with a published seed (to
 zp_r1cs_key_scalars, its group elements by zp_fixed_base_mul_bn254 / _g2 on the GPU), so a proof made here cannot verify under the key in
 the reference's contracts/EigenZkVM.json.  The JSON emitted follows the grammar eigen-zeth parses (src/settlement/ethereum/mod.rs:445-481).
 
-A backend without the GPU kernels (the CPU checker of the tests) may offer `groth16_prove(key, witness_ints, rand)` instead: with the toxic
-waste in hand the three proof elements are three scalar multiplications -- the SAME group elements (the tests compare the two provers)."""
+The prover is a method of the backend, like every other stage (`be.groth16(key, set_idx, set_val, rand)`; HipBackend: prove_on_gpu below).  The
+tests' CPU backend implements it its own way -- with the toxic waste of the test key in hand the three proof elements are three scalar
+multiplications, the SAME group elements (tests/cpu_wrap_backend.py; the tests compare the two provers)."""
 from __future__ import annotations
 
 import hashlib
@@ -102,15 +103,13 @@ def _g2_point(w):
 
 def prove(key, set_idx, set_val, be, rand):
     """set_idx u64[n], set_val u64[n][4]: the caller-set wires (zp_wrap_assign, or WrapCircuit.assign's witness where its mask is set);
-    rand = (r, s).  Returns ({"pi_a", "pi_b", "pi_c"}, [public inputs as ints], [ms witness, ms QAP, ms MSMs]).  ONE library call on a GPU
-    backend (zp_groth16_prove); ValueError when the assignment does not satisfy the circuit."""
-    if hasattr(be, "groth16_prove"):                 # a backend that proves another way (the CPU checker: by the trapdoor)
-        w = np.zeros((key.n_wires, 4), dtype=np.uint64)
-        mask = np.zeros(key.n_wires, dtype=np.uint8)
-        w[set_idx.astype(np.int64)] = set_val
-        mask[set_idx.astype(np.int64)] = 1
-        wf, _, _, _ = native.r1cs_eval(key.blob, w, mask)
-        return be.groth16_prove(key, native.fr_ints(wf), rand), native.fr_ints(wf[1:1 + key.n_pub]), [0.0, 0.0, 0.0]
+    rand = (r, s).  Returns ({"pi_a", "pi_b", "pi_c"}, [public inputs as ints], [ms witness, ms QAP, ms MSMs]); ValueError when the assignment
+    does not satisfy the circuit.  The backend's stage (HipBackend.groth16 -> prove_on_gpu: ONE library call, zp_groth16_prove)."""
+    return be.groth16(key, set_idx, set_val, rand)
+
+
+def prove_on_gpu(key, set_idx, set_val, be, rand):
+    """zp_groth16_prove on the backend's ctx over the key points resident in HBM"""
     dev = key.load_points(be)
     handles = {k: v[0] for k, v in dev.items() if k != "delta1"}
     handles["n_v"] = dev["v_wires"][1]

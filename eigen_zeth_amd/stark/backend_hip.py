@@ -429,6 +429,11 @@ class HipBackend:
         return self.p.merkle_open_batch(tree, M, idx)
 
     # ---- N6 (Groth16 wrap)
+    def groth16(self, key, set_idx, set_val, rand):
+        """the Groth16 wrap's prover (service/groth16.py: prove): witness completion, QAP quotient and the five MSMs behind zp_groth16_prove"""
+        from ..service import groth16 as G16
+        return G16.prove_on_gpu(key, set_idx, set_val, self, rand)
+
     def msm_g1(self, points, scalars):
         return self.p.msm_bn254([p if p is not None else (0, 0) for p in points], [int(s) for s in scalars])
 

@@ -18,7 +18,7 @@ from eigen_zeth_amd.stark.backend_hip import HipBackend
 from oracle import groth16_verify as GV
 from oracle import stark_verify as V
 from oracle import wrap_verify as WV
-from oracle.stark_cpu import CpuBackend
+from cpu_wrap_backend import CpuWrapBackend as CpuBackend
 
 pytestmark = pytest.mark.gpu
 

@@ -88,9 +88,9 @@ def _start(tmp_path, backend_factory, cfg=None):
 @pytest.fixture()
 def cpu_factory(tables):
     from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
-    from oracle.stark_cpu import CpuBackend
-    return lambda hash_mode="gl": CpuBackend(*tables, hash_mode=hash_mode,
-                                             bn_tables=bn254_poseidon_params(17) if hash_mode == "bn128" else None)
+    from cpu_wrap_backend import CpuWrapBackend
+    return lambda hash_mode="gl": CpuWrapBackend(*tables, hash_mode=hash_mode,
+                                                 bn_tables=bn254_poseidon_params(17) if hash_mode == "bn128" else None)
 
 
 def _check_result(res, tables, block, svc=None):

@@ -23,7 +23,7 @@ from oracle import groth16_verify as GV
 from oracle import naive as NV
 from oracle import stark_verify as V
 from oracle import wrap_verify as WV
-from oracle.stark_cpu import CpuBackend
+from cpu_wrap_backend import CpuWrapBackend as CpuBackend
 
 R = R1.R
 
