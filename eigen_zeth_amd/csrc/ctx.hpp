@@ -166,6 +166,9 @@ int32_t zpi_get_plan_role(zp_ctx *ctx, int logn, bool inverse, int role, NttPlan
 int32_t zpi_lde_plan_json(zp_ctx *ctx, int logn, int want_coef, std::string *out);           // which path zp_lde takes at this size
 int32_t zpi_get_coset(zp_ctx *ctx, int logn, u64 shift, u64 pre, CosetTable **out);
 int32_t zpi_poseidon_sync_tables(zp_ctx *ctx);
+int32_t zpi_poseidon_chains(zp_ctx *ctx, const u64 *d_blocks, const unsigned char *d_absorb, const unsigned int *d_first, int nchains, u64 *d_out);
+int32_t zpi_poseidon_openings_walk(zp_ctx *ctx, const u64 *d_op, const u64 *d_vals, u64 mw, const u64 *d_index, const u64 *d_sib, const u64 *d_sib_off,
+                                   size_t count, u64 *d_inputs, u64 *d_digests);
 // run the transform on W columns; in/out column strides are 2^logn (or in_valid for zero-padded input)
 struct NttRunOpts {
     const CosetTable *post_scale = nullptr;  // multiply output i by table(i) (last pass)

@@ -238,6 +238,92 @@ __global__ void __launch_bounds__(64) poseidon_sponge_pinned_kernel(u64 *buf, in
     if (on) buf[e] = s;
 }
 
+// ---- the hashing walk of a recursion witness on the device (csrc/recursion.hip, round 5): no host round trip per permutation
+// one permutation of the state a wave holds in its lanes 0..11 (same arithmetic as the sponge kernels above)
+__device__ __forceinline__ u64 wave12_perm(u64 s, int e, bool on, u64 *sh, const u64 *rc, const u32 *mds) {
+    for (int r = 0; r < 30; r++) {
+        s = gl_add_weak(s, rc[r * 12 + (on ? e : 0)]);
+        if (r < 4 || r >= 26 || e == 0) s = sbox7(s);
+        if (on) sh[e] = s;
+        __syncthreads();
+        u64 alo = 0, ahi = 0;
+        if (on) {
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const u64 v = sh[j];
+                const u32 m = mds[e * 12 + j];
+                alo += (u64)m * (u32)v;
+                ahi += (u64)m * (u32)(v >> 32);
+            }
+        }
+        __syncthreads();
+        const u64 mid = (alo >> 32) + ahi;
+        s = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
+    }
+    return gl_canon(s);
+}
+
+// Whole Fiat-Shamir transcripts in ONE launch: workgroup c walks the steps [first[c], first[c + 1]) of chain c from the zero state; a step
+// overwrites the rate with its block (absorb[s] != 0) or just permutes; out[s] = the 12 words entering the permutation, then the rate after it
+__global__ void __launch_bounds__(64) sponge_chains_kernel(const u64 *__restrict__ blocks, const unsigned char *__restrict__ absorb,
+                                                           const unsigned int *__restrict__ first, u64 *__restrict__ out, const u64 *rc, const u32 *mds) {
+    __shared__ u64 sh[12];
+    const int e = threadIdx.x;
+    const bool on = e < 12;
+    u64 s = 0;
+    for (unsigned int st = first[blockIdx.x]; st < first[blockIdx.x + 1]; st++) {
+        if (absorb[st] && e < 8) s = blocks[(size_t)st * 8 + e];
+        if (on) out[(size_t)st * 20 + e] = s;
+        s = wave12_perm(s, e, on, sh, rc, mds);
+        if (e < 8) out[(size_t)st * 20 + 12 + e] = s;
+    }
+}
+
+// Every opening of a recursion witness in ONE launch: workgroup o hashes the leaf of opening o (na blocks of 8 values: the linear hash of
+// merkle_leaves_kernel -- words 0..3 of a permutation's output are the capacity of the next block) and walks its nd path levels along the bits
+// of its index; the 12 words entering every permutation go to inputs[b0 + ...] (the verifier AIR's permutation blocks, in HBM where
+// zp_poseidon_trace reads them), the last digest to digests[o].   op: b0, na, nd per opening; vals: mw words per opening, zero padded;
+// sib: the siblings of opening o at sib_off[o], 4 words per level
+__global__ void __launch_bounds__(64) openings_walk_kernel(const u64 *__restrict__ op, const u64 *__restrict__ vals, u64 mw, const u64 *__restrict__ index,
+                                                           const u64 *__restrict__ sib, const u64 *__restrict__ sib_off, u64 *__restrict__ inputs,
+                                                           u64 *__restrict__ digests, const u64 *rc, const u32 *mds) {
+    __shared__ u64 sh[12];
+    __shared__ u64 cur[4];
+    const int e = threadIdx.x;
+    const bool on = e < 12;
+    const u64 o = blockIdx.x, b0 = op[3 * o], na = op[3 * o + 1], nd = op[3 * o + 2];
+    const u64 *v = vals + o * mw;
+    u64 s = 0;
+    if (e < 4) cur[e] = v[e];                               // an unhashed leaf (<= 4 values) is its own digest, zero padded
+    for (u64 j = 0; j < na; j++) {
+        if (e < 8) s = 8 * j + e < mw ? v[8 * j + e] : 0ULL;
+        if (on) inputs[(b0 + j) * 12 + e] = s;
+        s = wave12_perm(s, e, on, sh, rc, mds);
+        if (on) sh[e] = s;
+        __syncthreads();
+        if (e >= 8 && on) s = sh[e - 8];                    // the digest so far is the next block's capacity
+        if (e < 4) cur[e] = s;
+        __syncthreads();
+    }
+    const u64 idx = index[o];
+    const u64 *sb = sib + sib_off[o];
+    __syncthreads();
+    for (u64 lv = 0; lv < nd; lv++) {
+        const bool bit = (idx >> lv) & 1;
+        if (on) {
+            if (e < 4) s = bit ? sb[lv * 4 + e] : cur[e];
+            else if (e < 8) s = bit ? cur[e - 4] : sb[lv * 4 + (e - 4)];
+            else s = 0;
+            inputs[(b0 + na + lv) * 12 + e] = s;
+        }
+        __syncthreads();
+        s = wave12_perm(s, e, on, sh, rc, mds);
+        if (e < 4) cur[e] = s;
+        __syncthreads();
+    }
+    if (e < 4) digests[o * 4 + e] = cur[e];
+}
+
 // proof-of-work grinding (before the query phase of a STARK): lane = candidate nonce base + gid; a hit is a nonce with
 // Poseidon(seed[0..3] || nonce || 0^7)[0] >> (64 - bits) == 0; the smallest hit of the batch wins (atomicMin).
 template <bool DEFMDS>
@@ -567,6 +653,26 @@ int32_t zpi_poseidon_sync_tables(zp_ctx *ctx) {
         for (int j = 0; j < 12; j++)
             if (ctx->h_mds[i * 12 + j] != def_mds(i, j)) ctx->mds_is_default = false;
     ctx->poseidon_dirty = false;
+    return ZP_OK;
+}
+
+// nsteps steps of nchains sponge chains in one launch (sponge_chains_kernel); d_*: device buffers the caller filled, d_out u64[nsteps][20]
+int32_t zpi_poseidon_chains(zp_ctx *ctx, const u64 *d_blocks, const unsigned char *d_absorb, const unsigned int *d_first, int nchains, u64 *d_out) {
+    ZP_TRY(zpi_poseidon_sync_tables(ctx));
+    if (nchains <= 0) return ZP_OK;
+    hipLaunchKernelGGL(sponge_chains_kernel, dim3((unsigned)nchains), dim3(64), 0, ctx->stream, d_blocks, d_absorb, d_first, d_out, ctx->d_rc, ctx->d_mds);
+    ZP_HIP(ctx, hipGetLastError());
+    return ZP_OK;
+}
+
+// the leaf hash and the path of `count` openings in one launch (openings_walk_kernel)
+int32_t zpi_poseidon_openings_walk(zp_ctx *ctx, const u64 *d_op, const u64 *d_vals, u64 mw, const u64 *d_index, const u64 *d_sib, const u64 *d_sib_off,
+                                   size_t count, u64 *d_inputs, u64 *d_digests) {
+    ZP_TRY(zpi_poseidon_sync_tables(ctx));
+    if (!count) return ZP_OK;
+    hipLaunchKernelGGL(openings_walk_kernel, dim3((unsigned)count), dim3(64), 0, ctx->stream, d_op, d_vals, mw, d_index, d_sib, d_sib_off, d_inputs, d_digests,
+                       ctx->d_rc, ctx->d_mds);
+    ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
 }
 

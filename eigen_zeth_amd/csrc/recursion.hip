@@ -335,50 +335,42 @@ int32_t perm_batch(zp_ctx *ctx, DevTmp &scratch, u64 *states, size_t count) {
     return zp_d2h(ctx, states, scratch.p, count * 96);
 }
 
-// the sponge of stark/transcript.py that records, for every permutation, its input state, the number of values its block absorbed and
-// (when the protocol reads it) the rate after it
-struct RecSponge {
-    zp_ctx *ctx;
-    u64 state[12];
-    std::vector<u64> queue, avail;
-    struct Rec { u64 in[12]; int n_in; bool has_out; u64 out[8]; };
-    std::vector<Rec> rec;
-    int32_t rc = ZP_OK;
-    explicit RecSponge(zp_ctx *c) : ctx(c) { memset(state, 0, sizeof state); }
-    void absorb(const u64 *v, size_t n) { queue.insert(queue.end(), v, v + n); avail.clear(); }
+// the sponge of stark/transcript.py as a PLAN (round 5): what a verifier absorbs is all in the proof's header, and which permutations run when
+// depends on sizes only, so a replay first lists its steps -- a block of up to 8 values overwriting the rate, or a bare permutation when the
+// protocol squeezes past a rate -- and where every squeezed value will come from; the whole chain then runs in ONE launch
+// (zpi_poseidon_chains, all inner proofs side by side) and the squeezed values are read off its output.  Per step the witness needs the
+// input state, the number of values its block absorbed and (when the protocol reads it) the rate after it.
+struct PlanSponge {
+    std::vector<u64> queue;
+    std::vector<u64> blocks;                 // 8 words per step
+    std::vector<unsigned char> absorbs;      // per step: 1 = the block overwrites the rate
+    std::vector<int> n_in;
+    std::vector<char> has_out;
+    struct Fix { u64 *dst; size_t step; int off; };
+    std::vector<Fix> fixes;                  // dst <- rate[off] after step
+    bool have = false;
+    size_t have_step = 0;
+    int have_off = 0;
+    size_t steps() const { return absorbs.size(); }
+    void absorb(const u64 *v, size_t n) { queue.insert(queue.end(), v, v + n); have = false; }
+    void step(const u64 *blk, int n, bool ab) {
+        for (int i = 0; i < 8; i++) blocks.push_back(i < n ? blk[i] : 0ULL);
+        absorbs.push_back(ab ? 1 : 0);
+        n_in.push_back(n);
+        has_out.push_back(0);
+    }
     void flush() {
         const size_t nb = (queue.size() + 7) / 8;
-        std::vector<u64> blocks(nb * 8, 0), rates(8), caps((nb ? nb : 1) * 4);
-        memcpy(blocks.data(), queue.data(), queue.size() * 8);
-        std::vector<int> nin;
-        for (size_t i = 0; i < nb; i++) nin.push_back((int)(queue.size() - 8 * i < 8 ? queue.size() - 8 * i : 8));
-        u64 before[12];
-        memcpy(before, state, sizeof before);
+        if (nb == 0) step(nullptr, 0, false);
+        for (size_t i = 0; i < nb; i++) step(&queue[8 * i], (int)(queue.size() - 8 * i < 8 ? queue.size() - 8 * i : 8), true);
         queue.clear();
-        if (rc == ZP_OK) rc = zp_poseidon_sponge_caps(ctx, (uint64_t *)state, (const uint64_t *)blocks.data(), nb, 0, (uint64_t *)rates.data(), (uint64_t *)caps.data());
-        if (rc != ZP_OK) return;
-        if (nb == 0) {
-            Rec r; memcpy(r.in, before, sizeof before); r.n_in = 0; r.has_out = false;
-            rec.push_back(r);
-        }
-        for (size_t i = 0; i < nb; i++) {
-            Rec r;
-            memcpy(r.in, &blocks[8 * i], 64);
-            memcpy(r.in + 8, i == 0 ? before + 8 : &caps[4 * (i - 1)], 32);
-            r.n_in = nin[i]; r.has_out = false;
-            rec.push_back(r);
-        }
-        rec.back().has_out = true;
-        memcpy(rec.back().out, state, 64);
-        avail.assign(state, state + 8);
+        has_out.back() = 1;
+        have = true; have_step = steps() - 1; have_off = 0;
     }
     void squeeze(size_t n, u64 *out) {
-        size_t got = 0;
-        while (got < n && rc == ZP_OK) {
-            if (!queue.empty() || avail.empty()) flush();
-            if (rc != ZP_OK) break;
-            out[got++] = avail.front();
-            avail.erase(avail.begin());
+        for (size_t got = 0; got < n; got++) {
+            if (!queue.empty() || !have || have_off == 8) flush();
+            fixes.push_back(Fix{out + got, have_step, have_off++});
         }
     }
 };
@@ -421,68 +413,82 @@ int32_t publics_digest(zp_ctx *ctx, const u64 *pubs, size_t n, u64 out4[4]) {
     return zp_d2h(ctx, out4, (const char *)tree.p + (2 * M - 2) * 32, 32);
 }
 
-// replay of one inner transcript: fills `states` (L x 12: the inputs of its permutation blocks), appends its section of the public inputs
-// to `tp`, returns the challenges.  -14: the transcript does not give the proof's indices / the grinding nonce fails; -12: wrong shape.
-int32_t replay(zp_ctx *ctx, const Desc &D, const Stream &st, const u64 *index, DevTmp &scratch, std::vector<u64> &states, std::vector<u64> &tp, Chal *ch) {
-    RecSponge tr(ctx);
+// replay of one inner transcript, in two halves around the one launch that runs every proof's chain.  plan: lists the steps (the digest of a
+// long public vector is the one hash made on the way).  finish: `out` = u64[steps][20] of the chain (input state, rate after) -> fills `states`
+// (L x 12: the inputs of its permutation blocks), appends its section of the public inputs to `tp`, returns the challenges.  -14: the
+// transcript does not give the proof's indices / the grinding nonce fails; -12: wrong shape.
+struct ReplayPlan {
+    PlanSponge tr;
+    Chal ch;
+    std::vector<u64> idx;
+    u64 seed[4], tmp[8], pow_out[12];
+    u64 dg[4];
+};
+
+int32_t replay_plan(zp_ctx *ctx, const Desc &D, const Stream &st, ReplayPlan *rp) {
+    PlanSponge &tr = rp->tr;
+    Chal *ch = &rp->ch;
     std::vector<u64> head = {D.logn, D.logb, D.W, D.W2, D.fri_logf, D.fri_final_log, D.n_queries, D.pow_bits, D.root32, D.shift,
                              st.digest[0], st.digest[1], st.digest[2], st.digest[3], D.n_pub_inner};
     if (D.n_pub_inner <= PUBLICS_INLINE) {
         head.insert(head.end(), st.pubs, st.pubs + D.n_pub_inner);
         tr.absorb(head.data(), head.size());
     } else {
-        u64 dg[4];
-        ZP_TRY(publics_digest(ctx, st.pubs, D.n_pub_inner, dg));
+        ZP_TRY(publics_digest(ctx, st.pubs, D.n_pub_inner, rp->dg));
         tr.absorb(head.data(), head.size());
-        tr.absorb(dg, 4);
+        tr.absorb(rp->dg, 4);
     }
     const u64 Wt = D.W + D.W2;
-    u64 tmp[8];
     tr.absorb(st.root[0], 4);
-    if (D.W2) { tr.squeeze(3, tmp); tr.absorb(st.root[1], 4); }
-    tr.squeeze(3, tmp);                                       // alpha
+    if (D.W2) { tr.squeeze(3, rp->tmp); tr.absorb(st.root[1], 4); }
+    tr.squeeze(3, rp->tmp);                                   // alpha
     tr.absorb(st.root[D.TQ], 4);
     tr.squeeze(3, ch->zeta.c);
     tr.absorb(st.ev_z, 3 * (Wt + D.Wq));
     tr.absorb(st.ev_zw, 3 * Wt);
     tr.squeeze(3, ch->gamma.c);
+    ch->betas.assign(D.n_fri(), e3_make(0, 0, 0));            // (sized first: the fix-ups point into it)
     for (u64 l = 0; l < D.n_fri(); l++) {
         tr.absorb(st.root[D.TQ + 1 + l], 4);
-        e3 b;
-        tr.squeeze(3, b.c);
-        ch->betas.push_back(b);
+        tr.squeeze(3, ch->betas[l].c);
     }
     tr.absorb(st.final_l, (size_t)3 << D.final_log);
-    bool have_pow = false;
-    RecSponge::Rec powrec;
     if (D.pow_bits) {
-        u64 seed[4];
-        tr.squeeze(4, seed);
-        ZP_TRY(tr.rc);
+        tr.squeeze(4, rp->seed);
         if (st.nonce >= GL_P) return -14;
-        u64 pin[12] = {seed[0], seed[1], seed[2], seed[3], st.nonce, 0, 0, 0, 0, 0, 0, 0}, pout[12];
-        memcpy(pout, pin, sizeof pin);
-        ZP_TRY(perm_batch(ctx, scratch, pout, 1));
-        if (pout[0] >> (64 - D.pow_bits)) return -14;
-        memcpy(powrec.in, pin, sizeof pin); powrec.n_in = 5; powrec.has_out = true; memcpy(powrec.out, pout, 64);
-        have_pow = true;
         tr.absorb(&st.nonce, 1);
     }
-    std::vector<u64> idx(D.n_queries);
-    tr.squeeze(D.n_queries, idx.data());
-    ZP_TRY(tr.rc);
+    rp->idx.assign(D.n_queries, 0);
+    tr.squeeze(D.n_queries, rp->idx.data());
+    return ZP_OK;
+}
+
+// the grinding hash's input, once the chain has run (seed read off it)
+void replay_pow_input(const Stream &st, ReplayPlan *rp, const u64 *out, u64 pin[12]) {
+    for (const PlanSponge::Fix &f : rp->tr.fixes) *f.dst = out[f.step * 20 + 12 + f.off];
+    const u64 in[12] = {rp->seed[0], rp->seed[1], rp->seed[2], rp->seed[3], st.nonce, 0, 0, 0, 0, 0, 0, 0};
+    memcpy(pin, in, sizeof in);
+}
+
+int32_t replay_finish(const Desc &D, const Stream &st, const u64 *index, ReplayPlan *rp, const u64 *out, const u64 *pow_in, const u64 *pow_out,
+                      std::vector<u64> &states, std::vector<u64> &tp) {
+    const PlanSponge &tr = rp->tr;
+    if (D.pow_bits && (pow_out[0] >> (64 - D.pow_bits))) return -14;
     const u64 mask = ((u64)1 << (D.logn + D.logb)) - 1;
     for (u64 q = 0; q < D.n_queries; q++)
-        if ((idx[q] & mask) != index[q]) return -14;
-    if (have_pow) tr.rec.push_back(powrec);
-    if (tr.rec.size() != D.L) return -12;
+        if ((rp->idx[q] & mask) != index[q]) return -14;
+    const size_t nrec = tr.steps() + (D.pow_bits ? 1 : 0);
+    if (nrec != D.L) return -12;
     for (u64 j = 0; j < D.L; j++) {
         const u64 w = D.script[j];
-        const RecSponge::Rec &r = tr.rec[j];
-        if ((u64)r.n_in != (w & 255) || r.has_out != (((w >> 8) & 1) != 0)) return -12;
-        states.insert(states.end(), r.in, r.in + 12);
-        tp.insert(tp.end(), r.in, r.in + r.n_in);
-        if (r.has_out) tp.insert(tp.end(), r.out, r.out + 8);
+        const bool is_pow = j == tr.steps();
+        const int n_in = is_pow ? 5 : tr.n_in[j];
+        const bool has_out = is_pow ? true : tr.has_out[j] != 0;
+        if ((u64)n_in != (w & 255) || has_out != (((w >> 8) & 1) != 0)) return -12;
+        const u64 *in = is_pow ? pow_in : out + j * 20, *ro = is_pow ? pow_out : out + j * 20 + 12;
+        states.insert(states.end(), in, in + 12);
+        tp.insert(tp.end(), in, in + n_in);
+        if (has_out) tp.insert(tp.end(), ro, ro + 8);
     }
     return ZP_OK;
 }
@@ -568,65 +574,52 @@ int32_t recursion_witness(zp_ctx *ctx, const Desc &D, const uint64_t *const *h_i
         }
     ZP_ARG(ctx, ops.size() == D.n_open, "descriptor and schedule disagree on the number of openings");
     const u64 no = ops.size(), mw = D.max_w;
-    u64 max_d = 0, max_na = 0;
-    for (const Op &o : ops) { if (o.nd > max_d) max_d = o.nd; if (o.na > max_na) max_na = o.na; }
-    std::vector<u64> vals(no * mw, 0), index(no), inputs(nblk * 12, 0), dbit(nblk, 0), idxv(nblk, 0), digest(no * 4), cap(no * 4, 0);
+    std::vector<u64> vals(no * mw, 0), index(no), dbit(nblk, 0), idxv(nblk, 0), digest(no * 4);
+    // the siblings of every opening, back to back, and the (b0, na, nd) table: what openings_walk_kernel reads
+    std::vector<u64> opt(no * 3), sib_off(no + 1, 0);
+    for (u64 o = 0; o < no; o++) sib_off[o + 1] = sib_off[o] + ops[o].nd * 4;
+    std::vector<u64> sib(sib_off[no] ? sib_off[no] : 1);
     for (u64 o = 0; o < no; o++) {
         const Op &op = ops[o];
         memcpy(&vals[o * mw], (const u64 *)h_values[op.p] + voff[op.t] + op.q * wv[op.t], wv[op.t] * 8);
         index[o] = ((const u64 *)h_index[op.p])[op.q] & (((u64)1 << op.nd) - 1);
-    }
-    mark("opening table");
-    DevTmp scratch(ctx);
-    ZP_TRY(scratch.alloc((no > 1 ? no : 1) * 96));
-    std::vector<u64> stt(no * 12);
-    std::vector<u64> sel;
-    sel.reserve(no);
-    // ---- leaf hashes: absorb block j of every opening in one batch
-    for (u64 j = 0; j < max_na; j++) {
-        sel.clear();
-        for (u64 o = 0; o < no; o++) if (ops[o].na > j) sel.push_back(o);
-        for (size_t i = 0; i < sel.size(); i++) {
-            const u64 o = sel[i];
-            u64 *s = &stt[i * 12];
-            const u64 room = mw - 8 * j;
-            for (u64 e = 0; e < 8; e++) s[e] = e < room ? vals[o * mw + 8 * j + e] : 0;
-            memcpy(s + 8, &cap[o * 4], 32);
-            memcpy(&inputs[(ops[o].b0 + j) * 12], s, 96);
-        }
-        ZP_TRY(perm_batch(ctx, scratch, stt.data(), sel.size()));
-        for (size_t i = 0; i < sel.size(); i++) memcpy(&cap[sel[i] * 4], &stt[i * 12], 32);
-    }
-    mark("leaf hashes");
-    for (u64 o = 0; o < no; o++) memcpy(&digest[o * 4], ops[o].na ? &cap[o * 4] : &vals[o * mw], 32);     // unhashed leaves: identity, zero padded
-    // ---- paths: tree level lv of every opening in one batch
-    for (u64 lv = 0; lv < max_d; lv++) {
-        sel.clear();
-        for (u64 o = 0; o < no; o++) if (ops[o].nd > lv) sel.push_back(o);
-        if (sel.empty()) break;
-        for (size_t i = 0; i < sel.size(); i++) {
-            const u64 o = sel[i];
-            const Op &op = ops[o];
-            const u64 bit = (index[o] >> lv) & 1;
-            const u64 *sib = (const u64 *)h_paths[op.p] + poff[op.t] + (op.q * op.nd + lv) * 4, *cur = &digest[o * 4];
-            u64 *s = &stt[i * 12];
-            memcpy(s, bit ? sib : cur, 32);
-            memcpy(s + 4, bit ? cur : sib, 32);
-            memset(s + 8, 0, 32);
+        opt[3 * o] = op.b0; opt[3 * o + 1] = op.na; opt[3 * o + 2] = op.nd;
+        if (op.nd) memcpy(&sib[sib_off[o]], (const u64 *)h_paths[op.p] + poff[op.t] + op.q * op.nd * 4, op.nd * 32);
+        for (u64 lv = 0; lv < op.nd; lv++) {
             const u64 blk = op.b0 + op.na + lv;
-            memcpy(&inputs[blk * 12], s, 96);
-            dbit[blk] = bit;
+            dbit[blk] = (index[o] >> lv) & 1;
             idxv[blk] = index[o] & (((u64)2 << lv) - 1);
         }
-        ZP_TRY(perm_batch(ctx, scratch, stt.data(), sel.size()));
-        for (size_t i = 0; i < sel.size(); i++) memcpy(&digest[sel[i] * 4], &stt[i * 12], 32);
+    }
+    mark("opening table");
+    // ---- leaf hashes and paths ON THE DEVICE, one launch (round 5; rounds 3-4: one batched permutation and one host round trip per absorb block
+    //      and per tree level, ~30 of them): every opening's workgroup writes the 12 words entering each of its permutations straight into the
+    //      block-input buffer zp_poseidon_trace reads below, and hands back its last digest -- which must be the root
+    DevTmp scratch(ctx), d_in(ctx), d_opn(ctx);
+    ZP_TRY(scratch.alloc(NP * 96));
+    ZP_TRY(d_in.alloc(nblk * 96));
+    ZP_TRY(zp_dev_zero(ctx, d_in.p, nblk * 96));            // idle blocks permute the zero state
+    {
+        // one upload: [op table | index | sibling offsets | values | siblings], digests behind them
+        const size_t o_idx = opt.size(), o_so = o_idx + no, o_val = o_so + no, o_sib = o_val + vals.size(), o_dg = o_sib + sib.size(), words = o_dg + no * 4;
+        std::vector<u64> up(o_dg);
+        memcpy(&up[0], opt.data(), opt.size() * 8);
+        memcpy(&up[o_idx], index.data(), no * 8);
+        memcpy(&up[o_so], sib_off.data(), no * 8);
+        memcpy(&up[o_val], vals.data(), vals.size() * 8);
+        memcpy(&up[o_sib], sib.data(), sib.size() * 8);
+        ZP_TRY(d_opn.alloc(words * 8));
+        u64 *d = (u64 *)d_opn.p;
+        ZP_TRY(zp_h2d(ctx, d, up.data(), up.size() * 8));
+        ZP_TRY(zpi_poseidon_openings_walk(ctx, d, d + o_val, mw, d + o_idx, d + o_sib, d + o_so, no, (u64 *)d_in.p, d + o_dg));
+        ZP_TRY(zp_d2h(ctx, digest.data(), d + o_dg, no * 32));
     }
     for (u64 o = 0; o < no; o++)
         if (memcmp(&digest[o * 4], st[ops[o].p].root[ops[o].t], 32) != 0) {
             ctx->err = "an opening of an inner proof does not hash to its root: no accepting witness";
             return -13;
         }
-    mark("paths");
+    mark("leaf hashes + paths (device)");
     // ---- public inputs: roots | indices | transcripts | arithmetic constants | final-layer values
     u64 *pub = h_pubs;
     for (u64 p = 0; p < NP; p++)
@@ -635,19 +628,56 @@ int32_t recursion_witness(zp_ctx *ctx, const Desc &D, const uint64_t *const *h_i
         for (u64 p = 0; p < NP; p++)
             for (u64 t = 0; t < T; t++) *pub++ = ((const u64 *)h_index[p])[g % nq] & (((u64)1 << dv[t]) - 1);
     std::vector<u64> aps(NP * D.ap_n, 0), fin(nslots * NP * 3);
-    for (u64 p = 0; p < NP; p++) {
-        std::vector<u64> states, tp;
-        Chal ch;
-        const int32_t r = replay(ctx, D, st[p], (const u64 *)h_index[p], scratch, states, tp, &ch);
+    // ---- transcripts: every inner proof's whole sponge chain in ONE launch, the grinding hashes in a second one (rounds 3-4: a host round
+    //      trip per transcript step, ~12 per proof)
+    std::vector<ReplayPlan> plans(NP);
+    auto replay_error = [&](int32_t r) {
         if (r == -14) ctx->err = "the transcript of an inner proof does not give its query indices or its grinding nonce fails: no accepting witness";
         if (r == -12) ctx->err = "an inner proof does not have the shape the verifier AIR was built for";
-        if (r != ZP_OK) return r;
-        if (tp.size() != tp_per) { ctx->err = "transcript section of the wrong size"; return ZP_ERR_INTERNAL; }
-        memcpy(&inputs[(D.tblock0 + p * D.L) * 12], states.data(), states.size() * 8);
+        return r;
+    };
+    std::vector<unsigned int> first(NP + 1, 0);
+    for (u64 p = 0; p < NP; p++) {
+        const int32_t r = replay_plan(ctx, D, st[p], &plans[p]);
+        if (r != ZP_OK) return replay_error(r);
+        first[p + 1] = first[p] + (unsigned int)plans[p].tr.steps();
+    }
+    const size_t nsteps = first[NP];
+    std::vector<u64> chain_out(nsteps * 20), pow_io(NP * 12, 0), pow_in(NP * 12, 0);
+    {
+        // one upload: [blocks (8 words per step) | first (NP + 1 u32, padded) | absorb flags (bytes, padded)], the output behind them
+        const size_t w_first = (NP + 2) / 2, w_abs = (nsteps + 7) / 8, o_first = nsteps * 8, o_abs = o_first + w_first, o_out = o_abs + w_abs;
+        std::vector<u64> up(o_out, 0);
+        unsigned char *ab = (unsigned char *)&up[o_abs];
+        for (u64 p = 0; p < NP; p++) {
+            memcpy(&up[(size_t)first[p] * 8], plans[p].tr.blocks.data(), plans[p].tr.blocks.size() * 8);
+            memcpy(ab + first[p], plans[p].tr.absorbs.data(), plans[p].tr.absorbs.size());
+        }
+        memcpy(&up[o_first], first.data(), (NP + 1) * 4);
+        DevTmp d_ch(ctx);
+        ZP_TRY(d_ch.alloc((o_out + nsteps * 20) * 8));
+        u64 *d = (u64 *)d_ch.p;
+        ZP_TRY(zp_h2d(ctx, d, up.data(), up.size() * 8));
+        ZP_TRY(zpi_poseidon_chains(ctx, d, (const unsigned char *)(d + o_abs), (const unsigned int *)(d + o_first), (int)NP, d + o_out));
+        ZP_TRY(zp_d2h(ctx, chain_out.data(), d + o_out, chain_out.size() * 8));
+    }
+    for (u64 p = 0; p < NP; p++) replay_pow_input(st[p], &plans[p], &chain_out[(size_t)first[p] * 20], &pow_in[p * 12]);
+    if (D.pow_bits) {
+        pow_io = pow_in;
+        ZP_TRY(perm_batch(ctx, scratch, pow_io.data(), NP));
+    }
+    std::vector<u64> tstates;                         // the transcript blocks' input states, proof after proof: one upload into the block-input buffer
+    for (u64 p = 0; p < NP; p++) {
+        std::vector<u64> states, tp;
+        const int32_t r = replay_finish(D, st[p], (const u64 *)h_index[p], &plans[p], &chain_out[(size_t)first[p] * 20], &pow_in[p * 12], &pow_io[p * 12], states, tp);
+        if (r != ZP_OK) return replay_error(r);
+        if (tp.size() != tp_per || states.size() != D.L * 12) { ctx->err = "transcript section of the wrong size"; return ZP_ERR_INTERNAL; }
+        tstates.insert(tstates.end(), states.begin(), states.end());
         memcpy(pub, tp.data(), tp.size() * 8);
         pub += tp.size();
-        arith_publics(D, st[p], ch, &aps[p * D.ap_n]);
+        arith_publics(D, st[p], plans[p].ch, &aps[p * D.ap_n]);
     }
+    ZP_TRY(zp_h2d(ctx, (u64 *)d_in.p + D.tblock0 * 12, tstates.data(), tstates.size() * 8));
     memcpy(pub, aps.data(), aps.size() * 8);
     pub += aps.size();
     const u64 fmask = ((u64)1 << D.final_log) - 1, fl = (u64)1 << D.final_log;
@@ -658,24 +688,23 @@ int32_t recursion_witness(zp_ctx *ctx, const Desc &D, const uint64_t *const *h_i
         }
     memcpy(pub, fin.data(), fin.size() * 8);
     mark("transcripts replayed");
-    // ---- the arithmetic columns
-    Records rec(nblk);
-    const int rc = walk_all(D, vals.data(), index.data(), dbit.data(), blk_op.data(), aps.data(), fin.data(), rec.view(), threads);
-    if (rc == -12) { ctx->err = "arithmetic-witness inputs do not match the descriptor"; return ZP_ERR_ARG; }
-    if (rc != 0) { ctx->err = "the opened values of an inner proof are inconsistent: no accepting witness"; return rc; }
-    mark("arithmetic columns (host)");
-    // ---- the trace in HBM: 24 permutation columns, direction bit, index, 21 arithmetic columns
-    DevTmp d_in(ctx), d_pb(ctx);
-    ZP_TRY(d_in.alloc(inputs.size() * 8));
-    ZP_TRY(zp_h2d(ctx, d_in.p, inputs.data(), inputs.size() * 8));
-    ZP_TRY(zp_poseidon_trace(ctx, (const uint64_t *)d_in.p, nblk, (uint64_t *)d_trace, (uint64_t *)(d_trace + 12 * N), N));
+    // ---- the trace in HBM: 24 permutation columns, direction bit, index -- launched first, so that the kernels run while the host walks the
+    //      arithmetic (round 5) -- then the 21 arithmetic columns
+    DevTmp d_pb(ctx);
     ZP_TRY(d_pb.alloc(2 * nblk * 8));
     ZP_TRY(zp_h2d(ctx, d_pb.p, dbit.data(), nblk * 8));
     ZP_TRY(zp_h2d(ctx, (u64 *)d_pb.p + nblk, idxv.data(), nblk * 8));
+    ZP_TRY(zp_poseidon_trace(ctx, (const uint64_t *)d_in.p, nblk, (uint64_t *)d_trace, (uint64_t *)(d_trace + 12 * N), N));
     for (int c = 0; c < 2; c++) {
         hipLaunchKernelGGL(block_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_trace + (24 + c) * N, (const u64 *)d_pb.p + c * nblk, N);
         if (hipGetLastError() != hipSuccess) { ctx->err = "block_fill_kernel launch failed"; return ZP_ERR_HIP; }
     }
+    Records rec(nblk);
+    const int rc = walk_all(D, vals.data(), index.data(), dbit.data(), blk_op.data(), aps.data(), fin.data(), rec.view(), threads);
+    if (rc != 0) (void)zp_sync(ctx);                       // the kernels above read buffers that die with this frame
+    if (rc == -12) { ctx->err = "arithmetic-witness inputs do not match the descriptor"; return ZP_ERR_ARG; }
+    if (rc != 0) { ctx->err = "the opened values of an inner proof are inconsistent: no accepting witness"; return rc; }
+    mark("arithmetic columns (host) beside the permutation columns (device)");
     const int32_t rrc = records_to_device(ctx, rec, nblk, d_trace + 26 * N);
     mark("trace assembled in HBM");
     return rrc;
