@@ -886,7 +886,8 @@ def config5_probe(K=64, logn=22, msm_log=26, air_name="chunk64"):
     from eigen_zeth_amd.service.engine import Engine, EngineConfig
     from eigen_zeth_amd.service.server import default_backend_factory
     cfg = EngineConfig(air=air_name, logn=logn, crs_dir=os.path.join(tempfile.gettempdir(), "zp_crs_c5_%d" % os.getuid()),
-                       witness_threads=12)          # 2 GiB of page-locked witness per chunk in flight at 2^22 x 64 (14 in flight at most)
+                       witness_threads=int(os.environ.get("ZP_C5_WITNESS_THREADS", "12")),          # 2 GiB of page-locked witness per chunk in flight at 2^22 x 64 (14 in flight at most)
+                       prover_streams=int(os.environ.get("ZP_C5_STREAMS", "8")))                    # (both overridable for sweeps: tools, not the driver's run)
     eng = Engine(default_backend_factory(0), cfg)
     eng.groth16_keys()
     out = {"workload": "%d chunks x 2^%d rows x (64 + 12) columns, %d bits conjectured; recursion; 4 G1 + 1 G2 MSMs of 2^%d points"

@@ -85,6 +85,37 @@ __global__ void __launch_bounds__(64) mix_expand_kernel(const u64 *__restrict__ 
     }
 }
 
+// The same with the rows STAGED through LDS (round 5): the kernel above stores row by row -- 64 lanes, 64 columns, 8 bytes each, 2^logn rows apart --
+// and a 2^22 x 64 trace is 2 GiB of such stores.  Here a block of RB = 64 / CPL rows is collected in LDS (row stride Ww + 1 words: no bank
+// conflicts either way) and written out column by column: RB consecutive rows of one column per RB lanes, 512-byte runs for one column per lane.
+template <int CPL>
+__global__ void __launch_bounds__(64) mix_expand_tiled_kernel(const u64 *__restrict__ ckpt, u64 *__restrict__ trace, int logn, int seg_log, int Ww) {
+    constexpr int RB = CPL == 1 ? 64 : CPL == 2 ? 32 : 16;
+    __shared__ u64 lds[2][64 * MAX_CPL + 2];
+    __shared__ u64 tile[RB * (64 * CPL + 1)];
+    const int lane = threadIdx.x, stride = Ww + 1;
+    const size_t s = blockIdx.x, N = (size_t)1 << logn, r0 = s << seg_log;
+    u64 cur[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) cur[c] = lane + 64 * c < Ww ? ckpt[s * Ww + lane + 64 * c] : 0;
+    const int rows = 1 << seg_log;
+    for (int rb = 0; rb < rows; rb += RB) {
+        const int nr = rows - rb < RB ? rows - rb : RB;         // (a segment shorter than RB: logn < log2 RB)
+        for (int r = 0; r < nr; r++) {
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+                if (lane + 64 * c < Ww) tile[r * stride + lane + 64 * c] = cur[c];
+            mix_step<CPL>(cur, lds[r & 1], lane, Ww);
+        }
+        __syncthreads();
+        for (int i = lane; i < Ww * RB; i += 64) {
+            const int col = i / RB, rr = i % RB;
+            if (rr < nr) trace[(size_t)col * N + r0 + rb + rr] = tile[rr * stride + col];
+        }
+        __syncthreads();
+    }
+}
+
 // (F(k), F(k + 1)) mod p by fast doubling
 __host__ __device__ inline void fib_pair(u64 k, u64 &fk, u64 &fk1) {
     u64 a = 0, b = 1;                           // F(0), F(1)
@@ -190,11 +221,22 @@ int32_t run_checkpoints(zp_ctx *ctx, int logn, int Ww, int n, const u64 *d_init,
 int32_t run_expand(zp_ctx *ctx, int logn, int Ww, const u64 *d_ckpt, u64 *d_trace) {
     const int sl = seg_log_of(logn), cpl = (Ww + 63) / 64;
     const unsigned nseg = (unsigned)(((size_t)1 << logn) >> sl);
-    switch (cpl) {
-        case 1: hipLaunchKernelGGL(mix_expand_kernel<1>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
-        case 2: hipLaunchKernelGGL(mix_expand_kernel<2>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
-        case 3: hipLaunchKernelGGL(mix_expand_kernel<3>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
-        default: hipLaunchKernelGGL(mix_expand_kernel<4>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
+    // measured (profiles/r5_synth_fill_ab.txt): 2^22 x 64 2.57 -> 1.63 ms (kind 3), 3.31 -> 1.30 ms (kind 1); at 2^20 rows the 256 one-wave blocks
+    // do not fill the chip either way and the extra LDS pass loses 12-16 %: column runs from 2^21 rows
+    if (ctx->tune_synth_rowwise == 1 || (ctx->tune_synth_rowwise == 0 && logn < 21)) {
+        switch (cpl) {
+            case 1: hipLaunchKernelGGL(mix_expand_kernel<1>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
+            case 2: hipLaunchKernelGGL(mix_expand_kernel<2>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
+            case 3: hipLaunchKernelGGL(mix_expand_kernel<3>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
+            default: hipLaunchKernelGGL(mix_expand_kernel<4>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
+        }
+    } else {
+        switch (cpl) {
+            case 1: hipLaunchKernelGGL(mix_expand_tiled_kernel<1>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
+            case 2: hipLaunchKernelGGL(mix_expand_tiled_kernel<2>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
+            case 3: hipLaunchKernelGGL(mix_expand_tiled_kernel<3>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
+            default: hipLaunchKernelGGL(mix_expand_tiled_kernel<4>, dim3(nseg), dim3(64), 0, ctx->stream, d_ckpt, d_trace, logn, sl, Ww); break;
+        }
     }
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;

@@ -16,13 +16,20 @@ P = 0xFFFFFFFF00000001
     (3, 8, 12, None), (3, 13, 24, [11, 12, 13, 14, 15, 16]), (3, 14, 76, [P - 1, 0, 1, 2, 3]), (3, 17, 76, [1, 2, 3, 4, 5, 6]), (3, 1, 16, None),
 ])
 def test_device_trace_equals_host_trace(prover, kind, logn, W, bind):
+    """both expansion kernels (knob synth_rowwise: 1 = one store per lane and row, 2 = rows staged through LDS, written as column runs; the
+    default takes the second from 2^21 rows: profiles/r5_synth_fill_ab.txt)"""
     seed = 0xC0FFEE + 17 * logn + W
     tr, pub = native.synth_trace(kind, logn, W, seed, bind=bind)
-    d, dpub = prover.synth_trace_device(kind, logn, W, seed, bind=bind)
-    got = prover.download(d, (W, 1 << logn))
-    d.free()
-    assert (dpub == pub).all()
-    assert (got == tr).all()
+    for knob in (1, 2):
+        prover.set_tuning("synth_rowwise", knob)
+        try:
+            d, dpub = prover.synth_trace_device(kind, logn, W, seed, bind=bind)
+            got = prover.download(d, (W, 1 << logn))
+        finally:
+            prover.set_tuning("synth_rowwise", 0)
+        d.free()
+        assert (dpub == pub).all()
+        assert (got == tr).all()
 
 
 def test_batch_checkpoints_then_traces(prover):
