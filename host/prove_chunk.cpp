@@ -6,7 +6,7 @@
 // usage: prove_chunk <program.bin> <trace.bin> <publics.bin> <logn> <logb> <fri_logf> <fri_final_log> <n_queries> <pow_bits> <out.json> [air_name
 //                     [rank world id-file [run-nonce]]]
 //   with rank / world / id-file: ONE proof over `world` GPUs, one process per GPU (zp_stark_prove_sharded on an RCCL communicator; rank 0
-//   publishes the 128-byte RCCL id in <id-file>, the others wait for the record that carries this run's nonce: host/rendezvous.hpp).  Rank r reads only ITS W/world columns of trace.bin and drives GPU r;
+//   publishes the 128-byte RCCL id in <id-file>, the others wait for the record that carries this run's nonce: host/rendezvous.hpp).  Rank r reads only ITS columns of trace.bin (ceil(W / world) per rank, the tail ranks fewer) and drives GPU r;
 //   every rank obtains the same proof text (rank 0 writes <out.json>), byte for byte the single-GPU text.
 //   program.bin : the constraint program blob (u64 words, layout in the header)
 //   trace.bin   : u64[W][2^logn] column-major, canonical values
@@ -61,14 +61,16 @@ int main(int argc, char **argv) {
     if (pubs.size() != program[4]) { fprintf(stderr, "%s: %zu public inputs, the program declares %llu\n", argv[3], pubs.size(), (unsigned long long)program[4]); return 2; }
     for (uint64_t v : trace)
         if (v >= 0xFFFFFFFF00000001ULL) { fprintf(stderr, "%s: non-canonical trace value (precondition of zp_stark_prove)\n", argv[2]); return 2; }
-    if (world < 1 || rank < 0 || rank >= world || program[1] % (uint64_t)world) { fprintf(stderr, "bad rank / world (the %llu columns must split evenly)\n", (unsigned long long)program[1]); return 2; }
+    if (world < 1 || rank < 0 || rank >= world) { fprintf(stderr, "bad rank / world\n"); return 2; }
     zp_ctx *ctx = nullptr;
     CHECK(zp_create(&ctx, rank));                      // one process per GPU: rank r drives device r
-    const size_t wl = (size_t)program[1] / world, words = wl << logn;
-    const uint64_t *mine = trace.data() + (size_t)rank * words;        // this rank's columns (a real host would read only these)
+    // rank r owns columns [r wl, min((r + 1) wl, W)), wl = ceil(W / world): the tail ranks hold fewer columns, or none (include/zeth_prover.h)
+    const size_t Wc = (size_t)program[1], wl = (Wc + (size_t)world - 1) / (size_t)world, c0 = (size_t)rank * wl < Wc ? (size_t)rank * wl : Wc,
+                 cols = Wc - c0 < wl ? Wc - c0 : wl, words = cols << logn;
+    const uint64_t *mine = trace.data() + (c0 << logn);                // this rank's columns (a real host would read only these)
     void *d_trace = nullptr;
-    CHECK(zp_dev_alloc(ctx, words * 8, &d_trace));
-    CHECK(zp_h2d(ctx, d_trace, mine, words * 8));
+    CHECK(zp_dev_alloc(ctx, (words ? words : 1) * 8, &d_trace));
+    if (words) CHECK(zp_h2d(ctx, d_trace, mine, words * 8));
     char *json = nullptr;
     size_t len = 0;
     zp_comm *comm = nullptr;
