@@ -74,7 +74,7 @@ class EngineConfig:
                  witness_threads=8, prover_streams=8, pow_bits=20,
                  final_air="chunk16", final_logn=10, final_logb=2, final_queries=50, native_prover=True,
                  agg_queries=50, agg_pow_bits=0, aggregate_all_chunks=False, groth16_seed=None, witness="device",
-                 speculate_recursion=False, verify_before_wrap=True):
+                 speculate_recursion=False, verify_before_wrap=True, final_ranks=1, final_devices=None):
         self.air, self.logn, self.logb = air, logn, logb
         # GenFinalProof: check natively, before the final STARK and the wrap are made, what no query of the aggregation STARK covers (its
         # constraint identity at the out-of-domain point, its final layer, its grinding: stark/verifier.py).  Off only for timing experiments.
@@ -110,6 +110,10 @@ class EngineConfig:
         # (Merkle commitments), not idle latency -- made during the chunk proofs they slow those by what they take (16 chunks of 2^20 rows:
         # 0.336 + 0.229 s in sequence, 0.500 + 0.043 s overlapped; BASELINE configs[4]: 7.51 against 7.45 s).
         self.speculate_recursion = speculate_recursion
+        # final_ranks > 1 (a power of two): the final STARK is ONE proof over that many ranks of this process -- zp_stark_prove_sharded_bn128
+        # on an in-process communicator, rank r on final_devices[r] (default: all on the engine's GPU, which only rehearses the path).  Same
+        # text and wrap as with one rank (tests/test_gpu_verifier_air.py).  For a node whose GPUs would otherwise idle during GenFinalProof.
+        self.final_ranks, self.final_devices = final_ranks, final_devices
         self.prover_streams = prover_streams   # chunk proofs in flight on one GPU (each on its own ctx / stream); 8 measured best (profiles/r2_streams_sweep.txt)
         # the final STARK (BN128-hash mode, no grinding: 50 queries x blow-up 4 = 100 bits conjectured)
         self.final_air, self.final_logn, self.final_logb, self.final_queries = final_air, final_logn, final_logb, final_queries
@@ -525,7 +529,10 @@ class Engine:
         timings["verifier-witness"] = time.perf_counter() - t0
         params = params_of(shape)
         t0 = time.perf_counter()
-        if self.cfg.native_prover and hasattr(be, "prove_native"):
+        self._sharded_openings = None
+        if self.cfg.native_prover and self.cfg.final_ranks > 1 and params.hash == "bn128" and hasattr(be, "prove_native_sharded"):
+            text, self._sharded_openings = be.prove_native_sharded(vair, trace, pubs, params, self.cfg.final_ranks, self.cfg.final_devices)
+        elif self.cfg.native_prover and hasattr(be, "prove_native"):
             text = be.prove_native(vair, trace, pubs, params)
         else:
             text = PR.proof_to_json(PR.prove(vair, trace, pubs, params, be))
@@ -783,7 +790,9 @@ class Engine:
             raise e
         tmf["verify-aggregated-header(beside the final STARK)" if th is not None else "verify-aggregated-header"] = hdr["t"]
         openings = None
-        if self.cfg.native_prover and hasattr(self.be_bn128, "stark_openings"):
+        if getattr(self, "_sharded_openings", None) is not None:
+            openings = self._sharded_openings               # rank 0's record (cfg.final_ranks > 1)
+        elif self.cfg.native_prover and hasattr(self.be_bn128, "stark_openings"):
             openings = self.be_bn128.stark_openings()       # the prover's own binary record of what the text carries: no text round trip
         return fshape, fair, fp, final_stark, tmf, openings
 

@@ -212,6 +212,84 @@ class HipBackend:
         finally:
             d_tr.free()
 
+    def prove_native_sharded(self, air, trace, pubs, params, ranks, devices=None):
+        """ONE proof over `ranks` thread-ranks of this process (zp_stark_prove_sharded / zp_stark_prove_sharded_bn128 on an in-process
+        communicator, csrc/comm.hip: zp_comm_create_local): rank r drives devices[r] with a ctx of its own (default: every rank on this
+        backend's GPU -- the ranks then share its CUs, which is a rehearsal, not a speed-up).  Rank r takes ITS columns of the trace
+        (ceil(W / ranks) per rank, the tail ranks fewer: 47 columns of a verifier AIR over 8 ranks = 6 x 7 + 5).  Returns (proof text --
+        byte-identical to prove_native's --, rank 0's binary openings record in BN128 mode, else None).  The sharded provers run the
+        constraint program through the interpreter (row windows), whatever this backend's quotient mode."""
+        assert self.hash_mode == params.hash and ranks >= 1 and (ranks & (ranks - 1)) == 0
+        bn = params.hash == "bn128"
+        devs = list(devices) if devices else [self.p_device] * ranks
+        assert len(devs) == ranks
+        W, N = air.width, 1 << params.logn
+        with self._up_lock:
+            provers = getattr(self, "_rank_provers", None)
+            if provers is None or [d for d, _ in provers] != devs:
+                for _, q in provers or []:
+                    q.close()
+                provers = []
+                for d in devs:
+                    q = native.Prover(d)
+                    for kind, n in ((native.ZP_CONST_POSEIDON_RC, 360), (native.ZP_CONST_POSEIDON_MDS, 144), (native.ZP_CONST_ROOT32, 1),
+                                    (native.ZP_CONST_COSET_SHIFT, 1)):
+                        q.set_constants(kind, self.p.get_constants(kind, n))         # this backend's field / hash configuration
+                    if bn:
+                        q.install_poseidon_bn254(17)
+                    provers.append((d, q))
+                self._rank_provers = provers
+        dev_trace = isinstance(trace, native.DeviceBuffer)
+        if dev_trace:
+            self.p.sync()                                   # the witness builder's last kernels, before other ctxs read the buffer
+        host = None if dev_trace and all(d == self.p_device for d in devs) else (self.p.download(trace, (W, N)) if dev_trace else np.asarray(trace, dtype=np.uint64))
+        group = native.CommGroup(ranks)
+        texts, errs, rec = [None] * ranks, [None] * ranks, [None]
+        prog, pl = air.program(), [int(v) for v in pubs]
+
+        def body(r):
+            q = provers[r][1]
+            c, d_l = None, None
+            try:
+                c = native.Comm(q, r, ranks, group=group)
+                first, count = c.my_columns(W)
+                if count:
+                    if host is None:                        # same GPU: a device copy of my columns
+                        d_l = q.alloc(count * N)
+                        q.d2d(d_l, trace.ptr + first * N * 8, count * N * 8)
+                    else:
+                        d_l = q.upload(np.ascontiguousarray(host[first:first + count]))
+                texts[r] = c.stark_prove_sharded(air.name, prog, d_l, pl, params.logn, params.logb, params.fri_logf, params.fri_final_log, params.n_queries,
+                                                 0 if bn else params.pow_bits, bn128=bn)
+                if bn and r == 0:
+                    rec[0] = q.stark_openings()
+            except BaseException as e:                      # noqa: every rank's error is looked at below
+                errs[r] = e
+                if c is not None:
+                    try:
+                        c.abort()                           # the peers are inside the same collective call: free them
+                    except Exception:
+                        pass
+            finally:
+                if d_l is not None:
+                    d_l.free()
+                if c is not None:
+                    c.close()
+        ts = [threading.Thread(target=body, args=(r,), name="final-rank-%d" % r) for r in range(ranks)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        group.close()
+        if dev_trace:
+            trace.free()
+        bad = [e for e in errs if e is not None]
+        if bad:
+            real = [e for e in bad if not (isinstance(e, native.ZpError) and e.code == -6)]       # ZP_ERR_COMM: a peer of the rank that failed
+            raise (real or bad)[0]
+        assert all(t == texts[0] for t in texts)
+        return texts[0], rec[0]
+
     def poseidon_sponge(self, state, blocks, extra):
         return self.p.poseidon_sponge(state, blocks, extra)
 
