@@ -420,6 +420,45 @@ int32_t zp_program_digest(const uint64_t *h_program, size_t program_words, uint8
     return ZP_OK;
 }
 
+// The fixed columns of a program on its evaluation domain (zp_fixed_columns: boundary selectors + one extended period of every sparse periodic
+// column), from the ctx's cache: they depend on the domain and the program only; columns that hold public inputs (expected roots / indices /
+// transcript words of a verifier AIR: 37 of 104 at the service's size) are refreshed in place per proof, the others stay.  The buffer belongs
+// to the ctx.  (Both provers: the sharded one cuts its row windows out of it.)
+static int32_t fixed_columns_cached(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, const std::vector<ZpFixedCol> &fxc, const uint64_t *h_pubs,
+                             int32_t n_pubs, int32_t logn, int32_t logb, u64 shift, u64 root32, const char *dg_hex, u64 **out) {
+    bool has_pub = false;
+    for (const ZpFixedCol &fc : fxc) has_pub |= fc.has_pub;
+    const size_t fwords = zp_fixed_columns_words(h_program, program_words, logn, logb);
+    ZP_ARG(ctx, fwords != 0, "fixed column longer than the trace");
+    char key[128];
+    snprintf(key, sizeof key, "%d/%d/%llx/%llx/%s", logn, logb, (unsigned long long)shift, (unsigned long long)root32, fxc.empty() ? "" : dg_hex);
+    auto it = ctx->prove_fixed.find(key);
+    if (it != ctx->prove_fixed.end()) {
+        *out = it->second;
+        if (has_pub) {
+            ZpStage stage_fx(ctx, "fixed_columns");
+            PV_TRY(zpi_fixed_columns_build(ctx, h_program, program_words, h_pubs, n_pubs, logn, logb, shift, (uint64_t *)*out, fwords, true));
+        }
+        return ZP_OK;
+    }
+    // (a verifier AIR's columns are gigabytes -- 91 full-length columns at the service's size: 3 GB --; a ctx that has met many shapes
+    // starts over rather than grow without bound)
+    if (ctx->prove_fixed_bytes + fwords * 8 > ((size_t)24 << 30) && !ctx->prove_fixed.empty()) {
+        PV_TRY(zp_sync(ctx));
+        for (auto &kv : ctx->prove_fixed) (void)hipFree(kv.second);
+        ctx->prove_fixed.clear();
+        ctx->prove_fixed_bytes = 0;
+    }
+    void *pf = nullptr;
+    PV_TRY(zp_dev_alloc(ctx, fwords * 8, &pf));
+    const int32_t r = zp_fixed_columns(ctx, h_program, program_words, h_pubs, n_pubs, logn, logb, shift, (uint64_t *)pf, fwords);
+    if (r != ZP_OK) { (void)zp_dev_free(ctx, pf); return r; }
+    ctx->prove_fixed[key] = (u64 *)pf;
+    ctx->prove_fixed_bytes += fwords * 8;
+    *out = (u64 *)pf;
+    return ZP_OK;
+}
+
 static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint64_t *h_program, size_t program_words, const uint64_t *d_trace,
                           size_t trace_words, const uint64_t *h_pubs, int32_t n_pubs, int32_t logn, int32_t logb, int32_t fri_logf, int32_t fri_final_log,
                           int32_t n_queries, int32_t pow_bits, char **out_json, size_t *out_len) {
@@ -577,43 +616,7 @@ static int32_t prove_impl(zp_ctx *ctx, bool bn, const char *air_name, const uint
     mark("trace (+stage 2) committed");
     // 2. constraint quotient on the coset
     u64 *fixed, *dq, *dqcoef;
-    {
-        // the fixed columns on the evaluation domain (zp_fixed_columns: boundary selectors + one extended period of every sparse
-        // periodic column).  They depend on the domain and the program only -- cached per ctx --; columns that hold public
-        // inputs (expected roots / indices of a verifier AIR) are refreshed per proof.
-        bool has_pub = false;
-        for (const ZpFixedCol &fc : fxc) has_pub |= fc.has_pub;
-        const size_t fwords = zp_fixed_columns_words(h_program, program_words, logn, logb);
-        ZP_ARG(ctx, fwords != 0, "fixed column longer than the trace");
-        char key[128];
-        snprintf(key, sizeof key, "%d/%d/%llx/%llx/%s", logn, logb, (unsigned long long)shift, (unsigned long long)root32, fxc.empty() ? "" : dg_hex);
-        auto it = ctx->prove_fixed.find(key);
-        if (it != ctx->prove_fixed.end()) {
-            fixed = it->second;
-            // round 5: the statement's buffer is kept in either case; columns that hold public inputs (expected roots, indices, transcript
-            // words of a verifier AIR: 37 of 104 at the service's size) are refreshed in place for this proof, the others stay
-            if (has_pub) {
-                ZpStage stage_fx(ctx, "fixed_columns");
-                PV_TRY(zpi_fixed_columns_build(ctx, h_program, program_words, h_pubs, n_pubs, logn, logb, shift, (uint64_t *)fixed, fwords, true));
-            }
-        } else {
-            // (a verifier AIR's columns are gigabytes -- 91 full-length columns at the service's size: 3 GB --; a ctx that has met many shapes
-            // starts over rather than grow without bound)
-            if (ctx->prove_fixed_bytes + fwords * 8 > ((size_t)24 << 30) && !ctx->prove_fixed.empty()) {
-                PV_TRY(zp_sync(ctx));
-                for (auto &kv : ctx->prove_fixed) (void)hipFree(kv.second);
-                ctx->prove_fixed.clear();
-                ctx->prove_fixed_bytes = 0;
-            }
-            void *pf = nullptr;
-            PV_TRY(zp_dev_alloc(ctx, fwords * 8, &pf));
-            fixed = (u64 *)pf;
-            const int32_t r = zp_fixed_columns(ctx, h_program, program_words, h_pubs, n_pubs, logn, logb, shift, (uint64_t *)fixed, fwords);
-            if (r != ZP_OK) { (void)zp_dev_free(ctx, pf); return r; }
-            ctx->prove_fixed[key] = fixed;
-            ctx->prove_fixed_bytes += fwords * 8;
-        }
-    }
+    PV_TRY(fixed_columns_cached(ctx, h_program, program_words, fxc, h_pubs, n_pubs, logn, logb, shift, root32, dg_hex, &fixed));
     mark("fixed columns");
     std::vector<u64> apow(3 * K);
     {
@@ -1205,10 +1208,8 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
     u64 *dq_l;
     {
         const size_t fwords = zp_fixed_columns_words(h_program, program_words, logn, logb);
-        ZP_ARG(ctx, fwords != 0, "fixed column longer than the trace");
-        u64 *fixed, *fx_l;
-        PV_TRY(dev.alloc(fwords, &fixed));
-        PV_TRY(zp_fixed_columns(ctx, h_program, program_words, h_pubs, n_pubs, logn, logb, shift, (uint64_t *)fixed, fwords));
+        u64 *fixed, *fx_l;             // (round 5: from the ctx's cache, as in prove_impl -- they were rebuilt for every proof)
+        PV_TRY(fixed_columns_cached(ctx, h_program, program_words, fxc, h_pubs, n_pubs, logn, logb, shift, root32, dg_hex, &fixed));
         // my window of the two selectors, then the (whole, periodic) extra columns: the layout zp_eval_quotient_rows reads
         PV_TRY(dev.alloc(2 * nloc + (fwords - 2 * M), &fx_l));
         PV_TRY(zp_d2d(ctx, fx_l, fixed + r0, nloc * 8));
@@ -1249,7 +1250,6 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
             dev.release(buf);
         }
         PV_TRY(zp_sync(ctx));
-        dev.release(fixed);
         dev.release(fx_l);
     }
     // the quotient is needed whole on every rank: for its out-of-domain evaluation and, with Q > 1, for the coefficients its pieces are slices of
