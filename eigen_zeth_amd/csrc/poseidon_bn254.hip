@@ -35,8 +35,11 @@ struct P254Table {    // device tables of one instance, Montgomery form, 9 x u32
     u32 *d_a = nullptr;     // [rp][9]      the one constant of partial round j (element 0)
     u32 *d_sp = nullptr;    // [rp][2t-1][9]  per partial round: m00, v^_1 .. v^_(t-1), w_1 .. w_(t-1)
     u32 *d_rcb = nullptr;   // [t][9]       constants of the first full round after the partial rounds (+ the carried rest)
+    // the SCALED sparse form (round 5, cooperative kernels: perm_coop): per partial round A'_(j+1), V'_(j,1..t-1), W'_(j,1..t-1); tail: 1 / lambda_rp
+    u32 *d_sps = nullptr;   // [rp][2t-1][9]
+    u32 *d_spt = nullptr;   // [1][9]
 };
-struct P254Dev { const u32 *rc, *mds, *pre, *a, *sp, *rcb; int rp; };
+struct P254Dev { const u32 *rc, *mds, *pre, *a, *sp, *rcb, *sps, *spt; int rp; };
 // Installed tables: per DEVICE (a single-process multi-GPU host has a ctx per GPU), [0]: t = 3, [1]: t = 17; public constants, shared by
 // every ctx of the device.  A published table is never changed or freed: installing the same constants again is a no-op (the ranks of a
 // sharded proof all install before they prove), installing different ones publishes a new table and retires the old one, which a kernel
@@ -56,6 +59,29 @@ __device__ __forceinline__ fr fr_load(const u32 *p) {
 #pragma unroll
     for (int i = 0; i < 9; i++) r.l[i] = p[i];
     return r;
+}
+// sum of up to 18 normalised values (limb-wise in acc) -> the value mod r, normalised: a quotient estimate from the top limb (r's is 0x30644e:
+// the estimate is at most one short), one multiply-subtract row, one conditional subtraction -- a third of a Montgomery product, which is what
+// reducing such a sum by fr_mul(x, 1) costs
+__device__ __forceinline__ fr fr_reduce_small(const u64 *acc) {
+    u32 l[9];
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const u64 v = acc[i] + carry;
+        l[i] = i < 8 ? ((u32)v & FR_MASK) : (u32)v;
+        carry = v >> FR_B;
+    }
+    const u32 qe = l[8] / 0x30644fu;
+    u32 t[9];
+    long long c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const long long v = (long long)l[i] - (long long)((u64)qe * fr_p(i)) + c;
+        t[i] = i < 8 ? ((u32)v & FR_MASK) : (u32)v;
+        c = v >> FR_B;
+    }
+    return fr_norm_sub(t);                                 // value in [0, 2 r), limbs normalised
 }
 __device__ __forceinline__ fr sbox5(const fr &x) {
     const fr x2 = fr_mul(x, x), x4 = fr_mul(x2, x2);
@@ -119,6 +145,51 @@ __device__ __forceinline__ fr perm_coop(fr s, int q, int e, bool on, u32 (*sh)[T
         return s;
     }
     for (int r = 0; r < 4; r++) s = full_round<T>(s, q, e, on, sh, d.rc + (size_t)r * T * 9, r == 3 ? d.pre : d.mds);
+    if (d.sps != nullptr) {
+        // SCALED sparse form (round 5): lane 0 carries Y_j = lambda_j (s_0 + a_j) with lambda_(j+1) = lambda_j^5 / m00_j, so that
+        //     Y_(j+1) = Y_j^5 + sum_k V'_(j,k) s_k + A'_(j+1),      s_k <- s_k + W'_(j,k) Y_j^5      (V' = lambda_(j+1) v^, W' = w / lambda_j^5, A' = lambda a)
+        // -- THREE dependent products per round on the chain (Y^2, Y^4, Y^5) where the unscaled form below has five (x^2, x^4, x^5, m00 x^5 and the
+        // reduction of the row sum by a product with 1); the other lanes' two products (their update by the previous round's Y^5, then V' s_k)
+        // ride in the same instructions, and the row sum is reduced by fr_reduce_small.  Same field values on leaving the loop.
+        fr y = s, P = fr_zero();
+        if (on && e == 0) y = fr_add(s, fr_load(d.a));                       // Y_0 = s_0 + a_0 (lambda_0 = 1)
+        for (int j = 0; j < rp; j++) {
+            const u32 *S = d.sps + (size_t)j * (2 * T - 1) * 9;
+            const u32 *Sp = d.sps + (size_t)(j ? j - 1 : 0) * (2 * T - 1) * 9;
+            if (on) {
+                // product 1: lane 0 Y^2; lane k: W'_(j-1,k) Y_(j-1)^5 (P = 0 in round 0), added to s_k
+                const fr m1 = fr_mul(e == 0 ? y : fr_load(Sp + (size_t)(T - 1 + e) * 9), e == 0 ? y : P);
+                if (e != 0) s = fr_add(s, m1);
+                // product 2: lane 0 Y^4; lane k: V'_(j,k) s_k
+                fr m2 = fr_mul(e == 0 ? m1 : fr_load(S + (size_t)e * 9), e == 0 ? m1 : s);
+                if (e == 0) m2 = fr_mul(m2, y);                              // product 3: Y^5
+#pragma unroll
+                for (int i = 0; i < 9; i++) sh[q][e][i] = m2.l[i];
+            }
+            __syncthreads();
+            if (on) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) P.l[i] = sh[q][0][i];
+                if (e == 0) {
+                    u64 acc[9];
+                    const fr ap = fr_load(S);
+#pragma unroll
+                    for (int i = 0; i < 9; i++) acc[i] = (u64)P.l[i] + ap.l[i];
+                    for (int k = 1; k < T; k++) {
+#pragma unroll
+                        for (int i = 0; i < 9; i++) acc[i] += sh[q][k][i];
+                    }
+                    y = fr_reduce_small(acc);
+                }
+            }
+            __syncthreads();
+        }
+        if (on) {                                                            // leave the scaling: s_0 = Y_rp / lambda_rp; s_k takes the last Y^5
+            const u32 *Sl = d.sps + (size_t)(rp - 1) * (2 * T - 1) * 9;
+            const fr m = fr_mul(e == 0 ? y : fr_load(Sl + (size_t)(T - 1 + e) * 9), e == 0 ? fr_load(d.spt) : P);
+            s = e == 0 ? m : fr_add(s, m);
+        }
+    } else
     for (int j = 0; j < rp; j++) {
         const u32 *sp = d.sp + (size_t)j * (2 * T - 1) * 9;
         if (on) {
@@ -559,7 +630,10 @@ int bulk_threshold(zp_ctx *ctx) {
     const int lg = ctx->tune_p254_bulk_log > 0 ? ctx->tune_p254_bulk_log : 14;
     return lg >= 31 ? 0x7FFFFFFF : (1 << lg);
 }
-P254Dev dev_of(const P254Table *tb) { return P254Dev{tb->d_rc, tb->d_mds, tb->d_pre, tb->d_a, tb->d_sp, tb->d_rcb, tb->rp}; }
+P254Dev dev_of(const zp_ctx *ctx, const P254Table *tb) {       // (zp_set_tuning "p254_scaled" = 2: the cooperative kernels on the unscaled sparse form, for the A/B)
+    const bool scaled = ctx->tune_p254_scaled != 2 && tb->d_sps && tb->d_spt;
+    return P254Dev{tb->d_rc, tb->d_mds, tb->d_pre, tb->d_a, tb->d_sp, tb->d_rcb, scaled ? tb->d_sps : nullptr, scaled ? tb->d_spt : nullptr, tb->rp};
+}
 
 // ---- host: the sparse form of the partial rounds (column-vector convention, values in Montgomery form) ----
 // round j (0 <= j < rp) of the textbook is  x <- M sigma(x + c_j),  sigma = x^5 on element 0.  Backwards from the last round,
@@ -663,6 +737,28 @@ bool sparse_form(const FrVec &rc, const FrVec &M, int t, int rp, FrVec &pre, FrV
     for (int k = 0; k < t; k++) rcb[k] = fr_add(rc[(size_t)(4 + rp) * t + k], carry[k]);
     return true;
 }
+// the scaled sparse form of the partial rounds (perm_coop): from a (rp) and sp (rp x (2t-1): m00, v^_1.., w_1..) the per-round rows
+// [A'_(j+1), V'_(j,k) = lambda_(j+1) v^_(j,k), W'_(j,k) = w_(j,k) / lambda_j^5] and the tail 1 / lambda_rp, lambda_0 = 1, lambda_(j+1) = lambda_j^5 / m00_j,
+// A'_j = lambda_j a_j, A'_rp = 0.  false when some m00 is zero.
+bool scaled_sparse_form(const FrVec &a, const FrVec &sp, int t, int rp, FrVec &sps, FrVec &spt) {
+    sps.assign((size_t)rp * (2 * t - 1), fr_zero());
+    fr lam = fr_one();
+    for (int j = 0; j < rp; j++) {
+        const fr *S = &sp[(size_t)j * (2 * t - 1)];
+        if (fr_is_zero(S[0])) return false;
+        const fr l2 = fr_mul(lam, lam), l5 = fr_mul(fr_mul(l2, l2), lam);
+        const fr next = fr_mul(l5, h_inv_fr(S[0])), l5inv = h_inv_fr(l5);
+        fr *O = &sps[(size_t)j * (2 * t - 1)];
+        O[0] = j + 1 < rp ? fr_mul(next, a[j + 1]) : fr_zero();
+        for (int k = 1; k < t; k++) {
+            O[k] = fr_mul(next, S[k]);
+            O[t - 1 + k] = fr_mul(S[t - 1 + k], l5inv);
+        }
+        lam = next;
+    }
+    spt.assign(1, h_inv_fr(lam));
+    return true;
+}
 int32_t upload_fr(zp_ctx *ctx, const FrVec &v, u32 **d) {
     std::vector<u32> flat(v.size() * 9);
     for (size_t i = 0; i < v.size(); i++) memcpy(&flat[i * 9], v[i].l, 36);
@@ -706,6 +802,11 @@ int32_t zp_set_poseidon_bn254(zp_ctx *ctx, int32_t t, int32_t rp, const uint64_t
         ZP_TRY(upload_fr(ctx, a, &tb->d_a));
         ZP_TRY(upload_fr(ctx, sp, &tb->d_sp));
         ZP_TRY(upload_fr(ctx, rcb, &tb->d_rcb));
+        FrVec sps, spt;
+        if (scaled_sparse_form(a, sp, t, rp, sps, spt)) {        // (a zero m00 somewhere: the cooperative kernels keep the unscaled form)
+            ZP_TRY(upload_fr(ctx, sps, &tb->d_sps));
+            ZP_TRY(upload_fr(ctx, spt, &tb->d_spt));
+        }
     }
     ZP_HIP(ctx, hipMalloc((void **)&tb->d_rc, rc.size() * 4));
     ZP_HIP(ctx, hipMalloc((void **)&tb->d_mds, md.size() * 4));
@@ -727,13 +828,13 @@ int32_t zp_poseidon_bn254_perm(zp_ctx *ctx, uint64_t *d_states, size_t count, in
     ZP_ARG(ctx, d_states != nullptr, "null device pointer");
     if (t == 3)
         hipLaunchKernelGGL(poseidon254_perm_kernel<3>, dim3((unsigned)((count + 20) / 21)), dim3(64), 0, ctx->stream, (u64 *)d_states, count,
-                           dev_of(tb));
+                           dev_of(ctx, tb));
     else if (count >= (size_t)bulk_threshold(ctx))     // one lane per permutation once there are enough of them to fill the chip
         hipLaunchKernelGGL(p254_bulk_kernel<0>, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, (const u64 *)nullptr, (size_t)0, 0,
-                           (u64 *)d_states, count, dev_of(tb));
+                           (u64 *)d_states, count, dev_of(ctx, tb));
     else
         hipLaunchKernelGGL(poseidon254_perm_kernel<17>, dim3((unsigned)((count + 2) / 3)), dim3(64), 0, ctx->stream, (u64 *)d_states, count,
-                           dev_of(tb));
+                           dev_of(ctx, tb));
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
 }
@@ -766,7 +867,7 @@ int32_t zp_poseidon_bn254_sponge_caps(zp_ctx *ctx, uint64_t *h_state, const uint
     ZP_TRY(zpi_scratch(ctx, 3, words, &d));
     ZP_TRY(zpi_h2d_small(ctx, d, h.data(), (17 + nblocks * 16) * 32));
     u64 *d_caps = d + (17 + nblocks * 16 + nrate * 16) * 4;
-    hipLaunchKernelGGL(poseidon254_sponge_kernel, dim3(1), dim3(64), 0, ctx->stream, d, (int)nblocks, (int)extra, h_caps ? d_caps : (u64 *)nullptr, dev_of(tb));
+    hipLaunchKernelGGL(poseidon254_sponge_kernel, dim3(1), dim3(64), 0, ctx->stream, d, (int)nblocks, (int)extra, h_caps ? d_caps : (u64 *)nullptr, dev_of(ctx, tb));
     ZP_HIP(ctx, hipGetLastError());
     if (h_caps) ZP_TRY(zpi_d2h_small(ctx, h_caps, d_caps, nperm * 32));
     ZP_TRY(zpi_d2h_small(ctx, h_rates, d + (17 + nblocks * 16) * 4, nrate * 16 * 32));
@@ -789,10 +890,10 @@ int32_t zp_merkle16_commit_bn254(zp_ctx *ctx, const uint64_t *d_cols, size_t M, 
     const size_t bulk = (size_t)bulk_threshold(ctx);
     if (M >= bulk)
         hipLaunchKernelGGL(p254_bulk_kernel<1>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, ctx->stream, (const u64 *)d_cols, M, (int)W,
-                           (u64 *)d_tree, M, dev_of(tb));
+                           (u64 *)d_tree, M, dev_of(ctx, tb));
     else
         hipLaunchKernelGGL(merkle16_leaves_kernel, dim3((unsigned)((M + 2) / 3)), dim3(64), 0, ctx->stream, (const u64 *)d_cols, M, (int)W,
-                           (u64 *)d_tree, dev_of(tb));
+                           (u64 *)d_tree, dev_of(ctx, tb));
     ZP_HIP(ctx, hipGetLastError());
     return zpi_merkle16_levels_bn254(ctx, (u64 *)d_tree, M);
 }
@@ -856,10 +957,10 @@ int32_t zpi_merkle16_levels_bn254(zp_ctx *ctx, u64 *d_tree, size_t n) {
         const size_t nn = (n + 15) / 16;
         if (nn >= bulk)
             hipLaunchKernelGGL(p254_bulk_kernel<2>, dim3((unsigned)((nn + 63) / 64)), dim3(64), 0, ctx->stream, (const u64 *)d_tree + off * 4, n, 0,
-                               (u64 *)d_tree + (off + n) * 4, nn, dev_of(tb));
+                               (u64 *)d_tree + (off + n) * 4, nn, dev_of(ctx, tb));
         else
             hipLaunchKernelGGL(merkle16_level_kernel, dim3((unsigned)((nn + 2) / 3)), dim3(64), 0, ctx->stream, (const u64 *)d_tree + off * 4, n,
-                               (u64 *)d_tree + (off + n) * 4, nn, dev_of(tb));
+                               (u64 *)d_tree + (off + n) * 4, nn, dev_of(ctx, tb));
         ZP_HIP(ctx, hipGetLastError());
         off += n;
         n = nn;
@@ -876,7 +977,7 @@ int32_t zpi_r1cs_poseidon17(zp_ctx *ctx, const u64 *d_inst, size_t i0, size_t co
     if (rp_out) *rp_out = tb->rp;
     if (count == 0) return ZP_OK;
     hipLaunchKernelGGL(r1cs_poseidon17_kernel, dim3((unsigned)((count + 2) / 3)), dim3(64), 0, ctx->stream, d_inst, i0, count, d_w, d_set, d_a, d_b, d_c, d_flags,
-                       dev_of(tb));
+                       dev_of(ctx, tb));
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
 }
