@@ -154,6 +154,38 @@ __global__ void __launch_bounds__(64) poseidon_perm_small_kernel(u64 *states, in
     if (on) states[(size_t)perm * 12 + e] = gl_canon(s);
 }
 
+// one permutation of the state a wave holds in its lanes 0..11 (the single-wave kernels: transcript steps, recursion-witness walks)
+// (the round constants come from LDS -- rcs: all 360, loaded once per kernel by wave12_tables -- and the lane's matrix row from registers: a
+// permutation of these single-wave kernels is a chain of 30 dependent rounds, and a global load of a constant sat in every link)
+__device__ __forceinline__ void wave12_tables(int e, bool on, const u64 *rc, const u32 *mds, u64 *rcs, u32 *row) {
+    for (int i = threadIdx.x; i < 360; i += 64) rcs[i] = rc[i];
+#pragma unroll
+    for (int j = 0; j < 12; j++) row[j] = mds[(on ? e : 0) * 12 + j];
+    __syncthreads();
+}
+__device__ __forceinline__ u64 wave12_perm(u64 s, int e, bool on, u64 *sh, const u64 *rcs, const u32 *row) {
+    for (int r = 0; r < 30; r++) {
+        s = gl_add_weak(s, rcs[r * 12 + (on ? e : 0)]);
+        if (r < 4 || r >= 26 || e == 0) s = sbox7(s);
+        if (on) sh[e] = s;
+        __syncthreads();
+        u64 alo = 0, ahi = 0;
+        if (on) {
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const u64 v = sh[j];
+                const u32 m = row[j];
+                alo += (u64)m * (u32)v;
+                ahi += (u64)m * (u32)(v >> 32);
+            }
+        }
+        __syncthreads();
+        const u64 mid = (alo >> 32) + ahi;
+        s = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
+    }
+    return gl_canon(s);
+}
+
 // The Fiat-Shamir sponge as ONE launch: buf = [12 state words][nblocks x 8 block words][(1 + extra) x 8 rate words out].
 // For every block: the rate (state[0..8)) is overwritten with the block, then one permutation (no block: one permutation);
 // then `extra` further permutations, the rate after each of the 1 + extra steps is written out.  Same 12-lanes-per-state form
@@ -162,33 +194,17 @@ __global__ void __launch_bounds__(64) poseidon_perm_small_kernel(u64 *states, in
 // input state of every permutation of the step, what the verifier AIR's witness needs (stark/verifier_air.py: transcript blocks).
 __global__ void __launch_bounds__(64) poseidon_sponge_kernel(u64 *buf, int nblocks, int extra, const u64 *rc, const u32 *mds, u64 *caps) {
     __shared__ u64 sh[12];
+    __shared__ u64 rcs[360];
     const int e = threadIdx.x;
     const bool on = e < 12;
+    u32 row[12];
+    wave12_tables(e, on, rc, mds, rcs, row);
     u64 s = on ? buf[e] : 0ULL;
     u64 *rates = buf + 12 + (size_t)nblocks * 8;
     const int absorb = nblocks > 0 ? nblocks : 1;
     for (int b = 0; b < absorb + extra; b++) {
         if (b < nblocks && e < 8) s = buf[12 + (size_t)b * 8 + e];
-        for (int r = 0; r < 30; r++) {
-            s = gl_add_weak(s, rc[r * 12 + (on ? e : 0)]);
-            if (r < 4 || r >= 26 || e == 0) s = sbox7(s);
-            if (on) sh[e] = s;
-            __syncthreads();
-            u64 alo = 0, ahi = 0;
-            if (on) {
-#pragma unroll
-                for (int j = 0; j < 12; j++) {
-                    const u64 v = sh[j];
-                    const u32 m = mds[e * 12 + j];
-                    alo += (u64)m * (u32)v;
-                    ahi += (u64)m * (u32)(v >> 32);
-                }
-            }
-            __syncthreads();
-            const u64 mid = (alo >> 32) + ahi;
-            s = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
-        }
-        s = gl_canon(s);
+        s = wave12_perm(s, e, on, sh, rcs, row);
         if (b >= absorb - 1 && e < 8) rates[(size_t)(b - (absorb - 1)) * 8 + e] = s;
         if (caps && on && e >= 8) caps[(size_t)b * 4 + (e - 8)] = s;
     }
@@ -202,8 +218,11 @@ __global__ void __launch_bounds__(64) poseidon_sponge_kernel(u64 *buf, int nbloc
 __global__ void __launch_bounds__(64) poseidon_sponge_pinned_kernel(u64 *buf, int nblocks, int extra, const u64 *rc, const u32 *mds, int want_caps) {
     extern __shared__ u64 stage[];              // [12 + nblocks * 8]
     __shared__ u64 sh[12];
+    __shared__ u64 rcs[360];
     const int e = threadIdx.x;
     const bool on = e < 12;
+    u32 row[12];
+    wave12_tables(e, on, rc, mds, rcs, row);
     const int nin = 12 + nblocks * 8;
     for (int i = e; i < nin; i += 64) stage[i] = buf[i];
     __syncthreads();
@@ -212,26 +231,7 @@ __global__ void __launch_bounds__(64) poseidon_sponge_pinned_kernel(u64 *buf, in
     const int absorb = nblocks > 0 ? nblocks : 1;
     for (int b = 0; b < absorb + extra; b++) {
         if (b < nblocks && e < 8) s = stage[12 + b * 8 + e];
-        for (int r = 0; r < 30; r++) {
-            s = gl_add_weak(s, rc[r * 12 + (on ? e : 0)]);
-            if (r < 4 || r >= 26 || e == 0) s = sbox7(s);
-            if (on) sh[e] = s;
-            __syncthreads();
-            u64 alo = 0, ahi = 0;
-            if (on) {
-#pragma unroll
-                for (int j = 0; j < 12; j++) {
-                    const u64 v = sh[j];
-                    const u32 m = mds[e * 12 + j];
-                    alo += (u64)m * (u32)v;
-                    ahi += (u64)m * (u32)(v >> 32);
-                }
-            }
-            __syncthreads();
-            const u64 mid = (alo >> 32) + ahi;
-            s = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
-        }
-        s = gl_canon(s);
+        s = wave12_perm(s, e, on, sh, rcs, row);
         if (b >= absorb - 1 && e < 8) rates[(size_t)(b - (absorb - 1)) * 8 + e] = s;
         if (want_caps && on && e >= 8) caps[(size_t)b * 4 + (e - 8)] = s;
     }
@@ -239,42 +239,21 @@ __global__ void __launch_bounds__(64) poseidon_sponge_pinned_kernel(u64 *buf, in
 }
 
 // ---- the hashing walk of a recursion witness on the device (csrc/recursion.hip, round 5): no host round trip per permutation
-// one permutation of the state a wave holds in its lanes 0..11 (same arithmetic as the sponge kernels above)
-__device__ __forceinline__ u64 wave12_perm(u64 s, int e, bool on, u64 *sh, const u64 *rc, const u32 *mds) {
-    for (int r = 0; r < 30; r++) {
-        s = gl_add_weak(s, rc[r * 12 + (on ? e : 0)]);
-        if (r < 4 || r >= 26 || e == 0) s = sbox7(s);
-        if (on) sh[e] = s;
-        __syncthreads();
-        u64 alo = 0, ahi = 0;
-        if (on) {
-#pragma unroll
-            for (int j = 0; j < 12; j++) {
-                const u64 v = sh[j];
-                const u32 m = mds[e * 12 + j];
-                alo += (u64)m * (u32)v;
-                ahi += (u64)m * (u32)(v >> 32);
-            }
-        }
-        __syncthreads();
-        const u64 mid = (alo >> 32) + ahi;
-        s = gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
-    }
-    return gl_canon(s);
-}
-
 // Whole Fiat-Shamir transcripts in ONE launch: workgroup c walks the steps [first[c], first[c + 1]) of chain c from the zero state; a step
 // overwrites the rate with its block (absorb[s] != 0) or just permutes; out[s] = the 12 words entering the permutation, then the rate after it
 __global__ void __launch_bounds__(64) sponge_chains_kernel(const u64 *__restrict__ blocks, const unsigned char *__restrict__ absorb,
                                                            const unsigned int *__restrict__ first, u64 *__restrict__ out, const u64 *rc, const u32 *mds) {
     __shared__ u64 sh[12];
+    __shared__ u64 rcs[360];
     const int e = threadIdx.x;
     const bool on = e < 12;
+    u32 row[12];
+    wave12_tables(e, on, rc, mds, rcs, row);
     u64 s = 0;
     for (unsigned int st = first[blockIdx.x]; st < first[blockIdx.x + 1]; st++) {
         if (absorb[st] && e < 8) s = blocks[(size_t)st * 8 + e];
         if (on) out[(size_t)st * 20 + e] = s;
-        s = wave12_perm(s, e, on, sh, rc, mds);
+        s = wave12_perm(s, e, on, sh, rcs, row);
         if (e < 8) out[(size_t)st * 20 + 12 + e] = s;
     }
 }
@@ -289,8 +268,11 @@ __global__ void __launch_bounds__(64) openings_walk_kernel(const u64 *__restrict
                                                            u64 *__restrict__ digests, const u64 *rc, const u32 *mds) {
     __shared__ u64 sh[12];
     __shared__ u64 cur[4];
+    __shared__ u64 rcs[360];
     const int e = threadIdx.x;
     const bool on = e < 12;
+    u32 row[12];
+    wave12_tables(e, on, rc, mds, rcs, row);
     const u64 o = blockIdx.x, b0 = op[3 * o], na = op[3 * o + 1], nd = op[3 * o + 2];
     const u64 *v = vals + o * mw;
     u64 s = 0;
@@ -298,7 +280,7 @@ __global__ void __launch_bounds__(64) openings_walk_kernel(const u64 *__restrict
     for (u64 j = 0; j < na; j++) {
         if (e < 8) s = 8 * j + e < mw ? v[8 * j + e] : 0ULL;
         if (on) inputs[(b0 + j) * 12 + e] = s;
-        s = wave12_perm(s, e, on, sh, rc, mds);
+        s = wave12_perm(s, e, on, sh, rcs, row);
         if (on) sh[e] = s;
         __syncthreads();
         if (e >= 8 && on) s = sh[e - 8];                    // the digest so far is the next block's capacity
@@ -317,7 +299,7 @@ __global__ void __launch_bounds__(64) openings_walk_kernel(const u64 *__restrict
             inputs[(b0 + na + lv) * 12 + e] = s;
         }
         __syncthreads();
-        s = wave12_perm(s, e, on, sh, rc, mds);
+        s = wave12_perm(s, e, on, sh, rcs, row);
         if (e < 4) cur[e] = s;
         __syncthreads();
     }
