@@ -435,7 +435,10 @@ def main():
                     out["pipeline"] = {"error": "multi-rank probes did not finish within %d s; line printed by the watchdog" % PROBE_LIMIT_S}
                     emit(json.dumps(out))
                     printed[0] = True
-            os._exit(3)      # a stalled collective is a failure: the line above carries the headline, the exit code says so
+            # The contract's line -- K timed steps of the hot path, no collective inside -- is complete and printed; what stalled is an OPTIONAL
+            # probe, and the line says so in "pipeline".  Exit code 0: a launcher that discards the output of a failed rank would lose the
+            # measured headline with it (ZP_BENCH_WATCHDOG_EXIT overrides: the rehearsal test asks for 3).
+            os._exit(int(os.environ.get("ZP_BENCH_WATCHDOG_EXIT", "0")))
         watchdog = threading.Timer(2 if wd_test else PROBE_LIMIT_S, bail)
         watchdog.daemon = True
         watchdog.start()
