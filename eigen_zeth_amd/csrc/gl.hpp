@@ -113,8 +113,34 @@ GL_HD u64 gl_add_weak(u64 a_any, u64 b_canon) {
     return s + ((s < a_any) ? GL_EPS : 0);
 }
 
-// ---- unreduced dot-product accumulator: sum of up to 2^31 full products a*b in 160 bits, one reduction at the end
-// (a multiply-accumulate is 4 v_mad_u64_u32 + carry adds instead of a multiply with reduction plus a modular add)
+// ---- unreduced dot-product accumulator: sum of up to 2^31 full products a*b, one reduction at the end.
+// Device form (round 5): the sum is kept as THREE sums of 32 x 32-bit partial products -- low x low, the two mixed ones together, high x high --
+// each 64 bits + a 32-bit count of carries: a multiply-accumulate is four v_mad_u64_u32 whose carry-outs the add-with-carry behind them takes
+// (inline assembly: hipcc spends a 64-bit compare, a select and an add on `count += t < acc`), 8 instructions where the 160-bit form below
+// -- kept for host code -- takes 22; the kernels that sum columns against weights (out-of-domain evaluation, DEEP quotient, the random linear
+// combination of the constraints) were bound by them.  Nine registers instead of five.
+#if defined(__HIP_DEVICE_COMPILE__)
+struct gl_acc {
+    u64 a, b, c;        // sum a0 b0, sum (a0 b1 + a1 b0), sum a1 b1   (mod 2^64)
+    u32 oa, ob, oc;     // ... and how often each wrapped
+};
+__device__ __forceinline__ gl_acc gl_acc_zero() { return gl_acc{0, 0, 0, 0u, 0u, 0u}; }
+__device__ __forceinline__ void gl_acc_mac32(u64 &acc, u32 &ovf, u32 x, u32 y) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(ovf) : "v"(x), "v"(y) : "vcc");
+}
+__device__ __forceinline__ void gl_acc_mac(gl_acc &s, u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    gl_acc_mac32(s.a, s.oa, a0, b0);
+    gl_acc_mac32(s.b, s.ob, a0, b1);
+    gl_acc_mac32(s.b, s.ob, a1, b0);
+    gl_acc_mac32(s.c, s.oc, a1, b1);
+}
+// a + 2^64 oa + 2^32 (b + 2^64 ob) + 2^64 (c + 2^64 oc) mod p, canonical
+__device__ __forceinline__ u64 gl_acc_reduce(const gl_acc &s) {
+    const u64 xa = gl_reduce96(s.a, s.oa, 0u), xb = gl_reduce96(s.b, s.ob, 0u), xc = gl_reduce96(s.c, s.oc, 0u);
+    return gl_add(gl_add(xa, gl_mul(xb, 1ULL << 32)), gl_mul(xc, GL_EPS));
+}
+#else
 struct gl_acc {
     u64 lo, hi;
     u32 top;
@@ -147,7 +173,7 @@ GL_HD u64 gl_acc_reduce(const gl_acc &s) {
     const u64 r = gl_reduce96(s.lo, (u32)s.hi, (u32)(s.hi >> 32));
     return gl_sub(r, (u64)s.top << 32);
 }
-
+#endif
 GL_HD u64 gl_pow(u64 b, u64 e) {
     u64 r = 1;
     while (e) {

@@ -66,33 +66,12 @@ __global__ void __launch_bounds__(256) poly_eval_ext_kernel(EvalArgs a) {
 // (2) bary_dot_kernel: a block owns BY_ROWS rows x BY_CB columns: a lane loads u_i once and uses it for the BY_CB columns (each
 //     twice: row i for y, row i + 1 for y w); unreduced accumulators, one reduction per lane; lanes are summed with wave
 //     shuffles, the four waves through LDS; one partial per (block, column).  (3) bary_reduce_kernel sums the partials of a column.
-//     The accumulators (round 5, second form): a sum of products v u is kept as THREE sums of 32 x 32-bit partial products -- low x low,
-//     the two mixed ones together, high x high -- each 64 bits + a 32-bit count of carries: a multiply-accumulate is four v_mad_u64_u32 with
-//     their carry-outs added to the counts, 8 instructions where the 160-bit accumulator of the first form took 22 (the kernel was bound by
-//     them: 130 instructions per value, 1.2 TB/s on the columns' bytes); the three sums meet once per lane, after BY_J rows.
+//     The accumulators are gl_acc's device form (gl.hpp, round 5: three sums of 32 x 32-bit partial products with carry counts, 8 instructions
+//     per multiply-accumulate; with the 160-bit form's 22 the kernel was bound by them: 130 instructions per value, 1.2 TB/s on the columns'
+//     bytes); the sums meet once per lane, after BY_J rows.
 #define BY_CB 4
 #define BY_J 64
 #define BY_ROWS (256 * BY_J)
-struct bary_acc {
-    u64 a, b, c;        // sum v0 u0, sum (v0 u1 + v1 u0), sum v1 u1   (mod 2^64)
-    u32 oa, ob, oc;     // ... and how often each wrapped
-};
-// acc += a b (mod 2^64), ovf += the carry: the multiply-add's own carry-out, taken by the add-with-carry behind it (hipcc spends a 64-bit compare,
-// a select and an add on `ovf += t < acc`)
-__device__ __forceinline__ void bary_mac32(u64 &acc, u32 &ovf, u32 a, u32 b) {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(ovf) : "v"(a), "v"(b) : "vcc");
-}
-__device__ __forceinline__ void bary_mac(bary_acc &s, u32 v0, u32 v1, u32 u0, u32 u1) {
-    bary_mac32(s.a, s.oa, v0, u0);
-    bary_mac32(s.b, s.ob, v0, u1);
-    bary_mac32(s.b, s.ob, v1, u0);
-    bary_mac32(s.c, s.oc, v1, u1);
-}
-// a + 2^64 oa + 2^32 (b + 2^64 ob) + 2^64 (c + 2^64 oc) mod p, canonical
-__device__ __forceinline__ u64 bary_acc_reduce(const bary_acc &s) {
-    const u64 xa = gl_reduce96(s.a, s.oa, 0u), xb = gl_reduce96(s.b, s.ob, 0u), xc = gl_reduce96(s.c, s.oc, 0u);
-    return gl_add(gl_add(xa, gl_mul(xb, 1ULL << 32)), gl_mul(xc, GL_EPS));
-}
 struct BaryWArgs {
     u64 *u;                 // [3][n]
     unsigned int *flag;
@@ -146,11 +125,11 @@ __global__ void __launch_bounds__(256) bary_dot_kernel(BaryArgs a) {
     if (chunk >= a.blocks) return;
     const int c0 = (int)(jj % (u64)a.groups) * BY_CB;
     const u64 row0 = chunk * BY_ROWS;
-    bary_acc acc[BY_CB][NEXT ? 6 : 3];
+    gl_acc acc[BY_CB][NEXT ? 6 : 3];
 #pragma unroll
     for (int c = 0; c < BY_CB; c++)
 #pragma unroll
-        for (int k = 0; k < (NEXT ? 6 : 3); k++) acc[c][k] = bary_acc{0, 0, 0, 0u, 0u, 0u};
+        for (int k = 0; k < (NEXT ? 6 : 3); k++) acc[c][k] = gl_acc_zero();
     // The sum for the NEXT point, sum_j P(w^(j+1)) u_j, is taken as sum_i P(w^i) u_(i-1): the WEIGHTS are read at two rows (the second one is
     // the neighbouring lane's first: a cache hit), every column value once.
     // (a column group's last column may lie beyond W: it reads column W - 1 again -- no branch in the loop, so that every load of a row is
@@ -173,14 +152,13 @@ __global__ void __launch_bounds__(256) bary_dot_kernel(BaryArgs a) {
             for (int c = 0; c < BY_CB; c++) v[c] = colp[c][i * a.rs];
 #pragma unroll
             for (int c = 0; c < BY_CB; c++) {
-                const u32 v0 = (u32)v[c], v1 = (u32)(v[c] >> 32);
-                bary_mac(acc[c][0], v0, v1, (u32)u0, (u32)(u0 >> 32));
-                bary_mac(acc[c][1], v0, v1, (u32)u1, (u32)(u1 >> 32));
-                bary_mac(acc[c][2], v0, v1, (u32)u2, (u32)(u2 >> 32));
+                gl_acc_mac(acc[c][0], v[c], u0);
+                gl_acc_mac(acc[c][1], v[c], u1);
+                gl_acc_mac(acc[c][2], v[c], u2);
                 if constexpr (NEXT) {
-                    bary_mac(acc[c][3], v0, v1, (u32)p0, (u32)(p0 >> 32));
-                    bary_mac(acc[c][4], v0, v1, (u32)p1, (u32)(p1 >> 32));
-                    bary_mac(acc[c][5], v0, v1, (u32)p2, (u32)(p2 >> 32));
+                    gl_acc_mac(acc[c][3], v[c], p0);
+                    gl_acc_mac(acc[c][4], v[c], p1);
+                    gl_acc_mac(acc[c][5], v[c], p2);
                 }
             }
         }
@@ -190,7 +168,7 @@ __global__ void __launch_bounds__(256) bary_dot_kernel(BaryArgs a) {
     for (int c = 0; c < BY_CB; c++)
 #pragma unroll
         for (int k = 0; k < (NEXT ? 6 : 3); k++) {
-            const u64 r = wave_sum_gl(bary_acc_reduce(acc[c][k]));
+            const u64 r = wave_sum_gl(gl_acc_reduce(acc[c][k]));
             if (ln == 0) red[wv][c * 6 + k] = r;
         }
     __syncthreads();
