@@ -205,13 +205,25 @@ struct DeepArgs {
     u64 shift;               // shift * w_M^row0 for a row window
     u64 nrows, sa, sb, so;   // rows of this launch; column strides of cols_a, cols_b, out
     int logm, Wa, Wb, nnext, lb;
+    int pair_ok;             // column strides and base pointers allow 16-byte loads of row pairs
 };
 
 // numerators and denominators of one row: A = sum g^k p_k(x) - c_a, B = (prefix over the first nnext columns) g^W - c_b,
 // d1 = x - z, d2 = x - zw
 struct DeepRow { e3 A, B, d1, d2; };
+// what follows the column sums of a row: the constant terms and the two denominators
+__device__ __forceinline__ void deep_finish(const DeepArgs &a, u64 r, DeepRow &o) {
+    const int W = a.Wa + a.Wb;
+    if (a.nnext >= W) o.B = o.A;
+    if (a.nnext > 0) o.B = e3_mul(o.B, e3_make(a.gpow[W * 3], a.gpow[W * 3 + 1], a.gpow[W * 3 + 2]));
+    o.A = e3_sub(o.A, e3_make(a.ca[0], a.ca[1], a.ca[2]));
+    o.B = e3_sub(o.B, e3_make(a.cb[0], a.cb[1], a.cb[2]));
+    const u64 x = gl_mul(a.shift, gl_mul(a.twl[r & ((1ULL << a.lb) - 1)], a.twh[r >> a.lb]));
+    o.d1 = e3_make(gl_sub(x, a.z[0]), gl_neg(a.z[1]), gl_neg(a.z[2]));
+    o.d2 = e3_make(gl_sub(x, a.zw[0]), gl_neg(a.zw[1]), gl_neg(a.zw[2]));
+}
 __device__ __forceinline__ DeepRow deep_row(const DeepArgs &a, u64 r) {
-    // three unreduced 160-bit dot products; the second sum runs over the same columns with the powers shifted by W, so it is
+    // three unreduced dot products; the second sum runs over the same columns with the powers shifted by W, so it is
     // g^W times the prefix of A over the first nnext columns
     gl_acc s0 = gl_acc_zero(), s1 = gl_acc_zero(), s2 = gl_acc_zero();
     DeepRow o;
@@ -226,14 +238,38 @@ __device__ __forceinline__ DeepRow deep_row(const DeepArgs &a, u64 r) {
         gl_acc_mac(s2, v, g[2]);
     }
     o.A = e3_make(gl_acc_reduce(s0), gl_acc_reduce(s1), gl_acc_reduce(s2));
-    if (a.nnext >= W) o.B = o.A;
-    if (a.nnext > 0) o.B = e3_mul(o.B, e3_make(a.gpow[W * 3], a.gpow[W * 3 + 1], a.gpow[W * 3 + 2]));
-    o.A = e3_sub(o.A, e3_make(a.ca[0], a.ca[1], a.ca[2]));
-    o.B = e3_sub(o.B, e3_make(a.cb[0], a.cb[1], a.cb[2]));
-    const u64 x = gl_mul(a.shift, gl_mul(a.twl[r & ((1ULL << a.lb) - 1)], a.twh[r >> a.lb]));
-    o.d1 = e3_make(gl_sub(x, a.z[0]), gl_neg(a.z[1]), gl_neg(a.z[2]));
-    o.d2 = e3_make(gl_sub(x, a.zw[0]), gl_neg(a.zw[1]), gl_neg(a.zw[2]));
+    deep_finish(a, r, o);
     return o;
+}
+// rows r and r + 1 (r even, column strides even: the library's column matrices) in ONE walk over the columns, each lane reading its two
+// values with one 16-byte load -- a wave's load is a 1 KiB run, where two walks with 8-byte loads at stride 16 fetched every line twice
+__device__ __forceinline__ void deep_rows2(const DeepArgs &a, u64 r, DeepRow &o0, DeepRow &o1) {
+    gl_acc s[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) s[i][c] = gl_acc_zero();
+    o0.B = e3_make(0, 0, 0);
+    o1.B = o0.B;
+    const int W = a.Wa + a.Wb;
+    for (int k = 0; k < W; k++) {
+        if (k == a.nnext && k > 0) {
+            o0.B = e3_make(gl_acc_reduce(s[0][0]), gl_acc_reduce(s[0][1]), gl_acc_reduce(s[0][2]));
+            o1.B = e3_make(gl_acc_reduce(s[1][0]), gl_acc_reduce(s[1][1]), gl_acc_reduce(s[1][2]));
+        }
+        const u64 *p = k < a.Wa ? a.cols_a + (u64)k * a.sa + r : a.cols_b + (u64)(k - a.Wa) * a.sb + r;
+        const ulonglong2 v = *(const ulonglong2 *)p;
+        const u64 *g = a.gpow + k * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            gl_acc_mac(s[0][c], v.x, g[c]);
+            gl_acc_mac(s[1][c], v.y, g[c]);
+        }
+    }
+    o0.A = e3_make(gl_acc_reduce(s[0][0]), gl_acc_reduce(s[0][1]), gl_acc_reduce(s[0][2]));
+    o1.A = e3_make(gl_acc_reduce(s[1][0]), gl_acc_reduce(s[1][1]), gl_acc_reduce(s[1][2]));
+    deep_finish(a, r, o0);
+    deep_finish(a, r + 1, o1);
 }
 // Two rows per lane and ONE base-field inversion (Fermat, ~85 products) for their four denominators:
 // 1/d1 = d2 adj(d1 d2) / det, 1/d2 = d1 adj(d1 d2) / det per row, and 1/det_0, 1/det_1 from 1/(det_0 det_1).
@@ -241,7 +277,9 @@ __global__ void __launch_bounds__(256) deep_quotient_kernel(DeepArgs a) {
     const u64 r0 = ((u64)blockIdx.x * 256 + threadIdx.x) * 2;
     if (r0 >= a.nrows) return;
     const bool two = r0 + 1 < a.nrows;
-    const DeepRow q0 = deep_row(a, r0), q1 = two ? deep_row(a, r0 + 1) : q0;
+    DeepRow q0, q1;
+    if (two && a.pair_ok) deep_rows2(a, r0, q0, q1);
+    else { q0 = deep_row(a, r0); q1 = two ? deep_row(a, r0 + 1) : q0; }
     u64 det0, det1;
     const e3 adj0 = e3_adj(a.nnext > 0 ? e3_mul(q0.d1, q0.d2) : q0.d1, &det0);
     const e3 adj1 = e3_adj(a.nnext > 0 ? e3_mul(q1.d1, q1.d2) : q1.d1, &det1);
@@ -448,6 +486,7 @@ int32_t zp_deep_quotient_rows(zp_ctx *ctx, const uint64_t *d_cols_a, int32_t Wa,
     a.shift = gl_mul(shift, gl_pow(gl_root(ctx->root32, logm), (u64)row0));
     a.logm = logm; a.Wa = Wa; a.Wb = Wb; a.nnext = n_next;
     a.nrows = nrows; a.sa = stride_a; a.sb = stride_b; a.so = stride_out;
+    a.pair_ok = (stride_a % 2 == 0 || Wa <= 1) && (stride_b % 2 == 0 || Wb <= 1) && ((uintptr_t)d_cols_a % 16 == 0) && (Wb == 0 || (uintptr_t)d_cols_b % 16 == 0);
     hipLaunchKernelGGL(deep_quotient_kernel, dim3((unsigned)((nrows + 511) / 512)), dim3(256), 0, ctx->stream, a);
     ZP_HIP(ctx, hipGetLastError());
     return ZP_OK;
