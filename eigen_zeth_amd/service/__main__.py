@@ -28,9 +28,14 @@ def main():
     ap.add_argument("--no-prewarm", action="store_true",
                     help="open the port at once; the first request then also pays for the wrap key, the transform plans and tables, the kernels (seconds). "
                          "Default: one synthetic batch is proven end to end before the port opens")
+    ap.add_argument("--final-ranks", type=int, default=1,
+                    help="GenFinalProof's STARK as ONE proof over this many ranks of the process (a power of two; zp_stark_prove_sharded_bn128 on an in-process "
+                         "communicator), rank r on the r-th id of --final-devices (default: all on --device, which only rehearses the path)")
+    ap.add_argument("--final-devices", default=None, help="comma-separated GPU ids of the ranks of --final-ranks")
     a = ap.parse_args()
     server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, logb=a.logb, chunks_per_block=a.chunks_per_block, l2_addr=a.l2_addr, n_queries=a.n_queries, pow_bits=a.pow_bits,
-                                                               agg_queries=a.agg_queries, final_queries=a.final_queries, aggregate_all_chunks=a.aggregate_all_chunks), a.device,
+                                                               agg_queries=a.agg_queries, final_queries=a.final_queries, aggregate_all_chunks=a.aggregate_all_chunks, final_ranks=a.final_ranks,
+                                                               final_devices=[int(x) for x in a.final_devices.split(',')] if a.final_devices else None), a.device,
                          metrics_port=a.metrics_port,
                          devices=[int(x) for x in a.devices.split(',')] if a.devices else None, prewarm=not a.no_prewarm)
     print("prover.v1.ProverService listening on %s:%d  (chunk STARKs: %d queries x blow-up %d + %d grinding bits = %d bits conjectured)"
