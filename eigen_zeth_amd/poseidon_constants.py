@@ -2,11 +2,18 @@
 
 The reference (eigen-zeth) carries no hash constants at all -- its prover is an external, un-pinned
 service -- so the tables are *configuration*: `zp_set_constants` (include/
-zeth_prover.h) installs any 360 round constants + 12x12 MDS.  This module produces the documented
-default: round constants from the Poseidon reference Grain-LFSR procedure with parameters
-(field=1, sbox=0, n=64, t=12, R_F=8, R_P=22) and the circulant-plus-diagonal MDS: circulant first row
-[17,15,41,16,2,28,13,13,39,18,34,20] plus diag [8,0,...,0], i.e. the effective first row is the
-[25,15,41,16,2,28,13,13,39,18,34,20] SURVEY.md Appendix A recalls.
+zeth_prover.h) installs any 360 round constants + 12x12 MDS.  This module produces the default.
+
+Round 6: the default round constants are the table of the PUBLIC Goldilocks-Poseidon family (the one the
+pil-stark / eigen-zkvm provers are publicly known to share): 360 draws of `gen_range(0..p)` from a
+ChaCha8 stream seeded with the u64 0 (`chacha8_round_constants`).  Both anchors SURVEY.md Appendix A/C
+recalls from that family are reproduced: the first constant 0xb585f766f2144405 and, with the MDS below,
+perm(0^12)[0..4] = 3c18a9786cb0b359 c4055e3364a246c3 7953db0ab48808f4 c71603f33a1144ca
+(tests/test_poseidon_constants.py on the CPU, tests/test_gpu_parity.py through the C-ABI).  The MDS is the
+circulant-plus-diagonal matrix: circulant first row [17,15,41,16,2,28,13,13,39,18,34,20] plus diag
+[8,0,...,0], i.e. effective first row [25,15,41,...].  The table of rounds 1-5 (Poseidon reference
+Grain-LFSR with (field=1, sbox=0, n=64, t=12, R_F=8, R_P=22)) stays available as
+`grain_goldilocks_round_constants()`.
 
 The generator itself is anchored to a published value: with (1,0,254,3,8,57) over the BN254 scalar
 field its first output is 0x0ee9a592...cd8e6e (tests/test_poseidon_constants.py).
@@ -89,9 +96,67 @@ def bn254_poseidon_params(t):
     return rc, mds, rp
 
 
-def default_round_constants():
-    """360 Goldilocks constants, round-major: rc[r*12 + i]"""
+def grain_goldilocks_round_constants():
+    """the default table of rounds 1-5: Grain LFSR (1, 0, 64, 12, 8, 22)"""
     return grain_round_constants(1, 0, 64, 12, 8, 22, GL_P)
+
+
+# ---- the public family's table: a ChaCha8 stream, seeded the way a 64-bit seed is widened to a 256-bit key by a PCG32
+# sequence, drawn as uniform integers below p by the widening-multiply rejection rule
+_M32 = 0xFFFFFFFF
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+
+def _pcg32_key(seed64):
+    """eight little-endian u32 words of a PCG32 (XSH-RR) sequence started from `seed64`: the 256-bit key"""
+    st, key = seed64 & _M64, []
+    for _ in range(8):
+        st = (st * 6364136223846793005 + 11634580027462260723) & _M64
+        xs, rot = (((st >> 18) ^ st) >> 27) & _M32, st >> 59
+        key.append(((xs >> rot) | (xs << (32 - rot))) & _M32 if rot else xs)
+    return key
+
+
+def _chacha_block(key, counter, rounds):
+    """one 16-word ChaCha block: 64-bit block counter in words 12-13, stream id 0 in words 14-15"""
+    init = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + key + [counter & _M32, counter >> 32, 0, 0]
+    s = list(init)
+
+    def quarter(a, b, c, d):
+        for x, y, z, n in ((a, b, d, 16), (c, d, b, 12), (a, b, d, 8), (c, d, b, 7)):
+            s[x] = (s[x] + s[y]) & _M32
+            v = s[z] ^ s[x]
+            s[z] = ((v << n) | (v >> (32 - n))) & _M32
+
+    for _ in range(rounds // 2):
+        for a in range(4):
+            quarter(a, 4 + a, 8 + a, 12 + a)
+        for a in range(4):
+            quarter(a, 4 + (a + 1) % 4, 8 + (a + 2) % 4, 12 + (a + 3) % 4)
+    return [(s[i] + init[i]) & _M32 for i in range(16)]
+
+
+def chacha8_round_constants(seed64=0, count=360, prime=GL_P):
+    """`count` uniform draws below `prime` (a 64-bit prime with its top bit set) from ChaCha8 keyed by `seed64`: 64-bit words are
+    (low, high) pairs of consecutive output words; a word v is accepted when the low half of v * prime is <= prime - 1 and the
+    draw is the high half."""
+    assert prime >> 63 == 1
+    key, words, ctr, out = _pcg32_key(seed64), [], 0, []
+    while len(out) < count:
+        if len(words) < 2:
+            words += _chacha_block(key, ctr, 8)
+            ctr += 1
+        v = words[0] | (words[1] << 32)
+        del words[:2]
+        m = v * prime
+        if (m & _M64) <= prime - 1:
+            out.append(m >> 64)
+    return out
+
+
+def default_round_constants():
+    """360 Goldilocks constants, round-major: rc[r*12 + i] -- the public family's table (module docstring)"""
+    return chacha8_round_constants(0)
 
 
 def default_mds():
@@ -108,7 +173,7 @@ def write_inc(path):
     rc = default_round_constants()
     mds = default_mds()
     with open(path, "w") as f:
-        f.write("// generated by eigen_zeth_amd/poseidon_constants.py (Grain LFSR 1,0,64,12,8,22) -- do not edit\n")
+        f.write("// generated by eigen_zeth_amd/poseidon_constants.py (ChaCha8 stream seeded with 0: the public Goldilocks-Poseidon table) -- do not edit\n")
         f.write("static const uint64_t ZP_POSEIDON_DEFAULT_RC[360] = {\n")
         for i in range(0, 360, 4):
             f.write("    " + ", ".join("0x%016xULL" % v for v in rc[i:i + 4]) + ",\n")

@@ -176,6 +176,29 @@ def test_golden_poseidon_through_cabi(prover, golden):
         assert prover.download(d, (1, 12))[0].tolist() == case["out"]
 
 
+def test_compiled_in_table_hits_the_public_familys_anchor_on_the_gpu(prover, tables):
+    """the external Goldilocks-side KAT (tests/test_poseidon_constants.py) through the C-ABI: a fresh
+    context -- nothing installed with zp_set_constants -- maps 0^12 to the public family's output words, in the latency kernel
+    (1 state) and in the throughput kernel (the same state 4096 times), and the rounds-1-5 Grain table does not"""
+    from eigen_zeth_amd import native, poseidon_constants as PC
+    from oracle import chacha8_table as CT
+    want = CT.ANCHOR_PERM_ZERO
+    fresh = native.Prover(0)
+    try:
+        for count in (1, 4096):
+            d = fresh.upload(np.zeros((count, 12), dtype=np.uint64))
+            fresh.poseidon_perm(d, count)
+            got = fresh.download(d, (count, 12))
+            assert (got == got[0]).all() and [int(v) for v in got[0, :4]] == want
+            assert (got[0] == O.poseidon_perm(np.zeros((1, 12), dtype=np.uint64), u(CT.round_constants(0)), tables[1])[0]).all()
+        fresh.set_constants(native.ZP_CONST_POSEIDON_RC, u(PC.grain_goldilocks_round_constants()))
+        d = fresh.upload(np.zeros((1, 12), dtype=np.uint64))
+        fresh.poseidon_perm(d, 1)
+        assert [int(v) for v in fresh.download(d, (1, 12))[0, :4]] != want
+    finally:
+        fresh.close()
+
+
 def test_poseidon_batch_matches_oracle(prover, tables):
     rc, mds = tables
     st = O.random_field((5000, 12), 77)

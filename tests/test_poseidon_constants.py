@@ -1,10 +1,13 @@
-"""External anchor of the constant generator.
+"""External anchors of the constant generators.
 
-The reference holds no hash constants; the one value in this repo's hash stack that is pinned to something
-published outside the repo is the Poseidon reference Grain-LFSR stream: with the parameters of the widely published
-BN254 t = 3 instance (field 1, s-box 0, n = 254, t = 3, R_F = 8, R_P = 57) its first outputs are the first round
-constants of that instance.  The same generator, run with (1, 0, 64, 12, 8, 22), yields this repo's default
-Goldilocks table, which the C-ABI library compiles in (csrc/poseidon_default_table.inc)."""
+The reference holds no hash constants.  Two chains in this repo's hash stack are pinned to values published outside it:
+(1) BN254 side: the Poseidon reference Grain-LFSR stream with the parameters of the widely published BN254 t = 3 instance
+(field 1, s-box 0, n = 254, t = 3, R_F = 8, R_P = 57) yields that instance's first round constants and its hash of [1, 2];
+(2) Goldilocks side (round 6): a ChaCha8 stream seeded with 0 yields the public Goldilocks-Poseidon family's first round
+constant, and the permutation over that table and the circulant + diagonal linear layer maps 0^12 to the family's recalled
+output words -- two independent generators (product: poseidon_constants.chacha8_round_constants; checker:
+oracle/chacha8_table.py) and two independent permutations (big-int definition, C restatement) agree on both anchors.  That
+table is the one the C-ABI library compiles in (csrc/poseidon_default_table.inc)."""
 import os
 import re
 
@@ -33,11 +36,40 @@ def test_grain_stream_is_prefix_stable_and_in_range():
     assert all(0 <= v < PC.BN254_R for v in b)
 
 
-def test_default_goldilocks_table():
-    rc = PC.default_round_constants()
+def test_grain_goldilocks_table_of_rounds_1_to_5_is_still_reachable():
+    rc = PC.grain_goldilocks_round_constants()
     assert len(rc) == 360 and all(0 <= v < PC.GL_P for v in rc)
     # the (1,0,64,12,8,22) stream starts with these two values
     assert rc[0] == 0x13DCF33ABA214F46 and rc[1] == 0x30B3B654A1DA6D83
+
+
+def test_chacha8_seed0_table_hits_the_public_familys_anchors():
+    """SURVEY.md Appendix A / C record two values of the public Goldilocks-Poseidon family: the first round constant and
+    perm(0^12)[0..4].  The checker's own generator (oracle/chacha8_table.py) reproduces the first, its big-int permutation and
+    its C permutation reproduce the second, and the product's generator yields the very same 360 words."""
+    import numpy as np
+    from oracle import chacha8_table as CT
+    from oracle import naive as NV
+    from oracle import oracle as O
+    rc = CT.round_constants(0)
+    assert rc[0] == CT.ANCHOR_FIRST_CONSTANT == 0xB585F766F2144405
+    assert len(rc) == 360 and all(0 <= v < PC.GL_P for v in rc) and len(set(rc)) == 360
+    assert rc == PC.chacha8_round_constants(0) == PC.default_round_constants()
+    mds = PC.default_mds()
+    out = NV.poseidon_perm([0] * 12, rc, mds)
+    assert out[:4] == CT.ANCHOR_PERM_ZERO == [0x3C18A9786CB0B359, 0xC4055E3364A246C3, 0x7953DB0AB48808F4, 0xC71603F33A1144CA]
+    got = O.poseidon_perm(np.zeros((1, 12), dtype=np.uint64), np.array(rc, dtype=np.uint64), np.array(mds, dtype=np.uint64))
+    assert [int(v) for v in got[0]] == out
+    # neither anchor survives another seed, round count or the Grain table: the match is not an accident of the linear layer
+    assert CT.round_constants(1)[0] != CT.ANCHOR_FIRST_CONSTANT
+    assert CT.uniform_below(CT.ChaCha(CT.key_from_u64(0), 12), CT.P) != CT.ANCHOR_FIRST_CONSTANT
+    assert NV.poseidon_perm([0] * 12, PC.grain_goldilocks_round_constants(), mds)[:4] != CT.ANCHOR_PERM_ZERO
+
+
+def test_default_goldilocks_table():
+    rc = PC.default_round_constants()
+    assert len(rc) == 360 and all(0 <= v < PC.GL_P for v in rc)
+    assert rc[0] == 0xB585F766F2144405 and rc[1] == 0x7746A55F43921AD7
     mds = PC.default_mds()
     # effective first row = circulant first row + diagonal term: [17+8, 15, 41, ...]
     assert mds[:12] == [25, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
