@@ -214,6 +214,38 @@ def emit(line):
     os.write(fd, (line + "\n").encode())
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` typed plainly (no launcher, no WORLD_SIZE): start the N ranks here -- `python -m torch.distributed.run`, one
+    process per GPU, rendezvous on 127.0.0.1 at a free port -- as a CHILD of this process, which has not touched the GPU (nothing above imports
+    torch or opens the library), relay rank 0's single JSON line to stdout and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, ZP_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.stderr.write("bench.py: no WORLD_SIZE in the environment -- launching %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = 0
+    for line in child.stdout:
+        if line.startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write("bench.py: the ranks exited 0 but printed %d result lines\n" % lines)
+        rc = 4
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,6 +269,8 @@ def main():
     args = ap.parse_args()
     if args.scaling is None:
         args.scaling = "strong" if args.gpus > 1 else "weak"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.child_probe:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if not args.child_probe:
         _quiet_stdout()
 
@@ -256,8 +290,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or plainly, without a launcher: bench.py starts its own ranks)"
+                         % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     # ZP_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path with fewer GPUs than ranks (RCCL refuses two ranks on one
@@ -275,6 +310,21 @@ def main():
         else:
             dist.init_process_group(backend)
     from eigen_zeth_amd import multigpu as MG
+
+    # How many ranks did the TRANSPORT see?  WORLD_SIZE is what the launcher said; a sum of ones over the process group is what the collective
+    # library delivered (RCCL at the default backend).  N worlds of one rank, or ranks that never joined, cannot produce N here.
+    rccl_seen = {"backend": backend if world > 1 else "none (one rank)", "world_env": world, "ranks_seen_allreduce": 1,
+                 "devices_visible": torch.cuda.device_count(), "self_launched": bool(os.environ.get("ZP_BENCH_SELF_LAUNCHED"))}
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl_seen["ranks_seen_allreduce"] = int(ones.item())
+        devs = torch.zeros(world, dtype=torch.int64, device=ones.device)
+        devs[rank] = local + 1
+        dist.all_reduce(devs)
+        rccl_seen["device_of_rank"] = [int(v) - 1 for v in devs.tolist()]
+        if rccl_seen["ranks_seen_allreduce"] != world:
+            raise SystemExit("the process group delivered %d ranks, WORLD_SIZE says %d" % (rccl_seen["ranks_seen_allreduce"], world))
 
     from eigen_zeth_amd.native import Prover
 
@@ -394,6 +444,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
+            "degraded": False,            # true: an optional probe failed or stalled; the K timed steps above are complete either way
+            "exchange_stalled": False,    # true: a collective of the exchange probes never completed (watchdog) or returned an error
+            "rccl": rccl_seen,
             "config": {"workload": ("forward NTT, natural order in/out, 2^%d rows x %d columns per GPU (column-major u64), "
                                     "BASELINE configs[3] shape on one GPU" % (logn, cols)) if args.scaling == "weak" else
                                    ("forward NTT, natural order in/out, 2^%d rows x %d columns in total, %d per GPU (column-major u64): BASELINE "
@@ -433,11 +486,13 @@ def main():
             with out_lock:
                 if rank == 0 and not printed[0]:
                     out["pipeline"] = {"error": "multi-rank probes did not finish within %d s; line printed by the watchdog" % PROBE_LIMIT_S}
+                    out["degraded"] = out["exchange_stalled"] = True
                     emit(json.dumps(out))
                     printed[0] = True
             # The contract's line -- K timed steps of the hot path, no collective inside -- is complete and printed; what stalled is an OPTIONAL
-            # probe, and the line says so in "pipeline".  Exit code 0: a launcher that discards the output of a failed rank would lose the
-            # measured headline with it (ZP_BENCH_WATCHDOG_EXIT overrides: the rehearsal test asks for 3).
+            # probe, and the line says so at its top level ("degraded": true, "exchange_stalled": true) and in "pipeline".  Exit code 0: a
+            # launcher that discards the output of a failed rank would lose the measured headline with it (ZP_BENCH_WATCHDOG_EXIT overrides:
+            # the rehearsal test asks for 3).
             os._exit(int(os.environ.get("ZP_BENCH_WATCHDOG_EXIT", "0")))
         watchdog = threading.Timer(2 if wd_test else PROBE_LIMIT_S, bail)
         watchdog.daemon = True
@@ -521,6 +576,16 @@ def main():
         with out_lock:
             if not printed[0]:
                 out.update(extra)
+                pl = out.get("pipeline") or {}
+                stalled = [k for k in ("exchange", "rccl_direct", "four_step_single_column") if isinstance(pl.get(k), dict) and pl[k].get("error")]
+                if "error" in pl or stalled:
+                    out["degraded"] = True
+                    out["exchange_stalled"] = bool(stalled) or "error" in pl
+                if isinstance(pl.get("rccl_direct"), dict) and pl["rccl_direct"].get("comm_info"):
+                    out["rccl"]["comm"] = pl["rccl_direct"]["comm_info"]       # ncclCommCount / ncclCommUserRank of the C-ABI communicator
+                for k in ("batch_proof",):
+                    if isinstance(out.get(k), dict) and out[k].get("error"):
+                        out["degraded"] = True
                 emit(json.dumps(out))
                 printed[0] = True
     if world > 1:
@@ -647,6 +712,7 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world, steps=10):
             if int(msg[0].item()) == 1:
                 comm = _nat.Comm(prover, rk, world, bytes(int(v) for v in msg[1:].tolist()))
                 comm.set_timeout_ms(60000)          # a peer that never arrives ends the probe with an error instead of the watchdog
+                comm_info = comm.info()             # what RCCL itself reports: ranks in the communicator, this rank, its device
                 tl = torch.empty(((2 * Mloc - 1) * 4,), dtype=torch.int64, device=dev)
                 for it in range(2):
                     torch.cuda.synchronize()
@@ -654,7 +720,7 @@ def pipeline_probe(torch, dist, prover, dev, logn, cols, world, steps=10):
                     r2 = comm.merkle_commit_sharded(y, M, cols, tl)
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
-                res["rccl_direct"] = {"sharded_commit_ms": dt * 1e3, "root_matches_torch_path": [hex(v) for v in r2] == res["root"],
+                res["rccl_direct"] = {"comm_info": comm_info, "sharded_commit_ms": dt * 1e3, "root_matches_torch_path": [hex(v) for v in r2] == res["root"],
                                       "note": "zp_merkle_commit_sharded: exchange + hashing in one C-ABI call, wall-clock"}
                 del tl
 

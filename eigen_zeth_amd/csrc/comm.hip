@@ -39,6 +39,9 @@ struct Rccl {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclCommAbort) CommAbort = nullptr;                  // optional: the watchdog's way out of a collective a peer never joins
     decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;  // optional
+    decltype(&ncclCommCount) CommCount = nullptr;                  // optional: zp_comm_info asks the communicator itself how many ranks it joined
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;            // optional
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;            // optional
     bool ok = false;
 };
 
@@ -55,7 +58,7 @@ Rccl &rccl() {
 #define ZP_SYM(name) r.name = (decltype(r.name))dlsym(r.h, "nccl" #name)
     ZP_SYM(GetUniqueId); ZP_SYM(CommInitRank); ZP_SYM(CommDestroy); ZP_SYM(GroupStart); ZP_SYM(GroupEnd);
     ZP_SYM(Send); ZP_SYM(Recv); ZP_SYM(AllGather); ZP_SYM(Broadcast); ZP_SYM(AllReduce); ZP_SYM(GetErrorString);
-    ZP_SYM(CommAbort); ZP_SYM(CommGetAsyncError);
+    ZP_SYM(CommAbort); ZP_SYM(CommGetAsyncError); ZP_SYM(CommCount); ZP_SYM(CommUserRank); ZP_SYM(CommCuDevice);
 #undef ZP_SYM
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllGather && r.Broadcast &&
            r.AllReduce && r.GetErrorString;
@@ -100,7 +103,11 @@ struct zp_comm_group {
             return ZP_OK;
         }
         const bool woke = cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return gen != g || poisoned; });
-        if (woke && gen != g && !poisoned) return ZP_OK;
+        // The generation completed: every rank was counted and the last arriver has gone on to copy.  That is ZP_OK even when a peer has
+        // poisoned the group SINCE (its copy failed while this waiter was still asleep): this rank must take part in the closing rendezvous
+        // like everybody else -- returning ZP_ERR_COMM here made its caller free a published buffer that peers were still reading, and left
+        // them waiting drain_ms for an arrival that never came.  closing_barrier() reports the poison.
+        if (woke && gen != g) return ZP_OK;
         if (!poisoned) {        // timed out: take everybody else down too
             poisoned = true;
             cv.notify_all();
@@ -144,6 +151,11 @@ struct zp_comm {
     zp_comm_group *local = nullptr;    // non-null: in-process group, no RCCL
     bool dead = false;                 // aborted (zp_comm_abort, the watchdog): every later collective is ZP_ERR_COMM
     int timeout_ms = 120000;           // RCCL: > 0 = a collective returns when it is complete on the stream, or ZP_ERR_COMM after this long
+    // exchange buffers of zp_merkle_commit_sharded (pack, rows, sub-roots, tree top): grown on demand, kept until zp_comm_destroy.  A commitment
+    // per call used to hipMalloc / hipFree two buffers of the matrix's size (8.6 GB each at 2^25 x 32): one call in a dozen then took seconds
+    // (round 5: max 4 515 ms against a median of 81) while the driver gave the pages back and mapped them again.
+    void *xbuf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t xbytes[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -154,6 +166,18 @@ __global__ void __launch_bounds__(256) sum_parts_kernel(u64 *__restrict__ dst, c
     u64 a = 0;
     for (int k = 0; k < n; k++) a += parts[(size_t)k * words + i];
     dst[i] = a;
+}
+
+int32_t comm_scratch(zp_comm *c, int which, size_t bytes, void **out) {
+    if (c->xbytes[which] < bytes) {
+        if (c->xbuf[which]) (void)zp_dev_free(c->ctx, c->xbuf[which]);
+        c->xbuf[which] = nullptr;
+        c->xbytes[which] = 0;
+        ZP_TRY(zp_dev_alloc(c->ctx, bytes, &c->xbuf[which]));
+        c->xbytes[which] = bytes;
+    }
+    *out = c->xbuf[which];
+    return ZP_OK;
 }
 
 const char *const kDeadText = "communicator is dead: a peer rank failed, aborted or did not arrive in time";
@@ -181,8 +205,9 @@ int32_t local_exchange(zp_comm *c, const void *mine, const std::function<int32_t
         }
         if (rc != ZP_OK) g->fail();
     }
-    // every rank's own copies are complete here (or were never issued); nobody leaves before every peer has stopped reading.  When the
-    // opening barrier failed it failed for every rank (it needs all of them), so nobody copies and there is nothing to wait for.
+    // every rank's own copies are complete here (or were never issued); nobody leaves before every peer has stopped reading.  The opening
+    // barrier fails only when its generation never completed (poisoned before the last arrival, or a rank that never came): then no rank of
+    // that generation was told to copy, and there is nothing to wait for.
     const int32_t b2 = (b1 == ZP_OK) ? g->closing_barrier() : ZP_ERR_COMM;
     if (rc != ZP_OK) return rc;
     if (b1 != ZP_OK || b2 != ZP_OK) {
@@ -308,7 +333,39 @@ int32_t zp_comm_destroy(zp_comm *c) {
     ZP_BIND(c->ctx);
     if (!c->dead) (void)hipStreamSynchronize(c->ctx->stream);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
+    for (void *b : c->xbuf)
+        if (b) (void)zp_dev_free(c->ctx, b);
     delete c;
+    return ZP_OK;
+}
+
+// gives the exchange buffers the communicator keeps between commitments back to the device (they grow to the largest matrix committed)
+int32_t zp_comm_release_scratch(zp_comm *c) {
+    if (!c) return ZP_ERR_ARG;
+    ZP_BIND(c->ctx);
+    for (int i = 0; i < 4; i++) {
+        if (c->xbuf[i]) (void)zp_dev_free(c->ctx, c->xbuf[i]);
+        c->xbuf[i] = nullptr;
+        c->xbytes[i] = 0;
+    }
+    return ZP_OK;
+}
+
+// What the TRANSPORT says about this communicator, not what its creator was told: out4 = {transport (1 = RCCL, 0 = in-process group),
+// ranks the communicator joined (ncclCommCount), this rank inside it (ncclCommUserRank), HIP device it is bound to (ncclCommCuDevice)}.
+// A launcher that meant to start 8 ranks and started 8 worlds of one reads 1 here, whatever WORLD_SIZE said.  -1: RCCL does not export the query.
+int32_t zp_comm_info(const zp_comm *c, int32_t *out4) {
+    if (!c || !out4) return ZP_ERR_ARG;
+    if (c->local) {
+        out4[0] = 0; out4[1] = c->local->world; out4[2] = c->rank; out4[3] = c->ctx->device;
+        return ZP_OK;
+    }
+    if (c->dead || !c->comm) { c->ctx->err = kDeadText; return ZP_ERR_COMM; }
+    int v = -1;
+    out4[0] = 1;
+    out4[1] = (rccl().CommCount && rccl().CommCount(c->comm, &v) == ncclSuccess) ? v : -1;
+    out4[2] = (rccl().CommUserRank && rccl().CommUserRank(c->comm, &v) == ncclSuccess) ? v : -1;
+    out4[3] = (rccl().CommCuDevice && rccl().CommCuDevice(c->comm, &v) == ncclSuccess) ? v : -1;
     return ZP_OK;
 }
 
@@ -454,23 +511,19 @@ int32_t zp_merkle_commit_sharded(zp_comm *c, const uint64_t *d_cols, size_t M, i
     ZP_ARG(ctx, d_cols && d_tree_local && h_root4 && Wl >= 1 && M >= (size_t)2 * c->world && (M & (M - 1)) == 0, "bad arguments");
     const size_t G = (size_t)c->world, Ml = M / G;
     void *pack = nullptr, *rows = nullptr, *sub = nullptr;
-    int32_t rc = zp_dev_alloc(ctx, (size_t)Wl * M * 8, &pack);
-    if (rc == ZP_OK) rc = zp_dev_alloc(ctx, (size_t)Wl * M * 8, &rows);
-    if (rc == ZP_OK) rc = zp_dev_alloc(ctx, G * 12 * 8, &sub);
+    int32_t rc = comm_scratch(c, 0, G > 1 ? (size_t)Wl * M * 8 : 8, &pack);      // a world of one copies, it does not pack
+    if (rc == ZP_OK) rc = comm_scratch(c, 1, (size_t)Wl * M * 8, &rows);
+    if (rc == ZP_OK) rc = comm_scratch(c, 2, G * 12 * 8, &sub);
     if (rc == ZP_OK) rc = zp_exchange_columns_to_rows(c, d_cols, (size_t)Wl, M, (uint64_t *)pack, (uint64_t *)rows);
     if (rc == ZP_OK) rc = zp_merkle_commit(ctx, (const uint64_t *)rows, Ml, (int32_t)(G * Wl), d_tree_local);
     std::vector<u64> lvl(4);
     void *top = nullptr;                                     // the top log2(G) levels: the tree over the G sub-roots, on the device in one call
     if (rc == ZP_OK) rc = zp_comm_all_gather(c, d_tree_local + (2 * Ml - 2) * 4, (uint64_t *)sub, 4);
-    if (rc == ZP_OK) rc = zp_dev_alloc(ctx, (2 * G - 1) * 32, &top);
+    if (rc == ZP_OK) rc = comm_scratch(c, 3, (2 * G - 1) * 32, &top);
     if (rc == ZP_OK) rc = zp_merkle_commit_rows(ctx, (const uint64_t *)sub, G, 4, (uint64_t *)top);       // leaves of 4 values are their own digests
     if (rc == ZP_OK) rc = zp_d2h(ctx, lvl.data(), (const uint64_t *)top + (2 * G - 2) * 4, 32);
-    if (top) (void)zp_dev_free(ctx, top);
     if (rc == ZP_OK) memcpy(h_root4, lvl.data(), 32);
     else (void)zpi_comm_fail(c, rc);                       // whatever failed here, no peer may wait for this rank
-    if (pack) (void)zp_dev_free(ctx, pack);
-    if (rows) (void)zp_dev_free(ctx, rows);
-    if (sub) (void)zp_dev_free(ctx, sub);
     return rc;
 }
 

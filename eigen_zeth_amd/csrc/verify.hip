@@ -69,7 +69,11 @@ bool fixed_col_at(const uint64_t *prog, const ZpFixedCol &fc, const uint64_t *pu
 bool zpi_program_fixed_table(const uint64_t *h_program, size_t program_words, std::vector<ZpFixedCol> *cols) {
     if (program_words < 12) return false;
     const u64 n_fixed = h_program[3], n_pub = h_program[4], n_const = h_program[6], n_instr = h_program[7], n_s2 = h_program[10];
-    if (n_fixed < 2 || n_fixed > 4096 || n_const > (1u << 16) || n_instr > (1u << 24) || n_s2 > (1u << 16)) return false;
+    // EVERY count of the header is bounded before it enters a sum or sizes anything: n_pub + n_chal wraps for a blob that says n_pub = 2^64 - 3,
+    // and a public-input entry index is checked against n_pub alone (round-5 advisor item; this file is the sanitizer / fuzz surface for blobs)
+    if (n_fixed < 2 || n_fixed > 4096 || n_const > (1u << 16) || n_instr > (1u << 24) || n_s2 > (1u << 16) || n_pub > (1u << 24) ||
+        h_program[5] > (1u << 24) || h_program[8] > (1u << 24))
+        return false;
     size_t at = 12 + (size_t)n_const + (size_t)n_instr + 4 * (size_t)n_s2;
     if (cols) cols->clear();
     for (u64 k = 2; k < n_fixed; k++) {

@@ -131,6 +131,8 @@ SIGNATURES = {
     "zp_comm_destroy": (C.c_int32, [_vp]),
     "zp_comm_rank": (C.c_int32, [_vp]),
     "zp_comm_world": (C.c_int32, [_vp]),
+    "zp_comm_info": (C.c_int32, [_vp, _vp]),
+    "zp_comm_release_scratch": (C.c_int32, [_vp]),
     "zp_comm_abort": (C.c_int32, [_vp]),
     "zp_comm_set_timeout_ms": (C.c_int32, [_vp, C.c_int32]),
     "zp_comm_all_to_all": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
@@ -499,6 +501,15 @@ class Comm:
 
     def set_timeout_ms(self, ms):
         self.prover._chk(self.prover.lib.zp_comm_set_timeout_ms(self.h, int(ms)))
+
+    def info(self):
+        """zp_comm_info: what the transport itself reports -- {"transport": "rccl" | "local", "ranks_seen", "user_rank", "device"}"""
+        out = (C.c_int32 * 4)()
+        self.prover._chk(self.prover.lib.zp_comm_info(self.h, out))
+        return {"transport": "rccl" if out[0] == 1 else "local", "ranks_seen": int(out[1]), "user_rank": int(out[2]), "device": int(out[3])}
+
+    def release_scratch(self):
+        self.prover._chk(self.prover.lib.zp_comm_release_scratch(self.h))
 
     def all_to_all(self, d_send, d_recv, words_per_peer):
         self.prover._chk(self.prover.lib.zp_comm_all_to_all(self.h, _ptr(d_send), _ptr(d_recv), words_per_peer))

@@ -33,6 +33,10 @@ def main():
                          "communicator), rank r on the r-th id of --final-devices (default: all on --device, which only rehearses the path)")
     ap.add_argument("--final-devices", default=None, help="comma-separated GPU ids of the ranks of --final-ranks")
     a = ap.parse_args()
+    if a.final_ranks < 1 or a.final_ranks > 64 or a.final_ranks & (a.final_ranks - 1):
+        ap.error("--final-ranks must be a power of two between 1 and 64")
+    if a.final_devices and len(a.final_devices.split(",")) != a.final_ranks:
+        ap.error("--final-devices must name one GPU id per rank of --final-ranks")
     server, port = serve(a.port, a.host, a.state_dir, EngineConfig(a.air, a.logn, logb=a.logb, chunks_per_block=a.chunks_per_block, l2_addr=a.l2_addr, n_queries=a.n_queries, pow_bits=a.pow_bits,
                                                                agg_queries=a.agg_queries, final_queries=a.final_queries, aggregate_all_chunks=a.aggregate_all_chunks, final_ranks=a.final_ranks,
                                                                final_devices=[int(x) for x in a.final_devices.split(',')] if a.final_devices else None), a.device,

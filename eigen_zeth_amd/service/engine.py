@@ -113,6 +113,10 @@ class EngineConfig:
         # final_ranks > 1 (a power of two): the final STARK is ONE proof over that many ranks of this process -- zp_stark_prove_sharded_bn128
         # on an in-process communicator, rank r on final_devices[r] (default: all on the engine's GPU, which only rehearses the path).  Same
         # text and wrap as with one rank (tests/test_gpu_verifier_air.py).  For a node whose GPUs would otherwise idle during GenFinalProof.
+        if not isinstance(final_ranks, int) or isinstance(final_ranks, bool) or not 1 <= final_ranks <= 64 or final_ranks & (final_ranks - 1):
+            raise ValueError("final_ranks must be a power of two between 1 and 64, not %r" % (final_ranks,))
+        if final_devices is not None and (len(final_devices) != final_ranks or any(not isinstance(d, int) or d < 0 for d in final_devices)):
+            raise ValueError("final_devices must name one GPU id per rank of final_ranks (%d), not %r" % (final_ranks, final_devices))
         self.final_ranks, self.final_devices = final_ranks, final_devices
         self.prover_streams = prover_streams   # chunk proofs in flight on one GPU (each on its own ctx / stream); 8 measured best (profiles/r2_streams_sweep.txt)
         # the final STARK (BN128-hash mode, no grinding: 50 queries x blow-up 4 = 100 bits conjectured)
@@ -432,7 +436,7 @@ class Engine:
             tm["made-during-chunk-proofs"] = time.perf_counter() - t0
             self._spec["agg"] = ((batch_id, self._digest(p_first), self._digest(p_last)), text, tm)
             t0 = time.perf_counter()
-            fin = self._final_stark(text)
+            fin = self._final_stark(text, hdr_be=self._be_spec)     # never self.be off the engine's thread: chunk proofs are running on it
             self._spec["final"] = (self._digest(text), fin + (time.perf_counter() - t0,))
         except Exception:       # a proof that does not aggregate is reported when the client asks for it, by the ordinary path
             pass
@@ -739,8 +743,42 @@ class Engine:
         t_fs = time.perf_counter() - t0
         return self._final_wrap(batch_id, aggregator_addr, fair, fp, final_stark, tmf, openings, t_fs)
 
-    def _final_stark(self, recursive_proof):
-        """(shape, AIR, parameters, text, timings, binary openings) of the final STARK over an aggregated proof text"""
+    def _check_inner_headers(self, node, stark_publics, be, depth=0):
+        """What NO query of a recursion STARK covers, for the proofs it vouches for, level by level (round-5 advisor item).  node: an aggregated
+        proof (or a "children" entry of one) -- {"shape", "inner": headers, ["children"]}; stark_publics: the public inputs of the STARK over the
+        verifier AIR of that shape, already known to verify (the level above checked its header; the final STARK proves its query phase).  Per
+        inner header: the verifier's own parameters, the constraint identity at the out-of-domain point, the final layer's degree, the grinding
+        (stark/verifier.py) -- against the chunk AIR under this prover's STARK parameters at the leaves, against the verifier AIR of the level
+        below otherwise.  And the link: stark_publics are EXACTLY what these headers dictate (roots, indices and transcripts from each header's
+        own Fiat-Shamir stream, arithmetic constants, final-layer values) -- without it the STARK could vouch for the queries of other proofs than
+        the ones whose headers the text shows.  Raises ValueError."""
+        if depth > 8 or not isinstance(node.get("inner"), list):
+            raise ValueError("aggregated proof carries no inner headers")
+        shape = self._own_shape(node)
+        kids = node.get("children")
+        if not kids:
+            inner_air, params = AIR.get_air(self.cfg.air), self.stark_params(shape.logn)
+        else:
+            below = self._own_shape(kids[0])
+            inner_air, params = VA.verifier_air(below, *self._tables(self.be_bn128)), self._agg_params(below)
+        if len(node["inner"]) != shape.n_proofs:
+            raise ValueError("inner headers do not match the shape")
+        for h in node["inner"]:
+            if not isinstance(h, dict) or "queries" in h:
+                raise ValueError("an aggregated proof carries the HEADERS of its inner proofs")
+            SV.verify_header(h, inner_air, params, be)
+        want = VA.publics_from_headers(shape, node["inner"], inner_air.digest_words(), be)
+        if [int(v) for v in stark_publics] != want:
+            raise ValueError("the recursion STARK's public inputs are not what the inner proofs' headers dictate")
+        if kids:
+            for kid, hdr in zip(kids, node["inner"]):
+                self._check_inner_headers(kid, hdr["publics"], be, depth + 1)
+
+    def _final_stark(self, recursive_proof, hdr_be=None):
+        """(shape, AIR, parameters, text, timings, binary openings) of the final STARK over an aggregated proof text.  hdr_be: the backend the
+        header checks hash on -- the engine's own (self.be) on the engine's thread, the speculation thread's backend when that thread calls
+        (a zp_ctx is single-threaded; self.be is proving chunks while a speculation runs)"""
+        hb = self.be if hdr_be is None else hdr_be
         try:
             _, agg, prep = self._parse_and_prepare(recursive_proof)
             outer = agg["stark"]
@@ -762,13 +800,14 @@ class Engine:
             def check_header():
                 t0 = time.perf_counter()
                 try:
-                    SV.verify_header(outer, agg_air, self._agg_params(agg_shape), self.be)
+                    SV.verify_header(outer, agg_air, self._agg_params(agg_shape), hb)
+                    self._check_inner_headers(agg, outer["publics"], hb)       # ... and the same for every proof below it, down to the chunk proofs
                 except Exception as e:          # re-raised on the engine's thread below
                     hdr["err"] = e
                 hdr["t"] = time.perf_counter() - t0
             th = None
             if self.cfg.verify_before_wrap:
-                if self.be_bn128 is not self.be and hasattr(self.be, "p"):
+                if self.be_bn128 is not hb and hasattr(hb, "p"):
                     th = threading.Thread(target=check_header, name="verify-aggregated-header")
                     th.start()
                 else:                           # one ctx for both (the CPU checker's backend in tests): one after the other

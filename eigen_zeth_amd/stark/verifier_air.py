@@ -734,8 +734,9 @@ def replay_transcript(shape, proof, digest_words, be):
         idx = [v & ((1 << (shape.logn + shape.logb)) - 1) for v in tr.squeeze(shape.n_queries)]
     except (KeyError, TypeError, IndexError) as e:
         raise ValueError("inner proof is malformed (%s)" % e)
-    if idx != [int(q["index"]) for q in proof["queries"]]:
+    if "queries" in proof and idx != [int(q["index"]) for q in proof["queries"]]:      # a HEADER (publics_from_headers) carries no openings
         raise ValueError("the query indices of an inner proof do not follow its transcript: no accepting witness")
+    chal["indices"] = idx
     rec = tr.rec + ([pow_rec] if pow_rec else [])
     script = shape.transcript_perms()
     if [(r[1], r[2] is not None) for r in rec] != [(pm["n_in"], pm["out"]) for pm in script]:
@@ -822,6 +823,45 @@ def final_values(shape, proof, indices):
     if len(fin) != 3 or any(len(pl) != m + 1 for pl in fin):
         raise ValueError("inner proof has a final layer of the wrong size")
     return [[int(fin[c][int(j) & m]) for c in range(3)] for j in indices]
+
+
+def publics_from_headers(shape, headers, digest_words, be):
+    """The public inputs a STARK over verifier_air(shape) MUST have when its inner proofs have these headers -- derived from the headers alone
+    (no opening is read): roots; the leaf index of every (slot, proof, tree), from each header's own Fiat-Shamir transcript; the transcripts,
+    permutation by permutation; the arithmetic constants; the final-layer value at every query's position.  The same list build_witness returns
+    beside the trace, in the same order.  GenFinalProof compares the client's aggregation STARK's public inputs with it (service/engine.py): an
+    honest aggregation of the headers' proofs has exactly these, anything else vouches for other proofs than the ones the text carries.
+    Raises ValueError for a header whose grinding nonce fails or whose shape is not `shape`."""
+    if len(headers) != shape.n_proofs:
+        raise ValueError("wrong number of inner proofs")
+    parts, tps, chals = [], [], []
+    for h in headers:
+        names = {"trace": h["roots"]["trace"], "quotient": h["roots"]["quotient"]}
+        if shape.W2:
+            names["stage2"] = h["roots"]["stage2"]
+        for (name, _, _) in shape.trees:
+            root = h["fri"]["roots"][int(name[3:])] if name.startswith("fri") else names[name]
+            if len(root) != 4:
+                raise ValueError("malformed root")
+            parts += [int(v) for v in root]
+        _, tp, chal = replay_transcript(shape, h, digest_words, be)
+        tps.append(tp)
+        chals.append(chal)
+    nq = shape.n_queries
+    for g in range(shape.n_slots()):
+        for chal in chals:
+            j = chal["indices"][g % nq]
+            parts += [int(j) & ((1 << depth) - 1) for (_, _, depth) in shape.trees]
+    for tp in tps:
+        parts += [int(v) for v in tp]
+    for h, chal in zip(headers, chals):
+        parts += arith_publics(shape, h, chal)
+    for g in range(shape.n_slots()):
+        for h, chal in zip(headers, chals):
+            parts += final_values(shape, h, [chal["indices"][g % nq]])[0]
+    if len(parts) != shape.n_pub():
+        raise ValueError("inner proofs do not have the shape the verifier AIR was built for")
+    return parts
 
 
 def expected_publics(shape, proofs):

@@ -484,6 +484,13 @@ int32_t zp_comm_create(zp_ctx *ctx, int32_t rank, int32_t world, const uint8_t *
 int32_t zp_comm_destroy(zp_comm *comm);
 int32_t zp_comm_rank(const zp_comm *comm);
 int32_t zp_comm_world(const zp_comm *comm);
+/* What the TRANSPORT says about the communicator (not what its creator was told): out4 = {transport: 1 RCCL / 0 in-process group, ranks the
+ * communicator joined (ncclCommCount), this rank inside it (ncclCommUserRank), the HIP device it is bound to (ncclCommCuDevice); -1 where the
+ * loaded RCCL lacks the query}.  bench.py prints it ("rccl"): a launcher that started N worlds of one rank instead of one world of N shows here. */
+int32_t zp_comm_info(const zp_comm *comm, int32_t *out4);
+/* zp_merkle_commit_sharded keeps its exchange buffers (pack, rows) in the communicator between calls, grown to the largest matrix committed;
+ * this gives them back to the device (zp_comm_destroy does too). */
+int32_t zp_comm_release_scratch(zp_comm *comm);
 int32_t zp_comm_abort(zp_comm *comm);
 int32_t zp_comm_set_timeout_ms(zp_comm *comm, int32_t ms);
 int32_t zp_comm_all_to_all(zp_comm *comm, const uint64_t *d_send, uint64_t *d_recv, size_t words_per_peer);

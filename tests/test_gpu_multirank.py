@@ -54,22 +54,37 @@ def test_two_ranks_on_one_gpu_with_host_staged_collectives():
     assert res["sharded_proof_matches_single_gpu"]
 
 
-def test_bench_n2_code_path_on_one_gpu():
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), rehearsed on the one-GPU
-    box with ZP_BENCH_BACKEND=gloo: the multi-rank pipeline probes (all-to-all commit, four-step NTT, MSM ranges, per-rank
-    batch) must run to completion and the line must carry them"""
+def test_bench_n2_plain_launch_on_one_gpu():
+    """`python3 bench.py --gpus 2 ...` typed PLAINLY -- no launcher, no WORLD_SIZE: the way the driver started the N = 1 run.  bench.py starts its
+    two ranks itself (torch.distributed.run as a child, before anything touches the GPU), relays rank 0's ONE line and the ranks' exit code.
+    Rehearsed on the one-GPU box with ZP_BENCH_BACKEND=gloo: the multi-rank pipeline probes (all-to-all commit, four-step NTT, MSM ranges,
+    per-rank batch) run to completion, and the line says how many ranks the collective library delivered."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ZP_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--logn", "20", "--cols", "16", "--stark-logn", "14"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--logn", "20", "--cols", "16", "--stark-logn", "14"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), "stdout of a plain launch is rank 0's single JSON line: %r" % r.stdout[-600:]
+    line = json.loads(lines[0])
     # no --scaling flag, as the driver runs it: with N > 1 that means STRONG since round 5 (BASELINE configs[3] is ONE trace sharded over the GPUs)
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["config"]["cols_per_gpu"] == 8 and line["config"]["cols_total"] == 16
+    assert line["rccl"]["ranks_seen_allreduce"] == 2 and line["rccl"]["world_env"] == 2 and line["rccl"]["self_launched"] and line["rccl"]["backend"] == "gloo"
+    assert line["rccl"]["device_of_rank"] == [0, 0] or native_device_count() >= 2
+    assert line["degraded"] is False and line["exchange_stalled"] is False
     pipe = line["pipeline"]
     assert "error" not in pipe and pipe["all_to_all_ms"] > 0 and pipe["four_step_single_column"]["ms"] > 0
     assert pipe["msm_bn254"]["on_curve"]
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "r6_bench_n2_plain_launch.json"), "w") as f:
+            json.dump({"cmd": "ZP_BENCH_BACKEND=gloo python3 bench.py " + " ".join(cmd[2:]), "line": line}, f, indent=1)
+
+
+def native_device_count():
+    from eigen_zeth_amd import native
+    return native.device_count()
 
 
 def test_bench_strong_scaling_mode_and_the_timed_exchange_loops():
@@ -93,6 +108,10 @@ def test_bench_strong_scaling_mode_and_the_timed_exchange_loops():
     ex = line["pipeline"]["exchange"]
     assert "error" not in ex and ex["world"] == 1 and ex["all_to_all"]["steps"] == 3 and ex["all_to_all"]["median_ms"] > 0
     assert ex["sharded_commit"]["min_ms"] > 0 and ex["root_matches_torch_path"]
+    # the communicator itself reports its size (ncclCommCount / ncclCommUserRank), and one commitment in the timed loop costs what the others do
+    assert line["rccl"]["comm"] == {"transport": "rccl", "ranks_seen": 1, "user_rank": 0, "device": 0}
+    assert line["degraded"] is False and line["exchange_stalled"] is False
+    assert ex["sharded_commit"]["max_ms"] < 20 * ex["sharded_commit"]["median_ms"] + 50
 
 
 def test_rccl_world_of_one_on_the_one_gpu_box():

@@ -119,6 +119,16 @@ def test_engine_final_proof_wraps_the_final_stark(tables, tmp_path):
         b2 = json.loads(agg)                   # consistently forged proof -- false trace, honest transcript -- is what only the header check stops)
         b2["stark"]["evals"]["z"][0][0] ^= 1
         eng.final("w", json.dumps(b2, separators=(",", ":")), "BN128", addr)
+    # ... and the same holds ONE LEVEL DOWN (round-5 advisor item): the chunk-proof headers inside the aggregated proof are verified too -- identity at
+    # zeta, final layer, grinding -- and the aggregation STARK's public inputs must be what THOSE headers dictate.  A header whose out-of-domain
+    # evaluation was changed, or swapped for the header of another honest proof, is refused although the aggregation STARK itself is untouched.
+    for mutate in (lambda a: a["inner"][0]["evals"]["z"][5].__setitem__(0, a["inner"][0]["evals"]["z"][5][0] ^ 1),
+                   lambda a: a["inner"][1]["fri"]["final"][0].__setitem__(2, a["inner"][1]["fri"]["final"][0][2] ^ 1),
+                   lambda a: a["inner"].__setitem__(0, a["inner"][1])):
+        b3 = json.loads(agg)
+        mutate(b3)
+        with pytest.raises(ValueError):
+            eng.final("w", json.dumps(b3, separators=(",", ":")), "BN128", addr)
     ap = eng._agg_params(eng._own_shape(bad))
     from eigen_zeth_amd.stark import verifier_air as VA
     vair = VA.verifier_air(eng._own_shape(bad), *eng._tables(eng.be))

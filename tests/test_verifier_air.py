@@ -407,6 +407,28 @@ def test_native_proof_text_parser_equals_the_json_path(inner, cpu, tables, monke
     assert (t1 == t2).all() and (p1 == p2).all()
 
 
+def test_publics_from_headers_is_what_the_witness_builder_returns(inner, aggregated, cpu):
+    """GenFinalProof's link check (round-5 advisor item): the public inputs an honest aggregation STARK has are a function of the inner HEADERS
+    alone -- VA.publics_from_headers reads no opening and gives the list build_witness returned beside the trace; one changed header word gives
+    another list (or no list at all: a header that fails its own grinding)."""
+    air, params, proofs = inner
+    shape, _, _, _, pubs, agg = aggregated
+    got = VA.publics_from_headers(shape, agg["inner"], air.digest_words(), cpu)
+    assert got == [int(v) for v in pubs]
+    for mutate in (lambda h: h["evals"]["z"][2].__setitem__(1, (h["evals"]["z"][2][1] + 1) % P),
+                   lambda h: h["roots"]["trace"].__setitem__(0, (h["roots"]["trace"][0] + 1) % P),
+                   lambda h: h["fri"]["final"][1].__setitem__(0, (h["fri"]["final"][1][0] + 1) % P),
+                   lambda h: h["publics"].__setitem__(0, (h["publics"][0] + 1) % P)):
+        bad = [strip_paths(h) for h in agg["inner"]]
+        mutate(bad[1])
+        try:
+            assert VA.publics_from_headers(shape, bad, air.digest_words(), cpu) != got
+        except ValueError:
+            pass
+    with pytest.raises(ValueError):
+        VA.publics_from_headers(shape, agg["inner"][:1], air.digest_words(), cpu)
+
+
 def test_product_header_verifier_agrees_with_the_checker(inner, aggregated, cpu, tables):
     """stark/verifier.py (what Engine.final() runs on the client's aggregated proof before wrapping it; constraint identity through the library's
     zp_program_eval_ext) against the checker's verifier in header-only mode: same verdict and same transcript outputs on a chunk proof (stage-2
