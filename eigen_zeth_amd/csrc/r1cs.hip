@@ -101,8 +101,23 @@ inline bool std_canonical(const uint64_t *w) { return !fr_geq_mod(w); }
 
 // ---- the circuit blob (service/r1cs.py: pack_circuit)
 constexpr uint64_t MAGIC = 0x3130534331525a50ULL;   // "PZR1CS01"
+constexpr uint64_t MAGIC2 = 0x3230534331525a50ULL;  // "PZR1CS02": + the arithmetic templates (service/arith.py) behind the explicit constraints
 struct Mat { const uint64_t *ptr, *idx, *val; };      // CSR over constraints: ptr[n + 1], idx[nnz] (wire), val[nnz][4] (standard form)
+// An arithmetic template (service/arith.py: Goldilocks arithmetic of the final STARK's verifier inside F_r, wrap stage B-2): rows over LOCAL wires
+// (0 = the constant, 1..n_in inputs, then n_int internal wires) as triples of linear-combination ids into one pool, a witness program that
+// DEFINES every internal wire, and n_inst instances (input wires + the base of the internal wires).  Instance i owns the constraints
+// [first_row + i n_rows, first_row + (i + 1) n_rows).
+constexpr uint32_t AR_UNIT = 1u << 31;               // LC id: the unit combination of local wire (id & ~AR_UNIT)
+enum { AR_OP_MUL = 1, AR_OP_DIVMOD = 3, AR_OP_BITS = 4, AR_OP_INV3 = 5 };
+struct ArithT {
+    uint64_t n_in, n_int, n_coef, n_lc, nnz, n_rows, n_ops, n_inst, first_row;
+    const uint64_t *coef, *lc_ptr, *lc_ent, *rows, *ops, *inst;
+    uint64_t n_local() const { return 1 + n_in + n_int; }
+    uint64_t global(const uint64_t *in, uint64_t local) const { return local == 0 ? 0 : local <= n_in ? in[local - 1] : in[n_in] + (local - 1 - n_in); }
+};
 struct Circ {
+    std::vector<ArithT> ar;
+    uint64_t n_arith_rows = 0;
     uint64_t n_wires, n_cons, logm, t, n_local, tc, n_inst, n_extra, n_pub, n_waves;
     const uint64_t *tdef, *inst, *edef, *waves;      // waves[n_waves + 1]: instances [waves[k], waves[k + 1]) read only wires set before wave k               // tdef[tc]: the local wire a template constraint defines; inst: (t + 2) words each; edef[n_extra]
     Mat T[3], E[3];
@@ -122,14 +137,70 @@ bool parse_mat(const uint64_t *d, size_t words, size_t &at, uint64_t rows, uint6
     return true;
 }
 
+bool parse_arith(const uint64_t *d, size_t words, size_t &at, uint64_t n_tpl, Circ *c) {
+    uint64_t next_row = c->n_inst * c->tc + c->n_extra;
+    for (uint64_t k = 0; k < n_tpl; k++) {
+        if (at + 12 > words) return false;
+        ArithT t;
+        t.n_in = d[at]; t.n_int = d[at + 1]; t.n_coef = d[at + 2]; t.n_lc = d[at + 3]; t.nnz = d[at + 4]; t.n_rows = d[at + 5]; t.n_ops = d[at + 6]; t.n_inst = d[at + 7];
+        t.first_row = d[at + 8];
+        at += 12;
+        if (t.n_in > (1u << 20) || t.n_int < 1 || t.n_int > (1u << 26) || t.n_coef > (1u << 24) || t.n_lc < 1 || t.n_lc > (1u << 28) || t.nnz > (1ull << 30) || t.n_rows < 1 ||
+            t.n_rows > (1u << 26) || t.n_ops > (1u << 26) || t.n_inst < 1 || t.n_inst > (1u << 16) || t.first_row != next_row)
+            return false;
+        const uint64_t nl = t.n_local();
+        if (nl >= AR_UNIT) return false;
+        const uint64_t need = 4 * t.n_coef + (t.n_lc + 1) + t.nnz + 2 * t.n_rows + 4 * t.n_ops + t.n_inst * (t.n_in + 1);
+        if (at + need > words) return false;
+        t.coef = d + at; at += 4 * t.n_coef;
+        t.lc_ptr = d + at; at += t.n_lc + 1;
+        t.lc_ent = d + at; at += t.nnz;
+        t.rows = d + at; at += 2 * t.n_rows;
+        t.ops = d + at; at += 4 * t.n_ops;
+        t.inst = d + at; at += t.n_inst * (t.n_in + 1);
+        for (uint64_t i = 0; i < t.n_coef; i++) if (!std_canonical(t.coef + 4 * i)) return false;
+        if (t.lc_ptr[0] != 0 || t.lc_ptr[t.n_lc] != t.nnz || t.lc_ptr[1] != 0) return false;           // LC 0 is the empty combination
+        for (uint64_t i = 0; i < t.n_lc; i++) if (t.lc_ptr[i] > t.lc_ptr[i + 1]) return false;
+        for (uint64_t e = 0; e < t.nnz; e++) if ((t.lc_ent[e] & 0xFFFFFFFFull) >= nl || (t.lc_ent[e] >> 32) >= t.n_coef) return false;
+        auto lc_ok = [&](uint64_t id) { return (id & AR_UNIT) ? (id & (AR_UNIT - 1)) < nl && id < (1ull << 32) : id < t.n_lc; };
+        for (uint64_t q = 0; q < t.n_rows; q++)
+            if (!lc_ok(t.rows[2 * q] & 0xFFFFFFFFull) || !lc_ok(t.rows[2 * q] >> 32) || !lc_ok(t.rows[2 * q + 1])) return false;
+        for (uint64_t o = 0; o < t.n_ops; o++) {
+            const uint64_t *op = t.ops + 4 * o;
+            const uint64_t code = op[0] & 0xFF, nbits = (op[0] >> 8) & 0xFFFF, flag = (op[0] >> 24) & 0xFF, dst = op[1];
+            uint64_t cnt = 1;
+            if (code == AR_OP_MUL) cnt = 1;
+            else if (code == AR_OP_DIVMOD) { if (flag != 0 && flag != 2) return false; cnt = flag == 2 ? 1 : 2; }
+            else if (code == AR_OP_BITS) { if (nbits < 1 || nbits > 254) return false; cnt = nbits; }
+            else if (code == AR_OP_INV3) cnt = 3;
+            else return false;
+            if (dst < 1 + t.n_in || dst + cnt > nl) return false;                                        // an op defines INTERNAL wires
+            if (!lc_ok(op[2] & 0xFFFFFFFFull) || !lc_ok(op[2] >> 32) || !lc_ok(op[3])) return false;
+        }
+        for (uint64_t i = 0; i < t.n_inst; i++) {
+            const uint64_t *in = t.inst + i * (t.n_in + 1);
+            for (uint64_t j = 0; j < t.n_in; j++) if (in[j] >= c->n_wires) return false;
+            if (in[t.n_in] + t.n_int > c->n_wires || in[t.n_in] < 1 + c->n_pub) return false;
+        }
+        next_row += t.n_inst * t.n_rows;
+        c->n_arith_rows += t.n_inst * t.n_rows;
+        c->ar.push_back(t);
+    }
+    return true;
+}
+
 bool parse(const uint64_t *d, size_t words, Circ *c) {
-    if (!d || words < 16 || d[0] != MAGIC) return false;
+    if (!d || words < 16 || (d[0] != MAGIC && d[0] != MAGIC2)) return false;
+    const uint64_t n_tpl = d[0] == MAGIC2 ? d[11] : 0;
+    if (n_tpl > 16) return false;
+    c->ar.clear();
+    c->n_arith_rows = 0;
     c->n_wires = d[1]; c->n_cons = d[2]; c->logm = d[3]; c->t = d[4]; c->n_local = d[5]; c->tc = d[6]; c->n_inst = d[7]; c->n_extra = d[8]; c->n_pub = d[9];
     c->n_waves = d[10];
     if (c->n_wires < 2 || c->n_wires > (1ull << 28) || c->logm > 28 || c->t < 2 || c->t > 64 || c->n_local < 1 + c->t || c->n_local > (1u << 20) || c->tc < 1 ||
         c->tc > (1u << 20) || c->n_inst > (1u << 24) || c->n_extra > (1ull << 28) || c->n_pub < 1 || 1 + c->n_pub > c->n_wires)
         return false;
-    if (c->n_cons != c->n_inst * c->tc + c->n_extra || c->n_cons > (1ull << c->logm)) return false;
+    if (c->n_cons < c->n_inst * c->tc + c->n_extra || c->n_cons > (1ull << c->logm)) return false;
     size_t at = 16;
     if (at + c->tc > words) return false;
     c->tdef = d + at; at += c->tc;
@@ -151,7 +222,152 @@ bool parse(const uint64_t *d, size_t words, Circ *c) {
     c->edef = d + at; at += c->n_extra;
     for (uint64_t q = 0; q < c->n_extra; q++) if (c->edef[q] != ~0ull && c->edef[q] >= c->n_wires) return false;
     for (int k = 0; k < 3; k++) if (!parse_mat(d, words, at, c->n_extra, c->n_wires, &c->E[k])) return false;
-    return at == words;
+    if (!parse_arith(d, words, at, n_tpl, c)) return false;
+    return at == words && c->n_cons == c->n_inst * c->tc + c->n_extra + c->n_arith_rows;
+}
+
+// ---- the witness programs of the arithmetic templates, on the host.  W u64[n_wires][4]: wire values in standard form; set[n_wires].
+// Goldilocks on the host for the one op that needs it (the inverse in F_p^3)
+constexpr uint64_t GLP = 0xFFFFFFFF00000001ULL;
+inline uint64_t glh_mul(uint64_t a, uint64_t b) { return (uint64_t)((u128)a * b % GLP); }
+inline uint64_t glh_add(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a + b) % GLP); }
+inline uint64_t glh_sub(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a + GLP - b) % GLP); }
+uint64_t glh_inv(uint64_t a) {
+    uint64_t r = 1, e = GLP - 2;
+    while (e) { if (e & 1) r = glh_mul(r, a); a = glh_mul(a, a); e >>= 1; }
+    return r;
+}
+// y with x y = 1 in F_p[t] / (t^3 - t - 1): Cramer's rule on the multiplication matrix of x (columns: x, x t, x t^2 in the basis 1, t, t^2)
+bool glh_e3_inv(const uint64_t x[3], uint64_t y[3]) {
+    const uint64_t a0 = x[0], a1 = x[1], a2 = x[2];
+    const uint64_t m[3][3] = {{a0, a2, a1}, {a1, glh_add(a0, a2), glh_add(a1, a2)}, {a2, a1, glh_add(a0, a2)}};
+    auto det2 = [&](int r0, int r1, int c0, int c1) { return glh_sub(glh_mul(m[r0][c0], m[r1][c1]), glh_mul(m[r0][c1], m[r1][c0])); };
+    const uint64_t c00 = det2(1, 2, 1, 2), c01 = det2(1, 2, 0, 2), c02 = det2(1, 2, 0, 1);
+    const uint64_t det = glh_add(glh_sub(glh_mul(m[0][0], c00), glh_mul(m[0][1], c01)), glh_mul(m[0][2], c02));
+    if (det == 0) return false;
+    const uint64_t di = glh_inv(det);
+    // the first column of the inverse matrix = the solution of M y = e_0: cofactors of the first ROW, signs alternating
+    y[0] = glh_mul(c00, di);
+    y[1] = glh_mul(glh_sub(0, c01), di);
+    y[2] = glh_mul(c02, di);
+    return true;
+}
+struct ArithCoefs { std::vector<Fr> m; };       // a template's coefficients in Montgomery form: fr_mul(coef, standard-form wire) = the standard-form product
+void arith_coefs(const ArithT &t, ArithCoefs *out) {
+    out->m.resize(t.n_coef);
+    for (uint64_t i = 0; i < t.n_coef; i++) out->m[i] = fr_from_std(t.coef + 4 * i);
+}
+// value of LC `id` of instance `in` over W (standard form); false: it reads a wire nobody has set
+inline bool arith_lc(const ArithT &t, const ArithCoefs &cf, const uint64_t *in, uint32_t id, const uint64_t *W, const uint8_t *set, Fr *out) {
+    if (id & AR_UNIT) {
+        const uint64_t g = t.global(in, id & (AR_UNIT - 1));
+        if (!set[g]) return false;
+        memcpy(out->l, W + 4 * g, 32);
+        return true;
+    }
+    Fr acc = {{0, 0, 0, 0}};
+    for (uint64_t e = t.lc_ptr[id]; e < t.lc_ptr[id + 1]; e++) {
+        const uint64_t g = t.global(in, t.lc_ent[e] & 0xFFFFFFFFull);
+        if (!set[g]) return false;
+        Fr w;
+        memcpy(w.l, W + 4 * g, 32);
+        acc = fr_add(acc, fr_mul(cf.m[t.lc_ent[e] >> 32], w));
+    }
+    *out = acc;
+    return true;
+}
+// runs the witness program of instance i: 0 = done, -20 = an op cannot be carried out (no witness: the statement is false), -21 = unset input
+int32_t arith_witness(const ArithT &t, const ArithCoefs &cf, uint64_t i, uint64_t *W, uint8_t *set) {
+    const uint64_t *in = t.inst + i * (t.n_in + 1);
+    auto put = [&](uint64_t local, const uint64_t *v4) {
+        const uint64_t g = t.global(in, local);
+        memcpy(W + 4 * g, v4, 32);
+        set[g] = 1;
+    };
+    for (uint64_t o = 0; o < t.n_ops; o++) {
+        const uint64_t *op = t.ops + 4 * o;
+        const uint64_t code = op[0] & 0xFF, nbits = (op[0] >> 8) & 0xFFFF, flag = (op[0] >> 24) & 0xFF, dst = op[1];
+        Fr a, b, c3;
+        if (!arith_lc(t, cf, in, (uint32_t)(op[2] & 0xFFFFFFFFull), W, set, &a)) return -21;
+        if (code == AR_OP_MUL) {
+            if (!arith_lc(t, cf, in, (uint32_t)(op[2] >> 32), W, set, &b)) return -21;
+            const Fr pr = fr_mul(fr_mul(a, FR_R2), b);
+            put(dst, pr.l);
+        } else if (code == AR_OP_DIVMOD) {
+            uint64_t q[4], rem = 0;
+            for (int k = 3; k >= 0; k--) {
+                const u128 cur = ((u128)rem << 64) | a.l[k];
+                q[k] = (uint64_t)(cur / GLP);
+                rem = (uint64_t)(cur % GLP);
+            }
+            if (flag == 2) {
+                if (rem) return -20;
+                put(dst, q);
+            } else {
+                const uint64_t r4[4] = {rem, 0, 0, 0};
+                put(dst, q);
+                put(dst + 1, r4);
+            }
+        } else if (code == AR_OP_BITS) {
+            for (uint64_t k = nbits; k < 256; k++)
+                if ((a.l[k >> 6] >> (k & 63)) & 1) return -20;
+            for (uint64_t k = 0; k < nbits; k++) {
+                const uint64_t v4[4] = {(a.l[k >> 6] >> (k & 63)) & 1, 0, 0, 0};
+                put(dst + k, v4);
+            }
+        } else {        // AR_OP_INV3
+            if (!arith_lc(t, cf, in, (uint32_t)(op[2] >> 32), W, set, &b) || !arith_lc(t, cf, in, (uint32_t)op[3], W, set, &c3)) return -21;
+            auto modp = [](const Fr &v) {
+                uint64_t rem = 0;
+                for (int k = 3; k >= 0; k--) rem = (uint64_t)((((u128)rem << 64) | v.l[k]) % GLP);
+                return rem;
+            };
+            const uint64_t x[3] = {modp(a), modp(b), modp(c3)};
+            uint64_t y[3];
+            if (!glh_e3_inv(x, y)) return -20;
+            for (int k = 0; k < 3; k++) {
+                const uint64_t v4[4] = {y[k], 0, 0, 0};
+                put(dst + k, v4);
+            }
+        }
+    }
+    return ZP_OK;
+}
+// every instance of every template whose internal wires the caller did not set, in blob order (a template's instances on threads: they read
+// caller-set wires and wires of EARLIER templates, and write their own).  *bad: the first row of the instance that has no witness.
+int32_t arith_witness_all(const Circ &c, uint64_t *W, uint8_t *set, int64_t *bad) {
+    for (const ArithT &t : c.ar) {
+        ArithCoefs cf;
+        arith_coefs(t, &cf);
+        std::atomic<int64_t> fail{-1};
+        std::atomic<int32_t> code{ZP_OK};
+        std::atomic<uint64_t> next{0};
+        auto body = [&]() {
+            for (;;) {
+                const uint64_t i = next.fetch_add(1);
+                if (i >= t.n_inst) return;
+                if (set[t.inst[i * (t.n_in + 1) + t.n_in]]) continue;           // the caller brought this instance's wires (a complete witness)
+                const int32_t rc = arith_witness(t, cf, i, W, set);
+                if (rc != ZP_OK) {
+                    int64_t cur = fail.load();
+                    const int64_t row = (int64_t)(t.first_row + i * t.n_rows);
+                    while ((cur < 0 || row < cur) && !fail.compare_exchange_weak(cur, row)) {}
+                    code.store(rc);
+                }
+            }
+        };
+        int T = (int)std::thread::hardware_concurrency();
+        if (T > 16) T = 16;
+        if ((uint64_t)T > t.n_inst) T = (int)t.n_inst;
+        if (T <= 1) body();
+        else {
+            std::vector<std::thread> pool;
+            for (int k = 0; k < T; k++) pool.emplace_back(body);
+            for (auto &th : pool) th.join();
+        }
+        if (fail.load() >= 0) { if (bad) *bad = fail.load(); return code.load(); }
+    }
+    return ZP_OK;
 }
 
 inline uint64_t local_to_global(const Circ &c, const uint64_t *in, uint64_t local) {
@@ -175,6 +391,11 @@ int32_t zp_r1cs_eval(const uint64_t *circ, size_t words, uint64_t *witness, uint
     if (!parse(circ, words, &c) || !witness || !set || !a_ev || !b_ev || !c_ev) return ZP_ERR_ARG;
     if (bad) *bad = -1;
     try {
+        if (!c.ar.empty()) {
+            for (uint64_t j = 0; j < c.n_wires; j++) if (set[j] && !std_canonical(witness + 4 * j)) return ZP_ERR_ARG;
+            const int32_t arc = arith_witness_all(c, witness, set, bad);
+            if (arc != ZP_OK) return arc;
+        }
         std::vector<Fr> w(c.n_wires);
         for (uint64_t j = 0; j < c.n_wires; j++)
             if (set[j]) {
@@ -265,6 +486,48 @@ int32_t zp_r1cs_eval(const uint64_t *circ, size_t words, uint64_t *witness, uint
             }
             const uint64_t row = c.extra_base() + q;
             fr_to_std(s[0], a_ev + 4 * row); fr_to_std(s[1], b_ev + 4 * row); fr_to_std(s[2], c_ev + 4 * row);
+        }
+        for (const ArithT &t : c.ar) {          // the arithmetic templates' rows (their wires are all set: the witness programs ran first)
+            std::vector<Fr> cm(t.n_coef);
+            for (uint64_t i = 0; i < t.n_coef; i++) cm[i] = fr_from_std(t.coef + 4 * i);
+            std::atomic<int64_t> unset_row{-1};
+            auto rows_of = [&](uint64_t i) {
+                const uint64_t *in = t.inst + i * (t.n_in + 1);
+                for (uint64_t q = 0; q < t.n_rows; q++) {
+                    const uint32_t ids[3] = {(uint32_t)(t.rows[2 * q] & 0xFFFFFFFFull), (uint32_t)(t.rows[2 * q] >> 32), (uint32_t)t.rows[2 * q + 1]};
+                    Fr sv[3];
+                    bool ok = true;
+                    for (int k = 0; k < 3 && ok; k++) {
+                        if (ids[k] & AR_UNIT) {
+                            const uint64_t g = t.global(in, ids[k] & (AR_UNIT - 1));
+                            ok = set[g] != 0;
+                            sv[k] = w[g];
+                        } else {
+                            Fr acc = {{0, 0, 0, 0}};
+                            for (uint64_t e = t.lc_ptr[ids[k]]; e < t.lc_ptr[ids[k] + 1] && ok; e++) {
+                                const uint64_t g = t.global(in, t.lc_ent[e] & 0xFFFFFFFFull);
+                                ok = set[g] != 0;
+                                acc = fr_add(acc, fr_mul(cm[t.lc_ent[e] >> 32], w[g]));
+                            }
+                            sv[k] = acc;
+                        }
+                    }
+                    const uint64_t row = t.first_row + i * t.n_rows + q;
+                    if (!ok) { note(unset_row, (int64_t)row); return; }
+                    if (!fr_eq(fr_mul(sv[0], sv[1]), sv[2])) note(first_bad, (int64_t)row);
+                    fr_to_std(sv[0], a_ev + 4 * row); fr_to_std(sv[1], b_ev + 4 * row); fr_to_std(sv[2], c_ev + 4 * row);
+                }
+            };
+            std::atomic<uint64_t> next{0};
+            auto body = [&]() { for (;;) { const uint64_t i = next.fetch_add(1); if (i >= t.n_inst) return; rows_of(i); } };
+            const int nt = (uint64_t)T < t.n_inst ? T : (int)t.n_inst;
+            if (nt <= 1) body();
+            else {
+                std::vector<std::thread> pool;
+                for (int k = 0; k < nt; k++) pool.emplace_back(body);
+                for (auto &th : pool) th.join();
+            }
+            if (unset_row.load() >= 0) { if (bad) *bad = unset_row.load(); return -21; }
         }
         for (uint64_t j = 0; j < c.n_wires; j++) {
             if (!set[j]) { if (bad) *bad = (int64_t)j; return -21; }
@@ -375,6 +638,28 @@ int32_t zp_r1cs_key_scalars(const uint64_t *circ, size_t words, const uint64_t *
                 for (uint64_t x = c.E[k].ptr[q]; x < c.E[k].ptr[q + 1]; x++)
                     acc[k][c.E[k].idx[x]] = fr_add(acc[k][c.E[k].idx[x]], fr_mul(fr_from_std(c.E[k].val + 4 * x), Li));
             }
+        for (const ArithT &t : c.ar) {          // rows of the arithmetic templates: instance by instance over the template's combinations
+            std::vector<Fr> cm(t.n_coef);
+            for (uint64_t i = 0; i < t.n_coef; i++) cm[i] = fr_from_std(t.coef + 4 * i);
+            for (uint64_t i = 0; i < t.n_inst; i++) {
+                const uint64_t *in = t.inst + i * (t.n_in + 1);
+                for (uint64_t q = 0; q < t.n_rows; q++) {
+                    const Fr &Li = L[t.first_row + i * t.n_rows + q];
+                    const uint32_t ids[3] = {(uint32_t)(t.rows[2 * q] & 0xFFFFFFFFull), (uint32_t)(t.rows[2 * q] >> 32), (uint32_t)t.rows[2 * q + 1]};
+                    for (int k = 0; k < 3; k++) {
+                        if (ids[k] & AR_UNIT) {
+                            Fr &a = acc[k][t.global(in, ids[k] & (AR_UNIT - 1))];
+                            a = fr_add(a, Li);
+                        } else {
+                            for (uint64_t e = t.lc_ptr[ids[k]]; e < t.lc_ptr[ids[k] + 1]; e++) {
+                                Fr &a = acc[k][t.global(in, t.lc_ent[e] & 0xFFFFFFFFull)];
+                                a = fr_add(a, fr_mul(cm[t.lc_ent[e] >> 32], Li));
+                            }
+                        }
+                    }
+                }
+            }
+        }
         const Fr dinv = fr_inv(delta), ginv = fr_inv(gamma);
         for (uint64_t j = 0; j < c.n_wires; j++) {
             fr_to_std(acc[0][j], out_u + 4 * j);
@@ -524,6 +809,42 @@ __global__ void __launch_bounds__(256) r1cs_extras_kernel(DevMat A, DevMat B, De
     if (diff) atomicMin(&flags[0], (unsigned long long)(row_base + q));
     r1cs_store(a_ev, row_base + q, a); r1cs_store(b_ev, row_base + q, b); r1cs_store(c_ev, row_base + q, c);
 }
+// the rows of an arithmetic template: one lane per (instance, row); local wires resolve through the instance's input table
+struct ArithDev { u64 n_in, n_int, n_rows, n_inst, first_row; const u64 *coef, *lc_ptr, *lc_ent, *rows, *inst; };
+__device__ fr arith_lc_dev(const ArithDev &t, const u64 *in, u32 id, const u64 *w, const unsigned char *set, bool *unset) {
+    auto global = [&](u64 local) { return local == 0 ? (u64)0 : local <= t.n_in ? in[local - 1] : in[t.n_in] + (local - 1 - t.n_in); };
+    if (id & 0x80000000u) {
+        const u64 g = global(id & 0x7FFFFFFFu);
+        if (!set[g]) *unset = true;
+        return fr_from_u64(w + 4 * g);
+    }
+    fr acc = fr_zero();
+    for (u64 e = t.lc_ptr[id]; e < t.lc_ptr[id + 1]; e++) {
+        const u64 g = global(t.lc_ent[e] & 0xFFFFFFFFull);
+        if (!set[g]) *unset = true;
+        acc = fr_add(acc, fr_mul(fr_to_mont(fr_from_u64(t.coef + 4 * (t.lc_ent[e] >> 32))), fr_from_u64(w + 4 * g)));
+    }
+    return acc;
+}
+__global__ void __launch_bounds__(256) r1cs_arith_rows_kernel(ArithDev t, const u64 *__restrict__ w, const unsigned char *__restrict__ set, u64 *__restrict__ a_ev,
+                                                              u64 *__restrict__ b_ev, u64 *__restrict__ c_ev, unsigned long long *flags) {
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= t.n_inst * t.n_rows) return;
+    // consecutive lanes take the SAME row of consecutive instances: they walk the same combination (no divergence) over different wires
+    const u64 i = id % t.n_inst, q = id / t.n_inst;
+    const u64 *in = t.inst + i * (t.n_in + 1);
+    bool unset = false;
+    const fr a = arith_lc_dev(t, in, (u32)(t.rows[2 * q] & 0xFFFFFFFFull), w, set, &unset), b = arith_lc_dev(t, in, (u32)(t.rows[2 * q] >> 32), w, set, &unset),
+             c = arith_lc_dev(t, in, (u32)t.rows[2 * q + 1], w, set, &unset);
+    const u64 row = t.first_row + i * t.n_rows + q;
+    if (unset) { atomicMin(&flags[1], (unsigned long long)row); return; }
+    const fr ab = fr_mul(fr_to_mont(a), b);
+    u32 diff = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) diff |= ab.l[k] ^ c.l[k];
+    if (diff) atomicMin(&flags[0], (unsigned long long)row);
+    r1cs_store(a_ev, row, a); r1cs_store(b_ev, row, b); r1cs_store(c_ev, row, c);
+}
 __global__ void __launch_bounds__(256) r1cs_allset_kernel(const unsigned char *__restrict__ set, size_t n, unsigned long long *flags) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j < n && !set[j]) atomicMin(&flags[2], (unsigned long long)j);
@@ -538,9 +859,16 @@ struct ZpG16Cache {
     u64 *d_blob = nullptr, *d_defs = nullptr;
     size_t n_defs = 0;
     bool checked = false;
+    // circuits with arithmetic templates: the host's copy of the witness (standard form; page-locked when the runtime grants it) the witness
+    // programs run on, and its set flags -- kept between proofs, only the wires a proof sets are touched
+    uint64_t *hW = nullptr;
+    bool hW_pinned = false;
+    std::vector<uint8_t> hset;
+    std::vector<uint64_t> touched;       // the wires the last proof set from outside (their flags are cleared before the next one)
 };
 void zpi_g16_cache_free(zp_ctx *ctx) {
     if (!ctx->g16_cache) return;
+    if (ctx->g16_cache->hW) { if (ctx->g16_cache->hW_pinned) (void)hipHostFree(ctx->g16_cache->hW); else free(ctx->g16_cache->hW); }
     if (ctx->g16_cache->d_blob) (void)hipFree(ctx->g16_cache->d_blob);
     if (ctx->g16_cache->d_defs) (void)hipFree(ctx->g16_cache->d_defs);
     delete ctx->g16_cache;
@@ -552,7 +880,8 @@ namespace {
 // device evaluation of the parsed circuit c (its blob resident at d_blob): d_w u64[>= n_wires][4] and d_set are overwritten; d_a / d_b / d_c
 // u64[2^logm][4].  flags (host, 3 words): first violated row, first row that reads an unset wire, first wire left unset -- ~0 = none.
 int32_t eval_device(zp_ctx *ctx, const Circ &c, const uint64_t *circ, const u64 *d_blob, const u64 *d_defs, size_t n_defs, const u64 *d_idx, const u64 *d_val,
-                    size_t n_set, u64 *d_w, unsigned char *d_set, u64 *d_a, u64 *d_b, u64 *d_c, unsigned long long *d_flags, unsigned long long *h_flags) {
+                    size_t n_set, u64 *d_w, unsigned char *d_set, u64 *d_a, u64 *d_b, u64 *d_c, unsigned long long *d_flags, unsigned long long *h_flags,
+                    const uint64_t *hW = nullptr) {
     const size_t m = (size_t)1 << c.logm;
     ZP_HIP(ctx, hipMemsetAsync(d_w, 0, c.n_wires * 32, ctx->stream));
     ZP_HIP(ctx, hipMemsetAsync(d_set, 0, c.n_wires, ctx->stream));
@@ -562,6 +891,16 @@ int32_t eval_device(zp_ctx *ctx, const Circ &c, const uint64_t *circ, const u64 
     ZP_HIP(ctx, hipMemsetAsync(d_flags, 0xFF, 24, ctx->stream));
     hipLaunchKernelGGL(r1cs_scatter_kernel, dim3((unsigned)((n_set + 255) / 256)), dim3(256), 0, ctx->stream, d_idx, d_val, n_set, d_w, d_set);
     ZP_HIP(ctx, hipGetLastError());
+    // the internal wires of the arithmetic templates come from the host (hW: the witness programs ran there): every instance's wires are one
+    // contiguous range of the witness
+    for (const ArithT &t : c.ar) {
+        ZP_ARG(ctx, hW != nullptr, "internal: arithmetic templates without their host witness");
+        for (uint64_t i = 0; i < t.n_inst; i++) {
+            const uint64_t base = t.inst[i * (t.n_in + 1) + t.n_in];
+            ZP_HIP(ctx, hipMemcpyAsync(d_w + 4 * base, hW + 4 * base, t.n_int * 32, hipMemcpyHostToDevice, ctx->stream));
+            ZP_HIP(ctx, hipMemsetAsync(d_set + base, 1, t.n_int, ctx->stream));
+        }
+    }
     const u64 *d_inst = d_blob + (c.inst - circ);
     for (uint64_t wv = 0; wv < c.n_waves; wv++)
         ZP_TRY(zpi_r1cs_poseidon17(ctx, d_inst, c.waves[wv], c.waves[wv + 1] - c.waves[wv], d_w, d_set, d_a, d_b, d_c, d_flags, nullptr));
@@ -575,6 +914,14 @@ int32_t eval_device(zp_ctx *ctx, const Circ &c, const uint64_t *circ, const u64 
     if (c.n_extra) {
         hipLaunchKernelGGL(r1cs_extras_kernel, dim3((unsigned)((c.n_extra + 255) / 256)), dim3(256), 0, ctx->stream, E[0], E[1], E[2], (size_t)c.n_extra,
                            (u64)c.extra_base(), (const u64 *)d_w, (const unsigned char *)d_set, d_a, d_b, d_c, d_flags);
+        ZP_HIP(ctx, hipGetLastError());
+    }
+    for (const ArithT &t : c.ar) {
+        const ArithDev td = {t.n_in, t.n_int, t.n_rows, t.n_inst, t.first_row, d_blob + (t.coef - circ), d_blob + (t.lc_ptr - circ), d_blob + (t.lc_ent - circ),
+                             d_blob + (t.rows - circ), d_blob + (t.inst - circ)};
+        const size_t lanes = (size_t)(t.n_inst * t.n_rows);
+        hipLaunchKernelGGL(r1cs_arith_rows_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, td, (const u64 *)d_w, (const unsigned char *)d_set, d_a,
+                           d_b, d_c, d_flags);
         ZP_HIP(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(r1cs_allset_kernel, dim3((unsigned)((c.n_wires + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned char *)d_set, (size_t)c.n_wires, d_flags);
@@ -704,7 +1051,33 @@ int32_t zp_r1cs_eval_device(zp_ctx *ctx, const uint64_t *circ, size_t words, con
         ctx->err = "upload of the set wires failed";
         rc = ZP_ERR_HIP;
     }
-    if (rc == ZP_OK) rc = eval_device(ctx, c, circ, g->d_blob, g->d_defs, g->n_defs, d_idx, d_val, n_set, (u64 *)d_w, d_set, (u64 *)d_a, (u64 *)d_b, (u64 *)d_c, d_flags, hf);
+    if (rc == ZP_OK && !c.ar.empty()) {
+        // the witness programs of the arithmetic templates, on the host, over the caller-set wires (they read nothing else)
+        if (!g->hW) {
+            void *hp = nullptr;
+            if (hipHostMalloc(&hp, c.n_wires * 32, hipHostMallocDefault) == hipSuccess) { g->hW = (uint64_t *)hp; g->hW_pinned = true; }
+            else { (void)hipGetLastError(); g->hW = (uint64_t *)malloc(c.n_wires * 32); }
+            if (!g->hW) { ctx->err = "out of host memory for the witness"; rc = ZP_ERR_NOMEM; }
+            else g->hset.assign(c.n_wires, 0);
+        }
+        if (rc == ZP_OK) {
+            for (uint64_t j : g->touched) g->hset[j] = 0;
+            for (const ArithT &t : c.ar)
+                for (uint64_t i = 0; i < t.n_inst; i++) memset(g->hset.data() + t.inst[i * (t.n_in + 1) + t.n_in], 0, t.n_int);
+            g->touched.assign(set_idx, set_idx + n_set);
+            for (size_t k = 0; k < n_set; k++) {
+                memcpy(g->hW + 4 * set_idx[k], set_val + 4 * k, 32);
+                g->hset[set_idx[k]] = 1;
+            }
+            const int32_t arc = arith_witness_all(c, g->hW, g->hset.data(), bad);
+            if (arc != ZP_OK) {
+                ctx->err = arc == -20 ? "the assignment does not satisfy the circuit: no proof for a false statement" : "a wire of the circuit has no value";
+                rc = arc;
+            }
+        }
+    }
+    if (rc == ZP_OK) rc = eval_device(ctx, c, circ, g->d_blob, g->d_defs, g->n_defs, d_idx, d_val, n_set, (u64 *)d_w, d_set, (u64 *)d_a, (u64 *)d_b, (u64 *)d_c, d_flags, hf,
+                                      g->hW);
     if (rc == ZP_OK) rc = zpi_d2h_small(ctx, out_pub, (u64 *)d_w + 4, c.n_pub * 32);
     zpi_pool_release(ctx, d, bytes);
     if (rc != ZP_OK) return rc;
