@@ -15,7 +15,11 @@ Blob layout (u64 words; "PZR1CS01"):
              waves[n_waves + 1] ([10] = n_waves): the instances of wave k, [waves[k], waves[k + 1]), read only wires that the caller set or an
              earlier wave defined -- they are evaluated in parallel
   extras: def[n_extra] (the global wire extra constraint q defines, ~0: none), then for A, B, C: ptr[n_extra + 1], idx[nnz] (global wires), val[nnz][4]
-Constraint numbering: instance i owns [i tc, (i + 1) tc), the extras follow.  Wire 0 = 1, wires 1..n_pub the public inputs."""
+Constraint numbering: instance i owns [i tc, (i + 1) tc), the extras follow.  Wire 0 = 1, wires 1..n_pub the public inputs.
+
+"PZR1CS02" (round 6, wrap stage B-2): word [11] of the header counts ARITHMETIC TEMPLATES (service/arith.py: Goldilocks arithmetic inside F_r), whose
+sections follow the extras in evaluation order; their constraints follow the extras' (template k's instance i owns n_rows consecutive rows from
+first_row + i n_rows).  A circuit without such templates is still written as "PZR1CS01"."""
 from __future__ import annotations
 
 import numpy as np
@@ -24,6 +28,7 @@ from ..poseidon_constants import bn254_poseidon_params
 
 R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 MAGIC = int.from_bytes(b"PZR1CS01", "little")
+MAGIC2 = int.from_bytes(b"PZR1CS02", "little")
 NONE = (1 << 64) - 1
 _TEMPLATES = {}
 
@@ -111,6 +116,7 @@ class Circuit:
         self.tpl, self.n_pub = template, n_pub
         self.n_wires = 1 + n_pub
         self.instances, self.extras = [], []
+        self.ariths = []                 # [(arith.Template, [(input global wires, base of the internal wires)])] in evaluation order
         self._out_wave, self._by_out = {}, {}
 
     def new_wire(self):
@@ -139,6 +145,23 @@ class Circuit:
         inputs, base = self._by_out[out_wire]
         return {self.local_to_global(inputs, base, k): v for k, v in self.tpl.out_lcs[i].items()}
 
+    def add_arith_template(self, tpl):
+        """registers an arithmetic template (service/arith.py Template); returns its handle for add_arith.  Templates are evaluated in the order
+        they are registered: an instance may read internal wires of instances of EARLIER templates (besides caller-set wires)."""
+        self.ariths.append((tpl, []))
+        return len(self.ariths) - 1
+
+    def add_arith(self, handle, inputs):
+        """one instance: `inputs` are global wires (caller-set, or internal wires of an earlier template's instance); returns f(local wire) ->
+        global wire for the instance's wires"""
+        tpl, insts = self.ariths[handle]
+        assert len(inputs) == tpl.n_in and all(0 <= w < self.n_wires for w in inputs)
+        base = self.n_wires
+        self.n_wires += tpl.n_int
+        insts.append((list(inputs), base))
+        ins, n_in = list(inputs), tpl.n_in
+        return lambda lw: 0 if lw == 0 else ins[lw - 1] if lw <= n_in else base + (lw - 1 - n_in)
+
     def add_constraint(self, A, B, C, defines=None):
         """defines: a wire (coefficient 1 in C) that this constraint DEFINES when nobody has set it: value = (A w)(B w) - (rest of C w)"""
         assert defines is None or C.get(defines) == 1
@@ -146,7 +169,7 @@ class Circuit:
 
     @property
     def n_constraints(self):
-        return len(self.instances) * len(self.tpl.cons) + len(self.extras)
+        return len(self.instances) * len(self.tpl.cons) + len(self.extras) + sum(len(t.rows) * len(i) for t, i in self.ariths)
 
     def logm(self):
         lm = 1
@@ -159,7 +182,9 @@ class Circuit:
         self.instances.sort(key=lambda it: it[2])            # by wave (stable: constraint numbering follows this order)
         n_waves = (self.instances[-1][2] + 1) if self.instances else 1
         bounds = [sum(1 for it in self.instances if it[2] < k) for k in range(n_waves + 1)]
-        hdr = [MAGIC, self.n_wires, self.n_constraints, self.logm(), tpl.t, tpl.n_local, tc, len(self.instances), len(self.extras), self.n_pub, n_waves] + [0] * 5
+        ariths = [(t, i) for t, i in self.ariths if i]
+        hdr = [MAGIC2 if ariths else MAGIC, self.n_wires, self.n_constraints, self.logm(), tpl.t, tpl.n_local, tc, len(self.instances), len(self.extras), self.n_pub,
+               n_waves, len(ariths)] + [0] * 4
         body = [c[3] for c in tpl.cons]
         for k in range(3):
             body += _csr([c[k] for c in tpl.cons])
@@ -169,6 +194,10 @@ class Circuit:
         body += [NONE if e[3] is None else e[3] for e in self.extras]
         for k in range(3):
             body += _csr([e[k] for e in self.extras])
+        row = len(self.instances) * tc + len(self.extras)
+        for t, insts in ariths:
+            body += t.pack(insts, row)
+            row += len(t.rows) * len(insts)
         return np.array(hdr + body, dtype=np.uint64)
 
     # ---- reference evaluation (Python integers): what zp_r1cs_eval does, for tests
@@ -182,12 +211,32 @@ class Circuit:
                 yield tuple({self.local_to_global(inputs, base, k): v for k, v in M.items()} for M in (A, B, C))
         for e in self.extras:
             yield e[:3]
+        from .arith import UNIT
+        for t, insts in self.ariths:
+            for ins, base in insts:
+                g = lambda lw: 0 if lw == 0 else ins[lw - 1] if lw <= t.n_in else base + (lw - 1 - t.n_in)
+                lc = lambda i: {g(i & (UNIT - 1)): 1} if i & UNIT else {g(k): t.coefs[c] for c, k in t.lcs[i]}
+                for (a, b, c) in t.rows:
+                    yield lc(a), lc(b), lc(c)
 
     def complete(self, w):
         """w: dict {global wire: value} of the caller-set wires -> full assignment list, or raises ValueError on a violated constraint"""
         w = dict(w)
         w[0] = 1
         dot = lambda M: sum(c * w[k] for k, c in M.items()) % R
+        from .arith import NoWitness
+        for t, insts in self.ariths:              # the arithmetic templates' witness programs, in order (they read caller-set wires and earlier templates)
+            for ins, base in insts:
+                if base in w:
+                    continue
+                try:
+                    loc = t.run([w[k] for k in ins])
+                except NoWitness as e:
+                    raise ValueError("constraint violated (no witness: %s)" % e)
+                if t.check(loc) >= 0:
+                    raise ValueError("constraint violated")
+                for k in range(t.n_int):
+                    w[base + k] = loc[1 + t.n_in + k]
         for inputs, base, _ in sorted(self.instances, key=lambda it: it[2]):
             for (A, B, C, d) in self.tpl.cons:
                 g = lambda M: {self.local_to_global(inputs, base, k): v for k, v in M.items()}
