@@ -93,6 +93,7 @@ struct Transcript {
     bool bn;
     u64 state[17 * 4];                 // GL: 12 words; BN: 17 elements of 4 words (standard form)
     std::vector<u64> pending, out;     // GL: values; BN: pending holds 4 words per element
+    std::vector<u64> log_chal;         // BN: rate element 1 after every flush (4 words each): what the challenge squeezed there is read from (wrap stage B-2)
     std::vector<u64> log_blocks, last_rates, log_caps;   // BN: every absorbed block (16 elements x 4 words) in order; the rate elements of the latest flush; the capacity after every permutation (the wrap circuit's transcript gadgets: zp_wrap_assign)
     int32_t rc = ZP_OK;
     Transcript(zp_ctx *c, bool bn_) : ctx(c), bn(bn_) { memset(state, 0, sizeof state); }
@@ -138,6 +139,7 @@ struct Transcript {
             if (r != ZP_OK && rc == ZP_OK) rc = r;
             log_blocks.insert(log_blocks.end(), blocks.begin(), blocks.end());
             log_caps.insert(log_caps.end(), caps.begin(), caps.end());
+            log_chal.insert(log_chal.end(), rates.begin(), rates.begin() + 4);
             last_rates = rates;
             out.clear();
             for (size_t e = 0; e < rates.size() / 4; e++)
@@ -195,7 +197,7 @@ struct TreeOut { size_t width, rows; const u64 *root; const std::vector<u64> *va
 void openings_record(zp_ctx *ctx, const Transcript &tr, const std::vector<u64> &qidx, int logm, const std::vector<TreeOut> &trees) {
     std::vector<u64> &rec = ctx->last_openings;
     rec.clear();
-    rec.insert(rec.end(), {0x32304e45504f5a50ULL /* "PZOPEN02" */, (u64)qidx.size(), (u64)trees.size(), (u64)logm});
+    rec.insert(rec.end(), {0x33304e45504f5a50ULL /* "PZOPEN03" */, (u64)qidx.size(), (u64)trees.size(), (u64)logm});
     for (const TreeOut &t : trees) rec.insert(rec.end(), {(u64)t.width, (u64)t.rows, (u64)Trees::levels16(t.rows)});
     for (const TreeOut &t : trees) rec.insert(rec.end(), t.root, t.root + 4);
     for (size_t i = 0; i < qidx.size(); i++) {
@@ -211,6 +213,8 @@ void openings_record(zp_ctx *ctx, const Transcript &tr, const std::vector<u64> &
     rec.insert(rec.end(), tr.log_blocks.begin(), tr.log_blocks.end());
     rec.insert(rec.end(), tr.last_rates.begin(), tr.last_rates.end());
     rec.insert(rec.end(), tr.log_caps.begin(), tr.log_caps.end());         // one per permutation: n_blocks + (n_rates - 1)
+    rec.push_back((u64)(tr.log_chal.size() / 4));                           // "PZOPEN03": the rate element behind every challenge, in squeeze order
+    rec.insert(rec.end(), tr.log_chal.begin(), tr.log_chal.end());
 }
 
 // Device buffers of one proof.  They come from, and go back to, a per-ctx pool keyed by size: everything runs on the ctx

@@ -686,8 +686,8 @@ int32_t zp_r1cs_key_scalars(const uint64_t *circ, size_t words, const uint64_t *
 //                      the blinding terms -> the three proof elements
 namespace {
 
-constexpr uint64_t SCRIPT_MAGIC = 0x3253504152575a50ULL;   // "PZWRAPS2" (round 5: the transcript section)
-constexpr uint64_t OPEN_MAGIC = 0x32304e45504f5a50ULL;     // "PZOPEN02"
+constexpr uint64_t SCRIPT_MAGIC = 0x3353504152575a50ULL;   // "PZWRAPS3" (round 6: challenge elements, a list of aux elements)
+constexpr uint64_t OPEN_MAGIC = 0x33304e45504f5a50ULL;     // "PZOPEN03" (round 6: + the rate element behind every challenge)
 
 struct OpenTree { uint64_t width, leaves, levels; const uint64_t *root; size_t off; };   // off: word offset of this tree's part inside a query record
 struct Openings {
@@ -698,8 +698,9 @@ struct Openings {
     // the transcript of the proof (round 5): every block of 16 field elements its sponge absorbed, in order, then the 16 rate elements of the
     // last absorbing permutation and of the squeeze-only permutations behind it (csrc/prove.hip writes them, service/wrap_circuit.py
     // TranscriptLog states them); 4 words per element
-    uint64_t n_blocks, n_rates;
+    uint64_t n_blocks, n_rates, n_chal;
     const uint64_t *blocks, *rates, *caps;      // caps: the capacity after every permutation (n_blocks + n_rates - 1 of them)
+    const uint64_t *chal;                        // rate element 1 after every absorbed segment: what the challenge squeezed there is read from
     const uint64_t *query(uint64_t q) const { return q0 + q * qwords; }
 };
 bool parse_openings(const uint64_t *d, size_t words, Openings *o) {
@@ -725,7 +726,12 @@ bool parse_openings(const uint64_t *d, size_t words, Openings *o) {
     o->blocks = d + at + 2;
     o->rates = o->blocks + o->n_blocks * 64;
     o->caps = o->rates + o->n_rates * 64;
-    return words == at + 2 + (o->n_blocks + o->n_rates) * 64 + (o->n_blocks + o->n_rates - 1) * 4;
+    const size_t at2 = at + 2 + (o->n_blocks + o->n_rates) * 64 + (o->n_blocks + o->n_rates - 1) * 4;
+    if (words < at2 + 1) return false;
+    o->n_chal = d[at2];
+    if (o->n_chal > 256) return false;
+    o->chal = d + at2 + 1;
+    return words == at2 + 1 + o->n_chal * 4;
 }
 // the scalar field's modulus r, little-endian words, and bit i of a 4-word value
 constexpr uint64_t FR_R[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
@@ -1112,16 +1118,20 @@ extern "C" {
 //      (walking down from bit 253 over the positions where r has a 1: the AND of the element's bits there, first position excluded)
 //   14 the 30 partial products of the top 32 bits of 64-bit word c of that element (bits 32..33, 32..34, ... 32..62 of the word)
 //   15 the capacity element after permutation a of the transcript (absorbing permutations in order, then the squeeze-only ones)
+//   16 challenge element a (rate element 1 after absorbed segment a)               17 its low 192 bits (zeta as the circuit commits to it)
+// aux u64[n_aux][4]: element 0 the value the proof is bound to (the aggregator address), elements 1.. whatever else the circuit takes from its
+// caller (stage B-2: the statement's sparse fixed columns at zeta, one packed element each) -- op 1 reads element a.
 // out_idx u64[cap], out_val u64[cap][4] (standard form) receive the wires and their values; *n_set their number ([2] of the script).
-int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64_t *openings, size_t open_words, const uint64_t *aux4, uint64_t *out_idx,
+int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64_t *openings, size_t open_words, const uint64_t *aux, size_t n_aux, uint64_t *out_idx,
                        uint64_t *out_val, size_t cap, size_t *n_set) {
     Openings o;
-    if (!script || script_words < 6 || script[0] != SCRIPT_MAGIC || !aux4 || !out_idx || !out_val || !n_set || !parse_openings(openings, open_words, &o))
+    if (!script || script_words < 6 || script[0] != SCRIPT_MAGIC || !aux || n_aux < 1 || !out_idx || !out_val || !n_set || !parse_openings(openings, open_words, &o))
         return ZP_ERR_ARG;
     const uint64_t ne = script[1], total = script[2];
-    if (script[3] != o.nq || script[4] != o.ntr || script[5] != o.logm || ne > (1ull << 28) || script_words != 8 + 3 * o.ntr + 6 * ne || total > cap ||
-        !std_canonical(aux4))
+    if (script[3] != o.nq || script[4] != o.ntr || script[5] != o.logm || ne > (1ull << 28) || script_words != 8 + 3 * o.ntr + 6 * ne || total > cap)
         return ZP_ERR_ARG;
+    for (size_t i = 0; i < n_aux; i++) if (!std_canonical(aux + 4 * i)) return ZP_ERR_ARG;
+    for (uint64_t i = 0; i < o.n_chal; i++) if (!std_canonical(o.chal + 4 * i)) return ZP_ERR_ARG;
     for (uint64_t t = 0; t < o.ntr; t++)
         if (script[6 + 3 * t] != o.tr[t].width || script[7 + 3 * t] != o.tr[t].leaves || script[8 + 3 * t] != o.tr[t].levels) return ZP_ERR_ARG;   // another layout
     if (script[6 + 3 * o.ntr] != o.n_blocks || script[7 + 3 * o.ntr] != o.n_rates) return ZP_ERR_ARG;                                              // another transcript
@@ -1135,7 +1145,15 @@ int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64
     size_t n = 0;
     for (uint64_t k = 0; k < ne; k++, e += 6) {
         const uint64_t op = e[0], wire = e[1], cnt = e[2], a = e[3], b = e[4], c = e[5];
-        if (cnt < 1 || cnt > 64 || n + cnt > total || op > 15) return ZP_ERR_ARG;
+        if (cnt < 1 || cnt > 64 || n + cnt > total || op > 17) return ZP_ERR_ARG;
+        if (op >= 16) {                      // a challenge element, whole (16) or its low 192 bits (17)
+            if (cnt != 1 || a >= o.n_chal) return ZP_ERR_ARG;
+            out_idx[n] = wire;
+            memcpy(out_val + 4 * n, o.chal + 4 * a, 32);
+            if (op == 17) out_val[4 * n + 3] = 0;
+            n++;
+            continue;
+        }
         if (op == 15) {                      // the capacity after permutation a of the transcript
             if (cnt != 1 || a >= o.n_blocks + o.n_rates - 1) return ZP_ERR_ARG;
             out_idx[n] = wire;
@@ -1167,6 +1185,7 @@ int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64
             continue;
         }
         if (op >= 3 && a >= o.nq) return ZP_ERR_ARG;
+        if (op == 1 && a >= n_aux) return ZP_ERR_ARG;
         if ((op == 2 || op >= 5) && b >= o.ntr) return ZP_ERR_ARG;
         const uint64_t *q = op >= 3 ? o.query(a) : nullptr;
         const OpenTree *T = (op == 2 || op >= 5) ? &o.tr[b] : nullptr;
@@ -1184,7 +1203,7 @@ int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64
             v[0] = v[1] = v[2] = v[3] = 0;
             switch (op) {
                 case 0: v[0] = a; break;
-                case 1: memcpy(v, aux4, 32); break;
+                case 1: memcpy(v, aux + 4 * a, 32); break;
                 case 2: memcpy(v, T->root, 32); break;
                 case 3: v[0] = q[0]; break;
                 case 4: v[0] = (q[0] >> i) & 1; break;
@@ -1199,6 +1218,36 @@ int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64
     if (n != total) return ZP_ERR_ARG;
     *n_set = n;
     return ZP_OK;
+}
+
+// The aux list of a stage B-2 wrap (zp_wrap_assign's `aux`) from what the host of GenFinalProof holds: the final STARK's openings record (its
+// challenge element 1 IS zeta: three low 64-bit words, each mod p), the final STARK's statement (constraint program, public inputs, trace length,
+// root of unity) and the element the proof is bound to.  out_aux u64[cap][4]: element 0 = addr4, element 1 + k = sparse fixed column k of the
+// program at zeta, components packed c0 + c1 2^64 + c2 2^128; *n_aux = n_fixed - 1.  zeta3_out (may be NULL) u64[3]: the three WORDS zeta is read from.
+int32_t zp_wrap_aux(const uint64_t *openings, size_t open_words, const uint64_t *h_program, size_t program_words, const uint64_t *h_pub, int32_t n_pub, int32_t logn,
+                    uint64_t root32, const uint64_t *addr4, uint64_t *out_aux, size_t cap, size_t *n_aux, uint64_t *zeta3_out) {
+    Openings o;
+    if (!h_program || program_words < 12 || !addr4 || !out_aux || !n_aux || !parse_openings(openings, open_words, &o) || o.n_chal < 2 || !std_canonical(addr4))
+        return ZP_ERR_ARG;
+    const uint64_t n_fixed = h_program[3];
+    if (n_fixed < 2 || n_fixed > 4096 || cap < n_fixed - 1) return ZP_ERR_ARG;
+    uint64_t zeta[3];
+    for (int k = 0; k < 3; k++) zeta[k] = o.chal[4 + k] % GLP;
+    try {
+        std::vector<uint64_t> fixed(3 * n_fixed);
+        const int32_t rc = zp_program_fixed_eval_ext(h_program, program_words, h_pub, n_pub, logn, root32, zeta, fixed.data(), (int32_t)n_fixed, 0);
+        if (rc != ZP_OK) return rc;
+        memcpy(out_aux, addr4, 32);
+        for (uint64_t k = 2; k < n_fixed; k++) {
+            uint64_t *e = out_aux + 4 * (k - 1);
+            e[0] = fixed[3 * k]; e[1] = fixed[3 * k + 1]; e[2] = fixed[3 * k + 2]; e[3] = 0;
+        }
+        *n_aux = n_fixed - 1;
+        if (zeta3_out) memcpy(zeta3_out, o.chal + 4, 24);       // the words as the circuit commits to them (a word >= p names its residue a second time)
+        return ZP_OK;
+    } catch (...) {
+        return ZP_ERR_NOMEM;
+    }
 }
 
 // One Groth16 proof.  circ: the circuit blob; d_u1x (G1, u32[n_wires + 2][16]): [u_j]_1 | alpha_1 | delta_1; d_v_wires u32[n_v]: the wires with a

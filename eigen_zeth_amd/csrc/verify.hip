@@ -106,12 +106,13 @@ extern "C" {
 //   h_out u64[n_out][3]: constraint k at zeta (n_out must be the program's K) (numerators: the caller combines them with its alpha powers and compares with q(zeta) Z_H(zeta))
 // Fixed columns: 0 / 1 the first-row / last-row selectors (Lagrange basis polynomials), then the sparse periodic columns; "x - last" is
 // zeta - w^(N-1).  ZP_ERR_ARG: malformed program, non-canonical input, zeta on the trace domain.  threads <= 0: one per core, at most 16.
-int32_t zp_program_eval_ext(const uint64_t *h_program, size_t program_words, const uint64_t *h_pubchal, int32_t n_pubchal, int32_t logn, uint64_t root32,
-                            const uint64_t zeta3[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, int32_t n_cols, uint64_t *h_out, int32_t n_out,
-                            int32_t threads) {
+static int32_t program_eval_ext_impl(const uint64_t *h_program, size_t program_words, const uint64_t *h_pubchal, int32_t n_pubchal, int32_t logn, uint64_t root32,
+                                     const uint64_t zeta3[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, int32_t n_cols, uint64_t *h_out, int32_t n_out,
+                                     int32_t threads, uint64_t *h_fixed_out, int32_t n_fixed_out) {
+    const bool only_fixed = h_fixed_out != nullptr;
     try {
-        if (!h_program || !zeta3 || !h_ev_z || !h_ev_zw || !h_out || program_words < 12 || logn < 1 || logn > 32 || n_pubchal < 0 || (n_pubchal && !h_pubchal))
-            return ZP_ERR_ARG;
+        if (!h_program || !zeta3 || program_words < 12 || logn < 1 || logn > 32 || n_pubchal < 0 || (n_pubchal && !h_pubchal)) return ZP_ERR_ARG;
+        if (!only_fixed && (!h_ev_z || !h_ev_zw || !h_out)) return ZP_ERR_ARG;
         static const unsigned char magic[8] = {'Z', 'P', 'A', 'I', 'R', '1', 0, 0};
         if (memcmp(h_program, magic, 8) != 0) return ZP_ERR_ARG;
         const size_t W = h_program[1], W2 = h_program[2], n_fixed = h_program[3], n_pub = h_program[4], n_chal = h_program[5], n_const = h_program[6],
@@ -122,13 +123,14 @@ int32_t zp_program_eval_ext(const uint64_t *h_program, size_t program_words, con
             return ZP_ERR_ARG;
         // the caller's arrays are sized by ITS idea of the statement: they must be the program's (a blob with another width or constraint count
         // would be read / written past them)
-        if (n_cols < 0 || (size_t)n_cols != W + W2 || n_out < 0 || (size_t)n_out != K) return ZP_ERR_ARG;
+        if (!only_fixed && (n_cols < 0 || (size_t)n_cols != W + W2 || n_out < 0 || (size_t)n_out != K)) return ZP_ERR_ARG;
+        if (only_fixed && (n_fixed_out < 0 || (size_t)n_fixed_out != n_fixed)) return ZP_ERR_ARG;
         for (int i = 0; i < 3; i++)
             if (zeta3[i] >= GL_P) return ZP_ERR_ARG;
         for (int i = 0; i < n_pubchal; i++)
             if (h_pubchal[i] >= GL_P) return ZP_ERR_ARG;
         const size_t Wt = W + W2;
-        for (size_t i = 0; i < Wt * 3; i++)
+        for (size_t i = 0; !only_fixed && i < Wt * 3; i++)
             if (h_ev_z[i] >= GL_P || h_ev_zw[i] >= GL_P) return ZP_ERR_ARG;
         const e3 zeta = e3_make(zeta3[0], zeta3[1], zeta3[2]);
         const u64 N = 1ULL << logn, wN = gl_root(root32, logn), wlast = gl_pow(wN, N - 1), ninv = gl_inv(N % GL_P);
@@ -162,6 +164,10 @@ int32_t zp_program_eval_ext(const uint64_t *h_program, size_t program_words, con
         }
         for (int b : bad)
             if (b) return b == 2 ? ZP_ERR_NOMEM : ZP_ERR_ARG;
+        if (only_fixed) {
+            for (size_t k = 0; k < n_fixed; k++) memcpy(h_fixed_out + 3 * k, fixed[k].c, 24);
+            return ZP_OK;
+        }
         const e3 xml = e3_make(gl_sub(zeta.c[0], wlast), zeta.c[1], zeta.c[2]);
         // the three-address code in F_{p^3} (layout: stark/air.py compile_program; the prover's interpreter: csrc/stark.hip quotient_program_kernel)
         const uint64_t *consts = h_program + 12, *ins = consts + n_const;
@@ -199,6 +205,22 @@ int32_t zp_program_eval_ext(const uint64_t *h_program, size_t program_words, con
     } catch (...) {
         return ZP_ERR_NOMEM;
     }
+}
+
+int32_t zp_program_eval_ext(const uint64_t *h_program, size_t program_words, const uint64_t *h_pubchal, int32_t n_pubchal, int32_t logn, uint64_t root32,
+                            const uint64_t zeta3[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, int32_t n_cols, uint64_t *h_out, int32_t n_out,
+                            int32_t threads) {
+    return program_eval_ext_impl(h_program, program_words, h_pubchal, n_pubchal, logn, root32, zeta3, h_ev_z, h_ev_zw, n_cols, h_out, n_out, threads, nullptr, 0);
+}
+
+// The FIXED columns of a program at the out-of-domain point: h_fixed u64[n_fixed][3] (n_fixed must be the program's): columns 0 / 1 the first-row /
+// last-row selectors, then the sparse periodic columns (public-input entries read from h_pubchal).  A function of (statement, public inputs, zeta)
+// alone -- what the Groth16 wrap's circuit takes as committed input instead of evaluating ~10^5 entries in F_r (service/wrap_arith.py), and what a
+// reader of its public input recomputes.  Same refusals as zp_program_eval_ext.
+int32_t zp_program_fixed_eval_ext(const uint64_t *h_program, size_t program_words, const uint64_t *h_pubchal, int32_t n_pubchal, int32_t logn, uint64_t root32,
+                                  const uint64_t zeta3[3], uint64_t *h_fixed, int32_t n_fixed, int32_t threads) {
+    if (!h_fixed) return ZP_ERR_ARG;
+    return program_eval_ext_impl(h_program, program_words, h_pubchal, n_pubchal, logn, root32, zeta3, nullptr, nullptr, 0, nullptr, 0, threads, h_fixed, n_fixed);
 }
 
 }  // extern "C"

@@ -95,6 +95,7 @@ SIGNATURES = {
     "zp_fri_fold": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, _u64p, C.c_uint64]),
     "zp_poly_eval_ext": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _u64p, _u64p]),
     "zp_program_eval_ext": (C.c_int32, [_u64p, C.c_size_t, _u64p, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p, _u64p, C.c_int32, _u64p, C.c_int32, C.c_int32]),
+    "zp_program_fixed_eval_ext": (C.c_int32, [_u64p, C.c_size_t, _u64p, C.c_int32, C.c_int32, C.c_uint64, _u64p, _u64p, C.c_int32, C.c_int32]),
     "zp_ood_eval": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_uint64, _u64p, C.c_int32, _u64p, _u64p]),
     "zp_deep_quotient": (C.c_int32, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, _u64p, _u64p, _u64p,
                                      _u64p, _u64p, C.c_uint64, _vp]),
@@ -119,7 +120,8 @@ SIGNATURES = {
     "zp_r1cs_eval": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zp_r1cs_key_scalars": (C.c_int32, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "zp_stark_openings": (C.c_int32, [_vp, _vp, _vp]),
-    "zp_wrap_assign": (C.c_int32, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "zp_wrap_assign": (C.c_int32, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
+    "zp_wrap_aux": (C.c_int32, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int32, C.c_int32, C.c_uint64, _vp, _vp, C.c_size_t, _vp, _vp]),
     "zp_groth16_prove": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zp_sha256": (C.c_int32, [_vp, C.c_size_t, _vp]),
     "zp_r1cs_eval_device": (C.c_int32, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -302,15 +304,17 @@ def r1cs_eval(blob, witness, mask):
 
 
 def wrap_assign(script, openings, aux):
-    """zp_wrap_assign: (wire indices u64[n], values u64[n][4]) of the caller-set wires of the wrap circuit, from the binary openings of a final STARK"""
+    """zp_wrap_assign: (wire indices u64[n], values u64[n][4]) of the caller-set wires of the wrap circuit, from the binary openings of a final STARK.
+    aux: the element the proof is bound to (an int), or the list [that element, further elements the circuit takes from its caller ...]"""
     script = np.ascontiguousarray(script, dtype=np.uint64)
     openings = np.ascontiguousarray(openings, dtype=np.uint64)
     cap = int(script[2])
     idx, val = np.empty(cap, dtype=np.uint64), np.empty((cap, 4), dtype=np.uint64)
-    a = fr_words([int(aux)])
+    aux = [int(v) for v in aux] if isinstance(aux, (list, tuple)) else [int(aux)]
+    a = fr_words(aux)
     n = C.c_size_t(0)
-    rc = load_library().zp_wrap_assign(script.ctypes.data, script.size, openings.ctypes.data, openings.size, a.ctypes.data, idx.ctypes.data, val.ctypes.data, cap,
-                                       C.byref(n))
+    rc = load_library().zp_wrap_assign(script.ctypes.data, script.size, openings.ctypes.data, openings.size, a.ctypes.data, len(aux), idx.ctypes.data, val.ctypes.data,
+                                       cap, C.byref(n))
     if rc != 0:
         raise ValueError("final STARK does not have the shape the wrap circuit was built for")
     return idx[:n.value], val[:n.value]
@@ -330,6 +334,36 @@ def program_eval_ext(program, pubchal, logn, root32, zeta, ev_z, ev_zw, threads=
                                             threads)
     if rc != 0:
         raise ValueError("zp_program_eval_ext: malformed program or evaluations (%d)" % rc)
+    return out
+
+
+def wrap_aux(openings, program, pubs, logn, root32, addr):
+    """zp_wrap_aux: ([addr, packed sparse fixed columns at zeta ...] as ints, zeta) for a stage B-2 wrap"""
+    openings = np.ascontiguousarray(openings, dtype=np.uint64)
+    prog = np.ascontiguousarray(program, dtype=np.uint64)
+    pb = np.ascontiguousarray(np.array([int(v) for v in pubs] or [0], dtype=np.uint64))
+    a = fr_words([int(addr)])
+    cap = int(prog[3])
+    out = np.zeros((cap, 4), dtype=np.uint64)
+    n, z = C.c_size_t(0), np.zeros(3, dtype=np.uint64)
+    rc = load_library().zp_wrap_aux(openings.ctypes.data, openings.size, prog.ctypes.data, prog.size, pb.ctypes.data, len(pubs), logn, int(root32), a.ctypes.data,
+                                    out.ctypes.data, cap, C.byref(n), z.ctypes.data)
+    if rc != 0:
+        raise ValueError("zp_wrap_aux: the openings record or the statement is malformed (%d)" % rc)
+    return fr_ints(out[:n.value]), [int(v) for v in z]
+
+
+def program_fixed_eval_ext(program, pubchal, logn, root32, zeta, threads=0):
+    """zp_program_fixed_eval_ext: the fixed columns of a program at the out-of-domain point, u64[n_fixed][3]: the two boundary selectors, then the sparse
+    periodic columns (host code; ValueError: malformed input)"""
+    prog = np.ascontiguousarray(program, dtype=np.uint64)
+    pc = np.ascontiguousarray(np.array([int(v) for v in pubchal] or [0], dtype=np.uint64))
+    z = np.array([int(v) for v in zeta], dtype=np.uint64)
+    out = np.zeros((int(prog[3]), 3), dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(_u64p)
+    rc = load_library().zp_program_fixed_eval_ext(p(prog), prog.size, p(pc), len(pubchal), logn, int(root32), p(z), p(out), out.shape[0], threads)
+    if rc != 0:
+        raise ValueError("zp_program_fixed_eval_ext: malformed program or point (%d)" % rc)
     return out
 
 

@@ -239,10 +239,12 @@ class Builder:
         return _as_l(v)
 
     # ---- rows
-    def _row(self, a, b, c, what):
-        for x in (a, b, c):
-            assert -R < x.lo and x.hi < R, "an interval leaves the field: reduce earlier"
-        assert max(abs(a.lo), abs(a.hi)) * max(abs(b.lo), abs(b.hi)) < R, "a product leaves the field: reduce earlier"
+    def _row(self, a, b, c, what, mod_r=False):
+        """mod_r: the row is MEANT as an identity in F_r (bits_field: the canonical decomposition of a whole field element), no interval check"""
+        if not mod_r:
+            for x in (a, b, c):
+                assert -R < x.lo and x.hi < R, "an interval leaves the field: reduce earlier"
+            assert max(abs(a.lo), abs(a.hi)) * max(abs(b.lo), abs(b.hi)) < R, "a product leaves the field: reduce earlier"
         self.rows.append((a, b, c))
         self.stats[what] = self.stats.get(what, 0) + 1
 
@@ -277,6 +279,29 @@ class Builder:
             acc = acc + x * (1 << i)
         self._row(acc - a, _as_l(1), _as_l(0), what)
         return list(range(first, first + n))
+
+    def bits_field(self, wire, what="field element bits"):
+        """the CANONICAL 254 bits of a wire that holds an arbitrary field element (a sponge output): sum 2^i b_i = the element in F_r, and the bits
+        name a value below r -- walking down from the top bit, p = "equal to r so far": where r has a 0 the value has no 1 while p, where r has
+        a 1 p continues through a 1; equal to the end is r itself, excluded.  Without it a value v < 2^254 - r has a second decomposition, v + r."""
+        first = self._new(1, 254)
+        self._op(OP_BITS, 254, 0, first, self.w(wire))
+        acc = L({}, 0, 0)
+        for i in range(254):
+            x = self.w(first + i)
+            self._row(x, x, x, "boolean")
+            acc = acc + x * (1 << i)
+        self._row(acc - self.w(wire), _as_l(1), _as_l(0), what, mod_r=True)
+        p = None
+        for i in range(253, -1, -1):
+            x = self.w(first + i)
+            if (R >> i) & 1:
+                p = x if p is None else self.w(self.mul(p, x, what + ": below r"))
+            else:
+                assert p is not None
+                self._row(p, x, _as_l(0), what + ": below r")
+        self._row(p, _as_l(1), _as_l(0), what + ": below r")
+        return list(range(first, first + 254))
 
     def reduce(self, a, what="reduction"):
         """a weak residue of a mod p: a wire s in [0, 2^64) with a = q p + s for a range-checked q"""

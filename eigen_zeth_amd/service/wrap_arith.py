@@ -42,7 +42,9 @@ class Statement:
     """what the circuit is built FOR: the constraint program of the final STARK's AIR (decoded from the blob of include/zeth_prover.h) and the
     evaluation domain.  Only the instruction list, the constants and the counts are read: the sparse fixed columns stay outside the circuit."""
 
-    def __init__(self, program, root32, shift):
+    def __init__(self, program, root32, shift, head=None):
+        """head: the values the prover absorbs first (service/wrap_circuit.py head_values): the circuit pins the transcript to them"""
+        self.head = None if head is None else [int(v) for v in head]
         w = [int(v) for v in program[:12]]
         if w[0] != PROGRAM_MAGIC:
             raise ValueError("not a constraint program")
@@ -60,7 +62,7 @@ class Statement:
         self.digest = hashlib.sha256(np.ascontiguousarray(program, dtype=np.uint64).tobytes()).hexdigest()
 
     def key(self):
-        return (self.digest, self.root32, self.shift)
+        return (self.digest, self.root32, self.shift, tuple(self.head or ()))
 
     def root(self, logn):
         return pow(self.root32, 1 << (32 - logn), P)
@@ -72,19 +74,6 @@ def _wire_of(b, x, what="value"):
     if len(x.t) == 1 and 0 not in x.t and next(iter(x.t.values())) == 1:
         return next(iter(x.t))
     return b.mul(x, 1, what)
-
-
-def _assert_lt_r(b, bits):
-    """the 254 bit wires name a value BELOW r: walking down from the top, p = "equal to r so far"; where r has a 0 the value has no 1 while equal,
-    where r has a 1 equality continues through a 1; equal to the end is r itself: excluded"""
-    p = None
-    for i in range(253, -1, -1):
-        x = b.w(bits[i])
-        if R_BITS[i]:
-            p = x if p is None else b.w(b.mul(p, x, "below r"))
-        else:
-            b._row(x if p is None else p, x if p is not None else AR._as_l(1), AR._as_l(0), "below r")
-    b._row(p, AR._as_l(1), AR._as_l(0), "below r")
 
 
 def _words(b, bits, n):
@@ -116,6 +105,10 @@ class Shapes:
         self.n_ev = 2 * self.W + self.Wq
         self.fin_per_plane = -(-(1 << self.final_log) // 3)
         self.n_fz = st.n_fixed - 2
+        from ..stark.prover import PUBLICS_INLINE
+        self.inline = layout.n_pub <= PUBLICS_INLINE              # few public inputs: absorbed with the parameters, not through a commitment
+        self.n_head_el = -(-(layout.n_head + layout.n_pub) // 3) if self.inline else 0
+        self.n_pub = layout.n_pub
         self.n_exports = 3 * (self.Wall + self.W) + 3 + 3 + 3 + 3 + 3 * len(self.sched) + 3 * (1 << self.final_log)
         assert st.width == self.W and 3 * st.q_chunks == self.Wq, "statement and layout disagree"
 
@@ -129,12 +122,22 @@ def global_template(layout, st):
     ev_el = [b.inp(R - 1) for _ in range(sh.n_ev)]
     fin_el = [b.inp(R - 1) for _ in range(3 * sh.fin_per_plane)]
     fz_el = [b.inp(R - 1) for _ in range(sh.n_fz)]
+    head_el = [b.inp(R - 1) for _ in range(sh.n_head_el)]
+    pubs = []
+    if sh.inline:
+        # the public inputs sit behind the parameters in the first absorbed elements: unpack, pin the parameters to this statement's, keep the rest
+        words = []
+        for e in head_el:
+            words += _unpack3(b, e)
+        assert st.head is not None and len(st.head) == layout.n_head
+        for wv, cv in zip(words, st.head):
+            b._row(b.w(wv) - int(cv) % P, AR._as_l(1), AR._as_l(0), "parameters")
+        pubs = [b.w(k) for k in words[layout.n_head:layout.n_head + sh.n_pub]]
 
     # ---- challenges: canonical bits of the rate element, its three low words
     chal, zeta_bits = [], None
     for s, el in enumerate(chal_el):
-        bits = b.bits(b.w(el), 254, "challenge bits")
-        _assert_lt_r(b, bits)
+        bits = b.bits_field(el, "challenge bits")
         chal.append([b.w(k) for k in _words(b, bits[:192], 3)])
         if s == 1:
             zeta_bits = bits[:192]
@@ -186,7 +189,9 @@ def global_template(layout, st):
             return [AR._as_l(st.consts[i] % P), AR._as_l(0), AR._as_l(0)]
         if k == K_XML:
             return xml
-        raise ValueError("the final STARK's program reads a public input directly: not supported by the wrap circuit")
+        if k == K_PUB and sh.inline:
+            return [pubs[i], AR._as_l(0), AR._as_l(0)]
+        raise ValueError("the statement reads a public input that entered the transcript through a commitment: not available to the wrap circuit")
 
     def tidy(v):
         return [b.w(b.reduce(x, "program")) if x.hi >= BIG else x for x in v]

@@ -168,12 +168,14 @@ class TranscriptLog:
         self.data = [e for sg, spec in zip(segs, layout.transcript_segments()) for e, kind in zip(sg, [k for k, cnt in spec for _ in range(cnt)])
                      if not isinstance(kind, tuple)]      # everything absorbed besides the roots, in order
         self.blocks, self.caps, state = [], [], [0] * 17          # caps: the capacity element after every permutation, in order
+        self.chal = []                                            # rate element 1 after every segment: what the challenge squeezed there is read from
         for sg in segs:
             for off in range(0, len(sg), 16):
                 blk = sg[off:off + 16] + [0] * (16 - len(sg[off:off + 16]))
                 self.blocks.append(blk)
                 state = perm([state[0]] + blk)
                 self.caps.append(state[0])
+            self.chal.append(state[1])
         self.rates = [state[1:]]
         for _ in range(layout.squeeze_perms() - 1):
             state = perm(state)
@@ -188,8 +190,11 @@ class WrapCircuit:
     elements the indices are read from with their bits and the chains of the two range conditions, per query: j (its bits ARE transcript bits),
     per tree: leaf elements [blocks][16], per level: sib[16], child[16], onehot[16], e_lo[4], e_hi[4]"""
 
-    def __init__(self, layout):
-        self.layout = layout
+    def __init__(self, layout, statement=None):
+        """statement (wrap_arith.Statement + .head: the values the prover absorbs first): build stage B-2 too -- the verifier's field arithmetic
+        in two arithmetic templates, and a public input that commits to PUBLIC data only.  None: the hashing-only circuit of rounds 4-5."""
+        self.layout, self.statement = layout, statement
+        b2 = statement is not None
         c = R1.Circuit(R1.poseidon_template(17))
         self.c = c
         Z = c.new_wire()
@@ -198,7 +203,7 @@ class WrapCircuit:
         T = len(layout.trees)
         self.roots = c.new_wires(T)
         self.aux = c.new_wire()                                     # what else the proof is bound to (the aggregator address of the request)
-        data = list(self.roots) + [self.aux]
+        data = ([] if b2 else list(self.roots)) + [self.aux]       # stage B-2: the roots are private
         # the assignment script (zp_wrap_assign: op, first wire, count, a, b, c): how assign() below fills the caller-set wires
         ops = [(0, 0, 1, 1, 0, 0), (0, Z, 1, 0, 0, 0), (1, self.aux, 1, 0, 0, 0)] + [(2, w, 1, 0, t, 0) for t, w in enumerate(self.roots)]
 
@@ -208,6 +213,8 @@ class WrapCircuit:
         # side in the first wave of zp_r1cs_eval -- chained through their output wires the 23 + 1 permutations were 24 dependent single-instance
         # launches (16 ms of the 21 ms witness completion at the service's size).
         self.tdata, self.tblocks, self.tcaps = [], [], []          # data wires in absorb order; per block its 16 input wires; the capacity wires
+        self.tkind = []                                              # kind of every data wire ("head", "pubs", "evals", "final")
+        self.chal = []                                               # stage B-2: per segment but the last, a wire tied to rate element 1 after it
         cap, nblk, prev_out = Z, 0, None
 
         def next_cap(prev_out, k):
@@ -224,6 +231,7 @@ class WrapCircuit:
                 else:
                     new = c.new_wires(cnt)
                     self.tdata += new
+                    self.tkind += [kind] * cnt
                     fresh.update(new)
                     wires += new
             for off in range(0, len(wires), 16):
@@ -243,8 +251,15 @@ class WrapCircuit:
                 prev_out = c.add_instance([cap] + blk)
                 self.tblocks.append(blk)
                 nblk += 1
+            if b2 and len(self.chal) < len(layout.transcript_segments()) - 1:
+                # the challenge squeezed after this segment is read from rate element 1 of the state: a caller-set wire tied to the sponge
+                w = c.new_wire()
+                ops.append((16, w, 1, len(self.chal), 0, 0))
+                c.add_constraint(c.output_lc(prev_out, 1), {0: 1}, {w: 1})
+                self.chal.append(w)
         cap = prev_out
-        data += self.tdata
+        if not b2:
+            data += self.tdata
         # the rate the indices are read from: caller-set wires tied to the instance's output state (an R1CS gadget exposes element 0 only)
         self.rates = []
         n_sq = layout.squeeze_perms()
@@ -307,7 +322,8 @@ class WrapCircuit:
             bits = self.ebits[(k, e)][64 * w:64 * w + layout.logm]       # the transcript's bits: nobody chooses an index
             ops.append((3, j, 1, qi, 0, 0))
             c.add_constraint({b: (1 << i) % R for i, b in enumerate(bits)}, {0: 1}, {j: 1})
-            data.append(j)
+            if not b2:
+                data.append(j)
             trees = []
             for t, (_, width, n_leaves) in enumerate(layout.trees):
                 nb = Layout.blocks(width)
@@ -315,7 +331,8 @@ class WrapCircuit:
                 cap = Z
                 for b, blk in enumerate(elems):
                     cap = c.add_instance([cap] + blk)             # leaf sponge: capacity chained
-                    data += blk
+                    if not b2:
+                        data += blk
                     ops.append((5, blk[0], 16, qi, t, b))
                 cur, lv = cap, []
                 a = n_leaves.bit_length() - 1
@@ -336,6 +353,8 @@ class WrapCircuit:
                 c.add_constraint({cur: 1}, {0: 1}, {self.roots[t]: 1})            # the top of the path is the root
                 trees.append({"elems": elems, "levels": lv})
             self.q.append({"j": j, "bits": bits, "trees": trees})
+        if b2:
+            self._stage_b2(c, ops, data)
         # the public input: root of a 16-ary Poseidon tree over the data list (zero padded)
         self.data = data
         level = list(data)
@@ -344,15 +363,62 @@ class WrapCircuit:
             level = [c.add_instance([Z] + level[i:i + 16]) for i in range(0, len(level), 16)]
         c.add_constraint({level[0]: 1}, {0: 1}, {1: 1}, defines=1)       # the public input IS that root
         self.blob = c.pack()
-        hdr = [int.from_bytes(b"PZWRAPS2", "little"), len(ops), sum(o[2] for o in ops), layout.n_queries, T, layout.logm]
+        hdr = [int.from_bytes(b"PZWRAPS3", "little"), len(ops), sum(o[2] for o in ops), layout.n_queries, T, layout.logm]
         for (_, width, n_leaves) in layout.trees:
             hdr += [width, n_leaves, len(Layout.levels(n_leaves))]
         self.script = np.array(hdr + [len(self.tblocks), n_sq] + [x for o in ops for x in o], dtype=np.uint64)
 
+    def _stage_b2(self, c, ops, data):
+        """the verifier's field arithmetic (service/wrap_arith.py) wired to the hashing above, and the list the public input commits to:
+        aux | the parameter / statement-digest elements (constants of this circuit when the public inputs enter through their commitment) | the
+        commitment to the public inputs | zeta | the statement's sparse fixed columns at zeta.  Everything else -- roots, evaluations, final
+        layer, indices, opened values -- is private: the circuit vouches that they exist and verify."""
+        from . import wrap_arith as WA
+        lay, st = self.layout, self.statement
+        sh = WA.Shapes(lay, st)
+        assert len(self.chal) == sh.n_chal
+        self.zeta_el = c.new_wire()
+        ops.append((17, self.zeta_el, 1, 1, 0, 0))                # the low 192 bits of challenge element 1
+        self.fz = c.new_wires(sh.n_fz)
+        for k, w in enumerate(self.fz):
+            ops.append((1, w, 1, 1 + k, 0, 0))                    # aux element 1 + k (the caller computes the fixed columns at zeta natively)
+        by_kind = lambda kind: [w for w, k in zip(self.tdata, self.tkind) if k == kind]
+        head_w, pubs_w = by_kind("head"), by_kind("pubs")
+        from ..stark.prover import PUBLICS_INLINE
+        if lay.n_pub > PUBLICS_INLINE:
+            hv = [int(v) % WA.P for v in st.head]
+            hv += [0] * (-len(hv) % 3)
+            elems = [hv[i] + (hv[i + 1] << 64) + (hv[i + 2] << 128) for i in range(0, len(hv), 3)]
+            assert len(elems) == len(head_w)
+            for w, v in zip(head_w, elems):
+                c.add_constraint({w: 1}, {0: 1}, {0: v % R})      # the transcript starts from THIS statement's parameters and digest
+        else:
+            data += head_w                                         # few public inputs: they sit inside these elements
+        data += pubs_w + [self.zeta_el] + self.fz
+        g_tpl, exports = WA.global_template(lay, st)
+        q_tpl = WA.query_template(lay, st)
+        hg, hq = c.add_arith_template(g_tpl), c.add_arith_template(q_tpl)
+        g_of = c.add_arith(hg, self.chal + [self.zeta_el] + by_kind("evals") + by_kind("final") + self.fz + (head_w if lay.n_pub <= PUBLICS_INLINE else []))
+        exp_w = [g_of(k) for k in exports]
+        self.arith_stats = {"global": g_tpl.stats, "query": q_tpl.stats, "global_rows": len(g_tpl.rows), "query_rows": len(q_tpl.rows)}
+        for qw in self.q:
+            leaf = [w for tw in qw["trees"] for blk in tw["elems"] for w in blk]
+            c.add_arith(hq, list(qw["bits"]) + leaf + exp_w)
+
     # ---- assignment
     def data_values(self, proof, aux, tlog):
-        """the list the public input commits to, from a final STARK: roots | aux | transcript data | per query: index, leaf elements of every tree"""
+        """the list the public input commits to, from a final STARK: roots | aux | transcript data | per query: index, leaf elements of every tree
+        (stage B-2 -- aux is then the list [address, fixed columns at zeta ...]: aux | head elements if the publics are inline | publics commitment |
+        zeta | fixed columns at zeta)"""
         lay = self.layout
+        if self.statement is not None:
+            kinds = [k for seg in lay.transcript_segments() for k, cnt in seg for _ in range(cnt) if not isinstance(k, tuple)]
+            from ..stark.prover import PUBLICS_INLINE
+            out = [int(aux[0]) % R]
+            if lay.n_pub <= PUBLICS_INLINE:
+                out += [v for v, k in zip(tlog.data, kinds) if k == "head"]
+            out += [v for v, k in zip(tlog.data, kinds) if k == "pubs"]
+            return out + [tlog.chal[1] & ((1 << 192) - 1)] + [int(v) % R for v in aux[1:]]
         roots = [proof["roots"]["trace"], proof["roots"]["quotient"]] + list(proof["fri"]["roots"])
         out = [int(r[0]) for r in roots] + [int(aux) % R] + list(tlog.data)
         if len(proof["queries"]) != lay.n_queries or len(roots) != len(lay.trees):
@@ -374,7 +440,15 @@ class WrapCircuit:
         the STARK's openings do not hash to its roots or its indices are not the transcript's"""
         from .. import native
         lay = self.layout
-        vals = {0: 1, self.Z: 0, self.aux: int(aux) % R}
+        if self.statement is not None:
+            vals = {0: 1, self.Z: 0, self.aux: int(aux[0]) % R, self.zeta_el: tlog.chal[1] & ((1 << 192) - 1)}
+            assert len(aux) == 1 + len(self.fz)
+            for w, v in zip(self.fz, aux[1:]):
+                vals[w] = int(v) % R
+            for w, v in zip(self.chal, tlog.chal):
+                vals[w] = v
+        else:
+            vals = {0: 1, self.Z: 0, self.aux: int(aux) % R}
         roots = [proof["roots"]["trace"], proof["roots"]["quotient"]] + list(proof["fri"]["roots"])
         for w, r in zip(self.roots, roots):
             vals[w] = int(r[0])
@@ -448,7 +522,7 @@ def openings_record(proof, layout, tlog):
     roots = [proof["roots"]["trace"], proof["roots"]["quotient"]] + list(proof["fri"]["roots"])
     if len(proof["queries"]) != layout.n_queries or len(roots) != len(layout.trees):
         raise ValueError("final STARK does not have the shape the wrap circuit was built for")
-    rec = [int.from_bytes(b"PZOPEN02", "little"), layout.n_queries, len(layout.trees), layout.logm]
+    rec = [int.from_bytes(b"PZOPEN03", "little"), layout.n_queries, len(layout.trees), layout.logm]
     for (_, width, n_leaves) in layout.trees:
         rec += [width, n_leaves, len(Layout.levels(n_leaves))]
     for r in roots:
@@ -469,11 +543,25 @@ def openings_record(proof, layout, tlog):
     assert len(tlog.caps) == len(tlog.blocks) + len(tlog.rates) - 1
     for e in tlog.caps:
         rec += w4(e)
+    rec.append(len(tlog.chal))                 # "PZOPEN03": rate element 1 after every segment (the challenges' source; the last one leads the index rates)
+    for e in tlog.chal:
+        rec += w4(e)
     return np.array(rec, dtype=np.uint64)
 
 
-def wrap_circuit(layout):
-    k = layout.key()
+def fixed_z_elements(fixed_z):
+    """the committed form of the statement's sparse fixed columns at zeta: one field element per column, its three components packed like absorbed
+    values (c0 + c1 2^64 + c2 2^128, canonical residues)"""
+    return [int(v[0]) % 0xFFFFFFFF00000001 + ((int(v[1]) % 0xFFFFFFFF00000001) << 64) + ((int(v[2]) % 0xFFFFFFFF00000001) << 128) for v in fixed_z]
+
+
+def zeta_of(chal_element):
+    """zeta as the verifier uses it (canonical residues) from challenge element 1: its three low 64-bit words mod p"""
+    return [((int(chal_element) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF) % 0xFFFFFFFF00000001 for k in range(3)]
+
+
+def wrap_circuit(layout, statement=None):
+    k = layout.key() + (statement.key() if statement is not None else ())
     if k not in _CACHE:
-        _CACHE[k] = WrapCircuit(layout)
+        _CACHE[k] = WrapCircuit(layout, statement)
     return _CACHE[k]

@@ -215,11 +215,17 @@ static int run_final(int argc, char **argv) {
     const uint64_t *op = nullptr;
     size_t op_words = 0;
     CHECK(zp_stark_openings(ctx, &op, &op_words));
-    uint64_t aux[4];
-    if (dec_to_words(addr, aux)) reduce_mod(aux); else digest_words(addr, aux);
+    uint64_t addr4[4];
+    if (dec_to_words(addr, addr4)) reduce_mod(addr4); else digest_words(addr, addr4);
+    // stage B-2: the circuit takes the statement's sparse fixed columns at zeta from its caller (a function of the statement, the public inputs and zeta)
+    std::vector<uint64_t> aux(4 * (size_t)vprog[3]);
+    size_t n_aux = 0;
+    uint64_t zeta3[3], root32 = 0;
+    CHECK(zp_get_constants(ctx, ZP_CONST_ROOT32, &root32, 1));
+    CHECK(zp_wrap_aux(op, op_words, vprog.data(), vprog.size(), pubs.data(), (int32_t)npub, logn, root32, addr4, aux.data(), (size_t)vprog[3], &n_aux, zeta3));
     std::vector<uint64_t> set_idx(script[2]), set_val(4 * script[2]);
     size_t n_set = 0;
-    CHECK(zp_wrap_assign(script.data(), script.size(), op, op_words, aux, set_idx.data(), set_val.data(), set_idx.size(), &n_set));
+    CHECK(zp_wrap_assign(script.data(), script.size(), op, op_words, aux.data(), n_aux, set_idx.data(), set_val.data(), set_idx.size(), &n_set));
     // deterministic blinding, the engine's rule (EngineConfig.groth16_seed): SHA-256(seed|final STARK digest|address|tag) mod r, or 1
     uint64_t r[4], sc[4];
     for (int k = 0; k < 2; k++) {
@@ -253,7 +259,8 @@ static int run_final(int argc, char **argv) {
     // the text eigen-zeth parses (src/settlement/ethereum/mod.rs:445-481), written as json.dumps writes it
     std::string js = "{\"pi_a\": {\"x\": \"" + limbs_dec(pa) + "\", \"y\": \"" + limbs_dec(pa + 8) + "\"}, \"pi_b\": {\"x\": [\"" + limbs_dec(pb) + "\", \"" + limbs_dec(pb + 8) +
                      "\"], \"y\": [\"" + limbs_dec(pb + 16) + "\", \"" + limbs_dec(pb + 24) + "\"]}, \"pi_c\": {\"x\": \"" + limbs_dec(pc) + "\", \"y\": \"" + limbs_dec(pc + 8) +
-                     "\"}, \"protocol\": \"groth16\", \"curve\": \"BN128\", \"circuit\": \"" + circuit_text + "\", \"final_stark_sha256\": \"" + fs_hex + "\"}";
+                     "\"}, \"protocol\": \"groth16\", \"curve\": \"BN128\", \"circuit\": \"" + circuit_text + "\", \"final_stark_sha256\": \"" + fs_hex + "\", \"zeta\": [\"" +
+                     std::to_string(zeta3[0]) + "\", \"" + std::to_string(zeta3[1]) + "\", \"" + std::to_string(zeta3[2]) + "\"]}";
     const std::string pj = "[\"" + words_to_dec(pub.data()) + "\"]";
     for (int k = 0; k < 2; k++) {
         const std::string &out = k ? pj : js;

@@ -233,6 +233,11 @@ int32_t zp_poly_eval_ext(zp_ctx *ctx, const uint64_t *d_coef, int32_t logn, int3
 int32_t zp_program_eval_ext(const uint64_t *h_program, size_t program_words, const uint64_t *h_pubchal, int32_t n_pubchal, int32_t logn,
                             uint64_t root32, const uint64_t zeta[3], const uint64_t *h_ev_z, const uint64_t *h_ev_zw, int32_t n_cols,
                             uint64_t *h_out, int32_t n_out, int32_t threads);
+/* The FIXED columns of a program at the out-of-domain point: h_fixed u64[n_fixed][3] -- columns 0 / 1 the first-row / last-row selectors, then the
+ * sparse periodic columns.  A function of (statement, public inputs, zeta) alone: the Groth16 wrap's circuit takes columns 2.. as committed inputs
+ * (service/wrap_arith.py), a reader of its public input recomputes them.  Same arguments and refusals as zp_program_eval_ext.                       */
+int32_t zp_program_fixed_eval_ext(const uint64_t *h_program, size_t program_words, const uint64_t *h_pubchal, int32_t n_pubchal, int32_t logn,
+                                  uint64_t root32, const uint64_t zeta3[3], uint64_t *h_fixed, int32_t n_fixed, int32_t threads);
 /* Out-of-domain evaluations FROM VALUES (barycentric form; round 5: the provers keep no coefficient buffers for this any more).
  * Column c is a polynomial p_c of degree < 2^logn given by its values on the coset shift*<w>, w of order 2^logn:
  *   d_cols[c * col_stride + i * row_stride] = p_c(shift * w^i)      (row_stride = 2^logb reads the 2^logn-point sub-coset of an
@@ -428,8 +433,16 @@ int32_t zp_r1cs_key_scalars(const uint64_t *circ, size_t words, const uint64_t *
  *   milliseconds of witness, QAP, all MSMs, then A, B (G1), B (G2), l, h one by one.  -20 / -21 as zp_r1cs_eval: a false statement has no proof.
  * zp_sha256: SHA-256 of a byte string (the digests proof texts name; the deterministic blinding of a test run).                                    */
 int32_t zp_stark_openings(zp_ctx *ctx, const uint64_t **out, size_t *words);
-int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64_t *openings, size_t open_words, const uint64_t *aux4, uint64_t *out_idx,
-                       uint64_t *out_val, size_t cap, size_t *n_set);
+/* (round 6) aux u64[n_aux][4]: element 0 the value the proof is bound to (the aggregator address), elements 1.. what else the circuit takes from its
+ * caller -- wrap stage B-2: the statement's sparse fixed columns at zeta (zp_program_fixed_eval_ext, columns 2..), one element per column, the three
+ * components packed c0 + c1 2^64 + c2 2^128.  The openings record is "PZOPEN03": it ends with the rate element behind every challenge.              */
+int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64_t *openings, size_t open_words, const uint64_t *aux, size_t n_aux,
+                       uint64_t *out_idx, uint64_t *out_val, size_t cap, size_t *n_set);
+/* That aux list from what the host of GenFinalProof holds: the openings record (challenge element 1 is zeta), the final STARK's statement (program,
+ * public inputs, log2 of the trace length, root of unity) and the element the proof is bound to (addr4).  out_aux u64[cap][4], *n_aux = the program's
+ * n_fixed - 1; zeta3_out (may be NULL) u64[3] = zeta (what the proof text carries so that a reader can recompute the fixed columns).               */
+int32_t zp_wrap_aux(const uint64_t *openings, size_t open_words, const uint64_t *h_program, size_t program_words, const uint64_t *h_pub, int32_t n_pub,
+                    int32_t logn, uint64_t root32, const uint64_t *addr4, uint64_t *out_aux, size_t cap, size_t *n_aux, uint64_t *zeta3_out);
 int32_t zp_r1cs_eval_device(zp_ctx *ctx, const uint64_t *circ, size_t words, const uint64_t *set_idx, const uint64_t *set_val, size_t n_set, uint64_t *d_w,
                             uint64_t *d_a, uint64_t *d_b, uint64_t *d_c, uint64_t *out_pub, int64_t *bad);
 int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const uint32_t *d_u1x, const uint32_t *d_v_wires, size_t n_v, const uint32_t *d_v1x,

@@ -9,7 +9,14 @@ commits to: `public_input` recomputes d from a final STARK's data by this module
 verifies THE ARITHMETIC of the STARK (out-of-domain identity, DEEP, folds: `verify_rest`) on the opened values as given, without their
 authentication paths and WITHOUT RE-DERIVING THE QUERY INDICES: both are the circuit's business now.  (Round 4's circuit left the indices
 free, so its checker had to hash the transcript again and compare.)  `verify` = the comparison of d + the pairing check
-(oracle/groth16_verify.py).  PARITY UNPINNED w.r.t. the external prover."""
+(oracle/groth16_verify.py).
+
+Round 6, stage B-2: the circuit ALSO runs the verifier's field arithmetic (service/wrap_arith.py: challenges off the in-circuit sponge, the constraint
+identity at zeta, DEEP, every fold, the final layer's degree), so its public input commits to PUBLIC data only -- `public_input_b2`: aux | the
+parameter / digest elements (when the public inputs are few and sit among them) | the commitment to the public inputs | zeta | the statement's sparse
+fixed columns at zeta.  No part of the final STARK is needed to check a proof: `verify_b2` recomputes the fixed columns at the zeta the proof text
+names -- a function of (statement, public inputs, zeta) -- recomputes d, and runs the pairing check.  verify_rest is not part of that path any more;
+it stays for the hashing-only circuit of rounds 4-5 (which the tests still build).  PARITY UNPINNED w.r.t. the external prover."""
 from . import groth16_verify as GV
 from . import naive as NV
 from . import stark_verify as V
@@ -77,6 +84,52 @@ def verify(vk, proof, pub, final_stark, aux, bn_tables, program):
     """proof: {"pi_a", "pi_b", "pi_c"} points; pub: [d]; vk: the verifying key's points"""
     if len(pub) != 1 or int(pub[0]) != public_input(final_stark, aux, bn_tables, program):
         raise V.Reject("the public input is not the commitment to this final STARK's roots, indices and openings")
+    if not GV.verify(vk, proof, pub):
+        raise V.Reject("the Groth16 proof does not verify")
+    return True
+
+
+def fixed_columns_at(program, publics, zeta, logn, root32):
+    """the statement's SPARSE fixed columns (columns 2.. of the program) at the out-of-domain point, by the checker's own reader of the program blob"""
+    from .air_program import Program
+    air = program if isinstance(program, Program) else Program(program)
+    return [air.fixed_eval_ext(k, [int(v) for v in publics], [int(v) % V.P for v in zeta], logn, root32) for k in range(len(air.fixed_cols))]
+
+
+def public_input_b2(program, params, root32, shift, publics, aux, zeta_words, bn_tables):
+    """d of a stage B-2 wrap from PUBLIC data: the statement (constraint program + the STARK parameters and domain it is proven under), its public
+    inputs, the element the proof is bound to, and zeta_words -- the three 64-bit words of the challenge as the proof text carries them (a word may
+    be >= p: it is then a second name of its residue; the commitment holds the words, the evaluation takes them mod p)."""
+    from .air_program import Program
+    rc, mds, rp = bn_tables
+    air = program if isinstance(program, Program) else Program(program)
+    pubs = [int(v) for v in publics]
+    head = [params["logn"], params["logb"], air.width, air.width2, params["fri_logf"], params["fri_final_log"], params["n_queries"], params.get("pow_bits", 0),
+            int(root32), int(shift)] + air.digest_words() + [len(pubs)]
+    data = [int(aux) % NV.BN254_R]
+    if len(pubs) <= V.PUBLICS_INLINE:
+        data += _pack3(head + pubs)
+    else:
+        V.O.p254_set(17, rp, rc, mds)
+        data += [int(V.publics_digest(pubs, None, None, True)[0])]
+    zw = [int(v) for v in zeta_words]
+    if len(zw) != 3 or any(not 0 <= v < (1 << 64) for v in zw):
+        raise V.Reject("malformed zeta")
+    data.append(zw[0] + (zw[1] << 64) + (zw[2] << 128))
+    for fz in fixed_columns_at(air, pubs, zw, params["logn"], root32):
+        data.append(int(fz[0]) + (int(fz[1]) << 64) + (int(fz[2]) << 128))
+    lvl = data
+    while len(lvl) > 1:
+        lvl = lvl + [0] * (-len(lvl) % 16)
+        lvl = [NV.poseidon_bn254_perm([0] + lvl[i:i + 16], rc, mds, rp)[0] for i in range(0, len(lvl), 16)]
+    return lvl[0]
+
+
+def verify_b2(vk, proof, pub, program, params, root32, shift, publics, aux, zeta_words, bn_tables):
+    """everything a reader of a stage B-2 final proof does: d from public data, the pairing check.  (vk must be the key of the circuit built for this
+    statement: the circuit pins the transcript's parameter block to it.)"""
+    if len(pub) != 1 or int(pub[0]) != public_input_b2(program, params, root32, shift, publics, aux, zeta_words, bn_tables):
+        raise V.Reject("the public input is not the commitment to this statement, these public inputs and this zeta")
     if not GV.verify(vk, proof, pub):
         raise V.Reject("the Groth16 proof does not verify")
     return True
