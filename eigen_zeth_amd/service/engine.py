@@ -32,6 +32,7 @@ from . import bn254
 from . import groth16
 from . import statement
 from . import wrap_circuit as WC
+from . import wrap_arith as WA
 from ..stark import verifier as SV
 
 
@@ -148,6 +149,7 @@ class Engine:
         self._factory = self._factories[0]
         self._be = None
         self._be_bn = None        # backend of the final STARK (BN128-hash mode), created at the first GenFinalProof
+        self._last_wrap = None    # (circuit, key) of the most recent GenFinalProof
         self.final_starks = {}    # batch_id -> final STARK JSON of the most recent batches (inspection / tests)
         self.final_programs = {}  # batch_id -> constraint program of that final STARK's statement
         self._batch_chunk_proofs = {}   # batch_id -> chunk proof texts of the most recent batches (cfg.aggregate_all_chunks)
@@ -531,6 +533,7 @@ class Engine:
         # raises ValueError: an opening does not hash to its root / the transcript does not give the indices -> no witness
         trace, pubs = VA.build_witness(shape, proofs, be, inner_air.digest_words(), prepared)
         timings["verifier-witness"] = time.perf_counter() - t0
+        self._last_verifier_pubs = pubs                 # the public inputs of the STARK made next (GenFinalProof's wrap needs the final STARK's)
         params = params_of(shape)
         t0 = time.perf_counter()
         self._sharded_openings = None
@@ -664,12 +667,16 @@ class Engine:
         configured size"""
         return recursion_airs_for(self.cfg, self.be.root32, self.be.shift, *self._tables(self.be), n_proofs=n_proofs, logn=logn)
 
-    def _wrap_key(self, layout):
-        """(wrap circuit, Groth16 key) for a final-STARK layout: built once per layout (seconds at the service's size: the circuit in Python,
-        the key's scalars on the host, its group elements on the GPU) and kept -- key generation is setup, not proving"""
-        k = layout.key()
+    def _wrap_key(self, fair, fp):
+        """(wrap circuit, Groth16 key) for final STARKs of the statement `fair` (the verifier AIR over an aggregated proof's STARK) under the
+        parameters `fp`: built once per statement (seconds at the service's size: the circuit in Python, the key's scalars on the host, its group
+        elements on the GPU) and kept -- key generation is setup, not proving.  Stage B-2: the circuit runs the verifier's field arithmetic, so it is
+        built FOR this statement (its constraint program, domain and parameter block), not only for its shape."""
+        layout = WC.Layout.of_air(fair, fp)
+        st = WA.Statement(fair.program(), int(self.be.root32), int(self.be.shift), WC.head_values(fair, fp, int(self.be.root32), int(self.be.shift)))
+        k = layout.key() + st.key()
         if k not in self._g16:
-            wc = WC.wrap_circuit(layout)
+            wc = WC.wrap_circuit(layout, st)
             key = groth16.Key(wc.blob)
             if hasattr(self.be, "p"):          # the GPU backend: the key's points are made now and stay in HBM
                 key.load_points(self.be)
@@ -678,7 +685,8 @@ class Engine:
 
     def groth16_keys(self, n_proofs=2, logn=None):
         """make (or fetch) the wrap circuit and key for the usual request -- two chunk proofs of the configured size"""
-        return self._wrap_key(self.wrap_layout(n_proofs, logn))
+        fair = self.recursion_airs(n_proofs, logn)[1]
+        return self._wrap_key(fair, self.wrap_layout(n_proofs, logn).params)
 
     def prewarm(self, n_chunks=None, compile_kernels=True):
         """everything a first request would otherwise pay for, done at service start: the wrap circuit and its key (seconds: the circuit is built on
@@ -716,8 +724,13 @@ class Engine:
         return {"wrap_key_s": t_key, "recursion_kernels_s": t_k, "recursion_kernels": kernels, "chunk_proofs_s": t_chunks - t_k,
                 "recursion_s": total - t_key - t_chunks, "total_s": total}
 
-    def verifying_key_json(self, n_proofs=2, logn=None):
-        return groth16.vk_to_json(self.groth16_keys(n_proofs, logn)[1].vk)
+    def verifying_key_json(self, n_proofs=None, logn=None):
+        """the verifying key final proofs of this engine verify under.  A stage B-2 key belongs to ONE statement (the final STARK's AIR depends on how
+        many chunk proofs the aggregation folded): without arguments the key of the most recent GenFinalProof, else of the usual request (two chunk
+        proofs of the configured size); with arguments, of that request."""
+        if n_proofs is None and logn is None and self._last_wrap is not None:
+            return groth16.vk_to_json(self._last_wrap[1].vk)
+        return groth16.vk_to_json(self.groth16_keys(2 if n_proofs is None else n_proofs, logn)[1].vk)
 
     def final(self, batch_id, recursive_proof, curve_name, aggregator_addr):
         with self._serial, _no_cyclic_gc():
@@ -736,12 +749,12 @@ class Engine:
         t0 = time.perf_counter()
         hit = self._spec.get("final")
         if hit is not None and hit[0] == self._digest(recursive_proof):       # made while the batch was being proven
-            fshape, fair, fp, final_stark, tmf, openings, t_made = hit[1]
+            fshape, fair, fp, final_stark, tmf, openings, fpubs, t_made = hit[1]
             tmf = dict(tmf, **{"made-during-chunk-proofs": t_made, "answered-from-speculation": 1.0})
         else:
-            fshape, fair, fp, final_stark, tmf, openings = self._final_stark(recursive_proof)
+            fshape, fair, fp, final_stark, tmf, openings, fpubs = self._final_stark(recursive_proof)
         t_fs = time.perf_counter() - t0
-        return self._final_wrap(batch_id, aggregator_addr, fair, fp, final_stark, tmf, openings, t_fs)
+        return self._final_wrap(batch_id, aggregator_addr, fair, fp, final_stark, tmf, openings, t_fs, fpubs)
 
     def _check_inner_headers(self, node, stark_publics, be, depth=0):
         """What NO query of a recursion STARK covers, for the proofs it vouches for, level by level (round-5 advisor item).  node: an aggregated
@@ -819,6 +832,7 @@ class Engine:
         tmf = {}
         try:
             fshape, fair, fp, final_stark = self._prove_merkle_verifier([outer], lambda sh: self.final_stark_params(outer), self.be_bn128, tmf, agg_air, [prep])
+            fpubs = [int(v) for v in self._last_verifier_pubs]
         finally:
             if th is not None:
                 th.join()
@@ -833,9 +847,9 @@ class Engine:
             openings = self._sharded_openings               # rank 0's record (cfg.final_ranks > 1)
         elif self.cfg.native_prover and hasattr(self.be_bn128, "stark_openings"):
             openings = self.be_bn128.stark_openings()       # the prover's own binary record of what the text carries: no text round trip
-        return fshape, fair, fp, final_stark, tmf, openings
+        return fshape, fair, fp, final_stark, tmf, openings, fpubs
 
-    def _final_wrap(self, batch_id, aggregator_addr, fair, fp, final_stark, tmf, openings, t_fs):
+    def _final_wrap(self, batch_id, aggregator_addr, fair, fp, final_stark, tmf, openings, t_fs, final_publics):
         self.final_starks[batch_id] = final_stark
         self.final_programs[batch_id] = fair.program()         # the statement of that STARK (a checker recomputes the wrap's public input from both)
         while len(self.final_starks) > 4:
@@ -846,7 +860,8 @@ class Engine:
         # 2. the Groth16 wrap: an R1CS that verifies the hashing of that STARK's verifier at its queries (service/wrap_circuit.py); its one
         #    public input commits to the roots, indices and leaf elements it vouches for, and to the aggregator address of the request
         t0 = time.perf_counter()
-        wc, key = self._wrap_key(WC.Layout.of_air(fair, fp))
+        wc, key = self._wrap_key(fair, fp)
+        self._last_wrap = (wc, key)
         try:
             aux = int(aggregator_addr or "0")
         except ValueError:
@@ -856,7 +871,10 @@ class Engine:
             tlog = WC.TranscriptLog(fs, wc.layout, WC.head_values(fair, fp, fs["root32"], fs["shift"]), getattr(self.be_bn128, "publics_digest", None),
                                     getattr(self.be_bn128, "poseidon_bn254_perm17", WC.perm17))
             openings = WC.openings_record(fs, wc.layout, tlog)
-        set_idx, set_val = native.wrap_assign(wc.script, openings, aux % bn254.R)
+        # stage B-2: the circuit takes the statement's sparse fixed columns at zeta from its caller -- a function of (statement, public inputs, zeta);
+        # zeta is challenge element 1 of the prover's record.  The proof text carries zeta's words: a reader recomputes the columns and d from public data.
+        aux_list, zeta_words = native.wrap_aux(openings, fair.program(), final_publics, fp.logn, int(self.be.root32), aux % bn254.R)
+        set_idx, set_val = native.wrap_assign(wc.script, openings, aux_list)
         t_wit = time.perf_counter() - t0
         # fresh blinding per proof (zero knowledge); replays of a request are answered from the batch store (server.py),
         # which keeps the finished proof, so the client still sees one proof per batch
@@ -877,5 +895,5 @@ class Engine:
                                          "C: h (G1)": (1 << wc.c.logm()) - 1}}
         if self.metrics is not None:
             self.metrics.record_stage("groth16", self.stage_timings["final/" + batch_id]["groth16"])
-        js = groth16.proof_to_json(proof, {"circuit": groth16.circuit_text(wc, key), "final_stark_sha256": fs_digest})
+        js = groth16.proof_to_json(proof, {"circuit": groth16.circuit_text(wc, key), "final_stark_sha256": fs_digest, "zeta": [str(v) for v in zeta_words]})
         return js, json.dumps([str(pub[0])])

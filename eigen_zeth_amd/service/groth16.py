@@ -119,9 +119,14 @@ def prove_on_gpu(key, set_idx, set_val, be, rand):
 
 def circuit_text(wc, key):
     """the "circuit" member of a final proof: what was proven, under which key"""
-    return ("final-stark-hashing+transcript (Merkle openings at the queries and the Fiat-Shamir sponge that places them; NOT the STARK's field "
-            "arithmetic: the holder of the final STARK checks that): %d constraints (2^%d domain), %d wires, key %s (LOCAL SEEDED SETUP -- a test key, "
-            "its trapdoor is public: not a proof under the reference's verifying key)" % (wc.c.n_constraints, wc.c.logm(), wc.c.n_wires, key.digest[:16]))
+    if getattr(wc, "statement", None) is None:
+        return ("final-stark-hashing+transcript (Merkle openings at the queries and the Fiat-Shamir sponge that places them; NOT the STARK's field "
+                "arithmetic: the holder of the final STARK checks that): %d constraints (2^%d domain), %d wires, key %s (LOCAL SEEDED SETUP -- a test key, "
+                "its trapdoor is public: not a proof under the reference's verifying key)" % (wc.c.n_constraints, wc.c.logm(), wc.c.n_wires, key.digest[:16]))
+    return ("final-stark-verifier (stage B-2: Merkle openings, the Fiat-Shamir sponge, the constraint identity at zeta, the DEEP quotient and every fold of "
+            "every query, the final layer's degree -- the public input commits to the statement's public inputs, zeta and the statement's sparse fixed "
+            "columns at zeta, which a reader recomputes): %d constraints (2^%d domain), %d wires, key %s (LOCAL SEEDED SETUP -- a test key, its trapdoor "
+            "is public: not a proof under the reference's verifying key)" % (wc.c.n_constraints, wc.c.logm(), wc.c.n_wires, key.digest[:16]))
 
 
 def proof_to_json(proof, extra=None):

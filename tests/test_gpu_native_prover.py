@@ -238,7 +238,9 @@ def test_compiled_host_answers_gen_final_proof_like_the_service(tmp_path, tables
     assert (tmp_path / "proof.json").read_text() == want_js and (tmp_path / "public.json").read_text() == want_pub
     pr = CS.parse_proof(want_js)
     proof = {"pi_a": tuple(pr.a), "pi_b": (pr.b.x, pr.b.y), "pi_c": tuple(pr.c)}
-    assert WV.verify(key.vk, proof, CS.parse_public_input(want_pub), json.loads(eng.final_starks["b"]), int(addr), bn254_poseidon_params(17), eng.final_programs["b"])
+    fs = json.loads(eng.final_starks["b"])
+    assert WV.verify_b2(key.vk, proof, CS.parse_public_input(want_pub), eng.final_programs["b"], fp.to_dict(), fs["root32"], fs["shift"], fs["publics"], int(addr),
+                        [int(v) for v in json.loads(want_js)["zeta"]], bn254_poseidon_params(17))
     # an aggregated proof tampered with has no witness one level up: the host refuses as the service does
     bad = json.loads(agg)
     bad["stark"]["queries"][2]["trace"]["values"][5] ^= 1

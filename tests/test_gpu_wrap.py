@@ -76,6 +76,44 @@ def test_gpu_groth16_of_the_wrap_circuit_equals_the_trapdoor_proof(tables):
     print("zp_groth16_prove ms (witness, QAP, MSMs):", [round(x, 2) for x in ms])
     print("wrap circuit: %d constraints, domain 2^%d, %d wires" % (wc.c.n_constraints, wc.c.logm(), wc.c.n_wires))
 
+    # ---- stage B-2 (round 6): the circuit built FOR this statement also runs the verifier's field arithmetic (two arithmetic templates: witness
+    # programs on the host, their rows by a kernel); its public input commits to public data only
+    from eigen_zeth_amd.service import wrap_arith as WA
+    head = WC.head_values(air, params, proof["root32"], proof["shift"])
+    wc2 = WC.wrap_circuit(WC.Layout.of_air(air, params), WA.Statement(air.program(), proof["root32"], proof["shift"], head))
+    aux_l, zw = native.wrap_aux(hip.stark_openings(), air.program(), proof["publics"], params.logn, proof["root32"], aux)
+    assert aux_l == [aux] and zw == [(tlog.chal[1] >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(3)]
+    w0, mask = wc2.assign(proof, aux_l, tlog)
+    set_idx, set_val = native.wrap_assign(wc2.script, hip.stark_openings(), aux_l)
+    assert sorted(set_idx.tolist()) == np.flatnonzero(mask).tolist() and (w0[set_idx.astype(np.int64)] == set_val).all()
+    wf, a, b, c = native.r1cs_eval(wc2.blob, w0, mask)
+    gw, ga, gb, gc, gpub = hip.p.r1cs_eval_device(wc2.blob, set_idx, set_val)
+    assert (gw == wf).all() and (ga == a).all() and (gb == b).all() and (gc == c).all() and gpub == native.fr_ints(wf[1:2])
+    key2 = G16.Key(wc2.blob)
+    p_gpu, pubs, ms2 = G16.prove(key2, set_idx, set_val, hip, rand)
+    p_cpu, pubs_c, _ = G16.prove(key2, set_idx, set_val, cpu, rand)
+    stmt = (air.program(), params.to_dict(), proof["root32"], proof["shift"], proof["publics"])
+    assert p_gpu == p_cpu and pubs == pubs_c == [WV.public_input_b2(*stmt, aux, zw, bn)]
+    assert WV.verify_b2(key2.vk, p_gpu, pubs, *stmt, aux, zw, bn)
+    # a STARK the GPU prover makes HONESTLY FROM A FALSE WITNESS: hashes, indices, transcript all consistent (the hashing-only circuit proves it),
+    # the arithmetic is not -- no witness on the host, no proof on the GPU
+    tr2 = tr.copy()
+    tr2[5, 100] ^= np.uint64(1)
+    bad = json.loads(hip.prove_native(air, tr2, pub, params))
+    rec_bad = hip.stark_openings().copy()
+    tl_bad = WC.TranscriptLog(bad, wc.layout, head)
+    bi, bv = native.wrap_assign(wc.script, rec_bad, aux)
+    G16.prove(key, bi, bv, hip, rand)                                     # rounds 4-5: a pairing-valid proof "of" a false statement's hashing
+    aux_b, _ = native.wrap_aux(rec_bad, air.program(), bad["publics"], params.logn, bad["root32"], aux)
+    bi, bv = native.wrap_assign(wc2.script, rec_bad, aux_b)
+    with pytest.raises(ValueError, match="does not satisfy"):
+        G16.prove(key2, bi, bv, hip, rand)
+    with pytest.raises(ValueError, match="does not satisfy"):
+        native.r1cs_eval(wc2.blob, *wc2.assign(bad, aux_b, tl_bad))
+    # one arithmetic wire of a complete witness changed: refused by the rows kernel as by the host
+    print("stage B-2: %d constraints (global template %d rows, query template %d x %d), zp_groth16_prove ms:" % (wc2.c.n_constraints, wc2.arith_stats["global_rows"],
+          wc2.arith_stats["query_rows"], params.n_queries), [round(x, 2) for x in ms2])
+
 
 def test_engine_final_proof_wraps_the_final_stark(tables, tmp_path):
     """GenFinalProof at the service's default parameters: the Groth16 proof verifies under the engine's key, its public input commits to THIS
@@ -100,11 +138,18 @@ def test_engine_final_proof_wraps_the_final_stark(tables, tmp_path):
     g1 = lambda d: (int(d["x"]), int(d["y"]))
     g2 = lambda d: ((int(d["x"][0]), int(d["x"][1])), (int(d["y"][0]), int(d["y"][1])))
     vkp = {"alpha1": g1(vk["alpha1"]), "beta2": g2(vk["beta2"]), "gamma2": g2(vk["gamma2"]), "delta2": g2(vk["delta2"]), "ic": [g1(p) for p in vk["ic"]]}
-    assert WV.verify(vkp, proof, pub, fs, int(addr), bn, eng.final_programs["w"])
+    # stage B-2: everything a reader of the final proof checks -- d from PUBLIC data (the statement, its public inputs, the address, the proof text's zeta),
+    # the pairing -- with no part of the final STARK but its public inputs (which are the aggregated proof's STARK's roots, indices and transcripts)
     fp = eng.final_stark_params(json.loads(agg)["stark"])
-    assert WV.verify_rest(fs, eng.final_programs["w"], *tables, V.expectation(fp.to_dict(), fs["root32"], fs["shift"]), bn)
     meta = json.loads(js)
-    assert "final-stark-hashing+transcript" in meta["circuit"] and "2^21" in meta["circuit"] and "test key" in meta["circuit"]
+    zw = [int(v) for v in meta["zeta"]]
+    stmt = (eng.final_programs["w"], fp.to_dict(), fs["root32"], fs["shift"], fs["publics"])
+    assert WV.verify_b2(vkp, proof, pub, *stmt, int(addr), zw, bn)
+    with pytest.raises(V.Reject):
+        WV.verify_b2(vkp, proof, pub, *stmt, int(addr) + 1, zw, bn)
+    assert V.verify(fs, eng.final_programs["w"], *tables, V.expectation(fp.to_dict(), fs["root32"], fs["shift"]), bn)     # (the STARK the circuit verified does verify)
+    assert "stage B-2" in meta["circuit"] and "2^22" in meta["circuit"] and "test key" in meta["circuit"]
+    print("wrap info:", json.dumps(eng.wrap_info))
     js2, pub2 = eng.final("w", agg, "BN128", addr)
     assert js2 == js and pub2 == pub_js                       # deterministic blinding: the same proof.json
     js3, pub3 = eng.final("w", agg, "BN128", "1")

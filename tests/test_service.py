@@ -117,7 +117,8 @@ def _check_result(res, tables, block, svc=None):
         proof = {"pi_a": (pts[0], pts[1]), "pi_b": ((pts[2], pts[3]), (pts[4], pts[5])), "pi_c": (pts[6], pts[7])}
         assert GV.verify(vkp, proof, [pub])
         assert not GV.verify(vkp, proof, [(pub + 1) % bn254.R])
-        assert "final-stark-hashing+transcript" in json.loads(res["proof"])["circuit"]
+        meta = json.loads(res["proof"])
+        assert "final-stark-verifier (stage B-2" in meta["circuit"] and len(meta["zeta"]) == 3
         # ... and it names (by digest) a final STARK in BN128-hash mode that the independent verifier accepts
         import hashlib
         from eigen_zeth_amd.poseidon_constants import bn254_poseidon_params
@@ -125,12 +126,18 @@ def _check_result(res, tables, block, svc=None):
         assert len(fs) == 1
         fsp = json.loads(fs[0])
         assert fsp["params"]["hash"] == "bn128" and len(fsp["roots"]["trace"]) == 1
-        # the wrap's one public input IS the commitment to this final STARK's roots, query indices and opened leaves (and to the aggregator
-        # address of the request): recomputed by the checker from the STARK alone (oracle/wrap_verify.py)
+        # stage B-2 (round 6): the wrap's one public input commits to PUBLIC data only -- the statement's public inputs (through their commitment), the
+        # aggregator address of the request, zeta and the statement's sparse fixed columns at zeta: the checker recomputes it WITHOUT the final STARK's
+        # openings, evaluations or roots (oracle/wrap_verify.py: public_input_b2 reads the statement, its public inputs and the proof text's zeta)
         from oracle import wrap_verify as WV
         from eigen_zeth_amd.service.client import DEFAULT_AGGREGATOR_ADDR
         fs_id = [k for k, v in svc.engine.final_starks.items() if v == fs[0]][0]
-        assert pub == WV.public_input(fsp, int(DEFAULT_AGGREGATOR_ADDR), bn254_poseidon_params(17), svc.engine.final_programs[fs_id])
+        agg_stark = json.loads(res["aggregated"])["stark"]
+        fparams = svc.engine.final_stark_params(agg_stark).to_dict()
+        assert pub == WV.public_input_b2(svc.engine.final_programs[fs_id], fparams, fsp["root32"], fsp["shift"], fsp["publics"], int(DEFAULT_AGGREGATOR_ADDR),
+                                         [int(v) for v in meta["zeta"]], bn254_poseidon_params(17))
+        assert pub != WV.public_input_b2(svc.engine.final_programs[fs_id], fparams, fsp["root32"], fsp["shift"], fsp["publics"], int(DEFAULT_AGGREGATOR_ADDR) + 1,
+                                         [int(v) for v in meta["zeta"]], bn254_poseidon_params(17))
         # the recursion layers prove what they name.  (1) the aggregated proof: both chunk-proof headers verify (transcript,
         # out-of-domain identity, final layer), the outer STARK's publics are their roots and transcript-derived indices, and
         # the outer STARK verifies under the Merkle-verifier AIR of that shape

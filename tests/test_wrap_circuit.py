@@ -241,3 +241,72 @@ def test_indices_are_bound_by_the_transcript_in_the_circuit(final_like, tables, 
     assert WV.verify_rest(moved, air.program(), rc, mds, V.expectation(params.to_dict()), bn)
     with pytest.raises(V.Reject):                                  # (the full verifier, which hashes the transcript itself, refuses it)
         V.verify(moved, air.program(), rc, mds, V.expectation(params.to_dict()), bn)
+
+
+def test_stage_b2_the_circuit_runs_the_verifiers_arithmetic(final_like, tables, bn):
+    """wrap stage B-2 (round 6): built FOR a statement, the circuit also runs the verifier's field arithmetic (service/wrap_arith.py) -- challenges off
+    the in-circuit sponge, the constraint identity at zeta, the DEEP quotient and every fold at every query, the final layer's degree -- and its
+    public input commits to PUBLIC data only.  An honest STARK has a witness (the library's host evaluator: witness programs + every row); the
+    checker recomputes d from the statement, the public inputs, aux and zeta alone (no root, no evaluation, no opening); the library's assignment
+    equals the reference assignment; every arithmetic wire is pinned; and a STARK made HONESTLY FROM A FALSE WITNESS -- every hash, every index and
+    the whole transcript consistent, i.e. a proof the hashing-only circuit of rounds 4-5 has a witness for -- has none."""
+    from eigen_zeth_amd.service import wrap_arith as WA
+    cpu, air, params, proof = final_like
+    lay = WC.Layout.of_air(air, params)
+    head = WC.head_values(air, params, proof["root32"], proof["shift"])
+    st = WA.Statement(air.program(), proof["root32"], proof["shift"], head)
+    wc = WC.wrap_circuit(lay, st)
+    assert int(wc.blob[0]) == R1.MAGIC2 and int(wc.blob[11]) == 2 and len(wc.c.ariths[1][1]) == params.n_queries
+    tlog = WC.TranscriptLog(proof, lay, head)
+    aux = [479881985774944702531460751064278034642760119942]       # + one element per sparse fixed column (wide8 has none)
+    w0, mask = wc.assign(proof, aux, tlog)
+    wf, a, b, c = native.r1cs_eval(wc.blob, w0, mask)
+    d = native.fr_ints(wf[1:2])[0]
+    zw = [(tlog.chal[1] >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(3)]
+    args = (air.program(), params.to_dict(), proof["root32"], proof["shift"], proof["publics"])
+    assert d == WV.public_input_b2(*args, aux[0], zw, bn)
+    assert d != WV.public_input_b2(*args, aux[0] + 1, zw, bn) and d != WV.public_input_b2(*args, aux[0], [zw[0] ^ 1] + zw[1:], bn)
+    assert d != WV.public_input_b2(air.program(), params.to_dict(), proof["root32"], proof["shift"], [proof["publics"][0] ^ 1] + proof["publics"][1:], aux[0], zw, bn)
+    assert WC.zeta_of(tlog.chal[1]) == [v % V.P for v in zw]
+    # the same wires from the library's assignment script over the binary openings record ("PZOPEN03": + the rate element behind every challenge)
+    rec = WC.openings_record(proof, lay, tlog)
+    set_idx, set_val = native.wrap_assign(wc.script, rec, aux)
+    assert sorted(set_idx.tolist()) == np.flatnonzero(mask).tolist() and (w0[set_idx.astype(np.int64)] == set_val).all()
+    aux_l, zw_l = native.wrap_aux(rec, air.program(), proof["publics"], params.logn, proof["root32"], aux[0])
+    assert aux_l == aux and zw_l == zw
+    # the reference completion (Python integers: Template.run + every row) gives the same witness
+    vals = {int(k): v for k, v in zip(np.flatnonzero(mask), native.fr_ints(w0[np.flatnonzero(mask)]))}
+    assert native.fr_ints(wf) == wc.c.complete(vals)
+    # every arithmetic wire is pinned by a row
+    import random
+    rnd = random.Random(3)
+    full = np.ones(wc.c.n_wires, dtype=np.uint8)
+    for tpl, insts in wc.c.ariths:
+        for ins, base in (insts[0], insts[-1]):
+            for _ in range(5):
+                k = base + rnd.randrange(tpl.n_int)
+                w2 = wf.copy()
+                w2[k] = native.fr_words([(native.fr_ints(w2[k:k + 1])[0] + 1) % R])[0]
+                with pytest.raises(ValueError, match="does not satisfy"):
+                    native.r1cs_eval(wc.blob, w2, full.copy())
+    # a FALSE witness, proven honestly: hashes, indices and transcript are all consistent -- the hashing-only circuit accepts, stage B-2 does not
+    tr, pub = native.synth_trace(air.trace_kind, 6, air.width, 5)
+    tr[3, 17] ^= np.uint64(1)
+    bad = json.loads(PR.proof_to_json(PR.prove(air, tr, pub, params, cpu)))
+    tl2 = WC.TranscriptLog(bad, lay, head)
+    wc_hash_only = WC.wrap_circuit(lay)
+    native.r1cs_eval(wc_hash_only.blob, *wc_hash_only.assign(bad, aux[0], tl2))
+    with pytest.raises(ValueError, match="does not satisfy"):
+        native.r1cs_eval(wc.blob, *wc.assign(bad, aux, tl2))
+    with pytest.raises(V.Reject):
+        V.verify(bad, air.program(), *tables, V.expectation(params.to_dict()), bn)
+    # one wrong fold / one wrong opened value that still HASHES: impossible to stage without breaking a Merkle path, so the witness-level form --
+    # the honest caller-set wires with one FRI leaf element's VALUE wire and its sponge left as they are, and the fold's expected value changed --
+    # is what the pinned-wire loop above covers; the statement-level form is the false-witness proof.
+    # Groth16 over the enlarged circuit: the product's key scalars, the checker's trapdoor prover, the pairing check, d from public data
+    key = G16.Key(wc.blob)
+    proof_g, pubs, _ = G16.prove(key, set_idx, set_val, cpu, (11, 13))
+    assert pubs == [d] and WV.verify_b2(key.vk, proof_g, pubs, *args, aux[0], zw, bn)
+    with pytest.raises(V.Reject):
+        WV.verify_b2(key.vk, proof_g, pubs, *args, aux[0] + 1, zw, bn)
+    assert "stage B-2" in G16.circuit_text(wc, key)

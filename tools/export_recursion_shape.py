@@ -66,7 +66,7 @@ def export_final(out, eng, n_proofs=2, logn=None):
                          int(be.root32), int(be.shift))
     fair = VA.verifier_air(agg_shape, rc, mds)
     fp = VA.aggregation_params(agg_shape, cfg.final_queries, cfg.fri_logf, cfg.fri_final_log, 0, hash="bn128")
-    wc, key = eng._wrap_key(WC.Layout.of_air(fair, fp))
+    wc, key = eng._wrap_key(fair, fp)
     os.makedirs(out, exist_ok=True)
     w = lambda name, arr, dt=np.uint64: np.ascontiguousarray(arr, dtype=dt).tofile(os.path.join(out, name))
     w("inner_program.bin", agg_air.program())
