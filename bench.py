@@ -381,6 +381,29 @@ def main():
         copy_gbs = 2.0 * x.numel() * 8 / (ms * 1e-3) / 1e9
         del y
 
+    # north_star: "Goldilocks NTT field-elems/s on synthetic 2^20-2^26 traces ... as absolute numbers and as fraction of HBM roofline" -- a compact live
+    # sweep on the buffer of the timed region (16 columns; the full sweep with LDE and Merkle: tools/size_sweep.py -> profiles/r6_size_sweep.jsonl)
+    sweep = None
+    if rank == 0 and world == 1 and logn == 24 and cols >= 64:
+        try:
+            sweep = []
+            for lg in range(20, 27):
+                v = x.view(-1)[:16 << lg].view(16, 1 << lg)
+                prover.ntt(v, v, lg, 16)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 8 if lg <= 23 else 3
+                e0.record()
+                for _ in range(reps):
+                    prover.ntt(v, v, lg, 16)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                sweep.append({"logn": lg, "cols": 16, "passes": len(prover.ntt_plan(lg)["passes"]), "ms": ms, "Gelems_s": (16 << lg) / ms / 1e6,
+                              "frac_hbm": 16.0 * (16 << lg) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        except Exception as e:
+            sweep = {"error": repr(e)}
+
     if rank == 0:
         plan = prover.ntt_plan(logn)
         npass = max(1, len(plan["passes"]))
@@ -453,6 +476,7 @@ def main():
                                     "configs[3] as stated" % (logn, cols * world, cols)),
                        "logn": logn, "cols_per_gpu": cols, "cols_total": cols * world, "sharding": "columns, no data-path collective",
                        "plan": plan},
+            "sweep": sweep,
             "device_ms_per_step": dev_ms / args.steps,
             "device_ms_per_step_median": per_step[len(per_step) // 2],
             "device_ms_per_step_min": per_step[0],
@@ -942,9 +966,9 @@ def config5_probe(K=64, logn=22, msm_log=26, air_name="chunk64"):
       recursion           the client's contract: GenAggregatedProof(first, last) -> GenFinalProof (final STARK in BN128-hash mode + wrap);
                           and the fold of ALL K chunk proofs as a binary tree of GenAggregatedProof calls (K - 1 aggregation STARKs) under one
                           final proof -- what a batch-covering proof costs with this prover's pairwise aggregation
-      the wrap's MSMs     the wrap of this build verifies the HASHING of the final STARK: 1.3 M constraints, MSMs of 1.3 M / 2.1 M points inside
-                          final_s (batch.groth16_wrap); the 2^msm_log-point sizes BASELINE names (a wrap that also verifies the arithmetic) are
-                          timed beside it on synthetic points, labelled
+      the wrap's MSMs     round 6: the wrap verifies the final STARK's hashing AND its field arithmetic (stage B-2): 3.2 M constraints, a 2^22 QAP
+                          domain, MSMs of 2.8 M - 4.2 M points ON THE REQUEST PATH, inside final_s (batch.groth16_wrap, final_stages_s); the
+                          2^msm_log-point size BASELINE names is timed beside it on synthetic points, labelled
     One warm-up batch of 8 chunks first (CRS, buffer pools, plan tables)."""
     import ctypes as C
     import random

@@ -409,6 +409,24 @@ int32_t zp_stark_set_air_kernel(zp_ctx *ctx, const uint64_t *h_program, size_t p
     }
     return ZP_OK;
 }
+// The ROW-WINDOW form of a generated constraint kernel (`zpair_<air>_quotient_rows` of the same library; round 6): the sharded provers of this ctx
+// (zp_stark_prove_sharded, zp_stark_prove_sharded_bn128: every rank evaluates the quotient on ITS rows) use it instead of the interpreter -- same
+// values, proofs byte-identical either way.  fn = NULL forgets it.
+typedef int (*zp_air_quotient_rows_fn)(void *stream, const u64 *cols, u64 sc, const u64 *fixedc, u64 sf, u64 M, u64 b, u64 row0, u64 nrows, const u64 *pub,
+                                       const u64 *apow, const u64 *zhinv, const u64 *xs_lo, const u64 *xs_hi, int lb, u64 shift, u64 wlast, u64 *out, u64 so);
+int32_t zp_stark_set_air_kernel_rows(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, void *quotient_rows_fn) {
+    if (!ctx) return ZP_ERR_ARG;
+    ZP_ARG(ctx, h_program && program_words >= 8 && program_words < ((size_t)1 << 28), "null / implausible program");
+    try {
+        const std::string k = "rows:" + digest_hex64(h_program, program_words);
+        if (quotient_rows_fn) ctx->air_kernels[k] = quotient_rows_fn;
+        else ctx->air_kernels.erase(k);
+    } catch (...) {
+        ctx->err = "out of host memory";
+        return ZP_ERR_NOMEM;
+    }
+    return ZP_OK;
+}
 
 // SHA-256 of a constraint program blob: the AIR digest.  out32 = the 32 digest bytes (a proof text names the first 8 as 16 hex digits);
 // out_words4 (may be NULL) = the four little-endian 64-bit words, each reduced mod p, that the provers absorb into the transcript.
@@ -1231,7 +1249,42 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
             for (size_t j = 0; j < b; j++) { zhinv[j] = gl_inv(gl_sub(gl_mul(sN, p), 1)); p = gl_mul(p, wb); }
         }
         PV_TRY(dev.alloc(3 * nloc, &dq_l));
-        if (G == 1) {
+        // the generated kernel of this program in its row-window form, when the host registered one (zp_stark_set_air_kernel_rows): the small
+        // operands go up in one buffer [pub | 0 | apow | zhinv], as in prove_impl
+        zp_air_quotient_rows_fn plug = nullptr;
+        u64 *d_ops = nullptr;
+        size_t o_ap = 0, o_zh = 0;
+        const uint64_t *xlo = nullptr, *xhi = nullptr;
+        int32_t xlb = 0;
+        if (!ctx->air_kernels.empty()) {
+            char hex[65];
+            for (int i = 0; i < 32; i++) snprintf(hex + 2 * i, 3, "%02x", dg[i]);
+            auto it = ctx->air_kernels.find(std::string("rows:") + std::string(hex, 64));
+            if (it != ctx->air_kernels.end()) plug = (zp_air_quotient_rows_fn)it->second;
+        }
+        if (plug) {
+            std::vector<u64> ops(pubchal);
+            ops.push_back(0);
+            o_ap = ops.size();
+            ops.insert(ops.end(), apow.begin(), apow.end());
+            o_zh = ops.size();
+            ops.insert(ops.end(), zhinv.begin(), zhinv.end());
+            PV_TRY(dev.alloc(ops.size(), &d_ops));
+            PV_TRY(zp_h2d(ctx, d_ops, ops.data(), ops.size() * 8));
+            PV_TRY(zp_domain_tables(ctx, logm, &xlo, &xhi, &xlb));
+        }
+        auto run_plug = [&](const u64 *cols, size_t sc, size_t row0, size_t nrows) -> int32_t {
+            const int hrc = plug((void *)ctx->stream, cols, (u64)sc, (const u64 *)fx_l, (u64)nloc, (u64)M, (u64)b, (u64)row0, (u64)nrows, d_ops, d_ops + o_ap,
+                                 d_ops + o_zh, (const u64 *)xlo, (const u64 *)xhi, (int)xlb, shift, gl_inv(wN), dq_l, (u64)nloc);
+            if (hrc != 0) {
+                ctx->err = "generated constraint kernel (row window): launch failed (hip error " + std::to_string(hrc) + ")";
+                return ZP_ERR_HIP;
+            }
+            return ZP_OK;
+        };
+        if (G == 1 && plug) {
+            PV_TRY(run_plug((const u64 *)ext, nloc, 0, M));
+        } else if (G == 1) {
             PV_TRY(zp_eval_quotient_rows(ctx, h_program, program_words, (const uint64_t *)ext, nloc, (const uint64_t *)fx_l, nloc, logm, logb, 0, M,
                                          (const uint64_t *)pubchal.data(), (int32_t)pubchal.size(), (const uint64_t *)apow.data(),
                                          (const uint64_t *)zhinv.data(), shift, gl_inv(wN), (uint64_t *)dq_l, nloc));
@@ -1245,9 +1298,13 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
             ZP_HIP(ctx, hipMemcpy2DAsync(buf, (nloc + b) * 8, ext, nloc * 8, nloc * 8, Wt, hipMemcpyDeviceToDevice, ctx->stream));
             ZP_HIP(ctx, hipMemcpy2DAsync(buf + nloc, (nloc + b) * 8, allh + (size_t)((rank + 1) % G) * Wt * b, b * 8, b * 8, Wt, hipMemcpyDeviceToDevice,
                                          ctx->stream));                                                                 // ... of the next rank
-            PV_TRY(zp_eval_quotient_rows(ctx, h_program, program_words, (const uint64_t *)buf, nloc + b, (const uint64_t *)fx_l, nloc, logm, logb, r0,
-                                         nloc, (const uint64_t *)pubchal.data(), (int32_t)pubchal.size(), (const uint64_t *)apow.data(),
-                                         (const uint64_t *)zhinv.data(), shift, gl_inv(wN), (uint64_t *)dq_l, nloc));
+            if (plug) {
+                PV_TRY(run_plug((const u64 *)buf, nloc + b, r0, nloc));
+            } else {
+                PV_TRY(zp_eval_quotient_rows(ctx, h_program, program_words, (const uint64_t *)buf, nloc + b, (const uint64_t *)fx_l, nloc, logm, logb, r0,
+                                             nloc, (const uint64_t *)pubchal.data(), (int32_t)pubchal.size(), (const uint64_t *)apow.data(),
+                                             (const uint64_t *)zhinv.data(), shift, gl_inv(wN), (uint64_t *)dq_l, nloc));
+            }
             PV_TRY(zp_sync(ctx));
             dev.release(heads);
             dev.release(allh);
@@ -1255,6 +1312,7 @@ int32_t prove_sharded_impl(zp_comm *comm, zp_ctx *ctx, const char *air_name, con
         }
         PV_TRY(zp_sync(ctx));
         dev.release(fx_l);
+        if (d_ops) dev.release(d_ops);
     }
     // the quotient is needed whole on every rank: for its out-of-domain evaluation and, with Q > 1, for the coefficients its pieces are slices of
     u64 *dq_whole, *dq_rows = dq_l, *treeq;       // dq_whole: u64[Wq][M], the committed quotient columns (all rows)

@@ -67,6 +67,7 @@ SIGNATURES = {
     "zp_poseidon_bn254_sponge_caps": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp]),
     "zp_free_buffer": (C.c_int32, [_vp]),
     "zp_stark_set_air_kernel": (C.c_int32, [C.c_void_p, _u64p, C.c_size_t, C.c_void_p]),
+    "zp_stark_set_air_kernel_rows": (C.c_int32, [C.c_void_p, _u64p, C.c_size_t, C.c_void_p]),
     "zp_poseidon_sponge": (C.c_int32, [_vp, _u64p, _u64p, C.c_size_t, C.c_size_t, _u64p]),
     "zp_poseidon_sponge_caps": (C.c_int32, [_vp, _u64p, _u64p, C.c_size_t, C.c_size_t, _u64p, _u64p]),
     "zp_deep_quotient_rows": (C.c_int32, [_vp, _vp, C.c_int32, C.c_size_t, _vp, C.c_int32, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, C.c_int32,
@@ -1021,6 +1022,12 @@ class Prover:
         blob = np.ascontiguousarray(program, dtype=np.uint64)
         addr = C.cast(fn, C.c_void_p).value if fn is not None else None
         self._chk(self.lib.zp_stark_set_air_kernel(self.ctx, blob.ctypes.data_as(_u64p), blob.size, addr))
+
+    def set_air_kernel_rows(self, program, fn):
+        """zp_stark_set_air_kernel_rows: the row-window form of the generated constraint kernel (`<symbol>_rows`), for the sharded provers of this ctx"""
+        blob = np.ascontiguousarray(program, dtype=np.uint64)
+        addr = C.cast(fn, C.c_void_p).value if fn is not None else None
+        self._chk(self.lib.zp_stark_set_air_kernel_rows(self.ctx, blob.ctypes.data_as(_u64p), blob.size, addr))
 
     def stark_openings(self):
         """zp_stark_openings: the binary openings of the last BN128-mode proof of this ctx (a copy)"""

@@ -447,26 +447,28 @@ class _Emitter:
 
 
 def emit_quotient_source(air, target="hip"):
-    """device kernel + host launcher exported as air.symbol (gfx950 only; the checker in oracle/ interprets the
-    constraint program blob instead and shares no code with this emitter)"""
+    """device kernel + host launchers exported as air.symbol (the whole evaluation domain) and air.symbol + "_rows" (a row window of a sharded
+    proof: explicit strides, the window's first row, halo rows behind every column unless the window is the whole domain) -- ONE kernel serves both.
+    gfx950 only; the checker in oracle/ interprets the constraint program blob instead and shares no code with this emitter."""
     assert target == "hip"
     em = _Emitter(air.n_pub)
     outs = [em.emit(c) for c in air.constraints]
     body = []
     for (i, nxt) in sorted(em.cols):
-        body.append("    const u64 c%d%s = cols[(u64)%d * M + %s];" % (i, "n" if nxt else "", i, "rn" if nxt else "r"))
-    # fixed columns 0 / 1 (the boundary selectors) are whole columns; the sparse periodic ones behind them are ONE extended period each
-    # (zp_fixed_columns: column i >= 2 of period 2^lp holds 2^lp * b values at offset 2 M + b * sum of the earlier periods; row r reads r mod 2^lp b)
+        body.append("    const u64 c%d%s = cols[(u64)%d * sc + %s];" % (i, "n" if nxt else "", i, "in" if nxt else "i"))
+    # fixed columns 0 / 1 (the boundary selectors) are whole columns (a window of them for a row shard); the sparse periodic ones behind them are ONE
+    # extended period each (zp_fixed_columns: column i >= 2 of period 2^lp holds 2^lp * b values at offset 2 * stride + b * sum of the earlier
+    # periods; domain row r reads r mod 2^lp b)
     prefix, acc = {}, 0
     for k, fc in enumerate(air.fixed_cols):
         prefix[2 + k] = (acc, 1 << fc.lp)
         acc += 1 << fc.lp
     for i in sorted(em.fixed):
         if i < 2:
-            body.append("    const u64 f%d = fixedc[(u64)%d * M + r];" % (i, i))
+            body.append("    const u64 f%d = fixedc[(u64)%d * sf + i];" % (i, i))
         else:
             off, per = prefix[i]
-            body.append("    const u64 f%d = fixedc[2 * M + b * %dULL + (r & (b * %dULL - 1))];" % (i, off, per))
+            body.append("    const u64 f%d = fixedc[2 * sf + b * %dULL + (r & (b * %dULL - 1))];" % (i, off, per))
     body += em.lines
     # random linear combination with alpha^k as three unreduced 160-bit dot products (gl_acc), reduced once
     body.append("    gl_acc s0 = gl_acc_zero(), s1 = gl_acc_zero(), s2 = gl_acc_zero();")
@@ -475,22 +477,30 @@ def emit_quotient_source(air, target="hip"):
                     % (o, 3 * k, o, 3 * k + 1, o, 3 * k + 2))
     body.append("    const u64 a0 = gl_acc_reduce(s0), a1 = gl_acc_reduce(s1), a2 = gl_acc_reduce(s2);")
     body.append("    const u64 zi = zhinv[r & (b - 1)];")
-    body.append("    out[r] = gl_mul(a0, zi); out[M + r] = gl_mul(a1, zi); out[2 * M + r] = gl_mul(a2, zi);")
+    body.append("    out[i] = gl_mul(a0, zi); out[so + i] = gl_mul(a1, zi); out[2 * so + i] = gl_mul(a2, zi);")
     body = "\n".join(body)
     hdr = ("// generated by eigen_zeth_amd/stark/air.py for AIR '%s' (digest %s) -- do not edit\n"
            "// row-parallel constraint evaluation + quotient: lane = LDE row, column reads coalesced.\n"
            % (air.name, air.digest()))
-    args = ("const u64 *__restrict__ cols, const u64 *__restrict__ fixedc, u64 M, u64 b, const u64 *__restrict__ pub, "
-            "const u64 *__restrict__ apow, const u64 *__restrict__ zhinv, const u64 *__restrict__ xs_lo, "
+    tail = ("const u64 *__restrict__ pub, const u64 *__restrict__ apow, const u64 *__restrict__ zhinv, const u64 *__restrict__ xs_lo, "
             "const u64 *__restrict__ xs_hi, int lb, u64 shift, u64 wlast, u64 *__restrict__ out")
-    xcode = ("    const u64 rn = (r + b) & (M - 1);\n"
+    args = "const u64 *__restrict__ cols, const u64 *__restrict__ fixedc, u64 M, u64 b, " + tail
+    # the window form: rows [row0, row0 + nrows) of the M-row domain; columns at stride sc (with b halo rows behind each unless the window is the
+    # whole domain: then the next row wraps), the two selectors at stride sf, the output planes at stride so
+    kargs = "const u64 *__restrict__ cols, u64 sc, const u64 *__restrict__ fixedc, u64 sf, u64 M, u64 b, u64 row0, u64 nrows, " + tail + ", u64 so"
+    xcode = ("    const u64 r = row0 + i;\n"
+             "    const u64 in = nrows == M ? ((i + b) & (M - 1)) : i + b;\n"
              "    const u64 x = gl_mul(shift, gl_mul(xs_lo[r & ((1ULL << lb) - 1)], xs_hi[r >> lb]));\n"
              "    const u64 xml = gl_sub(x, wlast);\n")
+    launch = ("    hipLaunchKernelGGL(%s_kernel, dim3((unsigned)((%s + 255) / 256)), dim3(256), 0, (hipStream_t)stream,\n"
+              "                       cols, %s, fixedc, %s, M, b, %s, %s, pub, apow, zhinv, xs_lo, xs_hi, lb, shift, wlast, out, %s);\n"
+              "    return (int)hipGetLastError();\n}\n")
     return (hdr + '#include <hip/hip_runtime.h>\n#include "gl.hpp"\n'
             "__global__ void __launch_bounds__(256) %s_kernel(%s) {\n"
-            "    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (r >= M) return;\n%s%s\n}\n"
-            'extern "C" int %s(void *stream, %s) {\n'
-            "    hipLaunchKernelGGL(%s_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,\n"
-            "                       cols, fixedc, M, b, pub, apow, zhinv, xs_lo, xs_hi, lb, shift, wlast, out);\n"
-            "    return (int)hipGetLastError();\n}\n"
-            % (air.symbol, args, xcode, body, air.symbol, args, air.symbol))
+            "    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (i >= nrows) return;\n%s%s\n}\n"
+            % (air.symbol, kargs, xcode, body)
+            + 'extern "C" int %s(void *stream, %s) {\n' % (air.symbol, args)
+            + launch % (air.symbol, "M", "M", "M", "(u64)0", "M", "M")
+            + 'extern "C" int %s_rows(void *stream, const u64 *cols, u64 sc, const u64 *fixedc, u64 sf, u64 M, u64 b, u64 row0, u64 nrows, %s, u64 so) {\n'
+            % (air.symbol, tail.replace("__restrict__ ", ""))
+            + launch % (air.symbol, "nrows", "sc", "sf", "row0", "nrows", "so"))

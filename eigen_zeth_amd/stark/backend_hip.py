@@ -217,8 +217,9 @@ class HipBackend:
         communicator, csrc/comm.hip: zp_comm_create_local): rank r drives devices[r] with a ctx of its own (default: every rank on this
         backend's GPU -- the ranks then share its CUs, which is a rehearsal, not a speed-up).  Rank r takes ITS columns of the trace
         (ceil(W / ranks) per rank, the tail ranks fewer: 47 columns of a verifier AIR over 8 ranks = 6 x 7 + 5).  Returns (proof text --
-        byte-identical to prove_native's --, rank 0's binary openings record in BN128 mode, else None).  The sharded provers run the
-        constraint program through the interpreter (row windows), whatever this backend's quotient mode."""
+        byte-identical to prove_native's --, rank 0's binary openings record in BN128 mode, else None).  Round 6: every rank evaluates its row
+        window of the quotient through the AIR's GENERATED kernel (`<symbol>_rows`, zp_stark_set_air_kernel_rows) when this backend runs in
+        kernel mode and the AIR's library exists; the interpreter serves otherwise -- same proof bytes."""
         assert self.hash_mode == params.hash and ranks >= 1 and (ranks & (ranks - 1)) == 0
         bn = params.hash == "bn128"
         devs = list(devices) if devices else [self.p_device] * ranks
@@ -246,6 +247,14 @@ class HipBackend:
         group = native.CommGroup(ranks)
         texts, errs, rec = [None] * ranks, [None] * ranks, [None]
         prog, pl = air.program(), [int(v) for v in pubs]
+        rows_fn = None
+        if self.quotient_mode == "kernel" and (not air.fixed_cols or os.path.exists(build_airs.lib_path(air))):
+            try:
+                rows_fn = self._airlib_rows(air)
+            except (OSError, RuntimeError, AttributeError, subprocess.CalledProcessError):
+                rows_fn = None
+        for _, q in provers:
+            q.set_air_kernel_rows(prog, rows_fn)
 
         def body(r):
             q = provers[r][1]
@@ -424,6 +433,16 @@ class HipBackend:
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_int, C.c_uint64,
                                                                                                  C.c_uint64, C.c_void_p]
+            self._airlibs[k] = fn
+        return self._airlibs[k]
+
+    def _airlib_rows(self, air):
+        """the row-window entry point of the AIR's generated library (one kernel, two launchers: stark/air.py emit_quotient_source)"""
+        k = (air.name, air.digest(), "rows")
+        if k not in self._airlibs:
+            lib = C.CDLL(build_airs.build_air(air))
+            fn = getattr(lib, air.symbol + "_rows")
+            fn.restype = C.c_int
             self._airlibs[k] = fn
         return self._airlibs[k]
 

@@ -202,6 +202,10 @@ int32_t zp_free_buffer(void *p);
  * evaluate their constraints through it instead of the interpreter -- same proof bytes, 0.7 instead of 1.2 ms at 2^21 x 76.  Programs with sparse
  * periodic fixed columns and sharded proofs stay with the interpreter. */
 int32_t zp_stark_set_air_kernel(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, void *quotient_fn);
+/* (round 6) the same for the SHARDED provers of this ctx: `zpair_<air>_quotient_rows` of the same library evaluates a row window (explicit strides,
+ * first row, b halo rows behind every column unless the window is the whole domain): int fn(stream, cols, stride_cols, fixed, stride_fixed, M, b,
+ * row0, nrows, pub, apow, zhinv, xs_lo, xs_hi, lb, shift, wlast, out, stride_out).  Proof bytes are the same with the kernel or the interpreter. */
+int32_t zp_stark_set_air_kernel_rows(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, void *quotient_rows_fn);
 /* the AIR digest of a constraint program blob (host code, no ctx): SHA-256, out32 = the digest bytes (a proof's "air_digest" is the hex of the
  * first 8), out_words4 (or NULL) = the four 64-bit words (little-endian, mod p) a prover absorbs into its transcript and a verifier-AIR
  * witness builder needs for the inner proofs' statement (zp_recursion_witness: the head of the transcript stream). */

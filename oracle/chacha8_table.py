@@ -21,6 +21,10 @@ P = 0xFFFFFFFF00000001
 
 ANCHOR_FIRST_CONSTANT = 0xB585F766F2144405
 ANCHOR_PERM_ZERO = [0x3C18A9786CB0B359, 0xC4055E3364A246C3, 0x7953DB0AB48808F4, 0xC71603F33A1144CA]
+# Two more vectors of the public family's own test suite, written down from memory in round 6 BEFORE the permutation was run on them (they are not in
+# SURVEY.md; same standing as the anchors above: recalled, then reproduced): perm(0, 1, ..., 11)[0..4] and perm(p - 1, ..., p - 1)[0].
+ANCHOR_PERM_COUNTING = [0xD64E1E3EFC5B8E9E, 0x53666633020AAA47, 0xD40285597C6A8825, 0x613A4F81E81231D2]
+ANCHOR_PERM_MINUS_ONE_WORD0 = 0xBE0085CFC57A8357
 
 
 def _rotl32(x, n):

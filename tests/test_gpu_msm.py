@@ -29,7 +29,13 @@ def test_msm_matches_oracle(prover, table, n):
     scs = [rnd.randrange(0, 1 << 256) for _ in range(n)]
     for i, v in enumerate([0, 1, B.R - 1, B.R, (1 << 254) - 1, 1 << 253][:n]):
         scs[i] = v
-    assert prover.msm_bn254(pts, scs) == B.msm(pts, scs)
+    if n <= 200:
+        assert prover.msm_bn254(pts, scs) == B.msm(pts, scs)
+    else:       # (the checker's double-and-add over 1000 points is half a minute of Python: per DISTINCT point of the 64-point table, as below)
+        by_pt = {}
+        for p, sc in zip(pts, scs):
+            by_pt[p] = (by_pt.get(p, 0) + sc) % B.R
+        assert prover.msm_bn254(pts, scs) == B.msm(list(by_pt), list(by_pt.values()))
 
 
 def test_msm_in_several_runs_matches_oracle(prover, table):

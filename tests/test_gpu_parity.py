@@ -191,6 +191,10 @@ def test_compiled_in_table_hits_the_public_familys_anchor_on_the_gpu(prover, tab
             got = fresh.download(d, (count, 12))
             assert (got == got[0]).all() and [int(v) for v in got[0, :4]] == want
             assert (got[0] == O.poseidon_perm(np.zeros((1, 12), dtype=np.uint64), u(CT.round_constants(0)), tables[1])[0]).all()
+        d = fresh.upload(u([list(range(12)), [P - 1] * 12]))
+        fresh.poseidon_perm(d, 2)
+        got = fresh.download(d, (2, 12))
+        assert [int(v) for v in got[0, :4]] == CT.ANCHOR_PERM_COUNTING and int(got[1, 0]) == CT.ANCHOR_PERM_MINUS_ONE_WORD0
         fresh.set_constants(native.ZP_CONST_POSEIDON_RC, u(PC.grain_goldilocks_round_constants()))
         d = fresh.upload(np.zeros((1, 12), dtype=np.uint64))
         fresh.poseidon_perm(d, 1)

@@ -130,6 +130,48 @@ def test_sharded_prover_over_local_ranks_equals_the_single_gpu_proof(prover, tab
     assert V.verify(json.loads(texts[-1]), air.program(), rc, mds, V.expectation(params.to_dict()))
 
 
+@pytest.mark.parametrize("airname,logn,logb,logf,final_log,nq,pow_bits,G,bn", [("chunk16", 10, 1, 2, 3, 8, 8, 2, False), ("wide8", 9, 2, 3, 3, 6, 0, 4, False),
+                                                                                 ("periodic9", 9, 2, 2, 3, 6, 4, 2, False), ("chunk64", 12, 1, 4, 4, 10, 0, 4, True)])
+def test_sharded_provers_through_the_row_window_kernel(prover, tables, airname, logn, logb, logf, final_log, nq, pow_bits, G, bn):
+    """round 6: every rank evaluates ITS rows of the quotient through the AIR's generated kernel in its row-window form (`<symbol>_rows`,
+    zp_stark_set_air_kernel_rows: strides, first row, b halo rows of the next rank) instead of the interpreter -- the proof text is the single-GPU
+    text either way, in both hash modes, with stage-2 columns, blow-up 4 and sparse periodic fixed columns (the window reads the whole periodic
+    column at row mod period).  That the kernel really runs: with ANOTHER AIR's kernel registered for this program the text is no longer that one."""
+    from eigen_zeth_amd.stark.backend_hip import HipBackend
+    hip = HipBackend(prover=prover)
+    if airname.startswith("periodic"):
+        air = AIR.periodic_air(logn)
+        tr, pub = AIR.periodic_witness(logn, 5)
+    else:
+        air = AIR.get_air(airname)
+        tr, pub = native.synth_trace(air.trace_kind, logn, air.width, 21)
+    rows_fn = hip._airlib_rows(air)
+    args = (logn, logb, logf, final_log, nq) + (() if bn else (pow_bits,))
+    if bn:
+        prover.install_poseidon_bn254(17)
+    d = prover.upload(tr)
+    single = (prover.stark_prove_bn128 if bn else prover.stark_prove)(air.name, air.program(), d, [int(v) for v in pub], *args)
+    d.free()
+
+    def ranks(fn_rows):
+        def fn(r, p, c):
+            if bn:
+                p.install_poseidon_bn254(17)
+            p.set_air_kernel_rows(air.program(), fn_rows)
+            first, count = c.my_columns(air.width)
+            d_l = p.upload(np.ascontiguousarray(tr[first:first + count])) if count else None
+            return c.stark_prove_sharded(air.name, air.program(), d_l, [int(v) for v in pub], *args, bn128=bn)
+        return run_ranks(G, fn)
+    assert all(t == single for t in ranks(rows_fn))
+    assert all(t == single for t in ranks(None))
+    if airname == "chunk16":
+        other = hip._airlib_rows(AIR.get_air("wide8"))       # reads other columns, has other constraints: whatever comes out is not this proof
+        try:
+            assert all(t != single for t in ranks(other))
+        except native.ZpError:
+            pass
+
+
 def test_sharded_prover_takes_columns_that_do_not_divide_over_the_ranks(prover, tables):
     """ceil(W / G) columns per rank, the tail ranks fewer or none (periodic AIR: 3 columns over 2 and 4 ranks -> 2+1, 1+1+1+0)"""
     rc, mds = tables

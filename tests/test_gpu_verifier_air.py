@@ -155,11 +155,18 @@ def test_engine_aggregate_and_final_prove_what_they_name(tables, tmp_path):
         eng.final("x", json.dumps({"kind": "something-else"}), "BN128", "1")
     # the same request with the final STARK as ONE proof over two / eight ranks of the process (EngineConfig.final_ranks: zp_stark_prove_sharded_bn128
     # on an in-process communicator; the verifier AIR's 47 columns do not divide): the same final STARK, a wrap from rank 0's openings record
+    # (the same engine with the knob turned: a second engine would make the wrap key again -- seconds at stage B-2's 3.2 M constraints)
+    want_fs = eng.final_starks["agg"]
     for ranks in (2, 8):
-        cfg_r = EngineConfig(air="chunk64", logn=14, chunks_per_block=1, crs_dir=str(tmp_path / "crs"), final_ranks=ranks)
-        eng_r = Engine(default_backend_factory(0), cfg_r)
-        final_r, pub_r = eng_r.final("agg", text, "BN128", "479881985774944702531460751064278034642760119942")
-        assert eng_r.final_starks["agg"] == eng.final_starks["agg"] and pub_r == pub
+        assert EngineConfig(air="chunk64", logn=14, final_ranks=ranks).final_ranks == ranks
+        eng.cfg.final_ranks = ranks
+        try:
+            final_r, pub_r = eng.final("agg", text, "BN128", "479881985774944702531460751064278034642760119942")
+        finally:
+            eng.cfg.final_ranks = 1
+        assert eng.final_starks["agg"] == want_fs and pub_r == pub
+    with pytest.raises(ValueError):
+        EngineConfig(air="chunk64", logn=14, final_ranks=3)
     print("stage timings:", json.dumps({k: v for k, v in eng.stage_timings.items() if k.startswith(("aggregate", "final"))}))
 
 

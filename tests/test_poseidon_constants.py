@@ -60,6 +60,13 @@ def test_chacha8_seed0_table_hits_the_public_familys_anchors():
     assert out[:4] == CT.ANCHOR_PERM_ZERO == [0x3C18A9786CB0B359, 0xC4055E3364A246C3, 0x7953DB0AB48808F4, 0xC71603F33A1144CA]
     got = O.poseidon_perm(np.zeros((1, 12), dtype=np.uint64), np.array(rc, dtype=np.uint64), np.array(mds, dtype=np.uint64))
     assert [int(v) for v in got[0]] == out
+    # two more vectors of the public family's test suite (recalled in round 6 before they were computed): non-zero inputs exercise every column of the
+    # linear layer and the S-box of all twelve lanes, which perm(0) alone does not
+    assert NV.poseidon_perm(list(range(12)), rc, mds)[:4] == CT.ANCHOR_PERM_COUNTING
+    assert NV.poseidon_perm([PC.GL_P - 1] * 12, rc, mds)[0] == CT.ANCHOR_PERM_MINUS_ONE_WORD0
+    sts = np.array([list(range(12)), [PC.GL_P - 1] * 12], dtype=np.uint64)
+    got = O.poseidon_perm(sts, np.array(rc, dtype=np.uint64), np.array(mds, dtype=np.uint64))
+    assert [int(v) for v in got[0, :4]] == CT.ANCHOR_PERM_COUNTING and int(got[1, 0]) == CT.ANCHOR_PERM_MINUS_ONE_WORD0
     # neither anchor survives another seed, round count or the Grain table: the match is not an accident of the linear layer
     assert CT.round_constants(1)[0] != CT.ANCHOR_FIRST_CONSTANT
     assert CT.uniform_below(CT.ChaCha(CT.key_from_u64(0), 12), CT.P) != CT.ANCHOR_FIRST_CONSTANT
