@@ -1069,7 +1069,7 @@ def config5_probe(K=64, logn=22, msm_log=26, air_name="chunk64"):
         tc = time.perf_counter()
         out["wrap_msm_sizes"] = {"points": n, "g1_4x_s": tb - ta, "g2_1x_s": tc - tg, "g2_first_call_s_incl_arena_growth": tg - tb,
                                  "note": "synthetic points (a 2^20-point slice of a 32 / 16-point table, tiled) and uniform 253-bit scalars; NOT part of wall_s: "
-                                         "the wrap circuit of this build has 1.3 M constraints (its own MSMs are inside final_s)"}
+                                         "the wrap circuit of this build (stage B-2) has 3.2 M constraints: its own MSMs of 2.8 - 4.2 M points are inside final_s"}
         out["wall_s_plus_wrap_msm_sizes"] = out["wall_s"] + (tb - ta) + (tc - tg)
         for d in (d_s, d_p1, d_p2):
             d.free()
