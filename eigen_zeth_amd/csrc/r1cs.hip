@@ -747,6 +747,7 @@ void pack_element(const uint64_t *vals, uint64_t width, uint64_t block, int e, u
 }
 
 
+#ifndef ZP_R1CS_HOST_ONLY      /* (tests/test_r1cs_fuzz.py builds the host half of this file with g++ under ASan + UBSan) */
 // ---- witness completion and A w, B w, C w ON THE GPU (zp_r1cs_eval_device): the caller-set wires are scattered into the witness in HBM, the
 // instances of the gadget are evaluated wave by wave by the permutation kernel of csrc/poseidon_bn254.hip (an instance's internal wires and
 // rows ARE the intermediate values of its permutation), the explicit constraints by a sparse-row kernel.  Nothing but the few thousand set
@@ -856,8 +857,10 @@ __global__ void __launch_bounds__(256) r1cs_allset_kernel(const unsigned char *_
     if (j < n && !set[j]) atomicMin(&flags[2], (unsigned long long)j);
 }
 
+#endif
 }  // namespace
 
+#ifndef ZP_R1CS_HOST_ONLY
 // the circuit a ctx evaluated last, kept in HBM (the blob as it came, the list of its defining extra constraints); `checked`: the gadget template
 // of the blob has been compared with the kernel on one instance (zp_r1cs_eval_device)
 struct ZpG16Cache {
@@ -1102,6 +1105,7 @@ int32_t zp_r1cs_eval_device(zp_ctx *ctx, const uint64_t *circ, size_t words, con
 
 }  // extern "C"
 
+#endif
 namespace {
 
 }  // namespace
@@ -1162,8 +1166,10 @@ int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64
             continue;
         }
         if (op >= 10) {
-            if (op == 10 ? (a >= o.n_blocks || b + cnt > 16) : a >= o.n_rates) return ZP_ERR_ARG;
-            if ((op == 11 && cnt != 16) || (op >= 12 && b >= 16) || (op == 12 && c + cnt > 254) || (op == 13 && c + cnt > n_ones) || (op == 14 && (cnt != 30 || c >= 3)))
+            // (sums of script words are compared WITHOUT forming them: b + cnt wraps for a b near 2^64 -- found by tests/test_r1cs_fuzz.py, round 6)
+            if (op == 10 ? (a >= o.n_blocks || b >= 16 || cnt > 16 - b) : a >= o.n_rates) return ZP_ERR_ARG;
+            if ((op == 11 && cnt != 16) || (op >= 12 && b >= 16) || (op == 12 && (c >= 254 || cnt > 254 - c)) || (op == 13 && (c >= n_ones || cnt > n_ones - c)) ||
+                (op == 14 && (cnt != 30 || c >= 3)))
                 return ZP_ERR_ARG;
             const uint64_t *el = op == 10 ? o.blocks + (a * 16 + b) * 4 : o.rates + (a * 16 + (op == 11 ? 0 : b)) * 4;
             for (uint64_t i = 0; i < cnt; i++, n++) {
@@ -1194,7 +1200,7 @@ int32_t zp_wrap_assign(const uint64_t *script, size_t script_words, const uint64
             if (c >= T->levels) return ZP_ERR_ARG;
             pos = ((q[0] & (T->leaves - 1)) >> (4 * c)) & 15;
         }
-        if ((op == 5 && (cnt != 16 || 56 * c >= T->width)) || ((op == 6 || op == 7) && cnt != 16) || (op >= 8 && cnt != 4) || (op == 4 && cnt > 64) ||
+        if ((op == 5 && (cnt != 16 || c >= (T->width + 55) / 56)) || ((op == 6 || op == 7) && cnt != 16) || (op >= 8 && cnt != 4) || (op == 4 && cnt > 64) ||
             ((op == 1 || op == 2 || op == 3) && cnt != 1))
             return ZP_ERR_ARG;
         for (uint64_t i = 0; i < cnt; i++, n++) {
@@ -1250,6 +1256,7 @@ int32_t zp_wrap_aux(const uint64_t *openings, size_t open_words, const uint64_t 
     }
 }
 
+#ifndef ZP_R1CS_HOST_ONLY
 // One Groth16 proof.  circ: the circuit blob; d_u1x (G1, u32[n_wires + 2][16]): [u_j]_1 | alpha_1 | delta_1; d_v_wires u32[n_v]: the wires with a
 // non-zero column in B, ascending (a third of the gadget's wires never stand in B: their key points would be infinity); d_v1x (G1, u32[n_v + 2][16]):
 // [v_j]_1 of those wires | beta_1 | delta_1; d_v2x (G2, u32[n_v + 2][32]): [v_j]_2 of those wires | beta_2 | delta_2; d_l1 (G1, u32[n_wires][16], infinity at wire 0 and the public inputs: those are
@@ -1384,4 +1391,5 @@ int32_t zp_groth16_prove(zp_ctx *ctx, const uint64_t *circ, size_t words, const 
     }
 }
 
+#endif
 }  // extern "C"
