@@ -199,8 +199,8 @@ int32_t zp_stark_prove_bn128(zp_ctx *ctx, const char *air_name, const uint64_t *
 int32_t zp_free_buffer(void *p);
 /* Hand the one-call provers of this ctx the GENERATED constraint kernel of a program (the AIR plug-in ABI below: `zpair_<air>_quotient` from the
  * shared library stark/air.py's code generator built; quotient_fn = its address, NULL forgets it): proofs of the program with this digest
- * evaluate their constraints through it instead of the interpreter -- same proof bytes, 0.7 instead of 1.2 ms at 2^21 x 76.  Programs with sparse
- * periodic fixed columns and sharded proofs stay with the interpreter. */
+ * evaluate their constraints through it instead of the interpreter -- same proof bytes, 0.7 instead of 1.2 ms at 2^21 x 76.  (Sparse periodic fixed
+ * columns are read by the generated kernels since round 5; sharded proofs take the row-window form below since round 6.) */
 int32_t zp_stark_set_air_kernel(zp_ctx *ctx, const uint64_t *h_program, size_t program_words, void *quotient_fn);
 /* (round 6) the same for the SHARDED provers of this ctx: `zpair_<air>_quotient_rows` of the same library evaluates a row window (explicit strides,
  * first row, b halo rows behind every column unless the window is the whole domain): int fn(stream, cols, stride_cols, fixed, stride_fixed, M, b,
@@ -285,6 +285,11 @@ int32_t zp_merkle_open_batch(zp_ctx *ctx, const uint64_t *d_tree, size_t M, cons
  *        const u64 *d_xs_hi, int lb, u64 shift, u64 w_last, u64 *d_out);
  *   d_cols [W][M] LDE of the trace, d_fixed [2][M] LDE of L_first/L_last, d_alpha_pows [K][3],
  *   d_zhinv [blowup] = 1/Z_H on the coset (periodic), d_out [3][M] = quotient planes.
+ *   and (round 6) the same kernel for a ROW WINDOW of a sharded proof:
+ *   int zpair_<air>_quotient_rows(void *hip_stream, const u64 *d_cols, u64 stride_cols, const u64 *d_fixed, u64 stride_fixed, u64 M, u64 blowup,
+ *        u64 row0, u64 nrows, const u64 *d_pub, const u64 *d_alpha_pows, const u64 *d_zhinv, const u64 *d_xs_lo, const u64 *d_xs_hi, int lb,
+ *        u64 shift, u64 w_last, u64 *d_out, u64 stride_out);
+ *   rows [row0, row0 + nrows) of the M-row domain; unless nrows == M every column carries the window's blowup halo rows behind it.
  * zp_domain_tables hands such kernels the ctx-owned two-level table of w_M^e (x = shift*lo[e&mask]*hi[e>>lb]). */
 int32_t zp_domain_tables(zp_ctx *ctx, int32_t logm, const uint64_t **d_lo, const uint64_t **d_hi, int32_t *lb);
 /* ---- N4 as data: the constraint program ----------------------------------------------------------------
