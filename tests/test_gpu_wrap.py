@@ -89,6 +89,9 @@ def test_gpu_groth16_of_the_wrap_circuit_equals_the_trapdoor_proof(tables):
     wf, a, b, c = native.r1cs_eval(wc2.blob, w0, mask)
     gw, ga, gb, gc, gpub = hip.p.r1cs_eval_device(wc2.blob, set_idx, set_val)
     assert (gw == wf).all() and (ga == a).all() and (gb == b).all() and (gc == c).all() and gpub == native.fr_ints(wf[1:2])
+    # the witness the GPU completed, judged by the checker's own reader of the blob (oracle/r1cs_blob.py: no code shared with builder, host or kernels)
+    from oracle import r1cs_blob as RB
+    assert RB.first_violated(wc2.blob, native.fr_ints(gw)) == -1
     key2 = G16.Key(wc2.blob)
     p_gpu, pubs, ms2 = G16.prove(key2, set_idx, set_val, hip, rand)
     p_cpu, pubs_c, _ = G16.prove(key2, set_idx, set_val, cpu, rand)

@@ -277,6 +277,13 @@ def test_stage_b2_the_circuit_runs_the_verifiers_arithmetic(final_like, tables, 
     # the reference completion (Python integers: Template.run + every row) gives the same witness
     vals = {int(k): v for k, v in zip(np.flatnonzero(mask), native.fr_ints(w0[np.flatnonzero(mask)]))}
     assert native.fr_ints(wf) == wc.c.complete(vals)
+    # ... and the CHECKER's own reader of the blob (oracle/r1cs_blob.py: shares nothing with the builder or the library) finds every constraint --
+    # Poseidon instances, explicit rows, arithmetic templates -- satisfied by that witness, and names the row a changed wire breaks
+    from oracle import r1cs_blob as RB
+    wi = native.fr_ints(wf)
+    assert RB.first_violated(wc.blob, wi) == -1 and sum(1 for _ in RB.rows_of(wc.blob)) == wc.c.n_constraints
+    k = wc.c.ariths[1][1][1][1] + 77
+    assert RB.first_violated(wc.blob, wi[:k] + [(wi[k] + 1) % R] + wi[k + 1:]) >= len(wc.c.instances) * 613 + len(wc.c.extras)
     # every arithmetic wire is pinned by a row
     import random
     rnd = random.Random(3)
