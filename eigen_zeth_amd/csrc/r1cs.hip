@@ -10,6 +10,8 @@
 #include <atomic>
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -1078,7 +1080,11 @@ int32_t zp_r1cs_eval_device(zp_ctx *ctx, const uint64_t *circ, size_t words, con
                 memcpy(g->hW + 4 * set_idx[k], set_val + 4 * k, 32);
                 g->hset[set_idx[k]] = 1;
             }
+            const auto tw0 = std::chrono::steady_clock::now();
             const int32_t arc = arith_witness_all(c, g->hW, g->hset.data(), bad);
+            if (getenv("ZP_R1CS_TIMING"))
+                fprintf(stderr, "zp_r1cs_eval_device: witness programs of %zu arithmetic templates on the host: %.2f ms\n", c.ar.size(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
             if (arc != ZP_OK) {
                 ctx->err = arc == -20 ? "the assignment does not satisfy the circuit: no proof for a false statement" : "a wire of the circuit has no value";
                 rc = arc;
