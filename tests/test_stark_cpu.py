@@ -38,7 +38,7 @@ def test_codegen_is_deterministic_and_shares_subexpressions():
     assert a.symbol in src and "__global__" in src
     with pytest.raises(AssertionError):
         AIR.emit_quotient_source(a, "c")      # the product emits device code only; the checker interprets the blob
-    assert src.count("cols[(u64)0 * M + r]") == 1  # each column value is loaded once
+    assert src.count("cols[(u64)0 * sc + i]") == 1  # each column value is loaded once (row-window form: column stride sc, local row i)
 
 
 def test_transcript_is_deterministic_and_order_sensitive(be):
