@@ -75,12 +75,127 @@ __device__ __forceinline__ void mds_ark(u64 *s, const u32 *__restrict__ mds, con
     for (int i = 0; i < 12; i++) s[i] = o[i];
 }
 
+// ---- partial rounds THREE AT A TIME (default matrix; round 6).  A partial round is linear except for ONE S-box, so three of them are
+// three S-boxes and ONE matrix product instead of three.  With t = the state after the first S-box (y0 in element 0), Z = "clear
+// element 0", c1, c2, c3 the constants added after rounds r, r+1, r+2:
+//     x1 = (M t)_0 + c1_0                                        y1 = x1^7
+//     x2 = (M Z M t)_0 + M_00 y1 + (M Z c1 + c2)_0               y2 = x2^7
+//     state entering round r+3 = (M Z)^2 M t + (M Z M e0) y1 + (M e0) y2 + [(M Z)^2 c1 + M Z c2 + c3]
+// All matrices are products of M and M-with-column-0-cleared: non-negative integers below 2^21 (M^3 < 1 525 685), compile-time tables
+// that the mads take from SGPRs; the three constant terms (14 words per block) are made on the host whenever a table is installed and sit
+// behind the 360 round constants.  12 + 13 + 12 * 14 = 193 row terms per three rounds instead of 3 * 144: the 22 partial rounds cost
+// 7 * (386 mads + 14 reductions) + one textbook round instead of 22 * (288 + 12).  The same field values as the textbook schedule
+// (the oracle runs the textbook; every digest identical).  ZP_POSEIDON_BLOCK3=0 builds the textbook loop for A/B.
+#ifndef ZP_POSEIDON_BLOCK3
+#define ZP_POSEIDON_BLOCK3 1
+#endif
+#define ZP_POSEIDON_PK_BLOCKS 7          // partial rounds 4..24 in blocks of three; round 25 stays textbook
+#define ZP_POSEIDON_PK_WORDS 14          // k1, k2, K3[12]
+struct P3Tab {
+    u32 r1[12];       // row 0 of M
+    u32 r2[12];       // row 0 of M Z M
+    u32 a3[12][12];   // (M Z)^2 M
+    u32 u[12];        // column 0 of M Z M
+    u32 v[12];        // column 0 of M
+    u32 mz[12][12];   // M Z (host: the constant terms)
+};
+__host__ __device__ constexpr P3Tab p3_tab() {
+    P3Tab t{};
+    u32 m[12][12] = {}, mz[12][12] = {}, a2[12][12] = {};
+    for (int i = 0; i < 12; i++)
+        for (int j = 0; j < 12; j++) {
+            m[i][j] = def_mds(i, j);
+            mz[i][j] = j == 0 ? 0u : def_mds(i, j);
+        }
+    for (int i = 0; i < 12; i++)
+        for (int j = 0; j < 12; j++) {
+            u32 acc = 0;
+            for (int k = 0; k < 12; k++) acc += mz[i][k] * m[k][j];
+            a2[i][j] = acc;
+        }
+    for (int i = 0; i < 12; i++)
+        for (int j = 0; j < 12; j++) {
+            u32 acc = 0;
+            for (int k = 0; k < 12; k++) acc += mz[i][k] * a2[k][j];
+            t.a3[i][j] = acc;
+            t.mz[i][j] = mz[i][j];
+        }
+    for (int j = 0; j < 12; j++) {
+        t.r1[j] = m[0][j];
+        t.r2[j] = a2[0][j];
+        t.u[j] = a2[j][0];
+        t.v[j] = m[j][0];
+    }
+    return t;
+}
+__device__ __forceinline__ u64 p3_reduce(u64 alo, u64 ahi) {      // alo + ahi 2^32, both < 2^58  ->  weak
+    const u64 mid = (alo >> 32) + ahi;
+    return gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
+}
+// s: the state entering partial round r (its constants added); pk: the block's 14 constant words.  Leaves the state entering round r + 3.
+__device__ __forceinline__ void partial3_default(u64 *s, const u64 *__restrict__ pk) {
+    constexpr P3Tab T = p3_tab();
+    s[0] = sbox7(s[0]);
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) { lo[j] = (u32)s[j]; hi[j] = (u32)(s[j] >> 32); }
+    u64 alo = (u64)(u32)pk[0], ahi = pk[0] >> 32;
+#pragma unroll
+    for (int j = 0; j < 12; j++) { alo += (u64)T.r1[j] * lo[j]; ahi += (u64)T.r1[j] * hi[j]; }
+    const u64 y1 = sbox7(p3_reduce(alo, ahi));
+    const u32 y1l = (u32)y1, y1h = (u32)(y1 >> 32);
+    alo = (u64)(u32)pk[1];
+    ahi = pk[1] >> 32;
+#pragma unroll
+    for (int j = 0; j < 12; j++) { alo += (u64)T.r2[j] * lo[j]; ahi += (u64)T.r2[j] * hi[j]; }
+    alo += (u64)T.v[0] * y1l;
+    ahi += (u64)T.v[0] * y1h;
+    const u64 y2 = sbox7(p3_reduce(alo, ahi));
+    const u32 y2l = (u32)y2, y2h = (u32)(y2 >> 32);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        alo = (u64)(u32)pk[2 + i];
+        ahi = pk[2 + i] >> 32;
+#pragma unroll
+        for (int j = 0; j < 12; j++) { alo += (u64)T.a3[i][j] * lo[j]; ahi += (u64)T.a3[i][j] * hi[j]; }
+        alo += (u64)T.u[i] * y1l;
+        ahi += (u64)T.u[i] * y1h;
+        alo += (u64)T.v[i] * y2l;
+        ahi += (u64)T.v[i] * y2h;
+        s[i] = p3_reduce(alo, ahi);
+    }
+}
+
 // textbook schedule ARK -> S-box -> MDS, with each round's ARK folded into the previous round's
 // MDS accumulators; state is weak between rounds and canonicalised once at the end.
 template <bool DEFMDS>
 __device__ __forceinline__ void poseidon_perm(u64 *s, const u64 *__restrict__ rc, const u32 *__restrict__ mds) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_add_weak(s[i], rc[i]);
+    if constexpr (DEFMDS && ZP_POSEIDON_BLOCK3) {
+#pragma unroll 1
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int i = 0; i < 12; i += 2) sbox7x2(s[i], s[i + 1]);
+            mds_ark<true, true>(s, mds, rc + (r + 1) * 12);
+        }
+#pragma unroll 1
+        for (int b = 0; b < ZP_POSEIDON_PK_BLOCKS; b++) partial3_default(s, rc + 360 + b * ZP_POSEIDON_PK_WORDS);
+        s[0] = sbox7(s[0]);                                   // round 25
+        mds_ark<true, true>(s, mds, rc + 26 * 12);
+#pragma unroll 1
+        for (int r = 26; r < 29; r++) {
+#pragma unroll
+            for (int i = 0; i < 12; i += 2) sbox7x2(s[i], s[i + 1]);
+            mds_ark<true, true>(s, mds, rc + (r + 1) * 12);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i += 2) sbox7x2(s[i], s[i + 1]);
+        mds_ark<false, true>(s, mds, rc);
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+        return;
+    }
 #pragma unroll 1
     for (int r = 0; r < 29; r++) {
         if (r < 4 || r >= 26) {
@@ -623,7 +738,7 @@ int32_t tree_levels(zp_ctx *ctx, u64 *tree, size_t M) {
 int32_t zpi_poseidon_sync_tables(zp_ctx *ctx) {
     if (!ctx->poseidon_dirty) return ZP_OK;
     for (int i = 0; i < 144; i++) ZP_ARG(ctx, ctx->h_mds[i] < (1ULL << 28), "MDS entries must be < 2^28");
-    if (!ctx->d_rc) ZP_HIP(ctx, hipMalloc((void **)&ctx->d_rc, 360 * sizeof(u64)));
+    if (!ctx->d_rc) ZP_HIP(ctx, hipMalloc((void **)&ctx->d_rc, (360 + ZP_POSEIDON_PK_BLOCKS * ZP_POSEIDON_PK_WORDS) * sizeof(u64)));
     if (!ctx->d_mds) ZP_HIP(ctx, hipMalloc((void **)&ctx->d_mds, 144 * sizeof(u32)));
     u32 m32[144];
     for (int i = 0; i < 144; i++) m32[i] = (u32)ctx->h_mds[i];
@@ -634,6 +749,31 @@ int32_t zpi_poseidon_sync_tables(zp_ctx *ctx) {
     for (int i = 0; i < 12; i++)
         for (int j = 0; j < 12; j++)
             if (ctx->h_mds[i * 12 + j] != def_mds(i, j)) ctx->mds_is_default = false;
+    if (ctx->mds_is_default) {
+        // constant terms of the three-round blocks (partial3_default): k1 = c1_0, k2 = (M Z c1 + c2)_0, K3 = (M Z)^2 c1 + M Z c2 + c3
+        constexpr P3Tab T = p3_tab();
+        u64 pk[ZP_POSEIDON_PK_BLOCKS * ZP_POSEIDON_PK_WORDS];
+        auto mzv = [&](const u64 *x, u64 *y) {
+            for (int i = 0; i < 12; i++) {
+                u64 acc = 0;
+                for (int j = 1; j < 12; j++) acc = gl_add(acc, gl_mul((u64)T.mz[i][j], x[j]));
+                y[i] = acc;
+            }
+        };
+        for (int b = 0; b < ZP_POSEIDON_PK_BLOCKS; b++) {
+            const int r = 4 + 3 * b;
+            const u64 *c1 = ctx->h_rc + (r + 1) * 12, *c2 = ctx->h_rc + (r + 2) * 12, *c3 = ctx->h_rc + (r + 3) * 12;
+            u64 t1[12], t2[12], t3[12];
+            mzv(c1, t1);                 // M Z c1
+            mzv(t1, t2);                 // (M Z)^2 c1
+            mzv(c2, t3);                 // M Z c2
+            u64 *o = pk + b * ZP_POSEIDON_PK_WORDS;
+            o[0] = gl_canon(c1[0]);
+            o[1] = gl_add(t1[0], gl_canon(c2[0]));
+            for (int i = 0; i < 12; i++) o[2 + i] = gl_add(gl_add(t2[i], t3[i]), gl_canon(c3[i]));
+        }
+        ZP_HIP(ctx, hipMemcpy(ctx->d_rc + 360, pk, sizeof(pk), hipMemcpyHostToDevice));
+    }
     ctx->poseidon_dirty = false;
     return ZP_OK;
 }
