@@ -474,6 +474,7 @@ int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value) {
     else if (!strcmp(key, "ntt_small_wave")) ctx->tune_ntt_small_wave = value;
     else if (!strcmp(key, "synth_rowwise")) ctx->tune_synth_rowwise = value;
     else if (!strcmp(key, "p254_scaled")) ctx->tune_p254_scaled = value;
+    else if (!strcmp(key, "p254_block")) ctx->tune_p254_block = value;
     else if (!strcmp(key, "fri_fold_lanes")) ctx->tune_fri_fold_lanes = value;
     else if (!strcmp(key, "copy_grid")) ctx->tune_copy_grid = value;
     else if (!strcmp(key, "copy_nt")) ctx->tune_copy_nt = value;

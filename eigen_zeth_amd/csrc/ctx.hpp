@@ -87,6 +87,7 @@ struct zp_ctx {
     int tune_ntt_small_wave = 0;  // transforms of <= 4096 points: their last six stages inside a wave (DPP / ds_swizzle / ds_bpermute lane exchanges) instead of LDS + a barrier per stage.  0: where it measured faster (<= 64 points), 1: always, 2: never (A/B: profiles/r5_dpp_ab.txt)
     int tune_fri_fold_lanes = 0;  // the FRI fold by 16 with a coset spread over the 16 lanes of a DPP row.  0: where it measured faster (<= 2^16 inputs), 1: always, 2: never (A/B: profiles/r5_dpp_ab.txt)
     int tune_synth_rowwise = 0;   // the synthetic witness's expansion: 1: one 8-byte store per lane and row (round 4), 2: rows staged through LDS and written as column runs, 0: the faster of the two by size (A/B: profiles/r5_synth_fill_ab.txt)
+    int tune_p254_block = 0;     // 2: the lane-per-permutation Poseidon-BN254 kernel walks the partial rounds one by one instead of in blocks of four (A/B)
     int tune_p254_scaled = 0;     // 2: the cooperative Poseidon-BN254 kernels walk the unscaled sparse partial rounds (five dependent products per round instead of three; A/B: profiles/r5_p254_scaled_ab.txt)
     int tune_merkle_top_wave = 0; // 1: the subtree kernel of the small tree levels exchanges a node's state by wave shuffles (no LDS, one barrier per level) instead of LDS + two barriers per round
     int tune_merkle_coop_log = 0; // 0 = 15: tree levels with <= 2^15 nodes go to the 12-lanes-per-node subtree kernel

@@ -128,9 +128,23 @@ __host__ __device__ constexpr P3Tab p3_tab() {
     }
     return t;
 }
-__device__ __forceinline__ u64 p3_reduce(u64 alo, u64 ahi) {      // alo + ahi 2^32, both < 2^58  ->  weak
-    const u64 mid = (alo >> 32) + ahi;
-    return gl_reduce96_weak(((u64)(u32)mid << 32) | (u32)alo, (u32)(mid >> 32), 0u);
+// alo + ahi 2^32, both < 2^58  ->  weak.  The tail of poseidon_mds_asm.inc's rows: T = alo + (ahi >> 32) EPS (no overflow: < 2^59), then
+// hi(T) + lo(ahi) with 2^64 == EPS folded back (carry c: lo -= 1, and hi += 1 unless that borrowed) -- four VALU instructions
+__device__ __forceinline__ u64 p3_reduce(u64 alo, u64 ahi) {
+    const u64 t = (u64)(u32)(ahi >> 32) * 0xFFFFFFFFu + alo;
+    const u32 tl = (u32)t, th = (u32)(t >> 32), b0 = (u32)ahi;
+    u32 r0, r1;
+    u64 c, d;
+    asm("v_add_co_u32 %1, %2, %5, %6\n\t"
+        "s_nop 0\n\t"
+        "v_subbrev_co_u32 %0, %3, 0, %4, %2\n\t"
+        "s_nop 0\n\t"
+        "s_andn2_b64 %2, %2, %3\n\t"
+        "v_addc_co_u32 %1, %3, %1, 0, %2"
+        : "=&v"(r0), "=&v"(r1), "=&s"(c), "=&s"(d)
+        : "v"(tl), "v"(th), "v"(b0)
+        : "scc");
+    return ((u64)r1 << 32) | r0;
 }
 // s: the state entering partial round r (its constants added); pk: the block's 14 constant words.  Leaves the state entering round r + 3.
 __device__ __forceinline__ void partial3_default(u64 *s, const u64 *__restrict__ pk) {

@@ -38,8 +38,11 @@ struct P254Table {    // device tables of one instance, Montgomery form, 9 x u32
     // the SCALED sparse form (round 5, cooperative kernels: perm_coop): per partial round A'_(j+1), V'_(j,1..t-1), W'_(j,1..t-1); tail: 1 / lambda_rp
     u32 *d_sps = nullptr;   // [rp][2t-1][9]
     u32 *d_spt = nullptr;   // [1][9]
+    // the partial rounds in BLOCKS (round 6, lane-per-permutation kernel: bulk_partial_block, NB rounds per block): per block the cross
+    // terms C_(J,i) = v^_(j0+J) . w_(j0+i) (i < J), then w_k of the block's rounds for k = 1 .. t-1
+    u32 *d_blk = nullptr;   // [rp / NB][NB (NB-1) / 2 + NB (t-1)][9]
 };
-struct P254Dev { const u32 *rc, *mds, *pre, *a, *sp, *rcb, *sps, *spt; int rp; };
+struct P254Dev { const u32 *rc, *mds, *pre, *a, *sp, *rcb, *sps, *spt; int rp; const u32 *blk; };
 // Installed tables: per DEVICE (a single-process multi-GPU host has a ctx per GPU), [0]: t = 3, [1]: t = 17; public constants, shared by
 // every ctx of the device.  A published table is never changed or freed: installing the same constants again is a no-op (the ranks of a
 // sharded proof all install before they prove), installing different ones publishes a new table and retires the old one, which a kernel
@@ -271,11 +274,14 @@ __device__ __forceinline__ void static_for(F &&f) {      // expanded at compile 
         static_for<I + 1, N>(f);
     }
 }
-__device__ __forceinline__ void lds_put(u32 *st, int e, int lane, const fr &x) {
+// the LDS-resident state is named by address-space-3 pointers: with generic ones the round functions below met a code generator
+// fault (an LDS -> flat cast with its null check, "V_CMP_NE_U32 0, $src_shared_base: operand has incorrect register class")
+typedef __attribute__((address_space(3))) u32 lu32;
+__device__ __forceinline__ void lds_put(lu32 *st, int e, int lane, const fr &x) {
 #pragma unroll
     for (int i = 0; i < 9; i++) st[(e * 9 + i) * 64 + lane] = x.l[i];
 }
-__device__ __forceinline__ fr lds_get(const u32 *st, int e, int lane) {
+__device__ __forceinline__ fr lds_get(const lu32 *st, int e, int lane) {
     fr x;
 #pragma unroll
     for (int i = 0; i < 9; i++) x.l[i] = st[(e * 9 + i) * 64 + lane];
@@ -284,7 +290,7 @@ __device__ __forceinline__ fr lds_get(const u32 *st, int e, int lane) {
 // sum_j row[j] * state[j] over the LDS-resident state, 6 + 6 + 5 terms; with HAS_FIRST `first` stands in for element 0 (the S-box
 // output of a partial round, not written back yet)
 template <bool HAS_FIRST>
-__device__ __forceinline__ fr dot17_lds(const u32 *st, int lane, const u32 *__restrict__ row, const fr &first) {
+__device__ __forceinline__ fr dot17_lds(const lu32 *st, int lane, const u32 *__restrict__ row, const fr &first) {
     fr acc;
 #pragma unroll 1
     for (int g = 0; g < 2; g++) {
@@ -300,45 +306,78 @@ __device__ __forceinline__ fr dot17_lds(const u32 *st, int lane, const u32 *__re
     for (int jj = 0; jj < 5; jj++) x[jj] = lds_get(st, 12 + jj, lane);
     return fr_add(acc, fr_dotc<5>(x, row + 12 * 9));
 }
-__device__ __forceinline__ void bulk_perm17(u32 *st, int lane, const P254Dev &d) {
-    const int rp = d.rp;
+// One full round on the LDS-resident state: ARK -> x^5 -> dense matrix (the sparse form moves constants / matrices around them)
+__device__ __forceinline__ void bulk_full_round(lu32 *st, int lane, const u32 *c, const u32 *m) {
     const fr zero = fr_zero();
 #pragma unroll 1
-    for (int r = 0; r < 8 + rp; r++) {
-        if (r < 4 || r >= 4 + rp) {         // full round: ARK -> x^5 -> dense matrix (the sparse form moves constants / matrices around them)
-            const u32 *c = r == 4 + rp ? d.rcb : d.rc + (size_t)r * 17 * 9;
-            const u32 *m = r == 3 ? d.pre : d.mds;
+    for (int e = 0; e < 17; e++) lds_put(st, e, lane, sbox5(fr_add(lds_get(st, e, lane), fr_load(c + e * 9))));
+    fr o[17];
 #pragma unroll 1
-            for (int e = 0; e < 17; e++) lds_put(st, e, lane, sbox5(fr_add(lds_get(st, e, lane), fr_load(c + e * 9))));
-            fr o[17];
-#pragma unroll 1
-            for (int e = 0; e < 17; e++) {
-                const fr v = dot17_lds<false>(st, lane, m + (size_t)e * 17 * 9, zero);
-                switch (e) {                // wave-uniform: static register names for the rolled loop's results
+    for (int e = 0; e < 17; e++) {
+        const fr v = dot17_lds<false>(st, lane, m + (size_t)e * 17 * 9, zero);
+        switch (e) {                // wave-uniform: static register names for the rolled loop's results
 #define P254_CASE(K) case K: o[K] = v; break;
-                    P254_CASE(0) P254_CASE(1) P254_CASE(2) P254_CASE(3) P254_CASE(4) P254_CASE(5) P254_CASE(6) P254_CASE(7) P254_CASE(8)
-                    P254_CASE(9) P254_CASE(10) P254_CASE(11) P254_CASE(12) P254_CASE(13) P254_CASE(14) P254_CASE(15)
-                    default: o[16] = v; break;
+            P254_CASE(0) P254_CASE(1) P254_CASE(2) P254_CASE(3) P254_CASE(4) P254_CASE(5) P254_CASE(6) P254_CASE(7) P254_CASE(8)
+            P254_CASE(9) P254_CASE(10) P254_CASE(11) P254_CASE(12) P254_CASE(13) P254_CASE(14) P254_CASE(15)
+            default: o[16] = v; break;
 #undef P254_CASE
-                }
-            }
-            static_for<0, 17>([&](auto E) { lds_put(st, decltype(E)::value, lane, o[decltype(E)::value]); });
-        } else {                            // partial round j: s_0 <- (s_0 + a_j)^5; s_0' = m00 s_0 + sum_k v^_k s_k; s_k' = w_k s_0 + s_k
-            const u32 *sp = d.sp + (size_t)(r - 4) * 33 * 9;
-            const fr sg = sbox5(fr_add(lds_get(st, 0, lane), fr_load(d.a + (size_t)(r - 4) * 9)));
-            const fr n0 = dot17_lds<true>(st, lane, sp, sg);
-#pragma unroll 1
-            for (int k = 1; k < 17; k++) lds_put(st, k, lane, fr_add(fr_dotc<1>(&sg, sp + (16 + k) * 9), lds_get(st, k, lane)));
-            lds_put(st, 0, lane, n0);
         }
     }
+    static_for<0, 17>([&](auto E) { lds_put(st, decltype(E)::value, lane, o[decltype(E)::value]); });
+}
+// Partial rounds j0 .. j0 + NB - 1 in one block (round 6).  Round by round, every round updates the 16 other elements, s_k += w_k sg --
+// sixteen single products, each with its own Montgomery reduction and a canonical addition: two thirds of a partial round's instructions.
+// The updates are linear in the S-box outputs sg_i, so inside a block the elements stay at their block-start values S_k and round J reads
+//     s_0 <- m00 sg_J + sum_k v^_k S_k + sum_(i < J) C_(J,i) sg_i,          C_(J,i) = v^_(j0+J) . w_(j0+i)   (host, once per table)
+// and after the last round  S_k += sum_i w_k^(j0+i) sg_i : ONE NB-term dot product (one reduction) per element instead of NB single
+// products.  The same field values (every digest identical to the round-by-round form).  NB = 4: the S-box outputs of a block stay in
+// 36 registers (with five or six of them live across both loops the register allocator spilled to scratch: slower than round by round;
+// three: 34.0 M permutations/s, four: 34.5 M, round by round: 29.3 M -- profiles/r6_p254_block_ab.txt).
+#define P254_NB 4
+#define P254_BLK_ENTRIES (P254_NB * (P254_NB - 1) / 2 + P254_NB * 16)
+__device__ __forceinline__ void bulk_partial_block(lu32 *st, int lane, const P254Dev &d, int b) {
+    const int j0 = P254_NB * b;
+    const u32 *blk = d.blk + (size_t)b * P254_BLK_ENTRIES * 9;
+    fr sg[P254_NB];
+    fr s0 = lds_get(st, 0, lane);
+    static_for<0, P254_NB>([&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        const u32 *sp = d.sp + (size_t)(j0 + J) * 33 * 9;
+        sg[J] = sbox5(fr_add(s0, fr_load(d.a + (size_t)(j0 + J) * 9)));
+        s0 = dot17_lds<true>(st, lane, sp, sg[J]);
+        if constexpr (J > 0) s0 = fr_add(s0, fr_dotc<J>(sg, blk + (size_t)(J * (J - 1) / 2) * 9));
+    });
+#pragma unroll 1
+    for (int k = 1; k < 17; k++)
+        lds_put(st, k, lane, fr_add(fr_dotc<P254_NB>(sg, blk + (size_t)(P254_NB * (P254_NB - 1) / 2 + (k - 1) * P254_NB) * 9), lds_get(st, k, lane)));
+    lds_put(st, 0, lane, s0);
+}
+__device__ __forceinline__ void bulk_perm17(lu32 *st, int lane, const P254Dev &d) {
+    const int rp = d.rp;
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) bulk_full_round(st, lane, d.rc + (size_t)r * 17 * 9, r == 3 ? d.pre : d.mds);
+    const int nblk = d.blk ? rp / P254_NB : 0;
+#pragma unroll 1
+    for (int b = 0; b < nblk; b++) bulk_partial_block(st, lane, d, b);
+#pragma unroll 1
+    for (int j = P254_NB * nblk; j < rp; j++) {  // partial round j: s_0 <- (s_0 + a_j)^5; s_0' = m00 s_0 + sum_k v^_k s_k; s_k' = w_k s_0 + s_k
+        const u32 *sp = d.sp + (size_t)j * 33 * 9;
+        const fr sg = sbox5(fr_add(lds_get(st, 0, lane), fr_load(d.a + (size_t)j * 9)));
+        const fr n0 = dot17_lds<true>(st, lane, sp, sg);
+#pragma unroll 1
+        for (int k = 1; k < 17; k++) lds_put(st, k, lane, fr_add(fr_dotc<1>(&sg, sp + (16 + k) * 9), lds_get(st, k, lane)));
+        lds_put(st, 0, lane, n0);
+    }
+#pragma unroll 1
+    for (int r = 4 + rp; r < 8 + rp; r++) bulk_full_round(st, lane, r == 4 + rp ? d.rcb : d.rc + (size_t)r * 17 * 9, d.mds);
 }
 
 // mode 0: states u64[count][17][4] permuted in place;  mode 1: leaves of the 16-ary tree (lane = row, column reads are coalesced
 // 512-byte runs);  mode 2: one tree level (16 children per node)
 template <int MODE>
 __global__ void __launch_bounds__(64) p254_bulk_kernel(const u64 *__restrict__ in, size_t n_in, int W, u64 *__restrict__ out, size_t count, P254Dev d) {
-    __shared__ u32 st[P254_BULK_LDS];
+    __shared__ u32 st_mem[P254_BULK_LDS];
+    lu32 *const st = (lu32 *)st_mem;
     const int lane = threadIdx.x;
     const size_t i = (size_t)blockIdx.x * 64 + lane;
     const bool on = i < count;
@@ -632,7 +671,8 @@ int bulk_threshold(zp_ctx *ctx) {
 }
 P254Dev dev_of(const zp_ctx *ctx, const P254Table *tb) {       // (zp_set_tuning "p254_scaled" = 2: the cooperative kernels on the unscaled sparse form, for the A/B)
     const bool scaled = ctx->tune_p254_scaled != 2 && tb->d_sps && tb->d_spt;
-    return P254Dev{tb->d_rc, tb->d_mds, tb->d_pre, tb->d_a, tb->d_sp, tb->d_rcb, scaled ? tb->d_sps : nullptr, scaled ? tb->d_spt : nullptr, tb->rp};
+    return P254Dev{tb->d_rc, tb->d_mds, tb->d_pre, tb->d_a, tb->d_sp, tb->d_rcb, scaled ? tb->d_sps : nullptr, scaled ? tb->d_spt : nullptr, tb->rp,
+                   ctx->tune_p254_block == 2 ? nullptr : tb->d_blk};      // (zp_set_tuning "p254_block" = 2: round by round, for the A/B)
 }
 
 // ---- host: the sparse form of the partial rounds (column-vector convention, values in Montgomery form) ----
@@ -802,6 +842,22 @@ int32_t zp_set_poseidon_bn254(zp_ctx *ctx, int32_t t, int32_t rp, const uint64_t
         ZP_TRY(upload_fr(ctx, a, &tb->d_a));
         ZP_TRY(upload_fr(ctx, sp, &tb->d_sp));
         ZP_TRY(upload_fr(ctx, rcb, &tb->d_rcb));
+        if (rp >= P254_NB) {                        // the blocks of partial rounds (bulk_partial_block)
+            FrVec blk((size_t)(rp / P254_NB) * P254_BLK_ENTRIES, fr_zero());
+            for (int b = 0; b < rp / P254_NB; b++) {
+                fr *o = blk.data() + (size_t)b * P254_BLK_ENTRIES;
+                for (int J = 1; J < P254_NB; J++)
+                    for (int i = 0; i < J; i++) {
+                        const fr *v = sp.data() + (size_t)(P254_NB * b + J) * 33 + 1, *w = sp.data() + (size_t)(P254_NB * b + i) * 33 + 17;
+                        fr acc = fr_zero();
+                        for (int k = 0; k < 16; k++) acc = fr_add(acc, fr_mul(v[k], w[k]));
+                        o[J * (J - 1) / 2 + i] = acc;
+                    }
+                for (int k = 0; k < 16; k++)
+                    for (int i = 0; i < P254_NB; i++) o[P254_NB * (P254_NB - 1) / 2 + k * P254_NB + i] = sp[(size_t)(P254_NB * b + i) * 33 + 17 + k];
+            }
+            ZP_TRY(upload_fr(ctx, blk, &tb->d_blk));
+        }
         FrVec sps, spt;
         if (scaled_sparse_form(a, sp, t, rp, sps, spt)) {        // (a zero m00 somewhere: the cooperative kernels keep the unscaled form)
             ZP_TRY(upload_fr(ctx, sps, &tb->d_sps));
