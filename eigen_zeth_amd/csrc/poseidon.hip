@@ -75,6 +75,17 @@ __device__ __forceinline__ void mds_ark(u64 *s, const u32 *__restrict__ mds, con
     for (int i = 0; i < 12; i++) s[i] = o[i];
 }
 
+// rows 0..3 of the default matrix product, no constants (the last round of a permutation whose caller reads a digest only)
+__device__ __forceinline__ void mds_last4_default(u64 *s) {
+    u32 lo[12], hi[12], o0[4], o1[4];
+#pragma unroll
+    for (int j = 0; j < 12; j++) { lo[j] = (u32)s[j]; hi[j] = (u32)(s[j] >> 32); }
+    mds_rows_0_1(lo, hi, 0ULL, 0ULL, 0ULL, 0ULL, o0[0], o1[0], o0[1], o1[1]);
+    mds_rows_2_3(lo, hi, 0ULL, 0ULL, 0ULL, 0ULL, o0[2], o1[2], o0[3], o1[3]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) s[j] = ((u64)o1[j] << 32) | o0[j];
+}
+
 // ---- partial rounds THREE AT A TIME (default matrix; round 6).  A partial round is linear except for ONE S-box, so three of them are
 // three S-boxes and ONE matrix product instead of three.  With t = the state after the first S-box (y0 in element 0), Z = "clear
 // element 0", c1, c2, c3 the constants added after rounds r, r+1, r+2:
@@ -182,7 +193,9 @@ __device__ __forceinline__ void partial3_default(u64 *s, const u64 *__restrict__
 
 // textbook schedule ARK -> S-box -> MDS, with each round's ARK folded into the previous round's
 // MDS accumulators; state is weak between rounds and canonicalised once at the end.
-template <bool DEFMDS>
+// OUT4: the caller reads s[0..4) alone (a digest: Merkle leaves and nodes, the grinding hash) -- four rows of the last matrix product
+// instead of twelve; s[4..12) are left stale
+template <bool DEFMDS, bool OUT4 = false>
 __device__ __forceinline__ void poseidon_perm(u64 *s, const u64 *__restrict__ rc, const u32 *__restrict__ mds) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_add_weak(s[i], rc[i]);
@@ -205,9 +218,15 @@ __device__ __forceinline__ void poseidon_perm(u64 *s, const u64 *__restrict__ rc
         }
 #pragma unroll
         for (int i = 0; i < 12; i += 2) sbox7x2(s[i], s[i + 1]);
-        mds_ark<false, true>(s, mds, rc);
+        if constexpr (OUT4) {
+            mds_last4_default(s);
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+            for (int i = 0; i < 4; i++) s[i] = gl_canon(s[i]);
+        } else {
+            mds_ark<false, true>(s, mds, rc);
+#pragma unroll
+            for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+        }
         return;
     }
 #pragma unroll 1
@@ -449,7 +468,7 @@ __global__ void __launch_bounds__(256) pow_grind_kernel(const u64 *__restrict__ 
     s[4] = nonce;
 #pragma unroll
     for (int j = 5; j < 12; j++) s[j] = 0;
-    poseidon_perm<DEFMDS>(s, rc, mds);
+    poseidon_perm<DEFMDS, true>(s, rc, mds);
     if ((s[0] >> (64 - bits)) == 0) atomicMin((unsigned long long *)best, (unsigned long long)nonce);
 }
 
@@ -518,7 +537,7 @@ __global__ void __launch_bounds__(256) merkle_leaves_kernel(const u64 *__restric
     for (int off = 0; off < W; off += 8) {
 #pragma unroll
         for (int j = 0; j < 8; j++) s[j] = (off + j < W) ? cols[(size_t)(off + j) * M + i] : 0ULL;
-        poseidon_perm<DEFMDS>(s, rc, mds);
+        poseidon_perm<DEFMDS, true>(s, rc, mds);
 #pragma unroll
         for (int j = 0; j < 4; j++) s[8 + j] = s[j];
     }
@@ -595,7 +614,7 @@ __global__ void __launch_bounds__(256) merkle_leaves_rows_kernel(const u64 *__re
     for (size_t off = 0; off < len; off += 8) {
 #pragma unroll
         for (int j = 0; j < 8; j++) s[j] = (off + j < len) ? row[off + j] : 0ULL;
-        poseidon_perm<DEFMDS>(s, rc, mds);
+        poseidon_perm<DEFMDS, true>(s, rc, mds);
 #pragma unroll
         for (int j = 0; j < 4; j++) s[8 + j] = s[j];
     }
@@ -616,7 +635,7 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const u64 *__restrict
     for (int j = 0; j < 8; j++) s[j] = prev[i * 8 + j];
 #pragma unroll
     for (int j = 8; j < 12; j++) s[j] = 0;
-    poseidon_perm<DEFMDS>(s, rc, mds);
+    poseidon_perm<DEFMDS, true>(s, rc, mds);
 #pragma unroll
     for (int j = 0; j < 4; j++) next[i * 4 + j] = s[j];
 }

@@ -307,10 +307,17 @@ __device__ __forceinline__ fr dot17_lds(const lu32 *st, int lane, const u32 *__r
     return fr_add(acc, fr_dotc<5>(x, row + 12 * 9));
 }
 // One full round on the LDS-resident state: ARK -> x^5 -> dense matrix (the sparse form moves constants / matrices around them)
+// ONLY0: the caller reads element 0 alone afterwards (the LAST round of a sponge block or a tree node: the digest / next capacity) --
+// one row of the dense matrix instead of seventeen; elements 1..16 are left stale
+template <bool ONLY0 = false>
 __device__ __forceinline__ void bulk_full_round(lu32 *st, int lane, const u32 *c, const u32 *m) {
     const fr zero = fr_zero();
 #pragma unroll 1
     for (int e = 0; e < 17; e++) lds_put(st, e, lane, sbox5(fr_add(lds_get(st, e, lane), fr_load(c + e * 9))));
+    if constexpr (ONLY0) {
+        lds_put(st, 0, lane, dot17_lds<false>(st, lane, m, zero));
+        return;
+    }
     fr o[17];
 #pragma unroll 1
     for (int e = 0; e < 17; e++) {
@@ -352,6 +359,7 @@ __device__ __forceinline__ void bulk_partial_block(lu32 *st, int lane, const P25
         lds_put(st, k, lane, fr_add(fr_dotc<P254_NB>(sg, blk + (size_t)(P254_NB * (P254_NB - 1) / 2 + (k - 1) * P254_NB) * 9), lds_get(st, k, lane)));
     lds_put(st, 0, lane, s0);
 }
+template <bool ONLY0 = false>
 __device__ __forceinline__ void bulk_perm17(lu32 *st, int lane, const P254Dev &d) {
     const int rp = d.rp;
 #pragma unroll 1
@@ -369,7 +377,8 @@ __device__ __forceinline__ void bulk_perm17(lu32 *st, int lane, const P254Dev &d
         lds_put(st, 0, lane, n0);
     }
 #pragma unroll 1
-    for (int r = 4 + rp; r < 8 + rp; r++) bulk_full_round(st, lane, r == 4 + rp ? d.rcb : d.rc + (size_t)r * 17 * 9, d.mds);
+    for (int r = 4 + rp; r < 7 + rp; r++) bulk_full_round(st, lane, r == 4 + rp ? d.rcb : d.rc + (size_t)r * 17 * 9, d.mds);
+    bulk_full_round<ONLY0>(st, lane, d.rc + (size_t)(7 + rp) * 17 * 9, d.mds);
 }
 
 // mode 0: states u64[count][17][4] permuted in place;  mode 1: leaves of the 16-ary tree (lane = row, column reads are coalesced
@@ -411,7 +420,7 @@ __global__ void __launch_bounds__(64) p254_bulk_kernel(const u64 *__restrict__ i
                     leaf_block_element(in, (size_t)n_in, ii, W, base, e - 1, w);
                     lds_put(st, e, lane, fr_to_mont(fr_from_u64(w)));
                 }
-                bulk_perm17(st, lane, d);   // the digest (element 0) stays as the capacity of the next block
+                bulk_perm17<true>(st, lane, d);   // the digest (element 0) stays as the capacity of the next block: the only element read
             }
         } else {                            // in = previous level u64[n_in][4]
 #pragma unroll 1
@@ -424,7 +433,7 @@ __global__ void __launch_bounds__(64) p254_bulk_kernel(const u64 *__restrict__ i
                 }
                 lds_put(st, e, lane, fr_to_mont(fr_from_u64(w)));
             }
-            bulk_perm17(st, lane, d);
+            bulk_perm17<true>(st, lane, d);
         }
         u64 w[4];
         fr_to_u64(fr_from_mont(lds_get(st, 0, lane)), w);
