@@ -255,7 +255,9 @@ def main():
     ap.add_argument("--cols", type=int, default=64, help="columns per GPU (--scaling weak) or in total (--scaling strong)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="weak: --cols columns per GPU; strong: --cols columns in total, cols / N per GPU (BASELINE configs[3]: 64 columns, 8 per GPU). "
-                         "Default: weak on one GPU, STRONG with --gpus > 1 -- the driver passes no flags, and configs[3] is one 2^24 x 64 trace sharded over the GPUs")
+                         "Default: WEAK at every N -- the columns of a trace are independent units with no data-path collective, every GPU keeps the 2^24 x 64 "
+                         "workload the N = 1 line is quoted on (round 6; rounds 4-5 defaulted to strong with --gpus > 1: 8 columns = 1.4 ms per step and GPU "
+                         "at N = 8, where launch and barrier overheads, not the kernel, set the figure)")
     ap.add_argument("--stark-logn", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
@@ -268,7 +270,7 @@ def main():
     ap.add_argument("--child-probe", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.scaling is None:
-        args.scaling = "strong" if args.gpus > 1 else "weak"
+        args.scaling = "weak"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.child_probe:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if not args.child_probe:

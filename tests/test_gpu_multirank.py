@@ -68,8 +68,8 @@ def test_bench_n2_plain_launch_on_one_gpu():
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), "stdout of a plain launch is rank 0's single JSON line: %r" % r.stdout[-600:]
     line = json.loads(lines[0])
-    # no --scaling flag, as the driver runs it: with N > 1 that means STRONG since round 5 (BASELINE configs[3] is ONE trace sharded over the GPUs)
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["config"]["cols_per_gpu"] == 8 and line["config"]["cols_total"] == 16
+    # no --scaling flag, as the driver runs it: WEAK at every N since round 6 (independent columns, no data-path collective: every rank keeps --cols columns)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["config"]["cols_per_gpu"] == 16 and line["config"]["cols_total"] == 32
     assert line["rccl"]["ranks_seen_allreduce"] == 2 and line["rccl"]["world_env"] == 2 and line["rccl"]["self_launched"] and line["rccl"]["backend"] == "gloo"
     assert line["rccl"]["device_of_rank"] == [0, 0] or native_device_count() >= 2
     assert line["degraded"] is False and line["exchange_stalled"] is False
