@@ -5,7 +5,7 @@
 // prover.  Pippenger bucket method, window c bits:
 //   1. digits     : counting sort of the point indices by window digit (histogram -> scan -> scatter)
 //   2. bucket sums: one lane per (window, bucket) adds its points (Jacobian += affine, 7M+4S)
-//   3. reduction  : running sums over segments of 64 buckets, segment weights by double-and-add,
+//   3. reduction  : running sums over segments of MSM_SEG buckets, segment weights by double-and-add,
 //                   tree sum per window in LDS
 //   4. the <= 32 window results are combined on the host (254 doublings).
 // Field: F_q in Montgomery form, 9 x 29-bit limbs, product scanning with v_mad_u64_u32 (see below).  VALU only;
@@ -979,7 +979,9 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(HeavyLists hl, u3
     if (threadIdx.x == 0) buckets[h.x] = sh[0];
 }
 // ---- 3a. per segment of SEG buckets: sum_{b in seg} (b + 1) * B_b   (bucket index b holds the points of digit magnitude b + 1)
-#define MSM_SEG 64
+// (round 6: 16 instead of 64 -- the kernel is one dependent chain of additions per lane with fewer lanes than the chip has SIMD slots:
+// four times the lanes at a third of the chain, 2.2 -> 0.6 ms per 2^24-point run)
+#define MSM_SEG 16
 template <class F>
 __global__ void __launch_bounds__(64) msm_segment_kernel(const jacT<F> *buckets, int c, int nwin, jacT<F> *segs) {
     const u64 id = (u64)blockIdx.x * 64 + threadIdx.x;
@@ -999,14 +1001,14 @@ __global__ void __launch_bounds__(64) msm_segment_kernel(const jacT<F> *buckets,
 }
 // ---- 3b. tree sum of the segment results of one window (one block per window)
 template <class F>
-__global__ void __launch_bounds__(128) msm_window_kernel(const jacT<F> *segs, int nseg, jacT<F> *wins) {
-    __shared__ jacT<F> sh[128];
+__global__ void __launch_bounds__(256) msm_window_kernel(const jacT<F> *segs, int nseg, jacT<F> *wins) {
+    __shared__ jacT<F> sh[256];
     const jacT<F> *S = segs + (u64)blockIdx.x * nseg;
     jacT<F> acc = jac_inf<F>();
-    for (int k = threadIdx.x; k < nseg; k += 128) acc = jac_add(acc, S[k]);
+    for (int k = threadIdx.x; k < nseg; k += 256) acc = jac_add(acc, S[k]);
     sh[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = 64; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) sh[threadIdx.x] = jac_add(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
@@ -1056,7 +1058,7 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
     while (c < 16 && (1ULL << (c + 2)) <= n) c++;   // ~4 points per bucket up to c = 16
     while (c < 20 && (1ULL << (c + 8)) <= n) c++;   // wider windows only while buckets keep >= 128 points (signed digits: profiles/r2_msm_c_sweep.txt)
     if (ctx->tune_msm_c > 0) c = ctx->tune_msm_c;    // experiment knob
-    if (c < 6) c = 6;                                // segments of 64 buckets need c >= 6
+    if (c < 6) c = 6;                                // segments of MSM_SEG buckets (and the sort geometry) need c >= 6
     if (c > 22) c = 22;
     // c = bucket-index bits of a window; digits are signed and one bit wider (cd = c + 1).  s + K must stay below 2^(cd nwin)
     // for any 256-bit scalar (the BN254 group order has 254 bits): cd * nwin >= 258
@@ -1158,7 +1160,7 @@ int32_t msm_chunk(zp_ctx *ctx, const uint32_t *d_points, const uint32_t *d_scala
         }
     }
     hipLaunchKernelGGL(msm_segment_kernel<F>, dim3((unsigned)((nwin * nseg + 63) / 64)), dim3(64), 0, ctx->stream, d_buckets, c, nwin, d_segs);
-    hipLaunchKernelGGL(msm_window_kernel<F>, dim3(nwin), dim3(128), 0, ctx->stream, d_segs, (int)nseg, d_wins);
+    hipLaunchKernelGGL(msm_window_kernel<F>, dim3(nwin), dim3(256), 0, ctx->stream, d_segs, (int)nseg, d_wins);
     hipError_t le = hipGetLastError();
     std::vector<J> wins(nwin);
     hipError_t ce = hipMemcpyAsync(wins.data(), d_wins, nwin * sizeof(J), hipMemcpyDeviceToHost, ctx->stream);

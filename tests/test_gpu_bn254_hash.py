@@ -140,3 +140,25 @@ def test_merkle16_bulk_kernels_match_cooperative_and_oracle(p254, M, W):
     assert (bulk == coop).all()
     if M <= (1 << 14) + 64:
         assert (bulk == O.merkle16_tree(cols)).all()
+
+
+def test_partial_rounds_in_blocks_equal_round_by_round(p254):
+    """round 6: the lane-per-permutation kernel walks the partial rounds in blocks of four (cross terms made on the host when the tables are
+    installed; the last round of a leaf block / tree node computes element 0 only).  Knob p254_block = 2 walks them one by one, as rounds 3-5
+    did: whole permutations (17 outputs, generic entry point) and a tree with two sponge blocks per leaf must come out word for word the
+    same -- and both already equal the cooperative kernels and the CPU checker (the two tests above run on the blocked form)"""
+    count = (1 << 14) + 5
+    g = np.random.default_rng(2540)
+    st = g.integers(0, 1 << 62, size=(count, 17, 4), dtype=np.uint64)
+    st[:, :, 3] >>= 2
+    cols = O.random_field((60, (1 << 14) + 64), 7777)
+    res = {}
+    try:
+        for knob in (0, 2):
+            p254.set_tuning("p254_block", knob)
+            d = p254.upload(st.reshape(-1))
+            p254._chk(p254.lib.zp_poseidon_bn254_perm(p254.ctx, d.ptr, count, 17))
+            res[knob] = (p254.download(d, st.shape), _commit16(p254, cols))
+    finally:
+        p254.set_tuning("p254_block", 0)
+    assert (res[0][0] == res[2][0]).all() and (res[0][1] == res[2][1]).all()

@@ -242,6 +242,34 @@ def test_poseidon_custom_tables(prover, tables):
         prover.set_constants(native.ZP_CONST_POSEIDON_MDS, mds)
 
 
+def test_blocked_partial_rounds_with_injected_round_constants(prover, tables):
+    """round 6: on the default matrix the partial rounds run three at a time with block constants the LIBRARY derives from whatever round
+    constants are installed (zpi_poseidon_sync_tables).  Random round constants (no standard table) over the default matrix: the throughput
+    kernels -- whole permutations (12 outputs), leaves and nodes (digest-only last round) -- against the oracle's textbook schedule; extreme
+    states included; and back on the installed table afterwards"""
+    from eigen_zeth_amd import native
+    rc, mds = tables
+    rc2 = O.random_field((360,), 4242)
+    rc2[5 * 12:5 * 12 + 3] = u([0, P - 1, 1])
+    st = O.random_field((4096, 12), 79)
+    st[0] = 0
+    st[1] = P - 1
+    st[2, :] = u([P - 1, 0, 1, P - 2] * 3)
+    cols = O.random_field((19, 1 << 17), 80)          # 19 columns: three sponge blocks per leaf, the last one ragged; 2^17 leaves: lane-per-leaf and lane-per-node kernels, then the cooperative top
+    try:
+        prover.set_constants(native.ZP_CONST_POSEIDON_RC, rc2)
+        d = prover.upload(st)
+        prover.poseidon_perm(d, st.shape[0])
+        assert (prover.download(d, st.shape) == O.poseidon_perm(st, rc2, mds)).all()
+        tree = prover.merkle_commit_host(cols)
+        assert (tree == O.merkle_commit(cols, rc2, mds)).all()
+    finally:
+        prover.set_constants(native.ZP_CONST_POSEIDON_RC, rc)
+    d = prover.upload(st)
+    prover.poseidon_perm(d, st.shape[0])
+    assert (prover.download(d, st.shape) == O.poseidon_perm(st, rc, mds)).all()
+
+
 def test_golden_merkle_through_cabi(prover, golden):
     for case in golden["merkle"]:
         cols = np.ascontiguousarray(u(case["rows"]).T)

@@ -137,3 +137,36 @@ def test_generated_mds_rows_are_the_committed_ones(tmp_path):
     m = PC.default_mds()
     assert [m[j] for j in range(12)] == [circ[j] + (8 if j == 0 else 0) for j in range(12)]
     assert all(m[i * 12 + j] == circ[(j - i) % 12] + (8 if i == j == 0 else 0) for i in range(12) for j in range(12))
+
+
+def test_partial_rounds_three_at_a_time_equal_the_textbook_schedule():
+    """the algebra csrc/poseidon.hip's partial3_default relies on (round 6), in big integers: with t = the state after the first S-box of a
+    block, Z = clear element 0, c1..c3 the constants after rounds r..r+2 --  x1 = (M t)_0 + c1_0;  x2 = (M Z M t)_0 + M_00 y1 + (M Z c1 + c2)_0;
+    next state = (M Z)^2 M t + (M Z M e0) y1 + (M e0) y2 + (M Z)^2 c1 + M Z c2 + c3 -- equals three textbook rounds; and every integer
+    matrix entry stays below 2^21, so that the kernel's 64-bit sums over 32-bit halves (14 terms per row) cannot overflow"""
+    import random
+    p = PC.GL_P
+    rc = [int(v) for v in PC.default_round_constants()]
+    m = [int(v) for v in PC.default_mds()]
+    M = [m[i * 12:(i + 1) * 12] for i in range(12)]
+    MZ = [[0 if j == 0 else M[i][j] for j in range(12)] for i in range(12)]
+    mm = lambda A, B: [[sum(A[i][k] * B[k][j] for k in range(12)) for j in range(12)] for i in range(12)]
+    mv = lambda A, v: [sum(A[i][j] * v[j] for j in range(12)) % p for i in range(12)]
+    A2 = mm(MZ, M)
+    A3 = mm(MZ, A2)
+    assert max(max(r) for r in A3) < 1 << 21 and max(max(r) for r in A2) < 1 << 14
+    assert all(sum(A3[i]) + A2[i][0] + M[i][0] < 1 << 25 for i in range(12))        # row sums: (2^25 * 2^32) per half sum, far below 2^64
+    rnd = random.Random(6)
+    for r in range(4, 25, 3):
+        c1, c2, c3 = (rc[(r + k) * 12:(r + k + 1) * 12] for k in (1, 2, 3))
+        s = [rnd.randrange(p) for _ in range(12)]
+        want = list(s)
+        for k in range(3):                            # textbook: S-box on element 0, matrix, constants of the next round
+            want[0] = pow(want[0], 7, p)
+            want = [(a + b) % p for a, b in zip(mv(M, want), rc[(r + k + 1) * 12:(r + k + 2) * 12])]
+        t = [pow(s[0], 7, p)] + s[1:]
+        y1 = pow((mv(M, t)[0] + c1[0]) % p, 7, p)
+        y2 = pow((mv(A2, t)[0] + M[0][0] * y1 + mv(MZ, c1)[0] + c2[0]) % p, 7, p)
+        k3 = [(a + b + c) % p for a, b, c in zip(mv(MZ, mv(MZ, c1)), mv(MZ, c2), c3)]
+        got = [(mv(A3, t)[i] + A2[i][0] * y1 + M[i][0] * y2 + k3[i]) % p for i in range(12)]
+        assert got == want
