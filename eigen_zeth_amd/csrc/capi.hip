@@ -459,6 +459,7 @@ int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value) {
     if (!strcmp(key, "ntt_logt")) ctx->tune_logt = value;
     else if (!strcmp(key, "ntt_tpw")) ctx->tune_tpw = value;
     else if (!strcmp(key, "ntt_logt9")) ctx->tune_logt9 = value;
+    else if (!strcmp(key, "ntt_logt12")) ctx->tune_logt12 = value;
     else if (!strcmp(key, "msm_chunk_log")) ctx->tune_msm_chunk_log = value;
     else if (!strcmp(key, "msm_c")) ctx->tune_msm_c = value;
     else if (!strcmp(key, "ntt_chunk_log")) ctx->tune_ntt_chunk_log = value;

@@ -73,6 +73,7 @@ struct zp_ctx {
     // experiment knobs (zp_set_tuning): not part of the stable surface
     void *msm_arena = nullptr;    // scratch of zp_msm_bn254*: grows to the largest run, freed by zp_destroy
     size_t msm_arena_bytes = 0;
+    int tune_logt12 = 2;          // radix-4096 passes: 2 = tiles of 4 columns (128 KiB, one 1024-thread workgroup per CU), 1 = tiles of 2 columns (64 KiB, two 512-thread workgroups per CU; A/B: profiles/r6_ntt_two_pass_2wg_ab.txt)
     int tune_logt = 4, tune_tpw = 2, tune_logt9 = 4;   // (radix-512 passes: 16-wide tiles of 64 KiB, two workgroups per CU -- 5 to 19 % faster than the 32-wide 128-KiB tile at 2^17 .. 2^27, profiles/r4_logt9_sweep.txt)
     // tiles per workgroup: 2 measured best with the gl_asm.hpp arithmetic (profiles/r2_ntt_sweep.txt)
     int tune_ntt_tw1 = 26;        // largest log size whose first pass multiplies by a full precomputed table (0: always the per-lane chain)

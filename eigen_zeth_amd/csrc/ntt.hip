@@ -899,7 +899,10 @@ int32_t dispatch_pass(zp_ctx *ctx, const NttPass &p, const PassArgs &a, bool tra
         // 1024-thread workgroups, 128 KiB tiles: two-pass plans up to 2^20 / 2^22 / 2^24 (runs of 128 / 64 / 32 bytes)
         case 10: return launch_pass2<4, 3, 3, 4>(ctx, a, transpose, W);
         case 11: return launch_pass2<4, 4, 3, 3>(ctx, a, transpose, W);
-        case 12: return launch_pass2<4, 4, 4, 2>(ctx, a, transpose, W);
+        // (round 6, review item 4: knob ntt_logt12 = 1 -- 512-thread workgroups on 64-KiB tiles of 2 columns, TWO workgroups per CU, 16-byte runs;
+        //  a pass with a per-tile twiddle table needs 32 KiB more and stays on the 4-column tile)
+        case 12: return (ctx->tune_logt12 == 1 && (transpose || (a.flags & 7) == 0)) ? launch_pass2<4, 4, 4, 1>(ctx, a, transpose, W)
+                                                                                     : launch_pass2<4, 4, 4, 2>(ctx, a, transpose, W);
         default: ctx->err = "unsupported pass radix"; return ZP_ERR_UNSUPPORTED;
     }
 }
