@@ -116,6 +116,37 @@ GL_HD fr fr_mul(const fr &a, const fr &b) {
     t[8] = (u32)acc;
     return fr_norm_sub(t);
 }
+// a*a/R mod r: the 36 cross products once, doubled through the left operand (2 a_i < 2^30: a column takes at most
+// 4 doubled products + a square + 9 reduction terms, < 2^63) -- 45 limb products instead of 81
+GL_HD fr fr_sqr(const fr &a) {
+    u32 m[9], t[9], d[9];
+    u64 acc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.l[i] << 1;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) acc += (u64)d[i] * a.l[k - i];
+        if ((k & 1) == 0) acc += (u64)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (u64)m[i] * fr_p(k - i);
+        m[k] = ((u32)acc * FR_INV29) & FR_MASK;
+        acc += (u64)m[k] * fr_p(0);
+        acc >>= FR_B;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; i++) acc += (u64)d[i] * a.l[k - i];
+        if ((k & 1) == 0) acc += (u64)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (u64)m[i] * fr_p(k - i);
+        t[k - 9] = (u32)acc & FR_MASK;
+        acc >>= FR_B;
+    }
+    t[8] = (u32)acc;
+    return fr_norm_sub(t);
+}
 // (a0 b0 + a1 b1 + a2 b2) / R mod r with ONE Montgomery reduction: the three products share the column accumulators
 // (36 terms of < 2^58 per column stay below 2^64).  All limbs < 2^29; the sum is < 3 r^2 < R r, so the result is < 2 r.
 GL_HD fr fr_mul3(const fr &a0, const fr &b0, const fr &a1, const fr &b1, const fr &a2, const fr &b2) {

@@ -87,7 +87,7 @@ __device__ __forceinline__ fr fr_reduce_small(const u64 *acc) {
     return fr_norm_sub(t);                                 // value in [0, 2 r), limbs normalised
 }
 __device__ __forceinline__ fr sbox5(const fr &x) {
-    const fr x2 = fr_mul(x, x), x4 = fr_mul(x2, x2);
+    const fr x2 = fr_sqr(x), x4 = fr_sqr(x2);       // squarings: 45 limb products each instead of 81
     return fr_mul(x4, x);
 }
 
