@@ -580,7 +580,9 @@ int32_t zp_hbm_copy_probe(zp_ctx *ctx, const void *d_src, void *d_dst, size_t by
 /* experiment knobs for kernel tuning sweeps (keys: "ntt_logt" 4|5 tile of the radix-256 pass, "ntt_logt9" 4|5, "ntt_tpw" tiles per workgroup,
  * "ntt_chunk_log" log2 of the elements per NTT launch (27), "ntt_maxl" largest log2 radix of a pass (9; 10..12 select the 1024-thread two-pass plans), "merkle_coop_log" largest tree level given to the 12-lanes-per-node
  * kernel (15), "msm_chunk_log" log2 of the points per Pippenger run (24), "msm_c" window width, "ntt_small_wave" / "fri_fold_lanes" the in-wave (DPP / ds_swizzle) forms of the
- * small transform and of the fold by 16: 0 where they measured faster, 1 always, 2 never; 0 = default); not for production hosts */
+ * small transform and of the fold by 16: 0 where they measured faster, 1 always, 2 never; "ntt_logt12" 1: radix-4096 passes on 64-KiB tiles, two
+ * 512-thread workgroups per CU (2: 128-KiB tiles); "p254_block" 2: the lane-per-permutation Poseidon-BN254 kernel walks its partial rounds one by
+ * one instead of in blocks of four; 0 = default); not for production hosts */
 int32_t zp_set_tuning(zp_ctx *ctx, const char *key, int32_t value);
 
 /* ---- introspection ------------------------------------------------------------------------- */
