@@ -25,6 +25,16 @@ ANCHOR_PERM_ZERO = [0x3C18A9786CB0B359, 0xC4055E3364A246C3, 0x7953DB0AB48808F4, 
 # SURVEY.md; same standing as the anchors above: recalled, then reproduced): perm(0, 1, ..., 11)[0..4] and perm(p - 1, ..., p - 1)[0].
 ANCHOR_PERM_COUNTING = [0xD64E1E3EFC5B8E9E, 0x53666633020AAA47, 0xD40285597C6A8825, 0x613A4F81E81231D2]
 ANCHOR_PERM_MINUS_ONE_WORD0 = 0xBE0085CFC57A8357
+# Round 6, second half: the public family's three test vectors IN FULL (12 words each: inputs 0^12, 0..11, (p-1)^12), again written down
+# from memory and then compared (tests/test_poseidon_constants.py, tests/test_gpu_parity.py): 36 of 36 words
+ANCHOR_FULL = {
+    "zero": [0x3C18A9786CB0B359, 0xC4055E3364A246C3, 0x7953DB0AB48808F4, 0xC71603F33A1144CA, 0xD7709673896996DC, 0x46A84E87642F44ED,
+             0xD032648251EE0B3C, 0x1C687363B207DF62, 0xDF8565563E8045FE, 0x40F5B37FF4254DAE, 0xD070F637B431067C, 0x1792B1C4342109D7],
+    "counting": [0xD64E1E3EFC5B8E9E, 0x53666633020AAA47, 0xD40285597C6A8825, 0x613A4F81E81231D2, 0x414754BFEBD051F0, 0xCB1F8980294A023F,
+                 0x6EB2A9E4D54A9D0F, 0x1902BC3AF467E056, 0xF045D5EAFDC6021F, 0xE4150F77CAAA3BE5, 0xC9BFD01D39B50CCE, 0x5C0A27FCB0E1459B],
+    "minus_one": [0xBE0085CFC57A8357, 0xD95AF71847D05C09, 0xCF55A13D33C1C953, 0x95803A74F4530E82, 0xFCD99EB30A135DF1, 0xE095905E913A3029,
+                  0xDE0392461B42919B, 0x7D3260E24E81D031, 0x10D3D0465D9DEAA0, 0xA87571083DFC2A47, 0xE18263681E9958F8, 0xE28E96F1AE5E60D3],
+}
 
 
 def _rotl32(x, n):

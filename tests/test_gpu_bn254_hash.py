@@ -1,5 +1,6 @@
 """GPU tests of the BN128-hash mode (Poseidon over the BN254 scalar field, 16-ary Merkle tree) against the definition-level
-Python in oracle/naive.py, anchored on the published t = 3 vector."""
+Python in oracle/naive.py, anchored on the published t = 3 vector and (round 6) on the published 16-input vector of the width-17 instance --
+the width the final STARK's trees and the wrap circuit's gadget use."""
 import random
 
 import numpy as np
@@ -23,6 +24,32 @@ def p254(prover):
 def test_published_vector_on_the_gpu(p254):
     out = p254.poseidon_bn254_perm([[0, 1, 2]])
     assert out[0][0] == 0x115CC0F5E7D690413DF64C6B9662E9CF2A3617F2743245519E19607A4417189A
+
+
+PUBLISHED_T17_HASH_1_TO_16 = 9989051620750914585850546081941653841776809718687451684622678807385399211877
+
+
+def test_published_width17_vector_on_the_gpu(p254):
+    """the public JavaScript / circuit library of this hash family publishes poseidon([1, 2, ..., 16]) for its 16-input (t = 17, R_P = 68)
+    instance; written down from memory BEFORE it was computed here (tests/test_poseidon_constants.py has the CPU side).  Through the C-ABI: the
+    cooperative kernel (one state), the lane-per-permutation kernel with its partial rounds in blocks (2^14 + 3 copies of the state), and the
+    round-by-round form of that kernel (knob p254_block = 2) all return it in element 0"""
+    st = [0] + list(range(1, 17))
+    assert p254.poseidon_bn254_perm([st])[0][0] == PUBLISHED_T17_HASH_1_TO_16
+    count = (1 << 14) + 3
+    words = np.zeros((count, 17, 4), dtype=np.uint64)
+    words[:, :, 0] = np.arange(17, dtype=np.uint64)
+    try:
+        for knob in (0, 2):
+            p254.set_tuning("p254_block", knob)
+            d = p254.upload(words.reshape(-1))
+            p254._chk(p254.lib.zp_poseidon_bn254_perm(p254.ctx, d.ptr, count, 17))
+            got = p254.download(d, words.shape)
+            d.free()
+            assert (got == got[0]).all()
+            assert sum(int(got[0, 0, k]) << (64 * k) for k in range(4)) == PUBLISHED_T17_HASH_1_TO_16
+    finally:
+        p254.set_tuning("p254_block", 0)
 
 
 @pytest.mark.parametrize("t,count", [(3, 1), (3, 50), (17, 1), (17, 7)])

@@ -195,6 +195,16 @@ def test_compiled_in_table_hits_the_public_familys_anchor_on_the_gpu(prover, tab
         fresh.poseidon_perm(d, 2)
         got = fresh.download(d, (2, 12))
         assert [int(v) for v in got[0, :4]] == CT.ANCHOR_PERM_COUNTING and int(got[1, 0]) == CT.ANCHOR_PERM_MINUS_ONE_WORD0
+        # round 6, second half: the three public vectors in full, through the latency kernel (3 states) and the throughput kernel -- whose
+        # partial rounds run three at a time -- (the 3 states tiled 2048 times)
+        full = [CT.ANCHOR_FULL["zero"], CT.ANCHOR_FULL["counting"], CT.ANCHOR_FULL["minus_one"]]
+        three = u([[0] * 12, list(range(12)), [P - 1] * 12])
+        for reps in (1, 2048):
+            st3 = np.tile(three, (reps, 1))
+            d = fresh.upload(st3)
+            fresh.poseidon_perm(d, st3.shape[0])
+            got = fresh.download(d, st3.shape)
+            assert (got == np.tile(u(full), (reps, 1))).all()
         fresh.set_constants(native.ZP_CONST_POSEIDON_RC, u(PC.grain_goldilocks_round_constants()))
         d = fresh.upload(np.zeros((1, 12), dtype=np.uint64))
         fresh.poseidon_perm(d, 1)

@@ -117,6 +117,24 @@ def test_bn254_t3_instance_reproduces_the_published_hash_vector():
         assert O.p254_perm(sts, t) == [NV.poseidon_bn254_perm(st, rc_t, mds_t, rp_t) for st in sts]
 
 
+def test_bn254_t17_and_t5_instances_reproduce_published_vectors():
+    """round 6: two more vectors of the public hash family, written down from memory and THEN computed -- poseidon([1, 2, 3, 4]) of the t = 5
+    instance (R_P = 60) and poseidon([1, ..., 16]) of the t = 17 instance (R_P = 68), the width this repo's BN128 mode uses for every tree, sponge
+    and in-circuit gadget.  They pin, for that width, the Grain stream, the rejection sampling, the Cauchy matrix drawn from the continued
+    stream, the round numbers and the schedule -- in the big-integer definition and in the checker's C restatement"""
+    from oracle import naive as NV
+    from oracle import oracle as O
+    rc, mds, rp = PC.bn254_poseidon_params(5)
+    assert rp == 60
+    assert NV.poseidon_bn254_perm([0, 1, 2, 3, 4], rc, mds, rp)[0] == 0x299C867DB6C1FDD79DCEFA40E4510B9837E60EBB1CE0663DBAA525DF65250465
+    rc, mds, rp = PC.bn254_poseidon_params(17)
+    want = 9989051620750914585850546081941653841776809718687451684622678807385399211877
+    assert rp == 68
+    assert NV.poseidon_bn254_perm([0] + list(range(1, 17)), rc, mds, rp)[0] == want
+    O.p254_set(17, rp, rc, mds)
+    assert O.p254_perm([[0] + list(range(1, 17))], 17)[0][0] == want
+
+
 def test_bn254_t17_parameters_are_well_formed():
     rc, mds, rp = PC.bn254_poseidon_params(17)
     assert rp == 68 and len(rc) == 76 * 17 and len(mds) == 17 and all(len(r) == 17 for r in mds)
@@ -170,3 +188,41 @@ def test_partial_rounds_three_at_a_time_equal_the_textbook_schedule():
         k3 = [(a + b + c) % p for a, b, c in zip(mv(MZ, mv(MZ, c1)), mv(MZ, c2), c3)]
         got = [(mv(A3, t)[i] + A2[i][0] * y1 + M[i][0] * y2 + k3[i]) % p for i in range(12)]
         assert got == want
+
+
+def test_default_root_of_unity_reproduces_the_public_cpp_librarys_table_of_two_adic_roots():
+    """round 6: the public C++ Goldilocks library of the pil-stark prover family (the lineage of the external prover eigen-zeth calls) ships a
+    table W[0..32] of 2^k-th roots of unity.  Its 33 words, written down from memory and THEN compared: every one equals
+    w32^(2^(32 - k)) for this repo's DEFAULT 2^32-th root 1753635133440165772 = 7^((p - 1) / 2^32) -- which is also the public Rust
+    Goldilocks field's two-adic generator.  SURVEY.md section 8a lists the root as an unpinned choice between two candidates; the other
+    candidate (7277203076849721926) does not produce this table.  The coset shift 49 = 7^2 is the same family's."""
+    from eigen_zeth_amd import native
+    p = PC.GL_P
+    W = [1, 18446744069414584320, 281474976710656, 18446744069397807105, 17293822564807737345, 70368744161280, 549755813888,
+         17870292113338400769, 13797081185216407910, 1803076106186727246, 11353340290879379826, 455906449640507599,
+         17492915097719143606, 1532612707718625687, 16207902636198568418, 17776499369601055404, 6115771955107415310,
+         12380578893860276750, 9306717745644682924, 18146160046829613826, 3511170319078647661, 17654865857378133588,
+         5416168637041100469, 16905767614792059275, 9713644485405565297, 5456943929260765144, 17096174751763063430,
+         1213594585890690845, 6414415596519834757, 16116352524544190054, 9123114210336311365, 4614640910117430873,
+         1753635133440165772]
+    w32 = native.ROOT32_DEFAULT
+    assert w32 == W[32] == pow(7, (p - 1) >> 32, p)
+    assert all(pow(w32, 1 << (32 - k), p) == W[k] for k in range(33))
+    assert W[2] == 1 << 48 and W[1] == p - 1
+    alt = native.ROOT32_ALT
+    assert pow(alt, 1 << 32, p) == 1 and pow(alt, 1 << 31, p) == p - 1 and any(pow(alt, 1 << (32 - k), p) != W[k] for k in range(3, 33))
+
+
+def test_public_familys_three_test_vectors_in_full():
+    """all twelve output words of the public Goldilocks-Poseidon family's three test vectors (zeros, 0..11, p - 1 everywhere) -- 36 words from
+    memory -- against the big-integer definition and the checker's C restatement over the generated default table"""
+    import numpy as np
+    from oracle import chacha8_table as CT
+    from oracle import naive as NV
+    from oracle import oracle as O
+    rc, mds = [int(v) for v in PC.default_round_constants()], [int(v) for v in PC.default_mds()]
+    states = {"zero": [0] * 12, "counting": list(range(12)), "minus_one": [PC.GL_P - 1] * 12}
+    for name, st in states.items():
+        assert NV.poseidon_perm(st, rc, mds) == CT.ANCHOR_FULL[name], name
+        got = O.poseidon_perm(np.array([st], dtype=np.uint64), np.array(rc, dtype=np.uint64), np.array(mds, dtype=np.uint64))[0]
+        assert [int(v) for v in got] == CT.ANCHOR_FULL[name], name
