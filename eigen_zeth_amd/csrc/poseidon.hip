@@ -1,8 +1,10 @@
 // Poseidon-12 over Goldilocks, linear-hash leaves and binary Merkle trees.
 //
 // No reference counterpart in /root/reference (hashing happens inside the external prover service
-// that src/prover/provider.rs:358-377 calls).  Textbook schedule ARK -> S-box(x^7) -> MDS, 4 full +
-// 22 partial + 4 full rounds, tables injected through zp_set_constants.
+// that src/prover/provider.rs:358-377 calls).  Schedule ARK -> S-box(x^7) -> MDS, 4 full + 22 partial + 4 full
+// rounds, tables injected through zp_set_constants.  The field values are the textbook's; on the default matrix the
+// throughput kernels walk the partial rounds three at a time (partial3_default: three S-boxes + ONE matrix product,
+// round 6) and compute only the digest rows of the last product where only a digest is read.
 //
 // Mapping: one lane = one permutation, the 12-element state lives in 24 VGPRs; round constants and
 // the MDS matrix are wave-uniform and are fetched with scalar loads.  The leaf kernel walks the

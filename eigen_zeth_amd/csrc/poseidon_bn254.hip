@@ -3,7 +3,9 @@
 // packed three to a field element.  The request this serves is GenFinalProof (proto/prover/v1/prover.proto:130-148,
 // src/prover/provider.rs:472-503); the reference holds none of it.
 // Anchor: with the Grain-LFSR tables of eigen_zeth_amd/poseidon_constants.py the t = 3 instance reproduces the published
-// value poseidon([1, 2]) = 0x115cc0f5...189a (tests/test_poseidon_constants.py, tests/test_gpu_bn254_hash.py).
+// value poseidon([1, 2]) = 0x115cc0f5...189a, and the t = 17 instance -- the width used here -- the published 16-input value
+// poseidon([1 .. 16]) = 9989051620...9211877 (tests/test_poseidon_constants.py, tests/test_gpu_bn254_hash.py).
+// Lane-per-permutation kernel (commitments of the final STARK): partial rounds in blocks of four (bulk_partial_block, round 6).
 //
 // Mapping: T lanes per permutation (lane e owns state element e in nine 29-bit Montgomery limbs), floor(64/T)
 // permutations per 64-lane workgroup; a full round is  ARK -> S-box (lane-local) -> state to LDS -> each lane one row of the
