@@ -147,13 +147,13 @@ def cpu_baseline(logn, budget_cols):
 
 def integer_roofline(prover, pass_rows, alg_bytes, elems_per_launch, launches_per_step=None, ms_per_step=None):
     """the integer-VALU roofline next to the HBM one.  VALU instruction counts per element come from the committed PMC
-    file (profiles/r6_integer_roofline.json -- r5's when absent --, made by tools/integer_roofline.py from a rocprofv3 --pmc SQ_INSTS_VALU run: labelled
+    file (profiles/r6c_integer_roofline.json -- the newest of r6c / r6 / r5 --, made by tools/integer_roofline.py from a rocprofv3 --pmc SQ_INSTS_VALU run: labelled
     as such, not re-measured here; the counts equal the static ISA counts of profiles/r4_ntt_isa_breakdown.txt); the issue ceiling is
     1024 SIMDs x 64 lanes x clock / 4 cycles per instruction (every instruction of these kernels is of the 4-cycle class:
     tools/ubench_isa.hip, profiles/r2_ubench_isa.txt).  frac_int = the time the pure instruction issue of a launch needs / the
     measured launch time: a number in (0, 1] -- anything above 1 is a unit error in the table (round 4's file divided the count of a
     16-column launch by 8 columns), and the bench refuses to print it.  `plan` = the same over all launches of one step."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r6_integer_roofline.json", "r5_integer_roofline.json")) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r6c_integer_roofline.json", "r6_integer_roofline.json", "r5_integer_roofline.json")) if os.path.exists(q)), None)
     try:
         if path is None:
             raise FileNotFoundError("profiles/r6_integer_roofline.json")
@@ -445,7 +445,7 @@ def main():
                               "frac": (alg_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if a_ms else None})
         slowest = max((r for r in pass_rows if r["avg_launch_ms"]), key=lambda r: r["avg_launch_ms"], default=None)
         traffic, traffic_src = None, None
-        for tp in ("r6_ntt_traffic.json", "r5_ntt_traffic.json", "r4_ntt_traffic.json"):
+        for tp in ("r6c_ntt_traffic.json", "r6_ntt_traffic.json", "r5_ntt_traffic.json", "r4_ntt_traffic.json"):
             tp = os.path.join(ROOT, "profiles", tp)
             if os.path.exists(tp):
                 try:
