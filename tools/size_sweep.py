@@ -13,7 +13,7 @@ rows = []
 # applied per pass of whatever plan a size gets: an APPROXIMATION outside 2^22 .. 2^26), 17.5 k per Poseidon permutation (profiles/r5_pmc_sq_merkle*.json)
 info = p.device_info()
 CEIL = info["cus"] * 4 * 64 * info["clock_khz"] * 1e3 / 4.0
-VALU_PER_ELEM_PASS, VALU_PER_PERM = 318.7 / 3, 17.5e3
+VALU_PER_ELEM_PASS, VALU_PER_PERM = 318.7 / 3, 13.5e3      # (round 6, second half: 13.5 k per permutation with the blocked partial rounds, profiles/r6c_integer_roofline.json; 17.5 k before)
 for logn in [int(a) for a in sys.argv[1:]] or [20, 21, 22, 23, 24, 25, 26]:
     N, M = 1 << logn, 2 << logn
     x = np.random.default_rng(logn).integers(0, 2**62, size=(W, N), dtype=np.uint64)
